@@ -1,0 +1,194 @@
+// Shared device/host helpers for the gfx950 kernels.  All per-element arithmetic is fp32
+// with contraction OFF (the library is built with -ffp-contract=off) so that every
+// multiply/add rounds exactly once, in the order written here; fmaf() is used only where
+// named.  Division and sqrt are IEEE-correct (hipcc default).  That makes the per-pixel
+// and per-surfel results a pure function of the inputs, which is what lets the parity
+// tests demand integer-exact association.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/dmslam.h"
+
+namespace dms {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves: one per SIMD of a CU
+constexpr int kMaxPartialBlocks = DMS_MAX_PARTIAL_BLOCKS;
+constexpr int kSE3 = 29;                 // 27 products + residual + inliers (types.cuh:123-171)
+constexpr int kSO3 = 11;                 // 9 products + residual + inliers (types.cuh:173-197)
+
+// ---- error plumbing --------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define DMS_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) return ::dms::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define DMS_CHECK_LAUNCH() DMS_HIP(hipGetLastError())
+
+#define DMS_REQUIRE(cond, msg)                    \
+  do {                                            \
+    if (!(cond)) {                                \
+      ::dms::set_error("%s: %s", __func__, msg);  \
+      return DMS_ERR_INVALID_ARG;                 \
+    }                                             \
+  } while (0)
+
+// ---- pitched views ---------------------------------------------------------------------
+template <typename T>
+struct View {
+  T* data;
+  size_t pitch;  // bytes
+  int rows, cols;
+  __host__ __device__ __forceinline__ T* row(int y) const {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(data)) + (size_t)y * pitch);
+  }
+  __host__ __device__ __forceinline__ T& at(int y, int x) const { return row(y)[x]; }
+};
+
+template <typename T>
+inline View<T> view(const dms_image2d* im) {
+  View<T> v;
+  v.data = reinterpret_cast<T*>(im->data);
+  v.pitch = im->pitch;
+  v.rows = im->rows;
+  v.cols = im->cols;
+  return v;
+}
+
+// ---- tiny vector math (evaluation order is part of the contract) ------------------------
+struct f3 {
+  float x, y, z;
+};
+struct M33 {
+  f3 r0, r1, r2;
+};
+
+__host__ __device__ __forceinline__ f3 mk3(float x, float y, float z) {
+  f3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+__host__ __device__ __forceinline__ f3 operator-(const f3& a, const f3& b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ __forceinline__ f3 operator+(const f3& a, const f3& b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ __forceinline__ float dot3(const f3& a, const f3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ __forceinline__ f3 cross3(const f3& a, const f3& b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__host__ __device__ __forceinline__ float norm3(const f3& a) { return sqrtf(dot3(a, a)); }
+// normalise = v * (1 / sqrt(v.v)) — the reciprocal-square-root form of the reference
+// (operators.cuh:79-83) with an exactly rounded reciprocal and square root.
+__host__ __device__ __forceinline__ f3 normalized3(const f3& a) {
+  const float rn = 1.0f / sqrtf(dot3(a, a));
+  return mk3(a.x * rn, a.y * rn, a.z * rn);
+}
+__host__ __device__ __forceinline__ f3 mul(const M33& m, const f3& a) { return mk3(dot3(m.r0, a), dot3(m.r1, a), dot3(m.r2, a)); }
+
+inline M33 to_m33(const dms_mat33* m) {
+  M33 r;
+  r.r0 = mk3(m->m[0], m->m[1], m->m[2]);
+  r.r1 = mk3(m->m[3], m->m[4], m->m[5]);
+  r.r2 = mk3(m->m[6], m->m[7], m->m[8]);
+  return r;
+}
+inline f3 to_f3(const dms_float3* v) { return mk3(v->x, v->y, v->z); }
+
+__host__ __device__ __forceinline__ float qnan() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __int_as_float(0x7fffffff);
+#else
+  uint32_t u = 0x7fffffffu;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#endif
+}
+
+// round-to-nearest-even float -> int; NaN -> 0, saturating (CUDA __float2int_rn semantics,
+// which the reference relies on for NaN vertices).
+__device__ __forceinline__ int f2i_rn(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)rintf(v);
+}
+// float -> int truncation with the same NaN / saturation rule
+__device__ __forceinline__ int f2i_rz(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)v;
+}
+
+// ---- wave64 reductions -----------------------------------------------------------------
+// Butterfly inside each row of 16 lanes with DPP (no LDS traffic), then the two cross-row
+// steps with row broadcasts.  After the call lane 63 holds the sum of all 64 lanes.
+// The order is fixed, so results are run-to-run deterministic.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror     -> every lane holds its row's sum
+  v += dpp_mov<0x142, 0xa>(v);  // row_bcast15: rows 1,3 += lane 15 of rows 0,2
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast31: rows 2,3 += lane 31
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum_to_lane63_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+  return v;
+}
+
+// Block reduction of NV running sums held per thread.  256-thread blocks = 4 waves.
+// Writes the block's NV totals to out[k * out_stride + out_col] (SoA partial layout:
+// one row per quantity, one column per block, so the final pass reads coalesced).
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __restrict__ out,
+                                                   int out_stride, int out_col) {
+  __shared__ float lds[kBlock / kWave][NV];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float s = wave_sum_to_lane63(v[k]);
+    if (lane == kWave - 1) lds[wid][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    const int nw = blockDim.x >> 6;
+    float s = lds[0][k];
+    for (int w = 1; w < nw; ++w) s += lds[w][k];
+    out[(size_t)k * out_stride + out_col] = s;
+  }
+}
+
+// launch-shape helper: blocks of 256 threads, one pixel per thread up to the partial cap,
+// grid-stride beyond.  ≥ 2 blocks per CU at 640×480 so every XCD's L2 sees its share.
+inline int reduce_blocks_for(int n) {
+  int b = (n + kBlock - 1) / kBlock;
+  if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
+  if (b < 1) b = 1;
+  return b;
+}
+
+inline dim3 grid2d(int cols, int rows, dim3 block) { return dim3((cols + block.x - 1) / block.x, (rows + block.y - 1) / block.y); }
+
+}  // namespace dms

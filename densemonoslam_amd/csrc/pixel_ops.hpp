@@ -1,0 +1,253 @@
+// Per-pixel residual / Jacobian-row functions of the tracker.  Shared by the operator-layer
+// kernels (reduce.hip) and the fused device-resident Gauss-Newton loop (track.hip).
+#pragma once
+#include "common.hpp"
+
+namespace dms {
+
+// ---- ICP: projective association + point-to-plane row ---------------------------------
+// reference ICPReduction::search / getProducts (reduce.cu:259-344)
+struct IcpParams {
+  M33 Rcurr;
+  f3 tcurr;
+  M33 Rprev_inv;
+  f3 tprev;
+  float fx, fy, cx, cy;
+  float distThres, angleThres;
+  int cols, rows;
+};
+
+struct MapPtrs {  // stacked-plane maps: plane stride = rows * pitch
+  const float* vcurr;
+  size_t vcurr_pitch;
+  const float* ncurr;
+  size_t ncurr_pitch;
+  const float* vprev;
+  size_t vprev_pitch;
+  const float* nprev;
+  size_t nprev_pitch;
+};
+
+__device__ __forceinline__ const float* prow(const float* base, size_t pitch, int y) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch);
+}
+
+// row[0..5] = Jacobian, row[6] = residual.  Returns found flag; row is zero when not found.
+__device__ __forceinline__ bool icp_row(const IcpParams& p, const MapPtrs& m, int x, int y, float (&row)[7]) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) row[i] = 0.f;
+  const int rows = p.rows;
+  f3 vcurr;
+  vcurr.x = prow(m.vcurr, m.vcurr_pitch, y)[x];
+  vcurr.y = prow(m.vcurr, m.vcurr_pitch, y + rows)[x];
+  vcurr.z = prow(m.vcurr, m.vcurr_pitch, y + 2 * rows)[x];
+
+  const f3 vcurr_g = mul(p.Rcurr, vcurr) + p.tcurr;
+  const f3 vcurr_cp = mul(p.Rprev_inv, vcurr_g - p.tprev);
+
+  const int ux = f2i_rn((vcurr_cp.x * p.fx) / vcurr_cp.z + p.cx);
+  const int uy = f2i_rn((vcurr_cp.y * p.fy) / vcurr_cp.z + p.cy);
+  if (ux < 0 || uy < 0 || ux >= p.cols || uy >= rows || vcurr_cp.z < 0.f) return false;
+
+  f3 vprev_g;
+  vprev_g.x = prow(m.vprev, m.vprev_pitch, uy)[ux];
+  vprev_g.y = prow(m.vprev, m.vprev_pitch, uy + rows)[ux];
+  vprev_g.z = prow(m.vprev, m.vprev_pitch, uy + 2 * rows)[ux];
+
+  f3 ncurr;
+  ncurr.x = prow(m.ncurr, m.ncurr_pitch, y)[x];
+  ncurr.y = prow(m.ncurr, m.ncurr_pitch, y + rows)[x];
+  ncurr.z = prow(m.ncurr, m.ncurr_pitch, y + 2 * rows)[x];
+  const f3 ncurr_g = mul(p.Rcurr, ncurr);
+
+  f3 nprev_g;
+  nprev_g.x = prow(m.nprev, m.nprev_pitch, uy)[ux];
+  nprev_g.y = prow(m.nprev, m.nprev_pitch, uy + rows)[ux];
+  nprev_g.z = prow(m.nprev, m.nprev_pitch, uy + 2 * rows)[ux];
+
+  const float dist = norm3(vprev_g - vcurr_g);
+  const float sine = norm3(cross3(ncurr_g, nprev_g));
+  const bool found = (sine < p.angleThres && dist <= p.distThres && !isnan(ncurr.x) && !isnan(nprev_g.x));
+  if (!found) return false;
+
+  const f3 s_cp = mul(p.Rprev_inv, vcurr_g - p.tprev);
+  const f3 d_cp = mul(p.Rprev_inv, vprev_g - p.tprev);
+  const f3 n_cp = mul(p.Rprev_inv, nprev_g);
+  const f3 c = cross3(s_cp, n_cp);
+  row[0] = n_cp.x;
+  row[1] = n_cp.y;
+  row[2] = n_cp.z;
+  row[3] = c.x;
+  row[4] = c.y;
+  row[5] = c.z;
+  row[6] = dot3(n_cp, s_cp - d_cp);
+  return true;
+}
+
+// accumulate the 27 upper-triangle products + residual^2 + inlier into acc[29]
+// (field order of JtJJtrSE3, types.cuh:123-136)
+__device__ __forceinline__ void accumulate_se3(float (&acc)[kSE3], const float (&row)[7], bool found) {
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 7; ++j) acc[k++] += row[i] * row[j];
+  acc[27] += row[6] * row[6];
+  acc[28] += found ? 1.f : 0.f;
+}
+
+// ---- RGB correspondences (reference RGBResidual::getProducts, reduce.cu:767-843) -------
+struct RgbResParams {
+  float minScale;
+  float maxDepthDelta;
+  f3 kt;
+  M33 krkinv;
+  int cols, rows;
+};
+struct RgbResPtrs {
+  const short* dIdx;
+  size_t dI_pitch;
+  const short* dIdy;
+  const float* lastDepth;
+  size_t lastDepth_pitch;
+  const float* nextDepth;
+  size_t nextDepth_pitch;
+  const unsigned char* lastImage;
+  size_t lastImage_pitch;
+  const unsigned char* nextImage;
+  size_t nextImage_pitch;
+};
+
+template <typename T>
+__device__ __forceinline__ const T* trow(const T* base, size_t pitch, int y) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch);
+}
+
+// Returns validity; fills the DataTerm fields.  diff2_int is int(diff*diff) (reference
+// stores corres.diff * corres.diff into an int, reduce.cu:831).
+__device__ __forceinline__ bool rgb_residual(const RgbResParams& p, const RgbResPtrs& q, int j0, int i, dms_dataterm& out,
+                                             int& diff2_int) {
+  out.zero_x = out.zero_y = out.one_x = out.one_y = 0;
+  out.diff = 0.f;
+  out.valid = 0;
+  diff2_int = 0;
+  const int cols = p.cols, rows = p.rows;
+  if (!(j0 < cols - 5 && i < rows - 1)) return false;
+  bool valid = true;
+  for (int u = max(i - 2, 0); u < min(i + 2, rows); u++) {
+    const unsigned char* r = trow(q.nextImage, q.nextImage_pitch, u);
+    for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++) valid = valid && (r[v] > 0);
+  }
+  if (!valid) return false;
+  const short valx = trow(q.dIdx, q.dI_pitch, i)[j0];
+  const short valy = trow(q.dIdy, q.dI_pitch, i)[j0];
+  const float mTwo = (float)((int)valx * (int)valx + (int)valy * (int)valy);
+  if (!(mTwo >= p.minScale)) return false;
+  const int y = i, x = j0;
+  const float d1 = trow(q.nextDepth, q.nextDepth_pitch, y)[x];
+  if (isnan(d1)) return false;
+  const float fx_ = (float)x, fy_ = (float)y;
+  const float transformed_d1 = d1 * ((p.krkinv.r2.x * fx_ + p.krkinv.r2.y * fy_) + p.krkinv.r2.z) + p.kt.z;
+  const int u0 = f2i_rn((d1 * ((p.krkinv.r0.x * fx_ + p.krkinv.r0.y * fy_) + p.krkinv.r0.z) + p.kt.x) / transformed_d1);
+  const int v0 = f2i_rn((d1 * ((p.krkinv.r1.x * fx_ + p.krkinv.r1.y * fy_) + p.krkinv.r1.z) + p.kt.y) / transformed_d1);
+  if (!(u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows)) return false;
+  const float d0 = trow(q.lastDepth, q.lastDepth_pitch, v0)[u0];
+  const unsigned char l0 = trow(q.lastImage, q.lastImage_pitch, v0)[u0];
+  if (!(d0 > 0.f && fabsf(transformed_d1 - d0) <= p.maxDepthDelta && l0 != 0)) return false;
+  out.zero_x = (short)u0;
+  out.zero_y = (short)v0;
+  out.one_x = (short)x;
+  out.one_y = (short)y;
+  out.diff = (float)trow(q.nextImage, q.nextImage_pitch, y)[x] - (float)l0;
+  out.valid = 1;
+  diff2_int = f2i_rz(out.diff * out.diff);
+  return true;
+}
+
+// ---- RGB Jacobian row (reference RGBReduction::getProducts, reduce.cu:561-620) ---------
+struct RgbStepParams {
+  float sigma, fx, fy, sobelScale;
+};
+
+__device__ __forceinline__ void rgb_row(const RgbStepParams& p, const dms_dataterm& c, const float* __restrict__ cloud,
+                                        size_t cloud_pitch, const short* __restrict__ dIdx, const short* __restrict__ dIdy,
+                                        size_t dI_pitch, float (&row)[7]) {
+  float w = p.sigma + fabsf(c.diff);
+  w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
+  if (p.sigma == -1.f) w = 1.f;
+  row[6] = -w * c.diff;
+  const float* cp = trow(cloud, cloud_pitch, c.zero_y) + 3 * c.zero_x;
+  const f3 pt = mk3(cp[0], cp[1], cp[2]);
+  // reference: float invz = 1.0 / cloudPoint.z  (double division rounded to float)
+  const float invz = (float)(1.0 / (double)pt.z);
+  const float dI_dx_val = (w * p.sobelScale) * (float)trow(dIdx, dI_pitch, c.one_y)[c.one_x];
+  const float dI_dy_val = (w * p.sobelScale) * (float)trow(dIdy, dI_pitch, c.one_y)[c.one_x];
+  const float v0 = (dI_dx_val * p.fx) * invz;
+  const float v1 = (dI_dy_val * p.fy) * invz;
+  const float v2 = -(v0 * pt.x + v1 * pt.y) * invz;
+  row[0] = v0;
+  row[1] = v1;
+  row[2] = v2;
+  row[3] = -pt.z * v1 + pt.y * v2;
+  row[4] = pt.z * v0 - pt.x * v2;
+  row[5] = -pt.y * v0 + pt.x * v1;
+}
+
+// ---- SO3 (reference SO3Reduction::getProducts, reduce.cu:942-1032) ----------------------
+struct So3Params {
+  M33 imageBasis, kinv, krlr;
+  int cols, rows;
+};
+
+__device__ __forceinline__ void so3_gradient(const unsigned char* img, size_t pitch, int x, int y, float& gx, float& gy) {
+  const float actu = (float)trow(img, pitch, y)[x];
+  float back = (float)trow(img, pitch, y)[x - 1];
+  float fore = (float)trow(img, pitch, y)[x + 1];
+  gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+  back = (float)trow(img, pitch, y - 1)[x];
+  fore = (float)trow(img, pitch, y + 1)[x];
+  gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+}
+
+__device__ __forceinline__ bool so3_row(const So3Params& p, const unsigned char* lastImage, size_t last_pitch,
+                                        const unsigned char* nextImage, size_t next_pitch, int x, int y, float (&row)[4]) {
+  row[0] = row[1] = row[2] = row[3] = 0.f;
+  const f3 unwarped = mk3((float)x, (float)y, 1.0f);
+  const f3 warped = mul(p.imageBasis, unwarped);
+  const int wx = f2i_rn(warped.x / warped.z);
+  const int wy = f2i_rn(warped.y / warped.z);
+  const int cols = p.cols, rows = p.rows;
+  if (!(wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1)) return false;
+  float gnx, gny, glx, gly;
+  so3_gradient(nextImage, next_pitch, wx, wy, gnx, gny);
+  so3_gradient(lastImage, last_pitch, x, y, glx, gly);
+  const float gx = (gnx + glx) / 2.0f;
+  const float gy = (gny + gly) / 2.0f;
+  const f3 point = mul(p.kinv, unwarped);
+  const float z2 = point.z * point.z;
+  const float a = p.krlr.r0.x, b = p.krlr.r0.y, c = p.krlr.r0.z;
+  const float d = p.krlr.r1.x, e = p.krlr.r1.y, f = p.krlr.r1.z;
+  const float g = p.krlr.r2.x, h = p.krlr.r2.y, i = p.krlr.r2.z;
+  const float fx = (float)x, fy = (float)y;
+  const f3 left = mk3((((point.z * (d * gy + a * gx)) - ((gy * g) * fy)) - ((gx * g) * fx)) / z2,
+                      (((point.z * (e * gy + b * gx)) - ((gy * h) * fy)) - ((gx * h) * fx)) / z2,
+                      (((point.z * (f * gy + c * gx)) - ((gy * i) * fy)) - ((gx * i) * fx)) / z2);
+  const f3 jac = cross3(left, point);
+  row[0] = jac.x;
+  row[1] = jac.y;
+  row[2] = jac.z;
+  row[3] = -((float)trow(nextImage, next_pitch, wy)[wx] - (float)trow(lastImage, last_pitch, y)[x]);
+  return true;
+}
+
+__device__ __forceinline__ void accumulate_so3(float (&acc)[kSO3], const float (&row)[4], bool found) {
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 4; ++j) acc[k++] += row[i] * row[j];
+  acc[9] += row[3] * row[3];
+  acc[10] += found ? 1.f : 0.f;
+}
+
+}  // namespace dms

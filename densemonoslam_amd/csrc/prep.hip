@@ -1,0 +1,417 @@
+// Pyramid / map preparation kernels for the tracker (operator layer (B)).
+// Each kernel states which reference function it replaces.  These are HBM-streaming
+// kernels: one 64-wide wave covers 64 consecutive pixels of a row (coalesced 4-byte or
+// 16-byte accesses per lane); blocks are 64×4 so a 256-thread block spans 4 rows.
+#include "common.hpp"
+
+namespace dms {
+
+static constexpr int BX = 64, BY = 4;
+static inline dim3 blk() { return dim3(BX, BY); }
+
+// ---------------------------------------------------------------------------------------
+// pyrDown: u16 depth 5×5 Gaussian with σ_colour = 30 mm edge stop
+// (reference pyrDownGaussKernel, cudafuncs.cu:57-91)
+// ---------------------------------------------------------------------------------------
+__global__ void k_pyrDownDepth(View<const unsigned short> src, View<unsigned short> dst, float sigma_color) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const int D = 5;
+  const int center = src.at(2 * y, 2 * x);
+  const int x_mi = max(0, 2 * x - D / 2) - 2 * x;
+  const int y_mi = max(0, 2 * y - D / 2) - 2 * y;
+  const int x_ma = min(src.cols, 2 * x - D / 2 + D) - 2 * x;
+  const int y_ma = min(src.rows, 2 * y - D / 2 + D) - 2 * y;
+  float sum = 0.f, wall = 0.f;
+  const float weights[3] = {0.375f, 0.25f, 0.0625f};
+  for (int yi = y_mi; yi < y_ma; ++yi)
+    for (int xi = x_mi; xi < x_ma; ++xi) {
+      const int val = src.at(2 * y + yi, 2 * x + xi);
+      if ((float)abs(val - center) < 3.f * sigma_color) {
+        const float w = weights[abs(xi)] * weights[abs(yi)];
+        sum += ((float)val * weights[abs(xi)]) * weights[abs(yi)];
+        wall += w;
+      }
+    }
+  dst.at(y, x) = (unsigned short)f2i_rz(sum / wall);
+}
+
+// ---------------------------------------------------------------------------------------
+// createVMap: mm -> m back-projection (reference computeVmapKernel, cudafuncs.cu:106-128)
+// ---------------------------------------------------------------------------------------
+__global__ void k_createVMap(View<const unsigned short> depth, View<float> vmap, float fx_inv, float fy_inv,
+                             float cx, float cy, float depthCutoff) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y * blockDim.y + threadIdx.y;
+  if (u >= depth.cols || v >= depth.rows) return;
+  const float z = (float)depth.at(v, u) / 1000.f;
+  if (z != 0.f && z < depthCutoff) {
+    const float vx = (z * ((float)u - cx)) * fx_inv;
+    const float vy = (z * ((float)v - cy)) * fy_inv;
+    vmap.at(v, u) = vx;
+    vmap.at(v + depth.rows, u) = vy;
+    vmap.at(v + 2 * depth.rows, u) = z;
+  } else {
+    vmap.at(v, u) = qnan();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// createNMap: forward-difference normals (reference computeNmapKernel, cudafuncs.cu:149-182)
+// ---------------------------------------------------------------------------------------
+__global__ void k_createNMap(int rows, int cols, View<const float> vmap, View<float> nmap) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y * blockDim.y + threadIdx.y;
+  if (u >= cols || v >= rows) return;
+  if (u == cols - 1 || v == rows - 1) {
+    nmap.at(v, u) = qnan();
+    return;
+  }
+  f3 v00, v01, v10;
+  v00.x = vmap.at(v, u);
+  v01.x = vmap.at(v, u + 1);
+  v10.x = vmap.at(v + 1, u);
+  if (!isnan(v00.x) && !isnan(v01.x) && !isnan(v10.x)) {
+    v00.y = vmap.at(v + rows, u);
+    v01.y = vmap.at(v + rows, u + 1);
+    v10.y = vmap.at(v + 1 + rows, u);
+    v00.z = vmap.at(v + 2 * rows, u);
+    v01.z = vmap.at(v + 2 * rows, u + 1);
+    v10.z = vmap.at(v + 1 + 2 * rows, u);
+    const f3 r = normalized3(cross3(v01 - v00, v10 - v00));
+    nmap.at(v, u) = r.x;
+    nmap.at(v + rows, u) = r.y;
+    nmap.at(v + 2 * rows, u) = r.z;
+  } else {
+    nmap.at(v, u) = qnan();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// tranformMaps (reference tranformMapsKernel ×2, cudafuncs.cu:200-274); in-place capable
+// ---------------------------------------------------------------------------------------
+template <bool WITH_N>
+__global__ void k_transformMaps(int rows, int cols, View<const float> vsrc, View<const float> nsrc, M33 R, f3 t,
+                                View<float> vdst, View<float> ndst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  {
+    f3 s;
+    float outx = qnan();
+    s.x = vsrc.at(y, x);
+    if (!isnan(s.x)) {
+      s.y = vsrc.at(y + rows, x);
+      s.z = vsrc.at(y + 2 * rows, x);
+      const f3 d = mul(R, s) + t;
+      vdst.at(y + rows, x) = d.y;
+      vdst.at(y + 2 * rows, x) = d.z;
+      outx = d.x;
+    }
+    vdst.at(y, x) = outx;
+  }
+  if (WITH_N) {
+    f3 s;
+    float outx = qnan();
+    s.x = nsrc.at(y, x);
+    if (!isnan(s.x)) {
+      s.y = nsrc.at(y + rows, x);
+      s.z = nsrc.at(y + 2 * rows, x);
+      const f3 d = mul(R, s);
+      ndst.at(y + rows, x) = d.y;
+      ndst.at(y + 2 * rows, x) = d.z;
+      outx = d.x;
+    }
+    ndst.at(y, x) = outx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// copyMaps: dense RGBA32F -> stacked planes, z == 0 => NaN in all three planes
+// (reference copyMapsKernel ×2, cudafuncs.cu:313-378).  One float4 load per lane.
+// ---------------------------------------------------------------------------------------
+template <bool WITH_N>
+__global__ void k_copyMaps(int rows, int cols, const float4* __restrict__ vsrc, const float4* __restrict__ nsrc,
+                           View<float> vdst, View<float> ndst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const float4 v = vsrc[(size_t)y * cols + x];
+  const bool ok = !(v.z == 0.f);
+  const float n = qnan();
+  vdst.at(y, x) = ok ? v.x : n;
+  vdst.at(y + rows, x) = ok ? v.y : n;
+  vdst.at(y + 2 * rows, x) = ok ? v.z : n;
+  if (WITH_N) {
+    const float4 q = nsrc[(size_t)y * cols + x];
+    ndst.at(y, x) = ok ? q.x : n;
+    ndst.at(y + rows, x) = ok ? q.y : n;
+    ndst.at(y + 2 * rows, x) = ok ? q.z : n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// resizeVMap / resizeNMap: 2×2 box, NaN-propagating on plane x (reference resizeMapKernel,
+// cudafuncs.cu:445-492)
+// ---------------------------------------------------------------------------------------
+template <bool NORMALIZE>
+__global__ void k_resizeMap(int drows, int dcols, int srows, View<const float> in, View<float> out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dcols || y >= drows) return;
+  const int xs = x * 2, ys = y * 2;
+  const float x00 = in.at(ys, xs), x01 = in.at(ys, xs + 1), x10 = in.at(ys + 1, xs), x11 = in.at(ys + 1, xs + 1);
+  if (isnan(x00) || isnan(x01) || isnan(x10) || isnan(x11)) {
+    out.at(y, x) = qnan();
+    return;
+  }
+  f3 n;
+  n.x = (x00 + x01 + x10 + x11) / 4;
+  const float y00 = in.at(ys + srows, xs), y01 = in.at(ys + srows, xs + 1), y10 = in.at(ys + srows + 1, xs),
+              y11 = in.at(ys + srows + 1, xs + 1);
+  n.y = (y00 + y01 + y10 + y11) / 4;
+  const float z00 = in.at(ys + 2 * srows, xs), z01 = in.at(ys + 2 * srows, xs + 1), z10 = in.at(ys + 2 * srows + 1, xs),
+              z11 = in.at(ys + 2 * srows + 1, xs + 1);
+  n.z = (z00 + z01 + z10 + z11) / 4;
+  if (NORMALIZE) n = normalized3(n);
+  out.at(y, x) = n.x;
+  out.at(y + drows, x) = n.y;
+  out.at(y + 2 * drows, x) = n.z;
+}
+
+// ---------------------------------------------------------------------------------------
+// pyrDownGaussF: float depth 5×5, NaN-skipping, integer weight count
+// (reference pyrDownKernelGaussF, cudafuncs.cu:416-443).  The 25 weights live in
+// registers / constant operands instead of a per-call cudaMalloc'd table (:532-541).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gauss25(int r, int c) {
+  const float w[5] = {1.f, 4.f, 6.f, 4.f, 1.f};
+  return w[r] * w[c];
+}
+
+__global__ void k_pyrDownGaussF(View<const float> src, View<float> dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const int D = 5;
+  const int tx = min(2 * x - D / 2 + D, src.cols - 1);
+  const int ty = min(2 * y - D / 2 + D, src.rows - 1);
+  float sum = 0.f;
+  int count = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+      const float s = src.at(cy, cx);
+      if (!isnan(s)) {
+        const float g = gauss25(ty - cy - 1, tx - cx - 1);
+        sum += s * g;
+        count += (int)g;
+      }
+    }
+  dst.at(y, x) = sum / (float)count;
+}
+
+// reference pyrDownKernelIntensityGauss (cudafuncs.cu:544-573): zero-skipping, result
+// truncated to u8; an empty window gives NaN -> 0.
+__global__ void k_pyrDownUchar(View<const unsigned char> src, View<unsigned char> dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const int D = 5;
+  const int tx = min(2 * x - D / 2 + D, src.cols - 1);
+  const int ty = min(2 * y - D / 2 + D, src.rows - 1);
+  float sum = 0.f;
+  int count = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+      const unsigned char s = src.at(cy, cx);
+      if (s > 0) {
+        const float g = gauss25(ty - cy - 1, tx - cx - 1);
+        sum += (float)s * g;
+        count += (int)g;
+      }
+    }
+  dst.at(y, x) = (unsigned char)f2i_rz(sum / (float)count);
+}
+
+// reference verticesToDepthKernel / verticesToDepth2DKernel (cudafuncs.cu:597-630)
+__global__ void k_verticesToDepth(const float4* __restrict__ vsrc, View<float> dst, float cutOff) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const float z = vsrc[(size_t)y * dst.cols + x].z;
+  dst.at(y, x) = (z > cutOff || z <= 0.f) ? qnan() : z;
+}
+__global__ void k_verticesToDepth2D(View<const float> vsrc, View<float> dst, float cutOff) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const float z = vsrc.at(y + dst.rows * 2, x);
+  dst.at(y, x) = (z > cutOff || z <= 0.f) ? qnan() : z;
+}
+
+// reference bgr2IntensityKernel (cudafuncs.cu:643-655): int(0.114 x + 0.299 y + 0.587 z)
+__global__ void k_rgbaToIntensity(View<const uchar4> src, View<unsigned char> dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dst.cols || y >= dst.rows) return;
+  const uchar4 s = src.at(y, x);
+  const float f = ((float)s.x * 0.114f + (float)s.y * 0.299f) + (float)s.z * 0.587f;
+  dst.at(y, x) = (unsigned char)f2i_rz(f);
+}
+
+// reference applyKernel (cudafuncs.cu:674-695): 3×3 Scharr-like masks indexed from 8
+// downward over the clamped window (border quirk kept), float -> short truncation.
+__global__ void k_derivatives(View<const unsigned char> src, View<short> dx, View<short> dy) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= src.cols || y >= src.rows) return;
+  const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+  const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+  float dxVal = 0.f, dyVal = 0.f;
+  int k = 8;
+  for (int j = max(y - 1, 0); j <= min(y + 1, src.rows - 1); j++)
+    for (int i = max(x - 1, 0); i <= min(x + 1, src.cols - 1); i++) {
+      const float p = (float)src.at(j, i);
+      dxVal += p * gx[k];
+      dyVal += p * gy[k];
+      --k;
+    }
+  dx.at(y, x) = (short)f2i_rz(dxVal);
+  dy.at(y, x) = (short)f2i_rz(dyVal);
+}
+
+// reference projectPointsKernel (cudafuncs.cu:727-741); cloud is packed float3
+__global__ void k_projectPoints(View<const float> depth, View<float> cloud3, float invFx, float invFy, float cx, float cy) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= depth.cols || y >= depth.rows) return;
+  const float z = depth.at(y, x);
+  float* c = cloud3.row(y) + 3 * x;
+  c[0] = (((float)x - cx) * z) * invFx;
+  c[1] = (((float)y - cy) * z) * invFy;
+  c[2] = z;
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers (internal C++ API; the C ABI wrappers live in capi.hip)
+// ---------------------------------------------------------------------------------------
+#define LAUNCH2D(kern, cols, rows, stream, ...)                                  \
+  do {                                                                           \
+    dim3 b = blk();                                                              \
+    dim3 g = grid2d((cols), (rows), b);                                          \
+    hipLaunchKernelGGL(kern, g, b, 0, (hipStream_t)(stream), __VA_ARGS__);       \
+    DMS_CHECK_LAUNCH();                                                          \
+  } while (0)
+
+int pyrDown(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
+  DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
+  DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
+  LAUNCH2D(k_pyrDownDepth, dst->cols, dst->rows, s, view<const unsigned short>(src), view<unsigned short>(dst), 30.f);
+  return DMS_OK;
+}
+
+int createVMap(const dms_camera* intr, const dms_image2d* depth, dms_image2d* vmap, float cutoff, hipStream_t s) {
+  DMS_REQUIRE(intr && depth && vmap && depth->data && vmap->data, "null argument");
+  DMS_REQUIRE(vmap->rows == depth->rows * 3 && vmap->cols == depth->cols, "vmap must be (3*rows) x cols");
+  LAUNCH2D(k_createVMap, depth->cols, depth->rows, s, view<const unsigned short>(depth), view<float>(vmap), 1.f / intr->fx,
+           1.f / intr->fy, intr->cx, intr->cy, cutoff);
+  return DMS_OK;
+}
+
+int createNMap(const dms_image2d* vmap, dms_image2d* nmap, hipStream_t s) {
+  DMS_REQUIRE(vmap && nmap && vmap->data && nmap->data, "null argument");
+  DMS_REQUIRE(vmap->rows == nmap->rows && vmap->cols == nmap->cols && vmap->rows % 3 == 0, "shape mismatch");
+  const int rows = vmap->rows / 3, cols = vmap->cols;
+  LAUNCH2D(k_createNMap, cols, rows, s, rows, cols, view<const float>(vmap), view<float>(nmap));
+  return DMS_OK;
+}
+
+int transformMaps(const dms_image2d* vs, const dms_image2d* ns, const dms_mat33* R, const dms_float3* t, dms_image2d* vd,
+                  dms_image2d* nd, hipStream_t s) {
+  DMS_REQUIRE(vs && R && t && vd && vs->data && vd->data, "null argument");
+  DMS_REQUIRE(vs->rows % 3 == 0 && vd->rows == vs->rows && vd->cols == vs->cols, "shape mismatch");
+  const int rows = vs->rows / 3, cols = vs->cols;
+  if (ns) {
+    DMS_REQUIRE(nd && ns->data && nd->data && ns->rows == vs->rows && nd->rows == vs->rows, "normal map shape mismatch");
+    LAUNCH2D(k_transformMaps<true>, cols, rows, s, rows, cols, view<const float>(vs), view<const float>(ns), to_m33(R), to_f3(t),
+             view<float>(vd), view<float>(nd));
+  } else {
+    LAUNCH2D(k_transformMaps<false>, cols, rows, s, rows, cols, view<const float>(vs), view<const float>(vs), to_m33(R), to_f3(t),
+             view<float>(vd), view<float>(vd));
+  }
+  return DMS_OK;
+}
+
+int copyMaps(const float* vsrc, const float* nsrc, dms_image2d* vd, dms_image2d* nd, hipStream_t s) {
+  DMS_REQUIRE(vsrc && vd && vd->data && vd->rows % 3 == 0, "null argument");
+  const int rows = vd->rows / 3, cols = vd->cols;
+  if (nsrc) {
+    DMS_REQUIRE(nd && nd->data && nd->rows == vd->rows && nd->cols == vd->cols, "normal map shape mismatch");
+    LAUNCH2D(k_copyMaps<true>, cols, rows, s, rows, cols, (const float4*)vsrc, (const float4*)nsrc, view<float>(vd), view<float>(nd));
+  } else {
+    LAUNCH2D(k_copyMaps<false>, cols, rows, s, rows, cols, (const float4*)vsrc, (const float4*)vsrc, view<float>(vd), view<float>(vd));
+  }
+  return DMS_OK;
+}
+
+int resizeMap(const dms_image2d* in, dms_image2d* out, bool normalize, hipStream_t s) {
+  DMS_REQUIRE(in && out && in->data && out->data && in->rows % 3 == 0, "null argument");
+  const int in_rows = in->rows / 3, out_rows = in_rows / 2, out_cols = in->cols / 2;
+  DMS_REQUIRE(out->rows == out_rows * 3 && out->cols == out_cols, "output must be input/2");
+  if (normalize)
+    LAUNCH2D(k_resizeMap<true>, out_cols, out_rows, s, out_rows, out_cols, in_rows, view<const float>(in), view<float>(out));
+  else
+    LAUNCH2D(k_resizeMap<false>, out_cols, out_rows, s, out_rows, out_cols, in_rows, view<const float>(in), view<float>(out));
+  return DMS_OK;
+}
+
+int pyrDownGaussF(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
+  DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
+  DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
+  LAUNCH2D(k_pyrDownGaussF, dst->cols, dst->rows, s, view<const float>(src), view<float>(dst));
+  return DMS_OK;
+}
+
+int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
+  DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
+  DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
+  LAUNCH2D(k_pyrDownUchar, dst->cols, dst->rows, s, view<const unsigned char>(src), view<unsigned char>(dst));
+  return DMS_OK;
+}
+
+int verticesToDepth(const float* vsrc, dms_image2d* dst, float cutOff, hipStream_t s) {
+  DMS_REQUIRE(vsrc && dst && dst->data, "null argument");
+  LAUNCH2D(k_verticesToDepth, dst->cols, dst->rows, s, (const float4*)vsrc, view<float>(dst), cutOff);
+  return DMS_OK;
+}
+
+int verticesToDepth2D(const dms_image2d* vsrc, dms_image2d* dst, float cutOff, hipStream_t s) {
+  DMS_REQUIRE(vsrc && dst && vsrc->data && dst->data && vsrc->rows == 3 * dst->rows, "shape mismatch");
+  LAUNCH2D(k_verticesToDepth2D, dst->cols, dst->rows, s, view<const float>(vsrc), view<float>(dst), cutOff);
+  return DMS_OK;
+}
+
+int imageToIntensity(const dms_image2d* rgba, dms_image2d* dst, hipStream_t s) {
+  DMS_REQUIRE(rgba && dst && rgba->data && dst->data && rgba->rows == dst->rows && rgba->cols == dst->cols, "shape mismatch");
+  LAUNCH2D(k_rgbaToIntensity, dst->cols, dst->rows, s, view<const uchar4>(rgba), view<unsigned char>(dst));
+  return DMS_OK;
+}
+
+int derivativeImages(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, hipStream_t s) {
+  DMS_REQUIRE(src && dx && dy && src->data && dx->data && dy->data, "null argument");
+  DMS_REQUIRE(dx->rows == src->rows && dx->cols == src->cols && dy->rows == src->rows && dy->cols == src->cols, "shape mismatch");
+  LAUNCH2D(k_derivatives, src->cols, src->rows, s, view<const unsigned char>(src), view<short>(dx), view<short>(dy));
+  return DMS_OK;
+}
+
+int projectToPointCloud(const dms_image2d* depth, dms_image2d* cloud, const dms_camera* intr, int level, hipStream_t s) {
+  DMS_REQUIRE(depth && cloud && intr && depth->data && cloud->data, "null argument");
+  DMS_REQUIRE(cloud->rows == depth->rows && cloud->cols == depth->cols, "shape mismatch");
+  const int div = 1 << level;
+  const float fx = intr->fx / div, fy = intr->fy / div, cx = intr->cx / div, cy = intr->cy / div;
+  LAUNCH2D(k_projectPoints, depth->cols, depth->rows, s, view<const float>(depth), view<float>(cloud), 1.0f / fx, 1.0f / fy, cx, cy);
+  return DMS_OK;
+}
+
+}  // namespace dms

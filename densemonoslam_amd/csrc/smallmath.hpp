@@ -1,0 +1,176 @@
+// Small dense linear algebra used by the on-device Gauss-Newton solve: the pieces the
+// reference does on the host with Eigen (RGBDOdometry.cpp:295-585, OdometryProvider.h:35-93),
+// restated for a single GPU lane in fp64 (fp32 where the reference uses float).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dms {
+namespace sm {
+
+// 3×3 inverse through cofactors and one reciprocal of the determinant (row-major).
+template <typename T>
+__host__ __device__ inline void inv3(const T* m, T* o) {
+  const T c00 = m[4] * m[8] - m[5] * m[7];
+  const T c01 = m[5] * m[6] - m[3] * m[8];
+  const T c02 = m[3] * m[7] - m[4] * m[6];
+  const T det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const T id = T(1) / det;
+  o[0] = c00 * id;
+  o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+  o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  o[3] = c01 * id;
+  o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+  o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  o[6] = c02 * id;
+  o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+template <typename T>
+__host__ __device__ inline void mul3(const T* a, const T* b, T* o) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+template <typename T>
+__host__ __device__ inline void mul3v(const T* a, const T* v, T* o) {
+  for (int i = 0; i < 3; ++i) o[i] = a[i * 3 + 0] * v[0] + a[i * 3 + 1] * v[1] + a[i * 3 + 2] * v[2];
+}
+
+__host__ __device__ inline void mul4(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = a[i * 4 + 0] * b[0 * 4 + j];
+      s += a[i * 4 + 1] * b[1 * 4 + j];
+      s += a[i * 4 + 2] * b[2 * 4 + j];
+      s += a[i * 4 + 3] * b[3 * 4 + j];
+      o[i * 4 + j] = s;
+    }
+}
+
+// general 4×4 inverse by cofactor expansion (row-major)
+__host__ __device__ inline void inv4(const double* m, double* o) {
+  double inv[16];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const double id = 1.0 / det;
+  for (int i = 0; i < 16; ++i) o[i] = inv[i] * id;
+}
+
+// Pivoted LDLT solve of a symmetric N×N system (diagonal pivoting on |A_kk|, zero pivots
+// solved as 0): the algorithm behind `A.ldlt().solve(b)` at RGBDOdometry.cpp:371,554.
+template <typename T, int N>
+__host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny) {
+  T A[N * N];
+  int perm[N];
+  for (int i = 0; i < N * N; ++i) A[i] = Ain[i];
+  bool all_zero = false;
+  for (int k = 0; k < N; ++k) {
+    int p = k;
+    T best = A[k * N + k] < T(0) ? -A[k * N + k] : A[k * N + k];
+    for (int i = k + 1; i < N; ++i) {
+      const T v = A[i * N + i] < T(0) ? -A[i * N + i] : A[i * N + i];
+      if (v > best) {
+        best = v;
+        p = i;
+      }
+    }
+    perm[k] = p;
+    if (p != k) {
+      for (int j = 0; j < N; ++j) {
+        const T t = A[k * N + j];
+        A[k * N + j] = A[p * N + j];
+        A[p * N + j] = t;
+      }
+      for (int i = 0; i < N; ++i) {
+        const T t = A[i * N + k];
+        A[i * N + k] = A[i * N + p];
+        A[i * N + p] = t;
+      }
+    }
+    // lower-triangular update: column k below the diagonal
+    T temp[N];
+    for (int j = 0; j < k; ++j) temp[j] = A[j * N + j] * A[k * N + j];
+    T akk = A[k * N + k];
+    for (int j = 0; j < k; ++j) akk -= A[k * N + j] * temp[j];
+    A[k * N + k] = akk;
+    for (int i = k + 1; i < N; ++i) {
+      T v = A[i * N + k];
+      for (int j = 0; j < k; ++j) v -= A[i * N + j] * temp[j];
+      A[i * N + k] = v;
+    }
+    const T aabs = akk < T(0) ? -akk : akk;
+    const bool valid = aabs > T(0);
+    if (k == 0 && !valid) {
+      for (int j = 0; j < N; ++j) perm[j] = j;
+      all_zero = true;
+      break;
+    }
+    if (valid)
+      for (int i = k + 1; i < N; ++i) A[i * N + k] /= akk;
+  }
+  T y[N];
+  for (int i = 0; i < N; ++i) y[i] = b[i];
+  if (all_zero) {
+    for (int i = 0; i < N; ++i) x[i] = T(0);
+    return;
+  }
+  for (int k = 0; k < N; ++k)
+    if (perm[k] != k) {
+      const T t = y[k];
+      y[k] = y[perm[k]];
+      y[perm[k]] = t;
+    }
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < i; ++j) y[i] -= A[i * N + j] * y[j];
+  for (int i = 0; i < N; ++i) {
+    const T d = A[i * N + i];
+    const T dabs = d < T(0) ? -d : d;
+    y[i] = dabs > tiny ? y[i] / d : T(0);
+  }
+  for (int i = N - 1; i >= 0; --i)
+    for (int j = i + 1; j < N; ++j) y[i] -= A[j * N + i] * y[j];
+  for (int k = N - 1; k >= 0; --k)
+    if (perm[k] != k) {
+      const T t = y[k];
+      y[k] = y[perm[k]];
+      y[perm[k]] = t;
+    }
+  for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+// reference OdometryProvider::rodrigues (OdometryProvider.h:35-71), row-major 3×3
+__host__ __device__ inline void rodrigues(const double* src, double* R) {
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int k = 0; k < 9; ++k) R[k] = I[k];
+  double rx = src[0], ry = src[1], rz = src[2];
+  const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+  if (theta >= 2.2204460492503131e-16) {
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c;
+    const double itheta = theta ? 1. / theta : 0.;
+    rx *= itheta;
+    ry *= itheta;
+    rz *= itheta;
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double rx_[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * rx_[k];
+  }
+}
+
+}  // namespace sm
+}  // namespace dms

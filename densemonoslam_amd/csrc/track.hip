@@ -1,0 +1,1116 @@
+// Object layer: the tracker (reference RGBDOdometry, Utils/RGBDOdometry.{h,cpp}).
+//
+// MI355X design.  The reference runs ≈67 blocking device→host round trips per call (three
+// kernel pairs + a 116-byte copy + a host Eigen solve per Gauss-Newton iteration,
+// RGBDOdometry.cpp:425-586).  Here the whole coarse-to-fine loop is enqueued on one HIP
+// stream with no host involvement:
+//
+//   k_track_init     1 lane   prior pose -> state, first-iteration projection parameters
+//   k_so3_pass       grid     per-pixel SO3 rows -> partials[11][blocks]
+//   k_so3_solve      1 block  fold, converge/diverge tests, fp32 LDLT, exp map, next homography
+//   k_gn_pass1<I,R>  grid     RGB correspondence (DataTerm + count/Σdiff²) and ICP rows -> partials
+//   k_gn_pass2       grid     σ from the folded count, photometric rows -> partials
+//   k_gn_solve       1 block  fold both partial sets, fp64 6×6 LDLT, SE3 update, next KRK⁻¹ / Kt
+//   k_track_finalize 1 lane   0.3 m jump gate, result block
+//
+// The pose, the 4×4 accumulated transform (fp64) and the early-exit flags (SO3
+// converged/diverged, rgbOnly break) live in a device state block; kernels past an exit
+// return at once, which reproduces the host `break`s.  One D2H copy of the result block
+// (pinned) ends the call.
+#include <math.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "pixel_ops.hpp"
+#include "smallmath.hpp"
+
+namespace dms {
+
+struct TrackState {
+  // prior / current pose (float, as the reference's Eigen float types)
+  float Rprev[9], tprev[3], Rprev_inv[9];
+  float Rcurr[9], tcurr[3];
+  // accumulated incremental transform (RGBDOdometry.cpp:395) and SO3 rotation (:295,301,314)
+  double resultRt[16];
+  double resultR[9], lastResultR[9];
+  float R_lr[9];
+  float so3_lastError, so3_lastCount;
+  int so3_done, so3_iters;
+  // per-iteration projection parameters
+  float imageBasis[9], kinv[9], krlr[9];  // SO3 (:321-332)
+  float krkinv[9], kt[3];                 // GN  (:427-437)
+  int level_done[DMS_NUM_PYRS];
+  int iters_run[DMS_NUM_PYRS];
+  // side outputs
+  float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+  double lastA[36], lastb[6];
+  int rejected_jump;
+  float out_trans[3], out_rot[9];
+};
+
+struct Buf {
+  void* p = nullptr;
+  size_t pitch = 0;
+  int rows = 0, cols = 0;
+  dms_image2d img() const {
+    dms_image2d i;
+    i.data = p;
+    i.pitch = pitch;
+    i.rows = rows;
+    i.cols = cols;
+    return i;
+  }
+};
+
+struct KernelTime {
+  double ms = 0;
+  int launches = 0;
+};
+
+}  // namespace dms
+
+using namespace dms;
+
+struct dms_odometry {
+  int width, height;
+  float cx, cy, fx, fy, distThres, angleThres;
+  float sobelScale, maxDepthDeltaRGB, maxDepthRGB;
+  float minGrad[DMS_NUM_PYRS];
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  Buf depth_tmp[3], vmaps_g_prev[3], nmaps_g_prev[3], vmaps_curr[3], nmaps_curr[3];
+  Buf lastDepth[3], nextDepth[3], lastImage[3], nextImage[3], lastNextImage[3];
+  Buf nextdIdx[3], nextdIdy[3], pointClouds[3], corresImg[3];
+  float* vmaps_tmp = nullptr;
+  float* nmaps_tmp = nullptr;
+  float* part_icp = nullptr;   // [29][1024]
+  float* part_rgb = nullptr;   // [29][1024]
+  float* part_so3 = nullptr;   // [11][1024]
+  int* part_cnt = nullptr;     // [2][1024]
+  TrackState* state = nullptr;
+  TrackState* host_state = nullptr;  // pinned
+  bool profiling = false;
+  std::map<std::string, KernelTime> times;
+  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace dms {
+
+// ---------------------------------------------------------------------------------------
+// device-side scalar sections
+// ---------------------------------------------------------------------------------------
+__device__ inline void level_K(float fx, float fy, float cx, float cy, int level, double* K) {
+  // CameraModel::operator()(level) divides in float (types.cuh:115-119), then K is double
+  const int div = 1 << level;
+  for (int i = 0; i < 9; ++i) K[i] = 0.0;
+  K[0] = (double)(fx / (float)div);
+  K[4] = (double)(fy / (float)div);
+  K[2] = (double)(cx / (float)div);
+  K[5] = (double)(cy / (float)div);
+  K[8] = 1.0;
+}
+
+// RGBDOdometry.cpp:321-332
+__device__ inline void so3_params(TrackState* st, const double* K) {
+  double Kinv[9], t[9], H[9];
+  sm::inv3<double>(K, Kinv);
+  sm::mul3<double>(K, st->resultR, t);
+  sm::mul3<double>(t, Kinv, H);
+  for (int i = 0; i < 9; ++i) {
+    st->imageBasis[i] = (float)H[i];
+    st->kinv[i] = (float)Kinv[i];
+    st->krlr[i] = (float)t[i];
+  }
+}
+
+// RGBDOdometry.cpp:427-437
+__device__ inline void gn_params(TrackState* st, const double* K) {
+  double Rt[16], R[9], Kinv[9], t[9], H[9];
+  sm::inv4(st->resultRt, Rt);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rt[i * 4 + j];
+  sm::inv3<double>(K, Kinv);
+  sm::mul3<double>(K, R, t);
+  sm::mul3<double>(t, Kinv, H);
+  for (int i = 0; i < 9; ++i) st->krkinv[i] = (float)H[i];
+  const double tv[3] = {Rt[3], Rt[7], Rt[11]};
+  double kt[3];
+  sm::mul3v<double>(K, tv, kt);
+  st->kt[0] = (float)kt[0];
+  st->kt[1] = (float)kt[1];
+  st->kt[2] = (float)kt[2];
+}
+
+struct Prior {
+  float v[12];  // trans[3], rot[9] — passed by value so no staging copy can race a later call
+};
+
+__global__ void k_track_init(TrackState* st, Prior prior, float fx, float fy, float cx, float cy, int so3, int first_level) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 3; ++i) st->tprev[i] = st->tcurr[i] = prior.v[i];
+  for (int i = 0; i < 9; ++i) st->Rprev[i] = st->Rcurr[i] = prior.v[3 + i];
+  sm::inv3<float>(st->Rprev, st->Rprev_inv);
+  for (int i = 0; i < 16; ++i) st->resultRt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 9; ++i) {
+    st->resultR[i] = st->lastResultR[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    st->R_lr[i] = (i % 4 == 0) ? 1.f : 0.f;
+  }
+  st->so3_lastError = 3.402823466e+38F / 2;
+  st->so3_lastCount = 3.402823466e+38F / 2;
+  st->so3_done = 0;
+  st->so3_iters = 0;
+  for (int l = 0; l < DMS_NUM_PYRS; ++l) {
+    st->level_done[l] = 0;
+    st->iters_run[l] = 0;
+  }
+  st->rejected_jump = 0;
+  for (int i = 0; i < 36; ++i) st->lastA[i] = 0.0;
+  for (int i = 0; i < 6; ++i) st->lastb[i] = 0.0;
+  double K[9];
+  if (so3) {
+    level_K(fx, fy, cx, cy, 2, K);
+    so3_params(st, K);
+  } else {
+    level_K(fx, fy, cx, cy, first_level, K);
+    gn_params(st, K);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// SO3 pre-alignment (RGBDOdometry.cpp:297-385)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_so3_pass(const TrackState* __restrict__ st, const unsigned char* lastImage,
+                                                     size_t last_pitch, const unsigned char* nextImage, size_t next_pitch, int cols,
+                                                     int rows, float* __restrict__ partials, int stride) {
+  if (st->so3_done) return;
+  So3Params p;
+  const float* ib = st->imageBasis;
+  const float* ki = st->kinv;
+  const float* kr = st->krlr;
+  p.imageBasis.r0 = mk3(ib[0], ib[1], ib[2]);
+  p.imageBasis.r1 = mk3(ib[3], ib[4], ib[5]);
+  p.imageBasis.r2 = mk3(ib[6], ib[7], ib[8]);
+  p.kinv.r0 = mk3(ki[0], ki[1], ki[2]);
+  p.kinv.r1 = mk3(ki[3], ki[4], ki[5]);
+  p.kinv.r2 = mk3(ki[6], ki[7], ki[8]);
+  p.krlr.r0 = mk3(kr[0], kr[1], kr[2]);
+  p.krlr.r1 = mk3(kr[3], kr[4], kr[5]);
+  p.krlr.r2 = mk3(kr[6], kr[7], kr[8]);
+  p.cols = cols;
+  p.rows = rows;
+  const int N = cols * rows;
+  float acc[kSO3];
+#pragma unroll
+  for (int k = 0; k < kSO3; ++k) acc[k] = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
+    const int y = i / cols;
+    const int x = i - y * cols;
+    float row[4];
+    const bool found = so3_row(p, lastImage, last_pitch, nextImage, next_pitch, x, y, row);
+    accumulate_so3(acc, row, found);
+  }
+  block_reduce_store<kSO3>(acc, partials, stride, blockIdx.x);
+}
+
+// fold NV rows of partials into sums[] with one wave per row (block of 1024 = 16 waves)
+template <int NV>
+__device__ __forceinline__ void fold_rows(const float* __restrict__ partials, int stride, int nblocks, float* sums) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int k = wid; k < NV; k += nw) {
+    float s = 0.f;
+    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)k * stride + b];
+    s = wave_sum_to_lane63(s);
+    if (lane == 63) sums[k] = s;
+  }
+}
+__device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, int stride, int nblocks, int* sums) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (wid < 2) {
+    int s = 0;
+    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)wid * stride + b];
+    s = wave_sum_to_lane63_i(s);
+    if (lane == 63) sums[wid] = s;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_so3_solve(TrackState* st, const float* __restrict__ partials, int stride, int nblocks,
+                                                    float fx, float fy, float cx, float cy, int is_last, int first_gn_level) {
+  if (st->so3_done) return;
+  __shared__ float sums[kSO3];
+  fold_rows<kSO3>(partials, stride, nblocks, sums);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float jtj[9], jtr[3];
+  int shift = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 4; ++j) {
+      const float v = sums[shift++];
+      if (j == 3)
+        jtr[i] = v;
+      else
+        jtj[j * 3 + i] = jtj[i * 3 + j] = v;
+    }
+  const float res0 = sums[9], res1 = sums[10];
+  st->so3_iters += 1;
+  float err = sqrtf(res0) / res1;
+  float cnt = res1;
+  bool stop = false;
+  if (err < st->so3_lastError && st->so3_lastCount == cnt) {
+    stop = true;  // converged
+  } else if ((double)err > (double)st->so3_lastError + 0.001) {
+    err = st->so3_lastError;  // diverging: roll back
+    cnt = st->so3_lastCount;
+    for (int i = 0; i < 9; ++i) st->resultR[i] = st->lastResultR[i];
+    stop = true;
+  }
+  st->lastSO3Error = err;
+  st->lastSO3Count = cnt;
+  if (!stop) {
+    st->so3_lastError = err;
+    st->so3_lastCount = cnt;
+    for (int i = 0; i < 9; ++i) st->lastResultR[i] = st->resultR[i];
+    float delta[3];
+    sm::ldlt_solve<float, 3>(jtj, jtr, delta, 1.0f / 3.402823466e+38F);
+    const double dd[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
+    double rotUpdate[9];
+    sm::rodrigues(dd, rotUpdate);
+    float ru[9], nr[9];
+    for (int i = 0; i < 9; ++i) ru[i] = (float)rotUpdate[i];
+    sm::mul3<float>(ru, st->R_lr, nr);
+    for (int i = 0; i < 9; ++i) {
+      st->R_lr[i] = nr[i];
+      st->resultR[i] = (double)nr[i];
+    }
+  }
+  if (stop || is_last) {
+    st->so3_done = 1;
+    // seed resultRt with the rotation (RGBDOdometry.cpp:397-406) and derive the first GN parameters
+    for (int x = 0; x < 3; ++x)
+      for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = st->resultR[x * 3 + y];
+    double K[9];
+    level_K(fx, fy, cx, cy, first_gn_level, K);
+    gn_params(st, K);
+  } else {
+    double K[9];
+    level_K(fx, fy, cx, cy, 2, K);
+    so3_params(st, K);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Gauss-Newton passes (RGBDOdometry.cpp:425-586)
+// ---------------------------------------------------------------------------------------
+struct GnArgs {
+  // ICP
+  MapPtrs maps;
+  float fx, fy, cx, cy, distThres, angleThres;
+  // RGB
+  RgbResPtrs rgb;
+  dms_dataterm* corres;
+  const float* cloud;
+  size_t cloud_pitch;
+  float minScale, maxDepthDelta, sobelScale;
+  int cols, rows, level;
+};
+
+template <bool ICP, bool RGB>
+__global__ __launch_bounds__(kBlock) void k_gn_pass1(const TrackState* __restrict__ st, GnArgs a, float* __restrict__ part_icp,
+                                                     int* __restrict__ part_cnt, int stride) {
+  if (st->level_done[a.level]) return;
+  const int N = a.cols * a.rows;
+  IcpParams ip;
+  RgbResParams rp;
+  if (ICP) {
+    const float* R = st->Rcurr;
+    const float* Ri = st->Rprev_inv;
+    ip.Rcurr.r0 = mk3(R[0], R[1], R[2]);
+    ip.Rcurr.r1 = mk3(R[3], R[4], R[5]);
+    ip.Rcurr.r2 = mk3(R[6], R[7], R[8]);
+    ip.tcurr = mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]);
+    ip.Rprev_inv.r0 = mk3(Ri[0], Ri[1], Ri[2]);
+    ip.Rprev_inv.r1 = mk3(Ri[3], Ri[4], Ri[5]);
+    ip.Rprev_inv.r2 = mk3(Ri[6], Ri[7], Ri[8]);
+    ip.tprev = mk3(st->tprev[0], st->tprev[1], st->tprev[2]);
+    ip.fx = a.fx;
+    ip.fy = a.fy;
+    ip.cx = a.cx;
+    ip.cy = a.cy;
+    ip.distThres = a.distThres;
+    ip.angleThres = a.angleThres;
+    ip.cols = a.cols;
+    ip.rows = a.rows;
+  }
+  if (RGB) {
+    const float* H = st->krkinv;
+    rp.krkinv.r0 = mk3(H[0], H[1], H[2]);
+    rp.krkinv.r1 = mk3(H[3], H[4], H[5]);
+    rp.krkinv.r2 = mk3(H[6], H[7], H[8]);
+    rp.kt = mk3(st->kt[0], st->kt[1], st->kt[2]);
+    rp.minScale = a.minScale;
+    rp.maxDepthDelta = a.maxDepthDelta;
+    rp.cols = a.cols;
+    rp.rows = a.rows;
+  }
+  float acc[kSE3];
+#pragma unroll
+  for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
+  int cnt = 0, sig = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
+    const int y = i / a.cols;
+    const int x = i - y * a.cols;
+    if (RGB) {
+      dms_dataterm c;
+      int d2;
+      if (rgb_residual(rp, a.rgb, x, y, c, d2)) {
+        cnt += 1;
+        sig += d2;
+      }
+      a.corres[i] = c;
+    }
+    if (ICP) {
+      float row[7];
+      const bool found = icp_row(ip, a.maps, x, y, row);
+      accumulate_se3(acc, row, found);
+    }
+  }
+  if (ICP) block_reduce_store<kSE3>(acc, part_icp, stride, blockIdx.x);
+  if (RGB) {
+    __shared__ int lds[kBlock / kWave][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    cnt = wave_sum_to_lane63_i(cnt);
+    sig = wave_sum_to_lane63_i(sig);
+    if (lane == 63) {
+      lds[wid][0] = cnt;
+      lds[wid][1] = sig;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      int s = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += lds[w][threadIdx.x];
+      part_cnt[(size_t)threadIdx.x * stride + blockIdx.x] = s;
+    }
+  }
+}
+
+// σ as the reference computes it (RGBDOdometry.cpp:464, precedence quirk kept)
+__device__ __forceinline__ float sigma_val(int sigma, int rgbSize) {
+  const float q = (float)sigma / (float)rgbSize;
+  const int arg = (q == 0.f) ? 1 : rgbSize;
+  return (float)sqrt((double)arg);
+}
+__device__ __forceinline__ bool rgbonly_break(int sigma, int rgbSize, float lastRGBError) {
+  return sqrt((double)sigma) / (double)rgbSize > (double)lastRGBError;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gn_pass2(const TrackState* __restrict__ st, GnArgs a, const int* __restrict__ part_cnt,
+                                                     int nb_cnt, int stride, int rgbOnly, int first_iter,
+                                                     float* __restrict__ part_rgb) {
+  if (st->level_done[a.level]) return;
+  // every block folds the (≤1024) integer partials itself: integer sums are order-free, so
+  // all blocks agree bit-for-bit and no extra launch is needed to publish σ.
+  __shared__ int s_cnt[kBlock / kWave][2];
+  __shared__ int s_tot[2];
+  {
+    int c = 0, g = 0;
+    for (int b = threadIdx.x; b < nb_cnt; b += blockDim.x) {
+      c += part_cnt[b];
+      g += part_cnt[(size_t)stride + b];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    c = wave_sum_to_lane63_i(c);
+    g = wave_sum_to_lane63_i(g);
+    if (lane == 63) {
+      s_cnt[wid][0] = c;
+      s_cnt[wid][1] = g;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      int s = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_cnt[w][threadIdx.x];
+      s_tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
+  const int rgbSize = s_tot[0], sigma = s_tot[1];
+  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
+  if (rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) return;
+  RgbStepParams p;
+  p.sigma = rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
+  p.fx = a.fx;
+  p.fy = a.fy;
+  p.sobelScale = a.sobelScale;
+  const int N = a.cols * a.rows;
+  float acc[kSE3];
+#pragma unroll
+  for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
+    const dms_dataterm c = a.corres[i];
+    float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c.valid) rgb_row(p, c, a.cloud, a.cloud_pitch, a.rgb.dIdx, a.rgb.dIdy, a.rgb.dI_pitch, row);
+    accumulate_se3(acc, row, c.valid != 0);
+  }
+  block_reduce_store<kSE3>(acc, part_rgb, stride, blockIdx.x);
+}
+
+__device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const float v = s[shift++];
+      if (j == 6)
+        b[i] = v;
+      else
+        A[j * 6 + i] = A[i * 6 + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* __restrict__ part_icp,
+                                                   const float* __restrict__ part_rgb, const int* __restrict__ part_cnt, int stride,
+                                                   int nblocks, int icp, int rgb, int rgbOnly, float icpWeight, int level,
+                                                   int first_iter, int next_level, float fx, float fy, float cx, float cy) {
+  if (st->level_done[level]) return;
+  __shared__ float s_icp[kSE3];
+  __shared__ float s_rgb[kSE3];
+  __shared__ int s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (icp) fold_rows<kSE3>(part_icp, stride, nblocks, s_icp);
+  if (rgb) {
+    fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
+  }
+  __syncthreads();
+  const int rgbSize = s_cnt[0], sigma = s_cnt[1];
+  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
+  const bool brk = rgbOnly && rgbonly_break(sigma, rgbSize, lastErr);
+  if (brk) {
+    if (threadIdx.x == 0) st->level_done[level] = 1;
+    return;
+  }
+  if (rgb) fold_rows<kSE3>(part_rgb, stride, nblocks, s_rgb);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  st->iters_run[level] += 1;
+  st->lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
+  st->lastRGBCount = (float)rgbSize;
+
+  float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+  float residual[2] = {0.f, 0.f};
+  if (icp) {
+    unpack_se3_d(s_icp, A_icp, b_icp);
+    residual[0] = s_icp[27];
+    residual[1] = s_icp[28];
+  }
+  st->lastICPError = sqrtf(residual[0]) / residual[1];
+  st->lastICPCount = residual[1];
+  if (rgb) unpack_se3_d(s_rgb, A_rgb, b_rgb);
+
+  double A[36], b[6], x[6];
+  if (icp && rgb) {
+    const double w = (double)icpWeight;
+    const double ww = w * w;
+    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i] + ww * (double)A_icp[i];
+    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i] + w * (double)b_icp[i];
+  } else if (icp) {
+    for (int i = 0; i < 36; ++i) A[i] = (double)A_icp[i];
+    for (int i = 0; i < 6; ++i) b[i] = (double)b_icp[i];
+  } else {
+    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i];
+    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i];
+  }
+  for (int i = 0; i < 36; ++i) st->lastA[i] = A[i];
+  for (int i = 0; i < 6; ++i) st->lastb[i] = b[i];
+  sm::ldlt_solve<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308);
+
+  // OdometryProvider::computeUpdateSE3 (OdometryProvider.h:73-93)
+  double Rt[16];
+  for (int i = 0; i < 16; ++i) Rt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  const double rvec[3] = {x[3], x[4], x[5]};
+  double R[9];
+  sm::rodrigues(rvec, R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rt[i * 4 + j] = R[i * 3 + j];
+  Rt[3] = x[0];
+  Rt[7] = x[1];
+  Rt[11] = x[2];
+  double nr[16];
+  sm::mul4(Rt, st->resultRt, nr);
+  for (int i = 0; i < 16; ++i) st->resultRt[i] = nr[i];
+
+  // rgbOdom = float(resultRt); currentT = [Rprev|tprev] * rgbOdom^-1 with the isometry inverse
+  float Ro[9], to[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = (float)nr[i * 4 + j];
+    to[i] = (float)nr[i * 4 + 3];
+  }
+  float RoT[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) RoT[i * 3 + j] = Ro[j * 3 + i];
+  float ti[3];
+  sm::mul3v<float>(RoT, to, ti);
+  ti[0] = -ti[0];
+  ti[1] = -ti[1];
+  ti[2] = -ti[2];
+  float Rc[9], tc[3];
+  sm::mul3<float>(st->Rprev, RoT, Rc);
+  sm::mul3v<float>(st->Rprev, ti, tc);
+  for (int i = 0; i < 9; ++i) st->Rcurr[i] = Rc[i];
+  for (int i = 0; i < 3; ++i) st->tcurr[i] = tc[i] + st->tprev[i];
+
+  double K[9];
+  level_K(fx, fy, cx, cy, next_level, K);
+  gn_params(st, K);
+}
+
+__global__ void k_track_finalize(TrackState* st, int rgb) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
+  const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (rgb && (double)n > 0.3) {  // RGBDOdometry.cpp:589-593
+    for (int i = 0; i < 9; ++i) st->Rcurr[i] = st->Rprev[i];
+    for (int i = 0; i < 3; ++i) st->tcurr[i] = st->tprev[i];
+    st->rejected_jump = 1;
+  }
+  for (int i = 0; i < 3; ++i) st->out_trans[i] = st->tcurr[i];
+  for (int i = 0; i < 9; ++i) st->out_rot[i] = st->Rcurr[i];
+}
+
+}  // namespace dms
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  size_t off = 0;
+  char* base = nullptr;
+  void* take(size_t bytes) {
+    off = align_up(off, 256);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+void layout(dms_odometry* o, Carver& c) {
+  const int W = o->width, H = o->height;
+  auto mk = [&](Buf& b, int rows, int cols, size_t elem) {
+    b.rows = rows;
+    b.cols = cols;
+    b.pitch = (size_t)cols * elem;
+    b.p = c.take(b.pitch * rows);
+  };
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    const int r = H >> i, w = W >> i;
+    mk(o->depth_tmp[i], r, w, 2);
+    mk(o->vmaps_g_prev[i], r * 3, w, 4);
+    mk(o->nmaps_g_prev[i], r * 3, w, 4);
+    mk(o->vmaps_curr[i], r * 3, w, 4);
+    mk(o->nmaps_curr[i], r * 3, w, 4);
+    mk(o->lastDepth[i], r, w, 4);
+    mk(o->nextDepth[i], r, w, 4);
+    mk(o->lastImage[i], r, w, 1);
+    mk(o->nextImage[i], r, w, 1);
+    mk(o->lastNextImage[i], r, w, 1);
+    mk(o->nextdIdx[i], r, w, 2);
+    mk(o->nextdIdy[i], r, w, 2);
+    mk(o->pointClouds[i], r, w, 12);
+    mk(o->corresImg[i], r, w, sizeof(dms_dataterm));
+  }
+  o->vmaps_tmp = (float*)c.take((size_t)W * H * 16);
+  o->nmaps_tmp = (float*)c.take((size_t)W * H * 16);
+  o->part_icp = (float*)c.take((size_t)kSE3 * kMaxPartialBlocks * 4);
+  o->part_rgb = (float*)c.take((size_t)kSE3 * kMaxPartialBlocks * 4);
+  o->part_so3 = (float*)c.take((size_t)kSO3 * kMaxPartialBlocks * 4);
+  o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
+  o->state = (TrackState*)c.take(sizeof(TrackState));
+}
+
+struct Timer {
+  dms_odometry* o;
+  hipStream_t s;
+  const char* name;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timer(dms_odometry* o_, hipStream_t s_, const char* n) : o(o_), s(s_), name(n) {
+    if (!o->profiling) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!o->event_pool.empty()) {
+        e = o->event_pool.back();
+        o->event_pool.pop_back();
+      } else {
+        hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    hipEventRecord(a, s);
+  }
+  ~Timer() {
+    if (!o->profiling) return;
+    hipEventRecord(b, s);
+    o->pending.push_back({name, {a, b}});
+  }
+};
+
+void drain_timers(dms_odometry* o) {
+  for (auto& p : o->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+      KernelTime& t = o->times[p.first];
+      t.ms += ms;
+      t.launches += 1;
+    }
+    o->event_pool.push_back(p.second.first);
+    o->event_pool.push_back(p.second.second);
+  }
+  o->pending.clear();
+}
+
+int populateRGBDData(dms_odometry* o, const dms_image2d* rgba, Buf* destDepths, Buf* destImages, hipStream_t s) {
+  int rc;
+  dms_image2d d0 = destDepths[0].img();
+  if ((rc = verticesToDepth(o->vmaps_tmp, &d0, o->maxDepthRGB, s))) return rc;
+  for (int i = 0; i + 1 < DMS_NUM_PYRS; i++) {
+    dms_image2d a = destDepths[i].img(), b = destDepths[i + 1].img();
+    if ((rc = pyrDownGaussF(&a, &b, s))) return rc;
+  }
+  dms_image2d i0 = destImages[0].img();
+  if ((rc = imageToIntensity(rgba, &i0, s))) return rc;
+  for (int i = 0; i + 1 < DMS_NUM_PYRS; i++) {
+    dms_image2d a = destImages[i].img(), b = destImages[i + 1].img();
+    if ((rc = pyrDownUcharGauss(&a, &b, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dms_odometry_create(dms_odometry** out, int width, int height, float cx, float cy, float fx, float fy, float distThresh,
+                        float angleThresh) {
+  DMS_REQUIRE(out, "null out");
+  DMS_REQUIRE(width >= 16 && height >= 16 && width <= 32767 && height <= 32767, "bad resolution");
+  dms_odometry* o = new dms_odometry();
+  o->width = width;
+  o->height = height;
+  o->cx = cx;
+  o->cy = cy;
+  o->fx = fx;
+  o->fy = fy;
+  o->distThres = distThresh > 0.f ? distThresh : 0.10f;
+  o->angleThres = angleThresh > 0.f ? angleThresh : (float)sin(20.f * 3.14159254f / 180.f);
+  o->sobelScale = (float)(1.0 / pow(2.0, 3));  // RGBDOdometry.cpp:34-35
+  o->maxDepthDeltaRGB = 0.07f;
+  o->maxDepthRGB = 6.0f;
+  o->minGrad[0] = 5;
+  o->minGrad[1] = 3;
+  o->minGrad[2] = 1;
+  Carver sz;
+  layout(o, sz);
+  o->arena_bytes = align_up(sz.off, 256);
+  hipError_t e = hipMalloc((void**)&o->arena, o->arena_bytes);
+  if (e != hipSuccess) {
+    delete o;
+    return hip_fail(e, "hipMalloc(arena)", __FILE__, __LINE__);
+  }
+  // pyramids start as zeros (the reference's cudaMallocPitch memory is uninitialised;
+  // zero keeps the never-initialised-RGB case of GPUTest.cpp:247-286 deterministic)
+  hipMemset(o->arena, 0, o->arena_bytes);
+  Carver c;
+  c.base = o->arena;
+  layout(o, c);
+  e = hipHostMalloc((void**)&o->host_state, sizeof(TrackState), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    hipFree(o->arena);
+    delete o;
+    return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+  }
+  memset(o->host_state, 0, sizeof(TrackState));
+  *out = o;
+  return DMS_OK;
+}
+
+int dms_odometry_destroy(dms_odometry* o) {
+  if (!o) return DMS_OK;
+  drain_timers(o);
+  for (auto e : o->event_pool) hipEventDestroy(e);
+  if (o->arena) hipFree(o->arena);
+  if (o->host_state) hipHostFree(o->host_state);
+  delete o;
+  return DMS_OK;
+}
+
+int dms_odometry_initICP_depth(dms_odometry* o, const dms_image2d* depth, float depthCutoff, dms_stream st) {
+  DMS_REQUIRE(o && depth && depth->data, "null argument");
+  DMS_REQUIRE(depth->rows == o->height && depth->cols == o->width, "depth must be full resolution");
+  hipStream_t s = (hipStream_t)st;
+  DMS_HIP(hipMemcpy2DAsync(o->depth_tmp[0].p, o->depth_tmp[0].pitch, depth->data, depth->pitch, (size_t)o->width * 2, o->height,
+                           hipMemcpyDeviceToDevice, s));
+  int rc;
+  for (int i = 1; i < DMS_NUM_PYRS; ++i) {
+    dms_image2d a = o->depth_tmp[i - 1].img(), b = o->depth_tmp[i].img();
+    if ((rc = pyrDown(&a, &b, s))) return rc;
+  }
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    const int div = 1 << i;
+    dms_camera k = {o->fx / div, o->fy / div, o->cx / div, o->cy / div};
+    dms_image2d d = o->depth_tmp[i].img(), v = o->vmaps_curr[i].img(), n = o->nmaps_curr[i].img();
+    if ((rc = createVMap(&k, &d, &v, depthCutoff, s))) return rc;
+    if ((rc = createNMap(&v, &n, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+int dms_odometry_initICP_maps(dms_odometry* o, const float* verts, const float* norms, float depthCutoff, dms_stream st) {
+  (void)depthCutoff;
+  DMS_REQUIRE(o && verts && norms, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  const size_t bytes = (size_t)o->width * o->height * 16;
+  DMS_HIP(hipMemcpyAsync(o->vmaps_tmp, verts, bytes, hipMemcpyDeviceToDevice, s));
+  DMS_HIP(hipMemcpyAsync(o->nmaps_tmp, norms, bytes, hipMemcpyDeviceToDevice, s));
+  int rc;
+  dms_image2d v0 = o->vmaps_curr[0].img(), n0 = o->nmaps_curr[0].img();
+  if ((rc = copyMaps(o->vmaps_tmp, o->nmaps_tmp, &v0, &n0, s))) return rc;
+  for (int i = 1; i < DMS_NUM_PYRS; ++i) {
+    dms_image2d va = o->vmaps_curr[i - 1].img(), vb = o->vmaps_curr[i].img();
+    dms_image2d na = o->nmaps_curr[i - 1].img(), nb = o->nmaps_curr[i].img();
+    if ((rc = resizeMap(&va, &vb, false, s))) return rc;
+    if ((rc = resizeMap(&na, &nb, true, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+int dms_odometry_initICPModel(dms_odometry* o, const float* verts, const float* norms, float depthCutoff, const float* modelPose,
+                              dms_stream st) {
+  (void)depthCutoff;
+  DMS_REQUIRE(o && verts && norms && modelPose, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  const size_t bytes = (size_t)o->width * o->height * 16;
+  DMS_HIP(hipMemcpyAsync(o->vmaps_tmp, verts, bytes, hipMemcpyDeviceToDevice, s));
+  DMS_HIP(hipMemcpyAsync(o->nmaps_tmp, norms, bytes, hipMemcpyDeviceToDevice, s));
+  int rc;
+  dms_image2d v0 = o->vmaps_g_prev[0].img(), n0 = o->nmaps_g_prev[0].img();
+  if ((rc = copyMaps(o->vmaps_tmp, o->nmaps_tmp, &v0, &n0, s))) return rc;
+  for (int i = 1; i < DMS_NUM_PYRS; ++i) {
+    dms_image2d va = o->vmaps_g_prev[i - 1].img(), vb = o->vmaps_g_prev[i].img();
+    dms_image2d na = o->nmaps_g_prev[i - 1].img(), nb = o->nmaps_g_prev[i].img();
+    if ((rc = resizeMap(&va, &vb, false, s))) return rc;
+    if ((rc = resizeMap(&na, &nb, true, s))) return rc;
+  }
+  dms_mat33 R;
+  dms_float3 t;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R.m[i * 3 + j] = modelPose[i * 4 + j];
+  t.x = modelPose[3];
+  t.y = modelPose[7];
+  t.z = modelPose[11];
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    dms_image2d v = o->vmaps_g_prev[i].img(), n = o->nmaps_g_prev[i].img();
+    if ((rc = transformMaps(&v, &n, &R, &t, &v, &n, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+int dms_odometry_initRGB(dms_odometry* o, const dms_image2d* rgba, dms_stream s) {
+  DMS_REQUIRE(o && rgba && rgba->data, "null argument");
+  DMS_REQUIRE(rgba->rows == o->height && rgba->cols == o->width, "rgba must be full resolution");
+  return populateRGBDData(o, rgba, o->nextDepth, o->nextImage, (hipStream_t)s);
+}
+int dms_odometry_initRGBModel(dms_odometry* o, const dms_image2d* rgba, dms_stream s) {
+  DMS_REQUIRE(o && rgba && rgba->data, "null argument");
+  DMS_REQUIRE(rgba->rows == o->height && rgba->cols == o->width, "rgba must be full resolution");
+  return populateRGBDData(o, rgba, o->lastDepth, o->lastImage, (hipStream_t)s);
+}
+int dms_odometry_initFirstRGB(dms_odometry* o, const dms_image2d* rgba, dms_stream st) {
+  DMS_REQUIRE(o && rgba && rgba->data, "null argument");
+  DMS_REQUIRE(rgba->rows == o->height && rgba->cols == o->width, "rgba must be full resolution");
+  hipStream_t s = (hipStream_t)st;
+  int rc;
+  dms_image2d i0 = o->lastNextImage[0].img();
+  if ((rc = imageToIntensity(rgba, &i0, s))) return rc;
+  for (int i = 0; i + 1 < DMS_NUM_PYRS; i++) {
+    dms_image2d a = o->lastNextImage[i].img(), b = o->lastNextImage[i + 1].img();
+    if ((rc = pyrDownUcharGauss(&a, &b, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* rot, int rgbOnly, float icpWeight, int pyramid,
+                             int fastOdom, int so3, int interMap, dms_stream st) {
+  DMS_REQUIRE(o && trans && rot, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  const bool icp = !rgbOnly && icpWeight > 0;
+  const bool rgb = rgbOnly || icpWeight < 100;
+  DMS_REQUIRE(icp || rgb, "neither ICP nor RGB term active");
+  int rc;
+
+  Prior prior;
+  memcpy(prior.v, trans, 3 * sizeof(float));
+  memcpy(prior.v + 3, rot, 9 * sizeof(float));
+
+  if (rgb) {
+    for (int i = 0; i < DMS_NUM_PYRS; i++) {
+      dms_image2d a = o->nextImage[i].img(), dx = o->nextdIdx[i].img(), dy = o->nextdIdy[i].img();
+      if ((rc = derivativeImages(&a, &dx, &dy, s))) return rc;
+    }
+  }
+
+  int iterations[DMS_NUM_PYRS];
+  iterations[0] = interMap ? 50 : fastOdom ? 3 : 10;
+  iterations[1] = interMap ? 50 : pyramid ? 5 : 0;
+  iterations[2] = interMap ? 50 : pyramid ? 4 : 0;
+  int first_level = 0;
+  for (int l = DMS_NUM_PYRS - 1; l >= 0; --l)
+    if (iterations[l] > 0) {
+      first_level = l;
+      break;
+    }
+
+  {
+    Timer t(o, s, "track_init");
+    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, s, o->state, prior, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0, first_level);
+    DMS_CHECK_LAUNCH();
+  }
+
+  if (so3) {
+    const int L = 2;
+    const Buf& li = o->lastNextImage[L];
+    const Buf& ni = o->nextImage[L];
+    const int nb = reduce_blocks_for(li.rows * li.cols);
+    for (int i = 0; i < 10; ++i) {
+      {
+        Timer t(o, s, "so3_pass");
+        hipLaunchKernelGGL(k_so3_pass, dim3(nb), dim3(kBlock), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, kMaxPartialBlocks);
+        DMS_CHECK_LAUNCH();
+      }
+      {
+        Timer t(o, s, "so3_solve");
+        hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(1024), 0, s, o->state, o->part_so3, kMaxPartialBlocks, nb, o->fx, o->fy, o->cx,
+                           o->cy, i == 9 ? 1 : 0, first_level);
+        DMS_CHECK_LAUNCH();
+      }
+    }
+  }
+
+  for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
+    if (rgb) {
+      dms_camera k = {o->fx, o->fy, o->cx, o->cy};
+      dms_image2d d = o->lastDepth[l].img(), c = o->pointClouds[l].img();
+      if ((rc = projectToPointCloud(&d, &c, &k, l, s))) return rc;
+    }
+    if (iterations[l] == 0) continue;
+    const int div = 1 << l;
+    GnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.maps.vcurr = (const float*)o->vmaps_curr[l].p;
+    a.maps.vcurr_pitch = o->vmaps_curr[l].pitch;
+    a.maps.ncurr = (const float*)o->nmaps_curr[l].p;
+    a.maps.ncurr_pitch = o->nmaps_curr[l].pitch;
+    a.maps.vprev = (const float*)o->vmaps_g_prev[l].p;
+    a.maps.vprev_pitch = o->vmaps_g_prev[l].pitch;
+    a.maps.nprev = (const float*)o->nmaps_g_prev[l].p;
+    a.maps.nprev_pitch = o->nmaps_g_prev[l].pitch;
+    a.fx = o->fx / div;
+    a.fy = o->fy / div;
+    a.cx = o->cx / div;
+    a.cy = o->cy / div;
+    a.distThres = o->distThres;
+    a.angleThres = o->angleThres;
+    a.rgb.dIdx = (const short*)o->nextdIdx[l].p;
+    a.rgb.dIdy = (const short*)o->nextdIdy[l].p;
+    a.rgb.dI_pitch = o->nextdIdx[l].pitch;
+    a.rgb.lastDepth = (const float*)o->lastDepth[l].p;
+    a.rgb.lastDepth_pitch = o->lastDepth[l].pitch;
+    a.rgb.nextDepth = (const float*)o->nextDepth[l].p;
+    a.rgb.nextDepth_pitch = o->nextDepth[l].pitch;
+    a.rgb.lastImage = (const unsigned char*)o->lastImage[l].p;
+    a.rgb.lastImage_pitch = o->lastImage[l].pitch;
+    a.rgb.nextImage = (const unsigned char*)o->nextImage[l].p;
+    a.rgb.nextImage_pitch = o->nextImage[l].pitch;
+    a.corres = (dms_dataterm*)o->corresImg[l].p;
+    a.cloud = (const float*)o->pointClouds[l].p;
+    a.cloud_pitch = o->pointClouds[l].pitch;
+    // pow(minimumGradientMagnitudes[i], 2.0) / pow(sobelScale, 2.0) (RGBDOdometry.cpp:445)
+    a.minScale = (float)(pow((double)o->minGrad[l], 2.0) / pow((double)o->sobelScale, 2.0));
+    a.maxDepthDelta = o->maxDepthDeltaRGB;
+    a.sobelScale = o->sobelScale;
+    a.cols = o->vmaps_curr[l].cols;
+    a.rows = o->vmaps_curr[l].rows / 3;
+    a.level = l;
+    const int nb = reduce_blocks_for(a.cols * a.rows);
+    for (int j = 0; j < iterations[l]; ++j) {
+      int next_level = l;
+      if (j == iterations[l] - 1) {
+        for (int q = l - 1; q >= 0; --q)
+          if (iterations[q] > 0) {
+            next_level = q;
+            break;
+          }
+      }
+      {
+        Timer t(o, s, "gn_pass1");
+        if (icp && rgb)
+          hipLaunchKernelGGL((k_gn_pass1<true, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
+                             kMaxPartialBlocks);
+        else if (icp)
+          hipLaunchKernelGGL((k_gn_pass1<true, false>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
+                             kMaxPartialBlocks);
+        else
+          hipLaunchKernelGGL((k_gn_pass1<false, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
+                             kMaxPartialBlocks);
+        DMS_CHECK_LAUNCH();
+      }
+      if (rgb) {
+        Timer t(o, s, "gn_pass2");
+        hipLaunchKernelGGL(k_gn_pass2, dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_cnt, nb, kMaxPartialBlocks, rgbOnly ? 1 : 0,
+                           j == 0 ? 1 : 0, o->part_rgb);
+        DMS_CHECK_LAUNCH();
+      }
+      {
+        Timer t(o, s, "gn_solve");
+        hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks,
+                           nb, icp ? 1 : 0, rgb ? 1 : 0, rgbOnly ? 1 : 0, icpWeight, l, j == 0 ? 1 : 0, next_level, o->fx, o->fy,
+                           o->cx, o->cy);
+        DMS_CHECK_LAUNCH();
+      }
+    }
+  }
+
+  {
+    Timer t(o, s, "track_finalize");
+    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0);
+    DMS_CHECK_LAUNCH();
+  }
+  DMS_HIP(hipMemcpyAsync(o->host_state, o->state, sizeof(TrackState), hipMemcpyDeviceToHost, s));
+
+  if (so3) {  // RGBDOdometry.cpp:595-601 — stream-ordered, so swapping the handles is enough
+    for (int i = 0; i < DMS_NUM_PYRS; i++) std::swap(o->lastNextImage[i], o->nextImage[i]);
+  }
+  return DMS_OK;
+}
+
+int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {
+  DMS_REQUIRE(o && r, "null argument");
+  DMS_HIP(hipStreamSynchronize((hipStream_t)st));
+  drain_timers(o);
+  const TrackState* h = o->host_state;
+  memcpy(r->trans, h->out_trans, sizeof(r->trans));
+  memcpy(r->rot, h->out_rot, sizeof(r->rot));
+  r->lastICPError = h->lastICPError;
+  r->lastICPCount = h->lastICPCount;
+  r->lastRGBError = h->lastRGBError;
+  r->lastRGBCount = h->lastRGBCount;
+  r->lastSO3Error = h->lastSO3Error;
+  r->lastSO3Count = h->lastSO3Count;
+  memcpy(r->lastA, h->lastA, sizeof(r->lastA));
+  memcpy(r->lastb, h->lastb, sizeof(r->lastb));
+  for (int l = 0; l < DMS_NUM_PYRS; ++l) r->iterations_run[l] = h->iters_run[l];
+  r->so3_iterations_run = h->so3_iters;
+  r->rejected_jump = h->rejected_jump;
+  return DMS_OK;
+}
+
+int dms_odometry_getIncrementalTransformation(dms_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight, int pyramid,
+                                              int fastOdom, int so3, int interMap, dms_track_result* result, dms_stream s) {
+  DMS_REQUIRE(o && trans && rot, "null argument");
+  int rc = dms_odometry_track_async(o, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap, s);
+  if (rc) return rc;
+  dms_track_result local;
+  dms_track_result* r = result ? result : &local;
+  rc = dms_odometry_fetch_result(o, r, s);
+  if (rc) return rc;
+  memcpy(trans, r->trans, 3 * sizeof(float));
+  memcpy(rot, r->rot, 9 * sizeof(float));
+  return DMS_OK;
+}
+
+int dms_odometry_getCovariance(dms_odometry* o, double* cov36) {
+  DMS_REQUIRE(o && cov36, "null argument");
+  // lastA.lu().inverse() (RGBDOdometry.cpp:607-610): Gauss-Jordan with partial pivoting
+  double a[36], inv[36];
+  memcpy(a, o->host_state->lastA, sizeof(a));
+  for (int i = 0; i < 36; ++i) inv[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (fabs(a[r * 6 + c]) > fabs(a[p * 6 + c])) p = r;
+    if (p != c)
+      for (int j = 0; j < 6; ++j) {
+        std::swap(a[c * 6 + j], a[p * 6 + j]);
+        std::swap(inv[c * 6 + j], inv[p * 6 + j]);
+      }
+    const double d = a[c * 6 + c];
+    for (int j = 0; j < 6; ++j) {
+      a[c * 6 + j] /= d;
+      inv[c * 6 + j] /= d;
+    }
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = a[r * 6 + c];
+      for (int j = 0; j < 6; ++j) {
+        a[r * 6 + j] -= f * a[c * 6 + j];
+        inv[r * 6 + j] -= f * inv[c * 6 + j];
+      }
+    }
+  }
+  memcpy(cov36, inv, sizeof(inv));
+  return DMS_OK;
+}
+
+int dms_odometry_get_buffer(dms_odometry* o, int which, int level, dms_image2d* view) {
+  DMS_REQUIRE(o && view, "null argument");
+  DMS_REQUIRE(level >= 0 && level < DMS_NUM_PYRS, "bad level");
+  const Buf* b = nullptr;
+  switch (which) {
+    case 0: b = &o->vmaps_curr[level]; break;
+    case 1: b = &o->nmaps_curr[level]; break;
+    case 2: b = &o->vmaps_g_prev[level]; break;
+    case 3: b = &o->nmaps_g_prev[level]; break;
+    case 4: b = &o->lastDepth[level]; break;
+    case 5: b = &o->nextDepth[level]; break;
+    case 6: b = &o->lastImage[level]; break;
+    case 7: b = &o->nextImage[level]; break;
+    case 8: b = &o->lastNextImage[level]; break;
+    case 9: b = &o->nextdIdx[level]; break;
+    case 10: b = &o->nextdIdy[level]; break;
+    case 11: b = &o->pointClouds[level]; break;
+    case 12: b = &o->depth_tmp[level]; break;
+    case 13: b = &o->corresImg[level]; break;
+    default: DMS_REQUIRE(false, "bad buffer id");
+  }
+  *view = b->img();
+  return DMS_OK;
+}
+
+int dms_odometry_set_profiling(dms_odometry* o, int enabled) {
+  DMS_REQUIRE(o, "null argument");
+  o->profiling = enabled != 0;
+  if (enabled) o->times.clear();
+  return DMS_OK;
+}
+
+int dms_odometry_get_kernel_time(dms_odometry* o, const char* name, double* total_ms, int* launches) {
+  DMS_REQUIRE(o && name && total_ms && launches, "null argument");
+  auto it = o->times.find(name);
+  if (it == o->times.end()) {
+    *total_ms = 0;
+    *launches = 0;
+    return DMS_OK;
+  }
+  *total_ms = it->second.ms;
+  *launches = it->second.launches;
+  return DMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+/*
+ * orc.h — interface of the CPU ORACLE (test infrastructure; see the header of orc_track.c).
+ * Dense row-major host arrays everywhere; vertex/normal maps are 3 stacked planes.
+ */
+#ifndef ORC_H_
+#define ORC_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference DataTerm, Cuda/types.cuh:77-83 (bool widened to int) */
+typedef struct orc_dataterm {
+  short zero_x, zero_y, one_x, one_y;
+  float diff;
+  int valid;
+} orc_dataterm;
+
+float orc_qnan(void);
+
+/* ---- cudafuncs.cu restatements ---- */
+void orc_pyrDown(const uint16_t* src, int srows, int scols, uint16_t* dst);
+void orc_createVMap(float fx, float fy, float cx, float cy, const uint16_t* depth, int rows, int cols, float* vmap,
+                    float depthCutoff);
+void orc_createNMap(const float* vmap, int rows, int cols, float* nmap);
+void orc_tranformMaps(const float* vsrc, const float* nsrc, int rows, int cols, const float* R, const float* t, float* vdst,
+                      float* ndst);
+void orc_copyMaps(const float* vsrc4, const float* nsrc4, int rows, int cols, float* vdst, float* ndst);
+void orc_resizeMap(const float* in, int srows, int scols, float* out, int normalize);
+void orc_pyrDownGaussF(const float* src, int srows, int scols, float* dst);
+void orc_pyrDownUcharGauss(const uint8_t* src, int srows, int scols, uint8_t* dst);
+void orc_verticesToDepth(const float* vsrc4, int rows, int cols, float* dst, float cutOff);
+void orc_imageBGRToIntensity(const uint8_t* rgba, int rows, int cols, uint8_t* dst);
+void orc_computeDerivativeImages(const uint8_t* src, int rows, int cols, int16_t* dx, int16_t* dy);
+void orc_projectToPointCloud(const float* depth, int rows, int cols, float* cloud3, float fx, float fy, float cx, float cy,
+                             int level);
+
+/* ---- reduce.cu restatements ---- */
+int orc_icp_row(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
+                const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
+                float distThres, float angleThres, int rows, int cols, int x, int y, float* row);
+void orc_icpStep(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
+                 const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
+                 float distThres, float angleThres, int rows, int cols, float* A, float* b, float* residual);
+void orc_computeRgbResidual(float minScale, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                            const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, orc_dataterm* corres,
+                            float maxDepthDelta, const float* kt, const float* krkinv, int rows, int cols, int* sigmaSum,
+                            int* count);
+void orc_rgb_row(const orc_dataterm* c, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx,
+                 const int16_t* dIdy, float sobelScale, int cols, float* row);
+void orc_rgbStep(const orc_dataterm* corres, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx,
+                 const int16_t* dIdy, float sobelScale, int rows, int cols, float* A, float* b);
+int orc_so3_row(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis, const float* kinv, const float* krlr,
+                int rows, int cols, int x, int y, float* row);
+void orc_so3Step(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis, const float* kinv, const float* krlr,
+                 int rows, int cols, float* A, float* b, float* residual);
+
+/* ---- RGBDOdometry restatement (orc_odometry.c) ---- */
+typedef struct orc_odometry orc_odometry;
+
+typedef struct orc_track_result {
+  float trans[3];
+  float rot[9];
+  float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+  double lastA[36];
+  double lastb[6];
+  int iterations_run[3];
+  int so3_iterations_run;
+  int rejected_jump;
+  /* per-iteration pose trace (row-major 3x4 [R|t]) for up to 160 GN iterations */
+  int trace_len;
+  float trace[160][12];
+} orc_track_result;
+
+orc_odometry* orc_odometry_create(int width, int height, float cx, float cy, float fx, float fy, float distThresh,
+                                  float angleThresh);
+void orc_odometry_destroy(orc_odometry* o);
+void orc_odometry_initICP_depth(orc_odometry* o, const uint16_t* filteredDepth, float depthCutoff);
+void orc_odometry_initICP_maps(orc_odometry* o, const float* verts4, const float* norms4, float depthCutoff);
+void orc_odometry_initICPModel(orc_odometry* o, const float* verts4, const float* norms4, float depthCutoff,
+                               const float* modelPose16);
+void orc_odometry_initRGB(orc_odometry* o, const uint8_t* rgba);
+void orc_odometry_initRGBModel(orc_odometry* o, const uint8_t* rgba);
+void orc_odometry_initFirstRGB(orc_odometry* o, const uint8_t* rgba);
+void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
+                                               int pyramid, int fastOdom, int so3, int interMap, orc_track_result* result);
+/* which: same numbering as dms_odometry_get_buffer; returns pointer to the dense host buffer */
+void* orc_odometry_buffer(orc_odometry* o, int which, int level);
+void orc_covariance(const double* lastA36, double* cov36);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

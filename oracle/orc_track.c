@@ -1,0 +1,576 @@
+/*
+ * orc_track.c — CPU ORACLE for the tracking half of the hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of what the reference computes in
+ *   elasticfusion/Core/src/Cuda/cudafuncs.cu:57-757   (pyramid / map preparation kernels)
+ *   elasticfusion/Core/src/Cuda/reduce.cu:235-1103    (ICP / RGB / SO3 reduction steps)
+ *   elasticfusion/Core/src/Utils/RGBDOdometry.cpp:21-605 (pyramid init + coarse-to-fine GN loop)
+ *   elasticfusion/Core/src/Utils/OdometryProvider.h:35-93 (Rodrigues, SE3 update)
+ * Each function cites the lines it follows.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors, known-answer tests or numeric
+ * fixtures for this path (its only harness, GPUTest/src/GPUTest.cpp:146-332, asserts
+ * nothing), and it cannot be built here (CUDA + OpenGL + Eigen + Pangolin are absent and may
+ * not be stubbed).  The oracle is therefore anchored on (i) the reference's input fixture
+ * (the GPUTest RGB-D PNG pair, committed as tests/golden/gputest_pair.npz) run through the
+ * harness protocol of GPUTest.cpp:247-286, (ii) analytic properties (synthetic scenes with a
+ * known camera motion, finite-difference checks of the Jacobian rows) — see tests/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Numerics: fp32 per-pixel arithmetic exactly as written (build with -ffp-contract=off, no
+ * -ffast-math, SSE2 scalar math => IEEE single), IEEE division/sqrt where the reference was
+ * built with --prec-div=false/--prec-sqrt=false; reductions are accumulated in fp64 over the
+ * fp32 per-pixel products (the reference's fp32 tree order depends on its launch shape).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "orc.h"
+
+/* ------------------------------------------------------------------------------------ */
+/* helpers                                                                                */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }            /* operators.cuh:69-72 */
+static inline v3 vcross(v3 a, v3 b) {                                                        /* operators.cuh:64-67 */
+  return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float vnorm(v3 a) { return sqrtf(vdot(a, a)); }                                 /* operators.cuh:74-77 */
+static inline v3 vnormalized(v3 a) {                                                         /* operators.cuh:79-83 (rsqrt form) */
+  const float rn = 1.0f / sqrtf(vdot(a, a));
+  return V3(a.x * rn, a.y * rn, a.z * rn);
+}
+static inline v3 mmul(const float* m, v3 a) {                                                /* operators.cuh:86-89 */
+  return V3(vdot(V3(m[0], m[1], m[2]), a), vdot(V3(m[3], m[4], m[5]), a), vdot(V3(m[6], m[7], m[8]), a));
+}
+
+float orc_qnan(void) {
+  uint32_t u = 0x7fffffffu; /* CUDART_NAN_F bit pattern used at cudafuncs.cu:125 */
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* CUDA __float2int_rn: round to nearest even, NaN -> 0, saturating */
+static inline int f2i_rn(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)rintf(v);
+}
+/* float -> integer truncation as a CUDA cvt.rzi does it (NaN -> 0, saturating) */
+static inline int f2i_rz(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)v;
+}
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------------------------ */
+/* pyramid / preparation kernels (cudafuncs.cu)                                           */
+/* ------------------------------------------------------------------------------------ */
+
+/* pyrDownGaussKernel, cudafuncs.cu:57-91; sigma_color = 30 (:100) */
+void orc_pyrDown(const uint16_t* src, int srows, int scols, uint16_t* dst) {
+  const int drows = srows / 2, dcols = scols / 2;
+  const float sigma_color = 30.f;
+  const float weights[3] = {0.375f, 0.25f, 0.0625f};
+  const int D = 5;
+  for (int y = 0; y < drows; ++y)
+    for (int x = 0; x < dcols; ++x) {
+      const int center = src[(size_t)(2 * y) * scols + 2 * x];
+      const int x_mi = imax(0, 2 * x - D / 2) - 2 * x;
+      const int y_mi = imax(0, 2 * y - D / 2) - 2 * y;
+      const int x_ma = imin(scols, 2 * x - D / 2 + D) - 2 * x;
+      const int y_ma = imin(srows, 2 * y - D / 2 + D) - 2 * y;
+      float sum = 0, wall = 0;
+      for (int yi = y_mi; yi < y_ma; ++yi)
+        for (int xi = x_mi; xi < x_ma; ++xi) {
+          const int val = src[(size_t)(2 * y + yi) * scols + 2 * x + xi];
+          if ((float)abs(val - center) < 3 * sigma_color) {
+            sum += val * weights[abs(xi)] * weights[abs(yi)];
+            wall += weights[abs(xi)] * weights[abs(yi)];
+          }
+        }
+      dst[(size_t)y * dcols + x] = (uint16_t)f2i_rz(sum / wall);
+    }
+}
+
+/* computeVmapKernel, cudafuncs.cu:106-128.  vmap = 3 stacked planes of rows*cols */
+void orc_createVMap(float fx, float fy, float cx, float cy, const uint16_t* depth, int rows, int cols, float* vmap,
+                    float depthCutoff) {
+  const float fx_inv = 1.f / fx, fy_inv = 1.f / fy; /* :144 */
+  const size_t P = (size_t)rows * cols;
+  for (int v = 0; v < rows; ++v)
+    for (int u = 0; u < cols; ++u) {
+      const float z = depth[(size_t)v * cols + u] / 1000.f;
+      const size_t i = (size_t)v * cols + u;
+      if (z != 0 && z < depthCutoff) {
+        vmap[i] = z * (u - cx) * fx_inv;
+        vmap[P + i] = z * (v - cy) * fy_inv;
+        vmap[2 * P + i] = z;
+      } else {
+        vmap[i] = orc_qnan();
+      }
+    }
+}
+
+/* computeNmapKernel, cudafuncs.cu:149-182 */
+void orc_createNMap(const float* vmap, int rows, int cols, float* nmap) {
+  const size_t P = (size_t)rows * cols;
+  for (int v = 0; v < rows; ++v)
+    for (int u = 0; u < cols; ++u) {
+      const size_t i = (size_t)v * cols + u;
+      if (u == cols - 1 || v == rows - 1) {
+        nmap[i] = orc_qnan();
+        continue;
+      }
+      v3 v00, v01, v10;
+      v00.x = vmap[i];
+      v01.x = vmap[i + 1];
+      v10.x = vmap[i + cols];
+      if (!isnan(v00.x) && !isnan(v01.x) && !isnan(v10.x)) {
+        v00.y = vmap[P + i];
+        v01.y = vmap[P + i + 1];
+        v10.y = vmap[P + i + cols];
+        v00.z = vmap[2 * P + i];
+        v01.z = vmap[2 * P + i + 1];
+        v10.z = vmap[2 * P + i + cols];
+        const v3 r = vnormalized(vcross(vsub(v01, v00), vsub(v10, v00)));
+        nmap[i] = r.x;
+        nmap[P + i] = r.y;
+        nmap[2 * P + i] = r.z;
+      } else {
+        nmap[i] = orc_qnan();
+      }
+    }
+}
+
+/* tranformMapsKernel, cudafuncs.cu:200-246 (nmap may be NULL: :248-274).  In place allowed. */
+void orc_tranformMaps(const float* vsrc, const float* nsrc, int rows, int cols, const float* R, const float* t, float* vdst,
+                      float* ndst) {
+  const size_t P = (size_t)rows * cols;
+  const v3 tv = V3(t[0], t[1], t[2]);
+  for (size_t i = 0; i < P; ++i) {
+    {
+      v3 s;
+      float outx = orc_qnan();
+      s.x = vsrc[i];
+      if (!isnan(s.x)) {
+        s.y = vsrc[P + i];
+        s.z = vsrc[2 * P + i];
+        const v3 d = vadd(mmul(R, s), tv);
+        vdst[P + i] = d.y;
+        vdst[2 * P + i] = d.z;
+        outx = d.x;
+      }
+      vdst[i] = outx;
+    }
+    if (nsrc) {
+      v3 s;
+      float outx = orc_qnan();
+      s.x = nsrc[i];
+      if (!isnan(s.x)) {
+        s.y = nsrc[P + i];
+        s.z = nsrc[2 * P + i];
+        const v3 d = mmul(R, s);
+        ndst[P + i] = d.y;
+        ndst[2 * P + i] = d.z;
+        outx = d.x;
+      }
+      ndst[i] = outx;
+    }
+  }
+}
+
+/* copyMapsKernel, cudafuncs.cu:313-378: RGBA32F -> planes, vertex z == 0 => NaN for both */
+void orc_copyMaps(const float* vsrc4, const float* nsrc4, int rows, int cols, float* vdst, float* ndst) {
+  const size_t P = (size_t)rows * cols;
+  for (size_t i = 0; i < P; ++i) {
+    const float* v = vsrc4 + 4 * i;
+    const int ok = !(v[2] == 0);
+    vdst[i] = ok ? v[0] : orc_qnan();
+    vdst[P + i] = ok ? v[1] : orc_qnan();
+    vdst[2 * P + i] = ok ? v[2] : orc_qnan();
+    if (nsrc4) {
+      const float* n = nsrc4 + 4 * i;
+      ndst[i] = ok ? n[0] : orc_qnan();
+      ndst[P + i] = ok ? n[1] : orc_qnan();
+      ndst[2 * P + i] = ok ? n[2] : orc_qnan();
+    }
+  }
+}
+
+/* resizeMapKernel<normalize>, cudafuncs.cu:445-492 */
+void orc_resizeMap(const float* in, int srows, int scols, float* out, int normalize) {
+  const int drows = srows / 2, dcols = scols / 2;
+  const size_t SP = (size_t)srows * scols, DP = (size_t)drows * dcols;
+  for (int y = 0; y < drows; ++y)
+    for (int x = 0; x < dcols; ++x) {
+      const int xs = x * 2, ys = y * 2;
+      const size_t o = (size_t)y * dcols + x;
+      const float* p = in + (size_t)ys * scols + xs;
+      const float x00 = p[0], x01 = p[1], x10 = p[scols], x11 = p[scols + 1];
+      if (isnan(x00) || isnan(x01) || isnan(x10) || isnan(x11)) {
+        out[o] = orc_qnan();
+        continue;
+      }
+      v3 n;
+      n.x = (x00 + x01 + x10 + x11) / 4;
+      p += SP;
+      n.y = (p[0] + p[1] + p[scols] + p[scols + 1]) / 4;
+      p += SP;
+      n.z = (p[0] + p[1] + p[scols] + p[scols + 1]) / 4;
+      if (normalize) n = vnormalized(n);
+      out[o] = n.x;
+      out[DP + o] = n.y;
+      out[2 * DP + o] = n.z;
+    }
+}
+
+static const float kGauss[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1}; /* :529-530 */
+
+/* pyrDownKernelGaussF, cudafuncs.cu:416-443 */
+void orc_pyrDownGaussF(const float* src, int srows, int scols, float* dst) {
+  const int drows = srows / 2, dcols = scols / 2, D = 5;
+  for (int y = 0; y < drows; ++y)
+    for (int x = 0; x < dcols; ++x) {
+      const int tx = imin(2 * x - D / 2 + D, scols - 1);
+      const int ty = imin(2 * y - D / 2 + D, srows - 1);
+      float sum = 0;
+      int count = 0;
+      for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+          const float s = src[(size_t)cy * scols + cx];
+          if (!isnan(s)) {
+            sum += s * kGauss[(ty - cy - 1) * 5 + (tx - cx - 1)];
+            count += kGauss[(ty - cy - 1) * 5 + (tx - cx - 1)];
+          }
+        }
+      dst[(size_t)y * dcols + x] = (float)(sum / (float)count);
+    }
+}
+
+/* pyrDownKernelIntensityGauss, cudafuncs.cu:544-573 */
+void orc_pyrDownUcharGauss(const uint8_t* src, int srows, int scols, uint8_t* dst) {
+  const int drows = srows / 2, dcols = scols / 2, D = 5;
+  for (int y = 0; y < drows; ++y)
+    for (int x = 0; x < dcols; ++x) {
+      const int tx = imin(2 * x - D / 2 + D, scols - 1);
+      const int ty = imin(2 * y - D / 2 + D, srows - 1);
+      float sum = 0;
+      int count = 0;
+      for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx) {
+          if (src[(size_t)cy * scols + cx] > 0) {
+            sum += src[(size_t)cy * scols + cx] * kGauss[(ty - cy - 1) * 5 + (tx - cx - 1)];
+            count += kGauss[(ty - cy - 1) * 5 + (tx - cx - 1)];
+          }
+        }
+      dst[(size_t)y * dcols + x] = (uint8_t)f2i_rz(sum / (float)count);
+    }
+}
+
+/* verticesToDepthKernel, cudafuncs.cu:597-608 */
+void orc_verticesToDepth(const float* vsrc4, int rows, int cols, float* dst, float cutOff) {
+  for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+    const float z = vsrc4[4 * i + 2];
+    dst[i] = (z > cutOff || z <= 0) ? orc_qnan() : z;
+  }
+}
+
+/* bgr2IntensityKernel, cudafuncs.cu:643-655 */
+void orc_imageBGRToIntensity(const uint8_t* rgba, int rows, int cols, uint8_t* dst) {
+  for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+    const uint8_t* s = rgba + 4 * i;
+    const int value = f2i_rz((float)s[0] * 0.114f + (float)s[1] * 0.299f + (float)s[2] * 0.587f);
+    dst[i] = (uint8_t)value;
+  }
+}
+
+/* applyKernel, cudafuncs.cu:674-695; masks :703-707 */
+void orc_computeDerivativeImages(const uint8_t* src, int rows, int cols, int16_t* dx, int16_t* dy) {
+  const float gsx3x3[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+  const float gsy3x3[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      float dxVal = 0, dyVal = 0;
+      int kernelIndex = 8;
+      for (int j = imax(y - 1, 0); j <= imin(y + 1, rows - 1); j++)
+        for (int i = imax(x - 1, 0); i <= imin(x + 1, cols - 1); i++) {
+          dxVal += (float)src[(size_t)j * cols + i] * gsx3x3[kernelIndex];
+          dyVal += (float)src[(size_t)j * cols + i] * gsy3x3[kernelIndex];
+          --kernelIndex;
+        }
+      dx[(size_t)y * cols + x] = (int16_t)f2i_rz(dxVal);
+      dy[(size_t)y * cols + x] = (int16_t)f2i_rz(dyVal);
+    }
+}
+
+/* projectPointsKernel, cudafuncs.cu:727-741 with intrinsics(level) (:750-754) */
+void orc_projectToPointCloud(const float* depth, int rows, int cols, float* cloud3, float fx, float fy, float cx, float cy,
+                             int level) {
+  const int div = 1 << level;
+  const float lfx = fx / div, lfy = fy / div, lcx = cx / div, lcy = cy / div;
+  const float invFx = 1.0f / lfx, invFy = 1.0f / lfy;
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      const float z = depth[(size_t)y * cols + x];
+      float* c = cloud3 + 3 * ((size_t)y * cols + x);
+      c[0] = (float)((x - lcx) * z * invFx);
+      c[1] = (float)((y - lcy) * z * invFy);
+      c[2] = z;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* reduction steps (reduce.cu)                                                            */
+/* ------------------------------------------------------------------------------------ */
+
+static void unpack_se3(const double* s, float* A, float* b) { /* reduce.cu:415-424 */
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const float value = (float)s[shift++];
+      if (j == 6)
+        b[i] = value;
+      else
+        A[j * 6 + i] = A[i * 6 + j] = value;
+    }
+}
+
+/* ICPReduction::search + getProducts, reduce.cu:259-344.  Returns found flag, fills row[7]. */
+int orc_icp_row(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
+                const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
+                float distThres, float angleThres, int rows, int cols, int x, int y, float* row) {
+  const size_t P = (size_t)rows * cols;
+  for (int i = 0; i < 7; ++i) row[i] = 0;
+  const size_t i0 = (size_t)y * cols + x;
+  const v3 vcurr = V3(vmap_curr[i0], vmap_curr[P + i0], vmap_curr[2 * P + i0]);
+  const v3 tc = V3(tcurr[0], tcurr[1], tcurr[2]), tp = V3(tprev[0], tprev[1], tprev[2]);
+  const v3 vcurr_g = vadd(mmul(Rcurr, vcurr), tc);
+  const v3 vcurr_cp = mmul(Rprev_inv, vsub(vcurr_g, tp));
+  const int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx);
+  const int uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
+  if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return 0;
+  const size_t i1 = (size_t)uy * cols + ux;
+  const v3 vprev_g = V3(vmap_g_prev[i1], vmap_g_prev[P + i1], vmap_g_prev[2 * P + i1]);
+  const v3 ncurr = V3(nmap_curr[i0], nmap_curr[P + i0], nmap_curr[2 * P + i0]);
+  const v3 ncurr_g = mmul(Rcurr, ncurr);
+  const v3 nprev_g = V3(nmap_g_prev[i1], nmap_g_prev[P + i1], nmap_g_prev[2 * P + i1]);
+  const float dist = vnorm(vsub(vprev_g, vcurr_g));
+  const float sine = vnorm(vcross(ncurr_g, nprev_g));
+  if (!(sine < angleThres && dist <= distThres && !isnan(ncurr.x) && !isnan(nprev_g.x))) return 0;
+  const v3 s_cp = mmul(Rprev_inv, vsub(vcurr_g, tp));
+  const v3 d_cp = mmul(Rprev_inv, vsub(vprev_g, tp));
+  const v3 n_cp = mmul(Rprev_inv, nprev_g);
+  const v3 c = vcross(s_cp, n_cp);
+  row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+  row[3] = c.x; row[4] = c.y; row[5] = c.z;
+  row[6] = vdot(n_cp, vsub(s_cp, d_cp));
+  return 1;
+}
+
+static inline void acc_se3(double* acc, const float* row, int found) { /* reduce.cu:325-341 */
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) acc[k++] += (double)(row[i] * row[j]);
+  acc[27] += (double)(row[6] * row[6]);
+  acc[28] += found ? 1.0 : 0.0;
+}
+
+/* icpStep, reduce.cu:367-428 */
+void orc_icpStep(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
+                 const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
+                 float distThres, float angleThres, int rows, int cols, float* A, float* b, float* residual) {
+  double acc[29];
+  memset(acc, 0, sizeof(acc));
+#pragma omp parallel
+  {
+    double loc[29];
+    memset(loc, 0, sizeof(loc));
+#pragma omp for schedule(static) nowait
+    for (int y = 0; y < rows; ++y)
+      for (int x = 0; x < cols; ++x) {
+        float row[7];
+        const int found = orc_icp_row(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, fx, fy, cx, cy, vmap_g_prev,
+                                      nmap_g_prev, distThres, angleThres, rows, cols, x, y, row);
+        acc_se3(loc, row, found);
+      }
+#pragma omp critical
+    for (int k = 0; k < 29; ++k) acc[k] += loc[k];
+  }
+  unpack_se3(acc, A, b);
+  residual[0] = (float)acc[27];
+  residual[1] = (float)acc[28];
+}
+
+/* RGBResidual::getProducts, reduce.cu:767-843.  corres: orc_dataterm[rows*cols] */
+void orc_computeRgbResidual(float minScale, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                            const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, orc_dataterm* corres,
+                            float maxDepthDelta, const float* kt, const float* krkinv, int rows, int cols, int* sigmaSum,
+                            int* count) {
+  long long cnt = 0, sig = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cnt, sig)
+  for (int i = 0; i < rows; ++i)
+    for (int j0 = 0; j0 < cols; ++j0) {
+      orc_dataterm c;
+      memset(&c, 0, sizeof(c));
+      const size_t k = (size_t)i * cols + j0;
+      if (j0 < cols - 5 && i < rows - 1) {
+        int valid = 1;
+        for (int u = imax(i - 2, 0); u < imin(i + 2, rows); u++)
+          for (int v = imax(j0 - 2, 0); v < imin(j0 + 2, cols); v++) valid = valid && (nextImage[(size_t)u * cols + v] > 0);
+        if (valid) {
+          const short valx = dIdx[k], valy = dIdy[k];
+          const float mTwo = (valx * valx) + (valy * valy);
+          if (mTwo >= minScale) {
+            const int y = i, x = j0;
+            const float d1 = nextDepth[k];
+            if (!isnan(d1)) {
+              const float transformed_d1 = (float)(d1 * (krkinv[6] * x + krkinv[7] * y + krkinv[8]) + kt[2]);
+              const int u0 = f2i_rn((d1 * (krkinv[0] * x + krkinv[1] * y + krkinv[2]) + kt[0]) / transformed_d1);
+              const int v0 = f2i_rn((d1 * (krkinv[3] * x + krkinv[4] * y + krkinv[5]) + kt[1]) / transformed_d1);
+              if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                const float d0 = lastDepth[(size_t)v0 * cols + u0];
+                if (d0 > 0 && fabsf(transformed_d1 - d0) <= maxDepthDelta && lastImage[(size_t)v0 * cols + u0] != 0) {
+                  c.zero_x = (short)u0;
+                  c.zero_y = (short)v0;
+                  c.one_x = (short)x;
+                  c.one_y = (short)y;
+                  c.diff = (float)nextImage[k] - (float)lastImage[(size_t)v0 * cols + u0];
+                  c.valid = 1;
+                  cnt += 1;
+                  sig += f2i_rz(c.diff * c.diff);
+                }
+              }
+            }
+          }
+        }
+      }
+      corres[k] = c;
+    }
+  *count = (int)cnt;
+  *sigmaSum = (int)sig;
+}
+
+/* RGBReduction::getProducts, reduce.cu:561-620 */
+void orc_rgb_row(const orc_dataterm* c, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx,
+                 const int16_t* dIdy, float sobelScale, int cols, float* row) {
+  for (int i = 0; i < 7; ++i) row[i] = 0.f;
+  if (!c->valid) return;
+  float w = sigma + fabsf(c->diff);
+  w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
+  if (sigma == -1) w = 1;
+  row[6] = -w * c->diff;
+  const float* cp = cloud3 + 3 * ((size_t)c->zero_y * cols + c->zero_x);
+  const float invz = 1.0 / cp[2];
+  const size_t k1 = (size_t)c->one_y * cols + c->one_x;
+  const float dI_dx_val = w * sobelScale * dIdx[k1];
+  const float dI_dy_val = w * sobelScale * dIdy[k1];
+  const float v0 = dI_dx_val * fx * invz;
+  const float v1 = dI_dy_val * fy * invz;
+  const float v2 = -(v0 * cp[0] + v1 * cp[1]) * invz;
+  row[0] = v0;
+  row[1] = v1;
+  row[2] = v2;
+  row[3] = -cp[2] * v1 + cp[1] * v2;
+  row[4] = cp[2] * v0 - cp[0] * v2;
+  row[5] = -cp[1] * v0 + cp[0] * v1;
+}
+
+/* rgbStep, reduce.cu:643-685 */
+void orc_rgbStep(const orc_dataterm* corres, float sigma, const float* cloud3, float fx, float fy, const int16_t* dIdx,
+                 const int16_t* dIdy, float sobelScale, int rows, int cols, float* A, float* b) {
+  double acc[29];
+  memset(acc, 0, sizeof(acc));
+#pragma omp parallel
+  {
+    double loc[29];
+    memset(loc, 0, sizeof(loc));
+#pragma omp for schedule(static) nowait
+    for (int y = 0; y < rows; ++y)
+      for (int x = 0; x < cols; ++x) {
+        float row[7];
+        const orc_dataterm* c = corres + (size_t)y * cols + x;
+        orc_rgb_row(c, sigma, cloud3, fx, fy, dIdx, dIdy, sobelScale, cols, row);
+        acc_se3(loc, row, c->valid);
+      }
+#pragma omp critical
+    for (int k = 0; k < 29; ++k) acc[k] += loc[k];
+  }
+  unpack_se3(acc, A, b);
+}
+
+/* SO3Reduction, reduce.cu:927-1052 */
+static void so3_gradient(const uint8_t* img, int cols, int x, int y, float* gx, float* gy) { /* :942-957 */
+  const float actu = (float)img[(size_t)y * cols + x];
+  float back = (float)img[(size_t)y * cols + x - 1];
+  float fore = (float)img[(size_t)y * cols + x + 1];
+  *gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+  back = (float)img[(size_t)(y - 1) * cols + x];
+  fore = (float)img[(size_t)(y + 1) * cols + x];
+  *gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+}
+
+int orc_so3_row(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis, const float* kinv, const float* krlr,
+                int rows, int cols, int x, int y, float* row) {
+  row[0] = row[1] = row[2] = row[3] = 0.f;
+  const v3 unwarped = V3((float)x, (float)y, 1.0f);
+  const v3 warped = mmul(imageBasis, unwarped);
+  const int wx = f2i_rn(warped.x / warped.z), wy = f2i_rn(warped.y / warped.z);
+  if (!(wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1)) return 0;
+  float gnx, gny, glx, gly;
+  so3_gradient(nextImage, cols, wx, wy, &gnx, &gny);
+  so3_gradient(lastImage, cols, x, y, &glx, &gly);
+  const float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+  const v3 point = mmul(kinv, unwarped);
+  const float z2 = point.z * point.z;
+  const float a = krlr[0], b = krlr[1], c = krlr[2], d = krlr[3], e = krlr[4], f = krlr[5], g = krlr[6], h = krlr[7], i = krlr[8];
+  const v3 left = V3(((point.z * (d * gy + a * gx)) - (gy * g * y) - (gx * g * x)) / z2,
+                     ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
+                     ((point.z * (f * gy + c * gx)) - (gy * i * y) - (gx * i * x)) / z2);
+  const v3 jac = vcross(left, point);
+  row[0] = jac.x;
+  row[1] = jac.y;
+  row[2] = jac.z;
+  row[3] = -((float)nextImage[(size_t)wy * cols + wx] - (float)lastImage[(size_t)y * cols + x]);
+  return 1;
+}
+
+void orc_so3Step(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis, const float* kinv, const float* krlr,
+                 int rows, int cols, float* A, float* b, float* residual) {
+  double acc[11];
+  memset(acc, 0, sizeof(acc));
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      float row[4];
+      const int found = orc_so3_row(lastImage, nextImage, imageBasis, kinv, krlr, rows, cols, x, y, row);
+      int k = 0;
+      for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) acc[k++] += (double)(row[i] * row[j]);
+      acc[9] += (double)(row[3] * row[3]);
+      acc[10] += found ? 1.0 : 0.0;
+    }
+  int shift = 0; /* reduce.cu:1090-1102 */
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 4; ++j) {
+      const float value = (float)acc[shift++];
+      if (j == 3)
+        b[i] = value;
+      else
+        A[j * 3 + i] = A[i * 3 + j] = value;
+    }
+  residual[0] = (float)acc[9];
+  residual[1] = (float)acc[10];
+}

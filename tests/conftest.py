@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def gputest_pair():
+    """The reference's GPUTest RGB-D pair (elasticfusion/GPUTest/*.png), depth already /5 -> mm
+    as the harness does (GPUTest/src/GPUTest.cpp:51-57)."""
+    z = np.load(os.path.join(GOLDEN, "gputest_pair.npz"))
+    return {
+        "rgb1": z["rgb1"],
+        "rgb2": z["rgb2"],
+        "depth1_raw": z["depth1"],
+        "depth2_raw": z["depth2"],
+        "depth1": (z["depth1"] // 5).astype(np.uint16),
+        "depth2": (z["depth2"] // 5).astype(np.uint16),
+        "K": (528.0, 528.0, 320.0, 240.0),  # GPUTest.cpp:150-152
+    }
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as _orc
+
+    return _orc

@@ -1,0 +1,72 @@
+"""Shared test helpers (host-side numpy only)."""
+import numpy as np
+
+
+def gputest_model_maps(depth_raw, K):
+    """Model vertex / normal RGBA32F images from frame 1, built on the CPU the way the reference
+    harness does (GPUTest/src/GPUTest.cpp:69-129): forward differences, TUM depth / 5000, zero
+    where any 4-neighbour is missing, border rows/cols left zero."""
+    fx, fy, cx, cy = K
+    d = depth_raw.astype(np.float32) / np.float32(5000.0)
+    H, W = d.shape
+    rows, cols = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    ifx, ify = np.float32(1.0) / np.float32(fx), np.float32(1.0) / np.float32(fy)
+    vx = ((cols - np.float32(cx)) * d) * ifx
+    vy = ((rows - np.float32(cy)) * d) * ify
+    V = np.stack([vx, vy, d], axis=-1).astype(np.float32)
+    verts = np.zeros((H, W, 4), np.float32)
+    norms = np.zeros((H, W, 4), np.float32)
+    r = depth_raw
+    ok = np.zeros((H, W), bool)
+    ok[1:-1, 1:-1] = (r[1:-1, 1:-1] > 0) & (r[2:, 1:-1] > 0) & (r[1:-1, 2:] > 0) & (r[:-2, 1:-1] > 0) & (r[1:-1, :-2] > 0)
+    del_x = np.zeros_like(V)
+    del_y = np.zeros_like(V)
+    del_x[:, :-1] = V[:, 1:] - V[:, :-1]
+    del_y[:-1, :] = V[1:, :] - V[:-1, :]
+    n = np.cross(del_x, del_y).astype(np.float32)
+    nn = np.sqrt((n * n).sum(-1, keepdims=True))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = n / nn
+    # the harness carries the previous pixel's point/normal over invalid pixels? No: it resets
+    # both to (0,0,0,1) (GPUTest.cpp:106-110).
+    verts[..., :3] = np.where(ok[..., None], V, 0)
+    norms[..., :3] = np.where(ok[..., None], n, 0)
+    verts[1:-1, 1:-1, 3] = 1
+    norms[1:-1, 1:-1, 3] = 1
+    return verts, norms
+
+
+def rgba(rgb):
+    return np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+
+
+def rot_angle_deg(Ra, Rb):
+    R = np.asarray(Ra, np.float64).reshape(3, 3) @ np.asarray(Rb, np.float64).reshape(3, 3).T
+    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    return float(np.degrees(np.arccos(c)))
+
+
+def assert_pose_close(t_a, R_a, t_b, R_b, tol_m=1e-3, tol_deg=0.01, what=""):
+    """north_star tolerance: <= 1 mm and <= 0.01 degree per step."""
+    dt = float(np.linalg.norm(np.asarray(t_a, np.float64) - np.asarray(t_b, np.float64)))
+    da = rot_angle_deg(R_a, R_b)
+    assert dt <= tol_m, "%s translation differs by %.3e m (> %.1e)" % (what, dt, tol_m)
+    assert da <= tol_deg, "%s rotation differs by %.3e deg (> %.1e)" % (what, da, tol_deg)
+    return dt, da
+
+
+def nan_equal(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def planes_equal_where_valid(a, b):
+    """Stacked-plane maps: plane x must match including the NaN pattern; planes y/z only where
+    plane x is valid (invalid pixels keep stale data there)."""
+    a, b = np.asarray(a), np.asarray(b)
+    H = a.shape[0] // 3
+    ax, bx = a[:H], b[:H]
+    if not nan_equal(ax, bx):
+        return False
+    ok = ~np.isnan(ax)
+    return bool((a[H:2 * H][ok] == b[H:2 * H][ok]).all() and (a[2 * H:][ok] == b[2 * H:][ok]).all())

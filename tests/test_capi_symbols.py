@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads without a GPU and exports
+every entry point that include/*.h declares; argument validation works without device access."""
+import ctypes
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        names += re.findall(r"\b(dms_[a-zA-Z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from densemonoslam_amd import capi
+
+    names = declared_functions()
+    assert len(names) >= 40, names
+    missing = [n for n in names if not hasattr(capi.lib, n)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+
+
+def test_version_and_error_text_without_gpu():
+    from densemonoslam_amd import capi
+
+    assert b"gfx950" in capi.lib.dms_version()
+    assert capi.lib.dms_reduce_workspace_bytes() >= 29 * 1024 * 4
+    # argument validation happens before any device access
+    assert capi.lib.dms_createNMap(None, None, None) == -1
+    assert b"null" in capi.lib.dms_last_error()
+    n = ctypes.c_int(-1)
+    rc = capi.lib.dms_device_count(ctypes.byref(n))
+    assert rc in (0, -2)
+
+
+def test_struct_sizes_match_reference_types():
+    """JtJJtrSE3 = 29 floats, DataTerm = 16 bytes (Cuda/types.cuh:77-83,123-171)."""
+    from densemonoslam_amd import capi
+
+    assert capi.DATATERM_DTYPE.itemsize == 16
+    assert ctypes.sizeof(capi.Image2D) == 24
+    assert ctypes.sizeof(capi.Mat33) == 36
+    assert ctypes.sizeof(capi.Camera) == 16
