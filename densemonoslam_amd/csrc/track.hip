@@ -471,7 +471,8 @@ __device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
 __global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* __restrict__ part_icp,
                                                    const float* __restrict__ part_rgb, const int* __restrict__ part_cnt, int stride,
                                                    int nblocks, int icp, int rgb, int rgbOnly, float icpWeight, int level,
-                                                   int first_iter, int next_level, float fx, float fy, float cx, float cy) {
+                                                   int first_iter, int next_level, int level_below, float fx, float fy, float cx,
+                                                   float cy) {
   if (st->level_done[level]) return;
   __shared__ float s_icp[kSE3];
   __shared__ float s_rgb[kSE3];
@@ -487,7 +488,14 @@ __global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* 
   const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
   const bool brk = rgbOnly && rgbonly_break(sigma, rgbSize, lastErr);
   if (brk) {
-    if (threadIdx.x == 0) st->level_done[level] = 1;
+    // host `break` (RGBDOdometry.cpp:466-469): the level ends here; the next level that runs
+    // needs its own K in the projection parameters
+    if (threadIdx.x == 0) {
+      st->level_done[level] = 1;
+      double K[9];
+      level_K(fx, fy, cx, cy, level_below, K);
+      gn_params(st, K);
+    }
     return;
   }
   if (rgb) fold_rows<kSE3>(part_rgb, stride, nblocks, s_rgb);
@@ -646,17 +654,17 @@ struct Timer {
         e = o->event_pool.back();
         o->event_pool.pop_back();
       } else {
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
       }
       return e;
     };
     a = get();
     b = get();
-    hipEventRecord(a, s);
+    (void)hipEventRecord(a, s);
   }
   ~Timer() {
     if (!o->profiling) return;
-    hipEventRecord(b, s);
+    (void)hipEventRecord(b, s);
     o->pending.push_back({name, {a, b}});
   }
 };
@@ -725,13 +733,13 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
   }
   // pyramids start as zeros (the reference's cudaMallocPitch memory is uninitialised;
   // zero keeps the never-initialised-RGB case of GPUTest.cpp:247-286 deterministic)
-  hipMemset(o->arena, 0, o->arena_bytes);
+  (void)hipMemset(o->arena, 0, o->arena_bytes);
   Carver c;
   c.base = o->arena;
   layout(o, c);
   e = hipHostMalloc((void**)&o->host_state, sizeof(TrackState), hipHostMallocDefault);
   if (e != hipSuccess) {
-    hipFree(o->arena);
+    (void)hipFree(o->arena);
     delete o;
     return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
   }
@@ -743,9 +751,9 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
 int dms_odometry_destroy(dms_odometry* o) {
   if (!o) return DMS_OK;
   drain_timers(o);
-  for (auto e : o->event_pool) hipEventDestroy(e);
-  if (o->arena) hipFree(o->arena);
-  if (o->host_state) hipHostFree(o->host_state);
+  for (auto e : o->event_pool) (void)hipEventDestroy(e);
+  if (o->arena) (void)hipFree(o->arena);
+  if (o->host_state) (void)hipHostFree(o->host_state);
   delete o;
   return DMS_OK;
 }
@@ -949,15 +957,14 @@ int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* r
     a.rows = o->vmaps_curr[l].rows / 3;
     a.level = l;
     const int nb = reduce_blocks_for(a.cols * a.rows);
-    for (int j = 0; j < iterations[l]; ++j) {
-      int next_level = l;
-      if (j == iterations[l] - 1) {
-        for (int q = l - 1; q >= 0; --q)
-          if (iterations[q] > 0) {
-            next_level = q;
-            break;
-          }
+    int level_below = l;
+    for (int q = l - 1; q >= 0; --q)
+      if (iterations[q] > 0) {
+        level_below = q;
+        break;
       }
+    for (int j = 0; j < iterations[l]; ++j) {
+      const int next_level = (j == iterations[l] - 1) ? level_below : l;
       {
         Timer t(o, s, "gn_pass1");
         if (icp && rgb)
@@ -980,8 +987,8 @@ int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* r
       {
         Timer t(o, s, "gn_solve");
         hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks,
-                           nb, icp ? 1 : 0, rgb ? 1 : 0, rgbOnly ? 1 : 0, icpWeight, l, j == 0 ? 1 : 0, next_level, o->fx, o->fy,
-                           o->cx, o->cy);
+                           nb, icp ? 1 : 0, rgb ? 1 : 0, rgbOnly ? 1 : 0, icpWeight, l, j == 0 ? 1 : 0, next_level, level_below, o->fx,
+                           o->fy, o->cx, o->cy);
         DMS_CHECK_LAUNCH();
       }
     }

@@ -41,9 +41,12 @@ def rgba(rgb):
 
 
 def rot_angle_deg(Ra, Rb):
+    """Angle of Ra·Rbᵀ.  atan2 of (|skew part|, (trace-1)/2): well-conditioned at small angles
+    (arccos of the trace alone cannot resolve below ~0.03° on float32 matrices)."""
     R = np.asarray(Ra, np.float64).reshape(3, 3) @ np.asarray(Rb, np.float64).reshape(3, 3).T
-    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
-    return float(np.degrees(np.arccos(c)))
+    s = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    c = (np.trace(R) - 1.0) / 2.0
+    return float(np.degrees(np.arctan2(np.linalg.norm(s), c)))
 
 
 def assert_pose_close(t_a, R_a, t_b, R_b, tol_m=1e-3, tol_deg=0.01, what=""):
