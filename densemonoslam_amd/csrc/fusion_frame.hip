@@ -1,0 +1,590 @@
+// Object layer: one camera's frame step — the part of ElasticFusion::processFrame
+// (Core/src/ElasticFusion.cpp:99-637) that runs per frame with loop closure off (--o) and NID
+// keyframing off (--nkf) — plus the extern "C" wrappers of the fusion operators.
+//
+// MI355X design: the whole frame is enqueued on one HIP stream without a single host
+// synchronisation.  The camera pose never leaves HBM between tracking and fusion: the tracker
+// writes it into the context's pose block, a one-lane kernel derives the inverse and the
+// velocity weight (ElasticFusion.cpp:252-268), and every later kernel reads the block through a
+// pointer.  The fill-in decision (`denseEnough`, ElasticFusion.cpp:84-97,166-167), which the
+// reference takes on the host after a glReadPixels, is a device flag consumed by a select-copy.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "smallmath.hpp"
+#include "surfel.hpp"
+
+struct dms_odometry;
+
+namespace dms {
+// fusion_pre.hip
+int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
+int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
+int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
+            int pass_rgb, dms_predict_out* out, hipStream_t s);
+int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s);
+// fusion_map.hip
+int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
+                     int timeIdx, float maxDepth, hipStream_t s);
+int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
+              unsigned long long* zbuf, dms_indexmap_out* out, hipStream_t s);
+int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
+                  int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
+                  dms_image2d* depth_out, hipStream_t s);
+// fusion_fuse.hip
+int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
+               const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
+               const float* weighting_dev, hipStream_t s);
+int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
+                const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
+                int isFern, hipStream_t s);
+// track.hip
+int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
+                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s);
+int odometry_result_pose(dms_odometry* o, float* pose16_dev, hipStream_t s);
+int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA, const float* vB, const float* nB, const int* flag_dev,
+                              const float* pose16_dev, hipStream_t s);
+int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rgbaB, const int* flag_dev, int force_b, void* rgba_tmp,
+                              hipStream_t s);
+
+struct FrameState {
+  dms_pose_block cur;   // current pose + inverse
+  float lastPose[16];   // pose at the end of the previous frame (ElasticFusion.cpp:158)
+  float weighting;      // ElasticFusion.cpp:252-268
+  int fill_in;          // shouldFillIn (ElasticFusion.cpp:167)
+  unsigned surfels;
+  int pad;
+};
+
+// RGB8 (3 B/px, as the reference uploads, ElasticFusion.cpp:111) -> RGBA8 texture
+__global__ void k_rgb_to_rgba(const unsigned char* __restrict__ rgb, uchar4* __restrict__ rgba, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x)
+    rgba[i] = make_uchar4(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2], 255);
+}
+
+struct Pose16 {
+  float v[16];
+};
+
+// currPose = prior (host value) or keep the device pose; lastPose = pose before this frame
+__global__ void k_frame_begin(FrameState* st, Pose16 prior, int have_prior) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; ++i) st->lastPose[i] = st->cur.pose[i];
+  if (have_prior)
+    for (int i = 0; i < 16; ++i) st->cur.pose[i] = prior.v[i];
+  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
+}
+
+__global__ void k_pose_set(FrameState* st, Pose16 p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; ++i) st->cur.pose[i] = st->lastPose[i] = p.v[i];
+  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
+  st->weighting = 1.f;
+  st->fill_in = 0;
+}
+
+// after tracking: inverse of the new pose and the velocity weight (ElasticFusion.cpp:252-268).
+// rodrigues2 (ElasticFusion.cpp:941-985) re-orthonormalises diffRot with an SVD first; a product
+// of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
+__global__ void k_frame_after_track(FrameState* st, float weightMultiplier) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
+  float diff[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = st->cur.t_inv[i * 4 + 0] * st->lastPose[0 * 4 + j];
+      s += st->cur.t_inv[i * 4 + 1] * st->lastPose[1 * 4 + j];
+      s += st->cur.t_inv[i * 4 + 2] * st->lastPose[2 * 4 + j];
+      s += st->cur.t_inv[i * 4 + 3] * st->lastPose[3 * 4 + j];
+      diff[i * 4 + j] = s;
+    }
+  const float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
+  double rx = (double)diff[9] - (double)diff[6];
+  double ry = (double)diff[2] - (double)diff[8];
+  double rz = (double)diff[4] - (double)diff[1];
+  const double sn = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = ((double)(diff[0] + diff[5] + diff[10]) - 1) * 0.5;
+  c = c > 1. ? 1. : c < -1. ? -1. : c;
+  double theta = acos(c);
+  double rn;
+  if (sn < 1e-5) {
+    rn = c > 0 ? 0.0 : theta;  // |r| = theta in the c <= 0 branch (unit axis scaled by theta)
+  } else {
+    const double vth = (1 / (2 * sn)) * theta;
+    rx *= vth;
+    ry *= vth;
+    rz *= vth;
+    rn = sqrt(rx * rx + ry * ry + rz * rz);
+  }
+  float weighting = fmaxf(tn, (float)rn);
+  const float largest = 0.01f, minWeight = 0.5f;
+  if (weighting > largest) weighting = largest;
+  weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
+  st->weighting = weighting;
+}
+
+// denseEnough on the W/20 × H/20 nearest-neighbour subsample of the predicted image
+// (Resize::image + ElasticFusion::denseEnough, ElasticFusion.cpp:84-97,166-167)
+__global__ __launch_bounds__(256) void k_dense_enough(const uchar4* __restrict__ image, int cols, int rows, FrameState* st) {
+  const int dw = cols / 20, dh = rows / 20;
+  int sum = 0;
+  for (int k = threadIdx.x; k < dw * dh; k += blockDim.x) {
+    const int i = k % dw, j = k / dw;
+    const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
+    const int sx = texel(u, (float)cols, cols), sy = texel(v, (float)rows, rows);
+    const uchar4 c = image[(size_t)sy * cols + sx];
+    sum += (c.x > 0 && c.y > 0 && c.z > 0) ? 1 : 0;
+  }
+  __shared__ int s_sum[4];
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    const bool dense = (float)tot / (float)(dh * dw) > 0.95f;
+    st->fill_in = dense ? 0 : 1;
+  }
+}
+
+__global__ void k_frame_end(FrameState* st, const unsigned* __restrict__ d_count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->surfels = d_count[0];
+}
+
+struct FKernelTime {
+  double ms = 0;
+  int launches = 0;
+};
+
+}  // namespace dms
+
+using namespace dms;
+
+struct dms_fusion {
+  dms_fusion_params p;
+  dms_camera cam;
+  dms_model* model = nullptr;
+  dms_odometry* odom = nullptr;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  // images
+  dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
+  dms_indexmap_out imap;
+  dms_predict_out pred, fill;
+  void* rgba_tmp = nullptr;
+  unsigned long long* zbuf = nullptr;
+  FrameState* state = nullptr;
+  FrameState* h_state = nullptr;  // pinned
+  void* h_track = nullptr;
+  int tick = 1;
+  bool map_initialised = false;
+  int fused_last = 0;
+  bool profiling = false;
+  std::map<std::string, FKernelTime> times;
+  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Carve {
+  char* base = nullptr;
+  size_t off = 0;
+  void* take(size_t bytes) {
+    off = up256(off);
+    void* p = base ? base + off : nullptr;
+    off += bytes + 16;
+    return p;
+  }
+};
+
+dms_image2d mk_img(void* p, int rows, int cols, size_t elem) {
+  dms_image2d i;
+  i.data = p;
+  i.pitch = (size_t)cols * elem;
+  i.rows = rows;
+  i.cols = cols;
+  return i;
+}
+
+void layout(dms_fusion* f, Carve& c) {
+  const int W = f->p.width, H = f->p.height;
+  const size_t N = (size_t)W * H;
+  f->rgba = mk_img(c.take(N * 4), H, W, 4);
+  f->depth_raw = mk_img(c.take(N * 2), H, W, 2);
+  f->depth_filtered = mk_img(c.take(N * 2), H, W, 2);
+  f->depth_metric = mk_img(c.take(N * 4), H, W, 4);
+  f->depth_metric_filtered = mk_img(c.take(N * 4), H, W, 4);
+  f->imap.index = mk_img(c.take(N * 4), H, W, 4);
+  f->imap.vertConf = mk_img(c.take(N * 16), H, W, 16);
+  f->imap.colorTime = mk_img(c.take(N * 16), H, W, 16);
+  f->imap.normRad = mk_img(c.take(N * 16), H, W, 16);
+  f->pred.image = mk_img(c.take(N * 4), H, W, 4);
+  f->pred.vertex = mk_img(c.take(N * 16), H, W, 16);
+  f->pred.normal = mk_img(c.take(N * 16), H, W, 16);
+  f->pred.time = mk_img(c.take(N * 2), H, W, 2);
+  f->fill.image = mk_img(c.take(N * 4), H, W, 4);
+  f->fill.vertex = mk_img(c.take(N * 16), H, W, 16);
+  f->fill.normal = mk_img(c.take(N * 16), H, W, 16);
+  f->fill.time = f->pred.time;
+  f->rgba_tmp = c.take(N * 4);
+  f->zbuf = (unsigned long long*)c.take(N * 8);
+  f->state = (FrameState*)c.take(sizeof(FrameState));
+}
+
+struct FTimer {
+  dms_fusion* f;
+  hipStream_t s;
+  const char* name;
+  hipEvent_t a = nullptr, b = nullptr;
+  FTimer(dms_fusion* f_, hipStream_t s_, const char* n) : f(f_), s(s_), name(n) {
+    if (!f->profiling) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!f->pool.empty()) {
+        e = f->pool.back();
+        f->pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, s);
+  }
+  ~FTimer() {
+    if (!f->profiling) return;
+    (void)hipEventRecord(b, s);
+    f->pending.push_back({name, {a, b}});
+  }
+};
+
+void drain(dms_fusion* f) {
+  for (auto& p : f->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+      FKernelTime& t = f->times[p.first];
+      t.ms += ms;
+      t.launches += 1;
+    }
+    f->pool.push_back(p.second.first);
+    f->pool.push_back(p.second.second);
+  }
+  f->pending.clear();
+}
+
+// ElasticFusion::predict (ElasticFusion.cpp:688-746): ACTIVE splat + fill-in
+int predict(dms_fusion* f, float confidence, hipStream_t s) {
+  int rc;
+  {
+    FTimer t(f, s, "predict");
+    if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
+                            f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, s)))
+      return rc;
+  }
+  {
+    FTimer t(f, s, "fill_in");
+    if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, 0, f->p.frameToFrameRGB ? 1 : 0, &f->fill, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- operator-layer wrappers ----------------------------------------------------------------
+int dms_depth_bilateral(const dms_image2d* d, dms_image2d* o, float maxD, dms_stream s) { return depth_bilateral(d, o, maxD, (hipStream_t)s); }
+int dms_depth_metric(const dms_image2d* d, dms_image2d* o, float maxD, dms_stream s) { return depth_metric(d, o, maxD, (hipStream_t)s); }
+int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam,
+                         int time, int timeIdx, float maxDepth, dms_stream s) {
+  return model_initialise(m, rgba, dm, dmf, cam, time, timeIdx, maxDepth, (hipStream_t)s);
+}
+int dms_index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
+                  unsigned long long* zbuf, dms_indexmap_out* out, dms_stream s) {
+  return index_map(m, pose, cam, time, timeIdx, maxDepth, timeDelta, zbuf, out, (hipStream_t)s);
+}
+int dms_splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
+                      int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out, dms_stream s) {
+  DMS_REQUIRE(out, "null output");
+  return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, active, zbuf, out, nullptr, (hipStream_t)s);
+}
+int dms_splat_depth(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
+                    int timeIdx, int maxTime, int timeDelta, unsigned long long* zbuf, dms_image2d* depth, dms_stream s) {
+  DMS_REQUIRE(depth, "null output");
+  // synthesizeDepth never sets the `actv` uniform (IndexMap.cpp:370-452): it stays false
+  return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, 0, zbuf, nullptr, depth, (hipStream_t)s);
+}
+int dms_model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
+                   const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
+                   const float* weighting_dev, dms_stream s) {
+  return model_fuse(m, pose, time, timeIdx, rgba, dr, drf, im, cam, depthCutoff, weighting, weighting_dev, (hipStream_t)s);
+}
+int dms_model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im,
+                    const dms_image2d* depth_synth, const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes,
+                    int timeDelta, float maxDepth, int isFern, dms_stream s) {
+  return model_clean(m, pose, time, timeIdx, im, depth_synth, cam, confThreshold, graph_host, graph_nodes, timeDelta, maxDepth, isFern,
+                     (hipStream_t)s);
+}
+int dms_fill_in(const dms_predict_out* ex, const dms_image2d* d, const dms_image2d* rgba, const dms_camera* cam, int pg, int pr,
+                dms_predict_out* out, dms_stream s) {
+  return fill_in(ex, d, rgba, cam, pg, pr, out, (hipStream_t)s);
+}
+int dms_resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, dms_stream s) { return resize_nn(src, dst, elem, (hipStream_t)s); }
+
+// ---- frame object ---------------------------------------------------------------------------
+void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->width = width;
+  p->height = height;
+  p->fx = fx;
+  p->fy = fy;
+  p->cx = cx;
+  p->cy = cy;
+  p->timeDelta = 200;       // Options.h:90
+  p->confidence = 10.0f;    // Options.h:93
+  p->depthCut = 3.0f;       // Options.h:93
+  p->icpWeight = 10.0f;     // Options.h:93
+  p->fastOdom = 0;
+  p->so3 = 1;
+  p->frameToFrameRGB = 0;
+  p->pyramid = 1;           // ElasticFusion.cpp:59
+  p->hybrid_tracking = 1;
+  p->rgbOnly = 0;
+  p->timeIdx = 0;
+  p->maxDepthProcessed = 25.0f;  // ElasticFusion.cpp:56
+  p->model_capacity = 0;
+}
+
+int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
+  DMS_REQUIRE(out && p, "null argument");
+  DMS_REQUIRE(p->width >= 40 && p->height >= 40, "resolution too small");
+  DMS_REQUIRE(p->timeIdx >= 0 && p->timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  dms_fusion* f = new dms_fusion();
+  f->p = *p;
+  f->cam.fx = p->fx;
+  f->cam.fy = p->fy;
+  f->cam.cx = p->cx;
+  f->cam.cy = p->cy;
+  int rc = dms_model_create(&f->model, p->model_capacity, p->width, p->height);
+  if (rc) {
+    delete f;
+    return rc;
+  }
+  rc = dms_odometry_create(&f->odom, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
+  if (rc) {
+    dms_model_destroy(f->model);
+    delete f;
+    return rc;
+  }
+  Carve sz;
+  layout(f, sz);
+  f->arena_bytes = up256(sz.off);
+  hipError_t e = hipMalloc((void**)&f->arena, f->arena_bytes);
+  if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, sizeof(FrameState), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (f->arena) (void)hipFree(f->arena);
+    dms_odometry_destroy(f->odom);
+    dms_model_destroy(f->model);
+    delete f;
+    return hip_fail(e, "dms_fusion_create allocation", __FILE__, __LINE__);
+  }
+  Carve c;
+  c.base = f->arena;
+  layout(f, c);
+  Pose16 I;
+  for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
+  hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, 0, f->state, I);
+  (void)hipDeviceSynchronize();
+  memset(f->h_state, 0, sizeof(FrameState));
+  *out = f;
+  return DMS_OK;
+}
+
+int dms_fusion_destroy(dms_fusion* f) {
+  if (!f) return DMS_OK;
+  drain(f);
+  for (auto e : f->pool) (void)hipEventDestroy(e);
+  if (f->arena) (void)hipFree(f->arena);
+  if (f->h_state) (void)hipHostFree(f->h_state);
+  dms_odometry_destroy(f->odom);
+  dms_model_destroy(f->model);
+  delete f;
+  return DMS_OK;
+}
+
+dms_model* dms_fusion_model(dms_fusion* f) { return f ? f->model : nullptr; }
+dms_odometry* dms_fusion_odometry(dms_fusion* f) { return f ? f->odom : nullptr; }
+
+int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev, const float* inPose16,
+                             float weightMultiplier, dms_stream st) {
+  DMS_REQUIRE(f && rgb_dev && depth_dev, "null argument");
+  DMS_REQUIRE(rgb_channels == 3 || rgb_channels == 4, "rgb_channels must be 3 or 4");
+  hipStream_t s = (hipStream_t)st;
+  const int W = f->p.width, H = f->p.height, N = W * H;
+  int rc;
+
+  // "upload": the frame is already in HBM; bring it into the context's textures (ElasticFusion.cpp:111-114)
+  {
+    FTimer t(f, s, "ingest");
+    if (rgb_channels == 3)
+      hipLaunchKernelGGL(k_rgb_to_rgba, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, s, (const unsigned char*)rgb_dev,
+                         (uchar4*)f->rgba.data, N);
+    else
+      DMS_HIP(hipMemcpyAsync(f->rgba.data, rgb_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    DMS_CHECK_LAUNCH();
+    DMS_HIP(hipMemcpyAsync(f->depth_raw.data, depth_dev, (size_t)N * 2, hipMemcpyDeviceToDevice, s));
+  }
+  {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
+    FTimer t(f, s, "preprocess");
+    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, s))) return rc;
+    if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, s))) return rc;
+    if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, s))) return rc;
+  }
+
+  Pose16 prior;
+  memset(&prior, 0, sizeof(prior));
+  if (inPose16) memcpy(prior.v, inPose16, sizeof(prior.v));
+
+  int fused = 0;
+  if (!f->map_initialised) {
+    // first run (ElasticFusion.cpp:132-152): surfels from this frame, pose = inPose or identity
+    if (!inPose16)
+      for (int i = 0; i < 16; ++i) prior.v[i] = (i % 5 == 0) ? 1.f : 0.f;
+    hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, s, f->state, prior);
+    DMS_CHECK_LAUNCH();
+    {
+      FTimer t(f, s, "initialise");
+      // computeFeedbackBuffers takes `const int& maxDepthProcessed` (Context.h:211): 25.0f -> 25
+      if ((rc = model_initialise(f->model, &f->rgba, &f->depth_metric, &f->depth_metric_filtered, &f->cam, f->tick, f->p.timeIdx,
+                                 (float)(int)f->p.maxDepthProcessed, s)))
+        return rc;
+    }
+    if ((rc = dms_odometry_initFirstRGB(f->odom, &f->rgba, s))) return rc;
+    f->map_initialised = true;
+    fused = 1;
+  } else {
+    hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, f->state, prior, inPose16 ? 1 : 0);
+    DMS_CHECK_LAUNCH();
+    if ((rc = predict(f, 0.7f, s))) return rc;  // ElasticFusion.cpp:165
+    hipLaunchKernelGGL(k_dense_enough, dim3(1), dim3(256), 0, s, (const uchar4*)f->pred.image.data, W, H, f->state);
+    DMS_CHECK_LAUNCH();
+    if (f->p.hybrid_tracking) {
+      {
+        FTimer t(f, s, "odom_init");
+        // WARNING (reference): initICP* must be called before initRGB* (ElasticFusion.cpp:172)
+        if ((rc = odometry_initICPModel_sel(f->odom, (const float*)f->pred.vertex.data, (const float*)f->pred.normal.data,
+                                            (const float*)f->fill.vertex.data, (const float*)f->fill.normal.data, &f->state->fill_in,
+                                            f->state->cur.pose, s)))
+          return rc;
+        if ((rc = odometry_initRGBModel_sel(f->odom, f->pred.image.data, f->fill.image.data, &f->state->fill_in,
+                                            f->p.frameToFrameRGB ? 1 : 0, f->rgba_tmp, s)))
+          return rc;
+        if ((rc = dms_odometry_initICP_depth(f->odom, &f->depth_filtered, f->p.maxDepthProcessed, s))) return rc;
+        if ((rc = dms_odometry_initRGB(f->odom, &f->rgba, s))) return rc;
+      }
+      {
+        FTimer t(f, s, "track");
+        if ((rc = odometry_track_enqueue(f->odom, nullptr, nullptr, f->state->cur.pose, f->p.rgbOnly, f->p.icpWeight, f->p.pyramid,
+                                         f->p.fastOdom, f->p.so3, 0, s)))
+          return rc;
+        if ((rc = odometry_result_pose(f->odom, f->state->cur.pose, s))) return rc;
+      }
+    }
+    hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
+    DMS_CHECK_LAUNCH();
+    if ((rc = predict(f, f->p.confidence, s))) return rc;  // ElasticFusion.cpp:273
+
+    if (!f->p.rgbOnly) {  // fusion (ElasticFusion.cpp:506-564); NID gate off, tracking never "lost" without --rl
+      {
+        FTimer t(f, s, "index_map");
+        if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
+                            &f->imap, s)))
+          return rc;
+      }
+      {
+        FTimer t(f, s, "fuse");
+        if ((rc = model_fuse(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->rgba, &f->depth_metric, &f->depth_metric_filtered,
+                             &f->imap, &f->cam, f->p.maxDepthProcessed, 1.f, &f->state->weighting, s)))
+          return rc;
+      }
+      {
+        FTimer t(f, s, "index_map");
+        if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
+                            &f->imap, s)))
+          return rc;
+      }
+      {
+        FTimer t(f, s, "clean");
+        if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, nullptr, 0,
+                              f->p.timeDelta, f->p.maxDepthProcessed, 0, s)))
+          return rc;
+      }
+      fused = 1;
+    }
+  }
+  if ((rc = predict(f, f->p.confidence, s))) return rc;  // finalPredict (ElasticFusion.cpp:586)
+  hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, s, f->state, f->model->d_count);
+  DMS_CHECK_LAUNCH();
+  DMS_HIP(hipMemcpyAsync(f->h_state, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+  f->fused_last = fused;
+  f->tick += 1;  // if(!lost) tick++ (ElasticFusion.cpp:588-591)
+  return DMS_OK;
+}
+
+int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
+  DMS_REQUIRE(f && r, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  memset(r, 0, sizeof(*r));
+  int rc = DMS_OK;
+  if (f->p.hybrid_tracking && f->tick > 2) {
+    rc = dms_odometry_fetch_result(f->odom, &r->track, s);  // syncs
+    if (rc) return rc;
+  } else {
+    DMS_HIP(hipStreamSynchronize(s));
+  }
+  drain(f);
+  memcpy(r->pose, f->h_state->cur.pose, sizeof(r->pose));
+  r->surfels = f->h_state->surfels;
+  f->model->count_upper = r->surfels;
+  r->tick = f->tick;
+  r->fused = f->fused_last;
+  r->fill_in = f->h_state->fill_in;
+  r->weighting = f->h_state->weighting;
+  return DMS_OK;
+}
+
+int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {
+  DMS_REQUIRE(f && view, "null argument");
+  const dms_image2d* t[] = {&f->rgba,          &f->depth_raw,   &f->depth_filtered, &f->depth_metric, &f->depth_metric_filtered,
+                            &f->imap.index,    &f->imap.vertConf, &f->imap.colorTime, &f->imap.normRad, &f->pred.image,
+                            &f->pred.vertex,   &f->pred.normal, &f->pred.time,      &f->fill.image,   &f->fill.vertex,
+                            &f->fill.normal};
+  DMS_REQUIRE(which >= 0 && which < 16, "bad image id");
+  *view = *t[which];
+  return DMS_OK;
+}
+
+int dms_fusion_set_profiling(dms_fusion* f, int enabled) {
+  DMS_REQUIRE(f, "null argument");
+  f->profiling = enabled != 0;
+  if (enabled) f->times.clear();
+  return DMS_OK;
+}
+
+int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches) {
+  DMS_REQUIRE(f && name && total_ms && launches, "null argument");
+  auto it = f->times.find(name);
+  *total_ms = it == f->times.end() ? 0.0 : it->second.ms;
+  *launches = it == f->times.end() ? 0 : it->second.launches;
+  return DMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,576 @@
+// Fusion of a frame into the surfel map (G7 data.*, G8 update.vert) and map maintenance
+// (G9 copy_unstable.*).
+//
+// MI355X design.  The reference runs data.vert over all W·H pixels, scatters the measurements
+// into three 5700² RGBA32F textures addressed by surfel id, then streams the *whole* map through
+// update.vert (120 B/surfel) to pick them up.  Here:
+//   k_fuse_associate  one thread per candidate pixel (¼ of the image: the parity gate of
+//                     data.vert:112): measurement + 4×4-tap association; the measurement is
+//                     parked in its column-major slot and competes for its surfel with
+//                     atomicMin(winner[id], slot) — "first in draw order wins" of the
+//                     depth-tested scatter;
+//   k_fuse_update     one thread per candidate slot: the winning measurement is averaged into
+//                     its surfel in place (update.vert:59-96).  O(pixels), not O(map).
+//   k_fuse_emit       stable compaction of the slots into the new-unstable list (data.geom
+//                     emits both merged and new measurements, in draw order).
+// clean = flags → block scan → scatter over [map surfels ‖ new-unstable list], preserving
+// order (transform-feedback semantics), with the window tests of copy_unstable.vert.
+#include "scan.hpp"
+#include "smallmath.hpp"
+#include "surfel.hpp"
+
+namespace dms {
+
+// ---------------------------------------------------------------------------------------
+// G7: association (data.vert:76-192)
+// ---------------------------------------------------------------------------------------
+struct FuseArgs {
+  const dms_pose_block* pose;
+  const uchar4* rgba;
+  const float* dr;   // DEPTH_METRIC
+  const float* drf;  // DEPTH_METRIC_FILTERED
+  const unsigned* index;
+  const float4* vertConf;
+  const float4* normRad;
+  int cols, rows, slot_h;
+  float cx, cy, icx, icy;  // cam = (cx, cy, 1/fx, 1/fy) with the reciprocals taken in double (GlobalModel.cpp:546-550)
+  float maxDepth, timef, weighting;
+  const float* weighting_dev;
+  int time, timeIdx;
+};
+
+__device__ __forceinline__ f3 dv_vertex(const float* depth, int cols, int sx, int sy, float x, float y, float cx, float cy, float icx,
+                                        float icy) {  // geometry.glsl:21-25
+  const float z = depth[(size_t)sy * cols + sx];
+  return mk3(((x - cx) * z) * icx, ((y - cy) * z) * icy, z);
+}
+
+__device__ __forceinline__ f3 dv_normal(const float* depth, int cols, int rows, const f3& vPosition, float tx, float ty, float x, float y,
+                                        float cx, float cy, float icx, float icy) {  // geometry.glsl:27-39
+  const float colsf = (float)cols, rowsf = (float)rows;
+  const int sx = texel(tx, colsf, cols), sy = texel(ty, rowsf, rows);
+  const int sxf = texel(tx + (1.0f / colsf), colsf, cols), sxb = texel(tx - (1.0f / colsf), colsf, cols);
+  const int syf = texel(ty + (1.0f / rowsf), rowsf, rows), syb = texel(ty - (1.0f / rowsf), rowsf, rows);
+  const f3 xf = dv_vertex(depth, cols, sxf, sy, x + 1.f, y, cx, cy, icx, icy);
+  const f3 xb = dv_vertex(depth, cols, sxb, sy, x - 1.f, y, cx, cy, icx, icy);
+  const f3 yf = dv_vertex(depth, cols, sx, syf, x, y + 1.f, cx, cy, icx, icy);
+  const f3 yb = dv_vertex(depth, cols, sx, syb, x, y - 1.f, cx, cy, icx, icy);
+  const f3 del_x = mk3(((xb.x + vPosition.x) / 2.f) - ((xf.x + vPosition.x) / 2.f), ((xb.y + vPosition.y) / 2.f) - ((xf.y + vPosition.y) / 2.f),
+                       ((xb.z + vPosition.z) / 2.f) - ((xf.z + vPosition.z) / 2.f));
+  const f3 del_y = mk3(((yb.x + vPosition.x) / 2.f) - ((yf.x + vPosition.x) / 2.f), ((yb.y + vPosition.y) / 2.f) - ((yf.y + vPosition.y) / 2.f),
+                       ((yb.z + vPosition.z) / 2.f) - ((yf.z + vPosition.z) / 2.f));
+  return normalized3(cross3(del_x, del_y));
+}
+
+__device__ __forceinline__ float angle_between(const f3& a, const f3& b) {  // data.vert:66-69
+  return det_acosf(dot3(a, b) / (length3(a) * length3(b)));
+}
+
+__global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __restrict__ slot_pos, float4* __restrict__ slot_col,
+                                                        float4* __restrict__ slot_nrm, unsigned* __restrict__ slot_best,
+                                                        unsigned char* __restrict__ slot_flag, unsigned* __restrict__ winner, int slot_w) {
+  // candidate (i, j) -> pixel (2i + p, 2j + p), p = time % 2; slot = i * slot_h + j (column-major)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // along rows (fast in slot order)
+  const int i = blockIdx.y;
+  if (i >= slot_w || j >= a.slot_h) return;
+  const int slot = i * a.slot_h + j;
+  const int par = ((a.time % 2) + 2) % 2;
+  const int px = 2 * i + par, py = 2 * j + par;
+  unsigned char flag = 0;
+  if (px < a.cols && py < a.rows) {
+    const float colsf = (float)a.cols, rowsf = (float)a.rows;
+    const float tx = uv_coord(px, a.cols), ty = uv_coord(py, a.rows);
+    const float x = tx * colsf, y = ty * rowsf;
+    const int sx = texel(tx, colsf, a.cols), sy = texel(ty, rowsf, a.rows);
+    const f3 vPosLocal = dv_vertex(a.dr, a.cols, sx, sy, x, y, a.cx, a.cy, a.icx, a.icy);
+    // data.vert:112-114 gate (int(x)%2 == int(time)%2 etc. holds by construction of (px, py))
+    bool ok = ((int)x % 2 == (int)a.timef % 2) && ((int)y % 2 == (int)a.timef % 2);
+    if (ok) {  // checkNeighbours on the raw metric depth (data.vert:45-64)
+      const int sxb = texel(tx - (1.0f / colsf), colsf, a.cols), sxf = texel(tx + (1.0f / colsf), colsf, a.cols);
+      const int syb = texel(ty - (1.0f / rowsf), rowsf, a.rows), syf = texel(ty + (1.0f / rowsf), rowsf, a.rows);
+      ok = !(a.dr[(size_t)sy * a.cols + sxb] == 0.f) && !(a.dr[(size_t)syb * a.cols + sx] == 0.f) &&
+           !(a.dr[(size_t)sy * a.cols + sxf] == 0.f) && !(a.dr[(size_t)syf * a.cols + sx] == 0.f);
+    }
+    ok = ok && vPosLocal.z > 0.f && vPosLocal.z <= a.maxDepth;
+    if (ok) {
+      const float* P = a.pose->pose;
+      const f3 vPos = xform_point(P, vPosLocal);
+      const f3 vPos_f = dv_vertex(a.drf, a.cols, sx, sy, x, y, a.cx, a.cy, a.icx, a.icy);
+      const uchar4 c = a.rgba[(size_t)sy * a.cols + sx];
+      const f3 vNormLocal = dv_normal(a.drf, a.cols, a.rows, vPos_f, tx, ty, x, y, a.cx, a.cy, a.icx, a.icy);
+      const f3 nG = xform_dir(P, vNormLocal);
+      const float rad = surfel_radius(vPos_f.z, vNormLocal.z, a.icx, a.icy);
+      const float weighting = a.weighting_dev ? *a.weighting_dev : a.weighting;
+      const float conf = surfel_confidence(x, y, a.cx, a.cy, weighting);
+
+      // 4×4-tap association window in the index map (data.vert:116-160)
+      int counter = 0;
+      unsigned best = 0u;
+      const float scale = 1.0f;  // IndexMap::FACTOR
+      const float indexXStep = (1.0f / (colsf * scale)) * 0.5f;
+      const float indexYStep = (1.0f / (rowsf * scale)) * 0.5f;
+      float bestDist = 1000.f;
+      const float windowMultiplier = 2.f;
+      const float xl = (x - a.cx) * a.icx;
+      const float yl = (y - a.cy) * a.icy;
+      const float lambda = sqrtf((xl * xl + yl * yl) + 1.f);
+      const f3 ray = mk3(xl, yl, 1.f);
+      const float ray_len = length3(ray);
+      const float x_lo = tx - ((scale * indexXStep) * windowMultiplier), x_hi = tx + ((scale * indexXStep) * windowMultiplier);
+      const float y_lo = ty - ((scale * indexYStep) * windowMultiplier), y_hi = ty + ((scale * indexYStep) * windowMultiplier);
+      for (float wi = x_lo; wi < x_hi; wi += indexXStep) {
+        const int ux = texel(wi, colsf, a.cols);
+        for (float wj = y_lo; wj < y_hi; wj += indexYStep) {
+          const int uy = texel(wj, rowsf, a.rows);
+          const size_t q = (size_t)uy * a.cols + ux;
+          const unsigned current = a.index[q];
+          if (current > 0u) {
+            const float4 vc = a.vertConf[q];
+            if (fabsf((vc.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
+              const float dist = length3(cross3(ray, mk3(vc.x, vc.y, vc.z))) / ray_len;
+              const float4 nr = a.normRad[q];
+              if (dist < bestDist && (fabsf(nr.z) < 0.75f || fabsf(angle_between(mk3(nr.x, nr.y, nr.z), vNormLocal)) < 0.5f)) {
+                counter++;
+                bestDist = dist;
+                best = current;
+              }
+            }
+          }
+        }
+      }
+      flag = counter > 0 ? 1 : 2;
+      slot_pos[slot] = make_float4(vPos.x, vPos.y, vPos.z, conf);
+      slot_col[slot] = make_float4(encode_color_bytes(c.x, c.y, c.z), 0.f, a.timef, flag == 1 ? -1.f : -2.f);
+      slot_nrm[slot] = make_float4(nG.x, nG.y, nG.z, rad);
+      slot_best[slot] = best;
+      if (flag == 1) atomicMin(winner + best, (unsigned)slot);
+    }
+  }
+  slot_flag[slot] = flag;
+}
+
+// ---------------------------------------------------------------------------------------
+// G8: update (update.vert:42-104), in place, by the winning measurement of each surfel
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fuse_update(int nslots, const float4* __restrict__ slot_pos, const float4* __restrict__ slot_col,
+                                                     const float4* __restrict__ slot_nrm, const unsigned* __restrict__ slot_best,
+                                                     const unsigned char* __restrict__ slot_flag, unsigned* __restrict__ winner,
+                                                     SurfelPlanes sp, size_t cap, int time, int timeIdx) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots || slot_flag[slot] != 1) return;
+  const unsigned id = slot_best[slot];
+  if (winner[id] != (unsigned)slot) return;
+  winner[id] = kEmptyWinner;  // re-arm for the next frame
+  const float4 newPos = slot_pos[slot], newColor = slot_col[slot], newNorm = slot_nrm[slot];
+  const float4 vPosition = sp.pos[id], vColor = sp.col[id], vNormRad = sp.nrm[id];
+  const float c_k = vPosition.w;
+  const float av = newPos.w;
+  if (newNorm.w < (1.0f + 0.5f) * vNormRad.w) {
+    const float wsum = c_k + av;
+    sp.pos[id] = make_float4(((c_k * vPosition.x) + (av * newPos.x)) / wsum, ((c_k * vPosition.y) + (av * newPos.y)) / wsum,
+                             ((c_k * vPosition.z) + (av * newPos.z)) / wsum, wsum);
+    const f3 oldCol = decode_color(vColor.x), newCol = decode_color(newColor.x);
+    const float ar = ((c_k * oldCol.x) + (av * newCol.x)) / wsum, ag = ((c_k * oldCol.y) + (av * newCol.y)) / wsum,
+                ab = ((c_k * oldCol.z) + (av * newCol.z)) / wsum;
+    sp.col[id] = make_float4(encode_color(ar, ag, ab), vColor.y, vColor.z, vColor.w);
+    f3 n = mk3(((c_k * vNormRad.x) + (av * newNorm.x)) / wsum, ((c_k * vNormRad.y) + (av * newNorm.y)) / wsum,
+               ((c_k * vNormRad.z) + (av * newNorm.z)) / wsum);
+    const float r = ((c_k * vNormRad.w) + (av * newNorm.w)) / wsum;
+    n = normalized3(n);
+    sp.nrm[id] = make_float4(n.x, n.y, n.z, r);
+  } else {
+    sp.pos[id] = make_float4(vPosition.x, vPosition.y, vPosition.z, c_k + av);
+  }
+  sp.times[(size_t)timeIdx * cap + id] = (float)time;
+}
+
+// ---------------------------------------------------------------------------------------
+// G9: clean (copy_unstable.vert:53-352) over elements [0, M) = map, [M, M + slots) = slots
+// ---------------------------------------------------------------------------------------
+struct CleanArgs {
+  const dms_pose_block* pose;
+  const unsigned* index;
+  const float4* vertConf;
+  const float4* colorTime;
+  const float* depth_synth;
+  int cols, rows;
+  float cx, cy, fx, fy;
+  float confThreshold, maxDepth;
+  int time, timeIdx, timeDelta, isFern;
+  int nodes;
+  const float* node_table;
+  int nslots;
+};
+
+struct CleanElem {
+  float4 pos, col, nrm;
+  float times[DMS_MAX_SENSORS];
+};
+
+// load element e (map surfel or parked measurement); false when the slot holds nothing
+__device__ __forceinline__ bool clean_load(unsigned e, unsigned M, const SurfelPlanes& sp, size_t cap, const float4* slot_pos,
+                                           const float4* slot_col, const float4* slot_nrm, const unsigned char* slot_flag, int nslots,
+                                           int timeIdx, CleanElem& o) {
+  if (e < M) {
+    o.pos = sp.pos[e];
+    o.col = sp.col[e];
+    o.nrm = sp.nrm[e];
+#pragma unroll
+    for (int s = 0; s < DMS_MAX_SENSORS; ++s) o.times[s] = sp.times[(size_t)s * cap + e];
+    return true;
+  }
+  const unsigned slot = e - M;
+  if ((int)slot >= nslots || slot_flag[slot] == 0) return false;
+  o.pos = slot_pos[slot];
+  o.col = slot_col[slot];
+  o.nrm = slot_nrm[slot];
+  // data.geom:50-54: -3 for every sensor but this one, which carries the -1 / -2 marker
+#pragma unroll
+  for (int s = 0; s < DMS_MAX_SENSORS; ++s) o.times[s] = (s == timeIdx) ? o.col.w : -3.f;
+  return true;
+}
+
+// the keep/drop decision of copy_unstable.vert:70-159 (before any deformation)
+__device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v) {
+  int test = 1;
+  const float* Tinv = a.pose->t_inv;
+  const f3 localPos = xform_point(Tinv, mk3(v.pos.x, v.pos.y, v.pos.z));
+  const float x = ((a.fx * localPos.x) / localPos.z) + a.cx;
+  const float y = ((a.fy * localPos.y) / localPos.z) + a.cy;
+  const f3 localNorm = normalized3(xform_dir(Tinv, mk3(v.nrm.x, v.nrm.y, v.nrm.z)));
+  const float colsf = (float)a.cols, rowsf = (float)a.rows;
+  const float scale = 1.0f;
+  const float indexXStep = (1.0f / (colsf * scale)) * 0.5f;
+  const float indexYStep = (1.0f / (rowsf * scale)) * 0.5f;
+  const float windowMultiplier = 2.f;
+  int count = 0, zCount = 0;
+  const float vt = v.times[a.timeIdx];
+  if ((float)a.time - vt < (float)a.timeDelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < colsf && y < rowsf) {
+    const float xc = x / colsf, yc = y / rowsf;
+    const float x_lo = xc - ((scale * indexXStep) * windowMultiplier), x_hi = xc + ((scale * indexXStep) * windowMultiplier);
+    const float y_lo = yc - ((scale * indexYStep) * windowMultiplier), y_hi = yc + ((scale * indexYStep) * windowMultiplier);
+    for (float wi = x_lo; wi < x_hi; wi += indexXStep) {
+      const int ux = texel(wi, colsf, a.cols);
+      for (float wj = y_lo; wj < y_hi; wj += indexYStep) {
+        const int uy = texel(wj, rowsf, a.rows);
+        const size_t q = (size_t)uy * a.cols + ux;
+        const unsigned current = a.index[q];
+        if (current > 0u) {
+          const float4 vc = a.vertConf[q];
+          const float4 ct = a.colorTime[q];
+          const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
+          if (ct.z < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
+              sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f)
+            count++;
+          if (ct.w == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
+              fabsf(localNorm.z) > 0.85f)
+            zCount++;
+        }
+      }
+    }
+  }
+  if (count > 8 || zCount > 4) test = 0;
+  // new unstable point: times become `time` before the health test (copy_unstable.vert:124-129)
+  float times[DMS_MAX_SENSORS];
+#pragma unroll
+  for (int s = 0; s < DMS_MAX_SENSORS; ++s) times[s] = v.times[s];
+  if (times[a.timeIdx] == -2.f) times[a.timeIdx] = (float)a.time;
+  // "unhealthy for every sensor".  The reference loops over its NUM_CAMERAS = 3 slots
+  // (size.glsl:2); slots beyond the reference's three are extra sensors of the 8-GPU node and
+  // follow the same rule.
+  int unHealthy = 0;
+#pragma unroll
+  for (int s = 0; s < DMS_MAX_SENSORS; ++s)
+    if (times[s] == -1.f || (((float)a.time - times[s]) > 20.f && v.pos.w < a.confThreshold)) unHealthy++;
+  if (unHealthy == DMS_MAX_SENSORS) test = 0;
+  if (times[a.timeIdx] > 0.f && (float)a.time - times[a.timeIdx] > (float)a.timeDelta) test = 1;
+  return test;
+}
+
+__global__ __launch_bounds__(256) void k_clean_flags(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
+                                                     const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
+                                                     const unsigned char* slot_flag, unsigned char* __restrict__ keep,
+                                                     unsigned* __restrict__ block_count) {
+  const unsigned M = d_count[0];
+  const unsigned total = M + (unsigned)a.nslots;
+  const unsigned base = blockIdx.x * kScanChunk;
+  unsigned cnt = 0;
+  if (base < total) {
+    for (int k = 0; k < kScanChunk / 256; ++k) {
+      const unsigned e = base + k * 256 + threadIdx.x;
+      unsigned char f = 0;
+      if (e < total) {
+        CleanElem v;
+        if (clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v)) f = (unsigned char)clean_test(a, v);
+        keep[e] = f;
+      }
+      cnt += f;
+    }
+  }
+  const unsigned tot = block_sum_u32(cnt);
+  if (threadIdx.x == 0) block_count[blockIdx.x] = tot;
+}
+
+// deformation-graph application (copy_unstable.vert:161-351)
+__device__ __forceinline__ f3 node_pos(const float* nt, int j) { return mk3(nt[j * 16 + 0], nt[j * 16 + 1], nt[j * 16 + 2]); }
+
+__device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
+  const float* nt = a.node_table;
+  const int nodes = a.nodes;
+  const int k = 4;
+  const int lookBack = 20;
+  int nearNodes[20];
+  float nearDists[20];
+  for (int i = 0; i < lookBack; i++) {
+    nearNodes[i] = -1;
+    nearDists[i] = 16777216.0f;
+  }
+  const int poseTime = (int)v.col.z;
+  int foundIndex = 0;
+  int imin = 0, imax = nodes - 1, imid = (imin + imax) / 2;
+  while (imax >= imin) {
+    imid = (imin + imax) / 2;
+    const int nodeTime = (int)nt[imid * 16 + 15];
+    if (nodeTime < poseTime)
+      imin = imid + 1;
+    else if (nodeTime > poseTime)
+      imax = imid - 1;
+    else
+      break;
+  }
+  imin = min(imin, nodes - 1);
+  // the node table is a 1-D NEAREST / CLAMP_TO_EDGE texture: texel (k*16+15) for k >= 0; imax = -1
+  // (pose older than every node) samples a negative coordinate, which clamps to texel 0
+  const int nodeMin = (int)nt[imin * 16 + 15];
+  const int nodeMid = (int)nt[imid * 16 + 15];
+  const int nodeMax = imax < 0 ? (int)nt[0] : (int)nt[imax * 16 + 15];
+  if (abs(nodeMin - poseTime) <= abs(nodeMid - poseTime) && abs(nodeMin - poseTime) <= abs(nodeMax - poseTime))
+    foundIndex = imin;
+  else if (abs(nodeMid - poseTime) <= abs(nodeMin - poseTime) && abs(nodeMid - poseTime) <= abs(nodeMax - poseTime))
+    foundIndex = imid;
+  else
+    foundIndex = imax;
+  if (foundIndex == nodes) foundIndex = nodes - 1;
+  if (foundIndex < 0) foundIndex = 0;
+  const f3 P = mk3(v.pos.x, v.pos.y, v.pos.z);
+  int nearNodeIndex = 0, distanceBack = 0;
+  for (int j = foundIndex; j >= 0; j--) {
+    const f3 d = P - node_pos(nt, j);
+    nearNodes[nearNodeIndex] = j;
+    nearDists[nearNodeIndex] = sqrtf(dot3(d, d));
+    nearNodeIndex++;
+    if (++distanceBack == lookBack / 2) break;
+  }
+  for (int j = foundIndex + 1; j < nodes; j++) {
+    const f3 d = P - node_pos(nt, j);
+    nearNodes[nearNodeIndex] = j;
+    nearDists[nearNodeIndex] = sqrtf(dot3(d, d));
+    nearNodeIndex++;
+    if (++distanceBack == lookBack) break;
+  }
+  for (int i = 0; i < lookBack - 1; ++i)
+    for (int j = i + 1; j < lookBack; ++j)
+      if (nearDists[j] < nearDists[i]) {
+        const float t = nearDists[i];
+        nearDists[i] = nearDists[j];
+        nearDists[j] = t;
+        const int t2 = nearNodes[i];
+        nearNodes[i] = nearNodes[j];
+        nearNodes[j] = t2;
+      }
+  const float dMax = nearDists[k];
+  float nodeWeights[4];
+  float weightSum = 0.f;
+  for (int j = 0; j < k; j++) {
+    const int nj = max(nearNodes[j], 0);
+    const f3 d = P - node_pos(nt, nj);
+    const float w1 = 1.0f - (sqrtf(dot3(d, d)) / dMax);
+    nodeWeights[j] = w1 * w1;  // pow(., 2)
+    weightSum += nodeWeights[j];
+  }
+  for (int j = 0; j < k; j++) nodeWeights[j] /= weightSum;
+  f3 newPos = mk3(0.f, 0.f, 0.f), newNorm = mk3(0.f, 0.f, 0.f);
+  const f3 N = mk3(v.nrm.x, v.nrm.y, v.nrm.z);
+  for (int i = 0; i < k; i++) {
+    const int ni = max(nearNodes[i], 0);
+    const float* q = nt + ni * 16;
+    const f3 g = mk3(q[0], q[1], q[2]);
+    // rotation stored column-major (Eigen, Deformation.cpp:192-201): columns (q3..5), (q6..8), (q9..11)
+    const float R[9] = {q[3], q[6], q[9], q[4], q[7], q[10], q[5], q[8], q[11]};  // row-major
+    const f3 tr = mk3(q[12], q[13], q[14]);
+    const f3 d = P - g;
+    const f3 Rd = mk3((R[0] * d.x + R[1] * d.y) + R[2] * d.z, (R[3] * d.x + R[4] * d.y) + R[5] * d.z, (R[6] * d.x + R[7] * d.y) + R[8] * d.z);
+    const f3 cand = (Rd + g) + tr;
+    newPos = newPos + mk3(nodeWeights[i] * cand.x, nodeWeights[i] * cand.y, nodeWeights[i] * cand.z);
+    float Ri[9], RiT[9];
+    sm::inv3<float>(R, Ri);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) RiT[r * 3 + c] = Ri[c * 3 + r];
+    const f3 nn = mk3((RiT[0] * N.x + RiT[1] * N.y) + RiT[2] * N.z, (RiT[3] * N.x + RiT[4] * N.y) + RiT[5] * N.z,
+                      (RiT[6] * N.x + RiT[7] * N.y) + RiT[8] * N.z);
+    newNorm = newNorm + mk3(nodeWeights[i] * nn.x, nodeWeights[i] * nn.y, nodeWeights[i] * nn.z);
+  }
+  v.pos.x = newPos.x;
+  v.pos.y = newPos.y;
+  v.pos.z = newPos.z;
+  const f3 nn = normalized3(newNorm);
+  v.nrm.x = nn.x;
+  v.nrm.y = nn.y;
+  v.nrm.z = nn.z;
+  if (v.pos.w > a.confThreshold && a.isFern == 0) {
+    const float* Tinv = a.pose->t_inv;
+    const f3 lp = xform_point(Tinv, mk3(v.pos.x, v.pos.y, v.pos.z));
+    const float x = ((a.fx * lp.x) / lp.z) + a.cx;
+    const float y = ((a.fy * lp.y) / lp.z) + a.cy;
+    const float colsf = (float)a.cols, rowsf = (float)a.rows;
+    if (lp.z > 0.f && lp.z < a.maxDepth && x > 0.f && y > 0.f && x < colsf && y < rowsf) {
+      const int ux = texel(x / colsf, colsf, a.cols), uy = texel(y / rowsf, rowsf, a.rows);
+      const float currentDepth = a.depth_synth ? a.depth_synth[(size_t)uy * a.cols + ux] : 0.f;
+      if (currentDepth > 0.0f && lp.z < currentDepth + 0.1f) {
+        v.col.w = (float)a.time;
+        v.times[a.timeIdx] = (float)a.time;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
+                                                       const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
+                                                       const unsigned char* slot_flag, const unsigned char* __restrict__ keep,
+                                                       const unsigned* __restrict__ block_offset, SurfelPlanes out) {
+  const unsigned M = d_count[0];
+  const unsigned total = M + (unsigned)a.nslots;
+  const unsigned base = blockIdx.x * kScanChunk;
+  if (base >= total) return;
+  unsigned running = block_offset[blockIdx.x];
+  for (int k = 0; k < kScanChunk / 256; ++k) {
+    const unsigned e = base + k * 256 + threadIdx.x;
+    const bool f = (e < total) && keep[e];
+    unsigned tot;
+    const unsigned rank = block_exclusive_rank(f, tot);
+    if (f) {
+      const size_t dst = (size_t)running + rank;
+      if (dst < cap) {
+        CleanElem v;
+        clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v);
+        if (v.times[a.timeIdx] == -2.f) {  // copy_unstable.vert:124-129
+          v.col.w = (float)a.time;
+          v.times[a.timeIdx] = (float)a.time;
+        }
+        if (a.nodes > 0 && v.col.z != (float)a.time) clean_deform(a, v);  // :161
+        out.pos[dst] = v.pos;
+        out.col[dst] = v.col;
+        out.nrm[dst] = v.nrm;
+#pragma unroll
+        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = v.times[s];
+      }
+    }
+    running += tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------
+static bool dense_img(const dms_image2d& im, size_t elem, int w, int h) {
+  return im.data && im.cols == w && im.rows == h && im.pitch == (size_t)w * elem;
+}
+
+int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
+               const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
+               const float* weighting_dev, hipStream_t s) {
+  DMS_REQUIRE(m && pose && rgba && dr && drf && im && cam, "null argument");
+  DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  const int W = m->width, H = m->height;
+  DMS_REQUIRE(dense_img(*rgba, 4, W, H) && dense_img(*dr, 4, W, H) && dense_img(*drf, 4, W, H) && dense_img(im->index, 4, W, H) &&
+                  dense_img(im->vertConf, 16, W, H) && dense_img(im->normRad, 16, W, H),
+              "dense W×H images required");
+  FuseArgs a;
+  a.pose = pose;
+  a.rgba = (const uchar4*)rgba->data;
+  a.dr = (const float*)dr->data;
+  a.drf = (const float*)drf->data;
+  a.index = (const unsigned*)im->index.data;
+  a.vertConf = (const float4*)im->vertConf.data;
+  a.normRad = (const float4*)im->normRad.data;
+  a.cols = W;
+  a.rows = H;
+  a.slot_h = m->slot_h;
+  a.cx = cam->cx;
+  a.cy = cam->cy;
+  a.icx = (float)(1.0 / (double)cam->fx);
+  a.icy = (float)(1.0 / (double)cam->fy);
+  a.maxDepth = depthCutoff;
+  a.timef = (float)time;
+  a.weighting = weighting;
+  a.weighting_dev = weighting_dev;
+  a.time = time;
+  a.timeIdx = timeIdx;
+  const int slot_w = (W + 1) / 2;
+  dim3 b(256), g((m->slot_h + 255) / 256, slot_w);
+  hipLaunchKernelGGL(k_fuse_associate, g, b, 0, s, a, m->slot_pos, m->slot_col, m->slot_nrm, m->slot_best, m->slot_flag, m->winner, slot_w);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_fuse_update, dim3((m->slots + 255) / 256), dim3(256), 0, s, m->slots, m->slot_pos, m->slot_col, m->slot_nrm,
+                     m->slot_best, m->slot_flag, m->winner, m->buf[m->cur], m->cap, time, timeIdx);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
+                const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
+                int isFern, hipStream_t s) {
+  DMS_REQUIRE(m && pose && im && cam, "null argument");
+  DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  const int W = m->width, H = m->height;
+  DMS_REQUIRE(dense_img(im->index, 4, W, H) && dense_img(im->vertConf, 16, W, H) && dense_img(im->colorTime, 16, W, H),
+              "dense W×H index-map images required");
+  if (graph_nodes >= m->max_nodes) {  // assert(graph.size() / 16 < MAX_NODES), GlobalModel.cpp:703
+    set_error("dms_model_clean: %d deformation nodes exceed the limit %d", graph_nodes, m->max_nodes);
+    return DMS_ERR_CAPACITY;
+  }
+  if (graph_nodes > 0) {
+    DMS_REQUIRE(graph_host, "null graph");
+    DMS_HIP(hipMemcpyAsync(m->nodes, graph_host, (size_t)graph_nodes * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  CleanArgs a;
+  a.pose = pose;
+  a.index = (const unsigned*)im->index.data;
+  a.vertConf = (const float4*)im->vertConf.data;
+  a.colorTime = (const float4*)im->colorTime.data;
+  a.depth_synth = (depth_synth && depth_synth->data) ? (const float*)depth_synth->data : nullptr;
+  a.cols = W;
+  a.rows = H;
+  a.cx = cam->cx;
+  a.cy = cam->cy;
+  a.fx = cam->fx;
+  a.fy = cam->fy;
+  a.confThreshold = confThreshold;
+  a.maxDepth = maxDepth;
+  a.time = time;
+  a.timeIdx = timeIdx;
+  a.timeDelta = timeDelta;
+  a.isFern = isFern;
+  a.nodes = graph_nodes;
+  a.node_table = m->nodes;
+  a.nslots = m->slots;
+  const size_t upper = m->count_upper + (size_t)m->slots;
+  const int nb = (int)((upper + kScanChunk - 1) / kScanChunk);
+  const SurfelPlanes src = m->buf[m->cur], dst = m->buf[m->cur ^ 1];
+  hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
+                     m->slot_flag, m->keep, m->block_count);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count + 2, (unsigned)m->cap);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_clean_scatter, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
+                     m->slot_flag, m->keep, m->block_offset, dst);
+  DMS_CHECK_LAUNCH();
+  // publish the new count only after the scatter has read the old one
+  DMS_HIP(hipMemcpyAsync(m->d_count, m->d_count + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, s));
+  // the parked measurements are consumed: a later clean without a fuse must not re-append them
+  DMS_HIP(hipMemsetAsync(m->slot_flag, 0, m->slots, s));
+  m->cur ^= 1;
+  m->count_upper = upper < m->cap ? upper : m->cap;
+  return DMS_OK;
+}
+
+}  // namespace dms

@@ -1,0 +1,650 @@
+// Surfel map: storage, bootstrap from the first frame (G3+G4), index map (G5), splat
+// prediction (G6, G6').
+//
+// The reference renders the map through OpenGL (one point per surfel, depth-tested MRT).
+// Here every "draw" is two HBM passes:
+//   pass 1 (one thread per surfel): cull, project, and fight for each covered pixel with a
+//          64-bit atomicMin on key = depth24 << 32 | surfel id — GL_LESS on a 24-bit depth
+//          buffer with first-drawn-wins ties is exactly "smallest key";
+//   pass 2 (one thread per pixel): decode the winner and recompute its attributes.
+// Pass 1 streams only the position/normal planes; the colour plane is touched for winners only.
+#include <vector>
+
+#include "scan.hpp"
+#include "smallmath.hpp"
+#include "surfel.hpp"
+
+namespace dms {
+
+// ---------------------------------------------------------------------------------------
+// storage
+// ---------------------------------------------------------------------------------------
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct ModelCarver {
+  char* base = nullptr;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = up256(off);
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+static void model_layout(dms_model* m, ModelCarver& c) {
+  for (int b = 0; b < 2; ++b) {
+    m->buf[b].pos = c.take<float4>(m->cap);
+    m->buf[b].col = c.take<float4>(m->cap);
+    m->buf[b].nrm = c.take<float4>(m->cap);
+    m->buf[b].times = c.take<float>(m->cap * DMS_MAX_SENSORS);
+  }
+  m->d_count = c.take<unsigned>(8);
+  m->slot_pos = c.take<float4>(m->slots);
+  m->slot_col = c.take<float4>(m->slots);
+  m->slot_nrm = c.take<float4>(m->slots);
+  m->slot_best = c.take<unsigned>(m->slots);
+  m->slot_flag = c.take<unsigned char>(m->slots);
+  m->winner = c.take<unsigned>(m->cap);
+  const size_t total = m->cap + (size_t)m->width * m->height;  // clean: cap + slots; bootstrap: W*H
+  m->keep = c.take<unsigned char>(total);
+  m->block_count = c.take<unsigned>(total / kScanChunk + 2);
+  m->block_offset = c.take<unsigned>(total / kScanChunk + 2);
+  m->nodes = c.take<float>((size_t)m->max_nodes * 16);
+}
+
+__global__ void k_fill_u32(unsigned* p, size_t n, unsigned v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)blockDim.x * gridDim.x) p[i] = v;
+}
+
+}  // namespace dms
+
+using namespace dms;
+
+extern "C" {
+
+int dms_model_create(dms_model** out, size_t capacity, int width, int height) {
+  DMS_REQUIRE(out && width >= 16 && height >= 16, "bad argument");
+  dms_model* m = new dms_model();
+  m->cap = capacity ? capacity : (size_t)5700 * 5700;  // GlobalModel::MAX_VERTICES
+  m->width = width;
+  m->height = height;
+  m->slot_h = (height + 1) / 2;
+  m->slots = ((width + 1) / 2) * m->slot_h;
+  ModelCarver sz;
+  model_layout(m, sz);
+  m->arena_bytes = up256(sz.off);
+  hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
+  if (e != hipSuccess) {
+    delete m;
+    return hip_fail(e, "hipMalloc(model)", __FILE__, __LINE__);
+  }
+  ModelCarver c;
+  c.base = m->arena;
+  model_layout(m, c);
+  e = hipHostMalloc((void**)&m->h_count, 8 * sizeof(unsigned), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipFree(m->arena);
+    delete m;
+    return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+  }
+  DMS_HIP(hipMemset(m->d_count, 0, 8 * sizeof(unsigned)));
+  hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, 0, m->winner, m->cap, kEmptyWinner);
+  DMS_CHECK_LAUNCH();
+  DMS_HIP(hipDeviceSynchronize());
+  m->count_upper = 0;
+  *out = m;
+  return DMS_OK;
+}
+
+int dms_model_destroy(dms_model* m) {
+  if (!m) return DMS_OK;
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->h_count) (void)hipHostFree(m->h_count);
+  delete m;
+  return DMS_OK;
+}
+
+size_t dms_model_capacity(dms_model* m) { return m ? m->cap : 0; }
+
+int dms_model_count(dms_model* m, unsigned int* count, dms_stream s) {
+  DMS_REQUIRE(m && count, "null argument");
+  DMS_HIP(hipMemcpyAsync(m->h_count, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)s));
+  DMS_HIP(hipStreamSynchronize((hipStream_t)s));
+  *count = m->h_count[0];
+  m->count_upper = *count;
+  return DMS_OK;
+}
+
+static int model_download_planes(dms_model* m, unsigned n, std::vector<float4>& pos, std::vector<float4>& col, std::vector<float4>& nrm,
+                                 std::vector<float>& times, hipStream_t s) {
+  const SurfelPlanes& b = m->buf[m->cur];
+  pos.resize(n);
+  col.resize(n);
+  nrm.resize(n);
+  times.resize((size_t)n * DMS_MAX_SENSORS);
+  if (n == 0) return DMS_OK;
+  DMS_HIP(hipMemcpyAsync(pos.data(), b.pos, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipMemcpyAsync(col.data(), b.col, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipMemcpyAsync(nrm.data(), b.nrm, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+  for (int k = 0; k < DMS_MAX_SENSORS; ++k)
+    DMS_HIP(hipMemcpyAsync(times.data() + (size_t)k * n, b.times + (size_t)k * m->cap, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  return DMS_OK;
+}
+
+static int model_download_any(dms_model* m, float* host, unsigned max_count, unsigned* count, int nsens, bool ref_layout,
+                              hipStream_t s) {
+  DMS_REQUIRE(m && host && count, "null argument");
+  unsigned n = 0;
+  int rc = dms_model_count(m, &n, s);
+  if (rc) return rc;
+  if (n > max_count) n = max_count;
+  std::vector<float4> pos, col, nrm;
+  std::vector<float> times;
+  if ((rc = model_download_planes(m, n, pos, col, nrm, times, s))) return rc;
+  const int stride = 12 + nsens;
+  for (unsigned i = 0; i < n; ++i) {
+    float* r = host + (size_t)i * stride;
+    r[0] = pos[i].x; r[1] = pos[i].y; r[2] = pos[i].z; r[3] = pos[i].w;
+    r[4] = col[i].x; r[5] = col[i].y; r[6] = col[i].z; r[7] = col[i].w;
+    if (ref_layout) {  // Shaders/Vertex.cpp:21-50: times sit between colour and normal
+      for (int k = 0; k < nsens; ++k) r[8 + k] = times[(size_t)k * n + i];
+      r[8 + nsens] = nrm[i].x; r[9 + nsens] = nrm[i].y; r[10 + nsens] = nrm[i].z; r[11 + nsens] = nrm[i].w;
+    } else {
+      r[8] = nrm[i].x; r[9] = nrm[i].y; r[10] = nrm[i].z; r[11] = nrm[i].w;
+      for (int k = 0; k < nsens; ++k) r[12 + k] = times[(size_t)k * n + i];
+    }
+  }
+  *count = n;
+  return DMS_OK;
+}
+
+static int model_upload_any(dms_model* m, const float* host, unsigned n, int nsens, bool ref_layout, hipStream_t s) {
+  DMS_REQUIRE(m && (host || n == 0), "null argument");
+  if (n > m->cap) {
+    set_error("dms_model_upload: %u surfels exceed capacity %zu", n, m->cap);
+    return DMS_ERR_CAPACITY;
+  }
+  std::vector<float4> pos(n), col(n), nrm(n);
+  std::vector<float> times((size_t)n * DMS_MAX_SENSORS, -3.0f);
+  const int stride = 12 + nsens;
+  for (unsigned i = 0; i < n; ++i) {
+    const float* r = host + (size_t)i * stride;
+    pos[i] = make_float4(r[0], r[1], r[2], r[3]);
+    col[i] = make_float4(r[4], r[5], r[6], r[7]);
+    if (ref_layout) {
+      for (int k = 0; k < nsens; ++k) times[(size_t)k * n + i] = r[8 + k];
+      nrm[i] = make_float4(r[8 + nsens], r[9 + nsens], r[10 + nsens], r[11 + nsens]);
+    } else {
+      nrm[i] = make_float4(r[8], r[9], r[10], r[11]);
+      for (int k = 0; k < nsens; ++k) times[(size_t)k * n + i] = r[12 + k];
+    }
+  }
+  const SurfelPlanes& b = m->buf[m->cur];
+  if (n) {
+    DMS_HIP(hipMemcpyAsync(b.pos, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    DMS_HIP(hipMemcpyAsync(b.col, col.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    DMS_HIP(hipMemcpyAsync(b.nrm, nrm.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    for (int k = 0; k < DMS_MAX_SENSORS; ++k)
+      DMS_HIP(hipMemcpyAsync(b.times + (size_t)k * m->cap, times.data() + (size_t)k * n, n * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  unsigned cnt = n;
+  DMS_HIP(hipMemcpyAsync(m->d_count, &cnt, sizeof(unsigned), hipMemcpyHostToDevice, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  m->count_upper = n;
+  return DMS_OK;
+}
+
+int dms_model_download_ref(dms_model* m, float* host, unsigned int max_count, unsigned int* count, dms_stream s) {
+  return model_download_any(m, host, max_count, count, DMS_REF_MAX_SENSORS, true, (hipStream_t)s);
+}
+int dms_model_upload_ref(dms_model* m, const float* host, unsigned int count, dms_stream s) {
+  return model_upload_any(m, host, count, DMS_REF_MAX_SENSORS, true, (hipStream_t)s);
+}
+int dms_model_download(dms_model* m, float* host, unsigned int max_count, unsigned int* count, dms_stream s) {
+  return model_download_any(m, host, max_count, count, DMS_MAX_SENSORS, false, (hipStream_t)s);
+}
+int dms_model_upload(dms_model* m, const float* host, unsigned int count, dms_stream s) {
+  return model_upload_any(m, host, count, DMS_MAX_SENSORS, false, (hipStream_t)s);
+}
+
+int dms_pose_block_set(dms_pose_block* dev, const float* pose16, dms_stream s) {
+  DMS_REQUIRE(dev && pose16, "null argument");
+  dms_pose_block h;
+  memcpy(h.pose, pose16, sizeof(h.pose));
+  // Eigen Matrix4f::inverse() (IndexMap.cpp:166 etc.): general 4×4 inverse in float
+  sm::inv4t<float>(h.pose, h.t_inv);
+  DMS_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)s));
+  DMS_HIP(hipStreamSynchronize((hipStream_t)s));
+  return DMS_OK;
+}
+
+}  // extern "C"
+
+namespace dms {
+
+// ---------------------------------------------------------------------------------------
+// G3 + G4: first-frame surfels (vertex_feedback.{vert,geom}, init_unstable.vert)
+// ---------------------------------------------------------------------------------------
+struct BootArgs {
+  const uchar4* rgba;
+  const float* depth_raw;       // metric
+  const float* depth_filtered;  // metric, filtered
+  int cols, rows;
+  float cx, cy, ifx, ify;  // cam = (cx, cy, 1/fx, 1/fy), float reciprocals (FeedbackBuffer.cpp:93-96)
+  int time, timeIdx;
+  float maxDepth;
+};
+
+// geometry.glsl:19-39: vertex / central-difference normal on a float depth map.
+// texcoords are the uv-buffer values; x = tx * cols, y = ty * rows.
+__device__ __forceinline__ f3 fb_vertex(const float* depth, int cols, int sx, int sy, float x, float y, float cx, float cy, float ifx,
+                                        float ify) {
+  const float z = depth[(size_t)sy * cols + sx];
+  return mk3(((x - cx) * z) * ifx, ((y - cy) * z) * ify, z);
+}
+
+__device__ __forceinline__ f3 fb_normal(const float* depth, int cols, int rows, const f3& vPosition, float tx, float ty, float x, float y,
+                                        float cx, float cy, float ifx, float ify) {
+  const float colsf = (float)cols, rowsf = (float)rows;
+  const int sx = texel(tx, colsf, cols), sy = texel(ty, rowsf, rows);
+  const int sxf = texel(tx + (1.0f / colsf), colsf, cols), sxb = texel(tx - (1.0f / colsf), colsf, cols);
+  const int syf = texel(ty + (1.0f / rowsf), rowsf, rows), syb = texel(ty - (1.0f / rowsf), rowsf, rows);
+  const f3 xf = fb_vertex(depth, cols, sxf, sy, x + 1.f, y, cx, cy, ifx, ify);
+  const f3 xb = fb_vertex(depth, cols, sxb, sy, x - 1.f, y, cx, cy, ifx, ify);
+  const f3 yf = fb_vertex(depth, cols, sx, syf, x, y + 1.f, cx, cy, ifx, ify);
+  const f3 yb = fb_vertex(depth, cols, sx, syb, x, y - 1.f, cx, cy, ifx, ify);
+  const f3 del_x = mk3(((xb.x + vPosition.x) / 2.f) - ((xf.x + vPosition.x) / 2.f), ((xb.y + vPosition.y) / 2.f) - ((xf.y + vPosition.y) / 2.f),
+                       ((xb.z + vPosition.z) / 2.f) - ((xf.z + vPosition.z) / 2.f));
+  const f3 del_y = mk3(((yb.x + vPosition.x) / 2.f) - ((yf.x + vPosition.x) / 2.f), ((yb.y + vPosition.y) / 2.f) - ((yf.y + vPosition.y) / 2.f),
+                       ((yb.z + vPosition.z) / 2.f) - ((yf.z + vPosition.z) / 2.f));
+  return normalized3(cross3(del_x, del_y));
+}
+
+// element e = column-major pixel (x = e / rows, y = e % rows): GlobalModel.cpp:100-108 order
+__global__ __launch_bounds__(256) void k_boot_flags(BootArgs a, unsigned char* __restrict__ keep, unsigned* __restrict__ block_count) {
+  const int n = a.cols * a.rows;
+  const int base = blockIdx.x * kScanChunk;
+  int cnt = 0;
+  for (int k = 0; k < kScanChunk / 256; ++k) {
+    const int e = base + k * 256 + threadIdx.x;
+    unsigned char f = 0;
+    if (e < n) {
+      const int px = e / a.rows, py = e - px * a.rows;
+      const float z = a.depth_raw[(size_t)py * a.cols + px];
+      // vertex_feedback.vert:55-62 + .geom:38: emitted iff 0 < z <= maxDepth
+      f = (z > 0.f && !(z > a.maxDepth)) ? 1 : 0;
+      keep[e] = f;
+    }
+    cnt += f;
+  }
+  const unsigned tot = block_sum_u32(cnt);
+  if (threadIdx.x == 0) block_count[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_boot_scatter(BootArgs a, const unsigned char* __restrict__ keep,
+                                                      const unsigned* __restrict__ block_offset, SurfelPlanes out, size_t cap) {
+  const int n = a.cols * a.rows;
+  const int base = blockIdx.x * kScanChunk;
+  unsigned running = block_offset[blockIdx.x];
+  for (int k = 0; k < kScanChunk / 256; ++k) {
+    const int e = base + k * 256 + threadIdx.x;
+    const bool f = (e < n) && keep[e];
+    unsigned total;
+    const unsigned rank = block_exclusive_rank(f, total);
+    if (f) {
+      const size_t dst = running + rank;
+      if (dst < cap) {
+        const int px = e / a.rows, py = e - px * a.rows;
+        const float tx = uv_coord(px, a.cols), ty = uv_coord(py, a.rows);
+        const float x = tx * (float)a.cols, y = ty * (float)a.rows;
+        // RAW feedback: position, colour, confidence (GlobalModel.cpp:355-370)
+        const f3 vr = fb_vertex(a.depth_raw, a.cols, px, py, x, y, a.cx, a.cy, a.ifx, a.ify);
+        // FILTERED feedback: normal + radius (GlobalModel.cpp:372-378)
+        const f3 vf = fb_vertex(a.depth_filtered, a.cols, px, py, x, y, a.cx, a.cy, a.ifx, a.ify);
+        const f3 nf = fb_normal(a.depth_filtered, a.cols, a.rows, vf, tx, ty, x, y, a.cx, a.cy, a.ifx, a.ify);
+        const float rad = surfel_radius(vf.z, nf.z, a.ifx, a.ify);
+        const float conf = surfel_confidence(x, y, a.cx, a.cy, 1.0f);
+        const uchar4 c = a.rgba[(size_t)py * a.cols + px];
+        out.pos[dst] = make_float4(vr.x, vr.y, vr.z, conf);
+        // init_unstable.vert:36-39: colour kept, y = 0, z (init time) = 1, w = time stamp
+        out.col[dst] = make_float4(encode_color_bytes(c.x, c.y, c.z), 0.f, 1.f, (float)a.time);
+        out.nrm[dst] = make_float4(nf.x, nf.y, nf.z, rad);
+        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? (float)a.time : -3.f;
+      }
+    }
+    running += total;
+  }
+}
+
+int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
+                     int timeIdx, float maxDepth, hipStream_t s) {
+  DMS_REQUIRE(m && rgba && dm && dmf && cam, "null argument");
+  DMS_REQUIRE(rgba->cols == m->width && rgba->rows == m->height && dm->cols == m->width && dmf->cols == m->width, "shape mismatch");
+  DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  BootArgs a;
+  a.rgba = (const uchar4*)rgba->data;
+  a.depth_raw = (const float*)dm->data;
+  a.depth_filtered = (const float*)dmf->data;
+  a.cols = m->width;
+  a.rows = m->height;
+  a.cx = cam->cx;
+  a.cy = cam->cy;
+  a.ifx = 1.0f / cam->fx;
+  a.ify = 1.0f / cam->fy;
+  a.time = time;
+  a.timeIdx = timeIdx;
+  a.maxDepth = maxDepth;
+  const int n = a.cols * a.rows;
+  const int nb = (n + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(k_boot_flags, dim3(nb), dim3(256), 0, s, a, m->keep, m->block_count);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count, (unsigned)m->cap);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_boot_scatter, dim3(nb), dim3(256), 0, s, a, m->keep, m->block_offset, m->buf[m->cur], m->cap);
+  DMS_CHECK_LAUNCH();
+  m->count_upper = (size_t)n < m->cap ? (size_t)n : m->cap;
+  return DMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// G5: index map (index_map.vert:41-67, index_map.frag:31-37)
+// ---------------------------------------------------------------------------------------
+struct ProjArgs {
+  const dms_pose_block* pose;
+  float cx, cy, fx, fy;
+  float colsf, rowsf;
+  int cols, rows;
+  float maxDepth;
+  int time, timeIdx, timeDelta;
+  // splat only
+  float confThreshold;
+  int maxTime;
+  int actv;
+};
+
+__global__ void k_clear_zbuf(unsigned long long* z, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) z[i] = kZClear;
+}
+
+// window position of a camera-frame point through the shader's NDC arithmetic
+// (index_map.vert:56-57 / splat.vert:37-42) and the viewport transform xw = (x_ndc + 1) * (W/2).
+__device__ __forceinline__ bool project_window(const ProjArgs& a, const f3& p, float& xw, float& yw, float& zw) {
+  const float xn = ((((a.fx * p.x) / p.z) + a.cx) - (a.colsf * 0.5f)) / (a.colsf * 0.5f);
+  const float yn = ((((a.fy * p.y) / p.z) + a.cy) - (a.rowsf * 0.5f)) / (a.rowsf * 0.5f);
+  const float zn = p.z / a.maxDepth;
+  // GL clips a point by its centre against -w <= x,y,z <= w (w = 1)
+  if (!(xn >= -1.f && xn <= 1.f && yn >= -1.f && yn <= 1.f && zn >= -1.f && zn <= 1.f)) return false;
+  xw = (xn + 1.f) * (a.colsf * 0.5f);
+  yw = (yn + 1.f) * (a.rowsf * 0.5f);
+  zw = zn * 0.5f + 0.5f;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_index_project(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
+                                                       unsigned long long* __restrict__ zbuf) {
+  const unsigned M = d_count[0];
+  const float* Tinv = a.pose->t_inv;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += blockDim.x * gridDim.x) {
+    const float4 pc = sp.pos[i];
+    const f3 ph = xform_point(Tinv, mk3(pc.x, pc.y, pc.z));
+    const float vt = sp.times[(size_t)a.timeIdx * cap + i];
+    if (ph.z > a.maxDepth || ph.z < 0.f || (vt != -3.f && (float)a.time - vt > (float)a.timeDelta)) continue;
+    float xw, yw, zw;
+    if (!project_window(a, ph, xw, yw, zw)) continue;
+    const int px = (int)floorf(xw), py = (int)floorf(yw);
+    if (px < 0 || py < 0 || px >= a.cols || py >= a.rows) continue;
+    const unsigned d = depth24(zw);
+    if (d >= 0xFFFFFFu) continue;  // GL_LESS against the cleared depth 1.0
+    const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)i;
+    unsigned long long* cell = zbuf + (size_t)py * a.cols + px;
+    if (key < *cell) atomicMin(cell, key);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_index_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned long long* __restrict__ zbuf,
+                                                       unsigned* __restrict__ index, float4* __restrict__ vertConf,
+                                                       float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+  const int n = a.cols * a.rows;
+  const float* Tinv = a.pose->t_inv;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
+    const unsigned long long key = zbuf[p];
+    if ((unsigned)(key >> 32) >= 0xFFFFFFu) {  // cleared colour (glClearColor 0)
+      index[p] = 0;
+      vertConf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      colorTime[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      normRad[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const unsigned i = (unsigned)(key & 0xFFFFFFFFull);
+    const float4 pc = sp.pos[i], cc = sp.col[i], nr = sp.nrm[i];
+    const f3 ph = xform_point(Tinv, mk3(pc.x, pc.y, pc.z));
+    const f3 nh = normalized3(xform_dir(Tinv, mk3(nr.x, nr.y, nr.z)));
+    index[p] = i;
+    vertConf[p] = make_float4(ph.x, ph.y, ph.z, pc.w);
+    colorTime[p] = make_float4(cc.x, cc.y, cc.z, sp.times[(size_t)a.timeIdx * cap + i]);
+    normRad[p] = make_float4(nh.x, nh.y, nh.z, nr.w);
+  }
+}
+
+static int surfel_grid(size_t upper) {
+  size_t b = (upper + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (int)b;
+}
+
+static bool dense_img(const dms_image2d& im, size_t elem, int w, int h) {
+  return im.data && im.cols == w && im.rows == h && im.pitch == (size_t)w * elem;
+}
+
+static void fill_proj(ProjArgs& a, const dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, int time,
+                      int timeIdx, int timeDelta) {
+  a.pose = pose;
+  a.cx = cam->cx;
+  a.cy = cam->cy;
+  a.fx = cam->fx;
+  a.fy = cam->fy;
+  a.cols = m->width;
+  a.rows = m->height;
+  a.colsf = (float)m->width;
+  a.rowsf = (float)m->height;
+  a.maxDepth = maxDepth;
+  a.time = time;
+  a.timeIdx = timeIdx;
+  a.timeDelta = timeDelta;
+  a.confThreshold = 0.f;
+  a.maxTime = 0;
+  a.actv = 0;
+}
+
+int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
+              unsigned long long* zbuf, dms_indexmap_out* out, hipStream_t s) {
+  DMS_REQUIRE(m && pose && cam && zbuf && out, "null argument");
+  DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  const int W = m->width, H = m->height;
+  DMS_REQUIRE(dense_img(out->index, 4, W, H) && dense_img(out->vertConf, 16, W, H) && dense_img(out->colorTime, 16, W, H) &&
+                  dense_img(out->normRad, 16, W, H),
+              "index-map targets must be dense W×H");
+  ProjArgs a;
+  fill_proj(a, m, pose, cam, maxDepth, time, timeIdx, timeDelta);
+  const int n = W * H;
+  hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_index_project, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_index_resolve, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
+                     (unsigned*)out->index.data, (float4*)out->vertConf.data, (float4*)out->colorTime.data, (float4*)out->normRad.data);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// G6 / G6': splat prediction (splat.vert:57-94, combo_splat.frag:35-60, depth_splat.frag:29-46)
+// ---------------------------------------------------------------------------------------
+struct SplatSurfel {
+  f3 pos;       // camera frame
+  f3 nrm;       // camera frame, normalised
+  float rad, conf;
+  float xw, yw;  // sprite centre in window coordinates
+  float size;    // gl_PointSize
+};
+
+__device__ __forceinline__ f3 project_image(const ProjArgs& a, const f3& p) {  // splat.vert:44-49
+  return mk3(((a.fx * p.x) / p.z) + a.cx, ((a.fy * p.y) / p.z) + a.cy, p.z);
+}
+
+// vertex stage: returns false when the surfel is culled / clipped
+__device__ __forceinline__ bool splat_vertex(const ProjArgs& a, const float4& pc, const float4& nr, float vt, SplatSurfel& o) {
+  const float* Tinv = a.pose->t_inv;
+  const f3 ph = xform_point(Tinv, mk3(pc.x, pc.y, pc.z));
+  const bool actv = a.actv != 0;
+  const bool cull = !(!actv && vt == -3.f) && (ph.z > a.maxDepth || ph.z < 0.f || pc.w < a.confThreshold || (actv && vt == -3.f) ||
+                                               (vt != -3.f && (float)a.time - vt > (float)a.timeDelta) || vt > (float)a.maxTime);
+  if (cull) return false;
+  float zw;
+  if (!project_window(a, ph, o.xw, o.yw, zw)) return false;
+  o.pos = ph;
+  o.conf = pc.w;
+  o.rad = nr.w;
+  o.nrm = normalized3(xform_dir(Tinv, mk3(nr.x, nr.y, nr.z)));
+  const f3 x1n = normalized3(mk3(o.nrm.y - o.nrm.z, -o.nrm.x, o.nrm.x));
+  const f3 x1 = mk3((x1n.x * o.rad) * 1.41421356f, (x1n.y * o.rad) * 1.41421356f, (x1n.z * o.rad) * 1.41421356f);
+  const f3 y1 = cross3(o.nrm, x1);
+  const f3 p1 = project_image(a, ph + x1), p2 = project_image(a, ph + y1), p3 = project_image(a, ph - y1), p4 = project_image(a, ph - x1);
+  const float xmin = fminf(p1.x, fminf(p2.x, fminf(p3.x, p4.x))), xmax = fmaxf(p1.x, fmaxf(p2.x, fmaxf(p3.x, p4.x)));
+  const float ymin = fminf(p1.y, fminf(p2.y, fminf(p3.y, p4.y))), ymax = fmaxf(p1.y, fmaxf(p2.y, fmaxf(p3.y, p4.y)));
+  const float xDiff = fabsf(xmax - xmin), yDiff = fabsf(ymax - ymin);
+  o.size = fmaxf(0.f, fmaxf(xDiff, yDiff));
+  return true;
+}
+
+// fragment stage at pixel (px, py): ray/disc test.  Returns false on discard.
+__device__ __forceinline__ bool splat_fragment(const ProjArgs& a, const SplatSurfel& s, int px, int py, f3& corrected, float& zw) {
+  const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;  // gl_FragCoord
+  const f3 l = normalized3(mk3((fcx - a.cx) / a.fx, (fcy - a.cy) / a.fy, 1.0f));
+  const float k = dot3(s.pos, s.nrm) / dot3(l, s.nrm);
+  corrected = mk3(k * l.x, k * l.y, k * l.z);
+  const float sqrRad = s.rad * s.rad;  // pow(r, 2)
+  const f3 diff = corrected - s.pos;
+  if (dot3(diff, diff) > sqrRad) return false;
+  zw = (corrected.z / (2.f * a.maxDepth)) + 0.5f;  // gl_FragDepth
+  return true;
+}
+
+// sprite coverage: pixel centres inside [c - size/2, c + size/2); a size below 1 rasterises as 1
+__device__ __forceinline__ void sprite_range(float c, float size, int n, int& lo, int& hi) {
+  const float sz = fmaxf(size, 1.0f);
+  const float a = c - sz * 0.5f, b = c + sz * 0.5f;
+  lo = (int)ceilf(a - 0.5f);
+  hi = (int)ceilf(b - 0.5f) - 1;
+  if (lo < 0) lo = 0;
+  if (hi > n - 1) hi = n - 1;
+}
+
+__global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
+                                                       unsigned long long* __restrict__ zbuf) {
+  const unsigned M = d_count[0];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += blockDim.x * gridDim.x) {
+    SplatSurfel s;
+    if (!splat_vertex(a, sp.pos[i], sp.nrm[i], sp.times[(size_t)a.timeIdx * cap + i], s)) continue;
+    if (!(s.size == s.size)) continue;  // NaN size: no fragments
+    int x0, x1, y0, y1;
+    sprite_range(s.xw, s.size, a.cols, x0, x1);
+    sprite_range(s.yw, s.size, a.rows, y0, y1);
+    for (int py = y0; py <= y1; ++py)
+      for (int px = x0; px <= x1; ++px) {
+        f3 c;
+        float zw;
+        if (!splat_fragment(a, s, px, py, c, zw)) continue;
+        const unsigned d = depth24(zw);
+        if (d >= 0xFFFFFFu) continue;
+        const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)i;
+        unsigned long long* cell = zbuf + (size_t)py * a.cols + px;
+        if (key < *cell) atomicMin(cell, key);
+      }
+  }
+}
+
+template <bool DEPTH_ONLY>
+__global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned long long* __restrict__ zbuf,
+                                                       uchar4* __restrict__ image, float4* __restrict__ vertex, float4* __restrict__ normal,
+                                                       unsigned short* __restrict__ timeImg, float* __restrict__ depthOut) {
+  const int n = a.cols * a.rows;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
+    const unsigned long long key = zbuf[p];
+    if ((unsigned)(key >> 32) >= 0xFFFFFFu) {
+      if (DEPTH_ONLY) {
+        depthOut[p] = 0.f;
+      } else {
+        image[p] = make_uchar4(0, 0, 0, 0);
+        vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        normal[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        timeImg[p] = 0;
+      }
+      continue;
+    }
+    const unsigned i = (unsigned)(key & 0xFFFFFFFFull);
+    SplatSurfel s;
+    splat_vertex(a, sp.pos[i], sp.nrm[i], sp.times[(size_t)a.timeIdx * cap + i], s);
+    const int py = p / a.cols, px = p - py * a.cols;
+    f3 c;
+    float zw;
+    splat_fragment(a, s, px, py, c, zw);
+    if (DEPTH_ONLY) {
+      depthOut[p] = c.z;
+      continue;
+    }
+    const float4 cc = sp.col[i];
+    const f3 rgb = decode_color(cc.x);
+    // RGBA8 render target: round(c * 255)
+    image[p] = make_uchar4((unsigned char)f2i_rn(rgb.x * 255.0f), (unsigned char)f2i_rn(rgb.y * 255.0f),
+                           (unsigned char)f2i_rn(rgb.z * 255.0f), 255);
+    const float z = c.z;
+    const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+    vertex[p] = make_float4(((fcx - a.cx) * z) * (1.f / a.fx), ((fcy - a.cy) * z) * (1.f / a.fy), z, s.conf);
+    normal[p] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, s.rad);
+    // time = uint(colTime.z) into a 16-bit unsigned target
+    const float tz = cc.z;
+    unsigned tv = tz > 0.f ? (unsigned)f2i_rz(tz) : 0u;
+    if (tv > 65535u) tv = 65535u;
+    timeImg[p] = (unsigned short)tv;
+  }
+}
+
+int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
+                  int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
+                  dms_image2d* depth_out, hipStream_t s) {
+  DMS_REQUIRE(m && pose && cam && zbuf, "null argument");
+  DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  const int W = m->width, H = m->height;
+  if (depth_out)
+    DMS_REQUIRE(dense_img(*depth_out, 4, W, H), "depth target must be dense W×H f32");
+  else
+    DMS_REQUIRE(out && dense_img(out->image, 4, W, H) && dense_img(out->vertex, 16, W, H) && dense_img(out->normal, 16, W, H) &&
+                    dense_img(out->time, 2, W, H),
+                "prediction targets must be dense W×H");
+  ProjArgs a;
+  fill_proj(a, m, pose, cam, maxDepth, time, timeIdx, timeDelta);
+  a.confThreshold = confThreshold;
+  a.maxTime = maxTime;
+  a.actv = active ? 1 : 0;
+  const int n = W * H;
+  hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_splat_project, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf);
+  DMS_CHECK_LAUNCH();
+  if (depth_out)
+    hipLaunchKernelGGL(k_splat_resolve<true>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
+                       (uchar4*)nullptr, (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data);
+  else
+    hipLaunchKernelGGL(k_splat_resolve<false>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
+                       (uchar4*)out->image.data, (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data,
+                       (float*)nullptr);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+}  // namespace dms

@@ -1,0 +1,202 @@
+// Per-frame image stages of the fusion half: depth bilateral filter (G1), metric depth (G2),
+// hole fill-in of the model prediction (G10) and nearest-neighbour resize (G11).
+// All are one-thread-per-pixel streaming kernels over dense row-major images.
+#include "surfel.hpp"
+
+namespace dms {
+
+static constexpr int BX = 64, BY = 4;
+
+// G1 — depth_bilateral.frag:30-75.  Fragment (x, y) has texcoord ((x+0.5)/cols, (y+0.5)/rows);
+// taps are fetched at (float(cx)/cols, float(cy)/rows) with the NEAREST rule of surfel.hpp.
+__global__ __launch_bounds__(BX* BY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                            int cols, int rows, float maxD) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  const int py = blockIdx.y * blockDim.y + threadIdx.y;
+  if (px >= cols || py >= rows) return;
+  const float colsf = (float)cols, rowsf = (float)rows;
+  const unsigned value = src[(size_t)py * cols + px];
+  const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
+  if (value > gate || value < 300U) {
+    dst[(size_t)py * cols + px] = 0;
+    return;
+  }
+  // int(texcoord * cols): texcoord of the fragment centre
+  const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
+  const int x = (int)(tcx * colsf);
+  const int y = (int)(tcy * rowsf);
+  const float sigma_space2_inv_half = 0.024691358f;
+  const float sigma_color2_inv_half = 0.000555556f;
+  const int R = 6;
+  const int D = R * 2 + 1;
+  const int tx = min(x - D / 2 + D, cols);
+  const int ty = min(y - D / 2 + D, rows);
+  float sum1 = 0.f, sum2 = 0.f;
+  for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
+    const int sy = texel((float)cy / rowsf, rowsf, rows);
+    for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
+      const int sx = texel((float)cx / colsf, colsf, cols);
+      const unsigned tmp = src[(size_t)sy * cols + sx];
+      const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+      const float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);
+      const float weight = det_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+      sum1 += (float)tmp * weight;
+      sum2 += weight;
+    }
+  }
+  dst[(size_t)py * cols + px] = (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2));
+}
+
+// G2 — depth_metric.frag:28-39
+__global__ __launch_bounds__(BX* BY) void k_depth_metric(const unsigned short* __restrict__ src, float* __restrict__ dst, int n,
+                                                         float maxD) {
+  const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    const unsigned value = src[i];
+    dst[i] = (value > gate || value < 300U) ? 0.f : (float)value / 1000.0f;
+  }
+}
+
+// G10 — fill_vertex.frag / fill_normal.frag / fill_rgb.frag
+struct FillArgs {
+  const float4* ex_vertex;
+  const float4* ex_normal;
+  const uchar4* ex_image;
+  const unsigned short* depth;  // filtered, mm
+  const uchar4* rgba;
+  float4* out_vertex;
+  float4* out_normal;
+  uchar4* out_image;
+  int cols, rows;
+  float cx, cy, ifx, ify;  // cam = (cx, cy, 1/fx, 1/fy) with float reciprocals (FillIn.cpp:120-123)
+  int pass_geom, pass_rgb;
+};
+
+__device__ __forceinline__ f3 fill_vertex_at(const FillArgs& a, int sx, int sy, int x, int y) {
+  // geometry.glsl:41-45 (usampler2D variant): z = texel / 1000
+  const float z = (float)a.depth[(size_t)sy * a.cols + sx] / 1000.0f;
+  return mk3((((float)x - a.cx) * z) * a.ifx, (((float)y - a.cy) * z) * a.ify, z);
+}
+
+__global__ __launch_bounds__(BX* BY) void k_fill_in(FillArgs a) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  const int py = blockIdx.y * blockDim.y + threadIdx.y;
+  if (px >= a.cols || py >= a.rows) return;
+  const size_t i = (size_t)py * a.cols + px;
+  const float colsf = (float)a.cols, rowsf = (float)a.rows;
+  const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
+  const int x = (int)(tcx * colsf), y = (int)(tcy * rowsf);
+  {  // fill_vertex.frag:41-55
+    const float4 samp = a.ex_vertex[i];
+    if (samp.z == 0.f || a.pass_geom == 1) {
+      const f3 v = fill_vertex_at(a, px, py, x, y);
+      a.out_vertex[i] = make_float4(v.x, v.y, v.z, 1.f);
+    } else {
+      a.out_vertex[i] = samp;
+    }
+  }
+  {  // fill_normal.frag:33-48 with geometry.glsl:48-58 forward differences
+    const float4 samp = a.ex_normal[i];
+    if (samp.z == 0.f || a.pass_geom == 1) {
+      const f3 v = fill_vertex_at(a, px, py, x, y);
+      const int sxp = texel(tcx + (1.0f / colsf), colsf, a.cols);
+      const int syp = texel(tcy + (1.0f / rowsf), rowsf, a.rows);
+      const f3 vx = fill_vertex_at(a, sxp, py, x + 1, y);
+      const f3 vy = fill_vertex_at(a, px, syp, x, y + 1);
+      const f3 n = normalized3(cross3(vx - v, vy - v));
+      a.out_normal[i] = make_float4(n.x, n.y, n.z, 1.f);
+    } else {
+      a.out_normal[i] = samp;
+    }
+  }
+  {  // fill_rgb.frag:29-37: samp.x + samp.y + samp.z == 0 on normalised bytes <=> all three zero
+    const uchar4 samp = a.ex_image[i];
+    if ((samp.x == 0 && samp.y == 0 && samp.z == 0) || a.pass_rgb == 1)
+      a.out_image[i] = a.rgba[i];
+    else
+      a.out_image[i] = samp;
+  }
+}
+
+// G11 — resize.frag: dst pixel (i, j) samples src at ((i+0.5)/dw, (j+0.5)/dh), NEAREST
+template <typename T>
+__global__ void k_resize_nn(const T* __restrict__ src, int scols, int srows, T* __restrict__ dst, int dcols, int drows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= dcols || j >= drows) return;
+  const float u = ((float)i + 0.5f) / (float)dcols, v = ((float)j + 0.5f) / (float)drows;
+  const int sx = texel(u, (float)scols, scols), sy = texel(v, (float)srows, srows);
+  dst[(size_t)j * dcols + i] = src[(size_t)sy * scols + sx];
+}
+
+static bool dense(const dms_image2d* im, size_t elem) { return im && im->data && im->pitch == (size_t)im->cols * elem; }
+
+int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s) {
+  DMS_REQUIRE(dense(src, 2) && dense(dst, 2), "dense u16 images required");
+  DMS_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, "shape mismatch");
+  dim3 b(BX, BY), g = grid2d(src->cols, src->rows, b);
+  hipLaunchKernelGGL(k_depth_bilateral, g, b, 0, s, (const unsigned short*)src->data, (unsigned short*)dst->data, src->cols, src->rows,
+                     maxD);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s) {
+  DMS_REQUIRE(dense(src, 2) && dense(dst, 4), "dense images required");
+  DMS_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, "shape mismatch");
+  const int n = src->rows * src->cols;
+  hipLaunchKernelGGL(k_depth_metric, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, (const unsigned short*)src->data,
+                     (float*)dst->data, n, maxD);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
+            int pass_rgb, dms_predict_out* out, hipStream_t s) {
+  DMS_REQUIRE(ex && depth && rgba && cam && out, "null argument");
+  DMS_REQUIRE(dense(&ex->vertex, 16) && dense(&ex->normal, 16) && dense(&ex->image, 4) && dense(depth, 2) && dense(rgba, 4) &&
+                  dense(&out->vertex, 16) && dense(&out->normal, 16) && dense(&out->image, 4),
+              "dense images required");
+  FillArgs a;
+  a.ex_vertex = (const float4*)ex->vertex.data;
+  a.ex_normal = (const float4*)ex->normal.data;
+  a.ex_image = (const uchar4*)ex->image.data;
+  a.depth = (const unsigned short*)depth->data;
+  a.rgba = (const uchar4*)rgba->data;
+  a.out_vertex = (float4*)out->vertex.data;
+  a.out_normal = (float4*)out->normal.data;
+  a.out_image = (uchar4*)out->image.data;
+  a.cols = depth->cols;
+  a.rows = depth->rows;
+  a.cx = cam->cx;
+  a.cy = cam->cy;
+  a.ifx = 1.0f / cam->fx;
+  a.ify = 1.0f / cam->fy;
+  a.pass_geom = pass_geom ? 1 : 0;
+  a.pass_rgb = pass_rgb ? 1 : 0;
+  dim3 b(BX, BY), g = grid2d(a.cols, a.rows, b);
+  hipLaunchKernelGGL(k_fill_in, g, b, 0, s, a);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s) {
+  DMS_REQUIRE(src && dst && src->data && dst->data, "null argument");
+  DMS_REQUIRE(dense(src, elem) && dense(dst, elem), "dense images required");
+  dim3 b(32, 8), g = grid2d(dst->cols, dst->rows, b);
+  if (elem == 4)
+    hipLaunchKernelGGL(k_resize_nn<unsigned>, g, b, 0, s, (const unsigned*)src->data, src->cols, src->rows, (unsigned*)dst->data,
+                       dst->cols, dst->rows);
+  else if (elem == 16)
+    hipLaunchKernelGGL(k_resize_nn<float4>, g, b, 0, s, (const float4*)src->data, src->cols, src->rows, (float4*)dst->data, dst->cols,
+                       dst->rows);
+  else if (elem == 2)
+    hipLaunchKernelGGL(k_resize_nn<unsigned short>, g, b, 0, s, (const unsigned short*)src->data, src->cols, src->rows,
+                       (unsigned short*)dst->data, dst->cols, dst->rows);
+  else
+    DMS_REQUIRE(false, "elem_bytes must be 2, 4 or 16");
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+}  // namespace dms

@@ -127,6 +127,54 @@ __global__ void k_transformMaps(int rows, int cols, View<const float> vsrc, View
   }
 }
 
+// device-pose variant used by the frame step: R | t are read from a row-major 4×4 in HBM so the
+// pose never has to visit the host between tracking and map transformation
+__global__ void k_transformMaps_dev(int rows, int cols, View<float> vmap, View<float> nmap, const float* __restrict__ pose16) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  M33 R;
+  R.r0 = mk3(pose16[0], pose16[1], pose16[2]);
+  R.r1 = mk3(pose16[4], pose16[5], pose16[6]);
+  R.r2 = mk3(pose16[8], pose16[9], pose16[10]);
+  const f3 t = mk3(pose16[3], pose16[7], pose16[11]);
+  {
+    f3 s;
+    float outx = qnan();
+    s.x = vmap.at(y, x);
+    if (!isnan(s.x)) {
+      s.y = vmap.at(y + rows, x);
+      s.z = vmap.at(y + 2 * rows, x);
+      const f3 d = mul(R, s) + t;
+      vmap.at(y + rows, x) = d.y;
+      vmap.at(y + 2 * rows, x) = d.z;
+      outx = d.x;
+    }
+    vmap.at(y, x) = outx;
+  }
+  {
+    f3 s;
+    float outx = qnan();
+    s.x = nmap.at(y, x);
+    if (!isnan(s.x)) {
+      s.y = nmap.at(y + rows, x);
+      s.z = nmap.at(y + 2 * rows, x);
+      const f3 d = mul(R, s);
+      nmap.at(y + rows, x) = d.y;
+      nmap.at(y + 2 * rows, x) = d.z;
+      outx = d.x;
+    }
+    nmap.at(y, x) = outx;
+  }
+}
+
+// dst = (*flag ? b : a), 16 bytes per element
+__global__ void k_select_copy16(float4* __restrict__ dst, const float4* __restrict__ a, const float4* __restrict__ b,
+                                const int* __restrict__ flag, int force_b, size_t n) {
+  const float4* src = (force_b || (flag && *flag)) ? b : a;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)blockDim.x * gridDim.x) dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // copyMaps: dense RGBA32F -> stacked planes, z == 0 => NaN in all three planes
 // (reference copyMapsKernel ×2, cudafuncs.cu:313-378).  One float4 load per lane.
@@ -340,6 +388,23 @@ int transformMaps(const dms_image2d* vs, const dms_image2d* ns, const dms_mat33*
     LAUNCH2D(k_transformMaps<false>, cols, rows, s, rows, cols, view<const float>(vs), view<const float>(vs), to_m33(R), to_f3(t),
              view<float>(vd), view<float>(vd));
   }
+  return DMS_OK;
+}
+
+int transformMapsDev(dms_image2d* v, dms_image2d* n, const float* pose16_dev, hipStream_t s) {
+  DMS_REQUIRE(v && n && pose16_dev && v->data && n->data && v->rows % 3 == 0 && n->rows == v->rows, "bad argument");
+  const int rows = v->rows / 3, cols = v->cols;
+  LAUNCH2D(k_transformMaps_dev, cols, rows, s, rows, cols, view<float>(v), view<float>(n), pose16_dev);
+  return DMS_OK;
+}
+
+int selectCopy16(void* dst, const void* a, const void* b, const int* flag_dev, int force_b, size_t n16, hipStream_t s) {
+  DMS_REQUIRE(dst && a && b, "null argument");
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_select_copy16, dim3((unsigned)blocks), dim3(256), 0, s, (float4*)dst, (const float4*)a, (const float4*)b, flag_dev,
+                     force_b, n16);
+  DMS_CHECK_LAUNCH();
   return DMS_OK;
 }
 

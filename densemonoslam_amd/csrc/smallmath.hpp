@@ -49,8 +49,9 @@ __host__ __device__ inline void mul4(const double* a, const double* b, double* o
 }
 
 // general 4×4 inverse by cofactor expansion (row-major)
-__host__ __device__ inline void inv4(const double* m, double* o) {
-  double inv[16];
+template <typename T>
+__host__ __device__ inline void inv4t(const T* m, T* o) {
+  T inv[16];
   inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
   inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
   inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
@@ -67,10 +68,11 @@ __host__ __device__ inline void inv4(const double* m, double* o) {
   inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
   inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
   inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-  const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
-  const double id = 1.0 / det;
+  const T det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const T id = T(1) / det;
   for (int i = 0; i < 16; ++i) o[i] = inv[i] * id;
 }
+__host__ __device__ inline void inv4(const double* m, double* o) { inv4t<double>(m, o); }
 
 // Pivoted LDLT solve of a symmetric N×N system (diagonal pivoting on |A_kk|, zero pivots
 // solved as 0): the algorithm behind `A.ldlt().solve(b)` at RGBDOdometry.cpp:371,554.

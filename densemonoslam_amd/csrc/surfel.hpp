@@ -1,0 +1,117 @@
+// Surfel map storage and the shared device helpers of the fusion kernels.
+//
+// HBM layout (MI355X-first; the reference keeps 60-byte interleaved records in a GL VBO,
+// Shaders/Vertex.cpp:21-50): structure-of-arrays of float4 planes, so every pass streams only
+// the attributes it needs with 16-byte coalesced accesses per lane:
+//   pos[i] = (x, y, z, confidence)           col[i] = (colour, 0, initTime, stamp)
+//   nrm[i] = (nx, ny, nz, radius)            times[s * capacity + i] = last-seen time of sensor s
+// Two such sets ping-pong through the order-preserving compaction of `clean`.
+#pragma once
+#include "common.hpp"
+#include "detmath.hpp"
+#include "../../include/dmslam_fusion.h"
+
+namespace dms {
+
+struct SurfelPlanes {
+  float4* pos;
+  float4* col;
+  float4* nrm;
+  float* times;  // [DMS_MAX_SENSORS][cap]
+};
+
+constexpr unsigned kEmptyWinner = 0xFFFFFFFFu;
+constexpr unsigned long long kZClear = (0xFFFFFFull << 32) | 0xFFFFFFFFull;  // depth 1.0 (24-bit), no surfel
+constexpr int kScanChunk = 1024;  // elements per scan block
+
+// --- GL-rule helpers (DESIGN.md "Rasteriser rules") ---------------------------------------
+// NEAREST texel of a normalised coordinate: floor(u * n) evaluated in fp32, CLAMP_TO_EDGE.
+__host__ __device__ __forceinline__ int texel(float u, float n_f, int n) {
+  int i = (int)floorf(u * n_f);
+  if (i < 0) i = 0;
+  if (i > n - 1) i = n - 1;
+  return i;
+}
+// 24-bit fixed-point window depth of zw in [0,1]: round(zw * (2^24 - 1)), exact in fp64
+__host__ __device__ __forceinline__ unsigned depth24(float zw) {
+  if (!(zw >= 0.f)) return 0xFFFFFFFFu;  // clipped (also NaN)
+  if (zw > 1.f) return 0xFFFFFFFFu;
+  return (unsigned)llrint((double)zw * 16777215.0);
+}
+
+// mat4 * (p, 1): row-major, accumulated left to right, translation last
+__host__ __device__ __forceinline__ f3 xform_point(const float* M, const f3& p) {
+  return mk3(((M[0] * p.x + M[1] * p.y) + M[2] * p.z) + M[3], ((M[4] * p.x + M[5] * p.y) + M[6] * p.z) + M[7],
+             ((M[8] * p.x + M[9] * p.y) + M[10] * p.z) + M[11]);
+}
+// mat3(M) * v
+__host__ __device__ __forceinline__ f3 xform_dir(const float* M, const f3& v) {
+  return mk3((M[0] * v.x + M[1] * v.y) + M[2] * v.z, (M[4] * v.x + M[5] * v.y) + M[6] * v.z,
+             (M[8] * v.x + M[9] * v.y) + M[10] * v.z);
+}
+__host__ __device__ __forceinline__ float length3(const f3& a) { return sqrtf(dot3(a, a)); }
+
+// surfels.glsl:19-34; cam_z = 1/fx, cam_w = 1/fy as the caller's `cam` uniform holds them
+__host__ __device__ __forceinline__ float surfel_radius(float depth, float norm_z, float cam_z, float cam_w) {
+  const float meanFocal = ((1.0f / fabsf(cam_z)) + (1.0f / fabsf(cam_w))) / 2.0f;
+  const float sqrt2 = 1.41421356237f;
+  const float radius = (depth / meanFocal) * sqrt2;
+  float radius_n = radius;
+  radius_n = radius_n / fabsf(norm_z);
+  radius_n = fminf(2.0f * radius, radius_n);
+  return radius_n;
+}
+// surfels.glsl:36-46
+__host__ __device__ __forceinline__ float surfel_confidence(float x, float y, float cx, float cy, float weighting) {
+  const float maxRadDist = 400.f;
+  const float twoSigmaSquared = 0.72f;
+  const float px = x - cx, py = y - cy;
+  const float radialDist = sqrtf(px * px + py * py) / maxRadDist;
+  return det_expf((-(radialDist * radialDist) / twoSigmaSquared)) * weighting;
+}
+// color.glsl:19-34
+__host__ __device__ __forceinline__ float encode_color_bytes(unsigned r, unsigned g, unsigned b) {
+  return (float)(int)((((r << 8) + g) << 8) + b);
+}
+__host__ __device__ __forceinline__ float encode_color(float cx, float cy, float cz) {
+  int rgb = (int)roundf(cx * 255.0f);
+  rgb = (rgb << 8) + (int)roundf(cy * 255.0f);
+  rgb = (rgb << 8) + (int)roundf(cz * 255.0f);
+  return (float)rgb;
+}
+__host__ __device__ __forceinline__ f3 decode_color(float c) {
+  const int ci = (int)c;
+  return mk3((float)((ci >> 16) & 0xFF) / 255.0f, (float)((ci >> 8) & 0xFF) / 255.0f, (float)(ci & 0xFF) / 255.0f);
+}
+
+// uv buffer entry of the reference (GlobalModel.cpp:100-108, FeedbackBuffer.cpp:38-46):
+// ((float)i / (float)n) + 1.0 / (2 * (float)n) evaluated in double, stored as float
+__host__ __device__ __forceinline__ float uv_coord(int i, int n) {
+  return (float)((double)((float)i / (float)n) + 1.0 / (double)(2.0f * (float)n));
+}
+
+}  // namespace dms
+
+struct dms_model {
+  size_t cap = 0;
+  int width = 0, height = 0;
+  int slots = 0, slot_h = 0;  // fuse candidate grid ((W+1)/2 × (H+1)/2), column-major slot = i*slot_h + j
+  dms::SurfelPlanes buf[2];
+  int cur = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  unsigned* d_count = nullptr;      // [0] model count, [1] new-unstable count, [2] scratch
+  unsigned* h_count = nullptr;      // pinned mirror
+  size_t count_upper = 0;           // host-side upper bound of the model count
+  // fuse scratch (per candidate slot)
+  float4 *slot_pos = nullptr, *slot_col = nullptr, *slot_nrm = nullptr;
+  unsigned* slot_best = nullptr;
+  unsigned char* slot_flag = nullptr;
+  unsigned* winner = nullptr;       // [cap] column-major slot of the winning measurement per surfel
+  // compaction scratch
+  unsigned char* keep = nullptr;    // [cap + slots]
+  unsigned* block_count = nullptr;  // [(cap + slots) / kScanChunk + 2]
+  unsigned* block_offset = nullptr;
+  float* nodes = nullptr;           // deformation node table, 16 floats / node
+  int max_nodes = 2048;
+};

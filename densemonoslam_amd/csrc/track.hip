@@ -149,8 +149,15 @@ struct Prior {
   float v[12];  // trans[3], rot[9] — passed by value so no staging copy can race a later call
 };
 
-__global__ void k_track_init(TrackState* st, Prior prior, float fx, float fy, float cx, float cy, int so3, int first_level) {
+__global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
+                             int so3, int first_level) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (prior_pose16) {  // device-resident prior (frame step): row-major 4×4 camera-to-world
+    for (int i = 0; i < 3; ++i) {
+      prior.v[i] = prior_pose16[i * 4 + 3];
+      for (int j = 0; j < 3; ++j) prior.v[3 + i * 3 + j] = prior_pose16[i * 4 + j];
+    }
+  }
   for (int i = 0; i < 3; ++i) st->tprev[i] = st->tcurr[i] = prior.v[i];
   for (int i = 0; i < 9; ++i) st->Rprev[i] = st->Rcurr[i] = prior.v[3 + i];
   sm::inv3<float>(st->Rprev, st->Rprev_inv);
@@ -853,18 +860,39 @@ int dms_odometry_initFirstRGB(dms_odometry* o, const dms_image2d* rgba, dms_stre
   return DMS_OK;
 }
 
+}  // extern "C"
+
+namespace dms {
+int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
+                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s);
+}
+
+extern "C" {
+
 int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* rot, int rgbOnly, float icpWeight, int pyramid,
                              int fastOdom, int so3, int interMap, dms_stream st) {
   DMS_REQUIRE(o && trans && rot, "null argument");
-  hipStream_t s = (hipStream_t)st;
+  return odometry_track_enqueue(o, trans, rot, nullptr, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap, (hipStream_t)st);
+}
+
+}  // extern "C"
+
+namespace dms {
+
+int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
+                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s) {
+  DMS_REQUIRE(o && ((trans && rot) || prior_pose16_dev), "null argument");
   const bool icp = !rgbOnly && icpWeight > 0;
   const bool rgb = rgbOnly || icpWeight < 100;
   DMS_REQUIRE(icp || rgb, "neither ICP nor RGB term active");
   int rc;
 
   Prior prior;
-  memcpy(prior.v, trans, 3 * sizeof(float));
-  memcpy(prior.v + 3, rot, 9 * sizeof(float));
+  memset(&prior, 0, sizeof(prior));
+  if (!prior_pose16_dev) {
+    memcpy(prior.v, trans, 3 * sizeof(float));
+    memcpy(prior.v + 3, rot, 9 * sizeof(float));
+  }
 
   if (rgb) {
     for (int i = 0; i < DMS_NUM_PYRS; i++) {
@@ -886,7 +914,8 @@ int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* r
 
   {
     Timer t(o, s, "track_init");
-    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, s, o->state, prior, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0, first_level);
+    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
+                       first_level);
     DMS_CHECK_LAUNCH();
   }
 
@@ -1006,6 +1035,68 @@ int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* r
   }
   return DMS_OK;
 }
+
+// ---- device-resident variants used by the frame step (fusion_frame.hip) --------------------
+__global__ void k_track_pose_out(const TrackState* __restrict__ st, float* __restrict__ pose16) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) pose16[i * 4 + j] = st->out_rot[i * 3 + j];
+    pose16[i * 4 + 3] = st->out_trans[i];
+  }
+  pose16[12] = 0.f;
+  pose16[13] = 0.f;
+  pose16[14] = 0.f;
+  pose16[15] = 1.f;
+}
+
+int odometry_result_pose(dms_odometry* o, float* pose16_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_track_pose_out, dim3(1), dim3(64), 0, s, o->state, pose16_dev);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int selectCopy16(void* dst, const void* a, const void* b, const int* flag_dev, int force_b, size_t n16, hipStream_t s);
+int transformMapsDev(dms_image2d* v, dms_image2d* n, const float* pose16_dev, hipStream_t s);
+
+// initICPModel with the source chosen on device: (*flag ? fill-in maps : predicted maps), pose read from HBM
+int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA, const float* vB, const float* nB, const int* flag_dev,
+                              const float* pose16_dev, hipStream_t s) {
+  const size_t n16 = (size_t)o->width * o->height;
+  int rc;
+  if ((rc = selectCopy16(o->vmaps_tmp, vA, vB, flag_dev, 0, n16, s))) return rc;
+  if ((rc = selectCopy16(o->nmaps_tmp, nA, nB, flag_dev, 0, n16, s))) return rc;
+  dms_image2d v0 = o->vmaps_g_prev[0].img(), n0 = o->nmaps_g_prev[0].img();
+  if ((rc = copyMaps(o->vmaps_tmp, o->nmaps_tmp, &v0, &n0, s))) return rc;
+  for (int i = 1; i < DMS_NUM_PYRS; ++i) {
+    dms_image2d va = o->vmaps_g_prev[i - 1].img(), vb = o->vmaps_g_prev[i].img();
+    dms_image2d na = o->nmaps_g_prev[i - 1].img(), nb = o->nmaps_g_prev[i].img();
+    if ((rc = resizeMap(&va, &vb, false, s))) return rc;
+    if ((rc = resizeMap(&na, &nb, true, s))) return rc;
+  }
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    dms_image2d v = o->vmaps_g_prev[i].img(), n = o->nmaps_g_prev[i].img();
+    if ((rc = transformMapsDev(&v, &n, pose16_dev, s))) return rc;
+  }
+  return DMS_OK;
+}
+
+// initRGBModel with the image chosen on device; rgba_tmp: W*H*4-byte scratch
+int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rgbaB, const int* flag_dev, int force_b, void* rgba_tmp,
+                              hipStream_t s) {
+  const size_t n16 = ((size_t)o->width * o->height + 3) / 4;  // 4 pixels per 16 bytes (buffers are padded to 16 B)
+  int rc;
+  if ((rc = selectCopy16(rgba_tmp, rgbaA, rgbaB, flag_dev, force_b, n16, s))) return rc;
+  dms_image2d img;
+  img.data = rgba_tmp;
+  img.pitch = (size_t)o->width * 4;
+  img.rows = o->height;
+  img.cols = o->width;
+  return populateRGBDData(o, &img, o->lastDepth, o->lastImage, s);
+}
+
+}  // namespace dms
+
+extern "C" {
 
 int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {
   DMS_REQUIRE(o && r, "null argument");

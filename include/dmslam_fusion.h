@@ -1,0 +1,187 @@
+/*
+ * dmslam_fusion.h — C ABI of the surfel-map half of the hot path: depth pre-filter,
+ * surfel bootstrap, index map, splat prediction, fuse, clean, fill-in, resize, and the
+ * per-camera frame step that chains them with the tracker of dmslam.h.
+ *
+ * Each entry point replaces one GLSL program (+ its C++ wrapper) of the reference; see
+ * SURVEY.md §2.3 rows G1..G11 and the citations below.  The OpenGL rasteriser semantics the
+ * reference relies on (point ownership, 24-bit depth test with GL_LESS, first-drawn-wins,
+ * NEAREST texel fetch at computed coordinates, transform-feedback ordering) are restated as
+ * explicit integer rules — DESIGN.md §"Rasteriser rules".
+ *
+ * Images are dense row-major device arrays:
+ *   rgba8 (4 B/px) · depth u16 mm · metric depth f32 m · RGBA32F maps (16 B/px) · u32 index ·
+ *   u16 time.  Poses are 4×4 row-major float, camera-to-world.
+ */
+#ifndef DMSLAM_FUSION_H_
+#define DMSLAM_FUSION_H_
+
+#include "dmslam.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* surfel map (reference GlobalModel, Core/src/GlobalModel.{h,cpp})            */
+/* ------------------------------------------------------------------------- */
+typedef struct dms_model dms_model;
+
+/* HBM layout: structure-of-arrays of float4 planes (position+confidence, colour+times,
+ * normal+radius) plus one float plane per sensor for the last-seen time, double-buffered for
+ * the order-preserving compaction of `clean`.  capacity = maximum surfel count
+ * (reference MAX_VERTICES = 5700^2, GlobalModel.cpp:22-24). */
+int dms_model_create(dms_model** out, size_t capacity, int width, int height);
+int dms_model_destroy(dms_model* m);
+int dms_model_count(dms_model* m, unsigned int* count, dms_stream s); /* syncs */
+size_t dms_model_capacity(dms_model* m);
+
+/* reference surfel record (Shaders/Vertex.cpp:21-50): 15 floats =
+ * pos.xyz conf | colour 0 initTime stamp | times[3] | normal.xyz radius (60 bytes).
+ * download: reference GlobalModel::downloadMap (GlobalModel.cpp:866-896); sensors 0..2 only. */
+int dms_model_download_ref(dms_model* m, float* host_vertices15, unsigned int max_count, unsigned int* count, dms_stream s);
+int dms_model_upload_ref(dms_model* m, const float* host_vertices15, unsigned int count, dms_stream s);
+/* full-width records: 12 + DMS_MAX_SENSORS floats = pos.xyz conf | colour 0 initTime stamp |
+ * normal.xyz radius | times[DMS_MAX_SENSORS] */
+int dms_model_download(dms_model* m, float* host_records, unsigned int max_count, unsigned int* count, dms_stream s);
+int dms_model_upload(dms_model* m, const float* host_records, unsigned int count, dms_stream s);
+
+/* ------------------------------------------------------------------------- */
+/* operator layer — one per GLSL program                                       */
+/* ------------------------------------------------------------------------- */
+
+/* G1 depth_bilateral.frag:30-75 (ElasticFusion::filterDepth, ElasticFusion.cpp:759-768) */
+int dms_depth_bilateral(const dms_image2d* depth_u16, dms_image2d* filtered_u16, float maxD, dms_stream s);
+/* G2 depth_metric.frag:28-39 (ElasticFusion::metriciseDepth, ElasticFusion.cpp:748-757) */
+int dms_depth_metric(const dms_image2d* depth_u16, dms_image2d* metric_f32, float maxD, dms_stream s);
+
+/* G3+G4 vertex_feedback.{vert,geom} + init_unstable.vert: first-frame surfels
+ * (FeedbackBuffer::compute, FeedbackBuffer.cpp:84-143; GlobalModel::initialise, GlobalModel.cpp:266-417).
+ * Appends nothing: (re)initialises the map from one frame; surfels are emitted in column-major pixel order. */
+int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* depth_metric,
+                         const dms_image2d* depth_metric_filtered, const dms_camera* cam, int time, int timeIdx,
+                         float maxDepth, dms_stream s);
+
+/* index-map render target set (reference IndexMap index framebuffer, IndexMap.cpp:26-39) */
+typedef struct dms_indexmap_out {
+  dms_image2d index;      /* u32   */
+  dms_image2d vertConf;   /* float4: camera-frame position, confidence */
+  dms_image2d colorTime;  /* float4: colour, 0, initTime, times[timeIdx] */
+  dms_image2d normRad;    /* float4: camera-frame normal, radius */
+} dms_indexmap_out;
+
+/* G5 index_map.{vert,frag} (IndexMap::predictIndices, IndexMap.cpp:146-217).
+ * zbuf: W*H u64 scratch.  pose_dev: device pointer to dms_pose_block. */
+typedef struct dms_pose_block {
+  float pose[16];  /* camera-to-world */
+  float t_inv[16]; /* inverse */
+} dms_pose_block;
+int dms_pose_block_set(dms_pose_block* dev, const float* pose16_host, dms_stream s);
+
+int dms_index_map(dms_model* m, const dms_pose_block* pose_dev, const dms_camera* cam, int time, int timeIdx,
+                  float maxDepth, int timeDelta, unsigned long long* zbuf, dms_indexmap_out* out, dms_stream s);
+
+/* splat prediction targets (reference combined / old framebuffers, IndexMap.cpp:59-99) */
+typedef struct dms_predict_out {
+  dms_image2d image;  /* rgba8  */
+  dms_image2d vertex; /* float4 */
+  dms_image2d normal; /* float4 */
+  dms_image2d time;   /* u16    */
+} dms_predict_out;
+
+/* G6 splat.vert + combo_splat.frag (IndexMap::combinedPredict, IndexMap.cpp:253-368).
+ * active = 1 for IndexMap::ACTIVE, 0 for INACTIVE. */
+int dms_splat_predict(dms_model* m, const dms_pose_block* pose_dev, const dms_camera* cam, float maxDepth,
+                      float confThreshold, int time, int timeIdx, int maxTime, int timeDelta, int active,
+                      unsigned long long* zbuf, dms_predict_out* out, dms_stream s);
+/* G6' splat.vert + depth_splat.frag (IndexMap::synthesizeDepth, IndexMap.cpp:370-452) */
+int dms_splat_depth(dms_model* m, const dms_pose_block* pose_dev, const dms_camera* cam, float maxDepth,
+                    float confThreshold, int time, int timeIdx, int maxTime, int timeDelta,
+                    unsigned long long* zbuf, dms_image2d* depth_f32, dms_stream s);
+
+/* G7+G8 data.{vert,geom,frag} + update.vert (GlobalModel::fuse, GlobalModel.cpp:513-694).
+ * weighting_dev may be NULL (then `weighting` is used); otherwise the weight is read on device. */
+int dms_model_fuse(dms_model* m, const dms_pose_block* pose_dev, int time, int timeIdx, const dms_image2d* rgba,
+                   const dms_image2d* depth_metric, const dms_image2d* depth_metric_filtered,
+                   const dms_indexmap_out* indexmap, const dms_camera* cam, float depthCutoff, float weighting,
+                   const float* weighting_dev, dms_stream s);
+
+/* G9 copy_unstable.{vert,geom} (GlobalModel::clean, GlobalModel.cpp:696-853).
+ * graph: host array of 16 floats / node (Deformation.cpp:192-201), may be NULL / 0 nodes.
+ * depth_synth: float depth image used only when nodes > 0. */
+int dms_model_clean(dms_model* m, const dms_pose_block* pose_dev, int time, int timeIdx,
+                    const dms_indexmap_out* indexmap, const dms_image2d* depth_synth, const dms_camera* cam,
+                    float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
+                    int isFern, dms_stream s);
+
+/* G10 fill_{vertex,normal,rgb}.frag (FillIn::{vertex,normal,image}, Shaders/FillIn.cpp:65-190) */
+int dms_fill_in(const dms_predict_out* existing, const dms_image2d* depth_filtered_u16, const dms_image2d* rgba,
+                const dms_camera* cam, int passthrough_geom, int passthrough_rgb, dms_predict_out* filled, dms_stream s);
+
+/* G11 resize.frag (Resize::{image,vertex,time}, Shaders/Resize.cpp:67-170): nearest subsample.
+ * elem_bytes = 4 (rgba8), 16 (float4) or 2 (u16). */
+int dms_resize_nn(const dms_image2d* src, dms_image2d* dst, int elem_bytes, dms_stream s);
+
+/* ------------------------------------------------------------------------- */
+/* object layer — one camera's frame step (ElasticFusion::processFrame)        */
+/* ------------------------------------------------------------------------- */
+typedef struct dms_fusion dms_fusion;
+
+/* subset of the reference's ElasticFusion constructor arguments that reach the hot path
+ * (ElasticFusion.cpp:22-73) plus the per-camera options read in processFrame */
+typedef struct dms_fusion_params {
+  int width, height;
+  float fx, fy, cx, cy;
+  int timeDelta;             /* default 200 */
+  float confidence;          /* confidenceThreshold, default 10 */
+  float depthCut;            /* depthCutoff (m), default 3 */
+  float icpWeight;           /* icpThresh, default 10 */
+  int fastOdom;              /* --fo */
+  int so3;                   /* !--nso */
+  int frameToFrameRGB;       /* --ftf */
+  int pyramid;               /* GUI toggle, default 1 */
+  int hybrid_tracking;       /* --hybrid_tracking: refine the prior with the dense tracker */
+  int rgbOnly;               /* Context::rgbOnly() */
+  int timeIdx;               /* Context::id(): which per-sensor time slot this camera uses */
+  float maxDepthProcessed;   /* 25 (ElasticFusion.cpp:56) */
+  size_t model_capacity;     /* 0 = reference MAX_VERTICES */
+} dms_fusion_params;
+
+void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
+
+int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p);
+int dms_fusion_destroy(dms_fusion* f);
+
+/* Per-frame outputs */
+typedef struct dms_frame_result {
+  float pose[16];          /* camera-to-world after tracking */
+  unsigned int surfels;    /* map size after clean */
+  int tick;                /* Context::tick() after the frame */
+  int fused;               /* 1 when the fusion half ran */
+  int fill_in;             /* shouldFillIn decision (ElasticFusion.cpp:167) */
+  float weighting;         /* velocity weight (ElasticFusion.cpp:252-268) */
+  dms_track_result track;  /* tracker side outputs */
+} dms_frame_result;
+
+/* ElasticFusion::processFrame (ElasticFusion.cpp:99-637) for one camera with loop closure off
+ * (--o) and NID keyframing off (--nkf): upload-free — rgb (RGB8 or RGBA8 per `rgb_channels`)
+ * and depth (u16 mm) are device pointers already resident in HBM.  inPose: host 4×4 prior or
+ * NULL (then the previous pose is used; the reference would dereference NULL,
+ * ElasticFusion.cpp:164).  Asynchronous on `s`; dms_fusion_fetch syncs and returns the result. */
+int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev,
+                             const float* inPose16, float weightMultiplier, dms_stream s);
+int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream s);
+
+dms_model* dms_fusion_model(dms_fusion* f);
+dms_odometry* dms_fusion_odometry(dms_fusion* f);
+/* device images owned by the context; which: 0 rgb(rgba8) 1 depth_raw 2 depth_filtered 3 depth_metric
+ * 4 depth_metric_filtered 5 index 6 vertConf 7 colorTime 8 normRad 9 pred image 10 pred vertex
+ * 11 pred normal 12 pred time 13 fill image 14 fill vertex 15 fill normal */
+int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view);
+int dms_fusion_set_profiling(dms_fusion* f, int enabled);
+int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMSLAM_FUSION_H_ */
