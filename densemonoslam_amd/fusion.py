@@ -1,0 +1,348 @@
+"""Python mirror of the reference's surfel-map API over the C ABI (include/dmslam_fusion.h).
+
+Names follow the reference: `GlobalModel` (Core/src/GlobalModel.h:43-141), `IndexMap`
+(Core/src/IndexMap.h:33-205), `ElasticFusion.processFrame` (Core/src/ElasticFusion.h:92-100).
+All work happens on the GPU inside libdmslam_hip.so; numpy only crosses at upload / download.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Camera, DeviceBuffer, DeviceImage, Image2D, TrackResult, check, lib
+
+MAX_SENSORS = capi.MAX_SENSORS
+SURFEL_DTYPE = np.dtype([("pos", "<f4", (4,)), ("col", "<f4", (4,)), ("nrm", "<f4", (4,)), ("times", "<f4", (MAX_SENSORS,))])
+
+
+class PoseBlock(C.Structure):
+    _fields_ = [("pose", C.c_float * 16), ("t_inv", C.c_float * 16)]
+
+
+class IndexMapOut(C.Structure):
+    _fields_ = [("index", Image2D), ("vertConf", Image2D), ("colorTime", Image2D), ("normRad", Image2D)]
+
+
+class PredictOut(C.Structure):
+    _fields_ = [("image", Image2D), ("vertex", Image2D), ("normal", Image2D), ("time", Image2D)]
+
+
+class FusionParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("timeDelta", C.c_int), ("confidence", C.c_float), ("depthCut", C.c_float), ("icpWeight", C.c_float),
+        ("fastOdom", C.c_int), ("so3", C.c_int), ("frameToFrameRGB", C.c_int), ("pyramid", C.c_int),
+        ("hybrid_tracking", C.c_int), ("rgbOnly", C.c_int), ("timeIdx", C.c_int),
+        ("maxDepthProcessed", C.c_float), ("model_capacity", C.c_size_t),
+    ]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [
+        ("pose", C.c_float * 16), ("surfels", C.c_uint), ("tick", C.c_int), ("fused", C.c_int), ("fill_in", C.c_int),
+        ("weighting", C.c_float), ("track", TrackResult),
+    ]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_I2 = C.POINTER(Image2D)
+_K = C.POINTER(Camera)
+lib.dms_model_create.argtypes = [C.POINTER(_P), C.c_size_t, _I, _I]
+lib.dms_model_destroy.argtypes = [_P]
+lib.dms_model_count.argtypes = [_P, C.POINTER(C.c_uint), _P]
+lib.dms_model_capacity.argtypes = [_P]
+lib.dms_model_capacity.restype = C.c_size_t
+lib.dms_model_download.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_uint), _P]
+lib.dms_model_upload.argtypes = [_P, _P, C.c_uint, _P]
+lib.dms_model_download_ref.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_uint), _P]
+lib.dms_model_upload_ref.argtypes = [_P, _P, C.c_uint, _P]
+lib.dms_depth_bilateral.argtypes = [_I2, _I2, _F, _P]
+lib.dms_depth_metric.argtypes = [_I2, _I2, _F, _P]
+lib.dms_model_initialise.argtypes = [_P, _I2, _I2, _I2, _K, _I, _I, _F, _P]
+lib.dms_pose_block_set.argtypes = [_P, C.POINTER(C.c_float), _P]
+lib.dms_index_map.argtypes = [_P, _P, _K, _I, _I, _F, _I, _P, C.POINTER(IndexMapOut), _P]
+lib.dms_splat_predict.argtypes = [_P, _P, _K, _F, _F, _I, _I, _I, _I, _I, _P, C.POINTER(PredictOut), _P]
+lib.dms_splat_depth.argtypes = [_P, _P, _K, _F, _F, _I, _I, _I, _I, _P, _I2, _P]
+lib.dms_model_fuse.argtypes = [_P, _P, _I, _I, _I2, _I2, _I2, C.POINTER(IndexMapOut), _K, _F, _F, _P, _P]
+lib.dms_model_clean.argtypes = [_P, _P, _I, _I, C.POINTER(IndexMapOut), _I2, _K, _F, C.POINTER(C.c_float), _I, _I, _F, _I, _P]
+lib.dms_fill_in.argtypes = [C.POINTER(PredictOut), _I2, _I2, _K, _I, _I, C.POINTER(PredictOut), _P]
+lib.dms_resize_nn.argtypes = [_I2, _I2, _I, _P]
+lib.dms_fusion_default_params.argtypes = [C.POINTER(FusionParams), _I, _I, _F, _F, _F, _F]
+lib.dms_fusion_default_params.restype = None
+lib.dms_fusion_create.argtypes = [C.POINTER(_P), C.POINTER(FusionParams)]
+lib.dms_fusion_destroy.argtypes = [_P]
+lib.dms_fusion_process_frame.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_float), _F, _P]
+lib.dms_fusion_fetch.argtypes = [_P, C.POINTER(FrameResult), _P]
+lib.dms_fusion_model.argtypes = [_P]
+lib.dms_fusion_model.restype = _P
+lib.dms_fusion_odometry.argtypes = [_P]
+lib.dms_fusion_odometry.restype = _P
+lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
+lib.dms_fusion_set_profiling.argtypes = [_P, _I]
+lib.dms_fusion_get_kernel_time.argtypes = [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+
+def _cam(K):
+    return Camera(*[float(v) for v in K])  # (fx, fy, cx, cy)
+
+
+def _img(a, dtype=None):
+    if isinstance(a, DeviceImage):
+        return a
+    return DeviceImage.from_array(a if dtype is None else np.asarray(a, dtype))
+
+
+class DevicePose:
+    """dms_pose_block in HBM: pose + its inverse (Eigen Matrix4f::inverse on the reference side)."""
+
+    def __init__(self, pose=None):
+        self.buf = DeviceBuffer(C.sizeof(PoseBlock))
+        self.set(np.eye(4, dtype=np.float32) if pose is None else pose)
+
+    def set(self, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(16)
+        check(lib.dms_pose_block_set(C.c_void_p(self.buf.ptr), p.ctypes.data_as(C.POINTER(C.c_float)), None), "dms_pose_block_set")
+        return self
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.ptr)
+
+    def download(self):
+        raw = self.buf.download(np.float32, (32,))
+        return raw[:16].reshape(4, 4), raw[16:].reshape(4, 4)
+
+
+# ---- image-stage operators -------------------------------------------------------------------
+def depth_bilateral(depth_u16, maxD):
+    d = _img(depth_u16, np.uint16)
+    out = DeviceImage(d.rows, d.cols, np.uint16)
+    check(lib.dms_depth_bilateral(d.ref, out.ref, maxD, None), "dms_depth_bilateral")
+    return out
+
+
+def depth_metric(depth_u16, maxD):
+    d = _img(depth_u16, np.uint16)
+    out = DeviceImage(d.rows, d.cols, np.float32)
+    check(lib.dms_depth_metric(d.ref, out.ref, maxD, None), "dms_depth_metric")
+    return out
+
+
+def resize_nn(src, drows, dcols):
+    s = _img(src)
+    elem = s.dtype.itemsize
+    out = DeviceImage(drows, dcols, s.dtype)
+    check(lib.dms_resize_nn(s.ref, out.ref, elem, None), "dms_resize_nn")
+    return out
+
+
+class PredictionImages:
+    """image RGBA8 + vertex/normal RGBA32F + time u16 (IndexMap combined / old framebuffers)."""
+
+    def __init__(self, rows, cols):
+        self.image = DeviceImage(rows, cols, np.dtype((np.uint8, (4,))))
+        self.vertex = DeviceImage(rows, cols, np.dtype((np.float32, (4,))))
+        self.normal = DeviceImage(rows, cols, np.dtype((np.float32, (4,))))
+        self.time = DeviceImage(rows, cols, np.uint16)
+        self.c = PredictOut(self.image.view, self.vertex.view, self.normal.view, self.time.view)
+
+    def download(self):
+        return self.image.download(), self.vertex.download(), self.normal.download(), self.time.download()
+
+
+def fill_in(existing, depth_filtered_u16, rgba, K, passthrough_geom=False, passthrough_rgb=False):
+    d, c = _img(depth_filtered_u16, np.uint16), _img(rgba, np.uint8)
+    out = PredictionImages(d.rows, d.cols)
+    k = _cam(K)
+    check(lib.dms_fill_in(C.byref(existing.c), d.ref, c.ref, C.byref(k), int(passthrough_geom), int(passthrough_rgb), C.byref(out.c), None),
+          "dms_fill_in")
+    return out
+
+
+class GlobalModel:
+    """Surfel map in HBM (reference class GlobalModel)."""
+
+    def __init__(self, width, height, capacity=1 << 20, handle=None):
+        self.width, self.height = width, height
+        self._owned = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            check(lib.dms_model_create(C.byref(h), capacity, width, height), "dms_model_create")
+            self.h = h
+        else:
+            self.h = C.c_void_p(handle)
+        self.zbuf = DeviceBuffer(width * height * 8)
+
+    def close(self):
+        if getattr(self, "h", None) and self._owned:
+            lib.dms_model_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lastCount(self):
+        n = C.c_uint(0)
+        check(lib.dms_model_count(self.h, C.byref(n), None), "dms_model_count")
+        return n.value
+
+    def upload(self, surfels):
+        s = np.ascontiguousarray(surfels, SURFEL_DTYPE)
+        check(lib.dms_model_upload(self.h, s.ctypes.data_as(C.c_void_p), len(s), None), "dms_model_upload")
+
+    def downloadMap(self):
+        n = self.lastCount()
+        out = np.zeros(max(n, 1), SURFEL_DTYPE)
+        got = C.c_uint(0)
+        check(lib.dms_model_download(self.h, out.ctypes.data_as(C.c_void_p), n, C.byref(got), None), "dms_model_download")
+        return out[:got.value].copy()
+
+    def downloadMapRef(self):
+        """The reference's 15-float / 60-byte records (Shaders/Vertex.cpp:21-50)."""
+        n = self.lastCount()
+        out = np.zeros((max(n, 1), 15), np.float32)
+        got = C.c_uint(0)
+        check(lib.dms_model_download_ref(self.h, out.ctypes.data_as(C.c_void_p), n, C.byref(got), None), "dms_model_download_ref")
+        return out[:got.value].copy()
+
+    def initialise(self, rgba, depth_metric, depth_metric_filtered, K, time, timeIdx, maxDepth):
+        c, dm, dmf = _img(rgba, np.uint8), _img(depth_metric, np.float32), _img(depth_metric_filtered, np.float32)
+        k = _cam(K)
+        check(lib.dms_model_initialise(self.h, c.ref, dm.ref, dmf.ref, C.byref(k), time, timeIdx, maxDepth, None), "dms_model_initialise")
+
+    def fuse(self, pose, time, timeIdx, rgba, depth_metric, depth_metric_filtered, indexmap, K, depthCutoff, weighting):
+        c, dm, dmf = _img(rgba, np.uint8), _img(depth_metric, np.float32), _img(depth_metric_filtered, np.float32)
+        k = _cam(K)
+        check(lib.dms_model_fuse(self.h, pose.ptr, time, timeIdx, c.ref, dm.ref, dmf.ref, C.byref(indexmap.c), C.byref(k), depthCutoff,
+                                 weighting, None, None), "dms_model_fuse")
+
+    def clean(self, pose, time, timeIdx, indexmap, K, confThreshold, timeDelta, maxDepth, graph=None, depth_synth=None, isFern=False):
+        k = _cam(K)
+        gptr, gn = None, 0
+        if graph is not None and len(graph):
+            g = np.ascontiguousarray(graph, np.float32).reshape(-1, 16)
+            gptr, gn = g.ctypes.data_as(C.POINTER(C.c_float)), len(g)
+        dref = None
+        if depth_synth is not None:
+            self._ds = _img(depth_synth, np.float32)
+            dref = self._ds.ref
+        check(lib.dms_model_clean(self.h, pose.ptr, time, timeIdx, C.byref(indexmap.c), dref, C.byref(k), confThreshold, gptr, gn, timeDelta,
+                                  maxDepth, int(isFern), None), "dms_model_clean")
+        check(lib.dms_stream_sync(None))
+
+
+class IndexMap:
+    """Model rendering into the camera (reference class IndexMap)."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+        f4 = np.dtype((np.float32, (4,)))
+        self.index = DeviceImage(height, width, np.uint32)
+        self.vertConf = DeviceImage(height, width, f4)
+        self.colorTime = DeviceImage(height, width, f4)
+        self.normRad = DeviceImage(height, width, f4)
+        self.c = IndexMapOut(self.index.view, self.vertConf.view, self.colorTime.view, self.normRad.view)
+        self.active = PredictionImages(height, width)
+        self.inactive = PredictionImages(height, width)
+        self.depth = DeviceImage(height, width, np.float32)
+
+    def predictIndices(self, pose, time, timeIdx, model, K, depthCutoff, timeDelta):
+        k = _cam(K)
+        check(lib.dms_index_map(model.h, pose.ptr, C.byref(k), time, timeIdx, depthCutoff, timeDelta, C.c_void_p(model.zbuf.ptr),
+                                C.byref(self.c), None), "dms_index_map")
+
+    def combinedPredict(self, pose, model, K, depthCutoff, confThreshold, time, timeIdx, maxTime, timeDelta, active=True):
+        k = _cam(K)
+        tgt = self.active if active else self.inactive
+        check(lib.dms_splat_predict(model.h, pose.ptr, C.byref(k), depthCutoff, confThreshold, time, timeIdx, maxTime, timeDelta,
+                                    1 if active else 0, C.c_void_p(model.zbuf.ptr), C.byref(tgt.c), None), "dms_splat_predict")
+        return tgt
+
+    def synthesizeDepth(self, pose, model, K, depthCutoff, confThreshold, time, timeIdx, maxTime, timeDelta):
+        k = _cam(K)
+        check(lib.dms_splat_depth(model.h, pose.ptr, C.byref(k), depthCutoff, confThreshold, time, timeIdx, maxTime, timeDelta,
+                                  C.c_void_p(model.zbuf.ptr), self.depth.ref, None), "dms_splat_depth")
+        return self.depth
+
+    def download_index(self):
+        return self.index.download(), self.vertConf.download(), self.colorTime.download(), self.normRad.download()
+
+
+_IMG_TYPES = {0: (np.uint8, 4), 1: (np.uint16, 1), 2: (np.uint16, 1), 3: (np.float32, 1), 4: (np.float32, 1), 5: (np.uint32, 1),
+              6: (np.float32, 4), 7: (np.float32, 4), 8: (np.float32, 4), 9: (np.uint8, 4), 10: (np.float32, 4), 11: (np.float32, 4),
+              12: (np.uint16, 1), 13: (np.uint8, 4), 14: (np.float32, 4), 15: (np.float32, 4)}
+
+
+class ElasticFusion:
+    """One camera's frame step (ElasticFusion::processFrame with --o --nkf)."""
+
+    def __init__(self, width, height, K, **opts):
+        p = FusionParams()
+        lib.dms_fusion_default_params(C.byref(p), width, height, K[0], K[1], K[2], K[3])
+        for k, v in opts.items():
+            if not hasattr(p, k):
+                raise TypeError("unknown option %r" % k)
+            setattr(p, k, v)
+        self.params = p
+        h = C.c_void_p()
+        check(lib.dms_fusion_create(C.byref(h), C.byref(p)), "dms_fusion_create")
+        self.h = h
+        self.width, self.height = width, height
+        self._rgb = DeviceBuffer(width * height * 4)
+        self._depth = DeviceBuffer(width * height * 2)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.dms_fusion_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_frame(self, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        self._rgb.upload(rgb)
+        self._depth.upload(np.ascontiguousarray(depth, np.uint16))
+        return rgb.shape[2]
+
+    def processFrameAsync(self, rgb_ptr, channels, depth_ptr, inPose=None, weightMultiplier=1.0, stream=None):
+        pp = None
+        if inPose is not None:
+            self._pose = np.ascontiguousarray(inPose, np.float32).reshape(16)
+            pp = self._pose.ctypes.data_as(C.POINTER(C.c_float))
+        check(lib.dms_fusion_process_frame(self.h, C.c_void_p(rgb_ptr), channels, C.c_void_p(depth_ptr), pp, weightMultiplier, stream),
+              "dms_fusion_process_frame")
+
+    def fetch(self, stream=None):
+        r = FrameResult()
+        check(lib.dms_fusion_fetch(self.h, C.byref(r), stream), "dms_fusion_fetch")
+        return r
+
+    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0):
+        ch = self.upload_frame(rgb, depth)
+        self.processFrameAsync(self._rgb.ptr, ch, self._depth.ptr, inPose, weightMultiplier)
+        return self.fetch()
+
+    def globalModel(self):
+        return GlobalModel(self.width, self.height, handle=lib.dms_fusion_model(self.h))
+
+    def image(self, which):
+        v = Image2D()
+        check(lib.dms_fusion_get_image(self.h, which, C.byref(v)), "dms_fusion_get_image")
+        dt, k = _IMG_TYPES[which]
+        return capi.download_view(v, dt, k)
+
+    def set_profiling(self, on):
+        check(lib.dms_fusion_set_profiling(self.h, int(on)))
+
+    def kernel_time(self, name):
+        ms, n = C.c_double(0), C.c_int(0)
+        check(lib.dms_fusion_get_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -314,3 +314,153 @@ def covariance(lastA):
     out = np.zeros(36, np.float64)
     lib.orc_covariance(_p(a), _p(out))
     return out.reshape(6, 6)
+
+
+# =============================================================================================
+# fusion half (oracle/orc_fusion.c)
+# =============================================================================================
+MAX_SENSORS = 8
+SURFEL_DTYPE = np.dtype([("pos", "<f4", (4,)), ("col", "<f4", (4,)), ("nrm", "<f4", (4,)), ("times", "<f4", (MAX_SENSORS,))])
+assert SURFEL_DTYPE.itemsize == 4 * (12 + MAX_SENSORS)
+
+lib.orc_inv4f.argtypes = [_P, _P]
+lib.orc_depth_bilateral.argtypes = [_P, _I, _I, _F, _P]
+lib.orc_depth_metric.argtypes = [_P, _I, _I, _F, _P]
+lib.orc_model_initialise.argtypes = [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _F, _P, _I]
+lib.orc_model_initialise.restype = _I
+lib.orc_index_map.argtypes = [_P, _I, _P, _F, _F, _F, _F, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P]
+lib.orc_splat_predict.argtypes = [_P, _I, _P, _F, _F, _F, _F, _I, _I, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]
+lib.orc_model_fuse.argtypes = [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, C.POINTER(C.c_int)]
+lib.orc_model_fuse.restype = _I
+lib.orc_model_clean.argtypes = [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _I, _I, _F, _I, _P, _I]
+lib.orc_model_clean.restype = _I
+lib.orc_fill_in.argtypes = [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _P, _P, _P]
+lib.orc_resize_nn.argtypes = [_P, _I, _I, _P, _I, _I, _I]
+lib.orc_dense_enough.argtypes = [_P, _I, _I]
+lib.orc_dense_enough.restype = _I
+lib.orc_velocity_weight.argtypes = [_P, _P, _F]
+lib.orc_velocity_weight.restype = C.c_float
+
+
+def inv4f(m):
+    m = _c(m, np.float32).reshape(16)
+    o = np.zeros(16, np.float32)
+    lib.orc_inv4f(_p(m), _p(o))
+    return o.reshape(4, 4)
+
+
+def depth_bilateral(depth, maxD):
+    d = _c(depth, np.uint16)
+    out = np.zeros_like(d)
+    lib.orc_depth_bilateral(_p(d), d.shape[0], d.shape[1], maxD, _p(out))
+    return out
+
+
+def depth_metric(depth, maxD):
+    d = _c(depth, np.uint16)
+    out = np.zeros(d.shape, np.float32)
+    lib.orc_depth_metric(_p(d), d.shape[0], d.shape[1], maxD, _p(out))
+    return out
+
+
+def model_initialise(rgba, dm, dmf, cam, time, timeIdx, maxDepth, cap=None):
+    rgba, dm, dmf = _c(rgba, np.uint8), _c(dm, np.float32), _c(dmf, np.float32)
+    rows, cols = dm.shape
+    cap = rows * cols if cap is None else cap
+    out = np.zeros(cap, SURFEL_DTYPE)
+    n = lib.orc_model_initialise(_p(rgba), _p(dm), _p(dmf), rows, cols, cam[2], cam[3], cam[0], cam[1], time, timeIdx, maxDepth, _p(out), cap)
+    assert n >= 0, "raw / filtered feedback buffers have different lengths: the reference would pair mismatched streams"
+    return out[:n].copy()
+
+
+def index_map(model, pose, cam, rows, cols, time, timeIdx, maxDepth, timeDelta):
+    model = np.ascontiguousarray(model, SURFEL_DTYPE)
+    pose = _c(pose, np.float32).reshape(16)
+    index = np.zeros((rows, cols), np.uint32)
+    vc, ct, nr = (np.zeros((rows, cols, 4), np.float32) for _ in range(3))
+    lib.orc_index_map(_p(model), len(model), _p(pose), cam[2], cam[3], cam[0], cam[1], rows, cols, time, timeIdx, maxDepth, timeDelta,
+                      _p(index), _p(vc), _p(ct), _p(nr))
+    return index, vc, ct, nr
+
+
+def splat_predict(model, pose, cam, rows, cols, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, active, depth_only=False):
+    model = np.ascontiguousarray(model, SURFEL_DTYPE)
+    pose = _c(pose, np.float32).reshape(16)
+    if depth_only:
+        d = np.zeros((rows, cols), np.float32)
+        lib.orc_splat_predict(_p(model), len(model), _p(pose), cam[2], cam[3], cam[0], cam[1], rows, cols, maxDepth, confThreshold, time,
+                              timeIdx, maxTime, timeDelta, 0, None, None, None, None, _p(d))
+        return d
+    image = np.zeros((rows, cols, 4), np.uint8)
+    vertex = np.zeros((rows, cols, 4), np.float32)
+    normal = np.zeros((rows, cols, 4), np.float32)
+    timg = np.zeros((rows, cols), np.uint16)
+    lib.orc_splat_predict(_p(model), len(model), _p(pose), cam[2], cam[3], cam[0], cam[1], rows, cols, maxDepth, confThreshold, time,
+                          timeIdx, maxTime, timeDelta, int(active), _p(image), _p(vertex), _p(normal), _p(timg), None)
+    return image, vertex, normal, timg
+
+
+def model_fuse(model, pose, time, timeIdx, rgba, dr, drf, index, vertConf, normRad, cam, maxDepth, weighting):
+    """Returns (updated model, newUnstable list, merged count)."""
+    model = np.ascontiguousarray(model, SURFEL_DTYPE).copy()
+    pose = _c(pose, np.float32).reshape(16)
+    rgba, dr, drf = _c(rgba, np.uint8), _c(dr, np.float32), _c(drf, np.float32)
+    index, vertConf, normRad = _c(index, np.uint32), _c(vertConf, np.float32), _c(normRad, np.float32)
+    rows, cols = dr.shape
+    newU = np.zeros(rows * cols, SURFEL_DTYPE)
+    nnew = C.c_int(0)
+    merged = lib.orc_model_fuse(_p(model), len(model), _p(pose), time, timeIdx, _p(rgba), _p(dr), _p(drf), _p(index), _p(vertConf),
+                                _p(normRad), rows, cols, cam[2], cam[3], cam[0], cam[1], maxDepth, weighting, _p(newU), C.byref(nnew))
+    return model, newU[:nnew.value].copy(), merged
+
+
+def model_clean(model, newU, pose, time, timeIdx, index, vertConf, colorTime, cam, confThreshold, timeDelta, maxDepth, nodes=None,
+                depthSynth=None, isFern=0, cap=None):
+    model = np.ascontiguousarray(model, SURFEL_DTYPE)
+    newU = np.ascontiguousarray(newU, SURFEL_DTYPE)
+    pose = _c(pose, np.float32).reshape(16)
+    index, vertConf, colorTime = _c(index, np.uint32), _c(vertConf, np.float32), _c(colorTime, np.float32)
+    rows, cols = index.shape
+    cap = len(model) + len(newU) if cap is None else cap
+    out = np.zeros(max(cap, 1), SURFEL_DTYPE)
+    nn = 0
+    nptr = None
+    if nodes is not None and len(nodes):
+        nodes = _c(nodes, np.float32).reshape(-1, 16)
+        nn, nptr = len(nodes), _p(nodes)
+    dptr = None
+    if depthSynth is not None:
+        depthSynth = _c(depthSynth, np.float32)
+        dptr = _p(depthSynth)
+    n = lib.orc_model_clean(_p(model), len(model), _p(newU), len(newU), _p(pose), time, timeIdx, _p(index), _p(vertConf), _p(colorTime),
+                            dptr, rows, cols, cam[2], cam[3], cam[0], cam[1], confThreshold, nptr, nn, timeDelta, maxDepth, isFern,
+                            _p(out), cap)
+    return out[:n].copy()
+
+
+def fill_in(exVertex, exNormal, exImage, depth, rgba, cam, passGeom, passRgb):
+    exVertex, exNormal = _c(exVertex, np.float32), _c(exNormal, np.float32)
+    exImage, rgba, depth = _c(exImage, np.uint8), _c(rgba, np.uint8), _c(depth, np.uint16)
+    rows, cols = depth.shape
+    ov, on, oi = np.zeros_like(exVertex), np.zeros_like(exNormal), np.zeros_like(exImage)
+    lib.orc_fill_in(_p(exVertex), _p(exNormal), _p(exImage), _p(depth), _p(rgba), rows, cols, cam[2], cam[3], cam[0], cam[1],
+                    int(passGeom), int(passRgb), _p(ov), _p(on), _p(oi))
+    return ov, on, oi
+
+
+def resize_nn(src, drows, dcols):
+    src = np.ascontiguousarray(src)
+    elem = src.dtype.itemsize * (int(np.prod(src.shape[2:])) if src.ndim > 2 else 1)
+    dst = np.zeros((drows, dcols) + src.shape[2:], src.dtype)
+    lib.orc_resize_nn(_p(src), src.shape[0], src.shape[1], _p(dst), drows, dcols, elem)
+    return dst
+
+
+def dense_enough(image_rgba):
+    a = _c(image_rgba, np.uint8)
+    return bool(lib.orc_dense_enough(_p(a), a.shape[0], a.shape[1]))
+
+
+def velocity_weight(currPose, lastPose, weightMultiplier):
+    a, b = _c(currPose, np.float32).reshape(16), _c(lastPose, np.float32).reshape(16)
+    return float(lib.orc_velocity_weight(_p(a), _p(b), weightMultiplier))

@@ -1,0 +1,109 @@
+"""CPU ORACLE (test infrastructure): ElasticFusion::processFrame for one camera, restated over
+the oracle's C functions (oracle/orc_*.c) with host arrays.
+
+Follows elasticfusion/Core/src/ElasticFusion.cpp:99-637 with loop closure off (--o: the
+`closeLoops` block :399-497 is skipped), NID keyframing off (--nkf: fuseFrame returns true,
+:639-645), no relocalisation (--rl off: trackingOk is always true, :204-244), cluster 0.
+The deformation graph is empty (it is only filled by loop closures), so clean() runs without
+nodes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import numpy as np
+
+from . import orc
+
+
+class Frame:
+    pass
+
+
+class ElasticFusion:
+    def __init__(self, width, height, K, timeDelta=200, confidence=10.0, depthCut=3.0, icpWeight=10.0, fastOdom=False, so3=True,
+                 frameToFrameRGB=False, pyramid=True, hybrid_tracking=True, rgbOnly=False, timeIdx=0, maxDepthProcessed=25.0,
+                 model_capacity=None):
+        self.W, self.H, self.K = width, height, tuple(float(v) for v in K)
+        self.timeDelta, self.confidence, self.depthCut, self.icpWeight = timeDelta, confidence, depthCut, icpWeight
+        self.fastOdom, self.so3, self.frameToFrameRGB, self.pyramid = fastOdom, so3, frameToFrameRGB, pyramid
+        self.hybrid_tracking, self.rgbOnly, self.timeIdx = hybrid_tracking, rgbOnly, timeIdx
+        self.maxDepthProcessed = maxDepthProcessed
+        self.cap = model_capacity
+        fx, fy, cx, cy = self.K
+        self.frameToModel = orc.Odometry(width, height, cx, cy, fx, fy)
+        self.model = np.zeros(0, orc.SURFEL_DTYPE)
+        self.currPose = np.eye(4, dtype=np.float32)
+        self.tick = 1
+        self.initialised = False
+        self.last = Frame()
+
+    # ElasticFusion::predict (:688-746)
+    def predict(self, confidence):
+        img, vtx, nrm, tim = orc.splat_predict(self.model, self.currPose, self.K, self.H, self.W, self.maxDepthProcessed, confidence,
+                                               self.tick, self.timeIdx, self.tick, self.timeDelta, True)
+        fv, fn, fi = orc.fill_in(vtx, nrm, img, self.depth_filtered, self.rgba, self.K, False, self.frameToFrameRGB)
+        self.pred = (img, vtx, nrm, tim)
+        self.fill = (fi, fv, fn)
+
+    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        if rgb.shape[2] == 3:
+            rgb = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        self.rgba = rgb
+        depth = np.ascontiguousarray(depth, np.uint16)
+        # filterDepth / metriciseDepth (:118-119, :748-768)
+        self.depth_filtered = orc.depth_bilateral(depth, self.depthCut)
+        self.depth_metric = orc.depth_metric(depth, self.depthCut)
+        self.depth_metric_filtered = orc.depth_metric(self.depth_filtered, self.depthCut)
+        out = Frame()
+        out.fill_in = False
+        out.weighting = 1.0
+        out.track = None
+        fused = False
+        if not self.initialised:  # first run (:132-152)
+            pose = np.eye(4, dtype=np.float32) if inPose is None else np.asarray(inPose, np.float32).reshape(4, 4)
+            self.currPose = pose.copy()
+            # computeFeedbackBuffers(const int& maxDepthProcessed): 25.0f -> 25 (Context.h:211)
+            self.model = orc.model_initialise(self.rgba, self.depth_metric, self.depth_metric_filtered, self.K, self.tick, self.timeIdx,
+                                              float(int(self.maxDepthProcessed)), self.cap)
+            self.frameToModel.initFirstRGB(self.rgba)
+            self.initialised = True
+            fused = True
+        else:
+            lastPose = self.currPose.copy()  # :158
+            if inPose is not None:  # :164 (the reference dereferences NULL; the previous pose is used instead)
+                self.currPose = np.asarray(inPose, np.float32).reshape(4, 4).copy()
+            self.predict(0.7)  # :165
+            shouldFillIn = not orc.dense_enough(self.pred[0])  # :166-167
+            out.fill_in = shouldFillIn
+            if self.hybrid_tracking:
+                vtx, nrm = (self.fill[1], self.fill[2]) if shouldFillIn else (self.pred[1], self.pred[2])
+                self.frameToModel.initICPModel(vtx, nrm, self.maxDepthProcessed, self.currPose)  # :173-178
+                self.frameToModel.initRGBModel(self.fill[0] if (shouldFillIn or self.frameToFrameRGB) else self.pred[0])  # :179-181
+                self.frameToModel.initICP(self.depth_filtered, self.maxDepthProcessed)  # :183-184
+                self.frameToModel.initRGB(self.rgba)  # :185
+                t, R, res = self.frameToModel.getIncrementalTransformation(self.currPose[:3, 3], self.currPose[:3, :3], self.rgbOnly,
+                                                                         self.icpWeight, self.pyramid, self.fastOdom, self.so3)
+                self.currPose[:3, 3] = t
+                self.currPose[:3, :3] = R
+                out.track = res
+            weighting = orc.velocity_weight(self.currPose, lastPose, weightMultiplier)  # :252-268
+            out.weighting = weighting
+            self.predict(self.confidence)  # :273
+            if not self.rgbOnly:  # fusion (:506-564)
+                im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed,
+                                   self.timeDelta)
+                self.model, newU, _ = orc.model_fuse(self.model, self.currPose, self.tick, self.timeIdx, self.rgba, self.depth_metric,
+                                                     self.depth_metric_filtered, im[0], im[1], im[3], self.K, self.maxDepthProcessed,
+                                                     weighting)
+                im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed,
+                                   self.timeDelta)
+                self.imap = im
+                self.model = orc.model_clean(self.model, newU, self.currPose, self.tick, self.timeIdx, im[0], im[1], im[2], self.K,
+                                             self.confidence, self.timeDelta, self.maxDepthProcessed, cap=self.cap)
+                fused = True
+        self.predict(self.confidence)  # finalPredict (:586)
+        self.tick += 1  # :588-591
+        out.pose = self.currPose.copy()
+        out.surfels = len(self.model)
+        out.fused = fused
+        out.tick = self.tick
+        self.last = out
+        return out

@@ -1,0 +1,383 @@
+"""GPU parity tests of the surfel-map half: HIP (through the C ABI) vs the CPU oracle.
+
+Bar: everything in this half is per-pixel / per-surfel arithmetic with no cross-element
+floating-point reduction, so every output — surfel ids, counts, order, and every float
+attribute — must be BIT-EXACT against the oracle on the same inputs (the oracle executes the
+OpenGL semantics sequentially; the HIP path uses atomic z-buffers and parallel compaction).
+"""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 240
+K = (264.0, 264.0, 160.0, 120.0)  # fx, fy, cx, cy
+
+
+@pytest.fixture(scope="module")
+def fus():
+    from densemonoslam_amd import capi, fusion
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    return fusion
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from densemonoslam_amd import synth as s
+
+    return s
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def assert_bits(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.tobytes() != b.tobytes():
+        av, bv = a.reshape(-1).view(np.uint8), b.reshape(-1).view(np.uint8)
+        bad = np.flatnonzero(av != bv)
+        raise AssertionError("%s: %d differing bytes, first at byte %d" % (what, bad.size, bad[0]))
+
+
+def surfels_equal(a, b, what=""):
+    assert len(a) == len(b), "%s: surfel count %d vs %d" % (what, len(a), len(b))
+    for f in ("pos", "col", "nrm", "times"):
+        assert_bits(a[f], b[f], "%s field %s" % (what, f))
+
+
+@pytest.fixture(scope="module")
+def frames(synth):
+    out = []
+    T0 = None
+    for k in (0, 1, 2):
+        d, rgb, T = synth.frame(k, width=W, height=H, K=K, noise=True)
+        if T0 is None:
+            T0 = T
+        out.append((d, synth.rgba(rgb), (np.linalg.inv(T0) @ T).astype(np.float32)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# G1 / G2
+# ------------------------------------------------------------------------------------------
+def test_bilateral_metric_exact(fus, orc, frames, gputest_pair):
+    for depth, maxD in ((frames[0][0], 3.0), (gputest_pair["depth2"], 1.5), (gputest_pair["depth1"], 20.0)):
+        fo = orc.depth_bilateral(depth, maxD)
+        fg = fus.depth_bilateral(depth, maxD).download()
+        assert_bits(fg, fo, "bilateral")
+        assert_bits(fus.depth_metric(depth, maxD).download(), orc.depth_metric(depth, maxD), "metric raw")
+        assert_bits(fus.depth_metric(fo, maxD).download(), orc.depth_metric(fo, maxD), "metric filtered")
+    # the gate: below 300 mm and above maxD give 0
+    d = np.array([[0, 299, 300, 1500, 1501, 65535]] * 16, np.uint16).repeat(4, axis=1)
+    assert_bits(fus.depth_bilateral(d, 1.5).download(), orc.depth_bilateral(d, 1.5), "bilateral gate")
+
+
+# ------------------------------------------------------------------------------------------
+# G3 + G4 bootstrap, G5 index map, G6 splat
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def boot(fus, orc, frames):
+    depth, rgba, _ = frames[0]
+    df = orc.depth_bilateral(depth, 3.0)
+    dm, dmf = orc.depth_metric(depth, 3.0), orc.depth_metric(df, 3.0)
+    so = orc.model_initialise(rgba, dm, dmf, K, 1, 0, 25.0)
+    gm = fus.GlobalModel(W, H, capacity=400000)
+    gm.initialise(rgba, dm, dmf, K, 1, 0, 25.0)
+    return gm, so, (depth, rgba, df, dm, dmf)
+
+
+def test_initialise_exact(boot):
+    gm, so, _ = boot
+    sg = gm.downloadMap()
+    assert len(so) > 0.9 * W * H * 0.97 * 0.9
+    surfels_equal(sg, so, "bootstrap")
+    ref = gm.downloadMapRef()  # reference 60-byte layout: pos|col|times[3]|nrm
+    assert ref.shape == (len(so), 15)
+    assert_bits(ref[:, 0:4], so["pos"], "ref pos")
+    assert_bits(ref[:, 8:11], so["times"][:, :3], "ref times")
+    assert_bits(ref[:, 11:15], so["nrm"], "ref nrm")
+
+
+def _poses():
+    ang = 0.05
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    P1 = np.eye(4, dtype=np.float32)
+    P2 = np.eye(4, dtype=np.float32)
+    P2[:3, :3] = R
+    P2[:3, 3] = (0.03, -0.02, 0.05)
+    P3 = np.eye(4, dtype=np.float32)
+    P3[:3, 3] = (0.0, 0.0, 0.6)  # walk into the scene: large sprites, clipping
+    return [P1, P2, P3]
+
+
+def test_index_map_exact(fus, orc, boot):
+    gm, so, _ = boot
+    im = fus.IndexMap(W, H)
+    for pose in _poses():
+        for (time, timeDelta, maxDepth) in ((2, 200, 25.0), (500, 200, 25.0), (2, 200, 1.2)):
+            dp = fus.DevicePose(pose)
+            im.predictIndices(dp, time, 0, gm, K, maxDepth, timeDelta)
+            ig, vg, cg, ng = im.download_index()
+            io, vo, co, no = orc.index_map(so, pose, K, H, W, time, 0, maxDepth, timeDelta)
+            assert (ig == io).all(), "index ids differ at %d pixels" % int((ig != io).sum())
+            assert_bits(vg, vo, "vertConf")
+            assert_bits(cg, co, "colorTime")
+            assert_bits(ng, no, "normRad")
+    # time window: with time - t > timeDelta everything is culled
+    io = orc.index_map(so, _poses()[0], K, H, W, 500, 0, 25.0, 200)[0]
+    assert io.max() == 0
+
+
+def test_index_map_is_nearest_surfel(fus, orc, boot):
+    """Property anchoring the oracle: the winner of every pixel is the projected surfel with the
+    smallest 24-bit depth, ties to the smallest id (brute force in numpy)."""
+    gm, so, _ = boot
+    pose = _poses()[1]
+    io, vo, _, _ = orc.index_map(so, pose, K, H, W, 2, 0, 25.0, 200)
+    tinv = orc.inv4f(pose)
+    p = so["pos"][:, :3]
+    ph = np.stack([((tinv[r, 0] * p[:, 0] + tinv[r, 1] * p[:, 1]) + tinv[r, 2] * p[:, 2]) + tinv[r, 3] for r in range(3)], axis=1).astype(np.float32)
+    z = ph[:, 2]
+    with np.errstate(all="ignore"):
+        u = np.floor(((((K[0] * ph[:, 0]) / z + K[2]) - W * 0.5) / (W * 0.5) + 1) * (W * 0.5)).astype(np.int64)
+        v = np.floor(((((K[1] * ph[:, 1]) / z + K[3]) - H * 0.5) / (H * 0.5) + 1) * (H * 0.5)).astype(np.int64)
+    ok = (z > 0) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+    d24 = np.rint((z / np.float32(25.0) * np.float32(0.5) + np.float32(0.5)).astype(np.float64) * 16777215.0)
+    best = {}
+    for i in np.flatnonzero(ok):
+        key = (int(v[i]), int(u[i]))
+        cand = (d24[i], i)
+        if key not in best or cand < best[key]:
+            best[key] = cand
+    mism = 0
+    for (vv, uu), (_, i) in best.items():
+        if io[vv, uu] != i:
+            mism += 1
+    # float32 evaluation-order differences of this numpy re-derivation can move a projection
+    # across a pixel border for a handful of surfels; the rule itself must hold everywhere else
+    assert mism <= 5, mism
+    assert (io > 0).sum() >= len(best) - 6
+
+
+def test_splat_predict_exact(fus, orc, boot):
+    gm, so, _ = boot
+    im = fus.IndexMap(W, H)
+    for pose in _poses():
+        for (conf, time, maxTime, active) in ((0.7, 2, 2, True), (0.0, 2, 2, True), (0.5, 300, 100, False), (10.0, 2, 2, True)):
+            dp = fus.DevicePose(pose)
+            tgt = im.combinedPredict(dp, gm, K, 25.0, conf, time, 0, maxTime, 200, active)
+            ig, vg, ng, tg = tgt.download()
+            io, vo, no, to = orc.splat_predict(so, pose, K, H, W, 25.0, conf, time, 0, maxTime, 200, active)
+            assert_bits(vg, vo, "pred vertex")
+            assert_bits(ng, no, "pred normal")
+            assert_bits(ig, io, "pred image")
+            assert_bits(tg, to, "pred time")
+        dg = im.synthesizeDepth(fus.DevicePose(pose), gm, K, 25.0, 0.5, 2, 0, 2, 65535).download()
+        do = orc.splat_predict(so, pose, K, H, W, 25.0, 0.5, 2, 0, 2, 65535, False, depth_only=True)
+        assert_bits(dg, do, "synth depth")
+    # the prediction of the bootstrap frame from its own pose reproduces the depth map
+    io, vo, no, to = orc.splat_predict(so, _poses()[0], K, H, W, 25.0, 0.0, 2, 0, 2, 200, True)
+    dm = boot[2][3]
+    both = (vo[..., 2] > 0) & (dm > 0)
+    assert both.mean() > 0.9
+    assert np.abs(vo[..., 2] - dm)[both].mean() < 0.01
+
+
+def test_fill_in_resize_exact(fus, orc, boot):
+    gm, so, (depth, rgba, df, dm, dmf) = boot
+    im = fus.IndexMap(W, H)
+    pose = _poses()[2]
+    tgt = im.combinedPredict(fus.DevicePose(pose), gm, K, 25.0, 0.7, 2, 0, 2, 200, True)
+    io, vo, no, to = orc.splat_predict(so, pose, K, H, W, 25.0, 0.7, 2, 0, 2, 200, True)
+    assert (vo[..., 2] == 0).any(), "the test needs holes to fill"
+    for pg, pr in ((False, False), (True, True), (False, True)):
+        fg = fus.fill_in(tgt, df, rgba, K, pg, pr)
+        gi, gv, gn, _ = fg.download()
+        ov, on, oi = orc.fill_in(vo, no, io, df, rgba, K, pg, pr)
+        assert_bits(gv, ov, "fill vertex")
+        assert_bits(gn, on, "fill normal")
+        assert_bits(gi, oi, "fill image")
+    for src in (io, vo, to):
+        assert_bits(fus.resize_nn(src, H // 20, W // 20).download(), orc.resize_nn(src, H // 20, W // 20), "resize")
+        assert_bits(fus.resize_nn(src, H // 8, W // 8).download(), orc.resize_nn(src, H // 8, W // 8), "resize /8")
+
+
+# ------------------------------------------------------------------------------------------
+# G7 + G8 fuse, G9 clean
+# ------------------------------------------------------------------------------------------
+def _prep(orc, depth, maxD=3.0):
+    df = orc.depth_bilateral(depth, maxD)
+    return df, orc.depth_metric(depth, maxD), orc.depth_metric(df, maxD)
+
+
+def test_fuse_and_clean_exact(fus, orc, frames):
+    depth0, rgba0, _ = frames[0]
+    df0, dm0, dmf0 = _prep(orc, depth0)
+    so = orc.model_initialise(rgba0, dm0, dmf0, K, 1, 0, 25.0)
+    gm = fus.GlobalModel(W, H, capacity=400000)
+    gm.initialise(rgba0, dm0, dmf0, K, 1, 0, 25.0)
+    im = fus.IndexMap(W, H)
+    for step, (depth, rgba, pose) in enumerate(frames[1:], start=2):
+        df, dm, dmf = _prep(orc, depth)
+        time = step
+        weighting = 0.75
+        dp = fus.DevicePose(pose)
+        # pre-fusion index map
+        im.predictIndices(dp, time, 0, gm, K, 25.0, 200)
+        io = orc.index_map(so, pose, K, H, W, time, 0, 25.0, 200)
+        assert (im.index.download() == io[0]).all()
+        # fuse
+        gm.fuse(dp, time, 0, rgba, dm, dmf, im, K, 25.0, weighting)
+        so2, newU, merged = orc.model_fuse(so, pose, time, 0, rgba, dm, dmf, io[0], io[1], io[3], K, 25.0, weighting)
+        assert merged > 1000, merged
+        surfels_equal(gm.downloadMap(), so2, "after fuse (step %d)" % step)
+        # post-fusion index map + clean
+        im.predictIndices(dp, time, 0, gm, K, 25.0, 200)
+        io2 = orc.index_map(so2, pose, K, H, W, time, 0, 25.0, 200)
+        assert (im.index.download() == io2[0]).all()
+        gm.clean(dp, time, 0, im, K, 10.0, 200, 25.0)
+        so3 = orc.model_clean(so2, newU, pose, time, 0, io2[0], io2[1], io2[2], K, 10.0, 200, 25.0)
+        assert len(so3) > len(so2)  # early frames keep the merged duplicates
+        surfels_equal(gm.downloadMap(), so3, "after clean (step %d)" % step)
+        so = so3
+    # a second clean without a fuse must not re-append the consumed measurements
+    n0 = gm.lastCount()
+    gm.clean(fus.DevicePose(frames[-1][2]), 3, 0, im, K, 10.0, 200, 25.0)
+    so4 = orc.model_clean(so, so[:0], frames[-1][2], 3, 0, io2[0], io2[1], io2[2], K, 10.0, 200, 25.0)
+    surfels_equal(gm.downloadMap(), so4, "idempotent clean")
+    assert gm.lastCount() <= n0
+
+
+def test_fuse_conflict_first_in_column_major_order_wins(fus, orc):
+    """Several pixels associating with one surfel: the first in draw (column-major) order is the
+    one merged.  A single big fronto-parallel surfel seen by a flat depth image."""
+    depth = np.full((H, W), 1000, np.uint16)
+    rgba = np.full((H, W, 4), 200, np.uint8)
+    df, dm, dmf = depth.copy(), depth.astype(np.float32) / 1000, depth.astype(np.float32) / 1000
+    so = np.zeros(2, orc.SURFEL_DTYPE)
+    for i in range(2):  # surfel 0 never associates (id 0 == empty); surfel 1 is the target
+        so[i]["pos"] = (0.001 * i, 0.0, 1.0, 1.0)
+        so[i]["col"] = (float((100 << 16) + (100 << 8) + 100), 0, 1, 1)
+        so[i]["nrm"] = (0, 0, -1, 0.02)
+        so[i]["times"] = [1] + [-3] * 7
+    pose = np.eye(4, dtype=np.float32)
+    io = orc.index_map(so, pose, K, H, W, 2, 0, 25.0, 200)
+    assert (io[0] == 1).sum() == 1
+    so2, newU, merged = orc.model_fuse(so, pose, 2, 0, rgba, dm, dmf, io[0], io[1], io[3], K, 25.0, 1.0)
+    assert merged == 1
+    gm = fus.GlobalModel(W, H, capacity=1000)
+    gm.upload(so)
+    im = fus.IndexMap(W, H)
+    dp = fus.DevicePose(pose)
+    im.predictIndices(dp, 2, 0, gm, K, 25.0, 200)
+    gm.fuse(dp, 2, 0, rgba, dm, dmf, im, K, 25.0, 1.0)
+    surfels_equal(gm.downloadMap(), so2, "conflict")
+    # more than one measurement chose surfel 1, exactly one was merged
+    assert (newU["col"][:, 3] == -1).sum() >= 2
+
+
+def test_clean_with_deformation_graph_exact(fus, orc, boot):
+    gm0, so, (depth, rgba, df, dm, dmf) = boot
+    gm = fus.GlobalModel(W, H, capacity=400000)
+    so = so.copy()
+    so["pos"][:, 3] = np.where(np.arange(len(so)) % 3 == 0, 12.0, so["pos"][:, 3])  # some stable surfels
+    so["col"][:, 2] = 1 + (np.arange(len(so)) % 40)  # spread of init times for the node search
+    gm.upload(so)
+    rng = np.random.default_rng(3)
+    nn = 60
+    nodes = np.zeros((nn, 16), np.float32)
+    nodes[:, 0:3] = rng.uniform([-0.8, -0.6, 0.9], [0.8, 0.6, 1.4], (nn, 3))
+    for j in range(nn):
+        a = rng.normal(0, 0.01, 3)
+        th = np.linalg.norm(a)
+        k = a / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        nodes[j, 3:12] = R.T.reshape(9)  # column-major storage
+    nodes[:, 12:15] = rng.normal(0, 0.005, (nn, 3))
+    nodes[:, 15] = np.sort(rng.integers(1, 45, nn))
+    pose = _poses()[1]
+    time = 50
+    im = fus.IndexMap(W, H)
+    dp = fus.DevicePose(pose)
+    im.predictIndices(dp, time, 0, gm, K, 25.0, 200)
+    io = orc.index_map(so, pose, K, H, W, time, 0, 25.0, 200)
+    assert (im.index.download() == io[0]).all()
+    dsynth_o = orc.splat_predict(so, pose, K, H, W, 25.0, 10.0, time, 0, time, 65535, False, depth_only=True)
+    dsynth_g = im.synthesizeDepth(dp, gm, K, 25.0, 10.0, time, 0, time, 65535)
+    assert_bits(dsynth_g.download(), dsynth_o, "synth depth")
+    gm.clean(dp, time, 0, im, K, 10.0, 200, 25.0, graph=nodes, depth_synth=dsynth_g)
+    so2 = orc.model_clean(so, so[:0], pose, time, 0, io[0], io[1], io[2], K, 10.0, 200, 25.0, nodes=nodes, depthSynth=dsynth_o)
+    assert 0 < len(so2) <= len(so)
+    moved = np.abs(so2["pos"][:, :3] - so["pos"][:len(so2), :3]).max() if len(so2) == len(so) else 1
+    assert moved > 1e-4, "deformation must have moved surfels"
+    surfels_equal(gm.downloadMap(), so2, "clean with graph")
+
+
+# ------------------------------------------------------------------------------------------
+# whole frame step
+# ------------------------------------------------------------------------------------------
+def test_process_frame_pipeline_parity(fus, orc, synth):
+    """ElasticFusion::processFrame over a short synthetic stream: per-step pose within the
+    north-star bar against the oracle pipeline, and — teacher-forced on the GPU's own state —
+    integer-exact association."""
+    from oracle import orc_pipeline
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000)
+    n_frames = 6
+    for k in range(n_frames):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
+        assert rg.tick == ro.tick and bool(rg.fused) == ro.fused and bool(rg.fill_in) == ro.fill_in
+        assert abs(rg.weighting - ro.weighting) < 0.05
+        # pre-processing is input-only: exact
+        assert_bits(g.image(2), o.depth_filtered, "depth filtered")
+        assert_bits(g.image(3), o.depth_metric, "depth metric")
+        mg = g.globalModel().downloadMap()
+        if k == 0:
+            surfels_equal(mg, o.model, "bootstrap frame")
+        # counts track each other closely (poses differ by ~1e-6 so a few pixels may flip)
+        assert abs(int(rg.surfels) - ro.surfels) <= max(10, 2e-3 * ro.surfels), (rg.surfels, ro.surfels)
+        assert len(mg) == rg.surfels
+        # teacher forcing: oracle stages on the GPU's own map and pose must reproduce the GPU images
+        if k > 0:
+            time = rg.tick - 1
+            ig, vg, cg, ng = g.image(5), g.image(6), g.image(7), g.image(8)  # index map used by clean (post-fusion, pre-clean)
+            # final prediction of the frame from the final map
+            po = orc.splat_predict(mg, pose_g, K, H, W, 25.0, 10.0, time, 0, time, 200, True)
+            assert_bits(g.image(10), po[1], "final predicted vertex, frame %d" % k)
+            assert_bits(g.image(9), po[0], "final predicted image, frame %d" % k)
+    assert rg.surfels > 100000
+
+
+def test_process_frame_with_pose_prior_and_no_tracking(fus, orc, synth):
+    """hybrid_tracking off: the pose prior is taken as is (ElasticFusion.cpp:248-250); the whole
+    frame is then input-determined and must match the oracle exactly, map included."""
+    from oracle import orc_pipeline
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000, hybrid_tracking=0)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000, hybrid_tracking=False)
+    T0 = None
+    for k in range(4):
+        d, rgb, T = synth.frame(k, width=W, height=H, K=K, noise=True)
+        if T0 is None:
+            T0 = T
+        prior = (np.linalg.inv(T0) @ T).astype(np.float32)
+        rg = g.processFrame(rgb, d, inPose=prior)
+        ro = o.processFrame(rgb, d, inPose=prior)
+        assert_bits(np.array(rg.pose, np.float32).reshape(4, 4), ro.pose, "pose")
+        assert rg.weighting == np.float32(ro.weighting)
+        surfels_equal(g.globalModel().downloadMap(), o.model, "map after frame %d" % k)
+        assert_bits(g.image(5), o.imap[0] if k > 0 else g.image(5), "index map")
+        assert_bits(g.image(10), o.pred[1], "predicted vertex")
+        assert_bits(g.image(14), o.fill[1], "fill-in vertex")
