@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec of the full ICP + RGB + surfel-fusion frame step at 640x480.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic RGB-D frame already resident in HBM:
+depth bilateral + metric conversion, model prediction + fill-in, tracker pyramid
+initialisation, SO3 pre-alignment + 3-level combined ICP/RGB Gauss-Newton (10/5/4 iterations),
+second prediction, index map, fuse, index map, clean, final prediction
+(ElasticFusion::processFrame with --o --nkf; SURVEY.md §8(d) "frame step").
+Multi-GPU = the collaborative session: one camera (and its own map) per rank, weak scaling;
+the only exchange is the per-frame all-gather of each camera's W/8 x H/8 thumbnails (the fern
+matcher's inputs) over RCCL.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(kernel, W, H, M, level_px):
+    """Algorithmic HBM bytes of ONE launch of `kernel` (SURVEY.md §8(d) contract)."""
+    N0 = W * H
+    if kernel == "gn_pass1":  # ICP 48 B/px (4 SoA maps) + photometric count pass 14 B/px
+        return 62.0 * level_px
+    if kernel == "gn_pass2":  # photometric Jacobian pass 14 B/px
+        return 14.0 * level_px
+    if kernel == "splat_project":  # B_pred = 60 M + 38 N0, the 60 M surfel stream is this kernel
+        return 60.0 * M
+    if kernel == "index_project":
+        return 60.0 * M
+    if kernel == "clean_flags":  # B_clean = 120 M + 15 N0 split over flags (read) and scatter (write)
+        return 60.0 * M + 15.0 * N0
+    if kernel == "clean_scatter":
+        return 60.0 * M
+    if kernel == "depth_bilateral":  # u16 in, u16 out
+        return 4.0 * N0
+    return float("nan")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-pass", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~20 s)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from densemonoslam_amd import capi, fusion, synth
+
+    capi.check(capi.lib.dms_set_device(local_rank), "dms_set_device")
+    W, H = args.width, args.height
+    K = synth.K_640 if (W, H) == (640, 480) else (synth.K_KITTI if (W, H) == (1241, 376) else (0.825 * W, 0.825 * W, W / 2.0, H / 2.0))
+    n_total = args.warmup + args.steps
+
+    # ---- synthetic stream for this rank's camera, resident in HBM before timing --------------
+    n_unique = min(n_total, 32)
+    rgb_t = torch.empty((n_unique, H, W, 3), dtype=torch.uint8, device=dev)
+    dep_t = torch.empty((n_unique, H, W), dtype=torch.int16, device=dev)
+    host_frames = []
+    for k in range(n_unique):
+        d, rgb, _ = synth.frame(k, cam_id=rank, width=W, height=H, K=K, noise=True)
+        rgb_t[k] = torch.from_numpy(rgb)
+        dep_t[k] = torch.from_numpy(d.view(np.int16))
+        if rank == 0 and k < 8:
+            host_frames.append((d, rgb))
+
+    def frame_index(i):  # forward then backward along the trajectory: temporally coherent for any length
+        period = 2 * (n_unique - 1) if n_unique > 1 else 1
+        j = i % period
+        return j if j < n_unique else period - j
+
+    def make_engine():
+        return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ef = make_engine()
+
+    # thumbnails exchanged in collaborative mode: W/8 x H/8 image + vertex + normal
+    tw, th = W // 8, H // 8
+    thumb = torch.zeros((th * tw * (4 + 16 + 16),), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world, thumb.numel()), dtype=torch.uint8, device=dev) if distributed else None
+    import ctypes as C
+
+    def thumb_views():
+        base = thumb.data_ptr()
+        n = th * tw
+        return (capi.Image2D(base, tw * 4, th, tw), capi.Image2D(base + n * 4, tw * 16, th, tw), capi.Image2D(base + n * 20, tw * 16, th, tw))
+
+    tv = thumb_views()
+
+    def src_view(which):
+        v = capi.Image2D()
+        capi.check(capi.lib.dms_fusion_get_image(ef.h, which, C.byref(v)))
+        return v
+
+    src = None
+
+    def step(i):
+        nonlocal src
+        j = frame_index(i)
+        ef.processFrameAsync(rgb_t[j].data_ptr(), 3, dep_t[j].data_ptr(), None, 1.0, stream)
+        if distributed:
+            if src is None:
+                src = (src_view(13), src_view(14), src_view(15))  # fill-in image / vertex / normal
+            capi.check(capi.lib.dms_resize_nn(C.byref(src[0]), C.byref(tv[0]), 4, stream))
+            capi.check(capi.lib.dms_resize_nn(C.byref(src[1]), C.byref(tv[1]), 16, stream))
+            capi.check(capi.lib.dms_resize_nn(C.byref(src[2]), C.byref(tv[2]), 16, stream))
+            dist.all_gather_into_tensor(gathered.view(-1), thumb)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    res = ef.fetch(stream)
+    M = int(res.surfels)
+
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        msum = torch.tensor([M], dtype=torch.float64, device=dev)
+        dist.all_reduce(msum, op=dist.ReduceOp.SUM)
+        M_total = int(msum.item())
+    else:
+        M_total = M
+
+    fps = world * args.steps / elapsed
+    out = {
+        "metric": "frames/sec ICP+RGB+fusion @640x480" if (W, H) == (640, 480) else "frames/sec ICP+RGB+fusion @%dx%d" % (W, H),
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "TUM fr1/desk-like 640x480 full 3-level ICP+RGB tracking (SO3 + {10,5,4} GN iterations) + surfel index-map fusion; "
+                        "synthetic box-room RGB-D stream, loop closure off (--o), NID keyframing off (--nkf)" if (W, H) == (640, 480)
+                        else "same frame step at %dx%d" % (W, H),
+            "resolution": [W, H],
+            "cameras_per_gpu": 1,
+            "surfels_per_map": M,
+            "surfels_total": M_total,
+            "exchange": "all-gather of %d-byte W/8xH/8 thumbnails per camera per frame" % thumb.numel() if distributed else "none (1 camera)",
+        },
+    }
+
+    # ---- per-kernel timing with HIP events on the launch stream (own pass, not in `value`) ------
+    if rank == 0 and not args.no_kernel_pass:
+        ef.set_profiling(True)
+        od = fusion.lib.dms_fusion_odometry(ef.h)
+        capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 1))
+        nprof = min(args.steps, 20)
+        for i in range(n_total, n_total + nprof):
+            step(i)
+            ef.fetch(stream)
+        names_f = ["ingest", "preprocess", "predict", "fill_in", "odom_init", "track", "index_map", "fuse", "clean", "initialise"]
+        stages = {}
+        for n in names_f:
+            ms, cnt = ef.kernel_time(n)
+            if cnt:
+                stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
+        kern = {}
+        for n in ("gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "so3_solve"):
+            ms, cnt = C.c_double(0), C.c_int(0)
+            capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                kern[n] = {"ms_per_frame": ms.value / nprof, "avg_us": 1000.0 * ms.value / cnt.value, "launches_per_frame": cnt.value / nprof}
+        out["stage_ms_per_frame"] = {k: round(v["ms_per_frame"], 4) for k, v in stages.items()}
+        out["tracker_kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern.items()}
+        # dominant kernel: the Gauss-Newton pass-1 (ICP + photometric correspondence) over the pyramid
+        if "gn_pass1" in kern:
+            px = [W * H, (W // 2) * (H // 2), (W // 4) * (H // 4)]
+            its = [10, 5, 4]
+            bytes_per_frame = sum(algorithmic_bytes("gn_pass1", W, H, M, p) * n for p, n in zip(px, its))
+            launches = sum(its)
+            avg_s = kern["gn_pass1"]["avg_us"] * 1e-6
+            achieved = (bytes_per_frame / launches) / avg_s / 1e9
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_gn_pass1<ICP,RGB> (average over the 10+5+4 launches of the 3-level pyramid)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": bytes_per_frame / launches,
+                "avg_launch_us": kern["gn_pass1"]["avg_us"],
+            }
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores -----------
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import orc_pipeline  # checker / baseline only
+
+        cores = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=8_000_000)
+        nfr = args.cpu_frames or 6
+        tcpu = 0.0
+        done = 0
+        for k in range(min(nfr, len(host_frames))):
+            d, rgb = host_frames[k]
+            t1 = time.perf_counter()
+            o.processFrame(rgb, d)
+            dt = time.perf_counter() - t1
+            if k >= 1:  # frame 0 is the bootstrap frame, not a steady-state step
+                tcpu += dt
+                done += 1
+            if tcpu > 25.0:
+                break
+        out["cpu_baseline"] = {
+            "value": done / tcpu if tcpu > 0 else None,
+            "unit": "frames/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "%d steady-state frames of the same synthetic stream (after the bootstrap frame), oracle/ C restatement "
+                      "(OpenMP on the reduction kernels, the rest single-threaded), %dx%d" % (done, W, H),
+        }
+
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

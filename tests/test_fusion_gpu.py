@@ -262,9 +262,9 @@ def test_fuse_conflict_first_in_column_major_order_wins(fus, orc):
     df, dm, dmf = depth.copy(), depth.astype(np.float32) / 1000, depth.astype(np.float32) / 1000
     so = np.zeros(2, orc.SURFEL_DTYPE)
     for i in range(2):  # surfel 0 never associates (id 0 == empty); surfel 1 is the target
-        so[i]["pos"] = (0.001 * i, 0.0, 1.0, 1.0)
+        so[i]["pos"] = (0.05 * i, 0.0, 1.0, 1.0)
         so[i]["col"] = (float((100 << 16) + (100 << 8) + 100), 0, 1, 1)
-        so[i]["nrm"] = (0, 0, -1, 0.02)
+        so[i]["nrm"] = (0, 0, 1, 0.02)  # normals point away from the camera (geometry.glsl:27-39)
         so[i]["times"] = [1] + [-3] * 7
     pose = np.eye(4, dtype=np.float32)
     io = orc.index_map(so, pose, K, H, W, 2, 0, 25.0, 200)
@@ -332,32 +332,64 @@ def test_process_frame_pipeline_parity(fus, orc, synth):
     g = fus.ElasticFusion(W, H, K, model_capacity=600000)
     o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000)
     n_frames = 6
+    worst_t = worst_r = 0.0
     for k in range(n_frames):
         d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        model_before = o.model.copy()  # == the GPU's map (forced below)
         rg = g.processFrame(rgb, d)
         ro = o.processFrame(rgb, d)
         pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
-        helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
+        # per-step pose parity: both sides started this step from the same map and pose
+        dt, da = helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
+        worst_t, worst_r = max(worst_t, dt), max(worst_r, da)
         assert rg.tick == ro.tick and bool(rg.fused) == ro.fused and bool(rg.fill_in) == ro.fill_in
         assert abs(rg.weighting - ro.weighting) < 0.05
         # pre-processing is input-only: exact
         assert_bits(g.image(2), o.depth_filtered, "depth filtered")
         assert_bits(g.image(3), o.depth_metric, "depth metric")
         mg = g.globalModel().downloadMap()
+        assert len(mg) == rg.surfels
         if k == 0:
             surfels_equal(mg, o.model, "bootstrap frame")
-        # counts track each other closely (poses differ by ~1e-6 so a few pixels may flip)
-        assert abs(int(rg.surfels) - ro.surfels) <= max(10, 2e-3 * ro.surfels), (rg.surfels, ro.surfels)
-        assert len(mg) == rg.surfels
-        # teacher forcing: oracle stages on the GPU's own map and pose must reproduce the GPU images
-        if k > 0:
+        else:
             time = rg.tick - 1
-            ig, vg, cg, ng = g.image(5), g.image(6), g.image(7), g.image(8)  # index map used by clean (post-fusion, pre-clean)
+            # association replayed by the oracle from the GPU's pose and weight: integer-exact map
+            im = orc.index_map(model_before, pose_g, K, H, W, time, 0, 25.0, 200)
+            m2, newU, _ = orc.model_fuse(model_before, pose_g, time, 0, o.rgba, o.depth_metric, o.depth_metric_filtered, im[0], im[1], im[3],
+                                         K, 25.0, float(rg.weighting))
+            im2 = orc.index_map(m2, pose_g, K, H, W, time, 0, 25.0, 200)
+            assert (g.image(5) == im2[0]).all(), "post-fusion index map ids, frame %d" % k
+            assert_bits(g.image(6), im2[1], "post-fusion vertConf")
+            m3 = orc.model_clean(m2, newU, pose_g, time, 0, im2[0], im2[1], im2[2], K, 10.0, 200, 25.0, cap=600000)
+            surfels_equal(mg, m3, "map after frame %d" % k)
             # final prediction of the frame from the final map
             po = orc.splat_predict(mg, pose_g, K, H, W, 25.0, 10.0, time, 0, time, 200, True)
             assert_bits(g.image(10), po[1], "final predicted vertex, frame %d" % k)
             assert_bits(g.image(9), po[0], "final predicted image, frame %d" % k)
+            # the oracle's own free-running map stays close in size (poses differ by ~1e-6)
+            assert abs(int(rg.surfels) - ro.surfels) <= max(10, 2e-3 * ro.surfels), (rg.surfels, ro.surfels)
+        # teacher forcing: the next step starts from the GPU's state on both sides
+        o.model = mg.copy()
+        o.currPose = pose_g.copy()
     assert rg.surfels > 100000
+    assert worst_t < 1e-4 and worst_r < 1e-3, (worst_t, worst_r)  # observed: ~1e-6 m, ~1e-5 deg
+
+
+def test_process_frame_free_running_drift_is_bounded(fus, orc, synth):
+    """Without teacher forcing the two float implementations drift apart slowly (correspondences
+    flip under 1e-6 pose differences); the drift stays far below the scene scale."""
+    from oracle import orc_pipeline
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000)
+    for k in range(5):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+    pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+    assert np.linalg.norm(pose_g[:3, 3] - ro.pose[:3, 3]) < 5e-3
+    assert helpers.rot_angle_deg(pose_g[:3, :3], ro.pose[:3, :3]) < 0.2
+    assert abs(int(rg.surfels) - ro.surfels) <= 0.01 * ro.surfels
 
 
 def test_process_frame_with_pose_prior_and_no_tracking(fus, orc, synth):
