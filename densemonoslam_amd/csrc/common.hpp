@@ -16,6 +16,7 @@ namespace dms {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves: one per SIMD of a CU
 constexpr int kMaxPartialBlocks = DMS_MAX_PARTIAL_BLOCKS;
+constexpr int kAutoPartialBlocks = 512;  // 2 blocks per CU: enough waves to cover HBM latency, half the records to fold
 constexpr int kSE3 = 29;                 // 27 products + residual + inliers (types.cuh:123-171)
 constexpr int kSO3 = 11;                 // 9 products + residual + inliers (types.cuh:173-197)
 
@@ -156,12 +157,15 @@ __device__ __forceinline__ int wave_sum_to_lane63_i(int v) {
   return v;
 }
 
+// Partial sums are stored one 128-byte record per block (kPartStride floats), so the fold reads
+// them with 16-byte loads: 8 lanes cover one record, 32 record-groups are in flight per pass.
+constexpr int kPartStride = 32;
+
 // Block reduction of NV running sums held per thread.  256-thread blocks = 4 waves.
-// Writes the block's NV totals to out[k * out_stride + out_col] (SoA partial layout:
-// one row per quantity, one column per block, so the final pass reads coalesced).
+// Writes the block's NV totals to out[out_col * kPartStride + k].
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __restrict__ out,
-                                                   int out_stride, int out_col) {
+                                                   int /*out_stride*/, int out_col) {
   __shared__ float lds[kBlock / kWave][NV];
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x >> 6;
@@ -176,15 +180,46 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __rest
     const int nw = blockDim.x >> 6;
     float s = lds[0][k];
     for (int w = 1; w < nw; ++w) s += lds[w][k];
-    out[(size_t)k * out_stride + out_col] = s;
+    out[(size_t)out_col * kPartStride + k] = s;
   }
+}
+
+// Fold of the per-block records by one 256-thread block: thread (g = tid / 8, k4 = tid % 8) sums
+// the float4 column k4 of records g, g + 32, ... (independent 16-byte loads, unrolled so several
+// are in flight), then 32 lanes add the 32 group sums in a fixed order.  sums[] is LDS or global.
+__device__ __forceinline__ void fold_records256(const float* __restrict__ partials, int nblocks, int nv, float* sums) {
+  __shared__ float4 s_grp[32][8];
+  const int k4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const float4* p4 = reinterpret_cast<const float4*>(partials);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  int b = g;
+  for (; b + 32 < nblocks; b += 64) {
+    const float4 v0 = p4[(size_t)b * 8 + k4];
+    const float4 v1 = p4[(size_t)(b + 32) * 8 + k4];
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+  }
+  if (b < nblocks) {
+    const float4 v0 = p4[(size_t)b * 8 + k4];
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+  }
+  s_grp[g][k4] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const float* f = reinterpret_cast<const float*>(&s_grp[0][0]);
+    float acc = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 32; ++gg) acc += f[gg * 32 + threadIdx.x];
+    if ((int)threadIdx.x < nv) sums[threadIdx.x] = acc;
+  }
+  __syncthreads();
 }
 
 // launch-shape helper: blocks of 256 threads, one pixel per thread up to the partial cap,
 // grid-stride beyond.  ≥ 2 blocks per CU at 640×480 so every XCD's L2 sees its share.
 inline int reduce_blocks_for(int n) {
   int b = (n + kBlock - 1) / kBlock;
-  if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
+  if (b > kAutoPartialBlocks) b = kAutoPartialBlocks;
   if (b < 1) b = 1;
   return b;
 }

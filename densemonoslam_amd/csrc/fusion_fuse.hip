@@ -118,10 +118,12 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
       const float ray_len = length3(ray);
       const float x_lo = tx - ((scale * indexXStep) * windowMultiplier), x_hi = tx + ((scale * indexXStep) * windowMultiplier);
       const float y_lo = ty - ((scale * indexYStep) * windowMultiplier), y_hi = ty + ((scale * indexYStep) * windowMultiplier);
-      for (float wi = x_lo; wi < x_hi; wi += indexXStep) {
-        const int ux = texel(wi, colsf, a.cols);
-        for (float wj = y_lo; wj < y_hi; wj += indexYStep) {
-          const int uy = texel(wj, rowsf, a.rows);
+      // repeated taps of one texel cannot change `best` (the distance test is strict) and
+      // `counter` only matters as > 0, so each distinct texel is visited once, in tap order
+      const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
+      const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
+      for_taps(tx_, [&](int ux, int) {
+        for_taps(ty_, [&](int uy, int) {
           const size_t q = (size_t)uy * a.cols + ux;
           const unsigned current = a.index[q];
           if (current > 0u) {
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
               }
             }
           }
-        }
-      }
+        });
+      });
       flag = counter > 0 ? 1 : 2;
       slot_pos[slot] = make_float4(vPos.x, vPos.y, vPos.z, conf);
       slot_col[slot] = make_float4(encode_color_bytes(c.x, c.y, c.z), 0.f, a.timef, flag == 1 ? -1.f : -2.f);
@@ -230,6 +232,19 @@ __device__ __forceinline__ bool clean_load(unsigned e, unsigned M, const SurfelP
   return true;
 }
 
+// static-slot access to the per-sensor times (a dynamically indexed private array would live in
+// scratch memory)
+__device__ __forceinline__ float pick_time(const float (&t)[DMS_MAX_SENSORS], int idx) {
+  float r = t[0];
+#pragma unroll
+  for (int s = 1; s < DMS_MAX_SENSORS; ++s) r = (s == idx) ? t[s] : r;
+  return r;
+}
+__device__ __forceinline__ void put_time(float (&t)[DMS_MAX_SENSORS], int idx, float v) {
+#pragma unroll
+  for (int s = 0; s < DMS_MAX_SENSORS; ++s) t[s] = (s == idx) ? v : t[s];
+}
+
 // the keep/drop decision of copy_unstable.vert:70-159 (before any deformation)
 __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v) {
   int test = 1;
@@ -244,15 +259,15 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
   const float indexYStep = (1.0f / (rowsf * scale)) * 0.5f;
   const float windowMultiplier = 2.f;
   int count = 0, zCount = 0;
-  const float vt = v.times[a.timeIdx];
+  const float vt = pick_time(v.times, a.timeIdx);
   if ((float)a.time - vt < (float)a.timeDelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < colsf && y < rowsf) {
     const float xc = x / colsf, yc = y / rowsf;
     const float x_lo = xc - ((scale * indexXStep) * windowMultiplier), x_hi = xc + ((scale * indexXStep) * windowMultiplier);
     const float y_lo = yc - ((scale * indexYStep) * windowMultiplier), y_hi = yc + ((scale * indexYStep) * windowMultiplier);
-    for (float wi = x_lo; wi < x_hi; wi += indexXStep) {
-      const int ux = texel(wi, colsf, a.cols);
-      for (float wj = y_lo; wj < y_hi; wj += indexYStep) {
-        const int uy = texel(wj, rowsf, a.rows);
+    const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
+    const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
+    for_taps(tx_, [&](int ux, int mx) {
+      for_taps(ty_, [&](int uy, int my) {
         const size_t q = (size_t)uy * a.cols + ux;
         const unsigned current = a.index[q];
         if (current > 0u) {
@@ -261,29 +276,28 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
           const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
           if (ct.z < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
               sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f)
-            count++;
+            count += mx * my;  // every repeated tap of this texel counts
           if (ct.w == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
               fabsf(localNorm.z) > 0.85f)
-            zCount++;
+            zCount += mx * my;
         }
-      }
-    }
+      });
+    });
   }
   if (count > 8 || zCount > 4) test = 0;
   // new unstable point: times become `time` before the health test (copy_unstable.vert:124-129)
-  float times[DMS_MAX_SENSORS];
-#pragma unroll
-  for (int s = 0; s < DMS_MAX_SENSORS; ++s) times[s] = v.times[s];
-  if (times[a.timeIdx] == -2.f) times[a.timeIdx] = (float)a.time;
+  const float vt2 = (vt == -2.f) ? (float)a.time : vt;
   // "unhealthy for every sensor".  The reference loops over its NUM_CAMERAS = 3 slots
   // (size.glsl:2); slots beyond the reference's three are extra sensors of the 8-GPU node and
   // follow the same rule.
   int unHealthy = 0;
 #pragma unroll
-  for (int s = 0; s < DMS_MAX_SENSORS; ++s)
-    if (times[s] == -1.f || (((float)a.time - times[s]) > 20.f && v.pos.w < a.confThreshold)) unHealthy++;
+  for (int s = 0; s < DMS_MAX_SENSORS; ++s) {
+    const float ts = (s == a.timeIdx) ? vt2 : v.times[s];
+    if (ts == -1.f || (((float)a.time - ts) > 20.f && v.pos.w < a.confThreshold)) unHealthy++;
+  }
   if (unHealthy == DMS_MAX_SENSORS) test = 0;
-  if (times[a.timeIdx] > 0.f && (float)a.time - times[a.timeIdx] > (float)a.timeDelta) test = 1;
+  if (vt2 > 0.f && (float)a.time - vt2 > (float)a.timeDelta) test = 1;
   return test;
 }
 
@@ -428,7 +442,7 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
       const float currentDepth = a.depth_synth ? a.depth_synth[(size_t)uy * a.cols + ux] : 0.f;
       if (currentDepth > 0.0f && lp.z < currentDepth + 0.1f) {
         v.col.w = (float)a.time;
-        v.times[a.timeIdx] = (float)a.time;
+        put_time(v.times, a.timeIdx, (float)a.time);
       }
     }
   }
@@ -453,9 +467,9 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
       if (dst < cap) {
         CleanElem v;
         clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v);
-        if (v.times[a.timeIdx] == -2.f) {  // copy_unstable.vert:124-129
+        if (pick_time(v.times, a.timeIdx) == -2.f) {  // copy_unstable.vert:124-129
           v.col.w = (float)a.time;
-          v.times[a.timeIdx] = (float)a.time;
+          put_time(v.times, a.timeIdx, (float)a.time);
         }
         if (a.nodes > 0 && v.col.z != (float)a.time) clean_deform(a, v);  // :161
         out.pos[dst] = v.pos;

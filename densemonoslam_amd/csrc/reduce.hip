@@ -10,12 +10,12 @@ namespace dms {
 
 // workspace carving ----------------------------------------------------------------------
 struct ReduceWs {
-  float* partials;   // [29][kMaxPartialBlocks]
+  float* partials;   // [kMaxPartialBlocks][kPartStride] one 128-byte record per block
   float* result;     // [32]
   int* ipartials;    // [2][kMaxPartialBlocks]
   int* iresult;      // [4]
 };
-static constexpr size_t kWsBytes = (size_t)kSE3 * kMaxPartialBlocks * 4 + 32 * 4 + 2 * (size_t)kMaxPartialBlocks * 4 + 16;
+static constexpr size_t kWsBytes = (size_t)kPartStride * kMaxPartialBlocks * 4 + 32 * 4 + 2 * (size_t)kMaxPartialBlocks * 4 + 16;
 
 size_t reduce_workspace_bytes() { return kWsBytes; }
 
@@ -23,7 +23,7 @@ static inline ReduceWs carve(void* ws) {
   ReduceWs r;
   char* p = (char*)ws;
   r.partials = (float*)p;
-  p += (size_t)kSE3 * kMaxPartialBlocks * 4;
+  p += (size_t)kPartStride * kMaxPartialBlocks * 4;
   r.result = (float*)p;
   p += 32 * 4;
   r.ipartials = (int*)p;
@@ -32,16 +32,9 @@ static inline ReduceWs carve(void* ws) {
   return r;
 }
 
-// final fold: out[k] = sum_b partials[k][b]; one wave per row k -------------------------------
-__global__ __launch_bounds__(1024) void k_fold_rows(const float* __restrict__ partials, int stride, int nblocks, int nv,
-                                                    float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int k = wid; k < nv; k += nw) {
-    float s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)k * stride + b];
-    s = wave_sum_to_lane63(s);
-    if (lane == 63) out[k] = s;
-  }
+// final fold of the per-block records ---------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_records(const float* __restrict__ partials, int nblocks, int nv, float* __restrict__ out) {
+  fold_records256(partials, nblocks, nv, out);
 }
 
 __global__ __launch_bounds__(1024) void k_fold_rows_i(const int* __restrict__ partials, int stride, int nblocks, int nv,
@@ -197,7 +190,7 @@ int icpStep(const dms_mat33* Rcurr, const dms_float3* tcurr, const dms_image2d* 
   hipLaunchKernelGGL(k_icp, dim3(nb), dim3(kBlock), 0, s, p, make_map_ptrs(vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev), N,
                      w.partials, kMaxPartialBlocks);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(1024), 0, s, w.partials, kMaxPartialBlocks, nb, kSE3, w.result);
+  hipLaunchKernelGGL(k_fold_records, dim3(1), dim3(256), 0, s, w.partials, nb, kSE3, w.result);
   DMS_CHECK_LAUNCH();
   float host[32];
   DMS_HIP(hipMemcpyAsync(host, w.result, kSE3 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -230,7 +223,7 @@ int rgbStep(const dms_image2d* corresImg, float sigma, const dms_image2d* cloud,
                      cloud->pitch, (const short*)dIdx->data, (const short*)dIdy->data, dIdx->pitch, N, w.partials,
                      kMaxPartialBlocks);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(1024), 0, s, w.partials, kMaxPartialBlocks, nb, kSE3, w.result);
+  hipLaunchKernelGGL(k_fold_records, dim3(1), dim3(256), 0, s, w.partials, nb, kSE3, w.result);
   DMS_CHECK_LAUNCH();
   float host[32];
   DMS_HIP(hipMemcpyAsync(host, w.result, kSE3 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -313,7 +306,7 @@ int so3Step(const dms_image2d* lastImage, const dms_image2d* nextImage, const dm
   hipLaunchKernelGGL(k_so3, dim3(nb), dim3(kBlock), 0, s, p, (const unsigned char*)lastImage->data, lastImage->pitch,
                      (const unsigned char*)nextImage->data, nextImage->pitch, N, w.partials, kMaxPartialBlocks);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_fold_rows, dim3(1), dim3(1024), 0, s, w.partials, kMaxPartialBlocks, nb, kSO3, w.result);
+  hipLaunchKernelGGL(k_fold_records, dim3(1), dim3(256), 0, s, w.partials, nb, kSO3, w.result);
   DMS_CHECK_LAUNCH();
   float host[kSO3];
   DMS_HIP(hipMemcpyAsync(host, w.result, kSO3 * sizeof(float), hipMemcpyDeviceToHost, s));

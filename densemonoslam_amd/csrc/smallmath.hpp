@@ -76,10 +76,11 @@ __host__ __device__ inline void inv4(const double* m, double* o) { inv4t<double>
 
 // Pivoted LDLT solve of a symmetric N×N system (diagonal pivoting on |A_kk|, zero pivots
 // solved as 0): the algorithm behind `A.ldlt().solve(b)` at RGBDOdometry.cpp:371,554.
+// `A` (N*N), `temp`/`y` (N each) and `perm` (N) are caller-provided scratch: on the GPU they are
+// LDS arrays, because the pivoting indexes them dynamically and private arrays with dynamic
+// indices live in scratch memory (hundreds of cycles per access on the single solving lane).
 template <typename T, int N>
-__host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny) {
-  T A[N * N];
-  int perm[N];
+__host__ __device__ inline void ldlt_solve_ws(const T* Ain, const T* b, T* x, T tiny, T* A, T* temp, T* y, int* perm) {
   for (int i = 0; i < N * N; ++i) A[i] = Ain[i];
   bool all_zero = false;
   for (int k = 0; k < N; ++k) {
@@ -106,7 +107,6 @@ __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tin
       }
     }
     // lower-triangular update: column k below the diagonal
-    T temp[N];
     for (int j = 0; j < k; ++j) temp[j] = A[j * N + j] * A[k * N + j];
     T akk = A[k * N + k];
     for (int j = 0; j < k; ++j) akk -= A[k * N + j] * temp[j];
@@ -126,7 +126,6 @@ __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tin
     if (valid)
       for (int i = k + 1; i < N; ++i) A[i * N + k] /= akk;
   }
-  T y[N];
   for (int i = 0; i < N; ++i) y[i] = b[i];
   if (all_zero) {
     for (int i = 0; i < N; ++i) x[i] = T(0);
@@ -154,6 +153,13 @@ __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tin
       y[perm[k]] = t;
     }
   for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
+template <typename T, int N>
+__host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny) {
+  T A[N * N], temp[N], y[N];
+  int perm[N];
+  ldlt_solve_ws<T, N>(Ain, b, x, tiny, A, temp, y, perm);
 }
 
 // reference OdometryProvider::rodrigues (OdometryProvider.h:35-71), row-major 3×3

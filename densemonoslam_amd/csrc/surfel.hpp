@@ -84,6 +84,44 @@ __host__ __device__ __forceinline__ f3 decode_color(float c) {
   return mk3((float)((ci >> 16) & 0xFF) / 255.0f, (float)((ci >> 8) & 0xFF) / 255.0f, (float)(ci & 0xFF) / 255.0f);
 }
 
+// The 4×4-tap association / clean windows of data.vert:118-134 and copy_unstable.vert:84-122 walk
+// a float loop `for (w = c - 2*step; w < c + 2*step; w += step)` with step = half a texel and
+// fetch NEAREST, so consecutive taps repeat texels (at most 3 distinct per axis).  The loop is
+// replayed here exactly (fp32 accumulation of `w`), but collapsed into distinct texels with
+// multiplicities held in named slots — no dynamically indexed private arrays (those live in
+// scratch memory), and each distinct texel is fetched once.
+struct AxisTaps {
+  int t0, t1, t2, t3;
+  int m0, m1, m2, m3;
+};
+__device__ __forceinline__ AxisTaps axis_taps(float lo, float hi, float step, float nf, int n) {
+  AxisTaps a = {-1, -1, -1, -1, 0, 0, 0, 0};
+  int k = -1, last = -0x7fffffff;
+  for (float w = lo; w < hi; w += step) {
+    const int u = texel(w, nf, n);
+    if (u != last) {
+      ++k;
+      last = u;
+      if (k == 0) a.t0 = u;
+      else if (k == 1) a.t1 = u;
+      else if (k == 2) a.t2 = u;
+      else a.t3 = u;
+    }
+    if (k == 0) a.m0++;
+    else if (k == 1) a.m1++;
+    else if (k == 2) a.m2++;
+    else a.m3++;
+  }
+  return a;
+}
+template <class F>
+__device__ __forceinline__ void for_taps(const AxisTaps& a, F f) {
+  if (a.m0) f(a.t0, a.m0);
+  if (a.m1) f(a.t1, a.m1);
+  if (a.m2) f(a.t2, a.m2);
+  if (a.m3) f(a.t3, a.m3);
+}
+
 // uv buffer entry of the reference (GlobalModel.cpp:100-108, FeedbackBuffer.cpp:38-46):
 // ((float)i / (float)n) + 1.0 / (2 * (float)n) evaluated in double, stored as float
 __host__ __device__ __forceinline__ float uv_coord(int i, int n) {

@@ -223,17 +223,6 @@ __global__ __launch_bounds__(kBlock) void k_so3_pass(const TrackState* __restric
   block_reduce_store<kSO3>(acc, partials, stride, blockIdx.x);
 }
 
-// fold NV rows of partials into sums[] with one wave per row (block of 1024 = 16 waves)
-template <int NV>
-__device__ __forceinline__ void fold_rows(const float* __restrict__ partials, int stride, int nblocks, float* sums) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int k = wid; k < NV; k += nw) {
-    float s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)k * stride + b];
-    s = wave_sum_to_lane63(s);
-    if (lane == 63) sums[k] = s;
-  }
-}
 __device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, int stride, int nblocks, int* sums) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (wid < 2) {
@@ -244,11 +233,11 @@ __device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, i
   }
 }
 
-__global__ __launch_bounds__(1024) void k_so3_solve(TrackState* st, const float* __restrict__ partials, int stride, int nblocks,
+__global__ __launch_bounds__(256) void k_so3_solve(TrackState* st, const float* __restrict__ partials, int stride, int nblocks,
                                                     float fx, float fy, float cx, float cy, int is_last, int first_gn_level) {
   if (st->so3_done) return;
   __shared__ float sums[kSO3];
-  fold_rows<kSO3>(partials, stride, nblocks, sums);
+  fold_records256(partials, nblocks, kSO3, sums);
   __syncthreads();
   if (threadIdx.x != 0) return;
   float jtj[9], jtr[3];
@@ -281,7 +270,9 @@ __global__ __launch_bounds__(1024) void k_so3_solve(TrackState* st, const float*
     st->so3_lastCount = cnt;
     for (int i = 0; i < 9; ++i) st->lastResultR[i] = st->resultR[i];
     float delta[3];
-    sm::ldlt_solve<float, 3>(jtj, jtr, delta, 1.0f / 3.402823466e+38F);
+    __shared__ float l_A[9], l_t[3], l_y[3];
+    __shared__ int l_p[3];
+    sm::ldlt_solve_ws<float, 3>(jtj, jtr, delta, 1.0f / 3.402823466e+38F, l_A, l_t, l_y, l_p);
     const double dd[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
     double rotUpdate[9];
     sm::rodrigues(dd, rotUpdate);
@@ -475,7 +466,7 @@ __device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* __restrict__ part_icp,
+__global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* __restrict__ part_icp,
                                                    const float* __restrict__ part_rgb, const int* __restrict__ part_cnt, int stride,
                                                    int nblocks, int icp, int rgb, int rgbOnly, float icpWeight, int level,
                                                    int first_iter, int next_level, int level_below, float fx, float fy, float cx,
@@ -486,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* 
   __shared__ int s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  if (icp) fold_rows<kSE3>(part_icp, stride, nblocks, s_icp);
+  if (icp) fold_records256(part_icp, nblocks, kSE3, s_icp);
   if (rgb) {
     fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
   }
@@ -505,7 +496,7 @@ __global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* 
     }
     return;
   }
-  if (rgb) fold_rows<kSE3>(part_rgb, stride, nblocks, s_rgb);
+  if (rgb) fold_records256(part_rgb, nblocks, kSE3, s_rgb);
   __syncthreads();
   if (threadIdx.x != 0) return;
 
@@ -539,7 +530,9 @@ __global__ __launch_bounds__(1024) void k_gn_solve(TrackState* st, const float* 
   }
   for (int i = 0; i < 36; ++i) st->lastA[i] = A[i];
   for (int i = 0; i < 6; ++i) st->lastb[i] = b[i];
-  sm::ldlt_solve<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308);
+  __shared__ double l_A[36], l_t[6], l_y[6];
+  __shared__ int l_p[6];
+  sm::ldlt_solve_ws<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308, l_A, l_t, l_y, l_p);
 
   // OdometryProvider::computeUpdateSE3 (OdometryProvider.h:73-93)
   double Rt[16];
@@ -641,9 +634,9 @@ void layout(dms_odometry* o, Carver& c) {
   }
   o->vmaps_tmp = (float*)c.take((size_t)W * H * 16);
   o->nmaps_tmp = (float*)c.take((size_t)W * H * 16);
-  o->part_icp = (float*)c.take((size_t)kSE3 * kMaxPartialBlocks * 4);
-  o->part_rgb = (float*)c.take((size_t)kSE3 * kMaxPartialBlocks * 4);
-  o->part_so3 = (float*)c.take((size_t)kSO3 * kMaxPartialBlocks * 4);
+  o->part_icp = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
+  o->part_rgb = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
+  o->part_so3 = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
   o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
   o->state = (TrackState*)c.take(sizeof(TrackState));
 }
@@ -933,7 +926,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       }
       {
         Timer t(o, s, "so3_solve");
-        hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(1024), 0, s, o->state, o->part_so3, kMaxPartialBlocks, nb, o->fx, o->fy, o->cx,
+        hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(256), 0, s, o->state, o->part_so3, kMaxPartialBlocks, nb, o->fx, o->fy, o->cx,
                            o->cy, i == 9 ? 1 : 0, first_level);
         DMS_CHECK_LAUNCH();
       }
@@ -1015,7 +1008,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       }
       {
         Timer t(o, s, "gn_solve");
-        hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(1024), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks,
+        hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks,
                            nb, icp ? 1 : 0, rgb ? 1 : 0, rgbOnly ? 1 : 0, icpWeight, l, j == 0 ? 1 : 0, next_level, level_below, o->fx,
                            o->fy, o->cx, o->cy);
         DMS_CHECK_LAUNCH();

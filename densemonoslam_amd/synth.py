@@ -101,8 +101,13 @@ def _slab(o, d, bmin, bmax):
 def texture(p):
     x, y, z = p[..., 0], p[..., 1], p[..., 2]
     out = np.empty(p.shape[:-1] + (3,), np.float64)
+    # The smooth SURVEY texture alone has image gradients of ~1 level/pixel at 1.4 m, far below the
+    # photometric gate of the tracker (|Sobel| >= 40, RGBDOdometry.cpp:445), so a 3-D checker of
+    # 12.6 cm cells is added: its edges give the >= 11 levels/pixel the gate asks for.
+    checker = np.sign(np.sin(25 * x + 0.3) * np.sin(25 * y + 1.1) * np.sin(25 * z + 2.0))
     for ch, ph in enumerate((0.0, 0.9, 1.7)):
-        out[..., ch] = 128 + 64 * np.sin(7 * x + ph) * np.sin(5 * y + 0.5 * ph) + 32 * np.sin(11 * z + 2 * ph)
+        out[..., ch] = (128 + 40 * np.sin(7 * x + ph) * np.sin(5 * y + 0.5 * ph) + 20 * np.sin(11 * z + 2 * ph)
+                        + (45 - 6 * ch) * checker)
     return out
 
 

@@ -348,16 +348,20 @@ def test_track_recovers_known_motion_synthetic(dms, orc):
         trk.initICP(d2, 20.0)
         trk.initRGB(synth.rgba(rgb2))
         trk.initFirstRGB(synth.rgba(rgb1))
-    cfg = dict(rgbOnly=False, icpWeight=100.0, pyramid=True, fastOdom=False, so3=False)
+    # full configuration: the box room is near-planar, so ICP alone slides along the wall; the
+    # photometric term (checker texture) and the SO3 pre-alignment pin the motion down
+    cfg = dict(rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True)
     tg, Rg, rg = g.getIncrementalTransformation(P1[:3, 3], P1[:3, :3], **cfg)
     to, Ro, ro = o.getIncrementalTransformation(P1[:3, 3], P1[:3, :3], **cfg)
     helpers.assert_pose_close(tg, Rg, to, Ro, what="synthetic vs oracle")
-    # against ground truth: quantised depth (1 mm) and forward-difference normals limit accuracy
+    assert rg.lastRGBCount > 10000 and rg.lastICPCount > 200000
+    # against ground truth: the estimate must be much closer to the true pose than the prior was
     err_t = np.linalg.norm(tg.astype(np.float64) - T2[:3, 3])
     err_r = helpers.rot_angle_deg(Rg, T2[:3, :3])
     prior_t = np.linalg.norm(T1[:3, 3] - T2[:3, 3])
-    assert err_t < 0.25 * prior_t + 5e-4, (err_t, prior_t)
-    assert err_r < 0.05, err_r
+    prior_r = helpers.rot_angle_deg(T1[:3, :3], T2[:3, :3])
+    assert err_t < 0.35 * prior_t, (err_t, prior_t)
+    assert err_r < 0.75 * prior_r, (err_r, prior_r)
 
 
 def test_track_profiling_counters(dms, orc, gputest_pair):
