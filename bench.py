@@ -76,7 +76,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from densemonoslam_amd import capi, fusion, synth
+    from densemonoslam_amd import capi, collab, fusion, synth
 
     capi.check(capi.lib.dms_set_device(local_rank), "dms_set_device")
     W, H = args.width, args.height
@@ -108,8 +108,8 @@ def main():
 
     # thumbnails exchanged in collaborative mode: W/8 x H/8 image + vertex + normal
     tw, th = W // 8, H // 8
-    thumb = torch.zeros((th * tw * (4 + 16 + 16),), dtype=torch.uint8, device=dev)
-    gathered = torch.zeros((world, thumb.numel()), dtype=torch.uint8, device=dev) if distributed else None
+    exchange = collab.ThumbnailExchange(world, W, H, dev)
+    thumb = exchange.local
     import ctypes as C
 
     def thumb_views():
@@ -136,7 +136,7 @@ def main():
             capi.check(capi.lib.dms_resize_nn(C.byref(src[0]), C.byref(tv[0]), 4, stream))
             capi.check(capi.lib.dms_resize_nn(C.byref(src[1]), C.byref(tv[1]), 16, stream))
             capi.check(capi.lib.dms_resize_nn(C.byref(src[2]), C.byref(tv[2]), 16, stream))
-            dist.all_gather_into_tensor(gathered.view(-1), thumb)
+            exchange.gather()
 
     def barrier():
         if distributed:
@@ -154,15 +154,8 @@ def main():
     res = ef.fetch(stream)
     M = int(res.surfels)
 
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        msum = torch.tensor([M], dtype=torch.float64, device=dev)
-        dist.all_reduce(msum, op=dist.ReduceOp.SUM)
-        M_total = int(msum.item())
-    else:
-        M_total = M
+    elapsed = collab.max_over_ranks(elapsed, dev)  # the slowest rank defines the job time
+    M_total = int(collab.sum_over_ranks(M, dev))
 
     fps = world * args.steps / elapsed
     out = {

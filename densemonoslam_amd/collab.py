@@ -1,0 +1,59 @@
+"""Collaborative-session plumbing: one camera (and its own surfel map) per GPU / rank.
+
+The reference runs its cameras one after the other in one process on one GPU
+(GUI/src/MainController.cpp:262-400) and has its inter-map matching compiled out
+(Core/src/ElasticFusion.cpp:597).  Here every rank owns the Context + ReferenceFrame of its
+cameras; nothing is shared until a map merge, so the data path needs no collective.  The only
+per-frame exchange is the all-gather of each camera's W/8 x H/8 thumbnails (image, vertex and
+normal maps), the inputs of the fern matcher (Core/src/Ferns.cpp:277-423) — SURVEY.md §8(e).
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests)
+carries it; PyTorch is plumbing here, not the product.
+"""
+import torch
+import torch.distributed as dist
+
+THUMB_BYTES_PER_PIXEL = 4 + 16 + 16  # RGBA8 image + RGBA32F vertex + RGBA32F normal
+
+
+def thumbnail_bytes(width, height):
+    return (width // 8) * (height // 8) * THUMB_BYTES_PER_PIXEL
+
+
+def shard_cameras(n_cameras, rank, world):
+    """Camera ids owned by `rank`: round-robin, so n_cameras == world gives one camera per GPU."""
+    return [c for c in range(n_cameras) if c % world == rank]
+
+
+class ThumbnailExchange:
+    """Fixed-size per-frame all-gather of one camera's thumbnail block per rank."""
+
+    def __init__(self, world, width, height, device):
+        self.world = world
+        self.nbytes = thumbnail_bytes(width, height)
+        self.local = torch.zeros((self.nbytes,), dtype=torch.uint8, device=device)
+        self.gathered = torch.zeros((world, self.nbytes), dtype=torch.uint8, device=device)
+
+    def gather(self):
+        if self.world == 1:
+            self.gathered[0].copy_(self.local)
+            return self.gathered
+        try:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local)
+        except (RuntimeError, NotImplementedError):  # backends without the flat form
+            parts = [self.gathered[r] for r in range(self.world)]
+            dist.all_gather(parts, self.local)
+        return self.gathered
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

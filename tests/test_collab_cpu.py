@@ -1,0 +1,83 @@
+"""World-size-2 gloo test of the collaborative (N > 1) path on CPU: camera sharding, the
+per-frame thumbnail all-gather and the max-over-ranks timing reduction used by bench.py."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _thumbs_for_camera(cam, W, H):
+    """Thumbnail block of camera `cam` built on the CPU from the synthetic stream (oracle resize)."""
+    from densemonoslam_amd import synth
+    from oracle import orc
+
+    K = (0.825 * W, 0.825 * W, W / 2.0, H / 2.0)
+    d, rgb, _ = synth.frame(3, cam_id=cam, width=W, height=H, K=K, noise=False)
+    rgba = synth.rgba(rgb)
+    vmap = orc.createVMap(K, d, 20.0)
+    v4 = np.zeros((H, W, 4), np.float32)
+    for c in range(3):
+        v4[..., c] = np.nan_to_num(vmap[c * H:(c + 1) * H])
+    n4 = np.roll(v4, 1, axis=2)
+    parts = [orc.resize_nn(rgba, H // 8, W // 8), orc.resize_nn(v4, H // 8, W // 8), orc.resize_nn(n4, H // 8, W // 8)]
+    return np.concatenate([p.reshape(-1).view(np.uint8) for p in parts])
+
+
+def _worker(rank, world, port, W, H, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from densemonoslam_amd import collab
+
+    dev = torch.device("cpu")
+    cams = collab.shard_cameras(world, rank, world)
+    assert cams == [rank]
+    ex = collab.ThumbnailExchange(world, W, H, dev)
+    block = _thumbs_for_camera(cams[0], W, H)
+    assert block.size == ex.nbytes == collab.thumbnail_bytes(W, H)
+    ex.local.copy_(torch.from_numpy(block))
+    g = ex.gather().numpy().copy()
+    tmax = collab.max_over_ranks(0.5 + rank, dev)
+    tsum = collab.sum_over_ranks(10 + rank, dev)
+    out.put((rank, g, tmax, tsum))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_thumbnail_allgather_gloo():
+    world, W, H = 2, 160, 120
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.stack([_thumbs_for_camera(c, W, H) for c in range(world)])
+    assert (expect[0] != expect[1]).any(), "the two cameras must see different thumbnails"
+    for rank, g, tmax, tsum in results:
+        assert g.shape == expect.shape and (g == expect).all(), "rank %d gathered wrong thumbnails" % rank
+        assert tmax == 1.5 and tsum == 21.0
+
+
+def test_camera_sharding():
+    from densemonoslam_amd import collab
+
+    assert collab.shard_cameras(8, 3, 8) == [3]
+    assert collab.shard_cameras(4, 1, 2) == [1, 3]
+    assert sorted(sum((collab.shard_cameras(5, r, 2) for r in range(2)), [])) == [0, 1, 2, 3, 4]
+    assert collab.thumbnail_bytes(640, 480) == 80 * 60 * 36
