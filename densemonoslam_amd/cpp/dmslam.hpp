@@ -1,0 +1,176 @@
+// C++ mirror of the reference's elasticfusion/Core classes over the C ABI of libdmslam_hip.so.
+//
+// Header-only; no Eigen / Pangolin / CUDA needed.  Matrices cross as plain row-major float
+// arrays; when <Eigen/Core> is available the overloads at the bottom accept the reference's own
+// argument types (Eigen::Vector3f, Eigen::Matrix<float,3,3,RowMajor>, Eigen::Matrix4f) so that
+// GUI/src/MainController.cpp, Core/src/ElasticFusion.cpp and GPUTest.cpp call sites compile
+// unchanged against these classes.
+//
+//   reference class / method                                   -> here
+//   RGBDOdometry (Core/src/Utils/RGBDOdometry.h:32-153)        -> dms::RGBDOdometry
+//   GPUTexture   (Core/src/GPUTexture.h:29-57)                 -> dms::DeviceTexture (pitched HBM image)
+//   GlobalModel  (Core/src/GlobalModel.h:43-141)               -> dms::GlobalModel
+//   IndexMap     (Core/src/IndexMap.h:33-205)                  -> dms::IndexMap
+//   ElasticFusion::processFrame (ElasticFusion.h:92-100)       -> dms::ElasticFusion::processFrame
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dmslam.h"
+#include "../../include/dmslam_fusion.h"
+
+namespace dms {
+
+inline void check(int rc, const char* what) {
+  if (rc != DMS_OK) throw std::runtime_error(std::string(what) + ": " + dms_last_error());
+}
+
+// Pitched device image; replaces GPUTexture (GL texture + cudaGraphicsResource) in the kept API.
+class DeviceTexture {
+ public:
+  DeviceTexture(int width, int height, size_t elemBytes) : width(width), height(height), elem(elemBytes) {
+    check(dms_device_alloc(&ptr, (size_t)width * height * elemBytes), "dms_device_alloc");
+    view.data = ptr;
+    view.pitch = (size_t)width * elemBytes;
+    view.rows = height;
+    view.cols = width;
+  }
+  ~DeviceTexture() { dms_device_free(ptr); }
+  DeviceTexture(const DeviceTexture&) = delete;
+  DeviceTexture& operator=(const DeviceTexture&) = delete;
+  // GPUTexture::texture->Upload(ptr, format, type) (ElasticFusion.cpp:111-114, GPUTest.cpp:39,59)
+  void Upload(const void* host, dms_stream s = nullptr) { check(dms_memcpy_h2d(ptr, host, (size_t)width * height * elem, s), "upload"); }
+  void Download(void* host, dms_stream s = nullptr) const { check(dms_memcpy_d2h(host, ptr, (size_t)width * height * elem, s), "download"); }
+  const dms_image2d* image() const { return &view; }
+  void* ptr = nullptr;
+  dms_image2d view;
+  const int width, height;
+  const size_t elem;
+};
+
+class RGBDOdometry {
+ public:
+  RGBDOdometry(int width, int height, float cx, float cy, float fx, float fy, float distThresh = 0.10f, float angleThresh = 0.0f) {
+    check(dms_odometry_create(&h, width, height, cx, cy, fx, fy, distThresh, angleThresh), "dms_odometry_create");
+  }
+  virtual ~RGBDOdometry() { dms_odometry_destroy(h); }
+  RGBDOdometry(const RGBDOdometry&) = delete;
+
+  void initICP(DeviceTexture* filteredDepth, const float depthCutoff, dms_stream stream = nullptr) {
+    check(dms_odometry_initICP_depth(h, filteredDepth->image(), depthCutoff, stream), "initICP");
+  }
+  void initICP(DeviceTexture* predictedVertices, DeviceTexture* predictedNormals, const float depthCutoff, dms_stream stream = nullptr) {
+    check(dms_odometry_initICP_maps(h, (const float*)predictedVertices->ptr, (const float*)predictedNormals->ptr, depthCutoff, stream), "initICP");
+  }
+  void initICPModel(DeviceTexture* predictedVertices, DeviceTexture* predictedNormals, const float depthCutoff, const float* modelPose16,
+                    dms_stream stream = nullptr) {
+    check(dms_odometry_initICPModel(h, (const float*)predictedVertices->ptr, (const float*)predictedNormals->ptr, depthCutoff, modelPose16,
+                                    stream),
+          "initICPModel");
+  }
+  void initRGB(DeviceTexture* rgb, dms_stream stream = nullptr) { check(dms_odometry_initRGB(h, rgb->image(), stream), "initRGB"); }
+  void initRGBModel(DeviceTexture* rgb, dms_stream stream = nullptr) { check(dms_odometry_initRGBModel(h, rgb->image(), stream), "initRGBModel"); }
+  void initFirstRGB(DeviceTexture* rgb, dms_stream s = nullptr) { check(dms_odometry_initFirstRGB(h, rgb->image(), s), "initFirstRGB"); }
+
+  // trans[3], rot[9] row-major, in/out — RGBDOdometry::getIncrementalTransformation (RGBDOdometry.cpp:268)
+  void getIncrementalTransformation(float* trans, float* rot, const bool& rgbOnly, const float& icpWeight, const bool& pyramid,
+                                    const bool& fastOdom, const bool& so3, const bool interMap = false, dms_stream stream = nullptr) {
+    dms_track_result r;
+    check(dms_odometry_getIncrementalTransformation(h, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap, &r, stream),
+          "getIncrementalTransformation");
+    lastICPError = r.lastICPError;
+    lastICPCount = r.lastICPCount;
+    lastRGBError = r.lastRGBError;
+    lastRGBCount = r.lastRGBCount;
+    lastSO3Error = r.lastSO3Error;
+    lastSO3Count = r.lastSO3Count;
+    for (int i = 0; i < 36; ++i) lastA[i] = r.lastA[i];
+    for (int i = 0; i < 6; ++i) lastb[i] = r.lastb[i];
+  }
+  void getCovariance(double* cov36) { check(dms_odometry_getCovariance(h, cov36), "getCovariance"); }
+
+  float lastICPError = 0, lastICPCount = 0, lastRGBError = 0, lastRGBCount = 0, lastSO3Error = 0, lastSO3Count = 0;
+  double lastA[36] = {0};
+  double lastb[6] = {0};
+  dms_odometry* h = nullptr;
+};
+
+class GlobalModel {
+ public:
+  static const int TEXTURE_DIMENSION = 5700;  // GlobalModel.cpp:22
+  GlobalModel(int width, int height, size_t capacity = 0) : owned(true) { check(dms_model_create(&h, capacity, width, height), "dms_model_create"); }
+  explicit GlobalModel(dms_model* borrowed) : h(borrowed), owned(false) {}
+  virtual ~GlobalModel() {
+    if (owned) dms_model_destroy(h);
+  }
+  unsigned int lastCount() {
+    unsigned int n = 0;
+    check(dms_model_count(h, &n, nullptr), "lastCount");
+    return n;
+  }
+  // GlobalModel::downloadMap (GlobalModel.cpp:866-896): reference 15-float records
+  std::vector<float> downloadMap() {
+    unsigned int n = lastCount(), got = 0;
+    std::vector<float> v((size_t)n * 15);
+    check(dms_model_download_ref(h, v.data(), n, &got, nullptr), "downloadMap");
+    v.resize((size_t)got * 15);
+    return v;
+  }
+  dms_model* h = nullptr;
+
+ private:
+  bool owned;
+};
+
+class ElasticFusion {
+ public:
+  // the constructor arguments of the reference that reach the hot path (ElasticFusion.cpp:22-73)
+  ElasticFusion(int width, int height, float fx, float fy, float cx, float cy, const int timeDelta = 200, const float confidence = 10,
+                const float depthCut = 3, const float icpThresh = 10, const bool fastOdom = false, const bool so3 = true,
+                const bool frameToFrameRGB = false) {
+    dms_fusion_params p;
+    dms_fusion_default_params(&p, width, height, fx, fy, cx, cy);
+    p.timeDelta = timeDelta;
+    p.confidence = confidence;
+    p.depthCut = depthCut;
+    p.icpWeight = icpThresh;
+    p.fastOdom = fastOdom;
+    p.so3 = so3;
+    p.frameToFrameRGB = frameToFrameRGB;
+    check(dms_fusion_create(&h, &p), "dms_fusion_create");
+  }
+  virtual ~ElasticFusion() { dms_fusion_destroy(h); }
+  ElasticFusion(const ElasticFusion&) = delete;
+
+  // rgb (RGB8) and depth (u16 mm) already in HBM; inPose 4×4 row-major or nullptr
+  void processFrame(const unsigned char* rgb_dev, const unsigned short* depth_dev, const float* inPose = nullptr,
+                    const float weightMultiplier = 1.f, dms_stream s = nullptr) {
+    check(dms_fusion_process_frame(h, rgb_dev, 3, depth_dev, inPose, weightMultiplier, s), "processFrame");
+  }
+  dms_frame_result fetch(dms_stream s = nullptr) {
+    dms_frame_result r;
+    check(dms_fusion_fetch(h, &r, s), "fetch");
+    return r;
+  }
+  GlobalModel getGlobalModel() { return GlobalModel(dms_fusion_model(h)); }
+  dms_fusion* h = nullptr;
+};
+
+}  // namespace dms
+
+#if defined(DMS_WITH_EIGEN) || defined(EIGEN_CORE_H) || defined(EIGEN_CORE_MODULE_H)
+#include <Eigen/Core>
+namespace dms {
+// The reference's own signature (RGBDOdometry.h:55-60)
+inline void getIncrementalTransformation(RGBDOdometry& o, Eigen::Vector3f& trans, Eigen::Matrix<float, 3, 3, Eigen::RowMajor>& rot,
+                                         const bool& rgbOnly, const float& icpWeight, const bool& pyramid, const bool& fastOdom,
+                                         const bool& so3, const bool interMap = false) {
+  o.getIncrementalTransformation(trans.data(), rot.data(), rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap);
+}
+inline void initICPModel(RGBDOdometry& o, DeviceTexture* v, DeviceTexture* n, float depthCutoff, const Eigen::Matrix4f& modelPose) {
+  Eigen::Matrix<float, 4, 4, Eigen::RowMajor> p = modelPose;
+  o.initICPModel(v, n, depthCutoff, p.data());
+}
+}  // namespace dms
+#endif
