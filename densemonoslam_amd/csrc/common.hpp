@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dmslam.h"
@@ -219,7 +220,12 @@ __device__ __forceinline__ void fold_records256(const float* __restrict__ partia
 // grid-stride beyond.  ≥ 2 blocks per CU at 640×480 so every XCD's L2 sees its share.
 inline int reduce_blocks_for(int n) {
   int b = (n + kBlock - 1) / kBlock;
-  if (b > kAutoPartialBlocks) b = kAutoPartialBlocks;
+  static const int cap = [] {  // tuning knob for A/B runs: DMS_PARTIAL_BLOCKS=64..1024
+    const char* e = getenv("DMS_PARTIAL_BLOCKS");
+    int v = e ? atoi(e) : kAutoPartialBlocks;
+    return v < 64 ? 64 : (v > kMaxPartialBlocks ? kMaxPartialBlocks : v);
+  }();
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return b;
 }

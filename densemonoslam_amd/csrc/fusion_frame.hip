@@ -29,17 +29,18 @@ int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s)
 int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
                      int timeIdx, float maxDepth, hipStream_t s);
 int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
-              unsigned long long* zbuf, dms_indexmap_out* out, hipStream_t s);
+              unsigned long long* zbuf, dms_indexmap_out* out, int transposed, hipStream_t s);
+int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStream_t s);
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, hipStream_t s);
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
-               const float* weighting_dev, hipStream_t s);
+               const float* weighting_dev, int transposed, hipStream_t s);
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
-                int isFern, hipStream_t s);
+                int isFern, int transposed, hipStream_t s);
 // track.hip
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
                            float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s);
@@ -174,6 +175,7 @@ struct dms_fusion {
   dms_indexmap_out imap;
   dms_predict_out pred, fill;
   void* rgba_tmp = nullptr;
+  void* untr = nullptr;  // W*H*16 scratch for row-major copies handed out by dms_fusion_get_image
   unsigned long long* zbuf = nullptr;
   FrameState* state = nullptr;
   FrameState* h_state = nullptr;  // pinned
@@ -232,6 +234,7 @@ void layout(dms_fusion* f, Carve& c) {
   f->fill.normal = mk_img(c.take(N * 16), H, W, 16);
   f->fill.time = f->pred.time;
   f->rgba_tmp = c.take(N * 4);
+  f->untr = c.take(N * 16);
   f->zbuf = (unsigned long long*)c.take(N * 8);
   f->state = (FrameState*)c.take(sizeof(FrameState));
 }
@@ -307,7 +310,7 @@ int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2
 }
 int dms_index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
                   unsigned long long* zbuf, dms_indexmap_out* out, dms_stream s) {
-  return index_map(m, pose, cam, time, timeIdx, maxDepth, timeDelta, zbuf, out, (hipStream_t)s);
+  return index_map(m, pose, cam, time, timeIdx, maxDepth, timeDelta, zbuf, out, 0, (hipStream_t)s);
 }
 int dms_splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                       int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out, dms_stream s) {
@@ -323,12 +326,12 @@ int dms_splat_depth(dms_model* m, const dms_pose_block* pose, const dms_camera* 
 int dms_model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                    const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
                    const float* weighting_dev, dms_stream s) {
-  return model_fuse(m, pose, time, timeIdx, rgba, dr, drf, im, cam, depthCutoff, weighting, weighting_dev, (hipStream_t)s);
+  return model_fuse(m, pose, time, timeIdx, rgba, dr, drf, im, cam, depthCutoff, weighting, weighting_dev, 0, (hipStream_t)s);
 }
 int dms_model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im,
                     const dms_image2d* depth_synth, const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes,
                     int timeDelta, float maxDepth, int isFern, dms_stream s) {
-  return model_clean(m, pose, time, timeIdx, im, depth_synth, cam, confThreshold, graph_host, graph_nodes, timeDelta, maxDepth, isFern,
+  return model_clean(m, pose, time, timeIdx, im, depth_synth, cam, confThreshold, graph_host, graph_nodes, timeDelta, maxDepth, isFern, 0,
                      (hipStream_t)s);
 }
 int dms_fill_in(const dms_predict_out* ex, const dms_image2d* d, const dms_image2d* rgba, const dms_camera* cam, int pg, int pr,
@@ -506,25 +509,25 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
       {
         FTimer t(f, s, "index_map");
         if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
-                            &f->imap, s)))
+                            &f->imap, 1, s)))
           return rc;
       }
       {
         FTimer t(f, s, "fuse");
         if ((rc = model_fuse(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->rgba, &f->depth_metric, &f->depth_metric_filtered,
-                             &f->imap, &f->cam, f->p.maxDepthProcessed, 1.f, &f->state->weighting, s)))
+                             &f->imap, &f->cam, f->p.maxDepthProcessed, 1.f, &f->state->weighting, 1, s)))
           return rc;
       }
       {
         FTimer t(f, s, "index_map");
         if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
-                            &f->imap, s)))
+                            &f->imap, 1, s)))
           return rc;
       }
       {
         FTimer t(f, s, "clean");
         if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, nullptr, 0,
-                              f->p.timeDelta, f->p.maxDepthProcessed, 0, s)))
+                              f->p.timeDelta, f->p.maxDepthProcessed, 0, 1, s)))
           return rc;
       }
       fused = 1;
@@ -569,6 +572,15 @@ int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {
                             &f->fill.normal};
   DMS_REQUIRE(which >= 0 && which < 16, "bad image id");
   *view = *t[which];
+  if (which >= 5 && which <= 8) {
+    // the frame step keeps the index-map images column-major; hand out a row-major copy
+    const int elem = which == 5 ? 4 : 16;
+    void* dst = f->untr;
+    int rc = untranspose(t[which]->data, dst, f->p.width, f->p.height, elem, 0);
+    if (rc) return rc;
+    DMS_HIP(hipDeviceSynchronize());
+    view->data = dst;
+  }
   return DMS_OK;
 }
 

@@ -37,6 +37,7 @@ struct FuseArgs {
   float maxDepth, timef, weighting;
   const float* weighting_dev;
   int time, timeIdx;
+  int transposed;  // index-map images stored column-major (fusion_map.hip ProjArgs::transposed)
 };
 
 __device__ __forceinline__ f3 dv_vertex(const float* depth, int cols, int sx, int sy, float x, float y, float cx, float cy, float icx,
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
       const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
       for_taps(tx_, [&](int ux, int) {
         for_taps(ty_, [&](int uy, int) {
-          const size_t q = (size_t)uy * a.cols + ux;
+          const size_t q = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
           const unsigned current = a.index[q];
           if (current > 0u) {
             const float4 vc = a.vertConf[q];
@@ -202,6 +203,7 @@ struct CleanArgs {
   int nodes;
   const float* node_table;
   int nslots;
+  int transposed;
 };
 
 struct CleanElem {
@@ -268,7 +270,7 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
     const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
     for_taps(tx_, [&](int ux, int mx) {
       for_taps(ty_, [&](int uy, int my) {
-        const size_t q = (size_t)uy * a.cols + ux;
+        const size_t q = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
         const unsigned current = a.index[q];
         if (current > 0u) {
           const float4 vc = a.vertConf[q];
@@ -492,7 +494,7 @@ static bool dense_img(const dms_image2d& im, size_t elem, int w, int h) {
 
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
-               const float* weighting_dev, hipStream_t s) {
+               const float* weighting_dev, int transposed, hipStream_t s) {
   DMS_REQUIRE(m && pose && rgba && dr && drf && im && cam, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -520,6 +522,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   a.weighting_dev = weighting_dev;
   a.time = time;
   a.timeIdx = timeIdx;
+  a.transposed = transposed ? 1 : 0;
   const int slot_w = (W + 1) / 2;
   dim3 b(256), g((m->slot_h + 255) / 256, slot_w);
   hipLaunchKernelGGL(k_fuse_associate, g, b, 0, s, a, m->slot_pos, m->slot_col, m->slot_nrm, m->slot_best, m->slot_flag, m->winner, slot_w);
@@ -532,7 +535,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
 
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
-                int isFern, hipStream_t s) {
+                int isFern, int transposed, hipStream_t s) {
   DMS_REQUIRE(m && pose && im && cam, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -567,6 +570,7 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   a.nodes = graph_nodes;
   a.node_table = m->nodes;
   a.nslots = m->slots;
+  a.transposed = transposed ? 1 : 0;
   const size_t upper = m->count_upper + (size_t)m->slots;
   const int nb = (int)((upper + kScanChunk - 1) / kScanChunk);
   const SurfelPlanes src = m->buf[m->cur], dst = m->buf[m->cur ^ 1];

@@ -363,6 +363,10 @@ struct ProjArgs {
   float confThreshold;
   int maxTime;
   int actv;
+  // index map only: 1 = images stored column-major (pixel (x, y) at x * rows + y).  The fusion
+  // consumers walk the image by columns (the reference's draw order, GlobalModel.cpp:100-108),
+  // so this is the layout that makes their 16-byte gathers coalesce.
+  int transposed;
 };
 
 __global__ void k_clear_zbuf(unsigned long long* z, int n) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void k_index_project(ProjArgs a, SurfelPlanes 
     const unsigned d = depth24(zw);
     if (d >= 0xFFFFFFu) continue;  // GL_LESS against the cleared depth 1.0
     const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)i;
-    unsigned long long* cell = zbuf + (size_t)py * a.cols + px;
+    unsigned long long* cell = zbuf + (a.transposed ? (size_t)px * a.rows + py : (size_t)py * a.cols + px);
     if (key < *cell) atomicMin(cell, key);
   }
 }
@@ -407,6 +411,8 @@ __global__ __launch_bounds__(256) void k_index_project(ProjArgs a, SurfelPlanes 
 __global__ __launch_bounds__(256) void k_index_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned long long* __restrict__ zbuf,
                                                        unsigned* __restrict__ index, float4* __restrict__ vertConf,
                                                        float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+  // p runs over the storage order of the images (row-major, or column-major when a.transposed):
+  // the z-buffer uses the same order, so reads and writes are coalesced either way
   const int n = a.cols * a.rows;
   const float* Tinv = a.pose->t_inv;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
@@ -427,6 +433,26 @@ __global__ __launch_bounds__(256) void k_index_resolve(ProjArgs a, SurfelPlanes 
     colorTime[p] = make_float4(cc.x, cc.y, cc.z, sp.times[(size_t)a.timeIdx * cap + i]);
     normRad[p] = make_float4(nh.x, nh.y, nh.z, nr.w);
   }
+}
+
+// column-major -> row-major copy of an image with `elem`-byte pixels (inspection path only)
+template <typename T>
+__global__ void k_untranspose(const T* __restrict__ src, T* __restrict__ dst, int cols, int rows) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  dst[(size_t)y * cols + x] = src[(size_t)x * rows + y];
+}
+
+int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStream_t s) {
+  dim3 b(32, 8), g((cols + 31) / 32, (rows + 7) / 8);
+  if (elem == 4)
+    hipLaunchKernelGGL(k_untranspose<unsigned>, g, b, 0, s, (const unsigned*)src, (unsigned*)dst, cols, rows);
+  else if (elem == 16)
+    hipLaunchKernelGGL(k_untranspose<float4>, g, b, 0, s, (const float4*)src, (float4*)dst, cols, rows);
+  else
+    DMS_REQUIRE(false, "elem must be 4 or 16");
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
 }
 
 static int surfel_grid(size_t upper) {
@@ -458,10 +484,11 @@ static void fill_proj(ProjArgs& a, const dms_model* m, const dms_pose_block* pos
   a.confThreshold = 0.f;
   a.maxTime = 0;
   a.actv = 0;
+  a.transposed = 0;
 }
 
 int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
-              unsigned long long* zbuf, dms_indexmap_out* out, hipStream_t s) {
+              unsigned long long* zbuf, dms_indexmap_out* out, int transposed, hipStream_t s) {
   DMS_REQUIRE(m && pose && cam && zbuf && out, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -470,6 +497,7 @@ int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, i
               "index-map targets must be dense W×H");
   ProjArgs a;
   fill_proj(a, m, pose, cam, maxDepth, time, timeIdx, timeDelta);
+  a.transposed = transposed ? 1 : 0;
   const int n = W * H;
   hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
   DMS_CHECK_LAUNCH();
@@ -562,7 +590,9 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
         const unsigned d = depth24(zw);
         if (d >= 0xFFFFFFu) continue;
         const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)i;
-        unsigned long long* cell = zbuf + (size_t)py * a.cols + px;
+        // column-major z-buffer: surfels arrive in column-major order (GlobalModel.cpp:100-108), so the
+        // atomics of neighbouring lanes land in the same cache lines
+        unsigned long long* cell = zbuf + (size_t)px * a.rows + py;
         if (key < *cell) atomicMin(cell, key);
       }
   }
@@ -574,7 +604,9 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
                                                        unsigned short* __restrict__ timeImg, float* __restrict__ depthOut) {
   const int n = a.cols * a.rows;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
-    const unsigned long long key = zbuf[p];
+    // outputs are row-major (the tracker consumes them); the z-buffer is column-major
+    const int py = p / a.cols, px = p - py * a.cols;
+    const unsigned long long key = zbuf[(size_t)px * a.rows + py];
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {
       if (DEPTH_ONLY) {
         depthOut[p] = 0.f;
@@ -589,7 +621,6 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     const unsigned i = (unsigned)(key & 0xFFFFFFFFull);
     SplatSurfel s;
     splat_vertex(a, sp.pos[i], sp.nrm[i], sp.times[(size_t)a.timeIdx * cap + i], s);
-    const int py = p / a.cols, px = p - py * a.cols;
     f3 c;
     float zw;
     splat_fragment(a, s, px, py, c, zw);

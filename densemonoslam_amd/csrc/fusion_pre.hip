@@ -9,12 +9,22 @@ static constexpr int BX = 64, BY = 4;
 
 // G1 — depth_bilateral.frag:30-75.  Fragment (x, y) has texcoord ((x+0.5)/cols, (y+0.5)/rows);
 // taps are fetched at (float(cx)/cols, float(cy)/rows) with the NEAREST rule of surfel.hpp.
+// The tap -> texel tables (one fp32 division + floor per column / row) are built once per block
+// in LDS instead of once per tap; the 169-tap sum itself keeps the shader's order and arithmetic.
 __global__ __launch_bounds__(BX* BY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
                                                             int cols, int rows, float maxD) {
+  constexpr int HALO = 8;
+  __shared__ int s_sx[BX + 2 * HALO];
+  __shared__ int s_sy[BY + 2 * HALO];
+  const float colsf = (float)cols, rowsf = (float)rows;
+  const int bx0 = blockIdx.x * BX - HALO, by0 = blockIdx.y * BY - HALO;
+  const int tid = threadIdx.y * BX + threadIdx.x;
+  if (tid < BX + 2 * HALO) s_sx[tid] = texel((float)(bx0 + tid) / colsf, colsf, cols);
+  if (tid >= 128 && tid < 128 + BY + 2 * HALO) s_sy[tid - 128] = texel((float)(by0 + tid - 128) / rowsf, rowsf, rows);
+  __syncthreads();
   const int px = blockIdx.x * blockDim.x + threadIdx.x;
   const int py = blockIdx.y * blockDim.y + threadIdx.y;
   if (px >= cols || py >= rows) return;
-  const float colsf = (float)cols, rowsf = (float)rows;
   const unsigned value = src[(size_t)py * cols + px];
   const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
   if (value > gate || value < 300U) {
@@ -31,16 +41,24 @@ __global__ __launch_bounds__(BX* BY) void k_depth_bilateral(const unsigned short
   const int D = R * 2 + 1;
   const int tx = min(x - D / 2 + D, cols);
   const int ty = min(y - D / 2 + D, rows);
+  const float fvalue = (float)value;
   float sum1 = 0.f, sum2 = 0.f;
   for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
-    const int sy = texel((float)cy / rowsf, rowsf, rows);
+    const int ky = cy - by0;
+    const int sy = (ky >= 0 && ky < BY + 2 * HALO) ? s_sy[ky] : texel((float)cy / rowsf, rowsf, rows);
+    const unsigned short* srow = src + (size_t)sy * cols;
+    const int dyi = y - cy;
     for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
-      const int sx = texel((float)cx / colsf, colsf, cols);
-      const unsigned tmp = src[(size_t)sy * cols + sx];
-      const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
-      const float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);
+      const int kx = cx - bx0;
+      const int sx = (kx >= 0 && kx < BX + 2 * HALO) ? s_sx[kx] : texel((float)cx / colsf, colsf, cols);
+      const float ftmp = (float)srow[sx];
+      // (float(x)-float(cx))^2 + (float(y)-float(cy))^2: small integers, exact in fp32
+      const int dxi = x - cx;
+      const float space2 = (float)(dxi * dxi + dyi * dyi);
+      const float dc = fvalue - ftmp;
+      const float color2 = dc * dc;
       const float weight = det_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
-      sum1 += (float)tmp * weight;
+      sum1 += ftmp * weight;
       sum2 += weight;
     }
   }

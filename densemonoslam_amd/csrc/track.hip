@@ -90,6 +90,7 @@ struct dms_odometry {
   float* part_rgb = nullptr;   // [29][1024]
   float* part_so3 = nullptr;   // [11][1024]
   int* part_cnt = nullptr;     // [2][1024]
+  unsigned* tickets = nullptr; // [4] arrival counters of the last-block-solves hand-off (zero between launches)
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
   bool profiling = false;
@@ -190,9 +191,16 @@ __global__ void k_track_init(TrackState* st, Prior prior, const float* __restric
 // ---------------------------------------------------------------------------------------
 // SO3 pre-alignment (RGBDOdometry.cpp:297-385)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_so3_pass(const TrackState* __restrict__ st, const unsigned char* lastImage,
-                                                     size_t last_pitch, const unsigned char* nextImage, size_t next_pitch, int cols,
-                                                     int rows, float* __restrict__ partials, int stride) {
+struct SolveCam {
+  float fx, fy, cx, cy;
+};
+__device__ void so3_solve_body(TrackState* st, const float* partials, int nblocks, float fx, float fy, float cx, float cy, int is_last,
+                               int first_gn_level);
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket);
+
+__global__ __launch_bounds__(kBlock) void k_so3_pass(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
+                                                     const unsigned char* nextImage, size_t next_pitch, int cols, int rows, float* partials,
+                                                     int stride, unsigned* ticket, SolveCam cam, int is_last, int first_gn_level) {
   if (st->so3_done) return;
   So3Params p;
   const float* ib = st->imageBasis;
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_so3_pass(const TrackState* __restric
     accumulate_so3(acc, row, found);
   }
   block_reduce_store<kSO3>(acc, partials, stride, blockIdx.x);
+  if (last_block_arrives(ticket)) so3_solve_body(st, partials, gridDim.x, cam.fx, cam.fy, cam.cx, cam.cy, is_last, first_gn_level);
 }
 
 __device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, int stride, int nblocks, int* sums) {
@@ -233,9 +242,34 @@ __device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, i
   }
 }
 
-__global__ __launch_bounds__(256) void k_so3_solve(TrackState* st, const float* __restrict__ partials, int stride, int nblocks,
-                                                    float fx, float fy, float cx, float cy, int is_last, int first_gn_level) {
-  if (st->so3_done) return;
+// "Last block folds and solves": every block publishes its 128-byte record, then takes a ticket;
+// the block that draws the last ticket reads all records and runs the scalar solve, so no
+// separate launch (and no dependent-launch gap) is needed.  Hand-off protocol of
+// cdna_hip_programming.md §6 G16 / §5 split-K recipe: every wave drains its stores, one lane
+// issues an agent-scope release, then the relaxed ticket; the last arriver issues one agent-scope
+// acquire before the block reads.  Correct for any placement of the blocks over the 8 XCDs.
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == gridDim.x - 1) ? 1 : 0;
+    if (last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// run by the 256 threads of the last block of k_so3_pass
+__device__ void so3_solve_body(TrackState* st, const float* partials, int nblocks, float fx, float fy, float cx, float cy, int is_last,
+                               int first_gn_level) {
   __shared__ float sums[kSO3];
   fold_records256(partials, nblocks, kSO3, sums);
   __syncthreads();
@@ -302,6 +336,15 @@ __global__ __launch_bounds__(256) void k_so3_solve(TrackState* st, const float* 
 // ---------------------------------------------------------------------------------------
 // Gauss-Newton passes (RGBDOdometry.cpp:425-586)
 // ---------------------------------------------------------------------------------------
+struct SolveArgs {
+  int icp, rgb, rgbOnly;
+  float icpWeight;
+  int level, first_iter, next_level, level_below;
+  float fx, fy, cx, cy;
+};
+__device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
+                              const SolveArgs q);
+
 struct GnArgs {
   // ICP
   MapPtrs maps;
@@ -316,8 +359,8 @@ struct GnArgs {
 };
 
 template <bool ICP, bool RGB>
-__global__ __launch_bounds__(kBlock) void k_gn_pass1(const TrackState* __restrict__ st, GnArgs a, float* __restrict__ part_icp,
-                                                     int* __restrict__ part_cnt, int stride) {
+__global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, float* part_icp, int* __restrict__ part_cnt, int stride,
+                                                     unsigned* ticket, SolveArgs q) {
   if (st->level_done[a.level]) return;
   const int N = a.cols * a.rows;
   IcpParams ip;
@@ -392,6 +435,8 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(const TrackState* __restric
       part_cnt[(size_t)threadIdx.x * stride + blockIdx.x] = s;
     }
   }
+  (void)ticket;
+  (void)q;
 }
 
 // σ as the reference computes it (RGBDOdometry.cpp:464, precedence quirk kept)
@@ -404,9 +449,9 @@ __device__ __forceinline__ bool rgbonly_break(int sigma, int rgbSize, float last
   return sqrt((double)sigma) / (double)rgbSize > (double)lastRGBError;
 }
 
-__global__ __launch_bounds__(kBlock) void k_gn_pass2(const TrackState* __restrict__ st, GnArgs a, const int* __restrict__ part_cnt,
-                                                     int nb_cnt, int stride, int rgbOnly, int first_iter,
-                                                     float* __restrict__ part_rgb) {
+__global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, const int* __restrict__ part_cnt, int nb_cnt, int stride,
+                                                     int rgbOnly, int first_iter, const float* part_icp, float* part_rgb, unsigned* ticket,
+                                                     SolveArgs q) {
   if (st->level_done[a.level]) return;
   // every block folds the (≤1024) integer partials itself: integer sums are order-free, so
   // all blocks agree bit-for-bit and no extra launch is needed to publish σ.
@@ -435,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass2(const TrackState* __restric
   }
   const int rgbSize = s_tot[0], sigma = s_tot[1];
   const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
-  if (rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) return;
+  if (rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) return;  // host `break`; k_gn_solve records it
   RgbStepParams p;
   p.sigma = rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
   p.fx = a.fx;
@@ -452,6 +497,9 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass2(const TrackState* __restric
     accumulate_se3(acc, row, c.valid != 0);
   }
   block_reduce_store<kSE3>(acc, part_rgb, stride, blockIdx.x);
+  (void)ticket;
+  (void)q;
+  (void)part_icp;
 }
 
 __device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
@@ -466,12 +514,13 @@ __device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* __restrict__ part_icp,
-                                                   const float* __restrict__ part_rgb, const int* __restrict__ part_cnt, int stride,
-                                                   int nblocks, int icp, int rgb, int rgbOnly, float icpWeight, int level,
-                                                   int first_iter, int next_level, int level_below, float fx, float fy, float cx,
-                                                   float cy) {
-  if (st->level_done[level]) return;
+// run by the 256 threads of the last block of k_gn_pass2 (or of k_gn_pass1 when there is no
+// photometric term)
+__device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
+                              const SolveArgs q) {
+  const int icp = q.icp, rgb = q.rgb, rgbOnly = q.rgbOnly, level = q.level, first_iter = q.first_iter, next_level = q.next_level,
+            level_below = q.level_below;
+  const float icpWeight = q.icpWeight, fx = q.fx, fy = q.fy, cx = q.cx, cy = q.cy;
   __shared__ float s_icp[kSE3];
   __shared__ float s_rgb[kSE3];
   __shared__ int s_cnt[2];
@@ -574,6 +623,15 @@ __global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* _
   gn_params(st, K);
 }
 
+// The solve stays its own launch: folding it into the last block of pass 2 (ticket + agent-scope
+// release/acquire, as k_so3_pass does) was measured 5 us SLOWER per iteration than the launch
+// boundary it removes, because the fences and the ticket sit on the critical path.
+__global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt,
+                                                   int stride, int nblocks, SolveArgs q) {
+  if (st->level_done[q.level]) return;
+  gn_solve_body(st, part_icp, part_rgb, part_cnt, stride, nblocks, q);
+}
+
 __global__ void k_track_finalize(TrackState* st, int rgb) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
@@ -638,6 +696,7 @@ void layout(dms_odometry* o, Carver& c) {
   o->part_rgb = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
   o->part_so3 = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
   o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
+  o->tickets = (unsigned*)c.take(64);
   o->state = (TrackState*)c.take(sizeof(TrackState));
 }
 
@@ -920,14 +979,10 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     for (int i = 0; i < 10; ++i) {
       {
         Timer t(o, s, "so3_pass");
+        SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
         hipLaunchKernelGGL(k_so3_pass, dim3(nb), dim3(kBlock), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, kMaxPartialBlocks);
-        DMS_CHECK_LAUNCH();
-      }
-      {
-        Timer t(o, s, "so3_solve");
-        hipLaunchKernelGGL(k_so3_solve, dim3(1), dim3(256), 0, s, o->state, o->part_so3, kMaxPartialBlocks, nb, o->fx, o->fy, o->cx,
-                           o->cy, i == 9 ? 1 : 0, first_level);
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, kMaxPartialBlocks, o->tickets, cam,
+                           i == 9 ? 1 : 0, first_level);
         DMS_CHECK_LAUNCH();
       }
     }
@@ -987,30 +1042,41 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       }
     for (int j = 0; j < iterations[l]; ++j) {
       const int next_level = (j == iterations[l] - 1) ? level_below : l;
+      SolveArgs q;
+      q.icp = icp ? 1 : 0;
+      q.rgb = rgb ? 1 : 0;
+      q.rgbOnly = rgbOnly ? 1 : 0;
+      q.icpWeight = icpWeight;
+      q.level = l;
+      q.first_iter = j == 0 ? 1 : 0;
+      q.next_level = next_level;
+      q.level_below = level_below;
+      q.fx = o->fx;
+      q.fy = o->fy;
+      q.cx = o->cx;
+      q.cy = o->cy;
       {
         Timer t(o, s, "gn_pass1");
         if (icp && rgb)
           hipLaunchKernelGGL((k_gn_pass1<true, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
-                             kMaxPartialBlocks);
+                             kMaxPartialBlocks, o->tickets + 1, q);
         else if (icp)
           hipLaunchKernelGGL((k_gn_pass1<true, false>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
-                             kMaxPartialBlocks);
+                             kMaxPartialBlocks, o->tickets + 1, q);
         else
           hipLaunchKernelGGL((k_gn_pass1<false, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
-                             kMaxPartialBlocks);
+                             kMaxPartialBlocks, o->tickets + 1, q);
         DMS_CHECK_LAUNCH();
       }
       if (rgb) {
         Timer t(o, s, "gn_pass2");
         hipLaunchKernelGGL(k_gn_pass2, dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_cnt, nb, kMaxPartialBlocks, rgbOnly ? 1 : 0,
-                           j == 0 ? 1 : 0, o->part_rgb);
+                           j == 0 ? 1 : 0, o->part_icp, o->part_rgb, o->tickets + 2, q);
         DMS_CHECK_LAUNCH();
       }
       {
         Timer t(o, s, "gn_solve");
-        hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks,
-                           nb, icp ? 1 : 0, rgb ? 1 : 0, rgbOnly ? 1 : 0, icpWeight, l, j == 0 ? 1 : 0, next_level, level_below, o->fx,
-                           o->fy, o->cx, o->cy);
+        hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks, nb, q);
         DMS_CHECK_LAUNCH();
       }
     }

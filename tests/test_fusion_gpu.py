@@ -416,3 +416,37 @@ def test_process_frame_with_pose_prior_and_no_tracking(fus, orc, synth):
         assert_bits(g.image(5), o.imap[0] if k > 0 else g.image(5), "index map")
         assert_bits(g.image(10), o.pred[1], "predicted vertex")
         assert_bits(g.image(14), o.fill[1], "fill-in vertex")
+
+
+def test_process_frame_kitti_resolution_1241x376(fus, orc, synth):
+    """BASELINE config 4 geometry: odd width, 620x188 / 310x94 pyramid levels, KITTI intrinsics,
+    40 m depth cut-off.  Pose prior taken as is for two frames (exact map parity), then one tracked
+    frame (pose within the bar)."""
+    from oracle import orc_pipeline
+
+    Wk, Hk = 1241, 376
+    Kk = synth.K_KITTI
+    opts = dict(model_capacity=1500000, depthCut=40.0)
+    g = fus.ElasticFusion(Wk, Hk, Kk, hybrid_tracking=0, **opts)
+    o = orc_pipeline.ElasticFusion(Wk, Hk, Kk, hybrid_tracking=False, **opts)
+    T0 = None
+    for k in range(3):
+        d, rgb, T = synth.frame(k, width=Wk, height=Hk, K=Kk, noise=True)
+        if T0 is None:
+            T0 = T
+        prior = (np.linalg.inv(T0) @ T).astype(np.float32)
+        rg = g.processFrame(rgb, d, inPose=prior)
+        ro = o.processFrame(rgb, d, inPose=prior)
+        assert_bits(g.image(2), o.depth_filtered, "depth filtered %d" % k)
+        surfels_equal(g.globalModel().downloadMap(), o.model, "1241x376 map after frame %d" % k)
+        assert_bits(g.image(10), o.pred[1], "predicted vertex")
+    # tracked frame from the same state
+    g2 = fus.ElasticFusion(Wk, Hk, Kk, **opts)
+    o2 = orc_pipeline.ElasticFusion(Wk, Hk, Kk, **opts)
+    for k in range(2):
+        d, rgb, T = synth.frame(k, width=Wk, height=Hk, K=Kk, noise=True)
+        rg = g2.processFrame(rgb, d)
+        ro = o2.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="1241x376 frame %d" % k)
+    assert rg.track.iterations_run[0] == 10 and rg.track.iterations_run[1] == 5 and rg.track.iterations_run[2] == 4
