@@ -148,6 +148,24 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// fp64 variant: the two halves of the double travel through the same DPP controls
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63_d(double v) {
+  v += dpp_mov_d<0xB1>(v);
+  v += dpp_mov_d<0x4E>(v);
+  v += dpp_mov_d<0x141>(v);
+  v += dpp_mov_d<0x140>(v);
+  v += dpp_mov_d<0x142, 0xa>(v);
+  v += dpp_mov_d<0x143, 0xc>(v);
+  return v;
+}
+
 __device__ __forceinline__ int wave_sum_to_lane63_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
@@ -163,10 +181,13 @@ __device__ __forceinline__ int wave_sum_to_lane63_i(int v) {
 constexpr int kPartStride = 32;
 
 // Block reduction of NV running sums held per thread.  256-thread blocks = 4 waves.
-// Writes the block's NV totals to out[out_col * kPartStride + k].
+// fp32 DPP butterfly inside the wave, fp64 across the 4 waves, one fp32 record per block at
+// out[out_col * kPartStride + k].  The fold of the records (fold_records256) is fp64: rounding
+// noise of a tree sum is dominated by its top levels (the few, large partial sums), so keeping
+// those in fp64 makes the total independent of launch shape to ~1e-8 relative and directly
+// comparable with the oracle's fp64 accumulation, while the per-pixel / per-wave work stays fp32.
 template <int NV>
-__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __restrict__ out,
-                                                   int /*out_stride*/, int out_col) {
+__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* out, int /*out_stride*/, int out_col) {
   __shared__ float lds[kBlock / kWave][NV];
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x >> 6;
@@ -179,41 +200,70 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* __rest
   if (threadIdx.x < NV) {
     const int k = threadIdx.x;
     const int nw = blockDim.x >> 6;
-    float s = lds[0][k];
-    for (int w = 1; w < nw; ++w) s += lds[w][k];
-    out[(size_t)out_col * kPartStride + k] = s;
+    double s = (double)lds[0][k];
+    for (int w = 1; w < nw; ++w) s += (double)lds[w][k];
+    out[(size_t)out_col * kPartStride + k] = (float)s;
   }
 }
 
 // Fold of the per-block records by one 256-thread block: thread (g = tid / 8, k4 = tid % 8) sums
-// the float4 column k4 of records g, g + 32, ... (independent 16-byte loads, unrolled so several
-// are in flight), then 32 lanes add the 32 group sums in a fixed order.  sums[] is LDS or global.
-__device__ __forceinline__ void fold_records256(const float* __restrict__ partials, int nblocks, int nv, float* sums) {
-  __shared__ float4 s_grp[32][8];
+// the float4 column k4 of records g, g + 32, ... .  Eight independent 16-byte loads per set are
+// issued before the first add so their L2 latencies overlap (a load-add-load-add loop costs one
+// round trip per record group: measured 4-6 us per fold); two record sets can be folded in one
+// sweep.  Finally 32 lanes add the 32 group sums in a fixed order.  sums*[] is LDS or global.
+template <bool TWO>
+__device__ __forceinline__ void fold_records256_t(const float* partialsA, const float* partialsB, int nblocks, int nv, float* sumsA,
+                                                  float* sumsB) {
+  __shared__ double s_grp[TWO ? 2 : 1][32][32];
+  constexpr int U = 8;
   const int k4 = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const float4* p4 = reinterpret_cast<const float4*>(partials);
-  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-  int b = g;
-  for (; b + 32 < nblocks; b += 64) {
-    const float4 v0 = p4[(size_t)b * 8 + k4];
-    const float4 v1 = p4[(size_t)(b + 32) * 8 + k4];
-    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-  }
-  if (b < nblocks) {
-    const float4 v0 = p4[(size_t)b * 8 + k4];
-    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-  }
-  s_grp[g][k4] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const float* f = reinterpret_cast<const float*>(&s_grp[0][0]);
-    float acc = 0.f;
+  const float4* a4 = reinterpret_cast<const float4*>(partialsA);
+  const float4* b4 = reinterpret_cast<const float4*>(partialsB);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  double aA[4] = {0., 0., 0., 0.}, aB[4] = {0., 0., 0., 0.};
+  for (int b0 = g; b0 < nblocks; b0 += 32 * U) {
+    float4 va[U], vb[U];
 #pragma unroll
-    for (int gg = 0; gg < 32; ++gg) acc += f[gg * 32 + threadIdx.x];
-    if ((int)threadIdx.x < nv) sums[threadIdx.x] = acc;
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + 32 * u;
+      // clamped index + select AFTER the load: a conditional load makes the compiler serialise
+      // the batch (one branch and one s_waitcnt per element)
+      const int bc = b < nblocks ? b : 0;
+      va[u] = a4[(size_t)bc * 8 + k4];
+      if (TWO) vb[u] = b4[(size_t)bc * 8 + k4];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (b0 + 32 * u >= nblocks) {
+        va[u] = z;
+        if (TWO) vb[u] = z;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      aA[0] += (double)va[u].x; aA[1] += (double)va[u].y; aA[2] += (double)va[u].z; aA[3] += (double)va[u].w;
+      if (TWO) { aB[0] += (double)vb[u].x; aB[1] += (double)vb[u].y; aB[2] += (double)vb[u].z; aB[3] += (double)vb[u].w; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    s_grp[0][g][k4 * 4 + c] = aA[c];
+    if (TWO) s_grp[TWO ? 1 : 0][g][k4 * 4 + c] = aB[c];
   }
   __syncthreads();
+  if (threadIdx.x < 64) {
+    const int set = threadIdx.x >> 5, k = threadIdx.x & 31;
+    if (set == 0 || TWO) {
+      double acc = 0.;
+#pragma unroll
+      for (int gg = 0; gg < 32; ++gg) acc += s_grp[TWO ? set : 0][gg][k];
+      if (k < nv) (set == 0 ? sumsA : sumsB)[k] = (float)acc;
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void fold_records256(const float* partials, int nblocks, int nv, float* sums) {
+  fold_records256_t<false>(partials, partials, nblocks, nv, sums, sums);
 }
 
 // launch-shape helper: blocks of 256 threads, one pixel per thread up to the partial cap,

@@ -32,56 +32,83 @@ __device__ __forceinline__ const float* prow(const float* base, size_t pitch, in
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch);
 }
 
+// The row is evaluated in three stages so that a caller can put the loads of several pixels (and
+// of the photometric term) in flight together: a pixel costs two dependent memory round trips
+// (own vertex/normal -> projected model vertex/normal) instead of one per early-out test.
+// Speculative loads use clamped addresses; the arithmetic and its order are the reference's.
+struct IcpOwn {  // stage A: this pixel's vertex and normal (pose independent)
+  f3 vcurr, ncurr;
+};
+struct IcpProj {  // stage B: projection into the model frame
+  f3 vcurr_g;
+  int ux, uy;
+  bool ok;
+};
+struct IcpModel {  // stage C: model vertex / normal under the projection
+  f3 vprev_g, nprev_g;
+};
+
+__device__ __forceinline__ IcpOwn icp_load_own(const MapPtrs& m, int x, int y, int rows) {
+  IcpOwn o;
+  o.vcurr.x = prow(m.vcurr, m.vcurr_pitch, y)[x];
+  o.vcurr.y = prow(m.vcurr, m.vcurr_pitch, y + rows)[x];
+  o.vcurr.z = prow(m.vcurr, m.vcurr_pitch, y + 2 * rows)[x];
+  o.ncurr.x = prow(m.ncurr, m.ncurr_pitch, y)[x];
+  o.ncurr.y = prow(m.ncurr, m.ncurr_pitch, y + rows)[x];
+  o.ncurr.z = prow(m.ncurr, m.ncurr_pitch, y + 2 * rows)[x];
+  return o;
+}
+
+__device__ __forceinline__ IcpProj icp_project(const IcpParams& p, const IcpOwn& o) {
+  IcpProj r;
+  r.vcurr_g = mul(p.Rcurr, o.vcurr) + p.tcurr;
+  const f3 vcurr_cp = mul(p.Rprev_inv, r.vcurr_g - p.tprev);
+  r.ux = f2i_rn((vcurr_cp.x * p.fx) / vcurr_cp.z + p.cx);
+  r.uy = f2i_rn((vcurr_cp.y * p.fy) / vcurr_cp.z + p.cy);
+  r.ok = !((int)(r.ux < 0) | (int)(r.uy < 0) | (int)(r.ux >= p.cols) | (int)(r.uy >= p.rows) | (int)(vcurr_cp.z < 0.f));
+  return r;
+}
+
+__device__ __forceinline__ IcpModel icp_load_model(const MapPtrs& m, const IcpProj& r, int rows) {
+  const int ux = r.ok ? r.ux : 0, uy = r.ok ? r.uy : 0;
+  IcpModel c;
+  c.vprev_g.x = prow(m.vprev, m.vprev_pitch, uy)[ux];
+  c.vprev_g.y = prow(m.vprev, m.vprev_pitch, uy + rows)[ux];
+  c.vprev_g.z = prow(m.vprev, m.vprev_pitch, uy + 2 * rows)[ux];
+  c.nprev_g.x = prow(m.nprev, m.nprev_pitch, uy)[ux];
+  c.nprev_g.y = prow(m.nprev, m.nprev_pitch, uy + rows)[ux];
+  c.nprev_g.z = prow(m.nprev, m.nprev_pitch, uy + 2 * rows)[ux];
+  return c;
+}
+
 // row[0..5] = Jacobian, row[6] = residual.  Returns found flag; row is zero when not found.
-__device__ __forceinline__ bool icp_row(const IcpParams& p, const MapPtrs& m, int x, int y, float (&row)[7]) {
+__device__ __forceinline__ bool icp_finish(const IcpParams& p, const IcpOwn& o, const IcpProj& r, const IcpModel& c, float (&row)[7]) {
 #pragma unroll
   for (int i = 0; i < 7; ++i) row[i] = 0.f;
-  const int rows = p.rows;
-  f3 vcurr;
-  vcurr.x = prow(m.vcurr, m.vcurr_pitch, y)[x];
-  vcurr.y = prow(m.vcurr, m.vcurr_pitch, y + rows)[x];
-  vcurr.z = prow(m.vcurr, m.vcurr_pitch, y + 2 * rows)[x];
-
-  const f3 vcurr_g = mul(p.Rcurr, vcurr) + p.tcurr;
-  const f3 vcurr_cp = mul(p.Rprev_inv, vcurr_g - p.tprev);
-
-  const int ux = f2i_rn((vcurr_cp.x * p.fx) / vcurr_cp.z + p.cx);
-  const int uy = f2i_rn((vcurr_cp.y * p.fy) / vcurr_cp.z + p.cy);
-  if (ux < 0 || uy < 0 || ux >= p.cols || uy >= rows || vcurr_cp.z < 0.f) return false;
-
-  f3 vprev_g;
-  vprev_g.x = prow(m.vprev, m.vprev_pitch, uy)[ux];
-  vprev_g.y = prow(m.vprev, m.vprev_pitch, uy + rows)[ux];
-  vprev_g.z = prow(m.vprev, m.vprev_pitch, uy + 2 * rows)[ux];
-
-  f3 ncurr;
-  ncurr.x = prow(m.ncurr, m.ncurr_pitch, y)[x];
-  ncurr.y = prow(m.ncurr, m.ncurr_pitch, y + rows)[x];
-  ncurr.z = prow(m.ncurr, m.ncurr_pitch, y + 2 * rows)[x];
-  const f3 ncurr_g = mul(p.Rcurr, ncurr);
-
-  f3 nprev_g;
-  nprev_g.x = prow(m.nprev, m.nprev_pitch, uy)[ux];
-  nprev_g.y = prow(m.nprev, m.nprev_pitch, uy + rows)[ux];
-  nprev_g.z = prow(m.nprev, m.nprev_pitch, uy + 2 * rows)[ux];
-
-  const float dist = norm3(vprev_g - vcurr_g);
-  const float sine = norm3(cross3(ncurr_g, nprev_g));
-  const bool found = (sine < p.angleThres && dist <= p.distThres && !isnan(ncurr.x) && !isnan(nprev_g.x));
+  const f3 ncurr_g = mul(p.Rcurr, o.ncurr);
+  const float dist = norm3(c.vprev_g - r.vcurr_g);
+  const float sine = norm3(cross3(ncurr_g, c.nprev_g));
+  const bool found = r.ok && (sine < p.angleThres && dist <= p.distThres && !isnan(o.ncurr.x) && !isnan(c.nprev_g.x));
   if (!found) return false;
-
-  const f3 s_cp = mul(p.Rprev_inv, vcurr_g - p.tprev);
-  const f3 d_cp = mul(p.Rprev_inv, vprev_g - p.tprev);
-  const f3 n_cp = mul(p.Rprev_inv, nprev_g);
-  const f3 c = cross3(s_cp, n_cp);
+  const f3 s_cp = mul(p.Rprev_inv, r.vcurr_g - p.tprev);
+  const f3 d_cp = mul(p.Rprev_inv, c.vprev_g - p.tprev);
+  const f3 n_cp = mul(p.Rprev_inv, c.nprev_g);
+  const f3 cr = cross3(s_cp, n_cp);
   row[0] = n_cp.x;
   row[1] = n_cp.y;
   row[2] = n_cp.z;
-  row[3] = c.x;
-  row[4] = c.y;
-  row[5] = c.z;
+  row[3] = cr.x;
+  row[4] = cr.y;
+  row[5] = cr.z;
   row[6] = dot3(n_cp, s_cp - d_cp);
   return true;
+}
+
+__device__ __forceinline__ bool icp_row(const IcpParams& p, const MapPtrs& m, int x, int y, float (&row)[7]) {
+  const IcpOwn o = icp_load_own(m, x, y, p.rows);
+  const IcpProj r = icp_project(p, o);
+  const IcpModel c = icp_load_model(m, r, p.rows);
+  return icp_finish(p, o, r, c, row);
 }
 
 // accumulate the 27 upper-triangle products + residual^2 + inlier into acc[29]
@@ -123,45 +150,97 @@ __device__ __forceinline__ const T* trow(const T* base, size_t pitch, int y) {
   return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)y * pitch);
 }
 
+// Staged like the ICP row: stage A is pose independent (4x4 window test, gradient gate, own
+// depth), stage B reads the model depth / intensity under the projection.
+struct RgbOwn {
+  bool gate;  // inside the border, 4x4 window all non-zero, gradient above minScale, depth not NaN
+  float d1;
+  unsigned char i1;
+};
+struct RgbProj {
+  float transformed_d1;
+  int u0, v0;
+  bool ok;
+};
+struct RgbModel {
+  float d0;
+  unsigned char l0;
+};
+
+__device__ __forceinline__ RgbOwn rgb_load_own(const RgbResParams& p, const RgbResPtrs& q, int j0, int i) {
+  const int cols = p.cols, rows = p.rows;
+  const bool inside = (j0 < cols - 5 && i < rows - 1);
+  // taps outside the image are clamped onto taps that are inside the reference's clipped window,
+  // so the AND over the 16 loads equals the AND over the clipped window
+  unsigned acc = 1u;
+  unsigned char centre = 0;
+#pragma unroll
+  for (int du = -2; du < 2; ++du) {
+    const int u = min(max(i + du, 0), rows - 1);
+    const unsigned char* r = trow(q.nextImage, q.nextImage_pitch, u);
+#pragma unroll
+    for (int dv = -2; dv < 2; ++dv) {
+      const int v = min(max(j0 + dv, 0), cols - 1);
+      const unsigned char t = r[v];
+      acc &= (t > 0) ? 1u : 0u;
+      if (du == 0 && dv == 0) centre = t;
+    }
+  }
+  const short valx = trow(q.dIdx, q.dI_pitch, i)[j0];
+  const short valy = trow(q.dIdy, q.dI_pitch, i)[j0];
+  RgbOwn o;
+  o.d1 = trow(q.nextDepth, q.nextDepth_pitch, i)[j0];
+  o.i1 = centre;
+  const float mTwo = (float)((int)valx * (int)valx + (int)valy * (int)valy);
+  // bitwise, not short-circuit: a branch here makes the compiler sink the gradient loads behind it
+  o.gate = (int)inside & (int)(acc != 0u) & (int)(mTwo >= p.minScale) & (int)!isnan(o.d1);
+  return o;
+}
+
+__device__ __forceinline__ RgbProj rgb_project(const RgbResParams& p, const RgbOwn& o, int x, int y) {
+  const float d1 = o.d1;
+  const float fx_ = (float)x, fy_ = (float)y;
+  RgbProj r;
+  r.transformed_d1 = d1 * ((p.krkinv.r2.x * fx_ + p.krkinv.r2.y * fy_) + p.krkinv.r2.z) + p.kt.z;
+  r.u0 = f2i_rn((d1 * ((p.krkinv.r0.x * fx_ + p.krkinv.r0.y * fy_) + p.krkinv.r0.z) + p.kt.x) / r.transformed_d1);
+  r.v0 = f2i_rn((d1 * ((p.krkinv.r1.x * fx_ + p.krkinv.r1.y * fy_) + p.krkinv.r1.z) + p.kt.y) / r.transformed_d1);
+  r.ok = (int)o.gate & (int)(r.u0 >= 0) & (int)(r.v0 >= 0) & (int)(r.u0 < p.cols) & (int)(r.v0 < p.rows);
+  return r;
+}
+
+__device__ __forceinline__ RgbModel rgb_load_model(const RgbResPtrs& q, const RgbProj& r) {
+  const int u0 = r.ok ? r.u0 : 0, v0 = r.ok ? r.v0 : 0;
+  RgbModel m;
+  m.d0 = trow(q.lastDepth, q.lastDepth_pitch, v0)[u0];
+  m.l0 = trow(q.lastImage, q.lastImage_pitch, v0)[u0];
+  return m;
+}
+
 // Returns validity; fills the DataTerm fields.  diff2_int is int(diff*diff) (reference
 // stores corres.diff * corres.diff into an int, reduce.cu:831).
-__device__ __forceinline__ bool rgb_residual(const RgbResParams& p, const RgbResPtrs& q, int j0, int i, dms_dataterm& out,
-                                             int& diff2_int) {
+__device__ __forceinline__ bool rgb_finish(const RgbResParams& p, const RgbOwn& o, const RgbProj& r, const RgbModel& m, int x, int y,
+                                           dms_dataterm& out, int& diff2_int) {
   out.zero_x = out.zero_y = out.one_x = out.one_y = 0;
   out.diff = 0.f;
   out.valid = 0;
   diff2_int = 0;
-  const int cols = p.cols, rows = p.rows;
-  if (!(j0 < cols - 5 && i < rows - 1)) return false;
-  bool valid = true;
-  for (int u = max(i - 2, 0); u < min(i + 2, rows); u++) {
-    const unsigned char* r = trow(q.nextImage, q.nextImage_pitch, u);
-    for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++) valid = valid && (r[v] > 0);
-  }
-  if (!valid) return false;
-  const short valx = trow(q.dIdx, q.dI_pitch, i)[j0];
-  const short valy = trow(q.dIdy, q.dI_pitch, i)[j0];
-  const float mTwo = (float)((int)valx * (int)valx + (int)valy * (int)valy);
-  if (!(mTwo >= p.minScale)) return false;
-  const int y = i, x = j0;
-  const float d1 = trow(q.nextDepth, q.nextDepth_pitch, y)[x];
-  if (isnan(d1)) return false;
-  const float fx_ = (float)x, fy_ = (float)y;
-  const float transformed_d1 = d1 * ((p.krkinv.r2.x * fx_ + p.krkinv.r2.y * fy_) + p.krkinv.r2.z) + p.kt.z;
-  const int u0 = f2i_rn((d1 * ((p.krkinv.r0.x * fx_ + p.krkinv.r0.y * fy_) + p.krkinv.r0.z) + p.kt.x) / transformed_d1);
-  const int v0 = f2i_rn((d1 * ((p.krkinv.r1.x * fx_ + p.krkinv.r1.y * fy_) + p.krkinv.r1.z) + p.kt.y) / transformed_d1);
-  if (!(u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows)) return false;
-  const float d0 = trow(q.lastDepth, q.lastDepth_pitch, v0)[u0];
-  const unsigned char l0 = trow(q.lastImage, q.lastImage_pitch, v0)[u0];
-  if (!(d0 > 0.f && fabsf(transformed_d1 - d0) <= p.maxDepthDelta && l0 != 0)) return false;
-  out.zero_x = (short)u0;
-  out.zero_y = (short)v0;
+  if (!(r.ok && m.d0 > 0.f && fabsf(r.transformed_d1 - m.d0) <= p.maxDepthDelta && m.l0 != 0)) return false;
+  out.zero_x = (short)r.u0;
+  out.zero_y = (short)r.v0;
   out.one_x = (short)x;
   out.one_y = (short)y;
-  out.diff = (float)trow(q.nextImage, q.nextImage_pitch, y)[x] - (float)l0;
+  out.diff = (float)o.i1 - (float)m.l0;
   out.valid = 1;
   diff2_int = f2i_rz(out.diff * out.diff);
   return true;
+}
+
+__device__ __forceinline__ bool rgb_residual(const RgbResParams& p, const RgbResPtrs& q, int j0, int i, dms_dataterm& out,
+                                             int& diff2_int) {
+  const RgbOwn o = rgb_load_own(p, q, j0, i);
+  const RgbProj r = rgb_project(p, o, j0, i);
+  const RgbModel m = rgb_load_model(q, r);
+  return rgb_finish(p, o, r, m, j0, i, out, diff2_int);
 }
 
 // ---- RGB Jacobian row (reference RGBReduction::getProducts, reduce.cu:561-620) ---------
@@ -169,19 +248,36 @@ struct RgbStepParams {
   float sigma, fx, fy, sobelScale;
 };
 
-__device__ __forceinline__ void rgb_row(const RgbStepParams& p, const dms_dataterm& c, const float* __restrict__ cloud,
-                                        size_t cloud_pitch, const short* __restrict__ dIdx, const short* __restrict__ dIdy,
-                                        size_t dI_pitch, float (&row)[7]) {
+struct RgbRowIn {  // loads of one correspondence: cloud point of the model pixel, gradient of the live pixel
+  f3 pt;
+  short gx, gy;
+};
+
+// safe for an invalid correspondence (its coordinates are all zero)
+__device__ __forceinline__ RgbRowIn rgb_row_load(const dms_dataterm& c, const float* __restrict__ cloud, size_t cloud_pitch,
+                                                 const short* __restrict__ dIdx, const short* __restrict__ dIdy, size_t dI_pitch) {
+  RgbRowIn in;
+  const float* cp = trow(cloud, cloud_pitch, c.zero_y) + 3 * c.zero_x;
+  in.pt = mk3(cp[0], cp[1], cp[2]);
+  in.gx = trow(dIdx, dI_pitch, c.one_y)[c.one_x];
+  in.gy = trow(dIdy, dI_pitch, c.one_y)[c.one_x];
+  return in;
+}
+
+// row is all zero for an invalid correspondence
+__device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms_dataterm& c, const RgbRowIn& in, float (&row)[7]) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) row[i] = 0.f;
+  if (!c.valid) return;
   float w = p.sigma + fabsf(c.diff);
   w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
   if (p.sigma == -1.f) w = 1.f;
   row[6] = -w * c.diff;
-  const float* cp = trow(cloud, cloud_pitch, c.zero_y) + 3 * c.zero_x;
-  const f3 pt = mk3(cp[0], cp[1], cp[2]);
+  const f3 pt = in.pt;
   // reference: float invz = 1.0 / cloudPoint.z  (double division rounded to float)
   const float invz = (float)(1.0 / (double)pt.z);
-  const float dI_dx_val = (w * p.sobelScale) * (float)trow(dIdx, dI_pitch, c.one_y)[c.one_x];
-  const float dI_dy_val = (w * p.sobelScale) * (float)trow(dIdy, dI_pitch, c.one_y)[c.one_x];
+  const float dI_dx_val = (w * p.sobelScale) * (float)in.gx;
+  const float dI_dy_val = (w * p.sobelScale) * (float)in.gy;
   const float v0 = (dI_dx_val * p.fx) * invz;
   const float v1 = (dI_dy_val * p.fy) * invz;
   const float v2 = -(v0 * pt.x + v1 * pt.y) * invz;
@@ -191,6 +287,14 @@ __device__ __forceinline__ void rgb_row(const RgbStepParams& p, const dms_datate
   row[3] = -pt.z * v1 + pt.y * v2;
   row[4] = pt.z * v0 - pt.x * v2;
   row[5] = -pt.y * v0 + pt.x * v1;
+}
+
+// (the caller zero-fills row and skips invalid correspondences, as the reference does)
+__device__ __forceinline__ void rgb_row(const RgbStepParams& p, const dms_dataterm& c, const float* __restrict__ cloud,
+                                        size_t cloud_pitch, const short* __restrict__ dIdx, const short* __restrict__ dIdy,
+                                        size_t dI_pitch, float (&row)[7]) {
+  const RgbRowIn in = rgb_row_load(c, cloud, cloud_pitch, dIdx, dIdy, dI_pitch);
+  rgb_row_finish(p, c, in, row);
 }
 
 // ---- SO3 (reference SO3Reduction::getProducts, reduce.cu:942-1032) ----------------------

@@ -236,7 +236,16 @@ __device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, i
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (wid < 2) {
     int s = 0;
-    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)wid * stride + b];
+    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {  // 8 independent loads in flight
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 64 * u;
+        v[u] = partials[(size_t)wid * stride + (b < nblocks ? b : 0)];  // clamp + select: keeps the batch in flight
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (b0 + 64 * u < nblocks) ? v[u] : 0;
+    }
     s = wave_sum_to_lane63_i(s);
     if (lane == 63) sums[wid] = s;
   }
@@ -358,10 +367,19 @@ struct GnArgs {
   int cols, rows, level;
 };
 
+// Pixels are handed out in chunks of kBlock*kPix: thread t of the block owns pixels
+// chunk*kBlock*kPix + p*kBlock + t (p < kPix), i.e. kPix coalesced runs, and keeps the loads of all
+// kPix pixels (ICP and photometric) in flight together.  Two dependent round trips per chunk.
+constexpr int kPix = 2;
+inline int track_blocks_for(int n) {
+  int b = (n + kBlock * kPix - 1) / (kBlock * kPix);
+  return b < 1 ? 1 : (b > kMaxPartialBlocks ? kMaxPartialBlocks : b);
+}
+
 template <bool ICP, bool RGB>
 __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, float* part_icp, int* __restrict__ part_cnt, int stride,
                                                      unsigned* ticket, SolveArgs q) {
-  if (st->level_done[a.level]) return;
+  const int done = st->level_done[a.level];
   const int N = a.cols * a.rows;
   IcpParams ip;
   RgbResParams rp;
@@ -396,26 +414,64 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, f
     rp.cols = a.cols;
     rp.rows = a.rows;
   }
+  if (done) return;
   float acc[kSE3];
 #pragma unroll
   for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
   int cnt = 0, sig = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
-    const int y = i / a.cols;
-    const int x = i - y * a.cols;
-    if (RGB) {
-      dms_dataterm c;
-      int d2;
-      if (rgb_residual(rp, a.rgb, x, y, c, d2)) {
-        cnt += 1;
-        sig += d2;
-      }
-      a.corres[i] = c;
+  for (int base = blockIdx.x * (kBlock * kPix); base < N; base += gridDim.x * (kBlock * kPix)) {
+    int idx[kPix], px[kPix], py[kPix];
+    IcpOwn io[kPix];
+    RgbOwn ro[kPix];
+#pragma unroll
+    for (int p = 0; p < kPix; ++p) {
+      idx[p] = base + p * kBlock + (int)threadIdx.x;
+      const int ic = idx[p] < N ? idx[p] : 0;  // lanes past the end shadow pixel 0 and are masked below
+      py[p] = ic / a.cols;
+      px[p] = ic - py[p] * a.cols;
+      if (ICP) io[p] = icp_load_own(a.maps, px[p], py[p], a.rows);
+      if (RGB) ro[p] = rgb_load_own(rp, a.rgb, px[p], py[p]);
     }
-    if (ICP) {
-      float row[7];
-      const bool found = icp_row(ip, a.maps, x, y, row);
-      accumulate_se3(acc, row, found);
+    IcpProj ir[kPix];
+    RgbProj rr[kPix];
+    IcpModel im[kPix];
+    RgbModel rm[kPix];
+#pragma unroll
+    for (int p = 0; p < kPix; ++p) {
+      if (ICP) {
+        ir[p] = icp_project(ip, io[p]);
+        im[p] = icp_load_model(a.maps, ir[p], a.rows);
+      }
+      if (RGB) {
+        rr[p] = rgb_project(rp, ro[p], px[p], py[p]);
+        rm[p] = rgb_load_model(a.rgb, rr[p]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kPix; ++p) {
+      const bool live = idx[p] < N;
+      if (RGB) {
+        dms_dataterm c;
+        int d2;
+        const bool ok = rgb_finish(rp, ro[p], rr[p], rm[p], px[p], py[p], c, d2);
+        if (live) {
+          if (ok) {
+            cnt += 1;
+            sig += d2;
+          }
+          a.corres[idx[p]] = c;
+        }
+      }
+      if (ICP) {
+        float row[7];
+        bool found = icp_finish(ip, io[p], ir[p], im[p], row);
+        if (!live) {
+          found = false;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) row[k] = 0.f;
+        }
+        accumulate_se3(acc, row, found);
+      }
     }
   }
   if (ICP) block_reduce_store<kSE3>(acc, part_icp, stride, blockIdx.x);
@@ -481,20 +537,32 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, c
   const int rgbSize = s_tot[0], sigma = s_tot[1];
   const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
   if (rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) return;  // host `break`; k_gn_solve records it
-  RgbStepParams p;
-  p.sigma = rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
-  p.fx = a.fx;
-  p.fy = a.fy;
-  p.sobelScale = a.sobelScale;
+  RgbStepParams p_;
+  p_.sigma = rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
+  p_.fx = a.fx;
+  p_.fy = a.fy;
+  p_.sobelScale = a.sobelScale;
   const int N = a.cols * a.rows;
   float acc[kSE3];
 #pragma unroll
   for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
-    const dms_dataterm c = a.corres[i];
-    float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (c.valid) rgb_row(p, c, a.cloud, a.cloud_pitch, a.rgb.dIdx, a.rgb.dIdy, a.rgb.dI_pitch, row);
-    accumulate_se3(acc, row, c.valid != 0);
+  for (int base = blockIdx.x * (kBlock * kPix); base < N; base += gridDim.x * (kBlock * kPix)) {
+    dms_dataterm c[kPix];
+    RgbRowIn in[kPix];
+#pragma unroll
+    for (int p = 0; p < kPix; ++p) {
+      const int i = base + p * kBlock + (int)threadIdx.x;
+      c[p] = a.corres[i < N ? i : 0];
+      if (i >= N) c[p].valid = 0;
+    }
+#pragma unroll
+    for (int p = 0; p < kPix; ++p) in[p] = rgb_row_load(c[p], a.cloud, a.cloud_pitch, a.rgb.dIdx, a.rgb.dIdy, a.rgb.dI_pitch);
+#pragma unroll
+    for (int p = 0; p < kPix; ++p) {
+      float row[7];
+      rgb_row_finish(p_, c[p], in[p], row);
+      accumulate_se3(acc, row, c[p].valid != 0);
+    }
   }
   block_reduce_store<kSE3>(acc, part_rgb, stride, blockIdx.x);
   (void)ticket;
@@ -526,10 +594,15 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
   __shared__ int s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  if (icp) fold_records256(part_icp, nblocks, kSE3, s_icp);
-  if (rgb) {
-    fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
-  }
+  if (rgb) fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
+  // both record sets in one sweep (when pass 2 was skipped by the rgbOnly break its records are
+  // stale; they are folded but never used)
+  if (icp && rgb)
+    fold_records256_t<true>(part_icp, part_rgb, nblocks, kSE3, s_icp, s_rgb);
+  else if (icp)
+    fold_records256(part_icp, nblocks, kSE3, s_icp);
+  else
+    fold_records256(part_rgb, nblocks, kSE3, s_rgb);
   __syncthreads();
   const int rgbSize = s_cnt[0], sigma = s_cnt[1];
   const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
@@ -545,8 +618,6 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
     }
     return;
   }
-  if (rgb) fold_records256(part_rgb, nblocks, kSE3, s_rgb);
-  __syncthreads();
   if (threadIdx.x != 0) return;
 
   st->iters_run[level] += 1;
@@ -1033,7 +1104,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     a.cols = o->vmaps_curr[l].cols;
     a.rows = o->vmaps_curr[l].rows / 3;
     a.level = l;
-    const int nb = reduce_blocks_for(a.cols * a.rows);
+    const int nb = track_blocks_for(a.cols * a.rows);
     int level_below = l;
     for (int q = l - 1; q >= 0; --q)
       if (iterations[q] > 0) {
