@@ -155,6 +155,118 @@ __host__ __device__ inline void ldlt_solve_ws(const T* Ain, const T* b, T* x, T 
   for (int i = 0; i < N; ++i) x[i] = y[i];
 }
 
+// Same algorithm with every index a compile-time constant, so the matrix lives in registers on
+// the solving lane (no scratch, no LDS round trips).  The dynamic pivot position is resolved by a
+// chain of `if (p == pivot)` over fully unrolled loops; `swap_rc<K>` exchanges rows and columns K
+// and P of the full symmetric storage exactly as the loop version does.
+template <typename T, int N>
+__host__ __device__ __forceinline__ void ldlt_solve_reg(const T (&Ain)[N * N], const T (&b)[N], T (&x)[N], T tiny) {
+  T A[N * N];
+#pragma unroll
+  for (int i = 0; i < N * N; ++i) A[i] = Ain[i];
+  int perm[N];
+  bool all_zero = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (!all_zero) {
+      int p = k;
+      T best = A[k * N + k] < T(0) ? -A[k * N + k] : A[k * N + k];
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) {
+        const T v = A[i * N + i] < T(0) ? -A[i * N + i] : A[i * N + i];
+        if (v > best) {
+          best = v;
+          p = i;
+        }
+      }
+      perm[k] = p;
+#pragma unroll
+      for (int pp = k + 1; pp < N; ++pp) {
+        if (pp == p) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const T t = A[k * N + j];
+            A[k * N + j] = A[pp * N + j];
+            A[pp * N + j] = t;
+          }
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            const T t = A[i * N + k];
+            A[i * N + k] = A[i * N + pp];
+            A[i * N + pp] = t;
+          }
+        }
+      }
+      T temp[N];
+#pragma unroll
+      for (int j = 0; j < k; ++j) temp[j] = A[j * N + j] * A[k * N + j];
+      T akk = A[k * N + k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) akk -= A[k * N + j] * temp[j];
+      A[k * N + k] = akk;
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) {
+        T v = A[i * N + k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) v -= A[i * N + j] * temp[j];
+        A[i * N + k] = v;
+      }
+      const T aabs = akk < T(0) ? -akk : akk;
+      const bool valid = aabs > T(0);
+      if (k == 0 && !valid) {
+        all_zero = true;
+      } else if (valid) {
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) A[i * N + k] /= akk;
+      }
+    }
+  }
+  if (all_zero) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = T(0);
+    return;
+  }
+  T y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] = b[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int pp = k + 1; pp < N; ++pp)
+      if (perm[k] == pp) {
+        const T t = y[k];
+        y[k] = y[pp];
+        y[pp] = t;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j) y[i] -= A[i * N + j] * y[j];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const T d = A[i * N + i];
+    const T dabs = d < T(0) ? -d : d;
+    y[i] = dabs > tiny ? y[i] / d : T(0);
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i)
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) y[i] -= A[j * N + i] * y[j];
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int pp = k + 1; pp < N; ++pp)
+      if (perm[k] == pp) {
+        const T t = y[k];
+        y[k] = y[pp];
+        y[pp] = t;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+
 template <typename T, int N>
 __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny) {
   T A[N * N], temp[N], y[N];

@@ -128,10 +128,11 @@ __device__ inline void so3_params(TrackState* st, const double* K) {
   }
 }
 
-// RGBDOdometry.cpp:427-437
-__device__ inline void gn_params(TrackState* st, const double* K) {
+// RGBDOdometry.cpp:427-437.  `resultRt` is passed in registers: re-reading it from the state block
+// right after storing it costs a full memory round trip on the solving lane.
+__device__ inline void gn_params_from(TrackState* st, const double* resultRt, const double* K) {
   double Rt[16], R[9], Kinv[9], t[9], H[9];
-  sm::inv4(st->resultRt, Rt);
+  sm::inv4(resultRt, Rt);
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rt[i * 4 + j];
   sm::inv3<double>(K, Kinv);
@@ -144,6 +145,11 @@ __device__ inline void gn_params(TrackState* st, const double* K) {
   st->kt[0] = (float)kt[0];
   st->kt[1] = (float)kt[1];
   st->kt[2] = (float)kt[2];
+}
+__device__ inline void gn_params(TrackState* st, const double* K) {
+  double Rt[16];
+  for (int i = 0; i < 16; ++i) Rt[i] = st->resultRt[i];
+  gn_params_from(st, Rt, K);
 }
 
 struct Prior {
@@ -592,6 +598,21 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
   __shared__ float s_icp[kSE3];
   __shared__ float s_rgb[kSE3];
   __shared__ int s_cnt[2];
+  // everything the solving lane needs from the state block is fetched up front (uniform
+  // addresses), so these loads overlap the record fold instead of each costing its own round
+  // trip between dependent stores later on
+  double prevRt[16];
+  float Rprev[9], tprev[3];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) prevRt[i] = st->resultRt[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rprev[i] = st->Rprev[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tprev[i] = st->tprev[i];
+  const int iters_before = st->iters_run[level];
+  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
+  if (st->level_done[level]) return;
+
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   if (rgb) fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
@@ -605,7 +626,6 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
     fold_records256(part_rgb, nblocks, kSE3, s_rgb);
   __syncthreads();
   const int rgbSize = s_cnt[0], sigma = s_cnt[1];
-  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
   const bool brk = rgbOnly && rgbonly_break(sigma, rgbSize, lastErr);
   if (brk) {
     // host `break` (RGBDOdometry.cpp:466-469): the level ends here; the next level that runs
@@ -614,15 +634,11 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
       st->level_done[level] = 1;
       double K[9];
       level_K(fx, fy, cx, cy, level_below, K);
-      gn_params(st, K);
+      gn_params_from(st, prevRt, K);
     }
     return;
   }
   if (threadIdx.x != 0) return;
-
-  st->iters_run[level] += 1;
-  st->lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
-  st->lastRGBCount = (float)rgbSize;
 
   float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
   float residual[2] = {0.f, 0.f};
@@ -631,52 +647,58 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
     residual[0] = s_icp[27];
     residual[1] = s_icp[28];
   }
-  st->lastICPError = sqrtf(residual[0]) / residual[1];
-  st->lastICPCount = residual[1];
   if (rgb) unpack_se3_d(s_rgb, A_rgb, b_rgb);
 
   double A[36], b[6], x[6];
   if (icp && rgb) {
     const double w = (double)icpWeight;
     const double ww = w * w;
+#pragma unroll
     for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i] + ww * (double)A_icp[i];
+#pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i] + w * (double)b_icp[i];
   } else if (icp) {
+#pragma unroll
     for (int i = 0; i < 36; ++i) A[i] = (double)A_icp[i];
+#pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = (double)b_icp[i];
   } else {
+#pragma unroll
     for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i];
+#pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i];
   }
-  for (int i = 0; i < 36; ++i) st->lastA[i] = A[i];
-  for (int i = 0; i < 6; ++i) st->lastb[i] = b[i];
-  __shared__ double l_A[36], l_t[6], l_y[6];
-  __shared__ int l_p[6];
-  sm::ldlt_solve_ws<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308, l_A, l_t, l_y, l_p);
+  sm::ldlt_solve_reg<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308);
 
   // OdometryProvider::computeUpdateSE3 (OdometryProvider.h:73-93)
   double Rt[16];
+#pragma unroll
   for (int i = 0; i < 16; ++i) Rt[i] = (i % 5 == 0) ? 1.0 : 0.0;
   const double rvec[3] = {x[3], x[4], x[5]};
   double R[9];
   sm::rodrigues(rvec, R);
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) Rt[i * 4 + j] = R[i * 3 + j];
   Rt[3] = x[0];
   Rt[7] = x[1];
   Rt[11] = x[2];
   double nr[16];
-  sm::mul4(Rt, st->resultRt, nr);
-  for (int i = 0; i < 16; ++i) st->resultRt[i] = nr[i];
+  sm::mul4(Rt, prevRt, nr);
 
   // rgbOdom = float(resultRt); currentT = [Rprev|tprev] * rgbOdom^-1 with the isometry inverse
   float Ro[9], to[3];
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
+#pragma unroll
     for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = (float)nr[i * 4 + j];
     to[i] = (float)nr[i * 4 + 3];
   }
   float RoT[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) RoT[i * 3 + j] = Ro[j * 3 + i];
   float ti[3];
   sm::mul3v<float>(RoT, to, ti);
@@ -684,14 +706,29 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
   ti[1] = -ti[1];
   ti[2] = -ti[2];
   float Rc[9], tc[3];
-  sm::mul3<float>(st->Rprev, RoT, Rc);
-  sm::mul3v<float>(st->Rprev, ti, tc);
+  sm::mul3<float>(Rprev, RoT, Rc);
+  sm::mul3v<float>(Rprev, ti, tc);
+
+  // ---- all stores at the end, nothing read back ----
+  st->iters_run[level] = iters_before + 1;
+  st->lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
+  st->lastRGBCount = (float)rgbSize;
+  st->lastICPError = sqrtf(residual[0]) / residual[1];
+  st->lastICPCount = residual[1];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) st->lastA[i] = A[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) st->lastb[i] = b[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st->resultRt[i] = nr[i];
+#pragma unroll
   for (int i = 0; i < 9; ++i) st->Rcurr[i] = Rc[i];
-  for (int i = 0; i < 3; ++i) st->tcurr[i] = tc[i] + st->tprev[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st->tcurr[i] = tc[i] + tprev[i];
 
   double K[9];
   level_K(fx, fy, cx, cy, next_level, K);
-  gn_params(st, K);
+  gn_params_from(st, nr, K);
 }
 
 // The solve stays its own launch: folding it into the last block of pass 2 (ticket + agent-scope
@@ -699,7 +736,6 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
 // boundary it removes, because the fences and the ticket sit on the critical path.
 __global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt,
                                                    int stride, int nblocks, SolveArgs q) {
-  if (st->level_done[q.level]) return;
   gn_solve_body(st, part_icp, part_rgb, part_cnt, stride, nblocks, q);
 }
 
