@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="issue the live-frame half on the main stream (A/B switch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~20 s)")
     args = ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
         return j if j < n_unique else period - j
 
     def make_engine():
-        return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000)
+        return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1)
 
     stream = torch.cuda.current_stream().cuda_stream
     ef = make_engine()
@@ -126,10 +127,22 @@ def main():
 
     src = None
 
+    # bounded run-ahead: the host never has more than `depth` frames enqueued beyond the one the GPU
+    # is working on (what a live pipeline does anyway: frame t+depth does not exist yet)
+    depth = int(os.environ.get("DMS_RUNAHEAD", "0"))
+    inflight = []
+
     def step(i):
         nonlocal src
         j = frame_index(i)
+        if depth > 0:
+            if len(inflight) >= depth:
+                inflight.pop(0).synchronize()
         ef.processFrameAsync(rgb_t[j].data_ptr(), 3, dep_t[j].data_ptr(), None, 1.0, stream)
+        if depth > 0:
+            e = torch.cuda.Event()
+            e.record()
+            inflight.append(e)
         if distributed:
             if src is None:
                 src = (src_view(13), src_view(14), src_view(15))  # fill-in image / vertex / normal
@@ -149,6 +162,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, n_total):
         step(i)
+    t_enq = time.perf_counter() - t0  # host time to enqueue the timed frames (no synchronisation inside)
     barrier()
     elapsed = time.perf_counter() - t0
     res = ef.fetch(stream)
@@ -166,6 +180,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
+        "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -192,7 +207,7 @@ def main():
         for i in range(n_total, n_total + nprof):
             step(i)
             ef.fetch(stream)
-        names_f = ["ingest", "preprocess", "predict", "fill_in", "odom_init", "track", "index_map", "fuse", "clean", "initialise"]
+        names_f = ["ingest", "preprocess", "live_pyramids", "predict", "fill_in", "odom_init", "track", "index_map", "fuse", "clean", "initialise"]
         stages = {}
         for n in names_f:
             ms, cnt = ef.kernel_time(n)

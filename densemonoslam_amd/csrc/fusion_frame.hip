@@ -49,6 +49,11 @@ int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA,
                               const float* pose16_dev, hipStream_t s);
 int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rgbaB, const int* flag_dev, int force_b, void* rgba_tmp,
                               hipStream_t s);
+int odometry_enable_ring(dms_odometry* o);
+void odometry_bind_live(dms_odometry* o, int k);
+void odometry_bind_lastnext(dms_odometry* o, int k);
+int odometry_initRGB_image(dms_odometry* o, const dms_image2d* rgba, hipStream_t s);
+void odometry_alias_next_depth(dms_odometry* o);
 
 struct FrameState {
   dms_pose_block cur;   // current pose + inverse
@@ -170,8 +175,16 @@ struct dms_fusion {
   dms_odometry* odom = nullptr;
   char* arena = nullptr;
   size_t arena_bytes = 0;
-  // images
+  // images of the incoming frame: two sets, so that frame t+1 can be ingested and filtered on the
+  // prep stream while frame t is still being tracked and fused; the unsuffixed names are the set
+  // of the frame the main stream is working on
+  struct LiveImages {
+    dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
+  } live[2];
   dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
+  hipStream_t s_prep = nullptr;
+  hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr}, ev_inputs = nullptr;
+  long frames = 0;  // frames enqueued so far
   dms_indexmap_out imap;
   dms_predict_out pred, fill;
   void* rgba_tmp = nullptr;
@@ -216,11 +229,18 @@ dms_image2d mk_img(void* p, int rows, int cols, size_t elem) {
 void layout(dms_fusion* f, Carve& c) {
   const int W = f->p.width, H = f->p.height;
   const size_t N = (size_t)W * H;
-  f->rgba = mk_img(c.take(N * 4), H, W, 4);
-  f->depth_raw = mk_img(c.take(N * 2), H, W, 2);
-  f->depth_filtered = mk_img(c.take(N * 2), H, W, 2);
-  f->depth_metric = mk_img(c.take(N * 4), H, W, 4);
-  f->depth_metric_filtered = mk_img(c.take(N * 4), H, W, 4);
+  for (int k = 0; k < 2; ++k) {
+    f->live[k].rgba = mk_img(c.take(N * 4), H, W, 4);
+    f->live[k].depth_raw = mk_img(c.take(N * 2), H, W, 2);
+    f->live[k].depth_filtered = mk_img(c.take(N * 2), H, W, 2);
+    f->live[k].depth_metric = mk_img(c.take(N * 4), H, W, 4);
+    f->live[k].depth_metric_filtered = mk_img(c.take(N * 4), H, W, 4);
+  }
+  f->rgba = f->live[0].rgba;
+  f->depth_raw = f->live[0].depth_raw;
+  f->depth_filtered = f->live[0].depth_filtered;
+  f->depth_metric = f->live[0].depth_metric;
+  f->depth_metric_filtered = f->live[0].depth_metric_filtered;
   f->imap.index = mk_img(c.take(N * 4), H, W, 4);
   f->imap.vertConf = mk_img(c.take(N * 16), H, W, 16);
   f->imap.colorTime = mk_img(c.take(N * 16), H, W, 16);
@@ -268,6 +288,18 @@ struct FTimer {
 };
 
 void drain(dms_fusion* f) {
+  // DMS_TIMELINE=1: print every stage's start / end relative to the first stage of the batch
+  // (both streams share the clock) — shows whether the prep stream really overlaps the main one
+  static const bool timeline = getenv("DMS_TIMELINE") != nullptr;
+  if (timeline && !f->pending.empty()) {
+    hipEvent_t base = f->pending.front().second.first;
+    for (auto& p : f->pending) {
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, base, p.second.first);
+      (void)hipEventElapsedTime(&b, base, p.second.second);
+      fprintf(stderr, "[timeline] %-14s %9.3f -> %9.3f ms\n", p.first.c_str(), a, b);
+    }
+  }
   for (auto& p : f->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
@@ -363,6 +395,8 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->timeIdx = 0;
   p->maxDepthProcessed = 25.0f;  // ElasticFusion.cpp:56
   p->model_capacity = 0;
+  p->pipeline_ingest = 1;
+  p->global_predict = 0;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
@@ -386,10 +420,23 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     delete f;
     return rc;
   }
+  rc = odometry_enable_ring(f->odom);
+  if (rc) {
+    dms_odometry_destroy(f->odom);
+    dms_model_destroy(f->model);
+    delete f;
+    return rc;
+  }
   Carve sz;
   layout(f, sz);
   f->arena_bytes = up256(sz.off);
   hipError_t e = hipMalloc((void**)&f->arena, f->arena_bytes);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->s_prep, hipStreamNonBlocking);
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipEventCreateWithFlags(&f->ev_prep_done[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_main_done[k], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, sizeof(FrameState), hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -413,8 +460,15 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
 
 int dms_fusion_destroy(dms_fusion* f) {
   if (!f) return DMS_OK;
+  (void)hipDeviceSynchronize();
   drain(f);
   for (auto e : f->pool) (void)hipEventDestroy(e);
+  for (int k = 0; k < 2; ++k) {
+    if (f->ev_prep_done[k]) (void)hipEventDestroy(f->ev_prep_done[k]);
+    if (f->ev_main_done[k]) (void)hipEventDestroy(f->ev_main_done[k]);
+  }
+  if (f->ev_inputs) (void)hipEventDestroy(f->ev_inputs);
+  if (f->s_prep) (void)hipStreamDestroy(f->s_prep);
   if (f->arena) (void)hipFree(f->arena);
   if (f->h_state) (void)hipHostFree(f->h_state);
   dms_odometry_destroy(f->odom);
@@ -434,22 +488,57 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
   const int W = f->p.width, H = f->p.height, N = W * H;
   int rc;
 
+  // ---- live half: everything that depends on the incoming frame only -------------------------
+  // Runs on the prep stream into image set frames%2 and odometry ring set frames%3, so it
+  // overlaps the previous frame's tracking / fusion on the caller's stream.  Hazards: these sets
+  // were last read by frame-2 (image set; ring set as lastNextImage), hence the wait on its
+  // completion event.  With pipeline_ingest = 0 the same work is issued on the caller's stream.
+  const int k2 = (int)(f->frames % 2), k3 = (int)(f->frames % 3), k3prev = (int)((f->frames + 2) % 3);
+  hipStream_t sp = f->p.pipeline_ingest ? f->s_prep : s;
+  if (f->p.pipeline_ingest) {
+    // Bounded run-ahead: at most two frames are in flight.  The host blocks here until frame-2 has
+    // finished (normally long ago).  Besides protecting the double-buffered images this keeps the
+    // HIP command queues short: with the host many frames ahead the runtime's queue-full handling
+    // was measured to cost ~10% throughput.
+    DMS_HIP(hipEventSynchronize(f->ev_main_done[k2]));
+    DMS_HIP(hipStreamWaitEvent(sp, f->ev_main_done[k2], 0));  // frame-2 (never recorded: no-op)
+  }
+  f->rgba = f->live[k2].rgba;
+  f->depth_raw = f->live[k2].depth_raw;
+  f->depth_filtered = f->live[k2].depth_filtered;
+  f->depth_metric = f->live[k2].depth_metric;
+  f->depth_metric_filtered = f->live[k2].depth_metric_filtered;
+  odometry_bind_live(f->odom, k3);
+  odometry_bind_lastnext(f->odom, k3prev);
   // "upload": the frame is already in HBM; bring it into the context's textures (ElasticFusion.cpp:111-114)
   {
-    FTimer t(f, s, "ingest");
+    FTimer t(f, sp, "ingest");
     if (rgb_channels == 3)
-      hipLaunchKernelGGL(k_rgb_to_rgba, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, s, (const unsigned char*)rgb_dev,
+      hipLaunchKernelGGL(k_rgb_to_rgba, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, sp, (const unsigned char*)rgb_dev,
                          (uchar4*)f->rgba.data, N);
     else
-      DMS_HIP(hipMemcpyAsync(f->rgba.data, rgb_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+      DMS_HIP(hipMemcpyAsync(f->rgba.data, rgb_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, sp));
     DMS_CHECK_LAUNCH();
-    DMS_HIP(hipMemcpyAsync(f->depth_raw.data, depth_dev, (size_t)N * 2, hipMemcpyDeviceToDevice, s));
+    DMS_HIP(hipMemcpyAsync(f->depth_raw.data, depth_dev, (size_t)N * 2, hipMemcpyDeviceToDevice, sp));
   }
   {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
-    FTimer t(f, s, "preprocess");
-    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, s))) return rc;
-    if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, s))) return rc;
-    if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, s))) return rc;
+    FTimer t(f, sp, "preprocess");
+    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp))) return rc;
+    if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, sp))) return rc;
+    if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, sp))) return rc;
+  }
+  {  // live half of frameToModel.initICP / initRGB (ElasticFusion.cpp:190-194): depth pyramid, vertex / normal
+     // maps, intensity pyramid and its derivatives.  At the first frame the intensity pyramid is
+     // what initFirstRGB computes (ElasticFusion.cpp:151); it becomes lastNextImage of frame 1.
+    FTimer t(f, sp, "live_pyramids");
+    if (f->p.hybrid_tracking || f->frames == 0) {
+      if ((rc = dms_odometry_initICP_depth(f->odom, &f->depth_filtered, f->p.maxDepthProcessed, sp))) return rc;
+      if ((rc = odometry_initRGB_image(f->odom, &f->rgba, sp))) return rc;
+    }
+  }
+  if (f->p.pipeline_ingest) {
+    DMS_HIP(hipEventRecord(f->ev_prep_done[k2], sp));
+    DMS_HIP(hipStreamWaitEvent(s, f->ev_prep_done[k2], 0));
   }
 
   Pose16 prior;
@@ -470,7 +559,7 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
                                  (float)(int)f->p.maxDepthProcessed, s)))
         return rc;
     }
-    if ((rc = dms_odometry_initFirstRGB(f->odom, &f->rgba, s))) return rc;
+    // initFirstRGB (ElasticFusion.cpp:151): the intensity pyramid of this frame already sits in ring set 0
     f->map_initialised = true;
     fused = 1;
   } else {
@@ -490,8 +579,8 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
         if ((rc = odometry_initRGBModel_sel(f->odom, f->pred.image.data, f->fill.image.data, &f->state->fill_in,
                                             f->p.frameToFrameRGB ? 1 : 0, f->rgba_tmp, s)))
           return rc;
-        if ((rc = dms_odometry_initICP_depth(f->odom, &f->depth_filtered, f->p.maxDepthProcessed, s))) return rc;
-        if ((rc = dms_odometry_initRGB(f->odom, &f->rgba, s))) return rc;
+        // initICP / initRGB: the live half ran on the prep stream; nextDepth = lastDepth (same source)
+        odometry_alias_next_depth(f->odom);
       }
       {
         FTimer t(f, s, "track");
@@ -503,7 +592,11 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     }
     hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
     DMS_CHECK_LAUNCH();
-    if ((rc = predict(f, f->p.confidence, s))) return rc;  // ElasticFusion.cpp:273
+    // "GlobalPredict" (ElasticFusion.cpp:273): its only consumers are the fern / loop-closure blocks,
+    // which this reference compiles out with `if (false)` (ElasticFusion.cpp:279, :593), and the
+    // final predict below overwrites every image it writes before the frame returns.
+    if (f->p.global_predict)
+      if ((rc = predict(f, f->p.confidence, s))) return rc;
 
     if (!f->p.rgbOnly) {  // fusion (ElasticFusion.cpp:506-564); NID gate off, tracking never "lost" without --rl
       {
@@ -537,8 +630,10 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
   hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, s, f->state, f->model->d_count);
   DMS_CHECK_LAUNCH();
   DMS_HIP(hipMemcpyAsync(f->h_state, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+  if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
   f->fused_last = fused;
   f->tick += 1;  // if(!lost) tick++ (ElasticFusion.cpp:588-591)
+  f->frames += 1;
   return DMS_OK;
 }
 

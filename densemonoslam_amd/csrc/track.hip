@@ -84,6 +84,17 @@ struct dms_odometry {
   Buf depth_tmp[3], vmaps_g_prev[3], nmaps_g_prev[3], vmaps_curr[3], nmaps_curr[3];
   Buf lastDepth[3], nextDepth[3], lastImage[3], nextImage[3], lastNextImage[3];
   Buf nextdIdx[3], nextdIdy[3], pointClouds[3], corresImg[3];
+  // Live-frame ring (frame pipeline only): the buffers written from the incoming frame alone —
+  // depth pyramid, live vertex/normal maps, intensity pyramid and its derivatives — exist three
+  // times, so that the next frame can be prepared on a second stream while this one is tracked
+  // and the previous intensity pyramid still serves as lastNextImage.  Set 0 is the default set.
+  struct LiveSet {
+    Buf depth_tmp[3], vmaps_curr[3], nmaps_curr[3], nextImage[3], nextdIdx[3], nextdIdy[3];
+  };
+  LiveSet ring[3];
+  char* ring_arena = nullptr;
+  bool ring_enabled = false;
+  const void* deriv_of = nullptr;  // nextImage[0] the derivative pyramid was computed from
   float* vmaps_tmp = nullptr;
   float* nmaps_tmp = nullptr;
   float* part_icp = nullptr;   // [29][1024]
@@ -849,7 +860,7 @@ void drain_timers(dms_odometry* o) {
   o->pending.clear();
 }
 
-int populateRGBDData(dms_odometry* o, const dms_image2d* rgba, Buf* destDepths, Buf* destImages, hipStream_t s) {
+int populateDepth(dms_odometry* o, Buf* destDepths, hipStream_t s) {
   int rc;
   dms_image2d d0 = destDepths[0].img();
   if ((rc = verticesToDepth(o->vmaps_tmp, &d0, o->maxDepthRGB, s))) return rc;
@@ -857,12 +868,38 @@ int populateRGBDData(dms_odometry* o, const dms_image2d* rgba, Buf* destDepths, 
     dms_image2d a = destDepths[i].img(), b = destDepths[i + 1].img();
     if ((rc = pyrDownGaussF(&a, &b, s))) return rc;
   }
+  return DMS_OK;
+}
+
+int populateImage(const dms_image2d* rgba, Buf* destImages, hipStream_t s) {
+  int rc;
   dms_image2d i0 = destImages[0].img();
   if ((rc = imageToIntensity(rgba, &i0, s))) return rc;
   for (int i = 0; i + 1 < DMS_NUM_PYRS; i++) {
     dms_image2d a = destImages[i].img(), b = destImages[i + 1].img();
     if ((rc = pyrDownUcharGauss(&a, &b, s))) return rc;
   }
+  return DMS_OK;
+}
+
+// RGBDOdometry::populateRGBDData (RGBDOdometry.cpp:139-160): depth from the LAST vertex map that
+// initICPModel uploaded (vmaps_tmp), intensity from the given image
+int populateRGBDData(dms_odometry* o, const dms_image2d* rgba, Buf* destDepths, Buf* destImages, hipStream_t s) {
+  int rc;
+  if ((rc = populateDepth(o, destDepths, s))) return rc;
+  return populateImage(rgba, destImages, s);
+}
+
+// Sobel pyramid of nextImage (RGBDOdometry.cpp:279-283).  The reference computes it inside
+// getIncrementalTransformation; here it is computed where nextImage is written and only redone
+// by the tracker when nextImage is no longer the image it was computed from (SO3 handle swap).
+int nextDerivatives(dms_odometry* o, hipStream_t s) {
+  int rc;
+  for (int i = 0; i < DMS_NUM_PYRS; i++) {
+    dms_image2d a = o->nextImage[i].img(), dx = o->nextdIdx[i].img(), dy = o->nextdIdy[i].img();
+    if ((rc = derivativeImages(&a, &dx, &dy, s))) return rc;
+  }
+  o->deriv_of = o->nextImage[0].p;
   return DMS_OK;
 }
 
@@ -919,6 +956,7 @@ int dms_odometry_destroy(dms_odometry* o) {
   drain_timers(o);
   for (auto e : o->event_pool) (void)hipEventDestroy(e);
   if (o->arena) (void)hipFree(o->arena);
+  if (o->ring_arena) (void)hipFree(o->ring_arena);
   if (o->host_state) (void)hipHostFree(o->host_state);
   delete o;
   return DMS_OK;
@@ -998,7 +1036,9 @@ int dms_odometry_initICPModel(dms_odometry* o, const float* verts, const float* 
 int dms_odometry_initRGB(dms_odometry* o, const dms_image2d* rgba, dms_stream s) {
   DMS_REQUIRE(o && rgba && rgba->data, "null argument");
   DMS_REQUIRE(rgba->rows == o->height && rgba->cols == o->width, "rgba must be full resolution");
-  return populateRGBDData(o, rgba, o->nextDepth, o->nextImage, (hipStream_t)s);
+  int rc = populateRGBDData(o, rgba, o->nextDepth, o->nextImage, (hipStream_t)s);
+  if (rc) return rc;
+  return nextDerivatives(o, (hipStream_t)s);
 }
 int dms_odometry_initRGBModel(dms_odometry* o, const dms_image2d* rgba, dms_stream s) {
   DMS_REQUIRE(o && rgba && rgba->data, "null argument");
@@ -1053,11 +1093,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     memcpy(prior.v + 3, rot, 9 * sizeof(float));
   }
 
-  if (rgb) {
-    for (int i = 0; i < DMS_NUM_PYRS; i++) {
-      dms_image2d a = o->nextImage[i].img(), dx = o->nextdIdx[i].img(), dy = o->nextdIdy[i].img();
-      if ((rc = derivativeImages(&a, &dx, &dy, s))) return rc;
-    }
+  if (rgb && o->deriv_of != o->nextImage[0].p) {
+    if ((rc = nextDerivatives(o, s))) return rc;
   }
 
   int iterations[DMS_NUM_PYRS];
@@ -1223,6 +1260,79 @@ int odometry_result_pose(dms_odometry* o, float* pose16_dev, hipStream_t s) {
 
 int selectCopy16(void* dst, const void* a, const void* b, const int* flag_dev, int force_b, size_t n16, hipStream_t s);
 int transformMapsDev(dms_image2d* v, dms_image2d* n, const float* pose16_dev, hipStream_t s);
+
+// ---- live-frame ring (see dms_odometry::LiveSet) ----
+int odometry_enable_ring(dms_odometry* o) {
+  if (o->ring_enabled) return DMS_OK;
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    o->ring[0].depth_tmp[i] = o->depth_tmp[i];
+    o->ring[0].vmaps_curr[i] = o->vmaps_curr[i];
+    o->ring[0].nmaps_curr[i] = o->nmaps_curr[i];
+    o->ring[0].nextImage[i] = o->nextImage[i];
+    o->ring[0].nextdIdx[i] = o->nextdIdx[i];
+    o->ring[0].nextdIdy[i] = o->nextdIdy[i];
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver c;
+    c.base = pass ? o->ring_arena : nullptr;
+    const int W = o->width, H = o->height;
+    auto mk = [&](Buf& b, int rows, int cols, size_t elem) {
+      b.rows = rows;
+      b.cols = cols;
+      b.pitch = (size_t)cols * elem;
+      b.p = c.take(b.pitch * rows);
+    };
+    for (int k = 1; k < 3; ++k)
+      for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+        const int r = H >> i, w = W >> i;
+        mk(o->ring[k].depth_tmp[i], r, w, 2);
+        mk(o->ring[k].vmaps_curr[i], r * 3, w, 4);
+        mk(o->ring[k].nmaps_curr[i], r * 3, w, 4);
+        mk(o->ring[k].nextImage[i], r, w, 1);
+        mk(o->ring[k].nextdIdx[i], r, w, 2);
+        mk(o->ring[k].nextdIdy[i], r, w, 2);
+      }
+    if (!pass) {
+      const size_t bytes = align_up(c.off, 256);
+      hipError_t e = hipMalloc((void**)&o->ring_arena, bytes);
+      if (e == hipSuccess) e = hipMemset(o->ring_arena, 0, bytes);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc(live ring)", __FILE__, __LINE__);
+    }
+  }
+  o->ring_enabled = true;
+  return DMS_OK;
+}
+
+// point the tracker's live-frame buffers at ring set k (host-side handle swap, stream-ordered use)
+void odometry_bind_live(dms_odometry* o, int k) {
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    o->depth_tmp[i] = o->ring[k].depth_tmp[i];
+    o->vmaps_curr[i] = o->ring[k].vmaps_curr[i];
+    o->nmaps_curr[i] = o->ring[k].nmaps_curr[i];
+    o->nextImage[i] = o->ring[k].nextImage[i];
+    o->nextdIdx[i] = o->ring[k].nextdIdx[i];
+    o->nextdIdy[i] = o->ring[k].nextdIdy[i];
+  }
+  o->deriv_of = o->nextImage[0].p;  // every ring set carries the derivatives of its own image
+}
+
+void odometry_bind_lastnext(dms_odometry* o, int k) {
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) o->lastNextImage[i] = o->ring[k].nextImage[i];
+}
+
+// live half of initRGB: intensity pyramid + derivative pyramid of the bound live set
+int odometry_initRGB_image(dms_odometry* o, const dms_image2d* rgba, hipStream_t s) {
+  int rc = populateImage(rgba, o->nextImage, s);
+  if (rc) return rc;
+  return nextDerivatives(o, s);
+}
+
+// model half of initRGB.  populateRGBDData derives nextDepth from the same vmaps_tmp (and the same
+// cutoff) as initRGBModel derived lastDepth a moment earlier, so the two pyramids are identical:
+// the handles are aliased instead of recomputing three kernels.
+void odometry_alias_next_depth(dms_odometry* o) {
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) o->nextDepth[i] = o->lastDepth[i];
+}
 
 // initICPModel with the source chosen on device: (*flag ? fill-in maps : predicted maps), pose read from HBM
 int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA, const float* vB, const float* nB, const int* flag_dev,

@@ -35,6 +35,7 @@ class FusionParams(C.Structure):
         ("fastOdom", C.c_int), ("so3", C.c_int), ("frameToFrameRGB", C.c_int), ("pyramid", C.c_int),
         ("hybrid_tracking", C.c_int), ("rgbOnly", C.c_int), ("timeIdx", C.c_int),
         ("maxDepthProcessed", C.c_float), ("model_capacity", C.c_size_t),
+        ("pipeline_ingest", C.c_int), ("global_predict", C.c_int),
     ]
 
 

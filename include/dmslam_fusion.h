@@ -145,6 +145,14 @@ typedef struct dms_fusion_params {
   int timeIdx;               /* Context::id(): which per-sensor time slot this camera uses */
   float maxDepthProcessed;   /* 25 (ElasticFusion.cpp:56) */
   size_t model_capacity;     /* 0 = reference MAX_VERTICES */
+  int pipeline_ingest;       /* 1 (default): ingest, depth filter and the live pyramids of a frame run on an
+                                internal second stream and overlap the previous frame's tracking / fusion.
+                                Contract: rgb_dev / depth_dev are complete when process_frame is called and stay
+                                untouched until work enqueued on `stream` after the call would run.
+                                0: everything is issued on `stream`. */
+  int global_predict;        /* 1: also run the post-tracking "GlobalPredict" (ElasticFusion.cpp:273), whose
+                                consumers (ferns / loop closure) the reference compiles out; its images are
+                                overwritten by the final predict either way.  Default 0. */
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
