@@ -15,6 +15,7 @@ int resizeMap(const dms_image2d* in, dms_image2d* out, bool normalize, hipStream
 int pyrDownGaussF(const dms_image2d* src, dms_image2d* dst, hipStream_t s);
 int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s);
 int verticesToDepth(const float* vsrc, dms_image2d* dst, float cutOff, hipStream_t s);
+int rgbGate(const dms_image2d* src, const dms_image2d* dx, const dms_image2d* dy, dms_image2d* gate, float minScale, hipStream_t s);
 int verticesToDepth2D(const dms_image2d* vsrc, dms_image2d* dst, float cutOff, hipStream_t s);
 int imageToIntensity(const dms_image2d* rgba, dms_image2d* dst, hipStream_t s);
 int derivativeImages(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, hipStream_t s);

@@ -143,6 +143,9 @@ struct RgbResPtrs {
   size_t lastImage_pitch;
   const unsigned char* nextImage;
   size_t nextImage_pitch;
+  // optional precomputed pose-independent gate (k_rgb_gate); null = evaluate window and gradient here
+  const unsigned char* gate;
+  size_t gate_pitch;
 };
 
 template <typename T>
@@ -166,6 +169,16 @@ struct RgbModel {
   float d0;
   unsigned char l0;
 };
+
+// gated variant: window / gradient test read from the per-frame gate image (3 loads instead of 19)
+__device__ __forceinline__ RgbOwn rgb_load_own_gated(const RgbResPtrs& q, int j0, int i) {
+  RgbOwn o;
+  const unsigned char g = trow(q.gate, q.gate_pitch, i)[j0];
+  o.i1 = trow(q.nextImage, q.nextImage_pitch, i)[j0];
+  o.d1 = trow(q.nextDepth, q.nextDepth_pitch, i)[j0];
+  o.gate = (int)(g != 0) & (int)!isnan(o.d1);
+  return o;
+}
 
 __device__ __forceinline__ RgbOwn rgb_load_own(const RgbResParams& p, const RgbResPtrs& q, int j0, int i) {
   const int cols = p.cols, rows = p.rows;

@@ -329,6 +329,24 @@ __global__ void k_derivatives(View<const unsigned char> src, View<short> dx, Vie
   dy.at(y, x) = (short)f2i_rz(dyVal);
 }
 
+// Pose-independent part of the photometric correspondence test (RGBResidual::getProducts,
+// reduce.cu:775-797), evaluated once per frame and level instead of once per Gauss-Newton iteration:
+// gate = inside the border && all 16 taps of the clipped 4x4 window non-zero && |grad|^2 >= minScale,
+// with dx / dy exactly the values k_derivatives stores.
+__global__ void k_rgb_gate(View<const unsigned char> src, View<const short> dx, View<const short> dy, View<unsigned char> gate,
+                           float minScale) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= src.cols || y >= src.rows) return;
+  const int cols = src.cols, rows = src.rows;
+  bool ok = (x < cols - 5 && y < rows - 1);
+  for (int u = max(y - 2, 0); u < min(y + 2, rows); u++)
+    for (int v = max(x - 2, 0); v < min(x + 2, cols); v++) ok = ok && (src.at(u, v) > 0);
+  const int vx = dx.at(y, x), vy = dy.at(y, x);
+  const float mTwo = (float)(vx * vx + vy * vy);
+  gate.at(y, x) = (ok && mTwo >= minScale) ? 1 : 0;
+}
+
 // reference projectPointsKernel (cudafuncs.cu:727-741); cloud is packed float3
 __global__ void k_projectPoints(View<const float> depth, View<float> cloud3, float invFx, float invFy, float cx, float cy) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,6 +485,14 @@ int derivativeImages(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, h
   DMS_REQUIRE(src && dx && dy && src->data && dx->data && dy->data, "null argument");
   DMS_REQUIRE(dx->rows == src->rows && dx->cols == src->cols && dy->rows == src->rows && dy->cols == src->cols, "shape mismatch");
   LAUNCH2D(k_derivatives, src->cols, src->rows, s, view<const unsigned char>(src), view<short>(dx), view<short>(dy));
+  return DMS_OK;
+}
+
+int rgbGate(const dms_image2d* src, const dms_image2d* dx, const dms_image2d* dy, dms_image2d* gate, float minScale, hipStream_t s) {
+  DMS_REQUIRE(src && dx && dy && gate && src->data && dx->data && dy->data && gate->data, "null argument");
+  DMS_REQUIRE(gate->rows == src->rows && gate->cols == src->cols, "shape mismatch");
+  LAUNCH2D(k_rgb_gate, src->cols, src->rows, s, view<const unsigned char>(src), view<const short>(dx), view<const short>(dy),
+           view<unsigned char>(gate), minScale);
   return DMS_OK;
 }
 

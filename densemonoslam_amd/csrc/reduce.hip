@@ -246,6 +246,8 @@ RgbResPtrs make_rgbres_ptrs(const dms_image2d* dIdx, const dms_image2d* dIdy, co
   q.lastImage_pitch = lastImage->pitch;
   q.nextImage = (const unsigned char*)nextImage->data;
   q.nextImage_pitch = nextImage->pitch;
+  q.gate = nullptr;
+  q.gate_pitch = 0;
   return q;
 }
 

@@ -83,13 +83,13 @@ struct dms_odometry {
   size_t arena_bytes = 0;
   Buf depth_tmp[3], vmaps_g_prev[3], nmaps_g_prev[3], vmaps_curr[3], nmaps_curr[3];
   Buf lastDepth[3], nextDepth[3], lastImage[3], nextImage[3], lastNextImage[3];
-  Buf nextdIdx[3], nextdIdy[3], pointClouds[3], corresImg[3];
+  Buf nextdIdx[3], nextdIdy[3], nextGate[3], pointClouds[3], corresImg[3];
   // Live-frame ring (frame pipeline only): the buffers written from the incoming frame alone —
   // depth pyramid, live vertex/normal maps, intensity pyramid and its derivatives — exist three
   // times, so that the next frame can be prepared on a second stream while this one is tracked
   // and the previous intensity pyramid still serves as lastNextImage.  Set 0 is the default set.
   struct LiveSet {
-    Buf depth_tmp[3], vmaps_curr[3], nmaps_curr[3], nextImage[3], nextdIdx[3], nextdIdy[3];
+    Buf depth_tmp[3], vmaps_curr[3], nmaps_curr[3], nextImage[3], nextdIdx[3], nextdIdy[3], nextGate[3];
   };
   LiveSet ring[3];
   char* ring_arena = nullptr;
@@ -371,13 +371,22 @@ struct SolveArgs {
 __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
                               const SolveArgs q);
 
+// The fused loop's own correspondence record (the 16-byte DataTerm of the operator layer carries
+// the live pixel's coordinates, which are the record's position, and a float difference of two
+// bytes): half the bytes written by pass 1 and read back by pass 2.
+struct Corr8 {
+  short zero_x, zero_y;
+  short diff;  // nextImage - lastImage, an integer in [-255, 255]
+  short valid;
+};
+
 struct GnArgs {
   // ICP
   MapPtrs maps;
   float fx, fy, cx, cy, distThres, angleThres;
   // RGB
   RgbResPtrs rgb;
-  dms_dataterm* corres;
+  Corr8* corres;
   const float* cloud;
   size_t cloud_pitch;
   float minScale, maxDepthDelta, sobelScale;
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, f
       py[p] = ic / a.cols;
       px[p] = ic - py[p] * a.cols;
       if (ICP) io[p] = icp_load_own(a.maps, px[p], py[p], a.rows);
-      if (RGB) ro[p] = rgb_load_own(rp, a.rgb, px[p], py[p]);
+      if (RGB) ro[p] = rgb_load_own_gated(a.rgb, px[p], py[p]);
     }
     IcpProj ir[kPix];
     RgbProj rr[kPix];
@@ -476,7 +485,12 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, f
             cnt += 1;
             sig += d2;
           }
-          a.corres[idx[p]] = c;
+          Corr8 c8;
+          c8.zero_x = c.zero_x;
+          c8.zero_y = c.zero_y;
+          c8.diff = (short)f2i_rz(c.diff);
+          c8.valid = (short)c.valid;
+          a.corres[idx[p]] = c8;
         }
       }
       if (ICP) {
@@ -569,8 +583,15 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, c
 #pragma unroll
     for (int p = 0; p < kPix; ++p) {
       const int i = base + p * kBlock + (int)threadIdx.x;
-      c[p] = a.corres[i < N ? i : 0];
-      if (i >= N) c[p].valid = 0;
+      const int ic = i < N ? i : 0;
+      const Corr8 c8 = a.corres[ic];
+      const int y = ic / a.cols;
+      c[p].zero_x = c8.zero_x;
+      c[p].zero_y = c8.zero_y;
+      c[p].one_x = (short)(ic - y * a.cols);
+      c[p].one_y = (short)y;
+      c[p].diff = (float)c8.diff;
+      c[p].valid = (i < N) ? (int)c8.valid : 0;
     }
 #pragma unroll
     for (int p = 0; p < kPix; ++p) in[p] = rgb_row_load(c[p], a.cloud, a.cloud_pitch, a.rgb.dIdx, a.rgb.dIdy, a.rgb.dI_pitch);
@@ -805,6 +826,7 @@ void layout(dms_odometry* o, Carver& c) {
     mk(o->lastNextImage[i], r, w, 1);
     mk(o->nextdIdx[i], r, w, 2);
     mk(o->nextdIdy[i], r, w, 2);
+    mk(o->nextGate[i], r, w, 1);
     mk(o->pointClouds[i], r, w, 12);
     mk(o->corresImg[i], r, w, sizeof(dms_dataterm));
   }
@@ -860,6 +882,9 @@ void drain_timers(dms_odometry* o) {
   o->pending.clear();
 }
 
+// minimum squared gradient of level l (RGBDOdometry.cpp:287-291 / :453)
+float rgb_min_scale(const dms_odometry* o, int l) { return (float)(pow((double)o->minGrad[l], 2.0) / pow((double)o->sobelScale, 2.0)); }
+
 int populateDepth(dms_odometry* o, Buf* destDepths, hipStream_t s) {
   int rc;
   dms_image2d d0 = destDepths[0].img();
@@ -896,8 +921,9 @@ int populateRGBDData(dms_odometry* o, const dms_image2d* rgba, Buf* destDepths, 
 int nextDerivatives(dms_odometry* o, hipStream_t s) {
   int rc;
   for (int i = 0; i < DMS_NUM_PYRS; i++) {
-    dms_image2d a = o->nextImage[i].img(), dx = o->nextdIdx[i].img(), dy = o->nextdIdy[i].img();
+    dms_image2d a = o->nextImage[i].img(), dx = o->nextdIdx[i].img(), dy = o->nextdIdy[i].img(), g = o->nextGate[i].img();
     if ((rc = derivativeImages(&a, &dx, &dy, s))) return rc;
+    if ((rc = rgbGate(&a, &dx, &dy, &g, rgb_min_scale(o, i), s))) return rc;
   }
   o->deriv_of = o->nextImage[0].p;
   return DMS_OK;
@@ -1167,11 +1193,13 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     a.rgb.lastImage_pitch = o->lastImage[l].pitch;
     a.rgb.nextImage = (const unsigned char*)o->nextImage[l].p;
     a.rgb.nextImage_pitch = o->nextImage[l].pitch;
-    a.corres = (dms_dataterm*)o->corresImg[l].p;
+    a.rgb.gate = (const unsigned char*)o->nextGate[l].p;
+    a.rgb.gate_pitch = o->nextGate[l].pitch;
+    a.corres = (Corr8*)o->corresImg[l].p;
     a.cloud = (const float*)o->pointClouds[l].p;
     a.cloud_pitch = o->pointClouds[l].pitch;
     // pow(minimumGradientMagnitudes[i], 2.0) / pow(sobelScale, 2.0) (RGBDOdometry.cpp:445)
-    a.minScale = (float)(pow((double)o->minGrad[l], 2.0) / pow((double)o->sobelScale, 2.0));
+    a.minScale = rgb_min_scale(o, l);
     a.maxDepthDelta = o->maxDepthDeltaRGB;
     a.sobelScale = o->sobelScale;
     a.cols = o->vmaps_curr[l].cols;
@@ -1271,6 +1299,7 @@ int odometry_enable_ring(dms_odometry* o) {
     o->ring[0].nextImage[i] = o->nextImage[i];
     o->ring[0].nextdIdx[i] = o->nextdIdx[i];
     o->ring[0].nextdIdy[i] = o->nextdIdy[i];
+    o->ring[0].nextGate[i] = o->nextGate[i];
   }
   for (int pass = 0; pass < 2; ++pass) {
     Carver c;
@@ -1291,6 +1320,7 @@ int odometry_enable_ring(dms_odometry* o) {
         mk(o->ring[k].nextImage[i], r, w, 1);
         mk(o->ring[k].nextdIdx[i], r, w, 2);
         mk(o->ring[k].nextdIdy[i], r, w, 2);
+        mk(o->ring[k].nextGate[i], r, w, 1);
       }
     if (!pass) {
       const size_t bytes = align_up(c.off, 256);
@@ -1312,6 +1342,7 @@ void odometry_bind_live(dms_odometry* o, int k) {
     o->nextImage[i] = o->ring[k].nextImage[i];
     o->nextdIdx[i] = o->ring[k].nextdIdx[i];
     o->nextdIdy[i] = o->ring[k].nextdIdy[i];
+    o->nextGate[i] = o->ring[k].nextGate[i];
   }
   o->deriv_of = o->nextImage[0].p;  // every ring set carries the derivatives of its own image
 }
@@ -1461,6 +1492,7 @@ int dms_odometry_get_buffer(dms_odometry* o, int which, int level, dms_image2d* 
     case 11: b = &o->pointClouds[level]; break;
     case 12: b = &o->depth_tmp[level]; break;
     case 13: b = &o->corresImg[level]; break;
+    case 14: b = &o->nextGate[level]; break;
     default: DMS_REQUIRE(false, "bad buffer id");
   }
   *view = b->img();

@@ -248,7 +248,8 @@ int dms_odometry_getCovariance(dms_odometry* o, double* cov36);
 /* pyramid accessors used by tests and by the NID stage (RGBDOdometry.h:74-86):
  * which: 0 vmaps_curr 1 nmaps_curr 2 vmaps_g_prev 3 nmaps_g_prev 4 lastDepth 5 nextDepth
  *        6 lastImage 7 nextImage 8 lastNextImage 9 nextdIdx 10 nextdIdy 11 pointClouds
- *        12 depth_tmp 13 corresImg */
+ *        12 depth_tmp 13 corresImg (the fused tracker keeps 8-byte records there:
+ *        short zero_x, zero_y, diff, valid) 14 nextGate (pose-independent photometric gate, u8) */
 int dms_odometry_get_buffer(dms_odometry* o, int which, int level, dms_image2d* view);
 
 /* per-kernel device time of the last tracking call, measured with HIP events on the

@@ -378,6 +378,43 @@ def test_process_frame_pipeline_parity(fus, orc, synth):
     assert worst_t < 5e-4 and worst_r < 5e-3, (worst_t, worst_r)
 
 
+def test_process_frame_pipelined_equals_serial(fus, synth):
+    """The two-stream frame pipeline (live-frame half of frame t+1 overlapping tracking / fusion of
+    frame t, two frames in flight) must be invisible: enqueueing a burst of frames without any
+    host synchronisation gives bit-identical poses and maps to (a) synchronising after every frame
+    and (b) the single-stream mode."""
+    from densemonoslam_amd import capi
+
+    n_frames = 7
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(n_frames)]
+
+    def run(burst, **opts):
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, **opts)
+        rgbs = [capi.DeviceBuffer(W * H * 3) for _ in frames]
+        deps = [capi.DeviceBuffer(W * H * 2) for _ in frames]
+        for (d, rgb, _), rb, db in zip(frames, rgbs, deps):
+            rb.upload(np.ascontiguousarray(rgb, np.uint8))
+            db.upload(np.ascontiguousarray(d, np.uint16))
+        poses = []
+        for k in range(n_frames):
+            g.processFrameAsync(rgbs[k].ptr, 3, deps[k].ptr)
+            if not burst:
+                poses.append(np.array(g.fetch().pose, np.float32))
+        r = g.fetch()
+        m = g.globalModel().downloadMap()
+        return np.array(r.pose, np.float32), int(r.surfels), m, g.image(10), g.image(2)
+
+    ref = run(False, pipeline_ingest=0)
+    for burst, pipe in ((True, 1), (False, 1), (True, 0)):
+        got = run(burst, pipeline_ingest=pipe)
+        what = "burst=%s pipeline=%d" % (burst, pipe)
+        assert (got[0] == ref[0]).all(), what
+        assert got[1] == ref[1], what
+        surfels_equal(got[2], ref[2], what)
+        assert_bits(got[3], ref[3], "final predicted vertex " + what)
+        assert_bits(got[4], ref[4], "filtered depth " + what)
+
+
 def test_process_frame_free_running_drift_is_bounded(fus, orc, synth):
     """Without teacher forcing the two float implementations drift apart slowly (correspondences
     flip under 1e-6 pose differences); the drift stays far below the scene scale."""
