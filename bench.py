@@ -214,11 +214,22 @@ def main():
             if cnt:
                 stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
         kern = {}
-        for n in ("gn_pass1", "gn_pass2", "gn_solve", "so3_pass"):
+        for n in ("gn_level", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
             ms, cnt = C.c_double(0), C.c_int(0)
             capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
             if cnt.value:
                 kern[n] = {"ms_per_frame": ms.value / nprof, "avg_us": 1000.0 * ms.value / cnt.value, "launches_per_frame": cnt.value / nprof}
+        phase_names = ["setup", "pass1", "reduce_icp", "barrier_A", "pass2_reduce", "barrier_B", "gather", "solve", "writeback", "clock_overhead"]
+        phases = {}
+        for lvl in range(3):
+            row = {}
+            for i, n in enumerate(phase_names):
+                ms, cnt = C.c_double(0), C.c_int(0)
+                capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), ("phase:%d" % (lvl * 16 + i)).encode(), C.byref(ms), C.byref(cnt)))
+                row[n] = round(1000.0 * ms.value / nprof, 2)
+            phases["L%d" % lvl] = row
+        if sum(sum(r.values()) for r in phases.values()) > 0:
+            out["gn_level_phase_us_per_frame"] = phases  # in-kernel clock of block 0, summed over the level's iterations
         out["stage_ms_per_frame"] = {k: round(v["ms_per_frame"], 4) for k, v in stages.items()}
         out["tracker_kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern.items()}
         # dominant kernel: the Gauss-Newton pass-1 (ICP + photometric correspondence) over the pyramid

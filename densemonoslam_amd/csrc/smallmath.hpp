@@ -267,6 +267,63 @@ __host__ __device__ __forceinline__ void ldlt_solve_reg(const T (&Ain)[N * N], c
   for (int i = 0; i < N; ++i) x[i] = y[i];
 }
 
+// Fast path for the tracker's normal case: an unpivoted LDL^T of a symmetric positive definite
+// matrix, all in registers, one reciprocal per column.  Returns false (x untouched) unless every
+// pivot is positive and not tiny against the largest diagonal entry, i.e. unless the matrix is
+// safely positive definite; the caller then falls back to the pivoted routine above, which is what
+// defines the result on (near-)singular systems.  On accepted systems the two solutions agree to
+// cond(A) * 1e-16.
+template <typename T, int N>
+__host__ __device__ __forceinline__ bool ldlt_solve_spd(const T (&A)[N * N], const T (&b)[N], T (&x)[N]) {
+  T L[N * N], d[N], r[N];
+  T dmax = T(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) dmax = A[i * N + i] > dmax ? A[i * N + i] : dmax;
+  const T floor_ = dmax * T(1e-11);
+  bool ok = dmax > T(0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    T t[N];
+    T dk = A[k * N + k];
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      t[j] = L[k * N + j] * d[j];
+      dk -= L[k * N + j] * t[j];
+    }
+    d[k] = dk;
+    ok = ok && (dk > floor_);
+    r[k] = T(1) / dk;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      T v = A[i * N + k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= L[i * N + j] * t[j];
+      L[i * N + k] = v * r[k];
+    }
+  }
+  if (!ok) return false;
+  T y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    T v = b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) v -= L[i * N + j] * y[j];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] *= r[i];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    T v = y[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) v -= L[j * N + i] * y[j];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = y[i];
+  return true;
+}
+
 template <typename T, int N>
 __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tiny) {
   T A[N * N], temp[N], y[N];
@@ -281,7 +338,9 @@ __host__ __device__ inline void rodrigues(const double* src, double* R) {
   double rx = src[0], ry = src[1], rz = src[2];
   const double theta = sqrt(rx * rx + ry * ry + rz * rz);
   if (theta >= 2.2204460492503131e-16) {
-    const double c = cos(theta), s = sin(theta), c1 = 1. - c;
+    double s, c;
+    sincos(theta, &s, &c);  // one range reduction for both
+    const double c1 = 1. - c;
     const double itheta = theta ? 1. / theta : 0.;
     rx *= itheta;
     ry *= itheta;

@@ -26,6 +26,7 @@
 #include "internal.hpp"
 #include "pixel_ops.hpp"
 #include "smallmath.hpp"
+#include <mutex>
 
 namespace dms {
 
@@ -48,6 +49,7 @@ struct TrackState {
   float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
   double lastA[36], lastb[6];
   int rejected_jump;
+  int sync_timeout;  // a persistent kernel gave up waiting at a grid barrier (result invalid)
   float out_trans[3], out_rot[9];
 };
 
@@ -102,6 +104,9 @@ struct dms_odometry {
   float* part_so3 = nullptr;   // [11][1024]
   int* part_cnt = nullptr;     // [2][1024]
   unsigned* tickets = nullptr; // [4] arrival counters of the last-block-solves hand-off (zero between launches)
+  float* rec = nullptr;               // [2][kMaxPersistBlocks][kRecFloats] records of the persistent level kernels
+  unsigned long long* sync = nullptr; // [kSyncWords] barrier words, zeroed by k_track_init
+  long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
   bool profiling = false;
@@ -168,7 +173,10 @@ struct Prior {
 };
 
 __global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
-                             int so3, int first_level) {
+                             int so3, int first_level, unsigned long long* sync_words, int n_sync) {
+  // barrier words of the persistent kernels of this call: zero before any of them is launched
+  for (int i = threadIdx.x; i < n_sync; i += blockDim.x)
+    __hip_atomic_store(sync_words + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (prior_pose16) {  // device-resident prior (frame step): row-major 4×4 camera-to-world
     for (int i = 0; i < 3; ++i) {
@@ -193,6 +201,7 @@ __global__ void k_track_init(TrackState* st, Prior prior, const float* __restric
     st->iters_run[l] = 0;
   }
   st->rejected_jump = 0;
+  st->sync_timeout = 0;
   for (int i = 0; i < 36; ++i) st->lastA[i] = 0.0;
   for (int i = 0; i < 6; ++i) st->lastb[i] = 0.0;
   double K[9];
@@ -620,6 +629,170 @@ __device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
     }
 }
 
+// State of one Gauss-Newton level that evolves from iteration to iteration.  The launch path
+// keeps it in registers for one k_gn_solve; the persistent path keeps it in LDS for a whole level.
+struct GnLocal {
+  double resultRt[16];
+  float Rprev[9], tprev[3], Rprev_inv[9];  // constant during the loop
+  float Rcurr[9], tcurr[3];
+  float krkinv[9], kt[3];
+  float lastRGBError, lastRGBCount, lastICPError, lastICPCount;
+  int iters_run;
+  double lastA[36], lastb[6];
+};
+
+// projection parameters of the photometric term for the pose in `resultRt` at camera matrix K
+// (RGBDOdometry.cpp:427-437), into the local state
+// resultRt is a product of rigid transforms (orthonormal to 1e-16 in fp64), so its inverse is taken
+// in the isometry form [R^T | -R^T t] instead of the reference's general 4x4 inverse: the two agree
+// to ~1e-16 before the values are rounded to float, and the cofactor expansion was a quarter of the
+// serial solve time.
+__device__ __forceinline__ void gn_params_local(GnLocal& L, const double* K) {
+  // inverse pose [Ri | ti] = [R^T | -R^T t]
+  double Ri[9], ti[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = L.resultRt[j * 4 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ti[i] = -(Ri[i * 3 + 0] * L.resultRt[3] + Ri[i * 3 + 1] * L.resultRt[7] + Ri[i * 3 + 2] * L.resultRt[11]);
+  // K = [fx 0 cx; 0 fy cy; 0 0 1] (level_K): K Ri K^-1 and K ti in closed form instead of a general
+  // 3x3 inverse and two 3x3 products; same values to ~1e-16 before the float rounding
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const double ifx = 1.0 / fx, ify = 1.0 / fy;
+  double M[9];  // K * Ri
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    M[0 * 3 + j] = fx * Ri[0 * 3 + j] + cx * Ri[2 * 3 + j];
+    M[1 * 3 + j] = fy * Ri[1 * 3 + j] + cy * Ri[2 * 3 + j];
+    M[2 * 3 + j] = Ri[2 * 3 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double h0 = M[i * 3 + 0] * ifx, h1 = M[i * 3 + 1] * ify;
+    L.krkinv[i * 3 + 0] = (float)h0;
+    L.krkinv[i * 3 + 1] = (float)h1;
+    L.krkinv[i * 3 + 2] = (float)(M[i * 3 + 2] - h0 * cx - h1 * cy);
+  }
+  L.kt[0] = (float)(fx * ti[0] + cx * ti[2]);
+  L.kt[1] = (float)(fy * ti[1] + cy * ti[2]);
+  L.kt[2] = (float)ti[2];
+}
+
+// One Gauss-Newton update (RGBDOdometry.cpp:472-585): combine the two 6x6 systems, pivoted LDLT in
+// fp64, se(3) update of resultRt, new float pose, projection parameters for `next_level`.
+__device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma, const SolveArgs& q) {
+  float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+  float residual[2] = {0.f, 0.f};
+  if (q.icp) {
+    unpack_se3_d(s_icp, A_icp, b_icp);
+    residual[0] = s_icp[27];
+    residual[1] = s_icp[28];
+  }
+  if (q.rgb) unpack_se3_d(s_rgb, A_rgb, b_rgb);
+
+  double A[36], b[6], x[6];
+  if (q.icp && q.rgb) {
+    const double w = (double)q.icpWeight;
+    const double ww = w * w;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i] + ww * (double)A_icp[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i] + w * (double)b_icp[i];
+  } else if (q.icp) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = (double)A_icp[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = (double)b_icp[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i];
+  }
+  // A.ldlt().solve(b) (RGBDOdometry.cpp:554): unpivoted register LDL^T when A is safely positive
+  // definite, the pivoted routine (Eigen's semantics on degenerate systems) otherwise
+  if (!sm::ldlt_solve_spd<double, 6>(A, b, x)) sm::ldlt_solve_reg<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308);
+
+  // OdometryProvider::computeUpdateSE3 (OdometryProvider.h:73-93)
+  double Rt[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Rt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  const double rvec[3] = {x[3], x[4], x[5]};
+  double R[9];
+  sm::rodrigues(rvec, R);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rt[i * 4 + j] = R[i * 3 + j];
+  Rt[3] = x[0];
+  Rt[7] = x[1];
+  Rt[11] = x[2];
+  double prevRt[16], nr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) prevRt[i] = L.resultRt[i];
+  // resultRt = Rt * resultRt with both last rows (0 0 0 1): the skipped terms are exact zeros
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double v = Rt[i * 4 + 0] * prevRt[0 * 4 + j];
+      v += Rt[i * 4 + 1] * prevRt[1 * 4 + j];
+      v += Rt[i * 4 + 2] * prevRt[2 * 4 + j];
+      if (j == 3) v += Rt[i * 4 + 3];
+      nr[i * 4 + j] = v;
+    }
+  }
+  nr[12] = 0.0;
+  nr[13] = 0.0;
+  nr[14] = 0.0;
+  nr[15] = 1.0;
+
+  // rgbOdom = float(resultRt); currentT = [Rprev|tprev] * rgbOdom^-1 with the isometry inverse
+  float Ro[9], to[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = (float)nr[i * 4 + j];
+    to[i] = (float)nr[i * 4 + 3];
+  }
+  float RoT[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) RoT[i * 3 + j] = Ro[j * 3 + i];
+  float ti[3];
+  sm::mul3v<float>(RoT, to, ti);
+  ti[0] = -ti[0];
+  ti[1] = -ti[1];
+  ti[2] = -ti[2];
+  float Rprev[9], Rc[9], tc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rprev[i] = L.Rprev[i];
+  sm::mul3<float>(Rprev, RoT, Rc);
+  sm::mul3v<float>(Rprev, ti, tc);
+
+  L.iters_run += 1;
+  L.lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
+  L.lastRGBCount = (float)rgbSize;
+  L.lastICPError = sqrtf(residual[0]) / residual[1];
+  L.lastICPCount = residual[1];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) L.lastA[i] = A[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) L.lastb[i] = b[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) L.resultRt[i] = nr[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) L.Rcurr[i] = Rc[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) L.tcurr[i] = tc[i] + L.tprev[i];
+
+  double K[9];
+  level_K(q.fx, q.fy, q.cx, q.cy, q.next_level, K);
+  gn_params_local(L, K);
+}
+
 // run by the 256 threads of the last block of k_gn_pass2 (or of k_gn_pass1 when there is no
 // photometric term)
 __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
@@ -672,95 +845,36 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
   }
   if (threadIdx.x != 0) return;
 
-  float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
-  float residual[2] = {0.f, 0.f};
-  if (icp) {
-    unpack_se3_d(s_icp, A_icp, b_icp);
-    residual[0] = s_icp[27];
-    residual[1] = s_icp[28];
-  }
-  if (rgb) unpack_se3_d(s_rgb, A_rgb, b_rgb);
-
-  double A[36], b[6], x[6];
-  if (icp && rgb) {
-    const double w = (double)icpWeight;
-    const double ww = w * w;
+  GnLocal L;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i] + ww * (double)A_icp[i];
+  for (int i = 0; i < 16; ++i) L.resultRt[i] = prevRt[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i] + w * (double)b_icp[i];
-  } else if (icp) {
+  for (int i = 0; i < 9; ++i) L.Rprev[i] = Rprev[i];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = (double)A_icp[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = (double)b_icp[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i];
-  }
-  sm::ldlt_solve_reg<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308);
-
-  // OdometryProvider::computeUpdateSE3 (OdometryProvider.h:73-93)
-  double Rt[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) Rt[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  const double rvec[3] = {x[3], x[4], x[5]};
-  double R[9];
-  sm::rodrigues(rvec, R);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Rt[i * 4 + j] = R[i * 3 + j];
-  Rt[3] = x[0];
-  Rt[7] = x[1];
-  Rt[11] = x[2];
-  double nr[16];
-  sm::mul4(Rt, prevRt, nr);
-
-  // rgbOdom = float(resultRt); currentT = [Rprev|tprev] * rgbOdom^-1 with the isometry inverse
-  float Ro[9], to[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = (float)nr[i * 4 + j];
-    to[i] = (float)nr[i * 4 + 3];
-  }
-  float RoT[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) RoT[i * 3 + j] = Ro[j * 3 + i];
-  float ti[3];
-  sm::mul3v<float>(RoT, to, ti);
-  ti[0] = -ti[0];
-  ti[1] = -ti[1];
-  ti[2] = -ti[2];
-  float Rc[9], tc[3];
-  sm::mul3<float>(Rprev, RoT, Rc);
-  sm::mul3v<float>(Rprev, ti, tc);
+  for (int i = 0; i < 3; ++i) L.tprev[i] = tprev[i];
+  L.iters_run = iters_before;
+  gn_step_core(L, s_icp, s_rgb, rgbSize, sigma, q);
 
   // ---- all stores at the end, nothing read back ----
-  st->iters_run[level] = iters_before + 1;
-  st->lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
-  st->lastRGBCount = (float)rgbSize;
-  st->lastICPError = sqrtf(residual[0]) / residual[1];
-  st->lastICPCount = residual[1];
+  st->iters_run[level] = L.iters_run;
+  st->lastRGBError = L.lastRGBError;
+  st->lastRGBCount = L.lastRGBCount;
+  st->lastICPError = L.lastICPError;
+  st->lastICPCount = L.lastICPCount;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) st->lastA[i] = A[i];
+  for (int i = 0; i < 36; ++i) st->lastA[i] = L.lastA[i];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) st->lastb[i] = b[i];
+  for (int i = 0; i < 6; ++i) st->lastb[i] = L.lastb[i];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) st->resultRt[i] = nr[i];
+  for (int i = 0; i < 16; ++i) st->resultRt[i] = L.resultRt[i];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) st->Rcurr[i] = Rc[i];
+  for (int i = 0; i < 9; ++i) st->Rcurr[i] = L.Rcurr[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) st->tcurr[i] = tc[i] + tprev[i];
-
-  double K[9];
-  level_K(fx, fy, cx, cy, next_level, K);
-  gn_params_from(st, nr, K);
+  for (int i = 0; i < 3; ++i) st->tcurr[i] = L.tcurr[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) st->krkinv[i] = L.krkinv[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st->kt[i] = L.kt[i];
 }
 
 // The solve stays its own launch: folding it into the last block of pass 2 (ticket + agent-scope
@@ -769,6 +883,421 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
 __global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt,
                                                    int stride, int nblocks, SolveArgs q) {
   gn_solve_body(st, part_icp, part_rgb, part_cnt, stride, nblocks, q);
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent Gauss-Newton level: ALL iterations of one pyramid level in one launch
+// ---------------------------------------------------------------------------------------
+// A GN iteration is two grid-wide reductions deep (sigma needs the global correspondence count;
+// the 6x6 system needs every pixel), so the launch path pays three kernel boundaries, three
+// dispatch ramps and three rounds of dependent state loads per iteration.  Here one grid of
+// <= 256 blocks x 512 threads (at most one block per CU, 1-4 pixels per thread) stays resident for the
+// whole level:
+//   * everything pose independent is loaded ONCE per level into registers (own vertex / normal,
+//     photometric gate, own depth / intensity / gradient);
+//   * barrier A is a single relaxed agent-scope fetch_add whose 64-bit word carries the payload
+//     itself (35 bits sum of squared differences | 19 bits count | 10 bits arrivals) — integer
+//     sums are order free, so no memory has to be published and no fence is needed;
+//   * the correspondences never leave registers (no DataTerm image, no point-cloud image);
+//   * each block publishes one 256-byte record (29 ICP + 29 photometric sums) with write-through
+//     (sc1) stores, drains, and arrives at barrier B; then EVERY block gathers all records with
+//     sc1 loads, folds them in fp64 in a fixed order and runs the 6x6 solve itself.  All blocks
+//     hold bit-identical poses, so nothing is broadcast.  Records are double-buffered by iteration
+//     parity, which makes barrier B the only barrier needed around them.
+// Hand-off rules follow cdna_hip_programming.md G16 (every storing wave drains before the arrival,
+// relaxed polling, agent-scope words, bounded spins, words zeroed by an earlier kernel on the
+// stream); scripts/bench_gridbarrier.hip is the protocol's stand-alone visibility test.
+constexpr int kPB = 512;                 // 8 waves: 256 VGPRs per thread, half the reduction tail of 16 waves
+constexpr int kPWaves = kPB / kWave;
+constexpr int kRecFloats = 64;           // [0,29) ICP sums, [32,61) photometric sums
+constexpr int kMaxPersistBlocks = 256;   // one block per CU
+constexpr int kSyncWords = 512;          // barrier words per tracking call
+constexpr unsigned kSpinLimit = 1u << 22;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct LevelArgs {
+  int n_iter, level, level_below;
+  int rgbOnly;
+  float icpWeight;
+  float fx, fy, cx, cy;  // full-resolution intrinsics
+  float* rec;            // [2][gridDim.x][kRecFloats]
+  unsigned long long* sync;  // 2 words per iteration, zero on entry
+  long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
+};
+
+// arrive with `payload` added into the low 54 bits; returns the completed word
+__device__ __forceinline__ unsigned long long pk_barrier(unsigned long long* word, unsigned long long payload, int* timeout) {
+  __shared__ unsigned long long s_word;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(word, (1ull << 54) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long cur;
+    unsigned spins = 0;
+    for (;;) {
+      cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((cur >> 54) >= (unsigned long long)gridDim.x) break;
+      ++spins;
+      if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never hang the device
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_word = cur;
+  }
+  __syncthreads();
+  return s_word;
+}
+
+// split-phase form: pk_arrive (thread 0 only, after a __syncthreads() that orders the block's
+// work) ... independent work ... pk_wait
+__device__ __forceinline__ void pk_arrive(unsigned long long* word, unsigned long long payload) {
+  __hip_atomic_fetch_add(word, (1ull << 54) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long pk_wait(unsigned long long* word, int* timeout) {
+  __shared__ unsigned long long s_word2;
+  if (threadIdx.x == 0) {
+    unsigned long long cur;
+    unsigned spins = 0;
+    for (;;) {
+      cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((cur >> 54) >= (unsigned long long)gridDim.x) break;
+      ++spins;
+      if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_word2 = cur;
+  }
+  __syncthreads();
+  return s_word2;
+}
+
+// block-wide sum of NV per-thread values (16 waves): DPP inside the wave, then the 16 wave partials
+// of each value sit in 8 neighbouring lanes (thread = value * 8 + wave) and are summed in fp64 by a
+// 3-step butterfly.  The total of value k comes back in thread k * 8 (pblock_owner()).
+template <int NV>
+__device__ __forceinline__ float pblock_reduce(float (&v)[NV], float (*s_red)[32]) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();  // s_red may still be read from the previous use
+  wave_sum_all_to_lane63<NV>(v);
+  if (lane == kWave - 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s_red[wid][k] = v[k];
+  }
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < NV * kPWaves) r = (float)row8_sum_d((double)s_red[threadIdx.x & (kPWaves - 1)][threadIdx.x >> 3]);
+  return r;
+}
+template <int NV>
+__device__ __forceinline__ bool pblock_owner() {
+  return threadIdx.x < NV * kPWaves && (threadIdx.x & (kPWaves - 1)) == 0;
+}
+
+template <bool ICP, bool RGB, int P>
+__global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
+  __shared__ GnLocal s;
+  __shared__ float s_red[kPWaves][32];
+  __shared__ int s_redi[kPWaves][2];
+  __shared__ double s_grp[32][16][4];
+  __shared__ float s_sums[kRecFloats];
+  __shared__ int s_done;
+  const int tid = threadIdx.x;
+  const int nb = gridDim.x;
+  // optional phase clock (block 0, thread 0): wall_clock64 ticks (10 ns) summed per phase into L.prof
+  // (accumulated in LDS and flushed once at the end: a global read-modify-write per phase would
+  // stall wave 0 for a memory round trip each time and distort what it measures)
+  __shared__ long long s_prof[16];
+  if (tid < 16) s_prof[tid] = 0;
+  long long pc = L.prof ? wall_clock64() : 0;
+  auto phase = [&](int i) {
+    if (L.prof && blockIdx.x == 0 && tid == 0) {
+      const long long now = wall_clock64();
+      s_prof[i] += now - pc;
+      pc = now;
+    }
+  };
+
+  if (tid == 0) {
+    s_done = st->level_done[L.level];
+    for (int i = 0; i < 16; ++i) s.resultRt[i] = st->resultRt[i];
+    for (int i = 0; i < 9; ++i) {
+      s.Rprev[i] = st->Rprev[i];
+      s.Rprev_inv[i] = st->Rprev_inv[i];
+      s.Rcurr[i] = st->Rcurr[i];
+      s.krkinv[i] = st->krkinv[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+      s.tprev[i] = st->tprev[i];
+      s.tcurr[i] = st->tcurr[i];
+      s.kt[i] = st->kt[i];
+    }
+    s.lastRGBError = st->lastRGBError;
+    s.lastRGBCount = st->lastRGBCount;
+    s.lastICPError = st->lastICPError;
+    s.lastICPCount = st->lastICPCount;
+    s.iters_run = st->iters_run[L.level];
+    for (int i = 0; i < 36; ++i) s.lastA[i] = st->lastA[i];
+    for (int i = 0; i < 6; ++i) s.lastb[i] = st->lastb[i];
+  }
+
+  // ---- pose-independent per-pixel data, once per level ----
+  const int N = a.cols * a.rows;
+  int idx[P], px[P], py[P];
+  IcpOwn io[P];
+  RgbOwn ro[P];
+  short gx[P], gy[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    idx[p] = (blockIdx.x * P + p) * kPB + tid;
+    const int ic = idx[p] < N ? idx[p] : 0;  // threads past the end shadow pixel 0 and are masked
+    py[p] = ic / a.cols;
+    px[p] = ic - py[p] * a.cols;
+    if (ICP) io[p] = icp_load_own(a.maps, px[p], py[p], a.rows);
+    if (RGB) {
+      ro[p] = rgb_load_own_gated(a.rgb, px[p], py[p]);
+      gx[p] = trow(a.rgb.dIdx, a.rgb.dI_pitch, py[p])[px[p]];
+      gy[p] = trow(a.rgb.dIdy, a.rgb.dI_pitch, py[p])[px[p]];
+    }
+  }
+  const float invFx = 1.0f / a.fx, invFy = 1.0f / a.fy;  // as projectToPointCloud passes them
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(L.rec, 0, 2 * nb * kRecFloats * 4, 0x00020000);
+  __syncthreads();
+  if (s_done) return;  // level already ended (uniform: every block read the same flag)
+
+  bool ended = false;
+  phase(0);
+  for (int it = 0; it < L.n_iter; ++it) {
+    const int par = it & 1;
+    // ---- pass 1: correspondences + ICP rows ----
+    IcpParams ip;
+    RgbResParams rp;
+    if (ICP) {
+      ip.Rcurr.r0 = mk3(s.Rcurr[0], s.Rcurr[1], s.Rcurr[2]);
+      ip.Rcurr.r1 = mk3(s.Rcurr[3], s.Rcurr[4], s.Rcurr[5]);
+      ip.Rcurr.r2 = mk3(s.Rcurr[6], s.Rcurr[7], s.Rcurr[8]);
+      ip.tcurr = mk3(s.tcurr[0], s.tcurr[1], s.tcurr[2]);
+      ip.Rprev_inv.r0 = mk3(s.Rprev_inv[0], s.Rprev_inv[1], s.Rprev_inv[2]);
+      ip.Rprev_inv.r1 = mk3(s.Rprev_inv[3], s.Rprev_inv[4], s.Rprev_inv[5]);
+      ip.Rprev_inv.r2 = mk3(s.Rprev_inv[6], s.Rprev_inv[7], s.Rprev_inv[8]);
+      ip.tprev = mk3(s.tprev[0], s.tprev[1], s.tprev[2]);
+      ip.fx = a.fx;
+      ip.fy = a.fy;
+      ip.cx = a.cx;
+      ip.cy = a.cy;
+      ip.distThres = a.distThres;
+      ip.angleThres = a.angleThres;
+      ip.cols = a.cols;
+      ip.rows = a.rows;
+    }
+    if (RGB) {
+      rp.krkinv.r0 = mk3(s.krkinv[0], s.krkinv[1], s.krkinv[2]);
+      rp.krkinv.r1 = mk3(s.krkinv[3], s.krkinv[4], s.krkinv[5]);
+      rp.krkinv.r2 = mk3(s.krkinv[6], s.krkinv[7], s.krkinv[8]);
+      rp.kt = mk3(s.kt[0], s.kt[1], s.kt[2]);
+      rp.minScale = a.minScale;
+      rp.maxDepthDelta = a.maxDepthDelta;
+      rp.cols = a.cols;
+      rp.rows = a.rows;
+    }
+    const float lastErr = (it == 0) ? 3.402823466e+38F : s.lastRGBError;
+
+    IcpProj ir[P];
+    RgbProj rr[P];
+    IcpModel im[P];
+    RgbModel rm[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      if (ICP) {
+        ir[p] = icp_project(ip, io[p]);
+        im[p] = icp_load_model(a.maps, ir[p], a.rows);
+      }
+      if (RGB) {
+        rr[p] = rgb_project(rp, ro[p], px[p], py[p]);
+        rm[p] = rgb_load_model(a.rgb, rr[p]);
+      }
+    }
+    float acc[kSE3];
+#pragma unroll
+    for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
+    int cnt = 0, sig = 0;
+    dms_dataterm c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const bool live = idx[p] < N;
+      if (RGB) {
+        int d2;
+        const bool ok = rgb_finish(rp, ro[p], rr[p], rm[p], px[p], py[p], c[p], d2) && live;
+        if (!live) c[p].valid = 0;
+        if (ok) {
+          cnt += 1;
+          sig += d2;
+        }
+      }
+      if (ICP) {
+        float row[7];
+        bool found = icp_finish(ip, io[p], ir[p], im[p], row);
+        if (!live) {
+          found = false;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) row[k] = 0.f;
+        }
+        accumulate_se3(acc, row, found);
+      }
+    }
+    phase(1);
+    float* my_rec = L.rec + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+    int rgbSize = 0, sigma = 0;
+    if (RGB) {
+      // ---- barrier A, arrival: the word carries the count and the sum of squared differences ----
+      const int lane = tid & 63, wid = tid >> 6;
+      cnt = wave_sum_to_lane63_i(cnt);
+      sig = wave_sum_to_lane63_i(sig);
+      if (lane == 63) {
+        s_redi[wid][0] = cnt;
+        s_redi[wid][1] = sig;
+      }
+      __syncthreads();
+      if (tid < 64) {  // lanes 0-7: the 8 wave counts, lanes 8-15: the 8 wave sums (block sums fit an int)
+        const int t = row8_sum_i(tid < 16 ? s_redi[tid & 7][tid >> 3] : 0);
+        const unsigned long long cb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 0);
+        const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 8);
+        if (tid == 0) pk_arrive(L.sync + 2 * it, (cb << 35) | sb);
+      }
+    }
+    phase(2);
+    if (ICP) {  // the ICP block sum and its record store overlap the other blocks' arrivals
+      const float tot = pblock_reduce<kSE3>(acc, s_red);
+      if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (RGB) {
+      const unsigned long long word = pk_wait(L.sync + 2 * it, &st->sync_timeout);
+      phase(3);
+      rgbSize = (int)((word >> 35) & 0x7FFFFull);
+      sigma = (int)(word & 0x7FFFFFFFFull);
+      if (L.rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) {
+        // host `break` (RGBDOdometry.cpp:466-469): the level ends; the next level needs its own K
+        if (tid == 0) {
+          double K[9];
+          level_K(L.fx, L.fy, L.cx, L.cy, L.level_below, K);
+          gn_params_local(s, K);
+        }
+        ended = true;
+        break;
+      }
+      // ---- pass 2: photometric rows from the registers ----
+      RgbStepParams p_;
+      p_.sigma = L.rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
+      p_.fx = a.fx;
+      p_.fy = a.fy;
+      p_.sobelScale = a.sobelScale;
+#pragma unroll
+      for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        // the model pixel's cloud point, exactly as k_projectPoints builds it from lastDepth
+        RgbRowIn in;
+        const float z = rm[p].d0;
+        in.pt = mk3((((float)c[p].zero_x - a.cx) * z) * invFx, (((float)c[p].zero_y - a.cy) * z) * invFy, z);
+        in.gx = gx[p];
+        in.gy = gy[p];
+        float row[7];
+        rgb_row_finish(p_, c[p], in, row);
+        accumulate_se3(acc, row, c[p].valid != 0);
+      }
+      const float tot = pblock_reduce<kSE3>(acc, s_red);
+      if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + 32 + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- barrier B: records published ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase(4);
+    pk_barrier(L.sync + 2 * it + 1, 0ull, &st->sync_timeout);
+    phase(5);
+
+    // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
+    {
+      const int k4 = tid & 15, g = tid >> 4;  // 32 groups of records x 16 float4 per record
+      double f[4] = {0., 0., 0., 0.};
+      constexpr int U = kMaxPersistBlocks / 32;
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b = g + 32 * u;
+        const int bc = b < nb ? b : 0;
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((par * nb + bc) * kRecFloats + k4 * 4) * 4, 0, /*sc1*/ 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (g + 32 * u < nb) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) f[cc] += (double)__uint_as_float(v[u][cc]);
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) s_grp[g][k4][cc] = f[cc];
+      __syncthreads();
+      {  // thread = value * 8 + sub: 4 groups each, then the 8-lane butterfly (fixed order)
+        const int j = tid >> 3, sub = tid & 7;
+        double t = s_grp[sub * 4][j >> 2][j & 3];
+        t += s_grp[sub * 4 + 1][j >> 2][j & 3];
+        t += s_grp[sub * 4 + 2][j >> 2][j & 3];
+        t += s_grp[sub * 4 + 3][j >> 2][j & 3];
+        t = row8_sum_d(t);
+        if (sub == 0) s_sums[j] = (float)t;
+      }
+      __syncthreads();
+    }
+    phase(6);
+    if (tid == 0) {
+      SolveArgs q;
+      q.icp = ICP ? 1 : 0;
+      q.rgb = RGB ? 1 : 0;
+      q.rgbOnly = L.rgbOnly;
+      q.icpWeight = L.icpWeight;
+      q.level = L.level;
+      q.first_iter = it == 0;
+      q.next_level = (it == L.n_iter - 1) ? L.level_below : L.level;
+      q.level_below = L.level_below;
+      q.fx = L.fx;
+      q.fy = L.fy;
+      q.cx = L.cx;
+      q.cy = L.cy;
+      gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q);
+    }
+    __syncthreads();
+    phase(7);
+  }
+
+  // ---- block 0 hands the state to the next kernel on the stream ----
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {
+    if (ended) st->level_done[L.level] = 1;
+    for (int i = 0; i < 16; ++i) st->resultRt[i] = s.resultRt[i];
+    for (int i = 0; i < 9; ++i) {
+      st->Rcurr[i] = s.Rcurr[i];
+      st->krkinv[i] = s.krkinv[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+      st->tcurr[i] = s.tcurr[i];
+      st->kt[i] = s.kt[i];
+    }
+    st->lastRGBError = s.lastRGBError;
+    st->lastRGBCount = s.lastRGBCount;
+    st->lastICPError = s.lastICPError;
+    st->lastICPCount = s.lastICPCount;
+    st->iters_run[L.level] = s.iters_run;
+    for (int i = 0; i < 36; ++i) st->lastA[i] = s.lastA[i];
+    for (int i = 0; i < 6; ++i) st->lastb[i] = s.lastb[i];
+  }
+  phase(8);
+  if (L.prof && blockIdx.x == 0 && tid == 0) {
+    phase(9);  // = cost of one phase() call itself
+    for (int i = 0; i < 10; ++i) L.prof[L.level * 16 + i] += s_prof[i];
+  }
 }
 
 __global__ void k_track_finalize(TrackState* st, int rgb) {
@@ -837,6 +1366,9 @@ void layout(dms_odometry* o, Carver& c) {
   o->part_so3 = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
   o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
   o->tickets = (unsigned*)c.take(64);
+  o->rec = (float*)c.take((size_t)2 * kMaxPersistBlocks * kRecFloats * 4);
+  o->sync = (unsigned long long*)c.take((size_t)kSyncWords * 8);
+  o->prof = (long long*)c.take(3 * 16 * 8);
   o->state = (TrackState*)c.take(sizeof(TrackState));
 }
 
@@ -1104,6 +1636,68 @@ int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* r
 
 namespace dms {
 
+// ---- persistent level kernels: launch shape and cross-stream serialisation ----
+// DMS_TRACK_MODE=launches forces the three-launches-per-iteration path (A/B runs, fallback).
+static bool persistent_enabled() {  // read per call: tests switch modes inside one process
+  const char* e = getenv("DMS_TRACK_MODE");
+  return !(e && strcmp(e, "launches") == 0);
+}
+
+// pixels per thread (1 or 2) and grid of k_gn_level for an n-pixel level; 0 blocks = not eligible
+static void persistent_shape(int n, int& P, int& nb) {
+  // fewest pixels per thread (1, 2 or 4) that keeps the grid at <= 96 blocks if possible (cheap
+  // barriers and gathers), at <= 256 blocks otherwise
+  static const int target = getenv("DMS_PERSIST_BLOCKS") ? atoi(getenv("DMS_PERSIST_BLOCKS")) : 96;
+  P = 4;
+  for (int p : {1, 2, 4})
+    if ((n + kPB * p - 1) / (kPB * p) <= target) {
+      P = p;
+      break;
+    }
+  nb = (n + kPB * P - 1) / (kPB * P);
+  if (nb > kMaxPersistBlocks || n >= (1 << 19)) nb = 0;  // the barrier word holds a 19-bit count
+}
+
+// Blocks of a persistent kernel spin on each other, so two of them must never share the device
+// half-resident.  Every persistent section of this process is therefore chained on one event per
+// device: stream-ordered, free for a single stream, and it serialises trackers of different
+// cameras / streams against each other.
+struct PersistChain {
+  std::mutex mu;
+  hipEvent_t ev[64] = {};
+};
+static PersistChain g_persist;
+struct PersistSection {
+  hipStream_t s;
+  int dev = 0;
+  bool active = false;
+  explicit PersistSection(hipStream_t s_) : s(s_) {}
+  void begin() {
+    if (active) return;
+    g_persist.mu.lock();
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
+    (void)hipStreamWaitEvent(s, g_persist.ev[dev], 0);
+    active = true;
+  }
+  ~PersistSection() {
+    if (!active) return;
+    (void)hipEventRecord(g_persist.ev[dev], s);
+    g_persist.mu.unlock();
+  }
+};
+
+template <bool ICP, bool RGB>
+static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
+  if (P == 1)
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  else if (P == 2)
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  else
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+}
+
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
                            float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s) {
   DMS_REQUIRE(o && ((trans && rot) || prior_pose16_dev), "null argument");
@@ -1137,7 +1731,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   {
     Timer t(o, s, "track_init");
     hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
-                       first_level);
+                       first_level, o->sync, kSyncWords);
     DMS_CHECK_LAUNCH();
   }
 
@@ -1158,8 +1752,12 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     }
   }
 
+  PersistSection persist(s);
   for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
-    if (rgb) {
+    int pP = 1, pnb = 0;
+    if (persistent_enabled() && 2 * iterations[l] <= 128) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), pP, pnb);
+    const bool persistent = pnb > 0;
+    if (rgb && !persistent) {  // the persistent kernel rebuilds the cloud point from lastDepth itself
       dms_camera k = {o->fx, o->fy, o->cx, o->cy};
       dms_image2d d = o->lastDepth[l].img(), c = o->pointClouds[l].img();
       if ((rc = projectToPointCloud(&d, &c, &k, l, s))) return rc;
@@ -1212,6 +1810,31 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
         level_below = q;
         break;
       }
+    if (persistent) {
+      LevelArgs L;
+      L.n_iter = iterations[l];
+      L.level = l;
+      L.level_below = level_below;
+      L.rgbOnly = rgbOnly ? 1 : 0;
+      L.icpWeight = icpWeight;
+      L.fx = o->fx;
+      L.fy = o->fy;
+      L.cx = o->cx;
+      L.cy = o->cy;
+      L.rec = o->rec;
+      L.sync = o->sync + 64 + 128 * l;
+      L.prof = o->profiling ? o->prof : nullptr;
+      persist.begin();
+      Timer t(o, s, "gn_level");
+      if (icp && rgb)
+        launch_gn_level<true, true>(pP, pnb, s, o->state, a, L);
+      else if (icp)
+        launch_gn_level<true, false>(pP, pnb, s, o->state, a, L);
+      else
+        launch_gn_level<false, true>(pP, pnb, s, o->state, a, L);
+      DMS_CHECK_LAUNCH();
+      continue;
+    }
     for (int j = 0; j < iterations[l]; ++j) {
       const int next_level = (j == iterations[l] - 1) ? level_below : l;
       SolveArgs q;
@@ -1423,6 +2046,11 @@ int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream s
   for (int l = 0; l < DMS_NUM_PYRS; ++l) r->iterations_run[l] = h->iters_run[l];
   r->so3_iterations_run = h->so3_iters;
   r->rejected_jump = h->rejected_jump;
+  if (h->sync_timeout) {
+    set_error("dms_odometry_fetch_result: a persistent tracker kernel timed out at a grid barrier (its blocks were not all "
+              "resident; rerun with DMS_TRACK_MODE=launches)");
+    return DMS_ERR_TIMEOUT;
+  }
   return DMS_OK;
 }
 
@@ -1508,6 +2136,16 @@ int dms_odometry_set_profiling(dms_odometry* o, int enabled) {
 
 int dms_odometry_get_kernel_time(dms_odometry* o, const char* name, double* total_ms, int* launches) {
   DMS_REQUIRE(o && name && total_ms && launches, "null argument");
+  // "phase:<i>": accumulated in-kernel clock of phase i of the persistent level kernels (block 0)
+  if (strncmp(name, "phase:", 6) == 0) {
+    const int i = atoi(name + 6);  // level * 16 + phase
+    DMS_REQUIRE(i >= 0 && i < 48, "bad phase index");
+    long long v = 0;
+    DMS_HIP(hipMemcpy(&v, o->prof + i, sizeof(v), hipMemcpyDeviceToHost));
+    *total_ms = (double)v * 1e-5;  // 10 ns ticks
+    *launches = 1;
+    return DMS_OK;
+  }
   auto it = o->times.find(name);
   if (it == o->times.end()) {
     *total_ms = 0;

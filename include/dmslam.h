@@ -47,6 +47,7 @@ extern "C" {
 #define DMS_ERR_WORKSPACE (-3)
 #define DMS_ERR_CAPACITY (-4)
 #define DMS_ERR_STATE (-5)
+#define DMS_ERR_TIMEOUT (-6) /* a resident tracker kernel gave up at a grid barrier: result invalid */
 
 #define DMS_NUM_PYRS 3         /* RGBDOdometry.h: NUM_PYRS */
 #define DMS_MAX_SENSORS 8      /* reference Vertex::MAX_SENSORS = 3 (Shaders/Vertex.cpp:49); 8 = one per GPU of the node */

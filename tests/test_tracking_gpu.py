@@ -273,8 +273,20 @@ def _fresh_pair(dms, orc, gputest_pair):
     return g, o
 
 
+@pytest.fixture
+def track_mode(request, monkeypatch):
+    """'persistent' = one resident kernel per pyramid level (default); 'launches' = pass1 / pass2 /
+    solve launches per iteration (fallback path).  Read by the library at every tracking call."""
+    if request.param == "launches":
+        monkeypatch.setenv("DMS_TRACK_MODE", "launches")
+    else:
+        monkeypatch.delenv("DMS_TRACK_MODE", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
 @pytest.mark.parametrize("name", list(CONFIGS))
-def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name):
+def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode):
     cfg = CONFIGS[name]
     g, o = _fresh_pair(dms, orc, gputest_pair)
     t0, R0 = np.zeros(3, np.float32), np.eye(3, dtype=np.float32)
@@ -364,15 +376,24 @@ def test_track_recovers_known_motion_synthetic(dms, orc):
     assert err_r < 0.75 * prior_r, (err_r, prior_r)
 
 
-def test_track_profiling_counters(dms, orc, gputest_pair):
+@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
+def test_track_profiling_counters(dms, orc, gputest_pair, track_mode):
     g, _ = _fresh_pair(dms, orc, gputest_pair)
     g.set_profiling(True)
-    g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **CONFIGS["C3_full"])
-    ms1, n1 = g.kernel_time("gn_pass1")
-    ms2, n2 = g.kernel_time("gn_pass2")
-    ms3, n3 = g.kernel_time("gn_solve")
-    assert n1 == 19 and n2 == 19 and n3 == 19
-    assert ms1 > 0 and ms2 > 0 and ms3 > 0
+    _, _, r = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **CONFIGS["C3_full"])
+    assert list(r.iterations_run) == [10, 5, 4]
+    if track_mode == "persistent":
+        ms, n = g.kernel_time("gn_level")
+        assert n == 3 and ms > 0  # one resident kernel per pyramid level
+        assert g.kernel_time("gn_pass1")[1] == 0
+        # in-kernel phase clocks of block 0 (pass 1, ..., solve) are exposed as "phase:<i>"
+        assert g.kernel_time("phase:1")[0] > 0 and g.kernel_time("phase:39")[0] > 0  # level * 16 + phase
+    else:
+        ms1, n1 = g.kernel_time("gn_pass1")
+        ms2, n2 = g.kernel_time("gn_pass2")
+        ms3, n3 = g.kernel_time("gn_solve")
+        assert n1 == 19 and n2 == 19 and n3 == 19
+        assert ms1 > 0 and ms2 > 0 and ms3 > 0
     assert g.kernel_time("so3_pass")[1] == 10
 
 
