@@ -214,7 +214,7 @@ def main():
             if cnt:
                 stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
         kern = {}
-        for n in ("gn_level", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
+        for n in ("so3_level", "gn_level", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
             ms, cnt = C.c_double(0), C.c_int(0)
             capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
             if cnt.value:

@@ -303,12 +303,20 @@ __device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
 }
 
 // run by the 256 threads of the last block of k_so3_pass
+// one lane: the SO3 update from the folded sums (RGBDOdometry.cpp:334-385).  `st` may point to
+// the state block in HBM (launch path) or to a copy in LDS (persistent path).
+__device__ void so3_solve_core(TrackState* st, const float* sums, float fx, float fy, float cx, float cy, int is_last, int first_gn_level);
+
 __device__ void so3_solve_body(TrackState* st, const float* partials, int nblocks, float fx, float fy, float cx, float cy, int is_last,
                                int first_gn_level) {
   __shared__ float sums[kSO3];
   fold_records256(partials, nblocks, kSO3, sums);
   __syncthreads();
   if (threadIdx.x != 0) return;
+  so3_solve_core(st, sums, fx, fy, cx, cy, is_last, first_gn_level);
+}
+
+__device__ void so3_solve_core(TrackState* st, const float* sums, float fx, float fy, float cx, float cy, int is_last, int first_gn_level) {
   float jtj[9], jtr[3];
   int shift = 0;
   for (int i = 0; i < 3; ++i)
@@ -339,9 +347,7 @@ __device__ void so3_solve_body(TrackState* st, const float* partials, int nblock
     st->so3_lastCount = cnt;
     for (int i = 0; i < 9; ++i) st->lastResultR[i] = st->resultR[i];
     float delta[3];
-    __shared__ float l_A[9], l_t[3], l_y[3];
-    __shared__ int l_p[3];
-    sm::ldlt_solve_ws<float, 3>(jtj, jtr, delta, 1.0f / 3.402823466e+38F, l_A, l_t, l_y, l_p);
+    sm::ldlt_solve_reg<float, 3>(jtj, jtr, delta, 1.0f / 3.402823466e+38F);
     const double dd[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
     double rotUpdate[9];
     sm::rodrigues(dd, rotUpdate);
@@ -998,6 +1004,45 @@ __device__ __forceinline__ bool pblock_owner() {
   return threadIdx.x < NV * kPWaves && (threadIdx.x & (kPWaves - 1)) == 0;
 }
 
+// Every block reads ALL records of parity `par` with write-through-coherent (sc1) 16-byte loads and
+// folds them in fp64 in a fixed order: thread (g = tid / 16, k4 = tid % 16) sums float4 column k4
+// of records g, g + 32, ...; then thread (value * 8 + sub) adds 4 of the 32 group sums and an 8-lane
+// butterfly finishes.  s_sums[0..63] holds the totals afterwards (identical bits in every block).
+template <typename Rsrc>
+__device__ __forceinline__ void pk_gather(Rsrc rsrc, int par, int nb, double (*s_grp)[16][4], float* s_sums) {
+  const int tid = threadIdx.x;
+  const int k4 = tid & 15, g = tid >> 4;
+  double f[4] = {0., 0., 0., 0.};
+  constexpr int U = kMaxPersistBlocks / 32;
+  u32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int b = g + 32 * u;
+    const int bc = b < nb ? b : 0;
+    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((par * nb + bc) * kRecFloats + k4 * 4) * 4, 0, /*sc1*/ 16);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (g + 32 * u < nb) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) f[cc] += (double)__uint_as_float(v[u][cc]);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) s_grp[g][k4][cc] = f[cc];
+  __syncthreads();
+  {
+    const int j = tid >> 3, sub = tid & 7;
+    double t = s_grp[sub * 4][j >> 2][j & 3];
+    t += s_grp[sub * 4 + 1][j >> 2][j & 3];
+    t += s_grp[sub * 4 + 2][j >> 2][j & 3];
+    t += s_grp[sub * 4 + 3][j >> 2][j & 3];
+    t = row8_sum_d(t);
+    if (sub == 0) s_sums[j] = (float)t;
+  }
+  __syncthreads();
+}
+
 template <bool ICP, bool RGB, int P>
 __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
   __shared__ GnLocal s;
@@ -1219,38 +1264,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     phase(5);
 
     // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
-    {
-      const int k4 = tid & 15, g = tid >> 4;  // 32 groups of records x 16 float4 per record
-      double f[4] = {0., 0., 0., 0.};
-      constexpr int U = kMaxPersistBlocks / 32;
-      u32x4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int b = g + 32 * u;
-        const int bc = b < nb ? b : 0;
-        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((par * nb + bc) * kRecFloats + k4 * 4) * 4, 0, /*sc1*/ 16);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (g + 32 * u < nb) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) f[cc] += (double)__uint_as_float(v[u][cc]);
-        }
-      }
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) s_grp[g][k4][cc] = f[cc];
-      __syncthreads();
-      {  // thread = value * 8 + sub: 4 groups each, then the 8-lane butterfly (fixed order)
-        const int j = tid >> 3, sub = tid & 7;
-        double t = s_grp[sub * 4][j >> 2][j & 3];
-        t += s_grp[sub * 4 + 1][j >> 2][j & 3];
-        t += s_grp[sub * 4 + 2][j >> 2][j & 3];
-        t += s_grp[sub * 4 + 3][j >> 2][j & 3];
-        t = row8_sum_d(t);
-        if (sub == 0) s_sums[j] = (float)t;
-      }
-      __syncthreads();
-    }
+    pk_gather(rsrc, par, nb, s_grp, s_sums);
     phase(6);
     if (tid == 0) {
       SolveArgs q;
@@ -1297,6 +1311,79 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   if (L.prof && blockIdx.x == 0 && tid == 0) {
     phase(9);  // = cost of one phase() call itself
     for (int i = 0; i < 10; ++i) L.prof[L.level * 16 + i] += s_prof[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent SO3 pre-alignment: all (<= 10) iterations in one launch, same protocol as k_gn_level
+// with one barrier per iteration (records double-buffered).  The state block is copied into LDS
+// and the unchanged scalar code runs on the copy; block 0 writes it back at the end.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
+                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows, float* rec,
+                                                   unsigned long long* sync, SolveCam cam, int first_gn_level, int max_iter) {
+  __shared__ TrackState s;
+  __shared__ float s_red[kPWaves][32];
+  __shared__ double s_grp[32][16][4];
+  __shared__ float s_sums[kRecFloats];
+  const int tid = threadIdx.x;
+  const int nb = gridDim.x;
+  {
+    const int* src = reinterpret_cast<const int*>(st);
+    int* dst = reinterpret_cast<int*>(&s);
+    for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += kPB) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (s.so3_done) return;
+  const int N = cols * rows;
+  const int i = blockIdx.x * kPB + tid;
+  const bool live = i < N;
+  const int ic = live ? i : 0;
+  const int y = ic / cols, x = ic - y * cols;
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, 2 * nb * kRecFloats * 4, 0x00020000);
+  for (int it = 0; it < max_iter; ++it) {
+    const int par = it & 1;
+    So3Params p;
+    p.imageBasis.r0 = mk3(s.imageBasis[0], s.imageBasis[1], s.imageBasis[2]);
+    p.imageBasis.r1 = mk3(s.imageBasis[3], s.imageBasis[4], s.imageBasis[5]);
+    p.imageBasis.r2 = mk3(s.imageBasis[6], s.imageBasis[7], s.imageBasis[8]);
+    p.kinv.r0 = mk3(s.kinv[0], s.kinv[1], s.kinv[2]);
+    p.kinv.r1 = mk3(s.kinv[3], s.kinv[4], s.kinv[5]);
+    p.kinv.r2 = mk3(s.kinv[6], s.kinv[7], s.kinv[8]);
+    p.krlr.r0 = mk3(s.krlr[0], s.krlr[1], s.krlr[2]);
+    p.krlr.r1 = mk3(s.krlr[3], s.krlr[4], s.krlr[5]);
+    p.krlr.r2 = mk3(s.krlr[6], s.krlr[7], s.krlr[8]);
+    p.cols = cols;
+    p.rows = rows;
+    float acc[kSO3];
+#pragma unroll
+    for (int k = 0; k < kSO3; ++k) acc[k] = 0.f;
+    {
+      float row[4];
+      bool found = so3_row(p, lastImage, last_pitch, nextImage, next_pitch, x, y, row);
+      if (!live) {
+        found = false;
+        row[0] = row[1] = row[2] = row[3] = 0.f;
+      }
+      accumulate_so3(acc, row, found);
+    }
+    const float tot = pblock_reduce<kSO3>(acc, s_red);
+    float* my_rec = rec + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+    if (pblock_owner<kSO3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pk_barrier(sync + it, 0ull, &st->sync_timeout);
+    pk_gather(rsrc, par, nb, s_grp, s_sums);
+    if (tid == 0) so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
+    __syncthreads();
+    if (s.so3_done) break;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (tid == 0) s.sync_timeout = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int* src = reinterpret_cast<const int*>(&s);
+    int* dst = reinterpret_cast<int*>(st);
+    for (int k = tid; k < (int)(sizeof(TrackState) / 4); k += kPB) dst[k] = src[k];
   }
 }
 
@@ -1735,11 +1822,21 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     DMS_CHECK_LAUNCH();
   }
 
+  PersistSection persist(s);
   if (so3) {
     const int L = 2;
     const Buf& li = o->lastNextImage[L];
     const Buf& ni = o->nextImage[L];
     const int nb = reduce_blocks_for(li.rows * li.cols);
+    const int nbp = (li.rows * li.cols + kPB - 1) / kPB;
+    if (persistent_enabled() && nbp <= kMaxPersistBlocks) {
+      persist.begin();
+      Timer t(o, s, "so3_level");
+      SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
+      hipLaunchKernelGGL(k_so3_level, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->rec, o->sync, cam, first_level, 10);
+      DMS_CHECK_LAUNCH();
+    } else
     for (int i = 0; i < 10; ++i) {
       {
         Timer t(o, s, "so3_pass");
@@ -1752,7 +1849,6 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     }
   }
 
-  PersistSection persist(s);
   for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
     int pP = 1, pnb = 0;
     if (persistent_enabled() && 2 * iterations[l] <= 128) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), pP, pnb);

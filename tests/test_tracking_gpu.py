@@ -394,7 +394,10 @@ def test_track_profiling_counters(dms, orc, gputest_pair, track_mode):
         ms3, n3 = g.kernel_time("gn_solve")
         assert n1 == 19 and n2 == 19 and n3 == 19
         assert ms1 > 0 and ms2 > 0 and ms3 > 0
-    assert g.kernel_time("so3_pass")[1] == 10
+    if track_mode == "persistent":
+        assert g.kernel_time("so3_level")[1] == 1 and g.kernel_time("so3_pass")[1] == 0
+    else:
+        assert g.kernel_time("so3_pass")[1] == 10
 
 
 def test_error_paths(dms):
