@@ -191,7 +191,8 @@ struct dms_fusion {
   void* untr = nullptr;  // W*H*16 scratch for row-major copies handed out by dms_fusion_get_image
   unsigned long long* zbuf = nullptr;
   FrameState* state = nullptr;
-  FrameState* h_state = nullptr;  // pinned
+  FrameState* h_state = nullptr;  // pinned, two slots by frame parity (the host may read a slot once that frame's event has completed)
+  int last_slot = 0;
   void* h_track = nullptr;
   int tick = 1;
   bool map_initialised = false;
@@ -438,7 +439,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, sizeof(FrameState), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 2 * sizeof(FrameState), hipHostMallocDefault);
   if (e != hipSuccess) {
     if (f->arena) (void)hipFree(f->arena);
     dms_odometry_destroy(f->odom);
@@ -453,7 +454,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
   hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, 0, f->state, I);
   (void)hipDeviceSynchronize();
-  memset(f->h_state, 0, sizeof(FrameState));
+  memset(f->h_state, 0, 2 * sizeof(FrameState));
   *out = f;
   return DMS_OK;
 }
@@ -502,6 +503,15 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     // was measured to cost ~10% throughput.
     DMS_HIP(hipEventSynchronize(f->ev_main_done[k2]));
     DMS_HIP(hipStreamWaitEvent(sp, f->ev_main_done[k2], 0));  // frame-2 (never recorded: no-op)
+    // frame-2 is complete, so its result block (pinned slot k2) is readable: tighten the host-side
+    // bound of the surfel count (launch grids are sized from it).  One clean has run since then
+    // (frame-1) and adds at most `slots` surfels.
+    if (f->model->count_hold > 0) {
+      f->model->count_hold -= 1;
+    } else if (f->frames >= 2 && f->map_initialised) {
+      const size_t known = (size_t)f->h_state[k2].surfels + (size_t)f->model->slots;
+      if (known < f->model->count_upper) f->model->count_upper = known;
+    }
   }
   f->rgba = f->live[k2].rgba;
   f->depth_raw = f->live[k2].depth_raw;
@@ -629,7 +639,8 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
   if ((rc = predict(f, f->p.confidence, s))) return rc;  // finalPredict (ElasticFusion.cpp:586)
   hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, s, f->state, f->model->d_count);
   DMS_CHECK_LAUNCH();
-  DMS_HIP(hipMemcpyAsync(f->h_state, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+  f->last_slot = k2;
   if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
   f->fused_last = fused;
   f->tick += 1;  // if(!lost) tick++ (ElasticFusion.cpp:588-591)
@@ -649,13 +660,14 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
     DMS_HIP(hipStreamSynchronize(s));
   }
   drain(f);
-  memcpy(r->pose, f->h_state->cur.pose, sizeof(r->pose));
-  r->surfels = f->h_state->surfels;
+  const FrameState* hs = f->h_state + f->last_slot;
+  memcpy(r->pose, hs->cur.pose, sizeof(r->pose));
+  r->surfels = hs->surfels;
   f->model->count_upper = r->surfels;
   r->tick = f->tick;
   r->fused = f->fused_last;
-  r->fill_in = f->h_state->fill_in;
-  r->weighting = f->h_state->weighting;
+  r->fill_in = hs->fill_in;
+  r->weighting = hs->weighting;
   return DMS_OK;
 }
 

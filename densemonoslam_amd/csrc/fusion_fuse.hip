@@ -123,15 +123,40 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
       // `counter` only matters as > 0, so each distinct texel is visited once, in tap order
       const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
       const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
-      for_taps(tx_, [&](int ux, int) {
-        for_taps(ty_, [&](int uy, int) {
-          const size_t q = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
-          const unsigned current = a.index[q];
-          if (current > 0u) {
-            const float4 vc = a.vertConf[q];
+      // batched fetch of the (at most 4 x 4) distinct texels, evaluated in the original tap order:
+      // 16 ids in one round trip, then vertex + normal of 8 texels at a time
+      const int txs[4] = {tx_.t0, tx_.t1, tx_.t2, tx_.t3}, mxs[4] = {tx_.m0, tx_.m1, tx_.m2, tx_.m3};
+      const int tys[4] = {ty_.t0, ty_.t1, ty_.t2, ty_.t3}, mys[4] = {ty_.m0, ty_.m1, ty_.m2, ty_.m3};
+      size_t q[16];
+      bool used[16];
+      unsigned cur[16];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const bool u = mxs[ii] != 0 && mys[jj] != 0;
+          const int ux = u ? txs[ii] : 0, uy = u ? tys[jj] : 0;
+          used[ii * 4 + jj] = u;
+          q[ii * 4 + jj] = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
+        }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) cur[k] = a.index[q[k]];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 vcs[8], nrs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          vcs[k] = a.vertConf[q[h * 8 + k]];
+          nrs[k] = a.normRad[q[h * 8 + k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned current = cur[h * 8 + k];
+          if (used[h * 8 + k] && current > 0u) {
+            const float4 vc = vcs[k];
             if (fabsf((vc.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
               const float dist = length3(cross3(ray, mk3(vc.x, vc.y, vc.z))) / ray_len;
-              const float4 nr = a.normRad[q];
+              const float4 nr = nrs[k];
               if (dist < bestDist && (fabsf(nr.z) < 0.75f || fabsf(angle_between(mk3(nr.x, nr.y, nr.z), vNormLocal)) < 0.5f)) {
                 counter++;
                 bestDist = dist;
@@ -139,8 +164,8 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
               }
             }
           }
-        });
-      });
+        }
+      }
       flag = counter > 0 ? 1 : 2;
       slot_pos[slot] = make_float4(vPos.x, vPos.y, vPos.z, conf);
       slot_col[slot] = make_float4(encode_color_bytes(c.x, c.y, c.z), 0.f, a.timef, flag == 1 ? -1.f : -2.f);
@@ -268,23 +293,51 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
     const float y_lo = yc - ((scale * indexYStep) * windowMultiplier), y_hi = yc + ((scale * indexYStep) * windowMultiplier);
     const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
     const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
-    for_taps(tx_, [&](int ux, int mx) {
-      for_taps(ty_, [&](int uy, int my) {
-        const size_t q = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
-        const unsigned current = a.index[q];
-        if (current > 0u) {
-          const float4 vc = a.vertConf[q];
-          const float4 ct = a.colorTime[q];
+    // The (at most 4 x 4) distinct texels are fetched in three batches of independent loads —
+    // 16 ids, then vertex/confidence + colour/time of 8 texels at a time — instead of one dependent
+    // id -> attributes chain per texel (two memory round trips per tap, up to 32 in a row).
+    // Unused slots carry multiplicity 0 and read texel 0.
+    const int txs[4] = {tx_.t0, tx_.t1, tx_.t2, tx_.t3}, mxs[4] = {tx_.m0, tx_.m1, tx_.m2, tx_.m3};
+    const int tys[4] = {ty_.t0, ty_.t1, ty_.t2, ty_.t3}, mys[4] = {ty_.m0, ty_.m1, ty_.m2, ty_.m3};
+    size_t q[16];
+    int mult[16];
+    unsigned cur[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mxs[i] * mys[j];
+        const int ux = m ? txs[i] : 0, uy = m ? tys[j] : 0;
+        mult[i * 4 + j] = m;
+        q[i * 4 + j] = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
+      }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cur[k] = a.index[q[k]];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 vcs[8];
+      float2 cts[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        vcs[k] = a.vertConf[q[h * 8 + k]];
+        cts[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.colorTime[q[h * 8 + k]]) + 2);  // .z .w
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int m = mult[h * 8 + k];
+        if (m != 0 && cur[h * 8 + k] > 0u) {
+          const float4 vc = vcs[k];
+          const float ctz = cts[k].x, ctw = cts[k].y;
           const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
-          if (ct.z < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
+          if (ctz < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
               sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f)
-            count += mx * my;  // every repeated tap of this texel counts
-          if (ct.w == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
+            count += m;  // every repeated tap of this texel counts
+          if (ctw == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
               fabsf(localNorm.z) > 0.85f)
-            zCount += mx * my;
+            zCount += m;
         }
-      });
-    });
+      }
+    }
   }
   if (count > 8 || zCount > 4) test = 0;
   // new unstable point: times become `time` before the health test (copy_unstable.vert:124-129)

@@ -194,6 +194,7 @@ static int model_upload_any(dms_model* m, const float* host, unsigned n, int nse
   DMS_HIP(hipMemcpyAsync(m->d_count, &cnt, sizeof(unsigned), hipMemcpyHostToDevice, s));
   DMS_HIP(hipStreamSynchronize(s));
   m->count_upper = n;
+  m->count_hold = 3;  // the map was replaced from outside: older frame results no longer bound it
   return DMS_OK;
 }
 
@@ -346,6 +347,7 @@ int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* d
   hipLaunchKernelGGL(k_boot_scatter, dim3(nb), dim3(256), 0, s, a, m->keep, m->block_offset, m->buf[m->cur], m->cap);
   DMS_CHECK_LAUNCH();
   m->count_upper = (size_t)n < m->cap ? (size_t)n : m->cap;
+  m->count_hold = 3;
   return DMS_OK;
 }
 

@@ -3,7 +3,7 @@
 // Surfel ids are buffer positions and association keys, so every pass that removes or appends
 // surfels must keep their relative order (the reference gets this from OpenGL transform
 // feedback).  Three stream-ordered launches:
-//   flags  : each 256-thread block owns kScanChunk = 1024 consecutive elements, writes one
+//   flags  : each 256-thread block owns kScanChunk = 256 consecutive elements, writes one
 //            keep-byte per element and the block's kept count;
 //   scan   : one 1024-thread block turns the per-block counts into exclusive offsets and
 //            publishes the total;

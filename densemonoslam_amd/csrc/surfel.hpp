@@ -22,7 +22,7 @@ struct SurfelPlanes {
 
 constexpr unsigned kEmptyWinner = 0xFFFFFFFFu;
 constexpr unsigned long long kZClear = (0xFFFFFFull << 32) | 0xFFFFFFFFull;  // depth 1.0 (24-bit), no surfel
-constexpr int kScanChunk = 1024;  // elements per scan block
+constexpr int kScanChunk = 256;   // elements per scan block: one per thread, so no thread walks a serial chain of elements
 
 // --- GL-rule helpers (DESIGN.md "Rasteriser rules") ---------------------------------------
 // NEAREST texel of a normalised coordinate: floor(u * n) evaluated in fp32, CLAMP_TO_EDGE.
@@ -141,6 +141,7 @@ struct dms_model {
   unsigned* d_count = nullptr;      // [0] model count, [1] new-unstable count, [2] scratch
   unsigned* h_count = nullptr;      // pinned mirror
   size_t count_upper = 0;           // host-side upper bound of the model count
+  int count_hold = 0;               // frames for which the frame pipeline must not tighten count_upper from its (older) result blocks
   // fuse scratch (per candidate slot)
   float4 *slot_pos = nullptr, *slot_col = nullptr, *slot_nrm = nullptr;
   unsigned* slot_best = nullptr;
