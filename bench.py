@@ -33,6 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 def algorithmic_bytes(kernel, W, H, M, level_px):
     """Algorithmic HBM bytes of ONE launch of `kernel` (SURVEY.md §8(d) contract)."""
     N0 = W * H
+    if kernel == "gn_level":  # one GN iteration over a level: 62 + 14 B/px (SURVEY §8(d): 76 * sum_l it_l * N_l)
+        return 76.0 * level_px
     if kernel == "gn_pass1":  # ICP 48 B/px (4 SoA maps) + photometric count pass 14 B/px
         return 62.0 * level_px
     if kernel == "gn_pass2":  # photometric Jacobian pass 14 B/px
@@ -214,7 +216,7 @@ def main():
             if cnt:
                 stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
         kern = {}
-        for n in ("so3_level", "gn_level", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
+        for n in ("so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
             ms, cnt = C.c_double(0), C.c_int(0)
             capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
             if cnt.value:
@@ -232,10 +234,36 @@ def main():
             out["gn_level_phase_us_per_frame"] = phases  # in-kernel clock of block 0, summed over the level's iterations
         out["stage_ms_per_frame"] = {k: round(v["ms_per_frame"], 4) for k, v in stages.items()}
         out["tracker_kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern.items()}
-        # dominant kernel: the Gauss-Newton pass-1 (ICP + photometric correspondence) over the pyramid
-        if "gn_pass1" in kern:
-            px = [W * H, (W // 2) * (H // 2), (W // 4) * (H // 4)]
-            its = [10, 5, 4]
+        # dominant kernel: the resident Gauss-Newton kernel of pyramid level 0 (10 iterations in one
+        # launch); in DMS_TRACK_MODE=launches the per-iteration pass-1 kernel instead
+        px = [W * H, (W // 2) * (H // 2), (W // 4) * (H // 4)]
+        its = [10, 5, 4]
+        traffic = None
+        try:  # HBM bytes per launch from the PMC passes of the same command (profiles/)
+            with open(os.path.join(ROOT, "profiles", "pmc_gn_level0.json")) as fh:
+                pm = json.load(fh)
+            if pm.get("resolution") == [W, H]:
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        if "gn_level0" in kern:
+            bytes_per_launch = algorithmic_bytes("gn_level", W, H, M, px[0]) * its[0]
+            avg_s = kern["gn_level0"]["avg_us"] * 1e-6
+            achieved = bytes_per_launch / avg_s / 1e9
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_gn_level<ICP,RGB,4> (pyramid level 0: all 10 Gauss-Newton iterations in one resident launch)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_us": kern["gn_level0"]["avg_us"],
+                "note": "algorithmic bytes = 76 B/px/iteration (SURVEY 8d) x %d px x %d iterations; the launch is bound by its 20 grid-wide "
+                        "reductions (2 per iteration), not by HBM (DESIGN.md 6)" % (px[0], its[0]),
+            }
+        elif "gn_pass1" in kern:
             bytes_per_frame = sum(algorithmic_bytes("gn_pass1", W, H, M, p) * n for p, n in zip(px, its))
             launches = sum(its)
             avg_s = kern["gn_pass1"]["avg_us"] * 1e-6

@@ -1921,7 +1921,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.sync = o->sync + 64 + 128 * l;
       L.prof = o->profiling ? o->prof : nullptr;
       persist.begin();
-      Timer t(o, s, "gn_level");
+      static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
+      Timer t(o, s, kLevelTimer[l]);
       if (icp && rgb)
         launch_gn_level<true, true>(pP, pnb, s, o->state, a, L);
       else if (icp)
