@@ -223,6 +223,7 @@ lib.dms_odometry_initICPModel.argtypes = [_P, _P, _P, _F, _FP, _P]
 lib.dms_odometry_initRGB.argtypes = [_P, _I2, _P]
 lib.dms_odometry_initRGBModel.argtypes = [_P, _I2, _P]
 lib.dms_odometry_initFirstRGB.argtypes = [_P, _I2, _P]
+lib.dms_odometry_initModelFused.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]
 lib.dms_odometry_getIncrementalTransformation.argtypes = [_P, _FP, _FP, _I, _F, _I, _I, _I, _I, C.POINTER(TrackResult), _P]
 lib.dms_odometry_track_async.argtypes = [_P, _FP, _FP, _I, _F, _I, _I, _I, _I, _P]
 lib.dms_odometry_fetch_result.argtypes = [_P, C.POINTER(TrackResult), _P]

@@ -49,6 +49,8 @@ int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA,
                               const float* pose16_dev, hipStream_t s);
 int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rgbaB, const int* flag_dev, int force_b, void* rgba_tmp,
                               hipStream_t s);
+int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
+                             const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
 void odometry_bind_live(dms_odometry* o, int k);
 void odometry_bind_lastnext(dms_odometry* o, int k);
@@ -582,12 +584,9 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
       {
         FTimer t(f, s, "odom_init");
         // WARNING (reference): initICP* must be called before initRGB* (ElasticFusion.cpp:172)
-        if ((rc = odometry_initICPModel_sel(f->odom, (const float*)f->pred.vertex.data, (const float*)f->pred.normal.data,
-                                            (const float*)f->fill.vertex.data, (const float*)f->fill.normal.data, &f->state->fill_in,
-                                            f->state->cur.pose, s)))
-          return rc;
-        if ((rc = odometry_initRGBModel_sel(f->odom, f->pred.image.data, f->fill.image.data, &f->state->fill_in,
-                                            f->p.frameToFrameRGB ? 1 : 0, f->rgba_tmp, s)))
+        if ((rc = odometry_initModel_fused(f->odom, f->pred.vertex.data, f->pred.normal.data, f->pred.image.data, f->fill.vertex.data,
+                                           f->fill.normal.data, f->fill.image.data, &f->state->fill_in, f->p.frameToFrameRGB ? 1 : 0,
+                                           f->state->cur.pose, s)))
           return rc;
         // initICP / initRGB: the live half ran on the prep stream; nextDepth = lastDepth (same source)
         odometry_alias_next_depth(f->odom);

@@ -282,6 +282,159 @@ __global__ void k_pyrDownUchar(View<const unsigned char> src, View<unsigned char
   dst.at(y, x) = (unsigned char)f2i_rz(sum / (float)count);
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused model-side pyramid of the frame step (initICPModel + initRGBModel of ElasticFusion.cpp:172-189
+// = select x3, copyMaps, resizeMap x4, transformMaps x3, verticesToDepth, pyrDownGaussF x2,
+// bgr2Intensity, pyrDownUchar x2: 17 launches of the operator layer) in four launches.  Every value
+// is computed by the same expressions as the stand-alone kernels above, and — like them — a pixel
+// whose x plane is NaN gets only that NaN written (its y / z planes are never read downstream).
+// ---------------------------------------------------------------------------------------
+struct ModelSrc {
+  const float4* vA;  // predicted vertex / normal / image
+  const float4* nA;
+  const uchar4* iA;
+  const float4* vB;  // fill-in vertex / normal / image
+  const float4* nB;
+  const uchar4* iB;
+  const int* flag;   // device flag: 1 = use the fill-in maps
+  int force_b_img;   // frameToFrameRGB: always the fill-in image
+  const float* pose16;
+};
+
+struct Pose34 {
+  M33 R;
+  f3 t;
+};
+__device__ __forceinline__ Pose34 load_pose34(const float* pose16) {
+  Pose34 p;
+  p.R.r0 = mk3(pose16[0], pose16[1], pose16[2]);
+  p.R.r1 = mk3(pose16[4], pose16[5], pose16[6]);
+  p.R.r2 = mk3(pose16[8], pose16[9], pose16[10]);
+  p.t = mk3(pose16[3], pose16[7], pose16[11]);
+  return p;
+}
+// copyMaps rule: z == 0 in the VERTEX makes both the vertex and the normal NaN
+__device__ __forceinline__ void raw_maps(const float4 v, const float4 q, f3& rv, f3& rn) {
+  const bool ok = !(v.z == 0.f);
+  const float n = qnan();
+  rv = ok ? mk3(v.x, v.y, v.z) : mk3(n, n, n);
+  rn = ok ? mk3(q.x, q.y, q.z) : mk3(n, n, n);
+}
+// transformMaps rule + store into stacked planes
+__device__ __forceinline__ void store_transformed(View<float> vmap, View<float> nmap, int rows, int y, int x, const f3& rv, const f3& rn,
+                                                  const Pose34& P) {
+  if (!isnan(rv.x)) {
+    const f3 d = mul(P.R, rv) + P.t;
+    vmap.at(y, x) = d.x;
+    vmap.at(y + rows, x) = d.y;
+    vmap.at(y + 2 * rows, x) = d.z;
+  } else {
+    vmap.at(y, x) = qnan();
+  }
+  if (!isnan(rn.x)) {
+    const f3 d = mul(P.R, rn);
+    nmap.at(y, x) = d.x;
+    nmap.at(y + rows, x) = d.y;
+    nmap.at(y + 2 * rows, x) = d.z;
+  } else {
+    nmap.at(y, x) = qnan();
+  }
+}
+
+// level 0: transformed maps, float depth (verticesToDepth) and intensity, one thread per pixel
+__global__ void k_model_level0(ModelSrc m, int rows, int cols, View<float> vmap, View<float> nmap, View<float> depth,
+                               View<unsigned char> inten, float cutOff) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const bool useB = *m.flag != 0;
+  const size_t i = (size_t)y * cols + x;
+  const float4 v = useB ? m.vB[i] : m.vA[i];
+  const float4 q = useB ? m.nB[i] : m.nA[i];
+  const uchar4 c = (useB || m.force_b_img) ? m.iB[i] : m.iA[i];
+  const Pose34 P = load_pose34(m.pose16);
+  f3 rv, rn;
+  raw_maps(v, q, rv, rn);
+  store_transformed(vmap, nmap, rows, y, x, rv, rn, P);
+  depth.at(y, x) = (v.z > cutOff || v.z <= 0.f) ? qnan() : v.z;
+  const float f = ((float)c.x * 0.114f + (float)c.y * 0.299f) + (float)c.z * 0.587f;
+  inten.at(y, x) = (unsigned char)f2i_rz(f);
+}
+
+// resizeMap rule on four raw values
+template <bool NORMALIZE>
+__device__ __forceinline__ f3 resize4(const f3& a, const f3& b, const f3& c, const f3& d) {
+  if (isnan(a.x) || isnan(b.x) || isnan(c.x) || isnan(d.x)) return mk3(qnan(), qnan(), qnan());
+  f3 n;
+  n.x = (a.x + b.x + c.x + d.x) / 4;
+  n.y = (a.y + b.y + c.y + d.y) / 4;
+  n.z = (a.z + b.z + c.z + d.z) / 4;
+  if (NORMALIZE) n = normalized3(n);
+  return n;
+}
+
+// levels 1 and 2: one thread per level-2 pixel = 2x2 level-1 pixels = 4x4 level-0 pixels
+__global__ void k_model_levels12(ModelSrc m, int cols0, int rows1, int cols1, int rows2, int cols2, View<float> v1, View<float> n1,
+                                 View<float> v2, View<float> n2) {
+  const int x2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y2 = blockIdx.y * blockDim.y + threadIdx.y;
+  if (2 * x2 >= cols1 || 2 * y2 >= rows1) return;
+  const bool useB = *m.flag != 0;
+  const float4* vs = useB ? m.vB : m.vA;
+  const float4* ns = useB ? m.nB : m.nA;
+  const Pose34 P = load_pose34(m.pose16);
+  f3 lv[4], ln[4];
+  bool have[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x1 = 2 * x2 + (k & 1), y1 = 2 * y2 + (k >> 1);
+    have[k] = x1 < cols1 && y1 < rows1;
+    if (!have[k]) continue;
+    f3 rv[4], rn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t i = (size_t)(2 * y1 + (j >> 1)) * cols0 + (2 * x1 + (j & 1));
+      raw_maps(vs[i], ns[i], rv[j], rn[j]);
+    }
+    lv[k] = resize4<false>(rv[0], rv[1], rv[2], rv[3]);
+    ln[k] = resize4<true>(rn[0], rn[1], rn[2], rn[3]);
+    store_transformed(v1, n1, rows1, y1, x1, lv[k], ln[k], P);
+  }
+  if (x2 < cols2 && y2 < rows2) {  // then all four level-1 pixels exist
+    const f3 a = resize4<false>(lv[0], lv[1], lv[2], lv[3]);
+    const f3 b = resize4<true>(ln[0], ln[1], ln[2], ln[3]);
+    store_transformed(v2, n2, rows2, y2, x2, a, b, P);
+  }
+}
+
+// one pyramid step of both model images: float depth (pyrDownGaussF) and intensity (pyrDownUchar)
+__global__ void k_model_pyr_step(View<const float> dsrc, View<float> ddst, View<const unsigned char> isrc, View<unsigned char> idst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= ddst.cols || y >= ddst.rows) return;
+  const int D = 5;
+  const int tx = min(2 * x - D / 2 + D, dsrc.cols - 1);
+  const int ty = min(2 * y - D / 2 + D, dsrc.rows - 1);
+  float sum = 0.f, isum = 0.f;
+  int count = 0, icount = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+      const float g = gauss25(ty - cy - 1, tx - cx - 1);
+      const float s = dsrc.at(cy, cx);
+      if (!isnan(s)) {
+        sum += s * g;
+        count += (int)g;
+      }
+      const unsigned char c = isrc.at(cy, cx);
+      if (c > 0) {
+        isum += (float)c * g;
+        icount += (int)g;
+      }
+    }
+  ddst.at(y, x) = sum / (float)count;
+  idst.at(y, x) = (unsigned char)f2i_rz(isum / (float)icount);
+}
+
 // reference verticesToDepthKernel / verticesToDepth2DKernel (cudafuncs.cu:597-630)
 __global__ void k_verticesToDepth(const float4* __restrict__ vsrc, View<float> dst, float cutOff) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -460,6 +613,33 @@ int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
   DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
   DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
   LAUNCH2D(k_pyrDownUchar, dst->cols, dst->rows, s, view<const unsigned char>(src), view<unsigned char>(dst));
+  return DMS_OK;
+}
+
+int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void* vB, const void* nB, const void* iB, const int* flag_dev,
+                      int force_b_img, const float* pose16_dev, dms_image2d* vmaps, dms_image2d* nmaps, dms_image2d* depths,
+                      dms_image2d* images, float cutOff, hipStream_t s) {
+  DMS_REQUIRE(vA && nA && iA && vB && nB && iB && flag_dev && pose16_dev && vmaps && nmaps && depths && images, "null argument");
+  ModelSrc m;
+  m.vA = (const float4*)vA;
+  m.nA = (const float4*)nA;
+  m.iA = (const uchar4*)iA;
+  m.vB = (const float4*)vB;
+  m.nB = (const float4*)nB;
+  m.iB = (const uchar4*)iB;
+  m.flag = flag_dev;
+  m.force_b_img = force_b_img;
+  m.pose16 = pose16_dev;
+  const int rows0 = vmaps[0].rows / 3, cols0 = vmaps[0].cols;
+  const int rows1 = vmaps[1].rows / 3, cols1 = vmaps[1].cols, rows2 = vmaps[2].rows / 3, cols2 = vmaps[2].cols;
+  DMS_REQUIRE(rows1 == rows0 / 2 && cols1 == cols0 / 2 && rows2 == rows1 / 2 && cols2 == cols1 / 2, "pyramid shapes");
+  LAUNCH2D(k_model_level0, cols0, rows0, s, m, rows0, cols0, view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]),
+           view<unsigned char>(&images[0]), cutOff);
+  LAUNCH2D(k_model_levels12, (cols1 + 1) / 2, (rows1 + 1) / 2, s, m, cols0, rows1, cols1, rows2, cols2, view<float>(&vmaps[1]),
+           view<float>(&nmaps[1]), view<float>(&vmaps[2]), view<float>(&nmaps[2]));
+  for (int l = 1; l < 3; ++l)
+    LAUNCH2D(k_model_pyr_step, depths[l].cols, depths[l].rows, s, view<const float>(&depths[l - 1]), view<float>(&depths[l]),
+             view<const unsigned char>(&images[l - 1]), view<unsigned char>(&images[l]));
   return DMS_OK;
 }
 

@@ -2085,6 +2085,21 @@ void odometry_alias_next_depth(dms_odometry* o) {
   for (int i = 0; i < DMS_NUM_PYRS; ++i) o->nextDepth[i] = o->lastDepth[i];
 }
 
+// initICPModel + initRGBModel of the frame step in four launches (prep.hip, modelPyramidFused).
+// The operator-layer staging copy vmaps_tmp is not written on this path; nextDepth is aliased to
+// lastDepth by the caller, so nothing reads it.
+int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
+                             const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s) {
+  dms_image2d v[DMS_NUM_PYRS], n[DMS_NUM_PYRS], d[DMS_NUM_PYRS], im[DMS_NUM_PYRS];
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    v[i] = o->vmaps_g_prev[i].img();
+    n[i] = o->nmaps_g_prev[i].img();
+    d[i] = o->lastDepth[i].img();
+    im[i] = o->lastImage[i].img();
+  }
+  return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s);
+}
+
 // initICPModel with the source chosen on device: (*flag ? fill-in maps : predicted maps), pose read from HBM
 int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA, const float* vB, const float* nB, const int* flag_dev,
                               const float* pose16_dev, hipStream_t s) {
@@ -2124,6 +2139,13 @@ int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rg
 }  // namespace dms
 
 extern "C" {
+
+int dms_odometry_initModelFused(dms_odometry* o, const void* vertA, const void* normA, const void* rgbaA, const void* vertB,
+                                const void* normB, const void* rgbaB, const int* use_b_dev, int force_b_image,
+                                const float* modelPose16_dev, dms_stream s) {
+  DMS_REQUIRE(o, "null odometry");
+  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s);
+}
 
 int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {
   DMS_REQUIRE(o && r, "null argument");

@@ -290,6 +290,17 @@ class RGBDOdometry:
         check(lib.dms_odometry_initRGBModel(self.h, self._rgba(rgb).ref, self.stream), "initRGBModel")
         check(lib.dms_stream_sync(self.stream))
 
+    def initModelFused(self, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b, force_b_image, modelPose):
+        """Frame-step form of initICPModel + initRGBModel: source chosen by a device flag, pose read from HBM."""
+        keep = [self._dense(a) for a in (vertA, normA, vertB, normB)]
+        ia, ib = self._rgba(rgbaA), self._rgba(rgbaB)
+        flag = DeviceBuffer(4).upload(np.array([1 if use_b else 0], np.int32))
+        pose = DeviceBuffer(64).upload(np.ascontiguousarray(modelPose, np.float32).reshape(16))
+        check(lib.dms_odometry_initModelFused(self.h, C.c_void_p(keep[0][1]), C.c_void_p(keep[1][1]), C.c_void_p(ia.buf.ptr),
+                                              C.c_void_p(keep[2][1]), C.c_void_p(keep[3][1]), C.c_void_p(ib.buf.ptr), C.c_void_p(flag.ptr),
+                                              1 if force_b_image else 0, C.c_void_p(pose.ptr), self.stream), "initModelFused")
+        check(lib.dms_stream_sync(self.stream))
+
     def initFirstRGB(self, rgb):
         check(lib.dms_odometry_initFirstRGB(self.h, self._rgba(rgb).ref, self.stream), "initFirstRGB")
         check(lib.dms_stream_sync(self.stream))

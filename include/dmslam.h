@@ -216,6 +216,14 @@ int dms_odometry_initICPModel(dms_odometry* o, const float* predictedVertices,
 int dms_odometry_initRGB(dms_odometry* o, const dms_image2d* rgba, dms_stream s);
 int dms_odometry_initRGBModel(dms_odometry* o, const dms_image2d* rgba, dms_stream s);
 int dms_odometry_initFirstRGB(dms_odometry* o, const dms_image2d* rgba, dms_stream s);
+/* Frame-step form of initICPModel + initRGBModel (ElasticFusion.cpp:172-189) in four launches: the
+ * source (predicted maps A or fill-in maps B, dense W x H RGBA32F / RGBA8 in HBM) is chosen by a
+ * device flag (*use_b_dev != 0, or force_b_image for the image alone) and the model pose is read from a
+ * row-major 4x4 in HBM, so neither decision visits the host.  Writes vmaps_g_prev / nmaps_g_prev /
+ * lastDepth / lastImage exactly as the two reference calls do. */
+int dms_odometry_initModelFused(dms_odometry* o, const void* vertA, const void* normA, const void* rgbaA,
+                                const void* vertB, const void* normB, const void* rgbaB, const int* use_b_dev,
+                                int force_b_image, const float* modelPose16_dev, dms_stream s);
 
 /* Side outputs of getIncrementalTransformation (RGBDOdometry.h:64-72) */
 typedef struct dms_track_result {

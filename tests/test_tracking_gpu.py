@@ -170,6 +170,40 @@ def test_odometry_pyramids_exact(tracker_pair):
             assert (g.buffer(which, lvl) == o.buffer(which, lvl)).all(), (which, lvl)
 
 
+@pytest.mark.parametrize("use_b", [False, True])
+def test_fused_model_pyramid_equals_operator_chain(dms, orc, gputest_pair, use_b):
+    """dms_odometry_initModelFused (the frame step's 4-launch model pyramid: device-side source
+    selection, pose from HBM) against the oracle's initICPModel + initRGBModel on the selected
+    source, bit for bit (planes compared where the x plane is not NaN, as everywhere else)."""
+    K = gputest_pair["K"]
+    vA, nA = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
+    rng = np.random.default_rng(5)
+    vB = vA.copy()
+    vB[..., :3] += rng.normal(0, 0.01, vB[..., :3].shape).astype(np.float32)
+    vB[rng.random(vB.shape[:2]) < 0.05] = 0.0  # holes: z == 0 => NaN vertex and normal
+    nB = np.roll(nA, 3, axis=1).copy()
+    iA, iB = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
+    a = 0.05
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    pose[:3, 3] = (0.1, -0.2, 0.05)
+    g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+    o = orc.Odometry(640, 480, K[2], K[3], K[0], K[1])
+    g.initModelFused(vA, nA, iA, vB, nB, iB, use_b, False, pose)
+    o.initICPModel(vB if use_b else vA, nB if use_b else nA, 20.0, pose)
+    o.initRGBModel(iB if use_b else iA)
+    for lvl in range(3):
+        for which in (2, 3):
+            assert helpers.planes_equal_where_valid(g.buffer(which, lvl), o.buffer(which, lvl)), (which, lvl)
+        assert helpers.nan_equal(g.buffer(4, lvl), o.buffer(4, lvl)), ("lastDepth", lvl)
+        assert (g.buffer(6, lvl) == o.buffer(6, lvl)).all(), ("lastImage", lvl)
+    # frameToFrameRGB: the image alone comes from B
+    g.initModelFused(vA, nA, iA, vB, nB, iB, False, True, pose)
+    o.initRGBModel(iB)
+    for lvl in range(3):
+        assert (g.buffer(6, lvl) == o.buffer(6, lvl)).all(), ("lastImage forced", lvl)
+
+
 def test_icpStep_parity(dms, orc, tracker_pair):
     g, o = tracker_pair
     K = (528.0, 528.0, 320.0, 240.0)
