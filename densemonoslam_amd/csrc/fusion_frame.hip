@@ -29,18 +29,19 @@ int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s)
 int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
                      int timeIdx, float maxDepth, hipStream_t s);
 int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
-              unsigned long long* zbuf, dms_indexmap_out* out, int transposed, hipStream_t s);
+              unsigned long long* zbuf, dms_indexmap_out* out, int transposed, int zclean, hipStream_t s);
+int clear_zbuf(unsigned long long* zbuf, int n, hipStream_t s);
 int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStream_t s);
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
-                  dms_image2d* depth_out, hipStream_t s);
+                  dms_image2d* depth_out, int zclean, hipStream_t s);
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
                const float* weighting_dev, int transposed, hipStream_t s);
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
-                int isFern, int transposed, hipStream_t s);
+                int isFern, int transposed, unsigned* count_out2, hipStream_t s);
 // track.hip
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
                            float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s);
@@ -322,7 +323,7 @@ int predict(dms_fusion* f, float confidence, hipStream_t s) {
   {
     FTimer t(f, s, "predict");
     if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
-                            f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, s)))
+                            f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s)))
       return rc;
   }
   {
@@ -345,18 +346,18 @@ int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2
 }
 int dms_index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
                   unsigned long long* zbuf, dms_indexmap_out* out, dms_stream s) {
-  return index_map(m, pose, cam, time, timeIdx, maxDepth, timeDelta, zbuf, out, 0, (hipStream_t)s);
+  return index_map(m, pose, cam, time, timeIdx, maxDepth, timeDelta, zbuf, out, 0, 0, (hipStream_t)s);
 }
 int dms_splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                       int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out, dms_stream s) {
   DMS_REQUIRE(out, "null output");
-  return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, active, zbuf, out, nullptr, (hipStream_t)s);
+  return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, active, zbuf, out, nullptr, 0, (hipStream_t)s);
 }
 int dms_splat_depth(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                     int timeIdx, int maxTime, int timeDelta, unsigned long long* zbuf, dms_image2d* depth, dms_stream s) {
   DMS_REQUIRE(depth, "null output");
   // synthesizeDepth never sets the `actv` uniform (IndexMap.cpp:370-452): it stays false
-  return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, 0, zbuf, nullptr, depth, (hipStream_t)s);
+  return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, 0, zbuf, nullptr, depth, 0, (hipStream_t)s);
 }
 int dms_model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                    const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
@@ -367,7 +368,7 @@ int dms_model_clean(dms_model* m, const dms_pose_block* pose, int time, int time
                     const dms_image2d* depth_synth, const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes,
                     int timeDelta, float maxDepth, int isFern, dms_stream s) {
   return model_clean(m, pose, time, timeIdx, im, depth_synth, cam, confThreshold, graph_host, graph_nodes, timeDelta, maxDepth, isFern, 0,
-                     (hipStream_t)s);
+                     nullptr, (hipStream_t)s);
 }
 int dms_fill_in(const dms_predict_out* ex, const dms_image2d* d, const dms_image2d* rgba, const dms_camera* cam, int pg, int pr,
                 dms_predict_out* out, dms_stream s) {
@@ -455,6 +456,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   Pose16 I;
   for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
   hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, 0, f->state, I);
+  (void)clear_zbuf(f->zbuf, p->width * p->height, 0);  // kept empty from here on: every resolve pass clears what it reads
   (void)hipDeviceSynchronize();
   memset(f->h_state, 0, 2 * sizeof(FrameState));
   *out = f;
@@ -558,6 +560,7 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
   if (inPose16) memcpy(prior.v, inPose16, sizeof(prior.v));
 
   int fused = 0;
+  bool surfels_written = false;
   if (!f->map_initialised) {
     // first run (ElasticFusion.cpp:132-152): surfels from this frame, pose = inPose or identity
     if (!inPose16)
@@ -596,7 +599,7 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
         if ((rc = odometry_track_enqueue(f->odom, nullptr, nullptr, f->state->cur.pose, f->p.rgbOnly, f->p.icpWeight, f->p.pyramid,
                                          f->p.fastOdom, f->p.so3, 0, s)))
           return rc;
-        if ((rc = odometry_result_pose(f->odom, f->state->cur.pose, s))) return rc;
+        // (the tracker's finalize kernel writes the new pose straight back into f->state->cur.pose)
       }
     }
     hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
@@ -611,7 +614,7 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
       {
         FTimer t(f, s, "index_map");
         if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
-                            &f->imap, 1, s)))
+                            &f->imap, 1, 1, s)))
           return rc;
       }
       {
@@ -623,21 +626,24 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
       {
         FTimer t(f, s, "index_map");
         if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
-                            &f->imap, 1, s)))
+                            &f->imap, 1, 1, s)))
           return rc;
       }
       {
         FTimer t(f, s, "clean");
         if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, nullptr, 0,
-                              f->p.timeDelta, f->p.maxDepthProcessed, 0, 1, s)))
+                              f->p.timeDelta, f->p.maxDepthProcessed, 0, 1, &f->state->surfels, s)))
           return rc;
+        surfels_written = true;  // the clean's scan also stores the new count into the result block
       }
       fused = 1;
     }
   }
   if ((rc = predict(f, f->p.confidence, s))) return rc;  // finalPredict (ElasticFusion.cpp:586)
-  hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, s, f->state, f->model->d_count);
-  DMS_CHECK_LAUNCH();
+  if (!surfels_written) {
+    hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, s, f->state, f->model->d_count);
+    DMS_CHECK_LAUNCH();
+  }
   DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
   f->last_slot = k2;
   if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));

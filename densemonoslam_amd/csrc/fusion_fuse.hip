@@ -17,6 +17,8 @@
 // order (transform-feedback semantics), with the window tests of copy_unstable.vert.
 #include "scan.hpp"
 #include "smallmath.hpp"
+#include <utility>
+
 #include "surfel.hpp"
 
 namespace dms {
@@ -505,7 +507,7 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
 
 __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
                                                        const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
-                                                       const unsigned char* slot_flag, const unsigned char* __restrict__ keep,
+                                                       unsigned char* slot_flag, const unsigned char* __restrict__ keep,
                                                        const unsigned* __restrict__ block_offset, SurfelPlanes out) {
   const unsigned M = d_count[0];
   const unsigned total = M + (unsigned)a.nslots;
@@ -534,6 +536,9 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
         for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = v.times[s];
       }
     }
+    // the parked measurement of this element is consumed (a later clean without a fuse must not
+    // re-append it): only this thread ever reads the flag in this kernel
+    if (e >= M && e < total) slot_flag[e - M] = 0;
     running += tot;
   }
 }
@@ -588,7 +593,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
 
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
-                int isFern, int transposed, hipStream_t s) {
+                int isFern, int transposed, unsigned* count_out2, hipStream_t s) {
   DMS_REQUIRE(m && pose && im && cam, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -630,15 +635,14 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_count);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count + 2, (unsigned)m->cap);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt, (unsigned)m->cap,
+                     count_out2);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_clean_scatter, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_offset, dst);
   DMS_CHECK_LAUNCH();
-  // publish the new count only after the scatter has read the old one
-  DMS_HIP(hipMemcpyAsync(m->d_count, m->d_count + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, s));
-  // the parked measurements are consumed: a later clean without a fuse must not re-append them
-  DMS_HIP(hipMemsetAsync(m->slot_flag, 0, m->slots, s));
+  // the scatter still reads the old count cell; later launches get the new one
+  std::swap(m->d_count, m->d_count_alt);
   m->cur ^= 1;
   m->count_upper = upper < m->cap ? upper : m->cap;
   return DMS_OK;

@@ -41,6 +41,7 @@ static void model_layout(dms_model* m, ModelCarver& c) {
     m->buf[b].times = c.take<float>(m->cap * DMS_MAX_SENSORS);
   }
   m->d_count = c.take<unsigned>(8);
+  m->d_count_alt = m->d_count ? m->d_count + 4 : nullptr;
   m->slot_pos = c.take<float4>(m->slots);
   m->slot_col = c.take<float4>(m->slots);
   m->slot_nrm = c.take<float4>(m->slots);
@@ -342,7 +343,7 @@ int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* d
   const int nb = (n + kScanChunk - 1) / kScanChunk;
   hipLaunchKernelGGL(k_boot_flags, dim3(nb), dim3(256), 0, s, a, m->keep, m->block_count);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count, (unsigned)m->cap);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count, (unsigned)m->cap, (unsigned*)nullptr);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_boot_scatter, dim3(nb), dim3(256), 0, s, a, m->keep, m->block_offset, m->buf[m->cur], m->cap);
   DMS_CHECK_LAUNCH();
@@ -373,6 +374,12 @@ struct ProjArgs {
 
 __global__ void k_clear_zbuf(unsigned long long* z, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) z[i] = kZClear;
+}
+
+int clear_zbuf(unsigned long long* zbuf, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
 }
 
 // window position of a camera-frame point through the shader's NDC arithmetic
@@ -410,15 +417,16 @@ __global__ __launch_bounds__(256) void k_index_project(ProjArgs a, SurfelPlanes 
   }
 }
 
-__global__ __launch_bounds__(256) void k_index_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned long long* __restrict__ zbuf,
+__global__ __launch_bounds__(256) void k_index_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, unsigned long long* __restrict__ zbuf,
                                                        unsigned* __restrict__ index, float4* __restrict__ vertConf,
-                                                       float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+                                                       float4* __restrict__ colorTime, float4* __restrict__ normRad, int clear_after) {
   // p runs over the storage order of the images (row-major, or column-major when a.transposed):
   // the z-buffer uses the same order, so reads and writes are coalesced either way
   const int n = a.cols * a.rows;
   const float* Tinv = a.pose->t_inv;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
     const unsigned long long key = zbuf[p];
+    if (clear_after) zbuf[p] = kZClear;  // hand the z-buffer back empty: the next draw needs no clear launch
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {  // cleared colour (glClearColor 0)
       index[p] = 0;
       vertConf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -490,7 +498,9 @@ static void fill_proj(ProjArgs& a, const dms_model* m, const dms_pose_block* pos
 }
 
 int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
-              unsigned long long* zbuf, dms_indexmap_out* out, int transposed, hipStream_t s) {
+              unsigned long long* zbuf, dms_indexmap_out* out, int transposed, int zclean, hipStream_t s) {
+  // zclean: the caller's z-buffer is empty on entry and must be handed back empty (the resolve pass
+  // clears what it reads), so a chain of draws needs no clear launches
   DMS_REQUIRE(m && pose && cam && zbuf && out, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -501,12 +511,15 @@ int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, i
   fill_proj(a, m, pose, cam, maxDepth, time, timeIdx, timeDelta);
   a.transposed = transposed ? 1 : 0;
   const int n = W * H;
-  hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
-  DMS_CHECK_LAUNCH();
+  if (!zclean) {
+    hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
+    DMS_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(k_index_project, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_index_resolve, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
-                     (unsigned*)out->index.data, (float4*)out->vertConf.data, (float4*)out->colorTime.data, (float4*)out->normRad.data);
+                     (unsigned*)out->index.data, (float4*)out->vertConf.data, (float4*)out->colorTime.data, (float4*)out->normRad.data,
+                     zclean);
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }
@@ -601,14 +614,15 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
 }
 
 template <bool DEPTH_ONLY>
-__global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned long long* __restrict__ zbuf,
+__global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, unsigned long long* __restrict__ zbuf,
                                                        uchar4* __restrict__ image, float4* __restrict__ vertex, float4* __restrict__ normal,
-                                                       unsigned short* __restrict__ timeImg, float* __restrict__ depthOut) {
+                                                       unsigned short* __restrict__ timeImg, float* __restrict__ depthOut, int clear_after) {
   const int n = a.cols * a.rows;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
     // outputs are row-major (the tracker consumes them); the z-buffer is column-major
     const int py = p / a.cols, px = p - py * a.cols;
     const unsigned long long key = zbuf[(size_t)px * a.rows + py];
+    if (clear_after) zbuf[(size_t)px * a.rows + py] = kZClear;
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {
       if (DEPTH_ONLY) {
         depthOut[p] = 0.f;
@@ -649,7 +663,7 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
 
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
-                  dms_image2d* depth_out, hipStream_t s) {
+                  dms_image2d* depth_out, int zclean, hipStream_t s) {
   DMS_REQUIRE(m && pose && cam && zbuf, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -665,17 +679,19 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
   a.maxTime = maxTime;
   a.actv = active ? 1 : 0;
   const int n = W * H;
-  hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
-  DMS_CHECK_LAUNCH();
+  if (!zclean) {
+    hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
+    DMS_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(k_splat_project, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf);
   DMS_CHECK_LAUNCH();
   if (depth_out)
     hipLaunchKernelGGL(k_splat_resolve<true>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
-                       (uchar4*)nullptr, (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data);
+                       (uchar4*)nullptr, (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data, zclean);
   else
     hipLaunchKernelGGL(k_splat_resolve<false>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
                        (uchar4*)out->image.data, (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data,
-                       (float*)nullptr);
+                       (float*)nullptr, zclean);
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }

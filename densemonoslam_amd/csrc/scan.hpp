@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned block_exclusive_rank(bool flag, unsigned& to
 
 // exclusive scan of nb per-block counts by one 1024-thread block; out_count[0] = min(total, cap)
 static __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned* __restrict__ counts, unsigned* __restrict__ offsets, int nb,
-                                                      unsigned* __restrict__ out_count, unsigned cap) {
+                                                      unsigned* __restrict__ out_count, unsigned cap, unsigned* __restrict__ out_count2) {
   __shared__ unsigned s_w[16];
   __shared__ unsigned s_carry;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -70,7 +70,11 @@ static __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned* __r
     if (threadIdx.x == 1023) s_carry = carry + wbase + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) out_count[0] = s_carry < cap ? s_carry : cap;
+  if (threadIdx.x == 0) {
+    const unsigned c = s_carry < cap ? s_carry : cap;
+    out_count[0] = c;
+    if (out_count2) out_count2[0] = c;  // e.g. the frame context's result block
+  }
 }
 
 }  // namespace dms

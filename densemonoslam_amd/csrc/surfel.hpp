@@ -138,7 +138,8 @@ struct dms_model {
   int cur = 0;
   char* arena = nullptr;
   size_t arena_bytes = 0;
-  unsigned* d_count = nullptr;      // [0] model count, [1] new-unstable count, [2] scratch
+  unsigned* d_count = nullptr;      // [0] model count.  Two cells exist; clean writes the new count into the other
+  unsigned* d_count_alt = nullptr;  // one and the handles swap (no device copy, readers got the pointer at enqueue time)
   unsigned* h_count = nullptr;      // pinned mirror
   size_t count_upper = 0;           // host-side upper bound of the model count
   int count_hold = 0;               // frames for which the frame pipeline must not tighten count_upper from its (older) result blocks

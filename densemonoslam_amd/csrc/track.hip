@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   }
 }
 
-__global__ void k_track_finalize(TrackState* st, int rgb) {
+__global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ pose16_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
   const float n = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -1398,6 +1398,16 @@ __global__ void k_track_finalize(TrackState* st, int rgb) {
   }
   for (int i = 0; i < 3; ++i) st->out_trans[i] = st->tcurr[i];
   for (int i = 0; i < 9; ++i) st->out_rot[i] = st->Rcurr[i];
+  if (pose16_out) {  // frame step: the pose goes straight into the context's pose block (row-major 4x4)
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) pose16_out[i * 4 + j] = st->out_rot[i * 3 + j];
+      pose16_out[i * 4 + 3] = st->out_trans[i];
+    }
+    pose16_out[12] = 0.f;
+    pose16_out[13] = 0.f;
+    pose16_out[14] = 0.f;
+    pose16_out[15] = 1.f;
+  }
 }
 
 }  // namespace dms
@@ -1976,10 +1986,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
 
   {
     Timer t(o, s, "track_finalize");
-    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0);
+    // with a device-resident prior (frame step) the result is written back into the same pose block
+    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0, const_cast<float*>(prior_pose16_dev));
     DMS_CHECK_LAUNCH();
   }
-  DMS_HIP(hipMemcpyAsync(o->host_state, o->state, sizeof(TrackState), hipMemcpyDeviceToHost, s));
+  // (the result block is copied to the host by dms_odometry_fetch_result, not once per call)
 
   if (so3) {  // RGBDOdometry.cpp:595-601 — stream-ordered, so swapping the handles is enough
     for (int i = 0; i < DMS_NUM_PYRS; i++) std::swap(o->lastNextImage[i], o->nextImage[i]);
@@ -2149,6 +2160,7 @@ int dms_odometry_initModelFused(dms_odometry* o, const void* vertA, const void* 
 
 int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {
   DMS_REQUIRE(o && r, "null argument");
+  DMS_HIP(hipMemcpyAsync(o->host_state, o->state, sizeof(TrackState), hipMemcpyDeviceToHost, (hipStream_t)st));
   DMS_HIP(hipStreamSynchronize((hipStream_t)st));
   drain_timers(o);
   const TrackState* h = o->host_state;
