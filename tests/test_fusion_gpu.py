@@ -415,6 +415,23 @@ def test_process_frame_pipelined_equals_serial(fus, synth):
         assert_bits(got[4], ref[4], "filtered depth " + what)
 
 
+def test_global_predict_is_dead_work(fus, synth):
+    """The reference's post-tracking "GlobalPredict" (ElasticFusion.cpp:273) feeds only blocks the
+    fork compiles out and is overwritten by the final predict: running it (global_predict = 1)
+    must not change a single bit of the frame's outputs."""
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(4)]
+    out = []
+    for gp in (0, 1):
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, global_predict=gp)
+        for d, rgb, _ in frames:
+            r = g.processFrame(rgb, d)
+        out.append((np.array(r.pose, np.float32), int(r.surfels), g.globalModel().downloadMap(), g.image(10), g.image(9), g.image(14)))
+    assert (out[0][0] == out[1][0]).all() and out[0][1] == out[1][1]
+    surfels_equal(out[0][2], out[1][2], "map")
+    for k in (3, 4, 5):
+        assert_bits(out[0][k], out[1][k], "image %d" % k)
+
+
 def test_process_frame_free_running_drift_is_bounded(fus, orc, synth):
     """Without teacher forcing the two float implementations drift apart slowly (correspondences
     flip under 1e-6 pose differences); the drift stays far below the scene scale."""
