@@ -917,7 +917,9 @@ constexpr int kPB = 512;                 // 8 waves: 256 VGPRs per thread, half 
 constexpr int kPWaves = kPB / kWave;
 constexpr int kRecFloats = 64;           // [0,29) ICP sums, [32,61) photometric sums
 constexpr int kMaxPersistBlocks = 256;   // one block per CU
-constexpr int kSyncWords = 512;          // barrier words per tracking call
+constexpr int kBarrierStride = 16 * 9;    // words per barrier: top word + 8 shard words, one 128-byte line each
+constexpr int kMaxBarriers = 10 + 3 * 20; // SO3 iterations + 2 per GN iteration (<= 10 per level on this path)
+constexpr int kSyncWords = kMaxBarriers * kBarrierStride;  // barrier words per tracking call
 constexpr unsigned kSpinLimit = 1u << 22;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -927,21 +929,43 @@ struct LevelArgs {
   float icpWeight;
   float fx, fy, cx, cy;  // full-resolution intrinsics
   float* rec;            // [2][gridDim.x][kRecFloats]
-  unsigned long long* sync;  // 2 words per iteration, zero on entry
+  unsigned long long* sync;  // 2 barriers (kBarrierStride words each) per iteration, zero on entry
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
 };
 
-// arrive with `payload` added into the low 54 bits; returns the completed word
-__device__ __forceinline__ unsigned long long pk_barrier(unsigned long long* word, unsigned long long payload, int* timeout) {
+// Grid barrier whose arrival word carries a payload (low 54 bits, summed) next to the arrival count
+// (top 10 bits).  Arrivals on one word serialise at ~12 ns each, so grids above 64 blocks arrive on
+// 8 shard words (block % 8, one cache line each) and the last arriver of a shard forwards the shard's
+// sum to the top word; everybody polls the top word (relaxed loads, s_sleep) until it shows all
+// shards.  `b` points at the barrier's kBarrierStride words, all zero before the launch.
+__device__ __forceinline__ int pk_shards() { return gridDim.x > 64 ? 8 : 1; }
+
+// thread 0 only, after a __syncthreads() that orders the block's work
+__device__ __forceinline__ void pk_arrive(unsigned long long* b, unsigned long long payload) {
+  const unsigned long long one = 1ull << 54, low = one - 1ull;
+  const int ns = pk_shards();
+  if (ns == 1) {
+    // single level: the top word counts blocks; pk_wait expects gridDim.x arrivals
+    __hip_atomic_fetch_add(b, one | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int sh = blockIdx.x & 7;
+  const unsigned long long members = (gridDim.x - sh + 7) >> 3;
+  const unsigned long long old = __hip_atomic_fetch_add(b + 16 * (sh + 1), one | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((old >> 54) + 1ull == members)  // last of the shard: its sum (mine included) goes up
+    __hip_atomic_fetch_add(b, one | (((old & low) + payload) & low), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// all threads; returns the completed top word (payload sum in the low 54 bits)
+__device__ __forceinline__ unsigned long long pk_wait(unsigned long long* b, int* timeout) {
   __shared__ unsigned long long s_word;
-  __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(word, (1ull << 54) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long need = pk_shards() == 1 ? (unsigned long long)gridDim.x : 8ull;
     unsigned long long cur;
     unsigned spins = 0;
     for (;;) {
-      cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((cur >> 54) >= (unsigned long long)gridDim.x) break;
+      cur = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((cur >> 54) >= need) break;
       ++spins;
       if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never hang the device
@@ -955,30 +979,10 @@ __device__ __forceinline__ unsigned long long pk_barrier(unsigned long long* wor
   return s_word;
 }
 
-// split-phase form: pk_arrive (thread 0 only, after a __syncthreads() that orders the block's
-// work) ... independent work ... pk_wait
-__device__ __forceinline__ void pk_arrive(unsigned long long* word, unsigned long long payload) {
-  __hip_atomic_fetch_add(word, (1ull << 54) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long pk_wait(unsigned long long* word, int* timeout) {
-  __shared__ unsigned long long s_word2;
-  if (threadIdx.x == 0) {
-    unsigned long long cur;
-    unsigned spins = 0;
-    for (;;) {
-      cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((cur >> 54) >= (unsigned long long)gridDim.x) break;
-      ++spins;
-      if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    s_word2 = cur;
-  }
+__device__ __forceinline__ unsigned long long pk_barrier(unsigned long long* b, unsigned long long payload, int* timeout) {
   __syncthreads();
-  return s_word2;
+  if (threadIdx.x == 0) pk_arrive(b, payload);
+  return pk_wait(b, timeout);
 }
 
 // block-wide sum of NV per-thread values (16 waves): DPP inside the wave, then the 16 wave partials
@@ -1211,7 +1215,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         const int t = row8_sum_i(tid < 16 ? s_redi[tid & 7][tid >> 3] : 0);
         const unsigned long long cb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 0);
         const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 8);
-        if (tid == 0) pk_arrive(L.sync + 2 * it, (cb << 35) | sb);
+        if (tid == 0) pk_arrive(L.sync + (2 * it) * kBarrierStride, (cb << 35) | sb);
       }
     }
     phase(2);
@@ -1220,7 +1224,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (RGB) {
-      const unsigned long long word = pk_wait(L.sync + 2 * it, &st->sync_timeout);
+      const unsigned long long word = pk_wait(L.sync + (2 * it) * kBarrierStride, &st->sync_timeout);
       phase(3);
       rgbSize = (int)((word >> 35) & 0x7FFFFull);
       sigma = (int)(word & 0x7FFFFFFFFull);
@@ -1260,7 +1264,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     // ---- barrier B: records published ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase(4);
-    pk_barrier(L.sync + 2 * it + 1, 0ull, &st->sync_timeout);
+    pk_barrier(L.sync + (2 * it + 1) * kBarrierStride, 0ull, &st->sync_timeout);
     phase(5);
 
     // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
     float* my_rec = rec + ((size_t)par * nb + blockIdx.x) * kRecFloats;
     if (pblock_owner<kSO3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pk_barrier(sync + it, 0ull, &st->sync_timeout);
+    pk_barrier(sync + it * kBarrierStride, 0ull, &st->sync_timeout);
     pk_gather(rsrc, par, nb, s_grp, s_sums);
     if (tid == 0) so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
     __syncthreads();
@@ -1833,7 +1837,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
 
   {
     Timer t(o, s, "track_init");
-    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
+    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
                        first_level, o->sync, kSyncWords);
     DMS_CHECK_LAUNCH();
   }
@@ -1867,7 +1871,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
 
   for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
     int pP = 1, pnb = 0;
-    if (persistent_enabled() && 2 * iterations[l] <= 128) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), pP, pnb);
+    if (persistent_enabled() && iterations[l] <= 10) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), pP, pnb);
     const bool persistent = pnb > 0;
     if (rgb && !persistent) {  // the persistent kernel rebuilds the cloud point from lastDepth itself
       dms_camera k = {o->fx, o->fy, o->cx, o->cy};
@@ -1934,7 +1938,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.cx = o->cx;
       L.cy = o->cy;
       L.rec = o->rec;
-      L.sync = o->sync + 64 + 128 * l;
+      L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
       L.prof = o->profiling ? o->prof : nullptr;
       persist.begin();
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
