@@ -252,7 +252,7 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "k_gn_level<ICP,RGB,4> (pyramid level 0: all 10 Gauss-Newton iterations in one resident launch)",
+                "kernel": "k_gn_level<ICP,RGB,P> (pyramid level 0: all 10 Gauss-Newton iterations in one resident launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
