@@ -233,9 +233,26 @@ struct CleanArgs {
   int transposed;
 };
 
+// plain aggregates (HIP's float4 is a class with a union inside: as a member of the element it keeps
+// the whole 96-byte element in scratch memory instead of registers)
+struct F4 {
+  float x, y, z, w;
+};
+__device__ __forceinline__ F4 ld4(const float4* p) {
+  const float4 t = *p;
+  F4 r;
+  r.x = t.x;
+  r.y = t.y;
+  r.z = t.z;
+  r.w = t.w;
+  return r;
+}
+__device__ __forceinline__ float4 to4(const F4& v) { return make_float4(v.x, v.y, v.z, v.w); }
 struct CleanElem {
-  float4 pos, col, nrm;
+  F4 pos, col, nrm;
   float times[DMS_MAX_SENSORS];
+  float vt;  // this sensor's time (times[timeIdx]), kept separately: selecting it out of the array by a runtime
+             // index makes the compiler index the array dynamically, which moves the whole element to scratch memory
 };
 
 // load element e (map surfel or parked measurement); false when the slot holds nothing
@@ -243,38 +260,26 @@ __device__ __forceinline__ bool clean_load(unsigned e, unsigned M, const SurfelP
                                            const float4* slot_col, const float4* slot_nrm, const unsigned char* slot_flag, int nslots,
                                            int timeIdx, CleanElem& o) {
   if (e < M) {
-    o.pos = sp.pos[e];
-    o.col = sp.col[e];
-    o.nrm = sp.nrm[e];
+    o.pos = ld4(sp.pos + e);
+    o.col = ld4(sp.col + e);
+    o.nrm = ld4(sp.nrm + e);
 #pragma unroll
     for (int s = 0; s < DMS_MAX_SENSORS; ++s) o.times[s] = sp.times[(size_t)s * cap + e];
+    o.vt = sp.times[(size_t)timeIdx * cap + e];
     return true;
   }
   const unsigned slot = e - M;
   if ((int)slot >= nslots || slot_flag[slot] == 0) return false;
-  o.pos = slot_pos[slot];
-  o.col = slot_col[slot];
-  o.nrm = slot_nrm[slot];
+  o.pos = ld4(slot_pos + slot);
+  o.col = ld4(slot_col + slot);
+  o.nrm = ld4(slot_nrm + slot);
   // data.geom:50-54: -3 for every sensor but this one, which carries the -1 / -2 marker
 #pragma unroll
   for (int s = 0; s < DMS_MAX_SENSORS; ++s) o.times[s] = (s == timeIdx) ? o.col.w : -3.f;
+  o.vt = o.col.w;
   return true;
 }
 
-// static-slot access to the per-sensor times (a dynamically indexed private array would live in
-// scratch memory)
-__device__ __forceinline__ float pick_time(const float (&t)[DMS_MAX_SENSORS], int idx) {
-  float r = t[0];
-#pragma unroll
-  for (int s = 1; s < DMS_MAX_SENSORS; ++s) r = (s == idx) ? t[s] : r;
-  return r;
-}
-__device__ __forceinline__ void put_time(float (&t)[DMS_MAX_SENSORS], int idx, float v) {
-#pragma unroll
-  for (int s = 0; s < DMS_MAX_SENSORS; ++s) t[s] = (s == idx) ? v : t[s];
-}
-
-// the keep/drop decision of copy_unstable.vert:70-159 (before any deformation)
 __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v) {
   int test = 1;
   const float* Tinv = a.pose->t_inv;
@@ -288,55 +293,50 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
   const float indexYStep = (1.0f / (rowsf * scale)) * 0.5f;
   const float windowMultiplier = 2.f;
   int count = 0, zCount = 0;
-  const float vt = pick_time(v.times, a.timeIdx);
+  const float vt = v.vt;
   if ((float)a.time - vt < (float)a.timeDelta && localPos.z > 0.f && x > 0.f && y > 0.f && x < colsf && y < rowsf) {
     const float xc = x / colsf, yc = y / rowsf;
     const float x_lo = xc - ((scale * indexXStep) * windowMultiplier), x_hi = xc + ((scale * indexXStep) * windowMultiplier);
     const float y_lo = yc - ((scale * indexYStep) * windowMultiplier), y_hi = yc + ((scale * indexYStep) * windowMultiplier);
     const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
     const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
-    // The (at most 4 x 4) distinct texels are fetched in three batches of independent loads —
-    // 16 ids, then vertex/confidence + colour/time of 8 texels at a time — instead of one dependent
-    // id -> attributes chain per texel (two memory round trips per tap, up to 32 in a row).
-    // Unused slots carry multiplicity 0 and read texel 0.
+    // The (at most 4 x 4) distinct texels are visited one x slot at a time: the 12 loads of a slot's
+    // four texels (id, vertex/confidence, colour/time — none depends on another) are in flight
+    // together, a slot no lane of the wave uses is skipped, and the register footprint stays small
+    // enough that the 80-byte element is not spilled.  Unused y slots carry multiplicity 0 and read
+    // texel 0.
     const int txs[4] = {tx_.t0, tx_.t1, tx_.t2, tx_.t3}, mxs[4] = {tx_.m0, tx_.m1, tx_.m2, tx_.m3};
     const int tys[4] = {ty_.t0, ty_.t1, ty_.t2, ty_.t3}, mys[4] = {ty_.m0, ty_.m1, ty_.m2, ty_.m3};
-    size_t q[16];
-    int mult[16];
-    unsigned cur[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      if (mxs[i] != 0) {  // (divergent lanes wait here; a slot unused by the whole wave costs nothing)
+        unsigned cur[4];
+        float4 vcs[4];
+        float2 cts[4];
+        int mult[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = mxs[i] * mys[j];
-        const int ux = m ? txs[i] : 0, uy = m ? tys[j] : 0;
-        mult[i * 4 + j] = m;
-        q[i * 4 + j] = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
-      }
+        for (int j = 0; j < 4; ++j) {
+          mult[j] = mxs[i] * mys[j];
+          const int uy = mult[j] ? tys[j] : 0;
+          const unsigned q = a.transposed ? (unsigned)txs[i] * (unsigned)a.rows + (unsigned)uy : (unsigned)uy * (unsigned)a.cols + (unsigned)txs[i];
+          cur[j] = a.index[q];
+          vcs[j] = a.vertConf[q];
+          cts[j] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.colorTime[q]) + 2);  // .z .w
+        }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) cur[k] = a.index[q[k]];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float4 vcs[8];
-      float2 cts[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        vcs[k] = a.vertConf[q[h * 8 + k]];
-        cts[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.colorTime[q[h * 8 + k]]) + 2);  // .z .w
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int m = mult[h * 8 + k];
-        if (m != 0 && cur[h * 8 + k] > 0u) {
-          const float4 vc = vcs[k];
-          const float ctz = cts[k].x, ctw = cts[k].y;
-          const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
-          if (ctz < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
-              sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f)
-            count += m;  // every repeated tap of this texel counts
-          if (ctw == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
-              fabsf(localNorm.z) > 0.85f)
-            zCount += m;
+        for (int j = 0; j < 4; ++j) {
+          const int m = mult[j];
+          if (m != 0 && cur[j] > 0u) {
+            const float4 vc = vcs[j];
+            const float ctz = cts[j].x, ctw = cts[j].y;
+            const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
+            if (ctz < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
+                sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f)
+              count += m;  // every repeated tap of this texel counts
+            if (ctw == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
+                fabsf(localNorm.z) > 0.85f)
+              zCount += m;
+          }
         }
       }
     }
@@ -499,7 +499,7 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
       const float currentDepth = a.depth_synth ? a.depth_synth[(size_t)uy * a.cols + ux] : 0.f;
       if (currentDepth > 0.0f && lp.z < currentDepth + 0.1f) {
         v.col.w = (float)a.time;
-        put_time(v.times, a.timeIdx, (float)a.time);
+        v.vt = (float)a.time;
       }
     }
   }
@@ -524,16 +524,16 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
       if (dst < cap) {
         CleanElem v;
         clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v);
-        if (pick_time(v.times, a.timeIdx) == -2.f) {  // copy_unstable.vert:124-129
+        if (v.vt == -2.f) {  // copy_unstable.vert:124-129
           v.col.w = (float)a.time;
-          put_time(v.times, a.timeIdx, (float)a.time);
+          v.vt = (float)a.time;
         }
         if (a.nodes > 0 && v.col.z != (float)a.time) clean_deform(a, v);  // :161
-        out.pos[dst] = v.pos;
-        out.col[dst] = v.col;
-        out.nrm[dst] = v.nrm;
+        out.pos[dst] = to4(v.pos);
+        out.col[dst] = to4(v.col);
+        out.nrm[dst] = to4(v.nrm);
 #pragma unroll
-        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = v.times[s];
+        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? v.vt : v.times[s];
       }
     }
     // the parked measurement of this element is consumed (a later clean without a fuse must not
