@@ -214,6 +214,10 @@ lib.dms_pyrDown.argtypes = [_I2, _I2, _P]
 lib.dms_pyrDownGaussF.argtypes = [_I2, _I2, _P]
 lib.dms_pyrDownUcharGauss.argtypes = [_I2, _I2, _P]
 lib.dms_computeDerivativeImages.argtypes = [_I2, _I2, _I2, _P]
+lib.dms_nid_workspace_bytes.argtypes = [C.c_int]
+lib.dms_nid_workspace_bytes.restype = C.c_size_t
+lib.dms_computeNIDImg.argtypes = [_I2, _I2, _I2, _I2, _I2, C.c_int, _P, C.c_size_t, C.POINTER(C.c_float), _P]
+lib.dms_computeNIDDepth.argtypes = [_I2, _I2, _I2, C.c_int, C.c_float, _P, C.c_size_t, C.POINTER(C.c_float), _P]
 
 lib.dms_odometry_create.argtypes = [C.POINTER(_P), _I, _I, _F, _F, _F, _F, _F, _F]
 lib.dms_odometry_destroy.argtypes = [_P]

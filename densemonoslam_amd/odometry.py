@@ -146,6 +146,27 @@ class ops:
         return dx, dy
 
     @staticmethod
+    def computeNIDImg(img_kf, img_kf_old, dmap_kf, dmap_kf_old, img_curr, num_bins=64):
+        """nid of the intensity images (reference computeNIDImg); also returns the histogram (live bin, key-frame bin)."""
+        a, b, c, d, e = _img(img_kf), _img(img_kf_old), _img(dmap_kf), _img(dmap_kf_old), _img(img_curr)
+        n = lib.dms_nid_workspace_bytes(num_bins)
+        ws = DeviceBuffer(n)
+        out = C.c_float(0)
+        check(lib.dms_computeNIDImg(a.ref, b.ref, c.ref, d.ref, e.ref, num_bins, C.c_void_p(ws.ptr), n, C.byref(out), None), "dms_computeNIDImg")
+        hist = ws.download(np.uint32, (num_bins, num_bins))
+        return out.value, hist
+
+    @staticmethod
+    def computeNIDDepth(dmap_kf, dmap_kf_old, dmap_curr, num_bins=500, max_depth_mm=25000.0):
+        a, b, c = _img(dmap_kf), _img(dmap_kf_old), _img(dmap_curr)
+        n = lib.dms_nid_workspace_bytes(num_bins)
+        ws = DeviceBuffer(n)
+        out = C.c_float(0)
+        check(lib.dms_computeNIDDepth(a.ref, b.ref, c.ref, num_bins, max_depth_mm, C.c_void_p(ws.ptr), n, C.byref(out), None), "dms_computeNIDDepth")
+        hist = ws.download(np.uint32, (num_bins, num_bins))
+        return out.value, hist
+
+    @staticmethod
     def projectToPointCloud(depth, cam, level):
         depth = _img(depth)
         cloud = DeviceImage(depth.rows, depth.cols, np.dtype((np.float32, (3,))))

@@ -191,6 +191,22 @@ int dms_pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, dms_stream s
 int dms_computeDerivativeImages(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy,
                                 dms_stream stream);
 
+/* Normalised information distance of the NID key-framing gate (ElasticFusion::fuseFrame,
+ * ElasticFusion.cpp:639-677): reference computeNIDImg / computeNIDDepth (cudafuncs.cuh:170-181,
+ * cudafuncs.cu:1513-1650, 1794-1916).  Key-frame value per pixel = the nearer of the active and the
+ * "old" prediction (NaN depth = no prediction); joint histogram against the live frame (intensity:
+ * bins of 256 / num_bins grey levels; depth: bins of int(max_depth / num_bins) millimetres, depths in
+ * metres, max_depth in millimetres); nid = (H_joint - MI) / H_joint.  `workspace` holds the histogram
+ * (dms_nid_workspace_bytes(num_bins)); the score is written to *nid_host (the call synchronises,
+ * like the reference). */
+size_t dms_nid_workspace_bytes(int num_bins);
+int dms_computeNIDImg(const dms_image2d* img_kf, const dms_image2d* img_kf_old, const dms_image2d* dmap_kf,
+                      const dms_image2d* dmap_kf_old, const dms_image2d* img_curr, int num_bins,
+                      void* workspace, size_t workspace_bytes, float* nid_host, dms_stream stream);
+int dms_computeNIDDepth(const dms_image2d* dmap_kf, const dms_image2d* dmap_kf_old, const dms_image2d* dmap_curr,
+                        int num_bins, float max_depth, void* workspace, size_t workspace_bytes,
+                        float* nid_host, dms_stream stream);
+
 /* ------------------------------------------------------------------------- */
 /* (A) object layer — RGBDOdometry                                            */
 /* ------------------------------------------------------------------------- */

@@ -204,6 +204,41 @@ def test_fused_model_pyramid_equals_operator_chain(dms, orc, gputest_pair, use_b
         assert (g.buffer(6, lvl) == o.buffer(6, lvl)).all(), ("lastImage forced", lvl)
 
 
+def test_nid_scores_parity(dms, gputest_pair):
+    """NID key-framing operators: joint histograms integer-exact against the numpy
+    restatement of the reference's kernels, scores within 1e-5 (parallel fp64 sums on the GPU, the
+    reference's scalar float loops in the oracle)."""
+    from oracle import orc_nid
+
+    rng = np.random.default_rng(11)
+    g1 = helpers.rgba(gputest_pair["rgb1"])[..., :3].astype(np.float32) @ np.array([0.114, 0.299, 0.587], np.float32)
+    g2 = helpers.rgba(gputest_pair["rgb2"])[..., :3].astype(np.float32) @ np.array([0.114, 0.299, 0.587], np.float32)
+    img_kf, img_curr = g1.astype(np.uint8), g2.astype(np.uint8)
+    img_old = np.roll(img_kf, 5, axis=1)
+    d_kf = gputest_pair["depth1_raw"].astype(np.float32) / 5000.0
+    d_kf[d_kf == 0] = np.nan
+    d_old = d_kf + rng.normal(0, 0.05, d_kf.shape).astype(np.float32)
+    d_old[rng.random(d_kf.shape) < 0.3] = np.nan
+    d_cur = gputest_pair["depth2"].astype(np.float32) / 1000.0
+    d_cur[d_cur == 0] = np.nan
+    d_cur[::7, ::5] = 30.0  # beyond max_depth: clamped into the last bin
+    for bins in (64, 16):
+        s_g, h_g = dms.ops.computeNIDImg(img_kf, img_old, d_kf, d_old, img_curr, bins)
+        s_o, h_o = orc_nid.nid_img(img_kf, img_old, d_kf, d_old, img_curr, bins)
+        assert (h_g == h_o).all() and int(h_g.sum()) == img_kf.size
+        assert abs(s_g - float(s_o)) < 1e-5, (s_g, s_o)
+        assert 0.0 < s_g <= 1.0
+    for bins, maxd in ((500, 25000.0), (100, 3000.0)):
+        s_g, h_g = dms.ops.computeNIDDepth(d_kf, d_old, d_cur, bins, maxd)
+        s_o, h_o = orc_nid.nid_depth(d_kf, d_old, d_cur, bins, maxd)
+        assert (h_g == h_o).all() and int(h_g.sum()) == d_kf.size
+        assert abs(s_g - float(s_o)) < 1e-5, (s_g, s_o)
+    # identical frames: the joint histogram is diagonal, MI = H, nid = 0
+    ones = np.ones_like(d_kf)  # a prediction everywhere (a pixel without one contributes intensity 0)
+    s_same, _ = dms.ops.computeNIDImg(img_kf, img_kf, ones, ones, img_kf, 64)
+    assert abs(s_same) < 1e-6
+
+
 def test_icpStep_parity(dms, orc, tracker_pair):
     g, o = tracker_pair
     K = (528.0, 528.0, 320.0, 240.0)
