@@ -53,6 +53,14 @@ int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rg
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
+int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth);
+// nid.hip
+size_t nid_workspace_bytes(int num_bins);
+int computeNIDImg(const dms_image2d* img_kf, const dms_image2d* img_kf_old, const dms_image2d* dmap_kf, const dms_image2d* dmap_kf_old,
+                  const dms_image2d* img_curr, int num_bins, void* workspace, size_t workspace_bytes, float* nid_host, float* nid_dev,
+                  hipStream_t s);
+int computeNIDDepth(const dms_image2d* dmap_kf, const dms_image2d* dmap_kf_old, const dms_image2d* dmap_curr, int num_bins, float max_depth,
+                    void* workspace, size_t workspace_bytes, float* nid_host, float* nid_dev, hipStream_t s);
 void odometry_bind_live(dms_odometry* o, int k);
 void odometry_bind_lastnext(dms_odometry* o, int k);
 int odometry_initRGB_image(dms_odometry* o, const dms_image2d* rgba, hipStream_t s);
@@ -188,6 +196,13 @@ struct dms_fusion {
   hipStream_t s_prep = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr}, ev_inputs = nullptr;
   long frames = 0;  // frames enqueued so far
+  // NID key-framing (fuseFrame): candidate key frame of the current prediction, per pyramid level
+  dms_image2d kf_img[DMS_NUM_PYRS], kf_dmap[DMS_NUM_PYRS], kf_old_img[DMS_NUM_PYRS], kf_old_dmap[DMS_NUM_PYRS];
+  void* nid_ws = nullptr;
+  size_t nid_ws_bytes = 0;
+  float* nid_host = nullptr;  // pinned [2]
+  int frames_since_fusion = 0;
+  float last_nid = 0.f;
   dms_indexmap_out imap;
   dms_predict_out pred, fill;
   void* rgba_tmp = nullptr;
@@ -257,6 +272,18 @@ void layout(dms_fusion* f, Carve& c) {
   f->fill.vertex = mk_img(c.take(N * 16), H, W, 16);
   f->fill.normal = mk_img(c.take(N * 16), H, W, 16);
   f->fill.time = f->pred.time;
+  for (int l = 0; l < DMS_NUM_PYRS; ++l) {
+    const int h = H >> l, w = W >> l;
+    f->kf_img[l] = mk_img(c.take((size_t)h * w), h, w, 1);
+    f->kf_dmap[l] = mk_img(c.take((size_t)h * w * 4), h, w, 4);
+    f->kf_old_img[l] = mk_img(c.take((size_t)h * w), h, w, 1);
+    f->kf_old_dmap[l] = mk_img(c.take((size_t)h * w * 4), h, w, 4);
+  }
+  {
+    const int nb = f->p.nid_bins_depth > f->p.nid_bins_img ? f->p.nid_bins_depth : f->p.nid_bins_img;
+    f->nid_ws_bytes = nid_workspace_bytes(nb > 0 ? nb : 1);
+    f->nid_ws = c.take(f->nid_ws_bytes);
+  }
   f->rgba_tmp = c.take(N * 4);
   f->untr = c.take(N * 16);
   f->zbuf = (unsigned long long*)c.take(N * 8);
@@ -401,12 +428,21 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->model_capacity = 0;
   p->pipeline_ingest = 1;
   p->global_predict = 0;
+  p->nid_keyframing = 0;
+  p->nid_threshold = 0.80f;    // ElasticFusion.h:73-74
+  p->nid_depth_lambda = 0.7f;
+  p->nid_bins_img = 64;
+  p->nid_bins_depth = 500;
+  p->nid_pyramid_level = 0;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   DMS_REQUIRE(out && p, "null argument");
   DMS_REQUIRE(p->width >= 40 && p->height >= 40, "resolution too small");
   DMS_REQUIRE(p->timeIdx >= 0 && p->timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  DMS_REQUIRE(!p->nid_keyframing || (p->nid_bins_img >= 1 && p->nid_bins_img <= 256 && p->nid_bins_depth >= 1 && p->nid_bins_depth <= 4096 &&
+                                     p->nid_pyramid_level >= 0 && p->nid_pyramid_level < DMS_NUM_PYRS),
+              "bad NID key-framing parameters");
   dms_fusion* f = new dms_fusion();
   f->p = *p;
   f->cam.fx = p->fx;
@@ -443,6 +479,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 2 * sizeof(FrameState), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->nid_host, 2 * sizeof(float), hipHostMallocDefault);
   if (e != hipSuccess) {
     if (f->arena) (void)hipFree(f->arena);
     dms_odometry_destroy(f->odom);
@@ -456,7 +493,9 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   Pose16 I;
   for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
   hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, 0, f->state, I);
-  (void)clear_zbuf(f->zbuf, p->width * p->height, 0);  // kept empty from here on: every resolve pass clears what it reads
+  (void)clear_zbuf(f->zbuf, p->width * p->height, 0);
+  for (int l = 0; l < DMS_NUM_PYRS; ++l)  // the INACTIVE ("old") prediction is never rendered with loop closure off: no depth anywhere
+    (void)hipMemsetD32((hipDeviceptr_t)f->kf_old_dmap[l].data, 0x7fffffff, (size_t)f->kf_old_dmap[l].rows * f->kf_old_dmap[l].cols);  // kept empty from here on: every resolve pass clears what it reads
   (void)hipDeviceSynchronize();
   memset(f->h_state, 0, 2 * sizeof(FrameState));
   *out = f;
@@ -476,6 +515,7 @@ int dms_fusion_destroy(dms_fusion* f) {
   if (f->s_prep) (void)hipStreamDestroy(f->s_prep);
   if (f->arena) (void)hipFree(f->arena);
   if (f->h_state) (void)hipHostFree(f->h_state);
+  if (f->nid_host) (void)hipHostFree(f->nid_host);
   dms_odometry_destroy(f->odom);
   dms_model_destroy(f->model);
   delete f;
@@ -604,16 +644,43 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     }
     hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
     DMS_CHECK_LAUNCH();
-    // "GlobalPredict" (ElasticFusion.cpp:273): its only consumers are the fern / loop-closure blocks,
-    // which this reference compiles out with `if (false)` (ElasticFusion.cpp:279, :593), and the
-    // final predict below overwrites every image it writes before the frame returns.
-    if (f->p.global_predict)
+    // "GlobalPredict" (ElasticFusion.cpp:273): its consumers are the NID key-framing gate below and the
+    // fern / loop-closure blocks, which this reference compiles out with `if (false)` (ElasticFusion.cpp:279,
+    // :593); the final predict overwrites every image it writes before the frame returns.
+    bool fuse_now = true;
+    if (f->p.global_predict || f->p.nid_keyframing)
       if ((rc = predict(f, f->p.confidence, s))) return rc;
+    if (f->p.nid_keyframing) {
+      // ElasticFusion::fuseFrame (ElasticFusion.cpp:639-677): candidate key frame = this prediction
+      // (KeyFrame.h:83-172: intensity of the image, verticesToDepth of the vertex map), reduced
+      // nid_pyramid_level times (MutualInformation.cpp:169-174), scored against the live pyramids
+      FTimer t(f, s, "nid");
+      const int L = f->p.nid_pyramid_level;
+      if ((rc = imageToIntensity(&f->pred.image, &f->kf_img[0], s))) return rc;
+      if ((rc = verticesToDepth((const float*)f->pred.vertex.data, &f->kf_dmap[0], f->p.maxDepthProcessed, s))) return rc;
+      for (int l = 1; l <= L; ++l) {
+        if ((rc = pyrDownUcharGauss(&f->kf_img[l - 1], &f->kf_img[l], s))) return rc;
+        if ((rc = pyrDownGaussF(&f->kf_dmap[l - 1], &f->kf_dmap[l], s))) return rc;
+      }
+      dms_image2d nextImg, nextD;
+      if ((rc = odometry_next_buffers(f->odom, L, &nextImg, &nextD))) return rc;
+      if ((rc = computeNIDImg(&f->kf_img[L], &f->kf_old_img[L], &f->kf_dmap[L], &f->kf_old_dmap[L], &nextImg, f->p.nid_bins_img, f->nid_ws,
+                              f->nid_ws_bytes, f->nid_host, nullptr, s)))
+        return rc;
+      if ((rc = computeNIDDepth(&f->kf_dmap[L], &f->kf_old_dmap[L], &nextD, f->p.nid_bins_depth, f->p.maxDepthProcessed * 1000.0f, f->nid_ws,
+                                f->nid_ws_bytes, f->nid_host + 1, nullptr, s)))
+        return rc;  // (both calls synchronise: the decision is taken on the host, as in the reference)
+      f->last_nid = (f->p.nid_depth_lambda * f->nid_host[1]) + ((1.0f - f->p.nid_depth_lambda) * f->nid_host[0]);
+      fuse_now = f->last_nid > f->p.nid_threshold;
+    } else {
+      f->last_nid = 0.f;
+    }
+    const int timeDeltaEff = f->p.timeDelta + f->frames_since_fusion;  // ElasticFusion.cpp:518,541,563
 
-    if (!f->p.rgbOnly) {  // fusion (ElasticFusion.cpp:506-564); NID gate off, tracking never "lost" without --rl
+    if (!f->p.rgbOnly && fuse_now) {  // fusion (ElasticFusion.cpp:506-564); tracking is never "lost" without --rl
       {
         FTimer t(f, s, "index_map");
-        if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
+        if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, timeDeltaEff, f->zbuf,
                             &f->imap, 1, 1, s)))
           return rc;
       }
@@ -625,19 +692,20 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
       }
       {
         FTimer t(f, s, "index_map");
-        if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, f->p.timeDelta, f->zbuf,
+        if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, timeDeltaEff, f->zbuf,
                             &f->imap, 1, 1, s)))
           return rc;
       }
       {
         FTimer t(f, s, "clean");
         if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, nullptr, 0,
-                              f->p.timeDelta, f->p.maxDepthProcessed, 0, 1, &f->state->surfels, s)))
+                              timeDeltaEff, f->p.maxDepthProcessed, 0, 1, &f->state->surfels, s)))
           return rc;
         surfels_written = true;  // the clean's scan also stores the new count into the result block
       }
       fused = 1;
     }
+    f->frames_since_fusion = fuse_now ? 0 : f->frames_since_fusion + 1;  // ElasticFusion.cpp:567-568
   }
   if ((rc = predict(f, f->p.confidence, s))) return rc;  // finalPredict (ElasticFusion.cpp:586)
   if (!surfels_written) {
@@ -673,6 +741,7 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   r->fused = f->fused_last;
   r->fill_in = hs->fill_in;
   r->weighting = hs->weighting;
+  r->nid_score = f->last_nid;
   return DMS_OK;
 }
 

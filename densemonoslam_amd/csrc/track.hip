@@ -2106,6 +2106,14 @@ void odometry_alias_next_depth(dms_odometry* o) {
   for (int i = 0; i < DMS_NUM_PYRS; ++i) o->nextDepth[i] = o->lastDepth[i];
 }
 
+// views of the live intensity and depth pyramids at `level` (RGBDOdometry::nextImg / nextD, RGBDOdometry.h:79-87)
+int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth) {
+  DMS_REQUIRE(o && level >= 0 && level < DMS_NUM_PYRS, "bad argument");
+  if (nextImage) *nextImage = o->nextImage[level].img();
+  if (nextDepth) *nextDepth = o->nextDepth[level].img();
+  return DMS_OK;
+}
+
 // initICPModel + initRGBModel of the frame step in four launches (prep.hip, modelPyramidFused).
 // The operator-layer staging copy vmaps_tmp is not written on this path; nextDepth is aliased to
 // lastDepth by the caller, so nothing reads it.

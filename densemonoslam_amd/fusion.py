@@ -36,13 +36,15 @@ class FusionParams(C.Structure):
         ("hybrid_tracking", C.c_int), ("rgbOnly", C.c_int), ("timeIdx", C.c_int),
         ("maxDepthProcessed", C.c_float), ("model_capacity", C.c_size_t),
         ("pipeline_ingest", C.c_int), ("global_predict", C.c_int),
+        ("nid_keyframing", C.c_int), ("nid_threshold", C.c_float), ("nid_depth_lambda", C.c_float), ("nid_bins_img", C.c_int),
+        ("nid_bins_depth", C.c_int), ("nid_pyramid_level", C.c_int),
     ]
 
 
 class FrameResult(C.Structure):
     _fields_ = [
         ("pose", C.c_float * 16), ("surfels", C.c_uint), ("tick", C.c_int), ("fused", C.c_int), ("fill_in", C.c_int),
-        ("weighting", C.c_float), ("track", TrackResult),
+        ("weighting", C.c_float), ("nid_score", C.c_float), ("track", TrackResult),
     ]
 
 

@@ -153,6 +153,17 @@ typedef struct dms_fusion_params {
   int global_predict;        /* 1: also run the post-tracking "GlobalPredict" (ElasticFusion.cpp:273), whose
                                 consumers (ferns / loop closure) the reference compiles out; its images are
                                 overwritten by the final predict either way.  Default 0. */
+  /* NID key-framing gate of ElasticFusion::fuseFrame (ElasticFusion.cpp:639-677); 0 = off (--nkf).
+   * When on, the post-tracking prediction is compared with the live frame (dms_computeNIDImg /
+   * dms_computeNIDDepth at pyramid level nid_pyramid_level) and the fusion half runs only when
+   * nid_depth_lambda * nid_depth + (1 - nid_depth_lambda) * nid_img > nid_threshold.  The decision is
+   * taken on the host, as in the reference: the frame synchronises once mid-way (no pipelining). */
+  int nid_keyframing;
+  float nid_threshold;       /* 0.80 (ElasticFusion.h:73) */
+  float nid_depth_lambda;    /* 0.7 */
+  int nid_bins_img;          /* 64 */
+  int nid_bins_depth;        /* 500 */
+  int nid_pyramid_level;     /* 0 */
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
@@ -168,6 +179,7 @@ typedef struct dms_frame_result {
   int fused;               /* 1 when the fusion half ran */
   int fill_in;             /* shouldFillIn decision (ElasticFusion.cpp:167) */
   float weighting;         /* velocity weight (ElasticFusion.cpp:252-268) */
+  float nid_score;         /* Context::nidScores().back() (0 with key-framing off) */
   dms_track_result track;  /* tracker side outputs */
 } dms_frame_result;
 

@@ -2,14 +2,14 @@
 the oracle's C functions (oracle/orc_*.c) with host arrays.
 
 Follows elasticfusion/Core/src/ElasticFusion.cpp:99-637 with loop closure off (--o: the
-`closeLoops` block :399-497 is skipped), NID keyframing off (--nkf: fuseFrame returns true,
-:639-645), no relocalisation (--rl off: trackingOk is always true, :204-244), cluster 0.
+`closeLoops` block :399-497 is skipped), NID keyframing off by default (--nkf: fuseFrame returns
+true, :639-645; nid_keyframing=True restates the gate of :646-675), no relocalisation (--rl off: trackingOk is always true, :204-244), cluster 0.
 The deformation graph is empty (it is only filled by loop closures), so clean() runs without
 nodes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 import numpy as np
 
-from . import orc
+from . import orc, orc_nid
 
 
 class Frame:
@@ -19,13 +19,18 @@ class Frame:
 class ElasticFusion:
     def __init__(self, width, height, K, timeDelta=200, confidence=10.0, depthCut=3.0, icpWeight=10.0, fastOdom=False, so3=True,
                  frameToFrameRGB=False, pyramid=True, hybrid_tracking=True, rgbOnly=False, timeIdx=0, maxDepthProcessed=25.0,
-                 model_capacity=None):
+                 model_capacity=None, nid_keyframing=False, nid_threshold=0.80, nid_depth_lambda=0.7, nid_bins_img=64,
+                 nid_bins_depth=500, nid_pyramid_level=0):
         self.W, self.H, self.K = width, height, tuple(float(v) for v in K)
         self.timeDelta, self.confidence, self.depthCut, self.icpWeight = timeDelta, confidence, depthCut, icpWeight
         self.fastOdom, self.so3, self.frameToFrameRGB, self.pyramid = fastOdom, so3, frameToFrameRGB, pyramid
         self.hybrid_tracking, self.rgbOnly, self.timeIdx = hybrid_tracking, rgbOnly, timeIdx
         self.maxDepthProcessed = maxDepthProcessed
         self.cap = model_capacity
+        self.nid_keyframing, self.nid_threshold, self.nid_depth_lambda = nid_keyframing, nid_threshold, nid_depth_lambda
+        self.nid_bins_img, self.nid_bins_depth, self.nid_pyramid_level = nid_bins_img, nid_bins_depth, nid_pyramid_level
+        self.framesSinceLastFusion = 0
+        self.nidScores = []
         fx, fy, cx, cy = self.K
         self.frameToModel = orc.Odometry(width, height, cx, cy, fx, fy)
         self.model = np.zeros(0, orc.SURFEL_DTYPE)
@@ -42,6 +47,26 @@ class ElasticFusion:
         self.pred = (img, vtx, nrm, tim)
         self.fill = (fi, fv, fn)
 
+    # ElasticFusion::fuseFrame (:639-677): the candidate key frame is the model prediction at the new
+    # pose (GlobalPredict, :273); its "old" (INACTIVE) textures are never rendered with loop closure
+    # off, i.e. no prediction anywhere (NaN depth, black image)
+    def fuseFrame(self):
+        if not self.nid_keyframing:
+            self.nidScores.append(0.0)
+            return True, 0.0
+        img = orc.imageBGRToIntensity(self.pred[0])
+        dmap = orc.verticesToDepth(self.pred[1], self.maxDepthProcessed)
+        for _ in range(self.nid_pyramid_level):  # MutualInformation::nidImg (:169-174)
+            img, dmap = orc.pyrDownUcharGauss(img), orc.pyrDownGaussF(dmap)
+        old_img = np.zeros_like(img)
+        old_d = np.full_like(dmap, np.nan)
+        L = self.nid_pyramid_level
+        nid_img, _ = orc_nid.nid_img(img, old_img, dmap, old_d, self.frameToModel.buffer(7, L), self.nid_bins_img)
+        nid_depth, _ = orc_nid.nid_depth(dmap, old_d, self.frameToModel.buffer(5, L), self.nid_bins_depth, self.maxDepthProcessed * 1000.0)
+        score = float(np.float32(self.nid_depth_lambda) * nid_depth + (np.float32(1.0) - np.float32(self.nid_depth_lambda)) * nid_img)
+        self.nidScores.append(score)
+        return score > self.nid_threshold, score
+
     def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         if rgb.shape[2] == 3:
@@ -56,6 +81,7 @@ class ElasticFusion:
         out.fill_in = False
         out.weighting = 1.0
         out.track = None
+        out.nid_score = 0.0
         fused = False
         if not self.initialised:  # first run (:132-152)
             pose = np.eye(4, dtype=np.float32) if inPose is None else np.asarray(inPose, np.float32).reshape(4, 4)
@@ -87,18 +113,19 @@ class ElasticFusion:
             weighting = orc.velocity_weight(self.currPose, lastPose, weightMultiplier)  # :252-268
             out.weighting = weighting
             self.predict(self.confidence)  # :273
-            if not self.rgbOnly:  # fusion (:506-564)
-                im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed,
-                                   self.timeDelta)
+            fuse, out.nid_score = self.fuseFrame()  # :501
+            td = self.timeDelta + self.framesSinceLastFusion  # :518,:541,:563
+            if not self.rgbOnly and fuse:  # fusion (:506-564)
+                im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
                 self.model, newU, _ = orc.model_fuse(self.model, self.currPose, self.tick, self.timeIdx, self.rgba, self.depth_metric,
                                                      self.depth_metric_filtered, im[0], im[1], im[3], self.K, self.maxDepthProcessed,
                                                      weighting)
-                im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed,
-                                   self.timeDelta)
+                im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
                 self.imap = im
                 self.model = orc.model_clean(self.model, newU, self.currPose, self.tick, self.timeIdx, im[0], im[1], im[2], self.K,
-                                             self.confidence, self.timeDelta, self.maxDepthProcessed, cap=self.cap)
+                                             self.confidence, td, self.maxDepthProcessed, cap=self.cap)
                 fused = True
+            self.framesSinceLastFusion = 0 if fuse else self.framesSinceLastFusion + 1  # :567-568
         self.predict(self.confidence)  # finalPredict (:586)
         self.tick += 1  # :588-591
         out.pose = self.currPose.copy()

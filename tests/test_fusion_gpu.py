@@ -415,6 +415,44 @@ def test_process_frame_pipelined_equals_serial(fus, synth):
         assert_bits(got[4], ref[4], "filtered depth " + what)
 
 
+def test_nid_keyframing_gate(fus, orc, synth):
+    """ElasticFusion::fuseFrame with NID key-framing on (SURVEY 8(f3)): per-frame score and
+    fuse / skip decision against the oracle pipeline (teacher-forced map and pose), including the
+    widened time window after skipped frames."""
+    from oracle import orc_pipeline
+
+    scores = []
+    for thr in (0.0, 2.0):  # always fuse / never fuse (nid <= 1): both branches, then a mid threshold from the scores seen
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, nid_keyframing=1, nid_threshold=thr)
+        o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000, nid_keyframing=True, nid_threshold=thr)
+        for k in range(4):
+            d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+            rg, ro = g.processFrame(rgb, d), o.processFrame(rgb, d)
+            if k > 0:
+                assert abs(rg.nid_score - ro.nid_score) < 2e-4, (k, rg.nid_score, ro.nid_score)
+                assert bool(rg.fused) == ro.fused == (thr == 0.0)
+                scores.append(rg.nid_score)
+            assert abs(int(rg.surfels) - ro.surfels) <= max(10, 2e-3 * ro.surfels)
+            o.model = g.globalModel().downloadMap()
+            o.currPose = np.array(rg.pose, np.float32).reshape(4, 4)
+    assert all(0.0 < s_ <= 1.0 for s_ in scores)
+    thr = float(np.median(scores))
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000, nid_keyframing=1, nid_threshold=thr)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000, nid_keyframing=True, nid_threshold=thr)
+    decisions = []
+    for k in range(6):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg, ro = g.processFrame(rgb, d), o.processFrame(rgb, d)
+        if k > 0 and abs(ro.nid_score - thr) > 1e-3:  # away from the threshold the decisions must agree
+            assert bool(rg.fused) == ro.fused, (k, rg.nid_score, ro.nid_score, thr)
+        decisions.append(bool(rg.fused))
+        mg = g.globalModel().downloadMap()
+        if bool(rg.fused) == ro.fused:
+            assert abs(len(mg) - ro.surfels) <= max(10, 2e-3 * ro.surfels)
+        o.model, o.currPose = mg, np.array(rg.pose, np.float32).reshape(4, 4)
+        o.framesSinceLastFusion = 0 if rg.fused else o.framesSinceLastFusion  # keep the counters aligned when a borderline decision differed
+
+
 def test_global_predict_is_dead_work(fus, synth):
     """The reference's post-tracking "GlobalPredict" (ElasticFusion.cpp:273) feeds only blocks the
     fork compiles out and is overwritten by the final predict: running it (global_predict = 1)
