@@ -8,6 +8,10 @@ per-frame exchange is the all-gather of each camera's W/8 x H/8 thumbnails (imag
 normal maps), the inputs of the fern matcher (Core/src/Ferns.cpp:277-423) — SURVEY.md §8(e).
 `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests)
 carries it; PyTorch is plumbing here, not the product.
+
+A map merge (GlobalModel::consume, SURVEY §8(f1)) is the one bulk transfer: the consumed map travels
+once, point to point, as packed 80-byte surfel records (`send_map` / `recv_map`): 2 M surfels =
+160 MB, about 1 ms on one xGMI link; no collective is involved.
 """
 import torch
 import torch.distributed as dist
@@ -57,3 +61,38 @@ def sum_over_ranks(value, device):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+RECORD_FLOATS = 20  # pos4 col4 nrm4 times8: the dms_model_download / dms_model_export_records layout
+
+
+def send_map(records, count, dst):
+    """Point-to-point send of `count` surfel records (float32 tensor [>= count, 20]) to rank `dst`.
+    The count goes first so the receiver can size its buffer; both messages use the tensor's device
+    (RCCL p2p over xGMI for device tensors)."""
+    hdr = torch.tensor([int(count)], dtype=torch.int64, device=records.device)
+    dist.send(hdr, dst)
+    if count:
+        dist.send(records[:count].contiguous().view(-1), dst)
+
+
+def recv_map(src, device):
+    """Counterpart of send_map: returns (float32 tensor [count, 20] on `device`, count)."""
+    hdr = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(hdr, src)
+    count = int(hdr.item())
+    rec = torch.empty((max(count, 1), RECORD_FLOATS), dtype=torch.float32, device=device)
+    if count:
+        dist.recv(rec[:count].view(-1), src)
+    return rec, count
+
+
+def merge_remote_map(model, src, relative_transform, device):
+    """Receive the map rank `src` sends with send_map and append it to `model` (a fusion.GlobalModel)
+    moved by the 4x4 `relative_transform` — the consuming side of ReferenceFrame::consumeReferenceFrame."""
+    rec, count = recv_map(src, device)
+    if count:
+        torch.cuda.synchronize(device) if rec.is_cuda else None
+        model.consumeRecords(rec.data_ptr(), count, relative_transform)
+    return count
+

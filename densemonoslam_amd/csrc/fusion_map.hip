@@ -525,6 +525,135 @@ int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, i
 }
 
 // ---------------------------------------------------------------------------------------
+// Map merge: GlobalModel::consume (GlobalModel.cpp:898-993) + consume.vert — the
+// consuming map keeps its surfels (identity transform) and appends the other map's surfels moved by
+// the relative transform: pos = T * (x, y, z, 1) with the confidence kept, normal = mat3(T) * n with
+// the radius kept, colour and all per-sensor times unchanged.  The reference re-streams both maps
+// through transform feedback into the other buffer; appending in place moves only the consumed
+// map.  Sources: another model on this device, or a packed device buffer of 20-float records
+// (pos4 col4 nrm4 times8, the dms_model_download layout) as received from another rank.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void consume_store(const SurfelPlanes& dst, size_t cap, size_t at, const float* T, const float4 p, const float4 c,
+                                              const float4 n, const float (&tm)[DMS_MAX_SENSORS]) {
+  // GLSL `transform * vec4(v, 1)`: row i = ((T_i0 x + T_i1 y) + T_i2 z) + T_i3 (row-major T here)
+  const f3 q = xform_point(T, mk3(p.x, p.y, p.z));
+  const f3 m = xform_dir(T, mk3(n.x, n.y, n.z));
+  dst.pos[at] = make_float4(q.x, q.y, q.z, p.w);
+  dst.col[at] = c;
+  dst.nrm[at] = make_float4(m.x, m.y, m.z, n.w);
+#pragma unroll
+  for (int k = 0; k < DMS_MAX_SENSORS; ++k) dst.times[(size_t)k * cap + at] = tm[k];
+}
+
+struct Pose16v {
+  float v[16];
+};
+
+__global__ __launch_bounds__(256) void k_consume_model(SurfelPlanes dst, size_t dcap, const unsigned* __restrict__ dcount, unsigned* __restrict__ dcount_new,
+                                                       SurfelPlanes src, size_t scap, const unsigned* __restrict__ scount, Pose16v T) {
+  const unsigned base = dcount[0], ns = scount[0];
+  const unsigned room = base < dcap ? (unsigned)(dcap - base) : 0u;
+  const unsigned n = ns < room ? ns : room;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    float tm[DMS_MAX_SENSORS];
+#pragma unroll
+    for (int k = 0; k < DMS_MAX_SENSORS; ++k) tm[k] = src.times[(size_t)k * scap + i];
+    consume_store(dst, dcap, (size_t)base + i, T.v, src.pos[i], src.col[i], src.nrm[i], tm);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) dcount_new[0] = base + n;
+}
+
+__global__ __launch_bounds__(256) void k_consume_records(SurfelPlanes dst, size_t dcap, const unsigned* __restrict__ dcount, unsigned* __restrict__ dcount_new,
+                                                         const float* __restrict__ rec, unsigned ns, Pose16v T) {
+  const unsigned base = dcount[0];
+  const unsigned room = base < dcap ? (unsigned)(dcap - base) : 0u;
+  const unsigned n = ns < room ? ns : room;
+  constexpr int stride = 12 + DMS_MAX_SENSORS;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    const float4* r = reinterpret_cast<const float4*>(rec + (size_t)i * stride);  // 80-byte records: 16-byte aligned
+    float tm[DMS_MAX_SENSORS];
+#pragma unroll
+    for (int k = 0; k < DMS_MAX_SENSORS; k += 4) {
+      const float4 t4 = r[3 + k / 4];
+      tm[k] = t4.x;
+      tm[k + 1] = t4.y;
+      tm[k + 2] = t4.z;
+      tm[k + 3] = t4.w;
+    }
+    consume_store(dst, dcap, (size_t)base + i, T.v, r[0], r[1], r[2], tm);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) dcount_new[0] = base + n;
+}
+
+// pack the map into 20-float records in a device buffer (the device-side form of dms_model_download)
+__global__ __launch_bounds__(256) void k_export_records(SurfelPlanes src, size_t scap, const unsigned* __restrict__ scount, unsigned max_count,
+                                                        float* __restrict__ rec, unsigned* __restrict__ written) {
+  const unsigned ns = scount[0];
+  const unsigned n = ns < max_count ? ns : max_count;
+  constexpr int stride = 12 + DMS_MAX_SENSORS;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    float4* r = reinterpret_cast<float4*>(rec + (size_t)i * stride);
+    r[0] = src.pos[i];
+    r[1] = src.col[i];
+    r[2] = src.nrm[i];
+#pragma unroll
+    for (int k = 0; k < DMS_MAX_SENSORS; k += 4)
+      r[3 + k / 4] = make_float4(src.times[(size_t)k * scap + i], src.times[(size_t)(k + 1) * scap + i], src.times[(size_t)(k + 2) * scap + i],
+                                 src.times[(size_t)(k + 3) * scap + i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) written[0] = n;
+}
+
+static int consume_finish(dms_model* m, size_t added_upper) {
+  std::swap(m->d_count, m->d_count_alt);  // the kernel wrote the new count into the other cell
+  const size_t upper = m->count_upper + added_upper;
+  m->count_upper = upper < m->cap ? upper : m->cap;
+  m->count_hold = 3;
+  return DMS_OK;
+}
+
+int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStream_t s) {
+  DMS_REQUIRE(dst && src && T16 && dst != src, "bad argument");
+  if (dst->count_upper + src->count_upper > dst->cap) {
+    set_error("dms_model_consume: %zu + %zu surfels may exceed the capacity %zu", dst->count_upper, src->count_upper, dst->cap);
+    return DMS_ERR_CAPACITY;
+  }
+  Pose16v T;
+  memcpy(T.v, T16, sizeof(T.v));
+  hipLaunchKernelGGL(k_consume_model, dim3(surfel_grid(src->count_upper)), dim3(256), 0, s, dst->buf[dst->cur], dst->cap, dst->d_count,
+                     dst->d_count_alt, src->buf[src->cur], src->cap, src->d_count, T);
+  DMS_CHECK_LAUNCH();
+  return consume_finish(dst, src->count_upper);
+}
+
+int model_consume_records(dms_model* dst, const float* rec_dev, unsigned n, const float* T16, hipStream_t s) {
+  DMS_REQUIRE(dst && T16 && (rec_dev || n == 0), "bad argument");
+  DMS_REQUIRE(((uintptr_t)rec_dev & 15) == 0, "record buffer must be 16-byte aligned");
+  if (dst->count_upper + n > dst->cap) {
+    set_error("dms_model_consume_records: %zu + %u surfels may exceed the capacity %zu", dst->count_upper, n, dst->cap);
+    return DMS_ERR_CAPACITY;
+  }
+  Pose16v T;
+  memcpy(T.v, T16, sizeof(T.v));
+  hipLaunchKernelGGL(k_consume_records, dim3(surfel_grid(n)), dim3(256), 0, s, dst->buf[dst->cur], dst->cap, dst->d_count, dst->d_count_alt,
+                     rec_dev, n, T);
+  DMS_CHECK_LAUNCH();
+  return consume_finish(dst, n);
+}
+
+int model_export_records(dms_model* m, float* rec_dev, unsigned max_count, unsigned* count_host, hipStream_t s) {
+  DMS_REQUIRE(m && rec_dev && count_host, "null argument");
+  DMS_REQUIRE(((uintptr_t)rec_dev & 15) == 0, "record buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(k_export_records, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, m->buf[m->cur], m->cap, m->d_count, max_count,
+                     rec_dev, m->d_count_alt + 1);
+  DMS_CHECK_LAUNCH();
+  DMS_HIP(hipMemcpyAsync(m->h_count, m->d_count_alt + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  *count_host = m->h_count[0];
+  return DMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // G6 / G6': splat prediction (splat.vert:57-94, combo_splat.frag:35-60, depth_splat.frag:29-46)
 // ---------------------------------------------------------------------------------------
 struct SplatSurfel {
@@ -697,3 +826,15 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
 }
 
 }  // namespace dms
+
+extern "C" {
+int dms_model_consume(dms_model* dst, const dms_model* src, const float* relativeTransform16, dms_stream s) {
+  return dms::model_consume(dst, src, relativeTransform16, (hipStream_t)s);
+}
+int dms_model_consume_records(dms_model* dst, const float* records_dev, unsigned int count, const float* relativeTransform16, dms_stream s) {
+  return dms::model_consume_records(dst, records_dev, count, relativeTransform16, (hipStream_t)s);
+}
+int dms_model_export_records(dms_model* m, float* records_dev, unsigned int max_count, unsigned int* count, dms_stream s) {
+  return dms::model_export_records(m, records_dev, max_count, count, (hipStream_t)s);
+}
+}

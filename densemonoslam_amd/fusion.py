@@ -55,6 +55,9 @@ lib.dms_model_create.argtypes = [C.POINTER(_P), C.c_size_t, _I, _I]
 lib.dms_model_destroy.argtypes = [_P]
 lib.dms_model_count.argtypes = [_P, C.POINTER(C.c_uint), _P]
 lib.dms_model_capacity.argtypes = [_P]
+lib.dms_model_consume.argtypes = [_P, _P, C.POINTER(C.c_float), _P]
+lib.dms_model_export_records.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_uint), _P]
+lib.dms_model_consume_records.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_float), _P]
 lib.dms_model_capacity.restype = C.c_size_t
 lib.dms_model_download.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_uint), _P]
 lib.dms_model_upload.argtypes = [_P, _P, C.c_uint, _P]
@@ -211,6 +214,32 @@ class GlobalModel:
         got = C.c_uint(0)
         check(lib.dms_model_download_ref(self.h, out.ctypes.data_as(C.c_void_p), n, C.byref(got), None), "dms_model_download_ref")
         return out[:got.value].copy()
+
+    # -- map merge (GlobalModel::consume) ----------------------------------------------------
+    @staticmethod
+    def _T(relativeTransform):
+        t = np.ascontiguousarray(relativeTransform, np.float32).reshape(16)
+        return t, t.ctypes.data_as(C.POINTER(C.c_float))
+
+    def consume(self, other, relativeTransform):
+        """Append `other`'s surfels moved by relativeTransform (4x4); `other` is left untouched."""
+        keep, tp = self._T(relativeTransform)
+        check(lib.dms_model_consume(self.h, other.h, tp, None), "dms_model_consume")
+        check(lib.dms_stream_sync(None))
+
+    def exportRecords(self, max_count=None):
+        """(DeviceBuffer of 20-float records, count): the device-side form of downloadMap, for p2p transfers."""
+        cap = int(lib.dms_model_capacity(self.h)) if max_count is None else int(max_count)
+        n_now = min(self.lastCount(), cap)
+        buf = DeviceBuffer(max(n_now, 1) * SURFEL_DTYPE.itemsize)
+        n = C.c_uint(0)
+        check(lib.dms_model_export_records(self.h, C.c_void_p(buf.ptr), n_now, C.byref(n), None), "dms_model_export_records")
+        return buf, n.value
+
+    def consumeRecords(self, records_ptr, count, relativeTransform):
+        keep, tp = self._T(relativeTransform)
+        check(lib.dms_model_consume_records(self.h, C.c_void_p(records_ptr), count, tp, None), "dms_model_consume_records")
+        check(lib.dms_stream_sync(None))
 
     def initialise(self, rgba, depth_metric, depth_metric_filtered, K, time, timeIdx, maxDepth):
         c, dm, dmf = _img(rgba, np.uint8), _img(depth_metric, np.float32), _img(depth_metric_filtered, np.float32)

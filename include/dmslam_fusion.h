@@ -58,6 +58,18 @@ int dms_depth_metric(const dms_image2d* depth_u16, dms_image2d* metric_f32, floa
 /* G3+G4 vertex_feedback.{vert,geom} + init_unstable.vert: first-frame surfels
  * (FeedbackBuffer::compute, FeedbackBuffer.cpp:84-143; GlobalModel::initialise, GlobalModel.cpp:266-417).
  * Appends nothing: (re)initialises the map from one frame; surfels are emitted in column-major pixel order. */
+/* Map merge: GlobalModel::consume (GlobalModel.cpp:898-993, consume.vert).  `dst` keeps its
+ * surfels and appends those of `src` moved by the row-major 4x4 `relativeTransform16` (host pointer):
+ * position transformed, normal rotated, confidence / radius / colour / per-sensor times unchanged.
+ * DMS_ERR_CAPACITY when the sum may not fit.  The *_records forms move a map between devices or ranks:
+ * export packs the map into 20-float records (pos4 col4 nrm4 times8, the dms_model_download layout) in
+ * a 16-byte aligned device buffer (e.g. a tensor handed to an RCCL send), consume_records appends such
+ * a buffer (e.g. just received). */
+int dms_model_consume(dms_model* dst, const dms_model* src, const float* relativeTransform16, dms_stream s);
+int dms_model_export_records(dms_model* m, float* records_dev, unsigned int max_count, unsigned int* count, dms_stream s);
+int dms_model_consume_records(dms_model* dst, const float* records_dev, unsigned int count, const float* relativeTransform16,
+                              dms_stream s);
+
 int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* depth_metric,
                          const dms_image2d* depth_metric_filtered, const dms_camera* cam, int time, int timeIdx,
                          float maxDepth, dms_stream s);

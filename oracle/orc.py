@@ -438,6 +438,20 @@ def model_clean(model, newU, pose, time, timeIdx, index, vertConf, colorTime, ca
     return out[:n].copy()
 
 
+def model_consume(dst, src, relativeTransform):
+    """GlobalModel::consume (GlobalModel.cpp:898-993) with consume.vert: dst ++ transform(src); position
+    through the 4x4 (fp32, ((T0 x + T1 y) + T2 z) + T3), normal through its 3x3, everything else kept."""
+    T = np.asarray(relativeTransform, np.float32).reshape(4, 4)
+    out = np.concatenate([dst, src]).copy()
+    m = out[len(dst):]
+    p = src["pos"].astype(np.float32)
+    n = src["nrm"].astype(np.float32)
+    for i in range(3):
+        m["pos"][:, i] = ((T[i, 0] * p[:, 0] + T[i, 1] * p[:, 1]) + T[i, 2] * p[:, 2]) + T[i, 3]
+        m["nrm"][:, i] = (T[i, 0] * n[:, 0] + T[i, 1] * n[:, 1]) + T[i, 2] * n[:, 2]
+    return out
+
+
 def fill_in(exVertex, exNormal, exImage, depth, rgba, cam, passGeom, passRgb):
     exVertex, exNormal = _c(exVertex, np.float32), _c(exNormal, np.float32)
     exImage, rgba, depth = _c(exImage, np.uint8), _c(rgba, np.uint8), _c(depth, np.uint16)

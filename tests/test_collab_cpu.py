@@ -74,6 +74,61 @@ def test_two_rank_thumbnail_allgather_gloo():
         assert tmax == 1.5 and tsum == 21.0
 
 
+def _merge_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from densemonoslam_amd import collab
+    from oracle import orc
+
+    rng = np.random.default_rng(100 + rank)
+    n = 1000 + 500 * rank
+    m = np.zeros(n, orc.SURFEL_DTYPE)
+    for k in ("pos", "col", "nrm", "times"):
+        m[k] = rng.normal(size=m[k].shape).astype(np.float32)
+    rec = torch.from_numpy(m.view(np.float32).reshape(n, collab.RECORD_FLOATS).copy())
+    if rank == 1:  # rank 1's map is consumed by rank 0
+        collab.send_map(rec, n, 0)
+        out.put((rank, m, None))
+    else:
+        got, count = collab.recv_map(1, torch.device("cpu"))
+        theirs = got[:count].numpy().copy().view(orc.SURFEL_DTYPE).reshape(count)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = (1.0, 2.0, 3.0)
+        out.put((rank, m, orc.model_consume(m, theirs, T)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_map_merge_transfer_gloo():
+    """The map-merge transfer of the collaborative mode: rank 1 sends its map as packed records, rank 0
+    receives it and consumes it (oracle consume on the CPU; the HIP consume is tested on the GPU)."""
+    from oracle import orc
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, own, merged = q.get(timeout=180)
+        res[rank] = (own, merged)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    own0, merged = res[0]
+    own1, _ = res[1]
+    assert len(merged) == len(own0) + len(own1)
+    assert (merged[:len(own0)].view(np.uint32) == own0.view(np.uint32)).all()
+    tail = merged[len(own0):]
+    assert np.array_equal(tail["col"], own1["col"]) and np.array_equal(tail["times"], own1["times"])
+    assert np.allclose(tail["pos"][:, :3], own1["pos"][:, :3] + np.array([1, 2, 3], np.float32), atol=1e-6)
+    assert np.array_equal(tail["pos"][:, 3], own1["pos"][:, 3]) and np.array_equal(tail["nrm"], own1["nrm"])
+
+
 def test_camera_sharding():
     from densemonoslam_amd import collab
 

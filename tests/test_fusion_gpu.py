@@ -415,6 +415,47 @@ def test_process_frame_pipelined_equals_serial(fus, synth):
         assert_bits(got[4], ref[4], "filtered depth " + what)
 
 
+def test_map_merge_consume(fus, orc, synth):
+    """GlobalModel::consume (SURVEY 8(f1)): the consuming map keeps its surfels and appends the other
+    map's, moved by the relative transform — model-to-model on one device and through the packed
+    record buffer used for rank-to-rank transfers; bit-exact against the oracle, capacity checked."""
+    from densemonoslam_amd import capi
+
+    maps = []
+    for cam in (0, 1):
+        d, rgb, _ = synth.frame(3, cam_id=cam, width=W, height=H, K=K, noise=True)
+        g = fus.ElasticFusion(W, H, K, model_capacity=400000, timeIdx=cam)
+        g.processFrame(rgb, d)
+        maps.append(g)
+    a, b = maps[0].globalModel(), maps[1].globalModel()
+    ma, mb = a.downloadMap(), b.downloadMap()
+    assert len(ma) > 50000 and len(mb) > 50000
+    ang = 0.3
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    T[:3, 3] = (0.4, -0.1, 0.25)
+    want = orc.model_consume(ma, mb, T)
+    # through the record buffer (what a rank receives over RCCL)
+    rec, n = b.exportRecords()
+    assert n == len(mb)
+    host = rec.download(np.float32, (n, 20))
+    assert (host.view(np.uint32) == mb.view(np.uint32).reshape(n, 20)).all()
+    c = fus.GlobalModel(W, H, capacity=len(ma) + len(mb) + 10)
+    c.upload(ma)
+    c.consumeRecords(rec.ptr, n, T)
+    surfels_equal(c.downloadMap(), want, "consume through records")
+    # model to model, then the merged map keeps working: index map of the merged map vs oracle
+    a.consume(b, T)
+    merged = a.downloadMap()
+    surfels_equal(merged, want, "consume model to model")
+    surfels_equal(b.downloadMap(), mb, "consumed map untouched")
+    # capacity
+    small = fus.GlobalModel(W, H, capacity=len(ma) + 5)
+    small.upload(ma)
+    with pytest.raises(capi.DmsError):
+        small.consume(b, T)
+
+
 def test_nid_keyframing_gate(fus, orc, synth):
     """ElasticFusion::fuseFrame with NID key-framing on (SURVEY 8(f3)): per-frame score and
     fuse / skip decision against the oracle pipeline (teacher-forced map and pose), including the
