@@ -117,6 +117,8 @@ class GlobalModel {
     v.resize((size_t)got * 15);
     return v;
   }
+  // GlobalModel::consume (GlobalModel.cpp:898-993): append `other` moved by the row-major 4x4 relativeTransform
+  void consume(GlobalModel& other, const float* relativeTransform16) { check(dms_model_consume(h, other.h, relativeTransform16, nullptr), "consume"); }
   dms_model* h = nullptr;
 
  private:
@@ -140,6 +142,8 @@ class ElasticFusion {
     p.frameToFrameRGB = frameToFrameRGB;
     check(dms_fusion_create(&h, &p), "dms_fusion_create");
   }
+  // every option of dms_fusion_params (NID key-framing --nid/--ndw/--npl, hybrid tracking, pipelining ...)
+  explicit ElasticFusion(const dms_fusion_params& p) { check(dms_fusion_create(&h, &p), "dms_fusion_create"); }
   virtual ~ElasticFusion() { dms_fusion_destroy(h); }
   ElasticFusion(const ElasticFusion&) = delete;
 

@@ -1,9 +1,9 @@
 // Operator-layer reduction steps of the tracker: icpStep, rgbStep, computeRgbResidual,
 // so3Step (reference Cuda/reduce.cu).  Each is a grid-stride pass of 256-thread blocks that
-// accumulates per-thread running sums, reduces them per wave with DPP, per block through a
-// 4×NV LDS tile, and writes one SoA column of partials; a single 1024-thread block then
-// folds the columns (one wave per quantity, coalesced row reads).  No float atomics: the
-// summation order is fixed by the launch shape, so results are deterministic.
+// accumulates per-thread running sums, reduces them per wave with a step-major DPP butterfly,
+// across the 4 waves in fp64, and writes one 128-byte record per block; a single 256-thread
+// block then folds the records in fp64 with batched 16-byte loads (common.hpp).  No float
+// atomics: the summation order is fixed by the launch shape, so results are deterministic.
 #include "pixel_ops.hpp"
 
 namespace dms {

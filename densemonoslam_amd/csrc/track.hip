@@ -803,9 +803,8 @@ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, con
 // photometric term)
 __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
                               const SolveArgs q) {
-  const int icp = q.icp, rgb = q.rgb, rgbOnly = q.rgbOnly, level = q.level, first_iter = q.first_iter, next_level = q.next_level,
-            level_below = q.level_below;
-  const float icpWeight = q.icpWeight, fx = q.fx, fy = q.fy, cx = q.cx, cy = q.cy;
+  const int icp = q.icp, rgb = q.rgb, rgbOnly = q.rgbOnly, level = q.level, first_iter = q.first_iter, level_below = q.level_below;
+  const float fx = q.fx, fy = q.fy, cx = q.cx, cy = q.cy;
   __shared__ float s_icp[kSE3];
   __shared__ float s_rgb[kSE3];
   __shared__ int s_cnt[2];
