@@ -716,29 +716,89 @@ __device__ __forceinline__ void sprite_range(float c, float size, int n, int& lo
   if (hi > n - 1) hi = n - 1;
 }
 
+// Sprite sizes differ by up to 3x inside a wave (5x5 ... 9x9 pixels), so "one thread rasterises its
+// surfel" leaves ~55 % of the lanes idle in a loop that is instruction bound.  Here a block runs the
+// vertex stage for 256 surfels, parks their parameters in LDS, and then hands out sprite ROWS to
+// threads (prefix sum of the row counts + binary search): a thread's trip count is one sprite width,
+// and the rows of a large sprite are spread over many threads.  The winners are decided by 64-bit
+// atomicMin, so the work order does not matter.
 __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
                                                        unsigned long long* __restrict__ zbuf) {
+  __shared__ float s_par[7][256];   // pos.xyz, nrm.xyz, rad
+  __shared__ int s_box[3][256];     // x0, width, y0
+  __shared__ unsigned s_off[257];   // exclusive prefix of the row counts
+  __shared__ unsigned s_w[4];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const unsigned M = d_count[0];
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += blockDim.x * gridDim.x) {
-    SplatSurfel s;
-    if (!splat_vertex(a, sp.pos[i], sp.nrm[i], sp.times[(size_t)a.timeIdx * cap + i], s)) continue;
-    if (!(s.size == s.size)) continue;  // NaN size: no fragments
-    int x0, x1, y0, y1;
-    sprite_range(s.xw, s.size, a.cols, x0, x1);
-    sprite_range(s.yw, s.size, a.rows, y0, y1);
-    for (int py = y0; py <= y1; ++py)
-      for (int px = x0; px <= x1; ++px) {
+  for (unsigned base = blockIdx.x * 256u; base < M; base += gridDim.x * 256u) {
+    const unsigned i = base + t;
+    int rows_here = 0;
+    if (i < M) {
+      SplatSurfel s;
+      if (splat_vertex(a, sp.pos[i], sp.nrm[i], sp.times[(size_t)a.timeIdx * cap + i], s) && s.size == s.size) {
+        int x0, x1, y0, y1;
+        sprite_range(s.xw, s.size, a.cols, x0, x1);
+        sprite_range(s.yw, s.size, a.rows, y0, y1);
+        if (x1 >= x0 && y1 >= y0) {
+          rows_here = y1 - y0 + 1;
+          s_par[0][t] = s.pos.x;
+          s_par[1][t] = s.pos.y;
+          s_par[2][t] = s.pos.z;
+          s_par[3][t] = s.nrm.x;
+          s_par[4][t] = s.nrm.y;
+          s_par[5][t] = s.nrm.z;
+          s_par[6][t] = s.rad;
+          s_box[0][t] = x0;
+          s_box[1][t] = x1 - x0 + 1;
+          s_box[2][t] = y0;
+        }
+      }
+    }
+    // block-wide exclusive scan of rows_here
+    unsigned incl = (unsigned)rows_here;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (int w = 0; w < wid; ++w) wbase += s_w[w];
+    s_off[t] = wbase + incl - (unsigned)rows_here;
+    if (t == 255) s_off[256] = wbase + incl;
+    __syncthreads();
+    const unsigned total = s_off[256];
+    for (unsigned u = t; u < total; u += 256u) {
+      // surfel j with s_off[j] <= u < s_off[j + 1]
+      int lo = 0, hi = 256;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= u)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      const int j = lo;
+      SplatSurfel s;
+      s.pos = mk3(s_par[0][j], s_par[1][j], s_par[2][j]);
+      s.nrm = mk3(s_par[3][j], s_par[4][j], s_par[5][j]);
+      s.rad = s_par[6][j];
+      const int x0 = s_box[0][j], w = s_box[1][j];
+      const int py = s_box[2][j] + (int)(u - s_off[j]);
+      const unsigned long long id = (unsigned long long)(base + (unsigned)j);
+      for (int px = x0; px < x0 + w; ++px) {
         f3 c;
         float zw;
         if (!splat_fragment(a, s, px, py, c, zw)) continue;
         const unsigned d = depth24(zw);
         if (d >= 0xFFFFFFu) continue;
-        const unsigned long long key = ((unsigned long long)d << 32) | (unsigned long long)i;
-        // column-major z-buffer: surfels arrive in column-major order (GlobalModel.cpp:100-108), so the
-        // atomics of neighbouring lanes land in the same cache lines
-        unsigned long long* cell = zbuf + (size_t)px * a.rows + py;
+        const unsigned long long key = ((unsigned long long)d << 32) | id;
+        unsigned long long* cell = zbuf + (size_t)px * a.rows + py;  // column-major z-buffer
         if (key < *cell) atomicMin(cell, key);
       }
+    }
+    __syncthreads();  // the parameter tables are rewritten by the next chunk
   }
 }
 
