@@ -89,6 +89,21 @@ def float3(a):
     return Float3(float(a[0]), float(a[1]), float(a[2]))
 
 
+lib.dms_stream_create.argtypes = [C.POINTER(C.c_void_p)]
+lib.dms_stream_destroy.argtypes = [C.c_void_p]
+
+
+def create_stream():
+    """A non-blocking HIP stream handle (int) usable as the `stream` argument everywhere."""
+    h = C.c_void_p()
+    check(lib.dms_stream_create(C.byref(h)), "dms_stream_create")
+    return h.value
+
+
+def destroy_stream(s):
+    check(lib.dms_stream_destroy(C.c_void_p(s)), "dms_stream_destroy")
+
+
 class DeviceBuffer:
     """Owned HBM allocation (dms_device_alloc / dms_device_free)."""
 

@@ -53,6 +53,17 @@ int dms_device_free(void* ptr) {
   if (ptr) DMS_HIP(hipFree(ptr));
   return DMS_OK;
 }
+int dms_stream_create(dms_stream* out) {
+  DMS_REQUIRE(out, "null argument");
+  hipStream_t st = nullptr;
+  DMS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *out = (dms_stream)st;
+  return DMS_OK;
+}
+int dms_stream_destroy(dms_stream s) {
+  if (s) DMS_HIP(hipStreamDestroy(S(s)));
+  return DMS_OK;
+}
 int dms_memcpy_h2d(void* dst, const void* src, size_t bytes, dms_stream s) {
   DMS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(s)));
   DMS_HIP(hipStreamSynchronize(S(s)));

@@ -105,6 +105,9 @@ int dms_memcpy_h2d(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memcpy_d2h(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memset(void* dst, int value, size_t bytes, dms_stream s);
 int dms_stream_sync(dms_stream s);
+/* convenience for callers without a HIP runtime of their own (e.g. ctypes): a non-blocking stream */
+int dms_stream_create(dms_stream* out);
+int dms_stream_destroy(dms_stream s);
 
 /* ------------------------------------------------------------------------- */
 /* (B) operator layer — tracking (reference Cuda/cudafuncs.cuh)               */

@@ -415,6 +415,46 @@ def test_process_frame_pipelined_equals_serial(fus, synth):
         assert_bits(got[4], ref[4], "filtered depth " + what)
 
 
+def test_two_cameras_on_two_streams(fus, synth):
+    """Two camera contexts on one GPU, each on its own stream, frames enqueued interleaved without
+    host synchronisation: the resident tracker kernels (blocks that spin on each other) are chained
+    across streams by the library, so nothing deadlocks and each camera's result is bit-identical to
+    running it alone."""
+    from densemonoslam_amd import capi
+
+    n_frames = 5
+    streams = [capi.create_stream(), capi.create_stream()]
+    frames = [[synth.frame(k, cam_id=c, width=W, height=H, K=K, noise=True) for k in range(n_frames)] for c in (0, 1)]
+    bufs = []
+    for c in (0, 1):
+        rb = [capi.DeviceBuffer(W * H * 3).upload(np.ascontiguousarray(f[1], np.uint8)) for f in frames[c]]
+        db = [capi.DeviceBuffer(W * H * 2).upload(np.ascontiguousarray(f[0], np.uint16)) for f in frames[c]]
+        bufs.append((rb, db))
+
+    def alone(c):
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, timeIdx=c)
+        for k in range(n_frames):
+            g.processFrameAsync(bufs[c][0][k].ptr, 3, bufs[c][1][k].ptr)
+        r = g.fetch()
+        return np.array(r.pose, np.float32), int(r.surfels), g.globalModel().downloadMap()
+
+    ref = [alone(0), alone(1)]
+    cams = [fus.ElasticFusion(W, H, K, model_capacity=600000, timeIdx=c) for c in (0, 1)]
+    for k in range(n_frames):
+        for c in (0, 1):
+            cams[c].processFrameAsync(bufs[c][0][k].ptr, 3, bufs[c][1][k].ptr, None, 1.0, streams[c])
+    for c in (0, 1):
+        r = cams[c].fetch(streams[c])
+        assert (np.array(r.pose, np.float32) == ref[c][0]).all(), "camera %d pose" % c
+        assert int(r.surfels) == ref[c][1]
+        surfels_equal(cams[c].globalModel().downloadMap(), ref[c][2], "camera %d map" % c)
+    assert not (ref[0][0] == ref[1][0]).all()  # the two cameras really see different streams
+    for c in cams:
+        c.close()
+    for st in streams:
+        capi.destroy_stream(st)
+
+
 def test_map_merge_consume(fus, orc, synth):
     """GlobalModel::consume (SURVEY 8(f1)): the consuming map keeps its surfels and appends the other
     map's, moved by the relative transform — model-to-model on one device and through the packed
