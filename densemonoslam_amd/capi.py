@@ -89,6 +89,7 @@ def float3(a):
     return Float3(float(a[0]), float(a[1]), float(a[2]))
 
 
+lib.dms_stream_sync.argtypes = [C.c_void_p]
 lib.dms_stream_create.argtypes = [C.POINTER(C.c_void_p)]
 lib.dms_stream_destroy.argtypes = [C.c_void_p]
 
