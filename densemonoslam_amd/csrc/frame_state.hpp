@@ -1,0 +1,60 @@
+// Per-camera frame state kept in HBM by the frame step (fusion_frame.hip) and updated by the tracker's
+// last kernel (track.hip): shared so that the post-tracking bookkeeping needs no launch of its own.
+#pragma once
+#include "../../include/dmslam_fusion.h"
+#include "smallmath.hpp"
+
+namespace dms {
+
+struct FrameState {
+  dms_pose_block cur;   // current pose + inverse
+  float lastPose[16];   // pose at the end of the previous frame (ElasticFusion.cpp:158)
+  float weighting;      // ElasticFusion.cpp:252-268
+  int fill_in;          // shouldFillIn (ElasticFusion.cpp:167)
+  unsigned surfels;
+  int pad;
+};
+
+
+// after tracking: inverse of the new pose and the velocity weight (ElasticFusion.cpp:252-268); the
+// pose becomes next frame's lastPose (ElasticFusion.cpp:158).
+// rodrigues2 (ElasticFusion.cpp:941-985) re-orthonormalises diffRot with an SVD first; a product
+// of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
+__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier) {
+  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
+  float diff[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = st->cur.t_inv[i * 4 + 0] * st->lastPose[0 * 4 + j];
+      s += st->cur.t_inv[i * 4 + 1] * st->lastPose[1 * 4 + j];
+      s += st->cur.t_inv[i * 4 + 2] * st->lastPose[2 * 4 + j];
+      s += st->cur.t_inv[i * 4 + 3] * st->lastPose[3 * 4 + j];
+      diff[i * 4 + j] = s;
+    }
+  const float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
+  double rx = (double)diff[9] - (double)diff[6];
+  double ry = (double)diff[2] - (double)diff[8];
+  double rz = (double)diff[4] - (double)diff[1];
+  const double sn = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = ((double)(diff[0] + diff[5] + diff[10]) - 1) * 0.5;
+  c = c > 1. ? 1. : c < -1. ? -1. : c;
+  double theta = acos(c);
+  double rn;
+  if (sn < 1e-5) {
+    rn = c > 0 ? 0.0 : theta;  // |r| = theta in the c <= 0 branch (unit axis scaled by theta)
+  } else {
+    const double vth = (1 / (2 * sn)) * theta;
+    rx *= vth;
+    ry *= vth;
+    rz *= vth;
+    rn = sqrt(rx * rx + ry * ry + rz * rz);
+  }
+  float weighting = fmaxf(tn, (float)rn);
+  const float largest = 0.01f, minWeight = 0.5f;
+  if (weighting > largest) weighting = largest;
+  weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
+  st->weighting = weighting;
+  for (int i = 0; i < 16; ++i) st->lastPose[i] = st->cur.pose[i];
+}
+
+}  // namespace dms

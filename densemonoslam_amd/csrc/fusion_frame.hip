@@ -15,6 +15,7 @@
 #include "internal.hpp"
 #include "smallmath.hpp"
 #include "surfel.hpp"
+#include "frame_state.hpp"
 
 struct dms_odometry;
 
@@ -43,8 +44,10 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
                 int isFern, int transposed, unsigned* count_out2, hipStream_t s);
 // track.hip
+struct FrameState;
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
-                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s);
+                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s, FrameState* frame,
+                           float weightMultiplier);
 int odometry_result_pose(dms_odometry* o, float* pose16_dev, hipStream_t s);
 int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA, const float* vB, const float* nB, const int* flag_dev,
                               const float* pose16_dev, hipStream_t s);
@@ -65,15 +68,6 @@ void odometry_bind_live(dms_odometry* o, int k);
 void odometry_bind_lastnext(dms_odometry* o, int k);
 int odometry_initRGB_image(dms_odometry* o, const dms_image2d* rgba, hipStream_t s);
 void odometry_alias_next_depth(dms_odometry* o);
-
-struct FrameState {
-  dms_pose_block cur;   // current pose + inverse
-  float lastPose[16];   // pose at the end of the previous frame (ElasticFusion.cpp:158)
-  float weighting;      // ElasticFusion.cpp:252-268
-  int fill_in;          // shouldFillIn (ElasticFusion.cpp:167)
-  unsigned surfels;
-  int pad;
-};
 
 // RGB8 (3 B/px, as the reference uploads, ElasticFusion.cpp:111) -> RGBA8 texture
 __global__ void k_rgb_to_rgba(const unsigned char* __restrict__ rgb, uchar4* __restrict__ rgba, int n) {
@@ -102,44 +96,9 @@ __global__ void k_pose_set(FrameState* st, Pose16 p) {
   st->fill_in = 0;
 }
 
-// after tracking: inverse of the new pose and the velocity weight (ElasticFusion.cpp:252-268).
-// rodrigues2 (ElasticFusion.cpp:941-985) re-orthonormalises diffRot with an SVD first; a product
-// of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
 __global__ void k_frame_after_track(FrameState* st, float weightMultiplier) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
-  float diff[16];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      float s = st->cur.t_inv[i * 4 + 0] * st->lastPose[0 * 4 + j];
-      s += st->cur.t_inv[i * 4 + 1] * st->lastPose[1 * 4 + j];
-      s += st->cur.t_inv[i * 4 + 2] * st->lastPose[2 * 4 + j];
-      s += st->cur.t_inv[i * 4 + 3] * st->lastPose[3 * 4 + j];
-      diff[i * 4 + j] = s;
-    }
-  const float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
-  double rx = (double)diff[9] - (double)diff[6];
-  double ry = (double)diff[2] - (double)diff[8];
-  double rz = (double)diff[4] - (double)diff[1];
-  const double sn = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
-  double c = ((double)(diff[0] + diff[5] + diff[10]) - 1) * 0.5;
-  c = c > 1. ? 1. : c < -1. ? -1. : c;
-  double theta = acos(c);
-  double rn;
-  if (sn < 1e-5) {
-    rn = c > 0 ? 0.0 : theta;  // |r| = theta in the c <= 0 branch (unit axis scaled by theta)
-  } else {
-    const double vth = (1 / (2 * sn)) * theta;
-    rx *= vth;
-    ry *= vth;
-    rz *= vth;
-    rn = sqrt(rx * rx + ry * ry + rz * rz);
-  }
-  float weighting = fmaxf(tn, (float)rn);
-  const float largest = 0.01f, minWeight = 0.5f;
-  if (weighting > largest) weighting = largest;
-  weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
-  st->weighting = weighting;
+  frame_after_track_body(st, weightMultiplier);
 }
 
 // denseEnough on the W/20 × H/20 nearest-neighbour subsample of the predicted image
@@ -618,8 +577,10 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     f->map_initialised = true;
     fused = 1;
   } else {
-    hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, f->state, prior, inPose16 ? 1 : 0);
-    DMS_CHECK_LAUNCH();
+    if (inPose16) {  // without a prior the pose block is already consistent: the previous frame left lastPose = pose and its inverse
+      hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, f->state, prior, 1);
+      DMS_CHECK_LAUNCH();
+    }
     if ((rc = predict(f, 0.7f, s))) return rc;  // ElasticFusion.cpp:165
     hipLaunchKernelGGL(k_dense_enough, dim3(1), dim3(256), 0, s, (const uchar4*)f->pred.image.data, W, H, f->state);
     DMS_CHECK_LAUNCH();
@@ -637,13 +598,15 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
       {
         FTimer t(f, s, "track");
         if ((rc = odometry_track_enqueue(f->odom, nullptr, nullptr, f->state->cur.pose, f->p.rgbOnly, f->p.icpWeight, f->p.pyramid,
-                                         f->p.fastOdom, f->p.so3, 0, s)))
+                                         f->p.fastOdom, f->p.so3, 0, s, f->state, weightMultiplier)))
           return rc;
         // (the tracker's finalize kernel writes the new pose straight back into f->state->cur.pose)
       }
     }
-    hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
-    DMS_CHECK_LAUNCH();
+    if (!f->p.hybrid_tracking) {  // with tracking on, the tracker's last kernel does this
+      hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
+      DMS_CHECK_LAUNCH();
+    }
     // "GlobalPredict" (ElasticFusion.cpp:273): its consumers are the NID key-framing gate below and the
     // fern / loop-closure blocks, which this reference compiles out with `if (false)` (ElasticFusion.cpp:279,
     // :593); the final predict overwrites every image it writes before the frame returns.

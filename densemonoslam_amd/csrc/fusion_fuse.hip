@@ -508,12 +508,35 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
 __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
                                                        const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
                                                        unsigned char* slot_flag, const unsigned char* __restrict__ keep,
-                                                       const unsigned* __restrict__ block_offset, SurfelPlanes out) {
+                                                       const unsigned* __restrict__ block_offset, SurfelPlanes out,
+                                                       const unsigned* __restrict__ block_count, unsigned* __restrict__ count_new,
+                                                       unsigned* __restrict__ count_new2) {
   const unsigned M = d_count[0];
   const unsigned total = M + (unsigned)a.nslots;
   const unsigned base = blockIdx.x * kScanChunk;
+  unsigned running;
+  if (block_count) {
+    // small grids: every block sums the flag counts of the blocks before it itself (and block 0 the
+    // grand total = new map size), which saves the scan launch between the two clean kernels
+    unsigned below = 0, all = 0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+      const unsigned c = block_count[b];
+      all += c;
+      below += b < blockIdx.x ? c : 0u;
+    }
+    running = block_sum_u32(below);
+    if (blockIdx.x == 0) {
+      const unsigned tot = block_sum_u32(all);
+      if (threadIdx.x == 0) {
+        const unsigned c = tot < (unsigned)cap ? tot : (unsigned)cap;
+        count_new[0] = c;
+        if (count_new2) count_new2[0] = c;
+      }
+    }
+  } else {
+    running = block_offset[blockIdx.x];
+  }
   if (base >= total) return;
-  unsigned running = block_offset[blockIdx.x];
   for (int k = 0; k < kScanChunk / 256; ++k) {
     const unsigned e = base + k * 256 + threadIdx.x;
     const bool f = (e < total) && keep[e];
@@ -635,11 +658,15 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_count);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt, (unsigned)m->cap,
-                     count_out2);
-  DMS_CHECK_LAUNCH();
+  const bool inline_scan = nb <= 2048;
+  if (!inline_scan) {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt, (unsigned)m->cap,
+                       count_out2);
+    DMS_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(k_clean_scatter, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
-                     m->slot_flag, m->keep, m->block_offset, dst);
+                     m->slot_flag, m->keep, m->block_offset, dst, inline_scan ? m->block_count : (const unsigned*)nullptr, m->d_count_alt,
+                     count_out2);
   DMS_CHECK_LAUNCH();
   // the scatter still reads the old count cell; later launches get the new one
   std::swap(m->d_count, m->d_count_alt);

@@ -26,6 +26,7 @@
 #include "internal.hpp"
 #include "pixel_ops.hpp"
 #include "smallmath.hpp"
+#include "frame_state.hpp"
 #include <mutex>
 
 namespace dms {
@@ -1390,7 +1391,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   }
 }
 
-__global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ pose16_out) {
+__global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ pose16_out, FrameState* frame, float weightMultiplier) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
   const float n = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -1411,6 +1412,9 @@ __global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ po
     pose16_out[14] = 0.f;
     pose16_out[15] = 1.f;
   }
+  // frame step: pose16_out is frame->cur.pose; derive its inverse and the velocity weight here
+  // instead of in a launch of their own
+  if (frame) frame_after_track_body(frame, weightMultiplier);
 }
 
 }  // namespace dms
@@ -1721,7 +1725,8 @@ int dms_odometry_initFirstRGB(dms_odometry* o, const dms_image2d* rgba, dms_stre
 
 namespace dms {
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
-                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s);
+                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s, FrameState* frame = nullptr,
+                           float weightMultiplier = 1.f);
 }
 
 extern "C" {
@@ -1805,7 +1810,8 @@ static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const 
 }
 
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
-                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s) {
+                           float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s, FrameState* frame,
+                           float weightMultiplier) {
   DMS_REQUIRE(o && ((trans && rot) || prior_pose16_dev), "null argument");
   const bool icp = !rgbOnly && icpWeight > 0;
   const bool rgb = rgbOnly || icpWeight < 100;
@@ -1996,7 +2002,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   {
     Timer t(o, s, "track_finalize");
     // with a device-resident prior (frame step) the result is written back into the same pose block
-    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0, const_cast<float*>(prior_pose16_dev));
+    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0, const_cast<float*>(prior_pose16_dev), frame,
+                       weightMultiplier);
     DMS_CHECK_LAUNCH();
   }
   // (the result block is copied to the host by dms_odometry_fetch_result, not once per call)
