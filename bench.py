@@ -246,6 +246,22 @@ def main():
                 traffic = pm["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        # what a plain device-to-device copy reaches on this box, next to the spec peak
+        try:
+            a_ = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+            b_ = torch.empty_like(a_)
+            b_.copy_(a_)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b_.copy_(a_)
+            e1.record()
+            torch.cuda.synchronize()
+            measured_copy = 2.0 * a_.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + write
+            del a_, b_
+        except Exception:
+            measured_copy = None
         if "gn_level0" in kern:
             bytes_per_launch = algorithmic_bytes("gn_level", W, H, M, px[0]) * its[0]
             avg_s = kern["gn_level0"]["avg_us"] * 1e-6
@@ -260,6 +276,7 @@ def main():
                 "traffic": traffic,
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": kern["gn_level0"]["avg_us"],
+                "measured_copy_GBps": None if measured_copy is None else round(measured_copy, 1),
                 "note": "algorithmic bytes = 76 B/px/iteration (SURVEY 8d) x %d px x %d iterations; the launch is bound by its 20 grid-wide "
                         "reductions (2 per iteration), not by HBM (DESIGN.md 6)" % (px[0], its[0]),
             }

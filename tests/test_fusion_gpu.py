@@ -415,6 +415,34 @@ def test_process_frame_pipelined_equals_serial(fus, synth):
         assert_bits(got[4], ref[4], "filtered depth " + what)
 
 
+def test_frame_step_tracker_modes_agree(fus, synth, monkeypatch):
+    """The frame step with the launch-per-phase tracker (DMS_TRACK_MODE=launches, the fallback) and
+    with the resident level kernels stays on the same trajectory (free-running drift bound) with the
+    same iteration counts; each mode is checked against the oracle per step in test_tracking_gpu."""
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(5)]
+    res = {}
+    for mode in ("persistent", "launches"):
+        if mode == "launches":
+            monkeypatch.setenv("DMS_TRACK_MODE", "launches")
+        else:
+            monkeypatch.delenv("DMS_TRACK_MODE", raising=False)
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+        poses = []
+        for d, rgb, _ in frames:
+            r = g.processFrame(rgb, d)
+            poses.append(np.array(r.pose, np.float32).reshape(4, 4))
+        res[mode] = (poses, int(r.surfels), r.track)
+    monkeypatch.delenv("DMS_TRACK_MODE", raising=False)
+    for k, (pa, pb) in enumerate(zip(*[res[m][0] for m in ("persistent", "launches")])):
+        # free-running: 1e-8-level differences of the sums flip correspondences on this noisy, mostly planar
+        # scene, so the two trajectories drift apart like the GPU and the oracle do (same bound as
+        # test_process_frame_free_running_drift_is_bounded)
+        assert np.linalg.norm(pa[:3, 3] - pb[:3, 3]) < 5e-3, k
+        assert helpers.rot_angle_deg(pa[:3, :3], pb[:3, :3]) < 0.2, k
+    assert abs(res["persistent"][1] - res["launches"][1]) <= 0.01 * res["launches"][1]
+    assert list(res["persistent"][2].iterations_run) == list(res["launches"][2].iterations_run) == [10, 5, 4]
+
+
 def test_two_cameras_on_two_streams(fus, synth):
     """Two camera contexts on one GPU, each on its own stream, frames enqueued interleaved without
     host synchronisation: the resident tracker kernels (blocks that spin on each other) are chained
