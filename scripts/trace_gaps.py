@@ -3,7 +3,7 @@
 
     python scripts/trace_gaps.py gpurun_out/prof6/r6_kernel_trace.csv
 
-Finds the steady-state frames (delimited by k_frame_begin), and reports per kernel: launches per
+Finds the steady-state frames (delimited by k_track_init, launched once per tracked frame), and reports per kernel: launches per
 frame, busy time per frame, and the idle gap that precedes it on the device timeline.
 """
 import collections
@@ -19,7 +19,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ev = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-    starts = [i for i, e in enumerate(ev) if e[0] == "k_frame_begin"]
+    starts = [i for i, e in enumerate(ev) if e[0] == "k_track_init"]  # one per tracked frame
     if len(starts) < 12:
         print("too few frames")
         return

@@ -378,6 +378,44 @@ def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode
     assert 1e-4 < np.linalg.norm(tg) < 0.1
 
 
+@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
+@pytest.mark.parametrize("case", ["no_live_depth", "black_live_image"])
+def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
+    """Degenerate frames: no live depth at all (zero ICP correspondences: the 6x6 system is singular
+    and the pivoted LDLT semantics apply) and a black live image (zero photometric correspondences:
+    sigma of an empty set).  Every block of a resident kernel must take the same path; the result
+    must equal the oracle's, NaN for NaN."""
+    K = gputest_pair["K"]
+    verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
+    rgba1, rgba2 = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
+    depth2 = gputest_pair["depth2"].copy()
+    if case == "no_live_depth":
+        depth2[:] = 0
+    else:
+        rgba2 = np.zeros_like(rgba2)
+    g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+    o = orc.Odometry(640, 480, K[2], K[3], K[0], K[1])
+    for trk in (g, o):
+        trk.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+        trk.initRGBModel(rgba1)
+        trk.initICP(depth2, 20.0)
+        trk.initRGB(rgba2)
+        trk.initFirstRGB(rgba1)
+    cfg = CONFIGS["C3_full"]
+    t0, R0 = np.zeros(3, np.float32), np.eye(3, dtype=np.float32)
+    tg, Rg, rg = g.getIncrementalTransformation(t0, R0, **cfg)
+    to, Ro, ro = o.getIncrementalTransformation(t0, R0, **cfg)
+    assert list(rg.iterations_run) == list(ro.iterations_run)
+    assert rg.rejected_jump == ro.rejected_jump
+    assert np.array_equal(np.isnan(tg), np.isnan(to)) and np.array_equal(np.isnan(Rg), np.isnan(Ro))
+    if not np.isnan(to).any():
+        helpers.assert_pose_close(tg, Rg, to, Ro, what=case)
+    if case == "no_live_depth":
+        assert rg.lastICPCount == ro.lastICPCount == 0
+    else:
+        assert rg.lastRGBCount == ro.lastRGBCount == 0
+
+
 def test_track_from_nonidentity_prior_and_second_call(dms, orc, gputest_pair):
     """Prior pose with rotation + translation; two consecutive calls (the SO3 image swap of
     RGBDOdometry.cpp:595-601 changes what the second call sees)."""
