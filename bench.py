@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--no-kernel-pass", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="issue the live-frame half on the main stream (A/B switch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~20 s)")
+    ap.add_argument("--loop-closure", action="store_true",
+                    help="time the 'full' frame step: local loop closure on (INACTIVE prediction + model-to-model tracking every frame)")
+    ap.add_argument("--no-full-leg", action="store_true", help="skip the extra 'full' (loop closure on) leg of the default run")
     args = ap.parse_args()
 
     import torch
@@ -103,8 +106,9 @@ def main():
         j = i % period
         return j if j < n_unique else period - j
 
-    def make_engine():
-        return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1)
+    def make_engine(loop_closure=args.loop_closure):
+        return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1,
+                                    local_loop_closure=1 if loop_closure else 0)
 
     stream = torch.cuda.current_stream().cuda_stream
     ef = make_engine()
@@ -190,8 +194,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "TUM fr1/desk-like 640x480 full 3-level ICP+RGB tracking (SO3 + {10,5,4} GN iterations) + surfel index-map fusion; "
-                        "synthetic box-room RGB-D stream, loop closure off (--o), NID keyframing off (--nkf)" if (W, H) == (640, 480)
-                        else "same frame step at %dx%d" % (W, H),
+                        "synthetic box-room RGB-D stream, %s, NID keyframing off (--nkf)"
+                        % ("local loop closure on (INACTIVE prediction + model-to-model tracking every frame: the 'full' step)"
+                           if args.loop_closure else "loop closure off (--o)") if (W, H) == (640, 480)
+                        else "same frame step at %dx%d%s" % (W, H, ", local loop closure on" if args.loop_closure else ""),
             "resolution": [W, H],
             "cameras_per_gpu": 1,
             "surfels_per_map": M,
@@ -199,6 +205,32 @@ def main():
             "exchange": "all-gather of %d-byte W/8xH/8 thumbnails per camera per frame" % thumb.numel() if distributed else "none (1 camera)",
         },
     }
+
+    # ---- "full" frame step (report both): the same stream with local loop closure on ----
+    if rank == 0 and not distributed and not args.loop_closure and not args.no_full_leg:
+        ef_main = ef
+        ef = make_engine(True)
+        nfull = min(args.steps, 100)
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + nfull):
+            step(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        rf = ef.fetch(stream)
+        out["full_step"] = {
+            "value": nfull / el,
+            "unit": "frames/s",
+            "ms_per_step": 1000.0 * el / nfull,
+            "steps": nfull,
+            "what": "same frame step with local loop closure on: + INACTIVE prediction, second (model-to-model) 3-level tracker pass, "
+                    "acceptance test and constraint sampling on device (ElasticFusion.cpp:399-474)",
+            "last_loop_icp_count": float(rf.loop_icp_count),
+        }
+        ef.close()
+        ef = ef_main
 
     # ---- per-kernel timing with HIP events on the launch stream (own pass, not in `value`) ------
     if rank == 0 and not args.no_kernel_pass:
@@ -209,7 +241,8 @@ def main():
         for i in range(n_total, n_total + nprof):
             step(i)
             ef.fetch(stream)
-        names_f = ["ingest", "preprocess", "live_pyramids", "predict", "fill_in", "odom_init", "track", "index_map", "fuse", "clean", "initialise"]
+        names_f = ["ingest", "preprocess", "live_pyramids", "predict", "fill_in", "odom_init", "track", "predict_old", "loop_init", "loop_track",
+                   "index_map", "fuse", "clean", "initialise"]
         stages = {}
         for n in names_f:
             ms, cnt = ef.kernel_time(n)

@@ -15,6 +15,15 @@ struct FrameState {
   int pad;
 };
 
+// Outcome of the local loop-closure candidate of one frame (ElasticFusion.cpp:427-474); the sampled
+// constraints follow it in the same device buffer: 8 floats each {raw xyz, model xyz, time, 0}.
+struct LoopState {
+  int ok;
+  int n_constraints;
+  float icp_error, icp_count;
+  float est_pose[16];
+  double cov_diag[6];
+};
 
 // after tracking: inverse of the new pose and the velocity weight (ElasticFusion.cpp:252-268); the
 // pose becomes next frame's lastPose (ElasticFusion.cpp:158).

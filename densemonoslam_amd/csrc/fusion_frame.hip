@@ -57,6 +57,9 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
 int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth);
+struct LoopState;
+int odometry_loop_candidate(dms_odometry* o, const FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
+                            LoopState* out, float* cons, hipStream_t s);
 // nid.hip
 size_t nid_workspace_bytes(int num_bins);
 int computeNIDImg(const dms_image2d* img_kf, const dms_image2d* img_kf_old, const dms_image2d* dmap_kf, const dms_image2d* dmap_kf_old,
@@ -143,6 +146,11 @@ struct dms_fusion {
   dms_camera cam;
   dms_model* model = nullptr;
   dms_odometry* odom = nullptr;
+  dms_odometry* odom_m2m = nullptr;  // Context::modelToModel() (local loop closure)
+  dms_predict_out pred_old;          // IndexMap old* textures: the INACTIVE view
+  LoopState* loop = nullptr;         // device: LoopState + constraint rows
+  char* h_loop = nullptr;            // pinned, two slots by frame parity
+  size_t loop_bytes = 0;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   // images of the incoming frame: two sets, so that frame t+1 can be ingested and filtered on the
@@ -242,6 +250,15 @@ void layout(dms_fusion* f, Carve& c) {
     const int nb = f->p.nid_bins_depth > f->p.nid_bins_img ? f->p.nid_bins_depth : f->p.nid_bins_img;
     f->nid_ws_bytes = nid_workspace_bytes(nb > 0 ? nb : 1);
     f->nid_ws = c.take(f->nid_ws_bytes);
+  }
+  memset(&f->pred_old, 0, sizeof(f->pred_old));
+  if (f->p.local_loop_closure) {
+    f->pred_old.image = mk_img(c.take(N * 4), H, W, 4);
+    f->pred_old.vertex = mk_img(c.take(N * 16), H, W, 16);
+    f->pred_old.normal = mk_img(c.take(N * 16), H, W, 16);
+    f->pred_old.time = mk_img(c.take(N * 2), H, W, 2);
+    f->loop_bytes = up256(sizeof(LoopState)) + (size_t)(W / 20) * (H / 20) * 8 * sizeof(float);
+    f->loop = (LoopState*)c.take(f->loop_bytes);
   }
   f->rgba_tmp = c.take(N * 4);
   f->untr = c.take(N * 16);
@@ -393,6 +410,7 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->nid_bins_img = 64;
   p->nid_bins_depth = 500;
   p->nid_pyramid_level = 0;
+  p->local_loop_closure = 0;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
@@ -420,6 +438,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     return rc;
   }
   rc = odometry_enable_ring(f->odom);
+  if (!rc && p->local_loop_closure) rc = dms_odometry_create(&f->odom_m2m, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
   if (rc) {
     dms_odometry_destroy(f->odom);
     dms_model_destroy(f->model);
@@ -439,8 +458,13 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 2 * sizeof(FrameState), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->nid_host, 2 * sizeof(float), hipHostMallocDefault);
+  if (e == hipSuccess && f->loop_bytes) {
+    e = hipHostMalloc((void**)&f->h_loop, 2 * f->loop_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) memset(f->h_loop, 0, 2 * f->loop_bytes);
+  }
   if (e != hipSuccess) {
     if (f->arena) (void)hipFree(f->arena);
+    if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
     dms_odometry_destroy(f->odom);
     dms_model_destroy(f->model);
     delete f;
@@ -475,6 +499,8 @@ int dms_fusion_destroy(dms_fusion* f) {
   if (f->arena) (void)hipFree(f->arena);
   if (f->h_state) (void)hipHostFree(f->h_state);
   if (f->nid_host) (void)hipHostFree(f->nid_host);
+  if (f->h_loop) (void)hipHostFree(f->h_loop);
+  if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
   dms_odometry_destroy(f->odom);
   dms_model_destroy(f->model);
   delete f;
@@ -611,14 +637,56 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     // fern / loop-closure blocks, which this reference compiles out with `if (false)` (ElasticFusion.cpp:279,
     // :593); the final predict overwrites every image it writes before the frame returns.
     bool fuse_now = true;
-    if (f->p.global_predict || f->p.nid_keyframing)
+    if (f->p.global_predict || f->p.nid_keyframing || f->p.local_loop_closure)
       if ((rc = predict(f, f->p.confidence, s))) return rc;
+    if (f->p.local_loop_closure) {
+      // closeLoops without a fern match (ElasticFusion.cpp:399-497): the camera is never lost and
+      // rawGraph is empty (nothing deforms the map inside this library)
+      {
+        FTimer t(f, s, "predict_old");  // combinedPredict(..., 0, id, tick - timeDelta, timeDelta, INACTIVE) (:403-406)
+        if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, f->p.confidence, 0, f->p.timeIdx,
+                                f->tick - f->p.timeDelta, f->p.timeDelta, 0, f->zbuf, &f->pred_old, nullptr, 1, s)))
+          return rc;
+      }
+      {
+        FTimer t(f, s, "loop_init");  // modelToModel().initICPModel / initRGBModel / initICP / initRGB (:409-418)
+        if ((rc = odometry_initModel_fused(f->odom_m2m, f->pred_old.vertex.data, f->pred_old.normal.data, f->pred_old.image.data,
+                                           f->pred_old.vertex.data, f->pred_old.normal.data, f->pred_old.image.data, &f->state->fill_in, 0,
+                                           f->state->cur.pose, s)))
+          return rc;
+        if ((rc = dms_odometry_initICP_maps(f->odom_m2m, (const float*)f->pred.vertex.data, (const float*)f->pred.normal.data,
+                                            f->p.maxDepthProcessed, s)))
+          return rc;
+        if ((rc = dms_odometry_initRGB(f->odom_m2m, &f->pred.image, s))) return rc;
+      }
+      {
+        FTimer t(f, s, "loop_track");  // getIncrementalTransformation(trans, rot, false, 10, pyramid, fastOdom, false) (:424-425)
+        if ((rc = odometry_track_enqueue(f->odom_m2m, nullptr, nullptr, f->state->cur.pose, 0, 10.f, f->p.pyramid, f->p.fastOdom, 0, 0, s,
+                                         nullptr, 1.f)))
+          return rc;
+      }
+      // covariance + acceptance test + constraint sampling (:427-474), all on device
+      if ((rc = odometry_loop_candidate(f->odom_m2m, f->state, &f->pred.vertex, &f->pred_old.time, f->p.maxDepthProcessed, f->loop,
+                                        (float*)((char*)f->loop + up256(sizeof(LoopState))), s)))
+        return rc;
+    }
     if (f->p.nid_keyframing) {
       // ElasticFusion::fuseFrame (ElasticFusion.cpp:639-677): candidate key frame = this prediction
       // (KeyFrame.h:83-172: intensity of the image, verticesToDepth of the vertex map), reduced
       // nid_pyramid_level times (MutualInformation.cpp:169-174), scored against the live pyramids
       FTimer t(f, s, "nid");
       const int L = f->p.nid_pyramid_level;
+      if (f->p.local_loop_closure) {
+        // with a rendered INACTIVE view the key frame's "old" half is real (KeyFrame.h:139-166; the
+        // reference copies the old vertex texture with the byte count of a released array, :147-150,
+        // so its old depth map is undefined — the evident intent is implemented)
+        if ((rc = imageToIntensity(&f->pred_old.image, &f->kf_old_img[0], s))) return rc;
+        if ((rc = verticesToDepth((const float*)f->pred_old.vertex.data, &f->kf_old_dmap[0], f->p.maxDepthProcessed, s))) return rc;
+        for (int l = 1; l <= L; ++l) {
+          if ((rc = pyrDownUcharGauss(&f->kf_old_img[l - 1], &f->kf_old_img[l], s))) return rc;
+          if ((rc = pyrDownGaussF(&f->kf_old_dmap[l - 1], &f->kf_old_dmap[l], s))) return rc;
+        }
+      }
       if ((rc = imageToIntensity(&f->pred.image, &f->kf_img[0], s))) return rc;
       if ((rc = verticesToDepth((const float*)f->pred.vertex.data, &f->kf_dmap[0], f->p.maxDepthProcessed, s))) return rc;
       for (int l = 1; l <= L; ++l) {
@@ -676,6 +744,8 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     DMS_CHECK_LAUNCH();
   }
   DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+  if (f->p.local_loop_closure && f->frames > 0)
+    DMS_HIP(hipMemcpyAsync(f->h_loop + (size_t)k2 * f->loop_bytes, f->loop, f->loop_bytes, hipMemcpyDeviceToHost, s));
   f->last_slot = k2;
   if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
   f->fused_last = fused;
@@ -705,6 +775,27 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   r->fill_in = hs->fill_in;
   r->weighting = hs->weighting;
   r->nid_score = f->last_nid;
+  if (f->h_loop) {
+    const LoopState* L = (const LoopState*)(f->h_loop + (size_t)f->last_slot * f->loop_bytes);
+    r->loop_ok = L->ok;
+    r->loop_constraints = L->n_constraints;
+    r->loop_icp_error = L->icp_error;
+    r->loop_icp_count = L->icp_count;
+    memcpy(r->loop_pose, L->est_pose, sizeof(r->loop_pose));
+    memcpy(r->loop_cov_diag, L->cov_diag, sizeof(r->loop_cov_diag));
+  }
+  return DMS_OK;
+}
+
+int dms_fusion_get_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n) {
+  DMS_REQUIRE(f && n && (rows7_host || max_rows == 0), "null argument");
+  *n = 0;
+  if (!f->h_loop) return DMS_OK;
+  const char* slot = f->h_loop + (size_t)f->last_slot * f->loop_bytes;
+  const LoopState* L = (const LoopState*)slot;
+  const float* c = (const float*)(slot + up256(sizeof(LoopState)));
+  *n = L->n_constraints;
+  for (int i = 0; i < L->n_constraints && i < max_rows; ++i) memcpy(rows7_host + (size_t)i * 7, c + (size_t)i * 8, 7 * sizeof(float));
   return DMS_OK;
 }
 
@@ -713,8 +804,9 @@ int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {
   const dms_image2d* t[] = {&f->rgba,          &f->depth_raw,   &f->depth_filtered, &f->depth_metric, &f->depth_metric_filtered,
                             &f->imap.index,    &f->imap.vertConf, &f->imap.colorTime, &f->imap.normRad, &f->pred.image,
                             &f->pred.vertex,   &f->pred.normal, &f->pred.time,      &f->fill.image,   &f->fill.vertex,
-                            &f->fill.normal};
-  DMS_REQUIRE(which >= 0 && which < 16, "bad image id");
+                            &f->fill.normal,   &f->pred_old.image, &f->pred_old.vertex, &f->pred_old.normal, &f->pred_old.time};
+  DMS_REQUIRE(which >= 0 && which < 20, "bad image id");
+  DMS_REQUIRE(which < 16 || f->p.local_loop_closure, "the INACTIVE view exists only with local_loop_closure");
   *view = *t[which];
   if (which >= 5 && which <= 8) {
     // the frame step keeps the index-map images column-major; hand out a row-major copy

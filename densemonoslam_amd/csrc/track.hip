@@ -27,6 +27,7 @@
 #include "pixel_ops.hpp"
 #include "smallmath.hpp"
 #include "frame_state.hpp"
+#include "surfel.hpp"
 #include <mutex>
 
 namespace dms {
@@ -2001,9 +2002,10 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
 
   {
     Timer t(o, s, "track_finalize");
-    // with a device-resident prior (frame step) the result is written back into the same pose block
-    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0, const_cast<float*>(prior_pose16_dev), frame,
-                       weightMultiplier);
+    // frame step (frame state given): the result is written back into the pose block the prior came from;
+    // a device prior without frame state (model-to-model tracking) is read-only
+    hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, s, o->state, rgb ? 1 : 0,
+                       frame ? const_cast<float*>(prior_pose16_dev) : nullptr, frame, weightMultiplier);
     DMS_CHECK_LAUNCH();
   }
   // (the result block is copied to the host by dms_odometry_fetch_result, not once per call)
@@ -2029,6 +2031,121 @@ __global__ void k_track_pose_out(const TrackState* __restrict__ st, float* __res
 
 int odometry_result_pose(dms_odometry* o, float* pose16_dev, hipStream_t s) {
   hipLaunchKernelGGL(k_track_pose_out, dim3(1), dim3(64), 0, s, o->state, pose16_dev);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+// ---- local loop-closure candidate (ElasticFusion.cpp:427-474) --------------------------------
+// One block, after the model-to-model tracker: thread 0 takes the acceptance decision from the
+// tracker's side outputs (getCovariance = inverse of lastA by partially pivoted elimination in fp64,
+// RGBDOdometry.cpp:607-610; thresholds of ElasticFusion.cpp:428-442), then the block samples the
+// W/20 x H/20 nearest-neighbour grid of the ACTIVE vertex map and the INACTIVE time map
+// (Resize::vertex / Resize::time, :443-444) and compacts the surface constraints in the reference's
+// order (columns outer, rows inner, :446-447).
+__global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __restrict__ st, const FrameState* __restrict__ frame,
+                                                        const float4* __restrict__ vertex, const unsigned short* __restrict__ oldTime,
+                                                        int cols, int rows, float maxDepth, LoopState* __restrict__ out,
+                                                        float* __restrict__ cons) {
+  __shared__ int s_ok;
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) {
+    double a[36], inv[36];
+    for (int i = 0; i < 36; ++i) {
+      a[i] = st->lastA[i];
+      inv[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    }
+    for (int c = 0; c < 6; ++c) {
+      int p = c;
+      for (int r = c + 1; r < 6; ++r)
+        if (fabs(a[r * 6 + c]) > fabs(a[p * 6 + c])) p = r;
+      if (p != c)
+        for (int j = 0; j < 6; ++j) {
+          const double t0 = a[c * 6 + j], t1 = inv[c * 6 + j];
+          a[c * 6 + j] = a[p * 6 + j];
+          inv[c * 6 + j] = inv[p * 6 + j];
+          a[p * 6 + j] = t0;
+          inv[p * 6 + j] = t1;
+        }
+      const double d = a[c * 6 + c];
+      for (int j = 0; j < 6; ++j) {
+        a[c * 6 + j] /= d;
+        inv[c * 6 + j] /= d;
+      }
+      for (int r = 0; r < 6; ++r) {
+        if (r == c) continue;
+        const double f = a[r * 6 + c];
+        for (int j = 0; j < 6; ++j) {
+          a[r * 6 + j] -= f * a[c * 6 + j];
+          inv[r * 6 + j] -= f * inv[c * 6 + j];
+        }
+      }
+    }
+    bool covOk = true;
+    for (int i = 0; i < 6; ++i) {
+      out->cov_diag[i] = inv[i * 7];
+      if (inv[i * 7] > 8e-05) covOk = false;
+    }
+    const int ok = (covOk && st->lastICPCount > 15000.f && st->lastICPError < 0.0003f) ? 1 : 0;
+    out->ok = ok;
+    out->icp_error = st->lastICPError;
+    out->icp_count = st->lastICPCount;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) out->est_pose[i * 4 + j] = st->out_rot[i * 3 + j];
+      out->est_pose[i * 4 + 3] = st->out_trans[i];
+    }
+    out->est_pose[12] = out->est_pose[13] = out->est_pose[14] = 0.f;
+    out->est_pose[15] = 1.f;
+    s_ok = ok;
+    s_base = 0;
+  }
+  __syncthreads();
+  if (!s_ok) {
+    if (threadIdx.x == 0) out->n_constraints = 0;
+    return;
+  }
+  const int dw = cols / 20, dh = rows / 20, n = dw * dh;
+  const float* P = frame->cur.pose;
+  for (int base = 0; base < n; base += 256) {
+    const int k = base + (int)threadIdx.x;
+    bool valid = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned short t = 0;
+    if (k < n) {
+      const int i = k / dh, j = k - i * dh;
+      const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
+      const int sx = texel(u, (float)cols, cols), sy = texel(v, (float)rows, rows);
+      p = vertex[(size_t)sy * cols + sx];
+      t = oldTime[(size_t)sy * cols + sx];
+      valid = p.z > 0.f && p.z < maxDepth && t > 0;
+    }
+    const unsigned long long m = __ballot(valid);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_wave[w] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int q = 0; q < w; ++q) off += s_wave[q];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (valid) {
+      float* c = cons + (size_t)off * 8;
+      for (int r = 0; r < 3; ++r) {
+        c[r] = P[r * 4 + 0] * p.x + P[r * 4 + 1] * p.y + P[r * 4 + 2] * p.z + P[r * 4 + 3];
+        c[3 + r] = st->out_rot[r * 3 + 0] * p.x + st->out_rot[r * 3 + 1] * p.y + st->out_rot[r * 3 + 2] * p.z + st->out_trans[r];
+      }
+      c[6] = (float)t;
+      c[7] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out->n_constraints = s_base;
+}
+
+int odometry_loop_candidate(dms_odometry* o, const FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
+                            LoopState* out, float* cons, hipStream_t s) {
+  hipLaunchKernelGGL(k_loop_candidate, dim3(1), dim3(256), 0, s, o->state, frame, (const float4*)vertex->data,
+                     (const unsigned short*)oldTime->data, vertex->cols, vertex->rows, maxDepth, out, cons);
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }

@@ -38,6 +38,7 @@ class FusionParams(C.Structure):
         ("pipeline_ingest", C.c_int), ("global_predict", C.c_int),
         ("nid_keyframing", C.c_int), ("nid_threshold", C.c_float), ("nid_depth_lambda", C.c_float), ("nid_bins_img", C.c_int),
         ("nid_bins_depth", C.c_int), ("nid_pyramid_level", C.c_int),
+        ("local_loop_closure", C.c_int),
     ]
 
 
@@ -45,6 +46,8 @@ class FrameResult(C.Structure):
     _fields_ = [
         ("pose", C.c_float * 16), ("surfels", C.c_uint), ("tick", C.c_int), ("fused", C.c_int), ("fill_in", C.c_int),
         ("weighting", C.c_float), ("nid_score", C.c_float), ("track", TrackResult),
+        ("loop_ok", C.c_int), ("loop_constraints", C.c_int), ("loop_icp_error", C.c_float), ("loop_icp_count", C.c_float),
+        ("loop_pose", C.c_float * 16), ("loop_cov_diag", C.c_double * 6),
     ]
 
 
@@ -85,6 +88,7 @@ lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
 lib.dms_fusion_odometry.restype = _P
 lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
+lib.dms_fusion_get_loop_constraints.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]
 lib.dms_fusion_set_profiling.argtypes = [_P, _I]
 lib.dms_fusion_get_kernel_time.argtypes = [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -306,7 +310,8 @@ class IndexMap:
 
 _IMG_TYPES = {0: (np.uint8, 4), 1: (np.uint16, 1), 2: (np.uint16, 1), 3: (np.float32, 1), 4: (np.float32, 1), 5: (np.uint32, 1),
               6: (np.float32, 4), 7: (np.float32, 4), 8: (np.float32, 4), 9: (np.uint8, 4), 10: (np.float32, 4), 11: (np.float32, 4),
-              12: (np.uint16, 1), 13: (np.uint8, 4), 14: (np.float32, 4), 15: (np.float32, 4)}
+              12: (np.uint16, 1), 13: (np.uint8, 4), 14: (np.float32, 4), 15: (np.float32, 4),
+              16: (np.uint8, 4), 17: (np.float32, 4), 18: (np.float32, 4), 19: (np.uint16, 1)}
 
 
 class ElasticFusion:
@@ -370,6 +375,16 @@ class ElasticFusion:
         check(lib.dms_fusion_get_image(self.h, which, C.byref(v)), "dms_fusion_get_image")
         dt, k = _IMG_TYPES[which]
         return capi.download_view(v, dt, k)
+
+    def loopConstraints(self):
+        """Surface constraints of the last fetched frame's loop candidate: n x 7 float32
+        {worldRawPoint, worldModelPoint, source time} (ElasticFusion.cpp:446-474)."""
+        n = C.c_int(0)
+        cap = (self.width // 20) * (self.height // 20)
+        out = np.zeros((cap, 7), np.float32)
+        check(lib.dms_fusion_get_loop_constraints(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)),
+              "dms_fusion_get_loop_constraints")
+        return out[:n.value].copy()
 
     def set_profiling(self, on):
         check(lib.dms_fusion_set_profiling(self.h, int(on)))

@@ -176,6 +176,17 @@ typedef struct dms_fusion_params {
   int nid_bins_img;          /* 64 */
   int nid_bins_depth;        /* 500 */
   int nid_pyramid_level;     /* 0 */
+  /* Device half of the local loop-closure block (`closeLoops`, ElasticFusion.cpp:399-497, the branch
+   * without a fern match): INACTIVE prediction of the map (IndexMap::combinedPredict, window
+   * tick - timeDelta), model-to-model tracking of the ACTIVE against the INACTIVE view (a second
+   * RGBDOdometry, icpWeight 10, no SO3), the acceptance test (covariance diagonal <= 8e-5,
+   * lastICPCount > 15000, lastICPError < 3e-4) and the W/20 x H/20 surface-constraint sampling.
+   * Everything stays on the stream; the outcome is reported in dms_frame_result.loop_* and
+   * dms_fusion_get_loop_constraints.  The reference then hands the constraints to its CPU/CHOLMOD
+   * deformation solver (Deformation::constrain, :481), which is the caller's: the pose is left as
+   * tracked.  Implies global_predict.  This is the "full" frame step of the measurement contract
+   * (tracking runs twice per frame).  Default 0 (--o). */
+  int local_loop_closure;
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
@@ -193,6 +204,13 @@ typedef struct dms_frame_result {
   float weighting;         /* velocity weight (ElasticFusion.cpp:252-268) */
   float nid_score;         /* Context::nidScores().back() (0 with key-framing off) */
   dms_track_result track;  /* tracker side outputs */
+  /* local loop-closure candidate (local_loop_closure = 1; zero otherwise) */
+  int loop_ok;               /* acceptance test passed (ElasticFusion.cpp:441-442) */
+  int loop_constraints;      /* surface constraints sampled (:446-474); 0 unless loop_ok */
+  float loop_icp_error;      /* modelToModel().lastICPError */
+  float loop_icp_count;      /* modelToModel().lastICPCount */
+  float loop_pose[16];       /* estPose: the ACTIVE view registered onto the INACTIVE one */
+  double loop_cov_diag[6];   /* diagonal of modelToModel().getCovariance() */
 } dms_frame_result;
 
 /* ElasticFusion::processFrame (ElasticFusion.cpp:99-637) for one camera with loop closure off
@@ -208,8 +226,15 @@ dms_model* dms_fusion_model(dms_fusion* f);
 dms_odometry* dms_fusion_odometry(dms_fusion* f);
 /* device images owned by the context; which: 0 rgb(rgba8) 1 depth_raw 2 depth_filtered 3 depth_metric
  * 4 depth_metric_filtered 5 index 6 vertConf 7 colorTime 8 normRad 9 pred image 10 pred vertex
- * 11 pred normal 12 pred time 13 fill image 14 fill vertex 15 fill normal */
+ * 11 pred normal 12 pred time 13 fill image 14 fill vertex 15 fill normal; with local_loop_closure
+ * also the INACTIVE view: 16 old image 17 old vertex 18 old normal 19 old time */
 int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view);
+
+/* Surface constraints of the last fetched frame's loop candidate, in the reference's sampling
+ * order (columns outer, rows inner, ElasticFusion.cpp:446-447): per row
+ * {worldRawPoint xyz, worldModelPoint xyz, source time} = the arguments of
+ * Deformation::addConstraint (:468-470).  Copies min(*n, max_rows) rows of 7 floats to host memory. */
+int dms_fusion_get_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n);
 int dms_fusion_set_profiling(dms_fusion* f, int enabled);
 int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches);
 

@@ -1,8 +1,10 @@
 """CPU ORACLE (test infrastructure): ElasticFusion::processFrame for one camera, restated over
 the oracle's C functions (oracle/orc_*.c) with host arrays.
 
-Follows elasticfusion/Core/src/ElasticFusion.cpp:99-637 with loop closure off (--o: the
-`closeLoops` block :399-497 is skipped), NID keyframing off by default (--nkf: fuseFrame returns
+Follows elasticfusion/Core/src/ElasticFusion.cpp:99-637 with loop closure off by default (--o: the
+`closeLoops` block :399-497 is skipped; local_loop_closure=True restates its device half — INACTIVE
+prediction, model-to-model tracking, acceptance test, constraint sampling — and stops where the
+reference hands the constraints to the CPU/CHOLMOD deformation solver), NID keyframing off by default (--nkf: fuseFrame returns
 true, :639-645; nid_keyframing=True restates the gate of :646-675), no relocalisation (--rl off: trackingOk is always true, :204-244), cluster 0.
 The deformation graph is empty (it is only filled by loop closures), so clean() runs without
 nodes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
@@ -20,7 +22,7 @@ class ElasticFusion:
     def __init__(self, width, height, K, timeDelta=200, confidence=10.0, depthCut=3.0, icpWeight=10.0, fastOdom=False, so3=True,
                  frameToFrameRGB=False, pyramid=True, hybrid_tracking=True, rgbOnly=False, timeIdx=0, maxDepthProcessed=25.0,
                  model_capacity=None, nid_keyframing=False, nid_threshold=0.80, nid_depth_lambda=0.7, nid_bins_img=64,
-                 nid_bins_depth=500, nid_pyramid_level=0):
+                 nid_bins_depth=500, nid_pyramid_level=0, local_loop_closure=False):
         self.W, self.H, self.K = width, height, tuple(float(v) for v in K)
         self.timeDelta, self.confidence, self.depthCut, self.icpWeight = timeDelta, confidence, depthCut, icpWeight
         self.fastOdom, self.so3, self.frameToFrameRGB, self.pyramid = fastOdom, so3, frameToFrameRGB, pyramid
@@ -33,6 +35,9 @@ class ElasticFusion:
         self.nidScores = []
         fx, fy, cx, cy = self.K
         self.frameToModel = orc.Odometry(width, height, cx, cy, fx, fy)
+        self.local_loop_closure = local_loop_closure
+        self.modelToModel = orc.Odometry(width, height, cx, cy, fx, fy) if local_loop_closure else None  # Context.h:317-378
+        self.old = None
         self.model = np.zeros(0, orc.SURFEL_DTYPE)
         self.currPose = np.eye(4, dtype=np.float32)
         self.tick = 1
@@ -47,6 +52,48 @@ class ElasticFusion:
         self.pred = (img, vtx, nrm, tim)
         self.fill = (fi, fv, fn)
 
+    # closeLoops block without a fern match (:399-497): rawGraph is empty and the camera is never lost
+    def localLoop(self):
+        K, H, W = self.K, self.H, self.W
+        # combinedPredict(currPose, model, maxDepthProcessed, confidenceThreshold, 0, id, tick - timeDelta, timeDelta, INACTIVE) (:403-406)
+        self.old = orc.splat_predict(self.model, self.currPose, K, H, W, self.maxDepthProcessed, self.confidence, 0, self.timeIdx,
+                                     self.tick - self.timeDelta, self.timeDelta, False)
+        oimg, ovtx, onrm, otim = self.old
+        m = self.modelToModel
+        m.initICPModel(ovtx, onrm, self.maxDepthProcessed, self.currPose)  # :410-412
+        m.initRGBModel(oimg)  # :413
+        m.initICPMaps(self.pred[1], self.pred[2], self.maxDepthProcessed)  # :415-417
+        m.initRGB(self.pred[0])  # :418
+        t, R, res = m.getIncrementalTransformation(self.currPose[:3, 3], self.currPose[:3, :3], False, 10.0, self.pyramid, self.fastOdom,
+                                                   False)  # :424-425
+        covar = orc.covariance(np.array(res.lastA))  # :427
+        covOk = not any(covar[i, i] > 8e-05 for i in range(6))  # :428-435
+        estPose = np.eye(4, dtype=np.float32)
+        estPose[:3, 3] = t
+        estPose[:3, :3] = R
+        loop = Frame()
+        loop.track, loop.estPose, loop.covar = res, estPose, covar
+        loop.ok = bool(covOk and res.lastICPCount > 15000 and res.lastICPError < 0.0003)  # :441-442
+        loop.constraints = np.zeros((0, 7), np.float32)
+        if loop.ok:
+            dh, dw = H // 20, W // 20
+            cons = orc.resize_nn(self.pred[1], dh, dw)  # resize.vertex(vertexTex, consBuff) (:443)
+            times = orc.resize_nn(otim, dh, dw)  # resize.time(oldTimeTex, timesBuff) (:444)
+            rows = []
+            for i in range(dw):  # column-major walk (:446-447)
+                for j in range(dh):
+                    p = cons[j, i]
+                    if p[2] > 0 and p[2] < self.maxDepthProcessed and times[j, i] > 0:
+                        ph = np.array([p[0], p[1], p[2], 1.0], np.float32)
+                        raw = (self.currPose.astype(np.float32) @ ph)[:3]
+                        mod = (estPose @ ph)[:3]
+                        rows.append(np.concatenate([raw, mod, [np.float32(times[j, i])]]).astype(np.float32))
+            if rows:
+                loop.constraints = np.stack(rows)
+            # Deformation::constrain (:481) is the CPU/CHOLMOD graph optimisation: not part of the
+            # device path; the pose is left as tracked (the `constrain() == false` branch)
+        return loop
+
     # ElasticFusion::fuseFrame (:639-677): the candidate key frame is the model prediction at the new
     # pose (GlobalPredict, :273); its "old" (INACTIVE) textures are never rendered with loop closure
     # off, i.e. no prediction anywhere (NaN depth, black image)
@@ -58,8 +105,17 @@ class ElasticFusion:
         dmap = orc.verticesToDepth(self.pred[1], self.maxDepthProcessed)
         for _ in range(self.nid_pyramid_level):  # MutualInformation::nidImg (:169-174)
             img, dmap = orc.pyrDownUcharGauss(img), orc.pyrDownGaussF(dmap)
-        old_img = np.zeros_like(img)
-        old_d = np.full_like(dmap, np.nan)
+        if self.old is not None:
+            # KeyFrame (KeyFrame.h:83-172) with a rendered INACTIVE view.  (The reference copies the old
+            # vertex texture with the byte count of an already released array, KeyFrame.h:147-150, so what
+            # its verticesToDepth reads there is undefined; the evident intent is restated.)
+            old_img = orc.imageBGRToIntensity(self.old[0])
+            old_d = orc.verticesToDepth(self.old[1], self.maxDepthProcessed)
+            for _ in range(self.nid_pyramid_level):
+                old_img, old_d = orc.pyrDownUcharGauss(old_img), orc.pyrDownGaussF(old_d)
+        else:
+            old_img = np.zeros_like(img)
+            old_d = np.full_like(dmap, np.nan)
         L = self.nid_pyramid_level
         nid_img, _ = orc_nid.nid_img(img, old_img, dmap, old_d, self.frameToModel.buffer(7, L), self.nid_bins_img)
         nid_depth, _ = orc_nid.nid_depth(dmap, old_d, self.frameToModel.buffer(5, L), self.nid_bins_depth, self.maxDepthProcessed * 1000.0)
@@ -82,6 +138,7 @@ class ElasticFusion:
         out.weighting = 1.0
         out.track = None
         out.nid_score = 0.0
+        out.loop = None
         fused = False
         if not self.initialised:  # first run (:132-152)
             pose = np.eye(4, dtype=np.float32) if inPose is None else np.asarray(inPose, np.float32).reshape(4, 4)
@@ -113,6 +170,8 @@ class ElasticFusion:
             weighting = orc.velocity_weight(self.currPose, lastPose, weightMultiplier)  # :252-268
             out.weighting = weighting
             self.predict(self.confidence)  # :273
+            if self.local_loop_closure:
+                out.loop = self.localLoop()  # :399-497
             fuse, out.nid_score = self.fuseFrame()  # :501
             td = self.timeDelta + self.framesSinceLastFusion  # :518,:541,:563
             if not self.rgbOnly and fuse:  # fusion (:506-564)

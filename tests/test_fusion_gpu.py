@@ -563,6 +563,68 @@ def test_nid_keyframing_gate(fus, orc, synth):
         o.framesSinceLastFusion = 0 if rg.fused else o.framesSinceLastFusion  # keep the counters aligned when a borderline decision differed
 
 
+def test_local_loop_closure_candidate(fus, orc, synth):
+    """"Full" frame step (ElasticFusion.cpp:399-497, local loop closure on): the left 35% of the
+    depth image is blanked for four frames, so those surfels age out of the active window
+    (timeDelta = 2); when depth returns, new surfels are laid over them and the model-to-model
+    tracker registers the ACTIVE on the INACTIVE view.  Teacher-forced per step: INACTIVE view
+    exact, loop pose within the north-star bar, same decision, same constraints."""
+    from oracle import orc_pipeline
+
+    W6, H6, K6 = 640, 480, (528.0, 528.0, 320.0, 240.0)
+    opts = dict(model_capacity=2500000, timeDelta=2, confidence=1.0, local_loop_closure=True)
+    g = fus.ElasticFusion(W6, H6, K6, **opts)
+    o = orc_pipeline.ElasticFusion(W6, H6, K6, **opts)
+    accepted = 0
+    worst_t = worst_r = 0.0
+    for k in range(8):
+        d, rgb, _ = synth.frame(k, width=W6, height=H6, K=K6, noise=True)
+        if 2 <= k <= 5:
+            d = d.copy()
+            d[:, : int(W6 * 0.35)] = 0
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
+        if k > 0:
+            # the oracle tracked to a pose ~1e-5 away, which moves splat edges by whole pixels: replay its loop
+            # block from the GPU's post-tracking pose and the pre-fusion map both sides share
+            time = rg.tick - 1
+            o.model, o.currPose, o.tick = model_before, pose_g.copy(), time
+            o.predict(o.confidence)
+            L = o.localLoop()
+            o.tick = rg.tick
+            old = orc.splat_predict(model_before, pose_g, K6, H6, W6, 25.0, 1.0, 0, 0, time - 2, 2, False)
+            # (images 16-19 are the INACTIVE view of this frame: the final predict does not touch them)
+            assert_bits(g.image(17), old[1], "INACTIVE vertex, frame %d" % k)
+            assert_bits(g.image(16), old[0], "INACTIVE image, frame %d" % k)
+            assert_bits(g.image(19), old[3], "INACTIVE time, frame %d" % k)
+            assert rg.loop_icp_count == pytest.approx(L.track.lastICPCount, rel=2e-3, abs=4), k
+            if L.track.lastICPCount > 0:
+                assert rg.loop_icp_error == pytest.approx(L.track.lastICPError, rel=2e-2), k
+                lp = np.array(rg.loop_pose, np.float32).reshape(4, 4)
+                dt, da = helpers.assert_pose_close(lp[:3, 3], lp[:3, :3], L.estPose[:3, 3], L.estPose[:3, :3], what="loop pose, frame %d" % k)
+                worst_t, worst_r = max(worst_t, dt), max(worst_r, da)
+                assert np.allclose(np.array(rg.loop_cov_diag), np.diag(L.covar), rtol=2e-2), k
+            assert bool(rg.loop_ok) == L.ok, k
+            cg = g.loopConstraints()
+            assert len(cg) == rg.loop_constraints
+            if L.ok:
+                accepted += 1
+                # same sampled pixels in the same order (the ACTIVE vertex map differs by the pose difference only)
+                assert len(cg) == len(L.constraints), (k, len(cg), len(L.constraints))
+                assert (cg[:, 6] == L.constraints[:, 6]).all(), "constraint source times, frame %d" % k
+                assert np.abs(cg[:, :6] - L.constraints[:, :6]).max() < 2e-3, k
+            else:
+                assert len(cg) == 0
+        mg = g.globalModel().downloadMap()
+        o.model = mg.copy()
+        o.currPose = pose_g.copy()
+        model_before = mg
+    assert accepted >= 3, accepted
+    print("loop candidate: %d accepted, worst loop-pose difference %.3e m, %.3e deg" % (accepted, worst_t, worst_r))
+
+
 def test_global_predict_is_dead_work(fus, synth):
     """The reference's post-tracking "GlobalPredict" (ElasticFusion.cpp:273) feeds only blocks the
     fork compiles out and is overwritten by the final predict: running it (global_predict = 1)
