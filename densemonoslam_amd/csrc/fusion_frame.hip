@@ -55,6 +55,8 @@ int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rg
                               hipStream_t s);
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s);
+int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
+                            hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
 int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth);
 struct LoopState;
@@ -654,10 +656,8 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
                                            f->pred_old.vertex.data, f->pred_old.normal.data, f->pred_old.image.data, &f->state->fill_in, 0,
                                            f->state->cur.pose, s)))
           return rc;
-        if ((rc = dms_odometry_initICP_maps(f->odom_m2m, (const float*)f->pred.vertex.data, (const float*)f->pred.normal.data,
-                                            f->p.maxDepthProcessed, s)))
+        if ((rc = odometry_initLive_fused(f->odom_m2m, f->pred.vertex.data, f->pred.normal.data, f->pred.image.data, &f->state->fill_in, s)))
           return rc;
-        if ((rc = dms_odometry_initRGB(f->odom_m2m, &f->pred.image, s))) return rc;
       }
       {
         FTimer t(f, s, "loop_track");  // getIncrementalTransformation(trans, rot, false, 10, pyramid, fastOdom, false) (:424-425)

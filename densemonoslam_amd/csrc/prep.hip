@@ -298,7 +298,7 @@ struct ModelSrc {
   const uchar4* iB;
   const int* flag;   // device flag: 1 = use the fill-in maps
   int force_b_img;   // frameToFrameRGB: always the fill-in image
-  const float* pose16;
+  const float* pose16;  // model pose for transformMaps; null = leave the maps in the camera frame (live side, initICP from maps)
 };
 
 struct Pose34 {
@@ -307,6 +307,10 @@ struct Pose34 {
 };
 __device__ __forceinline__ Pose34 load_pose34(const float* pose16) {
   Pose34 p;
+  if (!pose16) {
+    p.R.r0 = p.R.r1 = p.R.r2 = p.t = mk3(0.f, 0.f, 0.f);
+    return p;
+  }
   p.R.r0 = mk3(pose16[0], pose16[1], pose16[2]);
   p.R.r1 = mk3(pose16[4], pose16[5], pose16[6]);
   p.R.r2 = mk3(pose16[8], pose16[9], pose16[10]);
@@ -322,9 +326,9 @@ __device__ __forceinline__ void raw_maps(const float4 v, const float4 q, f3& rv,
 }
 // transformMaps rule + store into stacked planes
 __device__ __forceinline__ void store_transformed(View<float> vmap, View<float> nmap, int rows, int y, int x, const f3& rv, const f3& rn,
-                                                  const Pose34& P) {
+                                                  const Pose34& P, bool xf) {
   if (!isnan(rv.x)) {
-    const f3 d = mul(P.R, rv) + P.t;
+    const f3 d = xf ? mul(P.R, rv) + P.t : rv;
     vmap.at(y, x) = d.x;
     vmap.at(y + rows, x) = d.y;
     vmap.at(y + 2 * rows, x) = d.z;
@@ -332,7 +336,7 @@ __device__ __forceinline__ void store_transformed(View<float> vmap, View<float> 
     vmap.at(y, x) = qnan();
   }
   if (!isnan(rn.x)) {
-    const f3 d = mul(P.R, rn);
+    const f3 d = xf ? mul(P.R, rn) : rn;
     nmap.at(y, x) = d.x;
     nmap.at(y + rows, x) = d.y;
     nmap.at(y + 2 * rows, x) = d.z;
@@ -355,7 +359,7 @@ __global__ void k_model_level0(ModelSrc m, int rows, int cols, View<float> vmap,
   const Pose34 P = load_pose34(m.pose16);
   f3 rv, rn;
   raw_maps(v, q, rv, rn);
-  store_transformed(vmap, nmap, rows, y, x, rv, rn, P);
+  store_transformed(vmap, nmap, rows, y, x, rv, rn, P, m.pose16 != nullptr);
   depth.at(y, x) = (v.z > cutOff || v.z <= 0.f) ? qnan() : v.z;
   const float f = ((float)c.x * 0.114f + (float)c.y * 0.299f) + (float)c.z * 0.587f;
   inten.at(y, x) = (unsigned char)f2i_rz(f);
@@ -398,12 +402,12 @@ __global__ void k_model_levels12(ModelSrc m, int cols0, int rows1, int cols1, in
     }
     lv[k] = resize4<false>(rv[0], rv[1], rv[2], rv[3]);
     ln[k] = resize4<true>(rn[0], rn[1], rn[2], rn[3]);
-    store_transformed(v1, n1, rows1, y1, x1, lv[k], ln[k], P);
+    store_transformed(v1, n1, rows1, y1, x1, lv[k], ln[k], P, m.pose16 != nullptr);
   }
   if (x2 < cols2 && y2 < rows2) {  // then all four level-1 pixels exist
     const f3 a = resize4<false>(lv[0], lv[1], lv[2], lv[3]);
     const f3 b = resize4<true>(ln[0], ln[1], ln[2], ln[3]);
-    store_transformed(v2, n2, rows2, y2, x2, a, b, P);
+    store_transformed(v2, n2, rows2, y2, x2, a, b, P, m.pose16 != nullptr);
   }
 }
 
@@ -482,20 +486,33 @@ __global__ void k_derivatives(View<const unsigned char> src, View<short> dx, Vie
   dy.at(y, x) = (short)f2i_rz(dyVal);
 }
 
-// Pose-independent part of the photometric correspondence test (RGBResidual::getProducts,
-// reduce.cu:775-797), evaluated once per frame and level instead of once per Gauss-Newton iteration:
-// gate = inside the border && all 16 taps of the clipped 4x4 window non-zero && |grad|^2 >= minScale,
-// with dx / dy exactly the values k_derivatives stores.
-__global__ void k_rgb_gate(View<const unsigned char> src, View<const short> dx, View<const short> dy, View<unsigned char> gate,
-                           float minScale) {
+// k_derivatives plus the pose-independent part of the photometric correspondence test
+// (RGBResidual::getProducts, reduce.cu:775-797), evaluated once per frame and level instead of once
+// per Gauss-Newton iteration: gate = inside the border && all 16 taps of the clipped 4x4 window
+// non-zero && |grad|^2 >= minScale, with dx / dy exactly the values stored here.
+__global__ void k_derivatives_gate(View<const unsigned char> src, View<short> dx, View<short> dy, View<unsigned char> gate, float minScale) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= src.cols || y >= src.rows) return;
   const int cols = src.cols, rows = src.rows;
+  const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+  const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+  float dxVal = 0.f, dyVal = 0.f;
+  int k = 8;
+  for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
+    for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); i++) {
+      const float p = (float)src.at(j, i);
+      dxVal += p * gx[k];
+      dyVal += p * gy[k];
+      --k;
+    }
+  const short sx = (short)f2i_rz(dxVal), sy = (short)f2i_rz(dyVal);
+  dx.at(y, x) = sx;
+  dy.at(y, x) = sy;
   bool ok = (x < cols - 5 && y < rows - 1);
   for (int u = max(y - 2, 0); u < min(y + 2, rows); u++)
     for (int v = max(x - 2, 0); v < min(x + 2, cols); v++) ok = ok && (src.at(u, v) > 0);
-  const int vx = dx.at(y, x), vy = dy.at(y, x);
+  const int vx = sx, vy = sy;
   const float mTwo = (float)(vx * vx + vy * vy);
   gate.at(y, x) = (ok && mTwo >= minScale) ? 1 : 0;
 }
@@ -619,7 +636,7 @@ int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
 int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void* vB, const void* nB, const void* iB, const int* flag_dev,
                       int force_b_img, const float* pose16_dev, dms_image2d* vmaps, dms_image2d* nmaps, dms_image2d* depths,
                       dms_image2d* images, float cutOff, hipStream_t s) {
-  DMS_REQUIRE(vA && nA && iA && vB && nB && iB && flag_dev && pose16_dev && vmaps && nmaps && depths && images, "null argument");
+  DMS_REQUIRE(vA && nA && iA && vB && nB && iB && flag_dev && vmaps && nmaps && depths && images, "null argument");
   ModelSrc m;
   m.vA = (const float4*)vA;
   m.nA = (const float4*)nA;
@@ -668,10 +685,12 @@ int derivativeImages(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, h
   return DMS_OK;
 }
 
-int rgbGate(const dms_image2d* src, const dms_image2d* dx, const dms_image2d* dy, dms_image2d* gate, float minScale, hipStream_t s) {
+int derivativeGate(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, dms_image2d* gate, float minScale, hipStream_t s) {
   DMS_REQUIRE(src && dx && dy && gate && src->data && dx->data && dy->data && gate->data, "null argument");
-  DMS_REQUIRE(gate->rows == src->rows && gate->cols == src->cols, "shape mismatch");
-  LAUNCH2D(k_rgb_gate, src->cols, src->rows, s, view<const unsigned char>(src), view<const short>(dx), view<const short>(dy),
+  DMS_REQUIRE(dx->rows == src->rows && dx->cols == src->cols && dy->rows == src->rows && dy->cols == src->cols && gate->rows == src->rows &&
+                  gate->cols == src->cols,
+              "shape mismatch");
+  LAUNCH2D(k_derivatives_gate, src->cols, src->rows, s, view<const unsigned char>(src), view<short>(dx), view<short>(dy),
            view<unsigned char>(gate), minScale);
   return DMS_OK;
 }

@@ -1559,8 +1559,7 @@ int nextDerivatives(dms_odometry* o, hipStream_t s) {
   int rc;
   for (int i = 0; i < DMS_NUM_PYRS; i++) {
     dms_image2d a = o->nextImage[i].img(), dx = o->nextdIdx[i].img(), dy = o->nextdIdy[i].img(), g = o->nextGate[i].img();
-    if ((rc = derivativeImages(&a, &dx, &dy, s))) return rc;
-    if ((rc = rgbGate(&a, &dx, &dy, &g, rgb_min_scale(o, i), s))) return rc;
+    if ((rc = derivativeGate(&a, &dx, &dy, &g, rgb_min_scale(o, i), s))) return rc;
   }
   o->deriv_of = o->nextImage[0].p;
   return DMS_OK;
@@ -2250,6 +2249,22 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
     im[i] = o->lastImage[i].img();
   }
   return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s);
+}
+
+// initICP(vertex map, normal map) + initRGB(image) of the live side in the fused form (RGBDOdometry.cpp:118-137,
+// :162-191 through populateRGBDData): no transform, nextDepth from the same vertex map, then the Sobel / gate pyramid
+int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
+                            hipStream_t s) {
+  dms_image2d v[DMS_NUM_PYRS], n[DMS_NUM_PYRS], d[DMS_NUM_PYRS], im[DMS_NUM_PYRS];
+  for (int i = 0; i < DMS_NUM_PYRS; ++i) {
+    v[i] = o->vmaps_curr[i].img();
+    n[i] = o->nmaps_curr[i].img();
+    d[i] = o->nextDepth[i].img();
+    im[i] = o->nextImage[i].img();
+  }
+  int rc = modelPyramidFused(verts, norms, rgba, verts, norms, rgba, any_flag_dev, 0, nullptr, v, n, d, im, o->maxDepthRGB, s);
+  if (rc) return rc;
+  return nextDerivatives(o, s);
 }
 
 // initICPModel with the source chosen on device: (*flag ? fill-in maps : predicted maps), pose read from HBM
