@@ -2048,42 +2048,39 @@ __global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __rest
   __shared__ int s_ok;
   __shared__ int s_wave[4];
   __shared__ int s_base;
+  // Gauss-Jordan on the augmented 6x12 matrix in LDS, one thread per element: the same operations
+  // in the same order per element as the scalar loop of dms_odometry_getCovariance
+  __shared__ double s_m[6][12];
+  const int er = threadIdx.x / 12, ej = threadIdx.x % 12;
+  const bool elem = threadIdx.x < 72;
+  if (elem) s_m[er][ej] = ej < 6 ? st->lastA[er * 6 + ej] : ((ej - 6 == er) ? 1.0 : 0.0);
+  __syncthreads();
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (fabs(s_m[r][c]) > fabs(s_m[p][c])) p = r;
+    __syncthreads();
+    if (p != c && threadIdx.x < 12) {
+      const double t0 = s_m[c][threadIdx.x];
+      s_m[c][threadIdx.x] = s_m[p][threadIdx.x];
+      s_m[p][threadIdx.x] = t0;
+    }
+    __syncthreads();
+    const double d = s_m[c][c];
+    __syncthreads();
+    if (threadIdx.x < 12) s_m[c][threadIdx.x] /= d;
+    __syncthreads();
+    const double f = elem ? s_m[er][c] : 0.0;
+    __syncthreads();
+    if (elem && er != c) s_m[er][ej] -= f * s_m[c][ej];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    double a[36], inv[36];
-    for (int i = 0; i < 36; ++i) {
-      a[i] = st->lastA[i];
-      inv[i] = (i % 7 == 0) ? 1.0 : 0.0;
-    }
-    for (int c = 0; c < 6; ++c) {
-      int p = c;
-      for (int r = c + 1; r < 6; ++r)
-        if (fabs(a[r * 6 + c]) > fabs(a[p * 6 + c])) p = r;
-      if (p != c)
-        for (int j = 0; j < 6; ++j) {
-          const double t0 = a[c * 6 + j], t1 = inv[c * 6 + j];
-          a[c * 6 + j] = a[p * 6 + j];
-          inv[c * 6 + j] = inv[p * 6 + j];
-          a[p * 6 + j] = t0;
-          inv[p * 6 + j] = t1;
-        }
-      const double d = a[c * 6 + c];
-      for (int j = 0; j < 6; ++j) {
-        a[c * 6 + j] /= d;
-        inv[c * 6 + j] /= d;
-      }
-      for (int r = 0; r < 6; ++r) {
-        if (r == c) continue;
-        const double f = a[r * 6 + c];
-        for (int j = 0; j < 6; ++j) {
-          a[r * 6 + j] -= f * a[c * 6 + j];
-          inv[r * 6 + j] -= f * inv[c * 6 + j];
-        }
-      }
-    }
     bool covOk = true;
     for (int i = 0; i < 6; ++i) {
-      out->cov_diag[i] = inv[i * 7];
-      if (inv[i * 7] > 8e-05) covOk = false;
+      const double cii = s_m[i][6 + i];
+      out->cov_diag[i] = cii;
+      if (cii > 8e-05) covOk = false;
     }
     const int ok = (covOk && st->lastICPCount > 15000.f && st->lastICPError < 0.0003f) ? 1 : 0;
     out->ok = ok;
