@@ -101,6 +101,14 @@ __global__ void k_pose_set(FrameState* st, Pose16 p) {
   st->fill_in = 0;
 }
 
+// context.currPose() = estPose after an accepted deformation (ElasticFusion.cpp:489): the velocity weight of
+// this frame is already fixed (:252-268); the next frame's lastPose is the new pose (:158)
+__global__ void k_pose_override(FrameState* st, Pose16 p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; ++i) st->cur.pose[i] = st->lastPose[i] = p.v[i];
+  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
+}
+
 __global__ void k_frame_after_track(FrameState* st, float weightMultiplier) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   frame_after_track_body(st, weightMultiplier);
@@ -172,6 +180,10 @@ struct dms_fusion {
   float* nid_host = nullptr;  // pinned [2]
   int frames_since_fusion = 0;
   float last_nid = 0.f;
+  // between dms_fusion_process_frame_begin and _end
+  bool in_frame = false, cur_bootstrap = false, cur_fuse_now = true;
+  int cur_k2 = 0;
+  dms_image2d depth_synth;  // IndexMap::synthesizeDepth target (deformation frames only)
   dms_indexmap_out imap;
   dms_predict_out pred, fill;
   void* rgba_tmp = nullptr;
@@ -262,6 +274,7 @@ void layout(dms_fusion* f, Carve& c) {
     f->loop_bytes = up256(sizeof(LoopState)) + (size_t)(W / 20) * (H / 20) * 8 * sizeof(float);
     f->loop = (LoopState*)c.take(f->loop_bytes);
   }
+  f->depth_synth = mk_img(c.take(N * 4), H, W, 4);
   f->rgba_tmp = c.take(N * 4);
   f->untr = c.take(N * 16);
   f->zbuf = (unsigned long long*)c.take(N * 8);
@@ -512,10 +525,11 @@ int dms_fusion_destroy(dms_fusion* f) {
 dms_model* dms_fusion_model(dms_fusion* f) { return f ? f->model : nullptr; }
 dms_odometry* dms_fusion_odometry(dms_fusion* f) { return f ? f->odom : nullptr; }
 
-int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev, const float* inPose16,
-                             float weightMultiplier, dms_stream st) {
+int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev,
+                                   const float* inPose16, float weightMultiplier, dms_stream st) {
   DMS_REQUIRE(f && rgb_dev && depth_dev, "null argument");
   DMS_REQUIRE(rgb_channels == 3 || rgb_channels == 4, "rgb_channels must be 3 or 4");
+  DMS_REQUIRE(!f->in_frame, "dms_fusion_process_frame_end has not been called for the previous frame");
   hipStream_t s = (hipStream_t)st;
   const int W = f->p.width, H = f->p.height, N = W * H;
   int rc;
@@ -586,8 +600,9 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
   memset(&prior, 0, sizeof(prior));
   if (inPose16) memcpy(prior.v, inPose16, sizeof(prior.v));
 
-  int fused = 0;
-  bool surfels_written = false;
+  f->cur_k2 = k2;
+  f->cur_bootstrap = !f->map_initialised;
+  f->cur_fuse_now = true;
   if (!f->map_initialised) {
     // first run (ElasticFusion.cpp:132-152): surfels from this frame, pose = inPose or identity
     if (!inPose16)
@@ -603,7 +618,6 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     }
     // initFirstRGB (ElasticFusion.cpp:151): the intensity pyramid of this frame already sits in ring set 0
     f->map_initialised = true;
-    fused = 1;
   } else {
     if (inPose16) {  // without a prior the pose block is already consistent: the previous frame left lastPose = pose and its inverse
       hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, f->state, prior, 1);
@@ -706,6 +720,40 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     } else {
       f->last_nid = 0.f;
     }
+    f->cur_fuse_now = fuse_now;
+    if (f->p.local_loop_closure) {
+      // the candidate is readable (dms_fusion_fetch_loop) before the second half is enqueued
+      DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+      DMS_HIP(hipMemcpyAsync(f->h_loop + (size_t)k2 * f->loop_bytes, f->loop, f->loop_bytes, hipMemcpyDeviceToHost, s));
+      f->last_slot = k2;
+    }
+  }
+  f->in_frame = true;
+  return DMS_OK;
+}
+
+int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int graph_nodes, const float* newPose16, dms_stream st) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(f->in_frame, "dms_fusion_process_frame_begin has not been called");
+  DMS_REQUIRE(graph_nodes == 0 || graph_host, "null graph");
+  hipStream_t s = (hipStream_t)st;
+  const int k2 = f->cur_k2;
+  int rc;
+  int fused = 0;
+  bool surfels_written = false;
+  f->in_frame = false;
+  if (f->cur_bootstrap) {
+    fused = 1;
+  } else {
+    if (newPose16) {
+      Pose16 np;
+      memcpy(np.v, newPose16, sizeof(np.v));
+      hipLaunchKernelGGL(k_pose_override, dim3(1), dim3(64), 0, s, f->state, np);
+      DMS_CHECK_LAUNCH();
+    }
+    // fuseFrame(context, rawGraph.size() > 0): a deforming frame always fuses (ElasticFusion.cpp:641-644)
+    const bool fuse_now = f->cur_fuse_now || graph_nodes > 0;
+    if (graph_nodes > 0) f->last_nid = 0.f;
     const int timeDeltaEff = f->p.timeDelta + f->frames_since_fusion;  // ElasticFusion.cpp:518,541,563
 
     if (!f->p.rgbOnly && fuse_now) {  // fusion (ElasticFusion.cpp:506-564); tracking is never "lost" without --rl
@@ -727,10 +775,18 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
                             &f->imap, 1, 1, s)))
           return rc;
       }
+      if (graph_nodes > 0) {
+        // a deformation is a second pose update this frame: predict the depth again to decide whose
+        // time stamps to refresh (ElasticFusion.cpp:541-553; synthesizeDepth leaves `actv` false)
+        FTimer t(f, s, "synth_depth");
+        if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, f->p.confidence, f->tick, f->p.timeIdx,
+                                f->tick - timeDeltaEff, 65535, 0, f->zbuf, nullptr, &f->depth_synth, 1, s)))
+          return rc;
+      }
       {
         FTimer t(f, s, "clean");
-        if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, nullptr, 0,
-                              timeDeltaEff, f->p.maxDepthProcessed, 0, 1, &f->state->surfels, s)))
+        if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, graph_nodes > 0 ? &f->depth_synth : nullptr, &f->cam,
+                              f->p.confidence, graph_host, graph_nodes, timeDeltaEff, f->p.maxDepthProcessed, 0, 1, &f->state->surfels, s)))
           return rc;
         surfels_written = true;  // the clean's scan also stores the new count into the result block
       }
@@ -744,13 +800,45 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
     DMS_CHECK_LAUNCH();
   }
   DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
-  if (f->p.local_loop_closure && f->frames > 0)
-    DMS_HIP(hipMemcpyAsync(f->h_loop + (size_t)k2 * f->loop_bytes, f->loop, f->loop_bytes, hipMemcpyDeviceToHost, s));
   f->last_slot = k2;
   if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
   f->fused_last = fused;
   f->tick += 1;  // if(!lost) tick++ (ElasticFusion.cpp:588-591)
   f->frames += 1;
+  return DMS_OK;
+}
+
+int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev, const float* inPose16,
+                             float weightMultiplier, dms_stream st) {
+  int rc = dms_fusion_process_frame_begin(f, rgb_dev, rgb_channels, depth_dev, inPose16, weightMultiplier, st);
+  if (rc) return rc;
+  return dms_fusion_process_frame_end(f, nullptr, 0, nullptr, st);
+}
+
+static void fill_loop(const dms_fusion* f, dms_frame_result* r) {
+  if (!f->h_loop) return;
+  const LoopState* L = (const LoopState*)(f->h_loop + (size_t)f->last_slot * f->loop_bytes);
+  r->loop_ok = L->ok;
+  r->loop_constraints = L->n_constraints;
+  r->loop_icp_error = L->icp_error;
+  r->loop_icp_count = L->icp_count;
+  memcpy(r->loop_pose, L->est_pose, sizeof(r->loop_pose));
+  memcpy(r->loop_cov_diag, L->cov_diag, sizeof(r->loop_cov_diag));
+}
+
+int dms_fusion_fetch_loop(dms_fusion* f, dms_frame_result* r, dms_stream st) {
+  DMS_REQUIRE(f && r, "null argument");
+  DMS_REQUIRE(f->in_frame && f->p.local_loop_closure, "only between process_frame_begin and _end with local_loop_closure");
+  memset(r, 0, sizeof(*r));
+  DMS_HIP(hipStreamSynchronize((hipStream_t)st));
+  if (f->cur_bootstrap) return DMS_OK;
+  const FrameState* hs = f->h_state + f->last_slot;
+  memcpy(r->pose, hs->cur.pose, sizeof(r->pose));
+  r->tick = f->tick;
+  r->fill_in = hs->fill_in;
+  r->weighting = hs->weighting;
+  r->nid_score = f->last_nid;
+  fill_loop(f, r);
   return DMS_OK;
 }
 
@@ -775,15 +863,7 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   r->fill_in = hs->fill_in;
   r->weighting = hs->weighting;
   r->nid_score = f->last_nid;
-  if (f->h_loop) {
-    const LoopState* L = (const LoopState*)(f->h_loop + (size_t)f->last_slot * f->loop_bytes);
-    r->loop_ok = L->ok;
-    r->loop_constraints = L->n_constraints;
-    r->loop_icp_error = L->icp_error;
-    r->loop_icp_count = L->icp_count;
-    memcpy(r->loop_pose, L->est_pose, sizeof(r->loop_pose));
-    memcpy(r->loop_cov_diag, L->cov_diag, sizeof(r->loop_cov_diag));
-  }
+  fill_loop(f, r);
   return DMS_OK;
 }
 

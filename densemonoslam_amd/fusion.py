@@ -88,6 +88,9 @@ lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
 lib.dms_fusion_odometry.restype = _P
 lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
+lib.dms_fusion_process_frame_begin.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_float), _F, _P]
+lib.dms_fusion_fetch_loop.argtypes = [_P, C.POINTER(FrameResult), _P]
+lib.dms_fusion_process_frame_end.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _P]
 lib.dms_fusion_get_loop_constraints.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]
 lib.dms_fusion_set_profiling.argtypes = [_P, _I]
 lib.dms_fusion_get_kernel_time.argtypes = [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -356,6 +359,30 @@ class ElasticFusion:
             pp = self._pose.ctypes.data_as(C.POINTER(C.c_float))
         check(lib.dms_fusion_process_frame(self.h, C.c_void_p(rgb_ptr), channels, C.c_void_p(depth_ptr), pp, weightMultiplier, stream),
               "dms_fusion_process_frame")
+
+    def processFrameBegin(self, rgb, depth, inPose=None, weightMultiplier=1.0, stream=None):
+        ch = self.upload_frame(rgb, depth)
+        pp = None
+        if inPose is not None:
+            self._pose = np.ascontiguousarray(inPose, np.float32).reshape(16)
+            pp = self._pose.ctypes.data_as(C.POINTER(C.c_float))
+        check(lib.dms_fusion_process_frame_begin(self.h, C.c_void_p(self._rgb.ptr), ch, C.c_void_p(self._depth.ptr), pp, weightMultiplier,
+                                                 stream), "dms_fusion_process_frame_begin")
+
+    def fetchLoop(self, stream=None):
+        r = FrameResult()
+        check(lib.dms_fusion_fetch_loop(self.h, C.byref(r), stream), "dms_fusion_fetch_loop")
+        return r
+
+    def processFrameEnd(self, graph=None, newPose=None, stream=None):
+        gp, nn, pp = None, 0, None
+        if graph is not None and len(graph):
+            self._graph = np.ascontiguousarray(graph, np.float32).reshape(-1, 16)
+            gp, nn = self._graph.ctypes.data_as(C.POINTER(C.c_float)), len(self._graph)
+        if newPose is not None:
+            self._newpose = np.ascontiguousarray(newPose, np.float32).reshape(16)
+            pp = self._newpose.ctypes.data_as(C.POINTER(C.c_float))
+        check(lib.dms_fusion_process_frame_end(self.h, gp, nn, pp, stream), "dms_fusion_process_frame_end")
 
     def fetch(self, stream=None):
         r = FrameResult()

@@ -222,6 +222,21 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
                              const float* inPose16, float weightMultiplier, dms_stream s);
 int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream s);
 
+/* The same frame step in two halves, for callers that close local loops: `_begin` enqueues
+ * everything up to and including the loop candidate (and takes the NID decision); the host may
+ * then read the candidate (dms_fusion_fetch_loop: synchronises `s`; fills pose, fill_in, weighting,
+ * nid_score and the loop_* fields; constraints through dms_fusion_get_loop_constraints), run the
+ * reference's Deformation::constrain on it (ElasticFusion.cpp:481) and hand the outcome to `_end`:
+ * graph_host = the deformation graph `rawGraph` (graph_nodes x 16 floats, the layout of
+ * dms_model_clean; 0 nodes = no deformation), newPose16 = the corrected pose (estPose, :489) or
+ * NULL.  `_end` runs the fusion half as ElasticFusion.cpp:506-591 does on such a frame: the frame
+ * always fuses, IndexMap::synthesizeDepth is rendered before the clean, and the clean applies the
+ * graph.  dms_fusion_process_frame == _begin + _end(NULL, 0, NULL). */
+int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev,
+                                   const float* inPose16, float weightMultiplier, dms_stream s);
+int dms_fusion_fetch_loop(dms_fusion* f, dms_frame_result* r, dms_stream s);
+int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int graph_nodes, const float* newPose16, dms_stream s);
+
 dms_model* dms_fusion_model(dms_fusion* f);
 dms_odometry* dms_fusion_odometry(dms_fusion* f);
 /* device images owned by the context; which: 0 rgb(rgba8) 1 depth_raw 2 depth_filtered 3 depth_metric

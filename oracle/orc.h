@@ -89,6 +89,8 @@ void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, fl
 /* which: same numbering as dms_odometry_get_buffer; returns pointer to the dense host buffer */
 void* orc_odometry_buffer(orc_odometry* o, int which, int level);
 void orc_covariance(const double* lastA36, double* cov36);
+void orc_set_threads(int n);
+int orc_get_threads(void);
 
 #ifdef __cplusplus
 }

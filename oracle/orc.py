@@ -309,6 +309,12 @@ class Odometry:
         return np.frombuffer(buf, dtype=dt, count=n).reshape(shape).copy()
 
 
+def set_threads(n):
+    """Threads of the oracle's OpenMP loops (works after libgomp has been initialised by another library)."""
+    lib.orc_set_threads(int(n))
+    return int(lib.orc_get_threads())
+
+
 def covariance(lastA):
     a = _c(lastA, np.float64).reshape(36)
     out = np.zeros(36, np.float64)

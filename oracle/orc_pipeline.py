@@ -123,7 +123,10 @@ class ElasticFusion:
         self.nidScores.append(score)
         return score > self.nid_threshold, score
 
-    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0):
+    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0, deform=None):
+        """deform(loop) stands in for Deformation::constrain (ElasticFusion.cpp:481, CPU/CHOLMOD, not
+        restated): called with the loop candidate, it returns None (no deformation) or
+        (rawGraph nodes n x 16, corrected pose)."""
         rgb = np.ascontiguousarray(rgb, np.uint8)
         if rgb.shape[2] == 3:
             rgb = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
@@ -170,9 +173,18 @@ class ElasticFusion:
             weighting = orc.velocity_weight(self.currPose, lastPose, weightMultiplier)  # :252-268
             out.weighting = weighting
             self.predict(self.confidence)  # :273
+            rawGraph = None
             if self.local_loop_closure:
                 out.loop = self.localLoop()  # :399-497
-            fuse, out.nid_score = self.fuseFrame()  # :501
+                res = deform(out.loop) if deform is not None else None
+                if res is not None:
+                    rawGraph = np.ascontiguousarray(res[0], np.float32).reshape(-1, 16)
+                    self.currPose = np.asarray(res[1], np.float32).reshape(4, 4).copy()  # context.currPose() = estPose (:489)
+            if rawGraph is not None and len(rawGraph):  # fuseFrame(context, deforming) (:641-644)
+                self.nidScores.append(0.0)
+                fuse, out.nid_score = True, 0.0
+            else:
+                fuse, out.nid_score = self.fuseFrame()  # :501
             td = self.timeDelta + self.framesSinceLastFusion  # :518,:541,:563
             if not self.rgbOnly and fuse:  # fusion (:506-564)
                 im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
@@ -181,8 +193,12 @@ class ElasticFusion:
                                                      weighting)
                 im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
                 self.imap = im
+                dsyn = None
+                if rawGraph is not None and len(rawGraph):  # synthesizeDepth (:541-553)
+                    dsyn = orc.splat_predict(self.model, self.currPose, self.K, self.H, self.W, self.maxDepthProcessed, self.confidence,
+                                             self.tick, self.timeIdx, self.tick - td, 65535, False, depth_only=True)
                 self.model = orc.model_clean(self.model, newU, self.currPose, self.tick, self.timeIdx, im[0], im[1], im[2], self.K,
-                                             self.confidence, td, self.maxDepthProcessed, cap=self.cap)
+                                             self.confidence, td, self.maxDepthProcessed, nodes=rawGraph, depthSynth=dsyn, cap=self.cap)
                 fused = True
             self.framesSinceLastFusion = 0 if fuse else self.framesSinceLastFusion + 1  # :567-568
         self.predict(self.confidence)  # finalPredict (:586)

@@ -30,6 +30,11 @@
 #include <string.h>
 
 #include "orc.h"
+#include <omp.h>
+
+/* thread count of the OpenMP loops below (the library default, one per core, oversubscribes these short loops on big hosts) */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_threads(void) { return omp_get_max_threads(); }
 
 /* ------------------------------------------------------------------------------------ */
 /* helpers                                                                                */

@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# the oracle's OpenMP loops are short: on a many-core host the default (one thread per core) costs more
+# in fork/join than it saves
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -34,4 +37,5 @@ def gputest_pair():
 def orc():
     from oracle import orc as _orc
 
+    _orc.set_threads(min(16, os.cpu_count() or 1))
     return _orc

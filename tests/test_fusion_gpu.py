@@ -577,9 +577,9 @@ def test_local_loop_closure_candidate(fus, orc, synth):
     o = orc_pipeline.ElasticFusion(W6, H6, K6, **opts)
     accepted = 0
     worst_t = worst_r = 0.0
-    for k in range(8):
+    for k in range(7):
         d, rgb, _ = synth.frame(k, width=W6, height=H6, K=K6, noise=True)
-        if 2 <= k <= 5:
+        if 2 <= k <= 4:
             d = d.copy()
             d[:, : int(W6 * 0.35)] = 0
         rg = g.processFrame(rgb, d)
@@ -623,6 +623,80 @@ def test_local_loop_closure_candidate(fus, orc, synth):
         model_before = mg
     assert accepted >= 3, accepted
     print("loop candidate: %d accepted, worst loop-pose difference %.3e m, %.3e deg" % (accepted, worst_t, worst_r))
+
+
+def _fake_graph(rng, nn, tmax):
+    nodes = np.zeros((nn, 16), np.float32)
+    nodes[:, 0:3] = rng.uniform([-1.0, -0.8, 0.9], [1.0, 0.8, 2.2], (nn, 3))
+    for j in range(nn):
+        a = rng.normal(0, 0.004, 3)
+        th = np.linalg.norm(a)
+        k = a / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        nodes[j, 3:12] = R.T.reshape(9)
+    nodes[:, 12:15] = rng.normal(0, 0.002, (nn, 3))
+    nodes[:, 15] = np.sort(rng.integers(1, tmax + 1, nn))
+    return nodes
+
+
+def test_two_phase_frame_step_with_deformation(fus, orc, synth):
+    """dms_fusion_process_frame_begin / fetch_loop / _end: the host sits where the reference calls
+    Deformation::constrain (ElasticFusion.cpp:481).  A stand-in graph and the candidate's estPose are
+    handed back on the accepted frames; the fusion half (always fuses, synthesizeDepth, clean with the
+    graph, :506-591) must reproduce the oracle's map exactly from the same pose."""
+    from oracle import orc_pipeline
+
+    W6, H6, K6 = 640, 480, (528.0, 528.0, 320.0, 240.0)
+    opts = dict(model_capacity=2500000, timeDelta=2, confidence=1.0, local_loop_closure=True)
+    g = fus.ElasticFusion(W6, H6, K6, **opts)
+    o = orc_pipeline.ElasticFusion(W6, H6, K6, **opts)
+    rng = np.random.default_rng(11)
+    deformed = 0
+    for k in range(6):
+        d, rgb, _ = synth.frame(k, width=W6, height=H6, K=K6, noise=True)
+        if 2 <= k <= 4:
+            d = d.copy()
+            d[:, : int(W6 * 0.35)] = 0
+        g.processFrameBegin(rgb, d)
+        rl = g.fetchLoop()
+        graph = newPose = None
+        if k > 0 and rl.loop_ok:
+            graph = _fake_graph(rng, 48, rl.tick)
+            newPose = np.array(rl.loop_pose, np.float32).reshape(4, 4)
+            deformed += 1
+        g.processFrameEnd(graph, newPose)
+        rg = g.fetch()
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        mg = g.globalModel().downloadMap()
+        if k == 0:
+            ro = o.processFrame(rgb, d)
+            surfels_equal(mg, o.model, "bootstrap")
+        else:
+            if newPose is not None:
+                assert_bits(pose_g, newPose, "pose after the deformation")
+            # teacher forcing: the oracle's second half from the GPU's pose (tracked or corrected) and graph
+            tracked = np.array(rl.pose, np.float32).reshape(4, 4)
+            ro = o.processFrame(rgb, d, inPose=None, deform=(lambda loop: (graph, newPose)) if graph is not None else None)
+            time = rg.tick - 1
+            im = orc.index_map(model_before, pose_g, K6, H6, W6, time, 0, 25.0, 2)
+            m2, newU, _ = orc.model_fuse(model_before, pose_g, time, 0, o.rgba, o.depth_metric, o.depth_metric_filtered, im[0], im[1], im[3],
+                                         K6, 25.0, float(rg.weighting))
+            im2 = orc.index_map(m2, pose_g, K6, H6, W6, time, 0, 25.0, 2)
+            dsyn = None
+            if graph is not None:
+                dsyn = orc.splat_predict(m2, pose_g, K6, H6, W6, 25.0, 1.0, time, 0, time - 2, 65535, False, depth_only=True)
+            m3 = orc.model_clean(m2, newU, pose_g, time, 0, im2[0], im2[1], im2[2], K6, 1.0, 2, 25.0, nodes=graph, depthSynth=dsyn,
+                                 cap=2500000)
+            surfels_equal(mg, m3, "map after frame %d (deformed=%s)" % (k, graph is not None))
+            assert bool(rg.fused)
+            # the free-running oracle pipeline (its own tracking, same callback) stays within the usual bound
+            helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], tol_m=1e-3, tol_deg=0.01,
+                                      what="frame %d" % k)
+        o.model = mg.copy()
+        o.currPose = pose_g.copy()
+        model_before = mg
+    assert deformed >= 2, deformed
 
 
 def test_global_predict_is_dead_work(fus, synth):
