@@ -157,6 +157,27 @@ class ElasticFusion {
     check(dms_fusion_fetch(h, &r, s), "fetch");
     return r;
   }
+  // local loop closure (ElasticFusion.cpp:399-497): the frame step in two halves around Deformation::constrain
+  void processFrameBegin(const unsigned char* rgb_dev, const unsigned short* depth_dev, const float* inPose = nullptr,
+                         const float weightMultiplier = 1.f, dms_stream s = nullptr) {
+    check(dms_fusion_process_frame_begin(h, rgb_dev, 3, depth_dev, inPose, weightMultiplier, s), "processFrameBegin");
+  }
+  dms_frame_result fetchLoop(dms_stream s = nullptr) {
+    dms_frame_result r;
+    check(dms_fusion_fetch_loop(h, &r, s), "fetchLoop");
+    return r;
+  }
+  // rows of {worldRawPoint, worldModelPoint, source time}: the arguments of Deformation::addConstraint (:468-470)
+  std::vector<float> loopConstraints(int count) {
+    std::vector<float> rows((size_t)count * 7);
+    int n = 0;
+    check(dms_fusion_get_loop_constraints(h, rows.data(), count, &n), "loopConstraints");
+    rows.resize((size_t)(n < count ? n : count) * 7);
+    return rows;
+  }
+  void processFrameEnd(const float* rawGraph = nullptr, int nodes = 0, const float* newPose = nullptr, dms_stream s = nullptr) {
+    check(dms_fusion_process_frame_end(h, rawGraph, nodes, newPose, s), "processFrameEnd");
+  }
   GlobalModel getGlobalModel() { return GlobalModel(dms_fusion_model(h)); }
   dms_fusion* h = nullptr;
 };
