@@ -36,6 +36,7 @@ int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStr
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, int zclean, hipStream_t s);
+int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s);
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
@@ -376,6 +377,9 @@ int dms_splat_depth(dms_model* m, const dms_pose_block* pose, const dms_camera* 
   DMS_REQUIRE(depth, "null output");
   // synthesizeDepth never sets the `actv` uniform (IndexMap.cpp:370-452): it stays false
   return splat_predict(m, pose, cam, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, 0, zbuf, nullptr, depth, 0, (hipStream_t)s);
+}
+int dms_model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n, dms_stream s) {
+  return model_sample_graph(m, sampleRate, rows4_host, max_rows, n, (hipStream_t)s);
 }
 int dms_model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                    const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,

@@ -654,6 +654,67 @@ int model_export_records(dms_model* m, float* rec_dev, unsigned max_count, unsig
 }
 
 // ---------------------------------------------------------------------------------------
+// Deformation::sampleGraphModel, device half (Deformation.cpp:250-348; sample.vert, sample.geom):
+// every sampleRate-th surfel as {pos.xyz, init time}, then ordered by init time.  The reference
+// downloads the samples and std::sorts them on the host (order of equal times unspecified); here
+// the ordering is a stable rank sort on device (ties keep surfel order) and only the sorted rows
+// travel.  Scratch: the inactive half of the double-buffered map (free between cleans).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_graph_sample(SurfelPlanes src, const unsigned* __restrict__ d_count, int rate, float4* __restrict__ out,
+                                                      unsigned* __restrict__ n_out) {
+  const unsigned M = d_count[0];
+  const unsigned n = (M + (unsigned)rate - 1u) / (unsigned)rate;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_out = n;
+  if (i >= n) return;
+  const size_t id = (size_t)i * (size_t)rate;  // gl_VertexID % sampleRate == 0
+  const float4 p = src.pos[id];
+  out[i] = make_float4(p.x, p.y, p.z, src.col[id].z);
+}
+
+__global__ __launch_bounds__(256) void k_graph_rank(const float4* __restrict__ in, const unsigned* __restrict__ n_in, float4* __restrict__ out) {
+  const unsigned n = *n_in;
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_t[256];
+  const float ti = i < n ? in[i].w : 0.f;
+  unsigned rank = 0;
+  for (unsigned base = 0; base < n; base += 256) {
+    const unsigned j = base + threadIdx.x;
+    s_t[threadIdx.x] = j < n ? in[j].w : 0.f;
+    __syncthreads();
+    const unsigned lim = min(256u, n - base);
+    for (unsigned q = 0; q < lim; ++q) {
+      const float tj = s_t[q];
+      rank += (tj < ti || (tj == ti && base + q < i)) ? 1u : 0u;
+    }
+    __syncthreads();
+  }
+  if (i < n) out[rank] = in[i];
+}
+
+int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s) {
+  DMS_REQUIRE(m && n_host && sampleRate >= 2 && (rows4_host || max_rows == 0), "bad argument");
+  const size_t n_upper = (m->count_upper + (size_t)sampleRate - 1) / (size_t)sampleRate;
+  DMS_REQUIRE(2 * n_upper <= m->cap, "sample scratch");
+  float4* raw = m->buf[1 - m->cur].pos;
+  float4* sorted = raw + n_upper;
+  const int nb = (int)((n_upper + 255) / 256);
+  *n_host = 0;
+  if (nb == 0) return DMS_OK;
+  hipLaunchKernelGGL(k_graph_sample, dim3(nb), dim3(256), 0, s, m->buf[m->cur], m->d_count, sampleRate, raw, m->d_count_alt + 1);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_graph_rank, dim3(nb), dim3(256), 0, s, raw, m->d_count_alt + 1, sorted);
+  DMS_CHECK_LAUNCH();
+  DMS_HIP(hipMemcpyAsync(m->h_count, m->d_count_alt + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  const unsigned n = m->h_count[0];
+  *n_host = (int)n;
+  const unsigned take = n < (unsigned)max_rows ? n : (unsigned)max_rows;
+  if (take) DMS_HIP(hipMemcpy(rows4_host, sorted, (size_t)take * sizeof(float4), hipMemcpyDeviceToHost));
+  return DMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // G6 / G6': splat prediction (splat.vert:57-94, combo_splat.frag:35-60, depth_splat.frag:29-46)
 // ---------------------------------------------------------------------------------------
 struct SplatSurfel {

@@ -87,6 +87,7 @@ lib.dms_fusion_model.argtypes = [_P]
 lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
 lib.dms_fusion_odometry.restype = _P
+lib.dms_model_sample_graph.argtypes = [_P, _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_int), _P]
 lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
 lib.dms_fusion_process_frame_begin.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_float), _F, _P]
 lib.dms_fusion_fetch_loop.argtypes = [_P, C.POINTER(FrameResult), _P]
@@ -233,6 +234,15 @@ class GlobalModel:
         keep, tp = self._T(relativeTransform)
         check(lib.dms_model_consume(self.h, other.h, tp, None), "dms_model_consume")
         check(lib.dms_stream_sync(None))
+
+    def sampleGraph(self, sampleRate=5000):
+        """Deformation::sampleGraphModel's samples: n x 4 float32 {pos.xyz, init time}, sorted by init time."""
+        cap = int(self.lastCount()) // sampleRate + 2
+        out = np.zeros((cap, 4), np.float32)
+        n = C.c_int(0)
+        check(lib.dms_model_sample_graph(self.h, sampleRate, out.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n), None),
+              "dms_model_sample_graph")
+        return out[:n.value].copy()
 
     def exportRecords(self, max_count=None):
         """(DeviceBuffer of 20-float records, count): the device-side form of downloadMap, for p2p transfers."""

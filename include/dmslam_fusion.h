@@ -58,6 +58,15 @@ int dms_depth_metric(const dms_image2d* depth_u16, dms_image2d* metric_f32, floa
 /* G3+G4 vertex_feedback.{vert,geom} + init_unstable.vert: first-frame surfels
  * (FeedbackBuffer::compute, FeedbackBuffer.cpp:84-143; GlobalModel::initialise, GlobalModel.cpp:266-417).
  * Appends nothing: (re)initialises the map from one frame; surfels are emitted in column-major pixel order. */
+/* Device half of Deformation::sampleGraphModel (Deformation.cpp:250-348; sample.vert / sample.geom):
+ * every sampleRate-th surfel (gl_VertexID % sampleRate == 0; reference default 5000, --dgs) as
+ * {pos.xyz, init time}, ordered by init time.  The reference downloads the samples and std::sorts
+ * them on the host (equal times in unspecified order); here a stable sort runs on device (ties keep
+ * surfel order) and only the sorted rows are copied: min(*n, max_rows) rows of 4 floats, ready for
+ * Deformation::initialiseGraph.  Synchronises `s`.  Call between frames (uses the idle half of the
+ * double-buffered map as scratch). */
+int dms_model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n, dms_stream s);
+
 /* Map merge: GlobalModel::consume (GlobalModel.cpp:898-993, consume.vert).  `dst` keeps its
  * surfels and appends those of `src` moved by the row-major 4x4 `relativeTransform16` (host pointer):
  * position transformed, normal rotated, confidence / radius / colour / per-sensor times unchanged.

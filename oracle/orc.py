@@ -444,6 +444,16 @@ def model_clean(model, newU, pose, time, timeIdx, index, vertConf, colorTime, ca
     return out[:n].copy()
 
 
+def sample_graph(model, sampleRate):
+    """Deformation::sampleGraphModel up to the sort (Deformation.cpp:250-331; sample.vert / sample.geom):
+    every sampleRate-th surfel as {pos.xyz, init time}, sorted by init time.  std::sort leaves the
+    order of equal times unspecified; the stable order is taken."""
+    model = np.ascontiguousarray(model, SURFEL_DTYPE)
+    sel = model[::sampleRate]
+    rows = np.concatenate([sel["pos"][:, :3], sel["col"][:, 2:3]], axis=1).astype(np.float32)
+    return rows[np.argsort(rows[:, 3], kind="stable")]
+
+
 def model_consume(dst, src, relativeTransform):
     """GlobalModel::consume (GlobalModel.cpp:898-993) with consume.vert: dst ++ transform(src); position
     through the 4x4 (fp32, ((T0 x + T1 y) + T2 z) + T3), normal through its 3x3, everything else kept."""

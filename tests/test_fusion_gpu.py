@@ -525,6 +525,24 @@ def test_map_merge_consume(fus, orc, synth):
         small.consume(b, T)
 
 
+def test_graph_sampling_exact(fus, orc, synth):
+    """Deformation::sampleGraphModel's device half: strided samples, stable order by init time."""
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+    for k in range(4):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg = g.processFrame(rgb, d)
+    gm = g.globalModel()
+    m = gm.downloadMap()
+    for rate in (5000, 97, 2):
+        want = orc.sample_graph(m, rate)
+        got = gm.sampleGraph(rate)
+        assert len(got) == len(want) == (len(m) + rate - 1) // rate
+        assert_bits(got, want, "graph samples, rate %d" % rate)
+        assert (np.diff(got[:, 3]) >= 0).all()
+    # the map itself is untouched (the scratch is the idle half of the double buffer)
+    surfels_equal(gm.downloadMap(), m, "map after sampling")
+
+
 def test_nid_keyframing_gate(fus, orc, synth):
     """ElasticFusion::fuseFrame with NID key-framing on (SURVEY 8(f3)): per-frame score and
     fuse / skip decision against the oracle pipeline (teacher-forced map and pose), including the
