@@ -183,6 +183,9 @@ struct dms_fusion {
   float last_nid = 0.f;
   // between dms_fusion_process_frame_begin and _end
   bool in_frame = false, cur_bootstrap = false, cur_fuse_now = true;
+  // --rl bookkeeping (ElasticFusion.cpp:204-244)
+  bool tracking_ok = true, lost = false;
+  int tracking_count = 0;
   int cur_k2 = 0;
   dms_image2d depth_synth;  // IndexMap::synthesizeDepth target (deformation frames only)
   dms_indexmap_out imap;
@@ -347,7 +350,10 @@ int predict(dms_fusion* f, float confidence, hipStream_t s) {
   }
   {
     FTimer t(f, s, "fill_in");
-    if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, 0, f->p.frameToFrameRGB ? 1 : 0, &f->fill, s))) return rc;
+    // passthrough = lost (geometry), lost || frameToFrameRGB (image) (ElasticFusion.cpp:704-712)
+    if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
+                      s)))
+      return rc;
   }
   return DMS_OK;
 }
@@ -430,6 +436,7 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->nid_bins_depth = 500;
   p->nid_pyramid_level = 0;
   p->local_loop_closure = 0;
+  p->reloc = 0;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
@@ -607,6 +614,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   f->cur_k2 = k2;
   f->cur_bootstrap = !f->map_initialised;
   f->cur_fuse_now = true;
+  f->tracking_ok = true;
   if (!f->map_initialised) {
     // first run (ElasticFusion.cpp:132-152): surfels from this frame, pose = inPose or identity
     if (!inPose16)
@@ -648,6 +656,26 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
           return rc;
         // (the tracker's finalize kernel writes the new pose straight back into f->state->cur.pose)
       }
+      if (f->p.reloc) {  // ElasticFusion.cpp:204-244; lastFrameRecovery is only ever set by the compiled-out fern block
+        dms_track_result tr;
+        if ((rc = dms_odometry_fetch_result(f->odom, &tr, s))) return rc;  // synchronises
+        f->tracking_ok = (double)tr.lastICPError < 1e-04;
+        if (!f->lost) {
+          double cov[36];
+          if ((rc = dms_odometry_getCovariance(f->odom, cov))) return rc;
+          for (int i = 0; i < 6; ++i)
+            if (cov[i * 7] > 1e-04) {
+              f->tracking_ok = false;
+              break;
+            }
+          if (!f->tracking_ok) {
+            f->tracking_count += 1;
+            if (f->tracking_count > 10) f->lost = true;
+          } else {
+            f->tracking_count = 0;
+          }
+        }
+      }
     }
     if (!f->p.hybrid_tracking) {  // with tracking on, the tracker's last kernel does this
       hipLaunchKernelGGL(k_frame_after_track, dim3(1), dim3(64), 0, s, f->state, weightMultiplier);
@@ -659,7 +687,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
     bool fuse_now = true;
     if (f->p.global_predict || f->p.nid_keyframing || f->p.local_loop_closure)
       if ((rc = predict(f, f->p.confidence, s))) return rc;
-    if (f->p.local_loop_closure) {
+    if (f->p.local_loop_closure && !f->lost) {
       // closeLoops without a fern match (ElasticFusion.cpp:399-497): the camera is never lost and
       // rawGraph is empty (nothing deforms the map inside this library)
       {
@@ -725,7 +753,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       f->last_nid = 0.f;
     }
     f->cur_fuse_now = fuse_now;
-    if (f->p.local_loop_closure) {
+    if (f->p.local_loop_closure && !f->lost) {
       // the candidate is readable (dms_fusion_fetch_loop) before the second half is enqueued
       DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
       DMS_HIP(hipMemcpyAsync(f->h_loop + (size_t)k2 * f->loop_bytes, f->loop, f->loop_bytes, hipMemcpyDeviceToHost, s));
@@ -760,7 +788,7 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
     if (graph_nodes > 0) f->last_nid = 0.f;
     const int timeDeltaEff = f->p.timeDelta + f->frames_since_fusion;  // ElasticFusion.cpp:518,541,563
 
-    if (!f->p.rgbOnly && fuse_now) {  // fusion (ElasticFusion.cpp:506-564); tracking is never "lost" without --rl
+    if (!f->p.rgbOnly && f->tracking_ok && !f->lost && fuse_now) {  // fusion (ElasticFusion.cpp:506-564)
       {
         FTimer t(f, s, "index_map");
         if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, timeDeltaEff, f->zbuf,
@@ -807,7 +835,7 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
   f->last_slot = k2;
   if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
   f->fused_last = fused;
-  f->tick += 1;  // if(!lost) tick++ (ElasticFusion.cpp:588-591)
+  if (!f->lost) f->tick += 1;  // ElasticFusion.cpp:588-591
   f->frames += 1;
   return DMS_OK;
 }
@@ -820,7 +848,9 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
 }
 
 static void fill_loop(const dms_fusion* f, dms_frame_result* r) {
-  if (!f->h_loop) return;
+  r->tracking_ok = f->tracking_ok ? 1 : 0;
+  r->lost = f->lost ? 1 : 0;
+  if (!f->h_loop || f->lost) return;
   const LoopState* L = (const LoopState*)(f->h_loop + (size_t)f->last_slot * f->loop_bytes);
   r->loop_ok = L->ok;
   r->loop_constraints = L->n_constraints;

@@ -38,7 +38,7 @@ class FusionParams(C.Structure):
         ("pipeline_ingest", C.c_int), ("global_predict", C.c_int),
         ("nid_keyframing", C.c_int), ("nid_threshold", C.c_float), ("nid_depth_lambda", C.c_float), ("nid_bins_img", C.c_int),
         ("nid_bins_depth", C.c_int), ("nid_pyramid_level", C.c_int),
-        ("local_loop_closure", C.c_int),
+        ("local_loop_closure", C.c_int), ("reloc", C.c_int),
     ]
 
 
@@ -48,6 +48,7 @@ class FrameResult(C.Structure):
         ("weighting", C.c_float), ("nid_score", C.c_float), ("track", TrackResult),
         ("loop_ok", C.c_int), ("loop_constraints", C.c_int), ("loop_icp_error", C.c_float), ("loop_icp_count", C.c_float),
         ("loop_pose", C.c_float * 16), ("loop_cov_diag", C.c_double * 6),
+        ("tracking_ok", C.c_int), ("lost", C.c_int),
     ]
 
 

@@ -196,6 +196,13 @@ typedef struct dms_fusion_params {
    * tracked.  Implies global_predict.  This is the "full" frame step of the measurement contract
    * (tracking runs twice per frame).  Default 0 (--o). */
   int local_loop_closure;
+  /* --rl: tracking-failure detection of ElasticFusion.cpp:204-244.  A frame whose lastICPError is not
+   * < 1e-4 or whose pose covariance has a diagonal entry > 1e-4 is tracked but not fused; more than
+   * 10 such frames in a row mark the camera lost: no fusion, no loop closure, the tick stops, fill-in
+   * passes the raw frame through (:588, :706-712).  (Recovery needs the fern relocaliser, which this
+   * reference compiles out, :351-393: a lost camera stays lost.)  The decision is taken on the host
+   * after one mid-frame synchronisation, as in the reference.  Default 0. */
+  int reloc;
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
@@ -220,6 +227,8 @@ typedef struct dms_frame_result {
   float loop_icp_count;      /* modelToModel().lastICPCount */
   float loop_pose[16];       /* estPose: the ACTIVE view registered onto the INACTIVE one */
   double loop_cov_diag[6];   /* diagonal of modelToModel().getCovariance() */
+  int tracking_ok;           /* trackingOk of this frame (always 1 without reloc) */
+  int lost;                  /* Context::lost() after this frame */
 } dms_frame_result;
 
 /* ElasticFusion::processFrame (ElasticFusion.cpp:99-637) for one camera with loop closure off

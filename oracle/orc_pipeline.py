@@ -22,7 +22,7 @@ class ElasticFusion:
     def __init__(self, width, height, K, timeDelta=200, confidence=10.0, depthCut=3.0, icpWeight=10.0, fastOdom=False, so3=True,
                  frameToFrameRGB=False, pyramid=True, hybrid_tracking=True, rgbOnly=False, timeIdx=0, maxDepthProcessed=25.0,
                  model_capacity=None, nid_keyframing=False, nid_threshold=0.80, nid_depth_lambda=0.7, nid_bins_img=64,
-                 nid_bins_depth=500, nid_pyramid_level=0, local_loop_closure=False):
+                 nid_bins_depth=500, nid_pyramid_level=0, local_loop_closure=False, reloc=False):
         self.W, self.H, self.K = width, height, tuple(float(v) for v in K)
         self.timeDelta, self.confidence, self.depthCut, self.icpWeight = timeDelta, confidence, depthCut, icpWeight
         self.fastOdom, self.so3, self.frameToFrameRGB, self.pyramid = fastOdom, so3, frameToFrameRGB, pyramid
@@ -35,6 +35,7 @@ class ElasticFusion:
         self.nidScores = []
         fx, fy, cx, cy = self.K
         self.frameToModel = orc.Odometry(width, height, cx, cy, fx, fy)
+        self.reloc, self.lost, self.trackingCount = reloc, False, 0  # --rl (:204-244)
         self.local_loop_closure = local_loop_closure
         self.modelToModel = orc.Odometry(width, height, cx, cy, fx, fy) if local_loop_closure else None  # Context.h:317-378
         self.old = None
@@ -48,7 +49,8 @@ class ElasticFusion:
     def predict(self, confidence):
         img, vtx, nrm, tim = orc.splat_predict(self.model, self.currPose, self.K, self.H, self.W, self.maxDepthProcessed, confidence,
                                                self.tick, self.timeIdx, self.tick, self.timeDelta, True)
-        fv, fn, fi = orc.fill_in(vtx, nrm, img, self.depth_filtered, self.rgba, self.K, False, self.frameToFrameRGB)
+        # passthrough = lost / lost || frameToFrameRGB (:704-712)
+        fv, fn, fi = orc.fill_in(vtx, nrm, img, self.depth_filtered, self.rgba, self.K, self.lost, self.lost or self.frameToFrameRGB)
         self.pred = (img, vtx, nrm, tim)
         self.fill = (fi, fv, fn)
 
@@ -142,6 +144,7 @@ class ElasticFusion:
         out.track = None
         out.nid_score = 0.0
         out.loop = None
+        out.tracking_ok = True
         fused = False
         if not self.initialised:  # first run (:132-152)
             pose = np.eye(4, dtype=np.float32) if inPose is None else np.asarray(inPose, np.float32).reshape(4, 4)
@@ -154,6 +157,7 @@ class ElasticFusion:
             fused = True
         else:
             lastPose = self.currPose.copy()  # :158
+            trackingOk = True
             if inPose is not None:  # :164 (the reference dereferences NULL; the previous pose is used instead)
                 self.currPose = np.asarray(inPose, np.float32).reshape(4, 4).copy()
             self.predict(0.7)  # :165
@@ -167,6 +171,19 @@ class ElasticFusion:
                 self.frameToModel.initRGB(self.rgba)  # :185
                 t, R, res = self.frameToModel.getIncrementalTransformation(self.currPose[:3, 3], self.currPose[:3, :3], self.rgbOnly,
                                                                          self.icpWeight, self.pyramid, self.fastOdom, self.so3)
+                # tracking-failure detection (:204-244); lastFrameRecovery is only set by the compiled-out fern block
+                trackingOk = (not self.reloc) or bool(res.lastICPError < 1e-04)
+                if self.reloc and not self.lost:
+                    cov = orc.covariance(np.array(res.lastA))
+                    if any(cov[i, i] > 1e-04 for i in range(6)):
+                        trackingOk = False
+                    if not trackingOk:
+                        self.trackingCount += 1
+                        if self.trackingCount > 10:
+                            self.lost = True
+                    else:
+                        self.trackingCount = 0
+                out.tracking_ok = bool(trackingOk)
                 self.currPose[:3, 3] = t
                 self.currPose[:3, :3] = R
                 out.track = res
@@ -174,7 +191,7 @@ class ElasticFusion:
             out.weighting = weighting
             self.predict(self.confidence)  # :273
             rawGraph = None
-            if self.local_loop_closure:
+            if self.local_loop_closure and not self.lost:
                 out.loop = self.localLoop()  # :399-497
                 res = deform(out.loop) if deform is not None else None
                 if res is not None:
@@ -186,7 +203,7 @@ class ElasticFusion:
             else:
                 fuse, out.nid_score = self.fuseFrame()  # :501
             td = self.timeDelta + self.framesSinceLastFusion  # :518,:541,:563
-            if not self.rgbOnly and fuse:  # fusion (:506-564)
+            if not self.rgbOnly and trackingOk and not self.lost and fuse:  # fusion (:506-564)
                 im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
                 self.model, newU, _ = orc.model_fuse(self.model, self.currPose, self.tick, self.timeIdx, self.rgba, self.depth_metric,
                                                      self.depth_metric_filtered, im[0], im[1], im[3], self.K, self.maxDepthProcessed,
@@ -202,7 +219,9 @@ class ElasticFusion:
                 fused = True
             self.framesSinceLastFusion = 0 if fuse else self.framesSinceLastFusion + 1  # :567-568
         self.predict(self.confidence)  # finalPredict (:586)
-        self.tick += 1  # :588-591
+        if not self.lost:
+            self.tick += 1  # :588-591
+        out.lost = self.lost
         out.pose = self.currPose.copy()
         out.surfels = len(self.model)
         out.fused = fused

@@ -717,6 +717,41 @@ def test_two_phase_frame_step_with_deformation(fus, orc, synth):
     assert deformed >= 2, deformed
 
 
+def test_tracking_failure_detection(fus, orc, synth):
+    """--rl (ElasticFusion.cpp:204-244): garbage depth for 12 frames.  Those frames are tracked but not
+    fused; after more than 10 in a row the camera is lost: the tick stops, nothing fuses any more and
+    fill-in passes the raw frame through (so the tracker then matches the frame with itself)."""
+    from oracle import orc_pipeline
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000, reloc=1)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000, reloc=True)
+    rng = np.random.default_rng(5)
+    seen_lost = False
+    for k in range(17):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        if 3 <= k <= 14:
+            d = rng.integers(500, 3000, d.shape).astype(np.uint16)
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+        what = "frame %d" % k
+        assert bool(rg.tracking_ok) == ro.tracking_ok, what
+        assert bool(rg.lost) == ro.lost, what
+        assert bool(rg.fused) == ro.fused and rg.tick == ro.tick and rg.surfels == ro.surfels, what
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        if k > 0 and ro.track.lastICPCount > 10000:  # (a handful of correspondences on garbage depth is not a conditioned problem)
+            helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what=what)
+            assert rg.track.lastICPCount == pytest.approx(ro.track.lastICPCount, rel=2e-3), what
+        if ro.lost and not seen_lost:
+            seen_lost = True
+            assert k == 13
+        mg = g.globalModel().downloadMap()
+        if k <= 2:
+            surfels_equal(mg, o.model, what) if k == 0 else None
+        o.model = mg.copy()
+        o.currPose = pose_g.copy()
+    assert seen_lost and rg.tick == 14 and not rg.fused
+
+
 def test_global_predict_is_dead_work(fus, synth):
     """The reference's post-tracking "GlobalPredict" (ElasticFusion.cpp:273) feeds only blocks the
     fork compiles out and is overwritten by the final predict: running it (global_predict = 1)
