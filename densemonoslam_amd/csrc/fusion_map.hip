@@ -867,10 +867,17 @@ template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, unsigned long long* __restrict__ zbuf,
                                                        uchar4* __restrict__ image, float4* __restrict__ vertex, float4* __restrict__ normal,
                                                        unsigned short* __restrict__ timeImg, float* __restrict__ depthOut, int clear_after) {
-  const int n = a.cols * a.rows;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
-    // outputs are row-major (the tracker consumes them); the z-buffer is column-major
-    const int py = p / a.cols, px = p - py * a.cols;
+  // outputs are row-major (the tracker consumes them), the z-buffer is column-major: each wave takes an
+  // 8 x 8 pixel tile, lanes running down the columns first, so that a z-buffer access touches 8 full
+  // 64-byte lines (instead of 64 lines with a row-major thread map) and every output row of the tile
+  // is one 128-byte (float4) run
+  const int tiles_y = (a.rows + 7) >> 3, tiles_x = (a.cols + 7) >> 3, ntiles = tiles_x * tiles_y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+  for (int t = blockIdx.x * waves_per_block + wave; t < ntiles; t += gridDim.x * waves_per_block) {
+    const int tx = t / tiles_y, ty = t - tx * tiles_y;
+    const int px = tx * 8 + (lane >> 3), py = ty * 8 + (lane & 7);
+    if (px >= a.cols || py >= a.rows) continue;
+    const int p = py * a.cols + px;
     const unsigned long long key = zbuf[(size_t)px * a.rows + py];
     if (clear_after) zbuf[(size_t)px * a.rows + py] = kZClear;
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {
