@@ -73,8 +73,15 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
                                                         float4* __restrict__ slot_nrm, unsigned* __restrict__ slot_best,
                                                         unsigned char* __restrict__ slot_flag, unsigned* __restrict__ winner, int slot_w) {
   // candidate (i, j) -> pixel (2i + p, 2j + p), p = time % 2; slot = i * slot_h + j (column-major)
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // along rows (fast in slot order)
-  const int i = blockIdx.y;
+  // one 8 x 8 tile of candidates per wave, lanes running down the column first: the column-major index
+  // maps and the row-major live images are then both read in runs of 8 neighbouring candidates
+  // (8 cache lines per access) instead of one of the two in 64 separate lines
+  const int tiles_j = (a.slot_h + 7) >> 3;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int ti = t / tiles_j, tj = t - ti * tiles_j;
+  const int lane = threadIdx.x & 63;
+  const int i = ti * 8 + (lane >> 3);
+  const int j = tj * 8 + (lane & 7);
   if (i >= slot_w || j >= a.slot_h) return;
   const int slot = i * a.slot_h + j;
   const int par = ((a.time % 2) + 2) % 2;
@@ -605,7 +612,8 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   a.timeIdx = timeIdx;
   a.transposed = transposed ? 1 : 0;
   const int slot_w = (W + 1) / 2;
-  dim3 b(256), g((m->slot_h + 255) / 256, slot_w);
+  const int tiles = ((m->slot_h + 7) / 8) * ((slot_w + 7) / 8);
+  dim3 b(256), g((tiles + 3) / 4);
   hipLaunchKernelGGL(k_fuse_associate, g, b, 0, s, a, m->slot_pos, m->slot_col, m->slot_nrm, m->slot_best, m->slot_flag, m->winner, slot_w);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_fuse_update, dim3((m->slots + 255) / 256), dim3(256), 0, s, m->slots, m->slot_pos, m->slot_col, m->slot_nrm,
