@@ -94,6 +94,13 @@ lib.dms_stream_create.argtypes = [C.POINTER(C.c_void_p)]
 lib.dms_stream_destroy.argtypes = [C.c_void_p]
 
 
+def mem_info():
+    """(free, total) bytes of HBM on the current device."""
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    check(lib.dms_mem_info(C.byref(f), C.byref(t)), "dms_mem_info")
+    return f.value, t.value
+
+
 def create_stream():
     """A non-blocking HIP stream handle (int) usable as the `stream` argument everywhere."""
     h = C.c_void_p()

@@ -78,6 +78,11 @@ int dms_memset(void* dst, int value, size_t bytes, dms_stream s) {
   DMS_HIP(hipMemsetAsync(dst, value, bytes, S(s)));
   return DMS_OK;
 }
+int dms_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  DMS_REQUIRE(free_bytes && total_bytes, "null argument");
+  DMS_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return DMS_OK;
+}
 int dms_stream_sync(dms_stream s) {
   DMS_HIP(hipStreamSynchronize(S(s)));
   return DMS_OK;

@@ -104,6 +104,8 @@ int dms_device_free(void* ptr);
 int dms_memcpy_h2d(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memcpy_d2h(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memset(void* dst, int value, size_t bytes, dms_stream s);
+/* free / total HBM of the current device (hipMemGetInfo): sizing maps against the 288 GB, leak checks */
+int dms_mem_info(size_t* free_bytes, size_t* total_bytes);
 int dms_stream_sync(dms_stream s);
 /* convenience for callers without a HIP runtime of their own (e.g. ctypes): a non-blocking stream */
 int dms_stream_create(dms_stream* out);

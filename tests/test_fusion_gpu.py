@@ -484,6 +484,75 @@ def test_two_cameras_on_two_streams(fus, synth):
         capi.destroy_stream(st)
 
 
+def test_two_cameras_on_two_host_threads(fus, synth):
+    """The C ABI is re-entrant per (device, stream): two host threads, each driving its own camera
+    context on its own stream at full speed, give the results of running each camera alone."""
+    import threading
+
+    from densemonoslam_amd import capi
+
+    n_frames = 12
+    frames = [[synth.frame(k, cam_id=c, width=W, height=H, K=K, noise=True) for k in range(n_frames)] for c in (0, 1)]
+    bufs = []
+    for c in (0, 1):
+        rb = [capi.DeviceBuffer(W * H * 3).upload(np.ascontiguousarray(f[1], np.uint8)) for f in frames[c]]
+        db = [capi.DeviceBuffer(W * H * 2).upload(np.ascontiguousarray(f[0], np.uint16)) for f in frames[c]]
+        bufs.append((rb, db))
+
+    def run(c, stream, out):
+        try:
+            g = fus.ElasticFusion(W, H, K, model_capacity=600000, timeIdx=c)
+            for k in range(n_frames):
+                g.processFrameAsync(bufs[c][0][k].ptr, 3, bufs[c][1][k].ptr, None, 1.0, stream)
+                if k % 4 == 3:
+                    g.fetch(stream)
+            r = g.fetch(stream)
+            out[c] = (np.array(r.pose, np.float32), int(r.surfels), g.globalModel().downloadMap())
+            g.close()
+        except Exception as e:  # surfaces in the main thread
+            out[c] = e
+
+    ref = {}
+    for c in (0, 1):
+        run(c, None, ref)
+        assert not isinstance(ref[c], Exception), ref[c]
+    streams = [capi.create_stream(), capi.create_stream()]
+    got = {}
+    th = [threading.Thread(target=run, args=(c, streams[c], got)) for c in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a camera thread hangs"
+    for c in (0, 1):
+        assert not isinstance(got[c], Exception), got[c]
+        assert (got[c][0] == ref[c][0]).all() and got[c][1] == ref[c][1], "camera %d" % c
+        surfels_equal(got[c][2], ref[c][2], "camera %d map" % c)
+    for st in streams:
+        capi.destroy_stream(st)
+
+
+def test_contexts_release_their_memory(fus, synth):
+    """Creating and destroying camera contexts (with every optional buffer set) returns the HBM."""
+    from densemonoslam_amd import capi
+
+    d, rgb, _ = synth.frame(0, width=W, height=H, K=K, noise=True)
+
+    def cycle():
+        g = fus.ElasticFusion(W, H, K, model_capacity=400000, local_loop_closure=1, nid_keyframing=1, reloc=1)
+        g.processFrame(rgb, d)
+        g.processFrame(rgb, d)
+        g.close()
+
+    cycle()
+    free0, total = capi.mem_info()
+    for _ in range(8):
+        cycle()
+    free1, _ = capi.mem_info()
+    assert abs(free0 - free1) < (8 << 20), (free0, free1)
+    assert total > (200 << 30)  # an MI355X
+
+
 def test_map_merge_consume(fus, orc, synth):
     """GlobalModel::consume (SURVEY 8(f1)): the consuming map keeps its surfels and appends the other
     map's, moved by the relative transform — model-to-model on one device and through the packed
