@@ -898,6 +898,12 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   r->weighting = hs->weighting;
   r->nid_score = f->last_nid;
   fill_loop(f, r);
+  if ((size_t)r->surfels >= f->model->cap) {
+    // the reference asserts on this (GlobalModel.cpp:703); here the kernels stop appending at the
+    // capacity, nothing is overwritten, and the caller is told (the result above is still valid)
+    set_error("dms_fusion_fetch: the map has reached its capacity of %zu surfels; new surfels are being dropped", f->model->cap);
+    return DMS_ERR_CAPACITY;
+  }
   return DMS_OK;
 }
 

@@ -238,6 +238,8 @@ typedef struct dms_frame_result {
  * ElasticFusion.cpp:164).  Asynchronous on `s`; dms_fusion_fetch syncs and returns the result. */
 int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev,
                              const float* inPose16, float weightMultiplier, dms_stream s);
+/* Returns DMS_ERR_CAPACITY (with the result filled in) once the map has reached model_capacity: the
+ * kernels stop appending there instead of asserting like the reference (GlobalModel.cpp:703). */
 int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream s);
 
 /* The same frame step in two halves, for callers that close local loops: `_begin` enqueues

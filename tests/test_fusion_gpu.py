@@ -532,6 +532,22 @@ def test_two_cameras_on_two_host_threads(fus, synth):
         capi.destroy_stream(st)
 
 
+def test_map_capacity_is_reported(fus, synth):
+    """A map that fills its capacity stops growing (nothing is overwritten) and fetch says so."""
+    from densemonoslam_amd import capi
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=80000)
+    d, rgb, _ = synth.frame(0, width=W, height=H, K=K, noise=True)
+    r = g.processFrame(rgb, d)
+    assert r.surfels < 80000
+    d, rgb, _ = synth.frame(1, width=W, height=H, K=K, noise=True)
+    with pytest.raises(capi.DmsError) as e:
+        g.processFrame(rgb, d)
+    assert "capacity" in str(e.value)
+    assert g.globalModel().lastCount() == 80000
+    g.close()
+
+
 def test_contexts_release_their_memory(fus, synth):
     """Creating and destroying camera contexts (with every optional buffer set) returns the HBM."""
     from densemonoslam_amd import capi
