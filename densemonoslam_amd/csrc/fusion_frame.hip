@@ -24,7 +24,8 @@ namespace dms {
 int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
 int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
-            int pass_rgb, dms_predict_out* out, hipStream_t s);
+            int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src = nullptr, void* mirror_dst = nullptr,
+            int mirror_bytes = 0);
 int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s);
 // fusion_map.hip
 int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
@@ -194,6 +195,7 @@ struct dms_fusion {
   void* untr = nullptr;  // W*H*16 scratch for row-major copies handed out by dms_fusion_get_image
   unsigned long long* zbuf = nullptr;
   FrameState* state = nullptr;
+  FrameState* h_state_dev = nullptr;  // device view of h_state
   FrameState* h_state = nullptr;  // pinned, two slots by frame parity (the host may read a slot once that frame's event has completed)
   int last_slot = 0;
   void* h_track = nullptr;
@@ -340,7 +342,7 @@ void drain(dms_fusion* f) {
 }
 
 // ElasticFusion::predict (ElasticFusion.cpp:688-746): ACTIVE splat + fill-in
-int predict(dms_fusion* f, float confidence, hipStream_t s) {
+int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr) {
   int rc;
   {
     FTimer t(f, s, "predict");
@@ -351,8 +353,9 @@ int predict(dms_fusion* f, float confidence, hipStream_t s) {
   {
     FTimer t(f, s, "fill_in");
     // passthrough = lost (geometry), lost || frameToFrameRGB (image) (ElasticFusion.cpp:704-712)
+    // (the frame's last fill-in also copies the result block into its pinned host slot)
     if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
-                      s)))
+                      s, state_mirror ? f->state : nullptr, state_mirror, (int)sizeof(FrameState))))
       return rc;
   }
   return DMS_OK;
@@ -482,7 +485,8 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 2 * sizeof(FrameState), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 2 * sizeof(FrameState), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&f->h_state_dev, f->h_state, 0);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->nid_host, 2 * sizeof(float), hipHostMallocDefault);
   if (e == hipSuccess && f->loop_bytes) {
     e = hipHostMalloc((void**)&f->h_loop, 2 * f->loop_bytes, hipHostMallocDefault);
@@ -826,12 +830,12 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
     }
     f->frames_since_fusion = fuse_now ? 0 : f->frames_since_fusion + 1;  // ElasticFusion.cpp:567-568
   }
-  if ((rc = predict(f, f->p.confidence, s))) return rc;  // finalPredict (ElasticFusion.cpp:586)
   if (!surfels_written) {
     hipLaunchKernelGGL(k_frame_end, dim3(1), dim3(64), 0, s, f->state, f->model->d_count);
     DMS_CHECK_LAUNCH();
   }
-  DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+  // finalPredict (ElasticFusion.cpp:586); its fill-in kernel mirrors the result block to the host slot
+  if ((rc = predict(f, f->p.confidence, s, f->h_state_dev + k2))) return rc;
   f->last_slot = k2;
   if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
   f->fused_last = fused;

@@ -82,6 +82,11 @@ struct FillArgs {
   const uchar4* ex_image;
   const unsigned short* depth;  // filtered, mm
   const uchar4* rgba;
+  // optional: block (0,0) also copies `mirror_words` dwords (the frame's result block into its pinned
+  // host mirror — the frame step's last kernel does the copy a separate blit launch would do)
+  const unsigned* mirror_src;
+  unsigned* mirror_dst;
+  int mirror_words;
   float4* out_vertex;
   float4* out_normal;
   uchar4* out_image;
@@ -99,6 +104,10 @@ __device__ __forceinline__ f3 fill_vertex_at(const FillArgs& a, int sx, int sy, 
 __global__ __launch_bounds__(BX* BY) void k_fill_in(FillArgs a) {
   const int px = blockIdx.x * blockDim.x + threadIdx.x;
   const int py = blockIdx.y * blockDim.y + threadIdx.y;
+  if (a.mirror_words > 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < a.mirror_words) a.mirror_dst[t] = a.mirror_src[t];
+  }
   if (px >= a.cols || py >= a.rows) return;
   const size_t i = (size_t)py * a.cols + px;
   const float colsf = (float)a.cols, rowsf = (float)a.rows;
@@ -170,7 +179,7 @@ int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream
 }
 
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
-            int pass_rgb, dms_predict_out* out, hipStream_t s) {
+            int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src, void* mirror_dst, int mirror_bytes) {
   DMS_REQUIRE(ex && depth && rgba && cam && out, "null argument");
   DMS_REQUIRE(dense(&ex->vertex, 16) && dense(&ex->normal, 16) && dense(&ex->image, 4) && dense(depth, 2) && dense(rgba, 4) &&
                   dense(&out->vertex, 16) && dense(&out->normal, 16) && dense(&out->image, 4),
@@ -192,6 +201,10 @@ int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image
   a.ify = 1.0f / cam->fy;
   a.pass_geom = pass_geom ? 1 : 0;
   a.pass_rgb = pass_rgb ? 1 : 0;
+  DMS_REQUIRE(mirror_bytes % 4 == 0 && mirror_bytes / 4 <= BX * BY, "mirror block too large");
+  a.mirror_src = (const unsigned*)mirror_src;
+  a.mirror_dst = (unsigned*)mirror_dst;
+  a.mirror_words = (mirror_src && mirror_dst) ? mirror_bytes / 4 : 0;
   dim3 b(BX, BY), g = grid2d(a.cols, a.rows, b);
   hipLaunchKernelGGL(k_fill_in, g, b, 0, s, a);
   DMS_CHECK_LAUNCH();
