@@ -138,7 +138,7 @@ def main():
     depth = int(os.environ.get("DMS_RUNAHEAD", "0"))
     inflight = []
 
-    def step(i):
+    def step(i, exchange_thumbnails=True):
         nonlocal src
         j = frame_index(i)
         if depth > 0:
@@ -149,7 +149,7 @@ def main():
             e = torch.cuda.Event()
             e.record()
             inflight.append(e)
-        if distributed:
+        if distributed and exchange_thumbnails:
             if src is None:
                 src = (src_view(13), src_view(14), src_view(15))  # fill-in image / vertex / normal
             capi.check(capi.lib.dms_resize_nn(C.byref(src[0]), C.byref(tv[0]), 4, stream))
@@ -239,7 +239,7 @@ def main():
         capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 1))
         nprof = min(args.steps, 20)
         for i in range(n_total, n_total + nprof):
-            step(i)
+            step(i, exchange_thumbnails=False)  # rank 0 only: no collective in this pass
             ef.fetch(stream)
         names_f = ["ingest", "preprocess", "live_pyramids", "predict", "fill_in", "odom_init", "track", "predict_old", "loop_init", "loop_track",
                    "index_map", "fuse", "clean", "initialise"]
@@ -331,7 +331,7 @@ def main():
             }
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on the host cores -----------
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline:  # reported at N = 1 only
         from oracle import orc_pipeline  # checker / baseline only
 
         from oracle import orc as _orc
