@@ -78,7 +78,17 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # test-only knobs: DMS_BENCH_SHARE_GPU=1 lets several ranks share the GPUs of a smaller box (rank -> device
+    # modulo the device count) and DMS_BENCH_BACKEND=gloo replaces RCCL there (two ranks on one device cannot form an
+    # RCCL communicator); used to rehearse the multi-rank control flow on a 1-GPU box
+    if os.environ.get("DMS_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
+    if distributed:
+        backend = os.environ.get("DMS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
