@@ -129,12 +129,12 @@ def main():
     thumb = exchange.local
     import ctypes as C
 
-    def thumb_views():
-        base = thumb.data_ptr()
+    def thumb_views(buf):
+        base = buf.data_ptr()
         n = th * tw
         return (capi.Image2D(base, tw * 4, th, tw), capi.Image2D(base + n * 4, tw * 16, th, tw), capi.Image2D(base + n * 20, tw * 16, th, tw))
 
-    tv = thumb_views()
+    tvs = {b.data_ptr(): thumb_views(b) for b in exchange.locals}
 
     def src_view(which):
         v = capi.Image2D()
@@ -162,12 +162,15 @@ def main():
         if distributed and exchange_thumbnails:
             if src is None:
                 src = (src_view(13), src_view(14), src_view(15))  # fill-in image / vertex / normal
+            tv = tvs[exchange.begin().data_ptr()]
             capi.check(capi.lib.dms_resize_nn(C.byref(src[0]), C.byref(tv[0]), 4, stream))
             capi.check(capi.lib.dms_resize_nn(C.byref(src[1]), C.byref(tv[1]), 16, stream))
             capi.check(capi.lib.dms_resize_nn(C.byref(src[2]), C.byref(tv[2]), 16, stream))
-            exchange.gather()
+            # the all-gather runs beside the next frame (its consumer, the inter-map matcher, works one frame behind)
+            exchange.gather(overlap=True)
 
     def barrier():
+        exchange.finish()  # collectives still in flight belong to the timed region
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()

@@ -29,24 +29,57 @@ def shard_cameras(n_cameras, rank, world):
 
 
 class ThumbnailExchange:
-    """Fixed-size per-frame all-gather of one camera's thumbnail block per rank."""
+    """Fixed-size per-frame all-gather of one camera's thumbnail block per rank.
+
+    Synchronous use: fill `local`, call `gather()`.  Overlapped use (bench.py): `begin()` hands out
+    this frame's block (two alternate, so the collective of frame t may still be in flight while frame
+    t+1 fills the other one), `gather(overlap=True)` starts the all-gather without making the calling
+    stream wait for it — the matcher that consumes it runs a frame later — and `finish()` waits for
+    whatever is still in flight."""
 
     def __init__(self, world, width, height, device):
         self.world = world
         self.nbytes = thumbnail_bytes(width, height)
-        self.local = torch.zeros((self.nbytes,), dtype=torch.uint8, device=device)
-        self.gathered = torch.zeros((world, self.nbytes), dtype=torch.uint8, device=device)
+        self.locals = [torch.zeros((self.nbytes,), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gathereds = [torch.zeros((world, self.nbytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.slot = 0
+        self.local = self.locals[0]
+        self.gathered = self.gathereds[0]
 
-    def gather(self):
+    def begin(self):
+        w = self.work[self.slot]
+        if w is not None:  # the collective that used this block two frames ago
+            w.wait()
+            self.work[self.slot] = None
+        self.local = self.locals[self.slot]
+        return self.local
+
+    def gather(self, overlap=False):
+        g, l = self.gathereds[self.slot], self.locals[self.slot]
+        self.gathered = g
         if self.world == 1:
-            self.gathered[0].copy_(self.local)
-            return self.gathered
+            g[0].copy_(l)
+            return g
+        if overlap:
+            try:
+                self.work[self.slot] = dist.all_gather_into_tensor(g.view(-1), l, async_op=True)
+            except (RuntimeError, NotImplementedError):
+                self.work[self.slot] = dist.all_gather([g[r] for r in range(self.world)], l, async_op=True)
+            self.slot ^= 1
+            return g
         try:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local)
+            dist.all_gather_into_tensor(g.view(-1), l)
         except (RuntimeError, NotImplementedError):  # backends without the flat form
-            parts = [self.gathered[r] for r in range(self.world)]
-            dist.all_gather(parts, self.local)
-        return self.gathered
+            parts = [g[r] for r in range(self.world)]
+            dist.all_gather(parts, l)
+        return g
+
+    def finish(self):
+        for k in range(2):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
 
 
 def max_over_ranks(value, device):

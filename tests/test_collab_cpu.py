@@ -74,6 +74,48 @@ def test_two_rank_thumbnail_allgather_gloo():
         assert tmax == 1.5 and tsum == 21.0
 
 
+def _overlap_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from densemonoslam_amd import collab
+
+    ex = collab.ThumbnailExchange(world, 160, 120, torch.device("cpu"))
+    got = []
+    handles = []
+    for frame in range(5):  # the block of frame t is refilled at frame t+2, after its collective was waited for
+        buf = ex.begin()
+        buf.fill_(10 * frame + rank)
+        handles.append(ex.gather(overlap=True))
+        if frame >= 1:  # the matcher works one frame behind: wait for the previous frame's gather only
+            ex.work[ex.slot].wait() if ex.work[ex.slot] is not None else None
+            got.append(handles[frame - 1][:, 0].clone().numpy())
+    ex.finish()
+    got.append(handles[4][:, 0].clone().numpy())
+    out.put((rank, np.stack(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_thumbnail_exchange_gloo():
+    """bench.py's use of the exchange: double-buffered blocks, all-gather started without waiting and
+    consumed a frame later."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.array([[10 * f + r for r in range(world)] for f in range(5)], np.uint8)
+    for rank, got in results:
+        assert (got == expect).all(), (rank, got)
+
+
 def _merge_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
