@@ -129,27 +129,12 @@ def main():
     thumb = exchange.local
     import ctypes as C
 
-    def thumb_views(buf):
-        base = buf.data_ptr()
-        n = th * tw
-        return (capi.Image2D(base, tw * 4, th, tw), capi.Image2D(base + n * 4, tw * 16, th, tw), capi.Image2D(base + n * 20, tw * 16, th, tw))
-
-    tvs = {b.data_ptr(): thumb_views(b) for b in exchange.locals}
-
-    def src_view(which):
-        v = capi.Image2D()
-        capi.check(capi.lib.dms_fusion_get_image(ef.h, which, C.byref(v)))
-        return v
-
-    src = None
-
     # bounded run-ahead: the host never has more than `depth` frames enqueued beyond the one the GPU
     # is working on (what a live pipeline does anyway: frame t+depth does not exist yet)
     depth = int(os.environ.get("DMS_RUNAHEAD", "0"))
     inflight = []
 
     def step(i, exchange_thumbnails=True):
-        nonlocal src
         j = frame_index(i)
         if depth > 0:
             if len(inflight) >= depth:
@@ -160,12 +145,7 @@ def main():
             e.record()
             inflight.append(e)
         if distributed and exchange_thumbnails:
-            if src is None:
-                src = (src_view(13), src_view(14), src_view(15))  # fill-in image / vertex / normal
-            tv = tvs[exchange.begin().data_ptr()]
-            capi.check(capi.lib.dms_resize_nn(C.byref(src[0]), C.byref(tv[0]), 4, stream))
-            capi.check(capi.lib.dms_resize_nn(C.byref(src[1]), C.byref(tv[1]), 16, stream))
-            capi.check(capi.lib.dms_resize_nn(C.byref(src[2]), C.byref(tv[2]), 16, stream))
+            ef.thumbnails(exchange.begin().data_ptr(), stream)  # fill-in image / vertex / normal at W/8 x H/8, one launch
             # the all-gather runs beside the next frame (its consumer, the inter-map matcher, works one frame behind)
             exchange.gather(overlap=True)
 

@@ -139,6 +139,24 @@ __global__ __launch_bounds__(256) void k_dense_enough(const uchar4* __restrict__
   }
 }
 
+// The W/8 x H/8 thumbnails a camera publishes per frame in collaborative mode (the fern matcher's
+// inputs: Resize of the fill-in image / vertex / normal textures, Ferns.cpp:277-423) in
+// one launch: block = [RGBA8 image | RGBA32F vertex | RGBA32F normal], each tw x th, NEAREST as resize.frag
+__global__ __launch_bounds__(256) void k_thumbnails(const uchar4* __restrict__ image, const float4* __restrict__ vertex,
+                                                    const float4* __restrict__ normal, int cols, int rows, int tw, int th,
+                                                    unsigned char* __restrict__ block) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= tw * th) return;
+  const int j = k / tw, i = k - j * tw;
+  const float u = ((float)i + 0.5f) / (float)tw, v = ((float)j + 0.5f) / (float)th;
+  const int sx = texel(u, (float)cols, cols), sy = texel(v, (float)rows, rows);
+  const size_t q = (size_t)sy * cols + sx;
+  const size_t n = (size_t)tw * th;
+  reinterpret_cast<uchar4*>(block)[k] = image[q];
+  reinterpret_cast<float4*>(block + n * 4)[k] = vertex[q];
+  reinterpret_cast<float4*>(block + n * 20)[k] = normal[q];
+}
+
 __global__ void k_frame_end(FrameState* st, const unsigned* __restrict__ d_count) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->surfels = d_count[0];
@@ -908,6 +926,17 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
     set_error("dms_fusion_fetch: the map has reached its capacity of %zu surfels; new surfels are being dropped", f->model->cap);
     return DMS_ERR_CAPACITY;
   }
+  return DMS_OK;
+}
+
+int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream st) {
+  DMS_REQUIRE(f && block_dev, "null argument");
+  DMS_REQUIRE(((uintptr_t)block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  const int tw = f->p.width / 8, th = f->p.height / 8;
+  hipLaunchKernelGGL(k_thumbnails, dim3((tw * th + 255) / 256), dim3(256), 0, (hipStream_t)st, (const uchar4*)f->fill.image.data,
+                     (const float4*)f->fill.vertex.data, (const float4*)f->fill.normal.data, f->p.width, f->p.height, tw, th,
+                     (unsigned char*)block_dev);
+  DMS_CHECK_LAUNCH();
   return DMS_OK;
 }
 

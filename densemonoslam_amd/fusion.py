@@ -89,6 +89,7 @@ lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
 lib.dms_fusion_odometry.restype = _P
 lib.dms_model_sample_graph.argtypes = [_P, _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_int), _P]
+lib.dms_fusion_thumbnails.argtypes = [_P, _P, _P]
 lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
 lib.dms_fusion_process_frame_begin.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_float), _F, _P]
 lib.dms_fusion_fetch_loop.argtypes = [_P, C.POINTER(FrameResult), _P]
@@ -413,6 +414,10 @@ class ElasticFusion:
         check(lib.dms_fusion_get_image(self.h, which, C.byref(v)), "dms_fusion_get_image")
         dt, k = _IMG_TYPES[which]
         return capi.download_view(v, dt, k)
+
+    def thumbnails(self, block_ptr, stream=None):
+        """Pack this frame's W/8 x H/8 fill-in thumbnails [image | vertex | normal] into device memory at block_ptr."""
+        check(lib.dms_fusion_thumbnails(self.h, C.c_void_p(block_ptr), stream), "dms_fusion_thumbnails")
 
     def loopConstraints(self):
         """Surface constraints of the last fetched frame's loop candidate: n x 7 float32

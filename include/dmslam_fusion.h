@@ -265,6 +265,12 @@ dms_odometry* dms_fusion_odometry(dms_fusion* f);
  * also the INACTIVE view: 16 old image 17 old vertex 18 old normal 19 old time */
 int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view);
 
+/* Collaborative mode: the per-frame block a camera publishes to the other ranks — the
+ * W/8 x H/8 NEAREST thumbnails of its fill-in image (RGBA8), vertex and normal maps (RGBA32F), the
+ * inputs of the inter-map fern matcher (Ferns.cpp:277-423) — packed [image | vertex | normal] into
+ * (W/8)(H/8) * 36 bytes of device memory, in one launch on `s` (stream-ordered after the frame). */
+int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream s);
+
 /* Surface constraints of the last fetched frame's loop candidate, in the reference's sampling
  * order (columns outer, rows inner, ElasticFusion.cpp:446-447): per row
  * {worldRawPoint xyz, worldModelPoint xyz, source time} = the arguments of

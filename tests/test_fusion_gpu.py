@@ -532,6 +532,26 @@ def test_two_cameras_on_two_host_threads(fus, synth):
         capi.destroy_stream(st)
 
 
+def test_thumbnail_block_matches_resize(fus, orc, synth):
+    """dms_fusion_thumbnails: the collaborative mode's per-frame block = W/8 x H/8 NEAREST resize of the
+    fill-in image, vertex and normal maps, packed [image | vertex | normal]."""
+    from densemonoslam_amd import capi
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+    for k in range(2):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        g.processFrame(rgb, d)
+    tw, th = W // 8, H // 8
+    buf = capi.DeviceBuffer(tw * th * 36)
+    g.thumbnails(buf.ptr)
+    block = buf.download(np.uint8, (tw * th * 36,))
+    img, vtx, nrm = g.image(13), g.image(14), g.image(15)
+    want = np.concatenate([orc.resize_nn(img, th, tw).reshape(-1).view(np.uint8), orc.resize_nn(vtx, th, tw).reshape(-1).view(np.uint8),
+                           orc.resize_nn(nrm, th, tw).reshape(-1).view(np.uint8)])
+    assert_bits(block, want, "thumbnail block")
+    g.close()
+
+
 def test_map_capacity_is_reported(fus, synth):
     """A map that fills its capacity stops growing (nothing is overwritten) and fetch says so."""
     from densemonoslam_amd import capi
