@@ -932,6 +932,12 @@ struct LevelArgs {
   float* rec;            // [2][gridDim.x][kRecFloats]
   unsigned long long* sync;  // 2 barriers (kBarrierStride words each) per iteration, zero on entry
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
+  // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
+  // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
+  int finalize, fin_rgb;
+  float* pose16_out;
+  FrameState* frame;
+  float weightMultiplier;
 };
 
 // Grid barrier whose arrival word carries a payload (low 54 bits, summed) next to the arrival count
@@ -1311,6 +1317,31 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     st->iters_run[L.level] = s.iters_run;
     for (int i = 0; i < 36; ++i) st->lastA[i] = s.lastA[i];
     for (int i = 0; i < 6; ++i) st->lastb[i] = s.lastb[i];
+    if (L.finalize) {  // == k_track_finalize, from the values this thread holds
+      float tc[3], Rc[9];
+      for (int i = 0; i < 3; ++i) tc[i] = s.tcurr[i];
+      for (int i = 0; i < 9; ++i) Rc[i] = s.Rcurr[i];
+      const float dx = tc[0] - s.tprev[0], dy = tc[1] - s.tprev[1], dz = tc[2] - s.tprev[2];
+      const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (L.fin_rgb && (double)n > 0.3) {  // RGBDOdometry.cpp:589-593
+        for (int i = 0; i < 9; ++i) Rc[i] = st->Rcurr[i] = s.Rprev[i];
+        for (int i = 0; i < 3; ++i) tc[i] = st->tcurr[i] = s.tprev[i];
+        st->rejected_jump = 1;
+      }
+      for (int i = 0; i < 3; ++i) st->out_trans[i] = tc[i];
+      for (int i = 0; i < 9; ++i) st->out_rot[i] = Rc[i];
+      if (L.pose16_out) {
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) L.pose16_out[i * 4 + j] = Rc[i * 3 + j];
+          L.pose16_out[i * 4 + 3] = tc[i];
+        }
+        L.pose16_out[12] = 0.f;
+        L.pose16_out[13] = 0.f;
+        L.pose16_out[14] = 0.f;
+        L.pose16_out[15] = 1.f;
+      }
+      if (L.frame) frame_after_track_body(L.frame, L.weightMultiplier);
+    }
   }
   phase(8);
   if (L.prof && blockIdx.x == 0 && tid == 0) {
@@ -1874,6 +1905,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     }
   }
 
+  bool finalized_in_kernel = false;
   for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
     int pP = 1, pnb = 0;
     if (persistent_enabled() && iterations[l] <= 10) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), pP, pnb);
@@ -1945,6 +1977,12 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.rec = o->rec;
       L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
       L.prof = o->profiling ? o->prof : nullptr;
+      L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
+      L.fin_rgb = rgb ? 1 : 0;
+      L.pose16_out = frame ? const_cast<float*>(prior_pose16_dev) : nullptr;
+      L.frame = frame;
+      L.weightMultiplier = weightMultiplier;
+      if (l == 0) finalized_in_kernel = true;
       persist.begin();
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
       Timer t(o, s, kLevelTimer[l]);
@@ -1999,7 +2037,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     }
   }
 
-  {
+  if (!finalized_in_kernel) {
     Timer t(o, s, "track_finalize");
     // frame step (frame state given): the result is written back into the pose block the prior came from;
     // a device prior without frame state (model-to-model tracking) is read-only
