@@ -946,3 +946,41 @@ def test_process_frame_kitti_resolution_1241x376(fus, orc, synth):
         pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
         helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="1241x376 frame %d" % k)
     assert rg.track.iterations_run[0] == 10 and rg.track.iterations_run[1] == 5 and rg.track.iterations_run[2] == 4
+
+
+@pytest.mark.parametrize("size", [(333, 251), (164, 126), (646, 486)])
+def test_process_frame_ragged_resolutions(fus, orc, synth, size):
+    """Resolutions that are not multiples of the 8 x 8 wave tiles, the 64 x 4 pixel blocks, the 2 x 2
+    candidate grid or the /2 pyramid steps: with the pose prior taken as is the map, the filtered depth
+    and the predictions must equal the oracle's byte for byte; one tracked frame stays within the bar."""
+    from oracle import orc_pipeline
+
+    Wr, Hr = size
+    Kr = (0.825 * Wr, 0.825 * Wr, Wr / 2.0 - 0.25, Hr / 2.0 + 0.25)
+    opts = dict(model_capacity=600000)
+    g = fus.ElasticFusion(Wr, Hr, Kr, hybrid_tracking=0, **opts)
+    o = orc_pipeline.ElasticFusion(Wr, Hr, Kr, hybrid_tracking=False, **opts)
+    T0 = None
+    for k in range(3):
+        d, rgb, T = synth.frame(k, width=Wr, height=Hr, K=Kr, noise=True)
+        if T0 is None:
+            T0 = T
+        prior = (np.linalg.inv(T0) @ T).astype(np.float32)
+        rg = g.processFrame(rgb, d, inPose=prior)
+        ro = o.processFrame(rgb, d, inPose=prior)
+        assert_bits(g.image(2), o.depth_filtered, "depth filtered %d" % k)
+        assert bool(rg.fill_in) == ro.fill_in
+        surfels_equal(g.globalModel().downloadMap(), o.model, "%dx%d map after frame %d" % (Wr, Hr, k))
+        assert_bits(g.image(10), o.pred[1], "predicted vertex")
+        assert_bits(g.image(9), o.pred[0], "predicted image")
+        assert_bits(g.image(14), o.fill[1], "fill-in vertex")
+    g2 = fus.ElasticFusion(Wr, Hr, Kr, **opts)
+    o2 = orc_pipeline.ElasticFusion(Wr, Hr, Kr, **opts)
+    for k in range(2):
+        d, rgb, T = synth.frame(k, width=Wr, height=Hr, K=Kr, noise=True)
+        rg = g2.processFrame(rgb, d)
+        ro = o2.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="%dx%d frame %d" % (Wr, Hr, k))
+    g.close()
+    g2.close()
