@@ -984,3 +984,30 @@ def test_process_frame_ragged_resolutions(fus, orc, synth, size):
         helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="%dx%d frame %d" % (Wr, Hr, k))
     g.close()
     g2.close()
+
+
+def test_frame_step_reproduces_fusion_golden(fus):
+    """The committed golden vectors of the fusion half (tests/golden/oracle_fusion.npz, made by
+    make_fusion_golden.py) reproduced by the HIP path alone — no oracle in this test."""
+    import importlib.util
+    import os
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_fusion_golden", os.path.join(golden, "make_fusion_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    want = np.load(os.path.join(golden, "oracle_fusion.npz"))
+    g = fus.ElasticFusion(mk.W, mk.H, mk.K, hybrid_tracking=0, model_capacity=200000)
+    got = {}
+    for k, d, rgb, prior in mk.frames():
+        r = g.processFrame(rgb, d, inPose=prior)
+        m = g.globalModel().downloadMap()
+        mk.record(got, k, m, g.image(5) if k > 0 else None, g.image(10), g.image(9), g.image(14), r.fused, r.fill_in)
+    got["final_index"] = g.image(5).astype(np.uint32)
+    got["final_map_head"] = np.ascontiguousarray(m[: mk.KEEP]).view(np.uint8).reshape(mk.KEEP, -1).copy()
+    got["graph_samples_97"] = g.globalModel().sampleGraph(97)
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        a, b = np.asarray(got[k]), want[k]
+        assert a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes(), k
+    g.close()

@@ -38,6 +38,20 @@ def test_oracle_reproduces_golden_vectors():
             assert np.allclose(a, b, rtol=1e-6, atol=1e-9), k
 
 
+def test_oracle_reproduces_fusion_golden(orc):
+    """Fusion half of the frame step with the pose prior taken as is: every stored value comes from
+    per-element arithmetic only, so the oracle must reproduce it bit for bit on any host."""
+    spec = importlib.util.spec_from_file_location("make_fusion_golden", os.path.join(GOLDEN, "make_fusion_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = np.load(os.path.join(GOLDEN, "oracle_fusion.npz"))
+    got = mod.compute()
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        a, b = np.asarray(got[k]), want[k]
+        assert a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes(), k
+
+
 def test_gputest_motion_is_small_and_consistent(orc):
     want = np.load(os.path.join(GOLDEN, "oracle_gputest.npz"))
     for name in ("C2_icp_fast", "C3_full", "gputest"):
