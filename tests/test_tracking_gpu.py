@@ -379,6 +379,33 @@ def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode
 
 
 @pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
+@pytest.mark.parametrize("name", ["C2_icp_fast", "C3_full", "gputest", "rgb_only"])
+def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, track_mode):
+    """The committed golden vectors of the tracker on the reference's GPUTest pair
+    (tests/golden/oracle_gputest.npz) against the HIP path alone — no oracle in this test:
+    pose within the north-star bar, same iteration counts, correspondence counts to 1e-3."""
+    import os
+
+    want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_gputest.npz"))
+    K = gputest_pair["K"]
+    verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
+    rgba1, rgba2 = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
+    g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+    g.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+    g.initRGBModel(rgba1)
+    g.initICP(gputest_pair["depth2"], 20.0)
+    g.initRGB(rgba2)
+    g.initFirstRGB(rgba1)
+    tg, Rg, rg = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **CONFIGS[name])
+    helpers.assert_pose_close(tg, Rg, want[name + "_t"], want[name + "_R"], what=name)  # <= 1 mm, <= 0.01 deg
+    c = want[name + "_counts"]  # ICP count, RGB count, SO3 count, SO3 iterations, iterations per level
+    assert [rg.so3_iterations_run] + list(rg.iterations_run) == [int(v) for v in c[3:7]]
+    for got, ref in ((rg.lastICPCount, c[0]), (rg.lastRGBCount, c[1]), (rg.lastSO3Count, c[2])):
+        assert abs(got - ref) <= max(5.0, 1e-3 * ref), (name, got, ref)
+    _sum_close(np.array(rg.lastA), want[name + "_lastA"], rtol=2e-3, what="lastA")
+
+
+@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
 @pytest.mark.parametrize("case", ["no_live_depth", "black_live_image"])
 def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
     """Degenerate frames: no live depth at all (zero ICP correspondences: the 6x6 system is singular
