@@ -58,6 +58,10 @@ int dms_depth_metric(const dms_image2d* depth_u16, dms_image2d* metric_f32, floa
 /* G3+G4 vertex_feedback.{vert,geom} + init_unstable.vert: first-frame surfels
  * (FeedbackBuffer::compute, FeedbackBuffer.cpp:84-143; GlobalModel::initialise, GlobalModel.cpp:266-417).
  * Appends nothing: (re)initialises the map from one frame; surfels are emitted in column-major pixel order. */
+int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* depth_metric,
+                         const dms_image2d* depth_metric_filtered, const dms_camera* cam, int time, int timeIdx,
+                         float maxDepth, dms_stream s);
+
 /* Device half of Deformation::sampleGraphModel (Deformation.cpp:250-348; sample.vert / sample.geom):
  * every sampleRate-th surfel (gl_VertexID % sampleRate == 0; reference default 5000, --dgs) as
  * {pos.xyz, init time}, ordered by init time.  The reference downloads the samples and std::sorts
@@ -78,10 +82,6 @@ int dms_model_consume(dms_model* dst, const dms_model* src, const float* relativ
 int dms_model_export_records(dms_model* m, float* records_dev, unsigned int max_count, unsigned int* count, dms_stream s);
 int dms_model_consume_records(dms_model* dst, const float* records_dev, unsigned int count, const float* relativeTransform16,
                               dms_stream s);
-
-int dms_model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* depth_metric,
-                         const dms_image2d* depth_metric_filtered, const dms_camera* cam, int time, int timeIdx,
-                         float maxDepth, dms_stream s);
 
 /* index-map render target set (reference IndexMap index framebuffer, IndexMap.cpp:26-39) */
 typedef struct dms_indexmap_out {
