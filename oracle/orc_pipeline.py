@@ -6,6 +6,8 @@ Follows elasticfusion/Core/src/ElasticFusion.cpp:99-637 with loop closure off by
 prediction, model-to-model tracking, acceptance test, constraint sampling — and stops where the
 reference hands the constraints to the CPU/CHOLMOD deformation solver), NID keyframing off by default (--nkf: fuseFrame returns
 true, :639-645; nid_keyframing=True restates the gate of :646-675), tracking-failure detection off by default (--rl off: trackingOk is always true; reloc=True restates :204-244), cluster 0.
+PARITY UNPINNED like the functions it chains (the reference has no vectors for this path and cannot be built
+here); its own regression pin is tests/golden/oracle_fusion.npz.
 The deformation graph is empty (it is only filled by loop closures), so clean() runs without
 nodes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
