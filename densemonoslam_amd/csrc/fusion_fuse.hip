@@ -238,6 +238,7 @@ struct CleanArgs {
   const float* node_table;
   int nslots;
   int transposed;
+  int suffix;  // large maps: surfels in the leading run of untouched blocks stay where they are (see model_clean)
 };
 
 // plain aggregates (HIP's float4 is a class with a union inside: as a member of the element it keeps
@@ -512,12 +513,39 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
   }
 }
 
+// Suffix mode (maps of a million surfels and more): in steady state removals and appends happen among
+// the most recent surfels, i.e. at the end of the buffer; a block of kScanChunk map surfels that is
+// complete and preceded only by complete blocks keeps its place and its contents (the graph-free clean
+// changes nothing in a surviving map surfel), so it is neither read nor written again.  Such blocks
+// form a prefix; the scatter stages everything behind it in the other buffer and k_clean_copy_back
+// returns it, so the map stays in one buffer and the traffic is 80 B per surfel for the flags plus
+// 320 B per surfel of the suffix instead of 240 B per surfel of the whole map.
+__device__ __forceinline__ bool clean_block_untouched(const unsigned* __restrict__ block_offset, const unsigned* __restrict__ block_count,
+                                                      unsigned b, unsigned M) {
+  const unsigned base = b * kScanChunk;
+  return base + kScanChunk <= M && block_offset[b] == base && block_count[b] == (unsigned)kScanChunk;
+}
+
+__global__ __launch_bounds__(256) void k_clean_copy_back(SurfelPlanes staged, SurfelPlanes map, size_t cap, const unsigned* __restrict__ count_new,
+                                                         const unsigned* __restrict__ d_count_old, const unsigned* __restrict__ block_offset,
+                                                         const unsigned* __restrict__ block_count) {
+  const unsigned n = count_new[0], M = d_count_old[0];
+  const unsigned i = blockIdx.x * kScanChunk + threadIdx.x;
+  if (i >= n) return;
+  if (clean_block_untouched(block_offset, block_count, blockIdx.x, M)) return;
+  map.pos[i] = staged.pos[i];
+  map.col[i] = staged.col[i];
+  map.nrm[i] = staged.nrm[i];
+#pragma unroll
+  for (int s = 0; s < DMS_MAX_SENSORS; ++s) map.times[(size_t)s * cap + i] = staged.times[(size_t)s * cap + i];
+}
+
 __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
                                                        const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
                                                        unsigned char* slot_flag, const unsigned char* __restrict__ keep,
                                                        const unsigned* __restrict__ block_offset, SurfelPlanes out,
                                                        const unsigned* __restrict__ block_count, unsigned* __restrict__ count_new,
-                                                       unsigned* __restrict__ count_new2) {
+                                                       unsigned* __restrict__ count_new2, const unsigned* __restrict__ block_count_all) {
   const unsigned M = d_count[0];
   const unsigned total = M + (unsigned)a.nslots;
   const unsigned base = blockIdx.x * kScanChunk;
@@ -544,6 +572,9 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
     running = block_offset[blockIdx.x];
   }
   if (base >= total) return;
+  // suffix mode: a block of map surfels none of which (nor any before it) is removed maps onto itself,
+  // unchanged: nothing to move
+  if (a.suffix && clean_block_untouched(block_offset, block_count_all, blockIdx.x, M)) return;
   for (int k = 0; k < kScanChunk / 256; ++k) {
     const unsigned e = base + k * 256 + threadIdx.x;
     const bool f = (e < total) && keep[e];
@@ -662,11 +693,16 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   a.transposed = transposed ? 1 : 0;
   const size_t upper = m->count_upper + (size_t)m->slots;
   const int nb = (int)((upper + kScanChunk - 1) / kScanChunk);
+  // suffix mode pays one more launch: worth it once the map is large (DMS_CLEAN_SUFFIX_MIN overrides the size)
+  const char* smin = getenv("DMS_CLEAN_SUFFIX_MIN");  // read per call: tests switch it inside one process
+  const size_t suffix_min = smin ? (size_t)atoll(smin) : ((size_t)1 << 20);
+  const bool suffix = graph_nodes == 0 && upper >= suffix_min;
+  a.suffix = suffix ? 1 : 0;
   const SurfelPlanes src = m->buf[m->cur], dst = m->buf[m->cur ^ 1];
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_count);
   DMS_CHECK_LAUNCH();
-  const bool inline_scan = nb <= 2048;
+  const bool inline_scan = nb <= 2048 && !suffix;  // suffix mode needs the block offsets in memory
   if (!inline_scan) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt, (unsigned)m->cap,
                        count_out2);
@@ -674,11 +710,16 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   }
   hipLaunchKernelGGL(k_clean_scatter, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_offset, dst, inline_scan ? m->block_count : (const unsigned*)nullptr, m->d_count_alt,
-                     count_out2);
+                     count_out2, m->block_count);
   DMS_CHECK_LAUNCH();
+  if (suffix) {
+    hipLaunchKernelGGL(k_clean_copy_back, dim3(nb), dim3(256), 0, s, dst, src, m->cap, m->d_count_alt, m->d_count, m->block_offset,
+                       m->block_count);
+    DMS_CHECK_LAUNCH();
+  }
   // the scatter still reads the old count cell; later launches get the new one
   std::swap(m->d_count, m->d_count_alt);
-  m->cur ^= 1;
+  if (!suffix) m->cur ^= 1;
   m->count_upper = upper < m->cap ? upper : m->cap;
   return DMS_OK;
 }

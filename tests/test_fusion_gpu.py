@@ -1011,3 +1011,35 @@ def test_frame_step_reproduces_fusion_golden(fus):
         a, b = np.asarray(got[k]), want[k]
         assert a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes(), k
     g.close()
+
+
+def test_clean_suffix_mode_equals_full_compaction(fus, synth, monkeypatch):
+    """Large-map clean (DMS_CLEAN_SUFFIX_MIN): leading blocks of untouched map surfels are left in place,
+    only the suffix is compacted and copied back.  Forced on a small map here: the whole frame step
+    must give the map, the count and the images of the default (full compaction) path, frame after frame,
+    also when a frame removes surfels near the front of the buffer."""
+    def run(suffix_min):
+        if suffix_min is None:
+            monkeypatch.delenv("DMS_CLEAN_SUFFIX_MIN", raising=False)
+        else:
+            monkeypatch.setenv("DMS_CLEAN_SUFFIX_MIN", str(suffix_min))
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, confidence=3.0)
+        out = []
+        for k in range(7):
+            d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+            if k == 4:  # a hole in the depth image ages some old surfels out (removals far from the end)
+                d = d.copy()
+                d[40:120, 60:200] = 0
+            r = g.processFrame(rgb, d)
+            out.append((int(r.surfels), g.globalModel().downloadMap(), g.image(5).copy(), g.image(10).copy()))
+        g.close()
+        return out
+
+    ref = run(None)
+    got = run(0)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a[0] == b[0], "count after frame %d" % k
+        surfels_equal(b[1], a[1], "map after frame %d" % k)
+        assert_bits(b[2], a[2], "index map %d" % k)
+        assert_bits(b[3], a[3], "prediction %d" % k)
+    assert ref[-1][0] > 100000
