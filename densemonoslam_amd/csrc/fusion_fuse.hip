@@ -380,7 +380,24 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanArgs a, SurfelPlanes s
       unsigned char f = 0;
       if (e < total) {
         CleanElem v;
-        if (clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v)) f = (unsigned char)clean_test(a, v);
+        if (a.suffix && e < M) {
+          // large maps are bandwidth-bound here: colour and normal (32 of the 80 bytes) are only used by the
+          // window test of surfels that are in view and inside the time window — fetch them for those only
+          v.pos = ld4(sp.pos + e);
+#pragma unroll
+          for (int s = 0; s < DMS_MAX_SENSORS; ++s) v.times[s] = sp.times[(size_t)s * cap + e];
+          v.vt = sp.times[(size_t)a.timeIdx * cap + e];
+          const f3 lp = xform_point(a.pose->t_inv, mk3(v.pos.x, v.pos.y, v.pos.z));
+          const float x = ((a.fx * lp.x) / lp.z) + a.cx, y = ((a.fy * lp.y) / lp.z) + a.cy;
+          const bool windowed = (float)a.time - v.vt < (float)a.timeDelta && lp.z > 0.f && x > 0.f && y > 0.f && x < (float)a.cols &&
+                                y < (float)a.rows;  // the condition of clean_test, evaluated the same way
+          const F4 zero = {0.f, 0.f, 0.f, 0.f};
+          v.col = windowed ? ld4(sp.col + e) : zero;
+          v.nrm = windowed ? ld4(sp.nrm + e) : zero;
+          f = (unsigned char)clean_test(a, v);
+        } else if (clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v)) {
+          f = (unsigned char)clean_test(a, v);
+        }
         keep[e] = f;
       }
       cnt += f;
