@@ -369,10 +369,11 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
 __global__ __launch_bounds__(256) void k_clean_flags(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
                                                      const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
                                                      const unsigned char* slot_flag, unsigned char* __restrict__ keep,
-                                                     unsigned* __restrict__ block_count) {
+                                                     unsigned* __restrict__ block_count, unsigned* __restrict__ first_touched) {
   const unsigned M = d_count[0];
   const unsigned total = M + (unsigned)a.nslots;
   const unsigned base = blockIdx.x * kScanChunk;
+  if (first_touched && blockIdx.x == 0 && threadIdx.x == 0) *first_touched = 0xFFFFFFFFu;  // the scan takes the minimum
   unsigned cnt = 0;
   if (base < total) {
     for (int k = 0; k < kScanChunk / 256; ++k) {
@@ -537,24 +538,19 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
 // form a prefix; the scatter stages everything behind it in the other buffer and k_clean_copy_back
 // returns it, so the map stays in one buffer and the traffic is 80 B per surfel for the flags plus
 // 320 B per surfel of the suffix instead of 240 B per surfel of the whole map.
-__device__ __forceinline__ bool clean_block_untouched(const unsigned* __restrict__ block_offset, const unsigned* __restrict__ block_count,
-                                                      unsigned b, unsigned M) {
-  const unsigned base = b * kScanChunk;
-  return base + kScanChunk <= M && block_offset[b] == base && block_count[b] == (unsigned)kScanChunk;
-}
-
 __global__ __launch_bounds__(256) void k_clean_copy_back(SurfelPlanes staged, SurfelPlanes map, size_t cap, const unsigned* __restrict__ count_new,
-                                                         const unsigned* __restrict__ d_count_old, const unsigned* __restrict__ block_offset,
-                                                         const unsigned* __restrict__ block_count) {
-  const unsigned n = count_new[0], M = d_count_old[0];
-  const unsigned i = blockIdx.x * kScanChunk + threadIdx.x;
-  if (i >= n) return;
-  if (clean_block_untouched(block_offset, block_count, blockIdx.x, M)) return;
-  map.pos[i] = staged.pos[i];
-  map.col[i] = staged.col[i];
-  map.nrm[i] = staged.nrm[i];
+                                                         const unsigned* __restrict__ first_touched) {
+  // a fixed grid walks the blocks behind the prefix that stayed in place: the work follows the suffix, not the map
+  const unsigned n = count_new[0];
+  for (unsigned b = first_touched[0] + blockIdx.x; (size_t)b * kScanChunk < n; b += gridDim.x) {
+    const unsigned i = b * kScanChunk + threadIdx.x;
+    if (i >= n) continue;
+    map.pos[i] = staged.pos[i];
+    map.col[i] = staged.col[i];
+    map.nrm[i] = staged.nrm[i];
 #pragma unroll
-  for (int s = 0; s < DMS_MAX_SENSORS; ++s) map.times[(size_t)s * cap + i] = staged.times[(size_t)s * cap + i];
+    for (int s = 0; s < DMS_MAX_SENSORS; ++s) map.times[(size_t)s * cap + i] = staged.times[(size_t)s * cap + i];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
@@ -562,7 +558,7 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
                                                        unsigned char* slot_flag, const unsigned char* __restrict__ keep,
                                                        const unsigned* __restrict__ block_offset, SurfelPlanes out,
                                                        const unsigned* __restrict__ block_count, unsigned* __restrict__ count_new,
-                                                       unsigned* __restrict__ count_new2, const unsigned* __restrict__ block_count_all) {
+                                                       unsigned* __restrict__ count_new2) {
   const unsigned M = d_count[0];
   const unsigned total = M + (unsigned)a.nslots;
   const unsigned base = blockIdx.x * kScanChunk;
@@ -589,9 +585,6 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
     running = block_offset[blockIdx.x];
   }
   if (base >= total) return;
-  // suffix mode: a block of map surfels none of which (nor any before it) is removed maps onto itself,
-  // unchanged: nothing to move
-  if (a.suffix && clean_block_untouched(block_offset, block_count_all, blockIdx.x, M)) return;
   for (int k = 0; k < kScanChunk / 256; ++k) {
     const unsigned e = base + k * 256 + threadIdx.x;
     const bool f = (e < total) && keep[e];
@@ -618,6 +611,41 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
     // re-append it): only this thread ever reads the flag in this kernel
     if (e >= M && e < total) slot_flag[e - M] = 0;
     running += tot;
+  }
+}
+
+// Suffix-mode scatter (large maps, no deformation graph): the blocks before first_touched[0] hold map surfels
+// none of which (nor any before them) is removed — they map onto themselves, unchanged, and are not visited;
+// a fixed grid walks the rest and stages the survivors in `out` (k_clean_copy_back returns them).
+__global__ __launch_bounds__(256) void k_clean_scatter_suffix(CleanArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
+                                                              const float4* slot_pos, const float4* slot_col, const float4* slot_nrm,
+                                                              unsigned char* slot_flag, const unsigned char* __restrict__ keep,
+                                                              const unsigned* __restrict__ block_offset, SurfelPlanes out,
+                                                              const unsigned* __restrict__ first_touched) {
+  const unsigned M = d_count[0];
+  const unsigned total = M + (unsigned)a.nslots;
+  for (unsigned b = first_touched[0] + blockIdx.x; (size_t)b * kScanChunk < total; b += gridDim.x) {
+    const unsigned e = b * kScanChunk + threadIdx.x;
+    const bool f = (e < total) && keep[e];
+    unsigned tot;
+    const unsigned rank = block_exclusive_rank(f, tot);
+    if (f) {
+      const size_t dst = (size_t)block_offset[b] + rank;
+      if (dst < cap) {
+        CleanElem v;
+        clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v);
+        if (v.vt == -2.f) {  // copy_unstable.vert:124-129
+          v.col.w = (float)a.time;
+          v.vt = (float)a.time;
+        }
+        out.pos[dst] = to4(v.pos);
+        out.col[dst] = to4(v.col);
+        out.nrm[dst] = to4(v.nrm);
+#pragma unroll
+        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? v.vt : v.times[s];
+      }
+    }
+    if (e >= M && e < total) slot_flag[e - M] = 0;  // the parked measurement is consumed
   }
 }
 
@@ -717,21 +745,26 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   a.suffix = suffix ? 1 : 0;
   const SurfelPlanes src = m->buf[m->cur], dst = m->buf[m->cur ^ 1];
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
-                     m->slot_flag, m->keep, m->block_count);
+                     m->slot_flag, m->keep, m->block_count, suffix ? m->clean_first : (unsigned*)nullptr);
   DMS_CHECK_LAUNCH();
   const bool inline_scan = nb <= 2048 && !suffix;  // suffix mode needs the block offsets in memory
   if (!inline_scan) {
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt, (unsigned)m->cap,
-                       count_out2);
+    // (limit = the old count: only complete blocks of map surfels can stay in place)
+    hipLaunchKernelGGL(k_scan_blocks_par, dim3((nb + 1023) / 1024), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt,
+                       (unsigned)m->cap, count_out2, suffix ? m->clean_first : (unsigned*)nullptr, m->d_count, (unsigned)kScanChunk);
     DMS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_clean_scatter, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
-                     m->slot_flag, m->keep, m->block_offset, dst, inline_scan ? m->block_count : (const unsigned*)nullptr, m->d_count_alt,
-                     count_out2, m->block_count);
+  const int suffix_grid = nb < 2048 ? nb : 2048;  // suffix mode: blocks loop from the first touched block on
+  if (suffix)
+    hipLaunchKernelGGL(k_clean_scatter_suffix, dim3(suffix_grid), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col,
+                       m->slot_nrm, m->slot_flag, m->keep, m->block_offset, dst, m->clean_first);
+  else
+    hipLaunchKernelGGL(k_clean_scatter, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
+                       m->slot_flag, m->keep, m->block_offset, dst, inline_scan ? m->block_count : (const unsigned*)nullptr, m->d_count_alt,
+                       count_out2);
   DMS_CHECK_LAUNCH();
   if (suffix) {
-    hipLaunchKernelGGL(k_clean_copy_back, dim3(nb), dim3(256), 0, s, dst, src, m->cap, m->d_count_alt, m->d_count, m->block_offset,
-                       m->block_count);
+    hipLaunchKernelGGL(k_clean_copy_back, dim3(suffix_grid), dim3(256), 0, s, dst, src, m->cap, m->d_count_alt, m->clean_first);
     DMS_CHECK_LAUNCH();
   }
   // the scatter still reads the old count cell; later launches get the new one

@@ -52,6 +52,7 @@ static void model_layout(dms_model* m, ModelCarver& c) {
   m->keep = c.take<unsigned char>(total);
   m->block_count = c.take<unsigned>(total / kScanChunk + 2);
   m->block_offset = c.take<unsigned>(total / kScanChunk + 2);
+  m->clean_first = c.take<unsigned>(4);
   m->nodes = c.take<float>((size_t)m->max_nodes * 16);
 }
 

@@ -77,4 +77,57 @@ static __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned* __r
   }
 }
 
+// The same scan for long count arrays (maps of a million surfels and more), one 1024-thread block per 1024
+// counts: each block first sums every count before its chunk itself (no inter-block wait; the counts
+// are a few hundred kilobytes in L2), then scans its own chunk.  The last block stores the total.
+// `first_touched` (optional): atomicMin of the first block index b that does not satisfy
+// counts[b] == full && (b + 1) * full <= limit[0] — the end of the prefix that the suffix-mode clean
+// leaves in place; the word is set to 0xFFFFFFFF by an earlier kernel on the stream.
+static __global__ __launch_bounds__(1024) void k_scan_blocks_par(const unsigned* __restrict__ counts, unsigned* __restrict__ offsets, int nb,
+                                                          unsigned* __restrict__ out_count, unsigned cap,
+                                                          unsigned* __restrict__ out_count2, unsigned* __restrict__ first_touched,
+                                                          const unsigned* __restrict__ limit, unsigned full) {
+  __shared__ unsigned s_w[16];
+  __shared__ unsigned s_prefix;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int chunk0 = blockIdx.x * 1024;
+  unsigned below = 0;
+  for (int i = threadIdx.x; i < chunk0; i += 1024) below += counts[i];
+  for (int off = 32; off > 0; off >>= 1) below += __shfl_down(below, off, 64);
+  if (lane == 0) s_w[wid] = below;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < 16; ++w) t += s_w[w];
+    s_prefix = t;
+  }
+  __syncthreads();
+  const unsigned prefix = s_prefix;
+  __syncthreads();
+  const int i = chunk0 + threadIdx.x;
+  const unsigned v = i < nb ? counts[i] : 0u;
+  unsigned incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_w[wid] = incl;
+  __syncthreads();
+  unsigned wbase = 0;
+  for (int w = 0; w < wid; ++w) wbase += s_w[w];
+  if (i < nb) {
+    offsets[i] = prefix + wbase + incl - v;
+    if (first_touched) {
+      const bool in_place = v == full && ((unsigned)i + 1u) * full <= limit[0];
+      if (!in_place) atomicMin(first_touched, (unsigned)i);
+    }
+  }
+  if (i == nb - 1) {
+    const unsigned tot = prefix + wbase + incl;
+    const unsigned c = tot < cap ? tot : cap;
+    out_count[0] = c;
+    if (out_count2) out_count2[0] = c;
+  }
+}
+
 }  // namespace dms

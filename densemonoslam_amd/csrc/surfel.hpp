@@ -152,6 +152,7 @@ struct dms_model {
   unsigned char* keep = nullptr;    // [cap + slots]
   unsigned* block_count = nullptr;  // [(cap + slots) / kScanChunk + 2]
   unsigned* block_offset = nullptr;
+  unsigned* clean_first = nullptr;  // suffix-mode clean: index of the first block that is not left in place
   float* nodes = nullptr;           // deformation node table, 16 floats / node
   int max_nodes = 2048;
 };
