@@ -1043,3 +1043,42 @@ def test_clean_suffix_mode_equals_full_compaction(fus, synth, monkeypatch):
         assert_bits(b[2], a[2], "index map %d" % k)
         assert_bits(b[3], a[3], "prediction %d" % k)
     assert ref[-1][0] > 100000
+
+
+FRAME_CONFIGS = {
+    # BASELINE config 2: ICP only (icpWeight 100 => rgb off), --fo, single pyramid level, no SO3
+    "C2_icp_fast_single_level": dict(icpWeight=100.0, fastOdom=1, pyramid=0, so3=0),
+    "no_so3": dict(so3=0),
+    "frame_to_frame_rgb": dict(frameToFrameRGB=1),
+    "rgb_only_camera": dict(rgbOnly=1),  # Context::rgbOnly(): tracked photometrically, never fused
+    "fast_odometry": dict(fastOdom=1),
+}
+
+
+@pytest.mark.parametrize("name", list(FRAME_CONFIGS))
+def test_process_frame_option_matrix(fus, orc, synth, name):
+    """The frame step under the tracker / fusion options of dms_fusion_params, teacher-forced per step
+    against the oracle pipeline: pose within the bar, identical decisions, identical map size."""
+    from oracle import orc_pipeline
+
+    cfg = FRAME_CONFIGS[name]
+    ocfg = {k: (bool(v) if k in ("fastOdom", "pyramid", "so3", "frameToFrameRGB", "rgbOnly") else v) for k, v in cfg.items()}
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000, **cfg)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000, **ocfg)
+    for k in range(4):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="%s frame %d" % (name, k))
+        assert bool(rg.fused) == ro.fused and bool(rg.fill_in) == ro.fill_in and rg.tick == ro.tick, (name, k)
+        if k > 0:
+            assert list(rg.track.iterations_run) == list(ro.track.iterations_run), (name, k)
+            assert rg.track.so3_iterations_run == ro.track.so3_iterations_run, (name, k)
+        mg = g.globalModel().downloadMap()
+        assert abs(len(mg) - ro.surfels) <= max(10, 2e-3 * ro.surfels), (name, k, len(mg), ro.surfels)
+        o.model = mg.copy()
+        o.currPose = pose_g.copy()
+    if cfg.get("rgbOnly"):
+        assert not rg.fused and rg.track.lastICPCount == 0
+    g.close()
