@@ -1082,3 +1082,33 @@ def test_process_frame_option_matrix(fus, orc, synth, name):
     if cfg.get("rgbOnly"):
         assert not rg.fused and rg.track.lastICPCount == 0
     g.close()
+
+
+def test_nid_gate_with_inactive_view(fus, orc, synth):
+    """NID key-framing together with local loop closure: the key frame's "old" half is the rendered
+    INACTIVE view (KeyFrame.h:139-166) instead of an empty one.  Depth blanking ages part of the map out
+    of a 2-frame window; the scores must follow the oracle's once that view is populated."""
+    from oracle import orc_pipeline
+
+    opts = dict(model_capacity=600000, timeDelta=2, confidence=1.0)
+    g = fus.ElasticFusion(W, H, K, nid_keyframing=1, nid_threshold=0.0, local_loop_closure=1, **opts)
+    o = orc_pipeline.ElasticFusion(W, H, K, nid_keyframing=True, nid_threshold=0.0, local_loop_closure=True, **opts)
+    populated = 0
+    for k in range(7):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        if 2 <= k <= 4:
+            d = d.copy()
+            d[:, : int(W * 0.35)] = 0
+        rg, ro = g.processFrame(rgb, d), o.processFrame(rgb, d)
+        if k > 0:
+            old_px = int((o.old[1][..., 2] > 0).sum())
+            populated += old_px > 1000
+            # (both sides track to poses ~1e-5 apart before scoring: splat edges move by whole pixels, the histograms with them)
+            assert abs(rg.nid_score - ro.nid_score) < 3e-3, (k, rg.nid_score, ro.nid_score, old_px)
+            assert bool(rg.fused) == ro.fused
+        mg = g.globalModel().downloadMap()
+        assert abs(len(mg) - ro.surfels) <= max(10, 2e-3 * ro.surfels)
+        o.model = mg
+        o.currPose = np.array(rg.pose, np.float32).reshape(4, 4)
+    assert populated >= 2, populated
+    g.close()
