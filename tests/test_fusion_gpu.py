@@ -1112,3 +1112,52 @@ def test_nid_gate_with_inactive_view(fus, orc, synth):
         o.currPose = np.array(rg.pose, np.float32).reshape(4, 4)
     assert populated >= 2, populated
     g.close()
+
+
+@pytest.mark.parametrize("container", ["klg_zlib", "lcm_raw"])
+def test_dataset_logs_feed_the_frame_step(fus, synth, tmp_path, container):
+    """SURVEY 8(f2) end to end: a .klg log (RawLogReader, zlib depth) and an LCM log of uncompressed
+    eflcm.Frame messages (RawLcmLogReader) written from the synthetic stream, read back through the library's
+    readers and fed to the frame step, give the map and pose of feeding the frames directly."""
+    from densemonoslam_amd import ingest
+    from oracle import orc_frame
+
+    n = 4
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(n)]
+
+    def run(seq):
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+        for d, rgb in seq:
+            r = g.processFrame(rgb, d)
+        out = (np.array(r.pose, np.float32), g.globalModel().downloadMap())
+        g.close()
+        return out
+
+    ref = run([(d, rgb) for d, rgb, _ in frames])
+    if container == "klg_zlib":
+        path = str(tmp_path / "seq.klg")
+        orc_frame.klg_write(path, [(1000 + k, d, rgb) for k, (d, rgb, _) in enumerate(frames)], compress_depth=True)
+        rd = ingest.KlgReader(path, W, H)
+        assert rd.numFrames == n
+        seq = [(d, rgb) for _, d, rgb in rd]
+        rd.close()
+    else:
+        path = str(tmp_path / "seq.lcm")
+        events = []
+        for k, (d, rgb, _) in enumerate(frames):
+            msg = orc_frame.frame_encode(False, False, k == n - 1, np.ascontiguousarray(d).tobytes(), np.ascontiguousarray(rgb).tobytes(),
+                                         1000 + k, k, "cam0")
+            events.append((1000 + k, "EFUSION_FRAMES", msg))
+        orc_frame.lcmlog_write(path, events)
+        rd = ingest.LcmLogReader(path)
+        seq = []
+        for ch, data, ts in rd:
+            f = ingest.Frame.decode(data)
+            seq.append(f.unpack(W, H))
+            if f.last:
+                break
+        rd.close()
+    assert len(seq) == n
+    got = run(seq)
+    assert_bits(got[0], ref[0], "pose")
+    surfels_equal(got[1], ref[1], "map from the %s log" % container)
