@@ -346,10 +346,10 @@ __device__ __forceinline__ void store_transformed(View<float> vmap, View<float> 
 }
 
 // level 0: transformed maps, float depth (verticesToDepth) and intensity, one thread per pixel
-__global__ void k_model_level0(ModelSrc m, int rows, int cols, View<float> vmap, View<float> nmap, View<float> depth,
-                               View<unsigned char> inten, float cutOff) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+__device__ __forceinline__ void model_level0_body(int bx, int by, const ModelSrc& m, int rows, int cols, View<float> vmap, View<float> nmap,
+                                                  View<float> depth, View<unsigned char> inten, float cutOff) {
+  const int x = bx * blockDim.x + threadIdx.x;
+  const int y = by * blockDim.y + threadIdx.y;
   if (x >= cols || y >= rows) return;
   const bool useB = *m.flag != 0;
   const size_t i = (size_t)y * cols + x;
@@ -378,10 +378,10 @@ __device__ __forceinline__ f3 resize4(const f3& a, const f3& b, const f3& c, con
 }
 
 // levels 1 and 2: one thread per level-2 pixel = 2x2 level-1 pixels = 4x4 level-0 pixels
-__global__ void k_model_levels12(ModelSrc m, int cols0, int rows1, int cols1, int rows2, int cols2, View<float> v1, View<float> n1,
-                                 View<float> v2, View<float> n2) {
-  const int x2 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y2 = blockIdx.y * blockDim.y + threadIdx.y;
+__device__ __forceinline__ void model_levels12_body(int bx, int by, const ModelSrc& m, int cols0, int rows1, int cols1, int rows2, int cols2,
+                                                    View<float> v1, View<float> n1, View<float> v2, View<float> n2) {
+  const int x2 = bx * blockDim.x + threadIdx.x;
+  const int y2 = by * blockDim.y + threadIdx.y;
   if (2 * x2 >= cols1 || 2 * y2 >= rows1) return;
   const bool useB = *m.flag != 0;
   const float4* vs = useB ? m.vB : m.vA;
@@ -408,6 +408,22 @@ __global__ void k_model_levels12(ModelSrc m, int cols0, int rows1, int cols1, in
     const f3 a = resize4<false>(lv[0], lv[1], lv[2], lv[3]);
     const f3 b = resize4<true>(ln[0], ln[1], ln[2], ln[3]);
     store_transformed(v2, n2, rows2, y2, x2, a, b, P, m.pose16 != nullptr);
+  }
+}
+
+// Level 0 and levels 1 + 2 read the same sources and do not depend on each other: one launch, the first
+// g0x * g0y blocks are level 0's 2-D grid, the rest levels 1 + 2's (a launch boundary and the short second
+// kernel's ramp are saved; the small grid runs in the shadow of the large one).
+__global__ void k_model_levels012(ModelSrc m, int g0x, int g0y, int g12x, int rows0, int cols0, View<float> v0, View<float> n0,
+                                  View<float> depth0, View<unsigned char> inten0, float cutOff, int rows1, int cols1, int rows2, int cols2,
+                                  View<float> v1, View<float> n1, View<float> v2, View<float> n2) {
+  const int b = blockIdx.x;
+  const int nb0 = g0x * g0y;
+  if (b < nb0) {
+    model_level0_body(b % g0x, b / g0x, m, rows0, cols0, v0, n0, depth0, inten0, cutOff);
+  } else {
+    const int c = b - nb0;
+    model_levels12_body(c % g12x, c / g12x, m, cols0, rows1, cols1, rows2, cols2, v1, n1, v2, n2);
   }
 }
 
@@ -650,10 +666,14 @@ int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void
   const int rows0 = vmaps[0].rows / 3, cols0 = vmaps[0].cols;
   const int rows1 = vmaps[1].rows / 3, cols1 = vmaps[1].cols, rows2 = vmaps[2].rows / 3, cols2 = vmaps[2].cols;
   DMS_REQUIRE(rows1 == rows0 / 2 && cols1 == cols0 / 2 && rows2 == rows1 / 2 && cols2 == cols1 / 2, "pyramid shapes");
-  LAUNCH2D(k_model_level0, cols0, rows0, s, m, rows0, cols0, view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]),
-           view<unsigned char>(&images[0]), cutOff);
-  LAUNCH2D(k_model_levels12, (cols1 + 1) / 2, (rows1 + 1) / 2, s, m, cols0, rows1, cols1, rows2, cols2, view<float>(&vmaps[1]),
-           view<float>(&nmaps[1]), view<float>(&vmaps[2]), view<float>(&nmaps[2]));
+  {
+    const dim3 b = blk();
+    const dim3 g0 = grid2d(cols0, rows0, b), g12 = grid2d((cols1 + 1) / 2, (rows1 + 1) / 2, b);
+    hipLaunchKernelGGL(k_model_levels012, dim3(g0.x * g0.y + g12.x * g12.y), b, 0, s, m, (int)g0.x, (int)g0.y, (int)g12.x, rows0, cols0,
+                       view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]), view<unsigned char>(&images[0]), cutOff, rows1,
+                       cols1, rows2, cols2, view<float>(&vmaps[1]), view<float>(&nmaps[1]), view<float>(&vmaps[2]), view<float>(&nmaps[2]));
+    DMS_CHECK_LAUNCH();
+  }
   for (int l = 1; l < 3; ++l)
     LAUNCH2D(k_model_pyr_step, depths[l].cols, depths[l].rows, s, view<const float>(&depths[l - 1]), view<float>(&depths[l]),
              view<const unsigned char>(&images[l - 1]), view<unsigned char>(&images[l]));
