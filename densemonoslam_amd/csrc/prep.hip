@@ -411,19 +411,61 @@ __device__ __forceinline__ void model_levels12_body(int bx, int by, const ModelS
   }
 }
 
+// first pyramid step of the model depth / intensity images, taken straight from the sources: every tap re-derives the
+// level-0 depth (verticesToDepth rule) and intensity (imageBGRToIntensity rule) that model_level0_body stores,
+// so the step does not have to wait for level 0
+__device__ __forceinline__ void model_pyr_step1_body(int bx, int by, const ModelSrc& m, int rows0, int cols0, float cutOff, View<float> ddst,
+                                                     View<unsigned char> idst) {
+  const int x = bx * blockDim.x + threadIdx.x;
+  const int y = by * blockDim.y + threadIdx.y;
+  if (x >= ddst.cols || y >= ddst.rows) return;
+  const bool useB = *m.flag != 0;
+  const float4* vs = useB ? m.vB : m.vA;
+  const uchar4* is = (useB || m.force_b_img) ? m.iB : m.iA;
+  const int D = 5;
+  const int tx = min(2 * x - D / 2 + D, cols0 - 1);
+  const int ty = min(2 * y - D / 2 + D, rows0 - 1);
+  float sum = 0.f, isum = 0.f;
+  int count = 0, icount = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+      const float g = gauss25(ty - cy - 1, tx - cx - 1);
+      const size_t i = (size_t)cy * cols0 + cx;
+      const float z = vs[i].z;
+      const float s = (z > cutOff || z <= 0.f) ? qnan() : z;
+      if (!isnan(s)) {
+        sum += s * g;
+        count += (int)g;
+      }
+      const uchar4 cc = is[i];
+      const unsigned char c = (unsigned char)f2i_rz(((float)cc.x * 0.114f + (float)cc.y * 0.299f) + (float)cc.z * 0.587f);
+      if (c > 0) {
+        isum += (float)c * g;
+        icount += (int)g;
+      }
+    }
+  ddst.at(y, x) = sum / (float)count;
+  idst.at(y, x) = (unsigned char)f2i_rz(isum / (float)icount);
+}
+
 // Level 0 and levels 1 + 2 read the same sources and do not depend on each other: one launch, the first
 // g0x * g0y blocks are level 0's 2-D grid, the rest levels 1 + 2's (a launch boundary and the short second
-// kernel's ramp are saved; the small grid runs in the shadow of the large one).
+// kernel's ramp are saved; the small grid runs in the shadow of the large one).  A third group of blocks takes
+// the first step of the depth / intensity pyramid directly from the sources.
 __global__ void k_model_levels012(ModelSrc m, int g0x, int g0y, int g12x, int rows0, int cols0, View<float> v0, View<float> n0,
                                   View<float> depth0, View<unsigned char> inten0, float cutOff, int rows1, int cols1, int rows2, int cols2,
-                                  View<float> v1, View<float> n1, View<float> v2, View<float> n2) {
+                                  View<float> v1, View<float> n1, View<float> v2, View<float> n2, int g12y, int gsx, View<float> depth1,
+                                  View<unsigned char> inten1) {
   const int b = blockIdx.x;
-  const int nb0 = g0x * g0y;
+  const int nb0 = g0x * g0y, nb12 = g12x * g12y;
   if (b < nb0) {
     model_level0_body(b % g0x, b / g0x, m, rows0, cols0, v0, n0, depth0, inten0, cutOff);
-  } else {
+  } else if (b < nb0 + nb12) {
     const int c = b - nb0;
     model_levels12_body(c % g12x, c / g12x, m, cols0, rows1, cols1, rows2, cols2, v1, n1, v2, n2);
+  } else {
+    const int c = b - nb0 - nb12;
+    model_pyr_step1_body(c % gsx, c / gsx, m, rows0, cols0, cutOff, depth1, inten1);
   }
 }
 
@@ -668,13 +710,15 @@ int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void
   DMS_REQUIRE(rows1 == rows0 / 2 && cols1 == cols0 / 2 && rows2 == rows1 / 2 && cols2 == cols1 / 2, "pyramid shapes");
   {
     const dim3 b = blk();
-    const dim3 g0 = grid2d(cols0, rows0, b), g12 = grid2d((cols1 + 1) / 2, (rows1 + 1) / 2, b);
-    hipLaunchKernelGGL(k_model_levels012, dim3(g0.x * g0.y + g12.x * g12.y), b, 0, s, m, (int)g0.x, (int)g0.y, (int)g12.x, rows0, cols0,
-                       view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]), view<unsigned char>(&images[0]), cutOff, rows1,
-                       cols1, rows2, cols2, view<float>(&vmaps[1]), view<float>(&nmaps[1]), view<float>(&vmaps[2]), view<float>(&nmaps[2]));
+    const dim3 g0 = grid2d(cols0, rows0, b), g12 = grid2d((cols1 + 1) / 2, (rows1 + 1) / 2, b),
+               gs = grid2d(depths[1].cols, depths[1].rows, b);
+    hipLaunchKernelGGL(k_model_levels012, dim3(g0.x * g0.y + g12.x * g12.y + gs.x * gs.y), b, 0, s, m, (int)g0.x, (int)g0.y, (int)g12.x, rows0,
+                       cols0, view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]), view<unsigned char>(&images[0]), cutOff,
+                       rows1, cols1, rows2, cols2, view<float>(&vmaps[1]), view<float>(&nmaps[1]), view<float>(&vmaps[2]),
+                       view<float>(&nmaps[2]), (int)g12.y, (int)gs.x, view<float>(&depths[1]), view<unsigned char>(&images[1]));
     DMS_CHECK_LAUNCH();
   }
-  for (int l = 1; l < 3; ++l)
+  for (int l = 2; l < 3; ++l)
     LAUNCH2D(k_model_pyr_step, depths[l].cols, depths[l].rows, s, view<const float>(&depths[l - 1]), view<float>(&depths[l]),
              view<const unsigned char>(&images[l - 1]), view<unsigned char>(&images[l]));
   return DMS_OK;
