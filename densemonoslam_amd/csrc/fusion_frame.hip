@@ -25,7 +25,7 @@ int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStr
 int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
             int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src = nullptr, void* mirror_dst = nullptr,
-            int mirror_bytes = 0);
+            int mirror_bytes = 0, int* dense_flag = nullptr);
 int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s);
 // fusion_map.hip
 int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
@@ -114,29 +114,6 @@ __global__ void k_pose_override(FrameState* st, Pose16 p) {
 __global__ void k_frame_after_track(FrameState* st, float weightMultiplier) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   frame_after_track_body(st, weightMultiplier);
-}
-
-// denseEnough on the W/20 × H/20 nearest-neighbour subsample of the predicted image
-// (Resize::image + ElasticFusion::denseEnough, ElasticFusion.cpp:84-97,166-167)
-__global__ __launch_bounds__(256) void k_dense_enough(const uchar4* __restrict__ image, int cols, int rows, FrameState* st) {
-  const int dw = cols / 20, dh = rows / 20;
-  int sum = 0;
-  for (int k = threadIdx.x; k < dw * dh; k += blockDim.x) {
-    const int i = k % dw, j = k / dw;
-    const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
-    const int sx = texel(u, (float)cols, cols), sy = texel(v, (float)rows, rows);
-    const uchar4 c = image[(size_t)sy * cols + sx];
-    sum += (c.x > 0 && c.y > 0 && c.z > 0) ? 1 : 0;
-  }
-  __shared__ int s_sum[4];
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int tot = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-    const bool dense = (float)tot / (float)(dh * dw) > 0.95f;
-    st->fill_in = dense ? 0 : 1;
-  }
 }
 
 // The W/8 x H/8 thumbnails a camera publishes per frame in collaborative mode (the fern matcher's
@@ -360,7 +337,7 @@ void drain(dms_fusion* f) {
 }
 
 // ElasticFusion::predict (ElasticFusion.cpp:688-746): ACTIVE splat + fill-in
-int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr) {
+int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr, bool dense_test = false) {
   int rc;
   {
     FTimer t(f, s, "predict");
@@ -373,7 +350,7 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
     // passthrough = lost (geometry), lost || frameToFrameRGB (image) (ElasticFusion.cpp:704-712)
     // (the frame's last fill-in also copies the result block into its pinned host slot)
     if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
-                      s, state_mirror ? f->state : nullptr, state_mirror, (int)sizeof(FrameState))))
+                      s, state_mirror ? f->state : nullptr, state_mirror, (int)sizeof(FrameState), dense_test ? &f->state->fill_in : nullptr)))
       return rc;
   }
   return DMS_OK;
@@ -657,9 +634,8 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, f->state, prior, 1);
       DMS_CHECK_LAUNCH();
     }
-    if ((rc = predict(f, 0.7f, s))) return rc;  // ElasticFusion.cpp:165
-    hipLaunchKernelGGL(k_dense_enough, dim3(1), dim3(256), 0, s, (const uchar4*)f->pred.image.data, W, H, f->state);
-    DMS_CHECK_LAUNCH();
+    // ElasticFusion.cpp:165-167: an extra block of this predict's fill-in launch takes the denseEnough decision
+    if ((rc = predict(f, 0.7f, s, nullptr, true))) return rc;
     if (f->p.hybrid_tracking) {
       {
         FTimer t(f, s, "odom_init");

@@ -87,6 +87,11 @@ struct FillArgs {
   const unsigned* mirror_src;
   unsigned* mirror_dst;
   int mirror_words;
+  // optional: one extra block (grid row `rows_blocks`) decides denseEnough (ElasticFusion.cpp:84-97,166-167) from the
+  // existing image: the share of non-black pixels on its W/20 x H/20 NEAREST subsample (Resize::image);
+  // *dense_flag = 0 when more than 95 % are covered, 1 (fill in) otherwise.  Independent of the fill-in itself.
+  int* dense_flag;
+  int rows_blocks;
   float4* out_vertex;
   float4* out_normal;
   uchar4* out_image;
@@ -104,6 +109,30 @@ __device__ __forceinline__ f3 fill_vertex_at(const FillArgs& a, int sx, int sy, 
 __global__ __launch_bounds__(BX* BY) void k_fill_in(FillArgs a) {
   const int px = blockIdx.x * blockDim.x + threadIdx.x;
   const int py = blockIdx.y * blockDim.y + threadIdx.y;
+  if (a.dense_flag && (int)blockIdx.y == a.rows_blocks) {  // the extra block row: block 0 of it does the test, the others idle
+    if (blockIdx.x != 0) return;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    const int dw = a.cols / 20, dh = a.rows / 20;
+    int sum = 0;
+    for (int k = t; k < dw * dh; k += BX * BY) {
+      const int i = k % dw, j = k / dw;
+      const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
+      const int sx = texel(u, (float)a.cols, a.cols), sy = texel(v, (float)a.rows, a.rows);
+      const uchar4 c = a.ex_image[(size_t)sy * a.cols + sx];
+      sum += (c.x > 0 && c.y > 0 && c.z > 0) ? 1 : 0;
+    }
+    __shared__ int s_sum[BX * BY / 64];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((t & 63) == 0) s_sum[t >> 6] = sum;
+    __syncthreads();
+    if (t == 0) {
+      int tot = 0;
+      for (int w = 0; w < BX * BY / 64; ++w) tot += s_sum[w];
+      const bool dense = (float)tot / (float)(dh * dw) > 0.95f;
+      *a.dense_flag = dense ? 0 : 1;
+    }
+    return;
+  }
   if (a.mirror_words > 0 && blockIdx.x == 0 && blockIdx.y == 0) {
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
     if (t < a.mirror_words) a.mirror_dst[t] = a.mirror_src[t];
@@ -179,7 +208,7 @@ int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream
 }
 
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
-            int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src, void* mirror_dst, int mirror_bytes) {
+            int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src, void* mirror_dst, int mirror_bytes, int* dense_flag) {
   DMS_REQUIRE(ex && depth && rgba && cam && out, "null argument");
   DMS_REQUIRE(dense(&ex->vertex, 16) && dense(&ex->normal, 16) && dense(&ex->image, 4) && dense(depth, 2) && dense(rgba, 4) &&
                   dense(&out->vertex, 16) && dense(&out->normal, 16) && dense(&out->image, 4),
@@ -206,6 +235,9 @@ int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image
   a.mirror_dst = (unsigned*)mirror_dst;
   a.mirror_words = (mirror_src && mirror_dst) ? mirror_bytes / 4 : 0;
   dim3 b(BX, BY), g = grid2d(a.cols, a.rows, b);
+  a.dense_flag = dense_flag;
+  a.rows_blocks = (int)g.y;
+  if (dense_flag) g.y += 1;
   hipLaunchKernelGGL(k_fill_in, g, b, 0, s, a);
   DMS_CHECK_LAUNCH();
   return DMS_OK;
