@@ -929,7 +929,7 @@ struct LevelArgs {
   int rgbOnly;
   float icpWeight;
   float fx, fy, cx, cy;  // full-resolution intrinsics
-  float* rec;            // [2][gridDim.x][kRecFloats]
+  void* rec;             // [2][gridDim.x][kRecFloats] floats (or doubles with fp64 sums)
   unsigned long long* sync;  // 2 barriers (kBarrierStride words each) per iteration, zero on entry
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
@@ -1054,12 +1054,85 @@ __device__ __forceinline__ void pk_gather(Rsrc rsrc, int par, int nb, double (*s
   __syncthreads();
 }
 
-template <bool ICP, bool RGB, int P>
+// ---- fp64-sum variant (DMS_SUMS=fp64) -------------------------------------------------------------------
+// Block-wide sum of NV per-thread fp32 values in fp64, through LDS: every thread parks its NV values
+// (value-major, s_t[k * kPB + thread]), then thread (k = tid / 16, seg = tid % 16) adds the 32 values of
+// threads seg * 32 .. seg * 32 + 31 of value k in fp64, in a fixed (bank-skewed) order, and a 16-lane fp64
+// butterfly finishes; the total of value k comes back in threads k * 16 .. k * 16 + 15.  Nothing is rounded
+// to fp32 on the way and the records are fp64: the block totals differ from an fp64 accumulation of the same
+// products by ~1e-10 of the sum of magnitudes instead of ~5e-9 (numerics).
+template <int NV>
+__device__ __forceinline__ double pblock_reduce_d(float (&v)[NV], float* s_t) {
+  static_assert(NV * 16 <= kPB, "one 16-thread group per value");
+  const int tid = threadIdx.x;
+  __syncthreads();  // s_t may still be read from its previous use (or as the gather scratch)
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s_t[k * kPB + tid] = v[k];
+  __syncthreads();
+  double r = 0.0;
+  if (tid < NV * 16) {
+    const int k = tid >> 4, seg = tid & 15;
+    const float* col = s_t + k * kPB + seg * 32;
+    const int skew = 2 * seg + (k & 1);  // the 64 lanes of a wave spread over all 32 banks
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) r += (double)col[(i + skew) & 31];
+    r = row16_sum_d(r);
+  }
+  return r;
+}
+template <int NV>
+__device__ __forceinline__ bool pblock_owner_d() {
+  return threadIdx.x < NV * 16 && (threadIdx.x & 15) == 0;
+}
+// gather of fp64 records: thread (g = tid / 32, c2 = tid % 32) sums the pair of doubles c2 of records g, g + 16, ...
+template <typename Rsrc>
+__device__ __forceinline__ void pk_gather_d(Rsrc rsrc, int par, int nb, double* s_grp /* [16][64] */, float* s_sums) {
+  const int tid = threadIdx.x;
+  const int c2 = tid & 31, g = tid >> 5;
+  double f0 = 0.0, f1 = 0.0;
+  constexpr int U = 4;
+#pragma unroll
+  for (int h = 0; h < kMaxPersistBlocks / 16 / U; ++h) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = g + 16 * (h * U + u);
+      const int bc = b < nb ? b : 0;
+      v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((par * nb + bc) * kRecFloats + c2 * 2) * 8, 0, /*sc1*/ 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (g + 16 * (h * U + u) < nb) {
+        f0 += __longlong_as_double((long long)(((unsigned long long)v[u][1] << 32) | v[u][0]));
+        f1 += __longlong_as_double((long long)(((unsigned long long)v[u][3] << 32) | v[u][2]));
+      }
+    }
+  }
+  __syncthreads();  // the scratch aliases the reduce buffer: everybody is done reading that
+  s_grp[g * 64 + c2 * 2] = f0;
+  s_grp[g * 64 + c2 * 2 + 1] = f1;
+  __syncthreads();
+  {
+    const int j = tid >> 3, sub = tid & 7;
+    double t = s_grp[(2 * sub) * 64 + j] + s_grp[(2 * sub + 1) * 64 + j];
+    t = row8_sum_d(t);
+    if (sub == 0) s_sums[j] = (float)t;
+  }
+  __syncthreads();
+}
+
+template <bool ICP, bool RGB, int P, bool F64>
 __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
   __shared__ GnLocal s;
-  __shared__ float s_red[kPWaves][32];
   __shared__ int s_redi[kPWaves][2];
-  __shared__ double s_grp[32][16][4];
+  // fp32 sums: s_red [kPWaves][32] floats + s_grp [32][16][4] doubles; fp64 sums: one [kSE3][kPB] float buffer whose
+  // first 8 KB double as the gather scratch
+  constexpr int kLdsBytes = F64 ? kSE3 * kPB * 4 : (kPWaves * 32 * 4 + 32 * 16 * 4 * 8);
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLdsBytes];
+  float(*s_red)[32] = reinterpret_cast<float(*)[32]>(s_raw);
+  double(*s_grp)[16][4] = reinterpret_cast<double(*)[16][4]>(s_raw + kPWaves * 32 * 4);
+  float* const s_t = reinterpret_cast<float*>(s_raw);
+  double* const s_grp_d = reinterpret_cast<double*>(s_raw);
   __shared__ float s_sums[kRecFloats];
   __shared__ int s_done;
   const int tid = threadIdx.x;
@@ -1121,7 +1194,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
   }
   const float invFx = 1.0f / a.fx, invFy = 1.0f / a.fy;  // as projectToPointCloud passes them
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(L.rec, 0, 2 * nb * kRecFloats * 4, 0x00020000);
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(L.rec, 0, 2 * nb * kRecFloats * (F64 ? 8 : 4), 0x00020000);
   __syncthreads();
   if (s_done) return;  // level already ended (uniform: every block read the same flag)
 
@@ -1206,7 +1279,8 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       }
     }
     phase(1);
-    float* my_rec = L.rec + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+    float* my_rec = reinterpret_cast<float*>(L.rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+    double* my_rec_d = reinterpret_cast<double*>(L.rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
     int rgbSize = 0, sigma = 0;
     if (RGB) {
       // ---- barrier A, arrival: the word carries the count and the sum of squared differences ----
@@ -1227,8 +1301,13 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
     phase(2);
     if (ICP) {  // the ICP block sum and its record store overlap the other blocks' arrivals
-      const float tot = pblock_reduce<kSE3>(acc, s_red);
-      if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (F64) {
+        const double tot = pblock_reduce_d<kSE3>(acc, s_t);
+        if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        const float tot = pblock_reduce<kSE3>(acc, s_red);
+        if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (RGB) {
       const unsigned long long word = pk_wait(L.sync + (2 * it) * kBarrierStride, &st->sync_timeout);
@@ -1265,8 +1344,13 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         rgb_row_finish(p_, c[p], in, row);
         accumulate_se3(acc, row, c[p].valid != 0);
       }
-      const float tot = pblock_reduce<kSE3>(acc, s_red);
-      if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + 32 + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (F64) {
+        const double tot = pblock_reduce_d<kSE3>(acc, s_t);
+        if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + 32 + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        const float tot = pblock_reduce<kSE3>(acc, s_red);
+        if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + 32 + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     // ---- barrier B: records published ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1275,7 +1359,10 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     phase(5);
 
     // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
-    pk_gather(rsrc, par, nb, s_grp, s_sums);
+    if (F64)
+      pk_gather_d(rsrc, par, nb, s_grp_d, s_sums);
+    else
+      pk_gather(rsrc, par, nb, s_grp, s_sums);
     phase(6);
     if (tid == 0) {
       SolveArgs q;
@@ -1355,12 +1442,18 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 // with one barrier per iteration (records double-buffered).  The state block is copied into LDS
 // and the unchanged scalar code runs on the copy; block 0 writes it back at the end.
 // ---------------------------------------------------------------------------------------
+template <bool F64>
 __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
-                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows, float* rec,
+                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows, void* rec,
                                                    unsigned long long* sync, SolveCam cam, int first_gn_level, int max_iter) {
   __shared__ TrackState s;
-  __shared__ float s_red[kPWaves][32];
-  __shared__ double s_grp[32][16][4];
+  constexpr int kLdsBytes = F64 ? kSO3 * kPB * 4 : (kPWaves * 32 * 4 + 32 * 16 * 4 * 8);
+  static_assert(!F64 || kLdsBytes >= 16 * 64 * 8, "gather scratch fits the reduce buffer");
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLdsBytes];
+  float(*s_red)[32] = reinterpret_cast<float(*)[32]>(s_raw);
+  double(*s_grp)[16][4] = reinterpret_cast<double(*)[16][4]>(s_raw + kPWaves * 32 * 4);
+  float* const s_t = reinterpret_cast<float*>(s_raw);
+  double* const s_grp_d = reinterpret_cast<double*>(s_raw);
   __shared__ float s_sums[kRecFloats];
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
@@ -1376,7 +1469,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   const bool live = i < N;
   const int ic = live ? i : 0;
   const int y = ic / cols, x = ic - y * cols;
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, 2 * nb * kRecFloats * 4, 0x00020000);
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, 2 * nb * kRecFloats * (F64 ? 8 : 4), 0x00020000);
   for (int it = 0; it < max_iter; ++it) {
     const int par = it & 1;
     So3Params p;
@@ -1403,12 +1496,21 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
       }
       accumulate_so3(acc, row, found);
     }
-    const float tot = pblock_reduce<kSO3>(acc, s_red);
-    float* my_rec = rec + ((size_t)par * nb + blockIdx.x) * kRecFloats;
-    if (pblock_owner<kSO3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (F64) {
+      const double tot = pblock_reduce_d<kSO3>(acc, s_t);
+      double* my_rec = reinterpret_cast<double*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+      if (pblock_owner_d<kSO3>()) __hip_atomic_store(my_rec + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const float tot = pblock_reduce<kSO3>(acc, s_red);
+      float* my_rec = reinterpret_cast<float*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+      if (pblock_owner<kSO3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pk_barrier(sync + it * kBarrierStride, 0ull, &st->sync_timeout);
-    pk_gather(rsrc, par, nb, s_grp, s_sums);
+    if (F64)
+      pk_gather_d(rsrc, par, nb, s_grp_d, s_sums);
+    else
+      pk_gather(rsrc, par, nb, s_grp, s_sums);
     if (tid == 0) so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
     __syncthreads();
     if (s.so3_done) break;
@@ -1502,7 +1604,7 @@ void layout(dms_odometry* o, Carver& c) {
   o->part_so3 = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
   o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
   o->tickets = (unsigned*)c.take(64);
-  o->rec = (float*)c.take((size_t)2 * kMaxPersistBlocks * kRecFloats * 4);
+  o->rec = (float*)c.take((size_t)2 * kMaxPersistBlocks * kRecFloats * 8);  // sized for the fp64-sum variant
   o->sync = (unsigned long long*)c.take((size_t)kSyncWords * 8);
   o->prof = (long long*)c.take(3 * 16 * 8);
   o->state = (TrackState*)c.take(sizeof(TrackState));
@@ -1828,16 +1930,29 @@ struct PersistSection {
   }
 };
 
+// DMS_SUMS=fp64: block sums and records in fp64 (tighter agreement with an fp64 accumulation, ~3 % slower)
+static bool sums_fp64() {  // read per call: tests switch it inside one process
+  const char* e = getenv("DMS_SUMS");
+  return e && strcmp(e, "fp64") == 0;
+}
+
+template <bool ICP, bool RGB, bool F64>
+static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
+  if (P == 1)
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  else if (P == 2)
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  else if (P == 3)
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  else
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+}
 template <bool ICP, bool RGB>
 static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
-  if (P == 1)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1>), dim3(nb), dim3(kPB), 0, s, st, a, L);
-  else if (P == 2)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2>), dim3(nb), dim3(kPB), 0, s, st, a, L);
-  else if (P == 3)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  if (sums_fp64())
+    launch_gn_level_f<ICP, RGB, true>(P, nb, s, st, a, L);
   else
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L);
 }
 
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
@@ -1889,8 +2004,12 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       persist.begin();
       Timer t(o, s, "so3_level");
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
-      hipLaunchKernelGGL(k_so3_level, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->rec, o->sync, cam, first_level, 10);
+      if (sums_fp64())
+        hipLaunchKernelGGL(k_so3_level<true>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, cam, first_level, 10);
+      else
+        hipLaunchKernelGGL(k_so3_level<false>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, cam, first_level, 10);
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {

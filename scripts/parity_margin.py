@@ -3,7 +3,7 @@
 the headline resolution (both sides start every step from the GPU's map and pose): the margin under the
 north-star bar (1 mm, 0.01 deg per step).  Uses oracle/ as the checker.
 
-    python scripts/parity_margin.py [--frames 100] [--width 640 --height 480]"""
+    python scripts/parity_margin.py [--frames 100] [--width 640 --height 480]      (DMS_SUMS=fp64 selects the fp64-sum tracker)"""
 import argparse
 import json
 import os
@@ -54,7 +54,8 @@ def main():
     print(json.dumps({"resolution": [W, H], "steps": len(dts), "worst_dt_m": float(dts.max()), "median_dt_m": float(np.median(dts)),
                       "p99_dt_m": float(np.percentile(dts, 99)), "worst_dR_deg": float(das.max()), "median_dR_deg": float(np.median(das)),
                       "p99_dR_deg": float(np.percentile(das, 99)), "decision_flips": flips, "surfels": int(rg.surfels),
-                      "bar": {"dt_m": 1e-3, "dR_deg": 0.01}}))
+                      "bar": {"dt_m": 1e-3, "dR_deg": 0.01},
+                      "sums": os.environ.get("DMS_SUMS", "fp32")}))
 
 
 if __name__ == "__main__":

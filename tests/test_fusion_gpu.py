@@ -1161,3 +1161,31 @@ def test_dataset_logs_feed_the_frame_step(fus, synth, tmp_path, container):
     got = run(seq)
     assert_bits(got[0], ref[0], "pose")
     surfels_equal(got[1], ref[1], "map from the %s log" % container)
+
+
+def test_process_frame_pipeline_parity_fp64_sums(fus, orc, synth, monkeypatch):
+    """DMS_SUMS=fp64 (block sums through an fp64 LDS transpose, fp64 records): the same teacher-forced
+    per-step check as the default path."""
+    from oracle import orc_pipeline
+
+    monkeypatch.setenv("DMS_SUMS", "fp64")
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000)
+    worst_t = worst_r = 0.0
+    for k in range(6):
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        dt, da = helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
+        worst_t, worst_r = max(worst_t, dt), max(worst_r, da)
+        assert rg.tick == ro.tick and bool(rg.fused) == ro.fused and bool(rg.fill_in) == ro.fill_in
+        if k > 0:
+            assert list(rg.track.iterations_run) == list(ro.track.iterations_run)
+        mg = g.globalModel().downloadMap()
+        assert abs(len(mg) - ro.surfels) <= max(10, 2e-3 * ro.surfels)
+        o.model = mg.copy()
+        o.currPose = pose_g.copy()
+    print("fp64 sums: worst per-step pose difference vs oracle: %.3e m, %.3e deg" % (worst_t, worst_r))
+    assert worst_t < 5e-4 and worst_r < 5e-3, (worst_t, worst_r)
+    g.close()

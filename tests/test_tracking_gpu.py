@@ -346,14 +346,17 @@ def _fresh_pair(dms, orc, gputest_pair):
 def track_mode(request, monkeypatch):
     """'persistent' = one resident kernel per pyramid level (default); 'launches' = pass1 / pass2 /
     solve launches per iteration (fallback path).  Read by the library at every tracking call."""
+    monkeypatch.delenv("DMS_SUMS", raising=False)
     if request.param == "launches":
         monkeypatch.setenv("DMS_TRACK_MODE", "launches")
     else:
         monkeypatch.delenv("DMS_TRACK_MODE", raising=False)
+        if request.param == "persistent_fp64":  # resident kernels with fp64 block sums and records (DMS_SUMS=fp64)
+            monkeypatch.setenv("DMS_SUMS", "fp64")
     return request.param
 
 
-@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
+@pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode):
     cfg = CONFIGS[name]
@@ -378,7 +381,7 @@ def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode
     assert 1e-4 < np.linalg.norm(tg) < 0.1
 
 
-@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
+@pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("name", ["C2_icp_fast", "C3_full", "gputest", "rgb_only"])
 def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, track_mode):
     """The committed golden vectors of the tracker on the reference's GPUTest pair
@@ -405,7 +408,7 @@ def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, trac
     _sum_close(np.array(rg.lastA), want[name + "_lastA"], rtol=2e-3, what="lastA")
 
 
-@pytest.mark.parametrize("track_mode", ["persistent", "launches"], indirect=True)
+@pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("case", ["no_live_depth", "black_live_image"])
 def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
     """Degenerate frames: no live depth at all (zero ICP correspondences: the 6x6 system is singular
