@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--loop-closure", action="store_true",
                     help="time the 'full' frame step: local loop closure on (INACTIVE prediction + model-to-model tracking every frame)")
     ap.add_argument("--no-full-leg", action="store_true", help="skip the extra 'full' (loop closure on) leg of the default run")
+    ap.add_argument("--time-delta", type=int, default=200,
+                    help="active time window in frames (reference default 200); a small value with --loop-closure populates the INACTIVE "
+                         "view on this cyclic stream, so the model-to-model tracker has correspondences")
     args = ap.parse_args()
 
     import torch
@@ -118,7 +121,7 @@ def main():
 
     def make_engine(loop_closure=args.loop_closure):
         return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1,
-                                    local_loop_closure=1 if loop_closure else 0)
+                                    local_loop_closure=1 if loop_closure else 0, timeDelta=args.time_delta)
 
     stream = torch.cuda.current_stream().cuda_stream
     ef = make_engine()
@@ -193,6 +196,8 @@ def main():
                         else "same frame step at %dx%d%s" % (W, H, ", local loop closure on" if args.loop_closure else ""),
             "resolution": [W, H],
             "cameras_per_gpu": 1,
+            "time_delta": args.time_delta,
+            "loop_icp_count_last_frame": float(res.loop_icp_count) if args.loop_closure else None,
             "surfels_per_map": M,
             "surfels_total": M_total,
             "exchange": "all-gather of %d-byte W/8xH/8 thumbnails per camera per frame" % thumb.numel() if distributed else "none (1 camera)",
