@@ -48,3 +48,17 @@ def test_struct_sizes_match_reference_types():
     assert ctypes.sizeof(capi.Image2D) == 24
     assert ctypes.sizeof(capi.Mat33) == 36
     assert ctypes.sizeof(capi.Camera) == 16
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: the three public headers compile as C99 (and as C++11) on their own,
+    without HIP or torch types."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include "dmslam.h"\n#include "dmslam_fusion.h"\n#include "dmslam_io.h"\n'
+                   "int main(void) { dms_fusion_params p; dms_frame_result r; dms_frame_msg m; (void)p; (void)r; (void)m; return 0; }\n")
+    inc = os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])

@@ -1189,3 +1189,28 @@ def test_process_frame_pipeline_parity_fp64_sums(fus, orc, synth, monkeypatch):
     print("fp64 sums: worst per-step pose difference vs oracle: %.3e m, %.3e deg" % (worst_t, worst_r))
     assert worst_t < 5e-4 and worst_r < 5e-3, (worst_t, worst_r)
     g.close()
+
+
+def test_frame_step_api_contract(fus, synth):
+    """Misuse of the two-phase frame step and of optional views is reported, not executed."""
+    from densemonoslam_amd import capi
+
+    d, rgb, _ = synth.frame(0, width=W, height=H, K=K, noise=True)
+    g = fus.ElasticFusion(W, H, K, model_capacity=300000)
+    with pytest.raises(capi.DmsError):
+        g.processFrameEnd()  # no begin
+    g.processFrameBegin(rgb, d)
+    with pytest.raises(capi.DmsError):
+        g.processFrameBegin(rgb, d)  # the previous frame has not been ended
+    with pytest.raises(capi.DmsError):
+        g.fetchLoop()  # only with local_loop_closure
+    g.processFrameEnd()
+    r = g.fetch()
+    assert r.fused and r.tick == 2
+    with pytest.raises(capi.DmsError):
+        g.image(17)  # the INACTIVE view exists only with local_loop_closure
+    assert g.loopConstraints().shape == (0, 7)
+    g.processFrame(rgb, d)  # the context is still usable after the reported errors
+    g.close()
+    with pytest.raises(capi.DmsError):
+        fus.ElasticFusion(W, H, K, timeIdx=99)  # out of range sensor slot
