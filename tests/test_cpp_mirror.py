@@ -40,3 +40,63 @@ def test_cpp_mirror_compiles_links_and_runs():
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
         assert "gfx950" in out.stdout
+
+
+GPU_SRC = r"""
+// A C++ host written against the mirror of the reference classes only: two frames of a synthetic plane
+// through ElasticFusion::processFrame, the way MainController drives the reference.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "densemonoslam_amd/cpp/dmslam.hpp"
+int main() {
+  const int W = 320, H = 240;
+  int ndev = 0;
+  if (dms_device_count(&ndev) != DMS_OK || ndev < 1) return 10;
+  dms::ElasticFusion ef(W, H, 264.f, 264.f, 160.f, 120.f);
+  std::vector<unsigned char> rgb((size_t)W * H * 3);
+  std::vector<unsigned short> depth((size_t)W * H);
+  void *rgb_dev = nullptr, *depth_dev = nullptr;
+  dms::check(dms_device_alloc(&rgb_dev, rgb.size()), "alloc");
+  dms::check(dms_device_alloc(&depth_dev, depth.size() * 2), "alloc");
+  dms_frame_result r;
+  for (int k = 0; k < 3; ++k) {
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        depth[i] = (unsigned short)(1500 + 2 * k + (x / 4) % 7 + 200.0 * std::sin(0.02 * x) * std::cos(0.03 * y));  // a wavy wall, mm
+        rgb[3 * i + 0] = (unsigned char)(128 + 100 * std::sin(0.11 * (x + k)));
+        rgb[3 * i + 1] = (unsigned char)(128 + 100 * std::sin(0.07 * y));
+        rgb[3 * i + 2] = (unsigned char)(128 + 60 * std::sin(0.05 * (x + y)));
+      }
+    dms::check(dms_memcpy_h2d(rgb_dev, rgb.data(), rgb.size(), nullptr), "h2d");
+    dms::check(dms_memcpy_h2d(depth_dev, depth.data(), depth.size() * 2, nullptr), "h2d");
+    ef.processFrame((const unsigned char*)rgb_dev, (const unsigned short*)depth_dev);
+    r = ef.fetch();
+    std::printf("frame %d: tick %d surfels %u fused %d icp %.0f\n", k, r.tick, r.surfels, r.fused, r.track.lastICPCount);
+  }
+  dms_device_free(rgb_dev);
+  dms_device_free(depth_dev);
+  if (r.tick != 4 || r.surfels < 50000 || !r.fused) return 11;
+  if (!(r.track.lastICPCount > 30000) || r.track.iterations_run[0] != 10) return 12;
+  if (!(std::fabs(r.pose[3]) < 0.05f && std::fabs(r.pose[11]) < 0.05f)) return 13;  // a static camera stays put
+  auto gm = ef.getGlobalModel();
+  if (gm.lastCount() != r.surfels) return 14;
+  return 0;
+}
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_cpp_host_runs_the_frame_step():
+    lib_dir = os.path.join(ROOT, "densemonoslam_amd")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "host.cpp")
+        exe = os.path.join(td, "host")
+        with open(src, "w") as f:
+            f.write(GPU_SRC)
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + ROOT, src, "-o", exe, "-L" + lib_dir, "-ldmslam_hip",
+                               "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
