@@ -86,6 +86,9 @@ def main():
     # RCCL communicator); used to rehearse the multi-rank control flow on a 1-GPU box
     if os.environ.get("DMS_BENCH_SHARE_GPU") == "1":
         local_rank = local_rank % torch.cuda.device_count()
+        # processes sharing a device must not run resident (spinning) kernels side by side: the library chains them
+        # within a process only; across processes they would time out at their grid barriers (DMS_ERR_TIMEOUT)
+        os.environ.setdefault("DMS_TRACK_MODE", "launches")
     if distributed:
         backend = os.environ.get("DMS_BENCH_BACKEND", "nccl")
         if backend == "nccl":

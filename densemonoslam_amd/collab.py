@@ -50,7 +50,9 @@ class ThumbnailExchange:
     def begin(self):
         w = self.work[self.slot]
         if w is not None:  # the collective that used this block two frames ago
-            w.wait()
+            # normally long finished: a host-side query then avoids putting a wait on the frame's stream
+            if not w.is_completed():
+                w.wait()
             self.work[self.slot] = None
         self.local = self.locals[self.slot]
         return self.local
