@@ -227,7 +227,10 @@ def main():
             "ms_per_step": 1000.0 * el / nfull,
             "steps": nfull,
             "what": "same frame step with local loop closure on: + INACTIVE prediction, second (model-to-model) 3-level tracker pass, "
-                    "acceptance test and constraint sampling on device (ElasticFusion.cpp:399-474)",
+                    "acceptance test and constraint sampling on device (ElasticFusion.cpp:399-474).  On this stream nothing is older than the "
+                    "200-frame window, so the INACTIVE view is (nearly) empty, as in any run without a revisit: a tracker level that finds no "
+                    "correspondence of either kind ends after that iteration (the remaining ones would repeat it bit for bit). "
+                    "`--loop-closure --time-delta 8` measures the same step with a populated view",
             "last_loop_icp_count": float(rf.loop_icp_count),
         }
         ef.close()

@@ -1382,6 +1382,19 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
     __syncthreads();
     phase(7);
+    // No correspondence of either kind: the system was all zeros and the update exactly the identity, so every
+    // remaining iteration of this level would reproduce this one bit for bit (same state, same sums, same side
+    // outputs).  Account for them and leave — e.g. the model-to-model pass of the full frame step while the
+    // INACTIVE view is empty.  Uniform: every block holds the same sums.
+    if (!L.rgbOnly && it < L.n_iter - 1 && (!ICP || s_sums[28] == 0.f) && (!RGB || rgbSize == 0)) {
+      if (tid == 0) {
+        s.iters_run += L.n_iter - 1 - it;
+        double K[9];
+        level_K(L.fx, L.fy, L.cx, L.cy, L.level_below, K);  // what the level's last iteration would have prepared
+        gn_params_local(s, K);
+      }
+      break;
+    }
   }
 
   // ---- block 0 hands the state to the next kernel on the stream ----

@@ -409,7 +409,7 @@ def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, trac
 
 
 @pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
-@pytest.mark.parametrize("case", ["no_live_depth", "black_live_image"])
+@pytest.mark.parametrize("case", ["no_live_depth", "black_live_image", "no_depth_and_black"])
 def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
     """Degenerate frames: no live depth at all (zero ICP correspondences: the 6x6 system is singular
     and the pivoted LDLT semantics apply) and a black live image (zero photometric correspondences:
@@ -419,9 +419,9 @@ def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
     verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
     rgba1, rgba2 = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
     depth2 = gputest_pair["depth2"].copy()
-    if case == "no_live_depth":
+    if case in ("no_live_depth", "no_depth_and_black"):
         depth2[:] = 0
-    else:
+    if case in ("black_live_image", "no_depth_and_black"):  # (both: no correspondence of either kind — the resident kernels leave a level early)
         rgba2 = np.zeros_like(rgba2)
     g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
     o = orc.Odometry(640, 480, K[2], K[3], K[0], K[1])
@@ -440,10 +440,11 @@ def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
     assert np.array_equal(np.isnan(tg), np.isnan(to)) and np.array_equal(np.isnan(Rg), np.isnan(Ro))
     if not np.isnan(to).any():
         helpers.assert_pose_close(tg, Rg, to, Ro, what=case)
-    if case == "no_live_depth":
+    if case in ("no_live_depth", "no_depth_and_black"):
         assert rg.lastICPCount == ro.lastICPCount == 0
-    else:
+    if case in ("black_live_image", "no_depth_and_black"):
         assert rg.lastRGBCount == ro.lastRGBCount == 0
+    assert np.array_equal(np.isnan(np.array(rg.lastA)), np.isnan(np.array(ro.lastA)))
 
 
 def test_track_from_nonidentity_prior_and_second_call(dms, orc, gputest_pair):
