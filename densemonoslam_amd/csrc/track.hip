@@ -934,6 +934,7 @@ struct LevelArgs {
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
+  int early_exit;  // leave a level after an iteration without any correspondence (DMS_TRACK_EARLY_EXIT=0 runs them all)
   int finalize, fin_rgb;
   float* pose16_out;
   FrameState* frame;
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     // remaining iteration of this level would reproduce this one bit for bit (same state, same sums, same side
     // outputs).  Account for them and leave — e.g. the model-to-model pass of the full frame step while the
     // INACTIVE view is empty.  Uniform: every block holds the same sums.
-    if (!L.rgbOnly && it < L.n_iter - 1 && (!ICP || s_sums[28] == 0.f) && (!RGB || rgbSize == 0)) {
+    if (L.early_exit && !L.rgbOnly && it < L.n_iter - 1 && (!ICP || s_sums[28] == 0.f) && (!RGB || rgbSize == 0)) {
       if (tid == 0) {
         s.iters_run += L.n_iter - 1 - it;
         double K[9];
@@ -2109,6 +2110,10 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.rec = o->rec;
       L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
       L.prof = o->profiling ? o->prof : nullptr;
+      {
+        const char* ee = getenv("DMS_TRACK_EARLY_EXIT");
+        L.early_exit = (ee && ee[0] == '0') ? 0 : 1;
+      }
       L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
       L.fin_rgb = rgb ? 1 : 0;
       L.pose16_out = frame ? const_cast<float*>(prior_pose16_dev) : nullptr;
