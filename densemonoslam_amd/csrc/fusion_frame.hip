@@ -60,6 +60,7 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
 int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
                             hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
+void odometry_set_early_exit(dms_odometry* o, int on);
 int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth);
 struct LoopState;
 int odometry_loop_candidate(dms_odometry* o, const FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
@@ -463,6 +464,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   }
   rc = odometry_enable_ring(f->odom);
   if (!rc && p->local_loop_closure) rc = dms_odometry_create(&f->odom_m2m, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
+  if (!rc && f->odom_m2m) odometry_set_early_exit(f->odom_m2m, 1);  // its INACTIVE side is empty on most frames
   if (rc) {
     dms_odometry_destroy(f->odom);
     dms_model_destroy(f->model);

@@ -79,6 +79,7 @@ struct KernelTime {
 using namespace dms;
 
 struct dms_odometry {
+  bool early_exit = false;  // use the resident kernels that leave a level after an iteration without any correspondence
   int width, height;
   float cx, cy, fx, fy, distThres, angleThres;
   float sobelScale, maxDepthDeltaRGB, maxDepthRGB;
@@ -934,7 +935,7 @@ struct LevelArgs {
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
-  int early_exit;  // leave a level after an iteration without any correspondence (DMS_TRACK_EARLY_EXIT=0 runs them all)
+  int early_exit;  // host side: selects the EXIT instantiation of k_gn_level
   int finalize, fin_rgb;
   float* pose16_out;
   FrameState* frame;
@@ -1122,19 +1123,30 @@ __device__ __forceinline__ void pk_gather_d(Rsrc rsrc, int par, int nb, double* 
   __syncthreads();
 }
 
-template <bool ICP, bool RGB, int P, bool F64>
+// LDS of the two sum variants as typed arrays (casts from a raw byte buffer cost the fp32 variant ~2 %: the
+// compiler no longer sees the arrays' shapes and alignment)
+template <bool F64, int NV>
+struct SumLds;
+template <int NV>
+struct SumLds<false, NV> {
+  float s_red[kPWaves][32];
+  double s_grp[32][16][4];
+};
+template <int NV>
+struct SumLds<true, NV> {
+  __attribute__((aligned(16))) float s_t[NV * kPB];  // reduce buffer; its first 8 KB double as the gather scratch [16][64] doubles
+};
+
+// EXIT: leave the level after an iteration without any correspondence (below).  A template parameter because the
+// mere presence of that exit costs the frame-to-model tracker ~1 % (codegen of the resident loop); the frame step
+// instantiates it for the model-to-model pass only.
+template <bool ICP, bool RGB, int P, bool F64, bool EXIT>
 __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
   __shared__ GnLocal s;
   __shared__ int s_redi[kPWaves][2];
-  // fp32 sums: s_red [kPWaves][32] floats + s_grp [32][16][4] doubles; fp64 sums: one [kSE3][kPB] float buffer whose
-  // first 8 KB double as the gather scratch
-  constexpr int kLdsBytes = F64 ? kSE3 * kPB * 4 : (kPWaves * 32 * 4 + 32 * 16 * 4 * 8);
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLdsBytes];
-  float(*s_red)[32] = reinterpret_cast<float(*)[32]>(s_raw);
-  double(*s_grp)[16][4] = reinterpret_cast<double(*)[16][4]>(s_raw + kPWaves * 32 * 4);
-  float* const s_t = reinterpret_cast<float*>(s_raw);
-  double* const s_grp_d = reinterpret_cast<double*>(s_raw);
+  __shared__ SumLds<F64, kSE3> lds;
   __shared__ float s_sums[kRecFloats];
+  __shared__ int s_none;
   __shared__ int s_done;
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
@@ -1153,6 +1165,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   };
 
   if (tid == 0) {
+    s_none = 0;
     s_done = st->level_done[L.level];
     for (int i = 0; i < 16; ++i) s.resultRt[i] = st->resultRt[i];
     for (int i = 0; i < 9; ++i) {
@@ -1302,11 +1315,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
     phase(2);
     if (ICP) {  // the ICP block sum and its record store overlap the other blocks' arrivals
-      if (F64) {
-        const double tot = pblock_reduce_d<kSE3>(acc, s_t);
+      if constexpr (F64) {
+        const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);
         if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        const float tot = pblock_reduce<kSE3>(acc, s_red);
+        const float tot = pblock_reduce<kSE3>(acc, lds.s_red);
         if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -1345,11 +1358,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         rgb_row_finish(p_, c[p], in, row);
         accumulate_se3(acc, row, c[p].valid != 0);
       }
-      if (F64) {
-        const double tot = pblock_reduce_d<kSE3>(acc, s_t);
+      if constexpr (F64) {
+        const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);
         if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + 32 + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        const float tot = pblock_reduce<kSE3>(acc, s_red);
+        const float tot = pblock_reduce<kSE3>(acc, lds.s_red);
         if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + 32 + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -1360,10 +1373,10 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     phase(5);
 
     // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
-    if (F64)
-      pk_gather_d(rsrc, par, nb, s_grp_d, s_sums);
+    if constexpr (F64)
+      pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
     else
-      pk_gather(rsrc, par, nb, s_grp, s_sums);
+      pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
     phase(6);
     if (tid == 0) {
       SolveArgs q;
@@ -1373,28 +1386,28 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       q.icpWeight = L.icpWeight;
       q.level = L.level;
       q.first_iter = it == 0;
-      q.next_level = (it == L.n_iter - 1) ? L.level_below : L.level;
+      // No correspondence of either kind: the system is all zeros and the update exactly the identity, so every
+      // remaining iteration of this level would reproduce this one bit for bit (same state, same sums, same side
+      // outputs) — e.g. the model-to-model pass of the full frame step while the INACTIVE view is empty.  This
+      // iteration then prepares the next level's projection parameters like the level's last one, the remaining
+      // ones are accounted for, and every block leaves (uniform: s_none is read after the barrier below).
+      const bool none = EXIT && !L.rgbOnly && it < L.n_iter - 1 && (!ICP || s_sums[28] == 0.f) && (!RGB || rgbSize == 0);
+      q.next_level = (it == L.n_iter - 1 || none) ? L.level_below : L.level;
       q.level_below = L.level_below;
       q.fx = L.fx;
       q.fy = L.fy;
       q.cx = L.cx;
       q.cy = L.cy;
       gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q);
+      if (none) {
+        s.iters_run += L.n_iter - 1 - it;
+        s_none = 1;
+      }
     }
     __syncthreads();
     phase(7);
-    // No correspondence of either kind: the system was all zeros and the update exactly the identity, so every
-    // remaining iteration of this level would reproduce this one bit for bit (same state, same sums, same side
-    // outputs).  Account for them and leave — e.g. the model-to-model pass of the full frame step while the
-    // INACTIVE view is empty.  Uniform: every block holds the same sums.
-    if (L.early_exit && !L.rgbOnly && it < L.n_iter - 1 && (!ICP || s_sums[28] == 0.f) && (!RGB || rgbSize == 0)) {
-      if (tid == 0) {
-        s.iters_run += L.n_iter - 1 - it;
-        double K[9];
-        level_K(L.fx, L.fy, L.cx, L.cy, L.level_below, K);  // what the level's last iteration would have prepared
-        gn_params_local(s, K);
-      }
-      break;
+    if constexpr (EXIT) {
+      if (s_none) break;
     }
   }
 
@@ -1461,13 +1474,8 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
                                                    const unsigned char* nextImage, size_t next_pitch, int cols, int rows, void* rec,
                                                    unsigned long long* sync, SolveCam cam, int first_gn_level, int max_iter) {
   __shared__ TrackState s;
-  constexpr int kLdsBytes = F64 ? kSO3 * kPB * 4 : (kPWaves * 32 * 4 + 32 * 16 * 4 * 8);
-  static_assert(!F64 || kLdsBytes >= 16 * 64 * 8, "gather scratch fits the reduce buffer");
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLdsBytes];
-  float(*s_red)[32] = reinterpret_cast<float(*)[32]>(s_raw);
-  double(*s_grp)[16][4] = reinterpret_cast<double(*)[16][4]>(s_raw + kPWaves * 32 * 4);
-  float* const s_t = reinterpret_cast<float*>(s_raw);
-  double* const s_grp_d = reinterpret_cast<double*>(s_raw);
+  static_assert(kSO3 * kPB * 4 >= 16 * 64 * 8, "gather scratch fits the reduce buffer");
+  __shared__ SumLds<F64, kSO3> lds;
   __shared__ float s_sums[kRecFloats];
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
@@ -1510,21 +1518,21 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
       }
       accumulate_so3(acc, row, found);
     }
-    if (F64) {
-      const double tot = pblock_reduce_d<kSO3>(acc, s_t);
+    if constexpr (F64) {
+      const double tot = pblock_reduce_d<kSO3>(acc, lds.s_t);
       double* my_rec = reinterpret_cast<double*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
       if (pblock_owner_d<kSO3>()) __hip_atomic_store(my_rec + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      const float tot = pblock_reduce<kSO3>(acc, s_red);
+      const float tot = pblock_reduce<kSO3>(acc, lds.s_red);
       float* my_rec = reinterpret_cast<float*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
       if (pblock_owner<kSO3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pk_barrier(sync + it * kBarrierStride, 0ull, &st->sync_timeout);
-    if (F64)
-      pk_gather_d(rsrc, par, nb, s_grp_d, s_sums);
+    if constexpr (F64)
+      pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
     else
-      pk_gather(rsrc, par, nb, s_grp, s_sums);
+      pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
     if (tid == 0) so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
     __syncthreads();
     if (s.so3_done) break;
@@ -1950,23 +1958,25 @@ static bool sums_fp64() {  // read per call: tests switch it inside one process
   return e && strcmp(e, "fp64") == 0;
 }
 
-template <bool ICP, bool RGB, bool F64>
+template <bool ICP, bool RGB, bool F64, bool EXIT>
 static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
   if (P == 1)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else if (P == 2)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else if (P == 3)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, F64>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
 }
 template <bool ICP, bool RGB>
 static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
   if (sums_fp64())
-    launch_gn_level_f<ICP, RGB, true>(P, nb, s, st, a, L);
+    launch_gn_level_f<ICP, RGB, true, true>(P, nb, s, st, a, L);  // (the precise variant always carries the exit)
+  else if (L.early_exit)
+    launch_gn_level_f<ICP, RGB, false, true>(P, nb, s, st, a, L);
   else
-    launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L);
+    launch_gn_level_f<ICP, RGB, false, false>(P, nb, s, st, a, L);
 }
 
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
@@ -2111,8 +2121,9 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
       L.prof = o->profiling ? o->prof : nullptr;
       {
+        // on for trackers that ask for it (the frame step's model-to-model pass); DMS_TRACK_EARLY_EXIT=1 / 0 forces it
         const char* ee = getenv("DMS_TRACK_EARLY_EXIT");
-        L.early_exit = (ee && ee[0] == '0') ? 0 : 1;
+        L.early_exit = ee ? (ee[0] != '0') : (o->early_exit ? 1 : 0);
       }
       L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
       L.fin_rgb = rgb ? 1 : 0;
@@ -2325,6 +2336,8 @@ int selectCopy16(void* dst, const void* a, const void* b, const int* flag_dev, i
 int transformMapsDev(dms_image2d* v, dms_image2d* n, const float* pose16_dev, hipStream_t s);
 
 // ---- live-frame ring (see dms_odometry::LiveSet) ----
+void odometry_set_early_exit(dms_odometry* o, int on) { o->early_exit = on != 0; }
+
 int odometry_enable_ring(dms_odometry* o) {
   if (o->ring_enabled) return DMS_OK;
   for (int i = 0; i < DMS_NUM_PYRS; ++i) {

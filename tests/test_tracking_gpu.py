@@ -410,11 +410,15 @@ def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, trac
 
 @pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("case", ["no_live_depth", "black_live_image", "no_depth_and_black"])
-def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case):
+@pytest.mark.parametrize("early_exit", [False, True])
+def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case, early_exit, monkeypatch):
     """Degenerate frames: no live depth at all (zero ICP correspondences: the 6x6 system is singular
     and the pivoted LDLT semantics apply) and a black live image (zero photometric correspondences:
     sigma of an empty set).  Every block of a resident kernel must take the same path; the result
     must equal the oracle's, NaN for NaN."""
+    # early_exit: the resident-kernel instantiation that leaves a level after an iteration without any correspondence
+    # (what the frame step uses for its model-to-model pass); the results must not depend on it
+    monkeypatch.setenv("DMS_TRACK_EARLY_EXIT", "1" if early_exit else "0")
     K = gputest_pair["K"]
     verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
     rgba1, rgba2 = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
