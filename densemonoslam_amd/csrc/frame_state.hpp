@@ -12,7 +12,8 @@ struct FrameState {
   float weighting;      // ElasticFusion.cpp:252-268
   int fill_in;          // shouldFillIn (ElasticFusion.cpp:167)
   unsigned surfels;
-  int pad;
+  int track_timeouts;   // sticky: tracker calls of this camera whose resident kernels timed out at a grid barrier (those frames keep
+                        // their prior pose and fuse nothing; dms_fusion_fetch reports DMS_ERR_TIMEOUT)
 };
 
 // Outcome of the local loop-closure candidate of one frame (ElasticFusion.cpp:427-474); the sampled
@@ -29,7 +30,9 @@ struct LoopState {
 // pose becomes next frame's lastPose (ElasticFusion.cpp:158).
 // rodrigues2 (ElasticFusion.cpp:941-985) re-orthonormalises diffRot with an SVD first; a product
 // of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
-__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier) {
+// `timed_out`: the tracker's result is invalid (the caller has restored the prior pose): count it and mark the frame
+// with a negative weight, which k_fuse_associate reads as "fuse nothing" (a legal weight is >= 0).
+__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false) {
   sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
   float diff[16];
   for (int i = 0; i < 4; ++i)
@@ -62,7 +65,8 @@ __device__ inline void frame_after_track_body(FrameState* st, float weightMultip
   const float largest = 0.01f, minWeight = 0.5f;
   if (weighting > largest) weighting = largest;
   weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
-  st->weighting = weighting;
+  st->weighting = timed_out ? -1.f : weighting;
+  if (timed_out) st->track_timeouts += 1;
   for (int i = 0; i < 16; ++i) st->lastPose[i] = st->cur.pose[i];
 }
 

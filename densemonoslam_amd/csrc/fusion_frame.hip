@@ -63,7 +63,7 @@ int odometry_enable_ring(dms_odometry* o);
 void odometry_set_early_exit(dms_odometry* o, int on);
 int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth);
 struct LoopState;
-int odometry_loop_candidate(dms_odometry* o, const FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
+int odometry_loop_candidate(dms_odometry* o, FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
                             LoopState* out, float* cons, hipStream_t s);
 // nid.hip
 size_t nid_workspace_bytes(int num_bins);
@@ -170,6 +170,8 @@ struct dms_fusion {
   dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
   hipStream_t s_prep = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr}, ev_inputs = nullptr;
+  bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
+  int last_prep = -1;         // image set whose ev_prep_done marks the end of the last enqueued ingest
   long frames = 0;  // frames enqueued so far
   // NID key-framing (fuseFrame): candidate key frame of the current prediction, per pyramid level
   dms_image2d kf_img[DMS_NUM_PYRS], kf_dmap[DMS_NUM_PYRS], kf_old_img[DMS_NUM_PYRS], kf_old_dmap[DMS_NUM_PYRS];
@@ -194,6 +196,7 @@ struct dms_fusion {
   FrameState* h_state_dev = nullptr;  // device view of h_state
   FrameState* h_state = nullptr;  // pinned, two slots by frame parity (the host may read a slot once that frame's event has completed)
   int last_slot = 0;
+  int timeouts_reported = 0;  // value of FrameState::track_timeouts the caller has been told about
   void* h_track = nullptr;
   int tick = 1;
   bool map_initialised = false;
@@ -436,12 +439,15 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->nid_pyramid_level = 0;
   p->local_loop_closure = 0;
   p->reloc = 0;
+  p->num_sensors = 3;       // NUM_CAMERAS (Shaders/size.glsl:2)
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   DMS_REQUIRE(out && p, "null argument");
   DMS_REQUIRE(p->width >= 40 && p->height >= 40, "resolution too small");
   DMS_REQUIRE(p->timeIdx >= 0 && p->timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  DMS_REQUIRE(p->num_sensors >= 0 && p->num_sensors <= DMS_MAX_SENSORS, "num_sensors out of range");
+  DMS_REQUIRE(p->num_sensors == 0 || p->timeIdx < p->num_sensors, "timeIdx must be one of the num_sensors time slots");
   DMS_REQUIRE(!p->nid_keyframing || (p->nid_bins_img >= 1 && p->nid_bins_img <= 256 && p->nid_bins_depth >= 1 && p->nid_bins_depth <= 4096 &&
                                      p->nid_pyramid_level >= 0 && p->nid_pyramid_level < DMS_NUM_PYRS),
               "bad NID key-framing parameters");
@@ -451,11 +457,13 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   f->cam.fy = p->fy;
   f->cam.cx = p->cx;
   f->cam.cy = p->cy;
+  if (f->p.num_sensors == 0) f->p.num_sensors = 3;  // (a zero-initialised params block of an older caller)
   int rc = dms_model_create(&f->model, p->model_capacity, p->width, p->height);
   if (rc) {
     delete f;
     return rc;
   }
+  (void)dms_model_set_num_sensors(f->model, f->p.num_sensors);
   rc = dms_odometry_create(&f->odom, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
   if (rc) {
     dms_model_destroy(f->model);
@@ -534,6 +542,24 @@ int dms_fusion_destroy(dms_fusion* f) {
   return DMS_OK;
 }
 
+int dms_fusion_inputs_ready(dms_fusion* f, dms_stream producer) {
+  DMS_REQUIRE(f, "null argument");
+  if (!f->p.pipeline_ingest) return DMS_OK;  // everything runs on the caller's stream: plain stream order applies
+  DMS_HIP(hipEventRecord(f->ev_inputs, (hipStream_t)producer));
+  f->inputs_armed = true;
+  return DMS_OK;
+}
+
+int dms_fusion_inputs_consumed(dms_fusion* f, dms_stream st) {
+  DMS_REQUIRE(f, "null argument");
+  if (f->p.pipeline_ingest) {
+    if (f->last_prep >= 0) DMS_HIP(hipEventSynchronize(f->ev_prep_done[f->last_prep]));
+  } else {
+    DMS_HIP(hipStreamSynchronize((hipStream_t)st));
+  }
+  return DMS_OK;
+}
+
 dms_model* dms_fusion_model(dms_fusion* f) { return f ? f->model : nullptr; }
 dms_odometry* dms_fusion_odometry(dms_fusion* f) { return f ? f->odom : nullptr; }
 
@@ -554,21 +580,30 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   const int k2 = (int)(f->frames % 2), k3 = (int)(f->frames % 3), k3prev = (int)((f->frames + 2) % 3);
   hipStream_t sp = f->p.pipeline_ingest ? f->s_prep : s;
   if (f->p.pipeline_ingest) {
+    // The ingest below reads rgb_dev / depth_dev on the prep stream.  Inputs produced asynchronously (an async upload, a
+    // decode kernel) are declared with dms_fusion_inputs_ready(f, producer_stream): the prep stream then waits for that
+    // point of the producer stream.  (Waiting on the caller's stream `s` unconditionally would put this frame's ingest
+    // behind the previous frame's tracking and fusion, which is exactly the overlap the prep stream exists for.)
+    if (f->inputs_armed) {
+      DMS_HIP(hipStreamWaitEvent(sp, f->ev_inputs, 0));
+      f->inputs_armed = false;
+    }
     // Bounded run-ahead: at most two frames are in flight.  The host blocks here until frame-2 has
     // finished (normally long ago).  Besides protecting the double-buffered images this keeps the
     // HIP command queues short: with the host many frames ahead the runtime's queue-full handling
     // was measured to cost ~10% throughput.
     DMS_HIP(hipEventSynchronize(f->ev_main_done[k2]));
     DMS_HIP(hipStreamWaitEvent(sp, f->ev_main_done[k2], 0));  // frame-2 (never recorded: no-op)
-    // frame-2 is complete, so its result block (pinned slot k2) is readable: tighten the host-side
-    // bound of the surfel count (launch grids are sized from it).  One clean has run since then
-    // (frame-1) and adds at most `slots` surfels.
-    if (f->model->count_hold > 0) {
-      f->model->count_hold -= 1;
-    } else if (f->frames >= 2 && f->map_initialised) {
-      const size_t known = (size_t)f->h_state[k2].surfels + (size_t)f->model->slots;
-      if (known < f->model->count_upper) f->model->count_upper = known;
-    }
+  }
+  // frame-2's result block (pinned slot k2) is readable once its completion event has passed — always here with the
+  // pipeline (the host has just waited for it), usually here without it: tighten the host-side bound of the surfel
+  // count that launch grids are sized from.  One clean has run since then (frame-1) and adds at most `slots` surfels.
+  // Without this the bound grows by `slots` per frame until it reaches the capacity.
+  if (f->model->count_hold > 0) {
+    f->model->count_hold -= 1;
+  } else if (f->frames >= 2 && f->map_initialised && (f->p.pipeline_ingest || hipEventQuery(f->ev_main_done[k2]) == hipSuccess)) {
+    const size_t known = (size_t)f->h_state[k2].surfels + (size_t)f->model->slots;
+    if (known < f->model->count_upper) f->model->count_upper = known;
   }
   f->rgba = f->live[k2].rgba;
   f->depth_raw = f->live[k2].depth_raw;
@@ -606,6 +641,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   if (f->p.pipeline_ingest) {
     DMS_HIP(hipEventRecord(f->ev_prep_done[k2], sp));
     DMS_HIP(hipStreamWaitEvent(s, f->ev_prep_done[k2], 0));
+    f->last_prep = k2;
   }
 
   Pose16 prior;
@@ -833,7 +869,7 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
   // finalPredict (ElasticFusion.cpp:586); its fill-in kernel mirrors the result block to the host slot
   if ((rc = predict(f, f->p.confidence, s, f->h_state_dev + k2))) return rc;
   f->last_slot = k2;
-  if (f->p.pipeline_ingest) DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));
+  DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));  // (also without the pipeline: it gates the reading of this frame's result slot)
   f->fused_last = fused;
   if (!f->lost) f->tick += 1;  // ElasticFusion.cpp:588-591
   f->frames += 1;
@@ -845,6 +881,20 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
   int rc = dms_fusion_process_frame_begin(f, rgb_dev, rgb_channels, depth_dev, inPose16, weightMultiplier, st);
   if (rc) return rc;
   return dms_fusion_process_frame_end(f, nullptr, 0, nullptr, st);
+}
+
+// Sticky tracker-timeout report: FrameState::track_timeouts counts the frames whose resident tracker kernels gave up at
+// a grid barrier (those frames kept their prior pose and fused nothing).  Any fetch that sees the counter move says so,
+// whichever frame it happened in.
+static int report_timeouts(dms_fusion* f, const FrameState* hs) {
+  if (hs->track_timeouts == f->timeouts_reported) return DMS_OK;
+  const int n = hs->track_timeouts - f->timeouts_reported;
+  f->timeouts_reported = hs->track_timeouts;
+  set_error("dms_fusion: %d frame(s) since the last fetch had a resident tracker kernel time out at a grid barrier (its blocks were not "
+            "all resident: another process on this GPU?); those frames kept their prior pose and were not fused.  "
+            "DMS_TRACK_MODE=launches avoids resident kernels",
+            n);
+  return DMS_ERR_TIMEOUT;
 }
 
 static void fill_loop(const dms_fusion* f, dms_frame_result* r) {
@@ -873,7 +923,7 @@ int dms_fusion_fetch_loop(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   r->weighting = hs->weighting;
   r->nid_score = f->last_nid;
   fill_loop(f, r);
-  return DMS_OK;
+  return report_timeouts(f, hs);
 }
 
 int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
@@ -883,7 +933,7 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   int rc = DMS_OK;
   if (f->p.hybrid_tracking && f->tick > 2) {
     rc = dms_odometry_fetch_result(f->odom, &r->track, s);  // syncs
-    if (rc) return rc;
+    if (rc && rc != DMS_ERR_TIMEOUT) return rc;  // (a timeout of the last frame is reported below with every other one)
   } else {
     DMS_HIP(hipStreamSynchronize(s));
   }
@@ -902,9 +952,10 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
     // the reference asserts on this (GlobalModel.cpp:703); here the kernels stop appending at the
     // capacity, nothing is overwritten, and the caller is told (the result above is still valid)
     set_error("dms_fusion_fetch: the map has reached its capacity of %zu surfels; new surfels are being dropped", f->model->cap);
+    (void)report_timeouts(f, hs);
     return DMS_ERR_CAPACITY;
   }
-  return DMS_OK;
+  return report_timeouts(f, hs);
 }
 
 int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream st) {

@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
            !(a.dr[(size_t)sy * a.cols + sxf] == 0.f) && !(a.dr[(size_t)syf * a.cols + sx] == 0.f);
     }
     ok = ok && vPosLocal.z > 0.f && vPosLocal.z <= a.maxDepth;
+    // a negative device-side weight marks a frame whose tracker result is invalid (grid-barrier timeout,
+    // frame_after_track_body): nothing is measured, so nothing merges and nothing is appended
+    const float weighting = a.weighting_dev ? *a.weighting_dev : a.weighting;
+    ok = ok && !(weighting < 0.f);
     if (ok) {
       const float* P = a.pose->pose;
       const f3 vPos = xform_point(P, vPosLocal);
@@ -110,7 +114,6 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
       const f3 vNormLocal = dv_normal(a.drf, a.cols, a.rows, vPos_f, tx, ty, x, y, a.cx, a.cy, a.icx, a.icy);
       const f3 nG = xform_dir(P, vNormLocal);
       const float rad = surfel_radius(vPos_f.z, vNormLocal.z, a.icx, a.icy);
-      const float weighting = a.weighting_dev ? *a.weighting_dev : a.weighting;
       const float conf = surfel_confidence(x, y, a.cx, a.cy, weighting);
 
       // 4×4-tap association window in the index map (data.vert:116-160)
@@ -239,6 +242,7 @@ struct CleanArgs {
   int nslots;
   int transposed;
   int suffix;  // large maps: surfels in the leading run of untouched blocks stay where they are (see model_clean)
+  int num_sensors;  // vTimes.length() of copy_unstable.vert: the reference's NUM_CAMERAS = 3 (size.glsl:2), <= DMS_MAX_SENSORS
 };
 
 // plain aggregates (HIP's float4 is a class with a union inside: as a member of the element it keeps
@@ -352,16 +356,17 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
   if (count > 8 || zCount > 4) test = 0;
   // new unstable point: times become `time` before the health test (copy_unstable.vert:124-129)
   const float vt2 = (vt == -2.f) ? (float)a.time : vt;
-  // "unhealthy for every sensor".  The reference loops over its NUM_CAMERAS = 3 slots
-  // (size.glsl:2); slots beyond the reference's three are extra sensors of the 8-GPU node and
-  // follow the same rule.
+  // "unhealthy for every sensor" (copy_unstable.vert:137-150): the loop runs over vTimes.length() = NUM_CAMERAS
+  // slots (3 in the reference, size.glsl:2).  The map stores DMS_MAX_SENSORS slots; only the first
+  // a.num_sensors take part — an unused slot holds -3 and would otherwise count as healthy during the
+  // first 17 ticks, keeping surfels the reference removes.
   int unHealthy = 0;
 #pragma unroll
   for (int s = 0; s < DMS_MAX_SENSORS; ++s) {
     const float ts = (s == a.timeIdx) ? vt2 : v.times[s];
-    if (ts == -1.f || (((float)a.time - ts) > 20.f && v.pos.w < a.confThreshold)) unHealthy++;
+    if (s < a.num_sensors && (ts == -1.f || (((float)a.time - ts) > 20.f && v.pos.w < a.confThreshold))) unHealthy++;
   }
-  if (unHealthy == DMS_MAX_SENSORS) test = 0;
+  if (unHealthy == a.num_sensors) test = 0;
   if (vt2 > 0.f && (float)a.time - vt2 > (float)a.timeDelta) test = 1;
   return test;
 }
@@ -738,11 +743,10 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   a.transposed = transposed ? 1 : 0;
   const size_t upper = m->count_upper + (size_t)m->slots;
   const int nb = (int)((upper + kScanChunk - 1) / kScanChunk);
-  // suffix mode pays one more launch: worth it once the map is large (DMS_CLEAN_SUFFIX_MIN overrides the size)
-  const char* smin = getenv("DMS_CLEAN_SUFFIX_MIN");  // read per call: tests switch it inside one process
-  const size_t suffix_min = smin ? (size_t)atoll(smin) : ((size_t)1 << 20);
-  const bool suffix = graph_nodes == 0 && upper >= suffix_min;
+  // suffix mode pays one more launch: worth it once the map is large
+  const bool suffix = graph_nodes == 0 && upper >= m->clean_suffix_min;  // (switch: dms_model_set_clean_suffix_min)
   a.suffix = suffix ? 1 : 0;
+  a.num_sensors = m->num_sensors;
   const SurfelPlanes src = m->buf[m->cur], dst = m->buf[m->cur ^ 1];
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_count, suffix ? m->clean_first : (unsigned*)nullptr);

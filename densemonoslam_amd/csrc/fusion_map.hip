@@ -96,7 +96,21 @@ int dms_model_create(dms_model** out, size_t capacity, int width, int height) {
   DMS_CHECK_LAUNCH();
   DMS_HIP(hipDeviceSynchronize());
   m->count_upper = 0;
+  if (const char* smin = getenv("DMS_CLEAN_SUFFIX_MIN")) m->clean_suffix_min = (size_t)atoll(smin);  // once, at creation
   *out = m;
+  return DMS_OK;
+}
+
+int dms_model_set_num_sensors(dms_model* m, int num_sensors) {
+  DMS_REQUIRE(m, "null argument");
+  DMS_REQUIRE(num_sensors >= 1 && num_sensors <= DMS_MAX_SENSORS, "num_sensors out of range");
+  m->num_sensors = num_sensors;
+  return DMS_OK;
+}
+
+int dms_model_set_clean_suffix_min(dms_model* m, size_t surfels) {
+  DMS_REQUIRE(m, "null argument");
+  m->clean_suffix_min = surfels;
   return DMS_OK;
 }
 
@@ -109,6 +123,7 @@ int dms_model_destroy(dms_model* m) {
 }
 
 size_t dms_model_capacity(dms_model* m) { return m ? m->cap : 0; }
+size_t dms_model_count_bound(dms_model* m) { return m ? m->count_upper : 0; }
 
 int dms_model_count(dms_model* m, unsigned int* count, dms_stream s) {
   DMS_REQUIRE(m && count, "null argument");
@@ -605,6 +620,14 @@ __global__ __launch_bounds__(256) void k_export_records(SurfelPlanes src, size_t
   if (blockIdx.x == 0 && threadIdx.x == 0) written[0] = n;
 }
 
+// exact device count -> host bound (synchronises `s`)
+static int refresh_count(dms_model* m, hipStream_t s) {
+  DMS_HIP(hipMemcpyAsync(m->h_count, m->d_count, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  m->count_upper = m->h_count[0];
+  return DMS_OK;
+}
+
 static int consume_finish(dms_model* m, size_t added_upper) {
   std::swap(m->d_count, m->d_count_alt);  // the kernel wrote the new count into the other cell
   const size_t upper = m->count_upper + added_upper;
@@ -616,7 +639,13 @@ static int consume_finish(dms_model* m, size_t added_upper) {
 int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStream_t s) {
   DMS_REQUIRE(dst && src && T16 && dst != src, "bad argument");
   if (dst->count_upper + src->count_upper > dst->cap) {
-    set_error("dms_model_consume: %zu + %zu surfels may exceed the capacity %zu", dst->count_upper, src->count_upper, dst->cap);
+    // the host-side bounds are loose (they grow by a frame's worth of slots per clean): read the exact counts before refusing
+    int rc = refresh_count(dst, s);
+    if (!rc) rc = refresh_count(const_cast<dms_model*>(src), s);
+    if (rc) return rc;
+  }
+  if (dst->count_upper + src->count_upper > dst->cap) {
+    set_error("dms_model_consume: %zu + %zu surfels exceed the capacity %zu", dst->count_upper, src->count_upper, dst->cap);
     return DMS_ERR_CAPACITY;
   }
   Pose16v T;
@@ -631,7 +660,11 @@ int model_consume_records(dms_model* dst, const float* rec_dev, unsigned n, cons
   DMS_REQUIRE(dst && T16 && (rec_dev || n == 0), "bad argument");
   DMS_REQUIRE(((uintptr_t)rec_dev & 15) == 0, "record buffer must be 16-byte aligned");
   if (dst->count_upper + n > dst->cap) {
-    set_error("dms_model_consume_records: %zu + %u surfels may exceed the capacity %zu", dst->count_upper, n, dst->cap);
+    const int rc = refresh_count(dst, s);  // loose bound: read the exact count before refusing
+    if (rc) return rc;
+  }
+  if (dst->count_upper + n > dst->cap) {
+    set_error("dms_model_consume_records: %zu + %u surfels exceed the capacity %zu", dst->count_upper, n, dst->cap);
     return DMS_ERR_CAPACITY;
   }
   Pose16v T;

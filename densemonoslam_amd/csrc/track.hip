@@ -80,6 +80,14 @@ using namespace dms;
 
 struct dms_odometry {
   bool early_exit = false;  // use the resident kernels that leave a level after an iteration without any correspondence
+  // Execution switches, fixed per handle: read from the environment once, at dms_odometry_create (DMS_TRACK_MODE,
+  // DMS_SUMS, DMS_TRACK_EARLY_EXIT, DMS_PERSIST_BLOCKS), changed only through dms_odometry_set_mode.  (Reading them at
+  // every call let a changing environment switch the sum order in the middle of a session.)
+  bool resident = true;       // false: three launches per iteration (DMS_TRACK_MODE=launches)
+  bool fp64_sums = false;     // block sums and records in fp64 (DMS_SUMS=fp64)
+  int early_exit_force = -1;  // -1: as `early_exit`; 0 / 1: forced (DMS_TRACK_EARLY_EXIT)
+  int persist_target = 96;    // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
+  int inject_timeouts = 0;    // dms_odometry_inject_timeout: calls left that start with the timeout flag set
   int width, height;
   float cx, cy, fx, fy, distThres, angleThres;
   float sobelScale, maxDepthDeltaRGB, maxDepthRGB;
@@ -176,7 +184,7 @@ struct Prior {
 };
 
 __global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
-                             int so3, int first_level, unsigned long long* sync_words, int n_sync) {
+                             int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout) {
   // barrier words of the persistent kernels of this call: zero before any of them is launched
   for (int i = threadIdx.x; i < n_sync; i += blockDim.x)
     __hip_atomic_store(sync_words + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -204,7 +212,7 @@ __global__ void k_track_init(TrackState* st, Prior prior, const float* __restric
     st->iters_run[l] = 0;
   }
   st->rejected_jump = 0;
-  st->sync_timeout = 0;
+  st->sync_timeout = inject_timeout;  // (0 unless a test injects the fault)
   for (int i = 0; i < 36; ++i) st->lastA[i] = 0.0;
   for (int i = 0; i < 6; ++i) st->lastb[i] = 0.0;
   double K[9];
@@ -1437,10 +1445,13 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       for (int i = 0; i < 9; ++i) Rc[i] = s.Rcurr[i];
       const float dx = tc[0] - s.tprev[0], dy = tc[1] - s.tprev[1], dz = tc[2] - s.tprev[2];
       const float n = sqrtf(dx * dx + dy * dy + dz * dz);
-      if (L.fin_rgb && (double)n > 0.3) {  // RGBDOdometry.cpp:589-593
+      // a grid-barrier timeout anywhere in this call (sticky flag, set before the waiting block gave up) leaves sums
+      // that are not the sums of the image: the prior pose is kept and the frame step fuses nothing
+      const bool timed_out = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (timed_out || (L.fin_rgb && (double)n > 0.3)) {  // RGBDOdometry.cpp:589-593
         for (int i = 0; i < 9; ++i) Rc[i] = st->Rcurr[i] = s.Rprev[i];
         for (int i = 0; i < 3; ++i) tc[i] = st->tcurr[i] = s.tprev[i];
-        st->rejected_jump = 1;
+        if (!timed_out) st->rejected_jump = 1;
       }
       for (int i = 0; i < 3; ++i) st->out_trans[i] = tc[i];
       for (int i = 0; i < 9; ++i) st->out_rot[i] = Rc[i];
@@ -1454,7 +1465,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         L.pose16_out[14] = 0.f;
         L.pose16_out[15] = 1.f;
       }
-      if (L.frame) frame_after_track_body(L.frame, L.weightMultiplier);
+      if (L.frame) frame_after_track_body(L.frame, L.weightMultiplier, timed_out);
     }
   }
   phase(8);
@@ -1551,10 +1562,11 @@ __global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ po
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
   const float n = sqrtf(dx * dx + dy * dy + dz * dz);
-  if (rgb && (double)n > 0.3) {  // RGBDOdometry.cpp:589-593
+  const bool timed_out = st->sync_timeout != 0;  // (see the finalize step of k_gn_level)
+  if (timed_out || (rgb && (double)n > 0.3)) {  // RGBDOdometry.cpp:589-593
     for (int i = 0; i < 9; ++i) st->Rcurr[i] = st->Rprev[i];
     for (int i = 0; i < 3; ++i) st->tcurr[i] = st->tprev[i];
-    st->rejected_jump = 1;
+    if (!timed_out) st->rejected_jump = 1;
   }
   for (int i = 0; i < 3; ++i) st->out_trans[i] = st->tcurr[i];
   for (int i = 0; i < 9; ++i) st->out_rot[i] = st->Rcurr[i];
@@ -1570,7 +1582,7 @@ __global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ po
   }
   // frame step: pose16_out is frame->cur.pose; derive its inverse and the velocity weight here
   // instead of in a launch of their own
-  if (frame) frame_after_track_body(frame, weightMultiplier);
+  if (frame) frame_after_track_body(frame, weightMultiplier, timed_out);
 }
 
 }  // namespace dms
@@ -1764,7 +1776,31 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
   }
   memset(o->host_state, 0, sizeof(TrackState));
+  {  // execution switches: the environment is consulted here and nowhere else
+    const char* e = getenv("DMS_TRACK_MODE");
+    o->resident = !(e && strcmp(e, "launches") == 0);
+    e = getenv("DMS_SUMS");
+    o->fp64_sums = e && strcmp(e, "fp64") == 0;
+    e = getenv("DMS_TRACK_EARLY_EXIT");
+    o->early_exit_force = e ? (e[0] != '0' ? 1 : 0) : -1;
+    e = getenv("DMS_PERSIST_BLOCKS");
+    if (e && atoi(e) > 0) o->persist_target = atoi(e);
+  }
   *out = o;
+  return DMS_OK;
+}
+
+int dms_odometry_inject_timeout(dms_odometry* o, int calls) {
+  DMS_REQUIRE(o && calls >= 0, "bad argument");
+  o->inject_timeouts = calls;
+  return DMS_OK;
+}
+
+int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit) {
+  DMS_REQUIRE(o, "null argument");
+  if (resident >= 0) o->resident = resident != 0;
+  if (fp64_sums >= 0) o->fp64_sums = fp64_sums != 0;
+  o->early_exit_force = early_exit < 0 ? -1 : (early_exit ? 1 : 0);
   return DMS_OK;
 }
 
@@ -1897,18 +1933,13 @@ int dms_odometry_track_async(dms_odometry* o, const float* trans, const float* r
 namespace dms {
 
 // ---- persistent level kernels: launch shape and cross-stream serialisation ----
-// DMS_TRACK_MODE=launches forces the three-launches-per-iteration path (A/B runs, fallback).
-static bool persistent_enabled() {  // read per call: tests switch modes inside one process
-  const char* e = getenv("DMS_TRACK_MODE");
-  return !(e && strcmp(e, "launches") == 0);
-}
+// dms_odometry::resident = false (DMS_TRACK_MODE=launches at creation) selects the three-launches-per-iteration path.
 
 // pixels per thread (1 or 2) and grid of k_gn_level for an n-pixel level; 0 blocks = not eligible
-static void persistent_shape(int n, int& P, int& nb) {
+static void persistent_shape(int n, int target, int& P, int& nb) {
   // 1 or 2 pixels per thread if that keeps the grid at <= 96 blocks (cheap barriers and gathers win
   // on the small levels); otherwise 3 pixels per thread on up to 256 blocks (the full-resolution
   // level is bound by its per-CU arithmetic: measured 221 us at 200 blocks vs 230 us at 150), else 4
-  static const int target = getenv("DMS_PERSIST_BLOCKS") ? atoi(getenv("DMS_PERSIST_BLOCKS")) : 96;
   auto blocks = [&](int p) { return (n + kPB * p - 1) / (kPB * p); };
   if (blocks(1) <= target)
     P = 1;
@@ -1952,11 +1983,7 @@ struct PersistSection {
   }
 };
 
-// DMS_SUMS=fp64: block sums and records in fp64 (tighter agreement with an fp64 accumulation, ~3 % slower)
-static bool sums_fp64() {  // read per call: tests switch it inside one process
-  const char* e = getenv("DMS_SUMS");
-  return e && strcmp(e, "fp64") == 0;
-}
+// dms_odometry::fp64_sums: block sums and records in fp64 (tighter agreement with an fp64 accumulation, ~3 % slower)
 
 template <bool ICP, bool RGB, bool F64, bool EXIT>
 static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
@@ -1970,8 +1997,8 @@ static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, cons
     hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
 }
 template <bool ICP, bool RGB>
-static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
-  if (sums_fp64())
+static void launch_gn_level(bool fp64_sums, int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
+  if (fp64_sums)
     launch_gn_level_f<ICP, RGB, true, true>(P, nb, s, st, a, L);  // (the precise variant always carries the exit)
   else if (L.early_exit)
     launch_gn_level_f<ICP, RGB, false, true>(P, nb, s, st, a, L);
@@ -2013,8 +2040,9 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   {
     Timer t(o, s, "track_init");
     hipLaunchKernelGGL(k_track_init, dim3(1), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
-                       first_level, o->sync, kSyncWords);
+                       first_level, o->sync, kSyncWords, o->inject_timeouts > 0 ? 1 : 0);
     DMS_CHECK_LAUNCH();
+    if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
   }
 
   PersistSection persist(s);
@@ -2024,11 +2052,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     const Buf& ni = o->nextImage[L];
     const int nb = reduce_blocks_for(li.rows * li.cols);
     const int nbp = (li.rows * li.cols + kPB - 1) / kPB;
-    if (persistent_enabled() && nbp <= kMaxPersistBlocks) {
+    if (o->resident && nbp <= kMaxPersistBlocks) {
       persist.begin();
       Timer t(o, s, "so3_level");
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
-      if (sums_fp64())
+      if (o->fp64_sums)
         hipLaunchKernelGGL(k_so3_level<true>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
                            (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, cam, first_level, 10);
       else
@@ -2051,7 +2079,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   bool finalized_in_kernel = false;
   for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
     int pP = 1, pnb = 0;
-    if (persistent_enabled() && iterations[l] <= 10) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), pP, pnb);
+    if (o->resident && iterations[l] <= 10) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, pP, pnb);
     const bool persistent = pnb > 0;
     if (rgb && !persistent) {  // the persistent kernel rebuilds the cloud point from lastDepth itself
       dms_camera k = {o->fx, o->fy, o->cx, o->cy};
@@ -2120,11 +2148,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.rec = o->rec;
       L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
       L.prof = o->profiling ? o->prof : nullptr;
-      {
-        // on for trackers that ask for it (the frame step's model-to-model pass); DMS_TRACK_EARLY_EXIT=1 / 0 forces it
-        const char* ee = getenv("DMS_TRACK_EARLY_EXIT");
-        L.early_exit = ee ? (ee[0] != '0') : (o->early_exit ? 1 : 0);
-      }
+      // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
+      L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
       L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
       L.fin_rgb = rgb ? 1 : 0;
       L.pose16_out = frame ? const_cast<float*>(prior_pose16_dev) : nullptr;
@@ -2135,11 +2160,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
       Timer t(o, s, kLevelTimer[l]);
       if (icp && rgb)
-        launch_gn_level<true, true>(pP, pnb, s, o->state, a, L);
+        launch_gn_level<true, true>(o->fp64_sums, pP, pnb, s, o->state, a, L);
       else if (icp)
-        launch_gn_level<true, false>(pP, pnb, s, o->state, a, L);
+        launch_gn_level<true, false>(o->fp64_sums, pP, pnb, s, o->state, a, L);
       else
-        launch_gn_level<false, true>(pP, pnb, s, o->state, a, L);
+        launch_gn_level<false, true>(o->fp64_sums, pP, pnb, s, o->state, a, L);
       DMS_CHECK_LAUNCH();
       continue;
     }
@@ -2227,7 +2252,7 @@ int odometry_result_pose(dms_odometry* o, float* pose16_dev, hipStream_t s) {
 // W/20 x H/20 nearest-neighbour grid of the ACTIVE vertex map and the INACTIVE time map
 // (Resize::vertex / Resize::time, :443-444) and compacts the surface constraints in the reference's
 // order (columns outer, rows inner, :446-447).
-__global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __restrict__ st, const FrameState* __restrict__ frame,
+__global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __restrict__ st, FrameState* __restrict__ frame,
                                                         const float4* __restrict__ vertex, const unsigned short* __restrict__ oldTime,
                                                         int cols, int rows, float maxDepth, LoopState* __restrict__ out,
                                                         float* __restrict__ cons) {
@@ -2268,7 +2293,9 @@ __global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __rest
       out->cov_diag[i] = cii;
       if (cii > 8e-05) covOk = false;
     }
-    const int ok = (covOk && st->lastICPCount > 15000.f && st->lastICPError < 0.0003f) ? 1 : 0;
+    const bool timed_out = st->sync_timeout != 0;  // model-to-model pass invalid: no candidate, counted like a tracker timeout
+    if (timed_out) frame->track_timeouts += 1;
+    const int ok = (!timed_out && covOk && st->lastICPCount > 15000.f && st->lastICPError < 0.0003f) ? 1 : 0;
     out->ok = ok;
     out->icp_error = st->lastICPError;
     out->icp_count = st->lastICPCount;
@@ -2324,7 +2351,7 @@ __global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __rest
   if (threadIdx.x == 0) out->n_constraints = s_base;
 }
 
-int odometry_loop_candidate(dms_odometry* o, const FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
+int odometry_loop_candidate(dms_odometry* o, FrameState* frame, const dms_image2d* vertex, const dms_image2d* oldTime, float maxDepth,
                             LoopState* out, float* cons, hipStream_t s) {
   hipLaunchKernelGGL(k_loop_candidate, dim3(1), dim3(256), 0, s, o->state, frame, (const float4*)vertex->data,
                      (const unsigned short*)oldTime->data, vertex->cols, vertex->rows, maxDepth, out, cons);

@@ -38,7 +38,7 @@ class FusionParams(C.Structure):
         ("pipeline_ingest", C.c_int), ("global_predict", C.c_int),
         ("nid_keyframing", C.c_int), ("nid_threshold", C.c_float), ("nid_depth_lambda", C.c_float), ("nid_bins_img", C.c_int),
         ("nid_bins_depth", C.c_int), ("nid_pyramid_level", C.c_int),
-        ("local_loop_closure", C.c_int), ("reloc", C.c_int),
+        ("local_loop_closure", C.c_int), ("reloc", C.c_int), ("num_sensors", C.c_int),
     ]
 
 
@@ -59,6 +59,8 @@ lib.dms_model_create.argtypes = [C.POINTER(_P), C.c_size_t, _I, _I]
 lib.dms_model_destroy.argtypes = [_P]
 lib.dms_model_count.argtypes = [_P, C.POINTER(C.c_uint), _P]
 lib.dms_model_capacity.argtypes = [_P]
+lib.dms_model_set_num_sensors.argtypes = [_P, _I]
+lib.dms_model_set_clean_suffix_min.argtypes = [_P, C.c_size_t]
 lib.dms_model_consume.argtypes = [_P, _P, C.POINTER(C.c_float), _P]
 lib.dms_model_export_records.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_uint), _P]
 lib.dms_model_consume_records.argtypes = [_P, _P, C.c_uint, C.POINTER(C.c_float), _P]
@@ -84,6 +86,8 @@ lib.dms_fusion_create.argtypes = [C.POINTER(_P), C.POINTER(FusionParams)]
 lib.dms_fusion_destroy.argtypes = [_P]
 lib.dms_fusion_process_frame.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_float), _F, _P]
 lib.dms_fusion_fetch.argtypes = [_P, C.POINTER(FrameResult), _P]
+lib.dms_fusion_inputs_ready.argtypes = [_P, _P]
+lib.dms_fusion_inputs_consumed.argtypes = [_P, _P]
 lib.dms_fusion_model.argtypes = [_P]
 lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
@@ -200,6 +204,12 @@ class GlobalModel:
             self.close()
         except Exception:
             pass
+
+    def setNumSensors(self, n):
+        check(lib.dms_model_set_num_sensors(self.h, int(n)), "dms_model_set_num_sensors")
+
+    def setCleanSuffixMin(self, n):
+        check(lib.dms_model_set_clean_suffix_min(self.h, int(n)), "dms_model_set_clean_suffix_min")
 
     def lastCount(self):
         n = C.c_uint(0)
@@ -358,11 +368,17 @@ class ElasticFusion:
         except Exception:
             pass
 
-    def upload_frame(self, rgb, depth):
+    def upload_frame(self, rgb, depth, stream=None):
+        # the previous frame's ingest (internal prep stream) may not have read the staging buffers yet
+        check(lib.dms_fusion_inputs_consumed(self.h, stream), "dms_fusion_inputs_consumed")
         rgb = np.ascontiguousarray(rgb, np.uint8)
         self._rgb.upload(rgb)
         self._depth.upload(np.ascontiguousarray(depth, np.uint16))
         return rgb.shape[2]
+
+    def inputsReady(self, producer_stream=None):
+        """The next frame's input buffers are produced by work enqueued on `producer_stream` so far."""
+        check(lib.dms_fusion_inputs_ready(self.h, producer_stream), "dms_fusion_inputs_ready")
 
     def processFrameAsync(self, rgb_ptr, channels, depth_ptr, inPose=None, weightMultiplier=1.0, stream=None):
         pp = None
@@ -373,7 +389,7 @@ class ElasticFusion:
               "dms_fusion_process_frame")
 
     def processFrameBegin(self, rgb, depth, inPose=None, weightMultiplier=1.0, stream=None):
-        ch = self.upload_frame(rgb, depth)
+        ch = self.upload_frame(rgb, depth, stream)
         pp = None
         if inPose is not None:
             self._pose = np.ascontiguousarray(inPose, np.float32).reshape(16)
@@ -400,6 +416,14 @@ class ElasticFusion:
         r = FrameResult()
         check(lib.dms_fusion_fetch(self.h, C.byref(r), stream), "dms_fusion_fetch")
         return r
+
+    def fetch_rc(self, stream=None):
+        """(status, result): like fetch, but hands DMS_ERR_CAPACITY / DMS_ERR_TIMEOUT back with the (valid) result."""
+        r = FrameResult()
+        return int(lib.dms_fusion_fetch(self.h, C.byref(r), stream)), r
+
+    def odometryHandle(self):
+        return C.c_void_p(lib.dms_fusion_odometry(self.h))
 
     def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0):
         ch = self.upload_frame(rgb, depth)

@@ -222,6 +222,16 @@ typedef struct dms_odometry dms_odometry;
 int dms_odometry_create(dms_odometry** out, int width, int height, float cx, float cy,
                         float fx, float fy, float distThresh, float angleThresh);
 int dms_odometry_destroy(dms_odometry* o);
+/* Execution switches of one tracker (no reference counterpart).  They are read from the environment ONCE, when the
+ * handle is created — DMS_TRACK_MODE=launches, DMS_SUMS=fp64, DMS_TRACK_EARLY_EXIT=0|1 — and changed only here:
+ *   resident    1 = one resident kernel per pyramid level (default), 0 = three launches per iteration; -1 = keep
+ *   fp64_sums   1 = block sums and records in fp64, 0 = fp32 wave sums (default); -1 = keep
+ *   early_exit  1 / 0 = force the resident-kernel variant that leaves a level after an iteration without any
+ *               correspondence on / off; -1 = the handle's default (on for the frame step's model-to-model tracker) */
+int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit);
+/* Fault injection for tests: the next `calls` tracking calls behave as if a resident kernel had timed out at a
+ * grid barrier (DMS_ERR_TIMEOUT from dms_odometry_fetch_result; the frame step keeps the prior pose and fuses nothing). */
+int dms_odometry_inject_timeout(dms_odometry* o, int calls);
 
 /* reference initICP(GPUTexture* filteredDepth, ...) (RGBDOdometry.cpp:118-142); depth = dense u16 mm */
 int dms_odometry_initICP_depth(dms_odometry* o, const dms_image2d* filteredDepth_u16,

@@ -33,8 +33,16 @@ typedef struct dms_model dms_model;
  * (reference MAX_VERTICES = 5700^2, GlobalModel.cpp:22-24). */
 int dms_model_create(dms_model** out, size_t capacity, int width, int height);
 int dms_model_destroy(dms_model* m);
+/* Number of time slots the clean's health test loops over (reference NUM_CAMERAS = 3, Shaders/size.glsl:2; default 3). */
+int dms_model_set_num_sensors(dms_model* m, int num_sensors);
+/* Map size (surfels) from which dms_model_clean compacts only the suffix behind the first removed surfel
+ * (default 2^20; the environment variable DMS_CLEAN_SUFFIX_MIN is read once, at dms_model_create). */
+int dms_model_set_clean_suffix_min(dms_model* m, size_t surfels);
 int dms_model_count(dms_model* m, unsigned int* count, dms_stream s); /* syncs */
 size_t dms_model_capacity(dms_model* m);
+/* Host-side upper bound of the surfel count (launch grids are sized from it; the exact count lives on the device,
+ * dms_model_count synchronises to read it). */
+size_t dms_model_count_bound(dms_model* m);
 
 /* reference surfel record (Shaders/Vertex.cpp:21-50): 15 floats =
  * pos.xyz conf | colour 0 initTime stamp | times[3] | normal.xyz radius (60 bytes).
@@ -203,6 +211,11 @@ typedef struct dms_fusion_params {
    * reference compiles out, :351-393: a lost camera stays lost.)  The decision is taken on the host
    * after one mid-frame synchronisation, as in the reference.  Default 0. */
   int reloc;
+  /* Number of per-surfel time slots that take part in the clean's "unhealthy for every sensor" test
+   * (copy_unstable.vert:137-150 loops over vTimes.length() = NUM_CAMERAS = 3, Shaders/size.glsl:2).
+   * Default 3 as in the reference; a node that merges more than three cameras into one map raises it
+   * (<= DMS_MAX_SENSORS); timeIdx must be < num_sensors. */
+  int num_sensors;
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
@@ -239,8 +252,25 @@ typedef struct dms_frame_result {
 int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev,
                              const float* inPose16, float weightMultiplier, dms_stream s);
 /* Returns DMS_ERR_CAPACITY (with the result filled in) once the map has reached model_capacity: the
- * kernels stop appending there instead of asserting like the reference (GlobalModel.cpp:703). */
+ * kernels stop appending there instead of asserting like the reference (GlobalModel.cpp:703).
+ * Returns DMS_ERR_TIMEOUT (result filled in) when ANY frame since the previous fetch had a resident
+ * tracker kernel give up at a grid barrier (possible only when its blocks were not all resident, e.g.
+ * a second process on the same GPU): such a frame keeps its prior pose and fuses nothing — the map is
+ * never updated from an invalid pose — and the event is counted on the device, so pipelined callers
+ * that fetch once per batch still learn about it. */
 int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream s);
+
+/* Input-buffer ordering with pipeline_ingest = 1 (the frame's ingest runs on an internal stream).
+ * Contract: rgb_dev / depth_dev are complete when process_frame[_begin] is called and stay untouched
+ * until that frame's ingest has run.  Two helpers make both halves enforceable:
+ *   dms_fusion_inputs_ready(f, producer)  the next frame's inputs are produced by work enqueued on
+ *       `producer` so far (async H2D copy, decode kernel): the ingest waits for that point.  Naming the
+ *       stream the frames run on is legal but serialises the ingest behind the previous frame.
+ *   dms_fusion_inputs_consumed(f, s)      blocks the host until the last enqueued frame's ingest has read
+ *       its input buffers (then they may be overwritten); `s` = the frames' stream (used when
+ *       pipeline_ingest = 0). */
+int dms_fusion_inputs_ready(dms_fusion* f, dms_stream producer);
+int dms_fusion_inputs_consumed(dms_fusion* f, dms_stream s);
 
 /* The same frame step in two halves, for callers that close local loops: `_begin` enqueues
  * everything up to and including the loop candidate (and takes the NID decision); the host may

@@ -315,6 +315,11 @@ def set_threads(n):
     return int(lib.orc_get_threads())
 
 
+def set_num_sensors(n):
+    """Time slots the clean's health test loops over (reference NUM_CAMERAS = 3, Shaders/size.glsl:2)."""
+    lib.orc_set_num_sensors(int(n))
+
+
 def covariance(lastA):
     a = _c(lastA, np.float64).reshape(36)
     out = np.zeros(36, np.float64)

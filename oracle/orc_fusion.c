@@ -199,6 +199,10 @@ static v3 getNormalF(const float* depth, int rows, int cols, v3 vPosition, float
 }
 
 /* ---- G3 + G4: FeedbackBuffer::compute x2 + GlobalModel::initialise ----------------------------- */
+/* time slots that take part in the clean's health test: NUM_CAMERAS of the reference (Shaders/size.glsl:2) */
+static int g_num_sensors = 3;
+void orc_set_num_sensors(int n) { g_num_sensors = n < 1 ? 1 : (n > ORC_MAX_SENSORS ? ORC_MAX_SENSORS : n); }
+
 typedef struct { float pos[4], col[4], times[ORC_MAX_SENSORS], nrm[4]; } fb_vertex;
 
 /* vertex_feedback.vert:43-75 + .geom:36-49; appends to out in column-major pixel order */
@@ -561,10 +565,11 @@ static int copy_unstable_vertex(orc_surfel* v, const float* t_inv, float cx, flo
     v->col[3] = (float)time;
     v->times[timeIdx] = (float)time;
   }
+  /* copy_unstable.vert:137-150: the loop runs over vTimes.length() = NUM_CAMERAS (3, Shaders/size.glsl:2) */
   int unHealthy = 0;
-  for (int i = 0; i < ORC_MAX_SENSORS; i++)
+  for (int i = 0; i < g_num_sensors; i++)
     if (v->times[i] == -1 || ((time - v->times[i]) > 20 && v->pos[3] < confThreshold)) unHealthy++;
-  if (unHealthy == ORC_MAX_SENSORS) test = 0;
+  if (unHealthy == g_num_sensors) test = 0;
   if (v->times[timeIdx] > 0 && time - v->times[timeIdx] > timeDelta) test = 1;
 
   if (test == 1 && nNodes > 0 && v->col[2] != time) { /* :161-351 */

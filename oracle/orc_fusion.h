@@ -40,6 +40,8 @@ void orc_fill_in(const float* exVertex, const float* exNormal, const uint8_t* ex
 void orc_resize_nn(const void* src, int srows, int scols, void* dst, int drows, int dcols, int elem);
 int orc_dense_enough(const uint8_t* image_rgba, int rows, int cols);
 float orc_velocity_weight(const float* currPose16, const float* lastPose16, float weightMultiplier);
+/* time slots in the clean's health test (copy_unstable.vert:137-150; reference NUM_CAMERAS = 3, the default) */
+void orc_set_num_sensors(int n);
 
 #ifdef __cplusplus
 }

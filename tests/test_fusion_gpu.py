@@ -320,6 +320,43 @@ def test_clean_with_deformation_graph_exact(fus, orc, boot):
     surfels_equal(gm.downloadMap(), so2, "clean with graph")
 
 
+def test_clean_health_rule_counts_the_reference_sensor_slots(fus, orc, boot):
+    """copy_unstable.vert:137-150 removes a surfel that EVERY sensor slot marks unhealthy, looping over
+    vTimes.length() = NUM_CAMERAS = 3 slots (Shaders/size.glsl:2).  The map here stores 8 slots; an unused slot holds -3
+    and is "healthy" during the first 17 ticks, so counting all 8 would keep surfels the reference removes.  Expected
+    result derived from the shader rule itself (surfels behind the camera: no window test applies), for the GPU and the
+    oracle; with num_sensors = 8 the extra slots take part and nothing is removed."""
+    _, so0, _ = boot
+    n = 4096
+    so = so0[:n].copy()
+    so["pos"][:, :3] = so["pos"][:, :3] * np.float32([1, 1, -1])  # behind the camera: localPos.z < 0, no window test
+    so["pos"][:, 3] = 1.0  # unstable (confidence below the threshold)
+    so["times"][:] = -3.0
+    so["times"][:, :3] = -1.0  # every real sensor: never seen since the merge
+    keep = np.arange(n) % 3 == 0
+    so["times"][keep, 1] = 3.0  # sensor 1 saw these two ticks ago: healthy for that sensor
+    time, timeIdx = 5, 0
+    pose = np.eye(4, dtype=np.float32)
+    expected = so[keep]
+    for sensors, want in ((3, expected), (8, so)):
+        gm = fus.GlobalModel(W, H, capacity=100000)
+        gm.setNumSensors(sensors)
+        gm.upload(so)
+        im = fus.IndexMap(W, H)
+        dp = fus.DevicePose(pose)
+        im.predictIndices(dp, time, timeIdx, gm, K, 25.0, 200)
+        io = orc.index_map(so, pose, K, H, W, time, timeIdx, 25.0, 200)
+        gm.clean(dp, time, timeIdx, im, K, 10.0, 200, 25.0)
+        orc.set_num_sensors(sensors)
+        try:
+            so2 = orc.model_clean(so, so[:0], pose, time, timeIdx, io[0], io[1], io[2], K, 10.0, 200, 25.0)
+        finally:
+            orc.set_num_sensors(3)
+        surfels_equal(so2, want, "oracle, %d sensor slots" % sensors)
+        surfels_equal(gm.downloadMap(), want, "GPU, %d sensor slots" % sensors)
+        gm.close()
+
+
 # ------------------------------------------------------------------------------------------
 # whole frame step
 # ------------------------------------------------------------------------------------------
@@ -1214,3 +1251,67 @@ def test_frame_step_api_contract(fus, synth):
     g.close()
     with pytest.raises(capi.DmsError):
         fus.ElasticFusion(W, H, K, timeIdx=99)  # out of range sensor slot
+
+
+def test_tracker_timeout_keeps_pose_skips_fusion_and_is_reported(fus, synth):
+    """A grid-barrier timeout of the resident tracker kernels (injected: dms_odometry_inject_timeout) must not reach the
+    map: the frame keeps its prior pose, fuses nothing, and the next fetch reports DMS_ERR_TIMEOUT — also when the
+    caller pipelines frames and fetches only later (the event is counted on the device)."""
+    from densemonoslam_amd.capi import lib
+
+    DMS_ERR_TIMEOUT = -6
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(5)]
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
+    for d, rgb, _ in frames[:2]:
+        r1 = g.processFrame(rgb, d)
+    pose1, n1 = np.array(r1.pose, np.float32), int(r1.surfels)
+    map1 = g.globalModel().downloadMap()
+    assert lib.dms_odometry_inject_timeout(g.odometryHandle(), 1) == 0
+    d, rgb, _ = frames[2]
+    ch = g.upload_frame(rgb, d)
+    g.processFrameAsync(g._rgb.ptr, ch, g._depth.ptr)  # the poisoned frame, not fetched on its own
+    map2 = g.globalModel().downloadMap()
+    d, rgb, _ = frames[3]
+    ch = g.upload_frame(rgb, d)
+    g.processFrameAsync(g._rgb.ptr, ch, g._depth.ptr)  # a healthy frame behind it
+    rc, r3 = g.fetch_rc()
+    assert rc == DMS_ERR_TIMEOUT, rc
+    assert b"time out" in lib.dms_last_error() or b"timed out" in lib.dms_last_error()
+    # the poisoned frame appended no measurement and merged none (positions / confidences of the survivors unchanged)
+    assert len(map2) <= n1
+    idx = {tuple(v) for v in map1["pos"].view(np.uint32).reshape(-1, 4)}
+    assert all(tuple(v) in idx for v in map2["pos"].view(np.uint32).reshape(-1, 4)[:2000])
+    # the healthy frame behind it tracked from the kept pose and fused
+    assert int(r3.fused) == 1 and int(r3.surfels) > len(map2)
+    assert np.abs(np.array(r3.pose, np.float32) - pose1).max() < 0.05
+    # reported once
+    d, rgb, _ = frames[4]
+    ch = g.upload_frame(rgb, d)
+    g.processFrameAsync(g._rgb.ptr, ch, g._depth.ptr)
+    rc, _ = g.fetch_rc()
+    assert rc == 0, rc
+    g.close()
+
+
+def test_surfel_bound_stays_tight_without_pipeline_or_fetch(fus, synth):
+    """The host-side upper bound of the map size (launch grids are sized from it) used to grow by a frame's worth of
+    slots per clean unless the pipelined path or a fetch tightened it: 40 frames with pipeline_ingest = 0
+    and a single fetch at the end must not end with DMS_ERR_CAPACITY on a map that fits."""
+    g = fus.ElasticFusion(W, H, K, model_capacity=300000, pipeline_ingest=0)
+    for k in range(40):
+        d, rgb, _ = synth.frame(k % 4, width=W, height=H, K=K, noise=True)
+        ch = g.upload_frame(rgb, d)
+        g.processFrameAsync(g._rgb.ptr, ch, g._depth.ptr)
+    from densemonoslam_amd.capi import lib
+    import ctypes as C
+
+    lib.dms_model_count_bound.restype = C.c_size_t
+    lib.dms_model_count_bound.argtypes = [C.c_void_p]
+    g.globalModel  # (handle below)
+    bound = int(lib.dms_model_count_bound(C.c_void_p(lib.dms_fusion_model(g.h))))
+    rc, r = g.fetch_rc()
+    assert rc == 0, rc
+    assert 50000 < int(r.surfels) < 300000
+    slots = ((W + 1) // 2) * ((H + 1) // 2)
+    assert bound <= int(r.surfels) + 3 * slots, (bound, int(r.surfels), slots)
+    g.close()
