@@ -117,6 +117,8 @@ struct dms_odometry {
   unsigned* tickets = nullptr; // [4] arrival counters of the last-block-solves hand-off (zero between launches)
   float* rec = nullptr;               // [2][kMaxPersistBlocks][kRecFloats] records of the persistent level kernels
   unsigned long long* sync = nullptr; // [kSyncWords] barrier words, zeroed by k_track_init
+  unsigned long long* ar = nullptr;   // [kArReductions][kArWords] all-reduce words, zeroed by k_track_init
+  bool atomic_reduce = true;          // false: record protocol everywhere (DMS_TRACK_REDUCE=records)
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
@@ -185,9 +187,12 @@ struct Prior {
 
 __global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
                              int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout) {
-  // barrier words of the persistent kernels of this call: zero before any of them is launched
-  for (int i = threadIdx.x; i < n_sync; i += blockDim.x)
-    __hip_atomic_store(sync_words + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // barrier and all-reduce words of the resident kernels of this call: zero before any of them is launched
+  // (n_sync counts 16-byte pairs; the grid shares the work, block 0 also sets up the state)
+  {
+    ulonglong2* w2 = reinterpret_cast<ulonglong2*>(sync_words);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sync; i += blockDim.x * gridDim.x) w2[i] = make_ulonglong2(0ull, 0ull);
+  }
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (prior_pose16) {  // device-resident prior (frame step): row-major 4×4 camera-to-world
     for (int i = 0; i < 3; ++i) {
@@ -664,7 +669,33 @@ struct GnLocal {
 // in the isometry form [R^T | -R^T t] instead of the reference's general 4x4 inverse: the two agree
 // to ~1e-16 before the values are rounded to float, and the cofactor expansion was a quarter of the
 // serial solve time.
+struct KPre {  // camera matrix of one pyramid level in fp64 with the reciprocals of the focal lengths (all exact IEEE operations)
+  double fx, fy, cx, cy, ifx, ify;
+};
+__device__ __forceinline__ KPre kpre_of(float fx, float fy, float cx, float cy, int level) {
+  double K[9];
+  level_K(fx, fy, cx, cy, level, K);
+  KPre k;
+  k.fx = K[0];
+  k.fy = K[4];
+  k.cx = K[2];
+  k.cy = K[5];
+  k.ifx = 1.0 / k.fx;
+  k.ify = 1.0 / k.fy;
+  return k;
+}
+__device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k);
 __device__ __forceinline__ void gn_params_local(GnLocal& L, const double* K) {
+  KPre k;
+  k.fx = K[0];
+  k.fy = K[4];
+  k.cx = K[2];
+  k.cy = K[5];
+  k.ifx = 1.0 / k.fx;
+  k.ify = 1.0 / k.fy;
+  gn_params_local_k(L, k);
+}
+__device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k) {
   // inverse pose [Ri | ti] = [R^T | -R^T t]
   double Ri[9], ti[3];
 #pragma unroll
@@ -675,8 +706,8 @@ __device__ __forceinline__ void gn_params_local(GnLocal& L, const double* K) {
   for (int i = 0; i < 3; ++i) ti[i] = -(Ri[i * 3 + 0] * L.resultRt[3] + Ri[i * 3 + 1] * L.resultRt[7] + Ri[i * 3 + 2] * L.resultRt[11]);
   // K = [fx 0 cx; 0 fy cy; 0 0 1] (level_K): K Ri K^-1 and K ti in closed form instead of a general
   // 3x3 inverse and two 3x3 products; same values to ~1e-16 before the float rounding
-  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  const double ifx = 1.0 / fx, ify = 1.0 / fy;
+  const double fx = k.fx, fy = k.fy, cx = k.cx, cy = k.cy;
+  const double ifx = k.ifx, ify = k.ify;
   double M[9];  // K * Ri
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -698,34 +729,38 @@ __device__ __forceinline__ void gn_params_local(GnLocal& L, const double* K) {
 
 // One Gauss-Newton update (RGBDOdometry.cpp:472-585): combine the two 6x6 systems, pivoted LDLT in
 // fp64, se(3) update of resultRt, new float pose, projection parameters for `next_level`.
-__device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma, const SolveArgs& q) {
-  float A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+// `kpre`: camera matrix of q.next_level prepared by the caller (resident kernels: once per level); null = derive it here.
+// `side`: store the side outputs lastA / lastb (only the values of a level's last iteration are ever read).
+__device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma, const SolveArgs& q,
+                                             const KPre* kpre = nullptr, bool side = true) {
   float residual[2] = {0.f, 0.f};
   if (q.icp) {
-    unpack_se3_d(s_icp, A_icp, b_icp);
     residual[0] = s_icp[27];
     residual[1] = s_icp[28];
   }
-  if (q.rgb) unpack_se3_d(s_rgb, A_rgb, b_rgb);
-
+  // the two symmetric systems are combined on their 21 + 6 unique entries (same expression per entry as the
+  // reference's full-matrix form, RGBDOdometry.cpp:531-552) and mirrored
   double A[36], b[6], x[6];
-  if (q.icp && q.rgb) {
+  {
     const double w = (double)q.icpWeight;
     const double ww = w * w;
+    int shift = 0;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i] + ww * (double)A_icp[i];
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i] + w * (double)b_icp[i];
-  } else if (q.icp) {
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = (double)A_icp[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = (double)b_icp[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = (double)A_rgb[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = (double)b_rgb[i];
+      for (int j = i; j < 7; ++j) {
+        const double vi = q.icp ? (double)s_icp[shift] : 0.0, vr = q.rgb ? (double)s_rgb[shift] : 0.0;
+        ++shift;
+        double v;
+        if (q.icp && q.rgb)
+          v = (j == 6) ? vr + w * vi : vr + ww * vi;
+        else
+          v = q.icp ? vi : vr;
+        if (j == 6)
+          b[i] = v;
+        else
+          A[j * 6 + i] = A[i * 6 + j] = v;
+      }
   }
   // A.ldlt().solve(b) (RGBDOdometry.cpp:554): unpivoted register LDL^T when A is safely positive
   // definite, the pivoted routine (Eigen's semantics on degenerate systems) otherwise
@@ -794,10 +829,12 @@ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, con
   L.lastRGBCount = (float)rgbSize;
   L.lastICPError = sqrtf(residual[0]) / residual[1];
   L.lastICPCount = residual[1];
+  if (side) {
 #pragma unroll
-  for (int i = 0; i < 36; ++i) L.lastA[i] = A[i];
+    for (int i = 0; i < 36; ++i) L.lastA[i] = A[i];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) L.lastb[i] = b[i];
+    for (int i = 0; i < 6; ++i) L.lastb[i] = b[i];
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) L.resultRt[i] = nr[i];
 #pragma unroll
@@ -805,9 +842,13 @@ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, con
 #pragma unroll
   for (int i = 0; i < 3; ++i) L.tcurr[i] = tc[i] + L.tprev[i];
 
-  double K[9];
-  level_K(q.fx, q.fy, q.cx, q.cy, q.next_level, K);
-  gn_params_local(L, K);
+  if (kpre) {
+    gn_params_local_k(L, *kpre);
+  } else {
+    double K[9];
+    level_K(q.fx, q.fy, q.cx, q.cy, q.next_level, K);
+    gn_params_local(L, K);
+  }
 }
 
 // run by the 256 threads of the last block of k_gn_pass2 (or of k_gn_pass1 when there is no
@@ -940,6 +981,8 @@ struct LevelArgs {
   float fx, fy, cx, cy;  // full-resolution intrinsics
   void* rec;             // [2][gridDim.x][kRecFloats] floats (or doubles with fp64 sums)
   unsigned long long* sync;  // 2 barriers (kBarrierStride words each) per iteration, zero on entry
+  unsigned long long* ar;    // kArWords per iteration of this level, zero on entry (integer all-reduce)
+  int use_ar;                // 0: record protocol in every iteration
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
@@ -1131,6 +1174,149 @@ __device__ __forceinline__ void pk_gather_d(Rsrc rsrc, int par, int nb, double* 
   __syncthreads();
 }
 
+// ---- grid-wide integer all-reduce in memory-side atomics ------------------------------------------------------
+// What barrier B + the record gather did in two steps (records published, barrier, every block reads every record)
+// is one step here: lane k of wave 0 converts the block's partial sum of value k to fixed point and adds it, with a
+// non-returning 64-bit agent-scope atomic, to word [block % 8][k]; the same lane then polls its own 8 shard words
+// until their arrival fields show every block — the total is then in its registers.  No record, no separate
+// barrier, no gather; integer adds are order free, so the totals are bit-identical in every block and from run to
+// run.  Measured stand-alone (scripts/bench_allreduce.hip, 200 blocks): 1.9 us against 4.1 us for the round-1
+// protocol; the words of one shard must be contiguous (one coalesced atomic instruction per shard region) — with
+// the 8 shards of a value in one cache line the atomics serialise per line (7.1 us).
+//   word = arrivals [63:58] | overflows [57:52] | field [51:0] = sum of (v + 2^46), |v| < 2^46, <= 32 blocks per shard
+// Fixed point needs a scale all blocks agree on BEFORE they add.  |sum_px J_i J_j| <= sqrt(T_ii T_jj) (Cauchy-
+// Schwarz, also for every block's partial sum), so the diagonal totals of the PREVIOUS iteration of the level bound
+// every product of this one up to how much the diagonals can grow in one iteration: the bound exponent of value
+// (i, j) is ceil((e_i + e_j) / 2) + kArMargin with T_ii < 2^e_i, which leaves 45 - 6 - log2(blocks) > 30 bits
+// below the totals while the diagonals stay within 2^-10 .. 2^6 of their previous values — the fp32 block records of
+// the round-1 path carry 24.  A block whose partial sum does not fit its bound adds an overflow mark instead; every
+// block then sees the mark in the completed word and the whole grid repeats this iteration's reduction with the
+// record protocol (the partial sums are still in registers).  The first iteration of a level has no previous totals
+// and uses the record protocol directly.
+constexpr int kArShards = 8;
+constexpr int kArStride = 64;                       // words per shard: slots 0..28 ICP | 32..60 photometric
+constexpr int kArPairBase = kArShards * kArStride;  // then the count / sum-of-squares pair: one 128-byte line per shard (slots 0, 1),
+constexpr int kArPairStride = 16;                   // apart from the lines the 58 sums arrive on (its pollers would slow those atomics)
+constexpr int kArWords = kArPairBase + kArShards * kArPairStride;  // 5 KB per iteration
+constexpr int kArSlotCnt = 0, kArSlotSig = 1;
+constexpr int kArMargin = 6;
+constexpr int kArReductions = 10 + 3 * 10;          // SO3 iterations + GN iterations of the three levels (resident path: <= 10 each)
+
+__device__ __forceinline__ unsigned long long ar_pack(long long v, bool ovf) {
+  return (1ull << 58) | (ovf ? (1ull << 52) : 0ull) | (unsigned long long)((ovf ? 0ll : v) + (1ll << 46));
+}
+// partial sum p of a value whose magnitude is bounded by 2^eb
+__device__ __forceinline__ unsigned long long ar_encode(double p, int eb) {
+  const double scaled = ldexp(p, 45 - eb);
+  const bool ok = fabs(scaled) < 35184372088832.0;  // 2^45; false for NaN
+  return ar_pack(ok ? (long long)rint(scaled) : 0ll, !ok);
+}
+__device__ __forceinline__ double ar_decode(long long total, int eb) { return ldexp((double)total, eb - 45); }
+
+// smallest e with d < 2^e; a value that is not a positive finite number bounds nothing
+__device__ __forceinline__ int ar_exp_of(float d) {
+  if (!(d > 0.f) || !(d < 3.0e38f)) return -127;
+  int e;
+  (void)frexpf(d, &e);
+  return e;
+}
+// bound exponent of value k of an (N+1) x (N+1) upper-triangle layout (N Jacobian columns + residual; then the
+// residual square and the count): N = 6 for the 29 SE3 sums, N = 3 for the 11 SO3 sums.  `sums` = previous totals.
+template <int N>
+__device__ __forceinline__ int ar_bound_exp(const float* sums, int k) {
+  constexpr int NP = N * (N + 3) / 2;
+  if (k > NP) return 20;  // the count: at most 2048 pixels per block
+  int i = N, j = N;       // k == NP: residual^2
+  if (k < NP) {
+    int off = 0;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const int len = N + 1 - r;
+      if (k >= off && k < off + len) {
+        i = r;
+        j = r + (k - off);
+      }
+      off += len;
+    }
+  }
+  const int di = i == N ? NP : (N + 1) * i - (i * (i - 1)) / 2;
+  const int dj = j == N ? NP : (N + 1) * j - (j * (j - 1)) / 2;
+  const int eb = ((ar_exp_of(sums[di]) + ar_exp_of(sums[dj]) + 1) >> 1) + kArMargin;
+  return eb < -200 ? -200 : (eb > 200 ? 200 : eb);
+}
+
+// wave 0, all 64 lanes: every lane with `mine` polls the 8 shard words of `slot` until they show nb arrivals.
+// tot = signed total, ovf = overflow marks seen.  Bounded: a timeout sets *timeout and returns false.
+// `probe` >= 0: first only lanes 0-7 watch the 8 shard words of slot `probe` (the slot added last) and the full sweep
+// starts when those are complete — 58 lanes of every waiting block sweeping the words that are still receiving
+// atomics slows the arrivals down (measured in the level-0 kernel: 4.7 us per reduction against 1.9 stand-alone).
+template <int STRIDE>
+__device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, bool mine, int nb, long long& tot, int& ovf, int* timeout,
+                                        int probe = -1) {
+  unsigned spins = 0;
+  if (probe >= 0) {
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+      const unsigned long long q = lane < kArShards ? __hip_atomic_load(w + lane * STRIDE + probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      int arr = (int)(q >> 58);
+      arr = row8_sum_i(arr);  // lanes 0-7: the 8 shards
+      if (__builtin_amdgcn_readlane(arr, 0) == nb) break;
+      ++spins;
+      if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;  // (reported below)
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  for (;;) {
+    unsigned long long arr = 0, fld = 0, ov = 0;
+    if (mine) {
+      unsigned long long q[kArShards];
+#pragma unroll
+      for (int s = 0; s < kArShards; ++s) q[s] = __hip_atomic_load(w + s * STRIDE + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int s = 0; s < kArShards; ++s) {
+        arr += q[s] >> 58;
+        ov += (q[s] >> 52) & 63ull;
+        fld += q[s] & ((1ull << 52) - 1ull);
+      }
+    }
+    const bool done = !mine || arr == (unsigned long long)nb;
+    if (__builtin_amdgcn_ballot_w64(done) == ~0ull) {
+      tot = (long long)fld - (long long)arr * (1ll << 46);
+      ovf = (int)ov;
+      return true;
+    }
+    ++spins;
+    if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never hang the device
+      tot = 0;
+      ovf = 0;
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// block-wide sum of NV per-thread values whose totals are wanted in wave 0: DPP inside the wave, then lane k < NV
+// of wave 0 adds the 8 wave partials of value k in fp64 (fixed order) — the lane that owns value k's atomic.
+template <int NV>
+__device__ __forceinline__ double pblock_reduce_w0(float (&v)[NV], float (*s_red)[32]) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();  // s_red may still be read from the previous use
+  wave_sum_all_to_lane63<NV>(v);
+  if (lane == kWave - 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s_red[wid][k] = v[k];
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < NV) {
+#pragma unroll
+    for (int w = 0; w < kPWaves; ++w) r += (double)s_red[w][threadIdx.x];
+  }
+  return r;
+}
+
 // LDS of the two sum variants as typed arrays (casts from a raw byte buffer cost the fp32 variant ~2 %: the
 // compiler no longer sees the arrays' shapes and alignment)
 template <bool F64, int NV>
@@ -1156,8 +1342,12 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   __shared__ float s_sums[kRecFloats];
   __shared__ int s_none;
   __shared__ int s_done;
+  __shared__ int s_cs[2];
+  __shared__ int s_ovf;
+  __shared__ KPre s_k[2];
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
+  int eb_icp = 0, eb_rgb = 0, eb_slot = 0;  // wave 0: bound exponents of the values this lane adds / polls (all-reduce)
   // optional phase clock (block 0, thread 0): wall_clock64 ticks (10 ns) summed per phase into L.prof
   // (accumulated in LDS and flushed once at the end: a global read-modify-write per phase would
   // stall wave 0 for a memory round trip each time and distort what it measures)
@@ -1221,6 +1411,12 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   if (s_done) return;  // level already ended (uniform: every block read the same flag)
 
   bool ended = false;
+  // camera matrices of this level and of the next one that runs, for the scalar section (thread 0 uses them)
+  // (kept in LDS: 24 more live registers per lane would spill the 256-register pixel loop)
+  if (tid == 0) {
+    s_k[0] = kpre_of(L.fx, L.fy, L.cx, L.cy, L.level);
+    s_k[1] = kpre_of(L.fx, L.fy, L.cx, L.cy, L.level_below);
+  }
   phase(0);
   for (int it = 0; it < L.n_iter; ++it) {
     const int par = it & 1;
@@ -1301,11 +1497,21 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       }
     }
     phase(1);
+    // per-block stamps of the level's middle iteration (profiling: arrival skew and completion latency of the two
+    // grid-wide reductions): pass 1 done | count pair complete | pass 2 + block sum done | totals complete
+    const bool stamp = L.prof && L.level == 0 && it == L.n_iter / 2 && tid == 0;
+    if (stamp) L.prof[48 + blockIdx.x * 8 + 0] = wall_clock64();
     float* my_rec = reinterpret_cast<float*>(L.rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
     double* my_rec_d = reinterpret_cast<double*>(L.rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
+    // integer all-reduce (fp32-sum variant): the count / sum-of-squares pair always; the 58 sums from the level's
+    // second iteration on (the first has no previous totals to scale by) unless a block's partial sum overflows
+    unsigned long long* arw = L.ar + (size_t)it * kArWords + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride;
+    const unsigned long long* arp = L.ar + (size_t)it * kArWords;
+    unsigned long long* arq = L.ar + (size_t)it * kArWords + kArPairBase + (size_t)(blockIdx.x & (kArShards - 1)) * kArPairStride;
+    const bool use_ar = !F64 && L.use_ar && it > 0;
     int rgbSize = 0, sigma = 0;
     if (RGB) {
-      // ---- barrier A, arrival: the word carries the count and the sum of squared differences ----
+      // ---- barrier A, arrival: the count and the sum of squared differences ----
       const int lane = tid & 63, wid = tid >> 6;
       cnt = wave_sum_to_lane63_i(cnt);
       sig = wave_sum_to_lane63_i(sig);
@@ -1318,24 +1524,54 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         const int t = row8_sum_i(tid < 16 ? s_redi[tid & 7][tid >> 3] : 0);
         const unsigned long long cb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 0);
         const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 8);
-        if (tid == 0) pk_arrive(L.sync + (2 * it) * kBarrierStride, (cb << 35) | sb);
+        if constexpr (F64) {
+          if (tid == 0) pk_arrive(L.sync + (2 * it) * kBarrierStride, (cb << 35) | sb);
+        } else {
+          if (tid < 2)
+            __hip_atomic_fetch_add(arq + tid, ar_pack((long long)(tid == kArSlotCnt ? cb : sb), false), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     phase(2);
-    if (ICP) {  // the ICP block sum and its record store overlap the other blocks' arrivals
+    double p_icp = 0.0, p_rgb = 0.0;  // fp32-sum variant: block totals of value k in thread k < 29
+    if (ICP) {  // the ICP block sum and its publication overlap the other blocks' arrivals
       if constexpr (F64) {
         const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);
         if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        const float tot = pblock_reduce<kSE3>(acc, lds.s_red);
-        if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p_icp = pblock_reduce_w0<kSE3>(acc, lds.s_red);
+        if (tid < kSE3) {
+          if (use_ar)
+            __hip_atomic_fetch_add(arw + tid, ar_encode(p_icp, eb_icp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            __hip_atomic_store(my_rec + tid, (float)p_icp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     if (RGB) {
-      const unsigned long long word = pk_wait(L.sync + (2 * it) * kBarrierStride, &st->sync_timeout);
+      if constexpr (F64) {
+        const unsigned long long word = pk_wait(L.sync + (2 * it) * kBarrierStride, &st->sync_timeout);
+        rgbSize = (int)((word >> 35) & 0x7FFFFull);
+        sigma = (int)(word & 0x7FFFFFFFFull);
+      } else {
+        if (tid < 64) {
+          long long tot;
+          int ov;
+          if (stamp) L.prof[48 + blockIdx.x * 8 + 4] = wall_clock64();  // poll start
+          ar_wait<kArPairStride>(arp + kArPairBase, tid, tid < 2, nb, tot, ov, &st->sync_timeout);
+
+          const int c0 = __builtin_amdgcn_readlane((int)tot, kArSlotCnt), s0 = __builtin_amdgcn_readlane((int)tot, kArSlotSig);
+          if (tid == 0) {
+            s_cs[0] = c0;
+            s_cs[1] = s0;  // (the low 32 bits: an int sum, as in the reference)
+          }
+        }
+        __syncthreads();
+        rgbSize = s_cs[0];
+        sigma = s_cs[1];
+      }
       phase(3);
-      rgbSize = (int)((word >> 35) & 0x7FFFFull);
-      sigma = (int)(word & 0x7FFFFFFFFull);
+      if (stamp) L.prof[48 + blockIdx.x * 8 + 1] = wall_clock64();
       if (L.rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) {
         // host `break` (RGBDOdometry.cpp:466-469): the level ends; the next level needs its own K
         if (tid == 0) {
@@ -1370,22 +1606,54 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);
         if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + 32 + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        const float tot = pblock_reduce<kSE3>(acc, lds.s_red);
-        if (pblock_owner<kSE3>()) __hip_atomic_store(my_rec + 32 + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p_rgb = pblock_reduce_w0<kSE3>(acc, lds.s_red);
+        if (tid < kSE3) {
+          if (use_ar)
+            __hip_atomic_fetch_add(arw + 32 + tid, ar_encode(p_rgb, eb_rgb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            __hip_atomic_store(my_rec + 32 + tid, (float)p_rgb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
-    // ---- barrier B: records published ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase(4);
-    pk_barrier(L.sync + (2 * it + 1) * kBarrierStride, 0ull, &st->sync_timeout);
-    phase(5);
+    if (stamp) L.prof[48 + blockIdx.x * 8 + 2] = wall_clock64();
+    bool records = !use_ar;
+    if constexpr (!F64) {
+      if (use_ar) {
+        // ---- the totals arrive in the lanes that poll them ----
+        if (tid < 64) {
+          const bool mine = (ICP && tid < kSE3) || (RGB && tid >= 32 && tid < 32 + kSE3);
+          long long tot;
+          int ov;
+          ar_wait<kArStride>(arp, tid, mine, nb, tot, ov, &st->sync_timeout, RGB ? 32 : 0);
 
-    // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
-    if constexpr (F64)
-      pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
-    else
-      pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
+          s_sums[tid] = mine ? (float)ar_decode(tot, eb_slot) : 0.f;
+          const unsigned long long any = __builtin_amdgcn_ballot_w64(mine && ov != 0);
+          if (tid == 0) s_ovf = any != 0ull ? 1 : 0;
+        }
+        __syncthreads();
+        records = s_ovf != 0;  // uniform over the grid: every block read the same completed words
+        if (records && tid < kSE3) {  // a partial sum did not fit its bound: this iteration falls back to the records
+          if (ICP) __hip_atomic_store(my_rec + tid, (float)p_icp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (RGB) __hip_atomic_store(my_rec + 32 + tid, (float)p_rgb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (records) {
+      // ---- barrier B: records published ----
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pk_barrier(L.sync + (2 * it + 1) * kBarrierStride, 0ull, &st->sync_timeout);
+      phase(5);
+      // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
+      if constexpr (F64)
+        pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
+      else
+        pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
+    } else {
+      phase(5);
+    }
     phase(6);
+    if (stamp) L.prof[48 + blockIdx.x * 8 + 3] = wall_clock64();
     if (tid == 0) {
       SolveArgs q;
       q.icp = ICP ? 1 : 0;
@@ -1406,13 +1674,23 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       q.fy = L.fy;
       q.cx = L.cx;
       q.cy = L.cy;
-      gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q);
+      const bool last = it == L.n_iter - 1 || none;
+      const KPre kp = s_k[last ? 1 : 0];
+      // (with rgbOnly the level may end at any iteration's break: the side outputs are then the previous iteration's)
+      gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q, &kp, last || L.rgbOnly);
       if (none) {
         s.iters_run += L.n_iter - 1 - it;
         s_none = 1;
       }
     }
     __syncthreads();
+    if constexpr (!F64) {
+      if (tid < 64) {  // scale of every value for the next iteration, from the totals all blocks hold
+        eb_icp = ar_bound_exp<6>(s_sums, tid < kSE3 ? tid : 0);
+        eb_rgb = ar_bound_exp<6>(s_sums + 32, tid < kSE3 ? tid : 0);
+        eb_slot = tid < 32 ? eb_icp : ar_bound_exp<6>(s_sums + 32, tid - 32 < kSE3 ? tid - 32 : 0);
+      }
+    }
     phase(7);
     if constexpr (EXIT) {
       if (s_none) break;
@@ -1483,8 +1761,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 template <bool F64>
 __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
                                                    const unsigned char* nextImage, size_t next_pitch, int cols, int rows, void* rec,
-                                                   unsigned long long* sync, SolveCam cam, int first_gn_level, int max_iter) {
+                                                   unsigned long long* sync, unsigned long long* ar, int use_ar_arg, SolveCam cam,
+                                                   int first_gn_level, int max_iter) {
   __shared__ TrackState s;
+  __shared__ int s_ovf;
+  int eb_mine = 0;  // wave 0, lane k < 11: bound exponent of value k (integer all-reduce, see ar_bound_exp)
   static_assert(kSO3 * kPB * 4 >= 16 * 64 * 8, "gather scratch fits the reduce buffer");
   __shared__ SumLds<F64, kSO3> lds;
   __shared__ float s_sums[kRecFloats];
@@ -1529,24 +1810,47 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
       }
       accumulate_so3(acc, row, found);
     }
+    const bool use_ar = !F64 && use_ar_arg && it > 0;  // (as in k_gn_level: the first iteration has no previous totals)
+    bool records = !use_ar;
     if constexpr (F64) {
       const double tot = pblock_reduce_d<kSO3>(acc, lds.s_t);
       double* my_rec = reinterpret_cast<double*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
       if (pblock_owner_d<kSO3>()) __hip_atomic_store(my_rec + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      const float tot = pblock_reduce<kSO3>(acc, lds.s_red);
+      const double p = pblock_reduce_w0<kSO3>(acc, lds.s_red);
       float* my_rec = reinterpret_cast<float*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
-      if (pblock_owner<kSO3>()) __hip_atomic_store(my_rec + (tid >> 3), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long* arp = ar + (size_t)it * kArWords;
+      if (use_ar) {
+        if (tid < kSO3)
+          __hip_atomic_fetch_add(ar + (size_t)it * kArWords + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride + tid, ar_encode(p, eb_mine),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 64) {
+          long long tot;
+          int ov;
+          ar_wait<kArStride>(arp, tid, tid < kSO3, nb, tot, ov, &st->sync_timeout, 0);
+          s_sums[tid] = tid < kSO3 ? (float)ar_decode(tot, eb_mine) : 0.f;
+          const unsigned long long any = __builtin_amdgcn_ballot_w64(tid < kSO3 && ov != 0);
+          if (tid == 0) s_ovf = any != 0ull ? 1 : 0;
+        }
+        __syncthreads();
+        records = s_ovf != 0;
+      }
+      if (records && tid < kSO3) __hip_atomic_store(my_rec + tid, (float)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pk_barrier(sync + it * kBarrierStride, 0ull, &st->sync_timeout);
-    if constexpr (F64)
-      pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
-    else
-      pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
+    if (records) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pk_barrier(sync + it * kBarrierStride, 0ull, &st->sync_timeout);
+      if constexpr (F64)
+        pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
+      else
+        pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
+    }
     if (tid == 0) so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
     __syncthreads();
     if (s.so3_done) break;
+    if constexpr (!F64) {
+      if (tid < 64) eb_mine = ar_bound_exp<3>(s_sums, tid < kSO3 ? tid : 0);
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -1640,7 +1944,8 @@ void layout(dms_odometry* o, Carver& c) {
   o->tickets = (unsigned*)c.take(64);
   o->rec = (float*)c.take((size_t)2 * kMaxPersistBlocks * kRecFloats * 8);  // sized for the fp64-sum variant
   o->sync = (unsigned long long*)c.take((size_t)kSyncWords * 8);
-  o->prof = (long long*)c.take(3 * 16 * 8);
+  o->ar = (unsigned long long*)c.take((size_t)kArReductions * kArWords * 8);
+  o->prof = (long long*)c.take((3 * 16 + 256 * 8) * 8);
   o->state = (TrackState*)c.take(sizeof(TrackState));
 }
 
@@ -1783,6 +2088,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     o->fp64_sums = e && strcmp(e, "fp64") == 0;
     e = getenv("DMS_TRACK_EARLY_EXIT");
     o->early_exit_force = e ? (e[0] != '0' ? 1 : 0) : -1;
+    e = getenv("DMS_TRACK_REDUCE");
+    o->atomic_reduce = !(e && strcmp(e, "records") == 0);
     e = getenv("DMS_PERSIST_BLOCKS");
     if (e && atoi(e) > 0) o->persist_target = atoi(e);
   }
@@ -1796,8 +2103,9 @@ int dms_odometry_inject_timeout(dms_odometry* o, int calls) {
   return DMS_OK;
 }
 
-int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit) {
+int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce) {
   DMS_REQUIRE(o, "null argument");
+  if (atomic_reduce >= 0) o->atomic_reduce = atomic_reduce != 0;
   if (resident >= 0) o->resident = resident != 0;
   if (fp64_sums >= 0) o->fp64_sums = fp64_sums != 0;
   o->early_exit_force = early_exit < 0 ? -1 : (early_exit ? 1 : 0);
@@ -2039,8 +2347,10 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
 
   {
     Timer t(o, s, "track_init");
-    hipLaunchKernelGGL(k_track_init, dim3(1), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
-                       first_level, o->sync, kSyncWords, o->inject_timeouts > 0 ? 1 : 0);
+    // (o->sync and o->ar are adjacent in the arena: one zeroing sweep covers both; resident mode only)
+    const int zero_pairs = o->resident ? (int)(((char*)(o->ar + (size_t)kArReductions * kArWords) - (char*)o->sync) / 16) : 0;
+    hipLaunchKernelGGL(k_track_init, dim3(o->resident ? 16 : 1), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy,
+                       so3 ? 1 : 0, first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0);
     DMS_CHECK_LAUNCH();
     if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
   }
@@ -2058,10 +2368,12 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
       if (o->fp64_sums)
         hipLaunchKernelGGL(k_so3_level<true>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, cam, first_level, 10);
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, o->atomic_reduce ? 1 : 0, cam, first_level,
+                           10);
       else
         hipLaunchKernelGGL(k_so3_level<false>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, cam, first_level, 10);
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, o->atomic_reduce ? 1 : 0, cam, first_level,
+                           10);
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {
@@ -2147,6 +2459,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.cy = o->cy;
       L.rec = o->rec;
       L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
+      L.ar = o->ar + (size_t)(10 + 10 * l) * kArWords;
+      L.use_ar = o->atomic_reduce ? 1 : 0;
       L.prof = o->profiling ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
       L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
@@ -2638,10 +2952,10 @@ int dms_odometry_get_kernel_time(dms_odometry* o, const char* name, double* tota
   // "phase:<i>": accumulated in-kernel clock of phase i of the persistent level kernels (block 0)
   if (strncmp(name, "phase:", 6) == 0) {
     const int i = atoi(name + 6);  // level * 16 + phase
-    DMS_REQUIRE(i >= 0 && i < 48, "bad phase index");
+    DMS_REQUIRE(i >= 0 && i < 48 + 256 * 8, "bad phase index");  // from 48 on: per-block stamps [block][8] of level 0's middle iteration
     long long v = 0;
     DMS_HIP(hipMemcpy(&v, o->prof + i, sizeof(v), hipMemcpyDeviceToHost));
-    *total_ms = (double)v * 1e-5;  // 10 ns ticks
+    *total_ms = i < 48 ? (double)v * 1e-5 : (double)(v % 100000000ll) * 1e-5;  // (counts: value * 1e-5)  // 10 ns ticks (stamps: modulo 1 s)
     *launches = 1;
     return DMS_OK;
   }

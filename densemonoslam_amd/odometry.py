@@ -255,9 +255,9 @@ class RGBDOdometry:
             lib.dms_odometry_destroy(self.h)
             self.h = None
 
-    def setMode(self, resident=-1, fp64_sums=-1, early_exit=-1):
+    def setMode(self, resident=-1, fp64_sums=-1, early_exit=-1, atomic_reduce=-1):
         """Execution switches of this handle (dms_odometry_set_mode); -1 keeps / restores the default."""
-        check(lib.dms_odometry_set_mode(self.h, int(resident), int(fp64_sums), int(early_exit)), "dms_odometry_set_mode")
+        check(lib.dms_odometry_set_mode(self.h, int(resident), int(fp64_sums), int(early_exit), int(atomic_reduce)), "dms_odometry_set_mode")
 
     def __del__(self):
         try:

@@ -223,12 +223,14 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
                         float fx, float fy, float distThresh, float angleThresh);
 int dms_odometry_destroy(dms_odometry* o);
 /* Execution switches of one tracker (no reference counterpart).  They are read from the environment ONCE, when the
- * handle is created — DMS_TRACK_MODE=launches, DMS_SUMS=fp64, DMS_TRACK_EARLY_EXIT=0|1 — and changed only here:
+ * handle is created — DMS_TRACK_MODE=launches, DMS_SUMS=fp64, DMS_TRACK_EARLY_EXIT=0|1, DMS_TRACK_REDUCE=records — and changed only here:
  *   resident    1 = one resident kernel per pyramid level (default), 0 = three launches per iteration; -1 = keep
  *   fp64_sums   1 = block sums and records in fp64, 0 = fp32 wave sums (default); -1 = keep
  *   early_exit  1 / 0 = force the resident-kernel variant that leaves a level after an iteration without any
- *               correspondence on / off; -1 = the handle's default (on for the frame step's model-to-model tracker) */
-int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit);
+ *               correspondence on / off; -1 = the handle's default (on for the frame step's model-to-model tracker)
+ *   atomic_reduce 1 = grid-wide sums of the resident kernels through integer atomics (default), 0 = through per-block
+ *               records + barrier + gather (DMS_TRACK_REDUCE=records); -1 = keep */
+int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce);
 /* Fault injection for tests: the next `calls` tracking calls behave as if a resident kernel had timed out at a
  * grid barrier (DMS_ERR_TIMEOUT from dms_odometry_fetch_result; the frame step keeps the prior pose and fuses nothing). */
 int dms_odometry_inject_timeout(dms_odometry* o, int calls);

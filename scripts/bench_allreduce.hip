@@ -188,6 +188,89 @@ __global__ __launch_bounds__(TPB) void k_atomic_t(u64* words, int iters, int* er
   if (bad || s_tot[3] == 123456789) atomicAdd(bad_out, 1);
 }
 
+// mode 9/10: the same all-reduce, but only ONE block per XCD (the first to take a ticket on its XCD's election word)
+// polls the memory-side words; it hands the totals to the other blocks of its XCD through 8-byte {value, tag} granules
+// in a per-XCD mailbox: plain (workgroup-scope) stores keep the lines in that XCD's L2, the followers' sc1 loads
+// bypass their L1 and hit it.  Readers per hot memory-side line: 8 instead of every block.
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF); }
+
+template <int NVT>
+__global__ __launch_bounds__(TPB) void k_atomic_xcd(u64* words, u64* mailbox, unsigned* elect, int iters, int* err, int* bad_out, int check) {
+  __shared__ long long s_tot[64];
+  __shared__ int s_leader;
+  const int nb = gridDim.x, tid = threadIdx.x;
+  const int xcd = xcc_id() & 7;
+  if (tid == 0) s_leader = atomicAdd(elect + xcd, 1u) == 0u ? 1 : 0;
+  __syncthreads();
+  const bool leader = s_leader != 0;
+  u64* mb = mailbox + xcd * 64;
+  int bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    u64* w = words + (size_t)it * (8 * 64);
+    const int sh = blockIdx.x & 7;
+    const unsigned tag = (unsigned)it + 1u;
+    if (tid < NVT) {
+      const long long v = value_of(it, blockIdx.x, tid);
+      __hip_atomic_fetch_add(w + sh * 64 + tid, (u64)(v + (1ll << 46)) | (1ull << 58), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {
+      unsigned spins = 0;
+      if (leader) {
+        long long tot = 0;
+        for (;;) {
+          u64 arr = 0, fld = 0;
+          if (tid < NVT) {
+            u64 q[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) q[s] = __hip_atomic_load(w + s * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+              arr += q[s] >> 58;
+              fld += q[s] & ((1ull << 52) - 1ull);
+            }
+          }
+          const bool done = tid >= NVT || arr == (u64)nb;
+          if (__builtin_amdgcn_ballot_w64(done) == ~0ull) {
+            tot = (long long)fld - (long long)arr * (1ll << 46);
+            break;
+          }
+          if (++spins > (1u << 14)) {
+            *err = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (tid < NVT) {
+          const u64 g = ((u64)tag << 32) | (u64)__float_as_uint((float)tot);
+          __hip_atomic_store(mb + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        s_tot[tid] = tot;
+      } else {
+        u64 g = 0;
+        for (;;) {
+          if (tid < NVT) g = __hip_atomic_load(mb + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool done = tid >= NVT || (unsigned)(g >> 32) == tag;
+          if (__builtin_amdgcn_ballot_w64(done) == ~0ull) break;
+          if (++spins > (1u << 16)) {
+            *err = 2;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        s_tot[tid] = (long long)__uint_as_float((unsigned)g);
+      }
+    }
+    __syncthreads();
+    if (check && tid < NVT) {
+      long long expect = 0;
+      for (int b = 0; b < nb; ++b) expect += value_of(it, b, tid);
+      if (s_tot[tid] != expect) bad = 1;
+    }
+    __syncthreads();
+  }
+  if (bad || s_tot[3] == 123456789) atomicAdd(bad_out, 1);
+}
+
 __global__ __launch_bounds__(TPB) void k_atomic(u64* words, int iters, int* err, int* bad_out, int layout, int check) {
   __shared__ long long s_tot[64];
   const int nb = gridDim.x, tid = threadIdx.x;
@@ -253,7 +336,11 @@ int main() {
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  for (int mode = 0; mode < 9; ++mode)
+  u64* mailbox;
+  unsigned* elect;
+  hipMalloc(&mailbox, 8 * 64 * 8);
+  hipMalloc(&elect, 64);
+  for (int mode = 3; mode < 11; ++mode)
     for (int nb : {38, 75, 150, 200, 256}) {
       float best = 1e9f;
       int e = 0, bd = 0;
@@ -261,6 +348,8 @@ int main() {
         const int check = rep == 0;
         hipMemset(words, 0, wbytes);
         hipMemset(err, 0, 4);
+        hipMemset(mailbox, 0, 8 * 64 * 8);
+        hipMemset(elect, 0, 64);
         hipMemset(bad, 0, 4);
         hipDeviceSynchronize();
         hipEventRecord(a, 0);
@@ -276,8 +365,12 @@ int main() {
           hipLaunchKernelGGL((k_atomic_t<58, 16>), dim3(nb), dim3(TPB), 0, 0, words, iters, err, bad, check);
         else if (mode == 7)
           hipLaunchKernelGGL((k_atomic_t<2, 8>), dim3(nb), dim3(TPB), 0, 0, words, iters, err, bad, check);
-        else
+        else if (mode == 8)
           hipLaunchKernelGGL((k_atomic_t<11, 8>), dim3(nb), dim3(TPB), 0, 0, words, iters, err, bad, check);
+        else if (mode == 9)
+          hipLaunchKernelGGL((k_atomic_xcd<58>), dim3(nb), dim3(TPB), 0, 0, words, mailbox, elect, iters, err, bad, check);
+        else
+          hipLaunchKernelGGL((k_atomic_xcd<2>), dim3(nb), dim3(TPB), 0, 0, words, mailbox, elect, iters, err, bad, check);
         hipEventRecord(b, 0);
         hipDeviceSynchronize();
         float ms;
