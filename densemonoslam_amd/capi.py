@@ -246,6 +246,7 @@ lib.dms_odometry_create.argtypes = [C.POINTER(_P), _I, _I, _F, _F, _F, _F, _F, _
 lib.dms_odometry_destroy.argtypes = [_P]
 lib.dms_odometry_set_mode.argtypes = [_P, _I, _I, _I, _I]
 lib.dms_odometry_inject_timeout.argtypes = [_P, _I]
+lib.dms_odometry_debug_set.argtypes = [_P, C.c_char_p, _I]
 lib.dms_odometry_initICP_depth.argtypes = [_P, _I2, _F, _P]
 lib.dms_odometry_initICP_maps.argtypes = [_P, _P, _P, _F, _P]
 lib.dms_odometry_initICPModel.argtypes = [_P, _P, _P, _F, _FP, _P]

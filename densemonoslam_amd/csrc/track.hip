@@ -119,6 +119,7 @@ struct dms_odometry {
   unsigned long long* sync = nullptr; // [kSyncWords] barrier words, zeroed by k_track_init
   unsigned long long* ar = nullptr;   // [kArReductions][kArWords] all-reduce words, zeroed by k_track_init
   bool atomic_reduce = true;          // false: record protocol everywhere (DMS_TRACK_REDUCE=records)
+  int ar_margin = 6;                  // = kArMargin; test hook (dms_odometry_debug_set "ar_margin"): a negative margin makes every partial sum overflow
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
@@ -983,6 +984,7 @@ struct LevelArgs {
   unsigned long long* sync;  // 2 barriers (kBarrierStride words each) per iteration, zero on entry
   unsigned long long* ar;    // kArWords per iteration of this level, zero on entry (integer all-reduce)
   int use_ar;                // 0: record protocol in every iteration
+  int ar_margin;             // headroom (bits) of the fixed-point scale over the previous totals (kArMargin)
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
@@ -1223,7 +1225,7 @@ __device__ __forceinline__ int ar_exp_of(float d) {
 // bound exponent of value k of an (N+1) x (N+1) upper-triangle layout (N Jacobian columns + residual; then the
 // residual square and the count): N = 6 for the 29 SE3 sums, N = 3 for the 11 SO3 sums.  `sums` = previous totals.
 template <int N>
-__device__ __forceinline__ int ar_bound_exp(const float* sums, int k) {
+__device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin) {
   constexpr int NP = N * (N + 3) / 2;
   if (k > NP) return 20;  // the count: at most 2048 pixels per block
   int i = N, j = N;       // k == NP: residual^2
@@ -1241,7 +1243,7 @@ __device__ __forceinline__ int ar_bound_exp(const float* sums, int k) {
   }
   const int di = i == N ? NP : (N + 1) * i - (i * (i - 1)) / 2;
   const int dj = j == N ? NP : (N + 1) * j - (j * (j - 1)) / 2;
-  const int eb = ((ar_exp_of(sums[di]) + ar_exp_of(sums[dj]) + 1) >> 1) + kArMargin;
+  const int eb = ((ar_exp_of(sums[di]) + ar_exp_of(sums[dj]) + 1) >> 1) + margin;
   return eb < -200 ? -200 : (eb > 200 ? 200 : eb);
 }
 
@@ -1686,9 +1688,9 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     __syncthreads();
     if constexpr (!F64) {
       if (tid < 64) {  // scale of every value for the next iteration, from the totals all blocks hold
-        eb_icp = ar_bound_exp<6>(s_sums, tid < kSE3 ? tid : 0);
-        eb_rgb = ar_bound_exp<6>(s_sums + 32, tid < kSE3 ? tid : 0);
-        eb_slot = tid < 32 ? eb_icp : ar_bound_exp<6>(s_sums + 32, tid - 32 < kSE3 ? tid - 32 : 0);
+        eb_icp = ar_bound_exp<6>(s_sums, tid < kSE3 ? tid : 0, L.ar_margin);
+        eb_rgb = ar_bound_exp<6>(s_sums + 32, tid < kSE3 ? tid : 0, L.ar_margin);
+        eb_slot = tid < 32 ? eb_icp : ar_bound_exp<6>(s_sums + 32, tid - 32 < kSE3 ? tid - 32 : 0, L.ar_margin);
       }
     }
     phase(7);
@@ -1810,7 +1812,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
       }
       accumulate_so3(acc, row, found);
     }
-    const bool use_ar = !F64 && use_ar_arg && it > 0;  // (as in k_gn_level: the first iteration has no previous totals)
+    const bool use_ar = !F64 && (use_ar_arg & 1) && it > 0;  // (as in k_gn_level: the first iteration has no previous totals)
     bool records = !use_ar;
     if constexpr (F64) {
       const double tot = pblock_reduce_d<kSO3>(acc, lds.s_t);
@@ -1849,7 +1851,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
     __syncthreads();
     if (s.so3_done) break;
     if constexpr (!F64) {
-      if (tid < 64) eb_mine = ar_bound_exp<3>(s_sums, tid < kSO3 ? tid : 0);
+      if (tid < 64) eb_mine = ar_bound_exp<3>(s_sums, tid < kSO3 ? tid : 0, use_ar_arg >> 8);
     }
   }
   __syncthreads();
@@ -2095,6 +2097,16 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
   }
   *out = o;
   return DMS_OK;
+}
+
+int dms_odometry_debug_set(dms_odometry* o, const char* key, int value) {
+  DMS_REQUIRE(o && key, "null argument");
+  if (strcmp(key, "ar_margin") == 0) {
+    DMS_REQUIRE(value >= -100 && value <= 100, "ar_margin out of range");
+    o->ar_margin = value;
+    return DMS_OK;
+  }
+  DMS_REQUIRE(false, "unknown key");
 }
 
 int dms_odometry_inject_timeout(dms_odometry* o, int calls) {
@@ -2368,11 +2380,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
       if (o->fp64_sums)
         hipLaunchKernelGGL(k_so3_level<true>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, o->atomic_reduce ? 1 : 0, cam, first_level,
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, (o->atomic_reduce ? 1 : 0) | (o->ar_margin * 256), cam, first_level,
                            10);
       else
         hipLaunchKernelGGL(k_so3_level<false>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, o->atomic_reduce ? 1 : 0, cam, first_level,
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, (o->atomic_reduce ? 1 : 0) | (o->ar_margin * 256), cam, first_level,
                            10);
       DMS_CHECK_LAUNCH();
     } else
@@ -2461,6 +2473,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
       L.ar = o->ar + (size_t)(10 + 10 * l) * kArWords;
       L.use_ar = o->atomic_reduce ? 1 : 0;
+      L.ar_margin = o->ar_margin;
       L.prof = o->profiling ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
       L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);

@@ -234,6 +234,9 @@ int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int earl
 /* Fault injection for tests: the next `calls` tracking calls behave as if a resident kernel had timed out at a
  * grid barrier (DMS_ERR_TIMEOUT from dms_odometry_fetch_result; the frame step keeps the prior pose and fuses nothing). */
 int dms_odometry_inject_timeout(dms_odometry* o, int calls);
+/* Test hooks by name.  "ar_margin": headroom in bits of the integer all-reduce's fixed-point scale (default 6); a large
+ * negative value makes every partial sum overflow its bound, so every reduction takes the record-protocol fallback. */
+int dms_odometry_debug_set(dms_odometry* o, const char* key, int value);
 
 /* reference initICP(GPUTexture* filteredDepth, ...) (RGBDOdometry.cpp:118-142); depth = dense u16 mm */
 int dms_odometry_initICP_depth(dms_odometry* o, const dms_image2d* filteredDepth_u16,

@@ -344,9 +344,13 @@ def _fresh_pair(dms, orc, gputest_pair):
 
 @pytest.fixture
 def track_mode(request, monkeypatch):
-    """'persistent' = one resident kernel per pyramid level (default); 'launches' = pass1 / pass2 /
-    solve launches per iteration (fallback path).  Read by the library at every tracking call."""
+    """'persistent' = one resident kernel per pyramid level, grid-wide sums through integer atomics (default);
+    'persistent_records' = the same kernels with the record protocol; 'launches' = pass1 / pass2 / solve launches per
+    iteration (fallback path).  Read by the library once, when a tracker is created."""
     monkeypatch.delenv("DMS_SUMS", raising=False)
+    monkeypatch.delenv("DMS_TRACK_REDUCE", raising=False)
+    if request.param == "persistent_records":  # resident kernels, grid-wide sums through records + barrier + gather (round-1 protocol)
+        monkeypatch.setenv("DMS_TRACK_REDUCE", "records")
     if request.param == "launches":
         monkeypatch.setenv("DMS_TRACK_MODE", "launches")
     else:
@@ -356,7 +360,7 @@ def track_mode(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
+@pytest.mark.parametrize("track_mode", ["persistent", "persistent_records", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode):
     cfg = CONFIGS[name]
@@ -381,7 +385,7 @@ def test_track_pose_parity_gputest_pair(dms, orc, gputest_pair, name, track_mode
     assert 1e-4 < np.linalg.norm(tg) < 0.1
 
 
-@pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
+@pytest.mark.parametrize("track_mode", ["persistent", "persistent_records", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("name", ["C2_icp_fast", "C3_full", "gputest", "rgb_only"])
 def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, track_mode):
     """The committed golden vectors of the tracker on the reference's GPUTest pair
@@ -408,7 +412,7 @@ def test_track_reproduces_committed_golden_vectors(dms, gputest_pair, name, trac
     _sum_close(np.array(rg.lastA), want[name + "_lastA"], rtol=2e-3, what="lastA")
 
 
-@pytest.mark.parametrize("track_mode", ["persistent", "launches", "persistent_fp64"], indirect=True)
+@pytest.mark.parametrize("track_mode", ["persistent", "persistent_records", "launches", "persistent_fp64"], indirect=True)
 @pytest.mark.parametrize("case", ["no_live_depth", "black_live_image", "no_depth_and_black"])
 @pytest.mark.parametrize("early_exit", [False, True])
 def test_track_degenerate_inputs(dms, orc, gputest_pair, track_mode, case, early_exit, monkeypatch):
@@ -563,3 +567,40 @@ def test_error_paths(dms):
     assert capi.lib.dms_pyrDown(src.ref, dst.ref, None) == -1
     # null pointers
     assert capi.lib.dms_createNMap(None, None, None) == -1
+
+
+def test_allreduce_overflow_falls_back_to_records_bit_for_bit(dms, gputest_pair, monkeypatch):
+    """Integer all-reduce of the resident kernels: a block whose partial sum does not fit the fixed-point bound marks an
+    overflow and the whole grid repeats that reduction with the record protocol.  Forced here (a bound far below the
+    previous totals: every reduction overflows): poses, side outputs and iteration counts must equal the pure record
+    protocol's bit for bit — and the default margin must give the same pose to well below the parity bar."""
+    from densemonoslam_amd.capi import lib
+
+    K = gputest_pair["K"]
+    verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
+    rgba1, rgba2 = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
+
+    def run(reduce_records, margin=None):
+        g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+        g.setMode(atomic_reduce=0 if reduce_records else 1)
+        if margin is not None:
+            assert lib.dms_odometry_debug_set(g.h, b"ar_margin", margin) == 0
+        g.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+        g.initRGBModel(rgba1)
+        g.initICP(gputest_pair["depth2"], 20.0)
+        g.initRGB(rgba2)
+        g.initFirstRGB(rgba1)
+        t, R, r = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **CONFIGS["C3_full"])
+        out = (t.copy(), R.copy(), np.array(r.lastA), np.array(r.lastb), list(r.iterations_run), r.so3_iterations_run,
+               r.lastICPCount, r.lastRGBCount)
+        g.close()
+        return out
+
+    rec = run(True)
+    forced = run(False, margin=-60)
+    for a, b, what in zip(rec, forced, ("t", "R", "lastA", "lastb", "iterations", "so3 iterations", "ICP count", "RGB count")):
+        assert np.array(a).tobytes() == np.array(b).tobytes(), what
+    dflt = run(False)
+    helpers.assert_pose_close(dflt[0], dflt[1], rec[0], rec[1], what="atomics vs records")
+    assert np.linalg.norm(dflt[0].astype(np.float64) - rec[0]) < 2e-5
+    assert dflt[4] == rec[4] and dflt[5] == rec[5]
