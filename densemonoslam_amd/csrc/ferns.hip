@@ -1,0 +1,593 @@
+// Randomised-fern keyframe database (reference class Ferns, Core/src/Ferns.{h,cpp}) — see include/dmslam_ferns.h.
+//
+// MI355X design.  The reference keeps the database in host vectors and walks, per query, 500 inverted lists
+// (`conservatory[i].ids[code]`) to count co-occurrences (Ferns.cpp:208-229) — a pointer chase that is the CPU form
+// of "for every stored frame, how many of its codes equal mine".  Here the database is dense in HBM:
+//   codes  [capacity][512] bytes (500 used, padded with the bad code), one 512-byte line per frame
+//   blocks [capacity][tw*th*36] bytes: RGBA8 image | RGBA32F vertex | RGBA32F normal thumbnails (what verification needs)
+// and a query is three tiny launches on one stream: resize (skipped for a thumbnail block), encode (one block, one lane
+// per fern), search (one wavefront per stored frame: 64 lanes x 8 codes, byte compares, DPP sum, one 64-bit atomicMin of
+// {dissimilarity bits, frame id} — "first strictly smaller" of the reference's loop is "smallest key").  8 000 stored
+// frames are 4 MB of codes: the search streams them once, ~1 us of HBM time.  The accept / reject decision and the
+// 500-sample photometric check stay on the host as in the reference (they follow a tracker call that synchronises).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dmslam_ferns.h"
+#include "internal.hpp"
+#include "smallmath.hpp"
+#include "surfel.hpp"
+
+namespace dms {
+
+constexpr int kFernPad = DMS_FERN_MAX;  // codes per stored frame (padded)
+
+struct FernTable {  // device copy of the conservatory
+  short x[kFernPad], y[kFernPad];
+  int r[kFernPad], g[kFernPad], b[kFernPad], d[kFernPad];
+};
+
+struct FernHost {  // pinned result block of one query
+  unsigned long long best;  // dissimilarity bits << 32 | frame id; all ones = none
+  int good;                 // goodCodes of the query frame
+  int hd_count, hd_equal;   // blockHDAware against the best frame
+  int pad;
+  float4 vert[kFernPad];    // vertSmall at the fern positions
+  uchar4 rgb[kFernPad];     // imgSmall at the fern positions
+};
+
+// Resize::image / Resize::vertex (Shaders/Resize.cpp:67-143, resize.frag): NEAREST samples of the full-resolution
+// textures at the thumbnail's pixel centres, packed as dms_fusion_thumbnails packs them
+__global__ __launch_bounds__(256) void k_fern_thumbs(const uchar4* __restrict__ image, const float4* __restrict__ vertex,
+                                                     const float4* __restrict__ normal, int cols, int rows, int tw, int th,
+                                                     unsigned char* __restrict__ block) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= tw * th) return;
+  const int j = k / tw, i = k - j * tw;
+  const float u = ((float)i + 0.5f) / (float)tw, v = ((float)j + 0.5f) / (float)th;
+  const int sx = texel(u, (float)cols, cols), sy = texel(v, (float)rows, rows);
+  const size_t q = (size_t)sy * cols + sx;
+  const size_t n = (size_t)tw * th;
+  reinterpret_cast<uchar4*>(block)[k] = image[q];
+  reinterpret_cast<float4*>(block + n * 4)[k] = vertex[q];
+  reinterpret_cast<float4*>(block + n * 20)[k] = normal[q];
+}
+
+// code of every fern (Ferns.cpp:208-233): one lane per fern; also the samples the host-side checks read
+__global__ __launch_bounds__(kFernPad) void k_fern_encode(const unsigned char* __restrict__ block, int tw, int th, const FernTable* __restrict__ tab,
+                                                          int num, unsigned char* __restrict__ codes, int* __restrict__ good,
+                                                          FernHost* __restrict__ res) {
+  __shared__ int s_good;
+  const int i = threadIdx.x;
+  if (i == 0) s_good = 0;
+  __syncthreads();
+  unsigned char code = DMS_FERN_BAD_CODE;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  uchar4 pix = make_uchar4(0, 0, 0, 0);
+  if (i < num) {
+    const size_t n = (size_t)tw * th;
+    const int q = (int)tab->y[i] * tw + (int)tab->x[i];
+    v = reinterpret_cast<const float4*>(block + n * 4)[q];
+    pix = reinterpret_cast<const uchar4*>(block)[q];
+    if (v.z > 0.f) {
+      code = (unsigned char)((((int)pix.x > tab->r[i]) << 3) | (((int)pix.y > tab->g[i]) << 2) | (((int)pix.z > tab->b[i]) << 1) |
+                             (f2i_rz(v.z * 1000.0f) > tab->d[i] ? 1 : 0));
+      atomicAdd(&s_good, 1);
+    }
+  }
+  __syncthreads();
+  if (codes) codes[i] = code;
+  if (good && i == 0) *good = s_good;
+  if (res) {
+    res->vert[i] = v;
+    res->rgb[i] = pix;
+    if (i == 0) {
+      res->good = s_good;
+      res->best = ~0ull;
+      res->hd_count = 0;
+      res->hd_equal = 0;
+    }
+  }
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+  v = wave_sum_to_lane63_i(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// minimum dissimilarity over the stored frames (Ferns.cpp:235-248 / 327-339): one wavefront per frame
+__global__ __launch_bounds__(256) void k_fern_search(const unsigned char* __restrict__ db_codes, const int* __restrict__ db_good,
+                                                     const int* __restrict__ db_time, int n, const unsigned char* __restrict__ cur_codes,
+                                                     const int* __restrict__ cur_good, int time, int all_frames,
+                                                     unsigned long long* __restrict__ best) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const unsigned long long mine = reinterpret_cast<const unsigned long long*>(cur_codes)[lane];
+  const unsigned long long theirs = reinterpret_cast<const unsigned long long*>(db_codes + (size_t)j * kFernPad)[lane];
+  int co = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const unsigned m = (unsigned)(mine >> (8 * b)) & 0xFFu, t = (unsigned)(theirs >> (8 * b)) & 0xFFu;
+    co += (m != DMS_FERN_BAD_CODE && m == t) ? 1 : 0;
+  }
+  co = wave_sum_i(co);
+  if (lane != 0) return;
+  if (!(all_frames || time - db_time[j] > 300)) return;
+  const int g = *cur_good, gj = db_good[j];
+  const float maxCo = (float)(g < gj ? g : gj);
+  const float dissim = (maxCo - (float)co) / maxCo;
+  if (dissim != dissim) return;  // 0 / 0: never "less than" in the reference's loop
+  atomicMin(best, ((unsigned long long)__float_as_uint(dissim) << 32) | (unsigned)j);
+}
+
+// blockHDAware(query, best frame) (Ferns.cpp:684-704) for the frame the search chose, without a host round trip
+__global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __restrict__ db_codes, const unsigned char* __restrict__ cur_codes,
+                                                      int num, FernHost* __restrict__ res) {
+  __shared__ int s_c, s_e;
+  if (threadIdx.x == 0) s_c = s_e = 0;
+  __syncthreads();
+  const unsigned long long best = res->best;
+  if (best == ~0ull) return;
+  const int id = (int)(best & 0xFFFFFFFFull);
+  const int i = threadIdx.x;
+  if (i < num) {
+    const unsigned char a = cur_codes[i], b = db_codes[(size_t)id * kFernPad + i];
+    if (a != DMS_FERN_BAD_CODE && b != DMS_FERN_BAD_CODE) {
+      atomicAdd(&s_c, 1);
+      if (a == b) atomicAdd(&s_e, 1);
+    }
+  }
+  __syncthreads();
+  if (i == 0) {
+    res->hd_count = s_c;
+    res->hd_equal = s_e;
+  }
+}
+
+// append the staged frame to the database: slot = n
+__global__ __launch_bounds__(256) void k_fern_commit(const unsigned char* __restrict__ cur_block, const unsigned char* __restrict__ cur_codes,
+                                                     size_t block_bytes, unsigned char* __restrict__ db_block, unsigned char* __restrict__ db_codes) {
+  const size_t n16 = block_bytes / 16;
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n16; k += (size_t)blockDim.x * gridDim.x)
+    reinterpret_cast<uint4*>(db_block)[k] = reinterpret_cast<const uint4*>(cur_block)[k];
+  if (blockIdx.x == 0 && threadIdx.x < kFernPad / 16) reinterpret_cast<uint4*>(db_codes)[threadIdx.x] = reinterpret_cast<const uint4*>(cur_codes)[threadIdx.x];
+}
+
+// ---- the table: mt19937 + uniform_int_distribution (Ferns.cpp:27-30,56,68-83) ------------------------------------
+struct Mt19937 {
+  uint32_t mt[624];
+  int idx;
+  explicit Mt19937(uint32_t seed) {
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int i = 0; i < 624; ++i) {
+        const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  // uniform integer in [a, b]: Lemire's nearly-divisionless mapping of one 32-bit draw (libstdc++ 11, uniform_int_dist.h)
+  int uniform(int a, int b) {
+    const uint32_t range = (uint32_t)(b - a) + 1u;
+    uint64_t product = (uint64_t)next() * (uint64_t)range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+      const uint32_t threshold = (0u - range) % range;
+      while (low < threshold) {
+        product = (uint64_t)next() * (uint64_t)range;
+        low = (uint32_t)product;
+      }
+    }
+    return a + (int)(product >> 32);
+  }
+};
+
+}  // namespace dms
+
+using namespace dms;
+
+struct dms_ferns {
+  int num = 0, W = 0, H = 0, tw = 0, th = 0, maxDepth = 0, capacity = 0, n = 0;
+  float photoThresh = 0.f;
+  float cx = 0, cy = 0, fx = 0, fy = 0;  // full resolution
+  std::vector<int> pos, rgbd;            // host table: [num][2], [num][4]
+  std::vector<float> poses;              // [capacity][16]
+  std::vector<int> times, goods;         // host mirrors of the per-frame metadata
+  size_t block_bytes = 0;
+  char* arena = nullptr;
+  FernTable* d_tab = nullptr;
+  unsigned char* d_codes = nullptr;   // [capacity][kFernPad]
+  int* d_good = nullptr;              // [capacity]
+  int* d_time = nullptr;              // [capacity]
+  unsigned char* d_blocks = nullptr;  // [capacity][block_bytes]
+  unsigned char* d_cur_block = nullptr;
+  unsigned char* d_cur_codes = nullptr;  // [kFernPad]
+  FernHost* d_res = nullptr;
+  FernHost* h_res = nullptr;       // pinned
+  unsigned char* h_rgb = nullptr;  // pinned: image thumbnail of the candidate (photometric check)
+  dms_odometry* rgbd_odom = nullptr;
+};
+
+namespace {
+
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+void mul44(const float* a, const float* b, float* o) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = a[i * 4 + 0] * b[0 * 4 + j];
+      s += a[i * 4 + 1] * b[1 * 4 + j];
+      s += a[i * 4 + 2] * b[2 * 4 + j];
+      s += a[i * 4 + 3] * b[3 * 4 + j];
+      o[i * 4 + j] = s;
+    }
+}
+void mul4v(const float* m, float x, float y, float z, float* o) {
+  for (int i = 0; i < 4; ++i) {
+    float s = m[i * 4 + 0] * x;
+    s += m[i * 4 + 1] * y;
+    s += m[i * 4 + 2] * z;
+    s += m[i * 4 + 3];
+    o[i] = s;
+  }
+}
+
+// resize (unless the frame arrives as a thumbnail block) + encode + reset of the result block
+int stage(dms_ferns* f, const dms_image2d* image, const dms_image2d* vertex, const dms_image2d* normal, const void* block_dev, hipStream_t s) {
+  const int n = f->tw * f->th;
+  if (block_dev) {
+    DMS_HIP(hipMemcpyAsync(f->d_cur_block, block_dev, f->block_bytes, hipMemcpyDeviceToDevice, s));
+  } else {
+    DMS_REQUIRE(image && vertex && normal && image->data && vertex->data && normal->data, "null texture");
+    DMS_REQUIRE(image->rows == f->H && image->cols == f->W && image->pitch == (size_t)f->W * 4 && vertex->rows == f->H && vertex->cols == f->W &&
+                    vertex->pitch == (size_t)f->W * 16 && normal->rows == f->H && normal->cols == f->W && normal->pitch == (size_t)f->W * 16,
+                "dense full-resolution RGBA8 / RGBA32F textures required");
+    hipLaunchKernelGGL(k_fern_thumbs, dim3((n + 255) / 256), dim3(256), 0, s, (const uchar4*)image->data, (const float4*)vertex->data,
+                       (const float4*)normal->data, f->W, f->H, f->tw, f->th, f->d_cur_block);
+    DMS_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_fern_encode, dim3(1), dim3(kFernPad), 0, s, f->d_cur_block, f->tw, f->th, f->d_tab, f->num, f->d_cur_codes,
+                     (int*)nullptr, f->d_res);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int search(dms_ferns* f, int time, int all_frames, bool with_hd, hipStream_t s) {
+  if (f->n > 0) {
+    hipLaunchKernelGGL(k_fern_search, dim3((f->n + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->n, f->d_cur_codes,
+                       &f->d_res->good, time, all_frames, &f->d_res->best);
+    DMS_CHECK_LAUNCH();
+    if (with_hd) {
+      hipLaunchKernelGGL(k_fern_hd, dim3(1), dim3(kFernPad), 0, s, f->d_codes, f->d_cur_codes, f->num, f->d_res);
+      DMS_CHECK_LAUNCH();
+    }
+  }
+  DMS_HIP(hipMemcpyAsync(f->h_res, f->d_res, sizeof(FernHost), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  return DMS_OK;
+}
+
+// decision of addFrame on the staged frame (Ferns.cpp:235-275)
+int decide_add(dms_ferns* f, const float* pose16, int srcTime, float threshold, int* added, hipStream_t s) {
+  const FernHost* r = f->h_res;
+  float minimum = 3.402823466e+38F;
+  if (r->good > 0 && r->best != ~0ull) {
+    const unsigned bits = (unsigned)(r->best >> 32);
+    memcpy(&minimum, &bits, 4);
+  }
+  *added = 0;
+  if ((minimum > threshold || f->n == 0) && r->good > 0) {
+    if (f->n >= f->capacity) {
+      set_error("dms_ferns: the database is full (%d frames)", f->capacity);
+      return DMS_ERR_CAPACITY;
+    }
+    const int slot = f->n;
+    hipLaunchKernelGGL(k_fern_commit, dim3(64), dim3(256), 0, s, f->d_cur_block, f->d_cur_codes, f->block_bytes,
+                       f->d_blocks + (size_t)slot * f->block_bytes, f->d_codes + (size_t)slot * kFernPad);
+    DMS_CHECK_LAUNCH();
+    f->goods[slot] = r->good;
+    f->times[slot] = srcTime;
+    memcpy(&f->poses[(size_t)slot * 16], pose16, 16 * sizeof(float));
+    DMS_HIP(hipMemcpyAsync(f->d_good + slot, &f->goods[slot], sizeof(int), hipMemcpyHostToDevice, s));
+    DMS_HIP(hipMemcpyAsync(f->d_time + slot, &f->times[slot], sizeof(int), hipMemcpyHostToDevice, s));
+    DMS_HIP(hipStreamSynchronize(s));  // (the sources are host vectors)
+    f->n += 1;
+    *added = 1;
+  }
+  return DMS_OK;
+}
+
+// Ferns::photometricCheck (Ferns.cpp:604-668) on the 500 fern samples
+float photometric_check(const dms_ferns* f, const float* estPose, const float* fernPose, const unsigned char* fernRgba) {
+  const FernHost* r = f->h_res;
+  const int factor = 8;
+  const float cx = f->cx / factor, cy = f->cy / factor;
+  const float invfx = 1.0f / (float)(f->fx / factor), invfy = 1.0f / (float)(f->fy / factor);
+  float inv[16], diff[16];
+  sm::inv4t<float>(fernPose, inv);
+  mul44(inv, estPose, diff);
+  float photoSum = 0.f;
+  int photoCount = 0;
+  for (int i = 0; i < f->num; ++i) {
+    const float4 v = r->vert[i];
+    if (v.z > 0.f && (int)(v.z * 1000.0f) < f->maxDepth) {
+      float w[4];
+      mul4v(diff, v.x, v.y, v.z, w);
+      const int c0 = (int)(w[0] * (1 / invfx) / w[2] + cx), c1 = (int)(w[1] * (1 / invfy) / w[2] + cy);
+      if (c0 >= 0 && c1 >= 0 && c0 < f->tw && c1 < f->th) {
+        const unsigned char* p = fernRgba + ((size_t)c1 * f->tw + c0) * 4;
+        if (p[0] > 0 || p[1] > 0 || p[2] > 0) {
+          const uchar4 q = r->rgb[i];
+          photoSum += (float)abs((int)p[0] - (int)q.x);
+          photoSum += (float)abs((int)p[1] - (int)q.y);
+          photoSum += (float)abs((int)p[2] - (int)q.z);
+          photoCount++;
+        }
+      }
+    }
+  }
+  return photoSum / (float)photoCount;
+}
+
+int find_common(dms_ferns* f, const float* currPose16, int time, int lost, int interMap, dms_fern_match* m, float* constraints, hipStream_t s) {
+  (void)lost;
+  int rc;
+  memset(m, 0, sizeof(*m));
+  m->closest = -1;
+  m->candidate = -1;
+  for (int i = 0; i < 16; ++i) m->estPose[i] = (i % 5 == 0) ? 1.f : 0.f;
+  if ((rc = search(f, time, interMap ? 1 : 0, true, s))) return rc;
+  const FernHost* r = f->h_res;
+  if (r->best == ~0ull) return DMS_OK;
+  const int minId = (int)(r->best & 0xFFFFFFFFull);
+  const unsigned bits = (unsigned)(r->best >> 32);
+  memcpy(&m->dissimilarity, &bits, 4);
+  m->candidate = minId;
+  m->blockHDAware = (float)r->hd_equal / (float)r->hd_count;
+  if (!(m->blockHDAware > 0.3f)) return DMS_OK;
+
+  // geometric verification with the thumbnail-sized tracker (Ferns.cpp:344-381)
+  const float* fernPose = &f->poses[(size_t)minId * 16];
+  const size_t n = (size_t)f->tw * f->th;
+  const unsigned char* fb = f->d_blocks + (size_t)minId * f->block_bytes;
+  const float cutoff = (float)f->maxDepth / 1000.0f;
+  if ((rc = dms_odometry_initICPModel(f->rgbd_odom, (const float*)(fb + n * 4), (const float*)(fb + n * 20), cutoff, fernPose, s))) return rc;
+  if ((rc = dms_odometry_initICP_maps(f->rgbd_odom, (const float*)(f->d_cur_block + n * 4), (const float*)(f->d_cur_block + n * 20), cutoff, s)))
+    return rc;
+  DMS_HIP(hipMemcpyAsync(f->h_rgb, fb, n * 4, hipMemcpyDeviceToHost, s));
+  float trans[3] = {fernPose[3], fernPose[7], fernPose[11]}, rot[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) rot[i * 3 + j] = fernPose[i * 4 + j];
+  dms_track_result tr;
+  if ((rc = dms_odometry_getIncrementalTransformation(f->rgbd_odom, trans, rot, 0, 100.0f, interMap ? 1 : 0, 0, interMap ? 1 : 0, interMap ? 1 : 0, &tr, s)))
+    return rc;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) m->estPose[i * 4 + j] = rot[i * 3 + j];
+    m->estPose[i * 4 + 3] = trans[i];
+  }
+  m->icp_error = tr.lastICPError;
+  m->icp_count = tr.lastICPCount;
+  m->photo_error = photometric_check(f, m->estPose, fernPose, f->h_rgb);
+  if (tr.lastICPError < 0.0003f && tr.lastICPCount > 400.f && m->photo_error < f->photoThresh) {
+    m->closest = minId;
+    const int step = f->num / 50 > 0 ? f->num / 50 : 1;
+    for (int i = 0; i < f->num && m->n_constraints < 64; i += step) {
+      const float4 v = r->vert[i];
+      if (v.z > 0.f && (int)(v.z * 1000.0f) < f->maxDepth) {
+        if (constraints) {
+          float* c = constraints + (size_t)m->n_constraints * 8;
+          mul4v(currPose16, v.x, v.y, v.z, c);
+          mul4v(m->estPose, v.x, v.y, v.z, c + 4);
+        }
+        m->n_constraints += 1;
+      }
+    }
+  }
+  return DMS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThresh, int width, int height, float cx, float cy, float fx,
+                     float fy, unsigned int seed, int capacity) {
+  DMS_REQUIRE(out, "null out");
+  DMS_REQUIRE(num >= 1 && num <= DMS_FERN_MAX, "1 <= num <= DMS_FERN_MAX");
+  DMS_REQUIRE(width >= 128 && height >= 128 && width % 8 == 0 && height % 8 == 0, "resolution must be a multiple of 8, at least 128");
+  DMS_REQUIRE(maxDepth_mm >= 400, "maxDepth below the depth-threshold range [400, maxDepth] (Ferns.cpp:30)");
+  DMS_REQUIRE(capacity >= 1, "capacity");
+  dms_ferns* f = new dms_ferns();
+  f->num = num;
+  f->W = width;
+  f->H = height;
+  f->tw = width / 8;
+  f->th = height / 8;
+  f->maxDepth = maxDepth_mm;
+  f->photoThresh = photoThresh;
+  f->capacity = capacity;
+  f->cx = cx;
+  f->cy = cy;
+  f->fx = fx;
+  f->fy = fy;
+  f->block_bytes = (size_t)f->tw * f->th * 36;
+  // generateFerns (Ferns.cpp:66-84)
+  Mt19937 rng(seed);
+  f->pos.resize((size_t)num * 2);
+  f->rgbd.resize((size_t)num * 4);
+  FernTable tab;
+  memset(&tab, 0, sizeof(tab));
+  for (int i = 0; i < num; ++i) {
+    f->pos[i * 2 + 0] = rng.uniform(0, f->tw - 1);
+    f->pos[i * 2 + 1] = rng.uniform(0, f->th - 1);
+    f->rgbd[i * 4 + 0] = rng.uniform(0, 255);
+    f->rgbd[i * 4 + 1] = rng.uniform(0, 255);
+    f->rgbd[i * 4 + 2] = rng.uniform(0, 255);
+    f->rgbd[i * 4 + 3] = rng.uniform(400, maxDepth_mm);
+    tab.x[i] = (short)f->pos[i * 2 + 0];
+    tab.y[i] = (short)f->pos[i * 2 + 1];
+    tab.r[i] = f->rgbd[i * 4 + 0];
+    tab.g[i] = f->rgbd[i * 4 + 1];
+    tab.b[i] = f->rgbd[i * 4 + 2];
+    tab.d[i] = f->rgbd[i * 4 + 3];
+  }
+  f->poses.assign((size_t)capacity * 16, 0.f);
+  f->times.assign(capacity, 0);
+  f->goods.assign(capacity, 0);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    off = up256(off);
+    const size_t at = off;
+    off += bytes;
+    return at;
+  };
+  const size_t o_tab = take(sizeof(FernTable)), o_codes = take((size_t)capacity * kFernPad), o_good = take((size_t)capacity * 4),
+               o_time = take((size_t)capacity * 4), o_blocks = take((size_t)capacity * f->block_bytes), o_cur = take(f->block_bytes),
+               o_cc = take(kFernPad), o_res = take(sizeof(FernHost));
+  hipError_t e = hipMalloc((void**)&f->arena, up256(off));
+  if (e == hipSuccess) e = hipMemset(f->arena, 0, up256(off));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_res, sizeof(FernHost), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_rgb, (size_t)f->tw * f->th * 4, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (f->arena) (void)hipFree(f->arena);
+    if (f->h_res) (void)hipHostFree(f->h_res);
+    delete f;
+    return hip_fail(e, "dms_ferns_create allocation", __FILE__, __LINE__);
+  }
+  f->d_tab = (FernTable*)(f->arena + o_tab);
+  f->d_codes = (unsigned char*)(f->arena + o_codes);
+  f->d_good = (int*)(f->arena + o_good);
+  f->d_time = (int*)(f->arena + o_time);
+  f->d_blocks = (unsigned char*)(f->arena + o_blocks);
+  f->d_cur_block = (unsigned char*)(f->arena + o_cur);
+  f->d_cur_codes = (unsigned char*)(f->arena + o_cc);
+  f->d_res = (FernHost*)(f->arena + o_res);
+  e = hipMemcpy(f->d_tab, &tab, sizeof(tab), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(f->d_codes, DMS_FERN_BAD_CODE, (size_t)capacity * kFernPad);
+  int rc = e == hipSuccess ? DMS_OK : hip_fail(e, "dms_ferns_create upload", __FILE__, __LINE__);
+  // the verification tracker at thumbnail size (Ferns.cpp:36-41: intrinsics / factor)
+  if (!rc) rc = dms_odometry_create(&f->rgbd_odom, f->tw, f->th, cx / 8, cy / 8, fx / 8, fy / 8, 0.f, 0.f);
+  if (rc) {
+    dms_ferns_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return DMS_OK;
+}
+
+int dms_ferns_destroy(dms_ferns* f) {
+  if (!f) return DMS_OK;
+  if (f->rgbd_odom) dms_odometry_destroy(f->rgbd_odom);
+  if (f->arena) (void)hipFree(f->arena);
+  if (f->h_res) (void)hipHostFree(f->h_res);
+  if (f->h_rgb) (void)hipHostFree(f->h_rgb);
+  delete f;
+  return DMS_OK;
+}
+
+int dms_ferns_get_table(dms_ferns* f, int* pos2, int* rgbd4) {
+  DMS_REQUIRE(f && pos2 && rgbd4, "null argument");
+  memcpy(pos2, f->pos.data(), f->pos.size() * sizeof(int));
+  memcpy(rgbd4, f->rgbd.data(), f->rgbd.size() * sizeof(int));
+  return DMS_OK;
+}
+
+int dms_ferns_num_frames(dms_ferns* f) { return f ? f->n : 0; }
+
+int dms_ferns_get_frame(dms_ferns* f, int id, float* pose16, int* srcTime, int* goodCodes, unsigned char* codes) {
+  DMS_REQUIRE(f && id >= 0 && id < f->n, "bad frame id");
+  if (pose16) memcpy(pose16, &f->poses[(size_t)id * 16], 16 * sizeof(float));
+  if (srcTime) *srcTime = f->times[id];
+  if (goodCodes) *goodCodes = f->goods[id];
+  if (codes) DMS_HIP(hipMemcpy(codes, f->d_codes + (size_t)id * kFernPad, f->num, hipMemcpyDeviceToHost));
+  return DMS_OK;
+}
+
+int dms_ferns_encode(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal, unsigned char* codes_dev,
+                     int* good_dev, dms_stream st) {
+  DMS_REQUIRE(f, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  int rc = stage(f, image_rgba, vertex, normal, nullptr, s);
+  if (rc) return rc;
+  if (codes_dev) DMS_HIP(hipMemcpyAsync(codes_dev, f->d_cur_codes, kFernPad, hipMemcpyDeviceToDevice, s));
+  if (good_dev) DMS_HIP(hipMemcpyAsync(good_dev, &f->d_res->good, sizeof(int), hipMemcpyDeviceToDevice, s));
+  return DMS_OK;
+}
+
+int dms_ferns_add_frame(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal, const float* pose16,
+                        int srcTime, float threshold, int* added, dms_stream st) {
+  DMS_REQUIRE(f && pose16 && added, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  int rc = stage(f, image_rgba, vertex, normal, nullptr, s);
+  if (!rc) rc = search(f, 0, 1, false, s);
+  if (rc) return rc;
+  return decide_add(f, pose16, srcTime, threshold, added, s);
+}
+
+int dms_ferns_find_frame(dms_ferns* f, const dms_image2d* vertex, const dms_image2d* normal, const dms_image2d* image_rgba,
+                         const float* currPose16, int time, int lost, int interMap, dms_fern_match* match, float* constraints, dms_stream st) {
+  DMS_REQUIRE(f && currPose16 && match, "null argument");
+  hipStream_t s = (hipStream_t)st;
+  int rc = stage(f, image_rgba, vertex, normal, nullptr, s);
+  if (rc) return rc;
+  return find_common(f, currPose16, time, lost, interMap, match, constraints, s);
+}
+
+int dms_ferns_find_frame_thumbs(dms_ferns* f, const void* thumb_block_dev, const float* currPose16, int time, int lost, int interMap,
+                                dms_fern_match* match, float* constraints, dms_stream st) {
+  DMS_REQUIRE(f && thumb_block_dev && currPose16 && match, "null argument");
+  DMS_REQUIRE(((uintptr_t)thumb_block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)st;
+  int rc = stage(f, nullptr, nullptr, nullptr, thumb_block_dev, s);
+  if (rc) return rc;
+  return find_common(f, currPose16, time, lost, interMap, match, constraints, s);
+}
+
+int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const int* good_dev, int time, int interMap, int* best2_dev,
+                           dms_stream st) {
+  DMS_REQUIRE(f && codes_dev && good_dev && best2_dev, "null argument");
+  DMS_REQUIRE(((uintptr_t)codes_dev & 7) == 0 && ((uintptr_t)best2_dev & 7) == 0, "codes and result must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)st;
+  // (the codes are read as 64 x 8 bytes: the caller's buffer holds DMS_FERN_MAX bytes, entries past num = the bad code)
+  DMS_HIP(hipMemsetAsync(best2_dev, 0xFF, 8, s));
+  if (f->n > 0) {
+    hipLaunchKernelGGL(k_fern_search, dim3((f->n + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->n, codes_dev, good_dev, time,
+                       interMap ? 1 : 0, (unsigned long long*)best2_dev);
+    DMS_CHECK_LAUNCH();
+  }
+  return DMS_OK;
+}
+
+int dms_ferns_consume(dms_ferns* dst, dms_ferns* src, const float* T16, float threshold, int* added, dms_stream st) {
+  DMS_REQUIRE(dst && src && T16 && added && dst != src, "bad argument");
+  DMS_REQUIRE(dst->tw == src->tw && dst->th == src->th, "databases of different thumbnail size");
+  hipStream_t s = (hipStream_t)st;
+  *added = 0;
+  for (int j = 0; j < src->n; ++j) {
+    float pose[16];
+    mul44(T16, &src->poses[(size_t)j * 16], pose);  // frame->pose = relativeTransform * frame->pose (Ferns.cpp:164)
+    int rc = stage(dst, nullptr, nullptr, nullptr, src->d_blocks + (size_t)j * src->block_bytes, s);
+    if (!rc) rc = search(dst, 0, 1, false, s);
+    int one = 0;
+    if (!rc) rc = decide_add(dst, pose, src->times[j], threshold, &one, s);
+    if (rc) return rc;
+    *added += one;
+  }
+  return DMS_OK;
+}
+
+}  // extern "C"

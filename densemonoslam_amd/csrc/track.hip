@@ -32,6 +32,8 @@
 
 namespace dms {
 
+constexpr int kArMargin = 6;  // integer all-reduce: headroom (bits) of the fixed-point scale over the previous totals (see ar_bound_exp)
+
 struct TrackState {
   // prior / current pose (float, as the reference's Eigen float types)
   float Rprev[9], tprev[3], Rprev_inv[9];
@@ -119,7 +121,7 @@ struct dms_odometry {
   unsigned long long* sync = nullptr; // [kSyncWords] barrier words, zeroed by k_track_init
   unsigned long long* ar = nullptr;   // [kArReductions][kArWords] all-reduce words, zeroed by k_track_init
   bool atomic_reduce = true;          // false: record protocol everywhere (DMS_TRACK_REDUCE=records)
-  int ar_margin = 6;                  // = kArMargin; test hook (dms_odometry_debug_set "ar_margin"): a negative margin makes every partial sum overflow
+  int ar_margin = dms::kArMargin;     // test hook (dms_odometry_debug_set "ar_margin"): a negative margin makes every partial sum overflow
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
@@ -1201,7 +1203,6 @@ constexpr int kArPairBase = kArShards * kArStride;  // then the count / sum-of-s
 constexpr int kArPairStride = 16;                   // apart from the lines the 58 sums arrive on (its pollers would slow those atomics)
 constexpr int kArWords = kArPairBase + kArShards * kArPairStride;  // 5 KB per iteration
 constexpr int kArSlotCnt = 0, kArSlotSig = 1;
-constexpr int kArMargin = 6;
 constexpr int kArReductions = 10 + 3 * 10;          // SO3 iterations + GN iterations of the three levels (resident path: <= 10 each)
 
 __device__ __forceinline__ unsigned long long ar_pack(long long v, bool ovf) {

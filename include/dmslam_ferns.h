@@ -1,0 +1,87 @@
+/* dmslam_ferns.h — randomised-fern keyframe database and (inter-map) relocalisation, SURVEY.md 8(f1).
+ *
+ * Replaces `class Ferns` (elasticfusion/Core/src/Ferns.{h,cpp}): the per-map database of W/8 x H/8 keyframe
+ * thumbnails encoded by 500 random 4-bit ferns, the dissimilarity search over it, and the geometric + photometric
+ * verification of the best match with a thumbnail-sized RGBDOdometry.  In the reference all of it is host code over
+ * glReadPixels'd thumbnails (Ferns.cpp:21-706) and its call sites are compiled out (ElasticFusion.cpp:279,589,597);
+ * here the database lives in HBM, encoding and the search over all stored frames are HIP kernels, the verification
+ * runs through the same tracker as the frame step, and only the accept / reject decision is taken on the host.
+ *
+ * Collaborative mode (one camera per GPU): every rank builds its fern table from the SAME seed, so the 500-byte code
+ * vector of a frame is a descriptor all ranks can match against their own database — that descriptor (plus the
+ * thumbnails the verification needs) is what travels over RCCL (densemonoslam_amd/collab.py).
+ */
+#ifndef DMSLAM_FERNS_H_
+#define DMSLAM_FERNS_H_
+
+#include "dmslam.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dms_ferns dms_ferns;
+
+#define DMS_FERN_BAD_CODE 255 /* Ferns::badCode (Ferns.cpp:35) */
+#define DMS_FERN_MAX 512      /* ferns per table (the reference uses 500, ReferenceFrame.h:17) */
+
+/* Ferns::Ferns(n, maxDepth, photoThresh) (Ferns.cpp:21-58).  width / height / intrinsics = the full-resolution camera
+ * (the reference reads the Resolution / Intrinsics singletons); thumbnails are width/8 x height/8.  maxDepth in
+ * millimetres (ReferenceFrame.h:17 passes depthCutoff * 1000).  `seed` replaces random.seed(time(0)) (Ferns.cpp:56):
+ * table = mt19937(seed) drawn through uniform_int_distribution in the reference's order (x, y, r, g, b, d per fern,
+ * Ferns.cpp:68-83; Lemire's nearly-divisionless mapping, as libstdc++ 11).  capacity = frames the database can hold. */
+int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThresh, int width, int height, float cx, float cy,
+                     float fx, float fy, unsigned int seed, int capacity);
+int dms_ferns_destroy(dms_ferns* f);
+/* the conservatory: pos[num][2] = (x, y) thumbnail pixel, rgbd[num][4] = thresholds (Ferns::Fern) */
+int dms_ferns_get_table(dms_ferns* f, int* pos2, int* rgbd4);
+int dms_ferns_num_frames(dms_ferns* f);
+/* stored frame `id`: pose (16 floats, row-major), source time, good-code count, codes (num bytes); NULL = skip */
+int dms_ferns_get_frame(dms_ferns* f, int id, float* pose16, int* srcTime, int* goodCodes, unsigned char* codes);
+
+/* Encode a frame without touching the database: the descriptor of collaborative mode.  image = RGBA8, vertex / normal =
+ * RGBA32F, full resolution, dense (the fill-in textures the reference passes, ElasticFusion.cpp:681-684).
+ * codes_dev: DMS_FERN_MAX bytes in HBM (entries past num hold the bad code), good_dev: one int in HBM (NULL = skip
+ * either).  Asynchronous on `s`. */
+int dms_ferns_encode(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal,
+                     unsigned char* codes_dev, int* good_dev, dms_stream s);
+
+/* bool Ferns::addFrame(imageTexture, vertexTexture, normalTexture, pose, srcTime, threshold) (Ferns.cpp:170-276):
+ * encode, minimum dissimilarity against every stored frame, append when (minimum > threshold || empty) && goodCodes > 0.
+ * Synchronises `s` (the reference returns the decision). */
+int dms_ferns_add_frame(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal,
+                        const float* pose16, int srcTime, float threshold, int* added, dms_stream s);
+
+typedef struct dms_fern_match {
+  int closest;            /* Ferns::lastClosest: accepted frame id or -1 */
+  int candidate;          /* minId of the dissimilarity search (-1: none eligible) */
+  float dissimilarity;    /* of the candidate */
+  float blockHDAware;     /* agreement of the jointly valid codes (verification runs when > 0.3, Ferns.cpp:342) */
+  float icp_error, icp_count, photo_error; /* verification outcome (Ferns.cpp:386-392) */
+  float estPose[16];      /* the returned pose: identity unless the candidate was verified by the tracker */
+  int n_constraints;      /* surface constraints (Ferns.cpp:396-414), rows of 8 floats {raw xyz 1 | model xyz 1} */
+} dms_fern_match;
+
+/* Eigen::Matrix4f Ferns::findFrame(constraints, currPose, vertexTexture, normalTexture, imageTexture, time, lost,
+ * depthCutoff, interMap) (Ferns.cpp:277-423).  constraints: room for 8 * 64 floats (or NULL).  Synchronises `s`. */
+int dms_ferns_find_frame(dms_ferns* f, const dms_image2d* vertex, const dms_image2d* normal, const dms_image2d* image_rgba,
+                         const float* currPose16, int time, int lost, int interMap, dms_fern_match* match, float* constraints,
+                         dms_stream s);
+/* The same query for a frame that arrives as thumbnails (collaborative mode: another camera's block, packed as
+ * dms_fusion_thumbnails writes it — RGBA8 image | RGBA32F vertex | RGBA32F normal, each W/8 x H/8). */
+int dms_ferns_find_frame_thumbs(dms_ferns* f, const void* thumb_block_dev, const float* currPose16, int time, int lost, int interMap,
+                                dms_fern_match* match, float* constraints, dms_stream s);
+/* Only the search half of the query (no verification, no host decision): best[0] = candidate id or -1,
+ * best[1] = dissimilarity bits, written to HBM asynchronously.  codes_dev / good as dms_ferns_encode writes them. */
+int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const int* good_dev, int time, int interMap, int* best2_dev,
+                           dms_stream s);
+
+/* void Ferns::consume(otherFrames, relativeTransform, threshold) (Ferns.cpp:160-168): every stored frame of `src`,
+ * re-posed by relativeTransform, goes through addFrame(Frame*, threshold) of `dst` (re-encoded with dst's table).
+ * added = frames accepted.  Synchronises. */
+int dms_ferns_consume(dms_ferns* dst, dms_ferns* src, const float* relativeTransform16, float threshold, int* added, dms_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

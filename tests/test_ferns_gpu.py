@@ -1,0 +1,190 @@
+"""Fern keyframe database (Ferns.cpp) — HIP path through the C ABI against the CPU restatement
+(oracle/orc_ferns.py).  Integer work (table, codes, good-code counts, the add / reject decisions, candidate ids) must be
+exact; the dissimilarity is one float division (exact); the verified pose follows the tracker's bar (<= 1 mm / 0.01 deg)."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 480  # thumbnails 80 x 60, as in the reference's configuration
+K = (528.0, 528.0, 320.0, 240.0)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from densemonoslam_amd import capi, ferns, fusion, synth
+    from oracle import orc, orc_ferns
+
+    assert capi.device_count() >= 1
+    return ferns, fusion, synth, orc, orc_ferns
+
+
+def textures(fusion, synth, k, noise=True):
+    """fill-in-like textures of synthetic frame k: RGBA8 image, RGBA32F vertex / normal maps (camera frame) + pose"""
+    from oracle import orc
+
+    d, rgb, T = synth.frame(k, width=W, height=H, K=K, noise=noise)
+    vo = orc.createVMap(K, d, 3.0)
+    no = orc.createNMap(vo)
+    ok = ~np.isnan(vo[:H]) & ~np.isnan(no[:H])
+    v = np.zeros((H, W, 4), np.float32)
+    n = np.zeros((H, W, 4), np.float32)
+    for c in range(3):
+        v[..., c] = np.where(ok, vo[c * H:(c + 1) * H], 0)
+        n[..., c] = np.where(ok, no[c * H:(c + 1) * H], 0)
+    return synth.rgba(rgb), v, n, T.astype(np.float32)
+
+
+def make_pair(mods, seed=11, **kw):
+    ferns, fusion, synth, orc, orc_ferns = mods
+    g = ferns.Ferns(W, H, K, seed=seed, **kw)
+    o = orc_ferns.Ferns(W, H, K, seed=seed, make_odometry=lambda: orc.Odometry(W // 8, H // 8, K[2] / 8, K[3] / 8, K[0] / 8, K[1] / 8), **kw)
+    return g, o
+
+
+def test_table_and_codes_exact(mods):
+    ferns, fusion, synth, orc, orc_ferns = mods
+    g, o = make_pair(mods)
+    pos, rgbd = g.table()
+    assert (pos == o.pos).all() and (rgbd == o.rgbd).all()
+    assert pos[:, 0].max() < W // 8 and pos[:, 1].max() < H // 8 and rgbd[:, 3].min() >= 400 and rgbd[:, 3].max() <= 3000
+    for k in (0, 7):
+        img, v, n, _ = textures(fusion, synth, k)
+        if k == 7:  # a hole: bad codes
+            v[60:180, 80:240] = 0
+        codes, good = g.encode(img, v, n)
+        ti, tv, tn = o._thumbs(img, v, n)
+        co, go, _ = o._encode(ti, tv)
+        assert good == go and (codes == co).all()
+        assert (codes == 255).sum() == 500 - good
+    g.close()
+
+
+def test_add_frame_decisions_and_database_exact(mods):
+    """A walk through the synthetic room: every accept / reject decision of addFrame, the stored codes, good counts,
+    times and poses must equal the reference loop's (inverted co-occurrence lists) exactly."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    g, o = make_pair(mods)
+    decisions = []
+    for k in range(0, 40, 2):
+        img, v, n, T = textures(fusion, synth, k)
+        a = g.addFrame(img, v, n, T, k, 0.3)
+        b = o.addFrame(img, v, n, T, k, 0.3)
+        assert a == b, k
+        decisions.append(a)
+    assert decisions[0] and 1 < sum(decisions) < len(decisions)  # first frame always; some rejected as too similar
+    assert len(g) == len(o.frames)
+    for i, fr in enumerate(o.frames):
+        pose, t, good, codes = g.frame(i)
+        assert t == fr.srcTime and good == fr.goodCodes and (codes == fr.codes).all() and (pose == fr.pose).all()
+    # an empty frame (no valid depth) is never added
+    img, v, n, T = textures(fusion, synth, 0)
+    assert not g.addFrame(img, np.zeros_like(v), n, T, 99, 0.05) and not o.addFrame(img, np.zeros_like(v), n, T, 99, 0.05)
+    g.close()
+
+
+def test_find_frame_matches_oracle(mods):
+    """findFrame: candidate id, dissimilarity and code agreement exact; where the thumbnail-sized ICP is well
+    conditioned (the intra-map query: 10 iterations at one level) the verified pose within the tracker's bar, the accept
+    decision, the photometric error and the surface constraints as the restatement gives them.  The 3 x 50 iterations
+    of the inter-map query slide along the walls of the synthetic room and end without correspondences on both sides
+    (chaotic: not comparable step by step) — both must reject."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    g, o = make_pair(mods, photoThresh=1000.0)  # (the colour check would reject the ICP-only pose of this scene)
+    for k in range(0, 40, 4):
+        img, v, n, T = textures(fusion, synth, k, noise=False)
+        assert g.addFrame(img, v, n, T, k, 0.02) == o.addFrame(img, v, n, T, k, 0.02)
+    assert len(g) >= 4
+    accepted = 0
+    for k, interMap, time in ((2, True, 50), (17, True, 60), (30, False, 500), (9, False, 400), (30, False, 100), (250, True, 70)):
+        img, v, n, T = textures(fusion, synth, k, noise=False)
+        m, cons = g.findFrame(T, v, n, img, time, interMap=interMap)
+        r = o.findFrame(T, v, n, img, time, interMap=interMap)
+        assert m.candidate == r["candidate"], (k, m.candidate, r["candidate"])
+        if r["candidate"] == -1:
+            assert m.closest == -1
+            continue
+        assert np.float32(m.dissimilarity) == np.float32(r["dissimilarity"])
+        assert np.float32(m.blockHDAware) == np.float32(r["blockHDAware"])
+        if not r["blockHDAware"] > 0.3:
+            assert m.closest == -1 and (np.array(m.estPose).reshape(4, 4) == np.eye(4)).all()
+            continue
+        stable = np.isfinite(r["icp_error"]) and r["icp_count"] > 400
+        if not stable:
+            assert m.closest == -1 and r["closest"] == -1
+            continue
+        est = np.array(m.estPose, np.float32).reshape(4, 4)
+        helpers.assert_pose_close(est[:3, 3], est[:3, :3], r["estPose"][:3, 3], r["estPose"][:3, :3], what="fern frame %d" % k)
+        assert abs(m.icp_count - r["icp_count"]) <= max(5.0, 2e-3 * r["icp_count"])
+        assert abs(m.icp_error - r["icp_error"]) <= 2e-3 * max(r["icp_error"], 1e-6)
+        assert abs(m.photo_error - r["photo_error"]) <= 0.02 * max(1.0, r["photo_error"])  # a rounding-flipped sample moves it slightly
+        assert m.closest == r["closest"]
+        if m.closest != -1:
+            accepted += 1
+            assert m.n_constraints == len(r["constraints"]) and m.n_constraints > 10
+            assert np.abs(cons - r["constraints"]).max() < 2e-3  # the poses differ by < 1 mm
+    assert accepted >= 1, "at least one revisit must be recognised and verified"
+    # the intra-map query only considers frames older than 300 ticks (Ferns.cpp:333)
+    img, v, n, T = textures(fusion, synth, 30, noise=False)
+    m, _ = g.findFrame(T, v, n, img, 100, interMap=False)
+    assert m.candidate == -1
+    g.close()
+
+
+def test_thumbnail_query_equals_texture_query(mods):
+    """Collaborative mode hands a remote camera's frame over as the thumbnail block of dms_fusion_thumbnails: the query
+    on the block must give what the query on the full-resolution textures gives; search_codes gives the same candidate."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    from densemonoslam_amd.capi import DeviceBuffer
+
+    g, o = make_pair(mods)
+    for k in range(0, 40, 4):
+        img, v, n, T = textures(fusion, synth, k)
+        g.addFrame(img, v, n, T, k, 0.02)
+    img, v, n, T = textures(fusion, synth, 18)
+    m1, c1 = g.findFrame(T, v, n, img, 577, interMap=False)
+    ti, tv, tn = o._thumbs(img, v, n)
+    block = DeviceBuffer(ti.nbytes + tv.nbytes + tn.nbytes)
+    block.upload(np.concatenate([ti.reshape(-1).view(np.uint8), tv.reshape(-1).view(np.uint8), tn.reshape(-1).view(np.uint8)]))
+    m2, c2 = g.findFrameThumbs(block.ptr, T, 577, interMap=False)
+    assert m1.candidate >= 0 and m1.blockHDAware > 0.3 and m1.icp_count > 100
+    for f in ("closest", "candidate", "dissimilarity", "blockHDAware", "icp_error", "icp_count", "photo_error", "n_constraints"):
+        assert np.array(getattr(m1, f)).tobytes() == np.array(getattr(m2, f)).tobytes(), f
+    assert bytes(m1.estPose) == bytes(m2.estPose) and c1.tobytes() == c2.tobytes()
+    # descriptor-only search (what travels between GPUs): same candidate and dissimilarity
+    codes, good = g.encode(img, v, n)
+    dc, dg, best = DeviceBuffer(512), DeviceBuffer(4), DeviceBuffer(8)
+    full = np.full(512, 255, np.uint8)
+    full[:500] = codes
+    dc.upload(full)
+    dg.upload(np.array([good], np.int32))
+    g.searchCodes(dc.ptr, dg.ptr, 577, False, best.ptr)
+    b = best.download(np.int32, (2,))
+    assert b[0] == m1.candidate and np.array([b[1]], np.int32).view(np.float32)[0] == np.float32(m1.dissimilarity)
+    g.close()
+
+
+def test_consume_reencodes_with_the_consumers_table(mods):
+    """Ferns::consume (map merge): the other database's frames, re-posed, go through addFrame of the consuming database —
+    re-encoded with ITS table (different seed here), accepted or rejected against its frames."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    ga, oa = make_pair(mods, seed=3)
+    gb, ob = make_pair(mods, seed=4)
+    for k in range(0, 24, 4):
+        img, v, n, T = textures(fusion, synth, k)
+        assert ga.addFrame(img, v, n, T, k, 0.02) == oa.addFrame(img, v, n, T, k, 0.02)
+    for k in range(12, 48, 4):
+        img, v, n, T = textures(fusion, synth, k)
+        assert gb.addFrame(img, v, n, T, 100 + k, 0.02) == ob.addFrame(img, v, n, T, 100 + k, 0.02)
+    rel = np.eye(4, dtype=np.float32)
+    rel[:3, 3] = (0.5, -0.25, 1.0)
+    na, no = ga.consume(gb, rel, 0.02), oa.consume(ob, rel, 0.02)
+    assert na == no and 0 < na <= len(ob.frames)
+    assert len(ga) == len(oa.frames)
+    for i, fr in enumerate(oa.frames):
+        pose, t, good, codes = ga.frame(i)
+        assert t == fr.srcTime and good == fr.goodCodes and (codes == fr.codes).all() and (pose == fr.pose).all(), i
+    ga.close()
+    gb.close()
