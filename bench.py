@@ -131,9 +131,19 @@ def main():
 
     # thumbnails exchanged in collaborative mode: W/8 x H/8 image + vertex + normal
     tw, th = W // 8, H // 8
-    exchange = collab.ThumbnailExchange(world, W, H, dev)
-    thumb = exchange.local
     import ctypes as C
+
+    # collaborative mode (N > 1): every camera publishes its frame block — fern descriptor + thumbnails — per frame;
+    # every rank keeps a fern database of its own key frames and searches it with the other cameras' descriptors
+    exchange = collab.ThumbnailExchange(world, W, H, dev, extra_bytes=collab.DESC_BYTES if distributed else 0)
+    thumb = exchange.local
+    matcher = None
+    if distributed:
+        from densemonoslam_amd import ferns as ferns_mod
+
+        fern_db = ferns_mod.Ferns(W, H, K, num=500, maxDepth_mm=3000, photoThresh=115.0, seed=20260929, capacity=4096)  # same table on every rank
+        matcher = collab.InterMapMatcher(fern_db, exchange, rank, world, dev, fern_threshold=0.3095,
+                                         verify_interval=int(os.environ.get("DMS_VERIFY_INTERVAL", "0")))
 
     # bounded run-ahead: the host never has more than `depth` frames enqueued beyond the one the GPU
     # is working on (what a live pipeline does anyway: frame t+depth does not exist yet)
@@ -151,9 +161,10 @@ def main():
             e.record()
             inflight.append(e)
         if distributed and exchange_thumbnails:
-            ef.thumbnails(exchange.begin().data_ptr(), stream)  # fill-in image / vertex / normal at W/8 x H/8, one launch
-            # the all-gather runs beside the next frame (its consumer, the inter-map matcher, works one frame behind)
-            exchange.gather(overlap=True)
+            # frame block (fill-in thumbnails + fern descriptor + pose from HBM), own key-frame database, all-gather beside
+            # the next frame; then the search of the local database with the descriptors gathered one frame earlier
+            prev = matcher.publish(ef, i + 1, stream)
+            matcher.match(prev, i + 1, stream)
 
     def barrier():
         exchange.finish()  # collectives still in flight belong to the timed region
@@ -203,7 +214,10 @@ def main():
             "loop_icp_count_last_frame": float(res.loop_icp_count) if args.loop_closure else None,
             "surfels_per_map": M,
             "surfels_total": M_total,
-            "exchange": "all-gather of %d-byte W/8xH/8 thumbnails per camera per frame" % thumb.numel() if distributed else "none (1 camera)",
+            "exchange": ("all-gather of one %d-byte frame block per camera per frame (592-byte fern descriptor + W/8xH/8 thumbnails), "
+                         "every rank searches its fern database (%d key frames on rank 0) with the other cameras' descriptors: "
+                         "%d remote descriptors found a candidate on rank 0, %d verified"
+                         % (thumb.numel(), len(fern_db), matcher.candidates, len(matcher.verified))) if distributed else "none (1 camera)",
         },
     }
 

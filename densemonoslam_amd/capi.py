@@ -90,6 +90,7 @@ def float3(a):
 
 
 lib.dms_stream_sync.argtypes = [C.c_void_p]
+lib.dms_memcpy_d2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
 lib.dms_stream_create.argtypes = [C.POINTER(C.c_void_p)]
 lib.dms_stream_destroy.argtypes = [C.c_void_p]
 

@@ -4,8 +4,12 @@ The reference runs its cameras one after the other in one process on one GPU
 (GUI/src/MainController.cpp:262-400) and has its inter-map matching compiled out
 (Core/src/ElasticFusion.cpp:597).  Here every rank owns the Context + ReferenceFrame of its
 cameras; nothing is shared until a map merge, so the data path needs no collective.  The only
-per-frame exchange is the all-gather of each camera's W/8 x H/8 thumbnails (image, vertex and
-normal maps), the inputs of the fern matcher (Core/src/Ferns.cpp:277-423) — SURVEY.md §8(e).
+per-frame exchange is the all-gather of each camera's frame block: its fern descriptor (the 500 codes
+of the shared fern table, good-code count, tick, pose: 592 bytes — what the inter-map search needs) and
+its W/8 x H/8 thumbnails (image, vertex and normal maps — what the verification of a candidate needs,
+Core/src/Ferns.cpp:277-423) — SURVEY.md §8(e).  `InterMapMatcher` is the consumer: every rank searches
+its own fern database with every other camera's descriptor (device only, one frame behind the
+all-gather) and verifies candidates with the thumbnail-sized tracker.
 `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests)
 carries it; PyTorch is plumbing here, not the product.
 
@@ -17,6 +21,10 @@ import torch
 import torch.distributed as dist
 
 THUMB_BYTES_PER_PIXEL = 4 + 16 + 16  # RGBA8 image + RGBA32F vertex + RGBA32F normal
+
+
+# fern descriptor appended to the thumbnails: codes[512] | goodCodes i32 | tick i32 | pose 16 x f32 | pad
+DESC_CODES, DESC_GOOD, DESC_TICK, DESC_POSE, DESC_BYTES = 0, 512, 516, 520, 592
 
 
 def thumbnail_bytes(width, height):
@@ -37,9 +45,10 @@ class ThumbnailExchange:
     stream wait for it — the matcher that consumes it runs a frame later — and `finish()` waits for
     whatever is still in flight."""
 
-    def __init__(self, world, width, height, device):
+    def __init__(self, world, width, height, device, extra_bytes=0):
         self.world = world
-        self.nbytes = thumbnail_bytes(width, height)
+        self.thumb_bytes = thumbnail_bytes(width, height)
+        self.nbytes = self.thumb_bytes + extra_bytes  # (thumb_bytes is a multiple of 16: the descriptor stays aligned)
         self.locals = [torch.zeros((self.nbytes,), dtype=torch.uint8, device=device) for _ in range(2)]
         self.gathereds = [torch.zeros((world, self.nbytes), dtype=torch.uint8, device=device) for _ in range(2)]
         self.work = [None, None]
@@ -131,3 +140,73 @@ def merge_remote_map(model, src, relative_transform, device):
         model.consumeRecords(rec.data_ptr(), count, relative_transform)
     return count
 
+
+
+class InterMapMatcher:
+    """Inter-map loop-closure search of collaborative mode (what ElasticFusion.cpp:595-632 does with every other map's
+    fern database, compiled out there): owner computes.
+
+    Per frame, on the frame's stream and without a host synchronisation:
+      publish()  packs this camera's frame block — thumbnails of the fill-in textures, fern codes of the SHARED table,
+                 tick and the pose read from HBM — offers the frame to the local database (Ferns::addFrame) and starts
+                 the all-gather;
+      match()    one frame later: searches the local database with every other camera's descriptor
+                 (dms_ferns_search_codes; results land in a pinned array the host reads a frame later).
+    Every `verify_interval` frames verify() runs the reference's full query (Ferns::findFrame with interMap = true: search,
+    code agreement, 3 x 50 ICP iterations at thumbnail size, photometric check) on each remote camera's latest block; that
+    call synchronises, like the reference's.  A verified match is what triggers a map merge (send_map / merge_remote_map)."""
+
+    def __init__(self, ferns, exchange, rank, world, device, fern_threshold=0.3095, verify_interval=0):
+        self.ferns, self.x, self.rank, self.world, self.device = ferns, exchange, rank, world, device
+        self.fern_threshold, self.verify_interval = fern_threshold, verify_interval
+        self.best_dev = torch.full((world, 2), -1, dtype=torch.int32, device=device)
+        self.best_host = torch.full((world, 2), -1, dtype=torch.int32).pin_memory() if device.type == "cuda" else torch.full((world, 2), -1, dtype=torch.int32)
+        self.prev = None  # (gathered tensor, work handle) of the previous publish
+        self.frames = 0
+        self.candidates = 0  # remote descriptors that found a candidate frame (from the host-visible results)
+        self.verified = []   # (frame, remote rank, FernMatch) of accepted verifications
+
+    def publish(self, ef, tick, stream):
+        blk = self.x.begin()
+        base, T = blk.data_ptr(), self.x.thumb_bytes
+        ef.thumbnails(base, stream)
+        self.ferns.encodeThumbs(base, base + T + DESC_CODES, base + T + DESC_GOOD, stream)
+        blk[T + DESC_TICK:T + DESC_TICK + 4].view(torch.int32).fill_(int(tick))
+        ef.exportPose(base + T + DESC_POSE, stream)  # 64 bytes, device to device, stream ordered
+        self.ferns.addFrameAsync(base, ef.poseDevice(), int(tick), self.fern_threshold, stream)
+        slot = self.x.slot
+        g = self.x.gather(overlap=True)
+        cur = (g, slot)
+        prev, self.prev = self.prev, cur
+        self.frames += 1
+        return prev
+
+    def match(self, prev, tick, stream):
+        """search the local database with the descriptors gathered by the PREVIOUS publish"""
+        if prev is None:
+            return
+        g, slot = prev
+        w = self.x.work[slot]
+        if w is not None:
+            w.wait()  # (stream-side wait; the collective had a whole frame to finish)
+        # results of the search enqueued a frame ago are on the host by now
+        self.candidates += int((self.best_host[:, 0] >= 0).sum())
+        T = self.x.thumb_bytes
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            p = g[r].data_ptr()
+            self.ferns.searchCodes(p + T + DESC_CODES, p + T + DESC_GOOD, int(tick), True, self.best_dev[r].data_ptr(), stream)
+        self.best_host.copy_(self.best_dev, non_blocking=True)
+        if self.verify_interval and self.frames % self.verify_interval == 0:
+            self.verify(g, tick, stream)
+
+    def verify(self, g, tick, stream):
+        T = self.x.thumb_bytes
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            pose = g[r][T + DESC_POSE:T + DESC_POSE + 64].view(torch.float32).cpu().numpy()  # synchronises
+            m, cons = self.ferns.findFrameThumbs(g[r].data_ptr(), pose, int(tick), False, True, stream)
+            if m.closest >= 0:
+                self.verified.append((self.frames, r, m))

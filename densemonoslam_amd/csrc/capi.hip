@@ -74,6 +74,10 @@ int dms_memcpy_d2h(void* dst, const void* src, size_t bytes, dms_stream s) {
   DMS_HIP(hipStreamSynchronize(S(s)));
   return DMS_OK;
 }
+int dms_memcpy_d2d_async(void* dst, const void* src, size_t bytes, dms_stream s) {
+  DMS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)));
+  return DMS_OK;
+}
 int dms_memset(void* dst, int value, size_t bytes, dms_stream s) {
   DMS_HIP(hipMemsetAsync(dst, value, bytes, S(s)));
   return DMS_OK;

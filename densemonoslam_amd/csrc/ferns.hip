@@ -29,11 +29,17 @@ struct FernTable {  // device copy of the conservatory
   int r[kFernPad], g[kFernPad], b[kFernPad], d[kFernPad];
 };
 
+struct Pose16f {
+  float v[16];
+};
+
 struct FernHost {  // pinned result block of one query
   unsigned long long best;  // dissimilarity bits << 32 | frame id; all ones = none
   int good;                 // goodCodes of the query frame
   int hd_count, hd_equal;   // blockHDAware against the best frame
-  int pad;
+  int slot;                 // addFrame: database slot the staged frame went to, -1 = rejected, -2 = database full
+  int n;                    // frames in the database after this operation
+  int pad[3];
   float4 vert[kFernPad];    // vertSmall at the fern positions
   uchar4 rgb[kFernPad];     // imgSmall at the fern positions
 };
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(kFernPad) void k_fern_encode(const unsigned char* _
       res->best = ~0ull;
       res->hd_count = 0;
       res->hd_equal = 0;
+      res->slot = -1;
     }
   }
 }
@@ -99,12 +106,13 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 
 // minimum dissimilarity over the stored frames (Ferns.cpp:235-248 / 327-339): one wavefront per frame
 __global__ __launch_bounds__(256) void k_fern_search(const unsigned char* __restrict__ db_codes, const int* __restrict__ db_good,
-                                                     const int* __restrict__ db_time, int n, const unsigned char* __restrict__ cur_codes,
+                                                     const int* __restrict__ db_time, const int* __restrict__ n_dev,
+                                                     const unsigned char* __restrict__ cur_codes,
                                                      const int* __restrict__ cur_good, int time, int all_frames,
                                                      unsigned long long* __restrict__ best) {
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= n) return;
+  if (j >= *n_dev) return;  // (the grid is sized from the host's upper bound of the count)
   const unsigned long long mine = reinterpret_cast<const unsigned long long*>(cur_codes)[lane];
   const unsigned long long theirs = reinterpret_cast<const unsigned long long*>(db_codes + (size_t)j * kFernPad)[lane];
   int co = 0;
@@ -147,9 +155,39 @@ __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __res
   }
 }
 
-// append the staged frame to the database: slot = n
+// addFrame's decision (Ferns.cpp:235-275) on the device: (minimum > threshold || empty) && goodCodes > 0 -> the
+// staged frame takes slot n; its metadata is written here, its payload by k_fern_commit
+__global__ void k_fern_decide(FernHost* __restrict__ res, int* __restrict__ n_dev, int capacity, float threshold, int srcTime,
+                              const float* __restrict__ pose_dev, Pose16f pose_host, int* __restrict__ db_good, int* __restrict__ db_time,
+                              float* __restrict__ db_pose) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = *n_dev;
+  float minimum = 3.402823466e+38F;
+  if (res->good > 0 && res->best != ~0ull) minimum = __uint_as_float((unsigned)(res->best >> 32));
+  int slot = -1;
+  if ((minimum > threshold || n == 0) && res->good > 0) {
+    if (n >= capacity) {
+      slot = -2;
+    } else {
+      slot = n;
+      db_good[n] = res->good;
+      db_time[n] = srcTime;
+      for (int i = 0; i < 16; ++i) db_pose[(size_t)n * 16 + i] = pose_dev ? pose_dev[i] : pose_host.v[i];
+      *n_dev = n + 1;
+    }
+  }
+  res->slot = slot;
+  res->n = *n_dev;
+}
+
+// payload of an accepted frame -> its slot
 __global__ __launch_bounds__(256) void k_fern_commit(const unsigned char* __restrict__ cur_block, const unsigned char* __restrict__ cur_codes,
-                                                     size_t block_bytes, unsigned char* __restrict__ db_block, unsigned char* __restrict__ db_codes) {
+                                                     size_t block_bytes, unsigned char* __restrict__ db_blocks, unsigned char* __restrict__ db_codes_all,
+                                                     const FernHost* __restrict__ res) {
+  const int slot = res->slot;
+  if (slot < 0) return;
+  unsigned char* db_block = db_blocks + (size_t)slot * block_bytes;
+  unsigned char* db_codes = db_codes_all + (size_t)slot * kFernPad;
   const size_t n16 = block_bytes / 16;
   for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n16; k += (size_t)blockDim.x * gridDim.x)
     reinterpret_cast<uint4*>(db_block)[k] = reinterpret_cast<const uint4*>(cur_block)[k];
@@ -201,12 +239,16 @@ struct Mt19937 {
 using namespace dms;
 
 struct dms_ferns {
-  int num = 0, W = 0, H = 0, tw = 0, th = 0, maxDepth = 0, capacity = 0, n = 0;
+  int num = 0, W = 0, H = 0, tw = 0, th = 0, maxDepth = 0, capacity = 0;
+  int n_upper = 0;  // host-side upper bound of the number of stored frames (the count itself lives on the device)
   float photoThresh = 0.f;
   float cx = 0, cy = 0, fx = 0, fy = 0;  // full resolution
   std::vector<int> pos, rgbd;            // host table: [num][2], [num][4]
-  std::vector<float> poses;              // [capacity][16]
-  std::vector<int> times, goods;         // host mirrors of the per-frame metadata
+  std::vector<float> poses;              // [capacity][16]   host mirrors of the per-frame metadata,
+  std::vector<int> times, goods;         //                  refreshed by mirror() (synchronises)
+  int n_host = 0;                        // frames the mirrors hold
+  int* d_n = nullptr;                    // number of stored frames
+  float* d_pose = nullptr;               // [capacity][16]
   size_t block_bytes = 0;
   char* arena = nullptr;
   FernTable* d_tab = nullptr;
@@ -266,9 +308,10 @@ int stage(dms_ferns* f, const dms_image2d* image, const dms_image2d* vertex, con
   return DMS_OK;
 }
 
-int search(dms_ferns* f, int time, int all_frames, bool with_hd, hipStream_t s) {
-  if (f->n > 0) {
-    hipLaunchKernelGGL(k_fern_search, dim3((f->n + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->n, f->d_cur_codes,
+// dissimilarity search of the staged codes (grid from the host's bound of the count; the kernel reads the count itself)
+int search_enqueue(dms_ferns* f, int time, int all_frames, bool with_hd, hipStream_t s) {
+  if (f->n_upper > 0) {
+    hipLaunchKernelGGL(k_fern_search, dim3((f->n_upper + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n, f->d_cur_codes,
                        &f->d_res->good, time, all_frames, &f->d_res->best);
     DMS_CHECK_LAUNCH();
     if (with_hd) {
@@ -276,37 +319,55 @@ int search(dms_ferns* f, int time, int all_frames, bool with_hd, hipStream_t s) 
       DMS_CHECK_LAUNCH();
     }
   }
+  return DMS_OK;
+}
+
+int fetch_result(dms_ferns* f, hipStream_t s) {
   DMS_HIP(hipMemcpyAsync(f->h_res, f->d_res, sizeof(FernHost), hipMemcpyDeviceToHost, s));
   DMS_HIP(hipStreamSynchronize(s));
   return DMS_OK;
 }
 
-// decision of addFrame on the staged frame (Ferns.cpp:235-275)
-int decide_add(dms_ferns* f, const float* pose16, int srcTime, float threshold, int* added, hipStream_t s) {
-  const FernHost* r = f->h_res;
-  float minimum = 3.402823466e+38F;
-  if (r->good > 0 && r->best != ~0ull) {
-    const unsigned bits = (unsigned)(r->best >> 32);
-    memcpy(&minimum, &bits, 4);
+// addFrame on the staged frame, without a host synchronisation: search, decision and commit are stream ordered
+int add_enqueue(dms_ferns* f, const float* pose16_host, const float* pose16_dev, int srcTime, float threshold, hipStream_t s) {
+  int rc = search_enqueue(f, 0, 1, false, s);
+  if (rc) return rc;
+  Pose16f ph;
+  memset(&ph, 0, sizeof(ph));
+  if (pose16_host) memcpy(ph.v, pose16_host, sizeof(ph.v));
+  hipLaunchKernelGGL(k_fern_decide, dim3(1), dim3(64), 0, s, f->d_res, f->d_n, f->capacity, threshold, srcTime, pose16_dev, ph, f->d_good,
+                     f->d_time, f->d_pose);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_fern_commit, dim3(64), dim3(256), 0, s, f->d_cur_block, f->d_cur_codes, f->block_bytes, f->d_blocks, f->d_codes,
+                     f->d_res);
+  DMS_CHECK_LAUNCH();
+  if (f->n_upper < f->capacity) f->n_upper += 1;
+  return DMS_OK;
+}
+
+// host mirrors of count and per-frame metadata (synchronises)
+int mirror(dms_ferns* f, hipStream_t s) {
+  DMS_HIP(hipMemcpyAsync(&f->n_host, f->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
+  const int n = f->n_host;
+  f->n_upper = n;
+  if (n > 0) {
+    DMS_HIP(hipMemcpyAsync(f->goods.data(), f->d_good, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    DMS_HIP(hipMemcpyAsync(f->times.data(), f->d_time, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    DMS_HIP(hipMemcpyAsync(f->poses.data(), f->d_pose, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToHost, s));
+    DMS_HIP(hipStreamSynchronize(s));
   }
-  *added = 0;
-  if ((minimum > threshold || f->n == 0) && r->good > 0) {
-    if (f->n >= f->capacity) {
-      set_error("dms_ferns: the database is full (%d frames)", f->capacity);
-      return DMS_ERR_CAPACITY;
-    }
-    const int slot = f->n;
-    hipLaunchKernelGGL(k_fern_commit, dim3(64), dim3(256), 0, s, f->d_cur_block, f->d_cur_codes, f->block_bytes,
-                       f->d_blocks + (size_t)slot * f->block_bytes, f->d_codes + (size_t)slot * kFernPad);
-    DMS_CHECK_LAUNCH();
-    f->goods[slot] = r->good;
-    f->times[slot] = srcTime;
-    memcpy(&f->poses[(size_t)slot * 16], pose16, 16 * sizeof(float));
-    DMS_HIP(hipMemcpyAsync(f->d_good + slot, &f->goods[slot], sizeof(int), hipMemcpyHostToDevice, s));
-    DMS_HIP(hipMemcpyAsync(f->d_time + slot, &f->times[slot], sizeof(int), hipMemcpyHostToDevice, s));
-    DMS_HIP(hipStreamSynchronize(s));  // (the sources are host vectors)
-    f->n += 1;
-    *added = 1;
+  return DMS_OK;
+}
+
+int add_result(dms_ferns* f, int* added, hipStream_t s) {
+  int rc = fetch_result(f, s);
+  if (rc) return rc;
+  f->n_upper = f->h_res->n;  // exact again
+  *added = f->h_res->slot >= 0 ? 1 : 0;
+  if (f->h_res->slot == -2) {
+    set_error("dms_ferns: the database is full (%d frames)", f->capacity);
+    return DMS_ERR_CAPACITY;
   }
   return DMS_OK;
 }
@@ -350,7 +411,8 @@ int find_common(dms_ferns* f, const float* currPose16, int time, int lost, int i
   m->closest = -1;
   m->candidate = -1;
   for (int i = 0; i < 16; ++i) m->estPose[i] = (i % 5 == 0) ? 1.f : 0.f;
-  if ((rc = search(f, time, interMap ? 1 : 0, true, s))) return rc;
+  if ((rc = search_enqueue(f, time, interMap ? 1 : 0, true, s))) return rc;
+  if ((rc = fetch_result(f, s))) return rc;
   const FernHost* r = f->h_res;
   if (r->best == ~0ull) return DMS_OK;
   const int minId = (int)(r->best & 0xFFFFFFFFull);
@@ -361,7 +423,9 @@ int find_common(dms_ferns* f, const float* currPose16, int time, int lost, int i
   if (!(m->blockHDAware > 0.3f)) return DMS_OK;
 
   // geometric verification with the thumbnail-sized tracker (Ferns.cpp:344-381)
-  const float* fernPose = &f->poses[(size_t)minId * 16];
+  float fernPose[16];
+  DMS_HIP(hipMemcpyAsync(fernPose, f->d_pose + (size_t)minId * 16, sizeof(fernPose), hipMemcpyDeviceToHost, s));
+  DMS_HIP(hipStreamSynchronize(s));
   const size_t n = (size_t)f->tw * f->th;
   const unsigned char* fb = f->d_blocks + (size_t)minId * f->block_bytes;
   const float cutoff = (float)f->maxDepth / 1000.0f;
@@ -457,7 +521,7 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
   };
   const size_t o_tab = take(sizeof(FernTable)), o_codes = take((size_t)capacity * kFernPad), o_good = take((size_t)capacity * 4),
                o_time = take((size_t)capacity * 4), o_blocks = take((size_t)capacity * f->block_bytes), o_cur = take(f->block_bytes),
-               o_cc = take(kFernPad), o_res = take(sizeof(FernHost));
+               o_cc = take(kFernPad), o_res = take(sizeof(FernHost)), o_n = take(64), o_pose = take((size_t)capacity * 64);
   hipError_t e = hipMalloc((void**)&f->arena, up256(off));
   if (e == hipSuccess) e = hipMemset(f->arena, 0, up256(off));
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_res, sizeof(FernHost), hipHostMallocDefault);
@@ -476,6 +540,8 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
   f->d_cur_block = (unsigned char*)(f->arena + o_cur);
   f->d_cur_codes = (unsigned char*)(f->arena + o_cc);
   f->d_res = (FernHost*)(f->arena + o_res);
+  f->d_n = (int*)(f->arena + o_n);
+  f->d_pose = (float*)(f->arena + o_pose);
   e = hipMemcpy(f->d_tab, &tab, sizeof(tab), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(f->d_codes, DMS_FERN_BAD_CODE, (size_t)capacity * kFernPad);
   int rc = e == hipSuccess ? DMS_OK : hip_fail(e, "dms_ferns_create upload", __FILE__, __LINE__);
@@ -506,10 +572,17 @@ int dms_ferns_get_table(dms_ferns* f, int* pos2, int* rgbd4) {
   return DMS_OK;
 }
 
-int dms_ferns_num_frames(dms_ferns* f) { return f ? f->n : 0; }
+int dms_ferns_num_frames(dms_ferns* f) {
+  if (!f) return 0;
+  if (mirror(f, nullptr)) return -1;
+  return f->n_host;
+}
 
 int dms_ferns_get_frame(dms_ferns* f, int id, float* pose16, int* srcTime, int* goodCodes, unsigned char* codes) {
-  DMS_REQUIRE(f && id >= 0 && id < f->n, "bad frame id");
+  DMS_REQUIRE(f, "null argument");
+  int rc = mirror(f, nullptr);
+  if (rc) return rc;
+  DMS_REQUIRE(id >= 0 && id < f->n_host, "bad frame id");
   if (pose16) memcpy(pose16, &f->poses[(size_t)id * 16], 16 * sizeof(float));
   if (srcTime) *srcTime = f->times[id];
   if (goodCodes) *goodCodes = f->goods[id];
@@ -528,14 +601,34 @@ int dms_ferns_encode(dms_ferns* f, const dms_image2d* image_rgba, const dms_imag
   return DMS_OK;
 }
 
+int dms_ferns_encode_thumbs(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, dms_stream st) {
+  DMS_REQUIRE(f && thumb_block_dev && codes_dev && good_dev, "null argument");
+  DMS_REQUIRE(((uintptr_t)thumb_block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  // straight from the caller's block into the caller's descriptor: nothing of the handle's staging area is touched
+  hipLaunchKernelGGL(k_fern_encode, dim3(1), dim3(kFernPad), 0, (hipStream_t)st, (const unsigned char*)thumb_block_dev, f->tw, f->th, f->d_tab,
+                     f->num, codes_dev, good_dev, (FernHost*)nullptr);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
 int dms_ferns_add_frame(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal, const float* pose16,
                         int srcTime, float threshold, int* added, dms_stream st) {
   DMS_REQUIRE(f && pose16 && added, "null argument");
   hipStream_t s = (hipStream_t)st;
   int rc = stage(f, image_rgba, vertex, normal, nullptr, s);
-  if (!rc) rc = search(f, 0, 1, false, s);
+  if (!rc) rc = add_enqueue(f, pose16, nullptr, srcTime, threshold, s);
   if (rc) return rc;
-  return decide_add(f, pose16, srcTime, threshold, added, s);
+  return add_result(f, added, s);
+}
+
+int dms_ferns_add_frame_async(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal,
+                              const void* thumb_block_dev, const float* pose16_host, const float* pose16_dev, int srcTime, float threshold,
+                              dms_stream st) {
+  DMS_REQUIRE(f && (pose16_host || pose16_dev), "null argument");
+  hipStream_t s = (hipStream_t)st;
+  int rc = stage(f, image_rgba, vertex, normal, thumb_block_dev, s);
+  if (rc) return rc;
+  return add_enqueue(f, pose16_host, pose16_dev, srcTime, threshold, s);
 }
 
 int dms_ferns_find_frame(dms_ferns* f, const dms_image2d* vertex, const dms_image2d* normal, const dms_image2d* image_rgba,
@@ -564,9 +657,9 @@ int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const i
   hipStream_t s = (hipStream_t)st;
   // (the codes are read as 64 x 8 bytes: the caller's buffer holds DMS_FERN_MAX bytes, entries past num = the bad code)
   DMS_HIP(hipMemsetAsync(best2_dev, 0xFF, 8, s));
-  if (f->n > 0) {
-    hipLaunchKernelGGL(k_fern_search, dim3((f->n + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->n, codes_dev, good_dev, time,
-                       interMap ? 1 : 0, (unsigned long long*)best2_dev);
+  if (f->n_upper > 0) {
+    hipLaunchKernelGGL(k_fern_search, dim3((f->n_upper + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n, codes_dev, good_dev,
+                       time, interMap ? 1 : 0, (unsigned long long*)best2_dev);
     DMS_CHECK_LAUNCH();
   }
   return DMS_OK;
@@ -577,13 +670,15 @@ int dms_ferns_consume(dms_ferns* dst, dms_ferns* src, const float* T16, float th
   DMS_REQUIRE(dst->tw == src->tw && dst->th == src->th, "databases of different thumbnail size");
   hipStream_t s = (hipStream_t)st;
   *added = 0;
-  for (int j = 0; j < src->n; ++j) {
+  int rc = mirror(src, s);
+  if (rc) return rc;
+  for (int j = 0; j < src->n_host; ++j) {
     float pose[16];
     mul44(T16, &src->poses[(size_t)j * 16], pose);  // frame->pose = relativeTransform * frame->pose (Ferns.cpp:164)
-    int rc = stage(dst, nullptr, nullptr, nullptr, src->d_blocks + (size_t)j * src->block_bytes, s);
-    if (!rc) rc = search(dst, 0, 1, false, s);
+    rc = stage(dst, nullptr, nullptr, nullptr, src->d_blocks + (size_t)j * src->block_bytes, s);
+    if (!rc) rc = add_enqueue(dst, pose, nullptr, src->times[j], threshold, s);
     int one = 0;
-    if (!rc) rc = decide_add(dst, pose, src->times[j], threshold, &one, s);
+    if (!rc) rc = add_result(dst, &one, s);
     if (rc) return rc;
     *added += one;
   }

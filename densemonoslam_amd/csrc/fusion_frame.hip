@@ -561,6 +561,7 @@ int dms_fusion_inputs_consumed(dms_fusion* f, dms_stream st) {
 }
 
 dms_model* dms_fusion_model(dms_fusion* f) { return f ? f->model : nullptr; }
+const float* dms_fusion_pose_device(dms_fusion* f) { return f ? f->state->cur.pose : nullptr; }
 dms_odometry* dms_fusion_odometry(dms_fusion* f) { return f ? f->odom : nullptr; }
 
 int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_channels, const unsigned short* depth_dev,

@@ -26,6 +26,8 @@ lib.dms_ferns_add_frame.argtypes = [_P, _I2, _I2, _I2, C.POINTER(_F), _I, _F, C.
 lib.dms_ferns_find_frame.argtypes = [_P, _I2, _I2, _I2, C.POINTER(_F), _I, _I, _I, C.POINTER(FernMatch), C.POINTER(_F), _P]
 lib.dms_ferns_find_frame_thumbs.argtypes = [_P, _P, C.POINTER(_F), _I, _I, _I, C.POINTER(FernMatch), C.POINTER(_F), _P]
 lib.dms_ferns_search_codes.argtypes = [_P, _P, _P, _I, _I, _P, _P]
+lib.dms_ferns_add_frame_async.argtypes = [_P, _I2, _I2, _I2, _P, C.POINTER(_F), _P, _I, _F, _P]
+lib.dms_ferns_encode_thumbs.argtypes = [_P, _P, _P, _P, _P]
 lib.dms_ferns_consume.argtypes = [_P, _P, C.POINTER(_F), _F, C.POINTER(_I), _P]
 
 
@@ -96,6 +98,15 @@ class Ferns:
         check(lib.dms_ferns_add_frame(self.h, C.byref(vi), C.byref(vv), C.byref(vn), p.ctypes.data_as(C.POINTER(_F)), srcTime, threshold,
                                       C.byref(added), stream), "dms_ferns_add_frame")
         return bool(added.value)
+
+    def addFrameAsync(self, block_ptr, pose_dev_ptr, srcTime, threshold, stream=None):
+        """addFrame of a thumbnail block with the pose read from HBM; no host synchronisation."""
+        check(lib.dms_ferns_add_frame_async(self.h, None, None, None, C.c_void_p(block_ptr), None, C.c_void_p(pose_dev_ptr), srcTime, threshold,
+                                            stream), "dms_ferns_add_frame_async")
+
+    def encodeThumbs(self, block_ptr, codes_ptr, good_ptr, stream=None):
+        check(lib.dms_ferns_encode_thumbs(self.h, C.c_void_p(block_ptr), C.c_void_p(codes_ptr), C.c_void_p(good_ptr), stream),
+              "dms_ferns_encode_thumbs")
 
     def findFrame(self, currPose, vertex, normal, image, time, lost=False, interMap=False, stream=None):
         keep, (vi, vv, vn) = self._tex(image, vertex, normal)

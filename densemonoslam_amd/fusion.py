@@ -92,6 +92,8 @@ lib.dms_fusion_model.argtypes = [_P]
 lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
 lib.dms_fusion_odometry.restype = _P
+lib.dms_fusion_pose_device.argtypes = [_P]
+lib.dms_fusion_pose_device.restype = _P
 lib.dms_model_sample_graph.argtypes = [_P, _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_int), _P]
 lib.dms_fusion_thumbnails.argtypes = [_P, _P, _P]
 lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
@@ -421,6 +423,14 @@ class ElasticFusion:
         """(status, result): like fetch, but hands DMS_ERR_CAPACITY / DMS_ERR_TIMEOUT back with the (valid) result."""
         r = FrameResult()
         return int(lib.dms_fusion_fetch(self.h, C.byref(r), stream)), r
+
+    def poseDevice(self):
+        """device address of the 4x4 pose the frame step keeps in HBM"""
+        return int(lib.dms_fusion_pose_device(self.h))
+
+    def exportPose(self, dst_ptr, stream=None):
+        """copy the pose (16 floats) from its place in HBM to device memory at dst_ptr, stream ordered"""
+        check(lib.dms_memcpy_d2d_async(C.c_void_p(dst_ptr), C.c_void_p(self.poseDevice()), 64, stream), "dms_memcpy_d2d_async")
 
     def odometryHandle(self):
         return C.c_void_p(lib.dms_fusion_odometry(self.h))

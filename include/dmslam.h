@@ -103,6 +103,7 @@ int dms_device_alloc(void** ptr, size_t bytes);
 int dms_device_free(void* ptr);
 int dms_memcpy_h2d(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memcpy_d2h(void* dst, const void* src, size_t bytes, dms_stream s);
+int dms_memcpy_d2d_async(void* dst, const void* src, size_t bytes, dms_stream s); /* stream ordered, no synchronisation */
 int dms_memset(void* dst, int value, size_t bytes, dms_stream s);
 /* free / total HBM of the current device (hipMemGetInfo): sizing maps against the 288 GB, leak checks */
 int dms_mem_info(size_t* free_bytes, size_t* total_bytes);

@@ -52,6 +52,17 @@ int dms_ferns_encode(dms_ferns* f, const dms_image2d* image_rgba, const dms_imag
 int dms_ferns_add_frame(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal,
                         const float* pose16, int srcTime, float threshold, int* added, dms_stream s);
 
+/* The same without a host synchronisation (the frame loop of a pipelined caller): search, decision and commit are
+ * stream ordered on `s`; the count and the per-frame metadata live on the device (dms_ferns_num_frames /
+ * dms_ferns_get_frame synchronise to read them).  Frame = full-resolution textures, or a thumbnail block
+ * (thumb_block_dev != NULL, textures ignored).  Pose = host matrix or, for callers whose pose never leaves HBM, a
+ * device pointer to 16 floats (pose16_dev, read when the kernel runs). */
+int dms_ferns_add_frame_async(dms_ferns* f, const dms_image2d* image_rgba, const dms_image2d* vertex, const dms_image2d* normal,
+                              const void* thumb_block_dev, const float* pose16_host, const float* pose16_dev, int srcTime, float threshold,
+                              dms_stream s);
+/* descriptor of a frame that already is a thumbnail block; touches nothing of the handle's state (any stream) */
+int dms_ferns_encode_thumbs(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, dms_stream s);
+
 typedef struct dms_fern_match {
   int closest;            /* Ferns::lastClosest: accepted frame id or -1 */
   int candidate;          /* minId of the dissimilarity search (-1: none eligible) */

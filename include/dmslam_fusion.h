@@ -288,6 +288,10 @@ int dms_fusion_fetch_loop(dms_fusion* f, dms_frame_result* r, dms_stream s);
 int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int graph_nodes, const float* newPose16, dms_stream s);
 
 dms_model* dms_fusion_model(dms_fusion* f);
+/* Device address of the camera pose (16 floats, row-major, camera-to-world) the frame step keeps in HBM: valid for the
+ * life of the context, written by the tracker's last kernel — stream-ordered consumers (e.g. dms_ferns_add_frame_async)
+ * read it without a host round trip. */
+const float* dms_fusion_pose_device(dms_fusion* f);
 dms_odometry* dms_fusion_odometry(dms_fusion* f);
 /* device images owned by the context; which: 0 rgb(rgba8) 1 depth_raw 2 depth_filtered 3 depth_metric
  * 4 depth_metric_filtered 5 index 6 vertConf 7 colorTime 8 normRad 9 pred image 10 pred vertex

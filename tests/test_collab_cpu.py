@@ -178,3 +178,124 @@ def test_camera_sharding():
     assert collab.shard_cameras(4, 1, 2) == [1, 3]
     assert sorted(sum((collab.shard_cameras(5, r, 2) for r in range(2)), [])) == [0, 1, 2, 3, 4]
     assert collab.thumbnail_bytes(640, 480) == 80 * 60 * 36
+
+
+# ---- the inter-map matcher's per-frame protocol, world size 2 on gloo ----------------------------------------
+class _CpuCamera:
+    """stand-in for fusion.ElasticFusion on a CPU rank: hands out this camera's thumbnails and pose"""
+
+    def __init__(self, cam, W, H):
+        import ctypes
+
+        self.ct, self.cam, self.W, self.H = ctypes, cam, W, H
+        self.pose = np.eye(4, dtype=np.float32)
+        self.pose[:3, 3] = (cam, 0.5, -0.25)
+        self.block = _thumbs_for_camera(cam, W, H)
+
+    def thumbnails(self, ptr, stream):
+        self.ct.memmove(ptr, self.block.ctypes.data, self.block.nbytes)
+
+    def poseDevice(self):
+        return self.pose.ctypes.data
+
+    def exportPose(self, ptr, stream):
+        self.ct.memmove(ptr, self.pose.ctypes.data, 64)
+
+
+class _CpuFerns:
+    """stand-in for ferns.Ferns built on the CPU restatement (oracle/orc_ferns.py), same call surface"""
+
+    def __init__(self, W, H, seed):
+        import ctypes
+        from oracle import orc_ferns
+
+        self.ct = ctypes
+        self.o = orc_ferns.Ferns(W, H, (0.825 * W, 0.825 * W, W / 2.0, H / 2.0), seed=seed)
+        self.tw, self.th = W // 8, H // 8
+        self.searches = []
+
+    def _unpack(self, ptr):
+        n = self.tw * self.th
+        raw = np.ctypeslib.as_array((self.ct.c_ubyte * (n * 36)).from_address(ptr)).copy()
+        return (raw[:n * 4].reshape(self.th, self.tw, 4), raw[n * 4:n * 20].view(np.float32).reshape(self.th, self.tw, 4),
+                raw[n * 20:].view(np.float32).reshape(self.th, self.tw, 4))
+
+    def encodeThumbs(self, ptr, codes_ptr, good_ptr, stream):
+        img, v, _ = self._unpack(ptr)
+        codes, good, _ = self.o._encode(img, v)
+        full = np.full(512, 255, np.uint8)
+        full[:len(codes)] = codes
+        self.ct.memmove(codes_ptr, full.ctypes.data, 512)
+        self.ct.memmove(good_ptr, np.array([good], np.int32).ctypes.data, 4)
+
+    def addFrameAsync(self, ptr, pose_ptr, tick, thr, stream):
+        img, v, n = self._unpack(ptr)
+        pose = np.ctypeslib.as_array((self.ct.c_float * 16).from_address(pose_ptr)).copy()
+        self.o._add(img, v, n, pose, tick, thr)
+
+    def searchCodes(self, codes_ptr, good_ptr, tick, interMap, best_ptr, stream):
+        codes = np.ctypeslib.as_array((self.ct.c_ubyte * 512).from_address(codes_ptr)).copy()[:self.o.num]
+        good = int(np.ctypeslib.as_array((self.ct.c_int * 1).from_address(good_ptr))[0])
+        best, bid = np.float32(3.4e38), -1
+        for i, fr in enumerate(self.o.frames):
+            co = int(((codes == fr.codes) & (codes != 255)).sum())
+            m = np.float32(min(good, fr.goodCodes))
+            d = np.float32(m - np.float32(co)) / m
+            if d < best:
+                best, bid = d, i
+        out = np.array([bid, np.array([best], np.float32).view(np.int32)[0] if bid >= 0 else -1], np.int32)
+        self.ct.memmove(best_ptr, out.ctypes.data, 8)
+        self.searches.append((tick, bid, float(best)))
+
+
+def _matcher_worker(rank, world, port, W, H, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from densemonoslam_amd import collab
+
+    dev = torch.device("cpu")
+    ex = collab.ThumbnailExchange(world, W, H, dev, extra_bytes=collab.DESC_BYTES)
+    cam, ferns = _CpuCamera(rank, W, H), _CpuFerns(W, H, seed=99)
+    m = collab.InterMapMatcher(ferns, ex, rank, world, dev, fern_threshold=0.3)
+    seen = []
+    for tick in range(1, 5):
+        prev = m.publish(cam, tick, None)
+        m.match(prev, tick, None)
+        if prev is not None:
+            g = prev[0]
+            T = ex.thumb_bytes
+            other = 1 - rank
+            seen.append((int(g[other][T + collab.DESC_TICK:T + collab.DESC_TICK + 4].view(torch.int32)[0]),
+                         g[other][T + collab.DESC_POSE:T + collab.DESC_POSE + 64].view(torch.float32).numpy().copy(),
+                         int(g[other][T + collab.DESC_GOOD:T + collab.DESC_GOOD + 4].view(torch.int32)[0])))
+    ex.finish()
+    out.put((rank, seen, ferns.searches, len(ferns.o.frames), m.best_host.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_intermap_matcher_protocol_gloo():
+    """Descriptor + thumbnails of each camera reach the other rank one frame later (tick, pose, good-code count intact),
+    every rank searches its own fern database with the remote descriptor, and the own frame is offered to the local
+    database each frame.  Both cameras see the same synthetic room from different places."""
+    world, W, H = 2, 320, 240
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_matcher_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r[0]: r for r in [q.get(timeout=240) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        _, seen, searches, nframes, best = results[rank]
+        other = 1 - rank
+        assert [s[0] for s in seen] == [1, 2, 3]  # the remote descriptor of tick t is consumed at tick t + 1
+        for tick, pose, good in seen:
+            assert pose.reshape(4, 4)[0, 3] == float(other) and good > 0
+        assert nframes == 1  # the static camera's first frame is a key frame, the identical later ones are rejected
+        assert len(searches) == 3 and all(s[1] == 0 for s in searches)  # one stored frame: it is the candidate
+        assert best[other, 0] == 0 and best[rank, 0] == -1

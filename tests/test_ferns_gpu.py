@@ -188,3 +188,43 @@ def test_consume_reencodes_with_the_consumers_table(mods):
         assert t == fr.srcTime and good == fr.goodCodes and (codes == fr.codes).all() and (pose == fr.pose).all(), i
     ga.close()
     gb.close()
+
+
+def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
+    """What collab.InterMapMatcher enqueues per frame — thumbnails of the frame step's fill-in textures, descriptor
+    (dms_ferns_encode_thumbs), addFrame without a host synchronisation with the pose read from HBM, descriptor search
+    of another camera's block — against the synchronous calls on the same inputs: same database, same candidates."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    from densemonoslam_amd.capi import DeviceBuffer
+    from densemonoslam_amd import collab
+
+    ef = fusion.ElasticFusion(W, H, K, model_capacity=2_000_000)
+    ga, gs = ferns.Ferns(W, H, K, seed=5), ferns.Ferns(W, H, K, seed=5)
+    T = collab.thumbnail_bytes(W, H)
+    blocks = []
+    for k in range(8):
+        d, rgb, _ = synth.frame(3 * k, width=W, height=H, K=K, noise=True)
+        r = ef.processFrame(rgb, d)
+        blk = DeviceBuffer(T + collab.DESC_BYTES)
+        ef.thumbnails(blk.ptr)
+        ga.encodeThumbs(blk.ptr, blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD)
+        ga.addFrameAsync(blk.ptr, ef.poseDevice(), k + 1, 0.1)
+        # the synchronous reference call on the fill-in textures themselves
+        img, vert, nrm = ef.image(13), ef.image(14), ef.image(15)
+        gs.addFrame(img, vert, nrm, np.array(r.pose, np.float32), k + 1, 0.1)
+        blocks.append(blk)
+    assert len(ga) == len(gs) >= 3
+    for i in range(len(gs)):
+        pa, ta, ga_, ca = ga.frame(i)
+        ps, ts, gs_, cs = gs.frame(i)
+        assert ta == ts and ga_ == gs_ and (ca == cs).all() and (pa == ps).all(), i
+    # descriptor search of a block == candidate of the full synchronous query on the same block
+    best = DeviceBuffer(8)
+    for blk in blocks[::3]:
+        ga.searchCodes(blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD, 1000, True, best.ptr)
+        b = best.download(np.int32, (2,))
+        m, _ = gs.findFrameThumbs(blk.ptr, np.eye(4, dtype=np.float32), 1000, interMap=True)
+        assert b[0] == m.candidate and np.array([b[1]], np.int32).view(np.float32)[0] == np.float32(m.dissimilarity)
+    ga.close()
+    gs.close()
+    ef.close()
