@@ -124,7 +124,8 @@ def main():
 
     def make_engine(loop_closure=args.loop_closure):
         return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1,
-                                    local_loop_closure=1 if loop_closure else 0, timeDelta=args.time_delta)
+                                    local_loop_closure=1 if loop_closure else 0, timeDelta=args.time_delta,
+                                    share_projection=int(os.environ.get("DMS_SHARE_PROJECTION", "1")))
 
     stream = torch.cuda.current_stream().cuda_stream
     ef = make_engine()
@@ -175,10 +176,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    host_wait0 = ef.kernel_time("host_wait")[0]
     t0 = time.perf_counter()
     for i in range(args.warmup, n_total):
         step(i)
     t_enq = time.perf_counter() - t0  # host time to enqueue the timed frames (no synchronisation inside)
+    host_wait_ms = ef.kernel_time("host_wait")[0] - host_wait0
     barrier()
     elapsed = time.perf_counter() - t0
     res = ef.fetch(stream)
@@ -197,6 +200,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 4),
+        "host_blocked_ms_per_step": round(host_wait_ms / args.steps, 4),  # of which: waiting for frame t-2 (0 = host-bound)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -8,6 +8,7 @@
 // velocity weight (ElasticFusion.cpp:252-268), and every later kernel reads the block through a
 // pointer.  The fill-in decision (`denseEnough`, ElasticFusion.cpp:84-97,166-167), which the
 // reference takes on the host after a glReadPixels, is a device flag consumed by a select-copy.
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -36,7 +37,8 @@ int clear_zbuf(unsigned long long* zbuf, int n, hipStream_t s);
 int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStream_t s);
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
-                  dms_image2d* depth_out, int zclean, hipStream_t s);
+                  dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime = nullptr,
+                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0);
 int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s);
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
@@ -157,7 +159,7 @@ struct dms_fusion {
   dms_odometry* odom_m2m = nullptr;  // Context::modelToModel() (local loop closure)
   dms_predict_out pred_old;          // IndexMap old* textures: the INACTIVE view
   LoopState* loop = nullptr;         // device: LoopState + constraint rows
-  char* h_loop = nullptr;            // pinned, two slots by frame parity
+  char* h_loop = nullptr;            // pinned, four slots (frame % 4)
   size_t loop_bytes = 0;
   char* arena = nullptr;
   size_t arena_bytes = 0;
@@ -169,7 +171,8 @@ struct dms_fusion {
   } live[2];
   dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
   hipStream_t s_prep = nullptr;
-  hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[2] = {nullptr, nullptr}, ev_inputs = nullptr;
+  hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_inputs = nullptr;
+  int host_lag = 2;  // the host enqueues frame t once frame t - host_lag has completed (DMS_HOST_LAG = 2 | 3; 3 measured -2.4 %)
   bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
   int last_prep = -1;         // image set whose ev_prep_done marks the end of the last enqueued ingest
   long frames = 0;  // frames enqueued so far
@@ -192,9 +195,16 @@ struct dms_fusion {
   void* rgba_tmp = nullptr;
   void* untr = nullptr;  // W*H*16 scratch for row-major copies handed out by dms_fusion_get_image
   unsigned long long* zbuf = nullptr;
+  // second z-buffer: filled by the final prediction's project pass with the NEXT frame's tracking prediction (same map,
+  // same pose unless the caller brings a prior), resolved at that frame's begin instead of projecting the map again
+  unsigned long long* zbuf2 = nullptr;
+  double host_wait_ms = 0.0;     // host time spent blocked on the bounded run-ahead ("host_wait" of dms_fusion_get_kernel_time)
+  bool pre_valid = false;        // zbuf2 holds a projection
+  int pre_tick = 0;              // ... rendered for this tick
+  unsigned long pre_version = 0; // ... of this version of the map
   FrameState* state = nullptr;
   FrameState* h_state_dev = nullptr;  // device view of h_state
-  FrameState* h_state = nullptr;  // pinned, two slots by frame parity (the host may read a slot once that frame's event has completed)
+  FrameState* h_state = nullptr;  // pinned, four slots, frame % 4 (the host may read a slot once that frame's event has completed)
   int last_slot = 0;
   int timeouts_reported = 0;  // value of FrameState::track_timeouts the caller has been told about
   void* h_track = nullptr;
@@ -283,6 +293,7 @@ void layout(dms_fusion* f, Carve& c) {
   f->rgba_tmp = c.take(N * 4);
   f->untr = c.take(N * 16);
   f->zbuf = (unsigned long long*)c.take(N * 8);
+  f->zbuf2 = (unsigned long long*)c.take(N * 8);
   f->state = (FrameState*)c.take(sizeof(FrameState));
 }
 
@@ -341,13 +352,41 @@ void drain(dms_fusion* f) {
 }
 
 // ElasticFusion::predict (ElasticFusion.cpp:688-746): ACTIVE splat + fill-in
-int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr, bool dense_test = false) {
+// mode 0: plain.  mode 1 (the frame's final prediction): the project pass also fills zbuf2 for the next frame's tracking
+// prediction (confidence 0.7, next tick).  mode 2 (that next frame's begin): resolve zbuf2 if it is still what this
+// prediction would render — nothing changed the map, the pose comes from the previous frame — else project as usual.
+int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr, bool dense_test = false, int mode = 0,
+            bool have_prior = false) {
   int rc;
   {
     FTimer t(f, s, "predict");
-    if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
-                            f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s)))
-      return rc;
+    const int W = f->p.width, H = f->p.height;
+    bool done = false;
+    if (mode == 2 && f->pre_valid) {
+      if (!have_prior && f->pre_tick == f->tick && f->pre_version == f->model->version) {
+        if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
+                                f->p.timeDelta, 1, f->zbuf2, &f->pred, nullptr, 1, s, nullptr, nullptr, 1)))
+          return rc;
+        done = true;
+      } else if ((rc = clear_zbuf(f->zbuf2, W * H, s))) {  // stale: the resolve that would have cleaned it never runs
+        return rc;
+      }
+      f->pre_valid = false;
+    }
+    if (!done) {
+      const int next_tick = f->lost ? f->tick : f->tick + 1;  // (the tick advances at the end of the frame unless the camera is lost)
+      const float second[3] = {0.7f, (float)next_tick, (float)next_tick};
+      const bool dual = mode == 1 && f->p.share_projection && f->p.hybrid_tracking;
+      if (dual && f->pre_valid && (rc = clear_zbuf(f->zbuf2, W * H, s))) return rc;  // (never consumed)
+      if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
+                              f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s, dual ? second : nullptr, dual ? f->zbuf2 : nullptr, 0)))
+        return rc;
+      if (dual) {
+        f->pre_valid = true;
+        f->pre_tick = next_tick;
+        f->pre_version = f->model->version;
+      }
+    }
   }
   {
     FTimer t(f, s, "fill_in");
@@ -440,6 +479,7 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->local_loop_closure = 0;
   p->reloc = 0;
   p->num_sensors = 3;       // NUM_CAMERAS (Shaders/size.glsl:2)
+  p->share_projection = 1;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
@@ -484,18 +524,17 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   f->arena_bytes = up256(sz.off);
   hipError_t e = hipMalloc((void**)&f->arena, f->arena_bytes);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->s_prep, hipStreamNonBlocking);
-  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-    e = hipEventCreateWithFlags(&f->ev_prep_done[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_main_done[k], hipEventDisableTiming);
-  }
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_prep_done[k], hipEventDisableTiming);
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_main_done[k], hipEventDisableTiming);
+  if (const char* hl = getenv("DMS_HOST_LAG")) f->host_lag = atoi(hl) == 3 ? 3 : 2;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 2 * sizeof(FrameState), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 4 * sizeof(FrameState), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&f->h_state_dev, f->h_state, 0);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->nid_host, 2 * sizeof(float), hipHostMallocDefault);
   if (e == hipSuccess && f->loop_bytes) {
-    e = hipHostMalloc((void**)&f->h_loop, 2 * f->loop_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) memset(f->h_loop, 0, 2 * f->loop_bytes);
+    e = hipHostMalloc((void**)&f->h_loop, 4 * f->loop_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) memset(f->h_loop, 0, 4 * f->loop_bytes);
   }
   if (e != hipSuccess) {
     if (f->arena) (void)hipFree(f->arena);
@@ -512,10 +551,11 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
   hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, 0, f->state, I);
   (void)clear_zbuf(f->zbuf, p->width * p->height, 0);
+  (void)clear_zbuf(f->zbuf2, p->width * p->height, 0);
   for (int l = 0; l < DMS_NUM_PYRS; ++l)  // the INACTIVE ("old") prediction is never rendered with loop closure off: no depth anywhere
     (void)hipMemsetD32((hipDeviceptr_t)f->kf_old_dmap[l].data, 0x7fffffff, (size_t)f->kf_old_dmap[l].rows * f->kf_old_dmap[l].cols);  // kept empty from here on: every resolve pass clears what it reads
   (void)hipDeviceSynchronize();
-  memset(f->h_state, 0, 2 * sizeof(FrameState));
+  memset(f->h_state, 0, 4 * sizeof(FrameState));
   *out = f;
   return DMS_OK;
 }
@@ -525,10 +565,10 @@ int dms_fusion_destroy(dms_fusion* f) {
   (void)hipDeviceSynchronize();
   drain(f);
   for (auto e : f->pool) (void)hipEventDestroy(e);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2; ++k)
     if (f->ev_prep_done[k]) (void)hipEventDestroy(f->ev_prep_done[k]);
+  for (int k = 0; k < 4; ++k)
     if (f->ev_main_done[k]) (void)hipEventDestroy(f->ev_main_done[k]);
-  }
   if (f->ev_inputs) (void)hipEventDestroy(f->ev_inputs);
   if (f->s_prep) (void)hipStreamDestroy(f->s_prep);
   if (f->arena) (void)hipFree(f->arena);
@@ -589,22 +629,32 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       DMS_HIP(hipStreamWaitEvent(sp, f->ev_inputs, 0));
       f->inputs_armed = false;
     }
-    // Bounded run-ahead: at most two frames are in flight.  The host blocks here until frame-2 has
-    // finished (normally long ago).  Besides protecting the double-buffered images this keeps the
-    // HIP command queues short: with the host many frames ahead the runtime's queue-full handling
-    // was measured to cost ~10% throughput.
-    DMS_HIP(hipEventSynchronize(f->ev_main_done[k2]));
-    DMS_HIP(hipStreamWaitEvent(sp, f->ev_main_done[k2], 0));  // frame-2 (never recorded: no-op)
+    // Bounded run-ahead: the host blocks here until frame t - host_lag has finished.  This keeps the HIP command queues
+    // short (with the host many frames ahead the runtime's queue-full handling was measured to cost ~10 % throughput,
+    // DESIGN.md §6).  The buffers themselves are protected on the device: this frame's live half reuses the image set and
+    // the tracker ring set that frame t-2 read, so the prep stream waits for THAT frame's completion event.  (host_lag = 3
+    // has the live half enqueued before frame t-2 ends, so that it starts at once instead of ~60 us into frame t-1:
+    // measured 2.4 % slower — the deeper queues cost more than the earlier start returns; default 2.)
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      DMS_HIP(hipEventSynchronize(f->ev_main_done[(f->frames + 4 - f->host_lag) % 4]));  // (never recorded: returns at once)
+      f->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    DMS_HIP(hipStreamWaitEvent(sp, f->ev_main_done[(f->frames + 2) % 4], 0));  // frame t-2
   }
-  // frame-2's result block (pinned slot k2) is readable once its completion event has passed — always here with the
-  // pipeline (the host has just waited for it), usually here without it: tighten the host-side bound of the surfel
-  // count that launch grids are sized from.  One clean has run since then (frame-1) and adds at most `slots` surfels.
-  // Without this the bound grows by `slots` per frame until it reaches the capacity.
+  // A completed frame's result block (pinned ring slot) tightens the host-side bound of the surfel count that launch grids
+  // are sized from; every clean since then adds at most `slots` surfels.  Without this the bound grows by `slots` per
+  // frame until it reaches the capacity.
   if (f->model->count_hold > 0) {
     f->model->count_hold -= 1;
-  } else if (f->frames >= 2 && f->map_initialised && (f->p.pipeline_ingest || hipEventQuery(f->ev_main_done[k2]) == hipSuccess)) {
-    const size_t known = (size_t)f->h_state[k2].surfels + (size_t)f->model->slots;
-    if (known < f->model->count_upper) f->model->count_upper = known;
+  } else if (f->map_initialised) {
+    // newest frame whose result slot is certainly readable: t - host_lag with the pipeline (just waited for), else t - 2 if done
+    const int lag = f->p.pipeline_ingest ? f->host_lag : 2;
+    const int slot = (int)((f->frames + 4 - lag) % 4);
+    if (f->frames >= lag && (f->p.pipeline_ingest || hipEventQuery(f->ev_main_done[slot]) == hipSuccess)) {
+      const size_t known = (size_t)f->h_state[slot].surfels + (size_t)(lag - 1) * (size_t)f->model->slots;  // one clean per later frame
+      if (known < f->model->count_upper) f->model->count_upper = known;
+    }
   }
   f->rgba = f->live[k2].rgba;
   f->depth_raw = f->live[k2].depth_raw;
@@ -674,7 +724,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       DMS_CHECK_LAUNCH();
     }
     // ElasticFusion.cpp:165-167: an extra block of this predict's fill-in launch takes the denseEnough decision
-    if ((rc = predict(f, 0.7f, s, nullptr, true))) return rc;
+    if ((rc = predict(f, 0.7f, s, nullptr, true, 2, inPose16 != nullptr))) return rc;
     if (f->p.hybrid_tracking) {
       {
         FTimer t(f, s, "odom_init");
@@ -792,9 +842,10 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
     f->cur_fuse_now = fuse_now;
     if (f->p.local_loop_closure && !f->lost) {
       // the candidate is readable (dms_fusion_fetch_loop) before the second half is enqueued
-      DMS_HIP(hipMemcpyAsync(f->h_state + k2, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
-      DMS_HIP(hipMemcpyAsync(f->h_loop + (size_t)k2 * f->loop_bytes, f->loop, f->loop_bytes, hipMemcpyDeviceToHost, s));
-      f->last_slot = k2;
+      const int k4 = (int)(f->frames % 4);  // this frame's result slot (the final prediction mirrors into the same one)
+      DMS_HIP(hipMemcpyAsync(f->h_state + k4, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, s));
+      DMS_HIP(hipMemcpyAsync(f->h_loop + (size_t)k4 * f->loop_bytes, f->loop, f->loop_bytes, hipMemcpyDeviceToHost, s));
+      f->last_slot = k4;
     }
   }
   f->in_frame = true;
@@ -868,9 +919,10 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
     DMS_CHECK_LAUNCH();
   }
   // finalPredict (ElasticFusion.cpp:586); its fill-in kernel mirrors the result block to the host slot
-  if ((rc = predict(f, f->p.confidence, s, f->h_state_dev + k2))) return rc;
-  f->last_slot = k2;
-  DMS_HIP(hipEventRecord(f->ev_main_done[k2], s));  // (also without the pipeline: it gates the reading of this frame's result slot)
+  const int k4 = (int)(f->frames % 4);
+  if ((rc = predict(f, f->p.confidence, s, f->h_state_dev + k4, false, 1))) return rc;
+  f->last_slot = k4;
+  DMS_HIP(hipEventRecord(f->ev_main_done[k4], s));  // (also without the pipeline: it gates the reading of this frame's result slot)
   f->fused_last = fused;
   if (!f->lost) f->tick += 1;  // ElasticFusion.cpp:588-591
   f->frames += 1;
@@ -1012,6 +1064,11 @@ int dms_fusion_set_profiling(dms_fusion* f, int enabled) {
 
 int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches) {
   DMS_REQUIRE(f && name && total_ms && launches, "null argument");
+  if (strcmp(name, "host_wait") == 0) {  // always on: how long the host has waited for frame t-2 so far (0 = the host is the bottleneck)
+    *total_ms = f->host_wait_ms;
+    *launches = (int)f->frames;
+    return DMS_OK;
+  }
   auto it = f->times.find(name);
   *total_ms = it == f->times.end() ? 0.0 : it->second.ms;
   *launches = it == f->times.end() ? 0 : it->second.launches;

@@ -700,6 +700,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   hipLaunchKernelGGL(k_fuse_update, dim3((m->slots + 255) / 256), dim3(256), 0, s, m->slots, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_best, m->slot_flag, m->winner, m->buf[m->cur], m->cap, time, timeIdx);
   DMS_CHECK_LAUNCH();
+  m->version += 1;
   return DMS_OK;
 }
 
@@ -775,6 +776,7 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   std::swap(m->d_count, m->d_count_alt);
   if (!suffix) m->cur ^= 1;
   m->count_upper = upper < m->cap ? upper : m->cap;
+  m->version += 1;
   return DMS_OK;
 }
 

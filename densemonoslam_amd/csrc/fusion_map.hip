@@ -212,6 +212,7 @@ static int model_upload_any(dms_model* m, const float* host, unsigned n, int nse
   DMS_HIP(hipStreamSynchronize(s));
   m->count_upper = n;
   m->count_hold = 3;  // the map was replaced from outside: older frame results no longer bound it
+  m->version += 1;
   return DMS_OK;
 }
 
@@ -365,6 +366,7 @@ int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* d
   DMS_CHECK_LAUNCH();
   m->count_upper = (size_t)n < m->cap ? (size_t)n : m->cap;
   m->count_hold = 3;
+  m->version += 1;
   return DMS_OK;
 }
 
@@ -633,6 +635,7 @@ static int consume_finish(dms_model* m, size_t added_upper) {
   const size_t upper = m->count_upper + added_upper;
   m->count_upper = upper < m->cap ? upper : m->cap;
   m->count_hold = 3;
+  m->version += 1;
   return DMS_OK;
 }
 
@@ -766,13 +769,28 @@ __device__ __forceinline__ f3 project_image(const ProjArgs& a, const f3& p) {  /
 // vertex stage: returns false when the surfel is culled / clipped
 // (the normal / radius plane is read only for surfels that survive the cull and the clip: for a large map most do
 // not, and the pass is bandwidth-bound there — 20 instead of 36 bytes per culled surfel)
-__device__ __forceinline__ bool splat_vertex(const ProjArgs& a, const float4& pc, const float4* __restrict__ nrp, float vt, SplatSurfel& o) {
+// the cull of splat.vert for one set of (confidence threshold, time, newest time) — the part of the vertex stage that
+// differs between two predictions of the same map from the same pose
+__device__ __forceinline__ bool splat_culled(const ProjArgs& a, const f3& ph, float conf, float vt, float confThreshold, int time, int maxTime) {
+  const bool actv = a.actv != 0;
+  return !(!actv && vt == -3.f) && (ph.z > a.maxDepth || ph.z < 0.f || conf < confThreshold || (actv && vt == -3.f) ||
+                                    (vt != -3.f && (float)time - vt > (float)a.timeDelta) || vt > (float)maxTime);
+}
+
+struct SplatSecond {  // second prediction sharing the project pass (same map, pose, depth range and mode)
+  float confThreshold;
+  int time, maxTime;
+};
+
+// `pass`: bit 0 = survives the cull of `a`, bit 1 = survives the cull of `b` (when given)
+__device__ __forceinline__ bool splat_vertex(const ProjArgs& a, const float4& pc, const float4* __restrict__ nrp, float vt, SplatSurfel& o,
+                                             const SplatSecond* b = nullptr, int* pass = nullptr) {
   const float* Tinv = a.pose->t_inv;
   const f3 ph = xform_point(Tinv, mk3(pc.x, pc.y, pc.z));
-  const bool actv = a.actv != 0;
-  const bool cull = !(!actv && vt == -3.f) && (ph.z > a.maxDepth || ph.z < 0.f || pc.w < a.confThreshold || (actv && vt == -3.f) ||
-                                               (vt != -3.f && (float)a.time - vt > (float)a.timeDelta) || vt > (float)a.maxTime);
-  if (cull) return false;
+  int keep = splat_culled(a, ph, pc.w, vt, a.confThreshold, a.time, a.maxTime) ? 0 : 1;
+  if (b) keep |= splat_culled(a, ph, pc.w, vt, b->confThreshold, b->time, b->maxTime) ? 0 : 2;
+  if (pass) *pass = keep;
+  if (!keep) return false;
   float zw;
   if (!project_window(a, ph, o.xw, o.yw, zw)) return false;
   const float4 nr = *nrp;
@@ -820,10 +838,15 @@ __device__ __forceinline__ void sprite_range(float c, float size, int n, int& lo
 // threads (prefix sum of the row counts + binary search): a thread's trip count is one sprite width,
 // and the rows of a large sprite are spread over many threads.  The winners are decided by 64-bit
 // atomicMin, so the work order does not matter.
+// DUAL: one pass over the map feeds two z-buffers — two predictions of the same map from the same pose that differ in
+// the cull only (the frame's final prediction and the next frame's tracking prediction): the vertex stage and the sprite
+// loop run once, a fragment competes in the z-buffer of every prediction its surfel survives the cull of.
+template <bool DUAL>
 __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
-                                                       unsigned long long* __restrict__ zbuf) {
+                                                       unsigned long long* __restrict__ zbuf, SplatSecond b2,
+                                                       unsigned long long* __restrict__ zbuf2) {
   __shared__ float s_par[7][256];   // pos.xyz, nrm.xyz, rad
-  __shared__ int s_box[3][256];     // x0, width, y0
+  __shared__ int s_box[4][256];     // x0, width, y0, cull survivors (DUAL)
   __shared__ unsigned s_off[257];   // exclusive prefix of the row counts
   __shared__ unsigned s_w[4];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -853,7 +876,8 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
     int rows_here = 0;
     if (i < M) {
       SplatSurfel s;
-      if (splat_vertex(a, pc, sp.nrm + i, vt, s) && s.size == s.size) {
+      int pass = 1;
+      if (splat_vertex(a, pc, sp.nrm + i, vt, s, DUAL ? &b2 : nullptr, &pass) && s.size == s.size) {
         int x0, x1, y0, y1;
         sprite_range(s.xw, s.size, a.cols, x0, x1);
         sprite_range(s.yw, s.size, a.rows, y0, y1);
@@ -869,6 +893,7 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
           s_box[0][t] = x0;
           s_box[1][t] = x1 - x0 + 1;
           s_box[2][t] = y0;
+          if (DUAL) s_box[3][t] = pass;
         }
       }
     }
@@ -905,6 +930,7 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
       const int x0 = s_box[0][j], w = s_box[1][j];
       const int py = s_box[2][j] + (int)(u - s_off[j]);
       const unsigned long long id = (unsigned long long)(base + (unsigned)j);
+      const int pass = DUAL ? s_box[3][j] : 1;
       for (int px = x0; px < x0 + w; ++px) {
         f3 c;
         float zw;
@@ -912,8 +938,13 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
         const unsigned d = depth24(zw);
         if (d >= 0xFFFFFFu) continue;
         const unsigned long long key = ((unsigned long long)d << 32) | id;
-        unsigned long long* cell = zbuf + (size_t)px * a.rows + py;  // column-major z-buffer
-        if (key < *cell) atomicMin(cell, key);
+        const size_t q = (size_t)px * a.rows + py;  // column-major z-buffer
+        if (!DUAL || (pass & 1)) {
+          if (key < zbuf[q]) atomicMin(zbuf + q, key);
+        }
+        if (DUAL && (pass & 2)) {
+          if (key < zbuf2[q]) atomicMin(zbuf2 + q, key);
+        }
       }
     }
     __syncthreads();  // the parameter tables are rewritten by the next chunk
@@ -977,7 +1008,8 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
 
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
-                  dms_image2d* depth_out, int zclean, hipStream_t s) {
+                  dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime, unsigned long long* zbuf2,
+                  int resolve_only) {
   DMS_REQUIRE(m && pose && cam && zbuf, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -997,7 +1029,19 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
     hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
     DMS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_splat_project, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf);
+  SplatSecond b2 = {0.f, 0, 0};
+  if (resolve_only) {
+    // the z-buffer was filled by an earlier dual pass with exactly these parameters
+  } else if (second_conf_time_maxtime && zbuf2) {
+    b2.confThreshold = second_conf_time_maxtime[0];
+    b2.time = (int)second_conf_time_maxtime[1];
+    b2.maxTime = (int)second_conf_time_maxtime[2];
+    hipLaunchKernelGGL(k_splat_project<true>, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf, b2,
+                       zbuf2);
+  } else {
+    hipLaunchKernelGGL(k_splat_project<false>, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf,
+                       b2, (unsigned long long*)nullptr);
+  }
   DMS_CHECK_LAUNCH();
   if (depth_out)
     hipLaunchKernelGGL(k_splat_resolve<true>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,

@@ -155,6 +155,7 @@ struct dms_model {
   unsigned* clean_first = nullptr;  // suffix-mode clean: index of the first block that is not left in place
   float* nodes = nullptr;           // deformation node table, 16 floats / node
   int max_nodes = 2048;
+  unsigned long version = 0;        // bumped by every operation that changes the map (cached projections are tagged with it)
   int num_sensors = 3;              // per-surfel time slots that take part in the clean's health test (reference NUM_CAMERAS = 3)
   size_t clean_suffix_min = (size_t)1 << 20;  // map size from which the clean runs in suffix mode (DMS_CLEAN_SUFFIX_MIN at create)
 };

@@ -2278,9 +2278,16 @@ static void persistent_shape(int n, int target, int& P, int& nb) {
 // half-resident.  Every persistent section of this process is therefore chained on one event per
 // device: stream-ordered, free for a single stream, and it serialises trackers of different
 // cameras / streams against each other.
+// The event is only needed when the stream changes: a section on the stream that ran the previous one is ordered by
+// the stream itself.  When another stream takes over, the event is recorded on the PREVIOUS stream at that moment (its
+// tail is behind its section) and the new stream waits for it — a single camera on a single stream, the usual case,
+// pays nothing (the unconditional record after every tracker call cost ~6 us of idle stream per frame in the rocprof
+// trace).  A previous stream that has been destroyed meanwhile has finished its work: the failed record is ignored.
 struct PersistChain {
   std::mutex mu;
   hipEvent_t ev[64] = {};
+  hipStream_t last[64] = {};
+  bool used[64] = {};
 };
 static PersistChain g_persist;
 struct PersistSection {
@@ -2293,13 +2300,19 @@ struct PersistSection {
     g_persist.mu.lock();
     (void)hipGetDevice(&dev);
     dev &= 63;
-    if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
-    (void)hipStreamWaitEvent(s, g_persist.ev[dev], 0);
+    if (g_persist.used[dev] && g_persist.last[dev] != s) {
+      if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
+      if (hipEventRecord(g_persist.ev[dev], g_persist.last[dev]) == hipSuccess)
+        (void)hipStreamWaitEvent(s, g_persist.ev[dev], 0);
+      else
+        (void)hipGetLastError();
+    }
+    g_persist.last[dev] = s;
+    g_persist.used[dev] = true;
     active = true;
   }
   ~PersistSection() {
     if (!active) return;
-    (void)hipEventRecord(g_persist.ev[dev], s);
     g_persist.mu.unlock();
   }
 };

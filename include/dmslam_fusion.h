@@ -216,6 +216,11 @@ typedef struct dms_fusion_params {
    * Default 3 as in the reference; a node that merges more than three cameras into one map raises it
    * (<= DMS_MAX_SENSORS); timeIdx must be < num_sensors. */
   int num_sensors;
+  /* 1 (default): the project pass of a frame's final prediction (ElasticFusion.cpp:586) also fills the z-buffer of the
+   * NEXT frame's tracking prediction (:165, confidence 0.7, next tick) — the same map from the same pose, a different
+   * cull — and that frame resolves it instead of projecting the map again, provided nothing changed the map in between
+   * and it brings no pose prior.  Same images bit for bit; one map pass less per frame.  0: every prediction projects. */
+  int share_projection;
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);

@@ -8,7 +8,7 @@ python bench.py --steps 100 --warmup 10 > gpurun_out/r02/bench_$tag.json 2> gpur
 python - <<P
 import json
 j=json.loads(open("gpurun_out/r02/bench_$tag.json").read().strip().split("\n")[-1])
-print("fps", round(j["value"],1), "full", round(j["full_step"]["value"],1), "roofline", round(j["roofline"]["frac"],4))
+print("fps", round(j["value"],1), "enq", j["host_enqueue_ms_per_step"], "blocked", j["host_blocked_ms_per_step"], "full", round(j["full_step"]["value"],1), "roofline", round(j["roofline"]["frac"],4))
 print({k:v["avg_us"] for k,v in j["tracker_kernels"].items()})
 for l,d in j["gn_level_phase_us_per_frame"].items(): print(l, d)
 print(j["stage_ms_per_frame"])

@@ -1315,3 +1315,37 @@ def test_surfel_bound_stays_tight_without_pipeline_or_fetch(fus, synth):
     slots = ((W + 1) // 2) * ((H + 1) // 2)
     assert bound <= int(r.surfels) + 3 * slots, (bound, int(r.surfels), slots)
     g.close()
+
+
+def test_shared_projection_pass_changes_nothing(fus, synth):
+    """share_projection: the final prediction's project pass also fills the z-buffer of the next frame's tracking prediction
+    and that frame resolves it instead of projecting the map again.  Poses, maps and every image must equal the run that
+    projects for every prediction, bit for bit — also across a frame that brings a pose prior (the cached projection is for
+    the wrong pose and must not be used) and a map changed from outside between two frames."""
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(7)]
+
+    def run(share):
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, share_projection=share)
+        out = []
+        for k, (d, rgb, T) in enumerate(frames):
+            prior = None
+            if k == 3:  # a caller-supplied prior: slightly off the previous pose
+                prior = np.array(out[-1][0], np.float32).reshape(4, 4).copy()
+                prior[:3, 3] += np.float32([0.002, -0.001, 0.001])
+            if k == 5:  # the map is replaced from outside between two frames
+                m = g.globalModel().downloadMap()
+                g.globalModel().upload(m[:len(m) - 1000])
+            r = g.processFrame(rgb, d, inPose=prior)
+            out.append((np.array(r.pose, np.float32), int(r.surfels), g.image(10).copy(), g.image(13).copy(), g.image(14).copy()))
+        m = g.globalModel().downloadMap()
+        g.close()
+        return out, m
+
+    a, ma = run(1)
+    b, mb = run(0)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[0].tobytes() == y[0].tobytes(), "pose of frame %d" % k
+        assert x[1] == y[1]
+        for i in (2, 3, 4):
+            assert_bits(x[i], y[i], "image %d of frame %d" % (i, k))
+    surfels_equal(ma, mb, "map")
