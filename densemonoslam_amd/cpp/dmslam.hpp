@@ -12,12 +12,14 @@
 //   GlobalModel  (Core/src/GlobalModel.h:43-141)               -> dms::GlobalModel
 //   IndexMap     (Core/src/IndexMap.h:33-205)                  -> dms::IndexMap
 //   ElasticFusion::processFrame (ElasticFusion.h:92-100)       -> dms::ElasticFusion::processFrame
+//   Ferns        (Core/src/Ferns.h:35-266)                     -> dms::Ferns
 #pragma once
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/dmslam.h"
+#include "../../include/dmslam_ferns.h"
 #include "../../include/dmslam_fusion.h"
 
 namespace dms {
@@ -123,6 +125,90 @@ class GlobalModel {
 
  private:
   bool owned;
+};
+
+// IndexMap (IndexMap.h:39-162): the render targets of one camera and the three "draws" over a GlobalModel.
+// pose = device dms_pose_block (dms_pose_block_set); K = (fx, fy, cx, cy).
+class IndexMap {
+ public:
+  IndexMap(int width, int height)
+      : index(width, height, 4), vertConf(width, height, 16), colorTime(width, height, 16), normRad(width, height, 16),
+        image(width, height, 4), vertex(width, height, 16), normal(width, height, 16), time(width, height, 2), depth(width, height, 4) {
+    check(dms_device_alloc((void**)&zbuf, (size_t)width * height * 8), "dms_device_alloc");
+    check(dms_device_alloc((void**)&pose, sizeof(dms_pose_block)), "dms_device_alloc");
+  }
+  ~IndexMap() {
+    dms_device_free(zbuf);
+    dms_device_free(pose);
+  }
+  IndexMap(const IndexMap&) = delete;
+  void setPose(const float* pose16, dms_stream s = nullptr) { check(dms_pose_block_set(pose, pose16, s), "dms_pose_block_set"); }
+  // IndexMap::predictIndices (IndexMap.cpp:146-217)
+  void predictIndices(const float* pose16, const int& time, const int& timeIdx, GlobalModel& model, const dms_camera& K, const float depthCutoff,
+                      const int timeDelta, dms_stream s = nullptr) {
+    setPose(pose16, s);
+    dms_indexmap_out o = {index.view, vertConf.view, colorTime.view, normRad.view};
+    check(dms_index_map(model.h, pose, &K, time, timeIdx, depthCutoff, timeDelta, zbuf, &o, s), "predictIndices");
+  }
+  // IndexMap::combinedPredict (IndexMap.cpp:253-368); predictionType: 1 = ACTIVE, 0 = INACTIVE
+  void combinedPredict(const float* pose16, GlobalModel& model, const dms_camera& K, const float depthCutoff, const float confThreshold,
+                       const int time, const int timeIdx, const int maxTime, const int timeDelta, int predictionType, dms_stream s = nullptr) {
+    setPose(pose16, s);
+    dms_predict_out o = {image.view, vertex.view, normal.view, this->time.view};
+    check(dms_splat_predict(model.h, pose, &K, depthCutoff, confThreshold, time, timeIdx, maxTime, timeDelta, predictionType, zbuf, &o, s),
+          "combinedPredict");
+  }
+  // IndexMap::synthesizeDepth (IndexMap.cpp:370-452)
+  void synthesizeDepth(const float* pose16, GlobalModel& model, const dms_camera& K, const float depthCutoff, const float confThreshold,
+                       const int time, const int timeIdx, const int maxTime, const int timeDelta, dms_stream s = nullptr) {
+    setPose(pose16, s);
+    check(dms_splat_depth(model.h, pose, &K, depthCutoff, confThreshold, time, timeIdx, maxTime, timeDelta, zbuf, &depth.view, s),
+          "synthesizeDepth");
+  }
+  DeviceTexture index, vertConf, colorTime, normRad;  // indexTex / vertConfTex / colorTimeTex / normalRadTex
+  DeviceTexture image, vertex, normal, time;          // imageTex / vertexTex / normalTex / timeTex
+  DeviceTexture depth;                                // depthTex
+  unsigned long long* zbuf = nullptr;
+  dms_pose_block* pose = nullptr;
+};
+
+// Ferns (Ferns.h:35-266): the per-map keyframe database; textures = full-resolution RGBA8 / RGBA32F DeviceTextures
+class Ferns {
+ public:
+  Ferns(int n, int maxDepth, const float photoThresh, int width, int height, float cx, float cy, float fx, float fy, unsigned seed = 0,
+        int capacity = 4096) {
+    check(dms_ferns_create(&h, n, maxDepth, photoThresh, width, height, cx, cy, fx, fy, seed, capacity), "dms_ferns_create");
+  }
+  virtual ~Ferns() { dms_ferns_destroy(h); }
+  Ferns(const Ferns&) = delete;
+  bool addFrame(DeviceTexture* imageTexture, DeviceTexture* vertexTexture, DeviceTexture* normalTexture, const float* pose16, int srcTime,
+                const float threshold, dms_stream s = nullptr) {
+    int added = 0;
+    check(dms_ferns_add_frame(h, imageTexture->image(), vertexTexture->image(), normalTexture->image(), pose16, srcTime, threshold, &added, s),
+          "addFrame");
+    return added != 0;
+  }
+  // returns the estimated pose in match.estPose, lastClosest in match.closest; constraints = rows {raw xyz1 | model xyz1}
+  dms_fern_match findFrame(std::vector<float>& constraints, const float* currPose16, DeviceTexture* vertexTexture, DeviceTexture* normalTexture,
+                           DeviceTexture* imageTexture, const int time, const bool lost, const bool interMap = false, dms_stream s = nullptr) {
+    dms_fern_match m;
+    constraints.assign(8 * 64, 0.f);
+    check(dms_ferns_find_frame(h, vertexTexture->image(), normalTexture->image(), imageTexture->image(), currPose16, time, lost, interMap, &m,
+                               constraints.data(), s),
+          "findFrame");
+    constraints.resize((size_t)m.n_constraints * 8);
+    lastClosest = m.closest;
+    return m;
+  }
+  // Ferns::consume (Ferns.cpp:160-168)
+  int consume(Ferns& other, const float* relativeTransform16, const float threshold, dms_stream s = nullptr) {
+    int added = 0;
+    check(dms_ferns_consume(h, other.h, relativeTransform16, threshold, &added, s), "consume");
+    return added;
+  }
+  int frames() { return dms_ferns_num_frames(h); }
+  int lastClosest = -1;
+  dms_ferns* h = nullptr;
 };
 
 class ElasticFusion {

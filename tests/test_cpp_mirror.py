@@ -19,6 +19,10 @@ int main() {
   int rc = dms_createNMap(nullptr, nullptr, nullptr);
   if (rc != DMS_ERR_INVALID_ARG || !std::strstr(dms_last_error(), "null")) return 2;
   try { dms::check(rc, "createNMap"); return 3; } catch (const std::runtime_error&) {}
+  // the fern / index-map mirrors are part of the header: their entry points must resolve at link time
+  void* fns[] = {(void*)&dms_ferns_create, (void*)&dms_ferns_find_frame, (void*)&dms_index_map, (void*)&dms_splat_depth};
+  for (void* f : fns) if (!f) return 5;
+  if (sizeof(dms::Ferns) == 0 || sizeof(dms::IndexMap) == 0) return 6;
   dms_fusion_params p;
   dms_fusion_default_params(&p, 640, 480, 528.f, 528.f, 320.f, 240.f);
   return (p.timeDelta == 200 && p.confidence == 10.f && p.maxDepthProcessed == 25.f) ? 0 : 4;
