@@ -5,6 +5,34 @@
 
 namespace dms {
 
+// ---- optional fused multiply-adds ----------------------------------------------------------------------------------
+// FMA = false: every multiply and add rounds on its own, in the order written (what the operator layer and the oracle
+// evaluate: bit-identical rows).  FMA = true (resident tracker kernels): the same expressions with each multiply-add chain
+// fused, the association order unchanged — what nvcc's default -fmad=true does to the reference's own kernels; a row
+// element then differs from the unfused one by at most an ulp or two, and the pixel passes, which are bound by their
+// instruction count, lose about a quarter of their arithmetic instructions.
+template <bool FMA>
+__device__ __forceinline__ float madd(float a, float b, float c) {
+  return FMA ? fmaf(a, b, c) : a * b + c;
+}
+template <bool FMA>
+__device__ __forceinline__ float dot3t(const f3& a, const f3& b) {  // == dot3 for FMA = false (sums commute)
+  return madd<FMA>(a.z, b.z, madd<FMA>(a.y, b.y, a.x * b.x));
+}
+template <bool FMA>
+__device__ __forceinline__ f3 mult(const M33& m, const f3& a) {
+  return mk3(dot3t<FMA>(m.r0, a), dot3t<FMA>(m.r1, a), dot3t<FMA>(m.r2, a));
+}
+template <bool FMA>
+__device__ __forceinline__ f3 cross3t(const f3& a, const f3& b) {
+  if (FMA) return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+  return cross3(a, b);
+}
+template <bool FMA>
+__device__ __forceinline__ float norm3t(const f3& a) {
+  return sqrtf(dot3t<FMA>(a, a));
+}
+
 // ---- ICP: projective association + point-to-plane row ---------------------------------
 // reference ICPReduction::search / getProducts (reduce.cu:259-344)
 struct IcpParams {
@@ -59,10 +87,11 @@ __device__ __forceinline__ IcpOwn icp_load_own(const MapPtrs& m, int x, int y, i
   return o;
 }
 
+template <bool FMA = false>
 __device__ __forceinline__ IcpProj icp_project(const IcpParams& p, const IcpOwn& o) {
   IcpProj r;
-  r.vcurr_g = mul(p.Rcurr, o.vcurr) + p.tcurr;
-  const f3 vcurr_cp = mul(p.Rprev_inv, r.vcurr_g - p.tprev);
+  r.vcurr_g = mult<FMA>(p.Rcurr, o.vcurr) + p.tcurr;
+  const f3 vcurr_cp = mult<FMA>(p.Rprev_inv, r.vcurr_g - p.tprev);
   r.ux = f2i_rn((vcurr_cp.x * p.fx) / vcurr_cp.z + p.cx);
   r.uy = f2i_rn((vcurr_cp.y * p.fy) / vcurr_cp.z + p.cy);
   r.ok = !((int)(r.ux < 0) | (int)(r.uy < 0) | (int)(r.ux >= p.cols) | (int)(r.uy >= p.rows) | (int)(vcurr_cp.z < 0.f));
@@ -82,25 +111,26 @@ __device__ __forceinline__ IcpModel icp_load_model(const MapPtrs& m, const IcpPr
 }
 
 // row[0..5] = Jacobian, row[6] = residual.  Returns found flag; row is zero when not found.
+template <bool FMA = false>
 __device__ __forceinline__ bool icp_finish(const IcpParams& p, const IcpOwn& o, const IcpProj& r, const IcpModel& c, float (&row)[7]) {
 #pragma unroll
   for (int i = 0; i < 7; ++i) row[i] = 0.f;
-  const f3 ncurr_g = mul(p.Rcurr, o.ncurr);
-  const float dist = norm3(c.vprev_g - r.vcurr_g);
-  const float sine = norm3(cross3(ncurr_g, c.nprev_g));
+  const f3 ncurr_g = mult<FMA>(p.Rcurr, o.ncurr);
+  const float dist = norm3t<FMA>(c.vprev_g - r.vcurr_g);
+  const float sine = norm3t<FMA>(cross3t<FMA>(ncurr_g, c.nprev_g));
   const bool found = r.ok && (sine < p.angleThres && dist <= p.distThres && !isnan(o.ncurr.x) && !isnan(c.nprev_g.x));
   if (!found) return false;
-  const f3 s_cp = mul(p.Rprev_inv, r.vcurr_g - p.tprev);
-  const f3 d_cp = mul(p.Rprev_inv, c.vprev_g - p.tprev);
-  const f3 n_cp = mul(p.Rprev_inv, c.nprev_g);
-  const f3 cr = cross3(s_cp, n_cp);
+  const f3 s_cp = mult<FMA>(p.Rprev_inv, r.vcurr_g - p.tprev);
+  const f3 d_cp = mult<FMA>(p.Rprev_inv, c.vprev_g - p.tprev);
+  const f3 n_cp = mult<FMA>(p.Rprev_inv, c.nprev_g);
+  const f3 cr = cross3t<FMA>(s_cp, n_cp);
   row[0] = n_cp.x;
   row[1] = n_cp.y;
   row[2] = n_cp.z;
   row[3] = cr.x;
   row[4] = cr.y;
   row[5] = cr.z;
-  row[6] = dot3(n_cp, s_cp - d_cp);
+  row[6] = dot3t<FMA>(n_cp, s_cp - d_cp);
   return true;
 }
 
@@ -113,13 +143,17 @@ __device__ __forceinline__ bool icp_row(const IcpParams& p, const MapPtrs& m, in
 
 // accumulate the 27 upper-triangle products + residual^2 + inlier into acc[29]
 // (field order of JtJJtrSE3, types.cuh:123-136)
+template <bool FMA = false>
 __device__ __forceinline__ void accumulate_se3(float (&acc)[kSE3], const float (&row)[7], bool found) {
   int k = 0;
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = i; j < 7; ++j) acc[k++] += row[i] * row[j];
-  acc[27] += row[6] * row[6];
+    for (int j = i; j < 7; ++j) {
+      acc[k] = madd<FMA>(row[i], row[j], acc[k]);
+      ++k;
+    }
+  acc[27] = madd<FMA>(row[6], row[6], acc[27]);
   acc[28] += found ? 1.f : 0.f;
 }
 
@@ -210,13 +244,15 @@ __device__ __forceinline__ RgbOwn rgb_load_own(const RgbResParams& p, const RgbR
   return o;
 }
 
+template <bool FMA = false>
 __device__ __forceinline__ RgbProj rgb_project(const RgbResParams& p, const RgbOwn& o, int x, int y) {
   const float d1 = o.d1;
   const float fx_ = (float)x, fy_ = (float)y;
   RgbProj r;
-  r.transformed_d1 = d1 * ((p.krkinv.r2.x * fx_ + p.krkinv.r2.y * fy_) + p.krkinv.r2.z) + p.kt.z;
-  r.u0 = f2i_rn((d1 * ((p.krkinv.r0.x * fx_ + p.krkinv.r0.y * fy_) + p.krkinv.r0.z) + p.kt.x) / r.transformed_d1);
-  r.v0 = f2i_rn((d1 * ((p.krkinv.r1.x * fx_ + p.krkinv.r1.y * fy_) + p.krkinv.r1.z) + p.kt.y) / r.transformed_d1);
+  // d1 * ((k.x * x + k.y * y) + k.z) + kt
+  r.transformed_d1 = madd<FMA>(d1, madd<FMA>(p.krkinv.r2.y, fy_, p.krkinv.r2.x * fx_) + p.krkinv.r2.z, p.kt.z);
+  r.u0 = f2i_rn(madd<FMA>(d1, madd<FMA>(p.krkinv.r0.y, fy_, p.krkinv.r0.x * fx_) + p.krkinv.r0.z, p.kt.x) / r.transformed_d1);
+  r.v0 = f2i_rn(madd<FMA>(d1, madd<FMA>(p.krkinv.r1.y, fy_, p.krkinv.r1.x * fx_) + p.krkinv.r1.z, p.kt.y) / r.transformed_d1);
   r.ok = (int)o.gate & (int)(r.u0 >= 0) & (int)(r.v0 >= 0) & (int)(r.u0 < p.cols) & (int)(r.v0 < p.rows);
   return r;
 }
@@ -278,6 +314,7 @@ __device__ __forceinline__ RgbRowIn rgb_row_load(const dms_dataterm& c, const fl
 }
 
 // row is all zero for an invalid correspondence
+template <bool FMA = false>
 __device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms_dataterm& c, const RgbRowIn& in, float (&row)[7]) {
 #pragma unroll
   for (int i = 0; i < 7; ++i) row[i] = 0.f;
@@ -293,13 +330,13 @@ __device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms
   const float dI_dy_val = (w * p.sobelScale) * (float)in.gy;
   const float v0 = (dI_dx_val * p.fx) * invz;
   const float v1 = (dI_dy_val * p.fy) * invz;
-  const float v2 = -(v0 * pt.x + v1 * pt.y) * invz;
+  const float v2 = -madd<FMA>(v1, pt.y, v0 * pt.x) * invz;
   row[0] = v0;
   row[1] = v1;
   row[2] = v2;
-  row[3] = -pt.z * v1 + pt.y * v2;
-  row[4] = pt.z * v0 - pt.x * v2;
-  row[5] = -pt.y * v0 + pt.x * v1;
+  row[3] = madd<FMA>(pt.y, v2, -pt.z * v1);
+  row[4] = FMA ? fmaf(-pt.x, v2, pt.z * v0) : pt.z * v0 - pt.x * v2;
+  row[5] = madd<FMA>(pt.x, v1, -pt.y * v0);
 }
 
 // (the caller zero-fills row and skips invalid correspondences, as the reference does)

@@ -161,6 +161,7 @@ __host__ __device__ inline void ldlt_solve_ws(const T* Ain, const T* b, T* x, T 
 // and P of the full symmetric storage exactly as the loop version does.
 template <typename T, int N>
 __host__ __device__ __forceinline__ void ldlt_solve_reg(const T (&Ain)[N * N], const T (&b)[N], T (&x)[N], T tiny) {
+#pragma clang fp contract(fast)  // scalar section of the tracker: fused multiply-adds (see gn_step_core)
   T A[N * N];
 #pragma unroll
   for (int i = 0; i < N * N; ++i) A[i] = Ain[i];
@@ -275,6 +276,7 @@ __host__ __device__ __forceinline__ void ldlt_solve_reg(const T (&Ain)[N * N], c
 // cond(A) * 1e-16.
 template <typename T, int N>
 __host__ __device__ __forceinline__ bool ldlt_solve_spd(const T (&A)[N * N], const T (&b)[N], T (&x)[N]) {
+#pragma clang fp contract(fast)  // scalar section of the tracker: fused multiply-adds (see gn_step_core)
   T L[N * N], d[N], r[N];
   T dmax = T(0);
 #pragma unroll
@@ -333,6 +335,7 @@ __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tin
 
 // reference OdometryProvider::rodrigues (OdometryProvider.h:35-71), row-major 3×3
 __host__ __device__ inline void rodrigues(const double* src, double* R) {
+#pragma clang fp contract(fast)  // scalar section of the tracker: fused multiply-adds (see gn_step_core)
   const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   for (int k = 0; k < 9; ++k) R[k] = I[k];
   double rx = src[0], ry = src[1], rz = src[2];

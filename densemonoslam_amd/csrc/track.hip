@@ -32,6 +32,11 @@
 
 namespace dms {
 
+// The tracker object evaluates the Gauss-Newton rows with fused multiply-adds (pixel_ops.hpp madd<true>; what nvcc's default
+// -fmad=true does to the reference's kernels) in every execution mode; the operator layer (reduce.hip: dms_icpStep ...)
+// keeps every operation rounded.  The oracle restates both forms (orc_set_fused_rows).
+constexpr bool kTrackerFma = true;
+
 constexpr int kArMargin = 6;  // integer all-reduce: headroom (bits) of the fixed-point scale over the previous totals (see ar_bound_exp)
 
 struct TrackState {
@@ -499,11 +504,11 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, f
 #pragma unroll
     for (int p = 0; p < kPix; ++p) {
       if (ICP) {
-        ir[p] = icp_project(ip, io[p]);
+        ir[p] = icp_project<kTrackerFma>(ip, io[p]);
         im[p] = icp_load_model(a.maps, ir[p], a.rows);
       }
       if (RGB) {
-        rr[p] = rgb_project(rp, ro[p], px[p], py[p]);
+        rr[p] = rgb_project<kTrackerFma>(rp, ro[p], px[p], py[p]);
         rm[p] = rgb_load_model(a.rgb, rr[p]);
       }
     }
@@ -529,13 +534,13 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, f
       }
       if (ICP) {
         float row[7];
-        bool found = icp_finish(ip, io[p], ir[p], im[p], row);
+        bool found = icp_finish<kTrackerFma>(ip, io[p], ir[p], im[p], row);
         if (!live) {
           found = false;
 #pragma unroll
           for (int k = 0; k < 7; ++k) row[k] = 0.f;
         }
-        accumulate_se3(acc, row, found);
+        accumulate_se3<kTrackerFma>(acc, row, found);
       }
     }
   }
@@ -632,8 +637,8 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, c
 #pragma unroll
     for (int p = 0; p < kPix; ++p) {
       float row[7];
-      rgb_row_finish(p_, c[p], in[p], row);
-      accumulate_se3(acc, row, c[p].valid != 0);
+      rgb_row_finish<kTrackerFma>(p_, c[p], in[p], row);
+      accumulate_se3<kTrackerFma>(acc, row, c[p].valid != 0);
     }
   }
   block_reduce_store<kSE3>(acc, part_rgb, stride, blockIdx.x);
@@ -699,6 +704,7 @@ __device__ __forceinline__ void gn_params_local(GnLocal& L, const double* K) {
   gn_params_local_k(L, k);
 }
 __device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k) {
+#pragma clang fp contract(fast)  // the fp64 scalar section may fuse: ~1e-16 before the values are rounded to float, a quarter fewer dependent instructions
   // inverse pose [Ri | ti] = [R^T | -R^T t]
   double Ri[9], ti[3];
 #pragma unroll
@@ -736,6 +742,7 @@ __device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k) {
 // `side`: store the side outputs lastA / lastb (only the values of a level's last iteration are ever read).
 __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma, const SolveArgs& q,
                                              const KPre* kpre = nullptr, bool side = true) {
+#pragma clang fp contract(fast)  // the fp64 scalar section may fuse: ~1e-16 before the values are rounded to float, a quarter fewer dependent instructions
   float residual[2] = {0.f, 0.f};
   if (q.icp) {
     residual[0] = s_icp[27];
@@ -1339,6 +1346,10 @@ struct SumLds<true, NV> {
 // instantiates it for the model-to-model pass only.
 template <bool ICP, bool RGB, int P, bool F64, bool EXIT>
 __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
+  constexpr bool kFma = kTrackerFma;
+  // (the precise variant adds the rounded fp32 products, as the oracle does: a fused accumulate keeps the unrounded product, a
+  // ~3e-8 per-term difference that the fp64 sums of this variant would otherwise preserve)
+  constexpr bool kFmaAcc = kTrackerFma && !F64;
   __shared__ GnLocal s;
   __shared__ int s_redi[kPWaves][2];
   __shared__ SumLds<F64, kSE3> lds;
@@ -1463,11 +1474,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       if (ICP) {
-        ir[p] = icp_project(ip, io[p]);
+        ir[p] = icp_project<kFma>(ip, io[p]);
         im[p] = icp_load_model(a.maps, ir[p], a.rows);
       }
       if (RGB) {
-        rr[p] = rgb_project(rp, ro[p], px[p], py[p]);
+        rr[p] = rgb_project<kFma>(rp, ro[p], px[p], py[p]);
         rm[p] = rgb_load_model(a.rgb, rr[p]);
       }
     }
@@ -1490,13 +1501,13 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       }
       if (ICP) {
         float row[7];
-        bool found = icp_finish(ip, io[p], ir[p], im[p], row);
+        bool found = icp_finish<kFma>(ip, io[p], ir[p], im[p], row);
         if (!live) {
           found = false;
 #pragma unroll
           for (int k = 0; k < 7; ++k) row[k] = 0.f;
         }
-        accumulate_se3(acc, row, found);
+        accumulate_se3<kFmaAcc>(acc, row, found);
       }
     }
     phase(1);
@@ -1602,8 +1613,8 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         in.gx = gx[p];
         in.gy = gy[p];
         float row[7];
-        rgb_row_finish(p_, c[p], in, row);
-        accumulate_se3(acc, row, c[p].valid != 0);
+        rgb_row_finish<kFma>(p_, c[p], in, row);
+        accumulate_se3<kFmaAcc>(acc, row, c[p].valid != 0);
       }
       if constexpr (F64) {
         const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);

@@ -38,6 +38,10 @@ void orc_projectToPointCloud(const float* depth, int rows, int cols, float* clou
                              int level);
 
 /* ---- reduce.cu restatements ---- */
+/* rows of the tracker with every multiply-add chain fused in source order (1) or every operation rounded (0, default):
+ * see orc_track.c.  Process-wide switch; orc_odometry sets it around a call from its own `fused_rows` flag. */
+void orc_set_fused_rows(int on);
+int orc_get_fused_rows(void);
 int orc_icp_row(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
                 const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
                 float distThres, float angleThres, int rows, int cols, int x, int y, float* row);
@@ -84,6 +88,7 @@ void orc_odometry_initICPModel(orc_odometry* o, const float* verts4, const float
 void orc_odometry_initRGB(orc_odometry* o, const uint8_t* rgba);
 void orc_odometry_initRGBModel(orc_odometry* o, const uint8_t* rgba);
 void orc_odometry_initFirstRGB(orc_odometry* o, const uint8_t* rgba);
+void orc_odometry_set_fused_rows(orc_odometry* o, int on);
 void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
                                                int pyramid, int fastOdom, int so3, int interMap, orc_track_result* result);
 /* which: same numbering as dms_odometry_get_buffer; returns pointer to the dense host buffer */

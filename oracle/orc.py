@@ -54,6 +54,8 @@ lib.orc_qnan.restype = C.c_float
 lib.orc_odometry_create.restype = _P
 lib.orc_odometry_create.argtypes = [_I, _I, _F, _F, _F, _F, _F, _F]
 lib.orc_odometry_destroy.argtypes = [_P]
+lib.orc_odometry_set_fused_rows.argtypes = [_P, _I]
+lib.orc_set_fused_rows.argtypes = [_I]
 lib.orc_odometry_buffer.restype = _P
 lib.orc_odometry_buffer.argtypes = [_P, _I, _I]
 lib.orc_odometry_initICP_depth.argtypes = [_P, _P, _F]
@@ -284,6 +286,10 @@ class Odometry:
     def initFirstRGB(self, rgba):
         a = _c(rgba, np.uint8)
         lib.orc_odometry_initFirstRGB(self.h, _p(a))
+
+    def setFusedRows(self, on):
+        """rows with fused multiply-adds (the product's resident kernels) or with every operation rounded (its operator layer)"""
+        lib.orc_odometry_set_fused_rows(self.h, int(bool(on)))
 
     def getIncrementalTransformation(self, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap=False):
         t = _c(trans, np.float32).reshape(3).copy()

@@ -26,6 +26,7 @@ struct orc_odometry {
   float* pointClouds[NUM_PYRS];
   orc_dataterm* corresImg[NUM_PYRS];
   float *vmaps_tmp, *nmaps_tmp;
+  int fused_rows; /* evaluate the Gauss-Newton rows with fused multiply-adds (orc_set_fused_rows), as the product's resident kernels do */
 };
 
 /* ---- small dense algebra (Eigen stand-ins, fp64 unless stated) ------------------------ */
@@ -159,6 +160,7 @@ static void level_K(const orc_odometry* o, int level, double* K) { /* intr(level
 orc_odometry* orc_odometry_create(int width, int height, float cx, float cy, float fx, float fy, float distThresh,
                                   float angleThresh) {
   orc_odometry* o = (orc_odometry*)calloc(1, sizeof(orc_odometry));
+  o->fused_rows = 1; /* the tracker object of the product evaluates its rows fused (track.hip kTrackerFma) */
   o->width = width; o->height = height; o->cx = cx; o->cy = cy; o->fx = fx; o->fy = fy;
   o->distThres = distThresh > 0 ? distThresh : 0.10f;                                   /* RGBDOdometry.h:35 */
   o->angleThres = angleThresh > 0 ? angleThresh : (float)sin(20.f * 3.14159254f / 180.f); /* RGBDOdometry.h:36 */
@@ -282,7 +284,7 @@ void orc_odometry_initFirstRGB(orc_odometry* o, const uint8_t* rgba) {          
 }
 
 /* RGBDOdometry::getIncrementalTransformation, :268-605 */
-void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
+static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
                                                int pyramid, int fastOdom, int so3, int interMap, orc_track_result* res) {
   const int icp = !rgbOnly && icpWeight > 0; /* :278 */
   const int rgb = rgbOnly || icpWeight < 100; /* :279 */
@@ -475,4 +477,14 @@ void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, fl
   memcpy(rot, Rcurr, sizeof(Rcurr));
   memcpy(res->trans, tcurr, sizeof(tcurr));
   memcpy(res->rot, Rcurr, sizeof(Rcurr));
+}
+
+void orc_odometry_set_fused_rows(orc_odometry* o, int on) { o->fused_rows = on ? 1 : 0; }
+
+void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
+                                               int pyramid, int fastOdom, int so3, int interMap, orc_track_result* res) {
+  const int prev = orc_get_fused_rows();
+  orc_set_fused_rows(o->fused_rows);
+  track_impl(o, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap, res);
+  orc_set_fused_rows(prev);
 }

@@ -57,6 +57,35 @@ static inline v3 mmul(const float* m, v3 a) {                                   
   return V3(vdot(V3(m[0], m[1], m[2]), a), vdot(V3(m[3], m[4], m[5]), a), vdot(V3(m[6], m[7], m[8]), a));
 }
 
+/* ---- rows with fused multiply-adds ---------------------------------------------------------------------------
+ * The reference's kernels are built by nvcc with its default -fmad=true: multiply-add chains of the row arithmetic are
+ * contracted where the compiler sees fit, so "the" rounding of a row element is not defined by the source.  This
+ * restatement evaluates the rows in two forms: unfused (every operation rounds: the operator layer of the product) and,
+ * when orc_set_fused_rows(1), with every multiply-add chain fused in source order (the product's resident tracker
+ * kernels, pixel_ops.hpp madd<true>).  Hardware FMA when the CPU has it (a libm fmaf per operation is ~100x slower). */
+static int g_fused_rows = 0;
+void orc_set_fused_rows(int on) { g_fused_rows = on ? 1 : 0; }
+int orc_get_fused_rows(void) { return g_fused_rows; }
+
+__attribute__((target("fma"))) static inline float fma_hw(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline float fma_sw(float a, float b, float c) { return fmaf(a, b, c); }
+static int g_have_fma = -1;
+static inline float ffma(float a, float b, float c) {
+  if (g_have_fma < 0) g_have_fma = __builtin_cpu_supports("fma") ? 1 : 0;
+  return g_have_fma ? fma_hw(a, b, c) : fma_sw(a, b, c);
+}
+/* a*b + c, fused or not */
+static inline float madd(float a, float b, float c, int f) { return f ? ffma(a, b, c) : a * b + c; }
+static inline float vdot_t(v3 a, v3 b, int f) { return f ? ffma(a.z, b.z, ffma(a.y, b.y, a.x * b.x)) : vdot(a, b); }
+static inline v3 vcross_t(v3 a, v3 b, int f) {
+  if (f) return V3(ffma(a.y, b.z, -(a.z * b.y)), ffma(a.z, b.x, -(a.x * b.z)), ffma(a.x, b.y, -(a.y * b.x)));
+  return vcross(a, b);
+}
+static inline float vnorm_t(v3 a, int f) { return sqrtf(vdot_t(a, a, f)); }
+static inline v3 mmul_t(const float* m, v3 a, int f) {
+  return V3(vdot_t(V3(m[0], m[1], m[2]), a, f), vdot_t(V3(m[3], m[4], m[5]), a, f), vdot_t(V3(m[6], m[7], m[8]), a, f));
+}
+
 float orc_qnan(void) {
   uint32_t u = 0x7fffffffu; /* CUDART_NAN_F bit pattern used at cudafuncs.cu:125 */
   float f;
@@ -359,30 +388,31 @@ int orc_icp_row(const float* Rcurr, const float* tcurr, const float* vmap_curr, 
                 const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
                 float distThres, float angleThres, int rows, int cols, int x, int y, float* row) {
   const size_t P = (size_t)rows * cols;
+  const int f = g_fused_rows;
   for (int i = 0; i < 7; ++i) row[i] = 0;
   const size_t i0 = (size_t)y * cols + x;
   const v3 vcurr = V3(vmap_curr[i0], vmap_curr[P + i0], vmap_curr[2 * P + i0]);
   const v3 tc = V3(tcurr[0], tcurr[1], tcurr[2]), tp = V3(tprev[0], tprev[1], tprev[2]);
-  const v3 vcurr_g = vadd(mmul(Rcurr, vcurr), tc);
-  const v3 vcurr_cp = mmul(Rprev_inv, vsub(vcurr_g, tp));
+  const v3 vcurr_g = vadd(mmul_t(Rcurr, vcurr, f), tc);
+  const v3 vcurr_cp = mmul_t(Rprev_inv, vsub(vcurr_g, tp), f);
   const int ux = f2i_rn(vcurr_cp.x * fx / vcurr_cp.z + cx);
   const int uy = f2i_rn(vcurr_cp.y * fy / vcurr_cp.z + cy);
   if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return 0;
   const size_t i1 = (size_t)uy * cols + ux;
   const v3 vprev_g = V3(vmap_g_prev[i1], vmap_g_prev[P + i1], vmap_g_prev[2 * P + i1]);
   const v3 ncurr = V3(nmap_curr[i0], nmap_curr[P + i0], nmap_curr[2 * P + i0]);
-  const v3 ncurr_g = mmul(Rcurr, ncurr);
+  const v3 ncurr_g = mmul_t(Rcurr, ncurr, f);
   const v3 nprev_g = V3(nmap_g_prev[i1], nmap_g_prev[P + i1], nmap_g_prev[2 * P + i1]);
-  const float dist = vnorm(vsub(vprev_g, vcurr_g));
-  const float sine = vnorm(vcross(ncurr_g, nprev_g));
+  const float dist = vnorm_t(vsub(vprev_g, vcurr_g), f);
+  const float sine = vnorm_t(vcross_t(ncurr_g, nprev_g, f), f);
   if (!(sine < angleThres && dist <= distThres && !isnan(ncurr.x) && !isnan(nprev_g.x))) return 0;
-  const v3 s_cp = mmul(Rprev_inv, vsub(vcurr_g, tp));
-  const v3 d_cp = mmul(Rprev_inv, vsub(vprev_g, tp));
-  const v3 n_cp = mmul(Rprev_inv, nprev_g);
-  const v3 c = vcross(s_cp, n_cp);
+  const v3 s_cp = mmul_t(Rprev_inv, vsub(vcurr_g, tp), f);
+  const v3 d_cp = mmul_t(Rprev_inv, vsub(vprev_g, tp), f);
+  const v3 n_cp = mmul_t(Rprev_inv, nprev_g, f);
+  const v3 c = vcross_t(s_cp, n_cp, f);
   row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
   row[3] = c.x; row[4] = c.y; row[5] = c.z;
-  row[6] = vdot(n_cp, vsub(s_cp, d_cp));
+  row[6] = vdot_t(n_cp, vsub(s_cp, d_cp), f);
   return 1;
 }
 
@@ -443,9 +473,14 @@ void orc_computeRgbResidual(float minScale, const int16_t* dIdx, const int16_t* 
             const int y = i, x = j0;
             const float d1 = nextDepth[k];
             if (!isnan(d1)) {
-              const float transformed_d1 = (float)(d1 * (krkinv[6] * x + krkinv[7] * y + krkinv[8]) + kt[2]);
-              const int u0 = f2i_rn((d1 * (krkinv[0] * x + krkinv[1] * y + krkinv[2]) + kt[0]) / transformed_d1);
-              const int v0 = f2i_rn((d1 * (krkinv[3] * x + krkinv[4] * y + krkinv[5]) + kt[1]) / transformed_d1);
+              const int f = g_fused_rows;
+              const float xf = (float)x, yf = (float)y;
+              const float transformed_d1 = f ? ffma(d1, ffma(krkinv[7], yf, krkinv[6] * xf) + krkinv[8], kt[2])
+                                             : (float)(d1 * (krkinv[6] * x + krkinv[7] * y + krkinv[8]) + kt[2]);
+              const int u0 = f2i_rn((f ? ffma(d1, ffma(krkinv[1], yf, krkinv[0] * xf) + krkinv[2], kt[0])
+                                       : (d1 * (krkinv[0] * x + krkinv[1] * y + krkinv[2]) + kt[0])) / transformed_d1);
+              const int v0 = f2i_rn((f ? ffma(d1, ffma(krkinv[4], yf, krkinv[3] * xf) + krkinv[5], kt[1])
+                                       : (d1 * (krkinv[3] * x + krkinv[4] * y + krkinv[5]) + kt[1])) / transformed_d1);
               if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
                 const float d0 = lastDepth[(size_t)v0 * cols + u0];
                 if (d0 > 0 && fabsf(transformed_d1 - d0) <= maxDepthDelta && lastImage[(size_t)v0 * cols + u0] != 0) {
@@ -485,13 +520,14 @@ void orc_rgb_row(const orc_dataterm* c, float sigma, const float* cloud3, float 
   const float dI_dy_val = w * sobelScale * dIdy[k1];
   const float v0 = dI_dx_val * fx * invz;
   const float v1 = dI_dy_val * fy * invz;
-  const float v2 = -(v0 * cp[0] + v1 * cp[1]) * invz;
+  const int f = g_fused_rows;
+  const float v2 = -madd(v1, cp[1], v0 * cp[0], f) * invz;
   row[0] = v0;
   row[1] = v1;
   row[2] = v2;
-  row[3] = -cp[2] * v1 + cp[1] * v2;
-  row[4] = cp[2] * v0 - cp[0] * v2;
-  row[5] = -cp[1] * v0 + cp[0] * v1;
+  row[3] = madd(cp[1], v2, -cp[2] * v1, f);
+  row[4] = f ? ffma(-cp[0], v2, cp[2] * v0) : cp[2] * v0 - cp[0] * v2;
+  row[5] = madd(cp[0], v1, -cp[1] * v0, f);
 }
 
 /* rgbStep, reduce.cu:643-685 */

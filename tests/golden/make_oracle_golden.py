@@ -40,13 +40,17 @@ def fresh(z):
 
 def compute(z):
     out = {}
-    for name, cfg in CONFIGS.items():
-        o = fresh(z)
-        t, R, res = o.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **cfg)
-        out[name + "_t"] = t
-        out[name + "_R"] = R
-        out[name + "_counts"] = np.array([res.lastICPCount, res.lastRGBCount, res.lastSO3Count, res.so3_iterations_run] + list(res.iterations_run), np.float64)
-        out[name + "_lastA"] = np.array(res.lastA)
+    # two forms of the row arithmetic (oracle/orc_track.c): every operation rounded (the product's operator layer; keys
+    # without suffix) and multiply-add chains fused in source order (the product's tracker object; keys "_fma")
+    for fused, sfx in ((False, ""), (True, "_fma")):
+        for name, cfg in CONFIGS.items():
+            o = fresh(z)
+            o.setFusedRows(fused)
+            t, R, res = o.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **cfg)
+            out[name + sfx + "_t"] = t
+            out[name + sfx + "_R"] = R
+            out[name + sfx + "_counts"] = np.array([res.lastICPCount, res.lastRGBCount, res.lastSO3Count, res.so3_iterations_run] + list(res.iterations_run), np.float64)
+            out[name + sfx + "_lastA"] = np.array(res.lastA)
     o = fresh(z)
     K = (528.0, 528.0, 320.0, 240.0)
     I3, z3 = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)

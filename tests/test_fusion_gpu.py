@@ -860,9 +860,10 @@ def test_two_phase_frame_step_with_deformation(fus, orc, synth):
 
 
 def test_tracking_failure_detection(fus, orc, synth):
-    """--rl (ElasticFusion.cpp:204-244): garbage depth for 12 frames.  Those frames are tracked but not
-    fused; after more than 10 in a row the camera is lost: the tick stops, nothing fuses any more and
-    fill-in passes the raw frame through (so the tracker then matches the frame with itself)."""
+    """--rl (ElasticFusion.cpp:204-244): two frames of garbage depth, then ten without any.  Those frames are tracked
+    but not fused; after more than 10 in a row the camera is lost: the tick stops, nothing fuses any more and
+    fill-in passes the raw frame through (so the tracker then matches the frame with itself).  (Random depth alone is
+    not a robust failure: now and then a few hundred chance correspondences pass the error test and reset the count.)"""
     from oracle import orc_pipeline
 
     g = fus.ElasticFusion(W, H, K, model_capacity=600000, reloc=1)
@@ -871,8 +872,10 @@ def test_tracking_failure_detection(fus, orc, synth):
     seen_lost = False
     for k in range(17):
         d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
-        if 3 <= k <= 14:
+        if 3 <= k <= 4:
             d = rng.integers(500, 3000, d.shape).astype(np.uint16)
+        elif 5 <= k <= 14:
+            d = np.zeros_like(d)
         rg = g.processFrame(rgb, d)
         ro = o.processFrame(rgb, d)
         what = "frame %d" % k
