@@ -22,7 +22,7 @@ struct dms_odometry;
 
 namespace dms {
 // fusion_pre.hip
-int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
+int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s, int narrow_blocks = 0);
 int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
             int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src = nullptr, void* mirror_dst = nullptr,
@@ -172,6 +172,7 @@ struct dms_fusion {
   dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
   hipStream_t s_prep = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_inputs = nullptr;
+  int prep_blocks = 128;  // fat blocks of the bilateral filter on the prep stream (DMS_PREP_BLOCKS; 0 = one tile per block): 1816 -> 1867 frames/s
   int host_lag = 2;  // the host enqueues frame t once frame t - host_lag has completed (DMS_HOST_LAG = 2 | 3; 3 measured -2.4 %)
   bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
   int last_prep = -1;         // image set whose ev_prep_done marks the end of the last enqueued ingest
@@ -526,6 +527,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->s_prep, hipStreamNonBlocking);
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_prep_done[k], hipEventDisableTiming);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_main_done[k], hipEventDisableTiming);
+  if (const char* pb = getenv("DMS_PREP_BLOCKS")) f->prep_blocks = atoi(pb);
   if (const char* hl = getenv("DMS_HOST_LAG")) f->host_lag = atoi(hl) == 3 ? 3 : 2;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
@@ -676,7 +678,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   }
   {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
     FTimer t(f, sp, "preprocess");
-    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp))) return rc;
+    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp, f->p.pipeline_ingest ? f->prep_blocks : 0))) return rc;
     if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, sp))) return rc;
     if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, sp))) return rc;
   }

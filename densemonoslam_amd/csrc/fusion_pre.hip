@@ -11,58 +11,92 @@ static constexpr int BX = 64, BY = 4;
 // taps are fetched at (float(cx)/cols, float(cy)/rows) with the NEAREST rule of surfel.hpp.
 // The tap -> texel tables (one fp32 division + floor per column / row) are built once per block
 // in LDS instead of once per tap; the 169-tap sum itself keeps the shader's order and arithmetic.
-__global__ __launch_bounds__(BX* BY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
-                                                            int cols, int rows, float maxD) {
+// TBY rows per tile.  The kernel walks tiles with a block stride, so the launch decides its footprint: one tile per block
+// (grid = tiles: the whole chip, shortest run) or a few fat blocks that own the same few compute units for the whole image.
+// The frame step uses the second form on its prep stream: the previous frame's tracker runs beside it, and its resident
+// kernels need one EMPTY compute unit per block — with 1 200 small blocks sprinkled over every CU each tracker launch
+// waited for CUs to drain (+40 us on the level-0 kernel and +16 us on level 1 in the rocprof trace of round 2).
+// LUT (fat blocks only): the weight exp(-(space2 / 2 sigma_s^2 + (dv)^2 / 2 sigma_c^2)) depends on (|dx|, |dy|) in 0..6 and on the
+// integer depth difference |dv| in millimetres, and is exactly 0 from |dv| = 396 on (the argument falls below det_expf's
+// -87 cut-off whatever the distance): a 49 x 396 table in LDS, filled once per block with the very expression of the
+// direct form, replaces ~25 instructions per tap by one LDS read — the same bits, a third of the time.
+constexpr int kBilDv = 396;
+template <int TBY, bool LUT>
+__global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                                             int cols, int rows, float maxD) {
   constexpr int HALO = 8;
   __shared__ int s_sx[BX + 2 * HALO];
-  __shared__ int s_sy[BY + 2 * HALO];
+  __shared__ int s_sy[TBY + 2 * HALO];
   const float colsf = (float)cols, rowsf = (float)rows;
-  const int bx0 = blockIdx.x * BX - HALO, by0 = blockIdx.y * BY - HALO;
+  const int tiles_x = (cols + BX - 1) / BX, tiles_y = (rows + TBY - 1) / TBY;
   const int tid = threadIdx.y * BX + threadIdx.x;
-  if (tid < BX + 2 * HALO) s_sx[tid] = texel((float)(bx0 + tid) / colsf, colsf, cols);
-  if (tid >= 128 && tid < 128 + BY + 2 * HALO) s_sy[tid - 128] = texel((float)(by0 + tid - 128) / rowsf, rowsf, rows);
-  __syncthreads();
-  const int px = blockIdx.x * blockDim.x + threadIdx.x;
-  const int py = blockIdx.y * blockDim.y + threadIdx.y;
-  if (px >= cols || py >= rows) return;
-  const unsigned value = src[(size_t)py * cols + px];
-  const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
-  if (value > gate || value < 300U) {
-    dst[(size_t)py * cols + px] = 0;
-    return;
-  }
-  // int(texcoord * cols): texcoord of the fragment centre
-  const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
-  const int x = (int)(tcx * colsf);
-  const int y = (int)(tcy * rowsf);
-  const float sigma_space2_inv_half = 0.024691358f;
-  const float sigma_color2_inv_half = 0.000555556f;
-  const int R = 6;
-  const int D = R * 2 + 1;
-  const int tx = min(x - D / 2 + D, cols);
-  const int ty = min(y - D / 2 + D, rows);
-  const float fvalue = (float)value;
-  float sum1 = 0.f, sum2 = 0.f;
-  for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
-    const int ky = cy - by0;
-    const int sy = (ky >= 0 && ky < BY + 2 * HALO) ? s_sy[ky] : texel((float)cy / rowsf, rowsf, rows);
-    const unsigned short* srow = src + (size_t)sy * cols;
-    const int dyi = y - cy;
-    for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
-      const int kx = cx - bx0;
-      const int sx = (kx >= 0 && kx < BX + 2 * HALO) ? s_sx[kx] : texel((float)cx / colsf, colsf, cols);
-      const float ftmp = (float)srow[sx];
-      // (float(x)-float(cx))^2 + (float(y)-float(cy))^2: small integers, exact in fp32
-      const int dxi = x - cx;
-      const float space2 = (float)(dxi * dxi + dyi * dyi);
-      const float dc = fvalue - ftmp;
+  __shared__ float s_lut[LUT ? 49 * kBilDv : 1];
+  if (LUT) {
+    for (int e = tid; e < 49 * kBilDv; e += BX * TBY) {
+      const int pair = e / kBilDv, m = e - pair * kBilDv;
+      const int ady = pair / 7, adx = pair - ady * 7;
+      const float space2 = (float)(adx * adx + ady * ady);
+      const float dc = (float)m;
       const float color2 = dc * dc;
-      const float weight = det_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
-      sum1 += ftmp * weight;
-      sum2 += weight;
+      s_lut[e] = det_expf(-(space2 * 0.024691358f + color2 * 0.000555556f));
     }
   }
-  dst[(size_t)py * cols + px] = (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2));
+  for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int bx0 = txi * BX - HALO, by0 = tyi * TBY - HALO;
+    __syncthreads();  // the tables of the previous tile are no longer read
+    if (tid < BX + 2 * HALO) s_sx[tid] = texel((float)(bx0 + tid) / colsf, colsf, cols);
+    if (tid >= 128 && tid < 128 + TBY + 2 * HALO) s_sy[tid - 128] = texel((float)(by0 + tid - 128) / rowsf, rowsf, rows);
+    __syncthreads();
+    const int px = txi * BX + threadIdx.x;
+    const int py = tyi * TBY + threadIdx.y;
+    if (px >= cols || py >= rows) continue;
+    const unsigned value = src[(size_t)py * cols + px];
+    const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
+    if (value > gate || value < 300U) {
+      dst[(size_t)py * cols + px] = 0;
+      continue;
+    }
+    // int(texcoord * cols): texcoord of the fragment centre
+    const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
+    const int x = (int)(tcx * colsf);
+    const int y = (int)(tcy * rowsf);
+    const float sigma_space2_inv_half = 0.024691358f;
+    const float sigma_color2_inv_half = 0.000555556f;
+    const int R = 6;
+    const int D = R * 2 + 1;
+    const int tx = min(x - D / 2 + D, cols);
+    const int ty = min(y - D / 2 + D, rows);
+    const float fvalue = (float)value;
+    float sum1 = 0.f, sum2 = 0.f;
+    for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
+      const int ky = cy - by0;
+      const int sy = (ky >= 0 && ky < TBY + 2 * HALO) ? s_sy[ky] : texel((float)cy / rowsf, rowsf, rows);
+      const unsigned short* srow = src + (size_t)sy * cols;
+      const int dyi = y - cy;
+      for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
+        const int kx = cx - bx0;
+        const int sx = (kx >= 0 && kx < BX + 2 * HALO) ? s_sx[kx] : texel((float)cx / colsf, colsf, cols);
+        const unsigned tap = srow[sx];
+        const float ftmp = (float)tap;
+        // (float(x)-float(cx))^2 + (float(y)-float(cy))^2: small integers, exact in fp32
+        const int dxi = x - cx;
+        float weight;
+        if (LUT) {
+          const int dv = abs((int)value - (int)tap);
+          weight = dv < kBilDv ? s_lut[(abs(dyi) * 7 + abs(dxi)) * kBilDv + dv] : 0.f;
+        } else {
+          const float space2 = (float)(dxi * dxi + dyi * dyi);
+          const float dc = fvalue - ftmp;
+          const float color2 = dc * dc;
+          weight = det_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+        }
+        sum1 += ftmp * weight;
+        sum2 += weight;
+      }
+    }
+    dst[(size_t)py * cols + px] = (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2));
+  }
 }
 
 // G2 — depth_metric.frag:28-39
@@ -187,12 +221,17 @@ __global__ void k_resize_nn(const T* __restrict__ src, int scols, int srows, T* 
 
 static bool dense(const dms_image2d* im, size_t elem) { return im && im->data && im->pitch == (size_t)im->cols * elem; }
 
-int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s) {
+int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s, int narrow_blocks) {
   DMS_REQUIRE(dense(src, 2) && dense(dst, 2), "dense u16 images required");
   DMS_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, "shape mismatch");
-  dim3 b(BX, BY), g = grid2d(src->cols, src->rows, b);
-  hipLaunchKernelGGL(k_depth_bilateral, g, b, 0, s, (const unsigned short*)src->data, (unsigned short*)dst->data, src->cols, src->rows,
-                     maxD);
+  if (narrow_blocks > 0) {  // a few 1 024-thread blocks that keep to their compute units (see the kernel)
+    hipLaunchKernelGGL((k_depth_bilateral<16, true>), dim3(narrow_blocks), dim3(BX, 16), 0, s, (const unsigned short*)src->data,
+                       (unsigned short*)dst->data, src->cols, src->rows, maxD);
+  } else {
+    const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + BY - 1) / BY);
+    hipLaunchKernelGGL((k_depth_bilateral<BY, false>), dim3(tiles), dim3(BX, BY), 0, s, (const unsigned short*)src->data,
+                       (unsigned short*)dst->data, src->cols, src->rows, maxD);
+  }
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }
