@@ -295,7 +295,7 @@ def main():
         its = [10, 5, 4]
         traffic = None
         try:  # HBM bytes per launch from the PMC passes of the same command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "pmc_gn_level0.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_gn_level0.json")) as fh:
                 pm = json.load(fh)
             if pm.get("resolution") == [W, H]:
                 traffic = pm["hbm_bytes_per_launch"]
@@ -333,7 +333,7 @@ def main():
                 "avg_launch_us": kern["gn_level0"]["avg_us"],
                 "measured_copy_GBps": None if measured_copy is None else round(measured_copy, 1),
                 "note": "algorithmic bytes = 76 B/px/iteration (SURVEY 8d) x %d px x %d iterations; the launch is bound by its 20 grid-wide "
-                        "reductions (2 per iteration), not by HBM (DESIGN.md 6)" % (px[0], its[0]),
+                        "reductions (2 per iteration) and its per-CU arithmetic, not by HBM (DESIGN.md 6)" % (px[0], its[0]),
             }
         elif "gn_pass1" in kern:
             bytes_per_frame = sum(algorithmic_bytes("gn_pass1", W, H, M, p) * n for p, n in zip(px, its))
