@@ -347,6 +347,8 @@ int add_enqueue(dms_ferns* f, const float* pose16_host, const float* pose16_dev,
 
 // host mirrors of count and per-frame metadata (synchronises)
 int mirror(dms_ferns* f, hipStream_t s) {
+  // frames may have been added on any stream (dms_ferns_add_frame_async): wait for the device, not for `s` alone
+  DMS_HIP(hipDeviceSynchronize());
   DMS_HIP(hipMemcpyAsync(&f->n_host, f->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
   DMS_HIP(hipStreamSynchronize(s));
   const int n = f->n_host;
