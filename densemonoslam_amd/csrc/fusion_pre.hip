@@ -31,6 +31,8 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
   const int tiles_x = (cols + BX - 1) / BX, tiles_y = (rows + TBY - 1) / TBY;
   const int tid = threadIdx.y * BX + threadIdx.x;
   __shared__ float s_lut[LUT ? 49 * kBilDv : 1];
+  constexpr int TW = BX + 2 * HALO, TH = TBY + 2 * HALO;
+  __shared__ unsigned short s_tile[LUT ? TH : 1][LUT ? TW + 2 : 1];
   if (LUT) {
     for (int e = tid; e < 49 * kBilDv; e += BX * TBY) {
       const int pair = e / kBilDv, m = e - pair * kBilDv;
@@ -48,6 +50,15 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
     if (tid < BX + 2 * HALO) s_sx[tid] = texel((float)(bx0 + tid) / colsf, colsf, cols);
     if (tid >= 128 && tid < 128 + TBY + 2 * HALO) s_sy[tid - 128] = texel((float)(by0 + tid - 128) / rowsf, rowsf, rows);
     __syncthreads();
+    if (LUT) {
+      // the tile's source texels (halo included, through the same tap -> texel tables) once, coalesced: the tap loop then
+      // reads LDS only — per tap the direct form pays a dependent table read + global load + weight evaluation
+      for (int e = tid; e < TH * TW; e += BX * TBY) {
+        const int ky = e / TW, kx = e - ky * TW;
+        s_tile[ky][kx] = src[(size_t)s_sy[ky] * cols + s_sx[kx]];
+      }
+      __syncthreads();
+    }
     const int px = txi * BX + threadIdx.x;
     const int py = tyi * TBY + threadIdx.y;
     if (px >= cols || py >= rows) continue;
@@ -69,6 +80,32 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
     const int ty = min(y - D / 2 + D, rows);
     const float fvalue = (float)value;
     float sum1 = 0.f, sum2 = 0.f;
+    if (LUT) {
+      const int kx0 = x - D / 2 - bx0, ky0 = y - D / 2 - by0;
+      // interior pixel whose 13 x 13 window lies in the staged tile: constant trip counts, constant table rows; the same
+      // taps in the same order (rows outer, columns inner) and the same two sums
+      if (x - D / 2 >= 0 && x - D / 2 + D <= cols && y - D / 2 >= 0 && y - D / 2 + D <= rows && kx0 >= 0 && kx0 + D <= TW && ky0 >= 0 &&
+          ky0 + D <= TH) {
+#pragma unroll 1
+        for (int j = 0; j < D; ++j) {  // (rows stay a loop: 169 unrolled taps hoist more loads than 128 registers hold)
+          constexpr int R6 = D / 2;
+          const int ady = j < R6 ? R6 - j : j - R6;
+          const float* lrow = s_lut + ady * 7 * kBilDv;
+          const unsigned short* trow = &s_tile[ky0 + j][kx0];
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            const unsigned tap = trow[i];
+            const int dv = abs((int)value - (int)tap);
+            const int adx = i < R6 ? R6 - i : i - R6;
+            const float weight = dv < kBilDv ? lrow[adx * kBilDv + dv] : 0.f;
+            sum1 += (float)tap * weight;
+            sum2 += weight;
+          }
+        }
+        dst[(size_t)py * cols + px] = (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2));
+        continue;
+      }
+    }
     for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
       const int ky = cy - by0;
       const int sy = (ky >= 0 && ky < TBY + 2 * HALO) ? s_sy[ky] : texel((float)cy / rowsf, rowsf, rows);
