@@ -192,11 +192,15 @@ class InterMapMatcher:
         # results of the search enqueued a frame ago are on the host by now
         self.candidates += int((self.best_host[:, 0] >= 0).sum())
         T = self.x.thumb_bytes
-        for r in range(self.world):
-            if r == self.rank:
-                continue
-            p = g[r].data_ptr()
-            self.ferns.searchCodes(p + T + DESC_CODES, p + T + DESC_GOOD, int(tick), True, self.best_dev[r].data_ptr(), stream)
+        if hasattr(self.ferns, "searchBlocks"):  # every remote descriptor in one launch
+            self.ferns.searchBlocks(g.data_ptr(), self.x.nbytes, self.world, self.rank, T + DESC_CODES, T + DESC_GOOD, int(tick), True,
+                                    self.best_dev.data_ptr(), stream)
+        else:
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                p = g[r].data_ptr()
+                self.ferns.searchCodes(p + T + DESC_CODES, p + T + DESC_GOOD, int(tick), True, self.best_dev[r].data_ptr(), stream)
         self.best_host.copy_(self.best_dev, non_blocking=True)
         if self.verify_interval and self.frames % self.verify_interval == 0:
             self.verify(g, tick, stream)

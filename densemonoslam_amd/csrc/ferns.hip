@@ -131,6 +131,38 @@ __global__ __launch_bounds__(256) void k_fern_search(const unsigned char* __rest
   atomicMin(best, ((unsigned long long)__float_as_uint(dissim) << 32) | (unsigned)j);
 }
 
+// the same search for a batch of descriptors (collaborative mode: every other camera's frame block in the gathered
+// buffer): blockIdx.y = query, its codes / good-code count at base + q * stride + codes_off / good_off; query `skip`
+// (this rank's own block) is left alone.  best[q] must hold ~0 on entry.
+__global__ __launch_bounds__(256) void k_fern_search_batch(const unsigned char* __restrict__ db_codes, const int* __restrict__ db_good,
+                                                           const int* __restrict__ db_time, const int* __restrict__ n_dev,
+                                                           const unsigned char* __restrict__ base, size_t stride, size_t codes_off,
+                                                           size_t good_off, int skip, int time, int all_frames,
+                                                           unsigned long long* __restrict__ best) {
+  const int q = blockIdx.y;
+  if (q == skip) return;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= *n_dev) return;
+  const unsigned char* blk = base + (size_t)q * stride;
+  const unsigned long long mine = reinterpret_cast<const unsigned long long*>(blk + codes_off)[lane];
+  const unsigned long long theirs = reinterpret_cast<const unsigned long long*>(db_codes + (size_t)j * kFernPad)[lane];
+  int co = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const unsigned m = (unsigned)(mine >> (8 * b)) & 0xFFu, t = (unsigned)(theirs >> (8 * b)) & 0xFFu;
+    co += (m != DMS_FERN_BAD_CODE && m == t) ? 1 : 0;
+  }
+  co = wave_sum_i(co);
+  if (lane != 0) return;
+  if (!(all_frames || time - db_time[j] > 300)) return;
+  const int g = *reinterpret_cast<const int*>(blk + good_off), gj = db_good[j];
+  const float maxCo = (float)(g < gj ? g : gj);
+  const float dissim = (maxCo - (float)co) / maxCo;
+  if (dissim != dissim) return;
+  atomicMin(best + q, ((unsigned long long)__float_as_uint(dissim) << 32) | (unsigned)j);
+}
+
 // blockHDAware(query, best frame) (Ferns.cpp:684-704) for the frame the search chose, without a host round trip
 __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __restrict__ db_codes, const unsigned char* __restrict__ cur_codes,
                                                       int num, FernHost* __restrict__ res) {
@@ -662,6 +694,23 @@ int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const i
   if (f->n_upper > 0) {
     hipLaunchKernelGGL(k_fern_search, dim3((f->n_upper + 3) / 4), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n, codes_dev, good_dev,
                        time, interMap ? 1 : 0, (unsigned long long*)best2_dev);
+    DMS_CHECK_LAUNCH();
+  }
+  return DMS_OK;
+}
+
+int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride, int count, int skip, size_t codes_offset, size_t good_offset,
+                            int time, int interMap, int* best2_dev, dms_stream st) {
+  DMS_REQUIRE(f && blocks_dev && best2_dev && count >= 1, "bad argument");
+  DMS_REQUIRE(((uintptr_t)blocks_dev & 7) == 0 && (stride & 7) == 0 && (codes_offset & 7) == 0 && (good_offset & 3) == 0 &&
+                  ((uintptr_t)best2_dev & 7) == 0,
+              "8-byte aligned blocks, stride, code offset and result required");
+  hipStream_t s = (hipStream_t)st;
+  DMS_HIP(hipMemsetAsync(best2_dev, 0xFF, (size_t)count * 8, s));
+  if (f->n_upper > 0) {
+    hipLaunchKernelGGL(k_fern_search_batch, dim3((f->n_upper + 3) / 4, count), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n,
+                       (const unsigned char*)blocks_dev, stride, codes_offset, good_offset, skip, time, interMap ? 1 : 0,
+                       (unsigned long long*)best2_dev);
     DMS_CHECK_LAUNCH();
   }
   return DMS_OK;

@@ -87,6 +87,13 @@ int dms_ferns_find_frame_thumbs(dms_ferns* f, const void* thumb_block_dev, const
 int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const int* good_dev, int time, int interMap, int* best2_dev,
                            dms_stream s);
 
+/* The search for a batch of descriptors in one launch: `count` blocks of `stride` bytes at blocks_dev, each holding
+ * DMS_FERN_MAX code bytes at codes_offset and its good-code count (int) at good_offset — the gathered frame blocks of
+ * collaborative mode; block `skip` (the caller's own, or -1) is left out.  best2_dev: count x {candidate id or -1,
+ * dissimilarity bits}. */
+int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride, int count, int skip, size_t codes_offset,
+                            size_t good_offset, int time, int interMap, int* best2_dev, dms_stream s);
+
 /* void Ferns::consume(otherFrames, relativeTransform, threshold) (Ferns.cpp:160-168): every stored frame of `src`,
  * re-posed by relativeTransform, goes through addFrame(Frame*, threshold) of `dst` (re-encoded with dst's table).
  * added = frames accepted.  Synchronises. */

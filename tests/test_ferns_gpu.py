@@ -225,6 +225,20 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
         b = best.download(np.int32, (2,))
         m, _ = gs.findFrameThumbs(blk.ptr, np.eye(4, dtype=np.float32), 1000, interMap=True)
         assert b[0] == m.candidate and np.array([b[1]], np.int32).view(np.float32)[0] == np.float32(m.dissimilarity)
+    # the batched form (all gathered blocks in one launch) gives what the single searches give; the caller's own block is skipped
+    nb = len(blocks)
+    stride = T + collab.DESC_BYTES
+    allb = DeviceBuffer(nb * stride)
+    from densemonoslam_amd.capi import lib
+    for i, blk in enumerate(blocks):
+        assert lib.dms_memcpy_d2d_async(allb.ptr + i * stride, blk.ptr, stride, None) == 0
+    bestn = DeviceBuffer(8 * nb)
+    ga.searchBlocks(allb.ptr, stride, nb, 2, T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, bestn.ptr)
+    bn = bestn.download(np.int32, (nb, 2))
+    for i, blk in enumerate(blocks):
+        ga.searchCodes(blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD, 1000, True, best.ptr)
+        b = best.download(np.int32, (2,))
+        assert (bn[i] == ([-1, -1] if i == 2 else b)).all(), i
     ga.close()
     gs.close()
     ef.close()
