@@ -268,8 +268,23 @@ __host__ __device__ __forceinline__ void ldlt_solve_reg(const T (&Ain)[N * N], c
   for (int i = 0; i < N; ++i) x[i] = y[i];
 }
 
+// 1 / d for the unpivoted solve: the hardware estimate and two Newton steps (the first four operations of the
+// IEEE division sequence, without its scaling and final correction): within ~1e-16 of the quotient for normal d
+__host__ __device__ __forceinline__ double rcp_newton(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(e, r, r);
+#else
+  return 1.0 / d;
+#endif
+}
+__host__ __device__ __forceinline__ float rcp_newton(float d) { return 1.0f / d; }
+
 // Fast path for the tracker's normal case: an unpivoted LDL^T of a symmetric positive definite
-// matrix, all in registers, one reciprocal per column.  Returns false (x untouched) unless every
+// matrix, all in registers, one reciprocal (estimate + two Newton steps) per column.  Returns false (x untouched) unless every
 // pivot is positive and not tiny against the largest diagonal entry, i.e. unless the matrix is
 // safely positive definite; the caller then falls back to the pivoted routine above, which is what
 // defines the result on (near-)singular systems.  On accepted systems the two solutions agree to
@@ -294,7 +309,7 @@ __host__ __device__ __forceinline__ bool ldlt_solve_spd(const T (&A)[N * N], con
     }
     d[k] = dk;
     ok = ok && (dk > floor_);
-    r[k] = T(1) / dk;
+    r[k] = rcp_newton(dk);
 #pragma unroll
     for (int i = k + 1; i < N; ++i) {
       T v = A[i * N + k];
@@ -333,13 +348,42 @@ __host__ __device__ inline void ldlt_solve(const T* Ain, const T* b, T* x, T tin
   ldlt_solve_ws<T, N>(Ain, b, x, tiny, A, temp, y, perm);
 }
 
-// reference OdometryProvider::rodrigues (OdometryProvider.h:35-71), row-major 3×3
+// reference OdometryProvider::rodrigues (OdometryProvider.h:35-71), row-major 3×3:
+//   R = cos(t) I + (1 - cos(t)) r^ r^T + sin(t) [r^]x,  r^ = r / t,  t = |r|
+// For t < 0.78 (every Gauss-Newton update) the three coefficients cos(t), (1 - cos(t)) / t^2 and sin(t) / t are taken as
+// polynomials in z = t^2 (the minimax kernels of fdlibm's k_sin.c / k_cos.c, < 1 ulp on |t| <= pi/4), which needs no
+// square root, no division and no argument reduction: R = c I + b r r^T + a [r]x, the same matrix to ~2e-16 per entry
+// before the pose is rounded to float.  Larger angles take the reference's form.
 __host__ __device__ inline void rodrigues(const double* src, double* R) {
 #pragma clang fp contract(fast)  // scalar section of the tracker: fused multiply-adds (see gn_step_core)
+  double rx = src[0], ry = src[1], rz = src[2];
+  const double z = rx * rx + ry * ry + rz * rz;
+  if (z < 0.6 && z >= 4.9303806576313238e-32) {  // theta in [DBL_EPSILON, 0.77): below, the reference returns the identity
+    const double a = 1.0 + z * (-1.66666666666666324348e-01 +
+                                z * (8.33333333332248946124e-03 +
+                                     z * (-1.98412698298579493134e-04 +
+                                          z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+    const double q = 4.16666666666666019037e-02 +
+                     z * (-1.38888888888741095749e-03 +
+                          z * (2.48015872894767294178e-05 +
+                               z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double b = 0.5 - z * q;  // (1 - cos t) / t^2
+    const double c = 1.0 - z * b;  // cos t
+    const double bx = b * rx, by = b * ry, bz = b * rz;
+    R[0] = c + bx * rx;
+    R[1] = bx * ry - a * rz;
+    R[2] = bx * rz + a * ry;
+    R[3] = bx * ry + a * rz;
+    R[4] = c + by * ry;
+    R[5] = by * rz - a * rx;
+    R[6] = bx * rz - a * ry;
+    R[7] = by * rz + a * rx;
+    R[8] = c + bz * rz;
+    return;
+  }
   const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   for (int k = 0; k < 9; ++k) R[k] = I[k];
-  double rx = src[0], ry = src[1], rz = src[2];
-  const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+  const double theta = sqrt(z);
   if (theta >= 2.2204460492503131e-16) {
     double s, c;
     sincos(theta, &s, &c);  // one range reduction for both

@@ -739,7 +739,7 @@ __device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k) {
 // One Gauss-Newton update (RGBDOdometry.cpp:472-585): combine the two 6x6 systems, pivoted LDLT in
 // fp64, se(3) update of resultRt, new float pose, projection parameters for `next_level`.
 // `kpre`: camera matrix of q.next_level prepared by the caller (resident kernels: once per level); null = derive it here.
-// `side`: store the side outputs lastA / lastb (only the values of a level's last iteration are ever read).
+// `side`: store the side outputs lastA / lastb / last*Error / last*Count (only the values of a level's last iteration are ever read).
 __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma, const SolveArgs& q,
                                              const KPre* kpre = nullptr, bool side = true) {
 #pragma clang fp contract(fast)  // the fp64 scalar section may fuse: ~1e-16 before the values are rounded to float, a quarter fewer dependent instructions
@@ -835,11 +835,11 @@ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, con
   sm::mul3v<float>(Rprev, ti, tc);
 
   L.iters_run += 1;
-  L.lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
-  L.lastRGBCount = (float)rgbSize;
-  L.lastICPError = sqrtf(residual[0]) / residual[1];
-  L.lastICPCount = residual[1];
   if (side) {
+    L.lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
+    L.lastRGBCount = (float)rgbSize;
+    L.lastICPError = sqrtf(residual[0]) / residual[1];
+    L.lastICPCount = residual[1];
 #pragma unroll
     for (int i = 0; i < 36; ++i) L.lastA[i] = A[i];
 #pragma unroll
@@ -1232,10 +1232,12 @@ __device__ __forceinline__ int ar_exp_of(float d) {
 }
 // bound exponent of value k of an (N+1) x (N+1) upper-triangle layout (N Jacobian columns + residual; then the
 // residual square and the count): N = 6 for the 29 SE3 sums, N = 3 for the 11 SO3 sums.  `sums` = previous totals.
+// The two diagonal entries that bound value k (a lane constant: the resident kernels derive it once per launch);
+// packed as di | dj << 8, or -1 for the count.
 template <int N>
-__device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin) {
+__device__ __forceinline__ int ar_bound_idx(int k) {
   constexpr int NP = N * (N + 3) / 2;
-  if (k > NP) return 20;  // the count: at most 2048 pixels per block
+  if (k > NP) return -1;  // the count: at most 2048 pixels per block
   int i = N, j = N;       // k == NP: residual^2
   if (k < NP) {
     int off = 0;
@@ -1251,8 +1253,16 @@ __device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin
   }
   const int di = i == N ? NP : (N + 1) * i - (i * (i - 1)) / 2;
   const int dj = j == N ? NP : (N + 1) * j - (j * (j - 1)) / 2;
-  const int eb = ((ar_exp_of(sums[di]) + ar_exp_of(sums[dj]) + 1) >> 1) + margin;
+  return di | (dj << 8);
+}
+__device__ __forceinline__ int ar_bound_exp_at(const float* sums, int idx, int margin) {
+  if (idx < 0) return 20;
+  const int eb = ((ar_exp_of(sums[idx & 255]) + ar_exp_of(sums[idx >> 8]) + 1) >> 1) + margin;
   return eb < -200 ? -200 : (eb > 200 ? 200 : eb);
+}
+template <int N>
+__device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin) {
+  return ar_bound_exp_at(sums, ar_bound_idx<N>(k), margin);
 }
 
 // wave 0, all 64 lanes: every lane with `mine` polls the 8 shard words of `slot` until they show nb arrivals.
@@ -1362,6 +1372,8 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
   int eb_icp = 0, eb_rgb = 0, eb_slot = 0;  // wave 0: bound exponents of the values this lane adds / polls (all-reduce)
+  const int eb_idx = ar_bound_idx<6>(tid < kSE3 ? tid : 0);  // (lane constants of ar_bound_exp)
+  const int eb_idx_hi = ar_bound_idx<6>(tid >= 32 && tid - 32 < kSE3 ? tid - 32 : 0);
   // optional phase clock (block 0, thread 0): wall_clock64 ticks (10 ns) summed per phase into L.prof
   // (accumulated in LDS and flushed once at the end: a global read-modify-write per phase would
   // stall wave 0 for a memory round trip each time and distort what it measures)
@@ -1700,9 +1712,9 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     __syncthreads();
     if constexpr (!F64) {
       if (tid < 64) {  // scale of every value for the next iteration, from the totals all blocks hold
-        eb_icp = ar_bound_exp<6>(s_sums, tid < kSE3 ? tid : 0, L.ar_margin);
-        eb_rgb = ar_bound_exp<6>(s_sums + 32, tid < kSE3 ? tid : 0, L.ar_margin);
-        eb_slot = tid < 32 ? eb_icp : ar_bound_exp<6>(s_sums + 32, tid - 32 < kSE3 ? tid - 32 : 0, L.ar_margin);
+        eb_icp = ar_bound_exp_at(s_sums, eb_idx, L.ar_margin);
+        eb_rgb = ar_bound_exp_at(s_sums + 32, eb_idx, L.ar_margin);
+        eb_slot = tid < 32 ? eb_icp : ar_bound_exp_at(s_sums + 32, eb_idx_hi, L.ar_margin);
       }
     }
     phase(7);
@@ -1780,6 +1792,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   __shared__ TrackState s;
   __shared__ int s_ovf;
   int eb_mine = 0;  // wave 0, lane k < 11: bound exponent of value k (integer all-reduce, see ar_bound_exp)
+  const int eb_idx = ar_bound_idx<3>((int)threadIdx.x < kSO3 ? (int)threadIdx.x : 0);
   static_assert(kSO3 * kPB * 4 >= 16 * 64 * 8, "gather scratch fits the reduce buffer");
   __shared__ SumLds<F64, kSO3> lds;
   __shared__ float s_sums[kRecFloats];
@@ -1863,7 +1876,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
     __syncthreads();
     if (s.so3_done) break;
     if constexpr (!F64) {
-      if (tid < 64) eb_mine = ar_bound_exp<3>(s_sums, tid < kSO3 ? tid : 0, use_ar_arg >> 8);
+      if (tid < 64) eb_mine = ar_bound_exp_at(s_sums, eb_idx, use_ar_arg >> 8);
     }
   }
   __syncthreads();
