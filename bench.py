@@ -125,7 +125,8 @@ def main():
     def make_engine(loop_closure=args.loop_closure):
         return fusion.ElasticFusion(W, H, K, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1,
                                     local_loop_closure=1 if loop_closure else 0, timeDelta=args.time_delta,
-                                    share_projection=int(os.environ.get("DMS_SHARE_PROJECTION", "1")))
+                                    share_projection=int(os.environ.get("DMS_SHARE_PROJECTION", "1")),
+                                    fused_fill_in=int(os.environ.get("DMS_FUSED_FILL_IN", "1")))
 
     stream = torch.cuda.current_stream().cuda_stream
     ef = make_engine()

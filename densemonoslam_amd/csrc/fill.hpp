@@ -1,0 +1,118 @@
+// Hole fill-in of a model prediction (G10: fill_vertex.frag / fill_normal.frag / fill_rgb.frag), per pixel.
+// Shared by the stand-alone kernel (fusion_pre.hip) and the prediction's resolve pass (fusion_map.hip), which fills
+// the pixel it has just resolved instead of leaving that to a second launch over the same images.
+#pragma once
+#include "surfel.hpp"
+
+namespace dms {
+
+struct FillArgs {
+  const float4* ex_vertex;
+  const float4* ex_normal;
+  const uchar4* ex_image;
+  const unsigned short* depth;  // filtered, mm
+  const uchar4* rgba;
+  // optional: block (0,0) also copies `mirror_words` dwords (the frame's result block into its pinned
+  // host mirror — the frame step's last kernel does the copy a separate blit launch would do)
+  const unsigned* mirror_src;
+  unsigned* mirror_dst;
+  int mirror_words;
+  // optional: denseEnough (ElasticFusion.cpp:84-97,166-167) from the existing image: the share of non-black pixels on
+  // its W/20 x H/20 NEAREST subsample (Resize::image); *dense_flag = 0 when more than 95 % are covered, 1 (fill in)
+  // otherwise.  Independent of the fill-in itself.  Stand-alone kernel: one extra block (grid row `rows_blocks`);
+  // resolve pass: the block that finishes last (`tickets`: 17 zeroed counters, 64 bytes apart, left zeroed).
+  int* dense_flag;
+  int rows_blocks;
+  unsigned* tickets;
+  // resolve pass: bit masks of the columns (words 0..63) and rows (words 64..127) the subsample reads (fill_sample_masks);
+  // those pixels of the image are written through, the last block reads them back
+  const unsigned* sample_mask;
+  float4* out_vertex;
+  float4* out_normal;
+  uchar4* out_image;
+  int cols, rows;
+  float cx, cy, ifx, ify;  // cam = (cx, cy, 1/fx, 1/fy) with float reciprocals (FillIn.cpp:120-123)
+  int pass_geom, pass_rgb;
+};
+
+__device__ __forceinline__ f3 fill_vertex_at(const FillArgs& a, int sx, int sy, int x, int y) {
+  // geometry.glsl:41-45 (usampler2D variant): z = texel / 1000
+  const float z = (float)a.depth[(size_t)sy * a.cols + sx] / 1000.0f;
+  return mk3((((float)x - a.cx) * z) * a.ifx, (((float)y - a.cy) * z) * a.ify, z);
+}
+
+// pixel (px, py) whose existing (predicted) values are sv / sn / si
+__device__ __forceinline__ void fill_pixel(const FillArgs& a, int px, int py, const float4& sv, const float4& sn, const uchar4& si) {
+  const size_t i = (size_t)py * a.cols + px;
+  const float colsf = (float)a.cols, rowsf = (float)a.rows;
+  const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
+  const int x = (int)(tcx * colsf), y = (int)(tcy * rowsf);
+  {  // fill_vertex.frag:41-55
+    if (sv.z == 0.f || a.pass_geom == 1) {
+      const f3 v = fill_vertex_at(a, px, py, x, y);
+      a.out_vertex[i] = make_float4(v.x, v.y, v.z, 1.f);
+    } else {
+      a.out_vertex[i] = sv;
+    }
+  }
+  {  // fill_normal.frag:33-48 with geometry.glsl:48-58 forward differences
+    if (sn.z == 0.f || a.pass_geom == 1) {
+      const f3 v = fill_vertex_at(a, px, py, x, y);
+      const int sxp = texel(tcx + (1.0f / colsf), colsf, a.cols);
+      const int syp = texel(tcy + (1.0f / rowsf), rowsf, a.rows);
+      const f3 vx = fill_vertex_at(a, sxp, py, x + 1, y);
+      const f3 vy = fill_vertex_at(a, px, syp, x, y + 1);
+      const f3 n = normalized3(cross3(vx - v, vy - v));
+      a.out_normal[i] = make_float4(n.x, n.y, n.z, 1.f);
+    } else {
+      a.out_normal[i] = sn;
+    }
+  }
+  {  // fill_rgb.frag:29-37: samp.x + samp.y + samp.z == 0 on normalised bytes <=> all three zero
+    if ((si.x == 0 && si.y == 0 && si.z == 0) || a.pass_rgb == 1)
+      a.out_image[i] = a.rgba[i];
+    else
+      a.out_image[i] = si;
+  }
+}
+
+// host: the column / row masks of the W/20 x H/20 NEAREST subsample (cols, rows <= 2048), 128 words
+inline void fill_sample_masks(int cols, int rows, unsigned* words128) {
+  for (int i = 0; i < 128; ++i) words128[i] = 0u;
+  const int dw = cols / 20, dh = rows / 20;
+  for (int i = 0; i < dw; ++i) {
+    const int sx = texel(((float)i + 0.5f) / (float)dw, (float)cols, cols);
+    words128[sx >> 5] |= 1u << (sx & 31);
+  }
+  for (int j = 0; j < dh; ++j) {
+    const int sy = texel(((float)j + 0.5f) / (float)dh, (float)rows, rows);
+    words128[64 + (sy >> 5)] |= 1u << (sy & 31);
+  }
+}
+
+// the denseEnough decision by one block of NT threads (t = linear thread id); COHERENT: the image was written by other
+// blocks of the same launch (reads that bypass the non-coherent cache levels)
+template <int NT, bool COHERENT>
+__device__ __forceinline__ void fill_dense_test(const FillArgs& a, int t, int* s_sum /* [NT / 64] in LDS */) {
+  const int dw = a.cols / 20, dh = a.rows / 20;
+  int sum = 0;
+  for (int k = t; k < dw * dh; k += NT) {
+    const int i = k % dw, j = k / dw;
+    const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
+    const int sx = texel(u, (float)a.cols, a.cols), sy = texel(v, (float)a.rows, a.rows);
+    const unsigned* p = reinterpret_cast<const unsigned*>(a.ex_image + (size_t)sy * a.cols + sx);
+    const unsigned w = COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    sum += ((w & 0xFFu) > 0 && ((w >> 8) & 0xFFu) > 0 && ((w >> 16) & 0xFFu) > 0) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if ((t & 63) == 0) s_sum[t >> 6] = sum;
+  __syncthreads();
+  if (t == 0) {
+    int tot = 0;
+    for (int w = 0; w < NT / 64; ++w) tot += s_sum[w];
+    const bool dense = (float)tot / (float)(dh * dw) > 0.95f;
+    *a.dense_flag = dense ? 0 : 1;
+  }
+}
+
+}  // namespace dms

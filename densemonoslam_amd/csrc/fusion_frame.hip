@@ -17,6 +17,7 @@
 #include "smallmath.hpp"
 #include "surfel.hpp"
 #include "frame_state.hpp"
+#include "fill.hpp"
 
 struct dms_odometry;
 
@@ -27,6 +28,8 @@ int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
             int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src = nullptr, void* mirror_dst = nullptr,
             int mirror_bytes = 0, int* dense_flag = nullptr);
+int fill_args(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom, int pass_rgb,
+              dms_predict_out* out, const void* mirror_src, void* mirror_dst, int mirror_bytes, int* dense_flag, FillArgs* res);
 int resize_nn(const dms_image2d* src, dms_image2d* dst, int elem, hipStream_t s);
 // fusion_map.hip
 int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* dm, const dms_image2d* dmf, const dms_camera* cam, int time,
@@ -38,7 +41,7 @@ int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStr
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime = nullptr,
-                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0);
+                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0, const FillArgs* fill = nullptr);
 int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s);
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
@@ -199,6 +202,7 @@ struct dms_fusion {
   // second z-buffer: filled by the final prediction's project pass with the NEXT frame's tracking prediction (same map,
   // same pose unless the caller brings a prior), resolved at that frame's begin instead of projecting the map again
   unsigned long long* zbuf2 = nullptr;
+  unsigned* tickets = nullptr;  // 17 counters, 64 bytes apart (fused fill-in: which block finishes last); subsample masks at word 512
   double host_wait_ms = 0.0;     // host time spent blocked on the bounded run-ahead ("host_wait" of dms_fusion_get_kernel_time)
   bool pre_valid = false;        // zbuf2 holds a projection
   int pre_tick = 0;              // ... rendered for this tick
@@ -295,6 +299,7 @@ void layout(dms_fusion* f, Carve& c) {
   f->untr = c.take(N * 16);
   f->zbuf = (unsigned long long*)c.take(N * 8);
   f->zbuf2 = (unsigned long long*)c.take(N * 8);
+  f->tickets = (unsigned*)c.take(2048 + 512);  // + the subsample masks (128 words at word 512)
   f->state = (FrameState*)c.take(sizeof(FrameState));
 }
 
@@ -359,6 +364,16 @@ void drain(dms_fusion* f) {
 int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr, bool dense_test = false, int mode = 0,
             bool have_prior = false) {
   int rc;
+  FillArgs fa;
+  const FillArgs* fused = nullptr;
+  // passthrough = lost (geometry), lost || frameToFrameRGB (image) (ElasticFusion.cpp:704-712)
+  // (the frame's last fill-in also copies the result block into its pinned host slot)
+  if ((rc = fill_args(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
+                      state_mirror ? f->state : nullptr, state_mirror, (int)sizeof(FrameState), dense_test ? &f->state->fill_in : nullptr, &fa)))
+    return rc;
+  fa.tickets = f->tickets;
+  fa.sample_mask = f->tickets + 512;
+  if (f->p.fused_fill_in && f->p.width <= 2048 && f->p.height <= 2048) fused = &fa;
   {
     FTimer t(f, s, "predict");
     const int W = f->p.width, H = f->p.height;
@@ -366,7 +381,7 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
     if (mode == 2 && f->pre_valid) {
       if (!have_prior && f->pre_tick == f->tick && f->pre_version == f->model->version) {
         if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
-                                f->p.timeDelta, 1, f->zbuf2, &f->pred, nullptr, 1, s, nullptr, nullptr, 1)))
+                                f->p.timeDelta, 1, f->zbuf2, &f->pred, nullptr, 1, s, nullptr, nullptr, 1, fused)))
           return rc;
         done = true;
       } else if ((rc = clear_zbuf(f->zbuf2, W * H, s))) {  // stale: the resolve that would have cleaned it never runs
@@ -380,7 +395,8 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
       const bool dual = mode == 1 && f->p.share_projection && f->p.hybrid_tracking;
       if (dual && f->pre_valid && (rc = clear_zbuf(f->zbuf2, W * H, s))) return rc;  // (never consumed)
       if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
-                              f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s, dual ? second : nullptr, dual ? f->zbuf2 : nullptr, 0)))
+                              f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s, dual ? second : nullptr, dual ? f->zbuf2 : nullptr, 0,
+                              fused)))
         return rc;
       if (dual) {
         f->pre_valid = true;
@@ -389,10 +405,8 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
       }
     }
   }
-  {
+  if (!fused) {
     FTimer t(f, s, "fill_in");
-    // passthrough = lost (geometry), lost || frameToFrameRGB (image) (ElasticFusion.cpp:704-712)
-    // (the frame's last fill-in also copies the result block into its pinned host slot)
     if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
                       s, state_mirror ? f->state : nullptr, state_mirror, (int)sizeof(FrameState), dense_test ? &f->state->fill_in : nullptr)))
       return rc;
@@ -481,6 +495,7 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->reloc = 0;
   p->num_sensors = 3;       // NUM_CAMERAS (Shaders/size.glsl:2)
   p->share_projection = 1;
+  p->fused_fill_in = 1;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
@@ -554,6 +569,11 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   Carve c;
   c.base = f->arena;
   layout(f, c);
+  {
+    unsigned masks[128];
+    fill_sample_masks(p->width < 2048 ? p->width : 2048, p->height < 2048 ? p->height : 2048, masks);
+    (void)hipMemcpy(f->tickets + 512, masks, sizeof(masks), hipMemcpyHostToDevice);
+  }
   Pose16 I;
   for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
   hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, 0, f->state, I);

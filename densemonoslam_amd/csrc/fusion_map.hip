@@ -13,6 +13,7 @@
 #include "scan.hpp"
 #include "smallmath.hpp"
 #include "surfel.hpp"
+#include "fill.hpp"
 
 namespace dms {
 
@@ -951,10 +952,17 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
   }
 }
 
-template <bool DEPTH_ONLY>
+// FILL: the hole fill-in of the prediction (fill.hpp) for the pixel just resolved — the launch and the re-read of the
+// three images that a separate fill-in pass costs are saved; the denseEnough decision on the finished image is taken by
+// the block that finishes last (two-level ticket: 16 group counters, then one), the result-block mirror by block 0.
+template <bool DEPTH_ONLY, bool FILL>
 __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, unsigned long long* __restrict__ zbuf,
                                                        uchar4* __restrict__ image, float4* __restrict__ vertex, float4* __restrict__ normal,
-                                                       unsigned short* __restrict__ timeImg, float* __restrict__ depthOut, int clear_after) {
+                                                       unsigned short* __restrict__ timeImg, float* __restrict__ depthOut, int clear_after,
+                                                       FillArgs fa) {
+  if (FILL) {
+    if (fa.mirror_words > 0 && blockIdx.x == 0 && (int)threadIdx.x < fa.mirror_words) fa.mirror_dst[threadIdx.x] = fa.mirror_src[threadIdx.x];
+  }
   // outputs are row-major (the tracker consumes them), the z-buffer is column-major: each wave takes an
   // 8 x 8 pixel tile, lanes running down the columns first, so that a z-buffer access touches 8 full
   // 64-byte lines (instead of 64 lines with a row-major thread map) and every output row of the tile
@@ -968,14 +976,22 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     const int p = py * a.cols + px;
     const unsigned long long key = zbuf[(size_t)px * a.rows + py];
     if (clear_after) zbuf[(size_t)px * a.rows + py] = kZClear;
+    bool sampled = false;
+    if (FILL) {
+      if (fa.dense_flag) sampled = ((fa.sample_mask[px >> 5] >> (px & 31)) & (fa.sample_mask[64 + (py >> 5)] >> (py & 31)) & 1u) != 0u;
+    }
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {
       if (DEPTH_ONLY) {
         depthOut[p] = 0.f;
       } else {
-        image[p] = make_uchar4(0, 0, 0, 0);
+        if (FILL && sampled)
+          __hip_atomic_store(reinterpret_cast<unsigned*>(image + p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (see below)
+        else
+          image[p] = make_uchar4(0, 0, 0, 0);
         vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         normal[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         timeImg[p] = 0;
+        if (FILL) fill_pixel(fa, px, py, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_uchar4(0, 0, 0, 0));
       }
       continue;
     }
@@ -992,24 +1008,61 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     const float4 cc = sp.col[i];
     const f3 rgb = decode_color(cc.x);
     // RGBA8 render target: round(c * 255)
-    image[p] = make_uchar4((unsigned char)f2i_rn(rgb.x * 255.0f), (unsigned char)f2i_rn(rgb.y * 255.0f),
-                           (unsigned char)f2i_rn(rgb.z * 255.0f), 255);
+    const uchar4 o_img = make_uchar4((unsigned char)f2i_rn(rgb.x * 255.0f), (unsigned char)f2i_rn(rgb.y * 255.0f),
+                                     (unsigned char)f2i_rn(rgb.z * 255.0f), 255);
+    // FILL: the block that finishes last reads the subsampled pixels of the image (denseEnough) — those are written through
+    // to where every block sees them, instead of a cache write-back fence per block (measured: 1 200 fences over 17 MB
+    // of dirty output, +25 us per launch)
+    if (FILL && sampled)
+      __hip_atomic_store(reinterpret_cast<unsigned*>(image + p),
+                         (unsigned)o_img.x | ((unsigned)o_img.y << 8) | ((unsigned)o_img.z << 16) | ((unsigned)o_img.w << 24), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    else
+      image[p] = o_img;
     const float z = c.z;
     const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
-    vertex[p] = make_float4(((fcx - a.cx) * z) * (1.f / a.fx), ((fcy - a.cy) * z) * (1.f / a.fy), z, s.conf);
-    normal[p] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, s.rad);
+    const float4 o_v = make_float4(((fcx - a.cx) * z) * (1.f / a.fx), ((fcy - a.cy) * z) * (1.f / a.fy), z, s.conf);
+    const float4 o_n = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, s.rad);
+    vertex[p] = o_v;
+    normal[p] = o_n;
     // time = uint(colTime.z) into a 16-bit unsigned target
     const float tz = cc.z;
     unsigned tv = tz > 0.f ? (unsigned)f2i_rz(tz) : 0u;
     if (tv > 65535u) tv = 65535u;
     timeImg[p] = (unsigned short)tv;
+    if (FILL) fill_pixel(fa, px, py, o_v, o_n, o_img);
+  }
+  if (FILL) {
+    if (fa.dense_flag) {  // (uniform)
+      __shared__ int s_last;
+      __shared__ int s_sum[4];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's image pixels have been written through
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x & 15u;
+        const unsigned in_group = (gridDim.x - g + 15u) / 16u, groups = gridDim.x < 16u ? gridDim.x : 16u;
+        bool last = false;
+        if (atomicAdd(fa.tickets + g * 16u, 1u) == in_group - 1u) {
+          __hip_atomic_store(fa.tickets + g * 16u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (left zeroed for the next launch)
+          if (atomicAdd(fa.tickets + 256, 1u) == groups - 1u) {
+            __hip_atomic_store(fa.tickets + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = true;
+          }
+        }
+        s_last = last ? 1 : 0;
+      }
+      __syncthreads();
+      if (s_last) {
+        fill_dense_test<256, true>(fa, (int)threadIdx.x, s_sum);
+      }
+    }
   }
 }
 
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime, unsigned long long* zbuf2,
-                  int resolve_only) {
+                  int resolve_only, const FillArgs* fill) {
   DMS_REQUIRE(m && pose && cam && zbuf, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -1043,13 +1096,22 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
                        b2, (unsigned long long*)nullptr);
   }
   DMS_CHECK_LAUNCH();
-  if (depth_out)
-    hipLaunchKernelGGL(k_splat_resolve<true>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
-                       (uchar4*)nullptr, (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data, zclean);
-  else
-    hipLaunchKernelGGL(k_splat_resolve<false>, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
-                       (uchar4*)out->image.data, (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data,
-                       (float*)nullptr, zclean);
+  const FillArgs no_fill = {};
+  const dim3 rg(min((n + 255) / 256, 2048));
+  if (depth_out) {
+    hipLaunchKernelGGL((k_splat_resolve<true, false>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)nullptr,
+                       (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data, zclean, no_fill);
+  } else if (fill) {
+    DMS_REQUIRE(fill->ex_image == (const uchar4*)out->image.data && fill->ex_vertex == (const float4*)out->vertex.data &&
+                    fill->ex_normal == (const float4*)out->normal.data && fill->cols == W && fill->rows == H &&
+                    (!fill->dense_flag || (fill->tickets && fill->sample_mask && W <= 2048 && H <= 2048)) && fill->mirror_words <= 256,
+                "fill-in arguments do not describe this prediction");
+    hipLaunchKernelGGL((k_splat_resolve<false, true>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)out->image.data,
+                       (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, *fill);
+  } else {
+    hipLaunchKernelGGL((k_splat_resolve<false, false>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)out->image.data,
+                       (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, no_fill);
+  }
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }

@@ -2,6 +2,7 @@
 // hole fill-in of the model prediction (G10) and nearest-neighbour resize (G11).
 // All are one-thread-per-pixel streaming kernels over dense row-major images.
 #include "surfel.hpp"
+#include "fill.hpp"
 
 namespace dms {
 
@@ -146,62 +147,14 @@ __global__ __launch_bounds__(BX* BY) void k_depth_metric(const unsigned short* _
   }
 }
 
-// G10 — fill_vertex.frag / fill_normal.frag / fill_rgb.frag
-struct FillArgs {
-  const float4* ex_vertex;
-  const float4* ex_normal;
-  const uchar4* ex_image;
-  const unsigned short* depth;  // filtered, mm
-  const uchar4* rgba;
-  // optional: block (0,0) also copies `mirror_words` dwords (the frame's result block into its pinned
-  // host mirror — the frame step's last kernel does the copy a separate blit launch would do)
-  const unsigned* mirror_src;
-  unsigned* mirror_dst;
-  int mirror_words;
-  // optional: one extra block (grid row `rows_blocks`) decides denseEnough (ElasticFusion.cpp:84-97,166-167) from the
-  // existing image: the share of non-black pixels on its W/20 x H/20 NEAREST subsample (Resize::image);
-  // *dense_flag = 0 when more than 95 % are covered, 1 (fill in) otherwise.  Independent of the fill-in itself.
-  int* dense_flag;
-  int rows_blocks;
-  float4* out_vertex;
-  float4* out_normal;
-  uchar4* out_image;
-  int cols, rows;
-  float cx, cy, ifx, ify;  // cam = (cx, cy, 1/fx, 1/fy) with float reciprocals (FillIn.cpp:120-123)
-  int pass_geom, pass_rgb;
-};
-
-__device__ __forceinline__ f3 fill_vertex_at(const FillArgs& a, int sx, int sy, int x, int y) {
-  // geometry.glsl:41-45 (usampler2D variant): z = texel / 1000
-  const float z = (float)a.depth[(size_t)sy * a.cols + sx] / 1000.0f;
-  return mk3((((float)x - a.cx) * z) * a.ifx, (((float)y - a.cy) * z) * a.ify, z);
-}
-
+// G10 — fill_vertex.frag / fill_normal.frag / fill_rgb.frag (per-pixel body: fill.hpp)
 __global__ __launch_bounds__(BX* BY) void k_fill_in(FillArgs a) {
   const int px = blockIdx.x * blockDim.x + threadIdx.x;
   const int py = blockIdx.y * blockDim.y + threadIdx.y;
   if (a.dense_flag && (int)blockIdx.y == a.rows_blocks) {  // the extra block row: block 0 of it does the test, the others idle
     if (blockIdx.x != 0) return;
-    const int t = threadIdx.y * blockDim.x + threadIdx.x;
-    const int dw = a.cols / 20, dh = a.rows / 20;
-    int sum = 0;
-    for (int k = t; k < dw * dh; k += BX * BY) {
-      const int i = k % dw, j = k / dw;
-      const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
-      const int sx = texel(u, (float)a.cols, a.cols), sy = texel(v, (float)a.rows, a.rows);
-      const uchar4 c = a.ex_image[(size_t)sy * a.cols + sx];
-      sum += (c.x > 0 && c.y > 0 && c.z > 0) ? 1 : 0;
-    }
     __shared__ int s_sum[BX * BY / 64];
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-    if ((t & 63) == 0) s_sum[t >> 6] = sum;
-    __syncthreads();
-    if (t == 0) {
-      int tot = 0;
-      for (int w = 0; w < BX * BY / 64; ++w) tot += s_sum[w];
-      const bool dense = (float)tot / (float)(dh * dw) > 0.95f;
-      *a.dense_flag = dense ? 0 : 1;
-    }
+    fill_dense_test<BX * BY, false>(a, threadIdx.y * blockDim.x + threadIdx.x, s_sum);
     return;
   }
   if (a.mirror_words > 0 && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -210,39 +163,7 @@ __global__ __launch_bounds__(BX* BY) void k_fill_in(FillArgs a) {
   }
   if (px >= a.cols || py >= a.rows) return;
   const size_t i = (size_t)py * a.cols + px;
-  const float colsf = (float)a.cols, rowsf = (float)a.rows;
-  const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
-  const int x = (int)(tcx * colsf), y = (int)(tcy * rowsf);
-  {  // fill_vertex.frag:41-55
-    const float4 samp = a.ex_vertex[i];
-    if (samp.z == 0.f || a.pass_geom == 1) {
-      const f3 v = fill_vertex_at(a, px, py, x, y);
-      a.out_vertex[i] = make_float4(v.x, v.y, v.z, 1.f);
-    } else {
-      a.out_vertex[i] = samp;
-    }
-  }
-  {  // fill_normal.frag:33-48 with geometry.glsl:48-58 forward differences
-    const float4 samp = a.ex_normal[i];
-    if (samp.z == 0.f || a.pass_geom == 1) {
-      const f3 v = fill_vertex_at(a, px, py, x, y);
-      const int sxp = texel(tcx + (1.0f / colsf), colsf, a.cols);
-      const int syp = texel(tcy + (1.0f / rowsf), rowsf, a.rows);
-      const f3 vx = fill_vertex_at(a, sxp, py, x + 1, y);
-      const f3 vy = fill_vertex_at(a, px, syp, x, y + 1);
-      const f3 n = normalized3(cross3(vx - v, vy - v));
-      a.out_normal[i] = make_float4(n.x, n.y, n.z, 1.f);
-    } else {
-      a.out_normal[i] = samp;
-    }
-  }
-  {  // fill_rgb.frag:29-37: samp.x + samp.y + samp.z == 0 on normalised bytes <=> all three zero
-    const uchar4 samp = a.ex_image[i];
-    if ((samp.x == 0 && samp.y == 0 && samp.z == 0) || a.pass_rgb == 1)
-      a.out_image[i] = a.rgba[i];
-    else
-      a.out_image[i] = samp;
-  }
+  fill_pixel(a, px, py, a.ex_vertex[i], a.ex_normal[i], a.ex_image[i]);
 }
 
 // G11 — resize.frag: dst pixel (i, j) samples src at ((i+0.5)/dw, (j+0.5)/dh), NEAREST
@@ -283,8 +204,9 @@ int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream
   return DMS_OK;
 }
 
-int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
-            int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src, void* mirror_dst, int mirror_bytes, int* dense_flag) {
+// the argument block of the fill-in for `ex` -> `out` (shared with the prediction's fused resolve pass)
+int fill_args(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom, int pass_rgb,
+              dms_predict_out* out, const void* mirror_src, void* mirror_dst, int mirror_bytes, int* dense_flag, FillArgs* res) {
   DMS_REQUIRE(ex && depth && rgba && cam && out, "null argument");
   DMS_REQUIRE(dense(&ex->vertex, 16) && dense(&ex->normal, 16) && dense(&ex->image, 4) && dense(depth, 2) && dense(rgba, 4) &&
                   dense(&out->vertex, 16) && dense(&out->normal, 16) && dense(&out->image, 4),
@@ -310,8 +232,20 @@ int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image
   a.mirror_src = (const unsigned*)mirror_src;
   a.mirror_dst = (unsigned*)mirror_dst;
   a.mirror_words = (mirror_src && mirror_dst) ? mirror_bytes / 4 : 0;
-  dim3 b(BX, BY), g = grid2d(a.cols, a.rows, b);
   a.dense_flag = dense_flag;
+  a.rows_blocks = 0;
+  a.tickets = nullptr;
+  a.sample_mask = nullptr;
+  *res = a;
+  return DMS_OK;
+}
+
+int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
+            int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src, void* mirror_dst, int mirror_bytes, int* dense_flag) {
+  FillArgs a;
+  const int rc = fill_args(ex, depth, rgba, cam, pass_geom, pass_rgb, out, mirror_src, mirror_dst, mirror_bytes, dense_flag, &a);
+  if (rc) return rc;
+  dim3 b(BX, BY), g = grid2d(a.cols, a.rows, b);
   a.rows_blocks = (int)g.y;
   if (dense_flag) g.y += 1;
   hipLaunchKernelGGL(k_fill_in, g, b, 0, s, a);

