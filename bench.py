@@ -137,15 +137,19 @@ def main():
 
     # collaborative mode (N > 1): every camera publishes its frame block — fern descriptor + thumbnails — per frame;
     # every rank keeps a fern database of its own key frames and searches it with the other cameras' descriptors
-    exchange = collab.ThumbnailExchange(world, W, H, dev, extra_bytes=collab.DESC_BYTES if distributed else 0)
+    # (DMS_BENCH_EXCHANGE=1: the per-frame exchange work at N = 1 too, the all-gather being a local copy — measures what the
+    # collaborative mode adds to a frame without a second GPU)
+    exchange_on = distributed or os.environ.get("DMS_BENCH_EXCHANGE") == "1"
+    exchange = collab.ThumbnailExchange(world, W, H, dev, extra_bytes=collab.DESC_BYTES if exchange_on else 0)
     thumb = exchange.local
     matcher = None
-    if distributed:
+    if exchange_on:
         from densemonoslam_amd import ferns as ferns_mod
 
         fern_db = ferns_mod.Ferns(W, H, K, num=500, maxDepth_mm=3000, photoThresh=115.0, seed=20260929, capacity=4096)  # same table on every rank
         matcher = collab.InterMapMatcher(fern_db, exchange, rank, world, dev, fern_threshold=0.3095,
-                                         verify_interval=int(os.environ.get("DMS_VERIFY_INTERVAL", "0")))
+                                         verify_interval=int(os.environ.get("DMS_VERIFY_INTERVAL", "0")),
+                                         side_stream=os.environ.get("DMS_MATCHER_SIDE", "0") == "1")
 
     # bounded run-ahead: the host never has more than `depth` frames enqueued beyond the one the GPU
     # is working on (what a live pipeline does anyway: frame t+depth does not exist yet)
@@ -162,7 +166,7 @@ def main():
             e = torch.cuda.Event()
             e.record()
             inflight.append(e)
-        if distributed and exchange_thumbnails:
+        if exchange_on and exchange_thumbnails:
             # frame block (fill-in thumbnails + fern descriptor + pose from HBM), own key-frame database, all-gather beside
             # the next frame; then the search of the local database with the descriptors gathered one frame earlier
             prev = matcher.publish(ef, i + 1, stream)
@@ -222,7 +226,7 @@ def main():
             "exchange": ("all-gather of one %d-byte frame block per camera per frame (592-byte fern descriptor + W/8xH/8 thumbnails), "
                          "every rank searches its fern database (%d key frames on rank 0) with the other cameras' descriptors: "
                          "%d remote descriptors found a candidate on rank 0, %d verified"
-                         % (thumb.numel(), len(fern_db), matcher.candidates, len(matcher.verified))) if distributed else "none (1 camera)",
+                         % (thumb.numel(), len(fern_db), matcher.candidates, len(matcher.verified))) if exchange_on else "none (1 camera)",
         },
     }
 

@@ -156,8 +156,14 @@ class InterMapMatcher:
     code agreement, 3 x 50 ICP iterations at thumbnail size, photometric check) on each remote camera's latest block; that
     call synchronises, like the reference's.  A verified match is what triggers a map merge (send_map / merge_remote_map)."""
 
-    def __init__(self, ferns, exchange, rank, world, device, fern_threshold=0.3095, verify_interval=0):
+    def __init__(self, ferns, exchange, rank, world, device, fern_threshold=0.3095, verify_interval=0, side_stream=False):
         self.ferns, self.x, self.rank, self.world, self.device = ferns, exchange, rank, world, device
+        # side_stream: only the frame block itself (thumbnails, pose, tick: one launch) is taken on the frame's stream; the
+        # descriptor, the key-frame database, the all-gather and the search go to a side stream.  Off by default: measured on
+        # one MI355X (bench.py, DMS_BENCH_EXCHANGE=1) the third stream costs more than the ten small launches it takes off the
+        # frame's stream (1856 against 1873 frames/s; 1963 without any exchange).
+        self.side = torch.cuda.Stream(device) if (side_stream and device.type == "cuda") else None
+        self.block_ready = torch.cuda.Event() if self.side is not None else None
         self.fern_threshold, self.verify_interval = fern_threshold, verify_interval
         self.best_dev = torch.full((world, 2), -1, dtype=torch.int32, device=device)
         self.best_host = torch.full((world, 2), -1, dtype=torch.int32).pin_memory() if device.type == "cuda" else torch.full((world, 2), -1, dtype=torch.int32)
@@ -167,13 +173,25 @@ class InterMapMatcher:
         self.verified = []   # (frame, remote rank, FernMatch) of accepted verifications
 
     def publish(self, ef, tick, stream):
+        """`stream`: the raw handle of torch's current stream, on which the frame was enqueued"""
         blk = self.x.begin()
         base, T = blk.data_ptr(), self.x.thumb_bytes
-        ef.thumbnails(base, stream)
+        if hasattr(ef, "frameBlock"):  # thumbnails + pose from HBM + tick in one launch
+            ef.frameBlock(base, base + T + DESC_POSE, base + T + DESC_TICK, int(tick), stream)
+        else:
+            ef.thumbnails(base, stream)
+            blk[T + DESC_TICK:T + DESC_TICK + 4].view(torch.int32).fill_(int(tick))
+            ef.exportPose(base + T + DESC_POSE, stream)  # 64 bytes, device to device, stream ordered
+        if self.side is not None:
+            self.block_ready.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(self.block_ready)
+            with torch.cuda.stream(self.side):
+                return self._publish_rest(base, T, tick, self.side.cuda_stream)
+        return self._publish_rest(base, T, tick, stream)
+
+    def _publish_rest(self, base, T, tick, stream):
         self.ferns.encodeThumbs(base, base + T + DESC_CODES, base + T + DESC_GOOD, stream)
-        blk[T + DESC_TICK:T + DESC_TICK + 4].view(torch.int32).fill_(int(tick))
-        ef.exportPose(base + T + DESC_POSE, stream)  # 64 bytes, device to device, stream ordered
-        self.ferns.addFrameAsync(base, ef.poseDevice(), int(tick), self.fern_threshold, stream)
+        self.ferns.addFrameAsync(base, base + T + DESC_POSE, int(tick), self.fern_threshold, stream)  # (the block's copy of the pose)
         slot = self.x.slot
         g = self.x.gather(overlap=True)
         cur = (g, slot)
@@ -185,6 +203,12 @@ class InterMapMatcher:
         """search the local database with the descriptors gathered by the PREVIOUS publish"""
         if prev is None:
             return
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                return self._match(prev, tick, self.side.cuda_stream)
+        return self._match(prev, tick, stream)
+
+    def _match(self, prev, tick, stream):
         g, slot = prev
         w = self.x.work[slot]
         if w is not None:

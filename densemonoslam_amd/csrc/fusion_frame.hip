@@ -127,8 +127,11 @@ __global__ void k_frame_after_track(FrameState* st, float weightMultiplier) {
 // one launch: block = [RGBA8 image | RGBA32F vertex | RGBA32F normal], each tw x th, NEAREST as resize.frag
 __global__ __launch_bounds__(256) void k_thumbnails(const uchar4* __restrict__ image, const float4* __restrict__ vertex,
                                                     const float4* __restrict__ normal, int cols, int rows, int tw, int th,
-                                                    unsigned char* __restrict__ block) {
+                                                    unsigned char* __restrict__ block, const float* __restrict__ pose16, float* pose_dst,
+                                                    int* tick_dst, int tick) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pose_dst && k < 16) pose_dst[k] = pose16[k];  // (the frame block of collaborative mode: pose and tick ride along)
+  if (tick_dst && k == 0) *tick_dst = tick;
   if (k >= tw * th) return;
   const int j = k / tw, i = k - j * tw;
   const float u = ((float)i + 0.5f) / (float)tw, v = ((float)j + 0.5f) / (float)th;
@@ -1044,7 +1047,18 @@ int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream st) {
   const int tw = f->p.width / 8, th = f->p.height / 8;
   hipLaunchKernelGGL(k_thumbnails, dim3((tw * th + 255) / 256), dim3(256), 0, (hipStream_t)st, (const uchar4*)f->fill.image.data,
                      (const float4*)f->fill.vertex.data, (const float4*)f->fill.normal.data, f->p.width, f->p.height, tw, th,
-                     (unsigned char*)block_dev);
+                     (unsigned char*)block_dev, (const float*)nullptr, (float*)nullptr, (int*)nullptr, 0);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
+int dms_fusion_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev, int* tick_dst_dev, int tick, dms_stream st) {
+  DMS_REQUIRE(f && block_dev, "null argument");
+  DMS_REQUIRE(((uintptr_t)block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  const int tw = f->p.width / 8, th = f->p.height / 8;
+  hipLaunchKernelGGL(k_thumbnails, dim3((tw * th + 255) / 256), dim3(256), 0, (hipStream_t)st, (const uchar4*)f->fill.image.data,
+                     (const float4*)f->fill.vertex.data, (const float4*)f->fill.normal.data, f->p.width, f->p.height, tw, th,
+                     (unsigned char*)block_dev, (const float*)f->state->cur.pose, pose16_dst_dev, tick_dst_dev, tick);
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }

@@ -314,6 +314,10 @@ int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view);
  * inputs of the inter-map fern matcher (Ferns.cpp:277-423) — packed [image | vertex | normal] into
  * (W/8)(H/8) * 36 bytes of device memory, in one launch on `s` (stream-ordered after the frame). */
 int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream s);
+/* The same launch also copies the frame's pose (16 floats, from its place in HBM) to pose16_dst_dev and writes `tick` to
+ * tick_dst_dev (either may be NULL): everything of a published frame block that must be taken before the next frame
+ * starts, so that the rest of the exchange (encoding, key-frame database, all-gather, search) can run on a side stream. */
+int dms_fusion_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev, int* tick_dst_dev, int tick, dms_stream s);
 
 /* Surface constraints of the last fetched frame's loop candidate, in the reference's sampling
  * order (columns outer, rows inner, ElasticFusion.cpp:446-447): per row

@@ -206,9 +206,20 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
         d, rgb, _ = synth.frame(3 * k, width=W, height=H, K=K, noise=True)
         r = ef.processFrame(rgb, d)
         blk = DeviceBuffer(T + collab.DESC_BYTES)
-        ef.thumbnails(blk.ptr)
+        if k % 2:  # the one-launch form: thumbnails + pose + tick (what the matcher uses), pose taken from the block's copy
+            ef.frameBlock(blk.ptr, blk.ptr + T + collab.DESC_POSE, blk.ptr + T + collab.DESC_TICK, k + 1)
+            ref = DeviceBuffer(T)
+            ef.thumbnails(ref.ptr)
+            whole = blk.download(np.uint8, (T + collab.DESC_BYTES,))
+            assert (whole[:T] == ref.download(np.uint8, (T,))).all()
+            assert whole[T + collab.DESC_TICK:T + collab.DESC_TICK + 4].view(np.int32)[0] == k + 1
+            assert (whole[T + collab.DESC_POSE:T + collab.DESC_POSE + 64].view(np.float32) == np.array(r.pose, np.float32).reshape(16)).all()
+            pose_ptr = blk.ptr + T + collab.DESC_POSE
+        else:
+            ef.thumbnails(blk.ptr)
+            pose_ptr = ef.poseDevice()
         ga.encodeThumbs(blk.ptr, blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD)
-        ga.addFrameAsync(blk.ptr, ef.poseDevice(), k + 1, 0.1)
+        ga.addFrameAsync(blk.ptr, pose_ptr, k + 1, 0.1)
         # the synchronous reference call on the fill-in textures themselves
         img, vert, nrm = ef.image(13), ef.image(14), ef.image(15)
         gs.addFrame(img, vert, nrm, np.array(r.pose, np.float32), k + 1, 0.1)
