@@ -190,8 +190,11 @@ class InterMapMatcher:
         return self._publish_rest(base, T, tick, stream)
 
     def _publish_rest(self, base, T, tick, stream):
-        self.ferns.encodeThumbs(base, base + T + DESC_CODES, base + T + DESC_GOOD, stream)
-        self.ferns.addFrameAsync(base, base + T + DESC_POSE, int(tick), self.fern_threshold, stream)  # (the block's copy of the pose)
+        if hasattr(self.ferns, "publishBlock"):  # descriptor + key-frame insertion: one encoding pass, no staging copy
+            self.ferns.publishBlock(base, base + T + DESC_CODES, base + T + DESC_GOOD, base + T + DESC_POSE, int(tick), self.fern_threshold, stream)
+        else:
+            self.ferns.encodeThumbs(base, base + T + DESC_CODES, base + T + DESC_GOOD, stream)
+            self.ferns.addFrameAsync(base, base + T + DESC_POSE, int(tick), self.fern_threshold, stream)  # (the block's copy of the pose)
         slot = self.x.slot
         g = self.x.gather(overlap=True)
         cur = (g, slot)

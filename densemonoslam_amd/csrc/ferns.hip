@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_fern_thumbs(const uchar4* __restrict__ 
 // code of every fern (Ferns.cpp:208-233): one lane per fern; also the samples the host-side checks read
 __global__ __launch_bounds__(kFernPad) void k_fern_encode(const unsigned char* __restrict__ block, int tw, int th, const FernTable* __restrict__ tab,
                                                           int num, unsigned char* __restrict__ codes, int* __restrict__ good,
-                                                          FernHost* __restrict__ res) {
+                                                          FernHost* __restrict__ res, unsigned char* __restrict__ codes2 = nullptr) {
   __shared__ int s_good;
   const int i = threadIdx.x;
   if (i == 0) s_good = 0;
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kFernPad) void k_fern_encode(const unsigned char* _
   }
   __syncthreads();
   if (codes) codes[i] = code;
+  if (codes2) codes2[i] = code;  // (a second copy: the caller's descriptor beside the handle's staging area)
   if (good && i == 0) *good = s_good;
   if (res) {
     res->vert[i] = v;
@@ -663,6 +664,29 @@ int dms_ferns_add_frame_async(dms_ferns* f, const dms_image2d* image_rgba, const
   int rc = stage(f, image_rgba, vertex, normal, thumb_block_dev, s);
   if (rc) return rc;
   return add_enqueue(f, pose16_host, pose16_dev, srcTime, threshold, s);
+}
+
+int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, const float* pose16_dev,
+                            int srcTime, float threshold, dms_stream st) {
+  DMS_REQUIRE(f && thumb_block_dev && codes_dev && good_dev && pose16_dev, "null argument");
+  DMS_REQUIRE(((uintptr_t)thumb_block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)st;
+  // one encoding pass feeds the caller's descriptor and the handle's staged codes; the block is read where it lies
+  hipLaunchKernelGGL(k_fern_encode, dim3(1), dim3(kFernPad), 0, s, (const unsigned char*)thumb_block_dev, f->tw, f->th, f->d_tab, f->num,
+                     f->d_cur_codes, good_dev, f->d_res, codes_dev);
+  DMS_CHECK_LAUNCH();
+  int rc = search_enqueue(f, 0, 1, false, s);
+  if (rc) return rc;
+  Pose16f ph;
+  memset(&ph, 0, sizeof(ph));
+  hipLaunchKernelGGL(k_fern_decide, dim3(1), dim3(64), 0, s, f->d_res, f->d_n, f->capacity, threshold, srcTime, pose16_dev, ph, f->d_good,
+                     f->d_time, f->d_pose);
+  DMS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_fern_commit, dim3(64), dim3(256), 0, s, (const unsigned char*)thumb_block_dev, f->d_cur_codes, f->block_bytes,
+                     f->d_blocks, f->d_codes, f->d_res);
+  DMS_CHECK_LAUNCH();
+  if (f->n_upper < f->capacity) f->n_upper += 1;
+  return DMS_OK;
 }
 
 int dms_ferns_find_frame(dms_ferns* f, const dms_image2d* vertex, const dms_image2d* normal, const dms_image2d* image_rgba,

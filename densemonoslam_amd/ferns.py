@@ -28,6 +28,7 @@ lib.dms_ferns_find_frame_thumbs.argtypes = [_P, _P, C.POINTER(_F), _I, _I, _I, C
 lib.dms_ferns_search_codes.argtypes = [_P, _P, _P, _I, _I, _P, _P]
 lib.dms_ferns_add_frame_async.argtypes = [_P, _I2, _I2, _I2, _P, C.POINTER(_F), _P, _I, _F, _P]
 lib.dms_ferns_encode_thumbs.argtypes = [_P, _P, _P, _P, _P]
+lib.dms_ferns_publish_block.argtypes = [_P, _P, _P, _P, _P, _I, C.c_float, _P]
 lib.dms_ferns_search_blocks.argtypes = [_P, _P, C.c_size_t, _I, _I, C.c_size_t, C.c_size_t, _I, _I, _P, _P]
 lib.dms_ferns_consume.argtypes = [_P, _P, C.POINTER(_F), _F, C.POINTER(_I), _P]
 
@@ -104,6 +105,11 @@ class Ferns:
         """addFrame of a thumbnail block with the pose read from HBM; no host synchronisation."""
         check(lib.dms_ferns_add_frame_async(self.h, None, None, None, C.c_void_p(block_ptr), None, C.c_void_p(pose_dev_ptr), srcTime, threshold,
                                             stream), "dms_ferns_add_frame_async")
+
+    def publishBlock(self, block_ptr, codes_ptr, good_ptr, pose_dev_ptr, srcTime, threshold, stream=None):
+        """encodeThumbs + addFrameAsync of one block with a single encoding pass and no staging copy"""
+        check(lib.dms_ferns_publish_block(self.h, C.c_void_p(block_ptr), C.c_void_p(codes_ptr), C.c_void_p(good_ptr), C.c_void_p(pose_dev_ptr),
+                                          srcTime, threshold, stream), "dms_ferns_publish_block")
 
     def encodeThumbs(self, block_ptr, codes_ptr, good_ptr, stream=None):
         check(lib.dms_ferns_encode_thumbs(self.h, C.c_void_p(block_ptr), C.c_void_p(codes_ptr), C.c_void_p(good_ptr), stream),

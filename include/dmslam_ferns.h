@@ -63,6 +63,13 @@ int dms_ferns_add_frame_async(dms_ferns* f, const dms_image2d* image_rgba, const
 /* descriptor of a frame that already is a thumbnail block; touches nothing of the handle's state (any stream) */
 int dms_ferns_encode_thumbs(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, dms_stream s);
 
+/* What a camera does with its frame block every frame in collaborative mode, in four launches: the descriptor
+ * (dms_ferns_encode_thumbs: codes_dev / good_dev, inside or beside the block) and the key-frame insertion
+ * (dms_ferns_add_frame_async with the pose in HBM) share one encoding pass, and the block is read where it lies instead
+ * of being staged — it must stay unchanged until the work enqueued here has run. */
+int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, const float* pose16_dev,
+                            int srcTime, float threshold, dms_stream s);
+
 typedef struct dms_fern_match {
   int closest;            /* Ferns::lastClosest: accepted frame id or -1 */
   int candidate;          /* minId of the dissimilarity search (-1: none eligible) */

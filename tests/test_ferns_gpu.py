@@ -218,8 +218,17 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
         else:
             ef.thumbnails(blk.ptr)
             pose_ptr = ef.poseDevice()
-        ga.encodeThumbs(blk.ptr, blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD)
-        ga.addFrameAsync(blk.ptr, pose_ptr, k + 1, 0.1)
+        if k % 4 == 1:  # descriptor + insertion in one call (one encoding pass, block read in place)
+            ga.publishBlock(blk.ptr, blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD, pose_ptr, k + 1, 0.1)
+        else:
+            ga.encodeThumbs(blk.ptr, blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD)
+            ga.addFrameAsync(blk.ptr, pose_ptr, k + 1, 0.1)
+        if k % 2:
+            cd = blk.download(np.uint8, (T + collab.DESC_BYTES,))
+            chk = DeviceBuffer(512 + 8)
+            ga.encodeThumbs(blk.ptr, chk.ptr, chk.ptr + 512)
+            ck = chk.download(np.uint8, (520,))
+            assert (cd[T + collab.DESC_CODES:T + collab.DESC_CODES + 512] == ck[:512]).all() and (cd[T + collab.DESC_GOOD:T + collab.DESC_GOOD + 4] == ck[512:516]).all()
         # the synchronous reference call on the fill-in textures themselves
         img, vert, nrm = ef.image(13), ef.image(14), ef.image(15)
         gs.addFrame(img, vert, nrm, np.array(r.pose, np.float32), k + 1, 0.1)
