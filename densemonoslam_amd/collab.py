@@ -220,8 +220,12 @@ class InterMapMatcher:
         self.candidates += int((self.best_host[:, 0] >= 0).sum())
         T = self.x.thumb_bytes
         if hasattr(self.ferns, "searchBlocks"):  # every remote descriptor in one launch
+            # (the previous search's results go to the pinned array inside the same call: no copy engine on the frame's stream)
             self.ferns.searchBlocks(g.data_ptr(), self.x.nbytes, self.world, self.rank, T + DESC_CODES, T + DESC_GOOD, int(tick), True,
-                                    self.best_dev.data_ptr(), stream)
+                                    self.best_dev.data_ptr(), stream, previous_out=self.best_host.data_ptr())
+            if self.verify_interval and self.frames % self.verify_interval == 0:
+                self.verify(g, tick, stream)
+            return
         else:
             for r in range(self.world):
                 if r == self.rank:

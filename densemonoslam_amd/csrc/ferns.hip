@@ -164,6 +164,15 @@ __global__ __launch_bounds__(256) void k_fern_search_batch(const unsigned char* 
   atomicMin(best + q, ((unsigned long long)__float_as_uint(dissim) << 32) | (unsigned)j);
 }
 
+// hands the results of the previous batch search to `out` (mapped host memory: the caller reads them a frame later
+// without a copy engine on the frame's stream) and re-arms the result words
+__global__ void k_fern_best_rearm(unsigned long long* __restrict__ best, int count, unsigned long long* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  out[q] = best[q];
+  best[q] = ~0ull;
+}
+
 // blockHDAware(query, best frame) (Ferns.cpp:684-704) for the frame the search chose, without a host round trip
 __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __restrict__ db_codes, const unsigned char* __restrict__ cur_codes,
                                                       int num, FernHost* __restrict__ res) {
@@ -724,13 +733,20 @@ int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const i
 }
 
 int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride, int count, int skip, size_t codes_offset, size_t good_offset,
-                            int time, int interMap, int* best2_dev, dms_stream st) {
+                            int time, int interMap, int* best2_dev, int* previous_out, dms_stream st) {
   DMS_REQUIRE(f && blocks_dev && best2_dev && count >= 1, "bad argument");
   DMS_REQUIRE(((uintptr_t)blocks_dev & 7) == 0 && (stride & 7) == 0 && (codes_offset & 7) == 0 && (good_offset & 3) == 0 &&
                   ((uintptr_t)best2_dev & 7) == 0,
               "8-byte aligned blocks, stride, code offset and result required");
   hipStream_t s = (hipStream_t)st;
-  DMS_HIP(hipMemsetAsync(best2_dev, 0xFF, (size_t)count * 8, s));
+  if (previous_out) {
+    DMS_REQUIRE(((uintptr_t)previous_out & 7) == 0, "8-byte aligned result mirror required");
+    hipLaunchKernelGGL(k_fern_best_rearm, dim3((count + 63) / 64), dim3(64), 0, s, (unsigned long long*)best2_dev, count,
+                       (unsigned long long*)previous_out);
+    DMS_CHECK_LAUNCH();
+  } else {
+    DMS_HIP(hipMemsetAsync(best2_dev, 0xFF, (size_t)count * 8, s));
+  }
   if (f->n_upper > 0) {
     hipLaunchKernelGGL(k_fern_search_batch, dim3((f->n_upper + 3) / 4, count), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n,
                        (const unsigned char*)blocks_dev, stride, codes_offset, good_offset, skip, time, interMap ? 1 : 0,

@@ -29,7 +29,7 @@ lib.dms_ferns_search_codes.argtypes = [_P, _P, _P, _I, _I, _P, _P]
 lib.dms_ferns_add_frame_async.argtypes = [_P, _I2, _I2, _I2, _P, C.POINTER(_F), _P, _I, _F, _P]
 lib.dms_ferns_encode_thumbs.argtypes = [_P, _P, _P, _P, _P]
 lib.dms_ferns_publish_block.argtypes = [_P, _P, _P, _P, _P, _I, C.c_float, _P]
-lib.dms_ferns_search_blocks.argtypes = [_P, _P, C.c_size_t, _I, _I, C.c_size_t, C.c_size_t, _I, _I, _P, _P]
+lib.dms_ferns_search_blocks.argtypes = [_P, _P, C.c_size_t, _I, _I, C.c_size_t, C.c_size_t, _I, _I, _P, _P, _P]
 lib.dms_ferns_consume.argtypes = [_P, _P, C.POINTER(_F), _F, C.POINTER(_I), _P]
 
 
@@ -134,9 +134,10 @@ class Ferns:
         check(lib.dms_ferns_search_codes(self.h, C.c_void_p(codes_ptr), C.c_void_p(good_ptr), time, int(interMap), C.c_void_p(best_ptr), stream),
               "dms_ferns_search_codes")
 
-    def searchBlocks(self, blocks_ptr, stride, count, skip, codes_offset, good_offset, time, interMap, best_ptr, stream=None):
+    def searchBlocks(self, blocks_ptr, stride, count, skip, codes_offset, good_offset, time, interMap, best_ptr, stream=None, previous_out=None):
         check(lib.dms_ferns_search_blocks(self.h, C.c_void_p(blocks_ptr), stride, count, skip, codes_offset, good_offset, time, int(interMap),
-                                          C.c_void_p(best_ptr), stream), "dms_ferns_search_blocks")
+                                          C.c_void_p(best_ptr), C.c_void_p(previous_out) if previous_out else None, stream),
+              "dms_ferns_search_blocks")
 
     def consume(self, other, relativeTransform, threshold, stream=None):
         T = np.ascontiguousarray(relativeTransform, np.float32).reshape(16)

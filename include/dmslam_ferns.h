@@ -97,9 +97,11 @@ int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const i
 /* The search for a batch of descriptors in one launch: `count` blocks of `stride` bytes at blocks_dev, each holding
  * DMS_FERN_MAX code bytes at codes_offset and its good-code count (int) at good_offset — the gathered frame blocks of
  * collaborative mode; block `skip` (the caller's own, or -1) is left out.  best2_dev: count x {candidate id or -1,
- * dissimilarity bits}. */
+ * dissimilarity bits}.  previous_out (optional, device-accessible — e.g. mapped pinned host memory): receives what
+ * best2_dev held on entry, i.e. the results of the previous call, before the words are re-armed; a caller that reads
+ * its results one frame late gets them on the host without a copy on the frame's stream. */
 int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride, int count, int skip, size_t codes_offset,
-                            size_t good_offset, int time, int interMap, int* best2_dev, dms_stream s);
+                            size_t good_offset, int time, int interMap, int* best2_dev, int* previous_out, dms_stream s);
 
 /* void Ferns::consume(otherFrames, relativeTransform, threshold) (Ferns.cpp:160-168): every stored frame of `src`,
  * re-posed by relativeTransform, goes through addFrame(Frame*, threshold) of `dst` (re-encoded with dst's table).

@@ -259,6 +259,12 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
         ga.searchCodes(blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD, 1000, True, best.ptr)
         b = best.download(np.int32, (2,))
         assert (bn[i] == ([-1, -1] if i == 2 else b)).all(), i
+    # a second call hands the first call's results out (previous_out) before re-arming the result words
+    prev = DeviceBuffer(8 * nb)
+    ga.searchBlocks(allb.ptr, stride, nb, -1, T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, bestn.ptr, previous_out=prev.ptr)
+    assert (prev.download(np.int32, (nb, 2)) == bn).all()
+    bn2 = bestn.download(np.int32, (nb, 2))
+    assert (np.delete(bn2, 2, 0) == np.delete(bn, 2, 0)).all() and bn2[2, 0] >= 0  # (nothing skipped this time)
     ga.close()
     gs.close()
     ef.close()
