@@ -61,7 +61,8 @@ int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA,
 int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rgbaB, const int* flag_dev, int force_b, void* rgba_tmp,
                               hipStream_t s);
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
-                             const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s);
+                             const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
+                             int defer_last_step = 0);
 int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
                             hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
@@ -761,7 +762,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
         // WARNING (reference): initICP* must be called before initRGB* (ElasticFusion.cpp:172)
         if ((rc = odometry_initModel_fused(f->odom, f->pred.vertex.data, f->pred.normal.data, f->pred.image.data, f->fill.vertex.data,
                                            f->fill.normal.data, f->fill.image.data, &f->state->fill_in, f->p.frameToFrameRGB ? 1 : 0,
-                                           f->state->cur.pose, s)))
+                                           f->state->cur.pose, s, 1)))  // (last pyramid step: inside the tracker's first kernel, below)
           return rc;
         // initICP / initRGB: the live half ran on the prep stream; nextDepth = lastDepth (same source)
         odometry_alias_next_depth(f->odom);

@@ -3,6 +3,7 @@
 // kernels: one 64-wide wave covers 64 consecutive pixels of a row (coalesced 4-byte or
 // 16-byte accesses per lane); blocks are 64×4 so a 256-thread block spans 4 rows.
 #include "common.hpp"
+#include "pyr_body.hpp"
 
 namespace dms {
 
@@ -233,11 +234,6 @@ __global__ void k_resizeMap(int drows, int dcols, int srows, View<const float> i
 // (reference pyrDownKernelGaussF, cudafuncs.cu:416-443).  The 25 weights live in
 // registers / constant operands instead of a per-call cudaMalloc'd table (:532-541).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float gauss25(int r, int c) {
-  const float w[5] = {1.f, 4.f, 6.f, 4.f, 1.f};
-  return w[r] * w[c];
-}
-
 __global__ void k_pyrDownGaussF(View<const float> src, View<float> dst) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -471,30 +467,7 @@ __global__ void k_model_levels012(ModelSrc m, int g0x, int g0y, int g12x, int ro
 
 // one pyramid step of both model images: float depth (pyrDownGaussF) and intensity (pyrDownUchar)
 __global__ void k_model_pyr_step(View<const float> dsrc, View<float> ddst, View<const unsigned char> isrc, View<unsigned char> idst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= ddst.cols || y >= ddst.rows) return;
-  const int D = 5;
-  const int tx = min(2 * x - D / 2 + D, dsrc.cols - 1);
-  const int ty = min(2 * y - D / 2 + D, dsrc.rows - 1);
-  float sum = 0.f, isum = 0.f;
-  int count = 0, icount = 0;
-  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-      const float g = gauss25(ty - cy - 1, tx - cx - 1);
-      const float s = dsrc.at(cy, cx);
-      if (!isnan(s)) {
-        sum += s * g;
-        count += (int)g;
-      }
-      const unsigned char c = isrc.at(cy, cx);
-      if (c > 0) {
-        isum += (float)c * g;
-        icount += (int)g;
-      }
-    }
-  ddst.at(y, x) = sum / (float)count;
-  idst.at(y, x) = (unsigned char)f2i_rz(isum / (float)icount);
+  model_pyr_step_pixel(blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y * blockDim.y + threadIdx.y, dsrc, ddst, isrc, idst);
 }
 
 // reference verticesToDepthKernel / verticesToDepth2DKernel (cudafuncs.cu:597-630)
@@ -693,7 +666,7 @@ int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
 
 int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void* vB, const void* nB, const void* iB, const int* flag_dev,
                       int force_b_img, const float* pose16_dev, dms_image2d* vmaps, dms_image2d* nmaps, dms_image2d* depths,
-                      dms_image2d* images, float cutOff, hipStream_t s) {
+                      dms_image2d* images, float cutOff, hipStream_t s, bool skip_last_step) {
   DMS_REQUIRE(vA && nA && iA && vB && nB && iB && flag_dev && vmaps && nmaps && depths && images, "null argument");
   ModelSrc m;
   m.vA = (const float4*)vA;
@@ -718,7 +691,7 @@ int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void
                        view<float>(&nmaps[2]), (int)g12.y, (int)gs.x, view<float>(&depths[1]), view<unsigned char>(&images[1]));
     DMS_CHECK_LAUNCH();
   }
-  for (int l = 2; l < 3; ++l)
+  for (int l = 2; l < 3 && !skip_last_step; ++l)  // (skipped: the caller runs that step inside a kernel of its own)
     LAUNCH2D(k_model_pyr_step, depths[l].cols, depths[l].rows, s, view<const float>(&depths[l - 1]), view<float>(&depths[l]),
              view<const unsigned char>(&images[l - 1]), view<unsigned char>(&images[l]));
   return DMS_OK;

@@ -26,6 +26,7 @@
 #include "internal.hpp"
 #include "pixel_ops.hpp"
 #include "smallmath.hpp"
+#include "pyr_body.hpp"
 #include "frame_state.hpp"
 #include "surfel.hpp"
 #include <mutex>
@@ -94,6 +95,8 @@ struct dms_odometry {
   bool fp64_sums = false;     // block sums and records in fp64 (DMS_SUMS=fp64)
   int early_exit_force = -1;  // -1: as `early_exit`; 0 / 1: forced (DMS_TRACK_EARLY_EXIT)
   int persist_target = 96;    // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
+  // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
+  bool deferred_pyr = false;
   int inject_timeouts = 0;    // dms_odometry_inject_timeout: calls left that start with the timeout flag set
   int width, height;
   float cx, cy, fx, fy, distThres, angleThres;
@@ -193,15 +196,17 @@ struct Prior {
   float v[12];  // trans[3], rot[9] — passed by value so no staging copy can race a later call
 };
 
-__global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
-                             int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout) {
+// block `b` of `nb` blocks of `nt` threads (t = linear thread id)
+__device__ __forceinline__ void track_init_body(int b, int nb, int t, int nt, TrackState* st, Prior prior, const float* __restrict__ prior_pose16,
+                                                float fx, float fy, float cx, float cy, int so3, int first_level,
+                                                unsigned long long* sync_words, int n_sync, int inject_timeout) {
   // barrier and all-reduce words of the resident kernels of this call: zero before any of them is launched
   // (n_sync counts 16-byte pairs; the grid shares the work, block 0 also sets up the state)
   {
     ulonglong2* w2 = reinterpret_cast<ulonglong2*>(sync_words);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_sync; i += blockDim.x * gridDim.x) w2[i] = make_ulonglong2(0ull, 0ull);
+    for (int i = b * nt + t; i < n_sync; i += nt * nb) w2[i] = make_ulonglong2(0ull, 0ull);
   }
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (t != 0 || b != 0) return;
   if (prior_pose16) {  // device-resident prior (frame step): row-major 4×4 camera-to-world
     for (int i = 0; i < 3; ++i) {
       prior.v[i] = prior_pose16[i * 4 + 3];
@@ -236,6 +241,29 @@ __global__ void k_track_init(TrackState* st, Prior prior, const float* __restric
     level_K(fx, fy, cx, cy, first_level, K);
     gn_params(st, K);
   }
+}
+
+__global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
+                             int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout) {
+  track_init_body(blockIdx.x, gridDim.x, threadIdx.x, blockDim.x, st, prior, prior_pose16, fx, fy, cx, cy, so3, first_level, sync_words, n_sync,
+                  inject_timeout);
+}
+
+// The same with the last step of the model-side depth / intensity pyramid (prep.hip k_model_pyr_step, deferred by
+// odometry_initModel_fused) in the first gx * gy blocks: the two are independent, one launch boundary less per frame.
+// 64 x 4 thread blocks; the remaining `ni` blocks are k_track_init's.
+__global__ __launch_bounds__(256) void k_track_init_pyr(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy,
+                                                        float cx, float cy, int so3, int first_level, unsigned long long* sync_words,
+                                                        int n_sync, int inject_timeout, int gx, int gy, int ni, View<const float> dsrc,
+                                                        View<float> ddst, View<const unsigned char> isrc, View<unsigned char> idst) {
+  const int b = blockIdx.x;
+  if (b < gx * gy) {
+    const int by = b / gx, bx = b - by * gx;
+    model_pyr_step_pixel(bx * 64 + threadIdx.x, by * 4 + threadIdx.y, dsrc, ddst, isrc, idst);
+    return;
+  }
+  track_init_body(b - gx * gy, ni, threadIdx.y * 64 + threadIdx.x, 256, st, prior, prior_pose16, fx, fy, cx, cy, so3, first_level, sync_words,
+                  n_sync, inject_timeout);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2399,8 +2427,18 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     Timer t(o, s, "track_init");
     // (o->sync and o->ar are adjacent in the arena: one zeroing sweep covers both; resident mode only)
     const int zero_pairs = o->resident ? (int)(((char*)(o->ar + (size_t)kArReductions * kArWords) - (char*)o->sync) / 16) : 0;
-    hipLaunchKernelGGL(k_track_init, dim3(o->resident ? 16 : 1), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy,
-                       so3 ? 1 : 0, first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0);
+    const int ni = o->resident ? 16 : 1;
+    if (o->deferred_pyr) {
+      o->deferred_pyr = false;
+      dms_image2d d1 = o->lastDepth[1].img(), d2 = o->lastDepth[2].img(), i1 = o->lastImage[1].img(), i2 = o->lastImage[2].img();
+      const int gx = (d2.cols + 63) / 64, gy = (d2.rows + 3) / 4;
+      hipLaunchKernelGGL(k_track_init_pyr, dim3(gx * gy + ni), dim3(64, 4), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy,
+                         so3 ? 1 : 0, first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, gx, gy, ni, view<const float>(&d1),
+                         view<float>(&d2), view<const unsigned char>(&i1), view<unsigned char>(&i2));
+    } else {
+      hipLaunchKernelGGL(k_track_init, dim3(ni), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
+                         first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0);
+    }
     DMS_CHECK_LAUNCH();
     if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
   }
@@ -2816,8 +2854,11 @@ int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dm
 // initICPModel + initRGBModel of the frame step in four launches (prep.hip, modelPyramidFused).
 // The operator-layer staging copy vmaps_tmp is not written on this path; nextDepth is aliased to
 // lastDepth by the caller, so nothing reads it.
+// defer_last_step: the pyramid's last step is left to the first kernel of the NEXT odometry_track_enqueue on this object
+// (k_track_init_pyr), which the caller must enqueue on the same stream before anything else reads level 2 of lastDepth / lastImage
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
-                             const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s) {
+                             const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
+                             int defer_last_step) {
   dms_image2d v[DMS_NUM_PYRS], n[DMS_NUM_PYRS], d[DMS_NUM_PYRS], im[DMS_NUM_PYRS];
   for (int i = 0; i < DMS_NUM_PYRS; ++i) {
     v[i] = o->vmaps_g_prev[i].img();
@@ -2825,7 +2866,8 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
     d[i] = o->lastDepth[i].img();
     im[i] = o->lastImage[i].img();
   }
-  return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s);
+  o->deferred_pyr = defer_last_step != 0;
+  return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s, o->deferred_pyr);
 }
 
 // initICP(vertex map, normal map) + initRGB(image) of the live side in the fused form (RGBDOdometry.cpp:118-137,
@@ -2888,7 +2930,7 @@ int dms_odometry_initModelFused(dms_odometry* o, const void* vertA, const void* 
                                 const void* normB, const void* rgbaB, const int* use_b_dev, int force_b_image,
                                 const float* modelPose16_dev, dms_stream s) {
   DMS_REQUIRE(o, "null odometry");
-  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s);
+  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s, 0);
 }
 
 int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {
