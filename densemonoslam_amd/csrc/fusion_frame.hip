@@ -46,7 +46,7 @@ int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
-               const float* weighting_dev, int transposed, hipStream_t s);
+               const float* weighting_dev, int transposed, hipStream_t s, int defer_update = 0);
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
                 int isFern, int transposed, unsigned* count_out2, hipStream_t s);
@@ -917,7 +917,7 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
       {
         FTimer t(f, s, "fuse");
         if ((rc = model_fuse(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->rgba, &f->depth_metric, &f->depth_metric_filtered,
-                             &f->imap, &f->cam, f->p.maxDepthProcessed, 1.f, &f->state->weighting, 1, s)))
+                             &f->imap, &f->cam, f->p.maxDepthProcessed, 1.f, &f->state->weighting, 1, s, 1)))  // (update pass: inside the next index map)
           return rc;
       }
       {

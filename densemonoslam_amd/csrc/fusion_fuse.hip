@@ -201,27 +201,7 @@ __global__ __launch_bounds__(256) void k_fuse_update(int nslots, const float4* _
   const unsigned id = slot_best[slot];
   if (winner[id] != (unsigned)slot) return;
   winner[id] = kEmptyWinner;  // re-arm for the next frame
-  const float4 newPos = slot_pos[slot], newColor = slot_col[slot], newNorm = slot_nrm[slot];
-  const float4 vPosition = sp.pos[id], vColor = sp.col[id], vNormRad = sp.nrm[id];
-  const float c_k = vPosition.w;
-  const float av = newPos.w;
-  if (newNorm.w < (1.0f + 0.5f) * vNormRad.w) {
-    const float wsum = c_k + av;
-    sp.pos[id] = make_float4(((c_k * vPosition.x) + (av * newPos.x)) / wsum, ((c_k * vPosition.y) + (av * newPos.y)) / wsum,
-                             ((c_k * vPosition.z) + (av * newPos.z)) / wsum, wsum);
-    const f3 oldCol = decode_color(vColor.x), newCol = decode_color(newColor.x);
-    const float ar = ((c_k * oldCol.x) + (av * newCol.x)) / wsum, ag = ((c_k * oldCol.y) + (av * newCol.y)) / wsum,
-                ab = ((c_k * oldCol.z) + (av * newCol.z)) / wsum;
-    sp.col[id] = make_float4(encode_color(ar, ag, ab), vColor.y, vColor.z, vColor.w);
-    f3 n = mk3(((c_k * vNormRad.x) + (av * newNorm.x)) / wsum, ((c_k * vNormRad.y) + (av * newNorm.y)) / wsum,
-               ((c_k * vNormRad.z) + (av * newNorm.z)) / wsum);
-    const float r = ((c_k * vNormRad.w) + (av * newNorm.w)) / wsum;
-    n = normalized3(n);
-    sp.nrm[id] = make_float4(n.x, n.y, n.z, r);
-  } else {
-    sp.pos[id] = make_float4(vPosition.x, vPosition.y, vPosition.z, c_k + av);
-  }
-  sp.times[(size_t)timeIdx * cap + id] = (float)time;
+  fuse_update_apply(id, (unsigned)slot, slot_pos, slot_col, slot_nrm, sp, cap, time, timeIdx);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -663,8 +643,9 @@ static bool dense_img(const dms_image2d& im, size_t elem, int w, int h) {
 
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
-               const float* weighting_dev, int transposed, hipStream_t s) {
+               const float* weighting_dev, int transposed, hipStream_t s, int defer_update) {
   DMS_REQUIRE(m && pose && rgba && dr && drf && im && cam, "null argument");
+  DMS_REQUIRE(!m->pending_update, "a deferred update pass is still pending (index_map applies it)");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
   DMS_REQUIRE(dense_img(*rgba, 4, W, H) && dense_img(*dr, 4, W, H) && dense_img(*drf, 4, W, H) && dense_img(im->index, 4, W, H) &&
@@ -697,9 +678,15 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   dim3 b(256), g((tiles + 3) / 4);
   hipLaunchKernelGGL(k_fuse_associate, g, b, 0, s, a, m->slot_pos, m->slot_col, m->slot_nrm, m->slot_best, m->slot_flag, m->winner, slot_w);
   DMS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_fuse_update, dim3((m->slots + 255) / 256), dim3(256), 0, s, m->slots, m->slot_pos, m->slot_col, m->slot_nrm,
-                     m->slot_best, m->slot_flag, m->winner, m->buf[m->cur], m->cap, time, timeIdx);
-  DMS_CHECK_LAUNCH();
+  if (defer_update) {  // the caller's next index_map applies the winners while it projects: one pass and one launch less
+    m->pending_update = true;
+    m->pending_time = time;
+    m->pending_timeIdx = timeIdx;
+  } else {
+    hipLaunchKernelGGL(k_fuse_update, dim3((m->slots + 255) / 256), dim3(256), 0, s, m->slots, m->slot_pos, m->slot_col, m->slot_nrm,
+                       m->slot_best, m->slot_flag, m->winner, m->buf[m->cur], m->cap, time, timeIdx);
+    DMS_CHECK_LAUNCH();
+  }
   m->version += 1;
   return DMS_OK;
 }
@@ -707,6 +694,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
                 int isFern, int transposed, unsigned* count_out2, hipStream_t s) {
+  DMS_REQUIRE(m && !m->pending_update, "a deferred update pass is still pending (index_map applies it)");
   DMS_REQUIRE(m && pose && im && cam, "null argument");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;

@@ -415,11 +415,27 @@ __device__ __forceinline__ bool project_window(const ProjArgs& a, const f3& p, f
   return true;
 }
 
+// APPLY: the update pass of the preceding fuse (model_fuse with defer_update) has not run: a surfel that won a measurement
+// (winner[i] = its slot) is updated here, by the same function, before it is projected — the index map after a fuse reads
+// every surfel anyway, so the separate pass over the slots and its launch are saved.
+struct PendingUpdate {
+  const float4 *slot_pos, *slot_col, *slot_nrm;
+  unsigned* winner;
+  int time, timeIdx;
+};
+template <bool APPLY>
 __global__ __launch_bounds__(256) void k_index_project(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
-                                                       unsigned long long* __restrict__ zbuf) {
+                                                       unsigned long long* __restrict__ zbuf, PendingUpdate u) {
   const unsigned M = d_count[0];
   const float* Tinv = a.pose->t_inv;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += blockDim.x * gridDim.x) {
+    if (APPLY) {
+      const unsigned w = u.winner[i];
+      if (w != kEmptyWinner) {
+        u.winner[i] = kEmptyWinner;  // re-arm for the next frame
+        fuse_update_apply(i, w, u.slot_pos, u.slot_col, u.slot_nrm, sp, cap, u.time, u.timeIdx);
+      }
+    }
     const float4 pc = sp.pos[i];
     const f3 ph = xform_point(Tinv, mk3(pc.x, pc.y, pc.z));
     const float vt = sp.times[(size_t)a.timeIdx * cap + i];
@@ -534,7 +550,13 @@ int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, i
     hipLaunchKernelGGL(k_clear_zbuf, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, zbuf, n);
     DMS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_index_project, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf);
+  PendingUpdate u = {m->slot_pos, m->slot_col, m->slot_nrm, m->winner, m->pending_time, m->pending_timeIdx};
+  if (m->pending_update) {
+    m->pending_update = false;
+    hipLaunchKernelGGL(k_index_project<true>, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf, u);
+  } else {
+    hipLaunchKernelGGL(k_index_project<false>, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, m->d_count, zbuf, u);
+  }
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_index_resolve, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf,
                      (unsigned*)out->index.data, (float4*)out->vertConf.data, (float4*)out->colorTime.data, (float4*)out->normRad.data,
@@ -1064,6 +1086,7 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime, unsigned long long* zbuf2,
                   int resolve_only, const FillArgs* fill) {
   DMS_REQUIRE(m && pose && cam && zbuf, "null argument");
+  DMS_REQUIRE(!m->pending_update, "a deferred update pass is still pending (index_map applies it)");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
   if (depth_out)

@@ -128,6 +128,32 @@ __host__ __device__ __forceinline__ float uv_coord(int i, int n) {
   return (float)((double)((float)i / (float)n) + 1.0 / (double)(2.0f * (float)n));
 }
 
+// G8: update (update.vert:42-104) of surfel `id` by its winning measurement `slot`, in place
+__device__ __forceinline__ void fuse_update_apply(unsigned id, unsigned slot, const float4* __restrict__ slot_pos, const float4* __restrict__ slot_col,
+                                                  const float4* __restrict__ slot_nrm, const SurfelPlanes& sp, size_t cap, int time, int timeIdx) {
+  const float4 newPos = slot_pos[slot], newColor = slot_col[slot], newNorm = slot_nrm[slot];
+  const float4 vPosition = sp.pos[id], vColor = sp.col[id], vNormRad = sp.nrm[id];
+  const float c_k = vPosition.w;
+  const float av = newPos.w;
+  if (newNorm.w < (1.0f + 0.5f) * vNormRad.w) {
+    const float wsum = c_k + av;
+    sp.pos[id] = make_float4(((c_k * vPosition.x) + (av * newPos.x)) / wsum, ((c_k * vPosition.y) + (av * newPos.y)) / wsum,
+                             ((c_k * vPosition.z) + (av * newPos.z)) / wsum, wsum);
+    const f3 oldCol = decode_color(vColor.x), newCol = decode_color(newColor.x);
+    const float ar = ((c_k * oldCol.x) + (av * newCol.x)) / wsum, ag = ((c_k * oldCol.y) + (av * newCol.y)) / wsum,
+                ab = ((c_k * oldCol.z) + (av * newCol.z)) / wsum;
+    sp.col[id] = make_float4(encode_color(ar, ag, ab), vColor.y, vColor.z, vColor.w);
+    f3 n = mk3(((c_k * vNormRad.x) + (av * newNorm.x)) / wsum, ((c_k * vNormRad.y) + (av * newNorm.y)) / wsum,
+               ((c_k * vNormRad.z) + (av * newNorm.z)) / wsum);
+    const float r = ((c_k * vNormRad.w) + (av * newNorm.w)) / wsum;
+    n = normalized3(n);
+    sp.nrm[id] = make_float4(n.x, n.y, n.z, r);
+  } else {
+    sp.pos[id] = make_float4(vPosition.x, vPosition.y, vPosition.z, c_k + av);
+  }
+  sp.times[(size_t)timeIdx * cap + id] = (float)time;
+}
+
 }  // namespace dms
 
 struct dms_model {
@@ -155,6 +181,11 @@ struct dms_model {
   unsigned* clean_first = nullptr;  // suffix-mode clean: index of the first block that is not left in place
   float* nodes = nullptr;           // deformation node table, 16 floats / node
   int max_nodes = 2048;
+  // model_fuse(..., defer_update): the update pass (G8) has not run yet; the next index_map applies it surfel by surfel while
+  // it projects (fusion_map.hip k_index_project<true>), with these arguments.  Only the frame step uses it: fuse is
+  // always followed by the index map of the clean.
+  bool pending_update = false;
+  int pending_time = 0, pending_timeIdx = 0;
   unsigned long version = 0;        // bumped by every operation that changes the map (cached projections are tagged with it)
   int num_sensors = 3;              // per-surfel time slots that take part in the clean's health test (reference NUM_CAMERAS = 3)
   size_t clean_suffix_min = (size_t)1 << 20;  // map size from which the clean runs in suffix mode (DMS_CLEAN_SUFFIX_MIN at create)
