@@ -94,7 +94,7 @@ struct dms_odometry {
   bool resident = true;       // false: three launches per iteration (DMS_TRACK_MODE=launches)
   bool fp64_sums = false;     // block sums and records in fp64 (DMS_SUMS=fp64)
   int early_exit_force = -1;  // -1: as `early_exit`; 0 / 1: forced (DMS_TRACK_EARLY_EXIT)
-  int persist_target = 96;    // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
+  int persist_target = 160;   // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
   // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
   bool deferred_pyr = false;
   int inject_timeouts = 0;    // dms_odometry_inject_timeout: calls left that start with the timeout flag set
@@ -2310,8 +2310,10 @@ namespace dms {
 
 // pixels per thread (1 or 2) and grid of k_gn_level for an n-pixel level; 0 blocks = not eligible
 static void persistent_shape(int n, int target, int& P, int& nb) {
-  // 1 or 2 pixels per thread if that keeps the grid at <= 96 blocks (cheap barriers and gathers win
-  // on the small levels); otherwise 3 pixels per thread on up to 256 blocks (the full-resolution
+  // 1 or 2 pixels per thread if that keeps the grid at <= `target` blocks (cheap barriers win on the small levels; 96 while
+  // the cross-block sums went through per-block records and a gather, 160 since the integer all-reduce: level 1 of
+  // 640x480 on 150 blocks with one pixel per thread instead of 75 with two, +1 % frame rate);
+  // otherwise 3 pixels per thread on up to 256 blocks (the full-resolution
   // level is bound by its per-CU arithmetic: measured 221 us at 200 blocks vs 230 us at 150), else 4
   auto blocks = [&](int p) { return (n + kPB * p - 1) / (kPB * p); };
   if (blocks(1) <= target)
