@@ -452,16 +452,18 @@ __global__ void k_model_levels012(ModelSrc m, int g0x, int g0y, int g12x, int ro
                                   View<float> depth0, View<unsigned char> inten0, float cutOff, int rows1, int cols1, int rows2, int cols2,
                                   View<float> v1, View<float> n1, View<float> v2, View<float> n2, int g12y, int gsx, View<float> depth1,
                                   View<unsigned char> inten1) {
+  // (the two small groups come first in the grid: their threads carry 32 / 50 dependent-latency loads each and would
+  // otherwise start only when the 1 200 level-0 blocks have been handed out — the launch's tail)
   const int b = blockIdx.x;
-  const int nb0 = g0x * g0y, nb12 = g12x * g12y;
-  if (b < nb0) {
-    model_level0_body(b % g0x, b / g0x, m, rows0, cols0, v0, n0, depth0, inten0, cutOff);
-  } else if (b < nb0 + nb12) {
-    const int c = b - nb0;
-    model_levels12_body(c % g12x, c / g12x, m, cols0, rows1, cols1, rows2, cols2, v1, n1, v2, n2);
-  } else {
-    const int c = b - nb0 - nb12;
+  const int nb0 = g0x * g0y, nb12 = g12x * g12y, nbs = (int)gridDim.x - nb0 - nb12;
+  if (b < nb12) {
+    model_levels12_body(b % g12x, b / g12x, m, cols0, rows1, cols1, rows2, cols2, v1, n1, v2, n2);
+  } else if (b < nb12 + nbs) {
+    const int c = b - nb12;
     model_pyr_step1_body(c % gsx, c / gsx, m, rows0, cols0, cutOff, depth1, inten1);
+  } else {
+    const int c = b - nb12 - nbs;
+    model_level0_body(c % g0x, c / g0x, m, rows0, cols0, v0, n0, depth0, inten0, cutOff);
   }
 }
 

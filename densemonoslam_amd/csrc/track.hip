@@ -250,20 +250,21 @@ __global__ void k_track_init(TrackState* st, Prior prior, const float* __restric
 }
 
 // The same with the last step of the model-side depth / intensity pyramid (prep.hip k_model_pyr_step, deferred by
-// odometry_initModel_fused) in the first gx * gy blocks: the two are independent, one launch boundary less per frame.
-// 64 x 4 thread blocks; the remaining `ni` blocks are k_track_init's.
+// odometry_initModel_fused) in further blocks: the two are independent, one launch boundary less per frame.
+// 64 x 4 thread blocks; the first `ni` blocks are k_track_init's, the next gx * gy the pyramid step's.
 __global__ __launch_bounds__(256) void k_track_init_pyr(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy,
                                                         float cx, float cy, int so3, int first_level, unsigned long long* sync_words,
                                                         int n_sync, int inject_timeout, int gx, int gy, int ni, View<const float> dsrc,
                                                         View<float> ddst, View<const unsigned char> isrc, View<unsigned char> idst) {
   const int b = blockIdx.x;
-  if (b < gx * gy) {
-    const int by = b / gx, bx = b - by * gx;
+  if (b >= ni) {
+    const int c = b - ni, by = c / gx, bx = c - by * gx;
     model_pyr_step_pixel(bx * 64 + threadIdx.x, by * 4 + threadIdx.y, dsrc, ddst, isrc, idst);
     return;
   }
-  track_init_body(b - gx * gy, ni, threadIdx.y * 64 + threadIdx.x, 256, st, prior, prior_pose16, fx, fy, cx, cy, so3, first_level, sync_words,
-                  n_sync, inject_timeout);
+  // (first in the grid: block 0's one-lane state set-up is the longest dependency chain of the launch)
+  track_init_body(b, ni, threadIdx.y * 64 + threadIdx.x, 256, st, prior, prior_pose16, fx, fy, cx, cy, so3, first_level, sync_words, n_sync,
+                  inject_timeout);
 }
 
 // ---------------------------------------------------------------------------------------
