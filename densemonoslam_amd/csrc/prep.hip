@@ -373,36 +373,42 @@ __device__ __forceinline__ f3 resize4(const f3& a, const f3& b, const f3& c, con
   return n;
 }
 
-// levels 1 and 2: one thread per level-2 pixel = 2x2 level-1 pixels = 4x4 level-0 pixels
+// levels 1 and 2: one thread per level-1 pixel (its 2x2 level-0 pixels); the four level-1 pixels under one level-2 pixel
+// sit in four neighbouring lanes (k = lane & 3: x offset k & 1, y offset k >> 1), lane 0 of the quad gathers the four
+// level-1 values and writes level 2.  64 x BY thread blocks: 16 x BY level-2 pixels per block.  (One thread per level-2
+// pixel — 32 strided 16-byte loads per lane on 75 blocks — took 10.8 of the launch's 17.7 us.)
 __device__ __forceinline__ void model_levels12_body(int bx, int by, const ModelSrc& m, int cols0, int rows1, int cols1, int rows2, int cols2,
                                                     View<float> v1, View<float> n1, View<float> v2, View<float> n2) {
-  const int x2 = bx * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x, k = lane & 3;
+  const int x2 = bx * 16 + (lane >> 2);
   const int y2 = by * blockDim.y + threadIdx.y;
-  if (2 * x2 >= cols1 || 2 * y2 >= rows1) return;
+  const int x1 = 2 * x2 + (k & 1), y1 = 2 * y2 + (k >> 1);
   const bool useB = *m.flag != 0;
   const float4* vs = useB ? m.vB : m.vA;
   const float4* ns = useB ? m.nB : m.nA;
   const Pose34 P = load_pose34(m.pose16);
-  f3 lv[4], ln[4];
-  bool have[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x1 = 2 * x2 + (k & 1), y1 = 2 * y2 + (k >> 1);
-    have[k] = x1 < cols1 && y1 < rows1;
-    if (!have[k]) continue;
+  f3 lv = mk3(0.f, 0.f, 0.f), ln = mk3(0.f, 0.f, 0.f);
+  if (x1 < cols1 && y1 < rows1) {
     f3 rv[4], rn[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const size_t i = (size_t)(2 * y1 + (j >> 1)) * cols0 + (2 * x1 + (j & 1));
       raw_maps(vs[i], ns[i], rv[j], rn[j]);
     }
-    lv[k] = resize4<false>(rv[0], rv[1], rv[2], rv[3]);
-    ln[k] = resize4<true>(rn[0], rn[1], rn[2], rn[3]);
-    store_transformed(v1, n1, rows1, y1, x1, lv[k], ln[k], P, m.pose16 != nullptr);
+    lv = resize4<false>(rv[0], rv[1], rv[2], rv[3]);
+    ln = resize4<true>(rn[0], rn[1], rn[2], rn[3]);
+    store_transformed(v1, n1, rows1, y1, x1, lv, ln, P, m.pose16 != nullptr);
   }
-  if (x2 < cols2 && y2 < rows2) {  // then all four level-1 pixels exist
-    const f3 a = resize4<false>(lv[0], lv[1], lv[2], lv[3]);
-    const f3 b = resize4<true>(ln[0], ln[1], ln[2], ln[3]);
+  f3 qv[4], qn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int src = (lane & ~3) | j;
+    qv[j] = mk3(__shfl(lv.x, src, 64), __shfl(lv.y, src, 64), __shfl(lv.z, src, 64));
+    qn[j] = mk3(__shfl(ln.x, src, 64), __shfl(ln.y, src, 64), __shfl(ln.z, src, 64));
+  }
+  if (k == 0 && x2 < cols2 && y2 < rows2) {  // then all four level-1 pixels exist
+    const f3 a = resize4<false>(qv[0], qv[1], qv[2], qv[3]);
+    const f3 b = resize4<true>(qn[0], qn[1], qn[2], qn[3]);
     store_transformed(v2, n2, rows2, y2, x2, a, b, P, m.pose16 != nullptr);
   }
 }
@@ -412,12 +418,35 @@ __device__ __forceinline__ void model_levels12_body(int bx, int by, const ModelS
 // so the step does not have to wait for level 0
 __device__ __forceinline__ void model_pyr_step1_body(int bx, int by, const ModelSrc& m, int rows0, int cols0, float cutOff, View<float> ddst,
                                                      View<unsigned char> idst) {
-  const int x = bx * blockDim.x + threadIdx.x;
-  const int y = by * blockDim.y + threadIdx.y;
-  if (x >= ddst.cols || y >= ddst.rows) return;
+  // The block's 64 x BY outputs read a (2 * 64 + 3) x (2 * BY + 3) window of level 0: every source pixel is converted once,
+  // by coalesced loads, into LDS (25 strided taps per output straight from the float4 / uchar4 sources made this group
+  // the longest of the launch: 12 us alone); the taps, their order and their arithmetic are unchanged.
+  constexpr int TW = 2 * BX + 3, TH = 2 * BY + 3;
+  __shared__ float s_d[TH][TW + 1];
+  __shared__ unsigned char s_c[TH][TW + 1];
   const bool useB = *m.flag != 0;
   const float4* vs = useB ? m.vB : m.vA;
   const uchar4* is = (useB || m.force_b_img) ? m.iB : m.iA;
+  const int sx0 = 2 * (bx * BX) - 2, sy0 = 2 * (by * BY) - 2;
+  for (int e = threadIdx.y * BX + threadIdx.x; e < TH * TW; e += BX * BY) {
+    const int r = e / TW, c = e - r * TW;
+    const int gy = sy0 + r, gx = sx0 + c;
+    float sv = qnan();
+    unsigned char cv = 0;
+    if (gx >= 0 && gy >= 0 && gx < cols0 && gy < rows0) {
+      const size_t i = (size_t)gy * cols0 + gx;
+      const float z = vs[i].z;
+      sv = (z > cutOff || z <= 0.f) ? qnan() : z;
+      const uchar4 cc = is[i];
+      cv = (unsigned char)f2i_rz(((float)cc.x * 0.114f + (float)cc.y * 0.299f) + (float)cc.z * 0.587f);
+    }
+    s_d[r][c] = sv;
+    s_c[r][c] = cv;
+  }
+  __syncthreads();
+  const int x = bx * blockDim.x + threadIdx.x;
+  const int y = by * blockDim.y + threadIdx.y;
+  if (x >= ddst.cols || y >= ddst.rows) return;
   const int D = 5;
   const int tx = min(2 * x - D / 2 + D, cols0 - 1);
   const int ty = min(2 * y - D / 2 + D, rows0 - 1);
@@ -426,15 +455,12 @@ __device__ __forceinline__ void model_pyr_step1_body(int bx, int by, const Model
   for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
     for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
       const float g = gauss25(ty - cy - 1, tx - cx - 1);
-      const size_t i = (size_t)cy * cols0 + cx;
-      const float z = vs[i].z;
-      const float s = (z > cutOff || z <= 0.f) ? qnan() : z;
+      const float s = s_d[cy - sy0][cx - sx0];
       if (!isnan(s)) {
         sum += s * g;
         count += (int)g;
       }
-      const uchar4 cc = is[i];
-      const unsigned char c = (unsigned char)f2i_rz(((float)cc.x * 0.114f + (float)cc.y * 0.299f) + (float)cc.z * 0.587f);
+      const unsigned char c = s_c[cy - sy0][cx - sx0];
       if (c > 0) {
         isum += (float)c * g;
         icount += (int)g;
@@ -685,7 +711,7 @@ int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void
   DMS_REQUIRE(rows1 == rows0 / 2 && cols1 == cols0 / 2 && rows2 == rows1 / 2 && cols2 == cols1 / 2, "pyramid shapes");
   {
     const dim3 b = blk();
-    const dim3 g0 = grid2d(cols0, rows0, b), g12 = grid2d((cols1 + 1) / 2, (rows1 + 1) / 2, b),
+    const dim3 g0 = grid2d(cols0, rows0, b), g12 = dim3(((cols1 + 1) / 2 + 15) / 16, ((rows1 + 1) / 2 + b.y - 1) / b.y),  // 16 x BY level-2 pixels per block
                gs = grid2d(depths[1].cols, depths[1].rows, b);
     hipLaunchKernelGGL(k_model_levels012, dim3(g0.x * g0.y + g12.x * g12.y + gs.x * gs.y), b, 0, s, m, (int)g0.x, (int)g0.y, (int)g12.x, rows0,
                        cols0, view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]), view<unsigned char>(&images[0]), cutOff,
