@@ -292,42 +292,40 @@ __device__ __forceinline__ int clean_test(const CleanArgs& a, const CleanElem& v
     const float y_lo = yc - ((scale * indexYStep) * windowMultiplier), y_hi = yc + ((scale * indexYStep) * windowMultiplier);
     const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
     const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
-    // The (at most 4 x 4) distinct texels are visited one x slot at a time: the 12 loads of a slot's
-    // four texels (id, vertex/confidence, colour/time — none depends on another) are in flight
-    // together, a slot no lane of the wave uses is skipped, and the register footprint stays small
-    // enough that the 80-byte element is not spilled.  Unused y slots carry multiplicity 0 and read
-    // texel 0.
+    // The (at most 4 x 4) distinct texels are visited one x slot at a time: the 4 vertex / confidence loads of a slot's
+    // four texels are in flight together, a slot no lane of the wave uses is skipped, and the register footprint stays
+    // small enough that the 80-byte element is not spilled.  Unused y slots carry multiplicity 0 and read texel 0.
+    // Both counts need a stable texel that lies behind the surfel (vc.w > confThreshold && vc.z > localPos.z): only for
+    // those is the texel's id and colour / time pair fetched — the window loads are what this kernel spends its time
+    // on (27 of 35 us), and about half of the taps end at the first test.
     const int txs[4] = {tx_.t0, tx_.t1, tx_.t2, tx_.t3}, mxs[4] = {tx_.m0, tx_.m1, tx_.m2, tx_.m3};
     const int tys[4] = {ty_.t0, ty_.t1, ty_.t2, ty_.t3}, mys[4] = {ty_.m0, ty_.m1, ty_.m2, ty_.m3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (mxs[i] != 0) {  // (divergent lanes wait here; a slot unused by the whole wave costs nothing)
-        unsigned cur[4];
         float4 vcs[4];
-        float2 cts[4];
+        unsigned qs[4];
         int mult[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           mult[j] = mxs[i] * mys[j];
           const int uy = mult[j] ? tys[j] : 0;
-          const unsigned q = a.transposed ? (unsigned)txs[i] * (unsigned)a.rows + (unsigned)uy : (unsigned)uy * (unsigned)a.cols + (unsigned)txs[i];
-          cur[j] = a.index[q];
-          vcs[j] = a.vertConf[q];
-          cts[j] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.colorTime[q]) + 2);  // .z .w
+          qs[j] = a.transposed ? (unsigned)txs[i] * (unsigned)a.rows + (unsigned)uy : (unsigned)uy * (unsigned)a.cols + (unsigned)txs[i];
+          vcs[j] = a.vertConf[qs[j]];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int m = mult[j];
-          if (m != 0 && cur[j] > 0u) {
-            const float4 vc = vcs[j];
-            const float ctz = cts[j].x, ctw = cts[j].y;
-            const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
-            if (ctz < v.col.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
-                sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f)
-              count += m;  // every repeated tap of this texel counts
-            if (ctw == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f &&
-                fabsf(localNorm.z) > 0.85f)
-              zCount += m;
+          const float4 vc = vcs[j];
+          if (m != 0 && vc.w > a.confThreshold && vc.z > localPos.z) {
+            const unsigned cur = a.index[qs[j]];
+            const float2 ct = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(&a.colorTime[qs[j]]) + 2);  // .z .w
+            if (cur > 0u) {
+              const float ctz = ct.x, ctw = ct.y;
+              const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
+              if (ctz < v.col.z && vc.z - localPos.z < 0.01f && sqrtf(dx * dx + dy * dy) < v.nrm.w * 1.4f) count += m;  // every repeated tap of this texel counts
+              if (ctw == (float)a.time && vc.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f) zCount += m;
+            }
           }
         }
       }
