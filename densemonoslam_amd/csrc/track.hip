@@ -2333,16 +2333,19 @@ static void persistent_shape(int n, int target, int& P, int& nb) {
 // half-resident.  Every persistent section of this process is therefore chained on one event per
 // device: stream-ordered, free for a single stream, and it serialises trackers of different
 // cameras / streams against each other.
-// The event is only needed when the stream changes: a section on the stream that ran the previous one is ordered by
-// the stream itself.  When another stream takes over, the event is recorded on the PREVIOUS stream at that moment (its
-// tail is behind its section) and the new stream waits for it — a single camera on a single stream, the usual case,
-// pays nothing (the unconditional record after every tracker call cost ~6 us of idle stream per frame in the rocprof
-// trace).  A previous stream that has been destroyed meanwhile has finished its work: the failed record is ignored.
+// A process that runs all its trackers on one stream (one camera per process, the usual case) needs no event at all:
+// the stream orders the sections, and the unconditional record after every tracker call cost ~6 us of idle stream per
+// frame in the rocprof trace.  The first time a section arrives on a stream other than the previous one, the device is
+// synchronised once (the previous stream may have been destroyed since: its handle must not be touched any more) and the
+// device switches to the chained form: from then on every section ends with an event recorded on its own — live —
+// stream, and a section on another stream waits for it.
 struct PersistChain {
   std::mutex mu;
   hipEvent_t ev[64] = {};
   hipStream_t last[64] = {};
   bool used[64] = {};
+  bool chained[64] = {};   // several streams have run sections on this device: events from here on
+  bool ev_valid[64] = {};
 };
 static PersistChain g_persist;
 struct PersistSection {
@@ -2356,11 +2359,12 @@ struct PersistSection {
     (void)hipGetDevice(&dev);
     dev &= 63;
     if (g_persist.used[dev] && g_persist.last[dev] != s) {
-      if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
-      if (hipEventRecord(g_persist.ev[dev], g_persist.last[dev]) == hipSuccess)
+      if (!g_persist.chained[dev]) {
+        (void)hipDeviceSynchronize();
+        g_persist.chained[dev] = true;
+      } else if (g_persist.ev_valid[dev]) {
         (void)hipStreamWaitEvent(s, g_persist.ev[dev], 0);
-      else
-        (void)hipGetLastError();
+      }
     }
     g_persist.last[dev] = s;
     g_persist.used[dev] = true;
@@ -2368,6 +2372,11 @@ struct PersistSection {
   }
   ~PersistSection() {
     if (!active) return;
+    if (g_persist.chained[dev]) {
+      if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
+      g_persist.ev_valid[dev] = g_persist.ev[dev] && hipEventRecord(g_persist.ev[dev], s) == hipSuccess;
+      if (!g_persist.ev_valid[dev]) (void)hipGetLastError();
+    }
     g_persist.mu.unlock();
   }
 };
