@@ -707,7 +707,13 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   }
   {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
     FTimer t(f, sp, "preprocess");
-    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp, f->p.pipeline_ingest ? f->prep_blocks : 0))) return rc;
+    // (fat blocks only while the caller's stream is busy: they exist to leave the previous frame's tracker its compute
+    // units; when nothing is running there — the first frame after a pause — the whole-chip form is 2.5x shorter and this
+    // frame's tracker is waiting for it)
+    bool beside_tracker = f->p.pipeline_ingest != 0;
+    if (beside_tracker && hipStreamQuery(s) == hipSuccess) beside_tracker = false;
+    (void)hipGetLastError();  // (hipErrorNotReady is the expected answer)
+    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp, beside_tracker ? f->prep_blocks : 0))) return rc;
     if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, sp))) return rc;
     if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, sp))) return rc;
   }
