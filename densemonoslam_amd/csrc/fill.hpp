@@ -19,13 +19,13 @@ struct FillArgs {
   int mirror_words;
   // optional: denseEnough (ElasticFusion.cpp:84-97,166-167) from the existing image: the share of non-black pixels on
   // its W/20 x H/20 NEAREST subsample (Resize::image); *dense_flag = 0 when more than 95 % are covered, 1 (fill in)
-  // otherwise.  Independent of the fill-in itself.  Stand-alone kernel: one extra block (grid row `rows_blocks`);
-  // resolve pass: the block that finishes last (`tickets`: 17 zeroed counters, 64 bytes apart, left zeroed).
+  // otherwise.  Independent of the fill-in itself.  Stand-alone kernel: one extra block (grid row `rows_blocks`).
   int* dense_flag;
   int rows_blocks;
-  unsigned* tickets;
-  // resolve pass: bit masks of the columns (words 0..63) and rows (words 64..127) the subsample reads (fill_sample_masks);
-  // those pixels of the image are written through, the last block reads them back
+  // resolve pass: the threads that own a subsampled pixel (bit masks of its columns, words 0..63, and rows, words
+  // 64..127: fill_sample_masks) add their non-black pixel to one of 16 counters (64 bytes apart, zero on entry); the
+  // consumer of the decision sums them (dense_from_counters) — no block has to wait for the others inside the launch
+  unsigned* dense_cnt;
   const unsigned* sample_mask;
   float4* out_vertex;
   float4* out_normal;
@@ -90,9 +90,8 @@ inline void fill_sample_masks(int cols, int rows, unsigned* words128) {
   }
 }
 
-// the denseEnough decision by one block of NT threads (t = linear thread id); COHERENT: the image was written by other
-// blocks of the same launch (reads that bypass the non-coherent cache levels)
-template <int NT, bool COHERENT>
+// the denseEnough decision by one block of NT threads (t = linear thread id)
+template <int NT>
 __device__ __forceinline__ void fill_dense_test(const FillArgs& a, int t, int* s_sum /* [NT / 64] in LDS */) {
   const int dw = a.cols / 20, dh = a.rows / 20;
   int sum = 0;
@@ -100,9 +99,8 @@ __device__ __forceinline__ void fill_dense_test(const FillArgs& a, int t, int* s
     const int i = k % dw, j = k / dw;
     const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
     const int sx = texel(u, (float)a.cols, a.cols), sy = texel(v, (float)a.rows, a.rows);
-    const unsigned* p = reinterpret_cast<const unsigned*>(a.ex_image + (size_t)sy * a.cols + sx);
-    const unsigned w = COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-    sum += ((w & 0xFFu) > 0 && ((w >> 8) & 0xFFu) > 0 && ((w >> 16) & 0xFFu) > 0) ? 1 : 0;
+    const uchar4 c = a.ex_image[(size_t)sy * a.cols + sx];
+    sum += (c.x > 0 && c.y > 0 && c.z > 0) ? 1 : 0;
   }
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
   if ((t & 63) == 0) s_sum[t >> 6] = sum;
@@ -113,6 +111,14 @@ __device__ __forceinline__ void fill_dense_test(const FillArgs& a, int t, int* s
     const bool dense = (float)tot / (float)(dh * dw) > 0.95f;
     *a.dense_flag = dense ? 0 : 1;
   }
+}
+
+// the same decision from the 16 counters of the resolve pass: 1 = fill in (not dense enough)
+__device__ __forceinline__ int dense_from_counters(const unsigned* cnt, int samples) {
+  unsigned tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += cnt[k * 16];
+  return ((float)(int)tot / (float)samples > 0.95f) ? 0 : 1;
 }
 
 }  // namespace dms

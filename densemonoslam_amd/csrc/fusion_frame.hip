@@ -62,7 +62,7 @@ int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rg
                               hipStream_t s);
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
-                             int defer_last_step = 0);
+                             int defer_last_step = 0, unsigned* dense_cnt = nullptr, int dense_samples = 0);
 int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
                             hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
@@ -206,7 +206,8 @@ struct dms_fusion {
   // second z-buffer: filled by the final prediction's project pass with the NEXT frame's tracking prediction (same map,
   // same pose unless the caller brings a prior), resolved at that frame's begin instead of projecting the map again
   unsigned long long* zbuf2 = nullptr;
-  unsigned* tickets = nullptr;  // 17 counters, 64 bytes apart (fused fill-in: which block finishes last); subsample masks at word 512
+  unsigned* tickets = nullptr;  // 16 counters, 64 bytes apart (fused fill-in: non-black subsampled pixels of the tracking prediction); subsample masks at word 512
+  bool dense_by_counters = false;  // this frame's denseEnough decision is taken from them by the model pyramid kernel
   double host_wait_ms = 0.0;     // host time spent blocked on the bounded run-ahead ("host_wait" of dms_fusion_get_kernel_time)
   bool pre_valid = false;        // zbuf2 holds a projection
   int pre_tick = 0;              // ... rendered for this tick
@@ -375,9 +376,17 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
   if ((rc = fill_args(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
                       state_mirror ? f->state : nullptr, state_mirror, (int)sizeof(FrameState), dense_test ? &f->state->fill_in : nullptr, &fa)))
     return rc;
-  fa.tickets = f->tickets;
-  fa.sample_mask = f->tickets + 512;
-  if (f->p.fused_fill_in && f->p.width <= 2048 && f->p.height <= 2048) fused = &fa;
+  // the denseEnough decision of a fused pass is taken by the tracker's model pyramid kernel from the counters filled here
+  // (fill.hpp): only when that kernel follows, i.e. with hybrid tracking
+  f->dense_by_counters = false;
+  if (f->p.fused_fill_in && f->p.width <= 2048 && f->p.height <= 2048 && (!dense_test || f->p.hybrid_tracking)) {
+    fused = &fa;
+    if (dense_test) {
+      fa.dense_cnt = f->tickets;
+      fa.sample_mask = f->tickets + 512;
+      f->dense_by_counters = true;
+    }
+  }
   {
     FTimer t(f, s, "predict");
     const int W = f->p.width, H = f->p.height;
@@ -768,7 +777,8 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
         // WARNING (reference): initICP* must be called before initRGB* (ElasticFusion.cpp:172)
         if ((rc = odometry_initModel_fused(f->odom, f->pred.vertex.data, f->pred.normal.data, f->pred.image.data, f->fill.vertex.data,
                                            f->fill.normal.data, f->fill.image.data, &f->state->fill_in, f->p.frameToFrameRGB ? 1 : 0,
-                                           f->state->cur.pose, s, 1)))  // (last pyramid step: inside the tracker's first kernel, below)
+                                           f->state->cur.pose, s, 1,  // (last pyramid step: inside the tracker's first kernel, below)
+                                           f->dense_by_counters ? f->tickets : nullptr, (f->p.width / 20) * (f->p.height / 20))))
           return rc;
         // initICP / initRGB: the live half ran on the prep stream; nextDepth = lastDepth (same source)
         odometry_alias_next_depth(f->odom);

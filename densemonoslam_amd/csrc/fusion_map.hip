@@ -975,8 +975,10 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
 }
 
 // FILL: the hole fill-in of the prediction (fill.hpp) for the pixel just resolved — the launch and the re-read of the
-// three images that a separate fill-in pass costs are saved; the denseEnough decision on the finished image is taken by
-// the block that finishes last (two-level ticket: 16 group counters, then one), the result-block mirror by block 0.
+// three images that a separate fill-in pass costs are saved; the result-block mirror is done by block 0; for the
+// denseEnough decision the threads that own a subsampled pixel count the non-black ones into 16 counters, which the
+// consumer of the decision (the model pyramid kernel) sums.  (Taking the decision inside this launch — last block by
+// ticket, the subsampled pixels written through — cost the 6 us the separate launch had cost.)
 template <bool DEPTH_ONLY, bool FILL>
 __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, unsigned long long* __restrict__ zbuf,
                                                        uchar4* __restrict__ image, float4* __restrict__ vertex, float4* __restrict__ normal,
@@ -1000,16 +1002,13 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     if (clear_after) zbuf[(size_t)px * a.rows + py] = kZClear;
     bool sampled = false;
     if (FILL) {
-      if (fa.dense_flag) sampled = ((fa.sample_mask[px >> 5] >> (px & 31)) & (fa.sample_mask[64 + (py >> 5)] >> (py & 31)) & 1u) != 0u;
+      if (fa.dense_cnt) sampled = ((fa.sample_mask[px >> 5] >> (px & 31)) & (fa.sample_mask[64 + (py >> 5)] >> (py & 31)) & 1u) != 0u;
     }
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {
       if (DEPTH_ONLY) {
         depthOut[p] = 0.f;
       } else {
-        if (FILL && sampled)
-          __hip_atomic_store(reinterpret_cast<unsigned*>(image + p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (see below)
-        else
-          image[p] = make_uchar4(0, 0, 0, 0);
+        image[p] = make_uchar4(0, 0, 0, 0);
         vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         normal[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         timeImg[p] = 0;
@@ -1032,15 +1031,8 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     // RGBA8 render target: round(c * 255)
     const uchar4 o_img = make_uchar4((unsigned char)f2i_rn(rgb.x * 255.0f), (unsigned char)f2i_rn(rgb.y * 255.0f),
                                      (unsigned char)f2i_rn(rgb.z * 255.0f), 255);
-    // FILL: the block that finishes last reads the subsampled pixels of the image (denseEnough) — those are written through
-    // to where every block sees them, instead of a cache write-back fence per block (measured: 1 200 fences over 17 MB
-    // of dirty output, +25 us per launch)
-    if (FILL && sampled)
-      __hip_atomic_store(reinterpret_cast<unsigned*>(image + p),
-                         (unsigned)o_img.x | ((unsigned)o_img.y << 8) | ((unsigned)o_img.z << 16) | ((unsigned)o_img.w << 24), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    else
-      image[p] = o_img;
+    image[p] = o_img;
+    if (FILL && sampled && o_img.x > 0 && o_img.y > 0 && o_img.z > 0) atomicAdd(fa.dense_cnt + ((px + py) & 15) * 16, 1u);
     const float z = c.z;
     const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
     const float4 o_v = make_float4(((fcx - a.cx) * z) * (1.f / a.fx), ((fcy - a.cy) * z) * (1.f / a.fy), z, s.conf);
@@ -1053,31 +1045,6 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     if (tv > 65535u) tv = 65535u;
     timeImg[p] = (unsigned short)tv;
     if (FILL) fill_pixel(fa, px, py, o_v, o_n, o_img);
-  }
-  if (FILL) {
-    if (fa.dense_flag) {  // (uniform)
-      __shared__ int s_last;
-      __shared__ int s_sum[4];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's image pixels have been written through
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned g = blockIdx.x & 15u;
-        const unsigned in_group = (gridDim.x - g + 15u) / 16u, groups = gridDim.x < 16u ? gridDim.x : 16u;
-        bool last = false;
-        if (atomicAdd(fa.tickets + g * 16u, 1u) == in_group - 1u) {
-          __hip_atomic_store(fa.tickets + g * 16u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (left zeroed for the next launch)
-          if (atomicAdd(fa.tickets + 256, 1u) == groups - 1u) {
-            __hip_atomic_store(fa.tickets + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = true;
-          }
-        }
-        s_last = last ? 1 : 0;
-      }
-      __syncthreads();
-      if (s_last) {
-        fill_dense_test<256, true>(fa, (int)threadIdx.x, s_sum);
-      }
-    }
   }
 }
 
@@ -1127,7 +1094,7 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
   } else if (fill) {
     DMS_REQUIRE(fill->ex_image == (const uchar4*)out->image.data && fill->ex_vertex == (const float4*)out->vertex.data &&
                     fill->ex_normal == (const float4*)out->normal.data && fill->cols == W && fill->rows == H &&
-                    (!fill->dense_flag || (fill->tickets && fill->sample_mask && W <= 2048 && H <= 2048)) && fill->mirror_words <= 256,
+                    (!fill->dense_cnt || (fill->sample_mask && W <= 2048 && H <= 2048)) && fill->mirror_words <= 256,
                 "fill-in arguments do not describe this prediction");
     hipLaunchKernelGGL((k_splat_resolve<false, true>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)out->image.data,
                        (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, *fill);

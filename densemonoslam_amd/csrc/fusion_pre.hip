@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BX* BY) void k_fill_in(FillArgs a) {
   if (a.dense_flag && (int)blockIdx.y == a.rows_blocks) {  // the extra block row: block 0 of it does the test, the others idle
     if (blockIdx.x != 0) return;
     __shared__ int s_sum[BX * BY / 64];
-    fill_dense_test<BX * BY, false>(a, threadIdx.y * blockDim.x + threadIdx.x, s_sum);
+    fill_dense_test<BX * BY>(a, threadIdx.y * blockDim.x + threadIdx.x, s_sum);
     return;
   }
   if (a.mirror_words > 0 && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -234,7 +234,7 @@ int fill_args(const dms_predict_out* ex, const dms_image2d* depth, const dms_ima
   a.mirror_words = (mirror_src && mirror_dst) ? mirror_bytes / 4 : 0;
   a.dense_flag = dense_flag;
   a.rows_blocks = 0;
-  a.tickets = nullptr;
+  a.dense_cnt = nullptr;
   a.sample_mask = nullptr;
   *res = a;
   return DMS_OK;

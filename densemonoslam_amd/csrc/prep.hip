@@ -4,6 +4,7 @@
 // 16-byte accesses per lane); blocks are 64×4 so a 256-thread block spans 4 rows.
 #include "common.hpp"
 #include "pyr_body.hpp"
+#include "fill.hpp"
 
 namespace dms {
 
@@ -293,9 +294,18 @@ struct ModelSrc {
   const float4* nB;
   const uchar4* iB;
   const int* flag;   // device flag: 1 = use the fill-in maps
+  // instead of the flag: the 16 counters of the prediction's resolve pass (fill.hpp) and the sample count; the decision
+  // taken from them is also stored to *flag_out (block 0), for the result block and later readers of the flag
+  const unsigned* dense_cnt;
+  int dense_samples;
+  int* flag_out;
   int force_b_img;   // frameToFrameRGB: always the fill-in image
   const float* pose16;  // model pose for transformMaps; null = leave the maps in the camera frame (live side, initICP from maps)
 };
+
+__device__ __forceinline__ bool model_use_b(const ModelSrc& m) {
+  return (m.dense_cnt ? dense_from_counters(m.dense_cnt, m.dense_samples) : *m.flag) != 0;
+}
 
 struct Pose34 {
   M33 R;
@@ -347,7 +357,7 @@ __device__ __forceinline__ void model_level0_body(int bx, int by, const ModelSrc
   const int x = bx * blockDim.x + threadIdx.x;
   const int y = by * blockDim.y + threadIdx.y;
   if (x >= cols || y >= rows) return;
-  const bool useB = *m.flag != 0;
+  const bool useB = model_use_b(m);
   const size_t i = (size_t)y * cols + x;
   const float4 v = useB ? m.vB[i] : m.vA[i];
   const float4 q = useB ? m.nB[i] : m.nA[i];
@@ -383,7 +393,7 @@ __device__ __forceinline__ void model_levels12_body(int bx, int by, const ModelS
   const int x2 = bx * 16 + (lane >> 2);
   const int y2 = by * blockDim.y + threadIdx.y;
   const int x1 = 2 * x2 + (k & 1), y1 = 2 * y2 + (k >> 1);
-  const bool useB = *m.flag != 0;
+  const bool useB = model_use_b(m);
   const float4* vs = useB ? m.vB : m.vA;
   const float4* ns = useB ? m.nB : m.nA;
   const Pose34 P = load_pose34(m.pose16);
@@ -424,7 +434,7 @@ __device__ __forceinline__ void model_pyr_step1_body(int bx, int by, const Model
   constexpr int TW = 2 * BX + 3, TH = 2 * BY + 3;
   __shared__ float s_d[TH][TW + 1];
   __shared__ unsigned char s_c[TH][TW + 1];
-  const bool useB = *m.flag != 0;
+  const bool useB = model_use_b(m);
   const float4* vs = useB ? m.vB : m.vA;
   const uchar4* is = (useB || m.force_b_img) ? m.iB : m.iA;
   const int sx0 = 2 * (bx * BX) - 2, sy0 = 2 * (by * BY) - 2;
@@ -481,6 +491,7 @@ __global__ void k_model_levels012(ModelSrc m, int g0x, int g0y, int g12x, int ro
   // (the two small groups come first in the grid: their threads carry 32 / 50 dependent-latency loads each and would
   // otherwise start only when the 1 200 level-0 blocks have been handed out — the launch's tail)
   const int b = blockIdx.x;
+  if (m.dense_cnt && b == 0 && threadIdx.x == 0 && threadIdx.y == 0) *m.flag_out = model_use_b(m) ? 1 : 0;
   const int nb0 = g0x * g0y, nb12 = g12x * g12y, nbs = (int)gridDim.x - nb0 - nb12;
   if (b < nb12) {
     model_levels12_body(b % g12x, b / g12x, m, cols0, rows1, cols1, rows2, cols2, v1, n1, v2, n2);
@@ -694,7 +705,8 @@ int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
 
 int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void* vB, const void* nB, const void* iB, const int* flag_dev,
                       int force_b_img, const float* pose16_dev, dms_image2d* vmaps, dms_image2d* nmaps, dms_image2d* depths,
-                      dms_image2d* images, float cutOff, hipStream_t s, bool skip_last_step) {
+                      dms_image2d* images, float cutOff, hipStream_t s, bool skip_last_step, const unsigned* dense_cnt, int dense_samples,
+                      int* flag_out) {
   DMS_REQUIRE(vA && nA && iA && vB && nB && iB && flag_dev && vmaps && nmaps && depths && images, "null argument");
   ModelSrc m;
   m.vA = (const float4*)vA;
@@ -704,6 +716,10 @@ int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void
   m.nB = (const float4*)nB;
   m.iB = (const uchar4*)iB;
   m.flag = flag_dev;
+  m.dense_cnt = dense_cnt;
+  m.dense_samples = dense_samples;
+  m.flag_out = flag_out;
+  DMS_REQUIRE(!dense_cnt || (flag_out && dense_samples > 0), "dense counters need a flag destination");
   m.force_b_img = force_b_img;
   m.pose16 = pose16_dev;
   const int rows0 = vmaps[0].rows / 3, cols0 = vmaps[0].cols;

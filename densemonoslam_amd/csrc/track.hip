@@ -97,6 +97,7 @@ struct dms_odometry {
   int persist_target = 160;   // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
   // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
   bool deferred_pyr = false;
+  unsigned* dense_cnt_zero = nullptr;  // the frame step's 16 dense counters (fill.hpp), read by the model pyramid kernel: zeroed by the next track call's first kernel
   int inject_timeouts = 0;    // dms_odometry_inject_timeout: calls left that start with the timeout flag set
   int width, height;
   float cx, cy, fx, fy, distThres, angleThres;
@@ -199,7 +200,8 @@ struct Prior {
 // block `b` of `nb` blocks of `nt` threads (t = linear thread id)
 __device__ __forceinline__ void track_init_body(int b, int nb, int t, int nt, TrackState* st, Prior prior, const float* __restrict__ prior_pose16,
                                                 float fx, float fy, float cx, float cy, int so3, int first_level,
-                                                unsigned long long* sync_words, int n_sync, int inject_timeout) {
+                                                unsigned long long* sync_words, int n_sync, int inject_timeout, unsigned* zero16) {
+  if (zero16 && b == 0 && t < 16) zero16[t * 16] = 0u;  // (the frame step's dense counters: their reader ran before this launch)
   // barrier and all-reduce words of the resident kernels of this call: zero before any of them is launched
   // (n_sync counts 16-byte pairs; the grid shares the work, block 0 also sets up the state)
   {
@@ -244,9 +246,9 @@ __device__ __forceinline__ void track_init_body(int b, int nb, int t, int nt, Tr
 }
 
 __global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
-                             int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout) {
+                             int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout, unsigned* zero16) {
   track_init_body(blockIdx.x, gridDim.x, threadIdx.x, blockDim.x, st, prior, prior_pose16, fx, fy, cx, cy, so3, first_level, sync_words, n_sync,
-                  inject_timeout);
+                  inject_timeout, zero16);
 }
 
 // The same with the last step of the model-side depth / intensity pyramid (prep.hip k_model_pyr_step, deferred by
@@ -254,7 +256,7 @@ __global__ void k_track_init(TrackState* st, Prior prior, const float* __restric
 // 64 x 4 thread blocks; the first `ni` blocks are k_track_init's, the next gx * gy the pyramid step's.
 __global__ __launch_bounds__(256) void k_track_init_pyr(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy,
                                                         float cx, float cy, int so3, int first_level, unsigned long long* sync_words,
-                                                        int n_sync, int inject_timeout, int gx, int gy, int ni, View<const float> dsrc,
+                                                        int n_sync, int inject_timeout, unsigned* zero16, int gx, int gy, int ni, View<const float> dsrc,
                                                         View<float> ddst, View<const unsigned char> isrc, View<unsigned char> idst) {
   const int b = blockIdx.x;
   if (b >= ni) {
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void k_track_init_pyr(TrackState* st, Prior pr
   }
   // (first in the grid: block 0's one-lane state set-up is the longest dependency chain of the launch)
   track_init_body(b, ni, threadIdx.y * 64 + threadIdx.x, 256, st, prior, prior_pose16, fx, fy, cx, cy, so3, first_level, sync_words, n_sync,
-                  inject_timeout);
+                  inject_timeout, zero16);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2440,16 +2442,18 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     // (o->sync and o->ar are adjacent in the arena: one zeroing sweep covers both; resident mode only)
     const int zero_pairs = o->resident ? (int)(((char*)(o->ar + (size_t)kArReductions * kArWords) - (char*)o->sync) / 16) : 0;
     const int ni = o->resident ? 16 : 1;
+    unsigned* zero16 = o->dense_cnt_zero;
+    o->dense_cnt_zero = nullptr;
     if (o->deferred_pyr) {
       o->deferred_pyr = false;
       dms_image2d d1 = o->lastDepth[1].img(), d2 = o->lastDepth[2].img(), i1 = o->lastImage[1].img(), i2 = o->lastImage[2].img();
       const int gx = (d2.cols + 63) / 64, gy = (d2.rows + 3) / 4;
       hipLaunchKernelGGL(k_track_init_pyr, dim3(gx * gy + ni), dim3(64, 4), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy,
-                         so3 ? 1 : 0, first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, gx, gy, ni, view<const float>(&d1),
+                         so3 ? 1 : 0, first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, zero16, gx, gy, ni, view<const float>(&d1),
                          view<float>(&d2), view<const unsigned char>(&i1), view<unsigned char>(&i2));
     } else {
       hipLaunchKernelGGL(k_track_init, dim3(ni), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
-                         first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0);
+                         first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, zero16);
     }
     DMS_CHECK_LAUNCH();
     if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
@@ -2870,7 +2874,7 @@ int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dm
 // (k_track_init_pyr), which the caller must enqueue on the same stream before anything else reads level 2 of lastDepth / lastImage
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
-                             int defer_last_step) {
+                             int defer_last_step, unsigned* dense_cnt, int dense_samples) {
   dms_image2d v[DMS_NUM_PYRS], n[DMS_NUM_PYRS], d[DMS_NUM_PYRS], im[DMS_NUM_PYRS];
   for (int i = 0; i < DMS_NUM_PYRS; ++i) {
     v[i] = o->vmaps_g_prev[i].img();
@@ -2879,7 +2883,12 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
     im[i] = o->lastImage[i].img();
   }
   o->deferred_pyr = defer_last_step != 0;
-  return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s, o->deferred_pyr);
+  // dense_cnt: the source choice comes from the 16 counters of the prediction's resolve pass instead of *flag_dev, which then
+  // receives the decision; the next odometry_track_enqueue on this object zeroes the counters
+  DMS_REQUIRE(!dense_cnt || defer_last_step, "dense counters are zeroed by the track call that takes the deferred pyramid step");
+  o->dense_cnt_zero = dense_cnt;
+  return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s, o->deferred_pyr, dense_cnt,
+                           dense_samples, const_cast<int*>(flag_dev));
 }
 
 // initICP(vertex map, normal map) + initRGB(image) of the live side in the fused form (RGBDOdometry.cpp:118-137,
@@ -2942,7 +2951,7 @@ int dms_odometry_initModelFused(dms_odometry* o, const void* vertA, const void* 
                                 const void* normB, const void* rgbaB, const int* use_b_dev, int force_b_image,
                                 const float* modelPose16_dev, dms_stream s) {
   DMS_REQUIRE(o, "null odometry");
-  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s, 0);
+  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s, 0, nullptr, 0);
 }
 
 int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {
