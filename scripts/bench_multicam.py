@@ -34,7 +34,7 @@ def main():
             rb = [capi.DeviceBuffer(W * H * 3).upload(np.ascontiguousarray(f[1], np.uint8)) for f in frames]
             db = [capi.DeviceBuffer(W * H * 2).upload(np.ascontiguousarray(f[0], np.uint16)) for f in frames]
             bufs.append((rb, db))
-            cams.append(fusion.ElasticFusion(W, H, K, model_capacity=4_000_000, timeIdx=c))
+            cams.append(fusion.ElasticFusion(W, H, K, model_capacity=4_000_000, timeIdx=c, num_sensors=max(3, c + 1)))
             streams.append(capi.create_stream())
 
         def idx(i):
