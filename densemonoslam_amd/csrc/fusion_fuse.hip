@@ -73,15 +73,17 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
                                                         float4* __restrict__ slot_nrm, unsigned* __restrict__ slot_best,
                                                         unsigned char* __restrict__ slot_flag, unsigned* __restrict__ winner, int slot_w) {
   // candidate (i, j) -> pixel (2i + p, 2j + p), p = time % 2; slot = i * slot_h + j (column-major)
-  // one 8 x 8 tile of candidates per wave, lanes running down the column first: the column-major index
-  // maps and the row-major live images are then both read in runs of 8 neighbouring candidates
-  // (8 cache lines per access) instead of one of the two in 64 separate lines
+  // Four lanes per candidate: lane `sub` of a quad evaluates the (up to four) taps of x slot `sub` of the association
+  // window, the quad then agrees on the winner by shuffles and its lane 0 writes the slot.  (One lane per candidate —
+  // 76 800 threads, 48 dependent-latency gathers each — left the kernel latency-bound at about one wave per SIMD: 15.8 us,
+  // of which the evaluation itself was 2.)  One 2 x 8 tile of candidates per wave, quads running down the column first:
+  // the column-major index maps and the row-major live images are both read in runs of 8 neighbouring candidates.
   const int tiles_j = (a.slot_h + 7) >> 3;
   const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int ti = t / tiles_j, tj = t - ti * tiles_j;
-  const int lane = threadIdx.x & 63;
-  const int i = ti * 8 + (lane >> 3);
-  const int j = tj * 8 + (lane & 7);
+  const int lane = threadIdx.x & 63, quad = lane >> 2, sub = lane & 3;
+  const int i = ti * 2 + (quad >> 3);
+  const int j = tj * 8 + (quad & 7);
   if (i >= slot_w || j >= a.slot_h) return;
   const int slot = i * a.slot_h + j;
   const int par = ((a.time % 2) + 2) % 2;
@@ -135,58 +137,71 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
       // `counter` only matters as > 0, so each distinct texel is visited once, in tap order
       const AxisTaps tx_ = axis_taps(x_lo, x_hi, indexXStep, colsf, a.cols);
       const AxisTaps ty_ = axis_taps(y_lo, y_hi, indexYStep, rowsf, a.rows);
-      // batched fetch of the (at most 4 x 4) distinct texels, evaluated in the original tap order:
-      // 16 ids in one round trip, then vertex + normal of 8 texels at a time
-      const int txs[4] = {tx_.t0, tx_.t1, tx_.t2, tx_.t3}, mxs[4] = {tx_.m0, tx_.m1, tx_.m2, tx_.m3};
+      // Sequentially (data.vert:118-160) a tap is accepted when it passes the depth and normal tests and lies strictly closer
+      // to the ray than every tap accepted before it: the winner is the closest tap of those that pass the two tests, the
+      // earliest in tap order (x outer, y inner) among equals — which can be evaluated per tap and reduced.
+      const int txs_s = sub == 0 ? tx_.t0 : sub == 1 ? tx_.t1 : sub == 2 ? tx_.t2 : tx_.t3;
+      const int mxs_s = sub == 0 ? tx_.m0 : sub == 1 ? tx_.m1 : sub == 2 ? tx_.m2 : tx_.m3;
       const int tys[4] = {ty_.t0, ty_.t1, ty_.t2, ty_.t3}, mys[4] = {ty_.m0, ty_.m1, ty_.m2, ty_.m3};
-      size_t q[16];
-      bool used[16];
-      unsigned cur[16];
+      size_t q[4];
+      bool used[4];
+      unsigned cur[4];
+      float4 vcs[4], nrs[4];
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+      for (int jj = 0; jj < 4; ++jj) {
+        const bool u = mxs_s != 0 && mys[jj] != 0;
+        const int ux = u ? txs_s : 0, uy = u ? tys[jj] : 0;
+        used[jj] = u;
+        q[jj] = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
+      }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const bool u = mxs[ii] != 0 && mys[jj] != 0;
-          const int ux = u ? txs[ii] : 0, uy = u ? tys[jj] : 0;
-          used[ii * 4 + jj] = u;
-          q[ii * 4 + jj] = a.transposed ? (size_t)ux * a.rows + uy : (size_t)uy * a.cols + ux;
-        }
+      for (int jj = 0; jj < 4; ++jj) {
+        cur[jj] = a.index[q[jj]];
+        vcs[jj] = a.vertConf[q[jj]];
+        nrs[jj] = a.normRad[q[jj]];
+      }
+      int order = 64;  // tap order of this lane's winner (sub * 4 + jj); 64 = none
 #pragma unroll
-      for (int k = 0; k < 16; ++k) cur[k] = a.index[q[k]];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float4 vcs[8], nrs[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          vcs[k] = a.vertConf[q[h * 8 + k]];
-          nrs[k] = a.normRad[q[h * 8 + k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const unsigned current = cur[h * 8 + k];
-          if (used[h * 8 + k] && current > 0u) {
-            const float4 vc = vcs[k];
-            if (fabsf((vc.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
-              const float dist = length3(cross3(ray, mk3(vc.x, vc.y, vc.z))) / ray_len;
-              const float4 nr = nrs[k];
-              if (dist < bestDist && (fabsf(nr.z) < 0.75f || fabsf(angle_between(mk3(nr.x, nr.y, nr.z), vNormLocal)) < 0.5f)) {
-                counter++;
-                bestDist = dist;
-                best = current;
-              }
+      for (int jj = 0; jj < 4; ++jj) {
+        const unsigned current = cur[jj];
+        if (used[jj] && current > 0u) {
+          const float4 vc = vcs[jj];
+          if (fabsf((vc.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
+            const float dist = length3(cross3(ray, mk3(vc.x, vc.y, vc.z))) / ray_len;
+            const float4 nr = nrs[jj];
+            if (dist < bestDist && (fabsf(nr.z) < 0.75f || fabsf(angle_between(mk3(nr.x, nr.y, nr.z), vNormLocal)) < 0.5f)) {
+              counter++;
+              bestDist = dist;
+              best = current;
+              order = sub * 4 + jj;
             }
           }
         }
       }
+      // the quad's winner: smaller distance, then earlier tap (a lane without a winner holds distance 1000, order 64)
+#pragma unroll
+      for (int m = 1; m < 4; m <<= 1) {
+        const float od = __shfl_xor(bestDist, m, 64);
+        const int oo = __shfl_xor(order, m, 64);
+        const unsigned ob = __shfl_xor(best, m, 64);
+        counter += __shfl_xor(counter, m, 64);
+        if (od < bestDist || (od == bestDist && oo < order)) {
+          bestDist = od;
+          order = oo;
+          best = ob;
+        }
+      }
       flag = counter > 0 ? 1 : 2;
-      slot_pos[slot] = make_float4(vPos.x, vPos.y, vPos.z, conf);
-      slot_col[slot] = make_float4(encode_color_bytes(c.x, c.y, c.z), 0.f, a.timef, flag == 1 ? -1.f : -2.f);
-      slot_nrm[slot] = make_float4(nG.x, nG.y, nG.z, rad);
-      slot_best[slot] = best;
-      if (flag == 1) atomicMin(winner + best, (unsigned)slot);
+      if (sub == 0) {
+        slot_pos[slot] = make_float4(vPos.x, vPos.y, vPos.z, conf);
+        slot_col[slot] = make_float4(encode_color_bytes(c.x, c.y, c.z), 0.f, a.timef, flag == 1 ? -1.f : -2.f);
+        slot_nrm[slot] = make_float4(nG.x, nG.y, nG.z, rad);
+        slot_best[slot] = best;
+        if (flag == 1) atomicMin(winner + best, (unsigned)slot);
+      }
     }
   }
-  slot_flag[slot] = flag;
+  if (sub == 0) slot_flag[slot] = flag;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -672,7 +687,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   a.timeIdx = timeIdx;
   a.transposed = transposed ? 1 : 0;
   const int slot_w = (W + 1) / 2;
-  const int tiles = ((m->slot_h + 7) / 8) * ((slot_w + 7) / 8);
+  const int tiles = ((m->slot_h + 7) / 8) * ((slot_w + 1) / 2);  // 2 x 8 candidates per wave, four lanes each
   dim3 b(256), g((tiles + 3) / 4);
   hipLaunchKernelGGL(k_fuse_associate, g, b, 0, s, a, m->slot_pos, m->slot_col, m->slot_nrm, m->slot_best, m->slot_flag, m->winner, slot_w);
   DMS_CHECK_LAUNCH();
