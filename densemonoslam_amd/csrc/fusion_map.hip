@@ -868,7 +868,7 @@ template <bool DUAL>
 __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes sp, size_t cap, const unsigned* __restrict__ d_count,
                                                        unsigned long long* __restrict__ zbuf, SplatSecond b2,
                                                        unsigned long long* __restrict__ zbuf2) {
-  __shared__ float s_par[7][256];   // pos.xyz, nrm.xyz, rad
+  __shared__ float s_par[10][256];  // pos.xyz, nrm.xyz, rad, window x / y of the centre, squared reach (below)
   __shared__ int s_box[4][256];     // x0, width, y0, cull survivors (DUAL)
   __shared__ unsigned s_off[257];   // exclusive prefix of the row counts
   __shared__ unsigned s_w[4];
@@ -904,6 +904,26 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
         int x0, x1, y0, y1;
         sprite_range(s.xw, s.size, a.cols, x0, x1);
         sprite_range(s.yw, s.size, a.rows, y0, y1);
+        // The sprite is the square around four points at sqrt(2) r along the tangent axes; the disc test passes on about
+        // 40 % of its fragments.  A fragment can only pass if its ray comes within r of the centre P = Z (xc, yc, 1):
+        // the distance of P from the ray along v = (x, y, 1) is Z |(xc, yc, 1) x v| / |v| >= Z rho / |v|, with
+        // rho^2 = (x - xc)^2 + (y - yc)^2 — the fragment's offset from the centre in normalised image coordinates —
+        // and |v|^2 <= G2 = 1 + (|xc| + h)^2 + (|yc| + h)^2 inside the sprite (half size h).  So rho > r sqrt(G2) / Z
+        // rules a fragment out; with 2 % (and 0.02 pixel) added, far more than the rounding of the fragment test itself, the
+        // rows and the columns of each row are cut to that circle before any fragment is evaluated.
+        float reach = 3.0e18f;  // normalised units; no cut when the bound cannot be formed
+        {
+          const float ifx = 1.f / a.fx, ify = 1.f / a.fy;
+          const float h = (0.5f * fmaxf(s.size, 1.f) + 1.f) * fmaxf(ifx, ify);
+          const float xc = fabsf((s.xw - a.cx) * ifx) + h, yc = fabsf((s.yw - a.cy) * ify) + h;
+          const float g2 = 1.f + xc * xc + yc * yc;
+          const float rn = (s.rad * sqrtf(g2) / s.pos.z) * 1.02f + 0.02f * fmaxf(ifx, ify);
+          if (s.pos.z > 0.f && rn == rn && rn < 3.0e18f) reach = rn;
+          const float ry = fminf(reach * a.fy, 1.0e9f);
+          const int c0 = (int)ceilf(fmaxf(s.yw - ry - 0.5f, -1.0e9f)), c1 = (int)floorf(fminf(s.yw + ry - 0.5f, 1.0e9f));  // |py + 0.5 - yw| <= ry
+          y0 = max(y0, c0);
+          y1 = min(y1, c1);
+        }
         if (x1 >= x0 && y1 >= y0) {
           rows_here = y1 - y0 + 1;
           s_par[0][t] = s.pos.x;
@@ -913,6 +933,9 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
           s_par[4][t] = s.nrm.y;
           s_par[5][t] = s.nrm.z;
           s_par[6][t] = s.rad;
+          s_par[7][t] = s.xw;
+          s_par[8][t] = s.yw;
+          s_par[9][t] = reach * reach;
           s_box[0][t] = x0;
           s_box[1][t] = x1 - x0 + 1;
           s_box[2][t] = y0;
@@ -954,7 +977,14 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
       const int py = s_box[2][j] + (int)(u - s_off[j]);
       const unsigned long long id = (unsigned long long)(base + (unsigned)j);
       const int pass = DUAL ? s_box[3][j] : 1;
-      for (int px = x0; px < x0 + w; ++px) {
+      // columns of this row inside the surfel's reach (see the vertex stage)
+      const float dyn = (((float)py + 0.5f) - s_par[8][j]) * (1.f / a.fy);
+      const float left = s_par[9][j] - dyn * dyn;
+      if (left < 0.f) continue;
+      const float rx = fminf(sqrtf(left) * a.fx, 1.0e9f), xwc = s_par[7][j];
+      const int xa = max(x0, (int)ceilf(fmaxf(xwc - rx - 0.5f, -1.0e9f)));  // |px + 0.5 - xw| <= rx
+      const int xb = min(x0 + w - 1, (int)floorf(fminf(xwc + rx - 0.5f, 1.0e9f)));
+      for (int px = xa; px <= xb; ++px) {
         f3 c;
         float zw;
         if (!splat_fragment(a, s, px, py, c, zw)) continue;
