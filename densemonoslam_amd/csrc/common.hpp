@@ -168,6 +168,50 @@ __device__ __forceinline__ void wave_sum_all_to_lane63(float (&v)[NV]) {
   for (int k = 0; k < NV; ++k) v[k] += dpp_mov<0x143, 0xc>(v[k]);
 }
 
+// Sum of NV <= 32 per-lane values over the wave with the values spread over the lanes as the tree narrows: at every step
+// the two partner lanes split their values — each keeps the sum of one half and hands the other half over — so a step
+// costs one exchange per OUTPUT value (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges for 32 values) instead of one per value
+// (6 x NV for the butterfly above: 261 instructions for the 29 sums of a Gauss-Newton pass, a third of the pass).
+// Partners: lane ^ 1, ^ 2 (DPP quad permutes), ^ 4, ^ 8, ^ 16 (ds_swizzle, no memory), ^ 32 (one permute).  Returns, in
+// lanes k and k + 32, the sum of value k over all 64 lanes (k < 32; zero for k >= NV).  Fixed order: deterministic.
+template <int PATTERN>
+__device__ __forceinline__ float swizzle_f(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN));
+}
+template <int NV>
+__device__ __forceinline__ float wave_sum_transpose(const float (&v)[NV]) {
+  static_assert(NV <= 32, "at most 32 values");
+  const int lane = threadIdx.x & (kWave - 1);
+  float a[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) a[k] = k < NV ? v[k] : 0.f;
+  float b[16], c[8], d[4], e[2];
+  {
+    const bool hi = (lane & 1) != 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = (hi ? a[2 * k + 1] : a[2 * k]) + dpp_mov<0xB1>(hi ? a[2 * k] : a[2 * k + 1]);
+  }
+  {
+    const bool hi = (lane & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = (hi ? b[2 * k + 1] : b[2 * k]) + dpp_mov<0x4E>(hi ? b[2 * k] : b[2 * k + 1]);
+  }
+  {
+    const bool hi = (lane & 4) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = (hi ? c[2 * k + 1] : c[2 * k]) + swizzle_f<0x101F>(hi ? c[2 * k] : c[2 * k + 1]);
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) e[k] = (hi ? d[2 * k + 1] : d[2 * k]) + swizzle_f<0x201F>(hi ? d[2 * k] : d[2 * k + 1]);
+  }
+  const bool hi = (lane & 16) != 0;
+  float r = (hi ? e[1] : e[0]) + swizzle_f<0x401F>(hi ? e[0] : e[1]);
+  r += __shfl_xor(r, 32, 64);
+  return r;
+}
+
 // fp64 variant: the two halves of the double travel through the same DPP controls
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_mov_d(double v) {
@@ -240,11 +284,8 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* out, i
   __shared__ float lds[kBlock / kWave][NV];
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x >> 6;
-  wave_sum_all_to_lane63<NV>(v);
-  if (lane == kWave - 1) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) lds[wid][k] = v[k];
-  }
+  const float tot = wave_sum_transpose<NV>(v);
+  if (lane < NV) lds[wid][lane] = tot;
   __syncthreads();
   if (threadIdx.x < NV) {
     const int k = threadIdx.x;

@@ -1095,11 +1095,8 @@ __device__ __forceinline__ float pblock_reduce(float (&v)[NV], float (*s_red)[32
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x >> 6;
   __syncthreads();  // s_red may still be read from the previous use
-  wave_sum_all_to_lane63<NV>(v);
-  if (lane == kWave - 1) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) s_red[wid][k] = v[k];
-  }
+  const float tot = wave_sum_transpose<NV>(v);
+  if (lane < NV) s_red[wid][lane] = tot;
   __syncthreads();
   float r = 0.f;
   if (threadIdx.x < NV * kPWaves) r = (float)row8_sum_d((double)s_red[threadIdx.x & (kPWaves - 1)][threadIdx.x >> 3]);
@@ -1354,11 +1351,8 @@ __device__ __forceinline__ double pblock_reduce_w0(float (&v)[NV], float (*s_red
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x >> 6;
   __syncthreads();  // s_red may still be read from the previous use
-  wave_sum_all_to_lane63<NV>(v);
-  if (lane == kWave - 1) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) s_red[wid][k] = v[k];
-  }
+  const float tot = wave_sum_transpose<NV>(v);
+  if (lane < NV) s_red[wid][lane] = tot;
   __syncthreads();
   double r = 0.0;
   if (threadIdx.x < NV) {
