@@ -324,8 +324,11 @@ __device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms
   if (p.sigma == -1.f) w = 1.f;
   row[6] = -w * c.diff;
   const f3 pt = in.pt;
-  // reference: float invz = 1.0 / cloudPoint.z  (double division rounded to float)
-  const float invz = (float)(1.0 / (double)pt.z);
+  // reference: float invz = 1.0 / cloudPoint.z  (double division rounded to float).  Rounding the correctly rounded
+  // double quotient of two floats to float gives the correctly rounded float quotient (double rounding is innocuous for
+  // division when the wider format has at least 2 * 24 + 2 bits): the IEEE float division is the same value, a third of
+  // the instructions.
+  const float invz = 1.0f / pt.z;
   const float dI_dx_val = (w * p.sobelScale) * (float)in.gx;
   const float dI_dy_val = (w * p.sobelScale) * (float)in.gy;
   const float v0 = (dI_dx_val * p.fx) * invz;
