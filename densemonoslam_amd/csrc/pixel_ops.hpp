@@ -47,13 +47,13 @@ struct IcpParams {
 
 struct MapPtrs {  // stacked-plane maps: plane stride = rows * pitch
   const float* vcurr;
-  size_t vcurr_pitch;
+  unsigned vcurr_pitch;
   const float* ncurr;
-  size_t ncurr_pitch;
+  unsigned ncurr_pitch;
   const float* vprev;
-  size_t vprev_pitch;
+  unsigned vprev_pitch;
   const float* nprev;
-  size_t nprev_pitch;
+  unsigned nprev_pitch;
 };
 
 __device__ __forceinline__ const float* prow(const float* base, size_t pitch, int y) {
@@ -167,19 +167,19 @@ struct RgbResParams {
 };
 struct RgbResPtrs {
   const short* dIdx;
-  size_t dI_pitch;
+  unsigned dI_pitch;
   const short* dIdy;
   const float* lastDepth;
-  size_t lastDepth_pitch;
+  unsigned lastDepth_pitch;
   const float* nextDepth;
-  size_t nextDepth_pitch;
+  unsigned nextDepth_pitch;
   const unsigned char* lastImage;
-  size_t lastImage_pitch;
+  unsigned lastImage_pitch;
   const unsigned char* nextImage;
-  size_t nextImage_pitch;
+  unsigned nextImage_pitch;
   // optional precomputed pose-independent gate (k_rgb_gate); null = evaluate window and gradient here
   const unsigned char* gate;
-  size_t gate_pitch;
+  unsigned gate_pitch;
 };
 
 template <typename T>

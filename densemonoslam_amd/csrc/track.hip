@@ -458,7 +458,7 @@ struct GnArgs {
   RgbResPtrs rgb;
   Corr8* corres;
   const float* cloud;
-  size_t cloud_pitch;
+  unsigned cloud_pitch;
   float minScale, maxDepthDelta, sobelScale;
   int cols, rows, level;
 };
