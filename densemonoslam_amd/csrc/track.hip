@@ -156,36 +156,65 @@ __device__ inline void level_K(float fx, float fy, float cx, float cy, int level
   K[8] = 1.0;
 }
 
-// RGBDOdometry.cpp:321-332
+// K = [fx 0 cx; 0 fy cy; 0 0 1] (level_K) throughout: K^-1, K R and K R K^-1 are written out in closed form instead of a
+// general 3x3 inverse and two 3x3 products (the same values to ~1e-16 before they are rounded to float; the Gauss-Newton
+// levels do the same in gn_params_local_k).  RGBDOdometry.cpp:321-332
 __device__ inline void so3_params(TrackState* st, const double* K) {
-  double Kinv[9], t[9], H[9];
-  sm::inv3<double>(K, Kinv);
-  sm::mul3<double>(K, st->resultR, t);
-  sm::mul3<double>(t, Kinv, H);
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const double ifx = 1.0 / fx, ify = 1.0 / fy;
+  const double* R = st->resultR;
+  double t[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t[0 * 3 + j] = fx * R[0 * 3 + j] + cx * R[2 * 3 + j];
+    t[1 * 3 + j] = fy * R[1 * 3 + j] + cy * R[2 * 3 + j];
+    t[2 * 3 + j] = R[2 * 3 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double h0 = t[i * 3 + 0] * ifx, h1 = t[i * 3 + 1] * ify;
+    st->imageBasis[i * 3 + 0] = (float)h0;
+    st->imageBasis[i * 3 + 1] = (float)h1;
+    st->imageBasis[i * 3 + 2] = (float)(t[i * 3 + 2] - h0 * cx - h1 * cy);
+  }
+  const double kinv[9] = {ifx, 0.0, -(cx * ifx), 0.0, ify, -(cy * ify), 0.0, 0.0, 1.0};
+#pragma unroll
   for (int i = 0; i < 9; ++i) {
-    st->imageBasis[i] = (float)H[i];
-    st->kinv[i] = (float)Kinv[i];
+    st->kinv[i] = (float)kinv[i];
     st->krlr[i] = (float)t[i];
   }
 }
 
 // RGBDOdometry.cpp:427-437.  `resultRt` is passed in registers: re-reading it from the state block
-// right after storing it costs a full memory round trip on the solving lane.
+// right after storing it costs a full memory round trip on the solving lane.  resultRt is a product of rigid transforms:
+// its inverse is taken in the isometry form [R^T | -R^T t] (as gn_params_local_k does), not by a general 4x4 inverse.
 __device__ inline void gn_params_from(TrackState* st, const double* resultRt, const double* K) {
-  double Rt[16], R[9], Kinv[9], t[9], H[9];
-  sm::inv4(resultRt, Rt);
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const double ifx = 1.0 / fx, ify = 1.0 / fy;
+  double Ri[9], ti[3];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rt[i * 4 + j];
-  sm::inv3<double>(K, Kinv);
-  sm::mul3<double>(K, R, t);
-  sm::mul3<double>(t, Kinv, H);
-  for (int i = 0; i < 9; ++i) st->krkinv[i] = (float)H[i];
-  const double tv[3] = {Rt[3], Rt[7], Rt[11]};
-  double kt[3];
-  sm::mul3v<double>(K, tv, kt);
-  st->kt[0] = (float)kt[0];
-  st->kt[1] = (float)kt[1];
-  st->kt[2] = (float)kt[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = resultRt[j * 4 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ti[i] = -(Ri[i * 3 + 0] * resultRt[3] + Ri[i * 3 + 1] * resultRt[7] + Ri[i * 3 + 2] * resultRt[11]);
+  double M[9];  // K * Ri
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    M[0 * 3 + j] = fx * Ri[0 * 3 + j] + cx * Ri[2 * 3 + j];
+    M[1 * 3 + j] = fy * Ri[1 * 3 + j] + cy * Ri[2 * 3 + j];
+    M[2 * 3 + j] = Ri[2 * 3 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double h0 = M[i * 3 + 0] * ifx, h1 = M[i * 3 + 1] * ify;
+    st->krkinv[i * 3 + 0] = (float)h0;
+    st->krkinv[i * 3 + 1] = (float)h1;
+    st->krkinv[i * 3 + 2] = (float)(M[i * 3 + 2] - h0 * cx - h1 * cy);
+  }
+  st->kt[0] = (float)(fx * ti[0] + cx * ti[2]);
+  st->kt[1] = (float)(fy * ti[1] + cy * ti[2]);
+  st->kt[2] = (float)ti[2];
 }
 __device__ inline void gn_params(TrackState* st, const double* K) {
   double Rt[16];
