@@ -42,8 +42,25 @@ struct IcpParams {
   f3 tprev;
   float fx, fy, cx, cy;
   float distThres, angleThres;
+  // the two thresholds as bounds on the SQUARED quantities (sqrt_le_bound / sqrt_lt_bound below): the correctly rounded
+  // square root is monotone, so sqrtf(x) <= T and sqrtf(x) < T are each equivalent to x <= B for one float B — the loop
+  // compares the sums of squares and takes no square root (two of them per pixel and iteration, ~12 instructions each)
+  float dist2Le, sine2Le;
   int cols, rows;
 };
+
+// largest float x with sqrtf(x) <= T (strict = false) or sqrtf(x) < T (strict = true); -1 when no x >= 0 qualifies
+inline float sqrt_bound(float T, bool strict) {
+  auto ok = [&](float x) { return strict ? sqrtf(x) < T : sqrtf(x) <= T; };
+  if (!(T == T) || !ok(0.f)) return -1.f;
+  if (T > 1.8e19f) return strict ? 3.402823466e+38F : __builtin_inff();  // T * T overflows: every finite x qualifies (inf only without strict)
+  float x = (float)((double)T * (double)T);
+  while (ok(x)) x = nextafterf(x, __builtin_inff());
+  while (!ok(x)) x = nextafterf(x, 0.f);
+  return x;
+}
+inline float sqrt_le_bound(float T) { return sqrt_bound(T, false); }
+inline float sqrt_lt_bound(float T) { return sqrt_bound(T, true); }
 
 struct MapPtrs {  // stacked-plane maps: plane stride = rows * pitch
   const float* vcurr;
@@ -127,9 +144,10 @@ __device__ __forceinline__ bool icp_finish(const IcpParams& p, const IcpOwn& o, 
 #pragma unroll
   for (int i = 0; i < 7; ++i) row[i] = 0.f;
   const f3 ncurr_g = mult<FMA>(p.Rcurr, o.ncurr);
-  const float dist = norm3t<FMA>(c.vprev_g - r.vcurr_g);
-  const float sine = norm3t<FMA>(cross3t<FMA>(ncurr_g, c.nprev_g));
-  const bool found = r.ok && (sine < p.angleThres && dist <= p.distThres && !isnan(o.ncurr.x) && !isnan(c.nprev_g.x));
+  // dist = |vprev_g - vcurr_g| <= distThres, sine = |ncurr_g x nprev_g| < angleThres, on the squares (IcpParams)
+  const f3 dv = c.vprev_g - r.vcurr_g, cn = cross3t<FMA>(ncurr_g, c.nprev_g);
+  const float dist2 = dot3t<FMA>(dv, dv), sine2 = dot3t<FMA>(cn, cn);
+  const bool found = r.ok && (sine2 <= p.sine2Le && dist2 <= p.dist2Le && !isnan(o.ncurr.x) && !isnan(c.nprev_g.x));
   if (!found) return false;
   const f3 s_cp = mult<FMA>(p.Rprev_inv, r.vcurr_g - p.tprev);
   const f3 d_cp = mult<FMA>(p.Rprev_inv, c.vprev_g - p.tprev);

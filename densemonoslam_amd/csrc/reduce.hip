@@ -182,6 +182,8 @@ int icpStep(const dms_mat33* Rcurr, const dms_float3* tcurr, const dms_image2d* 
   p.cy = intr->cy;
   p.distThres = distThres;
   p.angleThres = angleThres;
+  p.dist2Le = sqrt_le_bound(distThres);
+  p.sine2Le = sqrt_lt_bound(angleThres);
   p.cols = vmap_curr->cols;
   p.rows = vmap_curr->rows / 3;
   const int N = p.cols * p.rows;

@@ -482,7 +482,7 @@ struct Corr8 {
 struct GnArgs {
   // ICP
   MapPtrs maps;
-  float fx, fy, cx, cy, distThres, angleThres;
+  float fx, fy, cx, cy, distThres, angleThres, dist2Le, sine2Le;  // (the last two: IcpParams)
   // RGB
   RgbResPtrs rgb;
   Corr8* corres;
@@ -525,6 +525,8 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, f
     ip.cy = a.cy;
     ip.distThres = a.distThres;
     ip.angleThres = a.angleThres;
+    ip.dist2Le = a.dist2Le;
+    ip.sine2Le = a.sine2Le;
     ip.cols = a.cols;
     ip.rows = a.rows;
   }
@@ -1518,6 +1520,8 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       ip.cy = a.cy;
       ip.distThres = a.distThres;
       ip.angleThres = a.angleThres;
+      ip.dist2Le = a.dist2Le;
+      ip.sine2Le = a.sine2Le;
       ip.cols = a.cols;
       ip.rows = a.rows;
     }
@@ -2543,6 +2547,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     a.cy = o->cy / div;
     a.distThres = o->distThres;
     a.angleThres = o->angleThres;
+    a.dist2Le = sqrt_le_bound(o->distThres);
+    a.sine2Le = sqrt_lt_bound(o->angleThres);
     a.rgb.dIdx = (const short*)o->nextdIdx[l].p;
     a.rgb.dIdy = (const short*)o->nextdIdy[l].p;
     a.rgb.dI_pitch = o->nextdIdx[l].pitch;
