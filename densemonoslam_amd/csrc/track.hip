@@ -130,6 +130,7 @@ struct dms_odometry {
   unsigned long long* sync = nullptr; // [kSyncWords] barrier words, zeroed by k_track_init
   unsigned long long* ar = nullptr;   // [kArReductions][kArWords] all-reduce words, zeroed by k_track_init
   bool atomic_reduce = true;          // false: record protocol everywhere (DMS_TRACK_REDUCE=records)
+  int ar_slack_shift = 2;             // integer all-reduce: the full sweep starts when all but nb >> shift blocks have arrived (DMS_AR_SLACK; 31 = wait for all)
   int ar_margin = dms::kArMargin;     // test hook (dms_odometry_debug_set "ar_margin"): a negative margin makes every partial sum overflow
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
@@ -1056,6 +1057,7 @@ struct LevelArgs {
   unsigned long long* ar;    // kArWords per iteration of this level, zero on entry (integer all-reduce)
   int use_ar;                // 0: record protocol in every iteration
   int ar_margin;             // headroom (bits) of the fixed-point scale over the previous totals (kArMargin)
+  int ar_slack_shift;        // see ar_wait
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
@@ -1329,9 +1331,12 @@ __device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin
 // `probe` >= 0: first only lanes 0-7 watch the 8 shard words of slot `probe` (the slot added last) and the full sweep
 // starts when those are complete — 58 lanes of every waiting block sweeping the words that are still receiving
 // atomics slows the arrivals down (measured in the level-0 kernel: 4.7 us per reduction against 1.9 stand-alone).
+// `slack`: the probe phase ends when all but `slack` blocks have arrived — the sweep that follows polls until every word is
+// complete, so the last arrivals are seen by the sweep itself instead of costing one more round trip after the probe
+// (the heavy polling then lasts only for the tail of the arrivals).
 template <int STRIDE>
 __device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, bool mine, int nb, long long& tot, int& ovf, int* timeout,
-                                        int probe = -1) {
+                                        int probe = -1, int slack = 0) {
   unsigned spins = 0;
   if (probe >= 0) {
     const int lane = threadIdx.x & 63;
@@ -1339,7 +1344,7 @@ __device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, b
       const unsigned long long q = lane < kArShards ? __hip_atomic_load(w + lane * STRIDE + probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       int arr = (int)(q >> 58);
       arr = row8_sum_i(arr);  // lanes 0-7: the 8 shards
-      if (__builtin_amdgcn_readlane(arr, 0) == nb) break;
+      if (__builtin_amdgcn_readlane(arr, 0) >= nb - slack) break;
       ++spins;
       if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;  // (reported below)
       __builtin_amdgcn_s_sleep(1);
@@ -1709,7 +1714,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
           const bool mine = (ICP && tid < kSE3) || (RGB && tid >= 32 && tid < 32 + kSE3);
           long long tot;
           int ov;
-          ar_wait<kArStride>(arp, tid, mine, nb, tot, ov, &st->sync_timeout, RGB ? 32 : 0);
+          ar_wait<kArStride>(arp, tid, mine, nb, tot, ov, &st->sync_timeout, RGB ? 32 : 0, L.ar_slack_shift < 31 ? nb >> L.ar_slack_shift : 0);
 
           s_sums[tid] = mine ? (float)ar_decode(tot, eb_slot) : 0.f;
           const unsigned long long any = __builtin_amdgcn_ballot_w64(mine && ov != 0);
@@ -2177,6 +2182,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     o->atomic_reduce = !(e && strcmp(e, "records") == 0);
     e = getenv("DMS_PERSIST_BLOCKS");
     if (e && atoi(e) > 0) o->persist_target = atoi(e);
+    e = getenv("DMS_AR_SLACK");
+    if (e && atoi(e) >= 0 && atoi(e) <= 31) o->ar_slack_shift = atoi(e);
   }
   *out = o;
   return DMS_OK;
@@ -2595,6 +2602,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.ar = o->ar + (size_t)(10 + 10 * l) * kArWords;
       L.use_ar = o->atomic_reduce ? 1 : 0;
       L.ar_margin = o->ar_margin;
+      L.ar_slack_shift = o->ar_slack_shift;
       L.prof = o->profiling ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
       L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
