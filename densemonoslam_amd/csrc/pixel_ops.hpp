@@ -120,7 +120,8 @@ __device__ __forceinline__ IcpProj icp_project(const IcpParams& p, const IcpOwn&
   const f3 vcurr_cp = mult<FMA>(p.Rprev_inv, r.vcurr_g - p.tprev);
   r.ux = f2i_rn((vcurr_cp.x * p.fx) / vcurr_cp.z + p.cx);
   r.uy = f2i_rn((vcurr_cp.y * p.fy) / vcurr_cp.z + p.cy);
-  r.ok = !((int)(r.ux < 0) | (int)(r.uy < 0) | (int)(r.ux >= p.cols) | (int)(r.uy >= p.rows) | (int)(vcurr_cp.z < 0.f));
+  // 0 <= ux < cols && 0 <= uy < rows (one unsigned compare each) && !(z < 0)
+  r.ok = (int)((unsigned)r.ux < (unsigned)p.cols) & (int)((unsigned)r.uy < (unsigned)p.rows) & (int)!(vcurr_cp.z < 0.f);
   return r;
 }
 
@@ -282,7 +283,7 @@ __device__ __forceinline__ RgbProj rgb_project(const RgbResParams& p, const RgbO
   r.transformed_d1 = madd<FMA>(d1, madd<FMA>(p.krkinv.r2.y, fy_, p.krkinv.r2.x * fx_) + p.krkinv.r2.z, p.kt.z);
   r.u0 = f2i_rn(madd<FMA>(d1, madd<FMA>(p.krkinv.r0.y, fy_, p.krkinv.r0.x * fx_) + p.krkinv.r0.z, p.kt.x) / r.transformed_d1);
   r.v0 = f2i_rn(madd<FMA>(d1, madd<FMA>(p.krkinv.r1.y, fy_, p.krkinv.r1.x * fx_) + p.krkinv.r1.z, p.kt.y) / r.transformed_d1);
-  r.ok = (int)o.gate & (int)(r.u0 >= 0) & (int)(r.v0 >= 0) & (int)(r.u0 < p.cols) & (int)(r.v0 < p.rows);
+  r.ok = (int)o.gate & (int)((unsigned)r.u0 < (unsigned)p.cols) & (int)((unsigned)r.v0 < (unsigned)p.rows);
   return r;
 }
 
