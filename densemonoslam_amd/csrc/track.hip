@@ -3,15 +3,20 @@
 // MI355X design.  The reference runs ≈67 blocking device→host round trips per call (three
 // kernel pairs + a 116-byte copy + a host Eigen solve per Gauss-Newton iteration,
 // RGBDOdometry.cpp:425-586).  Here the whole coarse-to-fine loop is enqueued on one HIP
-// stream with no host involvement:
+// stream with no host involvement.  Resident form (default): k_track_init, k_so3_level, one k_gn_level per pyramid
+// level — ALL iterations of a level in one launch, grid-wide sums through memory-side integer atomics.  Launch-per-phase
+// form (DMS_TRACK_MODE=launches; also every level with more than 10 iterations):
 //
 //   k_track_init     1 lane   prior pose -> state, first-iteration projection parameters
-//   k_so3_pass       grid     per-pixel SO3 rows -> partials[11][blocks]
-//   k_so3_solve      1 block  fold, converge/diverge tests, fp32 LDLT, exp map, next homography
-//   k_gn_pass1<I,R>  grid     RGB correspondence (DataTerm + count/Σdiff²) and ICP rows -> partials
-//   k_gn_pass2       grid     σ from the folded count, photometric rows -> partials
-//   k_gn_solve       1 block  fold both partial sets, fp64 6×6 LDLT, SE3 update, next KRK⁻¹ / Kt
+//   k_so3_pass       grid     per-pixel SO3 rows -> per-block integer records; the last block folds and solves
+//   k_gn_pass1<I,R>  grid     RGB correspondence (count / Σdiff²) and ICP rows -> records
+//   k_gn_pass2       grid     σ from the folded count, photometric rows -> records
+//   k_gn_solve       1 block  fold both record sets, fp64 6×6 LDLT, SE3 update, next KRK⁻¹ / Kt
 //   k_track_finalize 1 lane   0.3 m jump gate, result block
+//
+// Every cross-pixel sum is the order-free integer sum of canon.hpp and the scalar section is the fixed operation sequence
+// of gn_scalar.hpp, in both forms: a pose does not depend on the execution mode, the grid size or the run, and equals the
+// CPU oracle's bit for bit.
 //
 // The pose, the 4×4 accumulated transform (fp64) and the early-exit flags (SO3
 // converged/diverged, rgbOnly break) live in a device state block; kernels past an exit
@@ -26,6 +31,8 @@
 #include "internal.hpp"
 #include "pixel_ops.hpp"
 #include "smallmath.hpp"
+#include "gn_scalar.hpp"
+#include "canon.hpp"
 #include "pyr_body.hpp"
 #include "frame_state.hpp"
 #include "surfel.hpp"
@@ -37,31 +44,6 @@ namespace dms {
 // -fmad=true does to the reference's kernels) in every execution mode; the operator layer (reduce.hip: dms_icpStep ...)
 // keeps every operation rounded.  The oracle restates both forms (orc_set_fused_rows).
 constexpr bool kTrackerFma = true;
-
-constexpr int kArMargin = 6;  // integer all-reduce: headroom (bits) of the fixed-point scale over the previous totals (see ar_bound_exp)
-
-struct TrackState {
-  // prior / current pose (float, as the reference's Eigen float types)
-  float Rprev[9], tprev[3], Rprev_inv[9];
-  float Rcurr[9], tcurr[3];
-  // accumulated incremental transform (RGBDOdometry.cpp:395) and SO3 rotation (:295,301,314)
-  double resultRt[16];
-  double resultR[9], lastResultR[9];
-  float R_lr[9];
-  float so3_lastError, so3_lastCount;
-  int so3_done, so3_iters;
-  // per-iteration projection parameters
-  float imageBasis[9], kinv[9], krlr[9];  // SO3 (:321-332)
-  float krkinv[9], kt[3];                 // GN  (:427-437)
-  int level_done[DMS_NUM_PYRS];
-  int iters_run[DMS_NUM_PYRS];
-  // side outputs
-  float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
-  double lastA[36], lastb[6];
-  int rejected_jump;
-  int sync_timeout;  // a persistent kernel gave up waiting at a grid barrier (result invalid)
-  float out_trans[3], out_rot[9];
-};
 
 struct Buf {
   void* p = nullptr;
@@ -89,10 +71,9 @@ using namespace dms;
 struct dms_odometry {
   bool early_exit = false;  // use the resident kernels that leave a level after an iteration without any correspondence
   // Execution switches, fixed per handle: read from the environment once, at dms_odometry_create (DMS_TRACK_MODE,
-  // DMS_SUMS, DMS_TRACK_EARLY_EXIT, DMS_PERSIST_BLOCKS), changed only through dms_odometry_set_mode.  (Reading them at
-  // every call let a changing environment switch the sum order in the middle of a session.)
+  // DMS_TRACK_EARLY_EXIT, DMS_PERSIST_BLOCKS), changed only through dms_odometry_set_mode.  (Reading them at
+  // every call let a changing environment switch the execution mode in the middle of a session.)
   bool resident = true;       // false: three launches per iteration (DMS_TRACK_MODE=launches)
-  bool fp64_sums = false;     // block sums and records in fp64 (DMS_SUMS=fp64)
   int early_exit_force = -1;  // -1: as `early_exit`; 0 / 1: forced (DMS_TRACK_EARLY_EXIT)
   int persist_target = 160;   // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
   // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
@@ -121,17 +102,14 @@ struct dms_odometry {
   const void* deriv_of = nullptr;  // nextImage[0] the derivative pyramid was computed from
   float* vmaps_tmp = nullptr;
   float* nmaps_tmp = nullptr;
-  float* part_icp = nullptr;   // [29][1024]
-  float* part_rgb = nullptr;   // [29][1024]
-  float* part_so3 = nullptr;   // [11][1024]
+  long long* part_icp = nullptr;   // [kMaxPartialBlocks][32] integer records of the launch-per-phase kernels (grid units, canon.hpp)
+  long long* part_rgb = nullptr;   // [kMaxPartialBlocks][32]
+  long long* part_so3 = nullptr;   // [kMaxPartialBlocks][32]
   int* part_cnt = nullptr;     // [2][1024]
   unsigned* tickets = nullptr; // [4] arrival counters of the last-block-solves hand-off (zero between launches)
-  float* rec = nullptr;               // [2][kMaxPersistBlocks][kRecFloats] records of the persistent level kernels
-  unsigned long long* sync = nullptr; // [kSyncWords] barrier words, zeroed by k_track_init
-  unsigned long long* ar = nullptr;   // [kArReductions][kArWords] all-reduce words, zeroed by k_track_init
-  bool atomic_reduce = true;          // false: record protocol everywhere (DMS_TRACK_REDUCE=records)
+  unsigned long long* ar = nullptr;   // [kArSets][kArWords] all-reduce words of the resident kernels, zeroed by k_track_init
   int ar_slack_shift = 2;             // integer all-reduce: the full sweep starts when all but nb >> shift blocks have arrived (DMS_AR_SLACK; 31 = wait for all)
-  int ar_margin = dms::kArMargin;     // test hook (dms_odometry_debug_set "ar_margin"): a negative margin makes every partial sum overflow
+  int exp_bias = 0;                   // test hook (dms_odometry_debug_set "exp_bias"): added to the static exponents of a call's first reductions (negative: they do not fit and are repeated)
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
@@ -143,86 +121,6 @@ struct dms_odometry {
 
 namespace dms {
 
-// ---------------------------------------------------------------------------------------
-// device-side scalar sections
-// ---------------------------------------------------------------------------------------
-__device__ inline void level_K(float fx, float fy, float cx, float cy, int level, double* K) {
-  // CameraModel::operator()(level) divides in float (types.cuh:115-119), then K is double
-  const int div = 1 << level;
-  for (int i = 0; i < 9; ++i) K[i] = 0.0;
-  K[0] = (double)(fx / (float)div);
-  K[4] = (double)(fy / (float)div);
-  K[2] = (double)(cx / (float)div);
-  K[5] = (double)(cy / (float)div);
-  K[8] = 1.0;
-}
-
-// K = [fx 0 cx; 0 fy cy; 0 0 1] (level_K) throughout: K^-1, K R and K R K^-1 are written out in closed form instead of a
-// general 3x3 inverse and two 3x3 products (the same values to ~1e-16 before they are rounded to float; the Gauss-Newton
-// levels do the same in gn_params_local_k).  RGBDOdometry.cpp:321-332
-__device__ inline void so3_params(TrackState* st, const double* K) {
-  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  const double ifx = 1.0 / fx, ify = 1.0 / fy;
-  const double* R = st->resultR;
-  double t[9];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    t[0 * 3 + j] = fx * R[0 * 3 + j] + cx * R[2 * 3 + j];
-    t[1 * 3 + j] = fy * R[1 * 3 + j] + cy * R[2 * 3 + j];
-    t[2 * 3 + j] = R[2 * 3 + j];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double h0 = t[i * 3 + 0] * ifx, h1 = t[i * 3 + 1] * ify;
-    st->imageBasis[i * 3 + 0] = (float)h0;
-    st->imageBasis[i * 3 + 1] = (float)h1;
-    st->imageBasis[i * 3 + 2] = (float)(t[i * 3 + 2] - h0 * cx - h1 * cy);
-  }
-  const double kinv[9] = {ifx, 0.0, -(cx * ifx), 0.0, ify, -(cy * ify), 0.0, 0.0, 1.0};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    st->kinv[i] = (float)kinv[i];
-    st->krlr[i] = (float)t[i];
-  }
-}
-
-// RGBDOdometry.cpp:427-437.  `resultRt` is passed in registers: re-reading it from the state block
-// right after storing it costs a full memory round trip on the solving lane.  resultRt is a product of rigid transforms:
-// its inverse is taken in the isometry form [R^T | -R^T t] (as gn_params_local_k does), not by a general 4x4 inverse.
-__device__ inline void gn_params_from(TrackState* st, const double* resultRt, const double* K) {
-  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  const double ifx = 1.0 / fx, ify = 1.0 / fy;
-  double Ri[9], ti[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = resultRt[j * 4 + i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) ti[i] = -(Ri[i * 3 + 0] * resultRt[3] + Ri[i * 3 + 1] * resultRt[7] + Ri[i * 3 + 2] * resultRt[11]);
-  double M[9];  // K * Ri
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    M[0 * 3 + j] = fx * Ri[0 * 3 + j] + cx * Ri[2 * 3 + j];
-    M[1 * 3 + j] = fy * Ri[1 * 3 + j] + cy * Ri[2 * 3 + j];
-    M[2 * 3 + j] = Ri[2 * 3 + j];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double h0 = M[i * 3 + 0] * ifx, h1 = M[i * 3 + 1] * ify;
-    st->krkinv[i * 3 + 0] = (float)h0;
-    st->krkinv[i * 3 + 1] = (float)h1;
-    st->krkinv[i * 3 + 2] = (float)(M[i * 3 + 2] - h0 * cx - h1 * cy);
-  }
-  st->kt[0] = (float)(fx * ti[0] + cx * ti[2]);
-  st->kt[1] = (float)(fy * ti[1] + cy * ti[2]);
-  st->kt[2] = (float)ti[2];
-}
-__device__ inline void gn_params(TrackState* st, const double* K) {
-  double Rt[16];
-  for (int i = 0; i < 16; ++i) Rt[i] = st->resultRt[i];
-  gn_params_from(st, Rt, K);
-}
-
 struct Prior {
   float v[12];  // trans[3], rot[9] — passed by value so no staging copy can race a later call
 };
@@ -232,7 +130,7 @@ __device__ __forceinline__ void track_init_body(int b, int nb, int t, int nt, Tr
                                                 float fx, float fy, float cx, float cy, int so3, int first_level,
                                                 unsigned long long* sync_words, int n_sync, int inject_timeout, unsigned* zero16) {
   if (zero16 && b == 0 && t < 16) zero16[t * 16] = 0u;  // (the frame step's dense counters: their reader ran before this launch)
-  // barrier and all-reduce words of the resident kernels of this call: zero before any of them is launched
+  // all-reduce words of the resident kernels of this call: zero before any of them is launched
   // (n_sync counts 16-byte pairs; the grid shares the work, block 0 also sets up the state)
   {
     ulonglong2* w2 = reinterpret_cast<ulonglong2*>(sync_words);
@@ -263,15 +161,16 @@ __device__ __forceinline__ void track_init_body(int b, int nb, int t, int nt, Tr
   }
   st->rejected_jump = 0;
   st->sync_timeout = inject_timeout;  // (0 unless a test injects the fault)
+  st->have_E = 0;
+  st->canon_retries = 0;
   for (int i = 0; i < 36; ++i) st->lastA[i] = 0.0;
   for (int i = 0; i < 6; ++i) st->lastb[i] = 0.0;
-  double K[9];
   if (so3) {
-    level_K(fx, fy, cx, cy, 2, K);
-    so3_params(st, K);
+    sc::so3_params(st, sc::kpre_of(fx, fy, cx, cy, 2));
   } else {
-    level_K(fx, fy, cx, cy, first_level, K);
-    gn_params(st, K);
+    double Rt[16];
+    for (int i = 0; i < 16; ++i) Rt[i] = st->resultRt[i];
+    sc::gn_params(Rt, sc::kpre_of(fx, fy, cx, cy, first_level), st->krkinv, st->kt);
   }
 }
 
@@ -300,69 +199,11 @@ __global__ __launch_bounds__(256) void k_track_init_pyr(TrackState* st, Prior pr
 }
 
 // ---------------------------------------------------------------------------------------
-// SO3 pre-alignment (RGBDOdometry.cpp:297-385)
+// Launch-per-phase form: shared pieces
 // ---------------------------------------------------------------------------------------
-struct SolveCam {
-  float fx, fy, cx, cy;
-};
-__device__ void so3_solve_body(TrackState* st, const float* partials, int nblocks, float fx, float fy, float cx, float cy, int is_last,
-                               int first_gn_level);
-__device__ __forceinline__ bool last_block_arrives(unsigned* ticket);
+constexpr int kRecWords = 32;  // integer record of one block: value k of the reduction in word k (grid units of canon.hpp)
 
-__global__ __launch_bounds__(kBlock) void k_so3_pass(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
-                                                     const unsigned char* nextImage, size_t next_pitch, int cols, int rows, float* partials,
-                                                     int stride, unsigned* ticket, SolveCam cam, int is_last, int first_gn_level) {
-  if (st->so3_done) return;
-  So3Params p;
-  const float* ib = st->imageBasis;
-  const float* ki = st->kinv;
-  const float* kr = st->krlr;
-  p.imageBasis.r0 = mk3(ib[0], ib[1], ib[2]);
-  p.imageBasis.r1 = mk3(ib[3], ib[4], ib[5]);
-  p.imageBasis.r2 = mk3(ib[6], ib[7], ib[8]);
-  p.kinv.r0 = mk3(ki[0], ki[1], ki[2]);
-  p.kinv.r1 = mk3(ki[3], ki[4], ki[5]);
-  p.kinv.r2 = mk3(ki[6], ki[7], ki[8]);
-  p.krlr.r0 = mk3(kr[0], kr[1], kr[2]);
-  p.krlr.r1 = mk3(kr[3], kr[4], kr[5]);
-  p.krlr.r2 = mk3(kr[6], kr[7], kr[8]);
-  p.cols = cols;
-  p.rows = rows;
-  const int N = cols * rows;
-  float acc[kSO3];
-#pragma unroll
-  for (int k = 0; k < kSO3; ++k) acc[k] = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += blockDim.x * gridDim.x) {
-    const int y = i / cols;
-    const int x = i - y * cols;
-    float row[4];
-    const bool found = so3_row(p, lastImage, last_pitch, nextImage, next_pitch, x, y, row);
-    accumulate_so3(acc, row, found);
-  }
-  block_reduce_store<kSO3>(acc, partials, stride, blockIdx.x);
-  if (last_block_arrives(ticket)) so3_solve_body(st, partials, gridDim.x, cam.fx, cam.fy, cam.cx, cam.cy, is_last, first_gn_level);
-}
-
-__device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, int stride, int nblocks, int* sums) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (wid < 2) {
-    int s = 0;
-    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {  // 8 independent loads in flight
-      int v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = b0 + 64 * u;
-        v[u] = partials[(size_t)wid * stride + (b < nblocks ? b : 0)];  // clamp + select: keeps the batch in flight
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (b0 + 64 * u < nblocks) ? v[u] : 0;
-    }
-    s = wave_sum_to_lane63_i(s);
-    if (lane == 63) sums[wid] = s;
-  }
-}
-
-// "Last block folds and solves": every block publishes its 128-byte record, then takes a ticket;
+// "Last block folds and solves": every block publishes its record, then takes a ticket;
 // the block that draws the last ticket reads all records and runs the scalar solve, so no
 // separate launch (and no dependent-launch gap) is needed.  Hand-off protocol of
 // cdna_hip_programming.md §6 G16 / §5 split-K recipe: every wave drains its stores, one lane
@@ -387,89 +228,168 @@ __device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
   return s_last != 0;
 }
 
-// run by the 256 threads of the last block of k_so3_pass
-// one lane: the SO3 update from the folded sums (RGBDOdometry.cpp:334-385).  `st` may point to
-// the state block in HBM (launch path) or to a copy in LDS (persistent path).
-__device__ void so3_solve_core(TrackState* st, const float* sums, float fx, float fy, float cx, float cy, int is_last, int first_gn_level);
-
-__device__ void so3_solve_body(TrackState* st, const float* partials, int nblocks, float fx, float fy, float cx, float cy, int is_last,
-                               int first_gn_level) {
-  __shared__ float sums[kSO3];
-  fold_records256(partials, nblocks, kSO3, sums);
+// Fold of the integer records by one 256-thread block: thread (g = tid / 32, k = tid % 32) adds word k of records
+// g, g + 8, ...; then thread k < 32 adds the 8 group sums.  Integer sums: exact, any order.  totals: LDS [32].
+__device__ __forceinline__ void fold_records_i64(const long long* __restrict__ rec, int nblocks, long long* totals) {
+  __shared__ long long s_g[8][32];
+  const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+  long long s = 0;
+  for (int b = g; b < nblocks; b += 8) s += rec[(size_t)b * kRecWords + k];
+  s_g[g][k] = s;
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  so3_solve_core(st, sums, fx, fy, cx, cy, is_last, first_gn_level);
+  if (threadIdx.x < 32) {
+    long long t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += s_g[q][threadIdx.x];
+    totals[threadIdx.x] = t;
+  }
+  __syncthreads();
 }
 
-__device__ void so3_solve_core(TrackState* st, const float* sums, float fx, float fy, float cx, float cy, int is_last, int first_gn_level) {
-  float jtj[9], jtr[3];
-  int shift = 0;
-  for (int i = 0; i < 3; ++i)
-    for (int j = i; j < 4; ++j) {
-      const float v = sums[shift++];
-      if (j == 3)
-        jtr[i] = v;
-      else
-        jtj[j * 3 + i] = jtj[i * 3 + j] = v;
+__device__ __forceinline__ void fold_rows_i2(const int* __restrict__ partials, int stride, int nblocks, int* sums) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (wid < 2) {
+    int s = 0;
+    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {  // 8 independent loads in flight
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 64 * u;
+        v[u] = partials[(size_t)wid * stride + (b < nblocks ? b : 0)];  // clamp + select: keeps the batch in flight
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (b0 + 64 * u < nblocks) ? v[u] : 0;
     }
-  const float res0 = sums[9], res1 = sums[10];
-  st->so3_iters += 1;
-  float err = sqrtf(res0) / res1;
-  float cnt = res1;
-  bool stop = false;
-  if (err < st->so3_lastError && st->so3_lastCount == cnt) {
-    stop = true;  // converged
-  } else if ((double)err > (double)st->so3_lastError + 0.001) {
-    err = st->so3_lastError;  // diverging: roll back
-    cnt = st->so3_lastCount;
-    for (int i = 0; i < 9; ++i) st->resultR[i] = st->lastResultR[i];
-    stop = true;
-  }
-  st->lastSO3Error = err;
-  st->lastSO3Count = cnt;
-  if (!stop) {
-    st->so3_lastError = err;
-    st->so3_lastCount = cnt;
-    for (int i = 0; i < 9; ++i) st->lastResultR[i] = st->resultR[i];
-    float delta[3];
-    sm::ldlt_solve_reg<float, 3>(jtj, jtr, delta, 1.0f / 3.402823466e+38F);
-    const double dd[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
-    double rotUpdate[9];
-    sm::rodrigues(dd, rotUpdate);
-    float ru[9], nr[9];
-    for (int i = 0; i < 9; ++i) ru[i] = (float)rotUpdate[i];
-    sm::mul3<float>(ru, st->R_lr, nr);
-    for (int i = 0; i < 9; ++i) {
-      st->R_lr[i] = nr[i];
-      st->resultR[i] = (double)nr[i];
-    }
-  }
-  if (stop || is_last) {
-    st->so3_done = 1;
-    // seed resultRt with the rotation (RGBDOdometry.cpp:397-406) and derive the first GN parameters
-    for (int x = 0; x < 3; ++x)
-      for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = st->resultR[x * 3 + y];
-    double K[9];
-    level_K(fx, fy, cx, cy, first_gn_level, K);
-    gn_params(st, K);
-  } else {
-    double K[9];
-    level_K(fx, fy, cx, cy, 2, K);
-    so3_params(st, K);
+    s = wave_sum_to_lane63_i(s);
+    if (lane == 63) sums[wid] = s;
   }
 }
 
+// block of kBlock threads: the per-thread biased accumulators -> one integer record (words 0 .. NV-1)
+template <int N>
+__device__ __forceinline__ void store_record(const double (&acc)[canon::Layout<N>::NV], const int* E, long long* rec) {
+  __shared__ double s_red[kBlock / kWave][32];
+  const double t = canon::block_fold<N, kBlock / kWave>(canon::wave_tree<N>(acc), s_red);
+  if (threadIdx.x < 32) rec[threadIdx.x] = (int)threadIdx.x < canon::Layout<N>::NV ? canon::to_units(t, canon::value_exp<N>(E, threadIdx.x)) : 0ll;
+}
+
+// integer totals -> violation flag of a reduction with N columns (threads 0 .. 31 hold one value each)
+template <int N>
+__device__ __forceinline__ bool totals_violate(const long long* totals) {
+  bool v = false;
+#pragma unroll
+  for (int c = 0; c <= N; ++c) v = v || totals[canon::Layout<N>::diag(c)] >= canon::kViolation;
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void totals_to_float(const long long* totals, const int* E, float* sums) {
+  for (int k = 0; k < canon::Layout<N>::NV; ++k) sums[k] = canon::from_units(totals[k], canon::value_exp<N>(E, k));
+}
+
 // ---------------------------------------------------------------------------------------
-// Gauss-Newton passes (RGBDOdometry.cpp:425-586)
+// SO3 pre-alignment (RGBDOdometry.cpp:297-385), launch-per-phase form
 // ---------------------------------------------------------------------------------------
-struct SolveArgs {
-  int icp, rgb, rgbOnly;
-  float icpWeight;
-  int level, first_iter, next_level, level_below;
+struct SolveCam {
   float fx, fy, cx, cy;
 };
-__device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
-                              const SolveArgs q);
+
+__device__ __forceinline__ So3Params so3_params_of(const TrackState* st, int cols, int rows) {
+  So3Params p;
+  const float* ib = st->imageBasis;
+  const float* ki = st->kinv;
+  const float* kr = st->krlr;
+  p.imageBasis.r0 = mk3(ib[0], ib[1], ib[2]);
+  p.imageBasis.r1 = mk3(ib[3], ib[4], ib[5]);
+  p.imageBasis.r2 = mk3(ib[6], ib[7], ib[8]);
+  p.kinv.r0 = mk3(ki[0], ki[1], ki[2]);
+  p.kinv.r1 = mk3(ki[3], ki[4], ki[5]);
+  p.kinv.r2 = mk3(ki[6], ki[7], ki[8]);
+  p.krlr.r0 = mk3(kr[0], kr[1], kr[2]);
+  p.krlr.r1 = mk3(kr[3], kr[4], kr[5]);
+  p.krlr.r2 = mk3(kr[6], kr[7], kr[8]);
+  p.cols = cols;
+  p.rows = rows;
+  return p;
+}
+
+// the block's threads sweep pixels [first, N) with stride `stride` and leave the per-thread accumulators
+__device__ __forceinline__ void so3_accumulate(const So3Params& p, const unsigned char* lastImage, size_t last_pitch,
+                                               const unsigned char* nextImage, size_t next_pitch, int first, int stride,
+                                               double (&acc)[kSO3]) {
+  const int N = p.cols * p.rows;
+  for (int i = first; i < N; i += stride) {
+    const int y = i / p.cols;
+    const int x = i - y * p.cols;
+    float row[4];
+    const bool found = so3_row(p, lastImage, last_pitch, nextImage, next_pitch, x, y, row);
+    canon::acc_add<3>(acc, row, found);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_so3_pass(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
+                                                     const unsigned char* nextImage, size_t next_pitch, int cols, int rows, long long* records,
+                                                     unsigned* ticket, SolveCam cam, int iter, int is_last, int first_gn_level, int exp_bias) {
+  if (st->so3_done) return;
+  __shared__ int s_E[4];
+  __shared__ double s_bias[2][32];
+  __shared__ long long s_tot[32];
+  __shared__ float s_sums[kSO3];
+  __shared__ int s_viol;
+  const So3Params p = so3_params_of(st, cols, rows);
+  if (threadIdx.x == 0) {
+    int E[4];
+    if (iter == 0) {
+      canon::static_so3(cols * rows, E);
+      for (int c = 0; c < 4; ++c) E[c] = canon::clamp_e(E[c] + exp_bias);
+    } else {
+      for (int c = 0; c < 4; ++c) E[c] = st->E_icp[c];  // (the SO3 stage borrows the slot: no Gauss-Newton reduction has run yet)
+    }
+    for (int c = 0; c < 4; ++c) s_E[c] = E[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) canon::write_bias<3>(s_E, s_bias, threadIdx.x);
+  __syncthreads();
+  double acc[kSO3];
+  canon::acc_init<3>(acc, s_bias);
+  so3_accumulate(p, lastImage, last_pitch, nextImage, next_pitch, blockIdx.x * blockDim.x + threadIdx.x, blockDim.x * gridDim.x, acc);
+  store_record<3>(acc, s_E, records + (size_t)blockIdx.x * kRecWords);
+  if (!last_block_arrives(ticket)) return;
+  // ---- last block: fold, check the grid, repeat alone on a coarser one if a diagonal total did not fit, solve ----
+  fold_records_i64(records, gridDim.x, s_tot);
+  int retries = 0;
+  for (;;) {
+    if (threadIdx.x == 0) s_viol = totals_violate<3>(s_tot) ? 1 : 0;
+    __syncthreads();
+    if (!s_viol) break;
+    if (++retries > canon::kMaxRetries) break;
+    if (threadIdx.x == 0) canon::retry_step<3>(s_E);
+    __syncthreads();
+    if (threadIdx.x < 32) canon::write_bias<3>(s_E, s_bias, threadIdx.x);
+    __syncthreads();
+    canon::acc_init<3>(acc, s_bias);
+    so3_accumulate(p, lastImage, last_pitch, nextImage, next_pitch, threadIdx.x, blockDim.x, acc);
+    __shared__ double s_red[kBlock / kWave][32];
+    const double t = canon::block_fold<3, kBlock / kWave>(canon::wave_tree<3>(acc), s_red);
+    __syncthreads();
+    if (threadIdx.x < 32) s_tot[threadIdx.x] = (int)threadIdx.x < kSO3 ? canon::to_units(t, canon::value_exp<3>(s_E, threadIdx.x)) : 0ll;
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  totals_to_float<3>(s_tot, s_E, s_sums);
+  if (retries > canon::kMaxRetries)
+    for (int k = 0; k < kSO3 - 1; ++k) s_sums[k] = 0.f;
+  st->canon_retries += retries;
+  sc::so3_solve_core(st, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, is_last, first_gn_level);
+  int E[4];
+  for (int c = 0; c < 4; ++c) E[c] = s_E[c];
+  canon::next_exponents<3>(s_sums, E);
+  for (int c = 0; c < 4; ++c) st->E_icp[c] = E[c];
+}
+
+// ---------------------------------------------------------------------------------------
+// Gauss-Newton passes (RGBDOdometry.cpp:425-586), launch-per-phase form
+// ---------------------------------------------------------------------------------------
+using sc::SolveArgs;
 
 // The fused loop's own correspondence record (the 16-byte DataTerm of the operator layer carries
 // the live pixel's coordinates, which are the record's position, and a float difference of two
@@ -491,7 +411,65 @@ struct GnArgs {
   unsigned cloud_pitch;
   float minScale, maxDepthDelta, sobelScale;
   int cols, rows, level;
+  int rgbOnly, first_of_call, exp_bias;  // canonical sums: how the level's first exponents are derived (see level_exponents)
 };
+
+// Column exponents of a level's first reduction: the call's first Gauss-Newton level starts from the static table, every
+// later one from the coarser level's last totals, four times the pixels (canon.hpp).  Uniform: every block derives the same.
+__device__ __forceinline__ void level_exponents(const TrackState* st, const GnArgs& a, bool first_iter, int* E_icp, int* E_rgb) {
+  if (first_iter && !st->have_E) {
+    canon::static_icp(a.cols * a.rows, E_icp);
+    canon::static_rgb(a.cols * a.rows, a.fx, a.rgbOnly, E_rgb);
+    for (int c = 0; c < 7; ++c) {
+      E_icp[c] = canon::clamp_e(E_icp[c] + a.exp_bias);
+      E_rgb[c] = canon::clamp_e(E_rgb[c] + a.exp_bias);
+    }
+    return;
+  }
+  for (int c = 0; c < 7; ++c) {
+    E_icp[c] = st->E_icp[c];
+    E_rgb[c] = st->E_rgb[c];
+  }
+  if (first_iter) {
+    canon::level_step<6>(E_icp);
+    canon::level_step<6>(E_rgb);
+  }
+}
+
+__device__ __forceinline__ IcpParams icp_params_of(const float* Rcurr, const float* tcurr, const float* Rprev_inv, const float* tprev, const GnArgs& a) {
+  IcpParams ip;
+  ip.Rcurr.r0 = mk3(Rcurr[0], Rcurr[1], Rcurr[2]);
+  ip.Rcurr.r1 = mk3(Rcurr[3], Rcurr[4], Rcurr[5]);
+  ip.Rcurr.r2 = mk3(Rcurr[6], Rcurr[7], Rcurr[8]);
+  ip.tcurr = mk3(tcurr[0], tcurr[1], tcurr[2]);
+  ip.Rprev_inv.r0 = mk3(Rprev_inv[0], Rprev_inv[1], Rprev_inv[2]);
+  ip.Rprev_inv.r1 = mk3(Rprev_inv[3], Rprev_inv[4], Rprev_inv[5]);
+  ip.Rprev_inv.r2 = mk3(Rprev_inv[6], Rprev_inv[7], Rprev_inv[8]);
+  ip.tprev = mk3(tprev[0], tprev[1], tprev[2]);
+  ip.fx = a.fx;
+  ip.fy = a.fy;
+  ip.cx = a.cx;
+  ip.cy = a.cy;
+  ip.distThres = a.distThres;
+  ip.angleThres = a.angleThres;
+  ip.dist2Le = a.dist2Le;
+  ip.sine2Le = a.sine2Le;
+  ip.cols = a.cols;
+  ip.rows = a.rows;
+  return ip;
+}
+__device__ __forceinline__ RgbResParams rgb_params_of(const float* krkinv, const float* kt, const GnArgs& a) {
+  RgbResParams rp;
+  rp.krkinv.r0 = mk3(krkinv[0], krkinv[1], krkinv[2]);
+  rp.krkinv.r1 = mk3(krkinv[3], krkinv[4], krkinv[5]);
+  rp.krkinv.r2 = mk3(krkinv[6], krkinv[7], krkinv[8]);
+  rp.kt = mk3(kt[0], kt[1], kt[2]);
+  rp.minScale = a.minScale;
+  rp.maxDepthDelta = a.maxDepthDelta;
+  rp.cols = a.cols;
+  rp.rows = a.rows;
+  return rp;
+}
 
 // Pixels are handed out in chunks of kBlock*kPix: thread t of the block owns pixels
 // chunk*kBlock*kPix + p*kBlock + t (p < kPix), i.e. kPix coalesced runs, and keeps the loads of all
@@ -502,184 +480,44 @@ inline int track_blocks_for(int n) {
   return b < 1 ? 1 : (b > kMaxPartialBlocks ? kMaxPartialBlocks : b);
 }
 
-template <bool ICP, bool RGB>
-__global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, float* part_icp, int* __restrict__ part_cnt, int stride,
-                                                     unsigned* ticket, SolveArgs q) {
-  const int done = st->level_done[a.level];
+// ICP rows of the pixels [first chunk, N) in steps of `chunk_stride` chunks into the per-thread accumulators
+__device__ __forceinline__ void icp_accumulate(const IcpParams& ip, const GnArgs& a, int first_chunk, int chunk_stride, double (&acc)[kSE3]) {
   const int N = a.cols * a.rows;
-  IcpParams ip;
-  RgbResParams rp;
-  if (ICP) {
-    const float* R = st->Rcurr;
-    const float* Ri = st->Rprev_inv;
-    ip.Rcurr.r0 = mk3(R[0], R[1], R[2]);
-    ip.Rcurr.r1 = mk3(R[3], R[4], R[5]);
-    ip.Rcurr.r2 = mk3(R[6], R[7], R[8]);
-    ip.tcurr = mk3(st->tcurr[0], st->tcurr[1], st->tcurr[2]);
-    ip.Rprev_inv.r0 = mk3(Ri[0], Ri[1], Ri[2]);
-    ip.Rprev_inv.r1 = mk3(Ri[3], Ri[4], Ri[5]);
-    ip.Rprev_inv.r2 = mk3(Ri[6], Ri[7], Ri[8]);
-    ip.tprev = mk3(st->tprev[0], st->tprev[1], st->tprev[2]);
-    ip.fx = a.fx;
-    ip.fy = a.fy;
-    ip.cx = a.cx;
-    ip.cy = a.cy;
-    ip.distThres = a.distThres;
-    ip.angleThres = a.angleThres;
-    ip.dist2Le = a.dist2Le;
-    ip.sine2Le = a.sine2Le;
-    ip.cols = a.cols;
-    ip.rows = a.rows;
-  }
-  if (RGB) {
-    const float* H = st->krkinv;
-    rp.krkinv.r0 = mk3(H[0], H[1], H[2]);
-    rp.krkinv.r1 = mk3(H[3], H[4], H[5]);
-    rp.krkinv.r2 = mk3(H[6], H[7], H[8]);
-    rp.kt = mk3(st->kt[0], st->kt[1], st->kt[2]);
-    rp.minScale = a.minScale;
-    rp.maxDepthDelta = a.maxDepthDelta;
-    rp.cols = a.cols;
-    rp.rows = a.rows;
-  }
-  if (done) return;
-  float acc[kSE3];
-#pragma unroll
-  for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
-  int cnt = 0, sig = 0;
-  for (int base = blockIdx.x * (kBlock * kPix); base < N; base += gridDim.x * (kBlock * kPix)) {
-    int idx[kPix], px[kPix], py[kPix];
+  for (int base = first_chunk * (kBlock * kPix); base < N; base += chunk_stride * (kBlock * kPix)) {
+    int idx[kPix];
     IcpOwn io[kPix];
-    RgbOwn ro[kPix];
 #pragma unroll
     for (int p = 0; p < kPix; ++p) {
       idx[p] = base + p * kBlock + (int)threadIdx.x;
       const int ic = idx[p] < N ? idx[p] : 0;  // lanes past the end shadow pixel 0 and are masked below
-      py[p] = ic / a.cols;
-      px[p] = ic - py[p] * a.cols;
-      if (ICP) io[p] = icp_load_own(a.maps, px[p], py[p], a.rows);
-      if (RGB) ro[p] = rgb_load_own_gated(a.rgb, px[p], py[p]);
+      const int py = ic / a.cols;
+      io[p] = icp_load_own(a.maps, ic - py * a.cols, py, a.rows);
     }
     IcpProj ir[kPix];
-    RgbProj rr[kPix];
     IcpModel im[kPix];
-    RgbModel rm[kPix];
 #pragma unroll
     for (int p = 0; p < kPix; ++p) {
-      if (ICP) {
-        ir[p] = icp_project<kTrackerFma>(ip, io[p]);
-        im[p] = icp_load_model(a.maps, ir[p], a.rows);
-      }
-      if (RGB) {
-        rr[p] = rgb_project<kTrackerFma>(rp, ro[p], px[p], py[p]);
-        rm[p] = rgb_load_model(a.rgb, rr[p]);
-      }
+      ir[p] = icp_project<kTrackerFma>(ip, io[p]);
+      im[p] = icp_load_model(a.maps, ir[p], a.rows);
     }
 #pragma unroll
     for (int p = 0; p < kPix; ++p) {
-      const bool live = idx[p] < N;
-      if (RGB) {
-        dms_dataterm c;
-        int d2;
-        const bool ok = rgb_finish(rp, ro[p], rr[p], rm[p], px[p], py[p], c, d2);
-        if (live) {
-          if (ok) {
-            cnt += 1;
-            sig += d2;
-          }
-          Corr8 c8;
-          c8.zero_x = c.zero_x;
-          c8.zero_y = c.zero_y;
-          c8.diff = (short)f2i_rz(c.diff);
-          c8.valid = (short)c.valid;
-          a.corres[idx[p]] = c8;
-        }
-      }
-      if (ICP) {
-        float row[7];
-        bool found = icp_finish<kTrackerFma>(ip, io[p], ir[p], im[p], row);
-        if (!live) {
-          found = false;
+      float row[7];
+      bool found = icp_finish<kTrackerFma>(ip, io[p], ir[p], im[p], row);
+      if (idx[p] >= N) {
+        found = false;
 #pragma unroll
-          for (int k = 0; k < 7; ++k) row[k] = 0.f;
-        }
-        accumulate_se3<kTrackerFma>(acc, row, found);
+        for (int k = 0; k < 7; ++k) row[k] = 0.f;
       }
+      canon::acc_add<6>(acc, row, found);
     }
   }
-  if (ICP) block_reduce_store<kSE3>(acc, part_icp, stride, blockIdx.x);
-  if (RGB) {
-    __shared__ int lds[kBlock / kWave][2];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    cnt = wave_sum_to_lane63_i(cnt);
-    sig = wave_sum_to_lane63_i(sig);
-    if (lane == 63) {
-      lds[wid][0] = cnt;
-      lds[wid][1] = sig;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-      int s = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += lds[w][threadIdx.x];
-      part_cnt[(size_t)threadIdx.x * stride + blockIdx.x] = s;
-    }
-  }
-  (void)ticket;
-  (void)q;
 }
 
-// σ as the reference computes it (RGBDOdometry.cpp:464, precedence quirk kept)
-__device__ __forceinline__ float sigma_val(int sigma, int rgbSize) {
-  const float q = (float)sigma / (float)rgbSize;
-  const int arg = (q == 0.f) ? 1 : rgbSize;
-  return (float)sqrt((double)arg);
-}
-__device__ __forceinline__ bool rgbonly_break(int sigma, int rgbSize, float lastRGBError) {
-  return sqrt((double)sigma) / (double)rgbSize > (double)lastRGBError;
-}
-
-__global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, const int* __restrict__ part_cnt, int nb_cnt, int stride,
-                                                     int rgbOnly, int first_iter, const float* part_icp, float* part_rgb, unsigned* ticket,
-                                                     SolveArgs q) {
-  if (st->level_done[a.level]) return;
-  // every block folds the (≤1024) integer partials itself: integer sums are order-free, so
-  // all blocks agree bit-for-bit and no extra launch is needed to publish σ.
-  __shared__ int s_cnt[kBlock / kWave][2];
-  __shared__ int s_tot[2];
-  {
-    int c = 0, g = 0;
-    for (int b = threadIdx.x; b < nb_cnt; b += blockDim.x) {
-      c += part_cnt[b];
-      g += part_cnt[(size_t)stride + b];
-    }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    c = wave_sum_to_lane63_i(c);
-    g = wave_sum_to_lane63_i(g);
-    if (lane == 63) {
-      s_cnt[wid][0] = c;
-      s_cnt[wid][1] = g;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-      int s = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_cnt[w][threadIdx.x];
-      s_tot[threadIdx.x] = s;
-    }
-    __syncthreads();
-  }
-  const int rgbSize = s_tot[0], sigma = s_tot[1];
-  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
-  if (rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) return;  // host `break`; k_gn_solve records it
-  RgbStepParams p_;
-  p_.sigma = rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
-  p_.fx = a.fx;
-  p_.fy = a.fy;
-  p_.sobelScale = a.sobelScale;
+// photometric rows from the correspondence image, same sweep
+__device__ __forceinline__ void rgb_accumulate(const RgbStepParams& p_, const GnArgs& a, int first_chunk, int chunk_stride, double (&acc)[kSE3]) {
   const int N = a.cols * a.rows;
-  float acc[kSE3];
-#pragma unroll
-  for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
-  for (int base = blockIdx.x * (kBlock * kPix); base < N; base += gridDim.x * (kBlock * kPix)) {
+  for (int base = first_chunk * (kBlock * kPix); base < N; base += chunk_stride * (kBlock * kPix)) {
     dms_dataterm c[kPix];
     RgbRowIn in[kPix];
 #pragma unroll
@@ -701,291 +539,250 @@ __global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, c
     for (int p = 0; p < kPix; ++p) {
       float row[7];
       rgb_row_finish<kTrackerFma>(p_, c[p], in[p], row);
-      accumulate_se3<kTrackerFma>(acc, row, c[p].valid != 0);
+      canon::acc_add<6>(acc, row, c[p].valid != 0);
     }
   }
-  block_reduce_store<kSE3>(acc, part_rgb, stride, blockIdx.x);
-  (void)ticket;
-  (void)q;
-  (void)part_icp;
 }
 
-__device__ inline void unpack_se3_d(const float* s, float* A, float* b) {
-  int shift = 0;
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 7; ++j) {
-      const float v = s[shift++];
-      if (j == 6)
-        b[i] = v;
-      else
-        A[j * 6 + i] = A[i * 6 + j] = v;
-    }
-}
-
-// State of one Gauss-Newton level that evolves from iteration to iteration.  The launch path
-// keeps it in registers for one k_gn_solve; the persistent path keeps it in LDS for a whole level.
-struct GnLocal {
-  double resultRt[16];
-  float Rprev[9], tprev[3], Rprev_inv[9];  // constant during the loop
-  float Rcurr[9], tcurr[3];
-  float krkinv[9], kt[3];
-  float lastRGBError, lastRGBCount, lastICPError, lastICPCount;
-  int iters_run;
-  double lastA[36], lastb[6];
-};
-
-// projection parameters of the photometric term for the pose in `resultRt` at camera matrix K
-// (RGBDOdometry.cpp:427-437), into the local state
-// resultRt is a product of rigid transforms (orthonormal to 1e-16 in fp64), so its inverse is taken
-// in the isometry form [R^T | -R^T t] instead of the reference's general 4x4 inverse: the two agree
-// to ~1e-16 before the values are rounded to float, and the cofactor expansion was a quarter of the
-// serial solve time.
-struct KPre {  // camera matrix of one pyramid level in fp64 with the reciprocals of the focal lengths (all exact IEEE operations)
-  double fx, fy, cx, cy, ifx, ify;
-};
-__device__ __forceinline__ KPre kpre_of(float fx, float fy, float cx, float cy, int level) {
-  double K[9];
-  level_K(fx, fy, cx, cy, level, K);
-  KPre k;
-  k.fx = K[0];
-  k.fy = K[4];
-  k.cx = K[2];
-  k.cy = K[5];
-  k.ifx = 1.0 / k.fx;
-  k.ify = 1.0 / k.fy;
-  return k;
-}
-__device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k);
-__device__ __forceinline__ void gn_params_local(GnLocal& L, const double* K) {
-  KPre k;
-  k.fx = K[0];
-  k.fy = K[4];
-  k.cx = K[2];
-  k.cy = K[5];
-  k.ifx = 1.0 / k.fx;
-  k.ify = 1.0 / k.fy;
-  gn_params_local_k(L, k);
-}
-__device__ __forceinline__ void gn_params_local_k(GnLocal& L, const KPre& k) {
-#pragma clang fp contract(fast)  // the fp64 scalar section may fuse: ~1e-16 before the values are rounded to float, a quarter fewer dependent instructions
-  // inverse pose [Ri | ti] = [R^T | -R^T t]
-  double Ri[9], ti[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = L.resultRt[j * 4 + i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) ti[i] = -(Ri[i * 3 + 0] * L.resultRt[3] + Ri[i * 3 + 1] * L.resultRt[7] + Ri[i * 3 + 2] * L.resultRt[11]);
-  // K = [fx 0 cx; 0 fy cy; 0 0 1] (level_K): K Ri K^-1 and K ti in closed form instead of a general
-  // 3x3 inverse and two 3x3 products; same values to ~1e-16 before the float rounding
-  const double fx = k.fx, fy = k.fy, cx = k.cx, cy = k.cy;
-  const double ifx = k.ifx, ify = k.ify;
-  double M[9];  // K * Ri
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    M[0 * 3 + j] = fx * Ri[0 * 3 + j] + cx * Ri[2 * 3 + j];
-    M[1 * 3 + j] = fy * Ri[1 * 3 + j] + cy * Ri[2 * 3 + j];
-    M[2 * 3 + j] = Ri[2 * 3 + j];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double h0 = M[i * 3 + 0] * ifx, h1 = M[i * 3 + 1] * ify;
-    L.krkinv[i * 3 + 0] = (float)h0;
-    L.krkinv[i * 3 + 1] = (float)h1;
-    L.krkinv[i * 3 + 2] = (float)(M[i * 3 + 2] - h0 * cx - h1 * cy);
-  }
-  L.kt[0] = (float)(fx * ti[0] + cx * ti[2]);
-  L.kt[1] = (float)(fy * ti[1] + cy * ti[2]);
-  L.kt[2] = (float)ti[2];
-}
-
-// One Gauss-Newton update (RGBDOdometry.cpp:472-585): combine the two 6x6 systems, pivoted LDLT in
-// fp64, se(3) update of resultRt, new float pose, projection parameters for `next_level`.
-// `kpre`: camera matrix of q.next_level prepared by the caller (resident kernels: once per level); null = derive it here.
-// `side`: store the side outputs lastA / lastb / last*Error / last*Count (only the values of a level's last iteration are ever read).
-__device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma, const SolveArgs& q,
-                                             const KPre* kpre = nullptr, bool side = true) {
-#pragma clang fp contract(fast)  // the fp64 scalar section may fuse: ~1e-16 before the values are rounded to float, a quarter fewer dependent instructions
-  float residual[2] = {0.f, 0.f};
-  if (q.icp) {
-    residual[0] = s_icp[27];
-    residual[1] = s_icp[28];
-  }
-  // the two symmetric systems are combined on their 21 + 6 unique entries (same expression per entry as the
-  // reference's full-matrix form, RGBDOdometry.cpp:531-552) and mirrored
-  double A[36], b[6], x[6];
-  {
-    const double w = (double)q.icpWeight;
-    const double ww = w * w;
-    int shift = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 7; ++j) {
-        const double vi = q.icp ? (double)s_icp[shift] : 0.0, vr = q.rgb ? (double)s_rgb[shift] : 0.0;
-        ++shift;
-        double v;
-        if (q.icp && q.rgb)
-          v = (j == 6) ? vr + w * vi : vr + ww * vi;
-        else
-          v = q.icp ? vi : vr;
-        if (j == 6)
-          b[i] = v;
-        else
-          A[j * 6 + i] = A[i * 6 + j] = v;
-      }
-  }
-  // A.ldlt().solve(b) (RGBDOdometry.cpp:554): unpivoted register LDL^T when A is safely positive
-  // definite, the pivoted routine (Eigen's semantics on degenerate systems) otherwise
-  if (!sm::ldlt_solve_spd<double, 6>(A, b, x)) sm::ldlt_solve_reg<double, 6>(A, b, x, 1.0 / 1.7976931348623157e308);
-
-  // OdometryProvider::computeUpdateSE3 (OdometryProvider.h:73-93)
-  double Rt[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) Rt[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  const double rvec[3] = {x[3], x[4], x[5]};
-  double R[9];
-  sm::rodrigues(rvec, R);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Rt[i * 4 + j] = R[i * 3 + j];
-  Rt[3] = x[0];
-  Rt[7] = x[1];
-  Rt[11] = x[2];
-  double prevRt[16], nr[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) prevRt[i] = L.resultRt[i];
-  // resultRt = Rt * resultRt with both last rows (0 0 0 1): the skipped terms are exact zeros
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      double v = Rt[i * 4 + 0] * prevRt[0 * 4 + j];
-      v += Rt[i * 4 + 1] * prevRt[1 * 4 + j];
-      v += Rt[i * 4 + 2] * prevRt[2 * 4 + j];
-      if (j == 3) v += Rt[i * 4 + 3];
-      nr[i * 4 + j] = v;
-    }
-  }
-  nr[12] = 0.0;
-  nr[13] = 0.0;
-  nr[14] = 0.0;
-  nr[15] = 1.0;
-
-  // rgbOdom = float(resultRt); currentT = [Rprev|tprev] * rgbOdom^-1 with the isometry inverse
-  float Ro[9], to[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = (float)nr[i * 4 + j];
-    to[i] = (float)nr[i * 4 + 3];
-  }
-  float RoT[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) RoT[i * 3 + j] = Ro[j * 3 + i];
-  float ti[3];
-  sm::mul3v<float>(RoT, to, ti);
-  ti[0] = -ti[0];
-  ti[1] = -ti[1];
-  ti[2] = -ti[2];
-  float Rprev[9], Rc[9], tc[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) Rprev[i] = L.Rprev[i];
-  sm::mul3<float>(Rprev, RoT, Rc);
-  sm::mul3v<float>(Rprev, ti, tc);
-
-  L.iters_run += 1;
-  if (side) {
-    L.lastRGBError = (float)(sqrt((double)sigma) / (double)rgbSize);
-    L.lastRGBCount = (float)rgbSize;
-    L.lastICPError = sqrtf(residual[0]) / residual[1];
-    L.lastICPCount = residual[1];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) L.lastA[i] = A[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) L.lastb[i] = b[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) L.resultRt[i] = nr[i];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) L.Rcurr[i] = Rc[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) L.tcurr[i] = tc[i] + L.tprev[i];
-
-  if (kpre) {
-    gn_params_local_k(L, *kpre);
-  } else {
-    double K[9];
-    level_K(q.fx, q.fy, q.cx, q.cy, q.next_level, K);
-    gn_params_local(L, K);
-  }
-}
-
-// run by the 256 threads of the last block of k_gn_pass2 (or of k_gn_pass1 when there is no
-// photometric term)
-__device__ void gn_solve_body(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt, int stride, int nblocks,
-                              const SolveArgs q) {
-  const int icp = q.icp, rgb = q.rgb, rgbOnly = q.rgbOnly, level = q.level, first_iter = q.first_iter, level_below = q.level_below;
-  const float fx = q.fx, fy = q.fy, cx = q.cx, cy = q.cy;
-  __shared__ float s_icp[kSE3];
-  __shared__ float s_rgb[kSE3];
-  __shared__ int s_cnt[2];
-  // everything the solving lane needs from the state block is fetched up front (uniform
-  // addresses), so these loads overlap the record fold instead of each costing its own round
-  // trip between dependent stores later on
-  double prevRt[16];
-  float Rprev[9], tprev[3];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) prevRt[i] = st->resultRt[i];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) Rprev[i] = st->Rprev[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) tprev[i] = st->tprev[i];
-  const int iters_before = st->iters_run[level];
-  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
-  if (st->level_done[level]) return;
-
-  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+template <bool ICP, bool RGB>
+__global__ __launch_bounds__(kBlock) void k_gn_pass1(TrackState* st, GnArgs a, long long* part_icp, int* __restrict__ part_cnt, int stride,
+                                                     int first_iter) {
+  if (st->level_done[a.level]) return;
+  __shared__ int s_E[2][8];
+  __shared__ double s_bias[2][32];
+  const int N = a.cols * a.rows;
+  if (threadIdx.x == 0) level_exponents(st, a, first_iter != 0, s_E[0], s_E[1]);
   __syncthreads();
-  if (rgb) fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
-  // both record sets in one sweep (when pass 2 was skipped by the rgbOnly break its records are
-  // stale; they are folded but never used)
-  if (icp && rgb)
-    fold_records256_t<true>(part_icp, part_rgb, nblocks, kSE3, s_icp, s_rgb);
-  else if (icp)
-    fold_records256(part_icp, nblocks, kSE3, s_icp);
-  else
-    fold_records256(part_rgb, nblocks, kSE3, s_rgb);
+  if (ICP && threadIdx.x < 32) canon::write_bias<6>(s_E[0], s_bias, threadIdx.x);
+  __syncthreads();
+  if (ICP) {
+    const IcpParams ip = icp_params_of(st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, a);
+    double acc[kSE3];
+    canon::acc_init<6>(acc, s_bias);
+    icp_accumulate(ip, a, blockIdx.x, gridDim.x, acc);
+    store_record<6>(acc, s_E[0], part_icp + (size_t)blockIdx.x * kRecWords);
+  }
+  if (RGB) {
+    const RgbResParams rp = rgb_params_of(st->krkinv, st->kt, a);
+    int cnt = 0, sig = 0;
+    for (int base = blockIdx.x * (kBlock * kPix); base < N; base += gridDim.x * (kBlock * kPix)) {
+      int idx[kPix], px[kPix], py[kPix];
+      RgbOwn ro[kPix];
+#pragma unroll
+      for (int p = 0; p < kPix; ++p) {
+        idx[p] = base + p * kBlock + (int)threadIdx.x;
+        const int ic = idx[p] < N ? idx[p] : 0;
+        py[p] = ic / a.cols;
+        px[p] = ic - py[p] * a.cols;
+        ro[p] = rgb_load_own_gated(a.rgb, px[p], py[p]);
+      }
+      RgbProj rr[kPix];
+      RgbModel rm[kPix];
+#pragma unroll
+      for (int p = 0; p < kPix; ++p) {
+        rr[p] = rgb_project<kTrackerFma>(rp, ro[p], px[p], py[p]);
+        rm[p] = rgb_load_model(a.rgb, rr[p]);
+      }
+#pragma unroll
+      for (int p = 0; p < kPix; ++p) {
+        dms_dataterm c;
+        int d2;
+        const bool ok = rgb_finish(rp, ro[p], rr[p], rm[p], px[p], py[p], c, d2);
+        if (idx[p] < N) {
+          if (ok) {
+            cnt += 1;
+            sig += d2;
+          }
+          Corr8 c8;
+          c8.zero_x = c.zero_x;
+          c8.zero_y = c.zero_y;
+          c8.diff = (short)f2i_rz(c.diff);
+          c8.valid = (short)c.valid;
+          a.corres[idx[p]] = c8;
+        }
+      }
+    }
+    __shared__ int lds[kBlock / kWave][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    cnt = wave_sum_to_lane63_i(cnt);
+    sig = wave_sum_to_lane63_i(sig);
+    if (lane == 63) {
+      lds[wid][0] = cnt;
+      lds[wid][1] = sig;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      int s = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += lds[w][threadIdx.x];
+      part_cnt[(size_t)threadIdx.x * stride + blockIdx.x] = s;
+    }
+  }
+}
+
+// every block folds the (≤1024) integer partials itself: integer sums are order-free, so
+// all blocks agree bit-for-bit and no extra launch is needed to publish σ.
+__device__ __forceinline__ void fold_count_pair(const int* __restrict__ part_cnt, int nb_cnt, int stride, int* s_tot /* LDS [2] */) {
+  __shared__ int s_cnt[kBlock / kWave][2];
+  int c = 0, g = 0;
+  for (int b = threadIdx.x; b < nb_cnt; b += blockDim.x) {
+    c += part_cnt[b];
+    g += part_cnt[(size_t)stride + b];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  c = wave_sum_to_lane63_i(c);
+  g = wave_sum_to_lane63_i(g);
+  if (lane == 63) {
+    s_cnt[wid][0] = c;
+    s_cnt[wid][1] = g;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    int s = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_cnt[w][threadIdx.x];
+    s_tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void k_gn_pass2(TrackState* st, GnArgs a, const int* __restrict__ part_cnt, int nb_cnt, int stride,
+                                                     int first_iter, long long* part_rgb) {
+  if (st->level_done[a.level]) return;
+  __shared__ int s_tot[2];
+  __shared__ int s_E[2][8];
+  __shared__ double s_bias[2][32];
+  fold_count_pair(part_cnt, nb_cnt, stride, s_tot);
+  const int rgbSize = s_tot[0], sigma = s_tot[1];
+  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
+  if (a.rgbOnly && sc::rgbonly_break(sigma, rgbSize, lastErr)) return;  // host `break`; k_gn_solve records it
+  if (threadIdx.x == 0) level_exponents(st, a, first_iter != 0, s_E[0], s_E[1]);
+  __syncthreads();
+  if (threadIdx.x < 32) canon::write_bias<6>(s_E[1], s_bias, threadIdx.x);
+  __syncthreads();
+  RgbStepParams p_;
+  p_.sigma = a.rgbOnly ? -1.f : sc::sigma_val(sigma, rgbSize);
+  p_.fx = a.fx;
+  p_.fy = a.fy;
+  p_.sobelScale = a.sobelScale;
+  double acc[kSE3];
+  canon::acc_init<6>(acc, s_bias);
+  rgb_accumulate(p_, a, blockIdx.x, gridDim.x, acc);
+  store_record<6>(acc, s_E[1], part_rgb + (size_t)blockIdx.x * kRecWords);
+}
+
+// One block: fold both record sets, check their grids (a reduction whose diagonal totals did not fit is repeated by this
+// block alone on a coarser grid — rare: the static guess of a call's first iteration, or a scene change between
+// iterations), then the scalar section.
+template <bool ICP, bool RGB>
+__global__ __launch_bounds__(kBlock) void k_gn_solve(TrackState* st, GnArgs a, const long long* part_icp, const long long* part_rgb,
+                                                      const int* part_cnt, int stride, int nblocks, SolveArgs q) {
+  const int level = q.level, first_iter = q.first_iter;
+  __shared__ long long s_ti[32], s_tr[32];
+  __shared__ float s_icp[32], s_rgb[32];
+  __shared__ int s_cnt[2];
+  __shared__ int s_E[2][8];
+  __shared__ double s_bias[2][32];
+  __shared__ double s_red[kBlock / kWave][32];
+  __shared__ int s_viol;
+  if (st->level_done[level]) return;
+  const float lastErr = first_iter ? 3.402823466e+38F : st->lastRGBError;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) level_exponents(st, a, first_iter != 0, s_E[0], s_E[1]);
+  __syncthreads();
+  if (RGB) fold_rows_i2(part_cnt, stride, nblocks, s_cnt);
   __syncthreads();
   const int rgbSize = s_cnt[0], sigma = s_cnt[1];
-  const bool brk = rgbOnly && rgbonly_break(sigma, rgbSize, lastErr);
+  const bool brk = q.rgbOnly && sc::rgbonly_break(sigma, rgbSize, lastErr);
   if (brk) {
     // host `break` (RGBDOdometry.cpp:466-469): the level ends here; the next level that runs
     // needs its own K in the projection parameters
     if (threadIdx.x == 0) {
       st->level_done[level] = 1;
-      double K[9];
-      level_K(fx, fy, cx, cy, level_below, K);
-      gn_params_from(st, prevRt, K);
+      double Rt[16];
+      for (int i = 0; i < 16; ++i) Rt[i] = st->resultRt[i];
+      sc::gn_params(Rt, sc::kpre_of(q.fx, q.fy, q.cx, q.cy, q.level_below), st->krkinv, st->kt);
     }
     return;
   }
+  if (ICP) fold_records_i64(part_icp, nblocks, s_ti);
+  if (RGB) fold_records_i64(part_rgb, nblocks, s_tr);
+  int retries = 0;
+  bool gave_up_icp = false, gave_up_rgb = false;
+  if (ICP) {
+    int r = 0;
+    for (;;) {
+      if (threadIdx.x == 0) s_viol = totals_violate<6>(s_ti) ? 1 : 0;
+      __syncthreads();
+      if (!s_viol) break;
+      if (++r > canon::kMaxRetries) {
+        gave_up_icp = true;
+        break;
+      }
+      if (threadIdx.x == 0) canon::retry_step<6>(s_E[0]);
+      __syncthreads();
+      if (threadIdx.x < 32) canon::write_bias<6>(s_E[0], s_bias, threadIdx.x);
+      __syncthreads();
+      const IcpParams ip = icp_params_of(st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, a);
+      double acc[kSE3];
+      canon::acc_init<6>(acc, s_bias);
+      icp_accumulate(ip, a, 0, 1, acc);
+      const double t = canon::block_fold<6, kBlock / kWave>(canon::wave_tree<6>(acc), s_red);
+      __syncthreads();
+      if (threadIdx.x < 32) s_ti[threadIdx.x] = (int)threadIdx.x < kSE3 ? canon::to_units(t, canon::value_exp<6>(s_E[0], threadIdx.x)) : 0ll;
+      __syncthreads();
+    }
+    retries += r > canon::kMaxRetries ? canon::kMaxRetries : r;
+  }
+  if (RGB) {
+    int r = 0;
+    for (;;) {
+      if (threadIdx.x == 0) s_viol = totals_violate<6>(s_tr) ? 1 : 0;
+      __syncthreads();
+      if (!s_viol) break;
+      if (++r > canon::kMaxRetries) {
+        gave_up_rgb = true;
+        break;
+      }
+      if (threadIdx.x == 0) canon::retry_step<6>(s_E[1]);
+      __syncthreads();
+      if (threadIdx.x < 32) canon::write_bias<6>(s_E[1], s_bias, threadIdx.x);
+      __syncthreads();
+      RgbStepParams p_;
+      p_.sigma = q.rgbOnly ? -1.f : sc::sigma_val(sigma, rgbSize);
+      p_.fx = a.fx;
+      p_.fy = a.fy;
+      p_.sobelScale = a.sobelScale;
+      double acc[kSE3];
+      canon::acc_init<6>(acc, s_bias);
+      rgb_accumulate(p_, a, 0, 1, acc);
+      const double t = canon::block_fold<6, kBlock / kWave>(canon::wave_tree<6>(acc), s_red);
+      __syncthreads();
+      if (threadIdx.x < 32) s_tr[threadIdx.x] = (int)threadIdx.x < kSE3 ? canon::to_units(t, canon::value_exp<6>(s_E[1], threadIdx.x)) : 0ll;
+      __syncthreads();
+    }
+    retries += r > canon::kMaxRetries ? canon::kMaxRetries : r;
+  }
   if (threadIdx.x != 0) return;
+  if (ICP) {
+    totals_to_float<6>(s_ti, s_E[0], s_icp);
+    if (gave_up_icp)
+      for (int k = 0; k < 28; ++k) s_icp[k] = 0.f;
+  }
+  if (RGB) {
+    totals_to_float<6>(s_tr, s_E[1], s_rgb);
+    if (gave_up_rgb)
+      for (int k = 0; k < 28; ++k) s_rgb[k] = 0.f;
+  }
 
-  GnLocal L;
+  sc::GnLocal L;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) L.resultRt[i] = prevRt[i];
+  for (int i = 0; i < 16; ++i) L.resultRt[i] = st->resultRt[i];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) L.Rprev[i] = Rprev[i];
+  for (int i = 0; i < 9; ++i) L.Rprev[i] = st->Rprev[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) L.tprev[i] = tprev[i];
-  L.iters_run = iters_before;
-  gn_step_core(L, s_icp, s_rgb, rgbSize, sigma, q);
+  for (int i = 0; i < 3; ++i) L.tprev[i] = st->tprev[i];
+  L.iters_run = st->iters_run[level];
+  sc::gn_step_core(L, s_icp, s_rgb, rgbSize, sigma, q, sc::kpre_of(q.fx, q.fy, q.cx, q.cy, q.next_level));
 
-  // ---- all stores at the end, nothing read back ----
   st->iters_run[level] = L.iters_run;
   st->lastRGBError = L.lastRGBError;
   st->lastRGBCount = L.lastRGBCount;
@@ -1005,14 +802,15 @@ __device__ void gn_solve_body(TrackState* st, const float* part_icp, const float
   for (int i = 0; i < 9; ++i) st->krkinv[i] = L.krkinv[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) st->kt[i] = L.kt[i];
-}
-
-// The solve stays its own launch: folding it into the last block of pass 2 (ticket + agent-scope
-// release/acquire, as k_so3_pass does) was measured 5 us SLOWER per iteration than the launch
-// boundary it removes, because the fences and the ticket sit on the critical path.
-__global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* part_icp, const float* part_rgb, const int* part_cnt,
-                                                   int stride, int nblocks, SolveArgs q) {
-  gn_solve_body(st, part_icp, part_rgb, part_cnt, stride, nblocks, q);
+  // exponents of the next reduction from this one's totals
+  for (int c = 0; c < 7; ++c) {
+    st->E_icp[c] = s_E[0][c];
+    st->E_rgb[c] = s_E[1][c];
+  }
+  if (ICP) canon::next_exponents<6>(s_icp, st->E_icp);
+  if (RGB) canon::next_exponents<6>(s_rgb, st->E_rgb);
+  st->have_E = 1;
+  st->canon_retries += retries;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1025,38 +823,31 @@ __global__ __launch_bounds__(256) void k_gn_solve(TrackState* st, const float* p
 // whole level:
 //   * everything pose independent is loaded ONCE per level into registers (own vertex / normal,
 //     photometric gate, own depth / intensity / gradient);
-//   * barrier A is a single relaxed agent-scope fetch_add whose 64-bit word carries the payload
-//     itself (35 bits sum of squared differences | 19 bits count | 10 bits arrivals) — integer
-//     sums are order free, so no memory has to be published and no fence is needed;
 //   * the correspondences never leave registers (no DataTerm image, no point-cloud image);
-//   * each block publishes one 256-byte record (29 ICP + 29 photometric sums) with write-through
-//     (sc1) stores, drains, and arrives at barrier B; then EVERY block gathers all records with
-//     sc1 loads, folds them in fp64 in a fixed order and runs the 6x6 solve itself.  All blocks
-//     hold bit-identical poses, so nothing is broadcast.  Records are double-buffered by iteration
-//     parity, which makes barrier B the only barrier needed around them.
-// Hand-off rules follow cdna_hip_programming.md G16 (every storing wave drains before the arrival,
-// relaxed polling, agent-scope words, bounded spins, words zeroed by an earlier kernel on the
-// stream); scripts/bench_gridbarrier.hip is the protocol's stand-alone visibility test.
+//   * both grid-wide sums are integer all-reduces in memory-side atomics: lane k of wave 0 holds the block's exact
+//     total of value k in grid units (canon.hpp) and adds it with ONE non-returning 64-bit agent-scope atomic to word
+//     [block % 8][k]; the same lane then polls its own 8 shard words until their arrival fields show every block — the
+//     total is then in its registers.  No record, no separate barrier, no gather; integer adds are order free, so the
+//     totals are bit-identical in every block, from run to run and on any grid.  The words of one shard are contiguous
+//     (one coalesced atomic instruction per shard region); with the 8 shards of a value in one cache line the atomics
+//     serialise per line (7.1 us instead of 1.9, scripts/bench_allreduce.hip);
+//   * every block then runs the 6x6 solve itself on identical totals: all blocks hold bit-identical poses, nothing is
+//     broadcast; host `break`s are uniform decisions every block takes from the same sums;
+//   * a reduction whose diagonal totals do not fit the grid its exponents promised (canon.hpp) is repeated by the whole
+//     grid — a uniform decision again — on a word set from the launch's pool.
+// Hand-off rules follow cdna_hip_programming.md G16 (relaxed polling, agent-scope words, bounded spins, words zeroed
+// by an earlier kernel on the stream); scripts/bench_gridbarrier.hip is the protocol's stand-alone visibility test.
 constexpr int kPB = 512;                 // 8 waves: 256 VGPRs per thread, half the reduction tail of 16 waves
 constexpr int kPWaves = kPB / kWave;
-constexpr int kRecFloats = 64;           // [0,29) ICP sums, [32,61) photometric sums
 constexpr int kMaxPersistBlocks = 256;   // one block per CU
-constexpr int kBarrierStride = 16 * 9;    // words per barrier: top word + 8 shard words, one 128-byte line each
-constexpr int kMaxBarriers = 10 + 3 * 20; // SO3 iterations + 2 per GN iteration (<= 10 per level on this path)
-constexpr int kSyncWords = kMaxBarriers * kBarrierStride;  // barrier words per tracking call
 constexpr unsigned kSpinLimit = 1u << 22;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct LevelArgs {
   int n_iter, level, level_below;
   int rgbOnly;
   float icpWeight;
   float fx, fy, cx, cy;  // full-resolution intrinsics
-  void* rec;             // [2][gridDim.x][kRecFloats] floats (or doubles with fp64 sums)
-  unsigned long long* sync;  // 2 barriers (kBarrierStride words each) per iteration, zero on entry
-  unsigned long long* ar;    // kArWords per iteration of this level, zero on entry (integer all-reduce)
-  int use_ar;                // 0: record protocol in every iteration
-  int ar_margin;             // headroom (bits) of the fixed-point scale over the previous totals (kArMargin)
+  unsigned long long* ar;    // kArSetsPerKernel word sets of kArWords, zero on entry: one per iteration, then the retry pool
   int ar_slack_shift;        // see ar_wait
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
@@ -1068,266 +859,23 @@ struct LevelArgs {
   float weightMultiplier;
 };
 
-// Grid barrier whose arrival word carries a payload (low 54 bits, summed) next to the arrival count
-// (top 10 bits).  Arrivals on one word serialise at ~12 ns each, so grids above 64 blocks arrive on
-// 8 shard words (block % 8, one cache line each) and the last arriver of a shard forwards the shard's
-// sum to the top word; everybody polls the top word (relaxed loads, s_sleep) until it shows all
-// shards.  `b` points at the barrier's kBarrierStride words, all zero before the launch.
-__device__ __forceinline__ int pk_shards() { return gridDim.x > 64 ? 8 : 1; }
-
-// thread 0 only, after a __syncthreads() that orders the block's work
-__device__ __forceinline__ void pk_arrive(unsigned long long* b, unsigned long long payload) {
-  const unsigned long long one = 1ull << 54, low = one - 1ull;
-  const int ns = pk_shards();
-  if (ns == 1) {
-    // single level: the top word counts blocks; pk_wait expects gridDim.x arrivals
-    __hip_atomic_fetch_add(b, one | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  const int sh = blockIdx.x & 7;
-  const unsigned long long members = (gridDim.x - sh + 7) >> 3;
-  const unsigned long long old = __hip_atomic_fetch_add(b + 16 * (sh + 1), one | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if ((old >> 54) + 1ull == members)  // last of the shard: its sum (mine included) goes up
-    __hip_atomic_fetch_add(b, one | (((old & low) + payload) & low), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// all threads; returns the completed top word (payload sum in the low 54 bits)
-__device__ __forceinline__ unsigned long long pk_wait(unsigned long long* b, int* timeout) {
-  __shared__ unsigned long long s_word;
-  if (threadIdx.x == 0) {
-    const unsigned long long need = pk_shards() == 1 ? (unsigned long long)gridDim.x : 8ull;
-    unsigned long long cur;
-    unsigned spins = 0;
-    for (;;) {
-      cur = __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((cur >> 54) >= need) break;
-      ++spins;
-      if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never hang the device
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    s_word = cur;
-  }
-  __syncthreads();
-  return s_word;
-}
-
-__device__ __forceinline__ unsigned long long pk_barrier(unsigned long long* b, unsigned long long payload, int* timeout) {
-  __syncthreads();
-  if (threadIdx.x == 0) pk_arrive(b, payload);
-  return pk_wait(b, timeout);
-}
-
-// block-wide sum of NV per-thread values (16 waves): DPP inside the wave, then the 16 wave partials
-// of each value sit in 8 neighbouring lanes (thread = value * 8 + wave) and are summed in fp64 by a
-// 3-step butterfly.  The total of value k comes back in thread k * 8 (pblock_owner()).
-template <int NV>
-__device__ __forceinline__ float pblock_reduce(float (&v)[NV], float (*s_red)[32]) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = threadIdx.x >> 6;
-  __syncthreads();  // s_red may still be read from the previous use
-  const float tot = wave_sum_transpose<NV>(v);
-  if (lane < NV) s_red[wid][lane] = tot;
-  __syncthreads();
-  float r = 0.f;
-  if (threadIdx.x < NV * kPWaves) r = (float)row8_sum_d((double)s_red[threadIdx.x & (kPWaves - 1)][threadIdx.x >> 3]);
-  return r;
-}
-template <int NV>
-__device__ __forceinline__ bool pblock_owner() {
-  return threadIdx.x < NV * kPWaves && (threadIdx.x & (kPWaves - 1)) == 0;
-}
-
-// Every block reads ALL records of parity `par` with write-through-coherent (sc1) 16-byte loads and
-// folds them in fp64 in a fixed order: thread (g = tid / 16, k4 = tid % 16) sums float4 column k4
-// of records g, g + 32, ...; then thread (value * 8 + sub) adds 4 of the 32 group sums and an 8-lane
-// butterfly finishes.  s_sums[0..63] holds the totals afterwards (identical bits in every block).
-template <typename Rsrc>
-__device__ __forceinline__ void pk_gather(Rsrc rsrc, int par, int nb, double (*s_grp)[16][4], float* s_sums) {
-  const int tid = threadIdx.x;
-  const int k4 = tid & 15, g = tid >> 4;
-  double f[4] = {0., 0., 0., 0.};
-  constexpr int U = kMaxPersistBlocks / 32;
-  u32x4 v[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int b = g + 32 * u;
-    const int bc = b < nb ? b : 0;
-    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((par * nb + bc) * kRecFloats + k4 * 4) * 4, 0, /*sc1*/ 16);
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    if (g + 32 * u < nb) {
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) f[cc] += (double)__uint_as_float(v[u][cc]);
-    }
-  }
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) s_grp[g][k4][cc] = f[cc];
-  __syncthreads();
-  {
-    const int j = tid >> 3, sub = tid & 7;
-    double t = s_grp[sub * 4][j >> 2][j & 3];
-    t += s_grp[sub * 4 + 1][j >> 2][j & 3];
-    t += s_grp[sub * 4 + 2][j >> 2][j & 3];
-    t += s_grp[sub * 4 + 3][j >> 2][j & 3];
-    t = row8_sum_d(t);
-    if (sub == 0) s_sums[j] = (float)t;
-  }
-  __syncthreads();
-}
-
-// ---- fp64-sum variant (DMS_SUMS=fp64) -------------------------------------------------------------------
-// Block-wide sum of NV per-thread fp32 values in fp64, through LDS: every thread parks its NV values
-// (value-major, s_t[k * kPB + thread]), then thread (k = tid / 16, seg = tid % 16) adds the 32 values of
-// threads seg * 32 .. seg * 32 + 31 of value k in fp64, in a fixed (bank-skewed) order, and a 16-lane fp64
-// butterfly finishes; the total of value k comes back in threads k * 16 .. k * 16 + 15.  Nothing is rounded
-// to fp32 on the way and the records are fp64: the block totals differ from an fp64 accumulation of the same
-// products by ~1e-10 of the sum of magnitudes instead of ~5e-9 (numerics).
-template <int NV>
-__device__ __forceinline__ double pblock_reduce_d(float (&v)[NV], float* s_t) {
-  static_assert(NV * 16 <= kPB, "one 16-thread group per value");
-  const int tid = threadIdx.x;
-  __syncthreads();  // s_t may still be read from its previous use (or as the gather scratch)
-#pragma unroll
-  for (int k = 0; k < NV; ++k) s_t[k * kPB + tid] = v[k];
-  __syncthreads();
-  double r = 0.0;
-  if (tid < NV * 16) {
-    const int k = tid >> 4, seg = tid & 15;
-    const float* col = s_t + k * kPB + seg * 32;
-    const int skew = 2 * seg + (k & 1);  // the 64 lanes of a wave spread over all 32 banks
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) r += (double)col[(i + skew) & 31];
-    r = row16_sum_d(r);
-  }
-  return r;
-}
-template <int NV>
-__device__ __forceinline__ bool pblock_owner_d() {
-  return threadIdx.x < NV * 16 && (threadIdx.x & 15) == 0;
-}
-// gather of fp64 records: thread (g = tid / 32, c2 = tid % 32) sums the pair of doubles c2 of records g, g + 16, ...
-template <typename Rsrc>
-__device__ __forceinline__ void pk_gather_d(Rsrc rsrc, int par, int nb, double* s_grp /* [16][64] */, float* s_sums) {
-  const int tid = threadIdx.x;
-  const int c2 = tid & 31, g = tid >> 5;
-  double f0 = 0.0, f1 = 0.0;
-  constexpr int U = 4;
-#pragma unroll
-  for (int h = 0; h < kMaxPersistBlocks / 16 / U; ++h) {
-    u32x4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int b = g + 16 * (h * U + u);
-      const int bc = b < nb ? b : 0;
-      v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((par * nb + bc) * kRecFloats + c2 * 2) * 8, 0, /*sc1*/ 16);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (g + 16 * (h * U + u) < nb) {
-        f0 += __longlong_as_double((long long)(((unsigned long long)v[u][1] << 32) | v[u][0]));
-        f1 += __longlong_as_double((long long)(((unsigned long long)v[u][3] << 32) | v[u][2]));
-      }
-    }
-  }
-  __syncthreads();  // the scratch aliases the reduce buffer: everybody is done reading that
-  s_grp[g * 64 + c2 * 2] = f0;
-  s_grp[g * 64 + c2 * 2 + 1] = f1;
-  __syncthreads();
-  {
-    const int j = tid >> 3, sub = tid & 7;
-    double t = s_grp[(2 * sub) * 64 + j] + s_grp[(2 * sub + 1) * 64 + j];
-    t = row8_sum_d(t);
-    if (sub == 0) s_sums[j] = (float)t;
-  }
-  __syncthreads();
-}
-
 // ---- grid-wide integer all-reduce in memory-side atomics ------------------------------------------------------
-// What barrier B + the record gather did in two steps (records published, barrier, every block reads every record)
-// is one step here: lane k of wave 0 converts the block's partial sum of value k to fixed point and adds it, with a
-// non-returning 64-bit agent-scope atomic, to word [block % 8][k]; the same lane then polls its own 8 shard words
-// until their arrival fields show every block — the total is then in its registers.  No record, no separate
-// barrier, no gather; integer adds are order free, so the totals are bit-identical in every block and from run to
-// run.  Measured stand-alone (scripts/bench_allreduce.hip, 200 blocks): 1.9 us against 4.1 us for the round-1
-// protocol; the words of one shard must be contiguous (one coalesced atomic instruction per shard region) — with
-// the 8 shards of a value in one cache line the atomics serialise per line (7.1 us).
-//   word = arrivals [63:58] | overflows [57:52] | field [51:0] = sum of (v + 2^46), |v| < 2^46, <= 32 blocks per shard
-// Fixed point needs a scale all blocks agree on BEFORE they add.  |sum_px J_i J_j| <= sqrt(T_ii T_jj) (Cauchy-
-// Schwarz, also for every block's partial sum), so the diagonal totals of the PREVIOUS iteration of the level bound
-// every product of this one up to how much the diagonals can grow in one iteration: the bound exponent of value
-// (i, j) is ceil((e_i + e_j) / 2) + kArMargin with T_ii < 2^e_i, which leaves 45 - 6 - log2(blocks) > 30 bits
-// below the totals while the diagonals stay within 2^-10 .. 2^6 of their previous values — the fp32 block records of
-// the round-1 path carry 24.  A block whose partial sum does not fit its bound adds an overflow mark instead; every
-// block then sees the mark in the completed word and the whole grid repeats this iteration's reduction with the
-// record protocol (the partial sums are still in registers).  The first iteration of a level has no previous totals
-// and uses the record protocol directly.
+//   sum word  = arrivals [63:58] | sum of (S + 2^52) [57:0], |S| < 2^52 grid units, <= 32 blocks per shard (canon::pack_word)
+//   pair word = arrivals [63:58] | sum of v [57:0], v = the block's correspondence count or sum of squared differences
 constexpr int kArShards = 8;
 constexpr int kArStride = 64;                       // words per shard: slots 0..28 ICP | 32..60 photometric
 constexpr int kArPairBase = kArShards * kArStride;  // then the count / sum-of-squares pair: one 128-byte line per shard (slots 0, 1),
 constexpr int kArPairStride = 16;                   // apart from the lines the 58 sums arrive on (its pollers would slow those atomics)
-constexpr int kArWords = kArPairBase + kArShards * kArPairStride;  // 5 KB per iteration
+constexpr int kArWords = kArPairBase + kArShards * kArPairStride;  // 5 KB per reduction
 constexpr int kArSlotCnt = 0, kArSlotSig = 1;
-constexpr int kArReductions = 10 + 3 * 10;          // SO3 iterations + GN iterations of the three levels (resident path: <= 10 each)
+constexpr int kArPool = 6;                          // extra word sets per resident launch for repeated reductions
+constexpr int kArSetsPerKernel = 10 + kArPool;      // <= 10 iterations per resident launch
+constexpr int kArSets = 4 * kArSetsPerKernel;       // SO3 + three levels
 
-__device__ __forceinline__ unsigned long long ar_pack(long long v, bool ovf) {
-  return (1ull << 58) | (ovf ? (1ull << 52) : 0ull) | (unsigned long long)((ovf ? 0ll : v) + (1ll << 46));
-}
-// partial sum p of a value whose magnitude is bounded by 2^eb
-__device__ __forceinline__ unsigned long long ar_encode(double p, int eb) {
-  const double scaled = ldexp(p, 45 - eb);
-  const bool ok = fabs(scaled) < 35184372088832.0;  // 2^45; false for NaN
-  return ar_pack(ok ? (long long)rint(scaled) : 0ll, !ok);
-}
-__device__ __forceinline__ double ar_decode(long long total, int eb) { return ldexp((double)total, eb - 45); }
-
-// smallest e with d < 2^e; a value that is not a positive finite number bounds nothing
-__device__ __forceinline__ int ar_exp_of(float d) {
-  if (!(d > 0.f) || !(d < 3.0e38f)) return -127;
-  int e;
-  (void)frexpf(d, &e);
-  return e;
-}
-// bound exponent of value k of an (N+1) x (N+1) upper-triangle layout (N Jacobian columns + residual; then the
-// residual square and the count): N = 6 for the 29 SE3 sums, N = 3 for the 11 SO3 sums.  `sums` = previous totals.
-// The two diagonal entries that bound value k (a lane constant: the resident kernels derive it once per launch);
-// packed as di | dj << 8, or -1 for the count.
-template <int N>
-__device__ __forceinline__ int ar_bound_idx(int k) {
-  constexpr int NP = N * (N + 3) / 2;
-  if (k > NP) return -1;  // the count: at most 2048 pixels per block
-  int i = N, j = N;       // k == NP: residual^2
-  if (k < NP) {
-    int off = 0;
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-      const int len = N + 1 - r;
-      if (k >= off && k < off + len) {
-        i = r;
-        j = r + (k - off);
-      }
-      off += len;
-    }
-  }
-  const int di = i == N ? NP : (N + 1) * i - (i * (i - 1)) / 2;
-  const int dj = j == N ? NP : (N + 1) * j - (j * (j - 1)) / 2;
-  return di | (dj << 8);
-}
-__device__ __forceinline__ int ar_bound_exp_at(const float* sums, int idx, int margin) {
-  if (idx < 0) return 20;
-  const int eb = ((ar_exp_of(sums[idx & 255]) + ar_exp_of(sums[idx >> 8]) + 1) >> 1) + margin;
-  return eb < -200 ? -200 : (eb > 200 ? 200 : eb);
-}
-template <int N>
-__device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin) {
-  return ar_bound_exp_at(sums, ar_bound_idx<N>(k), margin);
-}
+__device__ __forceinline__ unsigned long long pair_pack(unsigned long long v) { return (1ull << 58) + v; }
 
 // wave 0, all 64 lanes: every lane with `mine` polls the 8 shard words of `slot` until they show nb arrivals.
-// tot = signed total, ovf = overflow marks seen.  Bounded: a timeout sets *timeout and returns false.
+// fld = sum of the 8 fields.  Bounded: a timeout sets *timeout and returns false.
 // `probe` >= 0: first only lanes 0-7 watch the 8 shard words of slot `probe` (the slot added last) and the full sweep
 // starts when those are complete — 58 lanes of every waiting block sweeping the words that are still receiving
 // atomics slows the arrivals down (measured in the level-0 kernel: 4.7 us per reduction against 1.9 stand-alone).
@@ -1335,7 +883,7 @@ __device__ __forceinline__ int ar_bound_exp(const float* sums, int k, int margin
 // complete, so the last arrivals are seen by the sweep itself instead of costing one more round trip after the probe
 // (the heavy polling then lasts only for the tail of the arrivals).
 template <int STRIDE>
-__device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, bool mine, int nb, long long& tot, int& ovf, int* timeout,
+__device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, bool mine, int nb, unsigned long long& fld_out, int* timeout,
                                         int probe = -1, int slack = 0) {
   unsigned spins = 0;
   if (probe >= 0) {
@@ -1351,7 +899,7 @@ __device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, b
     }
   }
   for (;;) {
-    unsigned long long arr = 0, fld = 0, ov = 0;
+    unsigned long long arr = 0, fld = 0;
     if (mine) {
       unsigned long long q[kArShards];
 #pragma unroll
@@ -1359,82 +907,59 @@ __device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, b
 #pragma unroll
       for (int s = 0; s < kArShards; ++s) {
         arr += q[s] >> 58;
-        ov += (q[s] >> 52) & 63ull;
-        fld += q[s] & ((1ull << 52) - 1ull);
+        fld += q[s] & ((1ull << 58) - 1ull);
       }
     }
     const bool done = !mine || arr == (unsigned long long)nb;
     if (__builtin_amdgcn_ballot_w64(done) == ~0ull) {
-      tot = (long long)fld - (long long)arr * (1ll << 46);
-      ovf = (int)ov;
+      fld_out = fld;
       return true;
     }
     ++spins;
     if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
       __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never hang the device
-      tot = 0;
-      ovf = 0;
+      fld_out = 0;
       return false;
     }
     __builtin_amdgcn_s_sleep(1);
   }
 }
+// completed sum words -> signed total in grid units
+__device__ __forceinline__ long long ar_total(unsigned long long fld, int nb) { return (long long)fld - (long long)nb * (1ll << 52); }
 
-// block-wide sum of NV per-thread values whose totals are wanted in wave 0: DPP inside the wave, then lane k < NV
-// of wave 0 adds the 8 wave partials of value k in fp64 (fixed order) — the lane that owns value k's atomic.
-template <int NV>
-__device__ __forceinline__ double pblock_reduce_w0(float (&v)[NV], float (*s_red)[32]) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = threadIdx.x >> 6;
-  __syncthreads();  // s_red may still be read from the previous use
-  const float tot = wave_sum_transpose<NV>(v);
-  if (lane < NV) s_red[wid][lane] = tot;
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x < NV) {
-#pragma unroll
-    for (int w = 0; w < kPWaves; ++w) r += (double)s_red[w][threadIdx.x];
-  }
-  return r;
+// bit k set: value k of the 29-value layout is a diagonal entry (the check of canon.hpp applies to it)
+__device__ __forceinline__ constexpr unsigned se3_diag_mask() {
+  unsigned m = 0;
+  for (int c = 0; c <= 6; ++c) m |= 1u << canon::Layout<6>::diag(c);
+  return m;
 }
-
-// LDS of the two sum variants as typed arrays (casts from a raw byte buffer cost the fp32 variant ~2 %: the
-// compiler no longer sees the arrays' shapes and alignment)
-template <bool F64, int NV>
-struct SumLds;
-template <int NV>
-struct SumLds<false, NV> {
-  float s_red[kPWaves][32];
-  double s_grp[32][16][4];
-};
-template <int NV>
-struct SumLds<true, NV> {
-  __attribute__((aligned(16))) float s_t[NV * kPB];  // reduce buffer; its first 8 KB double as the gather scratch [16][64] doubles
-};
+__device__ __forceinline__ constexpr unsigned so3_diag_mask() {
+  unsigned m = 0;
+  for (int c = 0; c <= 3; ++c) m |= 1u << canon::Layout<3>::diag(c);
+  return m;
+}
 
 // EXIT: leave the level after an iteration without any correspondence (below).  A template parameter because the
 // mere presence of that exit costs the frame-to-model tracker ~1 % (codegen of the resident loop); the frame step
 // instantiates it for the model-to-model pass only.
-template <bool ICP, bool RGB, int P, bool F64, bool EXIT>
+template <bool ICP, bool RGB, int P, bool EXIT>
 __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
   constexpr bool kFma = kTrackerFma;
-  // (the precise variant adds the rounded fp32 products, as the oracle does: a fused accumulate keeps the unrounded product, a
-  // ~3e-8 per-term difference that the fp64 sums of this variant would otherwise preserve)
-  constexpr bool kFmaAcc = kTrackerFma && !F64;
-  __shared__ GnLocal s;
+  __shared__ sc::GnLocal s;
   __shared__ int s_redi[kPWaves][2];
-  __shared__ SumLds<F64, kSE3> lds;
-  __shared__ float s_sums[kRecFloats];
+  __shared__ double s_red[kPWaves][32];
+  __shared__ double s_bias[2][2][32];  // [ICP | photometric][lanes 0-31 | 32-63][value]
+  __shared__ int s_E[2][8];            // column exponents of the two reductions
+  __shared__ float s_sums[64];
   __shared__ int s_none;
   __shared__ int s_done;
   __shared__ int s_cs[2];
-  __shared__ int s_ovf;
-  __shared__ KPre s_k[2];
+  __shared__ int s_viol;
+  __shared__ int s_retries;
+  __shared__ sc::KPre s_k[2];
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
-  int eb_icp = 0, eb_rgb = 0, eb_slot = 0;  // wave 0: bound exponents of the values this lane adds / polls (all-reduce)
-  const int eb_idx = ar_bound_idx<6>(tid < kSE3 ? tid : 0);  // (lane constants of ar_bound_exp)
-  const int eb_idx_hi = ar_bound_idx<6>(tid >= 32 && tid - 32 < kSE3 ? tid - 32 : 0);
+  int eb_icp = 0, eb_rgb = 0;  // wave 0: bound exponents of the values this lane adds (lanes 0-28) / polls (lane k: ICP k, lane 32 + k: photometric k)
   // optional phase clock (block 0, thread 0): wall_clock64 ticks (10 ns) summed per phase into L.prof
   // (accumulated in LDS and flushed once at the end: a global read-modify-write per phase would
   // stall wave 0 for a memory round trip each time and distort what it measures)
@@ -1451,6 +976,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 
   if (tid == 0) {
     s_none = 0;
+    s_retries = 0;
     s_done = st->level_done[L.level];
     for (int i = 0; i < 16; ++i) s.resultRt[i] = st->resultRt[i];
     for (int i = 0; i < 9; ++i) {
@@ -1471,6 +997,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     s.iters_run = st->iters_run[L.level];
     for (int i = 0; i < 36; ++i) s.lastA[i] = st->lastA[i];
     for (int i = 0; i < 6; ++i) s.lastb[i] = st->lastb[i];
+    level_exponents(st, a, true, s_E[0], s_E[1]);
+    // camera matrices of this level and of the next one that runs, for the scalar section (thread 0 uses them)
+    // (kept in LDS: 24 more live registers per lane would spill the 256-register pixel loop)
+    s_k[0] = sc::kpre_of(L.fx, L.fy, L.cx, L.cy, L.level);
+    s_k[1] = sc::kpre_of(L.fx, L.fy, L.cx, L.cy, L.level_below);
   }
 
   // ---- pose-independent per-pixel data, once per level ----
@@ -1493,53 +1024,25 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
   }
   const float invFx = 1.0f / a.fx, invFy = 1.0f / a.fy;  // as projectToPointCloud passes them
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(L.rec, 0, 2 * nb * kRecFloats * (F64 ? 8 : 4), 0x00020000);
   __syncthreads();
   if (s_done) return;  // level already ended (uniform: every block read the same flag)
+  if (tid < 64) {
+    canon::write_bias<6>(s_E[tid >> 5], s_bias[tid >> 5], tid & 31);
+    eb_icp = canon::value_exp<6>(s_E[0], tid & 31);
+    eb_rgb = canon::value_exp<6>(s_E[1], tid & 31);
+  }
+  __syncthreads();
 
   bool ended = false;
-  // camera matrices of this level and of the next one that runs, for the scalar section (thread 0 uses them)
-  // (kept in LDS: 24 more live registers per lane would spill the 256-register pixel loop)
-  if (tid == 0) {
-    s_k[0] = kpre_of(L.fx, L.fy, L.cx, L.cy, L.level);
-    s_k[1] = kpre_of(L.fx, L.fy, L.cx, L.cy, L.level_below);
-  }
+  int pool_used = 0;  // word sets of the retry pool consumed so far (uniform)
+  bool on_pool = false;
   phase(0);
-  for (int it = 0; it < L.n_iter; ++it) {
-    const int par = it & 1;
+  for (int it = 0; it < L.n_iter;) {
     // ---- pass 1: correspondences + ICP rows ----
     IcpParams ip;
     RgbResParams rp;
-    if (ICP) {
-      ip.Rcurr.r0 = mk3(s.Rcurr[0], s.Rcurr[1], s.Rcurr[2]);
-      ip.Rcurr.r1 = mk3(s.Rcurr[3], s.Rcurr[4], s.Rcurr[5]);
-      ip.Rcurr.r2 = mk3(s.Rcurr[6], s.Rcurr[7], s.Rcurr[8]);
-      ip.tcurr = mk3(s.tcurr[0], s.tcurr[1], s.tcurr[2]);
-      ip.Rprev_inv.r0 = mk3(s.Rprev_inv[0], s.Rprev_inv[1], s.Rprev_inv[2]);
-      ip.Rprev_inv.r1 = mk3(s.Rprev_inv[3], s.Rprev_inv[4], s.Rprev_inv[5]);
-      ip.Rprev_inv.r2 = mk3(s.Rprev_inv[6], s.Rprev_inv[7], s.Rprev_inv[8]);
-      ip.tprev = mk3(s.tprev[0], s.tprev[1], s.tprev[2]);
-      ip.fx = a.fx;
-      ip.fy = a.fy;
-      ip.cx = a.cx;
-      ip.cy = a.cy;
-      ip.distThres = a.distThres;
-      ip.angleThres = a.angleThres;
-      ip.dist2Le = a.dist2Le;
-      ip.sine2Le = a.sine2Le;
-      ip.cols = a.cols;
-      ip.rows = a.rows;
-    }
-    if (RGB) {
-      rp.krkinv.r0 = mk3(s.krkinv[0], s.krkinv[1], s.krkinv[2]);
-      rp.krkinv.r1 = mk3(s.krkinv[3], s.krkinv[4], s.krkinv[5]);
-      rp.krkinv.r2 = mk3(s.krkinv[6], s.krkinv[7], s.krkinv[8]);
-      rp.kt = mk3(s.kt[0], s.kt[1], s.kt[2]);
-      rp.minScale = a.minScale;
-      rp.maxDepthDelta = a.maxDepthDelta;
-      rp.cols = a.cols;
-      rp.rows = a.rows;
-    }
+    if (ICP) ip = icp_params_of(s.Rcurr, s.tcurr, s.Rprev_inv, s.tprev, a);
+    if (RGB) rp = rgb_params_of(s.krkinv, s.kt, a);
     const float lastErr = (it == 0) ? 3.402823466e+38F : s.lastRGBError;
 
     IcpProj ir[P];
@@ -1557,9 +1060,8 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         rm[p] = rgb_load_model(a.rgb, rr[p]);
       }
     }
-    float acc[kSE3];
-#pragma unroll
-    for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
+    float rows[P][7];
+    bool found[P];
     int cnt = 0, sig = 0;
     dms_dataterm c[P];
 #pragma unroll
@@ -1575,14 +1077,12 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         }
       }
       if (ICP) {
-        float row[7];
-        bool found = icp_finish<kFma>(ip, io[p], ir[p], im[p], row);
+        found[p] = icp_finish<kFma>(ip, io[p], ir[p], im[p], rows[p]);
         if (!live) {
-          found = false;
+          found[p] = false;
 #pragma unroll
-          for (int k = 0; k < 7; ++k) row[k] = 0.f;
+          for (int k = 0; k < 7; ++k) rows[p][k] = 0.f;
         }
-        accumulate_se3<kFmaAcc>(acc, row, found);
       }
     }
     phase(1);
@@ -1590,17 +1090,13 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     // grid-wide reductions): pass 1 done | count pair complete | pass 2 + block sum done | totals complete
     const bool stamp = L.prof && L.level == 0 && it == L.n_iter / 2 && tid == 0;
     if (stamp) L.prof[48 + blockIdx.x * 8 + 0] = wall_clock64();
-    float* my_rec = reinterpret_cast<float*>(L.rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
-    double* my_rec_d = reinterpret_cast<double*>(L.rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
-    // integer all-reduce (fp32-sum variant): the count / sum-of-squares pair always; the 58 sums from the level's
-    // second iteration on (the first has no previous totals to scale by) unless a block's partial sum overflows
-    unsigned long long* arw = L.ar + (size_t)it * kArWords + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride;
-    const unsigned long long* arp = L.ar + (size_t)it * kArWords;
-    unsigned long long* arq = L.ar + (size_t)it * kArWords + kArPairBase + (size_t)(blockIdx.x & (kArShards - 1)) * kArPairStride;
-    const bool use_ar = !F64 && L.use_ar && it > 0;
+    const size_t set = (size_t)(on_pool ? 10 + pool_used - 1 : it) * kArWords;
+    unsigned long long* arw = L.ar + set + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride;
+    const unsigned long long* arp = L.ar + set;
+    unsigned long long* arq = L.ar + set + kArPairBase + (size_t)(blockIdx.x & (kArShards - 1)) * kArPairStride;
     int rgbSize = 0, sigma = 0;
     if (RGB) {
-      // ---- barrier A, arrival: the count and the sum of squared differences ----
+      // ---- count / sum-of-squares pair, arrival ----
       const int lane = tid & 63, wid = tid >> 6;
       cnt = wave_sum_to_lane63_i(cnt);
       sig = wave_sum_to_lane63_i(sig);
@@ -1613,72 +1109,46 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         const int t = row8_sum_i(tid < 16 ? s_redi[tid & 7][tid >> 3] : 0);
         const unsigned long long cb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 0);
         const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(t, 8);
-        if constexpr (F64) {
-          if (tid == 0) pk_arrive(L.sync + (2 * it) * kBarrierStride, (cb << 35) | sb);
-        } else {
-          if (tid < 2)
-            __hip_atomic_fetch_add(arq + tid, ar_pack((long long)(tid == kArSlotCnt ? cb : sb), false), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid < 2) __hip_atomic_fetch_add(arq + tid, pair_pack(tid == kArSlotCnt ? cb : sb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     phase(2);
-    double p_icp = 0.0, p_rgb = 0.0;  // fp32-sum variant: block totals of value k in thread k < 29
     if (ICP) {  // the ICP block sum and its publication overlap the other blocks' arrivals
-      if constexpr (F64) {
-        const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);
-        if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        p_icp = pblock_reduce_w0<kSE3>(acc, lds.s_red);
-        if (tid < kSE3) {
-          if (use_ar)
-            __hip_atomic_fetch_add(arw + tid, ar_encode(p_icp, eb_icp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else
-            __hip_atomic_store(my_rec + tid, (float)p_icp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      const double p_icp = canon::block_sum<6, P, kPWaves>(rows, found, s_bias[0], s_red);
+      if (tid < kSE3) __hip_atomic_fetch_add(arw + tid, canon::pack_word(canon::to_units(p_icp, eb_icp)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (RGB) {
-      if constexpr (F64) {
-        const unsigned long long word = pk_wait(L.sync + (2 * it) * kBarrierStride, &st->sync_timeout);
-        rgbSize = (int)((word >> 35) & 0x7FFFFull);
-        sigma = (int)(word & 0x7FFFFFFFFull);
-      } else {
-        if (tid < 64) {
-          long long tot;
-          int ov;
-          if (stamp) L.prof[48 + blockIdx.x * 8 + 4] = wall_clock64();  // poll start
-          ar_wait<kArPairStride>(arp + kArPairBase, tid, tid < 2, nb, tot, ov, &st->sync_timeout);
-
-          const int c0 = __builtin_amdgcn_readlane((int)tot, kArSlotCnt), s0 = __builtin_amdgcn_readlane((int)tot, kArSlotSig);
-          if (tid == 0) {
-            s_cs[0] = c0;
-            s_cs[1] = s0;  // (the low 32 bits: an int sum, as in the reference)
-          }
+      if (tid < 64) {
+        unsigned long long fld;
+        if (stamp) L.prof[48 + blockIdx.x * 8 + 4] = wall_clock64();  // poll start
+        ar_wait<kArPairStride>(arp + kArPairBase, tid, tid < 2, nb, fld, &st->sync_timeout);
+        const int c0 = __builtin_amdgcn_readlane((int)fld, kArSlotCnt), s0 = __builtin_amdgcn_readlane((int)fld, kArSlotSig);
+        if (tid == 0) {
+          s_cs[0] = c0;
+          s_cs[1] = s0;  // (the low 32 bits: an int sum, as in the reference)
         }
-        __syncthreads();
-        rgbSize = s_cs[0];
-        sigma = s_cs[1];
       }
+      __syncthreads();
+      rgbSize = s_cs[0];
+      sigma = s_cs[1];
       phase(3);
       if (stamp) L.prof[48 + blockIdx.x * 8 + 1] = wall_clock64();
-      if (L.rgbOnly && rgbonly_break(sigma, rgbSize, lastErr)) {
+      if (L.rgbOnly && sc::rgbonly_break(sigma, rgbSize, lastErr)) {
         // host `break` (RGBDOdometry.cpp:466-469): the level ends; the next level needs its own K
         if (tid == 0) {
-          double K[9];
-          level_K(L.fx, L.fy, L.cx, L.cy, L.level_below, K);
-          gn_params_local(s, K);
+          double Rt[16];
+          for (int i = 0; i < 16; ++i) Rt[i] = s.resultRt[i];
+          sc::gn_params(Rt, s_k[1], s.krkinv, s.kt);
         }
         ended = true;
         break;
       }
       // ---- pass 2: photometric rows from the registers ----
       RgbStepParams p_;
-      p_.sigma = L.rgbOnly ? -1.f : sigma_val(sigma, rgbSize);
+      p_.sigma = L.rgbOnly ? -1.f : sc::sigma_val(sigma, rgbSize);
       p_.fx = a.fx;
       p_.fy = a.fy;
       p_.sobelScale = a.sobelScale;
-#pragma unroll
-      for (int k = 0; k < kSE3; ++k) acc[k] = 0.f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         // the model pixel's cloud point, exactly as k_projectPoints builds it from lastDepth
@@ -1687,62 +1157,56 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         in.pt = mk3((((float)c[p].zero_x - a.cx) * z) * invFx, (((float)c[p].zero_y - a.cy) * z) * invFy, z);
         in.gx = gx[p];
         in.gy = gy[p];
-        float row[7];
-        rgb_row_finish<kFma>(p_, c[p], in, row);
-        accumulate_se3<kFmaAcc>(acc, row, c[p].valid != 0);
+        rgb_row_finish<kFma>(p_, c[p], in, rows[p]);
+        found[p] = c[p].valid != 0;
       }
-      if constexpr (F64) {
-        const double tot = pblock_reduce_d<kSE3>(acc, lds.s_t);
-        if (pblock_owner_d<kSE3>()) __hip_atomic_store(my_rec_d + 32 + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        p_rgb = pblock_reduce_w0<kSE3>(acc, lds.s_red);
-        if (tid < kSE3) {
-          if (use_ar)
-            __hip_atomic_fetch_add(arw + 32 + tid, ar_encode(p_rgb, eb_rgb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else
-            __hip_atomic_store(my_rec + 32 + tid, (float)p_rgb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      const double p_rgb = canon::block_sum<6, P, kPWaves>(rows, found, s_bias[1], s_red);
+      if (tid < kSE3) __hip_atomic_fetch_add(arw + 32 + tid, canon::pack_word(canon::to_units(p_rgb, eb_rgb)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     phase(4);
     if (stamp) L.prof[48 + blockIdx.x * 8 + 2] = wall_clock64();
-    bool records = !use_ar;
-    if constexpr (!F64) {
-      if (use_ar) {
-        // ---- the totals arrive in the lanes that poll them ----
-        if (tid < 64) {
-          const bool mine = (ICP && tid < kSE3) || (RGB && tid >= 32 && tid < 32 + kSE3);
-          long long tot;
-          int ov;
-          ar_wait<kArStride>(arp, tid, mine, nb, tot, ov, &st->sync_timeout, RGB ? 32 : 0, L.ar_slack_shift < 31 ? nb >> L.ar_slack_shift : 0);
-
-          s_sums[tid] = mine ? (float)ar_decode(tot, eb_slot) : 0.f;
-          const unsigned long long any = __builtin_amdgcn_ballot_w64(mine && ov != 0);
-          if (tid == 0) s_ovf = any != 0ull ? 1 : 0;
-        }
-        __syncthreads();
-        records = s_ovf != 0;  // uniform over the grid: every block read the same completed words
-        if (records && tid < kSE3) {  // a partial sum did not fit its bound: this iteration falls back to the records
-          if (ICP) __hip_atomic_store(my_rec + tid, (float)p_icp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (RGB) __hip_atomic_store(my_rec + 32 + tid, (float)p_rgb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+    // ---- the totals arrive in the lanes that poll them ----
+    if (tid < 64) {
+      const int k = tid & 31;
+      const bool mine = k < kSE3 && (tid < 32 ? ICP : RGB);
+      unsigned long long fld;
+      ar_wait<kArStride>(arp, tid, mine, nb, fld, &st->sync_timeout, RGB ? 32 : 0, L.ar_slack_shift < 31 ? nb >> L.ar_slack_shift : 0);
+      const long long tot = ar_total(fld, nb);
+      s_sums[tid] = mine ? canon::from_units(tot, tid < 32 ? eb_icp : eb_rgb) : 0.f;
+      const bool bad = mine && ((se3_diag_mask() >> k) & 1u) && tot >= canon::kViolation;
+      const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+      if (tid == 0) s_viol = ((any & 0xffffffffull) ? 1 : 0) | ((any >> 32) ? 2 : 0);
     }
-    if (records) {
-      // ---- barrier B: records published ----
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pk_barrier(L.sync + (2 * it + 1) * kBarrierStride, 0ull, &st->sync_timeout);
-      phase(5);
-      // ---- gather: every block folds every record (fixed order => identical sums everywhere) ----
-      if constexpr (F64)
-        pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
-      else
-        pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
-    } else {
-      phase(5);
-    }
-    phase(6);
+    __syncthreads();
+    phase(5);
     if (stamp) L.prof[48 + blockIdx.x * 8 + 3] = wall_clock64();
+    if (s_viol) {
+      // a diagonal total does not fit the grid its exponents promised: every block saw the same totals, so the whole
+      // grid raises the exponents of that reduction and repeats the iteration on a word set of the pool (uniform)
+      const int viol = s_viol;
+      __syncthreads();  // (s_viol is rewritten by the repeated iteration)
+      pool_used += 1;
+      on_pool = true;
+      if (pool_used > kArPool) {  // no word set left: the call fails like a barrier timeout (prior pose kept, nothing fused)
+        if (tid == 0) __hip_atomic_store(&st->sync_timeout, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ended = true;
+        break;
+      }
+      if (tid == 0) {
+        if (viol & 1) canon::retry_step<6>(s_E[0]);
+        if (viol & 2) canon::retry_step<6>(s_E[1]);
+        s_retries += (viol & 1) + ((viol >> 1) & 1);  // (counted per reduction, as the oracle does)
+      }
+      __syncthreads();
+      if (tid < 64) {
+        canon::write_bias<6>(s_E[tid >> 5], s_bias[tid >> 5], tid & 31);
+        eb_icp = canon::value_exp<6>(s_E[0], tid & 31);
+        eb_rgb = canon::value_exp<6>(s_E[1], tid & 31);
+      }
+      __syncthreads();
+      continue;
+    }
+    on_pool = false;
     if (tid == 0) {
       SolveArgs q;
       q.icp = ICP ? 1 : 0;
@@ -1764,23 +1228,32 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       q.cx = L.cx;
       q.cy = L.cy;
       const bool last = it == L.n_iter - 1 || none;
-      const KPre kp = s_k[last ? 1 : 0];
+      const sc::KPre kp = s_k[last ? 1 : 0];
       // (with rgbOnly the level may end at any iteration's break: the side outputs are then the previous iteration's)
-      gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q, &kp, last || L.rgbOnly);
+      sc::gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q, kp, last || L.rgbOnly);
       if (none) {
         s.iters_run += L.n_iter - 1 - it;
         s_none = 1;
       }
-    }
-    __syncthreads();
-    if constexpr (!F64) {
-      if (tid < 64) {  // scale of every value for the next iteration, from the totals all blocks hold
-        eb_icp = ar_bound_exp_at(s_sums, eb_idx, L.ar_margin);
-        eb_rgb = ar_bound_exp_at(s_sums + 32, eb_idx, L.ar_margin);
-        eb_slot = tid < 32 ? eb_icp : ar_bound_exp_at(s_sums + 32, eb_idx_hi, L.ar_margin);
+    } else if (tid >= 64 && tid < 128) {
+      // wave 1, beside the solve: exponents and bias table of the next reduction from this one's totals (canon.hpp)
+      const int set_ = (tid - 64) >> 5, k = tid & 31;
+      if ((set_ == 0 && ICP) || (set_ == 1 && RGB)) {
+        int E[7];
+#pragma unroll
+        for (int c2 = 0; c2 < 7; ++c2) E[c2] = s_E[set_][c2];
+        canon::next_exponents<6>(s_sums + 32 * set_, E);
+        canon::write_bias<6>(E, s_bias[set_], k);
+        if (k < 7) s_E[set_][k] = E[k];
       }
     }
+    __syncthreads();
+    if (tid < 64) {
+      eb_icp = canon::value_exp<6>(s_E[0], tid & 31);
+      eb_rgb = canon::value_exp<6>(s_E[1], tid & 31);
+    }
     phase(7);
+    ++it;
     if constexpr (EXIT) {
       if (s_none) break;
     }
@@ -1806,6 +1279,12 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     st->iters_run[L.level] = s.iters_run;
     for (int i = 0; i < 36; ++i) st->lastA[i] = s.lastA[i];
     for (int i = 0; i < 6; ++i) st->lastb[i] = s.lastb[i];
+    for (int c2 = 0; c2 < 7; ++c2) {
+      st->E_icp[c2] = s_E[0][c2];
+      st->E_rgb[c2] = s_E[1][c2];
+    }
+    st->have_E = 1;
+    st->canon_retries += s_retries;
     if (L.finalize) {  // == k_track_finalize, from the values this thread holds
       float tc[3], Rc[9];
       for (int i = 0; i < 3; ++i) tc[i] = s.tcurr[i];
@@ -1844,21 +1323,19 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 
 // ---------------------------------------------------------------------------------------
 // Persistent SO3 pre-alignment: all (<= 10) iterations in one launch, same protocol as k_gn_level
-// with one barrier per iteration (records double-buffered).  The state block is copied into LDS
+// with one all-reduce per iteration.  The state block is copied into LDS
 // and the unchanged scalar code runs on the copy; block 0 writes it back at the end.
 // ---------------------------------------------------------------------------------------
-template <bool F64>
 __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
-                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows, void* rec,
-                                                   unsigned long long* sync, unsigned long long* ar, int use_ar_arg, SolveCam cam,
-                                                   int first_gn_level, int max_iter) {
+                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows,
+                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias) {
   __shared__ TrackState s;
-  __shared__ int s_ovf;
-  int eb_mine = 0;  // wave 0, lane k < 11: bound exponent of value k (integer all-reduce, see ar_bound_exp)
-  const int eb_idx = ar_bound_idx<3>((int)threadIdx.x < kSO3 ? (int)threadIdx.x : 0);
-  static_assert(kSO3 * kPB * 4 >= 16 * 64 * 8, "gather scratch fits the reduce buffer");
-  __shared__ SumLds<F64, kSO3> lds;
-  __shared__ float s_sums[kRecFloats];
+  __shared__ int s_viol;
+  __shared__ int s_E[4];
+  __shared__ double s_bias[2][32];
+  __shared__ double s_red[kPWaves][32];
+  __shared__ float s_sums[32];
+  int eb_mine = 0;  // wave 0, lane k < 11: bound exponent of value k
   const int tid = threadIdx.x;
   const int nb = gridDim.x;
   {
@@ -1866,85 +1343,96 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
     int* dst = reinterpret_cast<int*>(&s);
     for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += kPB) dst[i] = src[i];
   }
+  if (tid == 0) {
+    int E[4];
+    canon::static_so3(cols * rows, E);
+    for (int c = 0; c < 4; ++c) s_E[c] = canon::clamp_e(E[c] + exp_bias);
+  }
   __syncthreads();
   if (s.so3_done) return;
+  if (tid < 32) {
+    canon::write_bias<3>(s_E, s_bias, tid);
+    eb_mine = canon::value_exp<3>(s_E, tid);
+  }
+  __syncthreads();
   const int N = cols * rows;
   const int i = blockIdx.x * kPB + tid;
   const bool live = i < N;
   const int ic = live ? i : 0;
   const int y = ic / cols, x = ic - y * cols;
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, 2 * nb * kRecFloats * (F64 ? 8 : 4), 0x00020000);
-  for (int it = 0; it < max_iter; ++it) {
-    const int par = it & 1;
-    So3Params p;
-    p.imageBasis.r0 = mk3(s.imageBasis[0], s.imageBasis[1], s.imageBasis[2]);
-    p.imageBasis.r1 = mk3(s.imageBasis[3], s.imageBasis[4], s.imageBasis[5]);
-    p.imageBasis.r2 = mk3(s.imageBasis[6], s.imageBasis[7], s.imageBasis[8]);
-    p.kinv.r0 = mk3(s.kinv[0], s.kinv[1], s.kinv[2]);
-    p.kinv.r1 = mk3(s.kinv[3], s.kinv[4], s.kinv[5]);
-    p.kinv.r2 = mk3(s.kinv[6], s.kinv[7], s.kinv[8]);
-    p.krlr.r0 = mk3(s.krlr[0], s.krlr[1], s.krlr[2]);
-    p.krlr.r1 = mk3(s.krlr[3], s.krlr[4], s.krlr[5]);
-    p.krlr.r2 = mk3(s.krlr[6], s.krlr[7], s.krlr[8]);
-    p.cols = cols;
-    p.rows = rows;
-    float acc[kSO3];
+  int pool_used = 0, retries = 0;
+  bool on_pool = false, failed = false;
+  for (int it = 0; it < max_iter;) {
+    const So3Params p = so3_params_of(&s, cols, rows);
+    float rows_[1][4];
+    bool found[1];
+    found[0] = so3_row(p, lastImage, last_pitch, nextImage, next_pitch, x, y, rows_[0]);
+    if (!live) {
+      found[0] = false;
+      rows_[0][0] = rows_[0][1] = rows_[0][2] = rows_[0][3] = 0.f;
+    }
+    const size_t set = (size_t)(on_pool ? 10 + pool_used - 1 : it) * kArWords;
+    const double pt = canon::block_sum<3, 1, kPWaves>(rows_, found, s_bias, s_red);
+    if (tid < kSO3)
+      __hip_atomic_fetch_add(ar + set + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride + tid, canon::pack_word(canon::to_units(pt, eb_mine)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+      unsigned long long fld;
+      ar_wait<kArStride>(ar + set, tid, tid < kSO3, nb, fld, &st->sync_timeout, 0);
+      const long long tot = ar_total(fld, nb);
+      if (tid < 32) s_sums[tid] = tid < kSO3 ? canon::from_units(tot, eb_mine) : 0.f;
+      const bool bad = tid < kSO3 && ((so3_diag_mask() >> tid) & 1u) && tot >= canon::kViolation;
+      const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+      if (tid == 0) s_viol = any != 0ull ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_viol) {
+      __syncthreads();
+      pool_used += 1;
+      retries += 1;
+      on_pool = true;
+      if (pool_used > kArPool) {
+        failed = true;
+        break;
+      }
+      if (tid == 0) canon::retry_step<3>(s_E);
+      __syncthreads();
+      if (tid < 32) {
+        canon::write_bias<3>(s_E, s_bias, tid);
+        eb_mine = canon::value_exp<3>(s_E, tid);
+      }
+      __syncthreads();
+      continue;
+    }
+    on_pool = false;
+    if (tid == 0) {
+      sc::so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
+    } else if (tid >= 64 && tid < 96) {
+      int E[4];
 #pragma unroll
-    for (int k = 0; k < kSO3; ++k) acc[k] = 0.f;
-    {
-      float row[4];
-      bool found = so3_row(p, lastImage, last_pitch, nextImage, next_pitch, x, y, row);
-      if (!live) {
-        found = false;
-        row[0] = row[1] = row[2] = row[3] = 0.f;
-      }
-      accumulate_so3(acc, row, found);
+      for (int c = 0; c < 4; ++c) E[c] = s_E[c];
+      canon::next_exponents<3>(s_sums, E);
+      canon::write_bias<3>(E, s_bias, tid - 64);
+      if (tid - 64 < 4) s_E[tid - 64] = E[tid - 64];
     }
-    const bool use_ar = !F64 && (use_ar_arg & 1) && it > 0;  // (as in k_gn_level: the first iteration has no previous totals)
-    bool records = !use_ar;
-    if constexpr (F64) {
-      const double tot = pblock_reduce_d<kSO3>(acc, lds.s_t);
-      double* my_rec = reinterpret_cast<double*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
-      if (pblock_owner_d<kSO3>()) __hip_atomic_store(my_rec + (tid >> 4), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const double p = pblock_reduce_w0<kSO3>(acc, lds.s_red);
-      float* my_rec = reinterpret_cast<float*>(rec) + ((size_t)par * nb + blockIdx.x) * kRecFloats;
-      const unsigned long long* arp = ar + (size_t)it * kArWords;
-      if (use_ar) {
-        if (tid < kSO3)
-          __hip_atomic_fetch_add(ar + (size_t)it * kArWords + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride + tid, ar_encode(p, eb_mine),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 64) {
-          long long tot;
-          int ov;
-          ar_wait<kArStride>(arp, tid, tid < kSO3, nb, tot, ov, &st->sync_timeout, 0);
-          s_sums[tid] = tid < kSO3 ? (float)ar_decode(tot, eb_mine) : 0.f;
-          const unsigned long long any = __builtin_amdgcn_ballot_w64(tid < kSO3 && ov != 0);
-          if (tid == 0) s_ovf = any != 0ull ? 1 : 0;
-        }
-        __syncthreads();
-        records = s_ovf != 0;
-      }
-      if (records && tid < kSO3) __hip_atomic_store(my_rec + tid, (float)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (records) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pk_barrier(sync + it * kBarrierStride, 0ull, &st->sync_timeout);
-      if constexpr (F64)
-        pk_gather_d(rsrc, par, nb, reinterpret_cast<double*>(lds.s_t), s_sums);
-      else
-        pk_gather(rsrc, par, nb, lds.s_grp, s_sums);
-    }
-    if (tid == 0) so3_solve_core(&s, s_sums, cam.fx, cam.fy, cam.cx, cam.cy, it == max_iter - 1 ? 1 : 0, first_gn_level);
     __syncthreads();
     if (s.so3_done) break;
-    if constexpr (!F64) {
-      if (tid < 64) eb_mine = ar_bound_exp_at(s_sums, eb_idx, use_ar_arg >> 8);
-    }
+    if (tid < 32) eb_mine = canon::value_exp<3>(s_E, tid);
+    ++it;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
-    if (tid == 0) s.sync_timeout = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if (failed) __hip_atomic_store(&st->sync_timeout, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s.sync_timeout = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s.canon_retries += retries;
+      if (failed && !s.so3_done) {  // the Gauss-Newton levels still need their projection parameters
+        s.so3_done = 1;
+        double Rt[16];
+        for (int q = 0; q < 16; ++q) Rt[q] = s.resultRt[q];
+        sc::gn_params(Rt, sc::kpre_of(cam.fx, cam.fy, cam.cx, cam.cy, first_gn_level), s.krkinv, s.kt);
+      }
+    }
     __syncthreads();
     const int* src = reinterpret_cast<const int*>(&s);
     int* dst = reinterpret_cast<int*>(st);
@@ -2027,14 +1515,12 @@ void layout(dms_odometry* o, Carver& c) {
   }
   o->vmaps_tmp = (float*)c.take((size_t)W * H * 16);
   o->nmaps_tmp = (float*)c.take((size_t)W * H * 16);
-  o->part_icp = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
-  o->part_rgb = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
-  o->part_so3 = (float*)c.take((size_t)kPartStride * kMaxPartialBlocks * 4);
+  o->part_icp = (long long*)c.take((size_t)kRecWords * kMaxPartialBlocks * 8);
+  o->part_rgb = (long long*)c.take((size_t)kRecWords * kMaxPartialBlocks * 8);
+  o->part_so3 = (long long*)c.take((size_t)kRecWords * kMaxPartialBlocks * 8);
   o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
   o->tickets = (unsigned*)c.take(64);
-  o->rec = (float*)c.take((size_t)2 * kMaxPersistBlocks * kRecFloats * 8);  // sized for the fp64-sum variant
-  o->sync = (unsigned long long*)c.take((size_t)kSyncWords * 8);
-  o->ar = (unsigned long long*)c.take((size_t)kArReductions * kArWords * 8);
+  o->ar = (unsigned long long*)c.take((size_t)kArSets * kArWords * 8);
   o->prof = (long long*)c.take((3 * 16 + 256 * 8) * 8);
   o->state = (TrackState*)c.take(sizeof(TrackState));
 }
@@ -2174,12 +1660,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
   {  // execution switches: the environment is consulted here and nowhere else
     const char* e = getenv("DMS_TRACK_MODE");
     o->resident = !(e && strcmp(e, "launches") == 0);
-    e = getenv("DMS_SUMS");
-    o->fp64_sums = e && strcmp(e, "fp64") == 0;
     e = getenv("DMS_TRACK_EARLY_EXIT");
     o->early_exit_force = e ? (e[0] != '0' ? 1 : 0) : -1;
-    e = getenv("DMS_TRACK_REDUCE");
-    o->atomic_reduce = !(e && strcmp(e, "records") == 0);
     e = getenv("DMS_PERSIST_BLOCKS");
     if (e && atoi(e) > 0) o->persist_target = atoi(e);
     e = getenv("DMS_AR_SLACK");
@@ -2191,12 +1673,71 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
 
 int dms_odometry_debug_set(dms_odometry* o, const char* key, int value) {
   DMS_REQUIRE(o && key, "null argument");
-  if (strcmp(key, "ar_margin") == 0) {
-    DMS_REQUIRE(value >= -100 && value <= 100, "ar_margin out of range");
-    o->ar_margin = value;
+  if (strcmp(key, "exp_bias") == 0) {
+    DMS_REQUIRE(value >= -100 && value <= 100, "exp_bias out of range");
+    o->exp_bias = value;
     return DMS_OK;
   }
   DMS_REQUIRE(false, "unknown key");
+}
+
+int dms_odometry_canon_retries(dms_odometry* o, int* retries) {
+  DMS_REQUIRE(o && retries, "null argument");
+  *retries = o->host_state->canon_retries;
+  return DMS_OK;
+}
+
+// host builds of the scalar section (test hooks, see dmslam.h)
+int dms_debug_scalar_gn(const float* sums_icp, const float* sums_rgb, float icpWeight, const float* Rprev, const float* tprev,
+                        double* resultRt, float fx, float fy, float cx, float cy, int next_level, double* A, double* b, float* Rcurr,
+                        float* tcurr, float* krkinv, float* kt) {
+  DMS_REQUIRE((sums_icp || sums_rgb) && Rprev && tprev && resultRt && A && b && Rcurr && tcurr && krkinv && kt, "null argument");
+  sc::GnLocal L;
+  memset(&L, 0, sizeof(L));
+  for (int i = 0; i < 16; ++i) L.resultRt[i] = resultRt[i];
+  for (int i = 0; i < 9; ++i) L.Rprev[i] = Rprev[i];
+  for (int i = 0; i < 3; ++i) L.tprev[i] = tprev[i];
+  sc::SolveArgs q;
+  memset(&q, 0, sizeof(q));
+  q.icp = sums_icp ? 1 : 0;
+  q.rgb = sums_rgb ? 1 : 0;
+  q.icpWeight = icpWeight;
+  float zero[29] = {0};
+  sc::gn_step_core(L, sums_icp ? sums_icp : zero, sums_rgb ? sums_rgb : zero, 1, 1, q, sc::kpre_of(fx, fy, cx, cy, next_level), true);
+  for (int i = 0; i < 16; ++i) resultRt[i] = L.resultRt[i];
+  for (int i = 0; i < 36; ++i) A[i] = L.lastA[i];
+  for (int i = 0; i < 6; ++i) b[i] = L.lastb[i];
+  for (int i = 0; i < 9; ++i) {
+    Rcurr[i] = L.Rcurr[i];
+    krkinv[i] = L.krkinv[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    tcurr[i] = L.tcurr[i];
+    kt[i] = L.kt[i];
+  }
+  return DMS_OK;
+}
+
+int dms_debug_scalar_so3(const float* sums, float* R_lr, double* resultR, float fx, float fy, float cx, float cy, float* imageBasis,
+                         float* kinv, float* krlr) {
+  DMS_REQUIRE(sums && R_lr && resultR && imageBasis && kinv && krlr, "null argument");
+  TrackState st;
+  memset(&st, 0, sizeof(st));
+  for (int i = 0; i < 9; ++i) {
+    st.R_lr[i] = R_lr[i];
+    st.resultR[i] = st.lastResultR[i] = resultR[i];
+  }
+  st.so3_lastError = 3.402823466e+38F / 2;
+  st.so3_lastCount = 3.402823466e+38F / 2;
+  sc::so3_solve_core(&st, sums, fx, fy, cx, cy, 0, 0);
+  for (int i = 0; i < 9; ++i) {
+    R_lr[i] = st.R_lr[i];
+    resultR[i] = st.resultR[i];
+    imageBasis[i] = st.imageBasis[i];
+    kinv[i] = st.kinv[i];
+    krlr[i] = st.krlr[i];
+  }
+  return DMS_OK;
 }
 
 int dms_odometry_inject_timeout(dms_odometry* o, int calls) {
@@ -2207,9 +1748,9 @@ int dms_odometry_inject_timeout(dms_odometry* o, int calls) {
 
 int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce) {
   DMS_REQUIRE(o, "null argument");
-  if (atomic_reduce >= 0) o->atomic_reduce = atomic_reduce != 0;
+  (void)fp64_sums;      // (rounds 1-2: fp64 block sums / record protocol; every sum is the exact integer sum of canon.hpp now)
+  (void)atomic_reduce;
   if (resident >= 0) o->resident = resident != 0;
-  if (fp64_sums >= 0) o->fp64_sums = fp64_sums != 0;
   o->early_exit_force = early_exit < 0 ? -1 : (early_exit ? 1 : 0);
   return DMS_OK;
 }
@@ -2417,27 +1958,23 @@ struct PersistSection {
   }
 };
 
-// dms_odometry::fp64_sums: block sums and records in fp64 (tighter agreement with an fp64 accumulation, ~3 % slower)
-
-template <bool ICP, bool RGB, bool F64, bool EXIT>
+template <bool ICP, bool RGB, bool EXIT>
 static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
   if (P == 1)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else if (P == 2)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else if (P == 3)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, F64, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
 }
 template <bool ICP, bool RGB>
-static void launch_gn_level(bool fp64_sums, int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
-  if (fp64_sums)
-    launch_gn_level_f<ICP, RGB, true, true>(P, nb, s, st, a, L);  // (the precise variant always carries the exit)
-  else if (L.early_exit)
-    launch_gn_level_f<ICP, RGB, false, true>(P, nb, s, st, a, L);
+static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
+  if (L.early_exit)
+    launch_gn_level_f<ICP, RGB, true>(P, nb, s, st, a, L);
   else
-    launch_gn_level_f<ICP, RGB, false, false>(P, nb, s, st, a, L);
+    launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L);
 }
 
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
@@ -2473,8 +2010,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
 
   {
     Timer t(o, s, "track_init");
-    // (o->sync and o->ar are adjacent in the arena: one zeroing sweep covers both; resident mode only)
-    const int zero_pairs = o->resident ? (int)(((char*)(o->ar + (size_t)kArReductions * kArWords) - (char*)o->sync) / 16) : 0;
+    // all-reduce words of the call's resident kernels (resident mode only)
+    const int zero_pairs = o->resident ? (int)((size_t)kArSets * kArWords / 2) : 0;
     const int ni = o->resident ? 16 : 1;
     unsigned* zero16 = o->dense_cnt_zero;
     o->dense_cnt_zero = nullptr;
@@ -2483,11 +2020,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       dms_image2d d1 = o->lastDepth[1].img(), d2 = o->lastDepth[2].img(), i1 = o->lastImage[1].img(), i2 = o->lastImage[2].img();
       const int gx = (d2.cols + 63) / 64, gy = (d2.rows + 3) / 4;
       hipLaunchKernelGGL(k_track_init_pyr, dim3(gx * gy + ni), dim3(64, 4), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy,
-                         so3 ? 1 : 0, first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, zero16, gx, gy, ni, view<const float>(&d1),
+                         so3 ? 1 : 0, first_level, o->ar, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, zero16, gx, gy, ni, view<const float>(&d1),
                          view<float>(&d2), view<const unsigned char>(&i1), view<unsigned char>(&i2));
     } else {
       hipLaunchKernelGGL(k_track_init, dim3(ni), dim3(256), 0, s, o->state, prior, prior_pose16_dev, o->fx, o->fy, o->cx, o->cy, so3 ? 1 : 0,
-                         first_level, o->sync, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, zero16);
+                         first_level, o->ar, zero_pairs, o->inject_timeouts > 0 ? 1 : 0, zero16);
     }
     DMS_CHECK_LAUNCH();
     if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
@@ -2504,14 +2041,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       persist.begin();
       Timer t(o, s, "so3_level");
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
-      if (o->fp64_sums)
-        hipLaunchKernelGGL(k_so3_level<true>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, (o->atomic_reduce ? 1 : 0) | (o->ar_margin * 256), cam, first_level,
-                           10);
-      else
-        hipLaunchKernelGGL(k_so3_level<false>, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, (void*)o->rec, o->sync, o->ar, (o->atomic_reduce ? 1 : 0) | (o->ar_margin * 256), cam, first_level,
-                           10);
+      hipLaunchKernelGGL(k_so3_level, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch, (const unsigned char*)ni.p,
+                         ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias);
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {
@@ -2519,8 +2050,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
         Timer t(o, s, "so3_pass");
         SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
         hipLaunchKernelGGL(k_so3_pass, dim3(nb), dim3(kBlock), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, kMaxPartialBlocks, o->tickets, cam,
-                           i == 9 ? 1 : 0, first_level);
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, o->tickets, cam, i, i == 9 ? 1 : 0, first_level,
+                           o->exp_bias);
         DMS_CHECK_LAUNCH();
       }
     }
@@ -2579,6 +2110,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     a.cols = o->vmaps_curr[l].cols;
     a.rows = o->vmaps_curr[l].rows / 3;
     a.level = l;
+    a.rgbOnly = rgbOnly ? 1 : 0;
+    a.exp_bias = o->exp_bias;
     const int nb = track_blocks_for(a.cols * a.rows);
     int level_below = l;
     for (int q = l - 1; q >= 0; --q)
@@ -2597,11 +2130,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.fy = o->fy;
       L.cx = o->cx;
       L.cy = o->cy;
-      L.rec = o->rec;
-      L.sync = o->sync + (10 + 20 * l) * kBarrierStride;
-      L.ar = o->ar + (size_t)(10 + 10 * l) * kArWords;
-      L.use_ar = o->atomic_reduce ? 1 : 0;
-      L.ar_margin = o->ar_margin;
+      L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
       L.ar_slack_shift = o->ar_slack_shift;
       L.prof = o->profiling ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
@@ -2616,11 +2145,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
       Timer t(o, s, kLevelTimer[l]);
       if (icp && rgb)
-        launch_gn_level<true, true>(o->fp64_sums, pP, pnb, s, o->state, a, L);
+        launch_gn_level<true, true>(pP, pnb, s, o->state, a, L);
       else if (icp)
-        launch_gn_level<true, false>(o->fp64_sums, pP, pnb, s, o->state, a, L);
+        launch_gn_level<true, false>(pP, pnb, s, o->state, a, L);
       else
-        launch_gn_level<false, true>(o->fp64_sums, pP, pnb, s, o->state, a, L);
+        launch_gn_level<false, true>(pP, pnb, s, o->state, a, L);
       DMS_CHECK_LAUNCH();
       continue;
     }
@@ -2642,25 +2171,26 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       {
         Timer t(o, s, "gn_pass1");
         if (icp && rgb)
-          hipLaunchKernelGGL((k_gn_pass1<true, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
-                             kMaxPartialBlocks, o->tickets + 1, q);
+          hipLaunchKernelGGL((k_gn_pass1<true, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt, kMaxPartialBlocks, j == 0 ? 1 : 0);
         else if (icp)
-          hipLaunchKernelGGL((k_gn_pass1<true, false>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
-                             kMaxPartialBlocks, o->tickets + 1, q);
+          hipLaunchKernelGGL((k_gn_pass1<true, false>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt, kMaxPartialBlocks, j == 0 ? 1 : 0);
         else
-          hipLaunchKernelGGL((k_gn_pass1<false, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt,
-                             kMaxPartialBlocks, o->tickets + 1, q);
+          hipLaunchKernelGGL((k_gn_pass1<false, true>), dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_cnt, kMaxPartialBlocks, j == 0 ? 1 : 0);
         DMS_CHECK_LAUNCH();
       }
       if (rgb) {
         Timer t(o, s, "gn_pass2");
-        hipLaunchKernelGGL(k_gn_pass2, dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_cnt, nb, kMaxPartialBlocks, rgbOnly ? 1 : 0,
-                           j == 0 ? 1 : 0, o->part_icp, o->part_rgb, o->tickets + 2, q);
+        hipLaunchKernelGGL(k_gn_pass2, dim3(nb), dim3(kBlock), 0, s, o->state, a, o->part_cnt, nb, kMaxPartialBlocks, j == 0 ? 1 : 0, o->part_rgb);
         DMS_CHECK_LAUNCH();
       }
       {
         Timer t(o, s, "gn_solve");
-        hipLaunchKernelGGL(k_gn_solve, dim3(1), dim3(256), 0, s, o->state, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks, nb, q);
+        if (icp && rgb)
+          hipLaunchKernelGGL((k_gn_solve<true, true>), dim3(1), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks, nb, q);
+        else if (icp)
+          hipLaunchKernelGGL((k_gn_solve<true, false>), dim3(1), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks, nb, q);
+        else
+          hipLaunchKernelGGL((k_gn_solve<false, true>), dim3(1), dim3(kBlock), 0, s, o->state, a, o->part_icp, o->part_rgb, o->part_cnt, kMaxPartialBlocks, nb, q);
         DMS_CHECK_LAUNCH();
       }
     }
@@ -3011,8 +2541,12 @@ int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream s
   r->so3_iterations_run = h->so3_iters;
   r->rejected_jump = h->rejected_jump;
   if (h->sync_timeout) {
-    set_error("dms_odometry_fetch_result: a persistent tracker kernel timed out at a grid barrier (its blocks were not all "
-              "resident; rerun with DMS_TRACK_MODE=launches)");
+    if (h->sync_timeout == 2)
+      set_error("dms_odometry_fetch_result: no fixed-point range found for a cross-pixel sum (the retry pool of a resident kernel is "
+                "exhausted: non-finite input maps?)");
+    else
+      set_error("dms_odometry_fetch_result: a persistent tracker kernel timed out at a grid barrier (its blocks were not all "
+                "resident; rerun with DMS_TRACK_MODE=launches)");
     return DMS_ERR_TIMEOUT;
   }
   return DMS_OK;

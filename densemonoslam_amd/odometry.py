@@ -256,8 +256,19 @@ class RGBDOdometry:
             self.h = None
 
     def setMode(self, resident=-1, fp64_sums=-1, early_exit=-1, atomic_reduce=-1):
-        """Execution switches of this handle (dms_odometry_set_mode); -1 keeps / restores the default."""
+        """Execution switches of this handle (dms_odometry_set_mode); -1 keeps / restores the default.
+        (fp64_sums / atomic_reduce: ignored since round 3 — every sum is the order-free integer sum.)"""
         check(lib.dms_odometry_set_mode(self.h, int(resident), int(fp64_sums), int(early_exit), int(atomic_reduce)), "dms_odometry_set_mode")
+
+    def setExpBias(self, bias):
+        """test hook: bias of the static exponents of a call's first reductions (csrc/canon.hpp)"""
+        check(lib.dms_odometry_debug_set(self.h, b"exp_bias", int(bias)), "dms_odometry_debug_set")
+
+    def canonRetries(self):
+        """reductions of the last fetched call that were repeated on a coarser grid"""
+        n = C.c_int(0)
+        check(lib.dms_odometry_canon_retries(self.h, C.byref(n)), "dms_odometry_canon_retries")
+        return n.value
 
     def __del__(self):
         try:

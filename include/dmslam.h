@@ -224,20 +224,34 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
                         float fx, float fy, float distThresh, float angleThresh);
 int dms_odometry_destroy(dms_odometry* o);
 /* Execution switches of one tracker (no reference counterpart).  They are read from the environment ONCE, when the
- * handle is created — DMS_TRACK_MODE=launches, DMS_SUMS=fp64, DMS_TRACK_EARLY_EXIT=0|1, DMS_TRACK_REDUCE=records — and changed only here:
+ * handle is created — DMS_TRACK_MODE=launches, DMS_TRACK_EARLY_EXIT=0|1 — and changed only here:
  *   resident    1 = one resident kernel per pyramid level (default), 0 = three launches per iteration; -1 = keep
- *   fp64_sums   1 = block sums and records in fp64, 0 = fp32 wave sums (default); -1 = keep
  *   early_exit  1 / 0 = force the resident-kernel variant that leaves a level after an iteration without any
  *               correspondence on / off; -1 = the handle's default (on for the frame step's model-to-model tracker)
- *   atomic_reduce 1 = grid-wide sums of the resident kernels through integer atomics (default), 0 = through per-block
- *               records + barrier + gather (DMS_TRACK_REDUCE=records); -1 = keep */
+ *   fp64_sums, atomic_reduce: ignored (summation variants of rounds 1-2).  Every cross-pixel sum of the tracker is now the
+ *               order-free integer sum of csrc/canon.hpp in every execution mode: poses do not depend on these switches,
+ *               on the grid size or on the run. */
 int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce);
 /* Fault injection for tests: the next `calls` tracking calls behave as if a resident kernel had timed out at a
  * grid barrier (DMS_ERR_TIMEOUT from dms_odometry_fetch_result; the frame step keeps the prior pose and fuses nothing). */
 int dms_odometry_inject_timeout(dms_odometry* o, int calls);
-/* Test hooks by name.  "ar_margin": headroom in bits of the integer all-reduce's fixed-point scale (default 6); a large
- * negative value makes every partial sum overflow its bound, so every reduction takes the record-protocol fallback. */
+/* Test hooks by name.  "exp_bias": added to the static column exponents of a call's first reductions (csrc/canon.hpp); a
+ * negative value makes their diagonal totals overflow the grid, so those reductions are repeated on a coarser one. */
 int dms_odometry_debug_set(dms_odometry* o, const char* key, int value);
+/* Number of reductions of the last fetched call that were repeated on a coarser grid (csrc/canon.hpp). */
+int dms_odometry_canon_retries(dms_odometry* o, int* retries);
+/* The tracker's scalar section (csrc/gn_scalar.hpp: 6x6 solve, exp map, pose update, projection parameters; SO3 update)
+ * compiled for the HOST — the same source the kernels run, no GPU needed.  Test hooks: the CPU test suite checks that this
+ * operation sequence and the oracle's restatement of it give the same bits.
+ *   gn: sums_icp / sums_rgb = the 29 floats of a reduction (either may be null), resultRt (4x4 row-major, in / out),
+ *       out: A (36), b (6), Rcurr (9), tcurr (3), krkinv (9), kt (3) for the camera matrix of pyramid level `next_level`
+ *   so3: sums = the 11 floats of an SO3 reduction, R_lr (3x3 float) and resultR (3x3 double) in / out,
+ *       out: imageBasis, kinv, krlr (9 each) of the next iteration at pyramid level 2 */
+int dms_debug_scalar_gn(const float* sums_icp, const float* sums_rgb, float icpWeight, const float* Rprev, const float* tprev,
+                        double* resultRt, float fx, float fy, float cx, float cy, int next_level, double* A, double* b,
+                        float* Rcurr, float* tcurr, float* krkinv, float* kt);
+int dms_debug_scalar_so3(const float* sums, float* R_lr, double* resultR, float fx, float fy, float cx, float cy,
+                         float* imageBasis, float* kinv, float* krlr);
 
 /* reference initICP(GPUTexture* filteredDepth, ...) (RGBDOdometry.cpp:118-142); depth = dense u16 mm */
 int dms_odometry_initICP_depth(dms_odometry* o, const dms_image2d* filteredDepth_u16,

@@ -73,6 +73,7 @@ typedef struct orc_track_result {
   int iterations_run[3];
   int so3_iterations_run;
   int rejected_jump;
+  int canon_retries; /* canonical sums: reductions repeated with a coarser grid (orc_canon.c) */
   /* per-iteration pose trace (row-major 3x4 [R|t]) for up to 160 GN iterations */
   int trace_len;
   float trace[160][12];
@@ -89,6 +90,22 @@ void orc_odometry_initRGB(orc_odometry* o, const uint8_t* rgba);
 void orc_odometry_initRGBModel(orc_odometry* o, const uint8_t* rgba);
 void orc_odometry_initFirstRGB(orc_odometry* o, const uint8_t* rgba);
 void orc_odometry_set_fused_rows(orc_odometry* o, int on);
+/* cross-pixel sums of the tracker object: 1 (default) = canonical order-free sums (orc_canon.c), 0 = fp64 accumulation in
+ * loop / thread order (the order-dependent form, kept as the control of what summation order alone does to a pose) */
+void orc_odometry_set_sum_mode(orc_odometry* o, int mode);
+/* scalar section between the reductions: 1 (default) = the product's canonical operation order (orc_scalar.c), 0 = the
+ * independent Eigen-like restatement (pivoted LDLT in outer-product form, Rodrigues through libm, general inverses) */
+void orc_odometry_set_solve_mode(orc_odometry* o, int mode);
+/* canonical sums (orc_canon.c) */
+void orc_odometry_set_exp_bias(orc_odometry* o, int bias); /* test hook: static exponents of a call's first reductions + bias */
+int orc_canon_exp_of(float d);
+int orc_canon_clamp_e(int e);
+void orc_canon_next_exponents(int n, const float* sums, int* E);
+void orc_canon_level_step(int n, int* E);
+void orc_canon_static_icp(int npix, int* E);
+void orc_canon_static_rgb(int npix, float fx_level, int rgbOnly, int* E);
+void orc_canon_static_so3(int npix, int* E);
+int orc_canon_reduce(int n, const float* rows, const unsigned char* found, long npix, int* E, float* sums);
 void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
                                                int pyramid, int fastOdom, int so3, int interMap, orc_track_result* result);
 /* which: same numbering as dms_odometry_get_buffer; returns pointer to the dense host buffer */

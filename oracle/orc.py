@@ -42,6 +42,7 @@ class TrackResult(C.Structure):
         ("iterations_run", C.c_int * 3),
         ("so3_iterations_run", C.c_int),
         ("rejected_jump", C.c_int),
+        ("canon_retries", C.c_int),
         ("trace_len", C.c_int),
         ("trace", (C.c_float * 12) * 160),
     ]
@@ -56,6 +57,9 @@ lib.orc_odometry_create.argtypes = [_I, _I, _F, _F, _F, _F, _F, _F]
 lib.orc_odometry_destroy.argtypes = [_P]
 lib.orc_odometry_set_fused_rows.argtypes = [_P, _I]
 lib.orc_set_fused_rows.argtypes = [_I]
+lib.orc_odometry_set_sum_mode.argtypes = [_P, _I]
+lib.orc_odometry_set_solve_mode.argtypes = [_P, _I]
+lib.orc_odometry_set_exp_bias.argtypes = [_P, _I]
 lib.orc_odometry_buffer.restype = _P
 lib.orc_odometry_buffer.argtypes = [_P, _I, _I]
 lib.orc_odometry_initICP_depth.argtypes = [_P, _P, _F]
@@ -85,6 +89,20 @@ lib.orc_computeRgbResidual.argtypes = [_F, _P, _P, _P, _P, _P, _P, _P, _F, _P, _
 lib.orc_rgbStep.argtypes = [_P, _F, _P, _F, _F, _P, _P, _F, _I, _I, _P, _P]
 lib.orc_so3Step.argtypes = [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]
 lib.orc_covariance.argtypes = [_P, _P]
+
+
+class KPre(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "ifx", "ify")]
+
+
+lib.orc_kpre_of.restype = KPre
+lib.orc_kpre_of.argtypes = [_F, _F, _F, _F, _I]
+lib.orc_scalar_so3_params.argtypes = [_P, C.POINTER(KPre), _P, _P, _P]
+lib.orc_scalar_gn_params.argtypes = [_P, C.POINTER(KPre), _P, _P]
+lib.orc_scalar_so3_update.argtypes = [_P, _P, _P, _P]
+lib.orc_scalar_gn_update.argtypes = [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]
+lib.orc_canon_reduce.argtypes = [_I, _P, _P, C.c_long, _P, _P]
+lib.orc_canon_reduce.restype = _I
 
 
 def _p(a):
@@ -291,6 +309,18 @@ class Odometry:
         """rows with fused multiply-adds (the product's resident kernels) or with every operation rounded (its operator layer)"""
         lib.orc_odometry_set_fused_rows(self.h, int(bool(on)))
 
+    def setSumMode(self, canonical):
+        """cross-pixel sums: canonical order-free sums (default) or fp64 accumulation in loop / thread order (the control)"""
+        lib.orc_odometry_set_sum_mode(self.h, int(bool(canonical)))
+
+    def setExpBias(self, bias):
+        """test hook: bias of the static exponents of a call's first reductions (the product's "exp_bias")"""
+        lib.orc_odometry_set_exp_bias(self.h, int(bias))
+
+    def setSolveMode(self, canonical):
+        """scalar section: the product's canonical operation order (default) or the independent Eigen-like restatement (control)"""
+        lib.orc_odometry_set_solve_mode(self.h, int(bool(canonical)))
+
     def getIncrementalTransformation(self, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap=False):
         t = _c(trans, np.float32).reshape(3).copy()
         R = _c(rot, np.float32).reshape(9).copy()
@@ -313,6 +343,70 @@ class Odometry:
         n = int(np.prod(shape))
         buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
         return np.frombuffer(buf, dtype=dt, count=n).reshape(shape).copy()
+
+
+def unpack_se3(sums):
+    """29 sums (JtJJtrSE3 order) -> A (6x6 float32, symmetric), b (6)"""
+    A = np.zeros((6, 6), np.float32)
+    b = np.zeros(6, np.float32)
+    k = 0
+    for i in range(6):
+        for j in range(i, 7):
+            if j == 6:
+                b[i] = sums[k]
+            else:
+                A[i, j] = A[j, i] = sums[k]
+            k += 1
+    return A, b
+
+
+def scalar_gn_update(sums_icp, sums_rgb, icpWeight, Rprev, tprev, resultRt, cam, next_level):
+    """The oracle's restatement of one Gauss-Newton update in the canonical operation order (orc_scalar.c).
+    Returns resultRt', A, b, Rcurr, tcurr, krkinv, kt."""
+    icp, rgb = sums_icp is not None, sums_rgb is not None
+    Ai, bi = unpack_se3(sums_icp) if icp else (np.zeros((6, 6), np.float32), np.zeros(6, np.float32))
+    Ar, br = unpack_se3(sums_rgb) if rgb else (np.zeros((6, 6), np.float32), np.zeros(6, np.float32))
+    Rp, tp = _c(Rprev, np.float32).reshape(9), _c(tprev, np.float32).reshape(3)
+    Rt = _c(resultRt, np.float64).reshape(16).copy()
+    A, b = np.zeros(36, np.float64), np.zeros(6, np.float64)
+    Rc, tc = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    lib.orc_scalar_gn_update(_p(Ai), _p(bi), _p(Ar), _p(br), int(icp), int(rgb), icpWeight, _p(Rp), _p(tp), _p(Rt), _p(A), _p(b), _p(Rc), _p(tc))
+    k = lib.orc_kpre_of(cam[0], cam[1], cam[2], cam[3], next_level)
+    krk, kt = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    lib.orc_scalar_gn_params(_p(Rt), C.byref(k), _p(krk), _p(kt))
+    return Rt, A, b, Rc, tc, krk, kt
+
+
+def scalar_so3_update(sums, R_lr, resultR, cam):
+    """one SO3 update + the next iteration's parameters in the canonical operation order (orc_scalar.c)"""
+    jtj = np.zeros(9, np.float32)
+    jtr = np.zeros(3, np.float32)
+    k = 0
+    for i in range(3):
+        for j in range(i, 4):
+            if j == 3:
+                jtr[i] = sums[k]
+            else:
+                jtj[i * 3 + j] = jtj[j * 3 + i] = sums[k]
+            k += 1
+    lr = _c(R_lr, np.float32).reshape(9).copy()
+    rr = _c(resultR, np.float64).reshape(9).copy()
+    lib.orc_scalar_so3_update(_p(jtj), _p(jtr), _p(lr), _p(rr))
+    kp = lib.orc_kpre_of(cam[0], cam[1], cam[2], cam[3], 2)
+    ib, ki, kr = np.zeros(9, np.float32), np.zeros(9, np.float32), np.zeros(9, np.float32)
+    lib.orc_scalar_so3_params(_p(rr), C.byref(kp), _p(ib), _p(ki), _p(kr))
+    return lr, rr, ib, ki, kr
+
+
+def canon_reduce(rows, found, E):
+    """canonical order-free sums of per-pixel rows [n][cols] (orc_canon.c); returns sums, E after retries, retries"""
+    rows = _c(rows, np.float32)
+    n = rows.shape[1] - 1
+    fd = _c(found, np.uint8)
+    Ei = _c(E, np.int32).copy()
+    sums = np.zeros(n * (n + 3) // 2 + 2, np.float32)
+    r = lib.orc_canon_reduce(n, _p(rows), _p(fd), rows.shape[0], _p(Ei), _p(sums))
+    return sums, Ei, r
 
 
 def set_threads(n):

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "orc.h"
+#include "orc_scalar.h"
 
 #define NUM_PYRS 3
 
@@ -26,6 +27,9 @@ struct orc_odometry {
   float* pointClouds[NUM_PYRS];
   orc_dataterm* corresImg[NUM_PYRS];
   float *vmaps_tmp, *nmaps_tmp;
+  int exp_bias;   /* test hook: added to the static exponents of a call's first reductions (product: dms_odometry_debug_set "exp_bias") */
+  int solve_mode; /* 1 (default): scalar section in the product's canonical operation order (orc_scalar.c); 0: the independent Eigen-like restatement below */
+  int sum_mode;   /* 0: fp64 accumulation in loop order (order-dependent control), 1: canonical order-free sums (orc_canon.c) */
   int fused_rows; /* evaluate the Gauss-Newton rows with fused multiply-adds (orc_set_fused_rows), as the product's resident kernels do */
 };
 
@@ -160,6 +164,8 @@ static void level_K(const orc_odometry* o, int level, double* K) { /* intr(level
 orc_odometry* orc_odometry_create(int width, int height, float cx, float cy, float fx, float fy, float distThresh,
                                   float angleThresh) {
   orc_odometry* o = (orc_odometry*)calloc(1, sizeof(orc_odometry));
+  o->sum_mode = 1;
+  o->solve_mode = 1;
   o->fused_rows = 1; /* the tracker object of the product evaluates its rows fused (track.hip kTrackerFma) */
   o->width = width; o->height = height; o->cx = cx; o->cy = cy; o->fx = fx; o->fy = fy;
   o->distThres = distThresh > 0 ? distThresh : 0.10f;                                   /* RGBDOdometry.h:35 */
@@ -283,6 +289,90 @@ void orc_odometry_initFirstRGB(orc_odometry* o, const uint8_t* rgba) {          
     orc_pyrDownUcharGauss(o->lastNextImage[i], o->height >> i, o->width >> i, o->lastNextImage[i + 1]);
 }
 
+/* ---- canonical (order-free) reductions: rows of every pixel, then orc_canon_reduce ------------------------------ */
+static int canon_icp(const orc_odometry* o, int level, const float* Rcurr, const float* tcurr, const float* Rprev_inv, const float* tprev,
+                     float lfx, float lfy, float lcx, float lcy, int* E, float* A, float* b, float* residual) {
+  const int rows = o->height >> level, cols = o->width >> level;
+  const long n = (long)rows * cols;
+  float* rw = (float*)malloc((size_t)n * 7 * sizeof(float));
+  unsigned char* fd = (unsigned char*)malloc((size_t)n);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      const size_t p = (size_t)y * cols + x;
+      fd[p] = (unsigned char)orc_icp_row(Rcurr, tcurr, o->vmaps_curr[level], o->nmaps_curr[level], Rprev_inv, tprev, lfx, lfy, lcx, lcy,
+                                         o->vmaps_g_prev[level], o->nmaps_g_prev[level], o->distThres, o->angleThres, rows, cols, x, y,
+                                         rw + p * 7);
+    }
+  float sums[29];
+  const int retries = orc_canon_reduce(6, rw, fd, n, E, sums);
+  free(rw);
+  free(fd);
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const float v = sums[shift++];
+      if (j == 6) b[i] = v; else A[j * 6 + i] = A[i * 6 + j] = v;
+    }
+  residual[0] = sums[27];
+  residual[1] = sums[28];
+  orc_canon_next_exponents(6, sums, E);
+  return retries;
+}
+
+static int canon_rgb(const orc_odometry* o, int level, float sigma, float lfx, float lfy, int* E, float* A, float* b) {
+  const int rows = o->height >> level, cols = o->width >> level;
+  const long n = (long)rows * cols;
+  float* rw = (float*)malloc((size_t)n * 7 * sizeof(float));
+  unsigned char* fd = (unsigned char*)malloc((size_t)n);
+#pragma omp parallel for schedule(static)
+  for (long p = 0; p < n; ++p) {
+    const orc_dataterm* c = o->corresImg[level] + p;
+    orc_rgb_row(c, sigma, o->pointClouds[level], lfx, lfy, o->nextdIdx[level], o->nextdIdy[level], o->sobelScale, cols, rw + p * 7);
+    fd[p] = c->valid ? 1 : 0;
+  }
+  float sums[29];
+  const int retries = orc_canon_reduce(6, rw, fd, n, E, sums);
+  free(rw);
+  free(fd);
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const float v = sums[shift++];
+      if (j == 6) b[i] = v; else A[j * 6 + i] = A[i * 6 + j] = v;
+    }
+  orc_canon_next_exponents(6, sums, E);
+  return retries;
+}
+
+static int canon_so3(const orc_odometry* o, int level, const float* imageBasis, const float* kinv, const float* krlr, int* E, float* A,
+                     float* b, float* residual) {
+  const int rows = o->height >> level, cols = o->width >> level;
+  const long n = (long)rows * cols;
+  float* rw = (float*)malloc((size_t)n * 4 * sizeof(float));
+  unsigned char* fd = (unsigned char*)malloc((size_t)n);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      const size_t p = (size_t)y * cols + x;
+      fd[p] = (unsigned char)orc_so3_row(o->lastNextImage[level], o->nextImage[level], imageBasis, kinv, krlr, rows, cols, x, y, rw + p * 4);
+    }
+  float sums[11];
+  const int retries = orc_canon_reduce(3, rw, fd, n, E, sums);
+  free(rw);
+  free(fd);
+  int shift = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 4; ++j) {
+      const float v = sums[shift++];
+      if (j == 3) b[i] = v; else A[j * 3 + i] = A[i * 3 + j] = v;
+    }
+  residual[0] = sums[9];
+  residual[1] = sums[10];
+  orc_canon_next_exponents(3, sums, E);
+  return retries;
+}
+
 /* RGBDOdometry::getIncrementalTransformation, :268-605 */
 static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
                                                int pyramid, int fastOdom, int so3, int interMap, orc_track_result* res) {
@@ -301,6 +391,7 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
       orc_computeDerivativeImages(o->nextImage[i], o->height >> i, o->width >> i, o->nextdIdx[i], o->nextdIdy[i]);
 
   double resultR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  int E_so3[4], E_icp[7], E_rgb[7], have_E = 0; /* canonical sums: column exponents (orc_canon.c) */
 
   if (so3) { /* :297-385 */
     const int L = 2;
@@ -313,11 +404,23 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
     memcpy(lastResultR, resultR, sizeof(resultR));
     for (int i = 0; i < 10; i++) {
       double t[9], H[9];
-      matmul_d(K, resultR, 3, t);
-      matmul_d(t, Kinv, 3, H);
       float imageBasis[9], kinv[9], krlr[9];
-      for (int k = 0; k < 9; ++k) { imageBasis[k] = (float)H[k]; kinv[k] = (float)Kinv[k]; krlr[k] = (float)t[k]; }
+      if (o->solve_mode) {
+        const orc_kpre k2 = orc_kpre_of(o->fx, o->fy, o->cx, o->cy, L);
+        orc_scalar_so3_params(resultR, &k2, imageBasis, kinv, krlr);
+      } else {
+        matmul_d(K, resultR, 3, t);
+        matmul_d(t, Kinv, 3, H);
+        for (int k = 0; k < 9; ++k) { imageBasis[k] = (float)H[k]; kinv[k] = (float)Kinv[k]; krlr[k] = (float)t[k]; }
+      }
       float jtj[9], jtr[3], residual[2];
+      if (o->sum_mode) {
+        if (i == 0) {
+          orc_canon_static_so3((o->height >> L) * (o->width >> L), E_so3);
+          for (int c = 0; c < 4; ++c) E_so3[c] = orc_canon_clamp_e(E_so3[c] + o->exp_bias);
+        }
+        res->canon_retries += canon_so3(o, L, imageBasis, kinv, krlr, E_so3, jtj, jtr, residual);
+      } else
       orc_so3Step(o->lastNextImage[L], o->nextImage[L], imageBasis, kinv, krlr, o->height >> L, o->width >> L, jtj, jtr, residual);
       res->so3_iterations_run++;
       res->lastSO3Error = sqrtf(residual[0]) / residual[1];
@@ -332,6 +435,10 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
       lastError = res->lastSO3Error;
       lastCount = res->lastSO3Count;
       memcpy(lastResultR, resultR, sizeof(resultR));
+      if (o->solve_mode) {
+        orc_scalar_so3_update(jtj, jtr, R_lr, resultR);
+        continue;
+      }
       double Ad[9], bd[3], xd[3];
       for (int k = 0; k < 9; ++k) Ad[k] = jtj[k];
       for (int k = 0; k < 3; ++k) bd[k] = jtr[k];
@@ -371,6 +478,20 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
     const int div = 1 << i;
     const float lfx = o->fx / div, lfy = o->fy / div, lcx = o->cx / div, lcy = o->cy / div;
     float lastRGBError = FLT_MAX; /* :423 */
+    if (o->sum_mode && iterations[i] > 0) { /* first iteration of a level: static guess (first level of the call) or the coarser level's totals x 4 */
+      if (!have_E) {
+        orc_canon_static_icp(rows * cols, E_icp);
+        orc_canon_static_rgb(rows * cols, lfx, rgbOnly, E_rgb);
+        for (int c = 0; c < 7; ++c) {
+          E_icp[c] = orc_canon_clamp_e(E_icp[c] + o->exp_bias);
+          E_rgb[c] = orc_canon_clamp_e(E_rgb[c] + o->exp_bias);
+        }
+        have_E = 1;
+      } else {
+        orc_canon_level_step(6, E_icp);
+        orc_canon_level_step(6, E_rgb);
+      }
+    }
 
     for (int j = 0; j < iterations[i]; j++) {
       double Rt[16], R[9], t[9], H[9];
@@ -382,6 +503,10 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
       float krkInv[9], kt[3];
       for (int k = 0; k < 9; ++k) krkInv[k] = (float)H[k];
       for (int r = 0; r < 3; ++r) kt[r] = (float)(K[r * 3 + 0] * Rt[3] + K[r * 3 + 1] * Rt[7] + K[r * 3 + 2] * Rt[11]);
+      if (o->solve_mode) {
+        const orc_kpre kl = orc_kpre_of(o->fx, o->fy, o->cx, o->cy, i);
+        orc_scalar_gn_params(resultRt, &kl, krkInv, kt);
+      }
 
       int sigma = 0, rgbSize = 0;
       if (rgb)
@@ -399,16 +524,34 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
       float A_icp[36], b_icp[6], A_rgbd[36], b_rgbd[6];
       memset(A_icp, 0, sizeof(A_icp)); memset(b_icp, 0, sizeof(b_icp));
       memset(A_rgbd, 0, sizeof(A_rgbd)); memset(b_rgbd, 0, sizeof(b_rgbd));
-      if (icp)
+      if (icp && o->sum_mode)
+        res->canon_retries += canon_icp(o, i, Rcurr, tcurr, Rprev_inv, tprev, lfx, lfy, lcx, lcy, E_icp, A_icp, b_icp, residual);
+      else if (icp)
         orc_icpStep(Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, lfx, lfy, lcx, lcy, o->vmaps_g_prev[i],
                     o->nmaps_g_prev[i], o->distThres, o->angleThres, rows, cols, A_icp, b_icp, residual);
       res->lastICPError = sqrtf(residual[0]) / residual[1];
       res->lastICPCount = residual[1];
-      if (rgb)
+      if (rgb && o->sum_mode)
+        res->canon_retries += canon_rgb(o, i, sigmaVal, lfx, lfy, E_rgb, A_rgbd, b_rgbd);
+      else if (rgb)
         orc_rgbStep(o->corresImg[i], sigmaVal, o->pointClouds[i], lfx, lfy, o->nextdIdx[i], o->nextdIdy[i], o->sobelScale, rows,
                     cols, A_rgbd, b_rgbd);
 
       double A[36], b[6], x[6];
+      if (o->solve_mode) {
+        orc_scalar_gn_update(A_icp, b_icp, A_rgbd, b_rgbd, icp, rgb, icpWeight, Rprev, tprev, resultRt, A, b, Rcurr, tcurr);
+        memcpy(res->lastA, A, sizeof(A));
+        memcpy(res->lastb, b, sizeof(b));
+        res->iterations_run[i]++;
+        if (res->trace_len < 160) {
+          float* tr = res->trace[res->trace_len++];
+          for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) tr[r * 4 + c] = Rcurr[r * 3 + c];
+            tr[r * 4 + 3] = tcurr[r];
+          }
+        }
+        continue;
+      }
       if (icp && rgb) { /* :549-555 */
         const double w = icpWeight;
         for (int k = 0; k < 36; ++k) A[k] = (double)A_rgbd[k] + w * w * (double)A_icp[k];
@@ -480,6 +623,9 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
 }
 
 void orc_odometry_set_fused_rows(orc_odometry* o, int on) { o->fused_rows = on ? 1 : 0; }
+void orc_odometry_set_sum_mode(orc_odometry* o, int mode) { o->sum_mode = mode ? 1 : 0; }
+void orc_odometry_set_solve_mode(orc_odometry* o, int mode) { o->solve_mode = mode ? 1 : 0; }
+void orc_odometry_set_exp_bias(orc_odometry* o, int bias) { o->exp_bias = bias; }
 
 void orc_odometry_getIncrementalTransformation(orc_odometry* o, float* trans, float* rot, int rgbOnly, float icpWeight,
                                                int pyramid, int fastOdom, int so3, int interMap, orc_track_result* res) {

@@ -49,13 +49,27 @@ def rot_angle_deg(Ra, Rb):
     return float(np.degrees(np.arctan2(np.linalg.norm(s), c)))
 
 
-def assert_pose_close(t_a, R_a, t_b, R_b, tol_m=1e-3, tol_deg=0.01, what=""):
-    """north_star tolerance: <= 1 mm and <= 0.01 degree per step."""
+def assert_pose_close(t_a, R_a, t_b, R_b, tol_m=0.0, tol_deg=0.0, what=""):
+    """Poses of the tracker object / the frame step: IDENTICAL by default since round 3 (canonical sums + canonical scalar
+    section: tests/test_scalar_cpu.py, csrc/canon.hpp) — far inside the north-star bar of 1 mm / 0.01 degree per step.
+    A caller that compares against something other than the oracle's canonical modes passes its tolerance."""
     dt = float(np.linalg.norm(np.asarray(t_a, np.float64) - np.asarray(t_b, np.float64)))
     da = rot_angle_deg(R_a, R_b)
     assert dt <= tol_m, "%s translation differs by %.3e m (> %.1e)" % (what, dt, tol_m)
     assert da <= tol_deg, "%s rotation differs by %.3e deg (> %.1e)" % (what, da, tol_deg)
     return dt, da
+
+
+def assert_pose_identical(t_a, R_a, t_b, R_b, what=""):
+    """The tracker object's bar since round 3: the same bits (NaN for NaN).  Canonical sums + canonical scalar section make the
+    pose a pure function of the inputs on both sides; anything else is a real divergence, not summation noise."""
+    ta, tb = np.asarray(t_a, np.float32).reshape(-1), np.asarray(t_b, np.float32).reshape(-1)
+    Ra, Rb = np.asarray(R_a, np.float32).reshape(-1), np.asarray(R_b, np.float32).reshape(-1)
+    if ta.tobytes() != tb.tobytes() or Ra.tobytes() != Rb.tobytes():
+        if not (np.isnan(ta).any() or np.isnan(tb).any()):
+            dt = float(np.linalg.norm(ta.astype(np.float64) - tb.astype(np.float64)))
+            raise AssertionError("%s poses differ: translation by %.3e m, rotation by %.3e deg" % (what, dt, rot_angle_deg(Ra, Rb)))
+        assert nan_equal(ta, tb) and nan_equal(Ra, Rb), "%s poses differ (NaN pattern)" % what
 
 
 def nan_equal(a, b):

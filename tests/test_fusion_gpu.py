@@ -1203,32 +1203,39 @@ def test_dataset_logs_feed_the_frame_step(fus, synth, tmp_path, container):
     surfels_equal(got[1], ref[1], "map from the %s log" % container)
 
 
-def test_process_frame_pipeline_parity_fp64_sums(fus, orc, synth, monkeypatch):
-    """DMS_SUMS=fp64 (block sums through an fp64 LDS transpose, fp64 records): the same teacher-forced
-    per-step check as the default path."""
+def test_long_run_every_step_identical_640x480(fus, orc, synth):
+    """The north-star bar (<= 1 mm, <= 0.01 degree on EVERY step) on a long run of the headline stream at the headline
+    resolution, not teacher-forced: the HIP frame step and the oracle each run on their own map and pose for 100 frames
+    (DMS_LONG_RUN_FRAMES) and must hold the SAME BITS after every frame — pose, tracker side outputs, decisions — and
+    the same map at the end.  (Round 2 measured 2 of 99 teacher-forced steps above 0.01 degree: one-ulp differences of
+    the sums and of the scalar section, amplified by the correspondence search.  Both are canonical now.)"""
+    import os
+
+    from densemonoslam_amd import synth as syn
     from oracle import orc_pipeline
 
-    monkeypatch.setenv("DMS_SUMS", "fp64")
-    g = fus.ElasticFusion(W, H, K, model_capacity=600000)
-    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000)
-    worst_t = worst_r = 0.0
-    for k in range(6):
-        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+    n = int(os.environ.get("DMS_LONG_RUN_FRAMES", "100"))
+    W2, H2, K2 = 640, 480, syn.K_640
+    g = fus.ElasticFusion(W2, H2, K2, model_capacity=4_000_000)
+    o = orc_pipeline.ElasticFusion(W2, H2, K2, model_capacity=4_000_000)
+    retries = 0
+    for k in range(n):
+        d, rgb, _ = synth.frame(k, width=W2, height=H2, K=K2, noise=True)
         rg = g.processFrame(rgb, d)
         ro = o.processFrame(rgb, d)
         pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
-        dt, da = helpers.assert_pose_close(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
-        worst_t, worst_r = max(worst_t, dt), max(worst_r, da)
-        assert rg.tick == ro.tick and bool(rg.fused) == ro.fused and bool(rg.fill_in) == ro.fill_in
+        assert pose_g.tobytes() == np.asarray(ro.pose, np.float32).tobytes(), "frame %d: poses differ by %.3e m / %.3e deg" % (
+            k, np.linalg.norm(pose_g[:3, 3].astype(np.float64) - ro.pose[:3, 3]), helpers.rot_angle_deg(pose_g[:3, :3], ro.pose[:3, :3]))
+        assert rg.tick == ro.tick and bool(rg.fused) == ro.fused and bool(rg.fill_in) == ro.fill_in, k
+        assert int(rg.surfels) == ro.surfels, (k, rg.surfels, ro.surfels)
         if k > 0:
-            assert list(rg.track.iterations_run) == list(ro.track.iterations_run)
-        mg = g.globalModel().downloadMap()
-        assert abs(len(mg) - ro.surfels) <= max(10, 2e-3 * ro.surfels)
-        o.model = mg.copy()
-        o.currPose = pose_g.copy()
-    print("fp64 sums: worst per-step pose difference vs oracle: %.3e m, %.3e deg" % (worst_t, worst_r))
-    assert worst_t < 5e-4 and worst_r < 5e-3, (worst_t, worst_r)
-    g.close()
+            assert list(rg.track.iterations_run) == list(ro.track.iterations_run), k
+            for f in ("lastICPError", "lastICPCount", "lastRGBError", "lastRGBCount", "lastSO3Error", "lastSO3Count"):
+                assert np.float32(getattr(rg.track, f)).tobytes() == np.float32(getattr(ro.track, f)).tobytes(), (k, f)
+            assert np.array(rg.track.lastA).tobytes() == np.array(ro.track.lastA).tobytes(), k
+            retries += ro.track.canon_retries
+    surfels_equal(g.globalModel().downloadMap(), o.model, "map after %d free-running frames" % n)
+    assert retries <= n // 10, retries  # the static exponents fit this stream: repeated reductions are the exception
 
 
 def test_frame_step_api_contract(fus, synth):

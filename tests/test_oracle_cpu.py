@@ -31,11 +31,13 @@ def test_oracle_reproduces_golden_vectors():
     assert sorted(got) == sorted(want.files)
     for k in want.files:
         a, b = np.asarray(got[k]), want[k]
-        if k.endswith(("_counts", "_checksum")) or k.startswith("icp_r"):
-            assert np.array_equal(a, b), k
-        else:
-            # the OpenMP partial sums may be combined in a different order on another core count
+        if k.startswith(("icp_A", "icp_b")):
+            # operator layer (orc_icpStep): fp64 accumulation, the OpenMP partial sums may be combined in a different order on
+            # another core count
             assert np.allclose(a, b, rtol=1e-6, atol=1e-9), k
+        else:
+            # tracker object: order-free sums (orc_canon.c) + canonical scalar section (orc_scalar.c) — the same bits on any host
+            assert a.shape == b.shape and a.tobytes() == np.asarray(b, a.dtype).tobytes(), k
 
 
 def test_oracle_reproduces_fusion_golden(orc):
