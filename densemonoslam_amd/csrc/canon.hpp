@@ -239,29 +239,37 @@ __device__ __forceinline__ double wave_sum(const float (&rows)[P][N + 1], const 
   for (int p = 0; p < P; ++p)
 #pragma unroll
     for (int c = 0; c <= N; ++c) r64[p][c] = (double)rows[p][c];
+  // Groups of four values: the biases of the next group are fetched from LDS (into what will be its accumulators) before the
+  // current group's multiply-adds are issued, so no LDS round trip sits in front of a multiply-add chain; inside a group the
+  // four chains are interleaved pixel by pixel (the volatile multiply-adds keep the order written here).
+  constexpr int G = 4, NG = (Lay::NV + G - 1) / G;
   double o1[SL / 2];
+#pragma unroll
+  for (int m = 0; m < SL / 2; ++m) o1[m] = 0.0;
+  double cur[G], nxt[G];
+#pragma unroll
+  for (int h = 0; h < G; ++h) cur[h] = h < Lay::NV ? bias[h] : 0.0;
   round_down_begin();
 #pragma unroll
-  for (int m = 0; m < SL / 2; ++m) {
-    double v[2];
+  for (int g = 0; g < NG; ++g) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = 2 * m + h;
-      if (k < Lay::NV) {
-        double acc = bias[k];
-        if (k <= Lay::NP) {
+    for (int h = 0; h < G; ++h) nxt[h] = ((g + 1) * G + h < Lay::NV) ? bias[(g + 1) * G + h] : 0.0;
 #pragma unroll
-          for (int p = 0; p < P; ++p) acc = fma_down(r64[p][Lay::vi(k)], r64[p][Lay::vj(k)], acc);
-        } else {
+    for (int p = 0; p < P; ++p) {
 #pragma unroll
-          for (int p = 0; p < P; ++p) acc += found[p] ? 1.0 : 0.0;  // (integers on the unit grid: exact)
-        }
-        v[h] = acc;
-      } else {
-        v[h] = 0.0;
+      for (int h = 0; h < G; ++h) {
+        const int k = g * G + h;
+        if (k <= Lay::NP)
+          cur[h] = fma_down(r64[p][Lay::vi(k)], r64[p][Lay::vj(k)], cur[h]);
+        else if (k == Lay::NP + 1)
+          cur[h] += found[p] ? 1.0 : 0.0;  // (integers on the unit grid: exact)
       }
     }
-    o1[m] = (2 * m < Lay::NV) ? swap32_add(v[0], v[1]) : 0.0;
+#pragma unroll
+    for (int h = 0; h < G; h += 2)
+      if (g * G + h < Lay::NV) o1[(g * G + h) / 2] = swap32_add(cur[h], cur[h + 1]);
+#pragma unroll
+    for (int h = 0; h < G; ++h) cur[h] = nxt[h];
   }
   round_down_end();
   return tree_rest<SL>(o1);
