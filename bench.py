@@ -28,6 +28,73 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+CLOCK_GHZ = 2.4        # shader clock (MI355X_MICROARCH.md)
+
+
+def pmc_passes(args, W, H):
+    """HBM traffic and vector-ALU activity of the level-0 tracker kernel from hardware counters of THIS build: three nested
+    `rocprofv3 --kernel-trace --pmc ...` runs of this script (20 steps; FETCH_SIZE and WRITE_SIZE do not fit one pass,
+    MI355X_MICROARCH.md "rocprofv3 PMC slots").  Returns None when rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="dms_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for name, counters, extra in (("fetch", ["FETCH_SIZE"], []), ("write", ["WRITE_SIZE"], []),
+                                      ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"], ["--no-pipeline"])):
+            d = os.path.join(tmp, name)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "r", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--width", str(W), "--height", str(H), "--no-cpu-baseline",
+                   "--no-kernel-pass", "--no-full-leg", "--no-pmc"] + extra
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            if r.returncode != 0:
+                return None
+            vals, durs = {}, {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    kn = row["Kernel_Name"]
+                    if "k_gn_level" not in kn:
+                        continue
+                    key = (row["Dispatch_Id"], int(row["Grid_Size"]), int(row["Workgroup_Size"]))
+                    per = vals.setdefault(row["Counter_Name"], {})
+                    per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+                    durs[key] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
+            if not vals:
+                return None
+            for c, per in vals.items():  # level 0 = the launches with the largest grid
+                big = max(k[1] for k in per)
+                sel = [v for k, v in per.items() if k[1] == big]
+                res[c] = sum(sel) / len(sel)
+                res["blocks"] = big // max(1, next(k[2] for k in per if k[1] == big))
+                if name == "sq":
+                    dd = [v for k, v in durs.items() if k[1] == big]
+                    res["launch_us_under_pmc"] = round(sum(dd) / len(dd), 2)
+        if "FETCH_SIZE" not in res or "WRITE_SIZE" not in res:
+            return None
+        out = {
+            # FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes: doubled
+            # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported (uncalibrated there)
+            "hbm_bytes_per_launch": 2.0 * res["FETCH_SIZE"] * 1024.0 + res["WRITE_SIZE"] * 1024.0,
+            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two nested 20-step passes of this run's build: "
+                      "2 x %.0f KB fetched + %.0f KB written per level-0 launch" % (res["FETCH_SIZE"], res["WRITE_SIZE"]),
+            "blocks": res.get("blocks"),
+        }
+        if "SQ_INSTS_VALU" in res and "launch_us_under_pmc" in res:
+            out["valu_insts_per_launch"] = res["SQ_INSTS_VALU"]
+            out["valu_active_quadcycles_per_launch"] = res["SQ_ACTIVE_INST_VALU"]
+            out["launch_us_under_pmc"] = res["launch_us_under_pmc"]
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def algorithmic_bytes(kernel, W, H, M, level_px):
@@ -54,13 +121,14 @@ def algorithmic_bytes(kernel, W, H, M, level_px):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks = GPUs of this node (0: WORLD_SIZE if launched by torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-pass", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the nested rocprofv3 counter passes (HBM traffic and VALU activity of the dominant kernel)")
     ap.add_argument("--no-pipeline", action="store_true", help="issue the live-frame half on the main stream (A/B switch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto ~20 s)")
     ap.add_argument("--loop-closure", action="store_true",
@@ -71,12 +139,47 @@ def main():
                          "view on this cyclic stream, so the model-to-model tracker has correspondences")
     args = ap.parse_args()
 
-    import torch
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks (one per GPU, RCCL) ourselves
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus == 0:
+        args.gpus = world
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch with --nproc-per-node %d (or without a launcher: this script starts "
+                 "the ranks itself)" % (args.gpus, world, args.gpus))
     distributed = world > 1
+    if os.environ.get("DMS_BENCH_DRY") == "1":
+        # rendezvous rehearsal without a GPU (tests/test_collab_cpu.py): the ranks meet over gloo, rank 0 reports the job's shape
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if distributed:
+            dist.init_process_group(backend="gloo")
+            ranks = [None] * world
+            dist.all_gather_object(ranks, {"rank": rank, "local_rank": local_rank})
+        else:
+            ranks = [{"rank": 0, "local_rank": 0}]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks}))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import torch
+
     if distributed:
         import torch.distributed as dist
 
@@ -89,8 +192,8 @@ def main():
         # processes sharing a device must not run resident (spinning) kernels side by side: the library chains them
         # within a process only; across processes they would time out at their grid barriers (DMS_ERR_TIMEOUT)
         os.environ.setdefault("DMS_TRACK_MODE", "launches")
+    backend = os.environ.get("DMS_BENCH_BACKEND", "nccl") if distributed else "none"
     if distributed:
-        backend = os.environ.get("DMS_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -114,7 +217,7 @@ def main():
         d, rgb, _ = synth.frame(k, cam_id=rank, width=W, height=H, K=K, noise=True)
         rgb_t[k] = torch.from_numpy(rgb)
         dep_t[k] = torch.from_numpy(d.view(np.int16))
-        if rank == 0 and k < 8:
+        if rank == 0:
             host_frames.append((d, rgb))
 
     def frame_index(i):  # forward then backward along the trajectory: temporally coherent for any length
@@ -194,6 +297,14 @@ def main():
 
     elapsed = collab.max_over_ranks(elapsed, dev)  # the slowest rank defines the job time
     M_total = int(collab.sum_over_ranks(M, dev))
+    rank_devices = [{"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(dev)}]
+    if distributed:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_devices[0])
+        rank_devices = gathered
+        if dist.get_world_size() != args.gpus:
+            sys.exit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+    share_projection = int(os.environ.get("DMS_SHARE_PROJECTION", "1"))
 
     fps = world * args.steps / elapsed
     out = {
@@ -201,6 +312,9 @@ def main():
         "value": fps,
         "unit": "frames/s",
         "n_gpus": world,
+        "rccl_ranks": dist.get_world_size() if (distributed and backend == "nccl") else (0 if distributed else 1),
+        "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
+        "rank_devices": rank_devices,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -219,6 +333,11 @@ def main():
                         else "same frame step at %dx%d%s" % (W, H, ", local loop closure on" if args.loop_closure else ""),
             "resolution": [W, H],
             "cameras_per_gpu": 1,
+            # model predictions (60 M + 38 N0 bytes each in SURVEY 8(d)'s contract) run per frame: the tracking prediction and the
+            # final one; the reference's post-tracking "GlobalPredict" is dead work in this fork (off: `global_predict`), and with
+            # share_projection the final prediction's project pass also serves the next frame's tracking prediction
+            "n_pred": 2,
+            "n_pred_project_passes": 1 if share_projection else 2,
             "time_delta": args.time_delta,
             "loop_icp_count_last_frame": float(res.loop_icp_count) if args.loop_closure else None,
             "surfels_per_map": M,
@@ -259,53 +378,58 @@ def main():
         ef.close()
         ef = ef_main
 
-    # ---- per-kernel timing with HIP events on the launch stream (own pass, not in `value`) ------
+    # ---- per-kernel timing with HIP events on the launch stream (own passes, not in `value`) ------
     if rank == 0 and not args.no_kernel_pass:
-        ef.set_profiling(True)
         od = fusion.lib.dms_fusion_odometry(ef.h)
-        capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 1))
         nprof = min(args.steps, 20)
-        for i in range(n_total, n_total + nprof):
-            step(i, exchange_thumbnails=False)  # rank 0 only: no collective in this pass
+        next_frame = [n_total]
+
+        def kernel_pass(per_frame_fetch):
+            """nprof frames with an event pair around every launch.  per_frame_fetch = False: the frames are enqueued as in the timed
+            region (two frames in flight, the live half of frame t + 1 beside frame t) and drained once at the end;
+            True: the host waits for every frame (each kernel alone on the device)."""
+            ef.set_profiling(True)
+            capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 1))
+            for i in range(next_frame[0], next_frame[0] + nprof):
+                step(i, exchange_thumbnails=False)  # rank 0 only: no collective in this pass
+                if per_frame_fetch:
+                    ef.fetch(stream)
+            next_frame[0] += nprof
             ef.fetch(stream)
-        names_f = ["ingest", "preprocess", "live_pyramids", "predict", "fill_in", "odom_init", "track", "predict_old", "loop_init", "loop_track",
-                   "index_map", "fuse", "clean", "initialise"]
-        stages = {}
-        for n in names_f:
-            ms, cnt = ef.kernel_time(n)
-            if cnt:
-                stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
-        kern = {}
-        for n in ("so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
-            ms, cnt = C.c_double(0), C.c_int(0)
-            capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
-            if cnt.value:
-                kern[n] = {"ms_per_frame": ms.value / nprof, "avg_us": 1000.0 * ms.value / cnt.value, "launches_per_frame": cnt.value / nprof}
-        phase_names = ["setup", "pass1", "reduce_icp", "barrier_A", "pass2_reduce", "barrier_B", "gather", "solve", "writeback", "clock_overhead"]
-        phases = {}
-        for lvl in range(3):
-            row = {}
-            for i, n in enumerate(phase_names):
+            stages, kern, phases = {}, {}, {}
+            for n in ["ingest", "preprocess", "live_pyramids", "predict", "fill_in", "odom_init", "track", "predict_old", "loop_init", "loop_track",
+                      "index_map", "fuse", "clean", "initialise"]:
+                ms, cnt = ef.kernel_time(n)
+                if cnt:
+                    stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
+            for n in ("so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
                 ms, cnt = C.c_double(0), C.c_int(0)
-                capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), ("phase:%d" % (lvl * 16 + i)).encode(), C.byref(ms), C.byref(cnt)))
-                row[n] = round(1000.0 * ms.value / nprof, 2)
-            phases["L%d" % lvl] = row
+                capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
+                if cnt.value:
+                    kern[n] = {"ms_per_frame": ms.value / nprof, "avg_us": 1000.0 * ms.value / cnt.value, "launches_per_frame": cnt.value / nprof}
+            phase_names = ["setup", "pass1", "count_pair_arrival", "icp_sum_and_pair_wait", "pass2_and_rgb_sum", "totals_wait", "unused", "solve",
+                           "writeback", "clock_overhead"]
+            for lvl in range(3):
+                row = {}
+                for i, n in enumerate(phase_names):
+                    ms, cnt = C.c_double(0), C.c_int(0)
+                    capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), ("phase:%d" % (lvl * 16 + i)).encode(), C.byref(ms), C.byref(cnt)))
+                    if n != "unused":
+                        row[n] = round(1000.0 * ms.value / nprof, 2)
+                phases["L%d" % lvl] = row
+            return stages, kern, phases
+
+        _, kern_pipe, _ = kernel_pass(False)
+        stages, kern, phases = kernel_pass(True)
         if sum(sum(r.values()) for r in phases.values()) > 0:
-            out["gn_level_phase_us_per_frame"] = phases  # in-kernel clock of block 0, summed over the level's iterations
+            out["gn_level_phase_us_per_frame"] = phases  # in-kernel clock of block 0, summed over the level's iterations (isolated pass)
         out["stage_ms_per_frame"] = {k: round(v["ms_per_frame"], 4) for k, v in stages.items()}
         out["tracker_kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern.items()}
+        out["tracker_kernels_pipelined"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern_pipe.items()}
         # dominant kernel: the resident Gauss-Newton kernel of pyramid level 0 (10 iterations in one
         # launch); in DMS_TRACK_MODE=launches the per-iteration pass-1 kernel instead
         px = [W * H, (W // 2) * (H // 2), (W // 4) * (H // 4)]
         its = [10, 5, 4]
-        traffic = None
-        try:  # HBM bytes per launch from the PMC passes of the same command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_gn_level0.json")) as fh:
-                pm = json.load(fh)
-            if pm.get("resolution") == [W, H]:
-                traffic = pm["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
         # what a plain device-to-device copy reaches on this box, next to the spec peak (SURVEY 8(d))
         try:
             a_ = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
@@ -322,10 +446,14 @@ def main():
             del a_, b_
         except Exception:
             measured_copy = None
+        pmc = None
+        if "gn_level0" in kern and not args.no_pmc and not distributed:
+            pmc = pmc_passes(args, W, H)
         if "gn_level0" in kern:
             bytes_per_launch = algorithmic_bytes("gn_level", W, H, M, px[0]) * its[0]
-            avg_s = kern["gn_level0"]["avg_us"] * 1e-6
-            achieved = bytes_per_launch / avg_s / 1e9
+            us_pipe = kern_pipe.get("gn_level0", kern["gn_level0"])["avg_us"]
+            us_iso = kern["gn_level0"]["avg_us"]
+            achieved = bytes_per_launch / (us_pipe * 1e-6) / 1e9
             out["roofline"] = {
                 "bound": "hbm",
                 "kernel": "k_gn_level<ICP,RGB,P> (pyramid level 0: all 10 Gauss-Newton iterations in one resident launch)",
@@ -333,13 +461,34 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": None if not pmc else pmc.get("hbm_bytes_per_launch"),
                 "bytes_per_launch": bytes_per_launch,
-                "avg_launch_us": kern["gn_level0"]["avg_us"],
+                "avg_launch_us": us_pipe,
+                "avg_launch_us_source": "HIP events on the launch stream, frames enqueued as in the timed region (pipelined: the next frame's "
+                                        "live half runs beside this frame); `frac` uses this duration",
+                "avg_launch_us_isolated": us_iso,
+                "frac_isolated": bytes_per_launch / (us_iso * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "measured_copy_GBps": None if measured_copy is None else round(measured_copy, 1),
-                "note": "algorithmic bytes = 76 B/px/iteration (SURVEY 8d) x %d px x %d iterations; the launch is bound by its 20 grid-wide "
-                        "reductions (2 per iteration) and its per-CU arithmetic, not by HBM (DESIGN.md 6)" % (px[0], its[0]),
+                "note": "algorithmic bytes = 76 B/px/iteration (SURVEY 8d) x %d px x %d iterations.  The level's maps are read from HBM once and "
+                        "stay in registers / L2 for the ten iterations (`traffic`), so this launch cannot be HBM-bound: its time is 20 grid-wide "
+                        "integer all-reduces, 10 one-lane 6x6 solves and its per-CU arithmetic — see `issue_roof` (DESIGN.md 6)" % (px[0], its[0]),
             }
+            if pmc:
+                out["roofline"]["traffic_source"] = pmc.get("source")
+                if pmc.get("valu_insts_per_launch"):
+                    # second roof of the same kernel: vector-instruction issue.  One VALU per SIMD; ACTIVE_INST_VALU counts the
+                    # quad-cycles in which a wave executed a vector instruction, summed over the launch's waves.
+                    simds = pmc["blocks"] * 4
+                    busy_us = pmc["valu_active_quadcycles_per_launch"] * 4.0 / simds / (CLOCK_GHZ * 1e3)
+                    out["roofline"]["issue_roof"] = {
+                        "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                        "valu_busy_us_per_simd": round(busy_us, 2),
+                        "issue_frac": round(busy_us / pmc["launch_us_under_pmc"], 3),
+                        "simds_used": simds,
+                        "launch_us_under_pmc": pmc["launch_us_under_pmc"],
+                        "what": "SQ_ACTIVE_INST_VALU x 4 cycles / (blocks x 4 SIMDs) / %.1f GHz = time a SIMD's vector ALU was busy; "
+                                "issue_frac = that / the launch duration in the same (single-stream) run" % CLOCK_GHZ,
+                    }
         elif "gn_pass1" in kern:
             bytes_per_frame = sum(algorithmic_bytes("gn_pass1", W, H, M, p) * n for p, n in zip(px, its))
             launches = sum(its)
@@ -363,29 +512,46 @@ def main():
 
         from oracle import orc as _orc
 
+        def cpu_model():
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        return line.split(":", 1)[1].strip()
+            except OSError:
+                pass
+            return "unknown"
+
+        def run_oracle(threads, budget_s, max_frames):
+            n = _orc.set_threads(threads)
+            o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=8_000_000)
+            tcpu, done = 0.0, 0
+            for k in range(min(max_frames, len(host_frames))):
+                d, rgb = host_frames[k]
+                t1 = time.perf_counter()
+                o.processFrame(rgb, d)
+                dt = time.perf_counter() - t1
+                if k >= 2:  # frame 0 is the bootstrap frame, frame 1 the first tracked one (cold caches): not steady-state steps
+                    tcpu += dt
+                    done += 1
+                if tcpu > budget_s:
+                    break
+            return n, (done / tcpu if tcpu > 0 else None), done
+
         # the oracle's OpenMP loops are short; one thread per core of a 256-thread host is slower than 16
-        cores = _orc.set_threads(int(os.environ.get("DMS_CPU_THREADS", min(16, os.cpu_count() or 1))))
-        o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=8_000_000)
-        nfr = args.cpu_frames or 6
-        tcpu = 0.0
-        done = 0
-        for k in range(min(nfr, len(host_frames))):
-            d, rgb = host_frames[k]
-            t1 = time.perf_counter()
-            o.processFrame(rgb, d)
-            dt = time.perf_counter() - t1
-            if k >= 1:  # frame 0 is the bootstrap frame, not a steady-state step
-                tcpu += dt
-                done += 1
-            if tcpu > 25.0:
-                break
+        nproc = os.cpu_count() or 1
+        cores, fps_all, n_all = run_oracle(int(os.environ.get("DMS_CPU_THREADS", min(16, nproc))), 20.0, args.cpu_frames or len(host_frames))
+        _, fps_one, n_one = run_oracle(1, 8.0, args.cpu_frames or len(host_frames))
         out["cpu_baseline"] = {
-            "value": done / tcpu if tcpu > 0 else None,
+            "value": fps_all,
             "unit": "frames/s",
             "cores": cores,
             "kind": "port",
-            "sample": "%d steady-state frames of the same synthetic stream (after the bootstrap frame), oracle/ C restatement "
-                      "(OpenMP on the reduction kernels with `cores` threads, the rest single-threaded), %dx%d" % (done, W, H),
+            "one_core": {"value": fps_one, "unit": "frames/s", "cores": 1, "frames": n_one},
+            "host": {"nproc": nproc, "cpu_model": cpu_model()},
+            "sample": "%d steady-state frames (after the bootstrap frame and the first tracked one) of the same synthetic stream in ~20 s, "
+                      "oracle/ C restatement of the reference algorithm (OpenMP on the per-pixel loops of the tracker with `cores` threads, the "
+                      "surfel-map half single-threaded), %dx%d; one_core: the same with 1 thread, ~8 s.  Reported baseline of a CPU "
+                      "restatement, non-target" % (n_all, W, H),
         }
 
     if rank == 0:

@@ -2628,7 +2628,12 @@ int dms_odometry_get_buffer(dms_odometry* o, int which, int level, dms_image2d* 
 int dms_odometry_set_profiling(dms_odometry* o, int enabled) {
   DMS_REQUIRE(o, "null argument");
   o->profiling = enabled != 0;
-  if (enabled) o->times.clear();
+  if (enabled) {
+    drain_timers(o);
+    o->times.clear();
+    DMS_HIP(hipDeviceSynchronize());  // (the phase clocks are accumulated by the resident kernels)
+    DMS_HIP(hipMemset(o->prof, 0, (3 * 16 + 256 * 8) * 8));
+  }
   return DMS_OK;
 }
 

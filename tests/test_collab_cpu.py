@@ -299,3 +299,29 @@ def test_two_rank_intermap_matcher_protocol_gloo():
         assert nframes == 1  # the static camera's first frame is a key frame, the identical later ones are rejected
         assert len(searches) == 3 and all(s[1] == 0 for s in searches)  # one stored frame: it is the candidate
         assert best[other, 0] == 0 and best[rank, 0] == -1
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher around it must run TWO ranks (round 2: the flag was parsed and ignored, the
+    job ran one rank and reported n_gpus = 1).  Rendezvous rehearsal without a GPU (DMS_BENCH_DRY=1: the ranks meet over gloo and
+    rank 0 reports the job's shape); a mismatch between --gpus and the launcher's world size must fail loudly."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, DMS_BENCH_DRY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and sorted(x["rank"] for x in d["ranks"]) == [0, 1] and sorted(x["local_rank"] for x in d["ranks"]) == [0, 1]
+    # one rank, no launcher
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # a launcher's world size that contradicts --gpus
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -1390,3 +1390,24 @@ def test_fused_fill_in_changes_nothing(fus, synth):
         for i in range(3, 10):
             assert_bits(x[i], y[i], "image %d of frame %d" % (i + 6, k))
     surfels_equal(ma, mb, "map")
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(fus):
+    """`python bench.py --gpus 2` starts two ranks by itself.  On a 1-GPU box the ranks share the device (test-only knobs
+    DMS_BENCH_SHARE_GPU / DMS_BENCH_BACKEND=gloo: two processes on one device cannot form an RCCL communicator) — the control
+    flow (matched collectives, rank-0-only passes, max over ranks) is the one the 8-GPU run takes."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMS_BENCH_SHARE_GPU="1", DMS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--width", "320", "--height", "240",
+                        "--no-cpu-baseline", "--no-kernel-pass", "--no-full-leg", "--no-pmc"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and len(d["rank_devices"]) == 2 and d["backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert d["value"] > 0 and d["config"]["surfels_total"] > d["config"]["surfels_per_map"] > 0
