@@ -144,6 +144,68 @@ __global__ __launch_bounds__(256) void k_thumbnails(const uchar4* __restrict__ i
   reinterpret_cast<float4*>(block + n * 20)[k] = normal[q];
 }
 
+// ORB-triggered global loop closure (ElasticFusion.cpp:292-326 inside processFrame; ElasticFusion::applyGlobalLoop, :1148-1200):
+// the two poses the ORB-SLAM3 front end hands over, as pose blocks (pose + inverse) in HBM
+__global__ void k_pose_blocks2(dms_pose_block* pb, Pose16 a, Pose16 b) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; ++i) {
+    pb[0].pose[i] = a.v[i];
+    pb[1].pose[i] = b.v[i];
+  }
+  sm::inv4t<float>(pb[0].pose, pb[0].t_inv);
+  sm::inv4t<float>(pb[1].pose, pb[1].t_inv);
+}
+
+// One block: the W/20 x H/20 NEAREST samples of the ACTIVE vertex map (Resize::vertex -> consBuff) and of the INACTIVE time
+// map (Resize::time -> timesBuff), walked columns outer / rows inner (:303-304); a sample with 0 < z < maxDepth (and, in
+// applyGlobalLoop, a non-zero time) gives one constraint row {orbTcwOld * p, orbTcwNew * p, time, 0} = the arguments of
+// Deformation::addConstraint (:319-323).  pb[0] = orbTcwOld, pb[1] = orbTcwNew.  out[0] = number of rows.
+__global__ __launch_bounds__(256) void k_global_loop_constraints(const float4* __restrict__ vertex, const unsigned short* __restrict__ oldTime,
+                                                                 int cols, int rows, float maxDepth, const dms_pose_block* __restrict__ pb,
+                                                                 int require_time, int* __restrict__ out, float* __restrict__ cons) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int dw = cols / 20, dh = rows / 20, n = dw * dh;
+  const float* Po = pb[0].pose;
+  const float* Pn = pb[1].pose;
+  for (int base = 0; base < n; base += 256) {
+    const int k = base + (int)threadIdx.x;
+    bool valid = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned short t = 0;
+    if (k < n) {
+      const int i = k / dh, j = k - i * dh;
+      const float u = ((float)i + 0.5f) / (float)dw, v = ((float)j + 0.5f) / (float)dh;
+      const int sx = texel(u, (float)cols, cols), sy = texel(v, (float)rows, rows);
+      p = vertex[(size_t)sy * cols + sx];
+      t = oldTime[(size_t)sy * cols + sx];
+      valid = p.z > 0.f && p.z < maxDepth && (!require_time || t > 0);
+    }
+    const unsigned long long m = __ballot(valid);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_wave[w] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int q = 0; q < w; ++q) off += s_wave[q];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (valid) {
+      float* c = cons + (size_t)off * 8;
+      for (int r = 0; r < 3; ++r) {
+        c[r] = Po[r * 4 + 0] * p.x + Po[r * 4 + 1] * p.y + Po[r * 4 + 2] * p.z + Po[r * 4 + 3];
+        c[3 + r] = Pn[r * 4 + 0] * p.x + Pn[r * 4 + 1] * p.y + Pn[r * 4 + 2] * p.z + Pn[r * 4 + 3];
+      }
+      c[6] = (float)t;
+      c[7] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s_base;
+}
+
 __global__ void k_frame_end(FrameState* st, const unsigned* __restrict__ d_count) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->surfels = d_count[0];
@@ -165,6 +227,14 @@ struct dms_fusion {
   dms_odometry* odom = nullptr;
   dms_odometry* odom_m2m = nullptr;  // Context::modelToModel() (local loop closure)
   dms_predict_out pred_old;          // IndexMap old* textures: the INACTIVE view
+  // ORB-triggered global loop closure (hybrid_loops): the two poses of the next frame (armed by dms_fusion_set_orb_loop), their
+  // pose blocks in HBM, the constraint rows (device: 256-byte header with the count, then rows of 8 floats; pinned mirror)
+  bool orb_armed = false, gloop_ran = false, in_global_loop = false;
+  float orb_old[16], orb_new[16];
+  dms_pose_block* orb_pose = nullptr;
+  char* gloop = nullptr;
+  char* h_gloop = nullptr;
+  size_t gloop_bytes = 0;
   LoopState* loop = nullptr;         // device: LoopState + constraint rows
   char* h_loop = nullptr;            // pinned, four slots (frame % 4)
   size_t loop_bytes = 0;
@@ -291,11 +361,18 @@ void layout(dms_fusion* f, Carve& c) {
     f->nid_ws = c.take(f->nid_ws_bytes);
   }
   memset(&f->pred_old, 0, sizeof(f->pred_old));
-  if (f->p.local_loop_closure) {
+  if (f->p.local_loop_closure || f->p.hybrid_loops) {
     f->pred_old.image = mk_img(c.take(N * 4), H, W, 4);
     f->pred_old.vertex = mk_img(c.take(N * 16), H, W, 16);
     f->pred_old.normal = mk_img(c.take(N * 16), H, W, 16);
     f->pred_old.time = mk_img(c.take(N * 2), H, W, 2);
+  }
+  if (f->p.hybrid_loops) {
+    f->gloop_bytes = 256 + (size_t)(W / 20) * (H / 20) * 8 * sizeof(float);
+    f->gloop = (char*)c.take(f->gloop_bytes);
+    f->orb_pose = (dms_pose_block*)c.take(2 * sizeof(dms_pose_block));
+  }
+  if (f->p.local_loop_closure) {
     f->loop_bytes = up256(sizeof(LoopState)) + (size_t)(W / 20) * (H / 20) * 8 * sizeof(float);
     f->loop = (LoopState*)c.take(f->loop_bytes);
   }
@@ -427,6 +504,36 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
   return DMS_OK;
 }
 
+// Device half of the ORB-triggered global loop closure.  `active_new` = 0: the form inside processFrame (ElasticFusion.cpp:293-326):
+// ACTIVE prediction at orbTcwOld, INACTIVE at orbTcwNew, every sample with 0 < z < maxDepthProcessed (the time test is commented
+// out there).  1: ElasticFusion::applyGlobalLoop (:1158-1200): ACTIVE at orbTcwNew, INACTIVE at orbTcwOld, time > 0 required.
+// Both: constraint = (orbTcwOld * p, orbTcwNew * p, INACTIVE time).  The rows reach the pinned mirror on the stream.
+int global_loop_device(dms_fusion* f, const float* orbTcwOld, const float* orbTcwNew, int active_new, hipStream_t s) {
+  int rc;
+  Pose16 a, b;
+  memcpy(a.v, orbTcwOld, sizeof(a.v));
+  memcpy(b.v, orbTcwNew, sizeof(b.v));
+  hipLaunchKernelGGL(k_pose_blocks2, dim3(1), dim3(64), 0, s, f->orb_pose, a, b);
+  DMS_CHECK_LAUNCH();
+  FTimer t(f, s, "global_loop");
+  const int act = active_new ? 1 : 0;
+  // predict(context, rf) with currPose = the ACTIVE pose (:294-296 / :1158-1160): only its vertex map is consumed
+  if ((rc = splat_predict(f->model, f->orb_pose + act, &f->cam, f->p.maxDepthProcessed, f->p.confidence, f->tick, f->p.timeIdx, f->tick,
+                          f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s)))
+    return rc;
+  // combinedPredict(<other pose>, ..., confidenceThreshold, 0, id, tick - timeDelta, timeDelta, INACTIVE) (:299-302 / :1163-1166)
+  if ((rc = splat_predict(f->model, f->orb_pose + (1 - act), &f->cam, f->p.maxDepthProcessed, f->p.confidence, 0, f->p.timeIdx,
+                          f->tick - f->p.timeDelta, f->p.timeDelta, 0, f->zbuf, &f->pred_old, nullptr, 1, s)))
+    return rc;
+  hipLaunchKernelGGL(k_global_loop_constraints, dim3(1), dim3(256), 0, s, (const float4*)f->pred.vertex.data,
+                     (const unsigned short*)f->pred_old.time.data, f->p.width, f->p.height, f->p.maxDepthProcessed, f->orb_pose, active_new ? 1 : 0,
+                     (int*)f->gloop, (float*)(f->gloop + 256));
+  DMS_CHECK_LAUNCH();
+  DMS_HIP(hipMemcpyAsync(f->h_gloop, f->gloop, f->gloop_bytes, hipMemcpyDeviceToHost, s));
+  f->gloop_ran = true;
+  return DMS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -509,6 +616,7 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->num_sensors = 3;       // NUM_CAMERAS (Shaders/size.glsl:2)
   p->share_projection = 1;
   p->fused_fill_in = 1;
+  p->hybrid_loops = 0;
 }
 
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
@@ -571,6 +679,10 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     e = hipHostMalloc((void**)&f->h_loop, 4 * f->loop_bytes, hipHostMallocDefault);
     if (e == hipSuccess) memset(f->h_loop, 0, 4 * f->loop_bytes);
   }
+  if (e == hipSuccess && f->gloop_bytes) {
+    e = hipHostMalloc((void**)&f->h_gloop, f->gloop_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) memset(f->h_gloop, 0, f->gloop_bytes);
+  }
   if (e != hipSuccess) {
     if (f->arena) (void)hipFree(f->arena);
     if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
@@ -615,6 +727,7 @@ int dms_fusion_destroy(dms_fusion* f) {
   if (f->h_state) (void)hipHostFree(f->h_state);
   if (f->nid_host) (void)hipHostFree(f->nid_host);
   if (f->h_loop) (void)hipHostFree(f->h_loop);
+  if (f->h_gloop) (void)hipHostFree(f->h_gloop);
   if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
   dms_odometry_destroy(f->odom);
   dms_model_destroy(f->model);
@@ -821,6 +934,16 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
     bool fuse_now = true;
     if (f->p.global_predict || f->p.nid_keyframing || f->p.local_loop_closure)
       if ((rc = predict(f, f->p.confidence, s))) return rc;
+    f->gloop_ran = false;
+    if (f->orb_armed) {
+      // hybrid_loops && orbTcwOld && orbTcwNew (ElasticFusion.cpp:292-350): the constraints of the ORB loop closure; the caller's
+      // Deformation::constrain (:337) decides between dms_fusion_fetch_loop and _end.  The block ends with predict(context, rf)
+      // (:349), which restores the current view for whoever reads it next in this frame
+      f->orb_armed = false;
+      if ((rc = global_loop_device(f, f->orb_old, f->orb_new, 0, s))) return rc;
+      if (f->p.global_predict || f->p.nid_keyframing || f->p.local_loop_closure)
+        if ((rc = predict(f, f->p.confidence, s))) return rc;
+    }
     if (f->p.local_loop_closure && !f->lost) {
       // closeLoops without a fern match (ElasticFusion.cpp:399-497): the camera is never lost and
       // rawGraph is empty (nothing deforms the map inside this library)
@@ -1012,10 +1135,17 @@ static void fill_loop(const dms_fusion* f, dms_frame_result* r) {
 
 int dms_fusion_fetch_loop(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   DMS_REQUIRE(f && r, "null argument");
-  DMS_REQUIRE(f->in_frame && f->p.local_loop_closure, "only between process_frame_begin and _end with local_loop_closure");
+  DMS_REQUIRE(f->in_frame && (f->p.local_loop_closure || f->gloop_ran),
+              "only between process_frame_begin and _end, with local_loop_closure or after dms_fusion_set_orb_loop");
   memset(r, 0, sizeof(*r));
   DMS_HIP(hipStreamSynchronize((hipStream_t)st));
   if (f->cur_bootstrap) return DMS_OK;
+  if (!(f->p.local_loop_closure && !f->lost)) {  // (that branch has mirrored the frame state already)
+    const int k4 = (int)(f->frames % 4);
+    DMS_HIP(hipMemcpyAsync(f->h_state + k4, f->state, sizeof(FrameState), hipMemcpyDeviceToHost, (hipStream_t)st));
+    DMS_HIP(hipStreamSynchronize((hipStream_t)st));
+    f->last_slot = k4;
+  }
   const FrameState* hs = f->h_state + f->last_slot;
   memcpy(r->pose, hs->cur.pose, sizeof(r->pose));
   r->tick = f->tick;
@@ -1092,6 +1222,61 @@ int dms_fusion_get_loop_constraints(dms_fusion* f, float* rows7_host, int max_ro
   return DMS_OK;
 }
 
+int dms_fusion_set_orb_loop(dms_fusion* f, const float* orbTcwOld16, const float* orbTcwNew16) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(f->p.hybrid_loops, "the context was created without hybrid_loops");
+  DMS_REQUIRE(!f->in_frame, "between process_frame_begin and _end");
+  f->orb_armed = orbTcwOld16 && orbTcwNew16;
+  if (f->orb_armed) {
+    memcpy(f->orb_old, orbTcwOld16, sizeof(f->orb_old));
+    memcpy(f->orb_new, orbTcwNew16, sizeof(f->orb_new));
+  }
+  return DMS_OK;
+}
+
+int dms_fusion_get_global_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n, dms_stream st) {
+  DMS_REQUIRE(f && n && (rows7_host || max_rows == 0), "null argument");
+  *n = 0;
+  if (!f->h_gloop || !f->gloop_ran) return DMS_OK;
+  DMS_HIP(hipStreamSynchronize((hipStream_t)st));
+  const int cnt = *(const int*)f->h_gloop;
+  const float* c = (const float*)(f->h_gloop + 256);
+  *n = cnt;
+  for (int i = 0; i < cnt && i < max_rows; ++i) memcpy(rows7_host + (size_t)i * 7, c + (size_t)i * 8, 7 * sizeof(float));
+  return DMS_OK;
+}
+
+// ElasticFusion::applyGlobalLoop (ElasticFusion.cpp:1148-1240) in two halves around the caller's Deformation::constrain
+int dms_fusion_apply_global_loop_begin(dms_fusion* f, const float* orbTcwOld16, const float* orbTcwNew16, dms_stream st) {
+  DMS_REQUIRE(f && orbTcwOld16 && orbTcwNew16, "null argument");
+  DMS_REQUIRE(f->p.hybrid_loops, "the context was created without hybrid_loops");
+  DMS_REQUIRE(!f->in_frame && !f->in_global_loop && f->map_initialised, "needs an initialised map, outside a frame");
+  int rc = global_loop_device(f, orbTcwOld16, orbTcwNew16, 1, (hipStream_t)st);
+  if (rc) return rc;
+  f->in_global_loop = true;
+  return DMS_OK;
+}
+
+int dms_fusion_apply_global_loop_end(dms_fusion* f, const float* graph_host, int graph_nodes, int accepted, dms_stream st) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(f->in_global_loop, "dms_fusion_apply_global_loop_begin has not been called");
+  DMS_REQUIRE(graph_nodes == 0 || graph_host, "null graph");
+  hipStream_t s = (hipStream_t)st;
+  f->in_global_loop = false;
+  int rc;
+  // predict(context, rf); predictIndices(currPose, tick, id, model, maxDepthProcessed, timeDelta + framesSinceLastFusion);
+  // clean(..., rawGraph, timeDelta + framesSinceLastFusion, maxDepthProcessed, orbLoopClosureAccepted) (:1222-1239)
+  // (the clean changes the map's version: a projection the previous frame left for the next tracking prediction is stale and
+  // that prediction projects afresh, see predict() mode 2)
+  const int timeDeltaEff = f->p.timeDelta + f->frames_since_fusion;
+  if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, timeDeltaEff, f->zbuf, &f->imap, 1, 1, s)))
+    return rc;
+  if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, graph_host, graph_nodes,
+                        timeDeltaEff, f->p.maxDepthProcessed, accepted ? 1 : 0, 1, &f->state->surfels, s)))
+    return rc;
+  return predict(f, f->p.confidence, s);
+}
+
 int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {
   DMS_REQUIRE(f && view, "null argument");
   const dms_image2d* t[] = {&f->rgba,          &f->depth_raw,   &f->depth_filtered, &f->depth_metric, &f->depth_metric_filtered,
@@ -1099,7 +1284,7 @@ int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {
                             &f->pred.vertex,   &f->pred.normal, &f->pred.time,      &f->fill.image,   &f->fill.vertex,
                             &f->fill.normal,   &f->pred_old.image, &f->pred_old.vertex, &f->pred_old.normal, &f->pred_old.time};
   DMS_REQUIRE(which >= 0 && which < 20, "bad image id");
-  DMS_REQUIRE(which < 16 || f->p.local_loop_closure, "the INACTIVE view exists only with local_loop_closure");
+  DMS_REQUIRE(which < 16 || f->p.local_loop_closure || f->p.hybrid_loops, "the INACTIVE view exists only with local_loop_closure or hybrid_loops");
   *view = *t[which];
   if (which >= 5 && which <= 8) {
     // the frame step keeps the index-map images column-major; hand out a row-major copy

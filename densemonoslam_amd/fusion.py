@@ -39,7 +39,7 @@ class FusionParams(C.Structure):
         ("nid_keyframing", C.c_int), ("nid_threshold", C.c_float), ("nid_depth_lambda", C.c_float), ("nid_bins_img", C.c_int),
         ("nid_bins_depth", C.c_int), ("nid_pyramid_level", C.c_int),
         ("local_loop_closure", C.c_int), ("reloc", C.c_int), ("num_sensors", C.c_int), ("share_projection", C.c_int),
-        ("fused_fill_in", C.c_int),
+        ("fused_fill_in", C.c_int), ("hybrid_loops", C.c_int),
     ]
 
 
@@ -90,6 +90,10 @@ lib.dms_fusion_fetch.argtypes = [_P, C.POINTER(FrameResult), _P]
 lib.dms_fusion_inputs_ready.argtypes = [_P, _P]
 lib.dms_fusion_inputs_consumed.argtypes = [_P, _P]
 lib.dms_fusion_model.argtypes = [_P]
+lib.dms_fusion_set_orb_loop.argtypes = [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+lib.dms_fusion_get_global_loop_constraints.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int), _P]
+lib.dms_fusion_apply_global_loop_begin.argtypes = [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]
+lib.dms_fusion_apply_global_loop_end.argtypes = [_P, C.POINTER(C.c_float), _I, _I, _P]
 lib.dms_fusion_model.restype = _P
 lib.dms_fusion_odometry.argtypes = [_P]
 lib.dms_fusion_odometry.restype = _P
@@ -400,6 +404,39 @@ class ElasticFusion:
             pp = self._pose.ctypes.data_as(C.POINTER(C.c_float))
         check(lib.dms_fusion_process_frame_begin(self.h, C.c_void_p(self._rgb.ptr), ch, C.c_void_p(self._depth.ptr), pp, weightMultiplier,
                                                  stream), "dms_fusion_process_frame_begin")
+
+    def setOrbLoop(self, orbTcwOld, orbTcwNew):
+        """Arm the next processFrameBegin with an ORB loop closure (ElasticFusion.cpp:292-350); None, None disarms."""
+        if orbTcwOld is None or orbTcwNew is None:
+            check(lib.dms_fusion_set_orb_loop(self.h, None, None), "dms_fusion_set_orb_loop")
+            return
+        self._orb = (np.ascontiguousarray(orbTcwOld, np.float32).reshape(16), np.ascontiguousarray(orbTcwNew, np.float32).reshape(16))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        check(lib.dms_fusion_set_orb_loop(self.h, fp(self._orb[0]), fp(self._orb[1])), "dms_fusion_set_orb_loop")
+
+    def globalLoopConstraints(self, stream=None):
+        """Constraint rows of the last ORB loop closure: n x 7 float32 {orbTcwOld * p, orbTcwNew * p, INACTIVE time}."""
+        n = C.c_int(0)
+        cap = (self.width // 20) * (self.height // 20)
+        out = np.zeros((cap, 7), np.float32)
+        check(lib.dms_fusion_get_global_loop_constraints(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n), stream),
+              "dms_fusion_get_global_loop_constraints")
+        return out[:n.value].copy()
+
+    def applyGlobalLoopBegin(self, orbTcwOld, orbTcwNew, stream=None):
+        """ElasticFusion::applyGlobalLoop up to the constraints (ElasticFusion.cpp:1148-1200)"""
+        a = np.ascontiguousarray(orbTcwOld, np.float32).reshape(16)
+        b = np.ascontiguousarray(orbTcwNew, np.float32).reshape(16)
+        fp = lambda v: v.ctypes.data_as(C.POINTER(C.c_float))
+        check(lib.dms_fusion_apply_global_loop_begin(self.h, fp(a), fp(b), stream), "dms_fusion_apply_global_loop_begin")
+
+    def applyGlobalLoopEnd(self, graph=None, accepted=False, stream=None):
+        """... and from Deformation::constrain's outcome on: predict, predictIndices, clean with the graph (:1222-1239)"""
+        gp, nn = None, 0
+        if graph is not None and len(graph):
+            self._graph = np.ascontiguousarray(graph, np.float32).reshape(-1, 16)
+            gp, nn = self._graph.ctypes.data_as(C.POINTER(C.c_float)), len(self._graph)
+        check(lib.dms_fusion_apply_global_loop_end(self.h, gp, nn, int(bool(accepted)), stream), "dms_fusion_apply_global_loop_end")
 
     def fetchLoop(self, stream=None):
         r = FrameResult()

@@ -226,6 +226,10 @@ typedef struct dms_fusion_params {
    * decision (:84-97) — the separate fill-in launch and its re-read of the three images are saved.  Same images bit for
    * bit.  0: predict, then dms_fill_in as its own pass. */
   int fused_fill_in;
+  /* Options::hybrid_loops: the ORB-SLAM3 front end may hand over a loop closure (orbTcwOld, orbTcwNew) with a frame
+   * (ElasticFusion.cpp:292-350) or through applyGlobalLoop (:1148-1240); 1 allocates the INACTIVE-view images and the
+   * constraint buffer those blocks need.  Default 0. */
+  int hybrid_loops;
 } dms_fusion_params;
 
 void dms_fusion_default_params(dms_fusion_params* p, int width, int height, float fx, float fy, float cx, float cy);
@@ -296,6 +300,24 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
                                    const float* inPose16, float weightMultiplier, dms_stream s);
 int dms_fusion_fetch_loop(dms_fusion* f, dms_frame_result* r, dms_stream s);
 int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int graph_nodes, const float* newPose16, dms_stream s);
+
+/* ORB-triggered global loop closure, device half (the block `if (hybrid_loops && orbTcwOld && orbTcwNew)` of
+ * ElasticFusion::processFrame, ElasticFusion.cpp:292-350).  dms_fusion_set_orb_loop arms the NEXT
+ * dms_fusion_process_frame_begin with the two poses (row-major 4x4 camera-to-world; NULL, NULL disarms): after tracking, that
+ * frame predicts the ACTIVE view at orbTcwOld, samples its vertex map on the W/20 x H/20 grid (Resize::vertex), predicts the
+ * INACTIVE view at orbTcwNew, samples its time map (Resize::time) and emits one constraint row per sample with
+ * 0 < z < maxDepthProcessed: {orbTcwOld * p, orbTcwNew * p, time} = the arguments of Deformation::addConstraint (:319-323),
+ * columns outer / rows inner as :303-304; then the current view is predicted again (:349).  The host reads the rows
+ * (dms_fusion_get_global_loop_constraints: synchronises `s`), runs the reference's Deformation::constrain (:337, CPU/CHOLMOD,
+ * the caller's) and finishes the frame with dms_fusion_process_frame_end(graph, nodes, NULL) as for a local loop. */
+int dms_fusion_set_orb_loop(dms_fusion* f, const float* orbTcwOld16, const float* orbTcwNew16);
+int dms_fusion_get_global_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n, dms_stream s);
+/* ElasticFusion::applyGlobalLoop (ElasticFusion.cpp:1148-1240) in two halves around the caller's Deformation::constrain:
+ * `_begin`: ACTIVE prediction at orbTcwNew, INACTIVE at orbTcwOld, constraint rows as above but only where the INACTIVE time
+ * is non-zero (:1170-1173); `_end`: predict, predictIndices, clean with the deformation graph and isFern = accepted
+ * (:1222-1239).  Outside a frame (between dms_fusion_process_frame calls). */
+int dms_fusion_apply_global_loop_begin(dms_fusion* f, const float* orbTcwOld16, const float* orbTcwNew16, dms_stream s);
+int dms_fusion_apply_global_loop_end(dms_fusion* f, const float* graph_host, int graph_nodes, int accepted, dms_stream s);
 
 dms_model* dms_fusion_model(dms_fusion* f);
 /* Device address of the camera pose (16 floats, row-major, camera-to-world) the frame step keeps in HBM: valid for the

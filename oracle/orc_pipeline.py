@@ -20,6 +20,17 @@ class Frame:
     pass
 
 
+def _mat_vec_f32(M, v):
+    """float 4x4 * (x, y, z, 1), rows 0..2: products added left to right, every operation rounded (the kernel's order)"""
+    out = np.zeros(3, np.float32)
+    for r in range(3):
+        s = np.float32(M[r, 0] * v[0])
+        s = np.float32(s + np.float32(M[r, 1] * v[1]))
+        s = np.float32(s + np.float32(M[r, 2] * v[2]))
+        out[r] = np.float32(s + M[r, 3])
+    return out
+
+
 class ElasticFusion:
     def __init__(self, width, height, K, timeDelta=200, confidence=10.0, depthCut=3.0, icpWeight=10.0, fastOdom=False, so3=True,
                  frameToFrameRGB=False, pyramid=True, hybrid_tracking=True, rgbOnly=False, timeIdx=0, maxDepthProcessed=25.0,
@@ -98,6 +109,43 @@ class ElasticFusion:
             # device path; the pose is left as tracked (the `constrain() == false` branch)
         return loop
 
+    # The block `if (hybrid_loops && orbTcwOld && orbTcwNew)` of processFrame (:292-326, active_new = False) and the first half of
+    # ElasticFusion::applyGlobalLoop (:1148-1200, active_new = True): ACTIVE prediction at one pose, INACTIVE at the other,
+    # W/20 x H/20 samples -> the arguments of Deformation::addConstraint.  (Deformation::constrain itself is CPU/CHOLMOD: not restated.)
+    def globalLoopConstraints(self, orbTcwOld, orbTcwNew, active_new):
+        K, H, W = self.K, self.H, self.W
+        old = np.asarray(orbTcwOld, np.float32).reshape(4, 4)
+        new = np.asarray(orbTcwNew, np.float32).reshape(4, 4)
+        act, ina = (new, old) if active_new else (old, new)
+        # predict(context, rf) with currPose = the ACTIVE pose: only the vertex texture is read afterwards
+        _, vtx, _, _ = orc.splat_predict(self.model, act, K, H, W, self.maxDepthProcessed, self.confidence, self.tick, self.timeIdx, self.tick,
+                                         self.timeDelta, True)
+        self.old = orc.splat_predict(self.model, ina, K, H, W, self.maxDepthProcessed, self.confidence, 0, self.timeIdx,
+                                     self.tick - self.timeDelta, self.timeDelta, False)
+        dh, dw = H // 20, W // 20
+        cons = orc.resize_nn(vtx, dh, dw)  # resize.vertex(vertexTex, consBuff)
+        times = orc.resize_nn(self.old[3], dh, dw)  # resize.time(oldTimeTex, timesBuff)
+        rows = []
+        for i in range(dw):  # columns outer (:303-304)
+            for j in range(dh):
+                p = cons[j, i]
+                if p[2] > 0 and p[2] < self.maxDepthProcessed and (not active_new or times[j, i] > 0):
+                    ph = np.array([p[0], p[1], p[2], 1.0], np.float32)
+                    raw = _mat_vec_f32(old, ph)
+                    mod = _mat_vec_f32(new, ph)
+                    rows.append(np.concatenate([raw, mod, [np.float32(times[j, i])]]).astype(np.float32))
+        return np.stack(rows) if rows else np.zeros((0, 7), np.float32)
+
+    # second half of applyGlobalLoop (:1222-1239): predict, predictIndices, clean(rawGraph, isFern = accepted)
+    def applyGlobalLoopEnd(self, rawGraph=None, accepted=False):
+        td = self.timeDelta + self.framesSinceLastFusion
+        im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
+        nodes = None if rawGraph is None or not len(rawGraph) else np.ascontiguousarray(rawGraph, np.float32).reshape(-1, 16)
+        self.model = orc.model_clean(self.model, np.zeros(0, orc.SURFEL_DTYPE), self.currPose, self.tick, self.timeIdx, im[0], im[1], im[2],
+                                     self.K, self.confidence, td, self.maxDepthProcessed, nodes=nodes, depthSynth=None, cap=self.cap,
+                                     isFern=int(bool(accepted)))
+        self.predict(self.confidence)
+
     # ElasticFusion::fuseFrame (:639-677): the candidate key frame is the model prediction at the new
     # pose (GlobalPredict, :273); its "old" (INACTIVE) textures are never rendered with loop closure
     # off, i.e. no prediction anywhere (NaN depth, black image)
@@ -127,7 +175,7 @@ class ElasticFusion:
         self.nidScores.append(score)
         return score > self.nid_threshold, score
 
-    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0, deform=None):
+    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0, deform=None, orbTcwOld=None, orbTcwNew=None):
         """deform(loop) stands in for Deformation::constrain (ElasticFusion.cpp:481, CPU/CHOLMOD, not
         restated): called with the loop candidate, it returns None (no deformation) or
         (rawGraph nodes n x 16, corrected pose)."""
@@ -193,7 +241,14 @@ class ElasticFusion:
             out.weighting = weighting
             self.predict(self.confidence)  # :273
             rawGraph = None
-            if self.local_loop_closure and not self.lost:
+            out.global_loop = None
+            if orbTcwOld is not None and orbTcwNew is not None:  # hybrid_loops (:292-350)
+                out.global_loop = self.globalLoopConstraints(orbTcwOld, orbTcwNew, False)
+                res = deform(out.global_loop) if deform is not None else None  # Deformation::constrain (:337): fills rawGraph, pose unchanged
+                if res is not None and res[0] is not None:
+                    rawGraph = np.ascontiguousarray(res[0], np.float32).reshape(-1, 16)
+                self.predict(self.confidence)  # :349
+            if self.local_loop_closure and not self.lost and (rawGraph is None or not len(rawGraph)):  # `rawGraph.size() == 0` (:399)
                 out.loop = self.localLoop()  # :399-497
                 res = deform(out.loop) if deform is not None else None
                 if res is not None:

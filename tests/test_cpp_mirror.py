@@ -104,3 +104,117 @@ def test_cpp_host_runs_the_frame_step():
                                "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
         out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+ADAPTER_SRC = r"""
+// The reference's OUTER API (Core/src/ElasticFusion.h:63-134, Context.h) as GUI/src/MainController.cpp:39-60, :203-229 and :373-377
+// use it, against the adapter header — with a stand-in for Eigen::Matrix4f (this image has no Eigen).
+#include <cmath>
+#include <cstdio>
+#include <vector>
+namespace Eigen {
+struct Matrix4f {
+  float m[16];
+  float& operator()(int r, int c) { return m[r * 4 + c]; }
+  const float& operator()(int r, int c) const { return m[r * 4 + c]; }
+  void setIdentity() { for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f; }
+};
+}  // namespace Eigen
+#define DMS_EIGEN_MATRIX4F_DECLARED 1
+#include "densemonoslam_amd/cpp/ElasticFusion.h"
+
+int main(int argc, char** argv) {
+  const int W = 320, H = 240;
+  Resolution::getInstance(W, H);
+  Intrinsics::getInstance(264.f, 264.f, 160.f, 120.f);
+  dms::FrontEndOptions::get().hybrid_tracking = true;
+  dms::FrontEndOptions::get().hybrid_loops = true;
+  // MainController.cpp:203-214
+  ElasticFusion* eFusion = new ElasticFusion(200, 35000, 5e-05, 1e-05, /*closeLoops*/ false, false, false, 115, 10, 3, 10, false, 0.3095, true,
+                                             false, "model", ElasticFusion::SamplingScheme::NONE, 0.8f, 0.7f, 500, 64, 0);
+  Context& ctx = *(eFusion->frontend("camera0.klg"));
+  ctx.rgbOnly() = false;
+  if (argc < 2) {  // CPU build check: everything above compiled and linked; nothing touches the device
+    delete eFusion;
+    return ctx.id() == 0 ? 0 : 2;
+  }
+  int constrain_calls = 0, constraint_rows = 0;
+  eFusion->constrain = [&](const std::vector<float>& rows, int tick, bool isGlobal) {
+    constrain_calls += isGlobal ? 1 : 100;
+    constraint_rows += (int)(rows.size() / 7);
+    (void)tick;
+    return std::vector<float>();  // Deformation::constrain returned false: no deformation
+  };
+  std::shared_ptr<unsigned char> rgb(new unsigned char[(size_t)W * H * 3], std::default_delete<unsigned char[]>());
+  std::shared_ptr<unsigned short> depth(new unsigned short[(size_t)W * H], std::default_delete<unsigned short[]>());
+  Eigen::Matrix4f first;
+  first.setIdentity();
+  for (int k = 0; k < 4; ++k) {
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        depth.get()[i] = (unsigned short)(1500 + 2 * k + (x / 4) % 7 + 200.0 * std::sin(0.02 * x) * std::cos(0.03 * y));
+        rgb.get()[3 * i + 0] = (unsigned char)(128 + 100 * std::sin(0.11 * (x + k)));
+        rgb.get()[3 * i + 1] = (unsigned char)(128 + 100 * std::sin(0.07 * y));
+        rgb.get()[3 * i + 2] = (unsigned char)(128 + 60 * std::sin(0.05 * (x + y)));
+      }
+    Eigen::Matrix4f* currentPose = nullptr;
+    Eigen::Matrix4f *orb_lc_Tcw_old = nullptr, *orb_lc_Tcw_new = nullptr;
+    if (k > 0) {  // the ORB-SLAM3 pose prior (MainController.cpp:338-356): here the previous pose
+      currentPose = new Eigen::Matrix4f(ctx.currPose());
+    }
+    if (k == 3) {  // a loop-closure candidate of the front end (:358-367)
+      orb_lc_Tcw_old = new Eigen::Matrix4f(first);
+      orb_lc_Tcw_new = new Eigen::Matrix4f(ctx.currPose());
+    }
+    const int64_t timestamp = 1000 * k;
+    const int currentCluster = 0;
+    const float weightMultiplier = 1.f;
+    // MainController.cpp:373-377, verbatim
+    eFusion->processFrame(rgb, depth, timestamp, ctx, currentPose, orb_lc_Tcw_old, orb_lc_Tcw_new, currentCluster, weightMultiplier, false);
+    delete currentPose;
+    delete orb_lc_Tcw_old;
+    delete orb_lc_Tcw_new;
+    std::printf("frame %d: tick %d surfels %u fused %d\n", k, ctx.tick(), ctx.lastResult().surfels, ctx.lastResult().fused);
+  }
+  if (ctx.tick() != 5 || ctx.lastResult().surfels < 50000 || ctx.numFused() != 4) return 11;
+  if (!(std::fabs(ctx.currPose()(0, 3)) < 0.05f && std::fabs(ctx.currPose()(2, 3)) < 0.05f)) return 13;
+  if (constrain_calls != 1 || constraint_rows < 50) return 14;  // the ORB loop closure reached the caller's solver once, with its rows
+  Eigen::Matrix4f a = first, b = ctx.currPose();
+  eFusion->applyGlobalLoop(ctx, a, b);
+  auto gm = eFusion->getGlobalModel(ctx);
+  if (gm.lastCount() == 0) return 15;
+  delete eFusion;
+  return 0;
+}
+"""
+
+
+def _build_adapter(td):
+    lib_dir = os.path.join(ROOT, "densemonoslam_amd")
+    src = os.path.join(td, "adapter.cpp")
+    exe = os.path.join(td, "adapter")
+    with open(src, "w") as f:
+        f.write(ADAPTER_SRC)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I" + ROOT, src, "-o", exe, "-L" + lib_dir, "-ldmslam_hip", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_reference_outer_api_call_sites_compile_and_link():
+    """ElasticFusion's 22-parameter constructor, frontend(name), Context::rgbOnly() and the TEN-parameter processFrame call of
+    GUI/src/MainController.cpp:373-377 compile and link against densemonoslam_amd/cpp/ElasticFusion.h with a plain host compiler."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_adapter(td)
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_reference_outer_api_runs_frames_and_an_orb_loop_closure():
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_adapter(td)
+        out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)

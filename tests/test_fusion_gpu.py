@@ -1411,3 +1411,69 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(fus):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and len(d["rank_devices"]) == 2 and d["backend"] == "gloo" and d["rccl_ranks"] == 0
     assert d["value"] > 0 and d["config"]["surfels_total"] > d["config"]["surfels_per_map"] > 0
+
+
+def test_orb_global_loop_closure_device_half(fus, orc, synth):
+    """hybrid_loops: the ORB-SLAM3 front end hands a loop closure (orbTcwOld, orbTcwNew) to a frame (ElasticFusion.cpp:292-350) and
+    to applyGlobalLoop (:1148-1240).  The left third of the depth image is blanked for three frames so that surfels age out of
+    the active window (timeDelta = 2) and the INACTIVE view has content.  Free-running on both sides: the constraint rows
+    (the arguments of Deformation::addConstraint), the INACTIVE view, the maps after a deformation through a stand-in graph
+    and every pose must be the same bits."""
+    from oracle import orc_pipeline
+
+    W6, H6, K6 = 640, 480, (528.0, 528.0, 320.0, 240.0)
+    opts = dict(model_capacity=2500000, timeDelta=2, confidence=1.0)
+    g = fus.ElasticFusion(W6, H6, K6, hybrid_loops=1, **opts)
+    o = orc_pipeline.ElasticFusion(W6, H6, K6, **opts)
+    rng = np.random.default_rng(5)
+    poses = []
+    with_rows = 0
+    for k in range(8):
+        d, rgb, _ = synth.frame(k, width=W6, height=H6, K=K6, noise=True)
+        if 2 <= k <= 4:
+            d = d.copy()
+            d[:, : int(W6 * 0.35)] = 0
+        orb = None
+        if k in (5, 6):  # the front end reports: "the camera was at poses[k - 4] when it saw this place; it is at <perturbed current> now"
+            new = poses[-1].copy()
+            new[:3, 3] += np.array([0.004, -0.002, 0.003], np.float32)
+            orb = (poses[k - 4].copy(), new)
+        graph = None
+        if orb is not None:
+            g.setOrbLoop(*orb)
+            g.processFrameBegin(rgb, d)
+            cg = g.globalLoopConstraints()
+            if k == 6:  # Deformation::constrain "succeeded": a stand-in graph deforms the map in this frame's fusion half
+                graph = _fake_graph(rng, 40, g.fetchLoop().tick)
+            g.processFrameEnd(graph)
+            rg = g.fetch()
+            ro = o.processFrame(rgb, d, orbTcwOld=orb[0], orbTcwNew=orb[1], deform=(lambda loop: (graph, None)) if graph is not None else None)
+            assert len(cg) == len(ro.global_loop) > 0, (k, len(cg), len(ro.global_loop))
+            assert_bits(cg, ro.global_loop, "constraint rows of the ORB loop closure, frame %d" % k)
+            assert_bits(g.image(19), o.old[3], "INACTIVE time image at orbTcwNew, frame %d" % k)
+            with_rows += int((cg[:, 6] > 0).any())
+        else:
+            rg = g.processFrame(rgb, d)
+            ro = o.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        assert_bits(pose_g, np.asarray(ro.pose, np.float32), "pose, frame %d" % k)
+        assert int(rg.surfels) == ro.surfels, (k, rg.surfels, ro.surfels)
+        poses.append(pose_g)
+    surfels_equal(g.globalModel().downloadMap(), o.model, "map after the ORB loop closures")
+    assert with_rows >= 1
+    # ElasticFusion::applyGlobalLoop between two frames: constraints (time > 0 only), then predict + predictIndices + clean
+    old, new = poses[2].copy(), poses[-1].copy()
+    g.applyGlobalLoopBegin(old, new)
+    cg = g.globalLoopConstraints()
+    co = o.globalLoopConstraints(old, new, True)
+    assert len(cg) == len(co) and (len(cg) == 0 or (cg[:, 6] > 0).all())
+    assert_bits(cg, co, "applyGlobalLoop constraint rows")
+    graph = _fake_graph(rng, 32, o.tick)
+    g.applyGlobalLoopEnd(graph, accepted=True)
+    o.applyGlobalLoopEnd(graph, accepted=True)
+    surfels_equal(g.globalModel().downloadMap(), o.model, "map after applyGlobalLoop")
+    d, rgb, _ = synth.frame(8, width=W6, height=H6, K=K6, noise=True)
+    rg = g.processFrame(rgb, d)
+    ro = o.processFrame(rgb, d)
+    assert_bits(np.array(rg.pose, np.float32).reshape(4, 4), np.asarray(ro.pose, np.float32), "pose of the frame after applyGlobalLoop")
+    surfels_equal(g.globalModel().downloadMap(), o.model, "map of the frame after applyGlobalLoop")
