@@ -249,6 +249,7 @@ lib.dms_odometry_set_mode.argtypes = [_P, _I, _I, _I, _I]
 lib.dms_odometry_inject_timeout.argtypes = [_P, _I]
 lib.dms_odometry_debug_set.argtypes = [_P, C.c_char_p, _I]
 lib.dms_odometry_canon_retries.argtypes = [_P, _IP]
+lib.dms_odometry_get_mode.argtypes = [_P, _IP, _IP, _IP]
 lib.dms_debug_scalar_gn.argtypes = [_P, _P, _F, _P, _P, _P, _F, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P]
 lib.dms_debug_scalar_so3.argtypes = [_P, _P, _P, _F, _F, _F, _F, _P, _P, _P]
 lib.dms_odometry_initICP_depth.argtypes = [_P, _I2, _F, _P]

@@ -1113,9 +1113,13 @@ static int report_timeouts(dms_fusion* f, const FrameState* hs) {
   if (hs->track_timeouts == f->timeouts_reported) return DMS_OK;
   const int n = hs->track_timeouts - f->timeouts_reported;
   f->timeouts_reported = hs->track_timeouts;
-  set_error("dms_fusion: %d frame(s) since the last fetch had a resident tracker kernel time out at a grid barrier (its blocks were not "
-            "all resident: another process on this GPU?); those frames kept their prior pose and were not fused.  "
-            "DMS_TRACK_MODE=launches avoids resident kernels",
+  // resident kernels that cannot be co-resident would time out on every frame: the trackers of this camera run
+  // launch-per-phase from here on (same bits, see track.hip)
+  (void)dms_odometry_set_mode(f->odom, 0, -1, -1, -1);
+  if (f->odom_m2m) (void)dms_odometry_set_mode(f->odom_m2m, 0, -1, -1, -1);
+  set_error("dms_fusion: %d frame(s) since the last fetch had a resident tracker kernel time out at a grid-wide wait (its blocks were not "
+            "all on the device: another process on this GPU?); those frames kept their prior pose and were not fused.  "
+            "This camera's trackers have switched to launch-per-phase kernels (DMS_TRACK_MODE=launches)",
             n);
   return DMS_ERR_TIMEOUT;
 }

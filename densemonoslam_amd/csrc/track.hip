@@ -76,6 +76,13 @@ struct dms_odometry {
   bool resident = true;       // false: three launches per iteration (DMS_TRACK_MODE=launches)
   int early_exit_force = -1;  // -1: as `early_exit`; 0 / 1: forced (DMS_TRACK_EARLY_EXIT)
   int persist_target = 160;   // largest grid that still gets 1 or 2 pixels per thread (DMS_PERSIST_BLOCKS)
+  // Resident kernels spin on each other: ALL blocks of a launch must be on the device at once.  One block (512 threads x
+  // up to 256 registers) fills a compute unit, so a grid may have at most as many blocks as the device has compute units
+  // (hipDeviceProp_t::multiProcessorCount: 256 on a whole MI355X, fewer on a partition / under a CU mask), checked against the
+  // occupancy API at creation; DMS_PERSIST_MAX_BLOCKS lowers it further.  A level that does not fit with <= 4 pixels per
+  // thread runs launch-per-phase.
+  int max_resident_blocks = 256;
+  bool fell_back = false;     // a resident kernel timed out at a grid-wide wait: this handle has switched to launch-per-phase
   // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
   bool deferred_pyr = false;
   unsigned* dense_cnt_zero = nullptr;  // the frame step's 16 dense counters (fill.hpp), read by the model pyramid kernel: zeroed by the next track call's first kernel
@@ -1664,6 +1671,19 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     o->early_exit_force = e ? (e[0] != '0' ? 1 : 0) : -1;
     e = getenv("DMS_PERSIST_BLOCKS");
     if (e && atoi(e) > 0) o->persist_target = atoi(e);
+    {  // how many blocks of a resident kernel fit the device at once (see max_resident_blocks)
+      int dev = 0, cus = 0, per_cu = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_gn_level<true, true, 3, false>, kPB, 0) != hipSuccess) per_cu = 0;
+      (void)hipGetLastError();
+      // (the API is known to answer one block per CU too many near register-file edges, MI355X_MICROARCH.md: a 512-thread block
+      // at > 128 registers can only ever be alone on its CU, so one per CU is what is relied on)
+      o->max_resident_blocks = per_cu >= 1 ? (cus < kMaxPersistBlocks ? cus : kMaxPersistBlocks) : 0;
+      if (o->max_resident_blocks <= 0) o->resident = false;
+    }
+    e = getenv("DMS_PERSIST_MAX_BLOCKS");
+    if (e && atoi(e) > 0 && atoi(e) < o->max_resident_blocks) o->max_resident_blocks = atoi(e);
     e = getenv("DMS_AR_SLACK");
     if (e && atoi(e) >= 0 && atoi(e) <= 31) o->ar_slack_shift = atoi(e);
   }
@@ -1679,6 +1699,14 @@ int dms_odometry_debug_set(dms_odometry* o, const char* key, int value) {
     return DMS_OK;
   }
   DMS_REQUIRE(false, "unknown key");
+}
+
+int dms_odometry_get_mode(dms_odometry* o, int* resident, int* max_resident_blocks, int* fell_back) {
+  DMS_REQUIRE(o, "null argument");
+  if (resident) *resident = o->resident ? 1 : 0;
+  if (max_resident_blocks) *max_resident_blocks = o->max_resident_blocks;
+  if (fell_back) *fell_back = o->fell_back ? 1 : 0;
+  return DMS_OK;
 }
 
 int dms_odometry_canon_retries(dms_odometry* o, int* retries) {
@@ -1887,23 +1915,25 @@ namespace dms {
 // dms_odometry::resident = false (DMS_TRACK_MODE=launches at creation) selects the three-launches-per-iteration path.
 
 // pixels per thread (1 or 2) and grid of k_gn_level for an n-pixel level; 0 blocks = not eligible
-static void persistent_shape(int n, int target, int& P, int& nb) {
+static void persistent_shape(int n, int target, int max_blocks, int& P, int& nb) {
   // 1 or 2 pixels per thread if that keeps the grid at <= `target` blocks (cheap barriers win on the small levels; 96 while
   // the cross-block sums went through per-block records and a gather, 160 since the integer all-reduce: level 1 of
   // 640x480 on 150 blocks with one pixel per thread instead of 75 with two, +1 % frame rate);
   // otherwise 3 pixels per thread on up to 256 blocks (the full-resolution
   // level is bound by its per-CU arithmetic: measured 221 us at 200 blocks vs 230 us at 150), else 4
   auto blocks = [&](int p) { return (n + kPB * p - 1) / (kPB * p); };
-  if (blocks(1) <= target)
+  const int cap = max_blocks < kMaxPersistBlocks ? max_blocks : kMaxPersistBlocks;  // every block must be resident at once
+  const int small = target < cap ? target : cap;
+  if (blocks(1) <= small)
     P = 1;
-  else if (blocks(2) <= target)
+  else if (blocks(2) <= small)
     P = 2;
-  else if (blocks(3) <= kMaxPersistBlocks)
+  else if (blocks(3) <= cap)
     P = 3;
   else
     P = 4;
   nb = (n + kPB * P - 1) / (kPB * P);
-  if (nb > kMaxPersistBlocks || n >= (1 << 19)) nb = 0;  // the barrier word holds a 19-bit count
+  if (nb > cap || n >= (1 << 19)) nb = 0;  // does not fit the device (or the 19-bit count of the pair word): launch-per-phase
 }
 
 // Blocks of a persistent kernel spin on each other, so two of them must never share the device
@@ -2037,7 +2067,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     const Buf& ni = o->nextImage[L];
     const int nb = reduce_blocks_for(li.rows * li.cols);
     const int nbp = (li.rows * li.cols + kPB - 1) / kPB;
-    if (o->resident && nbp <= kMaxPersistBlocks) {
+    if (o->resident && nbp <= kMaxPersistBlocks && nbp <= o->max_resident_blocks) {
       persist.begin();
       Timer t(o, s, "so3_level");
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
@@ -2060,7 +2090,8 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   bool finalized_in_kernel = false;
   for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
     int pP = 1, pnb = 0;
-    if (o->resident && iterations[l] <= 10) persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, pP, pnb);
+    if (o->resident && iterations[l] <= 10)
+      persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, o->max_resident_blocks, pP, pnb);
     const bool persistent = pnb > 0;
     if (rgb && !persistent) {  // the persistent kernel rebuilds the cloud point from lastDepth itself
       dms_camera k = {o->fx, o->fy, o->cx, o->cy};
@@ -2541,12 +2572,16 @@ int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream s
   r->so3_iterations_run = h->so3_iters;
   r->rejected_jump = h->rejected_jump;
   if (h->sync_timeout) {
+    if (h->sync_timeout == 1 && o->resident) {  // its blocks were not all resident: never again on this handle
+      o->resident = false;
+      o->fell_back = true;
+    }
     if (h->sync_timeout == 2)
       set_error("dms_odometry_fetch_result: no fixed-point range found for a cross-pixel sum (the retry pool of a resident kernel is "
                 "exhausted: non-finite input maps?)");
     else
-      set_error("dms_odometry_fetch_result: a persistent tracker kernel timed out at a grid barrier (its blocks were not all "
-                "resident; rerun with DMS_TRACK_MODE=launches)");
+      set_error("dms_odometry_fetch_result: a resident tracker kernel timed out at a grid-wide wait (its blocks were not all on the device: "
+                "another process on this GPU?); this call's result is invalid and the handle has switched to DMS_TRACK_MODE=launches");
     return DMS_ERR_TIMEOUT;
   }
   return DMS_OK;
@@ -2559,7 +2594,17 @@ int dms_odometry_getIncrementalTransformation(dms_odometry* o, float* trans, flo
   if (rc) return rc;
   dms_track_result local;
   dms_track_result* r = result ? result : &local;
+  const bool was_resident = o->resident;
   rc = dms_odometry_fetch_result(o, r, s);
+  if (rc == DMS_ERR_TIMEOUT && was_resident && !o->resident) {
+    // The resident kernels could not be co-resident: the same call again, launch-per-phase (the inputs are untouched; the
+    // SO3 image swap of the first attempt, RGBDOdometry.cpp:595-601, is undone first).  Same bits as a resident run would give.
+    if (so3)
+      for (int i = 0; i < DMS_NUM_PYRS; i++) std::swap(o->lastNextImage[i], o->nextImage[i]);
+    rc = dms_odometry_track_async(o, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, interMap, s);
+    if (rc) return rc;
+    rc = dms_odometry_fetch_result(o, r, s);
+  }
   if (rc) return rc;
   memcpy(trans, r->trans, 3 * sizeof(float));
   memcpy(rot, r->rot, 9 * sizeof(float));

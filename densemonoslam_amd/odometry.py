@@ -260,6 +260,12 @@ class RGBDOdometry:
         (fp64_sums / atomic_reduce: ignored since round 3 — every sum is the order-free integer sum.)"""
         check(lib.dms_odometry_set_mode(self.h, int(resident), int(fp64_sums), int(early_exit), int(atomic_reduce)), "dms_odometry_set_mode")
 
+    def getMode(self):
+        """(resident, max_resident_blocks, fell_back) of this handle"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib.dms_odometry_get_mode(self.h, C.byref(a), C.byref(b), C.byref(c)), "dms_odometry_get_mode")
+        return bool(a.value), b.value, bool(c.value)
+
     def setExpBias(self, bias):
         """test hook: bias of the static exponents of a call's first reductions (csrc/canon.hpp)"""
         check(lib.dms_odometry_debug_set(self.h, b"exp_bias", int(bias)), "dms_odometry_debug_set")

@@ -232,6 +232,13 @@ int dms_odometry_destroy(dms_odometry* o);
  *               order-free integer sum of csrc/canon.hpp in every execution mode: poses do not depend on these switches,
  *               on the grid size or on the run. */
 int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce);
+/* Residency.  The blocks of a resident kernel wait for each other, so all of them must be on the device at once: a grid never
+ * has more blocks than the device has compute units (hipDeviceProp_t::multiProcessorCount, checked against the occupancy API
+ * when the handle is created; DMS_PERSIST_MAX_BLOCKS lowers the limit); a pyramid level that does not fit with <= 4 pixels
+ * per thread runs launch-per-phase.  If a resident kernel nevertheless times out at a grid-wide wait (another process holds
+ * compute units), the handle switches to launch-per-phase for good (`fell_back`); dms_odometry_getIncrementalTransformation
+ * repeats that call at once — same bits either way. */
+int dms_odometry_get_mode(dms_odometry* o, int* resident, int* max_resident_blocks, int* fell_back);
 /* Fault injection for tests: the next `calls` tracking calls behave as if a resident kernel had timed out at a
  * grid barrier (DMS_ERR_TIMEOUT from dms_odometry_fetch_result; the frame step keeps the prior pose and fuses nothing). */
 int dms_odometry_inject_timeout(dms_odometry* o, int calls);

@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
   dms::FrontEndOptions::get().hybrid_tracking = true;
   dms::FrontEndOptions::get().hybrid_loops = true;
   // MainController.cpp:203-214
-  ElasticFusion* eFusion = new ElasticFusion(200, 35000, 5e-05, 1e-05, /*closeLoops*/ false, false, false, 115, 10, 3, 10, false, 0.3095, true,
+  ElasticFusion* eFusion = new ElasticFusion(200, 35000, 5e-05, 1e-05, /*closeLoops*/ false, false, false, 115, /*confidence: the map is four frames old*/ 1, 3, 10, false, 0.3095, true,
                                              false, "model", ElasticFusion::SamplingScheme::NONE, 0.8f, 0.7f, 500, 64, 0);
   Context& ctx = *(eFusion->frontend("camera0.klg"));
   ctx.rgbOnly() = false;

@@ -1294,12 +1294,17 @@ def test_tracker_timeout_keeps_pose_skips_fusion_and_is_reported(fus, synth):
     # the healthy frame behind it tracked from the kept pose and fused
     assert int(r3.fused) == 1 and int(r3.surfels) > len(map2)
     assert np.abs(np.array(r3.pose, np.float32) - pose1).max() < 0.05
-    # reported once
+    # reported once; the camera's tracker runs launch-per-phase from here on (its blocks could not all be resident)
+    import ctypes as C
+
+    res = C.c_int(-1)
+    assert lib.dms_odometry_get_mode(g.odometryHandle(), C.byref(res), None, None) == 0 and res.value == 0
     d, rgb, _ = frames[4]
     ch = g.upload_frame(rgb, d)
     g.processFrameAsync(g._rgb.ptr, ch, g._depth.ptr)
-    rc, _ = g.fetch_rc()
+    rc, r4 = g.fetch_rc()
     assert rc == 0, rc
+    assert int(r4.fused) == 1 and list(r4.track.iterations_run) == [10, 5, 4]
     g.close()
 
 

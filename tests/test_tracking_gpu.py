@@ -593,13 +593,21 @@ def test_pose_does_not_depend_on_the_grid_size(dms, gputest_pair, monkeypatch):
     verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
     rgba1, rgba2 = helpers.rgba(gputest_pair["rgb1"]), helpers.rgba(gputest_pair["rgb2"])
     outs = []
-    for blocks, mode in ((160, None), (40, None), (96, None), (160, "launches")):
+    for blocks, mode, cap in ((160, None, 0), (40, None, 0), (96, None, 0), (160, "launches", 0), (160, None, 120), (160, None, 20)):
+        # cap: a device with that many compute units — 120: level 0 takes four pixels per thread; 20: no level fits, every level
+        # runs launch-per-phase while the SO3 stage (38 blocks) does too
         monkeypatch.setenv("DMS_PERSIST_BLOCKS", str(blocks))
+        if cap:
+            monkeypatch.setenv("DMS_PERSIST_MAX_BLOCKS", str(cap))
+        else:
+            monkeypatch.delenv("DMS_PERSIST_MAX_BLOCKS", raising=False)
         if mode:
             monkeypatch.setenv("DMS_TRACK_MODE", mode)
         else:
             monkeypatch.delenv("DMS_TRACK_MODE", raising=False)
         g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+        if cap:
+            assert g.getMode()[1] == cap
         g.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
         g.initRGBModel(rgba1)
         g.initICP(gputest_pair["depth2"], 20.0)
@@ -609,3 +617,27 @@ def test_pose_does_not_depend_on_the_grid_size(dms, gputest_pair, monkeypatch):
         outs.append(t.tobytes() + R.tobytes() + np.array(r.lastA).tobytes() + np.array(r.lastb).tobytes())
         g.close()
     assert all(o == outs[0] for o in outs[1:])
+
+
+def test_resident_timeout_repeats_the_call_launch_per_phase(dms, orc, gputest_pair):
+    """A resident kernel that times out at a grid-wide wait (injected) means its blocks were not all on the device.  The
+    synchronous call repeats itself launch-per-phase at once — the result equals the oracle's bit for bit — and the handle
+    stays in that mode."""
+    from densemonoslam_amd.capi import lib
+
+    g, o = _fresh_pair(dms, orc, gputest_pair)
+    assert g.getMode()[0] and not g.getMode()[2]
+    assert lib.dms_odometry_inject_timeout(g.h, 1) == 0
+    cfg = CONFIGS["C3_full"]
+    t0, R0 = np.zeros(3, np.float32), np.eye(3, dtype=np.float32)
+    tg, Rg, rg = g.getIncrementalTransformation(t0, R0, **cfg)
+    to, Ro, ro = o.getIncrementalTransformation(t0, R0, **cfg)
+    helpers.assert_pose_identical(tg, Rg, to, Ro, what="repeated call")
+    _assert_results_identical(rg, ro, g, "repeated call")
+    resident, _, fell_back = g.getMode()
+    assert not resident and fell_back
+    for lvl in range(3):  # the SO3 image swap happened exactly once
+        assert (g.buffer(7, lvl) == o.buffer(7, lvl)).all() and (g.buffer(8, lvl) == o.buffer(8, lvl)).all()
+    tg, Rg, rg = g.getIncrementalTransformation(t0, R0, **cfg)
+    to, Ro, ro = o.getIncrementalTransformation(t0, R0, **cfg)
+    helpers.assert_pose_identical(tg, Rg, to, Ro, what="next call")
