@@ -4,6 +4,7 @@
 // 16-byte accesses per lane); blocks are 64×4 so a 256-thread block spans 4 rows.
 #include "common.hpp"
 #include "pyr_body.hpp"
+#include "live_bodies.hpp"
 #include "fill.hpp"
 
 namespace dms {
@@ -12,83 +13,63 @@ static constexpr int BX = 64, BY = 4;
 static inline dim3 blk() { return dim3(BX, BY); }
 
 // ---------------------------------------------------------------------------------------
-// pyrDown: u16 depth 5×5 Gaussian with σ_colour = 30 mm edge stop
-// (reference pyrDownGaussKernel, cudafuncs.cu:57-91)
+// Operator layer of the live-side pyramid: every operator is the generic per-pixel launch below over a functor that applies
+// one body of live_bodies.hpp through a global-memory accessor.  (The frame step does not use these launches: it computes the
+// same bodies from LDS tiles, k_live_levels further down.)
 // ---------------------------------------------------------------------------------------
-__global__ void k_pyrDownDepth(View<const unsigned short> src, View<unsigned short> dst, float sigma_color) {
+template <class Op>
+__global__ void k_per_pixel(int cols, int rows, Op op) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const int D = 5;
-  const int center = src.at(2 * y, 2 * x);
-  const int x_mi = max(0, 2 * x - D / 2) - 2 * x;
-  const int y_mi = max(0, 2 * y - D / 2) - 2 * y;
-  const int x_ma = min(src.cols, 2 * x - D / 2 + D) - 2 * x;
-  const int y_ma = min(src.rows, 2 * y - D / 2 + D) - 2 * y;
-  float sum = 0.f, wall = 0.f;
-  const float weights[3] = {0.375f, 0.25f, 0.0625f};
-  for (int yi = y_mi; yi < y_ma; ++yi)
-    for (int xi = x_mi; xi < x_ma; ++xi) {
-      const int val = src.at(2 * y + yi, 2 * x + xi);
-      if ((float)abs(val - center) < 3.f * sigma_color) {
-        const float w = weights[abs(xi)] * weights[abs(yi)];
-        sum += ((float)val * weights[abs(xi)]) * weights[abs(yi)];
-        wall += w;
-      }
+  if (x < cols && y < rows) op(x, y);
+}
+
+struct OpDepthHalf {  // dms_pyrDown (reference pyrDown, cudafuncs.cu:93-104)
+  live::Pitched<unsigned short> src;
+  View<unsigned short> dst;
+  int scols, srows;
+  __device__ void operator()(int x, int y) const { dst.at(y, x) = live::depth_half(src, x, y, scols, srows); }
+};
+struct OpVertexMap {  // dms_createVMap (createVMap, cudafuncs.cu:130-147)
+  live::Pitched<unsigned short> depth;
+  View<float> vmap;
+  live::LevelCam cam;
+  float cutoff;
+  int rows;
+  __device__ void operator()(int u, int v) const {
+    const f3 p = live::vertex_of(depth(v, u), u, v, cam, cutoff);
+    vmap.at(v, u) = p.x;
+    if (!isnan(p.x)) {
+      vmap.at(v + rows, u) = p.y;
+      vmap.at(v + 2 * rows, u) = p.z;
     }
-  dst.at(y, x) = (unsigned short)f2i_rz(sum / wall);
-}
-
-// ---------------------------------------------------------------------------------------
-// createVMap: mm -> m back-projection (reference computeVmapKernel, cudafuncs.cu:106-128)
-// ---------------------------------------------------------------------------------------
-__global__ void k_createVMap(View<const unsigned short> depth, View<float> vmap, float fx_inv, float fy_inv,
-                             float cx, float cy, float depthCutoff) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y * blockDim.y + threadIdx.y;
-  if (u >= depth.cols || v >= depth.rows) return;
-  const float z = (float)depth.at(v, u) / 1000.f;
-  if (z != 0.f && z < depthCutoff) {
-    const float vx = (z * ((float)u - cx)) * fx_inv;
-    const float vy = (z * ((float)v - cy)) * fy_inv;
-    vmap.at(v, u) = vx;
-    vmap.at(v + depth.rows, u) = vy;
-    vmap.at(v + 2 * depth.rows, u) = z;
-  } else {
-    vmap.at(v, u) = qnan();
   }
-}
-
-// ---------------------------------------------------------------------------------------
-// createNMap: forward-difference normals (reference computeNmapKernel, cudafuncs.cu:149-182)
-// ---------------------------------------------------------------------------------------
-__global__ void k_createNMap(int rows, int cols, View<const float> vmap, View<float> nmap) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y * blockDim.y + threadIdx.y;
-  if (u >= cols || v >= rows) return;
-  if (u == cols - 1 || v == rows - 1) {
-    nmap.at(v, u) = qnan();
-    return;
+};
+struct OpNormalMap {  // dms_createNMap (createNMap, cudafuncs.cu:184-198)
+  View<const float> vmap;
+  View<float> nmap;
+  int rows, cols;
+  __device__ f3 vertex(int v, int u) const {
+    f3 p;
+    p.x = vmap.at(v, u);
+    p.y = p.z = 0.f;
+    if (!isnan(p.x)) {
+      p.y = vmap.at(v + rows, u);
+      p.z = vmap.at(v + 2 * rows, u);
+    }
+    return p;
   }
-  f3 v00, v01, v10;
-  v00.x = vmap.at(v, u);
-  v01.x = vmap.at(v, u + 1);
-  v10.x = vmap.at(v + 1, u);
-  if (!isnan(v00.x) && !isnan(v01.x) && !isnan(v10.x)) {
-    v00.y = vmap.at(v + rows, u);
-    v01.y = vmap.at(v + rows, u + 1);
-    v10.y = vmap.at(v + 1 + rows, u);
-    v00.z = vmap.at(v + 2 * rows, u);
-    v01.z = vmap.at(v + 2 * rows, u + 1);
-    v10.z = vmap.at(v + 1 + 2 * rows, u);
-    const f3 r = normalized3(cross3(v01 - v00, v10 - v00));
-    nmap.at(v, u) = r.x;
-    nmap.at(v + rows, u) = r.y;
-    nmap.at(v + 2 * rows, u) = r.z;
-  } else {
-    nmap.at(v, u) = qnan();
+  __device__ void operator()(int u, int v) const {
+    const bool border = u == cols - 1 || v == rows - 1;
+    const f3 nan3 = mk3(qnan(), 0.f, 0.f);
+    const f3 n = live::normal_of(vertex(v, u), border ? nan3 : vertex(v, u + 1), border ? nan3 : vertex(v + 1, u), border);
+    nmap.at(v, u) = n.x;
+    if (!isnan(n.x)) {
+      nmap.at(v + rows, u) = n.y;
+      nmap.at(v + 2 * rows, u) = n.z;
+    }
   }
-}
+};
 
 // ---------------------------------------------------------------------------------------
 // tranformMaps (reference tranformMapsKernel ×2, cudafuncs.cu:200-274); in-place capable
@@ -230,54 +211,18 @@ __global__ void k_resizeMap(int drows, int dcols, int srows, View<const float> i
   out.at(y + 2 * drows, x) = n.z;
 }
 
-// ---------------------------------------------------------------------------------------
-// pyrDownGaussF: float depth 5×5, NaN-skipping, integer weight count
-// (reference pyrDownKernelGaussF, cudafuncs.cu:416-443).  The 25 weights live in
-// registers / constant operands instead of a per-call cudaMalloc'd table (:532-541).
-// ---------------------------------------------------------------------------------------
-__global__ void k_pyrDownGaussF(View<const float> src, View<float> dst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const int D = 5;
-  const int tx = min(2 * x - D / 2 + D, src.cols - 1);
-  const int ty = min(2 * y - D / 2 + D, src.rows - 1);
-  float sum = 0.f;
-  int count = 0;
-  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-      const float s = src.at(cy, cx);
-      if (!isnan(s)) {
-        const float g = gauss25(ty - cy - 1, tx - cx - 1);
-        sum += s * g;
-        count += (int)g;
-      }
-    }
-  dst.at(y, x) = sum / (float)count;
-}
-
-// reference pyrDownKernelIntensityGauss (cudafuncs.cu:544-573): zero-skipping, result
-// truncated to u8; an empty window gives NaN -> 0.
-__global__ void k_pyrDownUchar(View<const unsigned char> src, View<unsigned char> dst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const int D = 5;
-  const int tx = min(2 * x - D / 2 + D, src.cols - 1);
-  const int ty = min(2 * y - D / 2 + D, src.rows - 1);
-  float sum = 0.f;
-  int count = 0;
-  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-      const unsigned char s = src.at(cy, cx);
-      if (s > 0) {
-        const float g = gauss25(ty - cy - 1, tx - cx - 1);
-        sum += (float)s * g;
-        count += (int)g;
-      }
-    }
-  dst.at(y, x) = (unsigned char)f2i_rz(sum / (float)count);
-}
+struct OpFloatHalf {  // dms_pyrDownGaussF (pyrDownGaussF, cudafuncs.cu:446-542)
+  live::Pitched<float> src;
+  View<float> dst;
+  int scols, srows;
+  __device__ void operator()(int x, int y) const { dst.at(y, x) = live::float_half(src, x, y, scols, srows); }
+};
+struct OpU8Half {  // dms_pyrDownUcharGauss (pyrDownUcharGauss, cudafuncs.cu:575-595)
+  live::Pitched<unsigned char> src;
+  View<unsigned char> dst;
+  int scols, srows;
+  __device__ void operator()(int x, int y) const { dst.at(y, x) = live::u8_half(src, x, y, scols, srows); }
+};
 
 // ---------------------------------------------------------------------------------------
 // Fused model-side pyramid of the frame step (initICPModel + initRGBModel of ElasticFusion.cpp:172-189
@@ -457,27 +402,10 @@ __device__ __forceinline__ void model_pyr_step1_body(int bx, int by, const Model
   const int x = bx * blockDim.x + threadIdx.x;
   const int y = by * blockDim.y + threadIdx.y;
   if (x >= ddst.cols || y >= ddst.rows) return;
-  const int D = 5;
-  const int tx = min(2 * x - D / 2 + D, cols0 - 1);
-  const int ty = min(2 * y - D / 2 + D, rows0 - 1);
-  float sum = 0.f, isum = 0.f;
-  int count = 0, icount = 0;
-  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-      const float g = gauss25(ty - cy - 1, tx - cx - 1);
-      const float s = s_d[cy - sy0][cx - sx0];
-      if (!isnan(s)) {
-        sum += s * g;
-        count += (int)g;
-      }
-      const unsigned char c = s_c[cy - sy0][cx - sx0];
-      if (c > 0) {
-        isum += (float)c * g;
-        icount += (int)g;
-      }
-    }
-  ddst.at(y, x) = sum / (float)count;
-  idst.at(y, x) = (unsigned char)f2i_rz(isum / (float)icount);
+  const live::Tile<float, TW + 1> dt = {&s_d[0][0], sy0, sx0};
+  const live::Tile<unsigned char, TW + 1> ct = {&s_c[0][0], sy0, sx0};
+  ddst.at(y, x) = live::float_half(dt, x, y, cols0, rows0);
+  idst.at(y, x) = live::u8_half(ct, x, y, cols0, rows0);
 }
 
 // Level 0 and levels 1 + 2 read the same sources and do not depend on each other: one launch, the first
@@ -525,67 +453,25 @@ __global__ void k_verticesToDepth2D(View<const float> vsrc, View<float> dst, flo
   dst.at(y, x) = (z > cutOff || z <= 0.f) ? qnan() : z;
 }
 
-// reference bgr2IntensityKernel (cudafuncs.cu:643-655): int(0.114 x + 0.299 y + 0.587 z)
-__global__ void k_rgbaToIntensity(View<const uchar4> src, View<unsigned char> dst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dst.cols || y >= dst.rows) return;
-  const uchar4 s = src.at(y, x);
-  const float f = ((float)s.x * 0.114f + (float)s.y * 0.299f) + (float)s.z * 0.587f;
-  dst.at(y, x) = (unsigned char)f2i_rz(f);
-}
-
-// reference applyKernel (cudafuncs.cu:674-695): 3×3 Scharr-like masks indexed from 8
-// downward over the clamped window (border quirk kept), float -> short truncation.
-__global__ void k_derivatives(View<const unsigned char> src, View<short> dx, View<short> dy) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= src.cols || y >= src.rows) return;
-  const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
-  const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
-  float dxVal = 0.f, dyVal = 0.f;
-  int k = 8;
-  for (int j = max(y - 1, 0); j <= min(y + 1, src.rows - 1); j++)
-    for (int i = max(x - 1, 0); i <= min(x + 1, src.cols - 1); i++) {
-      const float p = (float)src.at(j, i);
-      dxVal += p * gx[k];
-      dyVal += p * gy[k];
-      --k;
-    }
-  dx.at(y, x) = (short)f2i_rz(dxVal);
-  dy.at(y, x) = (short)f2i_rz(dyVal);
-}
-
-// k_derivatives plus the pose-independent part of the photometric correspondence test
-// (RGBResidual::getProducts, reduce.cu:775-797), evaluated once per frame and level instead of once
-// per Gauss-Newton iteration: gate = inside the border && all 16 taps of the clipped 4x4 window
-// non-zero && |grad|^2 >= minScale, with dx / dy exactly the values stored here.
-__global__ void k_derivatives_gate(View<const unsigned char> src, View<short> dx, View<short> dy, View<unsigned char> gate, float minScale) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= src.cols || y >= src.rows) return;
-  const int cols = src.cols, rows = src.rows;
-  const float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
-  const float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
-  float dxVal = 0.f, dyVal = 0.f;
-  int k = 8;
-  for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); j++)
-    for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); i++) {
-      const float p = (float)src.at(j, i);
-      dxVal += p * gx[k];
-      dyVal += p * gy[k];
-      --k;
-    }
-  const short sx = (short)f2i_rz(dxVal), sy = (short)f2i_rz(dyVal);
-  dx.at(y, x) = sx;
-  dy.at(y, x) = sy;
-  bool ok = (x < cols - 5 && y < rows - 1);
-  for (int u = max(y - 2, 0); u < min(y + 2, rows); u++)
-    for (int v = max(x - 2, 0); v < min(x + 2, cols); v++) ok = ok && (src.at(u, v) > 0);
-  const int vx = sx, vy = sy;
-  const float mTwo = (float)(vx * vx + vy * vy);
-  gate.at(y, x) = (ok && mTwo >= minScale) ? 1 : 0;
-}
+struct OpIntensity {  // dms_imageBGRToIntensity
+  View<const uchar4> src;
+  View<unsigned char> dst;
+  __device__ void operator()(int x, int y) const { dst.at(y, x) = live::intensity_of(src.at(y, x)); }
+};
+template <bool GATE>
+struct OpGradient {  // dms_computeDerivativeImages; GATE: + the per-frame photometric gate of the tracker (live_bodies.hpp)
+  live::Pitched<unsigned char> src;
+  View<short> dx, dy;
+  View<unsigned char> gate;
+  int cols, rows;
+  float minScale;
+  __device__ void operator()(int x, int y) const {
+    const live::Grad g = live::gradient_gate(src, x, y, cols, rows, minScale);
+    dx.at(y, x) = g.dx;
+    dy.at(y, x) = g.dy;
+    if (GATE) gate.at(y, x) = g.gate;
+  }
+};
 
 // reference projectPointsKernel (cudafuncs.cu:727-741); cloud is packed float3
 __global__ void k_projectPoints(View<const float> depth, View<float> cloud3, float invFx, float invFy, float cx, float cy) {
@@ -613,15 +499,17 @@ __global__ void k_projectPoints(View<const float> depth, View<float> cloud3, flo
 int pyrDown(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
   DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
   DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
-  LAUNCH2D(k_pyrDownDepth, dst->cols, dst->rows, s, view<const unsigned short>(src), view<unsigned short>(dst), 30.f);
+  const OpDepthHalf op = {{(const unsigned short*)src->data, (unsigned)src->pitch}, view<unsigned short>(dst), src->cols, src->rows};
+  LAUNCH2D(k_per_pixel<OpDepthHalf>, dst->cols, dst->rows, s, dst->cols, dst->rows, op);
   return DMS_OK;
 }
 
 int createVMap(const dms_camera* intr, const dms_image2d* depth, dms_image2d* vmap, float cutoff, hipStream_t s) {
   DMS_REQUIRE(intr && depth && vmap && depth->data && vmap->data, "null argument");
   DMS_REQUIRE(vmap->rows == depth->rows * 3 && vmap->cols == depth->cols, "vmap must be (3*rows) x cols");
-  LAUNCH2D(k_createVMap, depth->cols, depth->rows, s, view<const unsigned short>(depth), view<float>(vmap), 1.f / intr->fx,
-           1.f / intr->fy, intr->cx, intr->cy, cutoff);
+  const OpVertexMap op = {{(const unsigned short*)depth->data, (unsigned)depth->pitch}, view<float>(vmap),
+                          {1.f / intr->fx, 1.f / intr->fy, intr->cx, intr->cy}, cutoff, depth->rows};
+  LAUNCH2D(k_per_pixel<OpVertexMap>, depth->cols, depth->rows, s, depth->cols, depth->rows, op);
   return DMS_OK;
 }
 
@@ -629,7 +517,8 @@ int createNMap(const dms_image2d* vmap, dms_image2d* nmap, hipStream_t s) {
   DMS_REQUIRE(vmap && nmap && vmap->data && nmap->data, "null argument");
   DMS_REQUIRE(vmap->rows == nmap->rows && vmap->cols == nmap->cols && vmap->rows % 3 == 0, "shape mismatch");
   const int rows = vmap->rows / 3, cols = vmap->cols;
-  LAUNCH2D(k_createNMap, cols, rows, s, rows, cols, view<const float>(vmap), view<float>(nmap));
+  const OpNormalMap op = {view<const float>(vmap), view<float>(nmap), rows, cols};
+  LAUNCH2D(k_per_pixel<OpNormalMap>, cols, rows, s, cols, rows, op);
   return DMS_OK;
 }
 
@@ -692,14 +581,16 @@ int resizeMap(const dms_image2d* in, dms_image2d* out, bool normalize, hipStream
 int pyrDownGaussF(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
   DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
   DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
-  LAUNCH2D(k_pyrDownGaussF, dst->cols, dst->rows, s, view<const float>(src), view<float>(dst));
+  const OpFloatHalf op = {{(const float*)src->data, (unsigned)src->pitch}, view<float>(dst), src->cols, src->rows};
+  LAUNCH2D(k_per_pixel<OpFloatHalf>, dst->cols, dst->rows, s, dst->cols, dst->rows, op);
   return DMS_OK;
 }
 
 int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
   DMS_REQUIRE(src && dst && src->data && dst->data, "null image");
   DMS_REQUIRE(dst->rows == src->rows / 2 && dst->cols == src->cols / 2, "dst must be src/2");
-  LAUNCH2D(k_pyrDownUchar, dst->cols, dst->rows, s, view<const unsigned char>(src), view<unsigned char>(dst));
+  const OpU8Half op = {{(const unsigned char*)src->data, (unsigned)src->pitch}, view<unsigned char>(dst), src->cols, src->rows};
+  LAUNCH2D(k_per_pixel<OpU8Half>, dst->cols, dst->rows, s, dst->cols, dst->rows, op);
   return DMS_OK;
 }
 
@@ -755,14 +646,16 @@ int verticesToDepth2D(const dms_image2d* vsrc, dms_image2d* dst, float cutOff, h
 
 int imageToIntensity(const dms_image2d* rgba, dms_image2d* dst, hipStream_t s) {
   DMS_REQUIRE(rgba && dst && rgba->data && dst->data && rgba->rows == dst->rows && rgba->cols == dst->cols, "shape mismatch");
-  LAUNCH2D(k_rgbaToIntensity, dst->cols, dst->rows, s, view<const uchar4>(rgba), view<unsigned char>(dst));
+  const OpIntensity op = {view<const uchar4>(rgba), view<unsigned char>(dst)};
+  LAUNCH2D(k_per_pixel<OpIntensity>, dst->cols, dst->rows, s, dst->cols, dst->rows, op);
   return DMS_OK;
 }
 
 int derivativeImages(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, hipStream_t s) {
   DMS_REQUIRE(src && dx && dy && src->data && dx->data && dy->data, "null argument");
   DMS_REQUIRE(dx->rows == src->rows && dx->cols == src->cols && dy->rows == src->rows && dy->cols == src->cols, "shape mismatch");
-  LAUNCH2D(k_derivatives, src->cols, src->rows, s, view<const unsigned char>(src), view<short>(dx), view<short>(dy));
+  const OpGradient<false> op = {{(const unsigned char*)src->data, (unsigned)src->pitch}, view<short>(dx), view<short>(dy), view<unsigned char>(src), src->cols, src->rows, 0.f};
+  LAUNCH2D(k_per_pixel<OpGradient<false>>, src->cols, src->rows, s, src->cols, src->rows, op);
   return DMS_OK;
 }
 
@@ -771,8 +664,8 @@ int derivativeGate(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, dms
   DMS_REQUIRE(dx->rows == src->rows && dx->cols == src->cols && dy->rows == src->rows && dy->cols == src->cols && gate->rows == src->rows &&
                   gate->cols == src->cols,
               "shape mismatch");
-  LAUNCH2D(k_derivatives_gate, src->cols, src->rows, s, view<const unsigned char>(src), view<short>(dx), view<short>(dy),
-           view<unsigned char>(gate), minScale);
+  const OpGradient<true> op = {{(const unsigned char*)src->data, (unsigned)src->pitch}, view<short>(dx), view<short>(dy), view<unsigned char>(gate), src->cols, src->rows, minScale};
+  LAUNCH2D(k_per_pixel<OpGradient<true>>, src->cols, src->rows, s, src->cols, src->rows, op);
   return DMS_OK;
 }
 
