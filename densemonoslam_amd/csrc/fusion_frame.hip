@@ -17,13 +17,16 @@
 #include "smallmath.hpp"
 #include "surfel.hpp"
 #include "frame_state.hpp"
+#include "live_bodies.hpp"
 #include "fill.hpp"
 
 struct dms_odometry;
 
 namespace dms {
 // fusion_pre.hip
-int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s, int narrow_blocks = 0);
+int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s, int narrow_blocks = 0,
+                    const dms_image2d* metric_filtered = nullptr, const dms_image2d* depth_l0 = nullptr, const dms_image2d* vmap_l0 = nullptr,
+                    const dms_camera* cam_l0 = nullptr, float vmap_cutoff = 0.f);
 int depth_metric(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s);
 int fill_in(const dms_predict_out* ex, const dms_image2d* depth, const dms_image2d* rgba, const dms_camera* cam, int pass_geom,
             int pass_rgb, dms_predict_out* out, hipStream_t s, const void* mirror_src = nullptr, void* mirror_dst = nullptr,
@@ -81,12 +84,33 @@ int computeNIDDepth(const dms_image2d* dmap_kf, const dms_image2d* dmap_kf_old, 
 void odometry_bind_live(dms_odometry* o, int k);
 void odometry_bind_lastnext(dms_odometry* o, int k);
 int odometry_initRGB_image(dms_odometry* o, const dms_image2d* rgba, hipStream_t s);
+int odometry_live_views(dms_odometry* o, dms_image2d* depth, dms_image2d* vmap, dms_image2d* nmap, dms_image2d* image, dms_image2d* dx,
+                        dms_image2d* dy, dms_image2d* gate, float* minScale, bool mark_derivatives);
+int liveLevelsFused(const dms_image2d* depth, const dms_image2d* vmap, const dms_image2d* nmap, const dms_image2d* image, const dms_image2d* dx,
+                    const dms_image2d* dy, const dms_image2d* gate, const dms_camera* cam0, float cutoff, const float* minScale, hipStream_t s);
 void odometry_alias_next_depth(dms_odometry* o);
 
 // RGB8 (3 B/px, as the reference uploads, ElasticFusion.cpp:111) -> RGBA8 texture
 __global__ void k_rgb_to_rgba(const unsigned char* __restrict__ rgb, uchar4* __restrict__ rgba, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x)
     rgba[i] = make_uchar4(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2], 255);
+}
+
+// The whole "upload" of a frame in one pass over its pixels (ElasticFusion.cpp:111-119 + the first step of initRGB): the
+// colour texel (RGB8 -> RGBA8, or an RGBA8 copy), the raw depth, its metric form (metriciseDepth of the raw image,
+// depth_metric.frag:28-39) and — when the tracker wants it — the level-0 intensity of that texel (bgr2Intensity).
+__global__ __launch_bounds__(256) void k_live_ingest(const unsigned char* __restrict__ rgb, int channels, const unsigned short* __restrict__ depth,
+                                                     uchar4* __restrict__ rgba, unsigned short* __restrict__ depth_raw,
+                                                     float* __restrict__ depth_metric, unsigned char* __restrict__ intensity, int n, float maxD) {
+  const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    const uchar4 c = channels == 3 ? make_uchar4(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2], 255) : reinterpret_cast<const uchar4*>(rgb)[i];
+    rgba[i] = c;
+    const unsigned v = depth[i];
+    depth_raw[i] = (unsigned short)v;
+    depth_metric[i] = (v > gate || v < 300U) ? 0.f : (float)v / 1000.0f;
+    if (intensity) intensity[i] = live::intensity_of(c);
+  }
 }
 
 struct Pose16 {
@@ -249,6 +273,7 @@ struct dms_fusion {
   dms_image2d rgba, depth_raw, depth_filtered, depth_metric, depth_metric_filtered;
   hipStream_t s_prep = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_inputs = nullptr;
+  bool fused_live = true;  // the live half as three fused launches (DMS_FUSED_LIVE=0: the operator chain, fifteen)
   int prep_blocks = 64;  // fat blocks of the bilateral filter on the prep stream: 64 per 640x480 pixels, set at creation (DMS_PREP_BLOCKS; 0 = one tile per block)
   int host_lag = 2;  // the host enqueues frame t once frame t - host_lag has completed (DMS_HOST_LAG = 2 | 3; 3 measured -2.4 %)
   bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
@@ -669,6 +694,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     f->prep_blocks = (int)(b < 32 ? 32 : (b > 160 ? 160 : b));
   }
   if (const char* pb = getenv("DMS_PREP_BLOCKS")) f->prep_blocks = atoi(pb);
+  if (const char* fl = getenv("DMS_FUSED_LIVE")) f->fused_live = atoi(fl) != 0;
   if (const char* hl = getenv("DMS_HOST_LAG")) f->host_lag = atoi(hl) == 3 ? 3 : 2;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
@@ -816,36 +842,66 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   f->depth_metric_filtered = f->live[k2].depth_metric_filtered;
   odometry_bind_live(f->odom, k3);
   odometry_bind_lastnext(f->odom, k3prev);
-  // "upload": the frame is already in HBM; bring it into the context's textures (ElasticFusion.cpp:111-114)
-  {
-    FTimer t(f, sp, "ingest");
-    if (rgb_channels == 3)
-      hipLaunchKernelGGL(k_rgb_to_rgba, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, sp, (const unsigned char*)rgb_dev,
-                         (uchar4*)f->rgba.data, N);
-    else
-      DMS_HIP(hipMemcpyAsync(f->rgba.data, rgb_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, sp));
-    DMS_CHECK_LAUNCH();
-    DMS_HIP(hipMemcpyAsync(f->depth_raw.data, depth_dev, (size_t)N * 2, hipMemcpyDeviceToDevice, sp));
-  }
-  {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
-    FTimer t(f, sp, "preprocess");
-    // (fat blocks only while the caller's stream is busy: they exist to leave the previous frame's tracker its compute
-    // units; when nothing is running there — the first frame after a pause — the whole-chip form is 2.5x shorter and this
-    // frame's tracker is waiting for it)
-    bool beside_tracker = f->p.pipeline_ingest != 0;
-    if (beside_tracker && hipStreamQuery(s) == hipSuccess) beside_tracker = false;
-    (void)hipGetLastError();  // (hipErrorNotReady is the expected answer)
-    if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp, beside_tracker ? f->prep_blocks : 0))) return rc;
-    if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, sp))) return rc;
-    if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, sp))) return rc;
-  }
-  {  // live half of frameToModel.initICP / initRGB (ElasticFusion.cpp:190-194): depth pyramid, vertex / normal
-     // maps, intensity pyramid and its derivatives.  At the first frame the intensity pyramid is
-     // what initFirstRGB computes (ElasticFusion.cpp:151); it becomes lastNextImage of frame 1.
-    FTimer t(f, sp, "live_pyramids");
-    if (f->p.hybrid_tracking || f->frames == 0) {
-      if ((rc = dms_odometry_initICP_depth(f->odom, &f->depth_filtered, f->p.maxDepthProcessed, sp))) return rc;
-      if ((rc = odometry_initRGB_image(f->odom, &f->rgba, sp))) return rc;
+  const bool want_live = f->p.hybrid_tracking || f->frames == 0;  // the tracker's live pyramids (at the first frame: what initFirstRGB computes, :151)
+  if (f->fused_live) {
+    // The live half in three launches (prep.hip "Fused live half"): ingest (+ raw metric depth + level-0 intensity), the depth
+    // filter (+ filtered metric depth + level-0 depth and vertex map in its epilogue), and one kernel for everything else of the
+    // three pyramid levels.  Same bits as the operator chain below (GPU test).
+    dms_image2d ld[3], lv[3], ln[3], li[3], ldx[3], ldy[3], lg[3];
+    float minScale[3];
+    odometry_live_views(f->odom, ld, lv, ln, li, ldx, ldy, lg, minScale, want_live);
+    {
+      FTimer t(f, sp, "ingest");
+      hipLaunchKernelGGL(k_live_ingest, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, sp, (const unsigned char*)rgb_dev, rgb_channels,
+                         depth_dev, (uchar4*)f->rgba.data, (unsigned short*)f->depth_raw.data, (float*)f->depth_metric.data,
+                         want_live ? (unsigned char*)li[0].data : (unsigned char*)nullptr, N, f->p.depthCut);
+      DMS_CHECK_LAUNCH();
+    }
+    {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
+      FTimer t(f, sp, "preprocess");
+      bool beside_tracker = f->p.pipeline_ingest != 0;
+      if (beside_tracker && hipStreamQuery(s) == hipSuccess) beside_tracker = false;  // (see the operator chain below)
+      (void)hipGetLastError();
+      if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp, beside_tracker ? f->prep_blocks : 0, &f->depth_metric_filtered,
+                                want_live ? &ld[0] : nullptr, want_live ? &lv[0] : nullptr, &f->cam, f->p.maxDepthProcessed)))
+        return rc;
+    }
+    if (want_live) {
+      FTimer t(f, sp, "live_pyramids");
+      if ((rc = liveLevelsFused(ld, lv, ln, li, ldx, ldy, lg, &f->cam, f->p.maxDepthProcessed, minScale, sp))) return rc;
+    }
+  } else {
+    // "upload": the frame is already in HBM; bring it into the context's textures (ElasticFusion.cpp:111-114)
+    {
+      FTimer t(f, sp, "ingest");
+      if (rgb_channels == 3)
+        hipLaunchKernelGGL(k_rgb_to_rgba, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, sp, (const unsigned char*)rgb_dev,
+                           (uchar4*)f->rgba.data, N);
+      else
+        DMS_HIP(hipMemcpyAsync(f->rgba.data, rgb_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, sp));
+      DMS_CHECK_LAUNCH();
+      DMS_HIP(hipMemcpyAsync(f->depth_raw.data, depth_dev, (size_t)N * 2, hipMemcpyDeviceToDevice, sp));
+    }
+    {  // filterDepth + metriciseDepth (ElasticFusion.cpp:118-119)
+      FTimer t(f, sp, "preprocess");
+      // (fat blocks only while the caller's stream is busy: they exist to leave the previous frame's tracker its compute
+      // units; when nothing is running there — the first frame after a pause — the whole-chip form is 2.5x shorter and this
+      // frame's tracker is waiting for it)
+      bool beside_tracker = f->p.pipeline_ingest != 0;
+      if (beside_tracker && hipStreamQuery(s) == hipSuccess) beside_tracker = false;
+      (void)hipGetLastError();  // (hipErrorNotReady is the expected answer)
+      if ((rc = depth_bilateral(&f->depth_raw, &f->depth_filtered, f->p.depthCut, sp, beside_tracker ? f->prep_blocks : 0))) return rc;
+      if ((rc = depth_metric(&f->depth_raw, &f->depth_metric, f->p.depthCut, sp))) return rc;
+      if ((rc = depth_metric(&f->depth_filtered, &f->depth_metric_filtered, f->p.depthCut, sp))) return rc;
+    }
+    {  // live half of frameToModel.initICP / initRGB (ElasticFusion.cpp:190-194): depth pyramid, vertex / normal
+       // maps, intensity pyramid and its derivatives.  At the first frame the intensity pyramid is
+       // what initFirstRGB computes (ElasticFusion.cpp:151); it becomes lastNextImage of frame 1.
+      FTimer t(f, sp, "live_pyramids");
+      if (f->p.hybrid_tracking || f->frames == 0) {
+        if ((rc = dms_odometry_initICP_depth(f->odom, &f->depth_filtered, f->p.maxDepthProcessed, sp))) return rc;
+        if ((rc = odometry_initRGB_image(f->odom, &f->rgba, sp))) return rc;
+      }
     }
   }
   if (f->p.pipeline_ingest) {

@@ -3,6 +3,7 @@
 // All are one-thread-per-pixel streaming kernels over dense row-major images.
 #include "surfel.hpp"
 #include "fill.hpp"
+#include "live_bodies.hpp"
 
 namespace dms {
 
@@ -22,9 +23,38 @@ static constexpr int BX = 64, BY = 4;
 // -87 cut-off whatever the distance): a 49 x 396 table in LDS, filled once per block with the very expression of the
 // direct form, replaces ~25 instructions per tap by one LDS read — the same bits, a third of the time.
 constexpr int kBilDv = 396;
+
+// What else the frame step derives from a filtered depth value, per pixel, in the filter's own store (three launches and two
+// more passes over the image otherwise): its metric form (metriciseDepth of the filtered image, ElasticFusion.cpp:119), the
+// tracker's level-0 depth (the copy of RGBDOdometry::initICP, RGBDOdometry.cpp:122-128) and the level-0 vertex map
+// (createVMap at level 0, :132-137).  All optional (null = skip).
+struct BilateralEpilogue {
+  float* metric_filtered;     // dense float image
+  unsigned short* depth_l0;   // dense u16 image
+  float* vmap_l0;             // three stacked dense planes of `rows` rows
+  live::LevelCam cam;
+  float vmap_cutoff;
+};
+__device__ __forceinline__ void bilateral_store(unsigned short* __restrict__ dst, const BilateralEpilogue& ep, int px, int py, int cols, int rows,
+                                                unsigned short v, unsigned gate) {
+  const size_t i = (size_t)py * cols + px;
+  dst[i] = v;
+  if (ep.metric_filtered) ep.metric_filtered[i] = ((unsigned)v > gate || (unsigned)v < 300U) ? 0.f : (float)v / 1000.0f;  // depth_metric.frag:28-39
+  if (ep.depth_l0) ep.depth_l0[i] = v;
+  if (ep.vmap_l0) {
+    const f3 p = live::vertex_of(v, px, py, ep.cam, ep.vmap_cutoff);
+    const size_t plane = (size_t)rows * cols;
+    ep.vmap_l0[i] = p.x;
+    if (!isnan(p.x)) {
+      ep.vmap_l0[plane + i] = p.y;
+      ep.vmap_l0[2 * plane + i] = p.z;
+    }
+  }
+}
+
 template <int TBY, bool LUT>
 __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
-                                                             int cols, int rows, float maxD) {
+                                                             int cols, int rows, float maxD, BilateralEpilogue ep) {
   constexpr int HALO = 8;
   __shared__ int s_sx[BX + 2 * HALO];
   __shared__ int s_sy[TBY + 2 * HALO];
@@ -66,7 +96,7 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
     const unsigned value = src[(size_t)py * cols + px];
     const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
     if (value > gate || value < 300U) {
-      dst[(size_t)py * cols + px] = 0;
+      bilateral_store(dst, ep, px, py, cols, rows, 0, gate);
       continue;
     }
     // int(texcoord * cols): texcoord of the fragment centre
@@ -103,7 +133,7 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
             sum2 += weight;
           }
         }
-        dst[(size_t)py * cols + px] = (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2));
+        bilateral_store(dst, ep, px, py, cols, rows, (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2)), gate);
         continue;
       }
     }
@@ -133,7 +163,7 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
         sum2 += weight;
       }
     }
-    dst[(size_t)py * cols + px] = (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2));
+    bilateral_store(dst, ep, px, py, cols, rows, (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2)), gate);
   }
 }
 
@@ -179,16 +209,36 @@ __global__ void k_resize_nn(const T* __restrict__ src, int scols, int srows, T* 
 
 static bool dense(const dms_image2d* im, size_t elem) { return im && im->data && im->pitch == (size_t)im->cols * elem; }
 
-int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s, int narrow_blocks) {
+int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStream_t s, int narrow_blocks, const dms_image2d* metric_filtered,
+                    const dms_image2d* depth_l0, const dms_image2d* vmap_l0, const dms_camera* cam_l0, float vmap_cutoff) {
   DMS_REQUIRE(dense(src, 2) && dense(dst, 2), "dense u16 images required");
   DMS_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, "shape mismatch");
+  BilateralEpilogue ep;
+  memset(&ep, 0, sizeof(ep));
+  if (metric_filtered) {
+    DMS_REQUIRE(dense(metric_filtered, 4) && metric_filtered->rows == src->rows && metric_filtered->cols == src->cols, "metric image shape");
+    ep.metric_filtered = (float*)metric_filtered->data;
+  }
+  if (depth_l0) {
+    DMS_REQUIRE(dense(depth_l0, 2) && depth_l0->rows == src->rows && depth_l0->cols == src->cols, "level-0 depth shape");
+    ep.depth_l0 = (unsigned short*)depth_l0->data;
+  }
+  if (vmap_l0) {
+    DMS_REQUIRE(cam_l0 && dense(vmap_l0, 4) && vmap_l0->rows == 3 * src->rows && vmap_l0->cols == src->cols, "level-0 vertex map shape");
+    ep.vmap_l0 = (float*)vmap_l0->data;
+    ep.cam.fx_inv = 1.f / cam_l0->fx;
+    ep.cam.fy_inv = 1.f / cam_l0->fy;
+    ep.cam.cx = cam_l0->cx;
+    ep.cam.cy = cam_l0->cy;
+    ep.vmap_cutoff = vmap_cutoff;
+  }
   if (narrow_blocks > 0) {  // a few 1 024-thread blocks that keep to their compute units (see the kernel)
     hipLaunchKernelGGL((k_depth_bilateral<16, true>), dim3(narrow_blocks), dim3(BX, 16), 0, s, (const unsigned short*)src->data,
-                       (unsigned short*)dst->data, src->cols, src->rows, maxD);
+                       (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
   } else {
     const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + BY - 1) / BY);
     hipLaunchKernelGGL((k_depth_bilateral<BY, false>), dim3(tiles), dim3(BX, BY), 0, s, (const unsigned short*)src->data,
-                       (unsigned short*)dst->data, src->cols, src->rows, maxD);
+                       (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
   }
   DMS_CHECK_LAUNCH();
   return DMS_OK;

@@ -473,6 +473,194 @@ struct OpGradient {  // dms_computeDerivativeImages; GATE: + the per-frame photo
   }
 };
 
+// ---------------------------------------------------------------------------------------
+// Fused live half of the frame step.  What RGBDOdometry::initICP(filteredDepth) + initRGB(rgb) + the Sobel pass do in
+// fifteen launches of the operator layer (pyrDown x2, createVMap x3, createNMap x3, bgr2Intensity, pyrDownUcharGauss x2,
+// derivatives x3: RGBDOdometry.cpp:118-142, :244-266, :279-283) is here
+//   * the depth filter's epilogue (fusion_pre.hip): level-0 depth + level-0 vertex map of the value it has just filtered;
+//   * k_live_ingest (fusion_frame.hip): level-0 intensity of the texel it has just converted;
+//   * ONE launch of k_live_levels: group A — level-0 normals and level-0 gradients / gate, one thread per pixel; group B —
+//     everything of levels 1 and 2 (depth, vertex, normal, intensity, gradients, gate), one block per 16 x 16 level-1 tile,
+//     computed from LDS tiles of the level-0 depth and intensity: each level-0 texel is read from memory once per block and
+//     every intermediate level stays in LDS.
+// The bodies are live_bodies.hpp's: the same bits as the operator chain (GPU test).
+// ---------------------------------------------------------------------------------------
+struct LiveLevel {
+  unsigned short* depth;  // dense u16
+  float* vmap;            // 3 stacked dense planes
+  float* nmap;
+  unsigned char* image;   // dense u8
+  short* dx;
+  short* dy;
+  unsigned char* gate;
+  int cols, rows;
+  live::LevelCam cam;
+  float minScale;
+};
+struct LiveArgs {
+  LiveLevel L[3];
+  float cutoff;
+  int gAx, gAy;  // group A: 64 x 4 tiles of level 0
+  int gBx, gBy;  // group B: 16 x 16 tiles of level 1
+};
+
+__device__ __forceinline__ void store3(float* base, int rows, int cols, int y, int x, const f3& p) {
+  const size_t i = (size_t)y * cols + x, plane = (size_t)rows * cols;
+  base[i] = p.x;
+  if (!isnan(p.x)) {
+    base[plane + i] = p.y;
+    base[2 * plane + i] = p.z;
+  }
+}
+
+// group A: level 0, one thread per pixel.  The normal needs the vertices of the pixel, its right and its lower neighbour:
+// re-derived from the level-0 depth (the expression of the filter's epilogue), so nothing waits for the vertex map.
+__device__ __forceinline__ void live_level0_pixel(const LiveArgs& a, int x, int y) {
+  const LiveLevel& l = a.L[0];
+  if (x >= l.cols || y >= l.rows) return;
+  const live::Pitched<unsigned short> d = {l.depth, (unsigned)l.cols * 2u};
+  const bool border = x == l.cols - 1 || y == l.rows - 1;
+  const f3 nan3 = mk3(qnan(), 0.f, 0.f);
+  const f3 here = live::vertex_of(d(y, x), x, y, l.cam, a.cutoff);
+  const f3 right = border ? nan3 : live::vertex_of(d(y, x + 1), x + 1, y, l.cam, a.cutoff);
+  const f3 below = border ? nan3 : live::vertex_of(d(y + 1, x), x, y + 1, l.cam, a.cutoff);
+  store3(l.nmap, l.rows, l.cols, y, x, live::normal_of(here, right, below, border));
+  const live::Pitched<unsigned char> img = {l.image, (unsigned)l.cols};
+  const live::Grad g = live::gradient_gate(img, x, y, l.cols, l.rows, l.minScale);
+  const size_t i = (size_t)y * l.cols + x;
+  l.dx[i] = g.dx;
+  l.dy[i] = g.dy;
+  l.gate[i] = g.gate;
+}
+
+// group B tile geometry (level-1 tile of T1 x T1 pixels at (X1, Y1) = (16 bx, 16 by); level-2 tile T2 x T2 at (X1 / 2, Y1 / 2)):
+//   level-2 depth      [X2, X2 + T2]            (+1: forward difference of the normal)                 origin X2      width T2 + 1
+//   level-2 intensity  [X2 - 2, X2 + T2 + 1]    (gate window -2 .. +1, gradient -1 .. +1)              origin X2 - 2  width T2 + 4
+//   level-1 depth      [X1 - 2, X1 + T1 + 2]    (own + 1, and the 5 x 5 sources of level-2 depth)      origin X1 - 2  width T1 + 5
+//   level-1 intensity  [X1 - 6, X1 + T1 + 4]    (own windows, and the sources of level-2 intensity)    origin X1 - 6  width T1 + 11
+//   level-0 depth      [2 X1 - 6, 2 X1 + 2 T1 + 6]                                                      origin 2 X1 - 6   width 2 T1 + 13
+//   level-0 intensity  [2 X1 - 14, 2 X1 + 2 T1 + 10]                                                    origin 2 X1 - 14  width 2 T1 + 25
+constexpr int kT1 = 16, kT2 = 8;
+constexpr int kD2W = kT2 + 1, kI2W = kT2 + 4, kD1W = kT1 + 5, kI1W = kT1 + 11, kD0W = 2 * kT1 + 13, kI0W = 2 * kT1 + 25;
+
+__device__ __forceinline__ void live_levels12_tile(const LiveArgs& a, int bx, int by) {
+  __shared__ unsigned short s_d0[kD0W * kD0W], s_d1[kD1W * kD1W], s_d2[kD2W * kD2W];
+  __shared__ unsigned char s_i0[kI0W * kI0W], s_i1[kI1W * kI1W], s_i2[kI2W * kI2W];
+  const LiveLevel &l0 = a.L[0], &l1 = a.L[1], &l2 = a.L[2];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+  const int X1 = bx * kT1, Y1 = by * kT1, X2 = X1 / 2, Y2 = Y1 / 2;
+  // ---- level-0 tiles from memory (texels outside the image are never read by a body: zero) ----
+  const int d0x = 2 * X1 - 6, d0y = 2 * Y1 - 6, i0x = 2 * X1 - 14, i0y = 2 * Y1 - 14;
+  for (int e = tid; e < kD0W * kD0W; e += nt) {
+    const int r = e / kD0W, c = e - r * kD0W, gy = d0y + r, gx = d0x + c;
+    s_d0[e] = (gx >= 0 && gy >= 0 && gx < l0.cols && gy < l0.rows) ? l0.depth[(size_t)gy * l0.cols + gx] : (unsigned short)0;
+  }
+  for (int e = tid; e < kI0W * kI0W; e += nt) {
+    const int r = e / kI0W, c = e - r * kI0W, gy = i0y + r, gx = i0x + c;
+    s_i0[e] = (gx >= 0 && gy >= 0 && gx < l0.cols && gy < l0.rows) ? l0.image[(size_t)gy * l0.cols + gx] : (unsigned char)0;
+  }
+  __syncthreads();
+  // ---- level 1 into LDS ----
+  const live::Tile<unsigned short, kD0W> td0 = {s_d0, d0y, d0x};
+  const live::Tile<unsigned char, kI0W> ti0 = {s_i0, i0y, i0x};
+  const int d1x = X1 - 2, d1y = Y1 - 2, i1x = X1 - 6, i1y = Y1 - 6;
+  for (int e = tid; e < kD1W * kD1W; e += nt) {
+    const int r = e / kD1W, c = e - r * kD1W, gy = d1y + r, gx = d1x + c;
+    s_d1[e] = (gx >= 0 && gy >= 0 && gx < l1.cols && gy < l1.rows) ? live::depth_half(td0, gx, gy, l0.cols, l0.rows) : (unsigned short)0;
+  }
+  for (int e = tid; e < kI1W * kI1W; e += nt) {
+    const int r = e / kI1W, c = e - r * kI1W, gy = i1y + r, gx = i1x + c;
+    s_i1[e] = (gx >= 0 && gy >= 0 && gx < l1.cols && gy < l1.rows) ? live::u8_half(ti0, gx, gy, l0.cols, l0.rows) : (unsigned char)0;
+  }
+  __syncthreads();
+  // ---- level 2 into LDS ----
+  const live::Tile<unsigned short, kD1W> td1 = {s_d1, d1y, d1x};
+  const live::Tile<unsigned char, kI1W> ti1 = {s_i1, i1y, i1x};
+  const int i2x = X2 - 2, i2y = Y2 - 2;
+  for (int e = tid; e < kD2W * kD2W; e += nt) {
+    const int r = e / kD2W, c = e - r * kD2W, gy = Y2 + r, gx = X2 + c;
+    s_d2[e] = (gx < l2.cols && gy < l2.rows) ? live::depth_half(td1, gx, gy, l1.cols, l1.rows) : (unsigned short)0;
+  }
+  for (int e = tid; e < kI2W * kI2W; e += nt) {
+    const int r = e / kI2W, c = e - r * kI2W, gy = i2y + r, gx = i2x + c;
+    s_i2[e] = (gx >= 0 && gy >= 0 && gx < l2.cols && gy < l2.rows) ? live::u8_half(ti1, gx, gy, l1.cols, l1.rows) : (unsigned char)0;
+  }
+  __syncthreads();
+  const live::Tile<unsigned short, kD2W> td2 = {s_d2, Y2, X2};
+  const live::Tile<unsigned char, kI2W> ti2 = {s_i2, i2y, i2x};
+  // ---- outputs: the block's own level-1 pixels (one per thread) and level-2 pixels (first 64 threads) ----
+  auto emit = [&](const LiveLevel& l, auto depth_tile, auto image_tile, int x, int y) {
+    if (x >= l.cols || y >= l.rows) return;
+    const size_t i = (size_t)y * l.cols + x;
+    const unsigned short d = depth_tile(y, x);
+    l.depth[i] = d;
+    l.image[i] = image_tile(y, x);
+    const bool border = x == l.cols - 1 || y == l.rows - 1;
+    const f3 nan3 = mk3(qnan(), 0.f, 0.f);
+    const f3 here = live::vertex_of(d, x, y, l.cam, a.cutoff);
+    const f3 right = border ? nan3 : live::vertex_of(depth_tile(y, x + 1), x + 1, y, l.cam, a.cutoff);
+    const f3 below = border ? nan3 : live::vertex_of(depth_tile(y + 1, x), x, y + 1, l.cam, a.cutoff);
+    store3(l.vmap, l.rows, l.cols, y, x, here);
+    store3(l.nmap, l.rows, l.cols, y, x, live::normal_of(here, right, below, border));
+    const live::Grad g = live::gradient_gate(image_tile, x, y, l.cols, l.rows, l.minScale);
+    l.dx[i] = g.dx;
+    l.dy[i] = g.dy;
+    l.gate[i] = g.gate;
+  };
+  emit(l1, td1, ti1, X1 + (tid & (kT1 - 1)), Y1 + (tid >> 4));
+  if (tid < kT2 * kT2) emit(l2, td2, ti2, X2 + (tid & (kT2 - 1)), Y2 + (tid >> 3));
+}
+
+__global__ __launch_bounds__(256) void k_live_levels(LiveArgs a) {
+  const int b = blockIdx.x, nB = a.gBx * a.gBy;
+  if (b < nB) {  // (the tile blocks first: each is a longer dependency chain than a level-0 block)
+    live_levels12_tile(a, b % a.gBx, b / a.gBx);
+  } else {
+    const int c = b - nB;
+    live_level0_pixel(a, (c % a.gAx) * 64 + threadIdx.x, (c / a.gAx) * 4 + threadIdx.y);
+  }
+}
+
+// depth / vmap / nmap / image / dx / dy / gate: the three pyramid levels of the tracker's live buffers (level-0 depth, vertex map
+// and intensity already written by the depth filter's epilogue and the ingest kernel)
+int liveLevelsFused(const dms_image2d* depth, const dms_image2d* vmap, const dms_image2d* nmap, const dms_image2d* image, const dms_image2d* dx,
+                    const dms_image2d* dy, const dms_image2d* gate, const dms_camera* cam0, float cutoff, const float* minScale, hipStream_t s) {
+  LiveArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int l = 0; l < 3; ++l) {
+    const int rows = depth[l].rows, cols = depth[l].cols;
+    DMS_REQUIRE(depth[l].pitch == (size_t)cols * 2 && vmap[l].pitch == (size_t)cols * 4 && nmap[l].pitch == (size_t)cols * 4 &&
+                    image[l].pitch == (size_t)cols && dx[l].pitch == (size_t)cols * 2 && dy[l].pitch == (size_t)cols * 2 &&
+                    gate[l].pitch == (size_t)cols,
+                "the fused live half needs dense images");
+    DMS_REQUIRE(l == 0 || (rows == depth[l - 1].rows / 2 && cols == depth[l - 1].cols / 2), "pyramid shape");
+    LiveLevel& L = a.L[l];
+    L.depth = (unsigned short*)depth[l].data;
+    L.vmap = (float*)vmap[l].data;
+    L.nmap = (float*)nmap[l].data;
+    L.image = (unsigned char*)image[l].data;
+    L.dx = (short*)dx[l].data;
+    L.dy = (short*)dy[l].data;
+    L.gate = (unsigned char*)gate[l].data;
+    L.cols = cols;
+    L.rows = rows;
+    const float div = (float)(1 << l);
+    L.cam.fx_inv = 1.f / (cam0->fx / div);
+    L.cam.fy_inv = 1.f / (cam0->fy / div);
+    L.cam.cx = cam0->cx / div;
+    L.cam.cy = cam0->cy / div;
+    L.minScale = minScale[l];
+  }
+  a.cutoff = cutoff;
+  a.gAx = (a.L[0].cols + 63) / 64;
+  a.gAy = (a.L[0].rows + 3) / 4;
+  a.gBx = (a.L[1].cols + kT1 - 1) / kT1;
+  a.gBy = (a.L[1].rows + kT1 - 1) / kT1;
+  hipLaunchKernelGGL(k_live_levels, dim3(a.gBx * a.gBy + a.gAx * a.gAy), dim3(64, 4), 0, s, a);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
 // reference projectPointsKernel (cudafuncs.cu:727-741); cloud is packed float3
 __global__ void k_projectPoints(View<const float> depth, View<float> cloud3, float invFx, float invFy, float cx, float cy) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;

@@ -2443,6 +2443,24 @@ void odometry_bind_lastnext(dms_odometry* o, int k) {
   for (int i = 0; i < DMS_NUM_PYRS; ++i) o->lastNextImage[i] = o->ring[k].nextImage[i];
 }
 
+// The bound live set's three pyramid levels, for the frame step's fused live half (prep.hip liveLevelsFused): it writes them
+// all itself and the derivative pyramid with them (`mark_derivatives`: the bookkeeping of nextDerivatives)
+int odometry_live_views(dms_odometry* o, dms_image2d* depth, dms_image2d* vmap, dms_image2d* nmap, dms_image2d* image, dms_image2d* dx,
+                        dms_image2d* dy, dms_image2d* gate, float* minScale, bool mark_derivatives) {
+  for (int l = 0; l < DMS_NUM_PYRS; ++l) {
+    depth[l] = o->depth_tmp[l].img();
+    vmap[l] = o->vmaps_curr[l].img();
+    nmap[l] = o->nmaps_curr[l].img();
+    image[l] = o->nextImage[l].img();
+    dx[l] = o->nextdIdx[l].img();
+    dy[l] = o->nextdIdy[l].img();
+    gate[l] = o->nextGate[l].img();
+    minScale[l] = rgb_min_scale(o, l);
+  }
+  if (mark_derivatives) o->deriv_of = o->nextImage[0].p;
+  return DMS_OK;
+}
+
 // live half of initRGB: intensity pyramid + derivative pyramid of the bound live set
 int odometry_initRGB_image(dms_odometry* o, const dms_image2d* rgba, hipStream_t s) {
   int rc = populateImage(rgba, o->nextImage, s);

@@ -231,7 +231,7 @@ class ops:
 
 _BUF_TYPES = {0: (np.float32, 1), 1: (np.float32, 1), 2: (np.float32, 1), 3: (np.float32, 1), 4: (np.float32, 1), 5: (np.float32, 1),
               6: (np.uint8, 1), 7: (np.uint8, 1), 8: (np.uint8, 1), 9: (np.int16, 1), 10: (np.int16, 1), 11: (np.float32, 3),
-              12: (np.uint16, 1), 13: (capi.DATATERM_DTYPE, 1)}
+              12: (np.uint16, 1), 13: (capi.DATATERM_DTYPE, 1), 14: (np.uint8, 1)}
 
 
 class RGBDOdometry:

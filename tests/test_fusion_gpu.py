@@ -1482,3 +1482,52 @@ def test_orb_global_loop_closure_device_half(fus, orc, synth):
     ro = o.processFrame(rgb, d)
     assert_bits(np.array(rg.pose, np.float32).reshape(4, 4), np.asarray(ro.pose, np.float32), "pose of the frame after applyGlobalLoop")
     surfels_equal(g.globalModel().downloadMap(), o.model, "map of the frame after applyGlobalLoop")
+
+
+@pytest.mark.parametrize("size", [(320, 240), (326, 250), (1241, 376)])
+def test_fused_live_half_equals_operator_chain(fus, synth, size, monkeypatch):
+    """The live half of a frame in three fused launches (ingest + level-0 intensity; depth filter + filtered metric depth +
+    level-0 depth and vertex map; one LDS-tiled kernel for the rest of the three pyramid levels) against the fifteen launches
+    of the operator chain (DMS_FUSED_LIVE=0): every buffer the tracker and the fusion half read — depth pyramid, vertex and
+    normal maps (NaN pattern included), intensity pyramid, gradients, gate, both metric depth images — the poses and the
+    map, bit for bit; also at sizes whose pyramid levels are odd and not multiples of the 16 x 16 tile."""
+    from densemonoslam_amd import capi
+    from densemonoslam_amd.odometry import _BUF_TYPES, Image2D
+    import ctypes as C
+
+    Wr, Hr = size
+    Kr = (0.825 * Wr, 0.825 * Wr, Wr / 2.0, Hr / 2.0)
+    frames = [synth.frame(k, width=Wr, height=Hr, K=Kr, noise=True) for k in range(4)]
+
+    def tracker_buffer(g, which, level):
+        v = Image2D()
+        capi.check(capi.lib.dms_odometry_get_buffer(g.odometryHandle(), which, level, C.byref(v)), "get_buffer")
+        dt, k = _BUF_TYPES[which]
+        return capi.download_view(v, dt, k)
+
+    def run(fused):
+        monkeypatch.setenv("DMS_FUSED_LIVE", "1" if fused else "0")
+        g = fus.ElasticFusion(Wr, Hr, Kr, model_capacity=1500000)
+        out = []
+        for d, rgb, _ in frames:
+            r = g.processFrame(rgb, d)
+            bufs = {("img", i): g.image(i).copy() for i in (0, 1, 2, 3, 4)}
+            for which in (0, 1, 7, 9, 10, 12, 14):
+                for lvl in range(3):
+                    bufs[(which, lvl)] = tracker_buffer(g, which, lvl)
+            out.append((np.array(r.pose, np.float32), int(r.surfels), bufs))
+        m = g.globalModel().downloadMap()
+        g.close()
+        return out, m
+
+    a, ma = run(True)
+    b, mb = run(False)
+    for k, (x, y) in enumerate(zip(a, b)):
+        for key in x[2]:
+            if key[0] in (0, 1):  # stacked-plane maps: NaN in plane x marks an invalid pixel, whose y / z planes are never read
+                assert helpers.planes_equal_where_valid(x[2][key], y[2][key]), (k, key)
+            else:
+                assert_bits(x[2][key], y[2][key], "buffer %s of frame %d" % (key, k))
+        assert x[0].tobytes() == y[0].tobytes(), "pose of frame %d" % k
+        assert x[1] == y[1]
+    surfels_equal(ma, mb, "map")
