@@ -216,13 +216,22 @@ class InterMapMatcher:
         w = self.x.work[slot]
         if w is not None:
             w.wait()  # (stream-side wait; the collective had a whole frame to finish)
-        # results of the search enqueued a frame ago are on the host by now
-        self.candidates += int((self.best_host[:, 0] >= 0).sum())
+        # Results of the search enqueued a frame ago: counted only once the event recorded behind that search has completed
+        # (the pinned array is written by the device; reading it earlier would count the search before it a second time),
+        # then cleared so that a result is never counted twice.
+        ev = getattr(self, "_search_done", None)
+        if ev is None or ev.query():
+            self.candidates += int((self.best_host[:, 0] >= 0).sum())
+            self.best_host.fill_(-1)
+            self._search_done = None
         T = self.x.thumb_bytes
         if hasattr(self.ferns, "searchBlocks"):  # every remote descriptor in one launch
             # (the previous search's results go to the pinned array inside the same call: no copy engine on the frame's stream)
             self.ferns.searchBlocks(g.data_ptr(), self.x.nbytes, self.world, self.rank, T + DESC_CODES, T + DESC_GOOD, int(tick), True,
                                     self.best_dev.data_ptr(), stream, previous_out=self.best_host.data_ptr())
+            if self.device.type == "cuda":
+                self._search_done = torch.cuda.Event()
+                self._search_done.record(torch.cuda.current_stream(self.device))
             if self.verify_interval and self.frames % self.verify_interval == 0:
                 self.verify(g, tick, stream)
             return
@@ -233,6 +242,9 @@ class InterMapMatcher:
                 p = g[r].data_ptr()
                 self.ferns.searchCodes(p + T + DESC_CODES, p + T + DESC_GOOD, int(tick), True, self.best_dev[r].data_ptr(), stream)
         self.best_host.copy_(self.best_dev, non_blocking=True)
+        if self.device.type == "cuda":
+            self._search_done = torch.cuda.Event()
+            self._search_done.record(torch.cuda.current_stream(self.device))
         if self.verify_interval and self.frames % self.verify_interval == 0:
             self.verify(g, tick, stream)
 

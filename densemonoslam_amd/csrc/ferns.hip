@@ -199,9 +199,11 @@ __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __res
 
 // addFrame's decision (Ferns.cpp:235-275) on the device: (minimum > threshold || empty) && goodCodes > 0 -> the
 // staged frame takes slot n; its metadata is written here, its payload by k_fern_commit
+// `status` (mapped host memory, may be null): {sequence number of this add, frames stored, frames dropped because the database
+// was full} — the host polls it without a synchronisation (dms_ferns_status) and tightens its launch bound from it
 __global__ void k_fern_decide(FernHost* __restrict__ res, int* __restrict__ n_dev, int capacity, float threshold, int srcTime,
                               const float* __restrict__ pose_dev, Pose16f pose_host, int* __restrict__ db_good, int* __restrict__ db_time,
-                              float* __restrict__ db_pose) {
+                              float* __restrict__ db_pose, volatile int* status = nullptr, int seq = 0) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int n = *n_dev;
   float minimum = 3.402823466e+38F;
@@ -210,6 +212,7 @@ __global__ void k_fern_decide(FernHost* __restrict__ res, int* __restrict__ n_de
   if ((minimum > threshold || n == 0) && res->good > 0) {
     if (n >= capacity) {
       slot = -2;
+      n_dev[1] += 1;  // sticky: key frames lost to a full database (the reference's database grows without bound)
     } else {
       slot = n;
       db_good[n] = res->good;
@@ -220,6 +223,12 @@ __global__ void k_fern_decide(FernHost* __restrict__ res, int* __restrict__ n_de
   }
   res->slot = slot;
   res->n = *n_dev;
+  if (status) {
+    status[1] = *n_dev;
+    status[2] = n_dev[1];
+    __threadfence_system();
+    status[0] = seq;
+  }
 }
 
 // payload of an accepted frame -> its slot
@@ -283,6 +292,13 @@ using namespace dms;
 struct dms_ferns {
   int num = 0, W = 0, H = 0, tw = 0, th = 0, maxDepth = 0, capacity = 0;
   int n_upper = 0;  // host-side upper bound of the number of stored frames (the count itself lives on the device)
+  // asynchronous adds: {sequence number, stored, dropped} written by the decide kernel into mapped host memory; adds_issued counts
+  // the adds enqueued so far, so that n_upper = stored(at sequence q) + (adds_issued - q) whenever a newer q has landed
+  volatile int* h_status = nullptr;
+  int* d_status = nullptr;  // device view of h_status
+  int adds_issued = 0;
+  hipEvent_t ev_last_add = nullptr;  // recorded after the last asynchronous add: what mirror() has to wait for
+  bool ev_valid = false;
   float photoThresh = 0.f;
   float cx = 0, cy = 0, fx = 0, fy = 0;  // full resolution
   std::vector<int> pos, rgbd;            // host table: [num][2], [num][4]
@@ -309,6 +325,19 @@ struct dms_ferns {
 namespace {
 
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+// After an asynchronous add has been enqueued on `s`: remember what mirror() must wait for, and tighten the host's bound of
+// the frame count from the newest {sequence, stored} pair the decide kernels have written into mapped memory (a rejected
+// frame no longer widens every later search by one frame's worth of blocks until the next synchronisation).
+void after_async_add(dms_ferns* f, hipStream_t s) {
+  f->ev_valid = hipEventRecord(f->ev_last_add, s) == hipSuccess;
+  if (!f->ev_valid) (void)hipGetLastError();
+  const int q = f->h_status[0];  // (sequence last: the pair below belongs to a sequence >= q)
+  const int stored = f->h_status[1];
+  int bound = q > 0 ? stored + (f->adds_issued - q) : f->n_upper + 1;
+  if (bound > f->capacity) bound = f->capacity;
+  f->n_upper = bound;
+}
 
 void mul44(const float* a, const float* b, float* o) {
   for (int i = 0; i < 4; ++i)
@@ -377,20 +406,22 @@ int add_enqueue(dms_ferns* f, const float* pose16_host, const float* pose16_dev,
   Pose16f ph;
   memset(&ph, 0, sizeof(ph));
   if (pose16_host) memcpy(ph.v, pose16_host, sizeof(ph.v));
+  f->adds_issued += 1;
   hipLaunchKernelGGL(k_fern_decide, dim3(1), dim3(64), 0, s, f->d_res, f->d_n, f->capacity, threshold, srcTime, pose16_dev, ph, f->d_good,
-                     f->d_time, f->d_pose);
+                     f->d_time, f->d_pose, (volatile int*)f->d_status, f->adds_issued);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_fern_commit, dim3(64), dim3(256), 0, s, f->d_cur_block, f->d_cur_codes, f->block_bytes, f->d_blocks, f->d_codes,
                      f->d_res);
   DMS_CHECK_LAUNCH();
-  if (f->n_upper < f->capacity) f->n_upper += 1;
+  after_async_add(f, s);
   return DMS_OK;
 }
 
 // host mirrors of count and per-frame metadata (synchronises)
 int mirror(dms_ferns* f, hipStream_t s) {
-  // frames may have been added on any stream (dms_ferns_add_frame_async): wait for the device, not for `s` alone
-  DMS_HIP(hipDeviceSynchronize());
+  // frames may have been added on another stream (dms_ferns_add_frame_async): wait for the last such add — not for the
+  // whole device, which would stall the other cameras' resident tracker kernels and the collectives
+  if (f->ev_valid) DMS_HIP(hipEventSynchronize(f->ev_last_add));
   DMS_HIP(hipMemcpyAsync(&f->n_host, f->d_n, sizeof(int), hipMemcpyDeviceToHost, s));
   DMS_HIP(hipStreamSynchronize(s));
   const int n = f->n_host;
@@ -570,6 +601,12 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
   if (e == hipSuccess) e = hipMemset(f->arena, 0, up256(off));
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_res, sizeof(FernHost), hipHostMallocDefault);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_rgb, (size_t)f->tw * f->th * 4, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_status, 64, hipHostMallocMapped);
+  if (e == hipSuccess) {
+    memset((void*)f->h_status, 0, 64);
+    e = hipHostGetDevicePointer((void**)&f->d_status, (void*)f->h_status, 0);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_last_add, hipEventDisableTiming);
   if (e != hipSuccess) {
     if (f->arena) (void)hipFree(f->arena);
     if (f->h_res) (void)hipHostFree(f->h_res);
@@ -603,6 +640,8 @@ int dms_ferns_destroy(dms_ferns* f) {
   if (!f) return DMS_OK;
   if (f->rgbd_odom) dms_odometry_destroy(f->rgbd_odom);
   if (f->arena) (void)hipFree(f->arena);
+  if (f->h_status) (void)hipHostFree((void*)f->h_status);
+  if (f->ev_last_add) (void)hipEventDestroy(f->ev_last_add);
   if (f->h_res) (void)hipHostFree(f->h_res);
   if (f->h_rgb) (void)hipHostFree(f->h_rgb);
   delete f;
@@ -613,6 +652,14 @@ int dms_ferns_get_table(dms_ferns* f, int* pos2, int* rgbd4) {
   DMS_REQUIRE(f && pos2 && rgbd4, "null argument");
   memcpy(pos2, f->pos.data(), f->pos.size() * sizeof(int));
   memcpy(rgbd4, f->rgbd.data(), f->rgbd.size() * sizeof(int));
+  return DMS_OK;
+}
+
+int dms_ferns_status(dms_ferns* f, int* stored, int* dropped) {
+  DMS_REQUIRE(f, "null argument");
+  // no synchronisation: what the newest completed asynchronous add has reported (mapped host memory)
+  if (stored) *stored = f->h_status[1];
+  if (dropped) *dropped = f->h_status[2];
   return DMS_OK;
 }
 
@@ -688,13 +735,14 @@ int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned 
   if (rc) return rc;
   Pose16f ph;
   memset(&ph, 0, sizeof(ph));
+  f->adds_issued += 1;
   hipLaunchKernelGGL(k_fern_decide, dim3(1), dim3(64), 0, s, f->d_res, f->d_n, f->capacity, threshold, srcTime, pose16_dev, ph, f->d_good,
-                     f->d_time, f->d_pose);
+                     f->d_time, f->d_pose, (volatile int*)f->d_status, f->adds_issued);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_fern_commit, dim3(64), dim3(256), 0, s, (const unsigned char*)thumb_block_dev, f->d_cur_codes, f->block_bytes,
                      f->d_blocks, f->d_codes, f->d_res);
   DMS_CHECK_LAUNCH();
-  if (f->n_upper < f->capacity) f->n_upper += 1;
+  after_async_add(f, s);
   return DMS_OK;
 }
 

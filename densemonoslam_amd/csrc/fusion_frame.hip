@@ -46,6 +46,7 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime = nullptr,
                   unsigned long long* zbuf2 = nullptr, int resolve_only = 0, const FillArgs* fill = nullptr);
 int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s);
+int model_flush_pending(dms_model* m, hipStream_t s);
 // fusion_fuse.hip
 int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_image2d* rgba, const dms_image2d* dr,
                const dms_image2d* drf, const dms_indexmap_out* im, const dms_camera* cam, float depthCutoff, float weighting,
@@ -649,7 +650,8 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   DMS_REQUIRE(p->width >= 40 && p->height >= 40, "resolution too small");
   DMS_REQUIRE(p->timeIdx >= 0 && p->timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   DMS_REQUIRE(p->num_sensors >= 0 && p->num_sensors <= DMS_MAX_SENSORS, "num_sensors out of range");
-  DMS_REQUIRE(p->num_sensors == 0 || p->timeIdx < p->num_sensors, "timeIdx must be one of the num_sensors time slots");
+  // (0 = a zero-initialised params block of an older caller = the reference's 3: the default is applied BEFORE the slot is checked)
+  DMS_REQUIRE(p->timeIdx < (p->num_sensors == 0 ? 3 : p->num_sensors), "timeIdx must be one of the num_sensors time slots");
   DMS_REQUIRE(!p->nid_keyframing || (p->nid_bins_img >= 1 && p->nid_bins_img <= 256 && p->nid_bins_depth >= 1 && p->nid_bins_depth <= 4096 &&
                                      p->nid_pyramid_level >= 0 && p->nid_pyramid_level < DMS_NUM_PYRS),
               "bad NID key-framing parameters");
@@ -791,6 +793,9 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   hipStream_t s = (hipStream_t)st;
   const int W = f->p.width, H = f->p.height, N = W * H;
   int rc;
+  // a previous frame that failed between its fuse and the index map that applies the fuse's update left the map with a pending
+  // pass: apply it now instead of failing every later frame
+  if ((rc = model_flush_pending(f->model, s))) return rc;
 
   // ---- live half: everything that depends on the incoming frame only -------------------------
   // Runs on the prep stream into image set frames%2 and odometry ring set frames%3, so it

@@ -704,6 +704,18 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   return DMS_OK;
 }
 
+// A fuse with defer_update = 1 leaves the winners' update to the next index_map.  Every other reader of the surfel planes
+// (download, export, consume, graph sampling) and a frame step that starts after an error between the two must not see the
+// map half-updated: they apply the pending pass themselves first.
+int model_flush_pending(dms_model* m, hipStream_t s) {
+  if (!m || !m->pending_update) return DMS_OK;
+  m->pending_update = false;
+  hipLaunchKernelGGL(k_fuse_update, dim3((m->slots + 255) / 256), dim3(256), 0, s, m->slots, m->slot_pos, m->slot_col, m->slot_nrm, m->slot_best,
+                     m->slot_flag, m->winner, m->buf[m->cur], m->cap, m->pending_time, m->pending_timeIdx);
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
+
 int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, const dms_indexmap_out* im, const dms_image2d* depth_synth,
                 const dms_camera* cam, float confThreshold, const float* graph_host, int graph_nodes, int timeDelta, float maxDepth,
                 int isFern, int transposed, unsigned* count_out2, hipStream_t s) {

@@ -16,6 +16,7 @@
 #include "fill.hpp"
 
 namespace dms {
+int model_flush_pending(dms_model* m, hipStream_t s);  // fusion_fuse.hip: applies a fuse's deferred update pass
 
 // ---------------------------------------------------------------------------------------
 // storage
@@ -152,11 +153,13 @@ static int model_download_planes(dms_model* m, unsigned n, std::vector<float4>& 
   return DMS_OK;
 }
 
+
 static int model_download_any(dms_model* m, float* host, unsigned max_count, unsigned* count, int nsens, bool ref_layout,
                               hipStream_t s) {
   DMS_REQUIRE(m && host && count, "null argument");
   unsigned n = 0;
-  int rc = dms_model_count(m, &n, s);
+  int rc = model_flush_pending(m, s);
+  if (!rc) rc = dms_model_count(m, &n, s);
   if (rc) return rc;
   if (n > max_count) n = max_count;
   std::vector<float4> pos, col, nrm;
@@ -181,6 +184,7 @@ static int model_download_any(dms_model* m, float* host, unsigned max_count, uns
 
 static int model_upload_any(dms_model* m, const float* host, unsigned n, int nsens, bool ref_layout, hipStream_t s) {
   DMS_REQUIRE(m && (host || n == 0), "null argument");
+  m->pending_update = false;  // (the map is replaced: a deferred update of the old one has nothing left to update)
   if (n > m->cap) {
     set_error("dms_model_upload: %u surfels exceed capacity %zu", n, m->cap);
     return DMS_ERR_CAPACITY;
@@ -664,6 +668,11 @@ static int consume_finish(dms_model* m, size_t added_upper) {
 
 int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStream_t s) {
   DMS_REQUIRE(dst && src && T16 && dst != src, "bad argument");
+  {
+    int rc = model_flush_pending(dst, s);
+    if (!rc) rc = model_flush_pending(const_cast<dms_model*>(src), s);
+    if (rc) return rc;
+  }
   if (dst->count_upper + src->count_upper > dst->cap) {
     // the host-side bounds are loose (they grow by a frame's worth of slots per clean): read the exact counts before refusing
     int rc = refresh_count(dst, s);
@@ -684,6 +693,7 @@ int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStr
 
 int model_consume_records(dms_model* dst, const float* rec_dev, unsigned n, const float* T16, hipStream_t s) {
   DMS_REQUIRE(dst && T16 && (rec_dev || n == 0), "bad argument");
+  if (int rc0 = model_flush_pending(dst, s)) return rc0;
   DMS_REQUIRE(((uintptr_t)rec_dev & 15) == 0, "record buffer must be 16-byte aligned");
   if (dst->count_upper + n > dst->cap) {
     const int rc = refresh_count(dst, s);  // loose bound: read the exact count before refusing
@@ -703,6 +713,7 @@ int model_consume_records(dms_model* dst, const float* rec_dev, unsigned n, cons
 
 int model_export_records(dms_model* m, float* rec_dev, unsigned max_count, unsigned* count_host, hipStream_t s) {
   DMS_REQUIRE(m && rec_dev && count_host, "null argument");
+  if (int rc0 = model_flush_pending(m, s)) return rc0;
   DMS_REQUIRE(((uintptr_t)rec_dev & 15) == 0, "record buffer must be 16-byte aligned");
   hipLaunchKernelGGL(k_export_records, dim3(surfel_grid(m->count_upper)), dim3(256), 0, s, m->buf[m->cur], m->cap, m->d_count, max_count,
                      rec_dev, m->d_count_alt + 1);
@@ -754,6 +765,7 @@ __global__ __launch_bounds__(256) void k_graph_rank(const float4* __restrict__ i
 
 int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s) {
   DMS_REQUIRE(m && n_host && sampleRate >= 2 && (rows4_host || max_rows == 0), "bad argument");
+  if (int rc0 = model_flush_pending(m, s)) return rc0;
   const size_t n_upper = (m->count_upper + (size_t)sampleRate - 1) / (size_t)sampleRate;
   DMS_REQUIRE(2 * n_upper <= m->cap, "sample scratch");
   float4* raw = m->buf[1 - m->cur].pos;

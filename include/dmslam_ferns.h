@@ -35,6 +35,11 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
 int dms_ferns_destroy(dms_ferns* f);
 /* the conservatory: pos[num][2] = (x, y) thumbnail pixel, rgbd[num][4] = thresholds (Ferns::Fern) */
 int dms_ferns_get_table(dms_ferns* f, int* pos2, int* rgbd4);
+/* Without a synchronisation: the number of stored key frames and the number of key frames that were NOT stored because the
+ * database had reached its capacity, as of the newest completed asynchronous add (dms_ferns_add_frame_async /
+ * dms_ferns_publish_block).  The reference's database grows without bound (Ferns.cpp:235-275); a caller that sees `dropped`
+ * move should have created the handle with a larger capacity. */
+int dms_ferns_status(dms_ferns* f, int* stored, int* dropped);
 int dms_ferns_num_frames(dms_ferns* f);
 /* stored frame `id`: pose (16 floats, row-major), source time, good-code count, codes (num bytes); NULL = skip */
 int dms_ferns_get_frame(dms_ferns* f, int id, float* pose16, int* srcTime, int* goodCodes, unsigned char* codes);
