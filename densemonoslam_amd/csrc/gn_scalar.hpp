@@ -232,13 +232,40 @@ __host__ __device__ __forceinline__ bool ldlt_spd(const double (&A)[N * N], cons
   return true;
 }
 
+// sin and cos of an angle >= 0.77 as one fixed sequence of IEEE operations (no math library: its results differ between
+// the device's and the host's): Cody-Waite reduction by pi / 2 in two parts (fdlibm's pio2_1 / pio2_1t, exact products for
+// n < 2^20), then the same fdlibm kernels as above on |r| <= pi / 4; accurate to ~1e-16 for the angles a degenerate system
+// can produce, deterministic for all.
+__host__ __device__ inline void sincos_canon(double x, double* s_out, double* c_out) {
+  const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = fmad(-n, 1.57079632673412561417e+00, x);
+  r = fmad(-n, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double a = fmad(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  a = fmad(z, a, 2.75573137070700676789e-06);
+  a = fmad(z, a, -1.98412698298579493134e-04);
+  a = fmad(z, a, 8.33333333332248946124e-03);
+  a = fmad(z, a, -1.66666666666666324348e-01);
+  a = fmad(z, a, 1.0);
+  double q = fmad(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  q = fmad(z, q, -2.75573143513906633035e-07);
+  q = fmad(z, q, 2.48015872894767294178e-05);
+  q = fmad(z, q, -1.38888888888741095749e-03);
+  q = fmad(z, q, 4.16666666666666019037e-02);
+  const double b = fmad(-z, q, 0.5);
+  const double sr = a * r, cr = fmad(-z, b, 1.0);
+  const int quad = (int)((long long)n & 3);
+  const double s = (quad & 1) ? cr : sr, c = (quad & 1) ? sr : cr;
+  *s_out = (quad & 2) ? -s : s;
+  *c_out = (quad == 1 || quad == 2) ? -c : c;
+}
+
 // OdometryProvider::rodrigues (OdometryProvider.h:35-71), row-major 3x3:
 //   R = cos(t) I + (1 - cos(t)) r^ r^T + sin(t) [r^]x,  r^ = r / t,  t = |r|.
 // For t < 0.77 (every tracker update) the coefficients cos t, (1 - cos t) / t^2 and sin t / t are polynomials in z = t^2
 // (the minimax kernels of fdlibm's k_sin.c / k_cos.c, < 1 ulp on |t| <= pi / 4) in Horner form with fma: no square
 // root, no division, no argument reduction, R = c I + b r r^T + a [r]x — the reference's matrix to ~2e-16 per entry.
-// Larger angles take the reference's form through the math library (not canonical across libraries; no tracker update
-// gets there).
+// Larger angles (no tracker update gets there) take the reference's form with sincos_canon.
 __host__ __device__ inline void rodrigues(const double* src, double* R) {
   double rx = src[0], ry = src[1], rz = src[2];
   const double z = fmad(rz, rz, fmad(ry, ry, rx * rx));
@@ -271,7 +298,8 @@ __host__ __device__ inline void rodrigues(const double* src, double* R) {
   for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
   const double theta = sqrt(z);
   if (theta >= 2.2204460492503131e-16) {
-    const double s = sin(theta), c = cos(theta);
+    double s, c;
+    sincos_canon(theta, &s, &c);
     const double c1 = 1. - c;
     const double itheta = 1. / theta;
     rx *= itheta;
