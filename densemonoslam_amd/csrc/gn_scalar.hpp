@@ -459,34 +459,34 @@ struct GnLocal {
   double lastA[36], lastb[6];
 };
 
-// One Gauss-Newton update (RGBDOdometry.cpp:472-585): combine the two 6x6 systems, LDL^T in fp64, se(3) update of resultRt,
-// new float pose, projection parameters for the camera matrix `kpre` (of q.next_level).
+// Entry k of the combined system from entry k of the two reductions (RGBDOdometry.cpp:531-552: A = A_rgb + w^2 A_icp,
+// b = b_rgb + w b_icp; one fma per entry).  k runs over the 21 + 6 unique entries, rows of (A | b): the b entries are
+// k = 6, 12, 17, 21, 24, 26.  The resident kernels evaluate this in the lanes that hold the totals (lane k), every other
+// path through gn_step_core below: the same operation either way.
+__host__ __device__ __forceinline__ constexpr bool comb_is_b(int k) { return k == 6 || k == 12 || k == 17 || k == 21 || k == 24 || k == 26; }
+__host__ __device__ __forceinline__ double comb_entry(int k, bool icp, bool rgb, float icpWeight, float v_icp, float v_rgb) {
+  const double w = (double)icpWeight;
+  const double ww = w * w;
+  const double vi = icp ? (double)v_icp : 0.0, vr = rgb ? (double)v_rgb : 0.0;
+  if (icp && rgb) return comb_is_b(k) ? fmad(w, vi, vr) : fmad(ww, vi, vr);
+  return icp ? vi : vr;
+}
+
+// One Gauss-Newton update (RGBDOdometry.cpp:472-585) from the combined system `comb` (27 entries, comb_entry): LDL^T in fp64,
+// se(3) update of resultRt, new float pose, projection parameters for the camera matrix `kpre` (of q.next_level).
+// res0 / res1: the ICP residual sum and inlier count (side outputs).
 // `side`: store the side outputs lastA / lastb / last*Error / last*Count (only the values of a level's last iteration are read).
-__host__ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma,
-                                                      const SolveArgs& q, const KPre& kpre, bool side = true) {
-  float residual[2] = {0.f, 0.f};
-  if (q.icp) {
-    residual[0] = s_icp[27];
-    residual[1] = s_icp[28];
-  }
-  // the two symmetric systems are combined on their 21 + 6 unique entries (RGBDOdometry.cpp:531-552: A = A_rgb + w^2 A_icp,
-  // b = b_rgb + w b_icp; one fma per entry) and mirrored
+__host__ __device__ __forceinline__ void gn_step_combined(GnLocal& L, const double* comb, float res0, float res1, int rgbSize, int sigma,
+                                                          const SolveArgs& q, const KPre& kpre, bool side = true) {
+  const float residual[2] = {q.icp ? res0 : 0.f, q.icp ? res1 : 0.f};
   double A[36], b[6], x[6];
   {
-    const double w = (double)q.icpWeight;
-    const double ww = w * w;
     int shift = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = i; j < 7; ++j) {
-        const double vi = q.icp ? (double)s_icp[shift] : 0.0, vr = q.rgb ? (double)s_rgb[shift] : 0.0;
-        ++shift;
-        double v;
-        if (q.icp && q.rgb)
-          v = (j == 6) ? fmad(w, vi, vr) : fmad(ww, vi, vr);
-        else
-          v = q.icp ? vi : vr;
+        const double v = comb[shift++];
         if (j == 6)
           b[i] = v;
         else
@@ -556,6 +556,15 @@ __host__ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s
 #pragma unroll
   for (int i = 0; i < 3; ++i) L.tcurr[i] = tc[i] + L.tprev[i];
   gn_params(nr, kpre, L.krkinv, L.kt);
+}
+
+// The same from the sums of the two reductions (the launch-per-phase path, the host build of the CPU tests)
+__host__ __device__ __forceinline__ void gn_step_core(GnLocal& L, const float* s_icp, const float* s_rgb, int rgbSize, int sigma,
+                                                      const SolveArgs& q, const KPre& kpre, bool side = true) {
+  double comb[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) comb[k] = comb_entry(k, q.icp != 0, q.rgb != 0, q.icpWeight, q.icp ? s_icp[k] : 0.f, q.rgb ? s_rgb[k] : 0.f);
+  gn_step_combined(L, comb, q.icp ? s_icp[27] : 0.f, q.icp ? s_icp[28] : 0.f, rgbSize, sigma, q, kpre, side);
 }
 
 // sigma as the reference computes it (RGBDOdometry.cpp:464, precedence quirk kept)

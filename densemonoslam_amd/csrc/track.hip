@@ -115,7 +115,10 @@ struct dms_odometry {
   int* part_cnt = nullptr;     // [2][1024]
   unsigned* tickets = nullptr; // [4] arrival counters of the last-block-solves hand-off (zero between launches)
   unsigned long long* ar = nullptr;   // [kArSets][kArWords] all-reduce words of the resident kernels, zeroed by k_track_init
-  int ar_slack_shift = 2;             // integer all-reduce: the full sweep starts when all but nb >> shift blocks have arrived (DMS_AR_SLACK; 31 = wait for all)
+  int first_delay = -1;               // integer all-reduce: pause before the first read of the totals (DMS_AR_FIRST_DELAY; -1 = by grid size)
+  // the later the last arrival can be after one's own, the longer the pause pays: ~0.4 us on the 150 / 200-block levels, next to
+  // nothing on 38 blocks (measured: level 2 is best at 0 - 8 units, levels 1 and 0 at 12 - 20)
+  int first_delay_for(int nb) const { return first_delay >= 0 ? first_delay : (nb >= 96 ? 24 : 8); }
   int exp_bias = 0;                   // test hook (dms_odometry_debug_set "exp_bias"): added to the static exponents of a call's first reductions (negative: they do not fit and are repeated)
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
@@ -855,7 +858,7 @@ struct LevelArgs {
   float icpWeight;
   float fx, fy, cx, cy;  // full-resolution intrinsics
   unsigned long long* ar;    // kArSetsPerKernel word sets of kArWords, zero on entry: one per iteration, then the retry pool
-  int ar_slack_shift;        // see ar_wait
+  int first_delay;           // see ar_wait (units of 64 cycles)
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
@@ -883,28 +886,26 @@ __device__ __forceinline__ unsigned long long pair_pack(unsigned long long v) { 
 
 // wave 0, all 64 lanes: every lane with `mine` polls the 8 shard words of `slot` until they show nb arrivals.
 // fld = sum of the 8 fields.  Bounded: a timeout sets *timeout and returns false.
-// `probe` >= 0: first only lanes 0-7 watch the 8 shard words of slot `probe` (the slot added last) and the full sweep
-// starts when those are complete — 58 lanes of every waiting block sweeping the words that are still receiving
-// atomics slows the arrivals down (measured in the level-0 kernel: 4.7 us per reduction against 1.9 stand-alone).
-// `slack`: the probe phase ends when all but `slack` blocks have arrived — the sweep that follows polls until every word is
-// complete, so the last arrivals are seen by the sweep itself instead of costing one more round trip after the probe
-// (the heavy polling then lasts only for the tail of the arrivals).
+// WHEN to poll matters more than how: a read that reaches the words before the last block's atomic has landed costs a whole
+// further round trip (~0.8 us), and reads of words that are still receiving atomics slow those down.  The callers therefore
+// wait `first_delay` x 64 cycles after their own arrival before the first read of the totals (nobody's sum can be complete
+// earlier than one atomic flight after the last arrival).  Measured at 640x480 (level 0 / 1 / 2 launch, us), round 3:
+//   probe word, then a sweep of all 58 words, no delay (round 2's form)                        137 / 53 / 41.6
+//   ICP words (added a phase earlier, complete: one round trip), then the photometric words    131 / 48 / 40.5
+//   the same after a delay of 8 / 16 / 30 units                                                 121.5 / 118.3 / 120.6 (level 0)
+//   ICP wave sums kept in registers and folded over the waves together with the photometric
+//   ones (one LDS fold and one atomic instruction for both; the pair is polled ~0.5 us earlier),
+//   all 58 words polled at once after 24 units (8 on grids under 96 blocks)                     111 / 44 / 38.7
+// Tried without gain: pauses between polls (1 - 12 units); the ICP words read before pass 2 and looked at after it (140: the
+// early reads delay wave 0's share of the pass); every block adding to 2 or 4 copies of the words and polling one (120 ->
+// 121 / 122: the readers' fan-in per line is not what limits); a delay before the pair's poll (+0 - 3 us from 4 units on);
+// a block's chunks spread over the image instead of adjacent (no difference: the arrival spread is not a load imbalance).
+__device__ __forceinline__ void poll_pause(int n) {
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);  // 64 cycles each
+}
 template <int STRIDE>
-__device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, bool mine, int nb, unsigned long long& fld_out, int* timeout,
-                                        int probe = -1, int slack = 0) {
+__device__ __forceinline__ bool ar_wait(const unsigned long long* w, int slot, bool mine, int nb, unsigned long long& fld_out, int* timeout) {
   unsigned spins = 0;
-  if (probe >= 0) {
-    const int lane = threadIdx.x & 63;
-    for (;;) {
-      const unsigned long long q = lane < kArShards ? __hip_atomic_load(w + lane * STRIDE + probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-      int arr = (int)(q >> 58);
-      arr = row8_sum_i(arr);  // lanes 0-7: the 8 shards
-      if (__builtin_amdgcn_readlane(arr, 0) >= nb - slack) break;
-      ++spins;
-      if (spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;  // (reported below)
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
   for (;;) {
     unsigned long long arr = 0, fld = 0;
     if (mine) {
@@ -955,9 +956,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   __shared__ sc::GnLocal s;
   __shared__ int s_redi[kPWaves][2];
   __shared__ double s_red[kPWaves][32];
+  __shared__ double s_red2[2][kPWaves][32];  // [ICP | photometric][wave][value]: the two reductions folded at once
   __shared__ double s_bias[2][2][32];  // [ICP | photometric][lanes 0-31 | 32-63][value]
   __shared__ int s_E[2][8];            // column exponents of the two reductions
   __shared__ float s_sums[64];
+  __shared__ double s_comb[28];  // the combined 6x6 system (27 unique entries), written by the lanes that hold the totals
   __shared__ int s_none;
   __shared__ int s_done;
   __shared__ int s_cs[2];
@@ -1120,9 +1123,14 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       }
     }
     phase(2);
-    if (ICP) {  // the ICP block sum and its publication overlap the other blocks' arrivals
-      const double p_icp = canon::block_sum<6, P, kPWaves>(rows, found, s_bias[0], s_red);
-      if (tid < kSE3) __hip_atomic_fetch_add(arw + tid, canon::pack_word(canon::to_units(p_icp, eb_icp)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double r_icp = 0.0;  // (both terms on) this wave's ICP sums, one value per lane pair: folded over the waves together with the photometric ones
+    if (ICP) {  // the ICP sums overlap the other blocks' arrivals
+      if (RGB) {
+        r_icp = canon::wave_sum<6, P>(rows, found, s_bias[0]);
+      } else {
+        const double p_icp = canon::block_sum<6, P, kPWaves>(rows, found, s_bias[0], s_red);
+        if (tid < kSE3) __hip_atomic_fetch_add(arw + tid, canon::pack_word(canon::to_units(p_icp, eb_icp)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (RGB) {
       if (tid < 64) {
@@ -1167,8 +1175,28 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         rgb_row_finish<kFma>(p_, c[p], in, rows[p]);
         found[p] = c[p].valid != 0;
       }
+      if (ICP) {
+        // one fold for both reductions: lane k of wave 0 ends with the block's ICP total of value k, lane 32 + k with the
+        // photometric one — exactly the slot (tid) their words have in the shard
+        const double r_rgb = canon::wave_sum<6, P>(rows, found, s_bias[1]);
+        const int lane = tid & 63, wid = tid >> 6;
+        // (s_red2 was last read before the barrier that follows the totals: no barrier needed in front of these stores)
+        if ((lane & 1) == 0) {
+          const int sl = canon::slot_of_lane<32>(lane);
+          s_red2[0][wid][sl] = r_icp;
+          s_red2[1][wid][sl] = r_rgb;
+        }
+        __syncthreads();
+        if (tid < 64 && (tid & 31) < kSE3) {
+          double t = 0.0;
+#pragma unroll
+          for (int w = 0; w < kPWaves; ++w) t += s_red2[tid >> 5][w][tid & 31];
+          __hip_atomic_fetch_add(arw + tid, canon::pack_word(canon::to_units(t, tid < 32 ? eb_icp : eb_rgb)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
       const double p_rgb = canon::block_sum<6, P, kPWaves>(rows, found, s_bias[1], s_red);
       if (tid < kSE3) __hip_atomic_fetch_add(arw + 32 + tid, canon::pack_word(canon::to_units(p_rgb, eb_rgb)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     phase(4);
     if (stamp) L.prof[48 + blockIdx.x * 8 + 2] = wall_clock64();
@@ -1177,9 +1205,15 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       const int k = tid & 31;
       const bool mine = k < kSE3 && (tid < 32 ? ICP : RGB);
       unsigned long long fld;
-      ar_wait<kArStride>(arp, tid, mine, nb, fld, &st->sync_timeout, RGB ? 32 : 0, L.ar_slack_shift < 31 ? nb >> L.ar_slack_shift : 0);
+      poll_pause(L.first_delay);
+      ar_wait<kArStride>(arp, tid, mine, nb, fld, &st->sync_timeout);
       const long long tot = ar_total(fld, nb);
-      s_sums[tid] = mine ? canon::from_units(tot, tid < 32 ? eb_icp : eb_rgb) : 0.f;
+      const float val = mine ? canon::from_units(tot, tid < 32 ? eb_icp : eb_rgb) : 0.f;
+      s_sums[tid] = val;
+      {  // entry k of the combined system in lane k < 27: its photometric total sits in lane k + 32 (gn_scalar.hpp, comb_entry)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(val), __float_as_uint(val), false, false);
+        if (tid < 27) s_comb[tid] = sc::comb_entry(tid, ICP, RGB, L.icpWeight, val, __uint_as_float(sw[1]));
+      }
       const bool bad = mine && ((se3_diag_mask() >> k) & 1u) && tot >= canon::kViolation;
       const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
       if (tid == 0) s_viol = ((any & 0xffffffffull) ? 1 : 0) | ((any >> 32) ? 2 : 0);
@@ -1237,7 +1271,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       const bool last = it == L.n_iter - 1 || none;
       const sc::KPre kp = s_k[last ? 1 : 0];
       // (with rgbOnly the level may end at any iteration's break: the side outputs are then the previous iteration's)
-      sc::gn_step_core(s, s_sums, s_sums + 32, rgbSize, sigma, q, kp, last || L.rgbOnly);
+      sc::gn_step_combined(s, s_comb, s_sums[27], s_sums[28], rgbSize, sigma, q, kp, last || L.rgbOnly);
       if (none) {
         s.iters_run += L.n_iter - 1 - it;
         s_none = 1;
@@ -1335,7 +1369,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
                                                    const unsigned char* nextImage, size_t next_pitch, int cols, int rows,
-                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias) {
+                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias, int first_delay) {
   __shared__ TrackState s;
   __shared__ int s_viol;
   __shared__ int s_E[4];
@@ -1385,7 +1419,8 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 64) {
       unsigned long long fld;
-      ar_wait<kArStride>(ar + set, tid, tid < kSO3, nb, fld, &st->sync_timeout, 0);
+      poll_pause(first_delay);
+      ar_wait<kArStride>(ar + set, tid, tid < kSO3, nb, fld, &st->sync_timeout);
       const long long tot = ar_total(fld, nb);
       if (tid < 32) s_sums[tid] = tid < kSO3 ? canon::from_units(tot, eb_mine) : 0.f;
       const bool bad = tid < kSO3 && ((so3_diag_mask() >> tid) & 1u) && tot >= canon::kViolation;
@@ -1684,8 +1719,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     }
     e = getenv("DMS_PERSIST_MAX_BLOCKS");
     if (e && atoi(e) > 0 && atoi(e) < o->max_resident_blocks) o->max_resident_blocks = atoi(e);
-    e = getenv("DMS_AR_SLACK");
-    if (e && atoi(e) >= 0 && atoi(e) <= 31) o->ar_slack_shift = atoi(e);
+    e = getenv("DMS_AR_FIRST_DELAY");  // units of 64 cycles before the first read of the totals; default: by grid size
+    if (e && atoi(e) >= 0 && atoi(e) <= 1000) o->first_delay = atoi(e);
   }
   *out = o;
   return DMS_OK;
@@ -2072,7 +2107,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       Timer t(o, s, "so3_level");
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
       hipLaunchKernelGGL(k_so3_level, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch, (const unsigned char*)ni.p,
-                         ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias);
+                         ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias, o->first_delay_for(nbp));
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {
@@ -2162,7 +2197,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.cx = o->cx;
       L.cy = o->cy;
       L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
-      L.ar_slack_shift = o->ar_slack_shift;
+      L.first_delay = o->first_delay_for(pnb);
       L.prof = o->profiling ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
       L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
