@@ -68,12 +68,14 @@ lib.dms_reduce_workspace_bytes.restype = C.c_size_t
 
 
 class DmsError(RuntimeError):
-    pass
+    code = 0  # the DMS_ERR_* status the entry point returned
 
 
 def check(rc, what=""):
     if rc != DMS_OK:
-        raise DmsError("%s failed (%d): %s" % (what, rc, lib.dms_last_error().decode()))
+        e = DmsError("%s failed (%d): %s" % (what, rc, lib.dms_last_error().decode()))
+        e.code = rc
+        raise e
 
 
 def mat33(a):

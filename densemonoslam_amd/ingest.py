@@ -16,6 +16,7 @@ class FrameMsg(C.Structure):
 
 
 _P = C.c_void_p
+DMS_ERR_UNSUPPORTED, DMS_ERR_FORMAT = -7, -8  # include/dmslam_io.h
 lib.dms_eflcm_frame_encoded_size.argtypes = [C.POINTER(FrameMsg)]
 lib.dms_eflcm_frame_encoded_size.restype = C.c_size_t
 lib.dms_eflcm_frame_encode.argtypes = [C.POINTER(FrameMsg), _P, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -25,6 +26,7 @@ lib.dms_lcmlog_open.argtypes = [C.POINTER(_P), C.c_char_p]
 lib.dms_lcmlog_next.argtypes = [_P, C.c_char_p, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
 lib.dms_lcmlog_rewind.argtypes = [_P]
 lib.dms_lcmlog_close.argtypes = [_P]
+lib.dms_jpeg_decode.argtypes = [_P, C.c_size_t, C.c_int, C.c_int, _P]
 lib.dms_klg_open.argtypes = [C.POINTER(_P), C.c_char_p, C.c_int, C.c_int, C.c_int]
 lib.dms_klg_num_frames.argtypes = [_P]
 lib.dms_klg_next.argtypes = [_P, _P, _P, C.POINTER(C.c_int64)]
@@ -76,6 +78,14 @@ class Frame:
         rgb = np.zeros((height, width, 3), np.uint8)
         check(lib.dms_frame_unpack(C.byref(m), width, height, int(flipColors), d.ctypes.data_as(_P), rgb.ctypes.data_as(_P)), "dms_frame_unpack")
         return d, rgb
+
+
+def jpeg_decode(data, width, height):
+    """Baseline JPEG -> (H, W, 3) u8 in libjpeg's R, G, B order (dms_jpeg_decode)."""
+    data = bytes(data)
+    rgb = np.zeros((height, width, 3), np.uint8)
+    check(lib.dms_jpeg_decode(data, len(data), width, height, rgb.ctypes.data_as(_P)), "dms_jpeg_decode")
+    return rgb
 
 
 class LcmLogReader:

@@ -6,8 +6,10 @@
  *   - RawLcmLogReader (GUI/src/Tools/RawLcmLogReader.h:37-85): LCM event log -> frames;
  *   - RawLogReader / .klg (logs/rgbd/RawLogReader.cpp:30,70-110).
  * Host-side, plain C ABI, no device work: the decoded depth (u16 mm) and RGB8 buffers are what
- * dms_memcpy_h2d + dms_fusion_process_frame take.  zlib (depth) is loaded at run time; JPEG colour
- * is not decodable in this build (no libjpeg in the image): such frames return DMS_ERR_UNSUPPORTED.
+ * dms_memcpy_h2d + dms_fusion_process_frame take.  zlib (depth) is loaded at run time; JPEG colour is
+ * decoded by the library's own baseline decoder (csrc/jpeg.hpp: libjpeg's default arithmetic — slow integer
+ * inverse DCT, fancy upsampling, fixed-point colour conversion — byte for byte; progressive / arithmetic-coded /
+ * non-YCbCr streams return DMS_ERR_UNSUPPORTED).
  */
 #ifndef DMSLAM_IO_H_
 #define DMSLAM_IO_H_
@@ -19,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DMS_ERR_UNSUPPORTED (-7) /* e.g. JPEG colour, or zlib not loadable */
+#define DMS_ERR_UNSUPPORTED (-7) /* e.g. a progressive JPEG, or zlib not loadable */
 #define DMS_ERR_FORMAT (-8)      /* malformed message / log */
 #define DMS_EOF 1                /* readers: no more frames (not an error) */
 
@@ -40,6 +42,11 @@ typedef struct dms_frame_msg {
 size_t dms_eflcm_frame_encoded_size(const dms_frame_msg* m);
 int dms_eflcm_frame_encode(const dms_frame_msg* m, void* buf, size_t cap, size_t* written);
 int dms_eflcm_frame_decode(const void* data, size_t len, dms_frame_msg* out);
+
+/* Baseline JPEG -> W*H*3 bytes in libjpeg's R, G, B scanline order: what jpeg_read_scanlines hands
+ * JPEGLoader::readData (GUI/src/Tools/JPEGLoader.h:44-95) before its per-pixel R<->B exchange.  The size
+ * in the stream must equal width x height. */
+int dms_jpeg_decode(const void* data, size_t len, int width, int height, unsigned char* rgb_out);
 
 /* message -> W*H u16 depth + W*H*3 RGB8, as RawLcmLogReader::getNext does (uncompress / copy,
  * optional R<->B swap) */

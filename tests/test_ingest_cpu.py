@@ -69,7 +69,7 @@ def test_frame_unpack_raw_and_compressed(ing, golden):
     assert d.tobytes() == c["depth"] and rgb.tobytes() == c["image"]
     d2, rgb2 = f.unpack(W, H, flipColors=True)
     assert (rgb2[..., 0] == rgb[..., 2]).all() and (rgb2[..., 2] == rgb[..., 0]).all() and (rgb2[..., 1] == rgb[..., 1]).all()
-    # compressed message: zlib depth decodes, JPEG colour is reported as unsupported (no libjpeg here)
+    # compressed message: zlib depth decodes; its 41 opaque image bytes are not a JPEG stream
     f1 = ing.Frame.decode(_case(golden, 1)["enc"])
     assert f1.compressed and f1.last and f1.trackOnly
     with pytest.raises(capi.DmsError) as e:
@@ -114,3 +114,85 @@ def test_klg_reader(ing, tmp_path, compress):
     r.rewind()
     assert next(iter(r))[0] == 10
     r.close()
+
+
+# ---- JPEG colour (GUI/src/Tools/JPEGLoader.h): golden vectors encoded and decoded by libjpeg-turbo (make_jpeg_golden.py) ----
+@pytest.fixture(scope="module")
+def jpeg_cases():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_cases.npz"))
+
+
+def test_jpeg_decoder_reproduces_libjpeg_bytes(ing, jpeg_cases):
+    import hashlib
+
+    z = jpeg_cases
+    assert len(z["names"]) >= 12
+    for name in z["names"]:
+        name = str(name)
+        w, h = (int(v) for v in z[name + "_shape"])
+        got = ing.jpeg_decode(z[name + "_jpeg"].tobytes(), w, h)
+        ref = z[name + "_rgb"]
+        assert (got[: ref.shape[0]] == ref).all(), name
+        assert hashlib.sha256(got.tobytes()).digest() == z[name + "_sha256"].tobytes(), name
+
+
+def test_jpeg_decoder_refuses_what_it_cannot_decode(ing, jpeg_cases):
+    from densemonoslam_amd import capi
+
+    z = jpeg_cases
+    good = z["q95_420_jpeg"].tobytes()
+    with pytest.raises(capi.DmsError) as e:
+        ing.jpeg_decode(z["progressive_jpeg"].tobytes(), 32, 24)
+    assert e.value.code == ing.DMS_ERR_UNSUPPORTED and "progressive" in str(e.value)
+    with pytest.raises(capi.DmsError) as e:
+        ing.jpeg_decode(good, 32, 24)  # not the log's resolution
+    assert e.value.code == ing.DMS_ERR_FORMAT
+    for cut in (2, 100, len(good) // 2):
+        try:  # a truncated stream is either refused or decoded with libjpeg's zero-fill rule; it must not crash or read past the end
+            ing.jpeg_decode(good[:cut], 64, 48)
+        except capi.DmsError as err:
+            assert err.code == ing.DMS_ERR_FORMAT
+    with pytest.raises(capi.DmsError):
+        ing.jpeg_decode(b"\x00" * 64, 64, 48)
+    rng = np.random.default_rng(5)
+    for _ in range(200):  # corrupted entropy-coded data: any outcome but a crash
+        bad = bytearray(good)
+        for k in rng.integers(300, len(bad), 4):
+            bad[k] = int(rng.integers(0, 256))
+        try:
+            ing.jpeg_decode(bytes(bad), 64, 48)
+        except capi.DmsError:
+            pass
+
+
+def test_compressed_logs_decode_like_the_reference_readers(ing, jpeg_cases, tmp_path):
+    """RawLogReader (.klg) and RawLcmLogReader (eflcm.Frame, compressed = 1): zlib depth + JPEG colour; the loader leaves the
+    colour bytes as B, G, R (JPEGLoader.h:82-91: libjpeg's scanline with R and B exchanged), flipColors exchanges them again."""
+    import struct
+
+    z = jpeg_cases
+    W, H = (int(v) for v in z["q95_420_shape"])
+    jpg = z["q95_420_jpeg"].tobytes()
+    rgb = z["q95_420_rgb"]
+    rng = np.random.default_rng(9)
+    depth = rng.integers(0, 6000, (H, W), dtype=np.uint16)
+    zd = zlib.compress(depth.tobytes(), 6)
+    path = str(tmp_path / "c.klg")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", 2))
+        for ts in (5, 6):
+            f.write(struct.pack("<qii", ts, len(zd), len(jpg)) + zd + jpg)
+    for flip in (False, True):
+        r = ing.KlgReader(path, W, H, flipColors=flip)
+        got = list(r)
+        r.close()
+        assert [g[0] for g in got] == [5, 6]
+        for _, d, c in got:
+            assert (d == depth).all()
+            assert (c == (rgb if flip else rgb[..., ::-1])).all()
+    f = ing.Frame(zd, jpg, 77, 3, "cam", False, True, False)
+    g = ing.Frame.decode(f.encode())
+    d, c = g.unpack(W, H)
+    assert (d == depth).all() and (c == rgb[..., ::-1]).all()
+    d, c = g.unpack(W, H, flipColors=True)
+    assert (c == rgb).all()
