@@ -243,7 +243,12 @@ def main():
     # (DMS_BENCH_EXCHANGE=1: the per-frame exchange work at N = 1 too, the all-gather being a local copy — measures what the
     # collaborative mode adds to a frame without a second GPU)
     exchange_on = distributed or os.environ.get("DMS_BENCH_EXCHANGE") == "1"
-    exchange = collab.ThumbnailExchange(world, W, H, dev, extra_bytes=collab.DESC_BYTES if exchange_on else 0)
+    # DMS_BENCH_CARRIER=c: the all-gather through the library's own RCCL binding (include/dmslam_collab.h, what a C++ front end
+    # calls) instead of torch.distributed's; the process group only carries the 128-byte communicator id
+    carrier = None
+    if exchange_on and os.environ.get("DMS_BENCH_CARRIER") == "c" and dev.type == "cuda" and (not distributed or backend == "nccl"):
+        carrier = collab.rccl_carrier_from_process_group(rank, world)
+    exchange = collab.ThumbnailExchange(world, W, H, dev, extra_bytes=collab.DESC_BYTES if exchange_on else 0, carrier=carrier)
     thumb = exchange.local
     matcher = None
     if exchange_on:
@@ -314,6 +319,7 @@ def main():
         "n_gpus": world,
         "rccl_ranks": dist.get_world_size() if (distributed and backend == "nccl") else (0 if distributed else 1),
         "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
+        "exchange_carrier": "dms_collab_allgather (library's RCCL binding)" if carrier is not None else ("torch.distributed" if distributed else "none"),
         "rank_devices": rank_devices,
         "steps": args.steps,
         "warmup": args.warmup,

@@ -36,6 +36,88 @@ def shard_cameras(n_cameras, rank, world):
     return [c for c in range(n_cameras) if c % world == rank]
 
 
+class _EventWork:
+    """the two methods ThumbnailExchange uses of a torch.distributed work handle, over a stream event"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def is_completed(self):
+        return self.ev.query()
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+class RcclCarrier:
+    """ctypes mirror of include/dmslam_collab.h: the exchange step through the library's own RCCL binding — what a C++ front
+    end calls — instead of torch.distributed.  `create` is collective; the 128-byte id travels over whatever rendezvous the
+    caller has (here: a torch.distributed broadcast on the CPU group, or none for a single rank)."""
+
+    def __init__(self, rank, world, unique_id):
+        import ctypes as C
+
+        from . import capi
+
+        self._C, self._capi = C, capi
+        lib = capi.lib
+        lib.dms_collab_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p]
+        lib.dms_collab_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dms_collab_send.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        lib.dms_collab_recv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        lib.dms_collab_allreduce_max_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dms_collab_destroy.argtypes = [C.c_void_p]
+        lib.dms_collab_rank.argtypes = [C.c_void_p]
+        lib.dms_collab_size.argtypes = [C.c_void_p]
+        self.h = C.c_void_p()
+        capi.check(lib.dms_collab_create(C.byref(self.h), rank, world, bytes(unique_id)), "dms_collab_create")
+        self.rank, self.world = lib.dms_collab_rank(self.h), lib.dms_collab_size(self.h)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+
+        from . import capi
+
+        buf = C.create_string_buffer(128)
+        capi.check(capi.lib.dms_collab_unique_id(buf), "dms_collab_unique_id")
+        return buf.raw
+
+    def allgather(self, send, recv, stream=None):
+        """send: (n,) uint8 device tensor; recv: (world * n,) — on `stream` (a torch stream or None = the current one)"""
+        s = torch.cuda.current_stream() if stream is None else stream
+        self._capi.check(self._capi.lib.dms_collab_allgather(self.h, send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size(),
+                                                             self._C.c_void_p(s.cuda_stream)), "dms_collab_allgather")
+
+    def send(self, t, peer, stream=None):
+        s = torch.cuda.current_stream() if stream is None else stream
+        self._capi.check(self._capi.lib.dms_collab_send(self.h, t.data_ptr(), t.numel() * t.element_size(), peer, self._C.c_void_p(s.cuda_stream)),
+                         "dms_collab_send")
+
+    def recv(self, t, peer, stream=None):
+        s = torch.cuda.current_stream() if stream is None else stream
+        self._capi.check(self._capi.lib.dms_collab_recv(self.h, t.data_ptr(), t.numel() * t.element_size(), peer, self._C.c_void_p(s.cuda_stream)),
+                         "dms_collab_recv")
+
+    def max_f64(self, t, stream=None):
+        s = torch.cuda.current_stream() if stream is None else stream
+        self._capi.check(self._capi.lib.dms_collab_allreduce_max_f64(self.h, t.data_ptr(), self._C.c_void_p(s.cuda_stream)),
+                         "dms_collab_allreduce_max_f64")
+
+    def close(self):
+        if self.h:
+            self._capi.lib.dms_collab_destroy(self.h)
+            self.h = None
+
+
+def rccl_carrier_from_process_group(rank, world):
+    """Collective: rank 0 draws the id, the default process group (any backend) carries its 128 bytes."""
+    ident = [RcclCarrier.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ident, src=0)
+    return RcclCarrier(rank, world, ident[0])
+
+
 class ThumbnailExchange:
     """Fixed-size per-frame all-gather of one camera's thumbnail block per rank.
 
@@ -45,8 +127,10 @@ class ThumbnailExchange:
     stream wait for it — the matcher that consumes it runs a frame later — and `finish()` waits for
     whatever is still in flight."""
 
-    def __init__(self, world, width, height, device, extra_bytes=0):
+    def __init__(self, world, width, height, device, extra_bytes=0, carrier=None):
         self.world = world
+        self.carrier = carrier  # RcclCarrier: the all-gather through dms_collab_allgather instead of torch.distributed
+        self.side = None
         self.thumb_bytes = thumbnail_bytes(width, height)
         self.nbytes = self.thumb_bytes + extra_bytes  # (thumb_bytes is a multiple of 16: the descriptor stays aligned)
         self.locals = [torch.zeros((self.nbytes,), dtype=torch.uint8, device=device) for _ in range(2)]
@@ -69,8 +153,24 @@ class ThumbnailExchange:
     def gather(self, overlap=False):
         g, l = self.gathereds[self.slot], self.locals[self.slot]
         self.gathered = g
-        if self.world == 1:
+        if self.world == 1 and self.carrier is None:
             g[0].copy_(l)
+            return g
+        if self.carrier is not None:
+            # the library's collective is stream-ordered: it runs on a side stream behind the producer of the block, and the
+            # event recorded after it is what begin() / finish() / the consumer wait for
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            self.carrier.allgather(l, g.view(-1), self.side)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            if overlap:
+                self.work[self.slot] = _EventWork(ev)
+                self.slot ^= 1
+            else:
+                cur.wait_event(ev)
             return g
         if overlap:
             try:

@@ -32,15 +32,23 @@ struct LoopState {
 // of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
 // `timed_out`: the tracker's result is invalid (the caller has restored the prior pose): count it and mark the frame
 // with a negative weight, which k_fuse_associate reads as "fuse nothing" (a legal weight is >= 0).
-__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false) {
-  sm::inv4t<float>(st->cur.pose, st->cur.t_inv);
+// `pose` / `last`: the new pose and the previous frame's, when the caller already holds them (registers / LDS: the resident
+// tracker's last block has just written the pose and read lastPose at its start — re-reading both from memory costs two
+// dependent round trips at the very end of the kernel); null = read them from the state block.
+__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false, const float* pose = nullptr,
+                                              const float* last = nullptr) {
+  float P[16], Lp[16], Ti[16];
+  for (int i = 0; i < 16; ++i) P[i] = pose ? pose[i] : st->cur.pose[i];
+  for (int i = 0; i < 16; ++i) Lp[i] = last ? last[i] : st->lastPose[i];
+  sm::inv4t<float>(P, Ti);
+  for (int i = 0; i < 16; ++i) st->cur.t_inv[i] = Ti[i];
   float diff[16];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
-      float s = st->cur.t_inv[i * 4 + 0] * st->lastPose[0 * 4 + j];
-      s += st->cur.t_inv[i * 4 + 1] * st->lastPose[1 * 4 + j];
-      s += st->cur.t_inv[i * 4 + 2] * st->lastPose[2 * 4 + j];
-      s += st->cur.t_inv[i * 4 + 3] * st->lastPose[3 * 4 + j];
+      float s = Ti[i * 4 + 0] * Lp[0 * 4 + j];
+      s += Ti[i * 4 + 1] * Lp[1 * 4 + j];
+      s += Ti[i * 4 + 2] * Lp[2 * 4 + j];
+      s += Ti[i * 4 + 3] * Lp[3 * 4 + j];
       diff[i * 4 + j] = s;
     }
   const float tn = sqrtf(diff[3] * diff[3] + diff[7] * diff[7] + diff[11] * diff[11]);
@@ -67,7 +75,7 @@ __device__ inline void frame_after_track_body(FrameState* st, float weightMultip
   weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
   st->weighting = timed_out ? -1.f : weighting;
   if (timed_out) st->track_timeouts += 1;
-  for (int i = 0; i < 16; ++i) st->lastPose[i] = st->cur.pose[i];
+  for (int i = 0; i < 16; ++i) st->lastPose[i] = P[i];
 }
 
 }  // namespace dms

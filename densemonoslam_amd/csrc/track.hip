@@ -961,6 +961,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   __shared__ int s_E[2][8];            // column exponents of the two reductions
   __shared__ float s_sums[64];
   __shared__ double s_comb[28];  // the combined 6x6 system (27 unique entries), written by the lanes that hold the totals
+  __shared__ float s_lastPose[16];
   __shared__ int s_none;
   __shared__ int s_done;
   __shared__ int s_cs[2];
@@ -984,6 +985,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
   };
 
+  if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 64 && tid < 80) s_lastPose[tid - 64] = L.frame->lastPose[tid - 64];  // for the finalize step
   if (tid == 0) {
     s_none = 0;
     s_retries = 0;
@@ -1352,7 +1354,18 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         L.pose16_out[14] = 0.f;
         L.pose16_out[15] = 1.f;
       }
-      if (L.frame) frame_after_track_body(L.frame, L.weightMultiplier, timed_out);
+      if (L.frame) {
+        // (the pose block the frame step hands in IS the frame state's current pose: then this thread holds both matrices)
+        const bool own = L.pose16_out == L.frame->cur.pose;
+        float P16[16];
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) P16[i * 4 + j] = Rc[i * 3 + j];
+          P16[i * 4 + 3] = tc[i];
+        }
+        P16[12] = P16[13] = P16[14] = 0.f;
+        P16[15] = 1.f;
+        frame_after_track_body(L.frame, L.weightMultiplier, timed_out, own ? P16 : nullptr, own ? s_lastPose : nullptr);
+      }
     }
   }
   phase(8);

@@ -48,6 +48,10 @@ extern "C" {
 #define DMS_ERR_CAPACITY (-4)
 #define DMS_ERR_STATE (-5)
 #define DMS_ERR_TIMEOUT (-6) /* a resident tracker kernel gave up at a grid barrier: result invalid */
+#ifndef DMS_ERR_UNSUPPORTED
+#define DMS_ERR_UNSUPPORTED (-7) /* a dependency resolved at run time (zlib, RCCL) is missing, or an input flavour is not handled */
+#endif
+#define DMS_ERR_COMM (-9) /* an RCCL call failed (dmslam_collab.h) */
 
 #define DMS_NUM_PYRS 3         /* RGBDOdometry.h: NUM_PYRS */
 #define DMS_MAX_SENSORS 8      /* reference Vertex::MAX_SENSORS = 3 (Shaders/Vertex.cpp:49); 8 = one per GPU of the node */

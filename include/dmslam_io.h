@@ -21,7 +21,9 @@
 extern "C" {
 #endif
 
+#ifndef DMS_ERR_UNSUPPORTED
 #define DMS_ERR_UNSUPPORTED (-7) /* e.g. a progressive JPEG, or zlib not loadable */
+#endif
 #define DMS_ERR_FORMAT (-8)      /* malformed message / log */
 #define DMS_EOF 1                /* readers: no more frames (not an error) */
 

@@ -325,3 +325,24 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_collab_c_binding_validates_arguments_without_a_gpu():
+    """include/dmslam_collab.h: the entry points exist, refuse bad arguments before touching RCCL, and a single-camera
+    process has not loaded librccl by importing the package."""
+    import ctypes as C
+
+    from densemonoslam_amd import capi
+
+    lib = capi.lib
+    assert lib.dms_collab_unique_id(None) == -1
+    h = C.c_void_p()
+    ident = b"\0" * 128
+    assert lib.dms_collab_create(C.byref(h), 2, 2, ident) == -1 and b"rank" in lib.dms_last_error()
+    assert lib.dms_collab_create(C.byref(h), 0, 0, ident) == -1
+    assert lib.dms_collab_create(None, 0, 1, ident) == -1
+    assert lib.dms_collab_destroy(None) == 0
+    lib.dms_collab_size.argtypes = [C.c_void_p]
+    assert lib.dms_collab_size(None) == 0
+    maps = open("/proc/self/maps").read()
+    assert "libdmslam_hip" in maps
