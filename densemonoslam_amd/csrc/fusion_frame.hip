@@ -64,9 +64,13 @@ int odometry_initICPModel_sel(dms_odometry* o, const float* vA, const float* nA,
                               const float* pose16_dev, hipStream_t s);
 int odometry_initRGBModel_sel(dms_odometry* o, const void* rgbaA, const void* rgbaB, const int* flag_dev, int force_b, void* rgba_tmp,
                               hipStream_t s);
+struct TrackFold {  // the track call a model pyramid launch prepares (track.hip)
+  const float* prior_pose16;
+  int pyramid, fastOdom, so3, interMap;
+};
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
-                             int defer_last_step = 0, unsigned* dense_cnt = nullptr, int dense_samples = 0);
+                             int defer_last_step = 0, unsigned* dense_cnt = nullptr, int dense_samples = 0, const TrackFold* fold = nullptr);
 int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
                             hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
@@ -303,6 +307,7 @@ struct dms_fusion {
   // same pose unless the caller brings a prior), resolved at that frame's begin instead of projecting the map again
   unsigned long long* zbuf2 = nullptr;
   unsigned* tickets = nullptr;  // 16 counters, 64 bytes apart (fused fill-in: non-black subsampled pixels of the tracking prediction); subsample masks at word 512
+  bool fold_track_init = true;     // the tracker call's set-up as a block group of the model pyramid kernel (DMS_FOLD_TRACK_INIT=0: its own launch)
   bool dense_by_counters = false;  // this frame's denseEnough decision is taken from them by the model pyramid kernel
   double host_wait_ms = 0.0;     // host time spent blocked on the bounded run-ahead ("host_wait" of dms_fusion_get_kernel_time)
   bool pre_valid = false;        // zbuf2 holds a projection
@@ -697,6 +702,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   }
   if (const char* pb = getenv("DMS_PREP_BLOCKS")) f->prep_blocks = atoi(pb);
   if (const char* fl = getenv("DMS_FUSED_LIVE")) f->fused_live = atoi(fl) != 0;
+  if (const char* ft = getenv("DMS_FOLD_TRACK_INIT")) f->fold_track_init = atoi(ft) != 0;
   if (const char* hl = getenv("DMS_HOST_LAG")) f->host_lag = atoi(hl) == 3 ? 3 : 2;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
@@ -949,10 +955,13 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       {
         FTimer t(f, s, "odom_init");
         // WARNING (reference): initICP* must be called before initRGB* (ElasticFusion.cpp:172)
+        // (the set-up of the tracker call below rides on the pyramid kernel: no launch of its own, DMS_FOLD_TRACK_INIT=0 to compare)
+        const TrackFold fold = {f->state->cur.pose, f->p.pyramid, f->p.fastOdom, f->p.so3, 0};
         if ((rc = odometry_initModel_fused(f->odom, f->pred.vertex.data, f->pred.normal.data, f->pred.image.data, f->fill.vertex.data,
                                            f->fill.normal.data, f->fill.image.data, &f->state->fill_in, f->p.frameToFrameRGB ? 1 : 0,
                                            f->state->cur.pose, s, 1,  // (last pyramid step: inside the tracker's first kernel, below)
-                                           f->dense_by_counters ? f->tickets : nullptr, (f->p.width / 20) * (f->p.height / 20))))
+                                           f->dense_by_counters ? f->tickets : nullptr, (f->p.width / 20) * (f->p.height / 20),
+                                           f->fold_track_init ? &fold : nullptr)))
           return rc;
         // initICP / initRGB: the live half ran on the prep stream; nextDepth = lastDepth (same source)
         odometry_alias_next_depth(f->odom);

@@ -4,6 +4,8 @@
 
 namespace dms {
 
+struct TrackInitArgs;  // track_init.hpp
+
 // prep.hip
 int pyrDown(const dms_image2d* src, dms_image2d* dst, hipStream_t s);
 int createVMap(const dms_camera* intr, const dms_image2d* depth, dms_image2d* vmap, float cutoff, hipStream_t s);
@@ -18,7 +20,7 @@ int verticesToDepth(const float* vsrc, dms_image2d* dst, float cutOff, hipStream
 int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void* vB, const void* nB, const void* iB, const int* flag_dev,
                       int force_b_img, const float* pose16_dev, dms_image2d* vmaps, dms_image2d* nmaps, dms_image2d* depths,
                       dms_image2d* images, float cutOff, hipStream_t s, bool skip_last_step = false, const unsigned* dense_cnt = nullptr,
-                      int dense_samples = 0, int* flag_out = nullptr);
+                      int dense_samples = 0, int* flag_out = nullptr, const TrackInitArgs* init = nullptr);
 int verticesToDepth2D(const dms_image2d* vsrc, dms_image2d* dst, float cutOff, hipStream_t s);
 int imageToIntensity(const dms_image2d* rgba, dms_image2d* dst, hipStream_t s);
 int derivativeGate(const dms_image2d* src, dms_image2d* dx, dms_image2d* dy, dms_image2d* gate, float minScale, hipStream_t s);

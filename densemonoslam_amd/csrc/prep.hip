@@ -6,6 +6,7 @@
 #include "pyr_body.hpp"
 #include "live_bodies.hpp"
 #include "fill.hpp"
+#include "track_init.hpp"
 
 namespace dms {
 
@@ -415,12 +416,19 @@ __device__ __forceinline__ void model_pyr_step1_body(int bx, int by, const Model
 __global__ void k_model_levels012(ModelSrc m, int g0x, int g0y, int g12x, int rows0, int cols0, View<float> v0, View<float> n0,
                                   View<float> depth0, View<unsigned char> inten0, float cutOff, int rows1, int cols1, int rows2, int cols2,
                                   View<float> v1, View<float> n1, View<float> v2, View<float> n2, int g12y, int gsx, View<float> depth1,
-                                  View<unsigned char> inten1) {
+                                  View<unsigned char> inten1, TrackInitArgs ti) {
+  // A fourth group, first in the grid (block 0's one-lane state set-up is the longest dependency chain of the launch): the
+  // set-up of the tracker call that follows (track_init.hpp) — it depends on the prior pose only, not on this pyramid.
+  if ((int)blockIdx.x < ti.blocks) {
+    track_init_body((int)blockIdx.x, ti.blocks, (int)(threadIdx.y * blockDim.x + threadIdx.x), (int)(blockDim.x * blockDim.y), ti.st, ti.prior,
+                    ti.prior_pose16, ti.fx, ti.fy, ti.cx, ti.cy, ti.so3, ti.first_level, ti.sync_words, ti.n_sync, ti.inject_timeout, nullptr);
+    return;
+  }
   // (the two small groups come first in the grid: their threads carry 32 / 50 dependent-latency loads each and would
   // otherwise start only when the 1 200 level-0 blocks have been handed out — the launch's tail)
-  const int b = blockIdx.x;
+  const int b = (int)blockIdx.x - ti.blocks;
   if (m.dense_cnt && b == 0 && threadIdx.x == 0 && threadIdx.y == 0) *m.flag_out = model_use_b(m) ? 1 : 0;
-  const int nb0 = g0x * g0y, nb12 = g12x * g12y, nbs = (int)gridDim.x - nb0 - nb12;
+  const int nb0 = g0x * g0y, nb12 = g12x * g12y, nbs = (int)gridDim.x - ti.blocks - nb0 - nb12;
   if (b < nb12) {
     model_levels12_body(b % g12x, b / g12x, m, cols0, rows1, cols1, rows2, cols2, v1, n1, v2, n2);
   } else if (b < nb12 + nbs) {
@@ -785,7 +793,7 @@ int pyrDownUcharGauss(const dms_image2d* src, dms_image2d* dst, hipStream_t s) {
 int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void* vB, const void* nB, const void* iB, const int* flag_dev,
                       int force_b_img, const float* pose16_dev, dms_image2d* vmaps, dms_image2d* nmaps, dms_image2d* depths,
                       dms_image2d* images, float cutOff, hipStream_t s, bool skip_last_step, const unsigned* dense_cnt, int dense_samples,
-                      int* flag_out) {
+                      int* flag_out, const TrackInitArgs* init) {
   DMS_REQUIRE(vA && nA && iA && vB && nB && iB && flag_dev && vmaps && nmaps && depths && images, "null argument");
   ModelSrc m;
   m.vA = (const float4*)vA;
@@ -808,10 +816,13 @@ int modelPyramidFused(const void* vA, const void* nA, const void* iA, const void
     const dim3 b = blk();
     const dim3 g0 = grid2d(cols0, rows0, b), g12 = dim3(((cols1 + 1) / 2 + 15) / 16, ((rows1 + 1) / 2 + b.y - 1) / b.y),  // 16 x BY level-2 pixels per block
                gs = grid2d(depths[1].cols, depths[1].rows, b);
-    hipLaunchKernelGGL(k_model_levels012, dim3(g0.x * g0.y + g12.x * g12.y + gs.x * gs.y), b, 0, s, m, (int)g0.x, (int)g0.y, (int)g12.x, rows0,
+    TrackInitArgs ti;
+    memset(&ti, 0, sizeof(ti));
+    if (init) ti = *init;
+    hipLaunchKernelGGL(k_model_levels012, dim3(ti.blocks + g0.x * g0.y + g12.x * g12.y + gs.x * gs.y), b, 0, s, m, (int)g0.x, (int)g0.y, (int)g12.x, rows0,
                        cols0, view<float>(&vmaps[0]), view<float>(&nmaps[0]), view<float>(&depths[0]), view<unsigned char>(&images[0]), cutOff,
                        rows1, cols1, rows2, cols2, view<float>(&vmaps[1]), view<float>(&nmaps[1]), view<float>(&vmaps[2]),
-                       view<float>(&nmaps[2]), (int)g12.y, (int)gs.x, view<float>(&depths[1]), view<unsigned char>(&images[1]));
+                       view<float>(&nmaps[2]), (int)g12.y, (int)gs.x, view<float>(&depths[1]), view<unsigned char>(&images[1]), ti);
     DMS_CHECK_LAUNCH();
   }
   for (int l = 2; l < 3 && !skip_last_step; ++l)  // (skipped: the caller runs that step inside a kernel of its own)

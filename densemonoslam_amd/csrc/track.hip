@@ -35,6 +35,7 @@
 #include "canon.hpp"
 #include "pyr_body.hpp"
 #include "frame_state.hpp"
+#include "track_init.hpp"
 #include "surfel.hpp"
 #include <mutex>
 
@@ -85,6 +86,11 @@ struct dms_odometry {
   bool fell_back = false;     // a resident kernel timed out at a grid-wide wait: this handle has switched to launch-per-phase
   // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
   bool deferred_pyr = false;
+  // the set-up of the next track call ran inside the model pyramid kernel (odometry_initModel_fused, fold_init): that call then
+  // launches no kernel of its own before the SO3 level, which also carries the deferred pyramid step; the promised parameters
+  bool init_folded = false;
+  int folded_so3 = 0, folded_first_level = 0;
+  const float* folded_prior = nullptr;
   unsigned* dense_cnt_zero = nullptr;  // the frame step's 16 dense counters (fill.hpp), read by the model pyramid kernel: zeroed by the next track call's first kernel
   int inject_timeouts = 0;    // dms_odometry_inject_timeout: calls left that start with the timeout flag set
   int width, height;
@@ -130,59 +136,6 @@ struct dms_odometry {
 };
 
 namespace dms {
-
-struct Prior {
-  float v[12];  // trans[3], rot[9] — passed by value so no staging copy can race a later call
-};
-
-// block `b` of `nb` blocks of `nt` threads (t = linear thread id)
-__device__ __forceinline__ void track_init_body(int b, int nb, int t, int nt, TrackState* st, Prior prior, const float* __restrict__ prior_pose16,
-                                                float fx, float fy, float cx, float cy, int so3, int first_level,
-                                                unsigned long long* sync_words, int n_sync, int inject_timeout, unsigned* zero16) {
-  if (zero16 && b == 0 && t < 16) zero16[t * 16] = 0u;  // (the frame step's dense counters: their reader ran before this launch)
-  // all-reduce words of the resident kernels of this call: zero before any of them is launched
-  // (n_sync counts 16-byte pairs; the grid shares the work, block 0 also sets up the state)
-  {
-    ulonglong2* w2 = reinterpret_cast<ulonglong2*>(sync_words);
-    for (int i = b * nt + t; i < n_sync; i += nt * nb) w2[i] = make_ulonglong2(0ull, 0ull);
-  }
-  if (t != 0 || b != 0) return;
-  if (prior_pose16) {  // device-resident prior (frame step): row-major 4×4 camera-to-world
-    for (int i = 0; i < 3; ++i) {
-      prior.v[i] = prior_pose16[i * 4 + 3];
-      for (int j = 0; j < 3; ++j) prior.v[3 + i * 3 + j] = prior_pose16[i * 4 + j];
-    }
-  }
-  for (int i = 0; i < 3; ++i) st->tprev[i] = st->tcurr[i] = prior.v[i];
-  for (int i = 0; i < 9; ++i) st->Rprev[i] = st->Rcurr[i] = prior.v[3 + i];
-  sm::inv3<float>(st->Rprev, st->Rprev_inv);
-  for (int i = 0; i < 16; ++i) st->resultRt[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  for (int i = 0; i < 9; ++i) {
-    st->resultR[i] = st->lastResultR[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    st->R_lr[i] = (i % 4 == 0) ? 1.f : 0.f;
-  }
-  st->so3_lastError = 3.402823466e+38F / 2;
-  st->so3_lastCount = 3.402823466e+38F / 2;
-  st->so3_done = 0;
-  st->so3_iters = 0;
-  for (int l = 0; l < DMS_NUM_PYRS; ++l) {
-    st->level_done[l] = 0;
-    st->iters_run[l] = 0;
-  }
-  st->rejected_jump = 0;
-  st->sync_timeout = inject_timeout;  // (0 unless a test injects the fault)
-  st->have_E = 0;
-  st->canon_retries = 0;
-  for (int i = 0; i < 36; ++i) st->lastA[i] = 0.0;
-  for (int i = 0; i < 6; ++i) st->lastb[i] = 0.0;
-  if (so3) {
-    sc::so3_params(st, sc::kpre_of(fx, fy, cx, cy, 2));
-  } else {
-    double Rt[16];
-    for (int i = 0; i < 16; ++i) Rt[i] = st->resultRt[i];
-    sc::gn_params(Rt, sc::kpre_of(fx, fy, cx, cy, first_level), st->krkinv, st->kt);
-  }
-}
 
 __global__ void k_track_init(TrackState* st, Prior prior, const float* __restrict__ prior_pose16, float fx, float fy, float cx, float cy,
                              int so3, int first_level, unsigned long long* sync_words, int n_sync, int inject_timeout, unsigned* zero16) {
@@ -1375,6 +1328,18 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   }
 }
 
+// Independent work riding on the SO3 launch when the call's set-up was folded into the model pyramid kernel (frame step):
+// the pyramid's deferred last step in gx * gy blocks of 64 x 8 pixels behind the nb_so3 resident blocks (gx = 0: none),
+// and the re-arming of the frame step's dense counters.
+struct So3Extra {
+  int nb_so3, gx, gy;
+  unsigned* zero16;
+  View<const float> dsrc;
+  View<float> ddst;
+  View<const unsigned char> isrc;
+  View<unsigned char> idst;
+};
+
 // ---------------------------------------------------------------------------------------
 // Persistent SO3 pre-alignment: all (<= 10) iterations in one launch, same protocol as k_gn_level
 // with one all-reduce per iteration.  The state block is copied into LDS
@@ -1382,7 +1347,15 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
                                                    const unsigned char* nextImage, size_t next_pitch, int cols, int rows,
-                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias, int first_delay) {
+                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias, int first_delay, So3Extra ex) {
+  // Blocks past the resident grid carry independent work of the same call: the model pyramid's last step, whose output the
+  // first Gauss-Newton level reads (not this kernel) — see So3Extra.  They take no part in the all-reduce.
+  if ((int)blockIdx.x >= ex.nb_so3) {
+    const int c = (int)blockIdx.x - ex.nb_so3, by = c / ex.gx, bx = c - by * ex.gx;
+    model_pyr_step_pixel(bx * 64 + (int)(threadIdx.x & 63), by * (kPB / 64) + (int)(threadIdx.x >> 6), ex.dsrc, ex.ddst, ex.isrc, ex.idst);
+    return;
+  }
+  if (ex.zero16 && blockIdx.x == 0 && threadIdx.x < 16) ex.zero16[threadIdx.x * 16] = 0u;  // the frame step's dense counters (read before this launch)
   __shared__ TrackState s;
   __shared__ int s_viol;
   __shared__ int s_E[4];
@@ -1391,7 +1364,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   __shared__ float s_sums[32];
   int eb_mine = 0;  // wave 0, lane k < 11: bound exponent of value k
   const int tid = threadIdx.x;
-  const int nb = gridDim.x;
+  const int nb = ex.nb_so3;
   {
     const int* src = reinterpret_cast<const int*>(st);
     int* dst = reinterpret_cast<int*>(&s);
@@ -1942,6 +1915,10 @@ int dms_odometry_initFirstRGB(dms_odometry* o, const dms_image2d* rgba, dms_stre
 }  // extern "C"
 
 namespace dms {
+struct TrackFold {  // the track call a model pyramid launch prepares (odometry_initModel_fused)
+  const float* prior_pose16;
+  int pyramid, fastOdom, so3, interMap;
+};
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
                            float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s, FrameState* frame = nullptr,
                            float weightMultiplier = 1.f);
@@ -2055,6 +2032,13 @@ static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const 
     launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L);
 }
 
+// grid of the resident SO3 kernel for this handle; 0 = the SO3 stage runs launch-per-phase
+static int so3_resident_blocks(const dms_odometry* o) {
+  const Buf& li = o->lastNextImage[2];
+  const int nbp = (li.rows * li.cols + kPB - 1) / kPB;
+  return (o->resident && nbp <= kMaxPersistBlocks && nbp <= o->max_resident_blocks) ? nbp : 0;
+}
+
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
                            float icpWeight, int pyramid, int fastOdom, int so3, int interMap, hipStream_t s, FrameState* frame,
                            float weightMultiplier) {
@@ -2086,7 +2070,29 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       break;
     }
 
-  {
+  // set-up already done inside the model pyramid kernel (frame step): nothing to launch here; the SO3 launch below carries the
+  // deferred pyramid step and re-arms the dense counters
+  const bool folded = o->init_folded;
+  So3Extra ex;
+  memset(&ex, 0, sizeof(ex));
+  if (folded) {
+    o->init_folded = false;
+    DMS_REQUIRE(so3 && so3_resident_blocks(o) > 0 && o->folded_so3 == (so3 ? 1 : 0) && o->folded_first_level == first_level &&
+                    o->folded_prior == prior_pose16_dev && prior_pose16_dev,
+                "track call differs from the one its folded set-up was prepared for");
+    ex.zero16 = o->dense_cnt_zero;
+    o->dense_cnt_zero = nullptr;
+    if (o->deferred_pyr) {
+      o->deferred_pyr = false;
+      dms_image2d d1 = o->lastDepth[1].img(), d2 = o->lastDepth[2].img(), i1 = o->lastImage[1].img(), i2 = o->lastImage[2].img();
+      ex.gx = (d2.cols + 63) / 64;
+      ex.gy = (d2.rows + kPB / 64 - 1) / (kPB / 64);
+      ex.dsrc = view<const float>(&d1);
+      ex.ddst = view<float>(&d2);
+      ex.isrc = view<const unsigned char>(&i1);
+      ex.idst = view<unsigned char>(&i2);
+    }
+  } else {
     Timer t(o, s, "track_init");
     // all-reduce words of the call's resident kernels (resident mode only)
     const int zero_pairs = o->resident ? (int)((size_t)kArSets * kArWords / 2) : 0;
@@ -2114,13 +2120,14 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     const Buf& li = o->lastNextImage[L];
     const Buf& ni = o->nextImage[L];
     const int nb = reduce_blocks_for(li.rows * li.cols);
-    const int nbp = (li.rows * li.cols + kPB - 1) / kPB;
-    if (o->resident && nbp <= kMaxPersistBlocks && nbp <= o->max_resident_blocks) {
+    const int nbp = so3_resident_blocks(o);
+    if (nbp > 0) {
       persist.begin();
       Timer t(o, s, "so3_level");
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
-      hipLaunchKernelGGL(k_so3_level, dim3(nbp), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch, (const unsigned char*)ni.p,
-                         ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias, o->first_delay_for(nbp));
+      ex.nb_so3 = nbp;
+      hipLaunchKernelGGL(k_so3_level, dim3(nbp + ex.gx * ex.gy), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias, o->first_delay_for(nbp), ex);
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {
@@ -2536,9 +2543,13 @@ int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dm
 // lastDepth by the caller, so nothing reads it.
 // defer_last_step: the pyramid's last step is left to the first kernel of the NEXT odometry_track_enqueue on this object
 // (k_track_init_pyr), which the caller must enqueue on the same stream before anything else reads level 2 of lastDepth / lastImage
+// fold: the set-up of the NEXT odometry_track_enqueue on this object (prior = the pose block fold->prior_pose16, the given
+// so3 / pyramid / fastOdom switches) runs as a block group of the pyramid kernel; that call must follow on the same stream
+// with the same arguments.  Taken only where the call's first launch is the resident SO3 level (which then carries the
+// deferred pyramid step); otherwise ignored.
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
-                             int defer_last_step, unsigned* dense_cnt, int dense_samples) {
+                             int defer_last_step, unsigned* dense_cnt, int dense_samples, const TrackFold* fold) {
   dms_image2d v[DMS_NUM_PYRS], n[DMS_NUM_PYRS], d[DMS_NUM_PYRS], im[DMS_NUM_PYRS];
   for (int i = 0; i < DMS_NUM_PYRS; ++i) {
     v[i] = o->vmaps_g_prev[i].img();
@@ -2551,8 +2562,31 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
   // receives the decision; the next odometry_track_enqueue on this object zeroes the counters
   DMS_REQUIRE(!dense_cnt || defer_last_step, "dense counters are zeroed by the track call that takes the deferred pyramid step");
   o->dense_cnt_zero = dense_cnt;
+  TrackInitArgs ti;
+  memset(&ti, 0, sizeof(ti));
+  o->init_folded = false;
+  if (fold && fold->prior_pose16 && fold->so3 && !fold->interMap && defer_last_step && so3_resident_blocks(o) > 0) {
+    const int it1 = fold->pyramid ? 5 : 0, it2 = fold->pyramid ? 4 : 0;
+    ti.st = o->state;
+    ti.prior_pose16 = fold->prior_pose16;
+    ti.fx = o->fx;
+    ti.fy = o->fy;
+    ti.cx = o->cx;
+    ti.cy = o->cy;
+    ti.so3 = 1;
+    ti.first_level = it2 > 0 ? 2 : (it1 > 0 ? 1 : 0);
+    ti.sync_words = o->ar;
+    ti.n_sync = (int)((size_t)kArSets * kArWords / 2);
+    ti.inject_timeout = o->inject_timeouts > 0 ? 1 : 0;
+    if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
+    ti.blocks = 16;
+    o->init_folded = true;
+    o->folded_so3 = 1;
+    o->folded_first_level = ti.first_level;
+    o->folded_prior = fold->prior_pose16;
+  }
   return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s, o->deferred_pyr, dense_cnt,
-                           dense_samples, const_cast<int*>(flag_dev));
+                           dense_samples, const_cast<int*>(flag_dev), o->init_folded ? &ti : nullptr);
 }
 
 // initICP(vertex map, normal map) + initRGB(image) of the live side in the fused form (RGBDOdometry.cpp:118-137,
@@ -2615,7 +2649,7 @@ int dms_odometry_initModelFused(dms_odometry* o, const void* vertA, const void* 
                                 const void* normB, const void* rgbaB, const int* use_b_dev, int force_b_image,
                                 const float* modelPose16_dev, dms_stream s) {
   DMS_REQUIRE(o, "null odometry");
-  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s, 0, nullptr, 0);
+  return odometry_initModel_fused(o, vertA, normA, rgbaA, vertB, normB, rgbaB, use_b_dev, force_b_image, modelPose16_dev, (hipStream_t)s, 0, nullptr, 0, nullptr);
 }
 
 int dms_odometry_fetch_result(dms_odometry* o, dms_track_result* r, dms_stream st) {

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cameras", type=int, nargs="+", default=[1, 2, 4])
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--threads", action="store_true", help="one host thread per camera (each blocks on its own run-ahead bound)")
     args = ap.parse_args()
     from densemonoslam_amd import capi, fusion, synth
 
@@ -42,7 +43,21 @@ def main():
             j = i % period
             return j if j < n_unique else period - j
 
+        def run_cam(c, lo, hi):
+            for i in range(lo, hi):
+                cams[c].processFrameAsync(bufs[c][0][idx(i)].ptr, 3, bufs[c][1][idx(i)].ptr, None, 1.0, streams[c])
+            capi.check(capi.lib.dms_stream_sync(streams[c]))
+
         def run(lo, hi):
+            if args.threads and C_ > 1:
+                import threading
+
+                th = [threading.Thread(target=run_cam, args=(c, lo, hi)) for c in range(C_)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                return
             for i in range(lo, hi):
                 for c in range(C_):
                     cams[c].processFrameAsync(bufs[c][0][idx(i)].ptr, 3, bufs[c][1][idx(i)].ptr, None, 1.0, streams[c])
@@ -55,7 +70,8 @@ def main():
         dt = time.perf_counter() - t0
         surf = [int(cams[c].fetch(streams[c]).surfels) for c in range(C_)]
         print(json.dumps({"cameras_on_one_gpu": C_, "frames_per_s_aggregate": round(C_ * args.steps / dt, 1),
-                          "frames_per_s_per_camera": round(args.steps / dt, 1), "ms_per_round": round(1000 * dt / args.steps, 4), "surfels": surf}))
+                          "frames_per_s_per_camera": round(args.steps / dt, 1), "ms_per_round": round(1000 * dt / args.steps, 4), "surfels": surf,
+                          "host_threads": C_ if args.threads else 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")}))
         for c in cams:
             c.close()
         for s in streams:

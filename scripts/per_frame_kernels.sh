@@ -6,7 +6,7 @@ python - <<P
 import sqlite3,glob,collections
 c=sqlite3.connect(glob.glob("/tmp/kt/**/*results.db",recursive=True)[0])
 rows=list(c.execute("select name,start,end from kernels order by start"))
-idx=[i for i,r in enumerate(rows) if "k_track_init" in r[0]]
+idx=[i for i,r in enumerate(rows) if "k_so3_level" in r[0]]
 def seg(a,b):
     d=collections.defaultdict(float)
     for n,s,e in rows[idx[a]:idx[b]]: d[n.split("(")[0].replace("void ","").replace("dms::","")[:34]]+=(e-s)/1e3/(b-a)

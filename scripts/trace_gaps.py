@@ -19,7 +19,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ev = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-    starts = [i for i, e in enumerate(ev) if e[0] == "k_track_init"]  # one per tracked frame
+    starts = [i for i, e in enumerate(ev) if e[0] in ("k_track_init", "k_so3_level")]  # one per tracked frame
     if len(starts) < 12:
         print("too few frames")
         return
