@@ -196,8 +196,17 @@ __device__ __forceinline__ bool last_block_arrives(unsigned* ticket) {
 __device__ __forceinline__ void fold_records_i64(const long long* __restrict__ rec, int nblocks, long long* totals) {
   __shared__ long long s_g[8][32];
   const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+  // (eight loads in flight per thread: one dependent round trip per record made this fold 30 us of a 600-record level)
   long long s = 0;
-  for (int b = g; b < nblocks; b += 8) s += rec[(size_t)b * kRecWords + k];
+  int b = g;
+  for (; b + 56 < nblocks; b += 64) {
+    long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = rec[(size_t)(b + 8 * u) * kRecWords + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < nblocks; b += 8) s += rec[(size_t)b * kRecWords + k];
   s_g[g][k] = s;
   __syncthreads();
   if (threadIdx.x < 32) {
