@@ -74,6 +74,7 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
 int odometry_initLive_fused(dms_odometry* o, const void* verts, const void* norms, const void* rgba, const int* any_flag_dev,
                             hipStream_t s);
 int odometry_enable_ring(dms_odometry* o);
+int odometry_free_cus(const dms_odometry* o);
 void odometry_set_early_exit(dms_odometry* o, int on);
 int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dms_image2d* nextDepth);
 struct LoopState;
@@ -698,7 +699,14 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   {  // 64 fat blocks at 640x480 (1816 -> 1905 frames/s; 40: the prep stream becomes the bottleneck, 128: 1875), scaled with the image
     const long n = (long)p->width * p->height;
     long b = (n * 64 + 153600) / 307200;
-    f->prep_blocks = (int)(b < 32 ? 32 : (b > 160 ? 160 : b));
+    b = b < 32 ? 32 : (b > 160 ? 160 : b);
+    // ... but never more than the resident tracker kernels leave free: a fat block holds a whole compute unit for the length of
+    // the filter, and a resident grid that finds fewer free units than it has blocks starts incomplete — its blocks spin until
+    // the filter's blocks retire (640x480: 200 + 64 > 256 units made the level-0 launch 130 instead of 111 us beside the filter;
+    // 56 blocks: 114 us, 2470 -> 2572 frames/s).  Below 48 the prep stream itself becomes the bottleneck: then the overlap is kept.
+    const int free_cus = odometry_free_cus(f->odom);
+    if (free_cus >= 48 && free_cus < b) b = free_cus;
+    f->prep_blocks = (int)b;
   }
   if (const char* pb = getenv("DMS_PREP_BLOCKS")) f->prep_blocks = atoi(pb);
   if (const char* fl = getenv("DMS_FUSED_LIVE")) f->fused_live = atoi(fl) != 0;

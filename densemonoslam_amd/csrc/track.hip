@@ -2446,6 +2446,22 @@ int transformMapsDev(dms_image2d* v, dms_image2d* n, const float* pose16_dev, hi
 // ---- live-frame ring (see dms_odometry::LiveSet) ----
 void odometry_set_early_exit(dms_odometry* o, int on) { o->early_exit = on != 0; }
 
+// compute units the resident tracker kernels of this handle leave free at their widest level (-1: launch-per-phase, nothing
+// is held): what an overlapping stream can use without keeping a resident block off the device
+int odometry_free_cus(const dms_odometry* o) {
+  if (!o->resident) return -1;
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1;
+  int widest = so3_resident_blocks(o);
+  for (int l = 0; l < DMS_NUM_PYRS; ++l) {
+    int P = 1, nb = 0;
+    persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, o->max_resident_blocks, P, nb);
+    widest = nb > widest ? nb : widest;
+  }
+  return cus - widest;
+}
+
 int odometry_enable_ring(dms_odometry* o) {
   if (o->ring_enabled) return DMS_OK;
   for (int i = 0; i < DMS_NUM_PYRS; ++i) {

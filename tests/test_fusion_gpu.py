@@ -1531,3 +1531,37 @@ def test_fused_live_half_equals_operator_chain(fus, synth, size, monkeypatch):
         assert x[0].tobytes() == y[0].tobytes(), "pose of frame %d" % k
         assert x[1] == y[1]
     surfels_equal(ma, mb, "map")
+
+
+def test_folded_tracker_setup_changes_nothing(fus, synth, monkeypatch):
+    """The tracker call's set-up (prior pose -> state block, zeroed all-reduce words) runs as a block group of the model
+    pyramid kernel, the deferred pyramid step and the re-arming of the dense counters as extra blocks of the SO3 launch
+    (DMS_FOLD_TRACK_INIT, read when the context is created).  Poses, decisions, images and the map must equal the run
+    with the set-up kernel of its own — also across a frame with a caller-supplied prior and with SO3 switched off (the
+    fold is then not taken)."""
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(7)]
+
+    def run(fold, so3):
+        monkeypatch.setenv("DMS_FOLD_TRACK_INIT", "1" if fold else "0")
+        g = fus.ElasticFusion(W, H, K, model_capacity=600000, so3=so3)
+        out = []
+        for k, (d, rgb, T) in enumerate(frames):
+            prior = None
+            if k == 3:
+                prior = np.array(out[-1][0], np.float32).reshape(4, 4).copy()
+                prior[:3, 3] += np.float32([0.002, -0.001, 0.001])
+            r = g.processFrame(rgb, d, inPose=prior)
+            out.append((np.array(r.pose, np.float32), int(r.surfels), int(r.fill_in), g.image(10).copy(), g.image(13).copy()))
+        m = g.globalModel().downloadMap()
+        g.close()
+        return out, m
+
+    for so3 in (1, 0):
+        a, ma = run(True, so3)
+        b, mb = run(False, so3)
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert x[0].tobytes() == y[0].tobytes(), "pose of frame %d (so3 %d)" % (k, so3)
+            assert x[1:3] == y[1:3]
+            for i in (3, 4):
+                assert_bits(x[i], y[i], "image %d of frame %d" % (i, k))
+        surfels_equal(ma, mb, "map")
