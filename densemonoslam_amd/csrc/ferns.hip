@@ -245,6 +245,115 @@ __global__ __launch_bounds__(256) void k_fern_commit(const unsigned char* __rest
   if (blockIdx.x == 0 && threadIdx.x < kFernPad / 16) reinterpret_cast<uint4*>(db_codes)[threadIdx.x] = reinterpret_cast<const uint4*>(cur_codes)[threadIdx.x];
 }
 
+// dms_ferns_publish_block in ONE launch for databases of up to kPublishFusedMax key frames: encode (k_fern_encode), search
+// (k_fern_search: the block's 8 waves take the stored frames in turn, minimum through one LDS word), decision
+// (k_fern_decide) and commit (k_fern_commit) are four dependent steps of one block's worth of work each; as four launches they
+// cost four launch latencies on the frame's stream in collaborative mode.  Same arithmetic, same results.
+constexpr int kPublishFusedMax = 512;
+__global__ __launch_bounds__(kFernPad) void k_fern_publish(const unsigned char* __restrict__ block, int tw, int th, const FernTable* __restrict__ tab,
+                                                           int num, unsigned char* __restrict__ cur_codes, unsigned char* __restrict__ codes2,
+                                                           int* __restrict__ good_out, FernHost* __restrict__ res, const unsigned char* __restrict__ db_codes,
+                                                           int* __restrict__ db_good, int* __restrict__ db_time, float* __restrict__ db_pose,
+                                                           unsigned char* __restrict__ db_blocks, size_t block_bytes, int* __restrict__ n_dev, int capacity,
+                                                           float threshold, int srcTime, const float* __restrict__ pose_dev, volatile int* status, int seq) {
+  __shared__ int s_good, s_slot;
+  __shared__ unsigned long long s_best;
+  __shared__ __attribute__((aligned(8))) unsigned char s_codes[kFernPad];
+  const int i = threadIdx.x;
+  if (i == 0) {
+    s_good = 0;
+    s_best = ~0ull;
+  }
+  __syncthreads();
+  // ---- encode (Ferns.cpp:208-233)
+  unsigned char code = DMS_FERN_BAD_CODE;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  uchar4 pix = make_uchar4(0, 0, 0, 0);
+  if (i < num) {
+    const size_t n = (size_t)tw * th;
+    const int q = (int)tab->y[i] * tw + (int)tab->x[i];
+    v = reinterpret_cast<const float4*>(block + n * 4)[q];
+    pix = reinterpret_cast<const uchar4*>(block)[q];
+    if (v.z > 0.f) {
+      code = (unsigned char)((((int)pix.x > tab->r[i]) << 3) | (((int)pix.y > tab->g[i]) << 2) | (((int)pix.z > tab->b[i]) << 1) |
+                             (f2i_rz(v.z * 1000.0f) > tab->d[i] ? 1 : 0));
+      atomicAdd(&s_good, 1);
+    }
+  }
+  s_codes[i] = code;
+  cur_codes[i] = code;
+  if (codes2) codes2[i] = code;
+  res->vert[i] = v;
+  res->rgb[i] = pix;
+  __syncthreads();
+  const int good = s_good;
+  // ---- search (Ferns.cpp:235-248), every stored frame
+  const int n0 = *n_dev;
+  {
+    const int lane = i & 63, wave = i >> 6;
+    const unsigned long long mine = reinterpret_cast<const unsigned long long*>(s_codes)[lane];
+    for (int j = wave; j < n0; j += kFernPad / 64) {
+      const unsigned long long theirs = reinterpret_cast<const unsigned long long*>(db_codes + (size_t)j * kFernPad)[lane];
+      int co = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned m = (unsigned)(mine >> (8 * b)) & 0xFFu, t = (unsigned)(theirs >> (8 * b)) & 0xFFu;
+        co += (m != DMS_FERN_BAD_CODE && m == t) ? 1 : 0;
+      }
+      co = wave_sum_i(co);
+      if (lane == 0) {
+        const int gj = db_good[j];
+        const float maxCo = (float)(good < gj ? good : gj);
+        const float dissim = (maxCo - (float)co) / maxCo;
+        if (dissim == dissim) atomicMin(&s_best, ((unsigned long long)__float_as_uint(dissim) << 32) | (unsigned)j);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- decision (Ferns.cpp:235-275)
+  if (i == 0) {
+    const unsigned long long best = s_best;
+    float minimum = 3.402823466e+38F;
+    if (good > 0 && best != ~0ull) minimum = __uint_as_float((unsigned)(best >> 32));
+    int slot = -1;
+    if ((minimum > threshold || n0 == 0) && good > 0) {
+      if (n0 >= capacity) {
+        slot = -2;
+        n_dev[1] += 1;
+      } else {
+        slot = n0;
+        db_good[n0] = good;
+        db_time[n0] = srcTime;
+        for (int k = 0; k < 16; ++k) db_pose[(size_t)n0 * 16 + k] = pose_dev[k];
+        *n_dev = n0 + 1;
+      }
+    }
+    if (good_out) *good_out = good;
+    res->good = good;
+    res->best = best;
+    res->hd_count = 0;
+    res->hd_equal = 0;
+    res->slot = slot;
+    res->n = *n_dev;
+    s_slot = slot;
+    if (status) {
+      status[1] = *n_dev;
+      status[2] = n_dev[1];
+      __threadfence_system();
+      status[0] = seq;
+    }
+  }
+  __syncthreads();
+  // ---- commit: payload of an accepted frame -> its slot
+  const int slot = s_slot;
+  if (slot < 0) return;
+  unsigned char* db_block = db_blocks + (size_t)slot * block_bytes;
+  const size_t n16 = block_bytes / 16;
+  for (size_t k = i; k < n16; k += kFernPad) reinterpret_cast<uint4*>(db_block)[k] = reinterpret_cast<const uint4*>(block)[k];
+  if (i < kFernPad / 16)
+    reinterpret_cast<uint4*>(const_cast<unsigned char*>(db_codes) + (size_t)slot * kFernPad)[i] = reinterpret_cast<const uint4*>(s_codes)[i];
+}
+
 // ---- the table: mt19937 + uniform_int_distribution (Ferns.cpp:27-30,56,68-83) ------------------------------------
 struct Mt19937 {
   uint32_t mt[624];
@@ -297,6 +406,7 @@ struct dms_ferns {
   volatile int* h_status = nullptr;
   int* d_status = nullptr;  // device view of h_status
   int adds_issued = 0;
+  bool publish_fused = true;  // dms_ferns_publish_block as one launch while the database is small (DMS_FERNS_PUBLISH_FUSED=0: four)
   hipEvent_t ev_last_add = nullptr;  // recorded after the last asynchronous add: what mirror() has to wait for
   bool ev_valid = false;
   float photoThresh = 0.f;
@@ -632,6 +742,7 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
     dms_ferns_destroy(f);
     return rc;
   }
+  if (const char* pf = getenv("DMS_FERNS_PUBLISH_FUSED")) f->publish_fused = atoi(pf) != 0;
   *out = f;
   return DMS_OK;
 }
@@ -727,6 +838,15 @@ int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned 
   DMS_REQUIRE(f && thumb_block_dev && codes_dev && good_dev && pose16_dev, "null argument");
   DMS_REQUIRE(((uintptr_t)thumb_block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
   hipStream_t s = (hipStream_t)st;
+  if (f->n_upper <= kPublishFusedMax && f->publish_fused) {  // the four steps in one launch (k_fern_publish)
+    f->adds_issued += 1;
+    hipLaunchKernelGGL(k_fern_publish, dim3(1), dim3(kFernPad), 0, s, (const unsigned char*)thumb_block_dev, f->tw, f->th, f->d_tab, f->num,
+                       f->d_cur_codes, codes_dev, good_dev, f->d_res, (const unsigned char*)f->d_codes, f->d_good, f->d_time, f->d_pose, f->d_blocks,
+                       f->block_bytes, f->d_n, f->capacity, threshold, srcTime, pose16_dev, (volatile int*)f->d_status, f->adds_issued);
+    DMS_CHECK_LAUNCH();
+    after_async_add(f, s);
+    return DMS_OK;
+  }
   // one encoding pass feeds the caller's descriptor and the handle's staged codes; the block is read where it lies
   hipLaunchKernelGGL(k_fern_encode, dim3(1), dim3(kFernPad), 0, s, (const unsigned char*)thumb_block_dev, f->tw, f->th, f->d_tab, f->num,
                      f->d_cur_codes, good_dev, f->d_res, codes_dev);

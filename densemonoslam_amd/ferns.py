@@ -63,6 +63,13 @@ class Ferns:
         check(lib.dms_ferns_get_table(self.h, pos.ctypes.data_as(C.POINTER(_I)), rgbd.ctypes.data_as(C.POINTER(_I))), "dms_ferns_get_table")
         return pos, rgbd
 
+    def status(self):
+        """(frames stored, key frames dropped because the database was full) as of the last completed asynchronous add"""
+        a, b = C.c_int(0), C.c_int(0)
+        lib.dms_ferns_status.argtypes = [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        check(lib.dms_ferns_status(self.h, C.byref(a), C.byref(b)), "dms_ferns_status")
+        return a.value, b.value
+
     def __len__(self):
         return int(lib.dms_ferns_num_frames(self.h))
 

@@ -7,6 +7,13 @@ import pytest
 # the oracle's OpenMP loops are short: on a many-core host the default (one thread per core) costs more
 # in fork/join than it saves
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+# torch brings its own copy of the HIP runtime: whichever of torch / libdmslam_hip.so is loaded first decides which copy the
+# process uses, and a process that loads the library first and torch later ends up with two runtimes ("No HIP GPUs are
+# available" from the second).  The tests that need both (collab, bench rehearsals) must not depend on the collection order.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -268,3 +268,39 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
     ga.close()
     gs.close()
     ef.close()
+
+
+def test_publish_block_in_one_launch_equals_the_four_step_form(mods, monkeypatch):
+    """dms_ferns_publish_block encodes, searches, decides and commits in one launch while the database is small
+    (DMS_FERNS_PUBLISH_FUSED, read at creation); the descriptor written into the block, every add / reject decision, the
+    stored frames and the count of key frames lost to a full database must equal the four-launch form."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    from densemonoslam_amd import collab
+    from densemonoslam_amd.capi import DeviceBuffer
+
+    T = collab.thumbnail_bytes(W, H)
+    ef = fusion.ElasticFusion(W, H, K, model_capacity=2_000_000)
+    blocks = []
+    for k in range(10):
+        d, rgb, _ = synth.frame(4 * k, width=W, height=H, K=K, noise=True)
+        ef.processFrame(rgb, d)
+        blk = DeviceBuffer(T + collab.DESC_BYTES)
+        ef.frameBlock(blk.ptr, blk.ptr + T + collab.DESC_POSE, blk.ptr + T + collab.DESC_TICK, k + 1)
+        blocks.append(blk)
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DMS_FERNS_PUBLISH_FUSED", fused)
+        g = ferns.Ferns(W, H, K, seed=5, capacity=4)  # small: the last key frames find the database full
+        descs = []
+        for k, blk in enumerate(blocks):
+            g.publishBlock(blk.ptr, blk.ptr + T + collab.DESC_CODES, blk.ptr + T + collab.DESC_GOOD, blk.ptr + T + collab.DESC_POSE, k + 1, 0.05)
+            descs.append(blk.download(np.uint8, (T + collab.DESC_BYTES,))[T:].copy())
+        n = len(g)
+        frames = [g.frame(i) for i in range(n)]
+        out.append((descs, n, frames, g.status() if hasattr(g, "status") else None))
+    (da, na, fa, sa), (db, nb, fb, sb) = out
+    assert na == nb == 4 and sa == sb
+    for x, y in zip(da, db):
+        assert (x == y).all()
+    for (pa, ta, ga_, ca), (pb, tb, gb_, cb) in zip(fa, fb):
+        assert ta == tb and ga_ == gb_ and (ca == cb).all() and (pa == pb).all()
