@@ -32,16 +32,17 @@ struct LoopState {
 // of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
 // `timed_out`: the tracker's result is invalid (the caller has restored the prior pose): count it and mark the frame
 // with a negative weight, which k_fuse_associate reads as "fuse nothing" (a legal weight is >= 0).
-// `pose` / `last`: the new pose and the previous frame's, when the caller already holds them (registers / LDS: the resident
-// tracker's last block has just written the pose and read lastPose at its start — re-reading both from memory costs two
-// dependent round trips at the very end of the kernel); null = read them from the state block.
-__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false, const float* pose = nullptr,
-                                              const float* last = nullptr) {
-  float P[16], Lp[16], Ti[16];
-  for (int i = 0; i < 16; ++i) P[i] = pose ? pose[i] : st->cur.pose[i];
-  for (int i = 0; i < 16; ++i) Lp[i] = last ? last[i] : st->lastPose[i];
+// `held`: 48 floats the caller already holds in LDS — [0..15] the new pose, [16..31] the previous frame's (the resident
+// tracker's last block has just computed the one and read the other at its start: re-reading both from memory costs two
+// dependent round trips at the very end of the kernel), [32..47] room for the inverse; null = everything through the state
+// block.  (Pointers, not private arrays: 16-element arrays indexed in loops end up in scratch inside the large level kernels.)
+__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false, float* held = nullptr) {
+  const float* P = held ? held : st->cur.pose;
+  const float* Lp = held ? held + 16 : st->lastPose;
+  float* Ti = held ? held + 32 : st->cur.t_inv;
   sm::inv4t<float>(P, Ti);
-  for (int i = 0; i < 16; ++i) st->cur.t_inv[i] = Ti[i];
+  if (held)
+    for (int i = 0; i < 16; ++i) st->cur.t_inv[i] = Ti[i];
   float diff[16];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {

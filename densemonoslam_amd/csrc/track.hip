@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   __shared__ int s_E[2][8];            // column exponents of the two reductions
   __shared__ float s_sums[64];
   __shared__ double s_comb[28];  // the combined 6x6 system (27 unique entries), written by the lanes that hold the totals
-  __shared__ float s_lastPose[16];
+  __shared__ float s_held[48];  // finalize step: new pose | previous frame's pose | inverse (frame_state.hpp)
   __shared__ int s_none;
   __shared__ int s_done;
   __shared__ int s_cs[2];
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
     }
   };
 
-  if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 64 && tid < 80) s_lastPose[tid - 64] = L.frame->lastPose[tid - 64];  // for the finalize step
+  if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 64 && tid < 80) s_held[16 + tid - 64] = L.frame->lastPose[tid - 64];  // for the finalize step
   if (tid == 0) {
     s_none = 0;
     s_retries = 0;
@@ -1318,16 +1318,17 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         L.pose16_out[15] = 1.f;
       }
       if (L.frame) {
-        // (the pose block the frame step hands in IS the frame state's current pose: then this thread holds both matrices)
+        // (the pose block the frame step hands in IS the frame state's current pose: then this block holds both matrices)
         const bool own = L.pose16_out == L.frame->cur.pose;
-        float P16[16];
-        for (int i = 0; i < 3; ++i) {
-          for (int j = 0; j < 3; ++j) P16[i * 4 + j] = Rc[i * 3 + j];
-          P16[i * 4 + 3] = tc[i];
+        if (own) {
+          for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) s_held[i * 4 + j] = Rc[i * 3 + j];
+            s_held[i * 4 + 3] = tc[i];
+          }
+          s_held[12] = s_held[13] = s_held[14] = 0.f;
+          s_held[15] = 1.f;
         }
-        P16[12] = P16[13] = P16[14] = 0.f;
-        P16[15] = 1.f;
-        frame_after_track_body(L.frame, L.weightMultiplier, timed_out, own ? P16 : nullptr, own ? s_lastPose : nullptr);
+        frame_after_track_body(L.frame, L.weightMultiplier, timed_out, own ? s_held : nullptr);
       }
     }
   }
