@@ -32,19 +32,25 @@ struct LoopState {
 // of float rotations is orthonormal to ~1e-7, so the matrix is used as is.
 // `timed_out`: the tracker's result is invalid (the caller has restored the prior pose): count it and mark the frame
 // with a negative weight, which k_fuse_associate reads as "fuse nothing" (a legal weight is >= 0).
-// `held`: 48 floats the caller already holds in LDS — [0..15] the new pose, [16..31] the previous frame's (the resident
+// `held`: 32 floats the caller already holds in LDS — [0..15] the new pose, [16..31] the previous frame's (the resident
 // tracker's last block has just computed the one and read the other at its start: re-reading both from memory costs two
-// dependent round trips at the very end of the kernel), [32..47] room for the inverse; null = everything through the state
-// block.  (Pointers, not private arrays: 16-element arrays indexed in loops end up in scratch inside the large level kernels.)
+// dependent round trips at the very end of the kernel); null = read both from the state block.
 __device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false, float* held = nullptr) {
-  const float* P = held ? held : st->cur.pose;
-  const float* Lp = held ? held + 16 : st->lastPose;
-  float* Ti = held ? held + 32 : st->cur.t_inv;
+  // (every loop over these 16-element arrays is fully unrolled: constant indices keep them in registers — a loop left rolled
+  // puts them in scratch, which the large level kernels would then allocate for every lane)
+  float P[16], Lp[16], Ti[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    P[i] = held ? held[i] : st->cur.pose[i];
+    Lp[i] = held ? held[16 + i] : st->lastPose[i];
+  }
   sm::inv4t<float>(P, Ti);
-  if (held)
-    for (int i = 0; i < 16; ++i) st->cur.t_inv[i] = Ti[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st->cur.t_inv[i] = Ti[i];
   float diff[16];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       float s = Ti[i * 4 + 0] * Lp[0 * 4 + j];
       s += Ti[i * 4 + 1] * Lp[1 * 4 + j];
@@ -76,6 +82,7 @@ __device__ inline void frame_after_track_body(FrameState* st, float weightMultip
   weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
   st->weighting = timed_out ? -1.f : weighting;
   if (timed_out) st->track_timeouts += 1;
+#pragma unroll
   for (int i = 0; i < 16; ++i) st->lastPose[i] = P[i];
 }
 

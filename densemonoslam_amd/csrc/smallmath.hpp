@@ -70,6 +70,7 @@ __host__ __device__ inline void inv4t(const T* m, T* o) {
   inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
   const T det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
   const T id = T(1) / det;
+#pragma unroll
   for (int i = 0; i < 16; ++i) o[i] = inv[i] * id;
 }
 __host__ __device__ inline void inv4(const double* m, double* o) { inv4t<double>(m, o); }
