@@ -3,7 +3,7 @@
 the headline resolution (both sides start every step from the GPU's map and pose): the margin under the
 north-star bar (1 mm, 0.01 deg per step).  Uses oracle/ as the checker.
 
-    python scripts/parity_margin.py [--frames 100] [--width 640 --height 480]      (DMS_SUMS=fp64 selects the fp64-sum tracker)"""
+    python scripts/parity_margin.py [--frames 100] [--width 640 --height 480]      (round-2 instrument: since round 3 the two sides are bit-identical, tests/test_fusion_gpu.py::test_long_run_every_step_identical_640x480)"""
 import argparse
 import json
 import os
@@ -55,7 +55,7 @@ def main():
                       "p99_dt_m": float(np.percentile(dts, 99)), "worst_dR_deg": float(das.max()), "median_dR_deg": float(np.median(das)),
                       "p99_dR_deg": float(np.percentile(das, 99)), "decision_flips": flips, "surfels": int(rg.surfels),
                       "bar": {"dt_m": 1e-3, "dR_deg": 0.01},
-                      "sums": os.environ.get("DMS_SUMS", "fp32")}))
+                      "sums": "canonical"}))
 
 
 if __name__ == "__main__":
