@@ -1950,8 +1950,8 @@ namespace dms {
 // ---- persistent level kernels: launch shape and cross-stream serialisation ----
 // dms_odometry::resident = false (DMS_TRACK_MODE=launches at creation) selects the three-launches-per-iteration path.
 
-// pixels per thread (1 or 2) and grid of k_gn_level for an n-pixel level; 0 blocks = not eligible
-static void persistent_shape(int n, int target, int max_blocks, int& P, int& nb) {
+// pixels per thread (1 - 5) and grid of k_gn_level for an n-pixel level; 0 blocks = not eligible
+static void persistent_shape(int n, int target, int max_blocks, int& P, int& nb, int reserve = 56) {
   // 1 or 2 pixels per thread if that keeps the grid at <= `target` blocks (cheap barriers win on the small levels; 96 while
   // the cross-block sums went through per-block records and a gather, 160 since the integer all-reduce: level 1 of
   // 640x480 on 150 blocks with one pixel per thread instead of 75 with two, +1 % frame rate);
@@ -1960,14 +1960,21 @@ static void persistent_shape(int n, int target, int max_blocks, int& P, int& nb)
   auto blocks = [&](int p) { return (n + kPB * p - 1) / (kPB * p); };
   const int cap = max_blocks < kMaxPersistBlocks ? max_blocks : kMaxPersistBlocks;  // every block must be resident at once
   const int small = target < cap ? target : cap;
+  // ... and among 3 / 4 / 5 the fewest that leaves `reserve` compute units to whatever overlaps the tracker (the frame step's
+  // prep stream holds whole units for the length of its depth filter: 1241x376 on 228 blocks beside 97 filter blocks started
+  // incomplete; 5 pixels per thread = 183 blocks leave 73), else the fewest that fits at all
   if (blocks(1) <= small)
     P = 1;
   else if (blocks(2) <= small)
     P = 2;
-  else if (blocks(3) <= cap)
-    P = 3;
-  else
-    P = 4;
+  else {
+    P = 0;
+    for (int p = 3; p <= 5 && !P; ++p)
+      if (blocks(p) <= cap - reserve) P = p;
+    for (int p = 3; p <= 5 && !P; ++p)
+      if (blocks(p) <= cap) P = p;
+    if (!P) P = 5;
+  }
   nb = (n + kPB * P - 1) / (kPB * P);
   if (nb > cap || n >= (1 << 19)) nb = 0;  // does not fit the device (or the 19-bit count of the pair word): launch-per-phase
 }
@@ -2032,8 +2039,10 @@ static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, cons
     hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
   else if (P == 3)
     hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
-  else
+  else if (P == 4)
     hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+  else
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 5, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
 }
 template <bool ICP, bool RGB>
 static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
