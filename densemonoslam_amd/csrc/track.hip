@@ -1998,13 +1998,23 @@ struct PersistChain {
   bool ev_valid[64] = {};
 };
 static PersistChain g_persist;
+// DMS_PERSIST_UNCHAINED=1: the caller guarantees that the resident grids of all handles that may track at the same time fit the
+// device TOGETHER (DMS_PERSIST_MAX_BLOCKS of each, summed, <= compute units) — then every grid completes whatever the
+// interleaving and no section has to wait for another camera's.  Read once.
+static bool unchained() {
+  static const bool u = [] {
+    const char* e = getenv("DMS_PERSIST_UNCHAINED");
+    return e && atoi(e) != 0;
+  }();
+  return u;
+}
 struct PersistSection {
   hipStream_t s;
   int dev = 0;
   bool active = false;
   explicit PersistSection(hipStream_t s_) : s(s_) {}
   void begin() {
-    if (active) return;
+    if (active || unchained()) return;
     g_persist.mu.lock();
     (void)hipGetDevice(&dev);
     dev &= 63;

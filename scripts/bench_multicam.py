@@ -71,7 +71,8 @@ def main():
         surf = [int(cams[c].fetch(streams[c]).surfels) for c in range(C_)]
         print(json.dumps({"cameras_on_one_gpu": C_, "frames_per_s_aggregate": round(C_ * args.steps / dt, 1),
                           "frames_per_s_per_camera": round(args.steps / dt, 1), "ms_per_round": round(1000 * dt / args.steps, 4), "surfels": surf,
-                          "host_threads": C_ if args.threads else 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")}))
+                          "host_threads": C_ if args.threads else 1, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
+                          "DMS_PERSIST_MAX_BLOCKS": os.environ.get("DMS_PERSIST_MAX_BLOCKS"), "DMS_PERSIST_UNCHAINED": os.environ.get("DMS_PERSIST_UNCHAINED")}))
         for c in cams:
             c.close()
         for s in streams:

@@ -1565,3 +1565,46 @@ def test_folded_tracker_setup_changes_nothing(fus, synth, monkeypatch):
             for i in (3, 4):
                 assert_bits(x[i], y[i], "image %d of frame %d" % (i, k))
         surfels_equal(ma, mb, "map")
+
+
+def test_two_cameras_unchained_with_half_size_resident_grids():
+    """DMS_PERSIST_UNCHAINED=1 with DMS_PERSIST_MAX_BLOCKS=120: the resident tracker grids of two cameras fit the device together
+    (level 0 of 640x480 takes 5 pixels per thread on 120 blocks), so their sections are not chained across streams and may run
+    side by side.  A fresh process (the switch is read once): each camera's poses and map must equal the same camera running
+    alone, bit for bit, and no grid-wide wait may time out."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np
+from densemonoslam_amd import capi, fusion, synth
+W, H, K = 640, 480, synth.K_640
+n = 6
+frames = [[synth.frame(k, cam_id=c, width=W, height=H, K=K, noise=True) for k in range(n)] for c in (0, 1)]
+bufs = [([capi.DeviceBuffer(W * H * 3).upload(np.ascontiguousarray(f[1], np.uint8)) for f in fr],
+         [capi.DeviceBuffer(W * H * 2).upload(np.ascontiguousarray(f[0], np.uint16)) for f in fr]) for fr in frames]
+def alone(c):
+    g = fusion.ElasticFusion(W, H, K, model_capacity=2000000, timeIdx=c)
+    for k in range(n):
+        g.processFrameAsync(bufs[c][0][k].ptr, 3, bufs[c][1][k].ptr)
+    r = g.fetch()
+    out = (np.array(r.pose, np.float32).tobytes(), int(r.surfels), g.globalModel().downloadMap().tobytes())
+    g.close()
+    return out
+ref = [alone(0), alone(1)]
+streams = [capi.create_stream(), capi.create_stream()]
+cams = [fusion.ElasticFusion(W, H, K, model_capacity=2000000, timeIdx=c) for c in (0, 1)]
+for k in range(n):
+    for c in (0, 1):
+        cams[c].processFrameAsync(bufs[c][0][k].ptr, 3, bufs[c][1][k].ptr, None, 1.0, streams[c])
+for c in (0, 1):
+    r = cams[c].fetch(streams[c])   # raises on a timeout
+    got = (np.array(r.pose, np.float32).tobytes(), int(r.surfels), cams[c].globalModel().downloadMap().tobytes())
+    assert got == ref[c], "camera %d differs" % c
+print("UNCHAINED_OK")
+'''
+    env = dict(os.environ, DMS_PERSIST_UNCHAINED="1", DMS_PERSIST_MAX_BLOCKS="120", GPU_MAX_HW_QUEUES="8",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "UNCHAINED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
