@@ -344,8 +344,15 @@ __device__ __forceinline__ RgbRowIn rgb_row_load(const dms_dataterm& c, const fl
 }
 
 // row is all zero for an invalid correspondence
+// reference: float invz = 1.0 / cloudPoint.z  (double division rounded to float).  Rounding the correctly rounded
+// double quotient of two floats to float gives the correctly rounded float quotient (double rounding is innocuous for
+// division when the wider format has at least 2 * 24 + 2 bits): the IEEE float division is the same value, a third of
+// the instructions.  (sigma-independent: the resident kernels take it while the correspondence count is still in flight.)
+__device__ __forceinline__ float rgb_row_invz(const f3& pt) { return 1.0f / pt.z; }
+
 template <bool FMA = false>
-__device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms_dataterm& c, const RgbRowIn& in, float (&row)[7]) {
+__device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms_dataterm& c, const RgbRowIn& in, float (&row)[7], float invz_pre = 0.f,
+                                               bool have_invz = false) {
 #pragma unroll
   for (int i = 0; i < 7; ++i) row[i] = 0.f;
   if (!c.valid) return;
@@ -354,11 +361,7 @@ __device__ __forceinline__ void rgb_row_finish(const RgbStepParams& p, const dms
   if (p.sigma == -1.f) w = 1.f;
   row[6] = -w * c.diff;
   const f3 pt = in.pt;
-  // reference: float invz = 1.0 / cloudPoint.z  (double division rounded to float).  Rounding the correctly rounded
-  // double quotient of two floats to float gives the correctly rounded float quotient (double rounding is innocuous for
-  // division when the wider format has at least 2 * 24 + 2 bits): the IEEE float division is the same value, a third of
-  // the instructions.
-  const float invz = 1.0f / pt.z;
+  const float invz = have_invz ? invz_pre : rgb_row_invz(pt);
   const float dI_dx_val = (w * p.sobelScale) * (float)in.gx;
   const float dI_dy_val = (w * p.sobelScale) * (float)in.gy;
   const float v0 = (dI_dx_val * p.fx) * invz;

@@ -1097,6 +1097,18 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
         if (tid < kSE3) __hip_atomic_fetch_add(arw + tid, canon::pack_word(canon::to_units(p_icp, eb_icp)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    // what the photometric rows need that does not depend on sigma — the model pixel's cloud point, exactly as k_projectPoints
+    // builds it from lastDepth, and 1 / z — is taken while the count is in flight (the waves other than wave 0 only wait here)
+    f3 cpt[P];
+    float cinvz[P];
+    if (RGB) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float z = rm[p].d0;
+        cpt[p] = mk3((((float)c[p].zero_x - a.cx) * z) * invFx, (((float)c[p].zero_y - a.cy) * z) * invFy, z);
+        cinvz[p] = rgb_row_invz(cpt[p]);
+      }
+    }
     if (RGB) {
       if (tid < 64) {
         unsigned long long fld;
@@ -1131,13 +1143,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       p_.sobelScale = a.sobelScale;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        // the model pixel's cloud point, exactly as k_projectPoints builds it from lastDepth
         RgbRowIn in;
-        const float z = rm[p].d0;
-        in.pt = mk3((((float)c[p].zero_x - a.cx) * z) * invFx, (((float)c[p].zero_y - a.cy) * z) * invFy, z);
+        in.pt = cpt[p];
         in.gx = gx[p];
         in.gy = gy[p];
-        rgb_row_finish<kFma>(p_, c[p], in, rows[p]);
+        rgb_row_finish<kFma>(p_, c[p], in, rows[p], cinvz[p], true);
         found[p] = c[p].valid != 0;
       }
       if (ICP) {
