@@ -863,6 +863,8 @@ __device__ __forceinline__ unsigned long long pair_pack(unsigned long long v) { 
 // 121 / 122: the readers' fan-in per line is not what limits); a delay before the pair's poll (+0 - 3 us from 4 units on);
 // a block's chunks spread over the image instead of adjacent (no difference: the arrival spread is not a load imbalance);
 // 16 shards instead of 8 (no difference: 13 instead of 25 same-address atomics per word against twice the words to read).
+// Also without gain: the ICP rows computed after the count pair's arrival instead of before it (pass 1 -0.6 us per iteration,
+// the two waits +0.9: the pair's flight was already covered by the ICP wave sums).
 __device__ __forceinline__ void poll_pause(int n) {
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);  // 64 cycles each
 }
