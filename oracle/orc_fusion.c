@@ -143,6 +143,9 @@ static float uv_coord(int i, int n) { return (float)((double)((float)i / (float)
 void orc_depth_bilateral(const uint16_t* src, int rows, int cols, float maxD, uint16_t* dst) { /* depth_bilateral.frag:30-75 */
   const float colsf = (float)cols, rowsf = (float)rows;
   const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
+  /* (every output pixel is a function of the input image only: rows are independent, the thread count changes no bit;
+   * this filter was 60 % of the oracle's frame time on one thread) */
+#pragma omp parallel for schedule(static)
   for (int py = 0; py < rows; ++py)
     for (int px = 0; px < cols; ++px) {
       const unsigned value = src[(size_t)py * cols + px];
