@@ -555,8 +555,8 @@ def main():
             "one_core": {"value": fps_one, "unit": "frames/s", "cores": 1, "frames": n_one},
             "host": {"nproc": nproc, "cpu_model": cpu_model()},
             "sample": "%d steady-state frames (after the bootstrap frame and the first tracked one) of the same synthetic stream in ~20 s, "
-                      "oracle/ C restatement of the reference algorithm (OpenMP on the per-pixel loops of the tracker with `cores` threads, the "
-                      "surfel-map half single-threaded), %dx%d; one_core: the same with 1 thread, ~8 s.  Reported baseline of a CPU "
+                      "oracle/ C restatement of the reference algorithm (OpenMP on the per-pixel loops of the tracker and of the depth filter with "
+                      "`cores` threads; the surfel-map passes replay sequential GL draws on one thread), %dx%d; one_core: the same with 1 thread, ~8 s.  Reported baseline of a CPU "
                       "restatement, non-target" % (n_all, W, H),
         }
 
