@@ -2011,7 +2011,7 @@ struct PersistChain {
 };
 static PersistChain g_persist;
 // DMS_PERSIST_UNCHAINED=1: the caller guarantees that the resident grids of all handles that may track at the same time fit the
-// device TOGETHER (DMS_PERSIST_MAX_BLOCKS of each, summed, <= compute units) — then every grid completes whatever the
+// device TOGETHER (DMS_PERSIST_MAX_BLOCKS of each, summed, <= compute units; a handle whose bound exceeds half the device stays chained) — then every grid completes whatever the
 // interleaving and no section has to wait for another camera's.  Read once.
 static bool unchained() {
   static const bool u = [] {
@@ -2024,9 +2024,18 @@ struct PersistSection {
   hipStream_t s;
   int dev = 0;
   bool active = false;
-  explicit PersistSection(hipStream_t s_) : s(s_) {}
+  int budget;  // largest resident grid of the handle this section belongs to
+  PersistSection(hipStream_t s_, int budget_) : s(s_), budget(budget_) {}
   void begin() {
-    if (active || unchained()) return;
+    if (active) return;
+    if (unchained()) {  // honoured only for handles that hold at most half the device: two of them always fit together
+      static const int cus = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess ? n : 0;
+      }();
+      if (budget > 0 && 2 * budget <= cus) return;
+    }
     g_persist.mu.lock();
     (void)hipGetDevice(&dev);
     dev &= 63;
@@ -2156,7 +2165,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
   }
 
-  PersistSection persist(s);
+  PersistSection persist(s, o->max_resident_blocks);
   if (so3) {
     const int L = 2;
     const Buf& li = o->lastNextImage[L];
