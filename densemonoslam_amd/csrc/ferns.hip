@@ -139,8 +139,15 @@ __global__ __launch_bounds__(256) void k_fern_search_batch(const unsigned char* 
                                                            const int* __restrict__ db_time, const int* __restrict__ n_dev,
                                                            const unsigned char* __restrict__ base, size_t stride, size_t codes_off,
                                                            size_t good_off, int skip, int time, int all_frames,
-                                                           unsigned long long* __restrict__ best) {
+                                                           unsigned long long* __restrict__ best, unsigned long long* __restrict__ prev = nullptr,
+                                                           unsigned long long* __restrict__ prev_out = nullptr) {
   const int q = blockIdx.y;
+  // pipelined callers (prev != null): the previous call's results live in the OTHER word set — one block per query hands them
+  // to mapped host memory and re-arms them for the next call, which searches into that set (no re-arm launch between two searches)
+  if (prev && blockIdx.x == 0 && threadIdx.x == 0) {
+    prev_out[q] = prev[q];
+    prev[q] = ~0ull;
+  }
   if (q == skip) return;
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -406,6 +413,10 @@ struct dms_ferns {
   volatile int* h_status = nullptr;
   int* d_status = nullptr;  // device view of h_status
   int adds_issued = 0;
+  // dms_ferns_search_blocks with a result mirror: the handle's alternate word set and the sequence it belongs to
+  unsigned long long* d_best_alt = nullptr;
+  int* pipe_best = nullptr;
+  int pipe_count = 0, pipe_calls = 0;
   bool publish_fused = true;  // dms_ferns_publish_block as one launch while the database is small (DMS_FERNS_PUBLISH_FUSED=0: four)
   hipEvent_t ev_last_add = nullptr;  // recorded after the last asynchronous add: what mirror() has to wait for
   bool ev_valid = false;
@@ -751,6 +762,7 @@ int dms_ferns_destroy(dms_ferns* f) {
   if (!f) return DMS_OK;
   if (f->rgbd_odom) dms_odometry_destroy(f->rgbd_odom);
   if (f->arena) (void)hipFree(f->arena);
+  if (f->d_best_alt) (void)hipFree(f->d_best_alt);
   if (f->h_status) (void)hipHostFree((void*)f->h_status);
   if (f->ev_last_add) (void)hipEventDestroy(f->ev_last_add);
   if (f->h_res) (void)hipHostFree(f->h_res);
@@ -909,6 +921,29 @@ int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride,
   hipStream_t s = (hipStream_t)st;
   if (previous_out) {
     DMS_REQUIRE(((uintptr_t)previous_out & 7) == 0, "8-byte aligned result mirror required");
+    // Two word sets alternate (the caller's and one of the handle's): this call searches into the set the previous call's
+    // kernel re-armed and hands the other set's results over inside the same launch.  The first call of a sequence (or a change of
+    // the caller's buffer / count) arms both the old way.
+    if (f->pipe_best == best2_dev && f->pipe_count == count && f->d_best_alt) {
+      unsigned long long* cur = (f->pipe_calls & 1) ? f->d_best_alt : (unsigned long long*)best2_dev;
+      unsigned long long* other = (f->pipe_calls & 1) ? (unsigned long long*)best2_dev : f->d_best_alt;
+      f->pipe_calls += 1;
+      const int nu = f->n_upper > 0 ? f->n_upper : 1;
+      hipLaunchKernelGGL(k_fern_search_batch, dim3((nu + 3) / 4, count), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n,
+                         (const unsigned char*)blocks_dev, stride, codes_offset, good_offset, skip, time, interMap ? 1 : 0, cur, other,
+                         (unsigned long long*)previous_out);
+      DMS_CHECK_LAUNCH();
+      return DMS_OK;
+    }
+    if (!f->d_best_alt || f->pipe_count != count) {
+      if (f->d_best_alt) (void)hipFree(f->d_best_alt);
+      f->d_best_alt = nullptr;
+      DMS_HIP(hipMalloc((void**)&f->d_best_alt, (size_t)count * 8));
+    }
+    DMS_HIP(hipMemsetAsync(f->d_best_alt, 0xFF, (size_t)count * 8, s));
+    f->pipe_best = best2_dev;
+    f->pipe_count = count;
+    f->pipe_calls = 1;  // this call searches into the caller's set (armed below); the next one into the handle's
     hipLaunchKernelGGL(k_fern_best_rearm, dim3((count + 63) / 64), dim3(64), 0, s, (unsigned long long*)best2_dev, count,
                        (unsigned long long*)previous_out);
     DMS_CHECK_LAUNCH();

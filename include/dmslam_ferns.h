@@ -104,7 +104,9 @@ int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const i
  * collaborative mode; block `skip` (the caller's own, or -1) is left out.  best2_dev: count x {candidate id or -1,
  * dissimilarity bits}.  previous_out (optional, device-accessible — e.g. mapped pinned host memory): receives what
  * best2_dev held on entry, i.e. the results of the previous call, before the words are re-armed; a caller that reads
- * its results one frame late gets them on the host without a copy on the frame's stream. */
+ * its results one frame late gets them on the host without a copy on the frame's stream.  With previous_out the results
+ * alternate between best2_dev and a word set of the handle's (the search kernel itself hands the previous call's set over and
+ * re-arms it: no launch between two searches), so best2_dev is scratch then: read the results from previous_out. */
 int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride, int count, int skip, size_t codes_offset,
                             size_t good_offset, int time, int interMap, int* best2_dev, int* previous_out, dms_stream s);
 

@@ -265,6 +265,15 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
     assert (prev.download(np.int32, (nb, 2)) == bn).all()
     bn2 = bestn.download(np.int32, (nb, 2))
     assert (np.delete(bn2, 2, 0) == np.delete(bn, 2, 0)).all() and bn2[2, 0] >= 0  # (nothing skipped this time)
+    # a pipelined sequence: from the second call on the search kernel itself hands the previous call's results over and re-arms them
+    # (two alternating word sets, no launch between two searches); every call's mirror must hold the call before it
+    expect = bn2
+    chk = DeviceBuffer(8 * nb)
+    for skip in (0, 3, -1, 1, 2):
+        ga.searchBlocks(allb.ptr, stride, nb, skip, T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, bestn.ptr, previous_out=prev.ptr)
+        assert (prev.download(np.int32, (nb, 2)) == expect).all(), skip
+        ga.searchBlocks(allb.ptr, stride, nb, skip, T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, chk.ptr)  # the plain form of the same search
+        expect = chk.download(np.int32, (nb, 2))
     ga.close()
     gs.close()
     ef.close()
