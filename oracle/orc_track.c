@@ -8,13 +8,16 @@
  *   elasticfusion/Core/src/Utils/OdometryProvider.h:35-93 (Rodrigues, SE3 update)
  * Each function cites the lines it follows.
  *
- * PARITY UNPINNED: the reference holds no golden vectors, known-answer tests or numeric
- * fixtures for this path (its only harness, GPUTest/src/GPUTest.cpp:146-332, asserts
- * nothing), and it cannot be built here (CUDA + OpenGL + Eigen + Pangolin are absent and may
- * not be stubbed).  The oracle is therefore anchored on (i) the reference's input fixture
- * (the GPUTest RGB-D PNG pair, committed as tests/golden/gputest_pair.npz) run through the
- * harness protocol of GPUTest.cpp:247-286, (ii) analytic properties (synthetic scenes with a
- * known camera motion, finite-difference checks of the Jacobian rows) — see tests/.
+ * PARITY: the reduction steps (icpStep, computeRgbResidual, rgbStep, so3Step: reduce.cu:235-1103) are PINNED to the
+ * reference's own kernels: oracle/ref_build.sh compiles the reference's reduce.cu for gfx950, tests/golden/ref_reduce.npz
+ * holds what it returned on an MI355X, tests/test_ref_pin_cpu.py holds this file to it (per-pixel rows and every
+ * correspondence bit for bit, whole-image sums to summation-order tolerance).  Everything else here is PARITY UNPINNED:
+ * the reference holds no golden vectors, known-answer tests or numeric fixtures for this path (its only harness,
+ * GPUTest/src/GPUTest.cpp:146-332, asserts nothing); cudafuncs.cu does not compile from its own sources on this image
+ * (legacy texture reference; see ref_build.sh) and the host loop needs Eigen.  Those parts are anchored on (i) the
+ * reference's input fixture (the GPUTest RGB-D PNG pair, committed as tests/golden/gputest_pair.npz) run through the
+ * harness protocol of GPUTest.cpp:247-286, (ii) analytic properties (synthetic scenes with a known camera motion,
+ * finite-difference checks of the Jacobian rows) — see tests/.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *

@@ -1,0 +1,115 @@
+// Test infrastructure, compiled only by oracle/ref_build.sh into oracle/_ref/libref_reduce.so.
+//
+// extern "C" wrappers around the REFERENCE's tracking steps (elasticfusion/Core/src/Cuda/cudafuncs.cuh:70-117:
+// icpStep, rgbStep, so3Step, computeRgbResidual), so that a Python script on the GPU box can run the reference's own
+// kernels on host arrays and record what they return.  Everything that computes is the reference's; this file only moves
+// bytes: host array -> the reference's DeviceArray2D (containers/device_array.hpp:194-206) -> the reference's function with
+// the argument list RGBDOdometry.cpp:443-539 uses -> host.  Scratch buffers are sized as RGBDOdometry.cpp:44-49 sizes them.
+#include <cstdint>
+#include <cstring>
+
+#include "cudafuncs.cuh"
+
+namespace {
+template <class T>
+void up(DeviceArray2D<T>& d, const void* host, int rows, int cols) {
+  d.upload(host, (size_t)cols * sizeof(T), rows, cols);
+}
+mat33 m33(const float* p) {
+  mat33 m;
+  std::memcpy(&m.data[0], p, sizeof(mat33));
+  return m;
+}
+float3 f3(const float* p) {
+  float3 v = {p[0], p[1], p[2]};
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+int ref_sizes(int* out4) {
+  out4[0] = (int)sizeof(JtJJtrSE3);
+  out4[1] = (int)sizeof(JtJJtrSO3);
+  out4[2] = (int)sizeof(DataTerm);
+  out4[3] = (int)sizeof(mat33);
+  return 0;
+}
+
+// vmap / nmap: 3 planes stacked along rows (3*rows x cols floats), RGBDOdometry.cpp:97-101
+int ref_icpStep(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
+                const float* tprev, const float* cam4, const float* vmap_g_prev, const float* nmap_g_prev, int rows, int cols,
+                float distThres, float angleThres, int threads, int blocks, float* A36, float* b6, float* residual2) {
+  DeviceArray2D<float> vc, nc, vp, np_;
+  up(vc, vmap_curr, rows * 3, cols);
+  up(nc, nmap_curr, rows * 3, cols);
+  up(vp, vmap_g_prev, rows * 3, cols);
+  up(np_, nmap_g_prev, rows * 3, cols);
+  DeviceArray<JtJJtrSE3> sum, out;
+  sum.create(1024);
+  out.create(1);
+  CameraModel intr(cam4[0], cam4[1], cam4[2], cam4[3]);
+  icpStep(m33(Rcurr), f3(tcurr), vc, nc, m33(Rprev_inv), f3(tprev), intr, vp, np_, distThres, angleThres, sum, out, A36, b6,
+          residual2, threads, blocks);
+  return 0;
+}
+
+// corres_out: rows*cols DataTerm records as the kernel wrote them (linear index k = y*cols + x, reduce.cu:838)
+int ref_computeRgbResidual(float minScale, const short* dIdx, const short* dIdy, const float* lastDepth, const float* nextDepth,
+                           const unsigned char* lastImage, const unsigned char* nextImage, int rows, int cols,
+                           float maxDepthDelta, const float* kt3, const float* krkinv9, int threads, int blocks,
+                           void* corres_out, int* sigmaSum, int* count) {
+  DeviceArray2D<short> dx, dy;
+  DeviceArray2D<float> ld, nd;
+  DeviceArray2D<unsigned char> li, ni;
+  up(dx, dIdx, rows, cols);
+  up(dy, dIdy, rows, cols);
+  up(ld, lastDepth, rows, cols);
+  up(nd, nextDepth, rows, cols);
+  up(li, lastImage, rows, cols);
+  up(ni, nextImage, rows, cols);
+  DeviceArray2D<DataTerm> corres;
+  corres.create(rows, cols);
+  if (corres.step() != (size_t)cols * sizeof(DataTerm)) return -2;  // the kernel indexes it linearly
+  DeviceArray<int2> sumResidual;
+  sumResidual.create(1024);
+  int s = 0, c = 0;
+  computeRgbResidual(minScale, dx, dy, ld, nd, li, ni, corres, sumResidual, maxDepthDelta, f3(kt3), m33(krkinv9), s, c, threads,
+                     blocks);
+  corres.download(corres_out, (size_t)cols * sizeof(DataTerm));
+  *sigmaSum = s;
+  *count = c;
+  return 0;
+}
+
+// corres: rows*cols DataTerm records (as returned above); cloud: rows x cols float3
+int ref_rgbStep(const void* corres_in, float sigma, const float* cloud3, float fx, float fy, const short* dIdx, const short* dIdy,
+                float sobelScale, int rows, int cols, int threads, int blocks, float* A36, float* b6) {
+  DeviceArray2D<DataTerm> corres;
+  up(corres, corres_in, rows, cols);
+  if (corres.step() != (size_t)cols * sizeof(DataTerm)) return -2;
+  DeviceArray2D<float3> cloud;
+  up(cloud, cloud3, rows, cols);
+  DeviceArray2D<short> dx, dy;
+  up(dx, dIdx, rows, cols);
+  up(dy, dIdy, rows, cols);
+  DeviceArray<JtJJtrSE3> sum, out;
+  sum.create(1024);
+  out.create(1);
+  rgbStep(corres, sigma, cloud, fx, fy, dx, dy, sobelScale, sum, out, A36, b6, threads, blocks);
+  return 0;
+}
+
+int ref_so3Step(const unsigned char* lastImage, const unsigned char* nextImage, const float* imageBasis9, const float* kinv9,
+                const float* krlr9, int rows, int cols, int threads, int blocks, float* A9, float* b3, float* residual2) {
+  DeviceArray2D<unsigned char> li, ni;
+  up(li, lastImage, rows, cols);
+  up(ni, nextImage, rows, cols);
+  DeviceArray<JtJJtrSO3> sum, out;
+  sum.create(1024);
+  out.create(1);
+  so3Step(li, ni, m33(imageBasis9), m33(kinv9), m33(krlr9), sum, out, A9, b3, residual2, threads, blocks);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+"""The CPU restatement of the tracking steps (oracle/orc_track.c) held to the REFERENCE's own kernels.
+
+tests/golden/ref_reduce.npz holds what elasticfusion/Core/src/Cuda/reduce.cu itself returned on an MI355X (built from the
+reference's sources by oracle/ref_build.sh, recorded by tests/golden/make_ref_reduce_golden.py) for the cases of
+tests/ref_cases.py.  SURVEY 8 rows a2 (icpStep), a3 (computeRgbResidual), a4 (rgbStep), a5 (so3Step), a15 (types)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import ref_cases
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_reduce.npz")
+# whole-image float sums: the reference adds fp32 partials in its launch order, the restatement in fp64; observed <= 1.5e-6
+SUM_RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def golden():
+    z = np.load(GOLDEN)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def ours(orc, gputest_pair, golden):
+    assert orc.lib.orc_get_fused_rows() == 0  # the source's arithmetic, operation by operation (no contraction)
+    lv = ref_cases.inputs(orc, gputest_pair)
+    for k, v in ref_cases.input_hashes(lv).items():
+        assert str(v) == str(golden[k]), "the restatement is not being fed what the reference saw: " + k
+    return ref_cases.run(orc, lv, rows_from=golden)
+
+
+def _sum_close(a, b, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= SUM_RTOL, "%s: max |d| / max |ref| = %.3e" % (what, err)
+
+
+def test_fixture_is_the_references_output(golden):
+    assert "reduce.cu" in str(golden["meta"]) and "MI355X" in str(golden["meta"])
+    assert golden["icp_rows"].shape == (ref_cases.N_ICP_ROWS, 29)
+    assert golden["rgb_rows_S0"].shape == (ref_cases.N_RGB_ROWS, 27)
+
+
+def test_single_pixel_rows_bit_exact(ours, golden):
+    """One pixel alone in the image: the reference's sums are that pixel's 27 products, residual and inlier flag."""
+    for k in ("icp_rows", "rgb_rows_S0", "rgb_rows_S1"):
+        assert ours[k].dtype == golden[k].dtype == np.float32
+        assert np.array_equal(ours[k].view(np.uint32), golden[k].view(np.uint32)), k
+    assert golden["icp_rows"][:, 28].sum() >= 0.5 * ref_cases.N_ICP_ROWS  # most chosen pixels do find a correspondence
+    assert (np.abs(golden["rgb_rows_S0"]).sum(1) > 0).all()
+
+
+def test_photometric_correspondences_exact(ours, golden):
+    """Every DataTerm field of every pixel and both integer sums, three levels, three relative motions."""
+    n = 0
+    for lvl in range(3):
+        for p in range(len(ref_cases.POSES)):
+            key = "rgbres_L%d_P%d" % (lvl, p)
+            assert (ours[key + "_sums"] == golden[key + "_sums"]).all(), key
+            assert (ours[key + "_valid"] == golden[key + "_valid"]).all(), key
+            assert str(ours[key + "_sha"]) == str(golden[key + "_sha"]), key
+            n += int(golden[key + "_sums"][1])
+    for p in range(len(ref_cases.POSES)):
+        a, b = ours["rgbres_L2_P%d_corres" % p], golden["rgbres_L2_P%d_corres" % p]
+        for f in a.dtype.names:
+            assert (a[f] == b[f]).all(), (p, f)
+    assert n > 100000
+
+
+def test_whole_image_sums(ours, golden):
+    for k in golden:
+        if k.startswith("icp_L"):
+            assert ours[k][28] == golden[k][28] > 1000, "inlier count " + k
+            _sum_close(ours[k][:28], golden[k][:28], k)
+        elif k.startswith("rgb_L"):
+            _sum_close(ours[k], golden[k], k)
+        elif k.startswith("so3_L"):
+            assert ours[k][10] == golden[k][10] > 1000, "so3 count " + k
+            _sum_close(ours[k][:10], golden[k][:10], k)
