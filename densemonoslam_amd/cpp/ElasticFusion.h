@@ -2,7 +2,9 @@
 //
 //   class ElasticFusion  (Core/src/ElasticFusion.h:63-389)  constructor with the reference's 22 parameters (:69-82),
 //                        frontend(name) (:315), processFrame with the reference's TEN parameters (:92-100), applyGlobalLoop
-//                        (:110), predict (:107), getGlobalModel (:122)
+//                        (:110), getGlobalModel (:122), the GUI-driven setters (:168-226: setRgbOnly, setIcpWeight, setPyramid,
+//                        setFastOdom, setSo3, setFrameToFrameRGB, setConfidenceThreshold, setDepthCutoff) and the end-of-run
+//                        exports savePly / saveTrajectories / saveStats / saveTimes (:280-290)
 //   class Context        (Core/src/Context.h:25-378)         one camera ("a SLAM frontend"): owns the dms_fusion of that camera;
 //                        id(), rgbOnly(), currPose(), tick(), lost(), numFused()
 //   Resolution / Intrinsics (Core/src/Utils/Resolution.h, Intrinsics.h)  the singletons the front end fills before it
@@ -21,6 +23,7 @@
 // rf.globalDeformation().constrain / rf.localDeformation().constrain (ElasticFusion.cpp:337, :481).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -110,6 +113,30 @@ class ContextT {
   int& numFused() { return m_numFused; }
   const std::string& filename() const { return m_file; }
   const dms_frame_result& lastResult() const { return last; }
+  // one (tick, pose) per processed frame and its time stamp (ElasticFusion.cpp:571-574)
+  std::vector<std::pair<unsigned long long int, Mat4>>& poseGraph() { return m_poseGraph; }
+  std::vector<int64_t>& poseLogTimes() { return m_poseLogTimes; }
+
+  // Context::saveTrajectory (Context.h:117-156): <dir><log name from its last '/'>.freiburg, one 3 x 4 matrix per line
+  void saveTrajectory(std::string dir) {
+    const size_t slash = m_file.find_last_of("/");
+    std::string fname = dir + (slash == std::string::npos ? m_file : m_file.substr(slash)) + ".freiburg";
+    std::vector<float> flat(m_poseGraph.size() * 16);
+    for (size_t i = 0; i < m_poseGraph.size(); ++i)
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) flat[i * 16 + r * 4 + c] = m_poseGraph[i].second(r, c);
+    check(dms_trajectory_save(fname.c_str(), flat.data(), m_poseGraph.size()), "saveTrajectory");
+  }
+  // Context::saveStats (Context.h:106-115) writes the front end's Stats object (ORB / depth-net bookkeeping, not on this
+  // path); here: the counters this camera has, one "name value" line each, in <dir><log name>.stats
+  void saveStats(std::string dir) {
+    const size_t slash = m_file.find_last_of("/");
+    std::string fname = dir + (slash == std::string::npos ? m_file : m_file.substr(slash + 1)) + ".stats";
+    FILE* fp = fopen(fname.c_str(), "w");
+    if (!fp) throw std::runtime_error("saveStats: cannot open " + fname);
+    fprintf(fp, "frames %zu\nfused %d\ntick %d\nlost %d\nsurfels %u\n", m_poseGraph.size(), m_numFused, m_tick, m_lost ? 1 : 0, last.surfels);
+    fclose(fp);
+  }
 
   dms_fusion* fusion = nullptr;  // created by the first processFrame (it needs ElasticFusion's parameters)
   void* rgb_dev = nullptr;
@@ -126,6 +153,8 @@ class ContextT {
   bool m_rgbOnly = false, m_lost = false;
   int m_tick = 1, m_numFused = 0;
   Mat4 m_currPose;
+  std::vector<std::pair<unsigned long long int, Mat4>> m_poseGraph;
+  std::vector<int64_t> m_poseLogTimes;
 };
 
 template <class Mat4>
@@ -144,13 +173,12 @@ class ElasticFusionT {
       : timeDelta(timeDelta), closeLoops(closeLoops), iclnuim(iclnuim), reloc(reloc), confidence(confidence), depthCut(depthCut),
         icpThresh(icpThresh), fastOdom(fastOdom), so3(so3), frameToFrameRGB(frameToFrameRGB), scheme(sampling_scheme),
         nid_threshold(nid_threshold), nidDepthLambda(nidDepthLambda), bins_depth(num_bins_depth), bins_img(num_bins_img),
-        nid_level(m_nid_pyramid_level) {
+        nid_level(m_nid_pyramid_level), saveFilename(fileName) {
     (void)countThresh;  // icpCountThresh / icpErrThresh / covThresh are the thresholds of the local-loop acceptance test, fixed at the
     (void)errThresh;    // values ElasticFusion.cpp:428-442 hard-codes; photoThresh / fernThresh belong to the fern database
     (void)covThresh;    // (dms::Ferns), whose call sites this fork compiles out (:279, :589, :597)
     (void)photoThresh;
     (void)fernThresh;
-    (void)fileName;
   }
   virtual ~ElasticFusionT() {}
 
@@ -182,8 +210,8 @@ class ElasticFusionT {
   void processFrame(const std::shared_ptr<unsigned char>& rgb, const std::shared_ptr<unsigned short>& depth, const int64_t& timestamp,
                     Context& context, const Mat4* inPose = 0, const Mat4* orbTcwOld = 0, const Mat4* orbTcwNew = 0, const int cluster = 0,
                     const float weightMultiplier = 1.f, const bool bootstrap = false) {
-    (void)timestamp;
     (void)bootstrap;
+    const int tick_before = context.tick();
     if (cluster != 0) throw std::runtime_error("processFrame: only cluster 0 is implemented (one surfel store per ElasticFusion)");
     ensure(context);
     const int W = Resolution::getInstance().width(), H = Resolution::getInstance().height();
@@ -237,6 +265,9 @@ class ElasticFusionT {
             "processFrame");
     }
     refresh(context);
+    // :571-574 (the tick the frame was processed at; the pose after tracking / loop closure)
+    context.poseGraph().push_back(std::pair<unsigned long long int, Mat4>((unsigned long long int)tick_before, context.currPose()));
+    context.poseLogTimes().push_back(timestamp);
   }
 
   // ElasticFusion::applyGlobalLoop (ElasticFusion.h:110, ElasticFusion.cpp:1148-1240)
@@ -263,11 +294,69 @@ class ElasticFusionT {
   }
   const int& getTimeDelta() const { return timeDelta; }
   const float& getConfidenceThreshold() const { return confidence; }
+  const float& getMaxDepthProcessed() const { return FrontEndOptions::get().maxDepthProcessed; }
+
+  // the GUI-driven setters (ElasticFusion.h:168-226, ElasticFusion.cpp:1023-1043; MainController.cpp:760-775 calls them every
+  // frame): they take effect with the next processFrame of every camera
+  void setRgbOnly(const bool& val) { rgbOnly = val; push(DMS_OPT_RGB_ONLY, val); }
+  void setIcpWeight(const float& val) { icpThresh = val; push(DMS_OPT_ICP_WEIGHT, val); }
+  void setPyramid(const bool& val) { FrontEndOptions::get().pyramid = val; push(DMS_OPT_PYRAMID, val); }
+  void setFastOdom(const bool& val) { fastOdom = val; push(DMS_OPT_FAST_ODOM, val); }
+  void setSo3(const bool& val) { so3 = val; push(DMS_OPT_SO3, val); }
+  void setFrameToFrameRGB(const bool& val) { frameToFrameRGB = val; push(DMS_OPT_FRAME_TO_FRAME_RGB, val); }
+  void setConfidenceThreshold(const float& val) { confidence = val; push(DMS_OPT_CONFIDENCE, val); }
+  void setDepthCutoff(const float& val) { depthCut = val; push(DMS_OPT_DEPTH_CUTOFF, val); }
+  void setFernThresh(const float&) {}  // the fern relocaliser's call sites are compiled out in this fork (:279, :589)
+
+  // End-of-run exports (MainController.cpp:806-809).
+  // savePly (ElasticFusion.cpp:781-885): one file per map, <dir><fileName>.<j>.<log name>.ply, j counting from 1; the
+  // reference's bytes (dms_model_save_ply; `reference_normal_offset` = its stale + 18 read, see dmslam_fusion.h)
+  void savePly(std::string dir, bool reference_normal_offset = false) {
+    int j = 1;
+    for (auto& kv : m_contexts) {
+      Context& c = *kv.second;
+      if (!c.fusion) continue;
+      const std::string& name = c.filename();
+      const size_t slash = name.find_last_of("/");
+      const std::string refName = slash == std::string::npos ? name : name.substr(slash + 1);
+      const std::string filename = dir + saveFilename + "." + std::to_string(j++) + "." + refName + ".ply";
+      check(dms_model_save_ply(dms_fusion_model(c.fusion), filename.c_str(), confidence, reference_normal_offset ? 1 : 0, nullptr), "savePly");
+    }
+  }
+  void saveTrajectories(std::string dir) {  // :968-974
+    for (auto& kv : m_contexts) kv.second->saveTrajectory(dir);
+  }
+  void saveStats(std::string dir) {  // :887-891
+    for (auto& kv : m_contexts) kv.second->saveStats(dir);
+  }
+  // saveTimes (:893-966) dumps the reference's Stopwatch singleton (host wall-clock sections of the GUI loop, the ORB front
+  // end and the depth network: none of them on this path).  Here: the device-side stage times of every camera when
+  // profiling was switched on (dms_fusion_set_profiling), "camera<id><stage> total_ms launches" per line, in <dir><fileName>.timings
+  void saveTimes(std::string dir) {
+    const std::string fname = dir + saveFilename + ".timings";
+    FILE* fp = fopen(fname.c_str(), "w");
+    if (!fp) throw std::runtime_error("saveTimes: cannot open " + fname);
+    static const char* stages[] = {"ingest", "preprocess", "live_pyramids", "predict", "odom_init", "track", "index_map", "fuse", "clean", "host_wait"};
+    for (auto& kv : m_contexts) {
+      Context& c = *kv.second;
+      if (!c.fusion) continue;
+      for (const char* st : stages) {
+        double ms = 0.0;
+        int n = 0;
+        if (dms_fusion_get_kernel_time(c.fusion, st, &ms, &n) == 0) fprintf(fp, "camera%d%s %.6f %d\n", c.id(), st, ms, n);
+      }
+    }
+    fclose(fp);
+  }
 
  private:
   static void flat(const Mat4& m, float* o) {
     for (int r = 0; r < 4; ++r)
       for (int c = 0; c < 4; ++c) o[r * 4 + c] = m(r, c);
+  }
+  void push(int option, double value) {
+    for (auto& kv : m_contexts)
+      if (kv.second->fusion) check(dms_fusion_set_option(kv.second->fusion, option, value), "dms_fusion_set_option");
   }
   void ensure(Context& c) {
     if (c.fusion) return;
@@ -286,7 +375,7 @@ class ElasticFusionT {
     p.pyramid = o.pyramid;
     p.hybrid_tracking = o.hybrid_tracking;
     p.hybrid_loops = o.hybrid_loops;
-    p.rgbOnly = c.rgbOnly();
+    p.rgbOnly = c.rgbOnly() || rgbOnly;
     p.timeIdx = c.id();
     p.maxDepthProcessed = o.maxDepthProcessed;
     p.model_capacity = o.model_capacity;
@@ -313,11 +402,13 @@ class ElasticFusionT {
 
   const int timeDelta;
   const bool closeLoops, iclnuim, reloc;
-  const float confidence, depthCut, icpThresh;
-  const bool fastOdom, so3, frameToFrameRGB;
+  float confidence, depthCut, icpThresh;  // (changed by the setters below)
+  bool fastOdom, so3, frameToFrameRGB;
+  bool rgbOnly = false;  // ElasticFusion::setRgbOnly (:1023): every camera tracks photometrically only and fuses nothing
   const SamplingScheme scheme;
   const float nid_threshold, nidDepthLambda;
   const int bins_depth, bins_img, nid_level;
+  const std::string saveFilename;
   std::map<std::string, std::shared_ptr<Context>> m_contexts;
 };
 

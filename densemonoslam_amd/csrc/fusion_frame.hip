@@ -294,6 +294,8 @@ struct dms_fusion {
   float last_nid = 0.f;
   // between dms_fusion_process_frame_begin and _end
   bool in_frame = false, cur_bootstrap = false, cur_fuse_now = true;
+  int live_set = 0, lastnext_set = 0;  // ring sets of the previous frame's live pyramids and of its lastNextImage
+  bool prev_handed_on = false;         // the previous frame's tracker call ran with so3 (or was the first frame)
   // --rl bookkeeping (ElasticFusion.cpp:204-244)
   bool tracking_ok = true, lost = false;
   int tracking_count = 0;
@@ -816,7 +818,21 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   // overlaps the previous frame's tracking / fusion on the caller's stream.  Hazards: these sets
   // were last read by frame-2 (image set; ring set as lastNextImage), hence the wait on its
   // completion event.  With pipeline_ingest = 0 the same work is issued on the caller's stream.
-  const int k2 = (int)(f->frames % 2), k3 = (int)(f->frames % 3), k3prev = (int)((f->frames + 2) % 3);
+  // Which ring set holds lastNextImage: the reference hands this frame's intensity pyramid on to the next call only when the
+  // tracker ran with so3 (`if (so3) swap(lastNextImage[i], nextImage[i])`, RGBDOdometry.cpp:594-600; the first frame's comes
+  // from initFirstRGB, ElasticFusion.cpp:151) — with the GUI's so3 switch off for a while (dms_fusion_set_option) the SO3
+  // pre-alignment of the frame that turns it on again compares against the last pyramid that WAS handed on.  In flight are the
+  // previous frame's live set and its lastNextImage set; this frame takes the third.  With so3 always on: sets t % 3.
+  const int k2 = (int)(f->frames % 2);
+  int k3 = 0, k3prev = 0;
+  if (f->frames > 0) {
+    k3prev = f->prev_handed_on ? f->live_set : f->lastnext_set;
+    k3 = 0;
+    while (k3 == f->live_set || k3 == f->lastnext_set) ++k3;
+  }
+  f->live_set = k3;
+  f->lastnext_set = k3prev;
+  f->prev_handed_on = false;  // set where the tracker is enqueued / the first frame is initialised
   hipStream_t sp = f->p.pipeline_ingest ? f->s_prep : s;
   if (f->p.pipeline_ingest) {
     // The ingest below reads rgb_dev / depth_dev on the prep stream.  Inputs produced asynchronously (an async upload, a
@@ -952,6 +968,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
     }
     // initFirstRGB (ElasticFusion.cpp:151): the intensity pyramid of this frame already sits in ring set 0
     f->map_initialised = true;
+    f->prev_handed_on = true;
   } else {
     if (inPose16) {  // without a prior the pose block is already consistent: the previous frame left lastPose = pose and its inverse
       hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, f->state, prior, 1);
@@ -979,6 +996,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
         if ((rc = odometry_track_enqueue(f->odom, nullptr, nullptr, f->state->cur.pose, f->p.rgbOnly, f->p.icpWeight, f->p.pyramid,
                                          f->p.fastOdom, f->p.so3, 0, s, f->state, weightMultiplier)))
           return rc;
+        f->prev_handed_on = f->p.so3 != 0;
         // (the tracker's finalize kernel writes the new pose straight back into f->state->cur.pose)
       }
       if (f->p.reloc) {  // ElasticFusion.cpp:204-244; lastFrameRecovery is only ever set by the compiled-out fern block
@@ -1384,6 +1402,50 @@ int dms_fusion_set_profiling(dms_fusion* f, int enabled) {
   DMS_REQUIRE(f, "null argument");
   f->profiling = enabled != 0;
   if (enabled) f->times.clear();
+  return DMS_OK;
+}
+
+// ElasticFusion.cpp:1023-1043 (the reference's setters write members that processFrame reads on the next frame)
+int dms_fusion_set_option(dms_fusion* f, int option, double value) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(option >= 0 && option < DMS_OPT_COUNT, "unknown option");
+  if (f->in_frame || f->in_global_loop) {
+    ::dms::set_error("dms_fusion_set_option: inside a frame");
+    return DMS_ERR_STATE;
+  }
+  const int on = value != 0.0 ? 1 : 0;
+  switch (option) {
+    case DMS_OPT_RGB_ONLY: f->p.rgbOnly = on; break;
+    case DMS_OPT_ICP_WEIGHT: f->p.icpWeight = (float)value; break;
+    case DMS_OPT_PYRAMID: f->p.pyramid = on; break;
+    case DMS_OPT_FAST_ODOM: f->p.fastOdom = on; break;
+    case DMS_OPT_SO3: f->p.so3 = on; break;
+    case DMS_OPT_FRAME_TO_FRAME_RGB: f->p.frameToFrameRGB = on; break;
+    case DMS_OPT_CONFIDENCE:
+      DMS_REQUIRE(value == value, "confidence threshold is NaN");
+      f->p.confidence = (float)value;
+      break;
+    case DMS_OPT_DEPTH_CUTOFF:
+      DMS_REQUIRE(value > 0.0, "depth cut-off must be positive");
+      f->p.depthCut = (float)value;
+      break;
+  }
+  return DMS_OK;
+}
+
+int dms_fusion_get_option(dms_fusion* f, int option, double* value) {
+  DMS_REQUIRE(f && value, "null argument");
+  DMS_REQUIRE(option >= 0 && option < DMS_OPT_COUNT, "unknown option");
+  switch (option) {
+    case DMS_OPT_RGB_ONLY: *value = f->p.rgbOnly; break;
+    case DMS_OPT_ICP_WEIGHT: *value = f->p.icpWeight; break;
+    case DMS_OPT_PYRAMID: *value = f->p.pyramid; break;
+    case DMS_OPT_FAST_ODOM: *value = f->p.fastOdom; break;
+    case DMS_OPT_SO3: *value = f->p.so3; break;
+    case DMS_OPT_FRAME_TO_FRAME_RGB: *value = f->p.frameToFrameRGB; break;
+    case DMS_OPT_CONFIDENCE: *value = f->p.confidence; break;
+    case DMS_OPT_DEPTH_CUTOFF: *value = f->p.depthCut; break;
+  }
   return DMS_OK;
 }
 

@@ -5,6 +5,7 @@ Names follow the reference: `GlobalModel` (Core/src/GlobalModel.h:43-141), `Inde
 All work happens on the GPU inside libdmslam_hip.so; numpy only crosses at upload / download.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -242,6 +243,13 @@ class GlobalModel:
         got = C.c_uint(0)
         check(lib.dms_model_download_ref(self.h, out.ctypes.data_as(C.c_void_p), n, C.byref(got), None), "dms_model_download_ref")
         return out[:got.value].copy()
+
+    def savePly(self, path, confidenceThreshold, reference_offsets=False):
+        """ElasticFusion::savePly for this map (ElasticFusion.cpp:781-885); returns the number of vertices written."""
+        n = C.c_uint(0)
+        check(lib.dms_model_save_ply(self.h, os.fsencode(path), C.c_float(confidenceThreshold), int(bool(reference_offsets)), C.byref(n)),
+              "dms_model_save_ply")
+        return n.value
 
     # -- map merge (GlobalModel::consume) ----------------------------------------------------
     @staticmethod
@@ -506,6 +514,17 @@ class ElasticFusion:
         check(lib.dms_fusion_get_loop_constraints(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)),
               "dms_fusion_get_loop_constraints")
         return out[:n.value].copy()
+
+    OPTIONS = {"rgbOnly": 0, "icpWeight": 1, "pyramid": 2, "fastOdom": 3, "so3": 4, "frameToFrameRGB": 5, "confidence": 6, "depthCut": 7}
+
+    def setOption(self, name, value):
+        """The reference's run-time setters (ElasticFusion.cpp:1023-1043): setRgbOnly, setIcpWeight, setPyramid, ..."""
+        check(lib.dms_fusion_set_option(self.h, self.OPTIONS[name], C.c_double(float(value))), "dms_fusion_set_option")
+
+    def getOption(self, name):
+        v = C.c_double(0.0)
+        check(lib.dms_fusion_get_option(self.h, self.OPTIONS[name], C.byref(v)), "dms_fusion_get_option")
+        return v.value
 
     def set_profiling(self, on):
         check(lib.dms_fusion_set_profiling(self.h, int(on)))

@@ -346,6 +346,37 @@ int dms_fusion_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev
  * {worldRawPoint xyz, worldModelPoint xyz, source time} = the arguments of
  * Deformation::addConstraint (:468-470).  Copies min(*n, max_rows) rows of 7 floats to host memory. */
 int dms_fusion_get_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n);
+/* Run-time setters of the reference's ElasticFusion (ElasticFusion.h:168-226, ElasticFusion.cpp:1023-1043): the GUI of the
+ * reference drives them every frame (MainController.cpp:760-775), and BASELINE config 2 ("single pyramid") is reachable through
+ * setPyramid only.  Takes effect with the next dms_fusion_process_frame; between frames only (DMS_ERR_STATE inside a
+ * begin / end pair).  (Nothing rendered ahead depends on them: the projection a frame shares with the next one's tracking
+ * prediction uses that prediction's fixed 0.7 threshold, ElasticFusion.cpp:165.) */
+enum {
+  DMS_OPT_RGB_ONLY = 0,            /* setRgbOnly            (bool)  */
+  DMS_OPT_ICP_WEIGHT = 1,          /* setIcpWeight          (float) */
+  DMS_OPT_PYRAMID = 2,             /* setPyramid            (bool)  */
+  DMS_OPT_FAST_ODOM = 3,           /* setFastOdom           (bool)  */
+  DMS_OPT_SO3 = 4,                 /* setSo3                (bool)  */
+  DMS_OPT_FRAME_TO_FRAME_RGB = 5,  /* setFrameToFrameRGB    (bool)  */
+  DMS_OPT_CONFIDENCE = 6,          /* setConfidenceThreshold(float) */
+  DMS_OPT_DEPTH_CUTOFF = 7,        /* setDepthCutoff        (float) */
+  DMS_OPT_COUNT = 8
+};
+int dms_fusion_set_option(dms_fusion* f, int option, double value);
+int dms_fusion_get_option(dms_fusion* f, int option, double* value);
+
+/* End-of-run exports of the reference (MainController.cpp:806-807), host side, byte for byte the reference's files:
+ * dms_model_save_ply = ElasticFusion::savePly (ElasticFusion.cpp:781-885) for one map: ASCII header, then per surfel with
+ * confidence > confidenceThreshold {x y z (float) r g b (uchar) -nx -ny -nz radius (float)}, little endian.  The reference
+ * reads the normal at float offset 18 of its 15-float record — a constant left over from MAX_SENSORS = 10 (Vertex.cpp:49,
+ * 8 + 10); with 3 sensors that is the NEXT record's {confidence, colour...} and, for the last surfel, beyond the buffer.
+ * reference_offsets = 0 (default use): the normal and radius of the surfel itself (offset 8 + MAX_SENSORS = 11);
+ * reference_offsets = 1: the reference's offset, zeros where it leaves the buffer.  Syncs. */
+int dms_model_save_ply(dms_model* m, const char* path, float confidenceThreshold, int reference_offsets, unsigned int* written);
+/* Context::saveTrajectory (Context.h:117-156): one line per pose, the 3 x 4 matrix row by row with the stream's default float
+ * formatting (6 significant digits) and a blank before the newline.  poses16_host: n row-major 4 x 4 camera-to-world matrices. */
+int dms_trajectory_save(const char* path, const float* poses16_host, size_t n);
+
 int dms_fusion_set_profiling(dms_fusion* f, int enabled);
 int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches);
 

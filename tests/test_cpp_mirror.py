@@ -132,8 +132,17 @@ int main(int argc, char** argv) {
   // MainController.cpp:203-214
   ElasticFusion* eFusion = new ElasticFusion(200, 35000, 5e-05, 1e-05, /*closeLoops*/ false, false, false, 115, /*confidence: the map is four frames old*/ 1, 3, 10, false, 0.3095, true,
                                              false, "model", ElasticFusion::SamplingScheme::NONE, 0.8f, 0.7f, 500, 64, 0);
-  Context& ctx = *(eFusion->frontend("camera0.klg"));
+  Context& ctx = *(eFusion->frontend("logs/camera0.klg"));
   ctx.rgbOnly() = false;
+  // the GUI-driven setters, as MainController.cpp:760-775 calls them every frame
+  eFusion->setRgbOnly(false);
+  eFusion->setPyramid(true);
+  eFusion->setFastOdom(false);
+  eFusion->setConfidenceThreshold(1.f);
+  eFusion->setDepthCutoff(3.f);
+  eFusion->setIcpWeight(10.f);
+  eFusion->setSo3(true);
+  eFusion->setFrameToFrameRGB(false);
   if (argc < 2) {  // CPU build check: everything above compiled and linked; nothing touches the device
     delete eFusion;
     return ctx.id() == 0 ? 0 : 2;
@@ -184,6 +193,23 @@ int main(int argc, char** argv) {
   eFusion->applyGlobalLoop(ctx, a, b);
   auto gm = eFusion->getGlobalModel(ctx);
   if (gm.lastCount() == 0) return 15;
+  // a run-time switch reaches the device: one pyramid level, three iterations (BASELINE config 2's tracker shape)
+  eFusion->setPyramid(false);
+  eFusion->setFastOdom(true);
+  {
+    Eigen::Matrix4f* prior = new Eigen::Matrix4f(ctx.currPose());
+    eFusion->processFrame(rgb, depth, 4000, ctx, prior, nullptr, nullptr, 0, 1.f, false);
+    delete prior;
+  }
+  if (ctx.lastResult().track.iterations_run[0] != 3 || ctx.lastResult().track.iterations_run[1] != 0) return 16;
+  if (ctx.poseGraph().size() != 5 || ctx.poseLogTimes().back() != 4000 || ctx.poseGraph().back().first != 5) return 17;
+  // MainController.cpp:806-809, verbatim but for the directory
+  const std::string outDirectory = argv[2];
+  eFusion->savePly(outDirectory);
+  eFusion->saveTrajectories(outDirectory);
+  eFusion->saveTimes(outDirectory);
+  eFusion->saveStats(outDirectory);
+  std::printf("surfels %u\n", ctx.lastResult().surfels);
   delete eFusion;
   return 0;
 }
@@ -216,5 +242,18 @@ def test_reference_outer_api_call_sites_compile_and_link():
 def test_reference_outer_api_runs_frames_and_an_orb_loop_closure():
     with tempfile.TemporaryDirectory() as td:
         exe = _build_adapter(td)
-        out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=300)
+        outdir = os.path.join(td, "out") + "/"
+        os.makedirs(outdir)
+        out = subprocess.run([exe, "run", outdir], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+        # the reference's file names (ElasticFusion.cpp:784-787, Context.h:106-121) and shapes
+        files = sorted(os.listdir(outdir))
+        assert files == ["camera0.klg.freiburg", "camera0.klg.stats", "model.1.camera0.klg.ply", "model.timings"], files
+        ply = open(os.path.join(outdir, "model.1.camera0.klg.ply"), "rb").read()
+        head, body = ply.split(b"end_header\n", 1)
+        n = int(head.split(b"element vertex ")[1].split(b"\n")[0])
+        surfels = int(out.stdout.strip().splitlines()[-1].split()[1])
+        assert 0 < n <= surfels and len(body) == 31 * n
+        traj = open(os.path.join(outdir, "camera0.klg.freiburg")).read().splitlines()
+        assert len(traj) == 5 and all(len(line.split()) == 12 and line.endswith(" ") for line in traj)
+        assert traj[0].split()[:4] == ["1", "0", "0", "0"]

@@ -1608,3 +1608,60 @@ print("UNCHAINED_OK")
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "UNCHAINED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_runtime_setters_and_exports_match_the_oracle(fus, orc, synth, tmp_path):
+    """The reference's GUI-driven setters (ElasticFusion.cpp:1023-1043 through dms_fusion_set_option) change the frame step
+    between frames — BASELINE config 2's single pyramid level is reachable through setPyramid only — and the end-of-run
+    exports (savePly, saveTrajectory) write the reference's files.  Free-running on both sides: the poses and the map stay
+    bit-identical across the switches, and so are the exported bytes."""
+    from oracle import orc_export, orc_pipeline
+
+    g = fus.ElasticFusion(W, H, K, model_capacity=600000, confidence=2.0)
+    o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=600000, confidence=2.0)
+    switches = {
+        2: dict(pyramid=False, fastOdom=True, icpWeight=100.0, so3=False),  # config 2: {3, 0, 0} ICP-only iterations
+        4: dict(pyramid=True, fastOdom=False, icpWeight=10.0, so3=True, confidence=1.0, depthCut=2.5),
+        6: dict(frameToFrameRGB=True),
+        7: dict(rgbOnly=True),
+    }
+    poses = []
+    for k in range(8):
+        for name, v in switches.get(k, {}).items():
+            g.setOption(name, v)
+            assert g.getOption(name) == pytest.approx(float(v))
+            setattr(o, name, v)
+        d, rgb, _ = synth.frame(k, width=W, height=H, K=K, noise=True)
+        rg = g.processFrame(rgb, d)
+        ro = o.processFrame(rgb, d)
+        pose_g = np.array(rg.pose, np.float32).reshape(4, 4)
+        helpers.assert_pose_identical(pose_g[:3, 3], pose_g[:3, :3], ro.pose[:3, 3], ro.pose[:3, :3], what="frame %d" % k)
+        assert bool(rg.fused) == ro.fused and rg.tick == ro.tick and rg.surfels == ro.surfels, k
+        if k > 0:
+            assert list(rg.track.iterations_run) == list(ro.track.iterations_run), k
+            assert rg.track.so3_iterations_run == ro.track.so3_iterations_run, k
+        if k in (2, 3):
+            assert list(rg.track.iterations_run) == [3, 0, 0] and rg.track.lastRGBCount == 0
+        poses.append(pose_g)
+    assert not rg.fused  # setRgbOnly: tracked, not fused
+    mg = g.globalModel().downloadMap()
+    surfels_equal(mg, o.model, "map after the switches")
+    # savePly: the reference's bytes for this map, with the surfel's own normal and with the reference's stale offset
+    for ref_off in (False, True):
+        path = str(tmp_path / ("map%d.ply" % ref_off))
+        n = g.globalModel().savePly(path, 1.0, reference_offsets=ref_off)
+        want = orc_export.save_ply_bytes(orc_export.ref_records(o.model), 1.0, reference_offsets=ref_off)
+        got = open(path, "rb").read()
+        assert got == want, "ply (reference_offsets=%s): %d vs %d bytes" % (ref_off, len(got), len(want))
+        assert 0 < n < len(mg) and ("element vertex %d\n" % n).encode() in got[:200]
+    # inside a begin / end pair the setters refuse
+    g2 = fus.ElasticFusion(W, H, K, model_capacity=600000, local_loop_closure=1)
+    d, rgb, _ = synth.frame(0, width=W, height=H, K=K, noise=True)
+    g2.processFrame(rgb, d)
+    g2.processFrameBegin(rgb, d)
+    with pytest.raises(Exception):
+        g2.setOption("pyramid", 0)
+    g2.processFrameEnd()
+    g2.setOption("pyramid", 0)
+    g2.close()
+    g.close()
