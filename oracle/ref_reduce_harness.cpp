@@ -5,6 +5,8 @@
 // kernels on host arrays and record what they return.  Everything that computes is the reference's; this file only moves
 // bytes: host array -> the reference's DeviceArray2D (containers/device_array.hpp:194-206) -> the reference's function with
 // the argument list RGBDOdometry.cpp:443-539 uses -> host.  Scratch buffers are sized as RGBDOdometry.cpp:44-49 sizes them.
+#include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 
@@ -109,6 +111,70 @@ int ref_so3Step(const unsigned char* lastImage, const unsigned char* nextImage, 
   sum.create(1024);
   out.create(1);
   so3Step(li, ni, m33(imageBasis9), m33(kinv9), m33(krlr9), sum, out, A9, b3, residual2, threads, blocks);
+  return 0;
+}
+
+// Timing of the reference's Gauss-Newton inner loop as RGBDOdometry.cpp:425-541 runs it: per iteration computeRgbResidual,
+// icpStep, rgbStep, each with its own launches, device synchronisation and download (that is how the reference's functions
+// are written); inputs uploaded once, host clock around `iters` iterations (the host-side Eigen solve between them is not
+// included: Eigen is not in this image).  so3_iters > 0 times so3Step alone the same way.  Returns microseconds per iteration.
+int ref_time_iterations(float minScale, const short* dIdx, const short* dIdy, const float* lastDepth, const float* nextDepth,
+                        const unsigned char* lastImage, const unsigned char* nextImage, const float* cloud3, const float* vmap_curr,
+                        const float* nmap_curr, const float* vmap_g_prev, const float* nmap_g_prev, int rows, int cols,
+                        const float* cam4, const float* kt3, const float* krkinv9, int iters, int so3_iters, double* us_gn,
+                        double* us_so3) {
+  DeviceArray2D<short> dx, dy;
+  DeviceArray2D<float> ld, nd, vc, nc, vp, np_;
+  DeviceArray2D<unsigned char> li, ni;
+  DeviceArray2D<float3> cloud;
+  up(dx, dIdx, rows, cols);
+  up(dy, dIdy, rows, cols);
+  up(ld, lastDepth, rows, cols);
+  up(nd, nextDepth, rows, cols);
+  up(li, lastImage, rows, cols);
+  up(ni, nextImage, rows, cols);
+  up(cloud, cloud3, rows, cols);
+  up(vc, vmap_curr, rows * 3, cols);
+  up(nc, nmap_curr, rows * 3, cols);
+  up(vp, vmap_g_prev, rows * 3, cols);
+  up(np_, nmap_g_prev, rows * 3, cols);
+  DeviceArray2D<DataTerm> corres;
+  corres.create(rows, cols);
+  DeviceArray<int2> sumResidual;
+  sumResidual.create(1024);
+  DeviceArray<JtJJtrSE3> sum, out;
+  sum.create(1024);
+  out.create(1);
+  DeviceArray<JtJJtrSO3> sum3, out3;
+  sum3.create(1024);
+  out3.create(1);
+  CameraModel intr(cam4[0], cam4[1], cam4[2], cam4[3]);
+  const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+  float A[36], b[6], res[2], A3[9], b3[3];
+  int s = 0, c = 0;
+  for (int warm = 0; warm < 2; ++warm) {
+    const int n = warm ? iters : 3;
+    hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {
+      computeRgbResidual(minScale, dx, dy, ld, nd, li, ni, corres, sumResidual, 0.07f, f3(kt3), m33(krkinv9), s, c, 256, 336);
+      icpStep(m33(I9), f3(z3), vc, nc, m33(I9), f3(z3), intr, vp, np_, 0.10f, 0.342f, sum, out, A, b, res, 128, 112);
+      rgbStep(corres, sqrtf((float)(c > 0 ? c : 1)), cloud, intr.fx, intr.fy, dx, dy, 0.125f, sum, out, A, b, 128, 112);
+    }
+    hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    *us_gn = std::chrono::duration<double, std::micro>(t1 - t0).count() / n;
+  }
+  *us_so3 = 0.0;
+  for (int warm = 0; warm < 2 && so3_iters > 0; ++warm) {
+    const int n = warm ? so3_iters : 3;
+    hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) so3Step(li, ni, m33(krkinv9), m33(I9), m33(krkinv9), sum3, out3, A3, b3, res, 128, 64);
+    hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    *us_so3 = std::chrono::duration<double, std::micro>(t1 - t0).count() / n;
+  }
   return 0;
 }
 
