@@ -996,19 +996,33 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
       const float rx = fminf(sqrtf(left) * a.fx, 1.0e9f), xwc = s_par[7][j];
       const int xa = max(x0, (int)ceilf(fmaxf(xwc - rx - 0.5f, -1.0e9f)));  // |px + 0.5 - xw| <= rx
       const int xb = min(x0 + w - 1, (int)floorf(fminf(xwc + rx - 0.5f, 1.0e9f)));
-      for (int px = xa; px <= xb; ++px) {
-        f3 c;
-        float zw;
-        if (!splat_fragment(a, s, px, py, c, zw)) continue;
-        const unsigned d = depth24(zw);
-        if (d >= 0xFFFFFFu) continue;
-        const unsigned long long key = ((unsigned long long)d << 32) | id;
-        const size_t q = (size_t)px * a.rows + py;  // column-major z-buffer
-        if (!DUAL || (pass & 1)) {
-          if (key < zbuf[q]) atomicMin(zbuf + q, key);
+      // The row in groups of four fragments: the z-buffer cells a group will compete for are fetched first (their addresses
+      // depend on the pixel only), the ray / disc tests run while those loads are in flight, and a fragment goes to the
+      // atomic only when it beats the value fetched (cells only ever decrease: a stale value can cost an atomic, never a win).
+      const bool use1 = !DUAL || (pass & 1), use2 = DUAL && (pass & 2);
+      for (int px0 = xa; px0 <= xb; px0 += 4) {
+        unsigned long long z1[4], z2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int px = px0 + k;
+          const size_t q = (size_t)px * a.rows + py;  // column-major z-buffer
+          const bool in = px <= xb;
+          z1[k] = (in && use1) ? zbuf[q] : 0ull;
+          z2[k] = (in && use2) ? zbuf2[q] : 0ull;
         }
-        if (DUAL && (pass & 2)) {
-          if (key < zbuf2[q]) atomicMin(zbuf2 + q, key);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int px = px0 + k;
+          if (px > xb) break;
+          f3 c;
+          float zw;
+          if (!splat_fragment(a, s, px, py, c, zw)) continue;
+          const unsigned d = depth24(zw);
+          if (d >= 0xFFFFFFu) continue;
+          const unsigned long long key = ((unsigned long long)d << 32) | id;
+          const size_t q = (size_t)px * a.rows + py;
+          if (key < z1[k]) atomicMin(zbuf + q, key);
+          if (DUAL && key < z2[k]) atomicMin(zbuf2 + q, key);
         }
       }
     }
