@@ -214,6 +214,8 @@ class ElasticFusionT {
     const int tick_before = context.tick();
     if (cluster != 0) throw std::runtime_error("processFrame: only cluster 0 is implemented (one surfel store per ElasticFusion)");
     ensure(context);
+    // Context::rgbOnly() is read every frame by the reference (ElasticFusion.cpp:505): keep the device side in step
+    check(dms_fusion_set_option(context.fusion, DMS_OPT_RGB_ONLY, (context.rgbOnly() || rgbOnly) ? 1.0 : 0.0), "dms_fusion_set_option");
     const int W = Resolution::getInstance().width(), H = Resolution::getInstance().height();
     check(dms_memcpy_h2d(context.rgb_dev, rgb.get(), (size_t)W * H * 3, nullptr), "upload rgb");
     check(dms_memcpy_h2d(context.depth_dev, depth.get(), (size_t)W * H * 2, nullptr), "upload depth");
