@@ -93,6 +93,8 @@ void orc_odometry_set_fused_rows(orc_odometry* o, int on);
 /* cross-pixel sums of the tracker object: 1 (default) = canonical order-free sums (orc_canon.c), 0 = fp64 accumulation in
  * loop / thread order (the order-dependent form, kept as the control of what summation order alone does to a pose) */
 void orc_odometry_set_sum_mode(orc_odometry* o, int mode);
+/* sum_mode 0 only: replace the four step restatements by functions of the same signatures (NULL = own) */
+void orc_odometry_set_step_hooks(orc_odometry* o, void* so3, void* rgbres, void* icp, void* rgb);
 /* scalar section between the reductions: 1 (default) = the product's canonical operation order (orc_scalar.c), 0 = the
  * independent Eigen-like restatement (pivoted LDLT in outer-product form, Rodrigues through libm, general inverses) */
 void orc_odometry_set_solve_mode(orc_odometry* o, int mode);

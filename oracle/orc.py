@@ -58,6 +58,7 @@ lib.orc_odometry_destroy.argtypes = [_P]
 lib.orc_odometry_set_fused_rows.argtypes = [_P, _I]
 lib.orc_set_fused_rows.argtypes = [_I]
 lib.orc_odometry_set_sum_mode.argtypes = [_P, _I]
+lib.orc_odometry_set_step_hooks.argtypes = [_P, _P, _P, _P, _P]
 lib.orc_odometry_set_solve_mode.argtypes = [_P, _I]
 lib.orc_odometry_set_exp_bias.argtypes = [_P, _I]
 lib.orc_odometry_buffer.restype = _P
@@ -316,6 +317,11 @@ class Odometry:
     def setExpBias(self, bias):
         """test hook: bias of the static exponents of a call's first reductions (the product's "exp_bias")"""
         lib.orc_odometry_set_exp_bias(self.h, int(bias))
+
+    def setStepHooks(self, so3=None, rgbres=None, icp=None, rgb=None):
+        """sum mode 0 only: run the host loop around other implementations of the four steps (addresses of functions with the
+        signatures of orc_so3Step / orc_computeRgbResidual / orc_icpStep / orc_rgbStep; None = the restatement)"""
+        lib.orc_odometry_set_step_hooks(self.h, so3, rgbres, icp, rgb)
 
     def setSolveMode(self, canonical):
         """scalar section: the product's canonical operation order (default) or the independent Eigen-like restatement (control)"""

@@ -31,6 +31,15 @@ struct orc_odometry {
   int solve_mode; /* 1 (default): scalar section in the product's canonical operation order (orc_scalar.c); 0: the independent Eigen-like restatement below */
   int sum_mode;   /* 0: fp64 accumulation in loop order (order-dependent control), 1: canonical order-free sums (orc_canon.c) */
   int fused_rows; /* evaluate the Gauss-Newton rows with fused multiply-adds (orc_set_fused_rows), as the product's resident kernels do */
+  /* Step hooks (sum_mode 0 only; NULL = the restatements in orc_track.c): same signatures as orc_so3Step / orc_computeRgbResidual /
+   * orc_icpStep / orc_rgbStep.  tests/golden/make_ref_tracker_golden.py points them at the REFERENCE's own kernels
+   * (oracle/_ref/libref_reduce.so) so that whole tracker calls run this host loop around the reference's device code. */
+  void (*hook_so3)(const uint8_t*, const uint8_t*, const float*, const float*, const float*, int, int, float*, float*, float*);
+  void (*hook_rgbres)(float, const int16_t*, const int16_t*, const float*, const float*, const uint8_t*, const uint8_t*, orc_dataterm*, float,
+                      const float*, const float*, int, int, int*, int*);
+  void (*hook_icp)(const float*, const float*, const float*, const float*, const float*, const float*, float, float, float, float, const float*,
+                   const float*, float, float, int, int, float*, float*, float*);
+  void (*hook_rgb)(const orc_dataterm*, float, const float*, float, float, const int16_t*, const int16_t*, float, int, int, float*, float*);
 };
 
 /* ---- small dense algebra (Eigen stand-ins, fp64 unless stated) ------------------------ */
@@ -421,7 +430,7 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
         }
         res->canon_retries += canon_so3(o, L, imageBasis, kinv, krlr, E_so3, jtj, jtr, residual);
       } else
-      orc_so3Step(o->lastNextImage[L], o->nextImage[L], imageBasis, kinv, krlr, o->height >> L, o->width >> L, jtj, jtr, residual);
+      (o->hook_so3 ? o->hook_so3 : orc_so3Step)(o->lastNextImage[L], o->nextImage[L], imageBasis, kinv, krlr, o->height >> L, o->width >> L, jtj, jtr, residual);
       res->so3_iterations_run++;
       res->lastSO3Error = sqrtf(residual[0]) / residual[1];
       res->lastSO3Count = residual[1];
@@ -510,7 +519,7 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
 
       int sigma = 0, rgbSize = 0;
       if (rgb)
-        orc_computeRgbResidual((float)(pow(o->minGrad[i], 2.0) / pow(o->sobelScale, 2.0)), o->nextdIdx[i], o->nextdIdy[i],
+        ((o->hook_rgbres && !o->sum_mode) ? o->hook_rgbres : orc_computeRgbResidual)((float)(pow(o->minGrad[i], 2.0) / pow(o->sobelScale, 2.0)), o->nextdIdx[i], o->nextdIdy[i],
                                o->lastDepth[i], o->nextDepth[i], o->lastImage[i], o->nextImage[i], o->corresImg[i],
                                o->maxDepthDeltaRGB, kt, krkInv, rows, cols, &sigma, &rgbSize);
 
@@ -527,14 +536,14 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
       if (icp && o->sum_mode)
         res->canon_retries += canon_icp(o, i, Rcurr, tcurr, Rprev_inv, tprev, lfx, lfy, lcx, lcy, E_icp, A_icp, b_icp, residual);
       else if (icp)
-        orc_icpStep(Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, lfx, lfy, lcx, lcy, o->vmaps_g_prev[i],
+        (o->hook_icp ? o->hook_icp : orc_icpStep)(Rcurr, tcurr, o->vmaps_curr[i], o->nmaps_curr[i], Rprev_inv, tprev, lfx, lfy, lcx, lcy, o->vmaps_g_prev[i],
                     o->nmaps_g_prev[i], o->distThres, o->angleThres, rows, cols, A_icp, b_icp, residual);
       res->lastICPError = sqrtf(residual[0]) / residual[1];
       res->lastICPCount = residual[1];
       if (rgb && o->sum_mode)
         res->canon_retries += canon_rgb(o, i, sigmaVal, lfx, lfy, E_rgb, A_rgbd, b_rgbd);
       else if (rgb)
-        orc_rgbStep(o->corresImg[i], sigmaVal, o->pointClouds[i], lfx, lfy, o->nextdIdx[i], o->nextdIdy[i], o->sobelScale, rows,
+        (o->hook_rgb ? o->hook_rgb : orc_rgbStep)(o->corresImg[i], sigmaVal, o->pointClouds[i], lfx, lfy, o->nextdIdx[i], o->nextdIdy[i], o->sobelScale, rows,
                     cols, A_rgbd, b_rgbd);
 
       double A[36], b[6], x[6];
@@ -624,6 +633,15 @@ static void track_impl(orc_odometry* o, float* trans, float* rot, int rgbOnly, f
 
 void orc_odometry_set_fused_rows(orc_odometry* o, int on) { o->fused_rows = on ? 1 : 0; }
 void orc_odometry_set_sum_mode(orc_odometry* o, int mode) { o->sum_mode = mode ? 1 : 0; }
+void orc_odometry_set_step_hooks(orc_odometry* o, void* so3, void* rgbres, void* icp, void* rgb) {
+  o->hook_so3 = (void (*)(const uint8_t*, const uint8_t*, const float*, const float*, const float*, int, int, float*, float*, float*))so3;
+  o->hook_rgbres = (void (*)(float, const int16_t*, const int16_t*, const float*, const float*, const uint8_t*, const uint8_t*, orc_dataterm*,
+                             float, const float*, const float*, int, int, int*, int*))rgbres;
+  o->hook_icp = (void (*)(const float*, const float*, const float*, const float*, const float*, const float*, float, float, float, float,
+                          const float*, const float*, float, float, int, int, float*, float*, float*))icp;
+  o->hook_rgb = (void (*)(const orc_dataterm*, float, const float*, float, float, const int16_t*, const int16_t*, float, int, int, float*,
+                          float*))rgb;
+}
 void orc_odometry_set_solve_mode(orc_odometry* o, int mode) { o->solve_mode = mode ? 1 : 0; }
 void orc_odometry_set_exp_bias(orc_odometry* o, int bias) { o->exp_bias = bias; }
 

@@ -116,3 +116,11 @@ def so3Step(lastImage, nextImage, imageBasis, kinv, krlr, threads=128, blocks=64
     rc = lib().ref_so3Step(_p(lastImage), _p(nextImage), _p(ib), _p(ki), _p(kr), rows, cols, threads, blocks, _p(A), _p(b), _p(res))
     assert rc == 0, rc
     return A, b, res
+
+
+def step_hooks():
+    """Addresses of the reference's four steps behind the restatement's signatures (oracle/ref_reduce_harness.cpp ref_hook_*),
+    in the order of orc.Odometry.setStepHooks."""
+    L = lib()
+    return tuple(C.cast(getattr(L, n), C.c_void_p).value for n in ("ref_hook_so3Step", "ref_hook_computeRgbResidual", "ref_hook_icpStep",
+                                                                   "ref_hook_rgbStep"))

@@ -114,6 +114,38 @@ int ref_so3Step(const unsigned char* lastImage, const unsigned char* nextImage, 
   return 0;
 }
 
+// ---- the same four steps behind the signatures of the restatement (oracle/orc.h: orc_so3Step, orc_computeRgbResidual,
+// orc_icpStep, orc_rgbStep), so that oracle/orc_odometry.c can run its host loop around the reference's device code
+// (orc_odometry_set_step_hooks; tests/golden/make_ref_tracker_golden.py).  The restatement's DataTerm keeps `valid` in an int
+// where the reference has a bool and three bytes of padding: records are normalised on the way back.
+void ref_hook_so3Step(const unsigned char* lastImage, const unsigned char* nextImage, const float* imageBasis, const float* kinv,
+                      const float* krlr, int rows, int cols, float* A, float* b, float* residual) {
+  ref_so3Step(lastImage, nextImage, imageBasis, kinv, krlr, rows, cols, 128, 64, A, b, residual);
+}
+void ref_hook_computeRgbResidual(float minScale, const short* dIdx, const short* dIdy, const float* lastDepth, const float* nextDepth,
+                                 const unsigned char* lastImage, const unsigned char* nextImage, void* corres, float maxDepthDelta,
+                                 const float* kt, const float* krkinv, int rows, int cols, int* sigmaSum, int* count) {
+  ref_computeRgbResidual(minScale, dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, rows, cols, maxDepthDelta, kt, krkinv, 256, 336,
+                         corres, sigmaSum, count);
+  unsigned char* p = (unsigned char*)corres;
+  for (size_t k = 0; k < (size_t)rows * cols; ++k, p += 16) {
+    const int v = p[12] != 0;
+    if (!v) std::memset(p, 0, 16);
+    std::memcpy(p + 12, &v, 4);
+  }
+}
+void ref_hook_icpStep(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr, const float* Rprev_inv,
+                      const float* tprev, float fx, float fy, float cx, float cy, const float* vmap_g_prev, const float* nmap_g_prev,
+                      float distThres, float angleThres, int rows, int cols, float* A, float* b, float* residual) {
+  const float cam[4] = {fx, fy, cx, cy};
+  ref_icpStep(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, cam, vmap_g_prev, nmap_g_prev, rows, cols, distThres, angleThres, 128,
+              112, A, b, residual);
+}
+void ref_hook_rgbStep(const void* corres, float sigma, const float* cloud3, float fx, float fy, const short* dIdx, const short* dIdy,
+                      float sobelScale, int rows, int cols, float* A, float* b) {
+  ref_rgbStep(corres, sigma, cloud3, fx, fy, dIdx, dIdy, sobelScale, rows, cols, 128, 112, A, b);
+}
+
 // Timing of the reference's Gauss-Newton inner loop as RGBDOdometry.cpp:425-541 runs it: per iteration computeRgbResidual,
 // icpStep, rgbStep, each with its own launches, device synchronisation and download (that is how the reference's functions
 // are written); inputs uploaded once, host clock around `iters` iterations (the host-side Eigen solve between them is not

@@ -35,6 +35,12 @@ def main(outdir):
         a, b = out[k], again[k]
         same = (a == b).all() if a.dtype.kind in "iuSU" or a.dtype.names else np.array_equal(a, b, equal_nan=True)
         assert same, "reference not repeatable: " + k
+    # whole tracker calls: the restatement's host loop (oracle/orc_odometry.c, plain-order sums) around the reference's kernels
+    trk = ref_cases.run_trackers(orc, load_pair(), hooks=ref.step_hooks())
+    trk2 = ref_cases.run_trackers(orc, load_pair(), hooks=ref.step_hooks())
+    for k in trk:
+        assert np.array_equal(trk[k], trk2[k], equal_nan=True), "reference-driven tracker not repeatable: " + k
+    out.update(trk)
     out.update(ref_cases.input_hashes(lv))
     out["meta"] = np.array("reference kernels: elasticfusion/Core/src/Cuda/reduce.cu via oracle/ref_build.sh (hipify-perl + hipcc "
                            "-ffp-contract=off, gfx950), run on an MI355X; launch shapes icp/rgb 128x112, residual 256x336, so3 128x64")
@@ -43,7 +49,7 @@ def main(outdir):
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
     for k in sorted(out):
-        if k.startswith("icp_L") or k.endswith("_sums"):
+        if k.startswith("icp_L") or k.endswith("_sums") or k.endswith("_iters") or (k.startswith("trk_") and k.endswith("_t")):
             print(k, out[k][-2:])
 
 

@@ -159,3 +159,39 @@ def run(be, lv, rows_from=None):
             rr.append(_se3_vec(A, b))
         out["rgb_rows_S%d" % si] = np.stack(rr)
     return out
+
+
+# ---- whole tracker calls: the restatement's host loop around the reference's kernels -------------------------------------------
+TRACKER_CONFIGS = {
+    "C2_icp_fast": dict(rgbOnly=False, icpWeight=100.0, pyramid=False, fastOdom=True, so3=False),
+    "C3_full": dict(rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True),
+    "gputest": dict(rgbOnly=False, icpWeight=10.0, pyramid=False, fastOdom=False, so3=True),  # GPUTest.cpp:278
+    "rgb_only": dict(rgbOnly=True, icpWeight=10.0, pyramid=True, fastOdom=False, so3=False),
+    "icp_pyramid": dict(rgbOnly=False, icpWeight=100.0, pyramid=True, fastOdom=False, so3=False),
+}
+
+
+def run_trackers(orc, pair, hooks=None):
+    """getIncrementalTransformation from the identity on the GPUTest pair (the harness protocol, GPUTest.cpp:247-286) for every
+    configuration, sums in plain order (sum mode 0), rows without contraction; `hooks`: addresses from oracle.ref.step_hooks()."""
+    out = {}
+    for name, cfg in TRACKER_CONFIGS.items():
+        verts, norms = helpers.gputest_model_maps(pair["depth1_raw"], K)
+        o = orc.Odometry(640, 480, K[2], K[3], K[0], K[1])
+        o.setSumMode(False)
+        o.setFusedRows(False)
+        if hooks:
+            o.setStepHooks(*hooks)
+        o.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+        o.initRGBModel(helpers.rgba(pair["rgb1"]))
+        o.initICP(pair["depth2"], 20.0)
+        o.initRGB(helpers.rgba(pair["rgb2"]))
+        o.initFirstRGB(helpers.rgba(pair["rgb1"]))
+        t, R, res = o.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **cfg)
+        out["trk_%s_t" % name] = np.asarray(t, np.float32)
+        out["trk_%s_R" % name] = np.asarray(R, np.float32)
+        out["trk_%s_iters" % name] = np.array([res.so3_iterations_run] + list(res.iterations_run), np.int32)
+        out["trk_%s_counts" % name] = np.array([res.lastICPCount, res.lastRGBCount, res.lastSO3Count], np.float64)
+        out["trk_%s_errors" % name] = np.array([res.lastICPError, res.lastRGBError, res.lastSO3Error], np.float64)
+        out["trk_%s_trace" % name] = np.array([list(res.trace[i]) for i in range(res.trace_len)], np.float32).reshape(-1, 3, 4)
+    return out

@@ -1218,7 +1218,7 @@ def test_long_run_every_step_identical_640x480(fus, orc, synth):
     _free_run_identical(fus, synth, orc_pipeline, 640, 480, syn.K_640, n, {})
 
 
-def _free_run_identical(fus, synth, orc_pipeline, W2, H2, K2, n, opts, gopts=None):
+def _free_run_identical(fus, synth, orc_pipeline, W2, H2, K2, n, opts, gopts=None, retries_per_frame=0.1):
     o_opts = dict(opts)
     g_opts = dict(opts if gopts is None else gopts)
     g = fus.ElasticFusion(W2, H2, K2, model_capacity=4_000_000, **g_opts)
@@ -1240,7 +1240,9 @@ def _free_run_identical(fus, synth, orc_pipeline, W2, H2, K2, n, opts, gopts=Non
             assert np.array(rg.track.lastA).tobytes() == np.array(ro.track.lastA).tobytes(), k
             retries += ro.track.canon_retries
     surfels_equal(g.globalModel().downloadMap(), o.model, "map after %d free-running frames" % n)
-    assert retries <= max(2, n // 10), retries  # the static exponents fit this stream: repeated reductions are the exception
+    # repeated reductions (a diagonal total outgrew the grid its exponents promised; same decision on both sides) are the
+    # exception where the static first-iteration exponents fit the stream
+    assert retries <= max(2, int(n * retries_per_frame)), retries
     g.close()
 
 
@@ -1252,7 +1254,9 @@ def test_free_run_identical_at_kitti_size_1241x376(fus, orc, synth):
     from oracle import orc_pipeline
 
     n = int(os.environ.get("DMS_LONG_RUN_FRAMES_KITTI", "25"))
-    _free_run_identical(fus, synth, orc_pipeline, 1241, 376, synth.K_KITTI, n, dict(depthCut=40.0))
+    # (with geometry out to 40 m the rotation columns of the ICP rows outgrow the static guess of a call's first reduction —
+    # |v x n| of a few metres — on most calls once far walls are in view: 0.67 repeated iterations per frame over 200 frames)
+    _free_run_identical(fus, synth, orc_pipeline, 1241, 376, synth.K_KITTI, n, dict(depthCut=40.0), retries_per_frame=2.0)
 
 
 def test_frame_step_api_contract(fus, synth):
