@@ -67,3 +67,29 @@ def test_product_sums_equal_the_references(pair):
         elif k.startswith("so3_L"):
             assert ours[k][10] == golden[k][10], k
             close(ours[k][:10], golden[k][:10], k)
+
+
+def test_product_tracker_against_the_reference_driven_tracker(orc, gputest_pair):
+    """getIncrementalTransformation of the HIP path (resident kernels, canonical sums, fused rows) against tracker calls whose
+    every step ran the REFERENCE's kernels (`trk_*` of the fixture, see tests/test_ref_pin_cpu.py): the north-star bar, 1 mm and
+    0.01 degree, and the same iteration counts."""
+    from densemonoslam_amd import odometry
+    from tests import helpers
+
+    z = np.load(GOLDEN)
+    K = ref_cases.K
+    verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
+    worst = (0.0, 0.0)
+    for name, cfg in ref_cases.TRACKER_CONFIGS.items():
+        g = odometry.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+        g.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+        g.initRGBModel(helpers.rgba(gputest_pair["rgb1"]))
+        g.initICP(gputest_pair["depth2"], 20.0)
+        g.initRGB(helpers.rgba(gputest_pair["rgb2"]))
+        g.initFirstRGB(helpers.rgba(gputest_pair["rgb1"]))
+        t, R, res = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **cfg)
+        dt, da = helpers.assert_pose_close(t, R, z["trk_%s_t" % name], z["trk_%s_R" % name], tol_m=1e-3, tol_deg=1e-2, what=name)
+        worst = (max(worst[0], dt), max(worst[1], da))
+        assert [res.so3_iterations_run] + list(res.iterations_run) == list(z["trk_%s_iters" % name]), name
+        g.close()
+    print("worst difference to the reference-driven tracker: %.2e m, %.2e deg" % worst)
