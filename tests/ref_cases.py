@@ -25,7 +25,7 @@ SOBEL_SCALE = 1.0 / 8.0
 MIN_GRAD = (5.0, 3.0, 1.0)  # RGBDOdometry.cpp:60-62
 DIST_THRES, ANGLE_THRES = 0.10, float(np.sin(np.radians(20.0)))  # RGBDOdometry.cpp:33-34
 MAX_DEPTH_DELTA = 0.07  # RGBDOdometry.cpp:38
-N_ICP_ROWS, N_RGB_ROWS, N_SO3_ROWS = 192, 128, 0
+N_ICP_ROWS, N_RGB_ROWS, N_SO3_ROWS = 192, 128, 128
 
 
 def _rot(axis, ang):
@@ -158,6 +158,24 @@ def run(be, lv, rows_from=None):
             A, b = be.rgbStep(one, sg, d["cloud"], float(cam[0]), float(cam[1]), d["dIdx"], d["dIdy"], SOBEL_SCALE)
             rr.append(_se3_vec(A, b))
         out["rgb_rows_S%d" % si] = np.stack(rr)
+    # ---- single SO3 rows: a 3 x 3 image has ONE pixel that passes so3Step's bounds test (reduce.cu:975-979), so the sums of
+    # a call on a 3 x 3 patch pair are that pixel's ten products and its flag.  Patches cut from the level-2 images, the
+    # level-2 camera matrices with a small rotation (the warped pixel stays (1, 1)).
+    rng = np.random.default_rng(11)
+    rows, cols = lv[2]["nextImage"].shape
+    cam = _cam(2).astype(np.float64)
+    Km = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1]], np.float64)
+    so3_rows = []
+    for i in range(N_SO3_ROWS):
+        y, x = int(rng.integers(1, rows - 2)), int(rng.integers(1, cols - 2))
+        last = np.ascontiguousarray(lv[2]["lastNextImage"][y - 1:y + 2, x - 1:x + 2])
+        nxt = np.ascontiguousarray(lv[2]["nextImage"][y - 1:y + 2, x - 1:x + 2])
+        Rs = _rot(rng.standard_normal(3), np.radians(rng.uniform(0.0, 0.05)))
+        ib = (Km @ Rs @ np.linalg.inv(Km)).astype(np.float32)
+        ib[:, 2] = [np.float32(1.0) - ib[0, 0] - ib[0, 1], np.float32(1.0) - ib[1, 0] - ib[1, 1], np.float32(1.0) - ib[2, 0] - ib[2, 1]]  # (1, 1, 1) -> ~(1, 1, 1)
+        A, b, res = be.so3Step(last, nxt, ib, np.linalg.inv(Km).astype(np.float32), (Km @ Rs).astype(np.float32))
+        so3_rows.append(np.concatenate([A[np.triu_indices(3)], b, res]).astype(np.float32))
+    out["so3_rows"] = np.stack(so3_rows)
     return out
 
 

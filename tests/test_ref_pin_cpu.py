@@ -44,11 +44,12 @@ def test_fixture_is_the_references_output(golden):
 
 def test_single_pixel_rows_bit_exact(ours, golden):
     """One pixel alone in the image: the reference's sums are that pixel's 27 products, residual and inlier flag."""
-    for k in ("icp_rows", "rgb_rows_S0", "rgb_rows_S1"):
+    for k in ("icp_rows", "rgb_rows_S0", "rgb_rows_S1", "so3_rows"):
         assert ours[k].dtype == golden[k].dtype == np.float32
         assert np.array_equal(ours[k].view(np.uint32), golden[k].view(np.uint32)), k
     assert golden["icp_rows"][:, 28].sum() >= 0.5 * ref_cases.N_ICP_ROWS  # most chosen pixels do find a correspondence
     assert (np.abs(golden["rgb_rows_S0"]).sum(1) > 0).all()
+    assert (golden["so3_rows"][:, 10] == 1).all() and golden["so3_rows"].shape == (ref_cases.N_SO3_ROWS, 11)  # 3 x 3 patches: one pixel each
 
 
 def test_photometric_correspondences_exact(ours, golden):

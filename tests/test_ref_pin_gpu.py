@@ -39,7 +39,7 @@ def pair(orc, gputest_pair):
 
 def test_product_rows_and_correspondences_equal_the_references(pair):
     ours, golden = pair
-    for k in ("icp_rows", "rgb_rows_S0", "rgb_rows_S1"):
+    for k in ("icp_rows", "rgb_rows_S0", "rgb_rows_S1", "so3_rows"):
         # one pixel alone in the image: its 27 products, residual and inlier flag, bit for bit what the reference's kernel formed
         assert np.array_equal(ours[k].view(np.uint32), golden[k].view(np.uint32)), k
     for lvl in range(3):
