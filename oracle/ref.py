@@ -10,7 +10,9 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_reduce.so")
+# DMS_REF_VARIANT=fma selects the build with the compiler's default contraction (oracle/ref_build.sh); read when the library is first used
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref",
+                        "libref_reduce_fma.so" if os.environ.get("DMS_REF_VARIANT") == "fma" else "libref_reduce.so")
 
 # DataTerm as the reference lays it out (Cuda/types.cuh:75-81): short2, short2, float, bool (+3 bytes of padding)
 REF_DATATERM = np.dtype([("zero_x", "<i2"), ("zero_y", "<i2"), ("one_x", "<i2"), ("one_y", "<i2"), ("diff", "<f4"), ("valid", "u1"),

@@ -45,5 +45,12 @@ hipcc $FLAGS -c "$OUT/src/reduce.cu" -o "$OUT/reduce.o"
 hipcc $FLAGS -c "$OUT/src/containers/device_memory.cpp" -o "$OUT/device_memory.o"
 hipcc $FLAGS -c "$HERE/ref_reduce_harness.cpp" -o "$OUT/harness.o"
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_reduce.so" "$OUT/reduce.o" "$OUT/device_memory.o" "$OUT/harness.o"
+# second variant: the same sources with the compiler's DEFAULT contraction of device code (what nvcc's default -fmad=true is to
+# the reference's own build): multiply-adds fused where the compiler sees them.  The product's resident tracker evaluates its
+# rows with every multiply-add chain fused (pixel_ops.hpp madd<true>), restated by the oracle's fused mode; this library shows
+# how a compiler's own choice of fusions compares with that (tests/golden/make_ref_reduce_golden.py records it).
+FLAGS_FMA="${FLAGS/-ffp-contract=off/-ffp-contract=fast}"
+hipcc $FLAGS_FMA -c "$OUT/src/reduce.cu" -o "$OUT/reduce_fma.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_reduce_fma.so" "$OUT/reduce_fma.o" "$OUT/device_memory.o" "$OUT/harness.o"
 rm -rf "$OUT"/*.o "$OUT/src"   # only the library stays: no reference text is left in the tree
-echo "built $OUT/libref_reduce.so"
+echo "built $OUT/libref_reduce.so $OUT/libref_reduce_fma.so"

@@ -8,6 +8,8 @@ rgbStep / so3Step on an MI355X over the cases of tests/ref_cases.py and records 
     bash oracle/ref_build.sh                                               (container with /root/reference)
     gpurun -- 'python tests/golden/make_ref_reduce_golden.py gpurun_out'   (MI355X; writes gpurun_out/ref_reduce.npz)
     cp gpurun_out/ref_reduce.npz tests/golden/ref_reduce.npz              (commit)
+    gpurun -- 'DMS_REF_VARIANT=fma python tests/golden/make_ref_reduce_golden.py gpurun_out'   (second fixture, ref_reduce_fma.npz:
+                                                                           the reference built with the compiler's default contraction)
 
 tests/test_ref_pin_cpu.py then holds the CPU restatement (oracle/orc_track.c) to these numbers on every round.
 """
@@ -27,7 +29,26 @@ def load_pair():
     return {"rgb1": z["rgb1"], "rgb2": z["rgb2"], "depth1_raw": z["depth1"], "depth2": (z["depth2"] // 5).astype(np.uint16)}
 
 
+def main_fma(outdir):
+    """DMS_REF_VARIANT=fma: the reference built with the compiler's default contraction of device code (libref_reduce_fma.so)
+    -> tests/golden/ref_reduce_fma.npz, the comparison point of the restatement's FUSED mode (what the resident tracker runs)."""
+    lv = ref_cases.inputs(orc, load_pair())
+    base = np.load(os.path.join(ROOT, "tests", "golden", "ref_reduce.npz"))
+    out = ref_cases.run(ref, lv, rows_from={k: base[k] for k in ("icp_row_pix", "rgb_row_pix", "rgbres_L2_P1_corres")})
+    out = {k: v for k, v in out.items() if not (k.endswith("_valid") or k.endswith("_corres"))}
+    out.update(ref_cases.run_trackers(orc, load_pair(), hooks=ref.step_hooks()))
+    out.update(ref_cases.input_hashes(lv))
+    out["meta"] = np.array("reference kernels: elasticfusion/Core/src/Cuda/reduce.cu via oracle/ref_build.sh, variant built with "
+                           "-ffp-contract=fast (the compiler's default for device code), gfx950, run on an MI355X")
+    os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, "ref_reduce_fma.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main(outdir):
+    if os.environ.get("DMS_REF_VARIANT") == "fma":
+        return main_fma(outdir)
     lv = ref_cases.inputs(orc, load_pair())
     out = ref_cases.run(ref, lv)
     again = ref_cases.run(ref, lv, rows_from=out)  # the reference is deterministic on one device: record that it is

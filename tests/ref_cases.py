@@ -189,7 +189,7 @@ TRACKER_CONFIGS = {
 }
 
 
-def run_trackers(orc, pair, hooks=None):
+def run_trackers(orc, pair, hooks=None, fused=False):
     """getIncrementalTransformation from the identity on the GPUTest pair (the harness protocol, GPUTest.cpp:247-286) for every
     configuration, sums in plain order (sum mode 0), rows without contraction; `hooks`: addresses from oracle.ref.step_hooks()."""
     out = {}
@@ -197,7 +197,7 @@ def run_trackers(orc, pair, hooks=None):
         verts, norms = helpers.gputest_model_maps(pair["depth1_raw"], K)
         o = orc.Odometry(640, 480, K[2], K[3], K[0], K[1])
         o.setSumMode(False)
-        o.setFusedRows(False)
+        o.setFusedRows(fused)
         if hooks:
             o.setStepHooks(*hooks)
         o.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))

@@ -69,14 +69,16 @@ def test_product_sums_equal_the_references(pair):
             close(ours[k][:10], golden[k][:10], k)
 
 
-def test_product_tracker_against_the_reference_driven_tracker(orc, gputest_pair):
+@pytest.mark.parametrize("fixture", ["ref_reduce.npz", "ref_reduce_fma.npz"])
+def test_product_tracker_against_the_reference_driven_tracker(orc, gputest_pair, fixture):
     """getIncrementalTransformation of the HIP path (resident kernels, canonical sums, fused rows) against tracker calls whose
     every step ran the REFERENCE's kernels (`trk_*` of the fixture, see tests/test_ref_pin_cpu.py): the north-star bar, 1 mm and
     0.01 degree, and the same iteration counts."""
     from densemonoslam_amd import odometry
     from tests import helpers
 
-    z = np.load(GOLDEN)
+    # (ref_reduce_fma.npz: the reference's kernels built with the compiler's default contraction, see tests/test_ref_pin_cpu.py)
+    z = np.load(os.path.join(os.path.dirname(GOLDEN), fixture))
     K = ref_cases.K
     verts, norms = helpers.gputest_model_maps(gputest_pair["depth1_raw"], K)
     worst = (0.0, 0.0)
@@ -92,4 +94,4 @@ def test_product_tracker_against_the_reference_driven_tracker(orc, gputest_pair)
         worst = (max(worst[0], dt), max(worst[1], da))
         assert [res.so3_iterations_run] + list(res.iterations_run) == list(z["trk_%s_iters" % name]), name
         g.close()
-    print("worst difference to the reference-driven tracker: %.2e m, %.2e deg" % worst)
+    print("worst difference to the reference-driven tracker (%s): %.2e m, %.2e deg" % (fixture, worst[0], worst[1]))
