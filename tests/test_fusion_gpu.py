@@ -1675,6 +1675,22 @@ def test_runtime_setters_and_exports_match_the_oracle(fus, orc, synth, tmp_path)
         got = open(path, "rb").read()
         assert got == want, "ply (reference_offsets=%s): %d vs %d bytes" % (ref_off, len(got), len(want))
         assert 0 < n < len(mg) and ("element vertex %d\n" % n).encode() in got[:200]
+    # misuse is reported, not executed
+    from densemonoslam_amd import capi
+    import ctypes as C
+
+    assert capi.lib.dms_fusion_set_option(g.h, 99, C.c_double(1.0)) == -1 and b"unknown option" in capi.lib.dms_last_error()
+    assert capi.lib.dms_fusion_set_option(g.h, g.OPTIONS["depthCut"], C.c_double(0.0)) == -1
+    assert capi.lib.dms_fusion_set_option(g.h, g.OPTIONS["confidence"], C.c_double(float("nan"))) == -1
+    assert capi.lib.dms_fusion_set_option(None, 0, C.c_double(0.0)) == -1
+    assert g.getOption("depthCut") == pytest.approx(2.5) and g.getOption("confidence") == pytest.approx(1.0)  # unchanged by the failures
+    assert capi.lib.dms_model_save_ply(None, b"/tmp/x.ply", C.c_float(1.0), 0, None) == -1
+    assert capi.lib.dms_model_save_ply(g.globalModel().h, str(tmp_path / "no_such_dir" / "x.ply").encode(), C.c_float(1.0), 0, None) == -1
+    empty = fus.GlobalModel(W, H, capacity=1024)  # a map without surfels: a header, no vertices
+    assert empty.savePly(str(tmp_path / "empty.ply"), 1.0) == 0
+    assert open(str(tmp_path / "empty.ply"), "rb").read().endswith(b"element vertex 0\nproperty float x\nproperty float y\nproperty float z"
+                                                                     b"\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx"
+                                                                     b"\nproperty float ny\nproperty float nz\nproperty float radius\nend_header\n")
     # inside a begin / end pair the setters refuse
     g2 = fus.ElasticFusion(W, H, K, model_capacity=600000, local_loop_closure=1)
     d, rgb, _ = synth.frame(0, width=W, height=H, K=K, noise=True)
