@@ -371,7 +371,9 @@ int dms_fusion_get_option(dms_fusion* f, int option, double* value);
  * reads the normal at float offset 18 of its 15-float record — a constant left over from MAX_SENSORS = 10 (Vertex.cpp:49,
  * 8 + 10); with 3 sensors that is the NEXT record's {confidence, colour...} and, for the last surfel, beyond the buffer.
  * reference_offsets = 0 (default use): the normal and radius of the surfel itself (offset 8 + MAX_SENSORS = 11);
- * reference_offsets = 1: the reference's offset, zeros where it leaves the buffer.  Syncs. */
+ * reference_offsets = 1: the reference's offset, zeros where it leaves the buffer.  Synchronises the null stream only: call it
+ * once the last frame step on the map has completed (dms_fusion_fetch, or a synchronised stream), as the reference's savePly
+ * follows its glFinish (GlobalModel.cpp:867). */
 int dms_model_save_ply(dms_model* m, const char* path, float confidenceThreshold, int reference_offsets, unsigned int* written);
 /* Context::saveTrajectory (Context.h:117-156): one line per pose, the 3 x 4 matrix row by row with the stream's default float
  * formatting (6 significant digits) and a blank before the newline.  poses16_host: n row-major 4 x 4 camera-to-world matrices. */
