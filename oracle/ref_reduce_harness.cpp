@@ -72,13 +72,14 @@ int ref_computeRgbResidual(float minScale, const short* dIdx, const short* dIdy,
   up(ni, nextImage, rows, cols);
   DeviceArray2D<DataTerm> corres;
   corres.create(rows, cols);
-  if (corres.step() != (size_t)cols * sizeof(DataTerm)) return -2;  // the kernel indexes it linearly
   DeviceArray<int2> sumResidual;
   sumResidual.create(1024);
   int s = 0, c = 0;
   computeRgbResidual(minScale, dx, dy, ld, nd, li, ni, corres, sumResidual, maxDepthDelta, f3(kt3), m33(krkinv9), s, c, threads,
                      blocks);
-  corres.download(corres_out, (size_t)cols * sizeof(DataTerm));
+  // the kernels index the (pitched) allocation LINEARLY (corresImg.data[k], k = y * cols + x: reduce.cu:838, :560), whatever
+  // its pitch: the records are taken out the same way
+  if (hipMemcpy(corres_out, corres.ptr(), (size_t)rows * cols * sizeof(DataTerm), hipMemcpyDeviceToHost) != hipSuccess) return -3;
   *sigmaSum = s;
   *count = c;
   return 0;
@@ -88,8 +89,8 @@ int ref_computeRgbResidual(float minScale, const short* dIdx, const short* dIdy,
 int ref_rgbStep(const void* corres_in, float sigma, const float* cloud3, float fx, float fy, const short* dIdx, const short* dIdy,
                 float sobelScale, int rows, int cols, int threads, int blocks, float* A36, float* b6) {
   DeviceArray2D<DataTerm> corres;
-  up(corres, corres_in, rows, cols);
-  if (corres.step() != (size_t)cols * sizeof(DataTerm)) return -2;
+  corres.create(rows, cols);
+  if (hipMemcpy(corres.ptr(), corres_in, (size_t)rows * cols * sizeof(DataTerm), hipMemcpyHostToDevice) != hipSuccess) return -3;  // linear, as the kernel reads it
   DeviceArray2D<float3> cloud;
   up(cloud, cloud3, rows, cols);
   DeviceArray2D<short> dx, dy;
