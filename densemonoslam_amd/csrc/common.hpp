@@ -365,6 +365,26 @@ inline int reduce_blocks_for(int n) {
   return b;
 }
 
+// XCD-aware block order for per-pixel kernels: consecutive workgroups go round-robin to the 8 XCDs (each with its own L2), so
+// with the identity order neighbouring tiles — which gather the same surfels and share window halos — sit in eight different
+// L2s.  With `on`, the blocks of one XCD (b % 8) take a contiguous eighth of the tile sequence instead (DMS_XCD_REMAP=0: off).
+// Used by the per-PIXEL passes (index resolve, splat resolve, associate: 2590 -> 2620 frames/s).  Measured and not used: the
+// per-SURFEL passes (splat project 42 -> 49 us, clean flags 20 -> 24 us: contiguous ranges of the map have correlated cost —
+// culled or not, in the window or not — so one XCD ends up with the expensive eighth) and the resident tracker levels
+// (no change: their model-map gathers already hit in L2).
+// (A grid that is not a multiple of 8 keeps its last nb % 8 blocks in place; the map is a bijection either way.)
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, int on) {
+  const unsigned nb8 = nb & ~7u;
+  return (on && b < nb8) ? (b & 7u) * (nb8 >> 3) + (b >> 3) : b;
+}
+inline int xcd_remap_enabled() {
+  static const int v = [] {
+    const char* e = getenv("DMS_XCD_REMAP");
+    return e ? (atoi(e) != 0 ? 1 : 0) : 1;
+  }();
+  return v;
+}
+
 inline dim3 grid2d(int cols, int rows, dim3 block) { return dim3((cols + block.x - 1) / block.x, (rows + block.y - 1) / block.y); }
 
 }  // namespace dms

@@ -40,6 +40,7 @@ struct FuseArgs {
   const float* weighting_dev;
   int time, timeIdx;
   int transposed;  // index-map images stored column-major (fusion_map.hip ProjArgs::transposed)
+  int xcd;         // XCD-aware block order (common.hpp xcd_block)
 };
 
 __device__ __forceinline__ f3 dv_vertex(const float* depth, int cols, int sx, int sy, float x, float y, float cx, float cy, float icx,
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_fuse_associate(FuseArgs a, float4* __re
   // of which the evaluation itself was 2.)  One 2 x 8 tile of candidates per wave, quads running down the column first:
   // the column-major index maps and the row-major live images are both read in runs of 8 neighbouring candidates.
   const int tiles_j = (a.slot_h + 7) >> 3;
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int t = xcd_block(blockIdx.x, gridDim.x, a.xcd) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int ti = t / tiles_j, tj = t - ti * tiles_j;
   const int lane = threadIdx.x & 63, quad = lane >> 2, sub = lane & 3;
   const int i = ti * 2 + (quad >> 3);
@@ -665,6 +666,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
                   dense_img(im->vertConf, 16, W, H) && dense_img(im->normRad, 16, W, H),
               "dense W×H images required");
   FuseArgs a;
+  a.xcd = xcd_remap_enabled();
   a.pose = pose;
   a.rgba = (const uchar4*)rgba->data;
   a.dr = (const float*)dr->data;

@@ -393,6 +393,7 @@ struct ProjArgs {
   // consumers walk the image by columns (the reference's draw order, GlobalModel.cpp:100-108),
   // so this is the layout that makes their 16-byte gathers coalesce.
   int transposed;
+  int xcd;  // XCD-aware block order of the per-pixel passes (common.hpp xcd_block)
 };
 
 __global__ void k_clear_zbuf(unsigned long long* z, int n) {
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256) void k_index_resolve(ProjArgs a, SurfelPlanes 
   // the z-buffer uses the same order, so reads and writes are coalesced either way
   const int n = a.cols * a.rows;
   const float* Tinv = a.pose->t_inv;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
+  for (int p = xcd_block(blockIdx.x, gridDim.x, a.xcd) * blockDim.x + threadIdx.x; p < n; p += blockDim.x * gridDim.x) {
     const unsigned long long key = zbuf[p];
     if (clear_after) zbuf[p] = kZClear;  // hand the z-buffer back empty: the next draw needs no clear launch
     if ((unsigned)(key >> 32) >= 0xFFFFFFu) {  // cleared colour (glClearColor 0)
@@ -534,6 +535,7 @@ static void fill_proj(ProjArgs& a, const dms_model* m, const dms_pose_block* pos
   a.maxTime = 0;
   a.actv = 0;
   a.transposed = 0;
+  a.xcd = xcd_remap_enabled();
 }
 
 int index_map(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, int time, int timeIdx, float maxDepth, int timeDelta,
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
   // is one 128-byte (float4) run
   const int tiles_y = (a.rows + 7) >> 3, tiles_x = (a.cols + 7) >> 3, ntiles = tiles_x * tiles_y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
-  for (int t = blockIdx.x * waves_per_block + wave; t < ntiles; t += gridDim.x * waves_per_block) {
+  for (int t = xcd_block(blockIdx.x, gridDim.x, a.xcd) * waves_per_block + wave; t < ntiles; t += gridDim.x * waves_per_block) {
     const int tx = t / tiles_y, ty = t - tx * tiles_y;
     const int px = tx * 8 + (lane >> 3), py = ty * 8 + (lane & 7);
     if (px >= a.cols || py >= a.rows) continue;
