@@ -27,11 +27,13 @@ __device__ __forceinline__ int nid_bin_depth(float depth_mm, float max_depth, in
   return b < 0 ? 0 : (b < num_bins ? b : num_bins - 1);
 }
 
-// key-frame value of a pixel: the nearer of the active and the old prediction (NaN = none)
-__device__ __forceinline__ int kf_pick(float d, float dold) {  // 0 = active, 1 = old, 2 = neither
-  const bool v = !isnan(d), vo = !isnan(dold);
-  if (v && vo) return d <= dold ? 0 : 1;
-  return v ? 0 : (vo ? 1 : 2);
+// key-frame value of a pixel: the reference tests `dmap != __int_as_float(0x7fffffff)` (cudafuncs.cu:1099-1100, :1136-1137),
+// a comparison with a NaN, which is TRUE for every value: its first branch is always the one taken, i.e. the active
+// prediction where `d <= dold` holds and the old one otherwise - a NaN on either side makes the comparison false, so a pixel
+// the old view does not see takes the OLD image's value (or, for the depth score, the old depth's NaN -> bin 0).  Pinned by
+// the reference's own kernel run on gfx950 (tests/golden/ref_cudafuncs.npz `nid`).
+__device__ __forceinline__ int kf_pick(float d, float dold) {  // 0 = active, 1 = old
+  return d <= dold ? 0 : 1;
 }
 
 __global__ __launch_bounds__(256) void k_nid_hist_img(View<const unsigned char> img_kf, View<const unsigned char> img_kf_old,
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void k_nid_hist_img(View<const unsigned char> 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
     const int y = i / img_kf.cols, x = i - y * img_kf.cols;
     const int pick = kf_pick(dmap_kf.at(y, x), dmap_kf_old.at(y, x));
-    const unsigned a = pick == 0 ? img_kf.at(y, x) : (pick == 1 ? img_kf_old.at(y, x) : 0u);
+    const unsigned a = pick == 0 ? img_kf.at(y, x) : img_kf_old.at(y, x);
     const int cell = nid_bin_u8(img_curr.at(y, x), num_bins) * num_bins + nid_bin_u8(a, num_bins);  // row = live, column = key frame
     if (priv)
       atomicAdd(&s_hist[cell], 1u);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void k_nid_hist_depth(View<const float> dmap_k
     const int y = i / dmap_kf.cols, x = i - y * dmap_kf.cols;
     const float d = dmap_kf.at(y, x), dold = dmap_kf_old.at(y, x);
     const int pick = kf_pick(d, dold);
-    const float a = pick == 0 ? d * 1000.0f : (pick == 1 ? dold * 1000.0f : 0.0f);
+    const float a = (pick == 0 ? d : dold) * 1000.0f;  // NaN -> bin 0 (nid_bin_depth)
     const float b = dmap_curr.at(y, x) * 1000.0f;
     atomicAdd(&hist[nid_bin_depth(b, max_depth, num_bins) * num_bins + nid_bin_depth(a, max_depth, num_bins)], 1u);
   }

@@ -193,6 +193,16 @@ def verticesToDepth(v4, cutoff):
     return dst
 
 
+def verticesToDepth2D(vmap, cutoff):
+    """verticesToDepth2DKernel, cudafuncs.cu:619-630: the z plane of a 3-plane vertex map, NaN where z > cutOff or z <= 0
+    (a NaN z fails both tests and is passed through)."""
+    vmap = _c(vmap, np.float32)
+    r = vmap.shape[0] // 3
+    z = vmap[2 * r:3 * r]
+    with np.errstate(invalid="ignore"):
+        return np.where((z > np.float32(cutoff)) | (z <= 0), np.float32(np.nan), z).astype(np.float32)
+
+
 def imageBGRToIntensity(rgba):
     rgba = _c(rgba, np.uint8)
     dst = np.empty(rgba.shape[:2], np.uint8)

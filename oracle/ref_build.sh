@@ -19,8 +19,8 @@
 #   * -ffp-contract=off: a compiler choice either way (nvcc contracts by default, at places of its choosing); without
 #     contraction the per-pixel arithmetic is the source's, operation by operation, which is what the oracle's plain
 #     (non-fused) mode restates, so decisions (inliers, correspondences) can be compared exactly.
-# Not built: cudafuncs.cu (its imageBGRToIntensity samples a legacy texture reference; gfx950 has no image
-# instructions and HIP marks tex2D unavailable there) - unbuildable here, its restatement stays unpinned.
+# cudafuncs.cu (pyramid / preparation operators, NID scores) is built into a third library further down, minus the one
+# function gfx950 cannot compile (imageBGRToIntensity: a legacy texture-reference sampler).
 # The wavefront is 64 wide: the reference's block reduction is written against warpSize and is correct for any launch
 # whose thread count is a multiple of it (the harness's callers use 128 / 256; the reference's own 160 for so3Step is
 # not a multiple of 64 and would drop the last half wave).
@@ -52,5 +52,32 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_reduce.so" "$OUT/reduc
 FLAGS_FMA="${FLAGS/-ffp-contract=off/-ffp-contract=fast}"
 hipcc $FLAGS_FMA -c "$OUT/src/reduce.cu" -o "$OUT/reduce_fma.o"
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_reduce_fma.so" "$OUT/reduce_fma.o" "$OUT/device_memory.o" "$OUT/harness.o"
+# ---- third library: the reference's pyramid / preparation operators and NID scores (Cuda/cudafuncs.cu) -> libref_cudafuncs.so
+# cudafuncs.cu holds ONE function gfx950 cannot compile: imageBGRToIntensity with its kernel bgr2IntensityKernel and the legacy
+# texture reference `inTex` they sample (HIP: "tex2D is unavailable: the image/texture API is not supported on the device").
+# Those lines - from the `texture<...> inTex;` declaration to the closing `};` of imageBGRToIntensity - are removed by a
+# line-anchored deletion; NOTHING is put in their place, and the rest of the file is checked to be the reference's text, line for
+# line (SHA-256 of the surviving lines == SHA-256 of the same line ranges of the reference's file).  imageBGRToIntensity therefore
+# stays the one operator of SURVEY 8 a7 without a reference pin.
+# One more flag for this file: -include cstring (cudafuncs.cu:1376 calls memset on a host array without including <cstring>; nvcc's
+# own headers declare it, hipcc's only declare the device overload).
+CF="$REF/cudafuncs.cu"
+first=$(grep -n '^texture<uchar4, 2, cudaReadModeElementType> inTex;$' "$CF" | cut -d: -f1)
+fn=$(grep -n '^void imageBGRToIntensity(' "$CF" | cut -d: -f1)
+[ "$(echo "$first" | wc -w)" = 1 ] && [ "$(echo "$fn" | wc -w)" = 1 ] && [ "$fn" -gt "$first" ] || { echo "ref_build.sh: texture anchors not found / not unique" >&2; exit 1; }
+last=$(awk -v s="$fn" 'NR > s && /^};$/ { print NR; exit }' "$CF")
+# what goes: exactly one texture declaration, one __global__ (bgr2IntensityKernel), one host function (imageBGRToIntensity)
+cut_text=$(sed -n "${first},${last}p" "$CF")
+[ "$(echo "$cut_text" | grep -c '__global__')" = 1 ] && [ "$(echo "$cut_text" | grep -c '^void ')" = 1 ] && \
+  echo "$cut_text" | grep -q 'bgr2IntensityKernel' && [ $((last - first + 1)) -le 32 ] || { echo "ref_build.sh: the cut is not the texture sampler alone" >&2; exit 1; }
+sed "${first},${last}d" "$CF" > "$OUT/src/cudafuncs_cut.cu"
+want=$( (head -n $((first - 1)) "$CF"; tail -n +$((last + 1)) "$CF") | sha256sum | cut -d' ' -f1)
+got=$(sha256sum < "$OUT/src/cudafuncs_cut.cu" | cut -d' ' -f1)
+[ "$want" = "$got" ] || { echo "ref_build.sh: surviving text of cudafuncs.cu differs from the reference's lines" >&2; exit 1; }
+echo "cudafuncs.cu: removed lines ${first}-${last} (texture sampler); surviving $(wc -l < "$OUT/src/cudafuncs_cut.cu") lines sha256 $got"
+hipify-perl -quiet-warnings "$OUT/src/cudafuncs_cut.cu" > "$OUT/src/cudafuncs.cu" 2>/dev/null
+hipcc $FLAGS -include cstring -c "$OUT/src/cudafuncs.cu" -o "$OUT/cudafuncs.o"
+hipcc $FLAGS -c "$HERE/ref_cudafuncs_harness.cpp" -o "$OUT/cf_harness.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_cudafuncs.so" "$OUT/cudafuncs.o" "$OUT/device_memory.o" "$OUT/cf_harness.o"
 rm -rf "$OUT"/*.o "$OUT/src"   # only the library stays: no reference text is left in the tree
-echo "built $OUT/libref_reduce.so $OUT/libref_reduce_fma.so"
+echo "built $OUT/libref_reduce.so $OUT/libref_reduce_fma.so $OUT/libref_cudafuncs.so"
