@@ -79,5 +79,15 @@ hipify-perl -quiet-warnings "$OUT/src/cudafuncs_cut.cu" > "$OUT/src/cudafuncs.cu
 hipcc $FLAGS -include cstring -c "$OUT/src/cudafuncs.cu" -o "$OUT/cudafuncs.o"
 hipcc $FLAGS -c "$HERE/ref_cudafuncs_harness.cpp" -o "$OUT/cf_harness.o"
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libref_cudafuncs.so" "$OUT/cudafuncs.o" "$OUT/device_memory.o" "$OUT/cf_harness.o"
+# ---- fourth library: a host for the reference's GLSL programs (Shaders/*.vert, *.geom, *.frag) on the image's Mesa llvmpipe ->
+# libref_gl.so.  Nothing of the reference is compiled INTO it: ref_gl_harness.c is ours (context, textures, buffers, uniforms, the
+# draw-call sequences of IndexMap.cpp / GlobalModel.cpp / Shaders/*.cpp restated) and reads the shader files from the reference
+# tree at RUN time; Mesa's GLSL compiler builds them then (oracle/ref_gl.py, tests/golden/make_ref_glsl_golden.py).  Needs the
+# image's GL headers (GL/gl.h, GL/glext.h, GL/internal/dri_interface.h) and, at run time, its swrast_dri.so + libglapi.so.0.
+if [ -f /usr/include/GL/internal/dri_interface.h ]; then
+  gcc -O2 -std=gnu11 -fPIC -shared -Wall -Wno-unused-function -o "$OUT/libref_gl.so" "$HERE/ref_gl_harness.c" -ldl
+else
+  echo "ref_build.sh: no GL/internal/dri_interface.h in this image: libref_gl.so not built" >&2
+fi
 rm -rf "$OUT"/*.o "$OUT/src"   # only the library stays: no reference text is left in the tree
-echo "built $OUT/libref_reduce.so $OUT/libref_reduce_fma.so $OUT/libref_cudafuncs.so"
+echo "built $(ls "$OUT"/*.so | tr "\n" " ")"

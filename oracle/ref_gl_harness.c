@@ -1,0 +1,809 @@
+/* Test infrastructure, compiled only by oracle/ref_build.sh into oracle/_ref/libref_gl.so.
+ *
+ * Runs the REFERENCE's own GLSL programs - elasticfusion/Core/src/Shaders/ *.vert / *.geom / *.frag / *.glsl, read at RUN time from
+ * the directory handed to rgl_init (they are never copied into this repository) - on the image's own OpenGL implementation:
+ * Mesa 23.2 llvmpipe (a conformant software OpenGL 4.5, /usr/lib/x86_64-linux-gnu/dri/swrast_dri.so), reached without an X
+ * server through Mesa's public driver interface (GL/internal/dri_interface.h, the header the image installs for exactly this).
+ * Everything that computes is the reference's shader text compiled by Mesa's GLSL compiler; this file is the host side a GL
+ * program needs: context, textures, buffers, uniforms, draw calls.  The reference's own host side (IndexMap.cpp, GlobalModel.cpp,
+ * Shaders/{ComputePack,FeedbackBuffer,FillIn}.cpp) needs Pangolin, Eigen and CUDA-GL interop, none of which the image has, so
+ * the CALL SEQUENCES of those files are restated here, each function citing the lines it follows: same programs, same uniforms,
+ * same attribute layout (Shaders/Vertex.cpp: 15 floats = pos.xyz conf | colour 0 initTime stamp | times[3] | normal.xyz radius),
+ * same framebuffer attachments, same clear / depth-test / point-size state, same draw calls.
+ *
+ * Differences from the reference's host code, all of them:
+ *   - texture formats: the reference allocates legacy LUMINANCE32F / LUMINANCE16UI / LUMINANCE32UI textures (Context.h:162-177,
+ *     IndexMap.cpp:27-29); one-channel RED formats of the same width are used (R32F / R16UI / R32UI): a sampler returns the same
+ *     .x and a fragment output writes the same single channel (core-profile GL has no LUMINANCE render targets);
+ *   - transform-feedback varyings are named before linking (glTransformFeedbackVaryings, core GL) where the reference names them
+ *     after linking through NV_transform_feedback (GlobalModel.cpp:117-177): the same four varyings, interleaved;
+ *   - glDrawTransformFeedback(model.second) is issued as glDrawArrays(0, count) with the count the caller passes (the feedback
+ *     object's count is exactly that number; gl_VertexID runs 0..count-1 either way);
+ *   - Pangolin's `#include "x.glsl"` pre-processing (GlSlProgram::AddShaderFromFile with an include path) is done here by textual
+ *     insertion, which is what Pangolin does;
+ *   - integer colour attachments are cleared with glClearBuffer (glClear on them is undefined in the specification);
+ *   - the deformation-node texture is 16384 texels wide instead of 32768 (llvmpipe's maximum), see rgl_model_clean.
+ *   - texture filters: Pangolin's GlTexture(w, h, fmt, sampling_linear = GPUTexture::draw, ...) gives LINEAR to the RGB and the raw
+ *     metric depth textures (Context.h:158-160, :171-173: draw = true) and NEAREST to everything else, all CLAMP_TO_EDGE.  Every
+ *     lookup the compute shaders make into those two textures is at a texel CENTRE (the uv buffer, +- 1 / cols, +- 1 / rows), where
+ *     a hardware texture unit returns the texel itself: its bilinear weights are 8-bit fixed point (CUDA Programming Guide, "Texture
+ *     Fetching": 9-bit fixed point with 8 fractional bits), so the 1e-5 by which a centre computed in float misses the exact centre
+ *     vanishes.  llvmpipe evaluates the weights in full float precision and lets 1e-5 of the neighbour leak in - enough to give a
+ *     pixel WITHOUT depth a tiny positive z next to a valid one (vertex_feedback then emits it: 18 741 instead of 18 584 surfels on
+ *     a 160 x 120 frame, and the raw / filtered feedback buffers no longer pair up).  NEAREST is therefore used for these two as
+ *     well: it is what the reference's hardware computes.  rgl_set_linear(1) restores the literal setting (for that experiment).
+ * Depth renderbuffers are DEPTH_COMPONENT24 (Pangolin's GlRenderBuffer default); depth test on, LESS (GUI/src/Tools/GUI.h:73-75).
+ */
+
+#include <GL/gl.h>
+#include <GL/glext.h>
+#include <GL/internal/dri_interface.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- GL entry points through Mesa's dispatch (libglapi) ---------------------------------------------------------------------- */
+#define GLFUNCS(X)                                                                                                               \
+  X(PFNGLCREATESHADERPROC, glCreateShader) X(PFNGLSHADERSOURCEPROC, glShaderSource) X(PFNGLCOMPILESHADERPROC, glCompileShader)   \
+  X(PFNGLGETSHADERIVPROC, glGetShaderiv) X(PFNGLGETSHADERINFOLOGPROC, glGetShaderInfoLog) X(PFNGLCREATEPROGRAMPROC, glCreateProgram) \
+  X(PFNGLATTACHSHADERPROC, glAttachShader) X(PFNGLLINKPROGRAMPROC, glLinkProgram) X(PFNGLGETPROGRAMIVPROC, glGetProgramiv)       \
+  X(PFNGLGETPROGRAMINFOLOGPROC, glGetProgramInfoLog) X(PFNGLUSEPROGRAMPROC, glUseProgram)                                         \
+  X(PFNGLGETUNIFORMLOCATIONPROC, glGetUniformLocation) X(PFNGLUNIFORM1IPROC, glUniform1i) X(PFNGLUNIFORM1FPROC, glUniform1f)       \
+  X(PFNGLUNIFORM4FPROC, glUniform4f) X(PFNGLUNIFORMMATRIX4FVPROC, glUniformMatrix4fv)                                             \
+  X(PFNGLTRANSFORMFEEDBACKVARYINGSPROC, glTransformFeedbackVaryings) X(PFNGLGENBUFFERSPROC, glGenBuffers)                         \
+  X(PFNGLBINDBUFFERPROC, glBindBuffer) X(PFNGLBUFFERDATAPROC, glBufferData) X(PFNGLGETBUFFERSUBDATAPROC, glGetBufferSubData)       \
+  X(PFNGLDELETEBUFFERSPROC, glDeleteBuffers) X(PFNGLBINDBUFFERBASEPROC, glBindBufferBase)                                         \
+  X(PFNGLBEGINTRANSFORMFEEDBACKPROC, glBeginTransformFeedback) X(PFNGLENDTRANSFORMFEEDBACKPROC, glEndTransformFeedback)           \
+  X(PFNGLGENQUERIESPROC, glGenQueries) X(PFNGLBEGINQUERYPROC, glBeginQuery) X(PFNGLENDQUERYPROC, glEndQuery)                       \
+  X(PFNGLGETQUERYOBJECTUIVPROC, glGetQueryObjectuiv) X(PFNGLGENVERTEXARRAYSPROC, glGenVertexArrays)                               \
+  X(PFNGLBINDVERTEXARRAYPROC, glBindVertexArray) X(PFNGLENABLEVERTEXATTRIBARRAYPROC, glEnableVertexAttribArray)                   \
+  X(PFNGLDISABLEVERTEXATTRIBARRAYPROC, glDisableVertexAttribArray) X(PFNGLVERTEXATTRIBPOINTERPROC, glVertexAttribPointer)         \
+  X(PFNGLGENFRAMEBUFFERSPROC, glGenFramebuffers) X(PFNGLBINDFRAMEBUFFERPROC, glBindFramebuffer)                                   \
+  X(PFNGLFRAMEBUFFERTEXTURE2DPROC, glFramebufferTexture2D) X(PFNGLGENRENDERBUFFERSPROC, glGenRenderbuffers)                       \
+  X(PFNGLBINDRENDERBUFFERPROC, glBindRenderbuffer) X(PFNGLRENDERBUFFERSTORAGEPROC, glRenderbufferStorage)                         \
+  X(PFNGLFRAMEBUFFERRENDERBUFFERPROC, glFramebufferRenderbuffer) X(PFNGLCHECKFRAMEBUFFERSTATUSPROC, glCheckFramebufferStatus)     \
+  X(PFNGLDRAWBUFFERSPROC, glDrawBuffers) X(PFNGLDELETEFRAMEBUFFERSPROC, glDeleteFramebuffers)                                     \
+  X(PFNGLDELETERENDERBUFFERSPROC, glDeleteRenderbuffers) X(PFNGLCLEARBUFFERUIVPROC, glClearBufferuiv)                             \
+  X(PFNGLCLEARBUFFERFVPROC, glClearBufferfv)
+#define DECL(T, n) static T n;
+GLFUNCS(DECL)
+/* GL 1.x entry points (not exported by libglapi as symbols either: fetched the same way) */
+static void (*p_glGenTextures)(GLsizei, GLuint*);
+static void (*p_glBindTexture)(GLenum, GLuint);
+static void (*p_glTexImage2D)(GLenum, GLint, GLint, GLsizei, GLsizei, GLint, GLenum, GLenum, const void*);
+static void (*p_glTexParameteri)(GLenum, GLenum, GLint);
+static void (*p_glGetTexImage)(GLenum, GLint, GLenum, GLenum, void*);
+static void (*p_glDeleteTextures)(GLsizei, const GLuint*);
+static void (*p_glViewport)(GLint, GLint, GLsizei, GLsizei);
+static void (*p_glClearColor)(GLfloat, GLfloat, GLfloat, GLfloat);
+static void (*p_glClear)(GLbitfield);
+static void (*p_glEnable)(GLenum);
+static void (*p_glDisable)(GLenum);
+static void (*p_glDepthFunc)(GLenum);
+static void (*p_glDepthMask)(GLboolean);
+static void (*p_glDrawArrays)(GLenum, GLint, GLsizei);
+static void (*p_glFinish)(void);
+static GLenum (*p_glGetError)(void);
+static const GLubyte* (*p_glGetString)(GLenum);
+static void (*p_glPixelStorei)(GLenum, GLint);
+static void (*p_glActiveTexture)(GLenum);
+
+static char g_dir[1024];
+static char g_err[4096];
+static int g_ready = 0;
+static GLuint g_vao;
+static int g_linear = 0; /* see the header: filter of the RGB / raw metric depth textures */
+void rgl_set_linear(int on) { g_linear = on ? 1 : 0; }
+
+/* ---- context: Mesa's software rasteriser through its DRI driver interface ------------------------------------------------------ */
+static void getDrawableInfo(__DRIdrawable* d, int* x, int* y, int* w, int* h, void* p) { (void)d; (void)p; *x = *y = 0; *w = *h = 16; }
+static void putImage(__DRIdrawable* d, int op, int x, int y, int w, int h, char* data, void* p) { (void)d; (void)op; (void)x; (void)y; (void)w; (void)h; (void)data; (void)p; }
+static void getImage(__DRIdrawable* d, int x, int y, int w, int h, char* data, void* p) { (void)d; (void)x; (void)y; (void)w; (void)h; (void)data; (void)p; }
+static const __DRIswrastLoaderExtension swrastLoader = {{__DRI_SWRAST_LOADER, 1}, getDrawableInfo, putImage, getImage};
+static const __DRIextension* loader_ext[] = {&swrastLoader.base, NULL};
+
+static int fail(const char* what, const char* detail) {
+  snprintf(g_err, sizeof g_err, "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+  return -1;
+}
+const char* rgl_error(void) { return g_err; }
+
+static int make_context(void) {
+  const char* paths[] = {"/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so", "swrast_dri.so", NULL};
+  void* h = NULL;
+  for (int i = 0; paths[i] && !h; i++) h = dlopen(paths[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail("Mesa's swrast_dri.so not found", dlerror());
+  const __DRIextension** (*get)(void) = (const __DRIextension** (*)(void))dlsym(h, "__driDriverGetExtensions_swrast");
+  if (!get) return fail("__driDriverGetExtensions_swrast missing", NULL);
+  const __DRIextension** ext = get();
+  const __DRIcoreExtension* core = NULL;
+  const __DRIswrastExtension* sw = NULL;
+  for (int i = 0; ext[i]; i++) {
+    if (!strcmp(ext[i]->name, __DRI_CORE)) core = (const __DRIcoreExtension*)ext[i];
+    if (!strcmp(ext[i]->name, __DRI_SWRAST)) sw = (const __DRIswrastExtension*)ext[i];
+  }
+  if (!core || !sw || sw->base.version < 4) return fail("DRI_Core / DRI_SWRast (v4) not offered by the driver", NULL);
+  const __DRIconfig** configs = NULL;
+  __DRIscreen* scr = sw->createNewScreen2(0, loader_ext, ext, &configs, NULL);
+  if (!scr || !configs || !configs[0]) return fail("createNewScreen2 failed", NULL);
+  unsigned err = 0;
+  uint32_t attribs[] = {__DRI_CTX_ATTRIB_MAJOR_VERSION, 4, __DRI_CTX_ATTRIB_MINOR_VERSION, 5};
+  __DRIcontext* ctx = sw->createContextAttribs(scr, __DRI_API_OPENGL_CORE, configs[0], NULL, 2, attribs, &err, NULL);
+  if (!ctx) return fail("no OpenGL 4.5 core context from llvmpipe", NULL);
+  __DRIdrawable* dr = sw->createNewDrawable(scr, configs[0], NULL);
+  if (!dr || !core->bindContext(ctx, dr, dr)) return fail("bindContext failed", NULL);
+  void* glapi = dlopen("libglapi.so.0", RTLD_NOW | RTLD_GLOBAL);
+  if (!glapi) return fail("libglapi.so.0 not found", dlerror());
+  void* (*gpa)(const char*) = (void* (*)(const char*))dlsym(glapi, "_glapi_get_proc_address");
+  if (!gpa) return fail("_glapi_get_proc_address missing", NULL);
+#define LOAD(T, n)                                 \
+  n = (T)gpa(#n);                                  \
+  if (!n) return fail("GL entry point missing", #n);
+  GLFUNCS(LOAD)
+#define LOAD1(n)                                   \
+  *(void**)(&p_##n) = gpa(#n);                     \
+  if (!p_##n) return fail("GL entry point missing", #n);
+  LOAD1(glGenTextures) LOAD1(glBindTexture) LOAD1(glTexImage2D) LOAD1(glTexParameteri) LOAD1(glGetTexImage) LOAD1(glDeleteTextures)
+  LOAD1(glViewport) LOAD1(glClearColor) LOAD1(glClear) LOAD1(glEnable) LOAD1(glDisable) LOAD1(glDepthFunc) LOAD1(glDepthMask)
+  LOAD1(glDrawArrays) LOAD1(glFinish) LOAD1(glGetError) LOAD1(glGetString) LOAD1(glPixelStorei) LOAD1(glActiveTexture)
+  return 0;
+}
+
+/* ---- shader files: read where they lie, #include expanded as Pangolin does ------------------------------------------------------ */
+static char* read_file(const char* name) {
+  char path[1400];
+  snprintf(path, sizeof path, "%s/%s", g_dir, name);
+  FILE* f = fopen(path, "rb");
+  if (!f) { fail("cannot read shader", path); return NULL; }
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char* s = (char*)malloc(n + 1);
+  if (fread(s, 1, n, f) != (size_t)n) { fclose(f); free(s); fail("short read", path); return NULL; }
+  s[n] = 0;
+  fclose(f);
+  return s;
+}
+static char* expand(const char* name, int depth) {
+  char* src = read_file(name);
+  if (!src || depth > 4) return src;
+  size_t cap = strlen(src) + 1, len = 0;
+  char* out = (char*)malloc(cap);
+  out[0] = 0;
+  for (char* line = src; *line;) {
+    char* nl = strchr(line, '\n');
+    size_t ll = nl ? (size_t)(nl - line) + 1 : strlen(line);
+    char inc[256], one[512];
+    char* piece = NULL;
+    size_t cl = ll < sizeof one - 1 ? ll : sizeof one - 1;
+    memcpy(one, line, cl);
+    one[cl] = 0;
+    if (sscanf(one, " #include \"%255[^\"]\"", inc) == 1) {
+      piece = expand(inc, depth + 1);
+      if (!piece) { free(src); free(out); return NULL; }
+    }
+    size_t pl = piece ? strlen(piece) + 1 : ll;
+    if (len + pl + 1 > cap) { cap = (len + pl + 1) * 2; out = (char*)realloc(out, cap); }
+    if (piece) { memcpy(out + len, piece, pl - 1); out[len + pl - 1] = '\n'; free(piece); } else memcpy(out + len, line, ll);
+    len += pl;
+    out[len] = 0;
+    line += ll;
+  }
+  free(src);
+  return out;
+}
+static GLuint compile(GLenum type, const char* name) {
+  char* src = expand(name, 0);
+  if (!src) return 0;
+  GLuint s = glCreateShader(type);
+  const char* p = src;
+  glShaderSource(s, 1, &p, NULL);
+  glCompileShader(s);
+  GLint ok = 0;
+  glGetShaderiv(s, GL_COMPILE_STATUS, &ok);
+  free(src);
+  if (!ok) {
+    char log[3000];
+    glGetShaderInfoLog(s, sizeof log, NULL, log);
+    char msg[3400];
+    snprintf(msg, sizeof msg, "%s: %s", name, log);
+    fail("GLSL compile error", msg);
+    return 0;
+  }
+  return s;
+}
+static const char* TF4[] = {"vPosition0", "vColor0", "vTimes0", "vNormRad0"};
+/* loadProgramFromFile / loadProgramGeomFromFile (Shaders/Shaders.h:69-111); tf != 0: the four interleaved feedback varyings */
+static GLuint program(const char* vs, const char* gs, const char* fs, int tf) {
+  GLuint p = glCreateProgram(), s;
+  if (!(s = compile(GL_VERTEX_SHADER, vs))) return 0;
+  glAttachShader(p, s);
+  if (gs) { if (!(s = compile(GL_GEOMETRY_SHADER, gs))) return 0; glAttachShader(p, s); }
+  if (fs) { if (!(s = compile(GL_FRAGMENT_SHADER, fs))) return 0; glAttachShader(p, s); }
+  if (tf) glTransformFeedbackVaryings(p, 4, TF4, GL_INTERLEAVED_ATTRIBS);
+  glLinkProgram(p);
+  GLint ok = 0;
+  glGetProgramiv(p, GL_LINK_STATUS, &ok);
+  if (!ok) {
+    char log[3000];
+    glGetProgramInfoLog(p, sizeof log, NULL, log);
+    char msg[3400];
+    snprintf(msg, sizeof msg, "%s: %s", vs, log);
+    fail("GLSL link error", msg);
+    return 0;
+  }
+  return p;
+}
+static void u1i(GLuint p, const char* n, int v) { glUniform1i(glGetUniformLocation(p, n), v); }
+static void u1f(GLuint p, const char* n, float v) { glUniform1f(glGetUniformLocation(p, n), v); }
+static void u4f(GLuint p, const char* n, float a, float b, float c, float d) { glUniform4f(glGetUniformLocation(p, n), a, b, c, d); }
+/* Uniform::MAT4: glUniformMatrix4fv(loc, 1, false, m4.data()) with Eigen's column-major storage (Shaders.h:63).  The callers of
+ * this file pass row-major 4 x 4 arrays, transposed here into that storage. */
+static void um4(GLuint p, const char* n, const float* rowmajor) {
+  float cm[16];
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) cm[c * 4 + r] = rowmajor[r * 4 + c];
+  glUniformMatrix4fv(glGetUniformLocation(p, n), 1, GL_FALSE, cm);
+}
+
+/* ---- textures / framebuffers ----------------------------------------------------------------------------------------------------- */
+static GLuint tex2d(int w, int h, GLint ifmt, GLenum fmt, GLenum type, const void* data, int linear) {
+  GLuint t;
+  p_glGenTextures(1, &t);
+  p_glBindTexture(GL_TEXTURE_2D, t);
+  p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+  p_glTexImage2D(GL_TEXTURE_2D, 0, ifmt, w, h, 0, fmt, type, data);
+  p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, linear ? GL_LINEAR : GL_NEAREST); /* pangolin::GlTexture::Reinitialise */
+  p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, linear ? GL_LINEAR : GL_NEAREST);
+  p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+  p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+  p_glBindTexture(GL_TEXTURE_2D, 0);
+  return t;
+}
+static void tex_read(GLuint t, GLenum fmt, GLenum type, void* out) {
+  p_glBindTexture(GL_TEXTURE_2D, t);
+  p_glPixelStorei(GL_PACK_ALIGNMENT, 1);
+  p_glGetTexImage(GL_TEXTURE_2D, 0, fmt, type, out);
+  p_glBindTexture(GL_TEXTURE_2D, 0);
+}
+typedef struct { GLuint fbo, rbo; int n; } Fbo;
+/* pangolin::GlFramebuffer::AttachColour x n + AttachDepth(GlRenderBuffer(w, h) = DEPTH_COMPONENT24) */
+static int fbo_make(Fbo* f, int w, int h, const GLuint* tex, int n) {
+  glGenFramebuffers(1, &f->fbo);
+  glBindFramebuffer(GL_FRAMEBUFFER, f->fbo);
+  GLenum bufs[8];
+  for (int i = 0; i < n; i++) {
+    glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0 + i, GL_TEXTURE_2D, tex[i], 0);
+    bufs[i] = GL_COLOR_ATTACHMENT0 + i;
+  }
+  glGenRenderbuffers(1, &f->rbo);
+  glBindRenderbuffer(GL_RENDERBUFFER, f->rbo);
+  glRenderbufferStorage(GL_RENDERBUFFER, GL_DEPTH_COMPONENT24, w, h);
+  glFramebufferRenderbuffer(GL_FRAMEBUFFER, GL_DEPTH_ATTACHMENT, GL_RENDERBUFFER, f->rbo);
+  glDrawBuffers(n, bufs);
+  f->n = n;
+  if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) return fail("framebuffer incomplete", NULL);
+  return 0;
+}
+static void fbo_free(Fbo* f) {
+  glBindFramebuffer(GL_FRAMEBUFFER, 0);
+  glDeleteFramebuffers(1, &f->fbo);
+  glDeleteRenderbuffers(1, &f->rbo);
+}
+/* glClearColor(0,0,0,0); glClear(COLOR | DEPTH): integer attachments (bit i of int_mask) through glClearBuffer */
+static void clear_all(const Fbo* f, unsigned int_mask) {
+  p_glClearColor(0, 0, 0, 0);
+  p_glClear(GL_DEPTH_BUFFER_BIT);
+  const GLuint zu[4] = {0, 0, 0, 0};
+  const GLfloat zf[4] = {0, 0, 0, 0};
+  for (int i = 0; i < f->n; i++) {
+    if (int_mask & (1u << i)) glClearBufferuiv(GL_COLOR, i, zu); else glClearBufferfv(GL_COLOR, i, zf);
+  }
+}
+static int gl_ok(const char* where) {
+  GLenum e = p_glGetError();
+  if (e != GL_NO_ERROR) {
+    char m[64];
+    snprintf(m, sizeof m, "0x%x", e);
+    return fail(where, m);
+  }
+  return 0;
+}
+
+#define SURFEL_FLOATS 15 /* Vertex::SIZE = 60 bytes (Shaders/Vertex.cpp:21-50), Vertex::MAX_SENSORS = 3 */
+#define SURFEL_BYTES (SURFEL_FLOATS * 4)
+/* the attribute layout every map pass sets up (IndexMap.cpp:181-198, GlobalModel.cpp:611-631): 0 = pos+conf, 1 = colour quad,
+ * 2..4 = one float per sensor time, 5 = normal+radius */
+static void surfel_attribs(void) {
+  glEnableVertexAttribArray(0);
+  glVertexAttribPointer(0, 4, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)0);
+  glEnableVertexAttribArray(1);
+  glVertexAttribPointer(1, 4, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)16);
+  for (int i = 0; i < 3; i++) {
+    glEnableVertexAttribArray(2 + i);
+    glVertexAttribPointer(2 + i, 1, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)(size_t)(32 + 4 * i));
+  }
+  glEnableVertexAttribArray(5);
+  glVertexAttribPointer(5, 4, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)(size_t)(32 + 12));
+}
+static void no_attribs(void) { for (int i = 0; i < 6; i++) glDisableVertexAttribArray(i); }
+static GLuint vbo_make(const void* data, size_t bytes) {
+  GLuint b;
+  glGenBuffers(1, &b);
+  glBindBuffer(GL_ARRAY_BUFFER, b);
+  glBufferData(GL_ARRAY_BUFFER, bytes ? bytes : 4, data, GL_STREAM_DRAW);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  return b;
+}
+/* the per-pixel texture-coordinate buffer of FeedbackBuffer / GlobalModel (FeedbackBuffer.cpp:41-50, GlobalModel.cpp:92-103):
+ * COLUMN-major pixel order (outer loop over x), coordinates computed in double from float quotients and stored as floats */
+static GLuint uv_make(int width, int height) {
+  float* uv = (float*)malloc((size_t)width * height * 8);
+  size_t k = 0;
+  for (int i = 0; i < width; i++)
+    for (int j = 0; j < height; j++) {
+      uv[k++] = (float)(((float)i / (float)width) + 1.0 / (2 * (float)width));
+      uv[k++] = (float)(((float)j / (float)height) + 1.0 / (2 * (float)height));
+    }
+  GLuint b = vbo_make(uv, (size_t)width * height * 8);
+  free(uv);
+  return b;
+}
+
+/* ================================================================================================================================== */
+int rgl_init(const char* shader_dir) {
+  if (g_ready) return 0;
+  snprintf(g_dir, sizeof g_dir, "%s", shader_dir);
+  if (make_context()) return -1;
+  glGenVertexArrays(1, &g_vao); /* a core profile needs one bound; the reference runs in a compatibility context with the default one */
+  glBindVertexArray(g_vao);
+  p_glEnable(GL_DEPTH_TEST); /* GUI.h:73-75 */
+  p_glDepthMask(GL_TRUE);
+  p_glDepthFunc(GL_LESS);
+  g_ready = 1;
+  return gl_ok("rgl_init");
+}
+const char* rgl_renderer(void) { return g_ready ? (const char*)p_glGetString(GL_RENDERER) : ""; }
+const char* rgl_version(void) { return g_ready ? (const char*)p_glGetString(GL_VERSION) : ""; }
+
+/* ComputePack::compute (Shaders/ComputePack.cpp:44-73) with one input texture on unit 0 and one output attachment: the programs of
+ * Context.h:189-199 (empty.vert + quad.geom + <frag>), one point drawn, the geometry shader turns it into the full-screen quad */
+static int compute_pack(const char* frag, GLuint in_tex, GLuint out_tex, int out_is_int, int w, int h, float maxD) {
+  GLuint p = program("empty.vert", "quad.geom", frag, 0);
+  if (!p) return -1;
+  Fbo f;
+  if (fbo_make(&f, w, h, &out_tex, 1)) return -1;
+  p_glActiveTexture(GL_TEXTURE0);
+  p_glBindTexture(GL_TEXTURE_2D, in_tex); /* input->Bind() */
+  p_glViewport(0, 0, w, h);
+  clear_all(&f, out_is_int ? 1u : 0u);
+  glUseProgram(p);
+  u1f(p, "cols", (float)w); /* ElasticFusion.cpp:748-768: the uniform lists of filterDepth / metriciseDepth */
+  u1f(p, "rows", (float)h);
+  u1f(p, "maxD", maxD);
+  p_glDrawArrays(GL_POINTS, 0, 1);
+  p_glFinish();
+  glUseProgram(0);
+  fbo_free(&f);
+  return gl_ok(frag);
+}
+
+/* ElasticFusion::filterDepth (ElasticFusion.cpp:748-757): depth_bilateral.frag, u16 -> u16 */
+int rgl_depth_bilateral(const uint16_t* src, int rows, int cols, float maxD, uint16_t* dst) {
+  GLuint in = tex2d(cols, rows, GL_R16UI, GL_RED_INTEGER, GL_UNSIGNED_SHORT, src, 0);
+  GLuint out = tex2d(cols, rows, GL_R16UI, GL_RED_INTEGER, GL_UNSIGNED_SHORT, NULL, 0);
+  int rc = compute_pack("depth_bilateral.frag", in, out, 1, cols, rows, maxD);
+  if (!rc) tex_read(out, GL_RED_INTEGER, GL_UNSIGNED_SHORT, dst);
+  p_glDeleteTextures(1, &in);
+  p_glDeleteTextures(1, &out);
+  return rc;
+}
+/* ElasticFusion::metriciseDepth (:759-768): depth_metric.frag, u16 -> f32 */
+int rgl_depth_metric(const uint16_t* src, int rows, int cols, float maxD, float* dst) {
+  GLuint in = tex2d(cols, rows, GL_R16UI, GL_RED_INTEGER, GL_UNSIGNED_SHORT, src, 0);
+  GLuint out = tex2d(cols, rows, GL_R32F, GL_RED, GL_FLOAT, NULL, 0);
+  int rc = compute_pack("depth_metric.frag", in, out, 0, cols, rows, maxD);
+  if (!rc) tex_read(out, GL_RED, GL_FLOAT, dst);
+  p_glDeleteTextures(1, &in);
+  p_glDeleteTextures(1, &out);
+  return rc;
+}
+
+/* FeedbackBuffer::compute (Shaders/FeedbackBuffer.cpp:84-143): vertex_feedback.vert + .geom over every pixel (column-major uv
+ * buffer), transform feedback of the pixels with depth.  depth_linear: the raw metric depth texture is LINEAR-filtered, the
+ * filtered one NEAREST (Context.h:171-177); the RGB texture is LINEAR (Context.h:158-160).  Returns the count. */
+int rgl_vertex_feedback(const uint8_t* rgba, const float* depth_metric, int rows, int cols, float cx, float cy, float fx, float fy,
+                        int time, int timeIdx, float maxDepth, int depth_linear, float* out_surfels) {
+  GLuint p = program("vertex_feedback.vert", "vertex_feedback.geom", NULL, 1);
+  if (!p) return -1;
+  GLuint tc = tex2d(cols, rows, GL_RGBA8, GL_RGBA, GL_UNSIGNED_BYTE, rgba, g_linear);
+  GLuint td = tex2d(cols, rows, GL_R32F, GL_RED, GL_FLOAT, depth_metric, depth_linear && g_linear);
+  GLuint uv = uv_make(cols, rows);
+  GLuint out = vbo_make(NULL, (size_t)rows * cols * SURFEL_BYTES), q;
+  glGenQueries(1, &q);
+  glUseProgram(p);
+  u4f(p, "cam", cx, cy, 1.0f / fx, 1.0f / fy);
+  u1f(p, "threshold", 0.0f);
+  u1f(p, "cols", (float)cols);
+  u1f(p, "rows", (float)rows);
+  u1i(p, "time", time);
+  u1i(p, "timeIdx", timeIdx);
+  u1i(p, "gSampler", 0);
+  u1i(p, "cSampler", 1);
+  u1f(p, "maxDepth", maxDepth);
+  glEnableVertexAttribArray(0);
+  glBindBuffer(GL_ARRAY_BUFFER, uv);
+  glVertexAttribPointer(0, 2, GL_FLOAT, GL_FALSE, 0, 0);
+  p_glEnable(GL_RASTERIZER_DISCARD);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, out);
+  glBeginTransformFeedback(GL_POINTS);
+  glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
+  p_glActiveTexture(GL_TEXTURE0);
+  p_glBindTexture(GL_TEXTURE_2D, td);
+  p_glActiveTexture(GL_TEXTURE1);
+  p_glBindTexture(GL_TEXTURE_2D, tc);
+  p_glDrawArrays(GL_POINTS, 0, rows * cols);
+  glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
+  glEndTransformFeedback();
+  p_glDisable(GL_RASTERIZER_DISCARD);
+  no_attribs();
+  p_glFinish();
+  GLuint n = 0;
+  glGetQueryObjectuiv(q, GL_QUERY_RESULT, &n);
+  glBindBuffer(GL_ARRAY_BUFFER, out);
+  if (n) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)n * SURFEL_BYTES, out_surfels);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  glUseProgram(0);
+  glDeleteBuffers(1, &uv);
+  glDeleteBuffers(1, &out);
+  p_glDeleteTextures(1, &tc);
+  p_glDeleteTextures(1, &td);
+  return gl_ok("vertex_feedback") ? -1 : (int)n;
+}
+
+/* GlobalModel::initialise (GlobalModel.cpp:336-417): init_unstable.vert, attributes 0..4 from the RAW feedback buffer, attribute 5
+ * (normal, radius) from the FILTERED one, n records each */
+int rgl_model_initialise(const float* raw, const float* filtered, int n, float* out_surfels) {
+  GLuint p = program("init_unstable.vert", NULL, NULL, 1);
+  if (!p) return -1;
+  GLuint braw = vbo_make(raw, (size_t)n * SURFEL_BYTES), bfil = vbo_make(filtered, (size_t)n * SURFEL_BYTES);
+  GLuint out = vbo_make(NULL, (size_t)(n ? n : 1) * SURFEL_BYTES), q;
+  glGenQueries(1, &q);
+  glUseProgram(p);
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  um4(p, "t_inv", I);
+  glBindBuffer(GL_ARRAY_BUFFER, braw);
+  surfel_attribs();
+  glBindBuffer(GL_ARRAY_BUFFER, bfil);
+  glVertexAttribPointer(5, 4, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)(size_t)(32 + 12));
+  p_glEnable(GL_RASTERIZER_DISCARD);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, out);
+  glBeginTransformFeedback(GL_POINTS);
+  glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
+  p_glDrawArrays(GL_POINTS, 0, n);
+  glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
+  glEndTransformFeedback();
+  p_glDisable(GL_RASTERIZER_DISCARD);
+  no_attribs();
+  p_glFinish();
+  GLuint m = 0;
+  glGetQueryObjectuiv(q, GL_QUERY_RESULT, &m);
+  glBindBuffer(GL_ARRAY_BUFFER, out);
+  if (m) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)m * SURFEL_BYTES, out_surfels);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  glUseProgram(0);
+  glDeleteBuffers(1, &braw);
+  glDeleteBuffers(1, &bfil);
+  glDeleteBuffers(1, &out);
+  return gl_ok("model_initialise") ? -1 : (int)m;
+}
+
+/* IndexMap::predictIndices (IndexMap.cpp:146-217): index_map.vert + .frag, one GL point per surfel, four attachments.
+ * t_inv16: the INVERSE pose (row-major), computed by the caller (the reference: Eigen's pose.inverse(), :162). */
+int rgl_index_map(const float* model, int M, const float* t_inv16, float cx, float cy, float fx, float fy, int rows, int cols, int time,
+                  int timeIdx, float maxDepth, int timeDelta, uint32_t* index, float* vertConf, float* colorTime, float* normRad) {
+  GLuint p = program("index_map.vert", NULL, "index_map.frag", 0);
+  if (!p) return -1;
+  GLuint t[4] = {tex2d(cols, rows, GL_R32UI, GL_RED_INTEGER, GL_UNSIGNED_INT, NULL, 0), tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0),
+                 tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0), tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0)};
+  Fbo f;
+  if (fbo_make(&f, cols, rows, t, 4)) return -1;
+  GLuint vb = vbo_make(model, (size_t)M * SURFEL_BYTES);
+  p_glViewport(0, 0, cols, rows);
+  clear_all(&f, 1u);
+  glUseProgram(p);
+  um4(p, "t_inv", t_inv16);
+  u4f(p, "cam", cx, cy, fx, fy); /* IndexMap::FACTOR = 1 */
+  u1f(p, "maxDepth", maxDepth);
+  u1f(p, "cols", (float)cols);
+  u1f(p, "rows", (float)rows);
+  u1i(p, "time", time);
+  u1i(p, "timeIdx", timeIdx);
+  u1i(p, "timeDelta", timeDelta);
+  glBindBuffer(GL_ARRAY_BUFFER, vb);
+  surfel_attribs();
+  p_glDrawArrays(GL_POINTS, 0, M);
+  no_attribs();
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  p_glFinish();
+  glUseProgram(0);
+  tex_read(t[0], GL_RED_INTEGER, GL_UNSIGNED_INT, index);
+  tex_read(t[1], GL_RGBA, GL_FLOAT, vertConf);
+  tex_read(t[2], GL_RGBA, GL_FLOAT, colorTime);
+  tex_read(t[3], GL_RGBA, GL_FLOAT, normRad);
+  fbo_free(&f);
+  glDeleteBuffers(1, &vb);
+  p_glDeleteTextures(4, t);
+  return gl_ok("index_map");
+}
+
+/* IndexMap::combinedPredict (IndexMap.cpp:253-368; splat.vert + combo_splat.frag) when depth_only = 0, IndexMap::synthesizeDepth
+ * (:370-452; splat.vert + depth_splat.frag) when depth_only = 1.  GL_PROGRAM_POINT_SIZE on: the vertex shader sizes the sprite. */
+int rgl_splat(const float* model, int M, const float* t_inv16, float cx, float cy, float fx, float fy, int rows, int cols, float maxDepth,
+              float confThreshold, int time, int timeIdx, int maxTime, int timeDelta, int actv, int depth_only, uint8_t* image,
+              float* vertex, float* normal, uint16_t* timeImg, float* depth) {
+  GLuint p = program("splat.vert", NULL, depth_only ? "depth_splat.frag" : "combo_splat.frag", 0);
+  if (!p) return -1;
+  GLuint t[4];
+  int nt;
+  if (depth_only) {
+    t[0] = tex2d(cols, rows, GL_R32F, GL_RED, GL_FLOAT, NULL, 0);
+    nt = 1;
+  } else {
+    t[0] = tex2d(cols, rows, GL_RGBA8, GL_RGBA, GL_UNSIGNED_BYTE, NULL, 0);
+    t[1] = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0);
+    t[2] = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0);
+    t[3] = tex2d(cols, rows, GL_R16UI, GL_RED_INTEGER, GL_UNSIGNED_SHORT, NULL, 0);
+    nt = 4;
+  }
+  Fbo f;
+  if (fbo_make(&f, cols, rows, t, nt)) return -1;
+  GLuint vb = vbo_make(model, (size_t)M * SURFEL_BYTES);
+  p_glEnable(GL_PROGRAM_POINT_SIZE); /* (GL_POINT_SPRITE: always on in a core profile) */
+  p_glViewport(0, 0, cols, rows);
+  clear_all(&f, depth_only ? 0u : 8u);
+  glUseProgram(p);
+  um4(p, "t_inv", t_inv16);
+  u4f(p, "cam", cx, cy, fx, fy);
+  u1f(p, "maxDepth", maxDepth);
+  u1f(p, "confThreshold", confThreshold);
+  u1f(p, "cols", (float)cols);
+  u1f(p, "rows", (float)rows);
+  u1i(p, "time", time);
+  u1i(p, "timeIdx", timeIdx);
+  u1i(p, "maxTime", maxTime);
+  u1i(p, "timeDelta", timeDelta);
+  if (!depth_only) u1i(p, "actv", actv ? 1 : 0);
+  glBindBuffer(GL_ARRAY_BUFFER, vb);
+  surfel_attribs();
+  p_glDrawArrays(GL_POINTS, 0, M);
+  no_attribs();
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  p_glDisable(GL_PROGRAM_POINT_SIZE);
+  p_glFinish();
+  glUseProgram(0);
+  if (depth_only) {
+    tex_read(t[0], GL_RED, GL_FLOAT, depth);
+  } else {
+    tex_read(t[0], GL_RGBA, GL_UNSIGNED_BYTE, image);
+    tex_read(t[1], GL_RGBA, GL_FLOAT, vertex);
+    tex_read(t[2], GL_RGBA, GL_FLOAT, normal);
+    tex_read(t[3], GL_RED_INTEGER, GL_UNSIGNED_SHORT, timeImg);
+  }
+  fbo_free(&f);
+  glDeleteBuffers(1, &vb);
+  p_glDeleteTextures(nt, t);
+  return gl_ok("splat");
+}
+
+/* GlobalModel::fuse (GlobalModel.cpp:513-694).  Pass 1 "Fuse::Data": data.vert / .geom / .frag over every pixel (column-major uv
+ * buffer) into the texDim x texDim update maps (three RGBA32F attachments addressed by surfel id) with the new unstable surfels
+ * captured by transform feedback; pass 2 "Fuse::Update": update.vert over the M surfels, reading the update maps, captured into the
+ * other model buffer.  pose16: camera pose (row-major).  Returns nNew; model_out: M records. */
+int rgl_model_fuse(const float* model, int M, const float* pose16, int time, int timeIdx, const uint8_t* rgba, const float* dr,
+                   const float* drf, const uint32_t* index, const float* vertConf, const float* colorTime, const float* normRad, int rows,
+                   int cols, float cx, float cy, float fx, float fy, float maxDepth, float weighting, int texDim, float* model_out,
+                   float* newUnstable) {
+  GLuint pd = program("data.vert", "data.geom", "data.frag", 1);
+  if (!pd) return -1;
+  GLuint pu = program("update.vert", NULL, NULL, 1);
+  if (!pu) return -1;
+  GLuint um[3];
+  for (int i = 0; i < 3; i++) um[i] = tex2d(texDim, texDim, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0);
+  Fbo f;
+  if (fbo_make(&f, texDim, texDim, um, 3)) return -1;
+  GLuint trgb = tex2d(cols, rows, GL_RGBA8, GL_RGBA, GL_UNSIGNED_BYTE, rgba, g_linear);  /* RGB (Context.h:158-160) */
+  GLuint tdr = tex2d(cols, rows, GL_R32F, GL_RED, GL_FLOAT, dr, g_linear);               /* DEPTH_METRIC (:171-173) */
+  GLuint tdrf = tex2d(cols, rows, GL_R32F, GL_RED, GL_FLOAT, drf, 0);             /* DEPTH_METRIC_FILTERED: nearest (:175-177) */
+  GLuint tidx = tex2d(cols, rows, GL_R32UI, GL_RED_INTEGER, GL_UNSIGNED_INT, index, 0);
+  GLuint tvc = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, vertConf, 0);
+  GLuint tct = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, colorTime, 0);
+  GLuint tnr = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, normRad, 0);
+  GLuint uv = uv_make(cols, rows);
+  GLuint newb = vbo_make(NULL, (size_t)rows * cols * SURFEL_BYTES), q;
+  glGenQueries(1, &q);
+  /* ---- Fuse::Data (:522-584) */
+  p_glViewport(0, 0, texDim, texDim);
+  clear_all(&f, 0u);
+  glUseProgram(pd);
+  u1i(pd, "cSampler", 0); u1i(pd, "drSampler", 1); u1i(pd, "drfSampler", 2); u1i(pd, "indexSampler", 3);
+  u1i(pd, "vertConfSampler", 4); u1i(pd, "colorTimeSampler", 5); u1i(pd, "normRadSampler", 6);
+  u1f(pd, "time", (float)time);
+  u1i(pd, "timeIdx", timeIdx);
+  u1f(pd, "weighting", weighting);
+  u4f(pd, "cam", cx, cy, (float)(1.0 / fx), (float)(1.0 / fy)); /* Eigen::Vector4f(cx, cy, 1.0 / fx, 1.0 / fy): double quotients */
+  u1f(pd, "cols", (float)cols);
+  u1f(pd, "rows", (float)rows);
+  u1f(pd, "scale", 1.0f);
+  u1f(pd, "texDim", (float)texDim);
+  um4(pd, "pose", pose16);
+  u1f(pd, "maxDepth", maxDepth);
+  glEnableVertexAttribArray(0);
+  glBindBuffer(GL_ARRAY_BUFFER, uv);
+  glVertexAttribPointer(0, 2, GL_FLOAT, GL_FALSE, 0, 0);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, newb);
+  const GLuint tx[7] = {trgb, tdr, tdrf, tidx, tvc, tct, tnr};
+  for (int i = 0; i < 7; i++) { p_glActiveTexture(GL_TEXTURE0 + i); p_glBindTexture(GL_TEXTURE_2D, tx[i]); }
+  glBeginTransformFeedback(GL_POINTS);
+  glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
+  p_glDrawArrays(GL_POINTS, 0, rows * cols);
+  glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
+  glEndTransformFeedback();
+  glBindFramebuffer(GL_FRAMEBUFFER, 0);
+  no_attribs();
+  p_glFinish();
+  GLuint ntf = 0;
+  glGetQueryObjectuiv(q, GL_QUERY_RESULT, &ntf);
+  /* the feedback buffer holds BOTH kinds of emitted vertex (data.geom emits for updateId 1 and 2); the clean pass reads them all
+   * (GlobalModel.cpp:802-822) and copy_unstable.vert keeps a record only through its own tests: all of them are handed back */
+  glBindBuffer(GL_ARRAY_BUFFER, newb);
+  if (ntf) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)ntf * SURFEL_BYTES, newUnstable);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  /* ---- Fuse::Update (:588-671) */
+  GLuint src = vbo_make(model, (size_t)M * SURFEL_BYTES), dst = vbo_make(NULL, (size_t)(M ? M : 1) * SURFEL_BYTES);
+  glUseProgram(pu);
+  u1i(pu, "vertSamp", 0); u1i(pu, "colorSamp", 1); u1i(pu, "normSamp", 2);
+  u1f(pu, "texDim", (float)texDim);
+  u1i(pu, "time", time);
+  u1i(pu, "timeIdx", timeIdx);
+  glBindBuffer(GL_ARRAY_BUFFER, src);
+  surfel_attribs();
+  p_glEnable(GL_RASTERIZER_DISCARD);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, dst);
+  glBeginTransformFeedback(GL_POINTS);
+  for (int i = 0; i < 3; i++) { p_glActiveTexture(GL_TEXTURE0 + i); p_glBindTexture(GL_TEXTURE_2D, um[i]); }
+  p_glDrawArrays(GL_POINTS, 0, M);
+  glEndTransformFeedback();
+  p_glDisable(GL_RASTERIZER_DISCARD);
+  no_attribs();
+  p_glFinish();
+  glBindBuffer(GL_ARRAY_BUFFER, dst);
+  if (M) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)M * SURFEL_BYTES, model_out);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  glUseProgram(0);
+  p_glActiveTexture(GL_TEXTURE0);
+  fbo_free(&f);
+  GLuint bs[4] = {uv, newb, src, dst};
+  glDeleteBuffers(4, bs);
+  p_glDeleteTextures(3, um);
+  p_glDeleteTextures(7, tx);
+  return gl_ok("model_fuse") ? -1 : (int)ntf;
+}
+
+/* GlobalModel::clean (GlobalModel.cpp:696-853): copy_unstable.vert + .geom over the M model surfels and then the nNew records of
+ * the fuse's feedback buffer, ONE transform feedback capturing both draws.  nodes: nNodes x 16 floats (the deformation graph
+ * texture, NODE_TEXTURE_DIMENSION = 32768 wide, :27, :713-716).  Returns the new count. */
+int rgl_model_clean(const float* model, int M, const float* newUnstable, int nNew, const float* t_inv16, int time, int timeIdx,
+                    const uint32_t* index, const float* vertConf, const float* colorTime, const float* normRad, const float* depthSynth,
+                    int rows, int cols, float cx, float cy, float fx, float fy, float confThreshold, const float* nodes, int nNodes,
+                    int timeDelta, float maxDepth, int isFern, float* out_surfels) {
+  /* NODE_TEXTURE_DIMENSION = 16384 * 2 in the reference (GlobalModel.cpp:27); llvmpipe's GL_MAX_TEXTURE_SIZE is 16384, so the node row
+   * is that wide here and `nodeCols` says so: node j still sits at texels 16 j .. 16 j + 15, up to 1024 nodes */
+  const int NODE_DIM = 16384;
+  if (nNodes * 16 > NODE_DIM) return fail("too many deformation nodes for this GL's texture width", NULL);
+  GLuint p = program("copy_unstable.vert", "copy_unstable.geom", NULL, 1);
+  if (!p) return -1;
+  float* nodeRow = (float*)calloc(NODE_DIM, 4);
+  if (nNodes > 0) memcpy(nodeRow, nodes, (size_t)nNodes * 64);
+  GLuint tnode = tex2d(NODE_DIM, 1, GL_R32F, GL_RED, GL_FLOAT, nodeRow, 0);
+  free(nodeRow);
+  float* zero = NULL;
+  if (!depthSynth) zero = (float*)calloc((size_t)rows * cols, 4);
+  GLuint tidx = tex2d(cols, rows, GL_R32UI, GL_RED_INTEGER, GL_UNSIGNED_INT, index, 0);
+  GLuint tvc = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, vertConf, 0);
+  GLuint tct = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, colorTime, 0);
+  GLuint tnr = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, normRad, 0);
+  GLuint tdp = tex2d(cols, rows, GL_R32F, GL_RED, GL_FLOAT, depthSynth ? depthSynth : zero, 0);
+  free(zero);
+  GLuint src = vbo_make(model, (size_t)M * SURFEL_BYTES), nb = vbo_make(newUnstable, (size_t)nNew * SURFEL_BYTES);
+  GLuint dst = vbo_make(NULL, (size_t)(M + nNew + 1) * SURFEL_BYTES), q;
+  glGenQueries(1, &q);
+  glUseProgram(p);
+  u1i(p, "time", time);
+  u1i(p, "timeIdx", timeIdx);
+  u1f(p, "confThreshold", confThreshold);
+  u1f(p, "scale", 1.0f);
+  u1i(p, "indexSampler", 0); u1i(p, "vertConfSampler", 1); u1i(p, "colorTimeSampler", 2); u1i(p, "normRadSampler", 3);
+  u1i(p, "nodeSampler", 4); u1i(p, "depthSampler", 5);
+  u1f(p, "nodes", (float)nNodes);
+  u1f(p, "nodeCols", (float)NODE_DIM);
+  u1i(p, "timeDelta", timeDelta);
+  u1f(p, "maxDepth", maxDepth);
+  u1i(p, "isFern", isFern);
+  um4(p, "t_inv", t_inv16);
+  u4f(p, "cam", cx, cy, fx, fy);
+  u1f(p, "cols", (float)cols);
+  u1f(p, "rows", (float)rows);
+  const GLuint tx[6] = {tidx, tvc, tct, tnr, tnode, tdp};
+  for (int i = 0; i < 6; i++) { p_glActiveTexture(GL_TEXTURE0 + i); p_glBindTexture(GL_TEXTURE_2D, tx[i]); }
+  p_glEnable(GL_RASTERIZER_DISCARD);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, dst);
+  glBeginTransformFeedback(GL_POINTS);
+  glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
+  glBindBuffer(GL_ARRAY_BUFFER, src);
+  surfel_attribs();
+  p_glDrawArrays(GL_POINTS, 0, M);
+  glBindBuffer(GL_ARRAY_BUFFER, nb);
+  surfel_attribs();
+  p_glDrawArrays(GL_POINTS, 0, nNew);
+  glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
+  glEndTransformFeedback();
+  p_glDisable(GL_RASTERIZER_DISCARD);
+  no_attribs();
+  p_glFinish();
+  GLuint n = 0;
+  glGetQueryObjectuiv(q, GL_QUERY_RESULT, &n);
+  glBindBuffer(GL_ARRAY_BUFFER, dst);
+  if (n) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)n * SURFEL_BYTES, out_surfels);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  glUseProgram(0);
+  p_glActiveTexture(GL_TEXTURE0);
+  GLuint bs[3] = {src, nb, dst};
+  glDeleteBuffers(3, bs);
+  p_glDeleteTextures(6, tx);
+  return gl_ok("model_clean") ? -1 : (int)n;
+}
+
+/* FillIn::vertex / FillIn::normal (Shaders/FillIn.cpp:99-167): fill_vertex.frag / fill_normal.frag over the full-screen quad;
+ * existing: rows x cols x 4 floats (the prediction), raw depth u16.  which: 0 = vertex, 1 = normal. */
+int rgl_fill(int which, const float* existing, const uint16_t* depth, int rows, int cols, float cx, float cy, float fx, float fy,
+             int passthrough, float* out) {
+  GLuint p = program("empty.vert", "quad.geom", which ? "fill_normal.frag" : "fill_vertex.frag", 0);
+  if (!p) return -1;
+  GLuint te = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, existing, 0);
+  GLuint tr = tex2d(cols, rows, GL_R16UI, GL_RED_INTEGER, GL_UNSIGNED_SHORT, depth, 0);
+  GLuint to = tex2d(cols, rows, GL_RGBA32F, GL_RGBA, GL_FLOAT, NULL, 0);
+  Fbo f;
+  if (fbo_make(&f, cols, rows, &to, 1)) return -1;
+  p_glViewport(0, 0, cols, rows);
+  clear_all(&f, 0u);
+  glUseProgram(p);
+  u1i(p, "eSampler", 0);
+  u1i(p, "rSampler", 1);
+  u1i(p, "passthrough", passthrough);
+  u4f(p, "cam", cx, cy, 1.0f / fx, 1.0f / fy);
+  u1f(p, "cols", (float)cols);
+  u1f(p, "rows", (float)rows);
+  p_glActiveTexture(GL_TEXTURE0);
+  p_glBindTexture(GL_TEXTURE_2D, te);
+  p_glActiveTexture(GL_TEXTURE1);
+  p_glBindTexture(GL_TEXTURE_2D, tr);
+  p_glDrawArrays(GL_POINTS, 0, 1);
+  p_glFinish();
+  glUseProgram(0);
+  p_glActiveTexture(GL_TEXTURE0);
+  tex_read(to, GL_RGBA, GL_FLOAT, out);
+  fbo_free(&f);
+  GLuint ts[3] = {te, tr, to};
+  p_glDeleteTextures(3, ts);
+  return gl_ok("fill");
+}
+
+/* can the named fragment program of the reference be compiled at all by this (conformant) GLSL compiler?  fill_rgb.frag and
+ * resize.frag call texture2D under `#version 440 core`, which the specification removed; NVIDIA's compiler lets it pass */
+int rgl_try_program(const char* vs, const char* gs, const char* fs) {
+  GLuint p = program(vs, (gs && gs[0]) ? gs : NULL, (fs && fs[0]) ? fs : NULL, 0);
+  return p ? 0 : -1;
+}
