@@ -9,7 +9,7 @@ The chain is the sequence of operator calls RGBDOdometry::init* makes (Utils/RGB
 key-frame calls (KeyFrame.h:46-219: vertex-only copyMaps / tranformMaps, verticesToDepth on a 3-plane map) and the two NID
 scores (MutualInformation.cpp:154-213), on
   * "full":  the reference's GPUTest RGB-D pair at 640 x 480 (K = 528, 528, 320, 240);
-  * "small": the same pair sub-sampled and cropped to a ragged 123 x 91 (odd in both directions, so every halving truncates).
+  * "small": the same pair sub-sampled and cropped to a ragged 67 x 49 (odd in both directions, so every halving truncates).
 
 How an output is recorded: arrays of at most FULL_MAX elements in full; larger ones as a SHA-256 of the canonical bytes,
 a SHA-256 of the NaN mask and 4096 sampled values (fixed positions).  Canonical = every NaN is the same NaN, and the y / z
@@ -32,10 +32,11 @@ import numpy as np
 
 from tests import helpers
 
-FULL_MAX = 3 * 91 * 123  # one 3-plane map of the small case
+FULL_MAX = 3 * 49 * 67  # one 3-plane map of the small case
 NORMAL_TOL = 4e-7        # 1 ulp of rsqrt on a unit vector's component (2^-23 = 1.2e-7) with margin for the products
 N_SAMPLE = 4096
 K_FULL = (528.0, 528.0, 320.0, 240.0)
+CROP = (slice(25, 25 + 49), slice(30, 30 + 67))  # the small case's window in the 5x sub-sampled pair
 CUTOFF, MAX_DEPTH_RGB = 20.0, 6.0  # GPUTest.cpp:215-216 / RGBDOdometry.cpp:37
 
 
@@ -146,9 +147,9 @@ def inputs(case, pair, orc):
     d1, d2 = np.asarray(pair["depth1"]), np.asarray(pair["depth2"])
     rgb1, rgb2 = np.asarray(pair["rgb1"]), np.asarray(pair["rgb2"])
     K = K_FULL
-    if case == "small":  # every 5th pixel, cropped to 123 x 91
-        d1, d2, rgb1, rgb2 = (np.ascontiguousarray(a[2::5, 1::5][:91, :123]) for a in (d1, d2, rgb1, rgb2))
-        K = (K[0] / 5, K[1] / 5, (K[2] - 1) / 5, (K[3] - 2) / 5)
+    if case == "small":  # every 5th pixel, cropped to 67 x 49
+        d1, d2, rgb1, rgb2 = (np.ascontiguousarray(a[2::5, 1::5][CROP]) for a in (d1, d2, rgb1, rgb2))
+        K = (K[0] / 5, K[1] / 5, (K[2] - 1) / 5 - 30, (K[3] - 2) / 5 - 25)
     else:
         assert case == "full"
     verts4, norms4 = helpers.gputest_model_maps(d1, K)          # frame 1 as the model (GPUTest.cpp:69-129), TUM depth / 5000

@@ -34,6 +34,13 @@ TEX_DIM = 5700         # GlobalModel::TEXTURE_DIMENSION
 STRIDE = 6             # every 6th frame of the synthetic trajectory: the camera leaves parts of the map behind
 
 
+def configure(**kw):
+    """Another image size / warm-up for the live comparison (tests/test_ref_gl_live_cpu.py); returns the previous settings."""
+    old = {k: globals()[k] for k in kw}
+    globals().update(kw)
+    return old
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).reshape(-1).tobytes()).hexdigest()
 

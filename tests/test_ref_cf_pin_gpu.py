@@ -61,7 +61,7 @@ def test_fused_pyramid_kernels_equal_the_references(orc, case):
     pose[:3, :3], pose[:3, 3] = cf.POSE_R, cf.POSE_T
     rgb1, rgb2 = np.asarray(pair["rgb1"]), np.asarray(pair["rgb2"])
     if case == "small":
-        rgb1, rgb2 = (np.ascontiguousarray(a[2::5, 1::5][:91, :123]) for a in (rgb1, rgb2))
+        rgb1, rgb2 = (np.ascontiguousarray(a[2::5, 1::5][cf.CROP]) for a in (rgb1, rgb2))
     g = odometry.RGBDOdometry(W, H, K[2], K[3], K[0], K[1])
     g.initICPModel(inp["verts4"], inp["norms4"], cf.CUTOFF, pose)
     g.initRGBModel(helpers.rgba(rgb1))
