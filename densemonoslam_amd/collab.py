@@ -266,7 +266,13 @@ class InterMapMatcher:
         self.block_ready = torch.cuda.Event() if self.side is not None else None
         self.fern_threshold, self.verify_interval = fern_threshold, verify_interval
         self.best_dev = torch.full((world, 2), -1, dtype=torch.int32, device=device)
-        self.best_host = torch.full((world, 2), -1, dtype=torch.int32).pin_memory() if device.type == "cuda" else torch.full((world, 2), -1, dtype=torch.int32)
+        # two host-visible result arrays used in turn, each with the event recorded behind the call that fills it: a result that is
+        # still in flight when the next search is enqueued is counted a frame later instead of being overwritten
+        mk = lambda: torch.full((world, 2), -1, dtype=torch.int32).pin_memory() if device.type == "cuda" else torch.full((world, 2), -1, dtype=torch.int32)
+        self._hosts = [mk(), mk()]
+        self._events = [None, None]
+        self._turn = 0
+        self.best_host = self._hosts[0]  # the array the most recent search call wrote (or will write) its results to
         self.prev = None  # (gathered tensor, work handle) of the previous publish
         self.frames = 0
         self.candidates = 0  # remote descriptors that found a candidate frame (from the host-visible results)
@@ -316,22 +322,28 @@ class InterMapMatcher:
         w = self.x.work[slot]
         if w is not None:
             w.wait()  # (stream-side wait; the collective had a whole frame to finish)
-        # Results of the search enqueued a frame ago: counted only once the event recorded behind that search has completed
-        # (the pinned array is written by the device; reading it earlier would count the search before it a second time),
-        # then cleared so that a result is never counted twice.
-        ev = getattr(self, "_search_done", None)
-        if ev is None or ev.query():
-            self.candidates += int((self.best_host[:, 0] >= 0).sum())
-            self.best_host.fill_(-1)
-            self._search_done = None
+        # Results arrive in the pinned arrays one call late (the device writes them); each array is counted once the event recorded
+        # behind the call that fills it has completed, then cleared.  The array this call is about to reuse was filled two calls
+        # ago: if even that is still in flight, wait for it (it is two frames old) rather than lose it.
+        self._turn ^= 1
+        cur = self._turn
+        for k in (cur, cur ^ 1):
+            ev = self._events[k]
+            if ev is not None and k == cur and not ev.query():
+                ev.synchronize()
+            if ev is None or ev.query():
+                self.candidates += int((self._hosts[k][:, 0] >= 0).sum())
+                self._hosts[k].fill_(-1)
+                self._events[k] = None
+        self.best_host = self._hosts[cur]
         T = self.x.thumb_bytes
         if hasattr(self.ferns, "searchBlocks"):  # every remote descriptor in one launch
             # (the previous search's results go to the pinned array inside the same call: no copy engine on the frame's stream)
             self.ferns.searchBlocks(g.data_ptr(), self.x.nbytes, self.world, self.rank, T + DESC_CODES, T + DESC_GOOD, int(tick), True,
                                     self.best_dev.data_ptr(), stream, previous_out=self.best_host.data_ptr())
             if self.device.type == "cuda":
-                self._search_done = torch.cuda.Event()
-                self._search_done.record(torch.cuda.current_stream(self.device))
+                self._events[cur] = torch.cuda.Event()
+                self._events[cur].record(torch.cuda.current_stream(self.device))
             if self.verify_interval and self.frames % self.verify_interval == 0:
                 self.verify(g, tick, stream)
             return
@@ -343,8 +355,8 @@ class InterMapMatcher:
                 self.ferns.searchCodes(p + T + DESC_CODES, p + T + DESC_GOOD, int(tick), True, self.best_dev[r].data_ptr(), stream)
         self.best_host.copy_(self.best_dev, non_blocking=True)
         if self.device.type == "cuda":
-            self._search_done = torch.cuda.Event()
-            self._search_done.record(torch.cuda.current_stream(self.device))
+            self._events[cur] = torch.cuda.Event()
+            self._events[cur].record(torch.cuda.current_stream(self.device))
         if self.verify_interval and self.frames % self.verify_interval == 0:
             self.verify(g, tick, stream)
 

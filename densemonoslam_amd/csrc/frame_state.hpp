@@ -14,6 +14,8 @@ struct FrameState {
   unsigned surfels;
   int track_timeouts;   // sticky: tracker calls of this camera whose resident kernels timed out at a grid barrier (those frames keep
                         // their prior pose and fuse nothing; dms_fusion_fetch reports DMS_ERR_TIMEOUT)
+  int track_range_failures;  // sticky: tracker calls that found no fixed-point range for a cross-pixel sum (TrackState::sync_timeout
+                             // == 2: non-finite maps); same consequence for the frame, but nothing to do with residency
 };
 
 // Outcome of the local loop-closure candidate of one frame (ElasticFusion.cpp:427-474); the sampled
@@ -35,7 +37,8 @@ struct LoopState {
 // `held`: 32 floats the caller already holds in LDS — [0..15] the new pose, [16..31] the previous frame's (the resident
 // tracker's last block has just computed the one and read the other at its start: re-reading both from memory costs two
 // dependent round trips at the very end of the kernel); null = read both from the state block.
-__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, bool timed_out = false, float* held = nullptr) {
+__device__ inline void frame_after_track_body(FrameState* st, float weightMultiplier, int timeout_code = 0, float* held = nullptr) {
+  const bool timed_out = timeout_code != 0;  // 1: a grid-wide wait gave up, 2: no fixed-point range for a sum
   // (every loop over these 16-element arrays is fully unrolled: constant indices keep them in registers — a loop left rolled
   // puts them in scratch, which the large level kernels would then allocate for every lane)
   float P[16], Lp[16], Ti[16];
@@ -81,7 +84,10 @@ __device__ inline void frame_after_track_body(FrameState* st, float weightMultip
   if (weighting > largest) weighting = largest;
   weighting = fmaxf(1.0f - (weighting / largest), minWeight) * weightMultiplier;
   st->weighting = timed_out ? -1.f : weighting;
-  if (timed_out) st->track_timeouts += 1;
+  if (timeout_code == 2)
+    st->track_range_failures += 1;
+  else if (timed_out)
+    st->track_timeouts += 1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) st->lastPose[i] = P[i];
 }

@@ -321,6 +321,7 @@ struct dms_fusion {
   FrameState* h_state = nullptr;  // pinned, four slots, frame % 4 (the host may read a slot once that frame's event has completed)
   int last_slot = 0;
   int timeouts_reported = 0;  // value of FrameState::track_timeouts the caller has been told about
+  int range_failures_reported = 0;  // the same for FrameState::track_range_failures
   void* h_track = nullptr;
   int tick = 1;
   bool map_initialised = false;
@@ -809,6 +810,12 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   hipStream_t s = (hipStream_t)st;
   const int W = f->p.width, H = f->p.height, N = W * H;
   int rc;
+  // the ORB loop poses armed by dms_fusion_set_orb_loop belong to THIS call only, as the reference's hybrid_loops block uses only the
+  // pointers of the processFrame call it runs in (ElasticFusion.cpp:292-350, inside the not-first-frame branch): a bootstrap
+  // frame or a begin that fails further down must not leave them armed for a later frame
+  const bool orb_now = f->orb_armed;
+  f->orb_armed = false;
+  f->gloop_ran = false;
   // a previous frame that failed between its fuse and the index map that applies the fuse's update left the map with a pending
   // pass: apply it now instead of failing every later frame
   if ((rc = model_flush_pending(f->model, s))) return rc;
@@ -1030,15 +1037,12 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
     bool fuse_now = true;
     if (f->p.global_predict || f->p.nid_keyframing || f->p.local_loop_closure)
       if ((rc = predict(f, f->p.confidence, s))) return rc;
-    f->gloop_ran = false;
-    if (f->orb_armed) {
+    if (orb_now) {
       // hybrid_loops && orbTcwOld && orbTcwNew (ElasticFusion.cpp:292-350): the constraints of the ORB loop closure; the caller's
       // Deformation::constrain (:337) decides between dms_fusion_fetch_loop and _end.  The block ends with predict(context, rf)
       // (:349), which restores the current view for whoever reads it next in this frame
-      f->orb_armed = false;
       if ((rc = global_loop_device(f, f->orb_old, f->orb_new, 0, s))) return rc;
-      if (f->p.global_predict || f->p.nid_keyframing || f->p.local_loop_closure)
-        if ((rc = predict(f, f->p.confidence, s))) return rc;
+      if ((rc = predict(f, f->p.confidence, s))) return rc;  // unconditional, as :349
     }
     if (f->p.local_loop_closure && !f->lost) {
       // closeLoops without a fern match (ElasticFusion.cpp:399-497): the camera is never lost and
@@ -1206,13 +1210,23 @@ int dms_fusion_process_frame(dms_fusion* f, const void* rgb_dev, int rgb_channel
 // a grid barrier (those frames kept their prior pose and fused nothing).  Any fetch that sees the counter move says so,
 // whichever frame it happened in.
 static int report_timeouts(dms_fusion* f, const FrameState* hs) {
+  if (hs->track_range_failures != f->range_failures_reported) {
+    // not a residency problem: the maps held values no fixed-point range fits (non-finite input); the execution mode stays
+    const int n = hs->track_range_failures - f->range_failures_reported;
+    f->range_failures_reported = hs->track_range_failures;
+    if (hs->track_timeouts == f->timeouts_reported) {
+      set_error("dms_fusion: %d frame(s) since the last fetch found no fixed-point range for a cross-pixel sum of the tracker (non-finite "
+                "input maps?); those frames kept their prior pose and were not fused", n);
+      return DMS_ERR_TIMEOUT;
+    }
+  }
   if (hs->track_timeouts == f->timeouts_reported) return DMS_OK;
   const int n = hs->track_timeouts - f->timeouts_reported;
   f->timeouts_reported = hs->track_timeouts;
   // resident kernels that cannot be co-resident would time out on every frame: the trackers of this camera run
   // launch-per-phase from here on (same bits, see track.hip)
-  (void)dms_odometry_set_mode(f->odom, 0, -1, -1, -1);
-  if (f->odom_m2m) (void)dms_odometry_set_mode(f->odom_m2m, 0, -1, -1, -1);
+  (void)dms_odometry_fall_back_to_launches(f->odom);
+  if (f->odom_m2m) (void)dms_odometry_fall_back_to_launches(f->odom_m2m);
   set_error("dms_fusion: %d frame(s) since the last fetch had a resident tracker kernel time out at a grid-wide wait (its blocks were not "
             "all on the device: another process on this GPU?); those frames kept their prior pose and were not fused.  "
             "This camera's trackers have switched to launch-per-phase kernels (DMS_TRACK_MODE=launches)",
@@ -1368,13 +1382,13 @@ int dms_fusion_apply_global_loop_end(dms_fusion* f, const float* graph_host, int
   // clean(..., rawGraph, timeDelta + framesSinceLastFusion, maxDepthProcessed, orbLoopClosureAccepted) (:1222-1239)
   // (the clean changes the map's version: a projection the previous frame left for the next tracking prediction is stale and
   // that prediction projects afresh, see predict() mode 2)
+  // in the reference's order: the prediction images a caller reads afterwards show the map BEFORE this clean
+  if ((rc = predict(f, f->p.confidence, s))) return rc;
   const int timeDeltaEff = f->p.timeDelta + f->frames_since_fusion;
   if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, timeDeltaEff, f->zbuf, &f->imap, 1, 1, s)))
     return rc;
-  if ((rc = model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, graph_host, graph_nodes,
-                        timeDeltaEff, f->p.maxDepthProcessed, accepted ? 1 : 0, 1, &f->state->surfels, s)))
-    return rc;
-  return predict(f, f->p.confidence, s);
+  return model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, graph_host, graph_nodes,
+                     timeDeltaEff, f->p.maxDepthProcessed, accepted ? 1 : 0, 1, &f->state->surfels, s);
 }
 
 int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {

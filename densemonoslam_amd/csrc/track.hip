@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
           s_held[12] = s_held[13] = s_held[14] = 0.f;
           s_held[15] = 1.f;
         }
-        frame_after_track_body(L.frame, L.weightMultiplier, timed_out, own ? s_held : nullptr);
+        frame_after_track_body(L.frame, L.weightMultiplier, __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), own ? s_held : nullptr);
       }
     }
   }
@@ -1515,7 +1515,7 @@ __global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ po
   }
   // frame step: pose16_out is frame->cur.pose; derive its inverse and the velocity weight here
   // instead of in a launch of their own
-  if (frame) frame_after_track_body(frame, weightMultiplier, timed_out);
+  if (frame) frame_after_track_body(frame, weightMultiplier, st->sync_timeout);
 }
 
 }  // namespace dms
@@ -1822,8 +1822,17 @@ int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int earl
   DMS_REQUIRE(o, "null argument");
   (void)fp64_sums;      // (rounds 1-2: fp64 block sums / record protocol; every sum is the exact integer sum of canon.hpp now)
   (void)atomic_reduce;
-  if (resident >= 0) o->resident = resident != 0;
-  o->early_exit_force = early_exit < 0 ? -1 : (early_exit ? 1 : 0);
+  // resident = 1 on a handle whose device cannot hold a resident kernel's blocks at once (max_resident_blocks = 0) stays off
+  if (resident >= 0) o->resident = resident != 0 && o->max_resident_blocks > 0;
+  if (early_exit >= 0) o->early_exit_force = early_exit ? 1 : 0;  // -1: unchanged (keeps a DMS_TRACK_EARLY_EXIT choice made at creation)
+  return DMS_OK;
+}
+
+// the frame step's reaction to a resident kernel that timed out: launch-per-phase from here on, nothing else touched
+int dms_odometry_fall_back_to_launches(dms_odometry* o) {
+  DMS_REQUIRE(o, "null argument");
+  o->resident = false;
+  o->fell_back = true;
   return DMS_OK;
 }
 
@@ -2417,7 +2426,10 @@ __global__ __launch_bounds__(256) void k_loop_candidate(const TrackState* __rest
       if (cii > 8e-05) covOk = false;
     }
     const bool timed_out = st->sync_timeout != 0;  // model-to-model pass invalid: no candidate, counted like a tracker timeout
-    if (timed_out) frame->track_timeouts += 1;
+    if (st->sync_timeout == 2)
+      frame->track_range_failures += 1;
+    else if (timed_out)
+      frame->track_timeouts += 1;
     const int ok = (!timed_out && covOk && st->lastICPCount > 15000.f && st->lastICPError < 0.0003f) ? 1 : 0;
     out->ok = ok;
     out->icp_error = st->lastICPError;

@@ -139,12 +139,12 @@ class ElasticFusion:
     # second half of applyGlobalLoop (:1222-1239): predict, predictIndices, clean(rawGraph, isFern = accepted)
     def applyGlobalLoopEnd(self, rawGraph=None, accepted=False):
         td = self.timeDelta + self.framesSinceLastFusion
+        self.predict(self.confidence)  # the reference's order: predict, predictIndices, clean (the images show the map before the clean)
         im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
         nodes = None if rawGraph is None or not len(rawGraph) else np.ascontiguousarray(rawGraph, np.float32).reshape(-1, 16)
         self.model = orc.model_clean(self.model, np.zeros(0, orc.SURFEL_DTYPE), self.currPose, self.tick, self.timeIdx, im[0], im[1], im[2],
                                      self.K, self.confidence, td, self.maxDepthProcessed, nodes=nodes, depthSynth=None, cap=self.cap,
                                      isFern=int(bool(accepted)))
-        self.predict(self.confidence)
 
     # ElasticFusion::fuseFrame (:639-677): the candidate key frame is the model prediction at the new
     # pose (GlobalPredict, :273); its "old" (INACTIVE) textures are never rendered with loop closure
