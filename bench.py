@@ -119,6 +119,14 @@ def algorithmic_bytes(kernel, W, H, M, level_px):
     return float("nan")
 
 
+def contract_bytes(N0, M, it, rgb, n_pred, n_trk):
+    """SURVEY 8(d)'s algorithmic bytes of one whole frame: B = B_pre + n_pred B_pred + n_trk (B_init + B_gn) + 2 B_idx + B_fuse + B_clean."""
+    N = [N0, N0 // 4, N0 // 16]  # (W/2)(H/2), (W/4)(H/4) up to the truncation of odd sizes
+    per_px = 76.0 if rgb else 48.0
+    b_gn = (6.6 * N0 + 21.0 * N0 if rgb else 0.0) + per_px * sum(i * n for i, n in zip(it, N))
+    return 12.0 * N0 + n_pred * (60.0 * M + 38.0 * N0) + n_trk * (255.0 * N0 + b_gn) + 2 * (60.0 * M + 52.0 * N0) + (120.0 * M + 64.0 * N0) + (120.0 * M + 15.0 * N0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=0, help="ranks = GPUs of this node (0: WORLD_SIZE if launched by torch.distributed.run, else 1)")
@@ -134,6 +142,7 @@ def main():
     ap.add_argument("--loop-closure", action="store_true",
                     help="time the 'full' frame step: local loop closure on (INACTIVE prediction + model-to-model tracking every frame)")
     ap.add_argument("--no-full-leg", action="store_true", help="skip the extra 'full' (loop closure on) leg of the default run")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs for BASELINE configs 2 / 4, n_pred = 3 and the populated full step")
     ap.add_argument("--time-delta", type=int, default=200,
                     help="active time window in frames (reference default 200); a small value with --loop-closure populates the INACTIVE "
                          "view on this cyclic stream, so the model-to-model tracker has correspondences")
@@ -355,6 +364,10 @@ def main():
         },
     }
 
+    Bw = contract_bytes(W * H, M, (10, 5, 4), True, 2, 2 if args.loop_closure else 1)
+    out["whole_frame"] = {"contract_bytes_per_frame": Bw, "hbm_frac": Bw * (fps / world) / 8e12,
+                          "what": "SURVEY 8(d)'s algorithmic bytes of one frame (this run's surfel count, the 2 predictions actually run) x frames/s per GPU / 8 TB/s"}
+
     # ---- "full" frame step (report both): the same stream with local loop closure on ----
     if rank == 0 and not distributed and not args.loop_closure and not args.no_full_leg:
         ef_main = ef
@@ -383,6 +396,57 @@ def main():
         }
         ef.close()
         ef = ef_main
+
+    # ---- the other single-GPU configurations of BASELINE.json / SURVEY 8(d), short legs of their own (not in `value`) ----------
+    # Each: a fresh engine, `warmup` untimed frames, then `n` frames timed like the main region (enqueue, one synchronise);
+    # `hbm_frac_whole_frame` = SURVEY 8(d)'s contract bytes per frame B x frames/s / 8 TB/s with the leg's own surfel count.
+    if rank == 0 and not distributed and not args.loop_closure and not args.no_config_legs and (W, H) == (640, 480):
+        def leg(opts, what, it, rgb, n_pred, n_trk, Wl=W, Hl=H, Kl=K, n=50):
+            if (Wl, Hl) == (W, H):
+                rl, dl, nu = rgb_t, dep_t, n_unique
+            else:
+                nu = 16
+                rl = torch.empty((nu, Hl, Wl, 3), dtype=torch.uint8, device=dev)
+                dl = torch.empty((nu, Hl, Wl), dtype=torch.int16, device=dev)
+                for k in range(nu):
+                    d, rgbk, _ = synth.frame(k, cam_id=0, width=Wl, height=Hl, K=Kl, noise=True)
+                    rl[k] = torch.from_numpy(rgbk)
+                    dl[k] = torch.from_numpy(d.view(np.int16))
+            eng = fusion.ElasticFusion(Wl, Hl, Kl, model_capacity=8_000_000, pipeline_ingest=0 if args.no_pipeline else 1, **opts)
+
+            def fi(i):
+                period = 2 * (nu - 1)
+                j = i % period
+                return j if j < nu else period - j
+
+            for i in range(args.warmup):
+                eng.processFrameAsync(rl[fi(i)].data_ptr(), 3, dl[fi(i)].data_ptr(), None, 1.0, stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + n):
+                eng.processFrameAsync(rl[fi(i)].data_ptr(), 3, dl[fi(i)].data_ptr(), None, 1.0, stream)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            r = eng.fetch(stream)
+            eng.close()
+            Ml, fpsl = int(r.surfels), n / el
+            B = contract_bytes(Wl * Hl, Ml, it, rgb, n_pred, n_trk)
+            return {"value": fpsl, "unit": "frames/s", "ms_per_step": 1000.0 * el / n, "steps": n, "warmup": args.warmup, "resolution": [Wl, Hl],
+                    "surfels": Ml, "contract_bytes_per_frame": B, "hbm_frac_whole_frame": B * fpsl / 8e12, "what": what,
+                    **({"last_loop_icp_count": float(r.loop_icp_count)} if opts.get("local_loop_closure") else {})}
+
+        out["configs"] = {
+            "C2": leg(dict(icpWeight=100.0, fastOdom=1, pyramid=0, so3=0), "BASELINE config 2: ICP-only odometry (icpWeight 100 => no photometric term, "
+                      "RGBDOdometry.cpp:279), --fo, single pyramid level, no SO3: 3 point-to-plane iterations at 640x480, then the same fusion",
+                      (3, 0, 0), False, 2, 1),
+            "C3_n_pred3": leg(dict(global_predict=1, share_projection=0), "BASELINE config 3 with the reference's three model predictions per frame "
+                              "(post-tracking 'GlobalPredict' on, every prediction projects the map itself)", (10, 5, 4), True, 3, 1),
+            "full_step_populated": leg(dict(local_loop_closure=1, timeDelta=8), "the 'full' step (local loop closure: INACTIVE prediction + model-to-model "
+                                       "tracker) with an 8-frame active window, so the INACTIVE view is populated on this back-and-forth stream",
+                                       (10, 5, 4), True, 3, 2),
+            "C4": leg(dict(depthCut=40.0), "BASELINE config 4 geometry: 1241x376, KITTI intrinsics, 40 m depth cut-off, full 3-level ICP+RGB tracking "
+                      "+ fusion (synthetic depth in place of the absent depth network)", (10, 5, 4), True, 2, 1, 1241, 376, synth.K_KITTI),
+        }
 
     # ---- per-kernel timing with HIP events on the launch stream (own passes, not in `value`) ------
     if rank == 0 and not args.no_kernel_pass:
@@ -531,8 +595,8 @@ def main():
             n = _orc.set_threads(threads)
             o = orc_pipeline.ElasticFusion(W, H, K, model_capacity=8_000_000)
             tcpu, done = 0.0, 0
-            for k in range(min(max_frames, len(host_frames))):
-                d, rgb = host_frames[k]
+            for k in range(max_frames):
+                d, rgb = host_frames[frame_index(k)]  # the GPU legs' order: forward, then backward along the trajectory
                 t1 = time.perf_counter()
                 o.processFrame(rgb, d)
                 dt = time.perf_counter() - t1
@@ -545,8 +609,8 @@ def main():
 
         # the oracle's OpenMP loops are short; one thread per core of a 256-thread host is slower than 16
         nproc = os.cpu_count() or 1
-        cores, fps_all, n_all = run_oracle(int(os.environ.get("DMS_CPU_THREADS", min(16, nproc))), 20.0, args.cpu_frames or len(host_frames))
-        _, fps_one, n_one = run_oracle(1, 8.0, args.cpu_frames or len(host_frames))
+        cores, fps_all, n_all = run_oracle(int(os.environ.get("DMS_CPU_THREADS", min(16, nproc))), 60.0, args.cpu_frames or 102)
+        _, fps_one, n_one = run_oracle(1, 8.0, args.cpu_frames or 102)
         out["cpu_baseline"] = {
             "value": fps_all,
             "unit": "frames/s",
@@ -554,10 +618,12 @@ def main():
             "kind": "port",
             "one_core": {"value": fps_one, "unit": "frames/s", "cores": 1, "frames": n_one},
             "host": {"nproc": nproc, "cpu_model": cpu_model()},
-            "sample": "%d steady-state frames (after the bootstrap frame and the first tracked one) of the same synthetic stream in ~20 s, "
-                      "oracle/ C restatement of the reference algorithm (OpenMP on the per-pixel loops of the tracker and of the depth filter with "
-                      "`cores` threads; the surfel-map passes replay sequential GL draws on one thread), %dx%d; one_core: the same with 1 thread, ~8 s.  Reported baseline of a CPU "
-                      "restatement, non-target" % (n_all, W, H),
+            "sample": "%d steady-state frames (after the bootstrap frame and the first tracked one) of the same synthetic stream, %dx%d, run by the "
+                      "oracle/ C restatement of the reference algorithm with %d of the host's %d hardware threads: OpenMP covers the per-pixel loops "
+                      "of the tracker and the depth filter (more threads than this make those short loops slower), while the surfel-map passes "
+                      "(index map, splats, fuse, clean: about half of a frame) replay the reference's sequential GL draws on ONE thread by design "
+                      "(draw order decides ties).  So this is a weak baseline - a restatement written to be checked against, not tuned - and says "
+                      "nothing about kernel quality; one_core: the same with 1 thread for ~8 s.  Non-target" % (n_all, W, H, cores, nproc),
         }
 
     if rank == 0:
