@@ -633,7 +633,10 @@ int find_common(dms_ferns* f, const float* currPose16, int time, int lost, int i
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) rot[i * 3 + j] = fernPose[i * 4 + j];
   dms_track_result tr;
-  if ((rc = dms_odometry_getIncrementalTransformation(f->rgbd_odom, trans, rot, 0, 100.0f, interMap ? 1 : 0, 0, interMap ? 1 : 0, interMap ? 1 : 0, &tr, s)))
+  // interMap == 1: the reference's inter-map settings (pyramid, SO3, 50 iterations per level); interMap == 2: every frame eligible as
+  // for 1, verified with the intra-map settings (one level, 10 iterations) - see dmslam_ferns.h
+  const int deep = interMap == 1 ? 1 : 0;
+  if ((rc = dms_odometry_getIncrementalTransformation(f->rgbd_odom, trans, rot, 0, 100.0f, deep, 0, deep, deep, &tr, s)))
     return rc;
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) m->estPose[i * 4 + j] = rot[i * 3 + j];
@@ -971,6 +974,54 @@ int dms_ferns_consume(dms_ferns* dst, dms_ferns* src, const float* T16, float th
     mul44(T16, &src->poses[(size_t)j * 16], pose);  // frame->pose = relativeTransform * frame->pose (Ferns.cpp:164)
     rc = stage(dst, nullptr, nullptr, nullptr, src->d_blocks + (size_t)j * src->block_bytes, s);
     if (!rc) rc = add_enqueue(dst, pose, nullptr, src->times[j], threshold, s);
+    int one = 0;
+    if (!rc) rc = add_result(dst, &one, s);
+    if (rc) return rc;
+    *added += one;
+  }
+  return DMS_OK;
+}
+
+
+// ---- the database as records, for a merge across ranks (ReferenceFrame::consumeReferenceFrame, ReferenceFrame.h:125, when the two
+// reference frames live in different processes): record = {thumbnail block | pose 16 floats | srcTime | 3 ints of padding}
+size_t dms_ferns_record_bytes(dms_ferns* f) { return f ? up256(f->block_bytes + 80) : 0; }
+
+int dms_ferns_export_records(dms_ferns* f, void* dst_dev, int max_count, int* count, dms_stream st) {
+  DMS_REQUIRE(f && count && (dst_dev || max_count == 0), "null argument");
+  hipStream_t s = (hipStream_t)st;
+  int rc = mirror(f, s);
+  if (rc) return rc;
+  const int n = f->n_host < max_count ? f->n_host : max_count;
+  const size_t rb = dms_ferns_record_bytes(f);
+  for (int j = 0; j < n; ++j) {
+    char* rec = (char*)dst_dev + (size_t)j * rb;
+    DMS_HIP(hipMemcpyAsync(rec, f->d_blocks + (size_t)j * f->block_bytes, f->block_bytes, hipMemcpyDeviceToDevice, s));
+    float meta[20] = {0};
+    memcpy(meta, &f->poses[(size_t)j * 16], 64);
+    memcpy(meta + 16, &f->times[j], 4);
+    DMS_HIP(hipMemcpyAsync(rec + f->block_bytes, meta, 80, hipMemcpyHostToDevice, s));
+    DMS_HIP(hipStreamSynchronize(s));  // (`meta` is a stack buffer)
+  }
+  *count = n;
+  return DMS_OK;
+}
+
+int dms_ferns_consume_records(dms_ferns* dst, const void* records_dev, int count, const float* T16, float threshold, int* added, dms_stream st) {
+  DMS_REQUIRE(dst && T16 && added && (records_dev || count == 0) && count >= 0, "bad argument");
+  hipStream_t s = (hipStream_t)st;
+  *added = 0;
+  const size_t rb = dms_ferns_record_bytes(dst);
+  for (int j = 0; j < count; ++j) {
+    const char* rec = (const char*)records_dev + (size_t)j * rb;
+    float meta[20], pose[16];
+    DMS_HIP(hipMemcpyAsync(meta, rec + dst->block_bytes, 80, hipMemcpyDeviceToHost, s));
+    DMS_HIP(hipStreamSynchronize(s));
+    int srcTime;
+    memcpy(&srcTime, meta + 16, 4);
+    mul44(T16, meta, pose);  // frame->pose = relativeTransform * frame->pose (Ferns.cpp:164)
+    int rc = stage(dst, nullptr, nullptr, nullptr, rec, s);
+    if (!rc) rc = add_enqueue(dst, pose, nullptr, srcTime, threshold, s);
     int one = 0;
     if (!rc) rc = add_result(dst, &one, s);
     if (rc) return rc;

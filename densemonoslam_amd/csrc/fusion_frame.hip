@@ -254,6 +254,8 @@ struct dms_fusion {
   dms_fusion_params p;
   dms_camera cam;
   dms_model* model = nullptr;
+  dms_model* own_model = nullptr;  // the map this context created; != model once it has joined another camera's map
+  bool adopting = false;           // dms_fusion_import_camera: the next frame seeds the live state and touches no map
   dms_odometry* odom = nullptr;
   dms_odometry* odom_m2m = nullptr;  // Context::modelToModel() (local loop closure)
   dms_predict_out pred_old;          // IndexMap old* textures: the INACTIVE view
@@ -677,9 +679,10 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     return rc;
   }
   (void)dms_model_set_num_sensors(f->model, f->p.num_sensors);
+  f->own_model = f->model;
   rc = dms_odometry_create(&f->odom, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
   if (rc) {
-    dms_model_destroy(f->model);
+    dms_model_destroy(f->own_model ? f->own_model : f->model);
     delete f;
     return rc;
   }
@@ -688,7 +691,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (!rc && f->odom_m2m) odometry_set_early_exit(f->odom_m2m, 1);  // its INACTIVE side is empty on most frames
   if (rc) {
     dms_odometry_destroy(f->odom);
-    dms_model_destroy(f->model);
+    dms_model_destroy(f->own_model ? f->own_model : f->model);
     delete f;
     return rc;
   }
@@ -732,7 +735,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     if (f->arena) (void)hipFree(f->arena);
     if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
     dms_odometry_destroy(f->odom);
-    dms_model_destroy(f->model);
+    dms_model_destroy(f->own_model ? f->own_model : f->model);
     delete f;
     return hip_fail(e, "dms_fusion_create allocation", __FILE__, __LINE__);
   }
@@ -775,7 +778,7 @@ int dms_fusion_destroy(dms_fusion* f) {
   if (f->h_gloop) (void)hipHostFree(f->h_gloop);
   if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
   dms_odometry_destroy(f->odom);
-  dms_model_destroy(f->model);
+  dms_model_destroy(f->own_model ? f->own_model : f->model);
   delete f;
   return DMS_OK;
 }
@@ -866,9 +869,10 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   // A completed frame's result block (pinned ring slot) tightens the host-side bound of the surfel count that launch grids
   // are sized from; every clean since then adds at most `slots` surfels.  Without this the bound grows by `slots` per
   // frame until it reaches the capacity.
+  f->model->last_writer = f;
   if (f->model->count_hold > 0) {
     f->model->count_hold -= 1;
-  } else if (f->map_initialised) {
+  } else if (f->map_initialised && f->model->sharers == 1) {  // (a shared map: another camera's cleans are not counted by this context's frames)
     // newest frame whose result slot is certainly readable: t - host_lag with the pipeline (just waited for), else t - 2 if done
     const int lag = f->p.pipeline_ingest ? f->host_lag : 2;
     const int slot = (int)((f->frames + 4 - lag) % 4);
@@ -966,7 +970,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       for (int i = 0; i < 16; ++i) prior.v[i] = (i % 5 == 0) ? 1.f : 0.f;
     hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(64), 0, s, f->state, prior);
     DMS_CHECK_LAUNCH();
-    {
+    if (!f->adopting) {  // (an imported camera joins a map that exists: this frame only seeds its live state)
       FTimer t(f, s, "initialise");
       // computeFeedbackBuffers takes `const int& maxDepthProcessed` (Context.h:211): 25.0f -> 25
       if ((rc = model_initialise(f->model, &f->rgba, &f->depth_metric, &f->depth_metric_filtered, &f->cam, f->tick, f->p.timeIdx,
@@ -1133,7 +1137,8 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
   bool surfels_written = false;
   f->in_frame = false;
   if (f->cur_bootstrap) {
-    fused = 1;
+    fused = f->adopting ? 0 : 1;
+    f->adopting = false;
   } else {
     if (newPose16) {
       Pose16 np;
@@ -1285,7 +1290,7 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
   const FrameState* hs = f->h_state + f->last_slot;
   memcpy(r->pose, hs->cur.pose, sizeof(r->pose));
   r->surfels = hs->surfels;
-  f->model->count_upper = r->surfels;
+  if (f->model->sharers == 1 || f->model->last_writer == f) f->model->count_upper = r->surfels;
   r->tick = f->tick;
   r->fused = f->fused_last;
   r->fill_in = hs->fill_in;
@@ -1389,6 +1394,81 @@ int dms_fusion_apply_global_loop_end(dms_fusion* f, const float* graph_host, int
     return rc;
   return model_clean(f->model, &f->state->cur, f->tick, f->p.timeIdx, &f->imap, nullptr, &f->cam, f->p.confidence, graph_host, graph_nodes,
                      timeDeltaEff, f->p.maxDepthProcessed, accepted ? 1 : 0, 1, &f->state->surfels, s);
+}
+
+int dms_relative_transform(const float* recoveryPose16, const float* currPose16, float* out16) {
+  DMS_REQUIRE(recoveryPose16 && currPose16 && out16, "null argument");
+  float inv[16];
+  sm::inv4t<float>(currPose16, inv);
+  sm::mul44_host(recoveryPose16, inv, out16);
+  return DMS_OK;
+}
+int dms_pose_compose(const float* a16, const float* b16, float* out16) {
+  DMS_REQUIRE(a16 && b16 && out16, "null argument");
+  float tmp[16];
+  sm::mul44_host(a16, b16, tmp);
+  memcpy(out16, tmp, sizeof(tmp));
+  return DMS_OK;
+}
+
+// ---- after a map merge: several cameras, one map --------------------------------------------------------------------------------
+static int share_model(dms_fusion* f, dms_fusion* owner) {
+  DMS_REQUIRE(f && owner && f != owner, "bad argument");
+  DMS_REQUIRE(!f->in_frame && !owner->in_frame && !f->in_global_loop && !owner->in_global_loop, "inside a frame");
+  DMS_REQUIRE(f->p.width == owner->p.width && f->p.height == owner->p.height, "cameras of different resolution (the reference shares one Resolution singleton)");
+  DMS_REQUIRE(f->model == f->own_model, "this camera has already joined a map");
+  DMS_REQUIRE(owner->map_initialised, "the consuming map is empty");
+  DMS_REQUIRE(f->p.timeIdx != owner->p.timeIdx, "both cameras use the same time slot (timeIdx = Context::id())");
+  DMS_REQUIRE(f->p.timeIdx < owner->model->num_sensors && f->p.timeIdx < DMS_MAX_SENSORS, "the consuming map has no time slot for this camera (num_sensors)");
+  return DMS_OK;
+}
+
+int dms_fusion_join_map(dms_fusion* f, dms_fusion* owner, const float* relativeTransform16, dms_stream st) {
+  int rc = share_model(f, owner);
+  if (rc) return rc;
+  DMS_REQUIRE(relativeTransform16 && f->map_initialised, "join_map: a camera with a map of its own and the transform into the consuming map");
+  hipStream_t s = (hipStream_t)st;
+  DMS_HIP(hipStreamSynchronize(s));
+  if (f->p.pipeline_ingest) DMS_HIP(hipStreamSynchronize(f->s_prep));
+  // m_localModel.consume(other.globalModel().model(), relativeTransform) (ReferenceFrame.h:124)
+  if ((rc = model_flush_pending(f->model, s))) return rc;
+  if ((rc = dms_model_consume(owner->model, f->model, relativeTransform16, st))) return rc;
+  // kv.second->currPose() = relativeTransform * kv.second->currPose() (:131); the next frame's lastPose is read from it (:158)
+  float cur[16];
+  Pose16 np;
+  DMS_HIP(hipMemcpy(cur, f->state->cur.pose, sizeof(cur), hipMemcpyDeviceToHost));
+  sm::mul44_host(relativeTransform16, cur, np.v);
+  hipLaunchKernelGGL(k_pose_override, dim3(1), dim3(64), 0, s, f->state, np);
+  DMS_CHECK_LAUNCH();
+  f->model = owner->model;
+  f->model->sharers += 1;
+  f->model->count_hold = 3;
+  f->pre_valid = false;
+  DMS_HIP(hipStreamSynchronize(s));
+  return DMS_OK;
+}
+
+int dms_fusion_import_camera(dms_fusion* f, dms_fusion* owner, const float* pose16, int tick, const void* last_rgb_dev, int rgb_channels,
+                             const unsigned short* last_depth_dev, dms_stream st) {
+  int rc = share_model(f, owner);
+  if (rc) return rc;
+  DMS_REQUIRE(pose16 && last_rgb_dev && last_depth_dev && tick >= 2, "null argument / a camera that has not processed a frame");
+  DMS_REQUIRE(!f->map_initialised && f->frames == 0, "import_camera: a context that has not processed a frame");
+  f->model = owner->model;
+  f->model->sharers += 1;
+  f->model->count_hold = 3;
+  f->adopting = true;
+  f->tick = tick - 1;  // the seeding frame below ends with tick += 1 like any other
+  // the camera's last frame again, at its (already transformed) pose: its live pyramids are what the next frame's SO3
+  // pre-alignment compares against (lastNextImage), exactly what the camera's own context held after that frame
+  rc = dms_fusion_process_frame(f, last_rgb_dev, rgb_channels, last_depth_dev, pose16, 1.f, st);
+  if (rc) {  // leave the context as it was
+    f->adopting = false;
+    f->model->sharers -= 1;
+    f->model = f->own_model;
+    f->tick = 1;
+  }
+  return rc;
 }
 
 int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view) {

@@ -73,6 +73,18 @@ __host__ __device__ inline void inv4t(const T* m, T* o) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[i] = inv[i] * id;
 }
+// c = a * b for row-major 4 x 4 float matrices, every element ((a0 b0 + a1 b1) + a2 b2) + a3 b3 with every operation rounded
+// (the order of oracle/orc_ferns.py _mul44 and of the map-merge kernels; the library is built with -ffp-contract=off)
+inline void mul44_host(const float* a, const float* b, float* o) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = a[i * 4 + 0] * b[0 * 4 + j];
+      s = s + a[i * 4 + 1] * b[1 * 4 + j];
+      s = s + a[i * 4 + 2] * b[2 * 4 + j];
+      s = s + a[i * 4 + 3] * b[3 * 4 + j];
+      o[i * 4 + j] = s;
+    }
+}
 __host__ __device__ inline void inv4(const double* m, double* o) { inv4t<double>(m, o); }
 
 // Pivoted LDLT solve of a symmetric N×N system (diagonal pivoting on |A_kk|, zero pivots

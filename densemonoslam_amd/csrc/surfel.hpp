@@ -189,4 +189,8 @@ struct dms_model {
   unsigned long version = 0;        // bumped by every operation that changes the map (cached projections are tagged with it)
   int num_sensors = 3;              // per-surfel time slots that take part in the clean's health test (reference NUM_CAMERAS = 3)
   size_t clean_suffix_min = (size_t)1 << 20;  // map size from which the clean runs in suffix mode (DMS_CLEAN_SUFFIX_MIN at create)
+  // After a map merge several cameras (frame-step contexts) fuse into this one map (dms_fusion_join_map): how many do, and which of
+  // them enqueued the last frame - only that one's result block says anything about the current count.
+  int sharers = 1;
+  const void* last_writer = nullptr;
 };

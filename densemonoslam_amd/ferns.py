@@ -31,6 +31,10 @@ lib.dms_ferns_encode_thumbs.argtypes = [_P, _P, _P, _P, _P]
 lib.dms_ferns_publish_block.argtypes = [_P, _P, _P, _P, _P, _I, C.c_float, _P]
 lib.dms_ferns_search_blocks.argtypes = [_P, _P, C.c_size_t, _I, _I, C.c_size_t, C.c_size_t, _I, _I, _P, _P, _P]
 lib.dms_ferns_consume.argtypes = [_P, _P, C.POINTER(_F), _F, C.POINTER(_I), _P]
+lib.dms_ferns_record_bytes.argtypes = [_P]
+lib.dms_ferns_record_bytes.restype = C.c_size_t
+lib.dms_ferns_export_records.argtypes = [_P, _P, _I, C.POINTER(_I), _P]
+lib.dms_ferns_consume_records.argtypes = [_P, _P, _I, C.POINTER(_F), _F, C.POINTER(_I), _P]
 
 
 def _view(ptr, rows, cols, elem):
@@ -150,4 +154,20 @@ class Ferns:
         T = np.ascontiguousarray(relativeTransform, np.float32).reshape(16)
         added = _I(0)
         check(lib.dms_ferns_consume(self.h, other.h, T.ctypes.data_as(C.POINTER(_F)), threshold, C.byref(added), stream), "dms_ferns_consume")
+        return added.value
+
+    # -- the database as records, for a merge across ranks ------------------------------------------------------
+    def recordBytes(self):
+        return int(lib.dms_ferns_record_bytes(self.h))
+
+    def exportRecords(self, dst_ptr, max_count, stream=None):
+        n = _I(0)
+        check(lib.dms_ferns_export_records(self.h, C.c_void_p(dst_ptr), int(max_count), C.byref(n), stream), "dms_ferns_export_records")
+        return n.value
+
+    def consumeRecords(self, records_ptr, count, relativeTransform, threshold, stream=None):
+        T = np.ascontiguousarray(relativeTransform, np.float32).reshape(16)
+        added = _I(0)
+        check(lib.dms_ferns_consume_records(self.h, C.c_void_p(records_ptr), int(count), T.ctypes.data_as(C.POINTER(_F)), threshold, C.byref(added),
+                                            stream), "dms_ferns_consume_records")
         return added.value

@@ -108,6 +108,10 @@ lib.dms_fusion_process_frame_begin.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_flo
 lib.dms_fusion_fetch_loop.argtypes = [_P, C.POINTER(FrameResult), _P]
 lib.dms_fusion_process_frame_end.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _P]
 lib.dms_fusion_get_loop_constraints.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]
+lib.dms_fusion_join_map.argtypes = [_P, _P, C.POINTER(C.c_float), _P]
+lib.dms_fusion_import_camera.argtypes = [_P, _P, C.POINTER(C.c_float), _I, _P, _I, _P, _P]
+lib.dms_relative_transform.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+lib.dms_pose_compose.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 lib.dms_fusion_set_profiling.argtypes = [_P, _I]
 lib.dms_fusion_get_kernel_time.argtypes = [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -120,6 +124,29 @@ def _img(a, dtype=None):
     if isinstance(a, DeviceImage):
         return a
     return DeviceImage.from_array(a if dtype is None else np.asarray(a, dtype))
+
+
+def _f16(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(16)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def relative_transform(recoveryPose, currPose):
+    """relativeTransform = recoveryPose * currPose.inverse() (ReferenceFrame.h:98), the library's fixed float order."""
+    a, ap = _f16(recoveryPose)
+    b, bp = _f16(currPose)
+    o, op = _f16(np.zeros(16, np.float32))
+    check(lib.dms_relative_transform(ap, bp, op), "dms_relative_transform")
+    return o.reshape(4, 4)
+
+
+def pose_compose(a, b):
+    """a * b for 4 x 4 float matrices in the library's fixed float order (poseGraph / relativeCons re-basing after a merge)."""
+    a, ap = _f16(a)
+    b, bp = _f16(b)
+    o, op = _f16(np.zeros(16, np.float32))
+    check(lib.dms_pose_compose(ap, bp, op), "dms_pose_compose")
+    return o.reshape(4, 4)
 
 
 class DevicePose:
@@ -412,6 +439,22 @@ class ElasticFusion:
             pp = self._pose.ctypes.data_as(C.POINTER(C.c_float))
         check(lib.dms_fusion_process_frame_begin(self.h, C.c_void_p(self._rgb.ptr), ch, C.c_void_p(self._depth.ptr), pp, weightMultiplier,
                                                  stream), "dms_fusion_process_frame_begin")
+
+    # -- after a map merge (ReferenceFrame::consumeReferenceFrame): several cameras, one map ------------------
+    def joinMap(self, owner, relativeTransform, stream=None):
+        """`owner`'s map consumes this camera's map (moved by relativeTransform); this camera's pose is re-based and its later
+        frames track against / fuse into owner's map.  Both contexts in this process, driven from one thread and stream."""
+        t, tp = _f16(relativeTransform)
+        check(lib.dms_fusion_join_map(self.h, owner.h, tp, stream), "dms_fusion_join_map")
+        self._owner = owner  # must outlive this context
+
+    def importCamera(self, owner, pose, tick, last_rgb_ptr, channels, last_depth_ptr, stream=None):
+        """This fresh context becomes a camera that arrives from another rank: `pose` (already in owner's frame), `tick`, and the
+        last frame it processed (device pointers), from which the live state is rebuilt.  Joins owner's map; fuses nothing."""
+        t, tp = _f16(pose)
+        check(lib.dms_fusion_import_camera(self.h, owner.h, tp, int(tick), C.c_void_p(last_rgb_ptr), int(channels), C.c_void_p(last_depth_ptr),
+                                           stream), "dms_fusion_import_camera")
+        self._owner = owner
 
     def setOrbLoop(self, orbTcwOld, orbTcwNew):
         """Arm the next processFrameBegin with an ORB loop closure (ElasticFusion.cpp:292-350); None, None disarms."""

@@ -1,0 +1,388 @@
+"""Collaborative session past the merge: cameras whose maps merge, across ranks.
+
+The reference runs every camera's processFrame in turn in one process (GUI/src/MainController.cpp:262-400); its inter-map block
+(Core/src/ElasticFusion.cpp:595-632, compiled out with `if (false)`) lets a camera query every OTHER reference frame's fern
+database and, on a verified match, has that reference frame consume the camera's own (ReferenceFrame::consumeReferenceFrame,
+ReferenceFrame.h:121-150): surfels and key frames are appended, the consumed frame's cameras move over with their pose, pose graph and
+relative constraints re-based, and from then on all of them track against and fuse into ONE map.
+
+Here camera c is READ on rank c % world for the whole session (its frames arrive there) and is HOSTED - its Context lives, its
+frames are processed - on the rank that hosts its reference frame: rank c % world until its frame is consumed, then the consuming
+frame's rank.  Per tick, on every rank, `CollabSession.step`:
+
+  1. forward   a rank whose camera is hosted elsewhere sends that camera's frame to the host, point to point (RGB8 + depth u16:
+               1.5 MB at 640 x 480, nothing against one xGMI link);
+  2. frames    every hosted camera's processFrame, in camera-id order (one thread, one stream: the reference's loop);
+  3. publish   every hosted camera's frame block (W/8 x H/8 thumbnails of its fill-in textures | pose | tick | camera id) is offered
+               to ITS map's fern database (Ferns::addFrame) and all-gathered (the one collective; slots per rank = the most cameras
+               any rank hosts, 1 before the first merge);
+  4. query     owner computes: for every reference frame hosted here and every camera of another frame, Ferns::findFrame with
+               interMap = true on the gathered thumbnails (search, code agreement, thumbnail-sized ICP + photometric check);
+               the (closest, recoveryPose) table is all-gathered (18 floats per pair);
+  5. decide    every rank applies the reference's sequential rule to the same table - cameras in id order, reference frames in
+               id order, first verified match wins, at most one merge per frame and tick - so all ranks agree without a vote;
+  6. merge     relativeTransform = recoveryPose * currPose.inverse() (ReferenceFrame.h:98).  Same rank: the consuming map
+               consumes the other (dms_fusion_join_map), fern databases merge (dms_ferns_consume).  Across ranks: the consumed
+               frame's rank sends, point to point, its surfel records, its key-frame records and per camera {pose, tick, last
+               frame, pose graph, relative constraints}; the consuming rank appends them (dms_model_consume_records,
+               dms_ferns_consume_records) and re-creates each camera (dms_fusion_import_camera); the sender frees its copies.
+
+The engines behind `backend` are either the product (GpuBackend below: fusion.ElasticFusion + ferns.Ferns in HBM) or, in the CPU
+tests, stand-ins with the same call surface built on the oracle - so the protocol itself (who sends what to whom, the decision
+rule, the re-basing) is exercised over gloo without a GPU and compared with oracle/orc_pipeline.Session, which plays the same
+session in one process.  torch.distributed carries everything (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in tests)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+META_BYTES = 80  # per published block: camera id i32 | tick i32 | 2 x pad | pose 16 x f32
+
+
+class CollabSession:
+    def __init__(self, backend, n_cameras, width, height, rank=0, world=1, device=None, fern_threshold=0.3095, inter_map=1, query_from=0):
+        self.be, self.n, self.W, self.H = backend, n_cameras, width, height
+        self.rank, self.world = rank, world
+        self.device = device or torch.device("cpu")
+        self.fern_threshold = fern_threshold
+        self.inter_map = inter_map  # Ferns::findFrame's interMap argument (1 = the reference's; 2: see dmslam_ferns.h)
+        self.query_from = query_from  # first tick index at which cameras query other maps (0: from the start, as the reference would)
+        self.frame_of = list(range(n_cameras))                    # camera -> reference frame (the id of its founding camera)
+        self.host_of_frame = {c: c % world for c in range(n_cameras)}  # reference frame -> rank
+        self.cams, self.ferns = {}, {}                            # hosted here: camera id -> engine, frame id -> fern database
+        self.pose_graph = {c: [] for c in range(n_cameras)}       # of the cameras hosted here
+        self.relative_cons = {c: [] for c in range(n_cameras)}
+        self.last_frame = {}                                      # camera -> (rgb, depth) of the last processed frame (host arrays)
+        for c in range(n_cameras):
+            if c % world == rank:
+                self.cams[c] = backend.make_camera(c)
+                self.ferns[c] = backend.make_ferns()
+        self.block_bytes = backend.block_bytes() + META_BYTES
+        self.merges, self.matches = [], []
+
+    # ---- helpers -------------------------------------------------------------------------------------------------------------
+    def host_of_camera(self, c):
+        return self.host_of_frame[self.frame_of[c]]
+
+    def hosted(self):
+        return sorted(self.cams)
+
+    def _t(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def _send(self, arr, dst):
+        t = self._t(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+        dist.send(torch.tensor([t.numel()], dtype=torch.int64, device=self.device), dst)
+        if t.numel():
+            dist.send(t, dst)
+
+    def _recv(self, src, dtype, shape=None):
+        n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        dist.recv(n, src)
+        t = torch.zeros(int(n.item()), dtype=torch.uint8, device=self.device)
+        if t.numel():
+            dist.recv(t, src)
+        a = t.cpu().numpy().view(dtype)
+        return a.reshape(shape) if shape is not None else a
+
+    # ---- one tick ------------------------------------------------------------------------------------------------------------
+    def step(self, k, my_frames):
+        """my_frames: {camera id: (rgb u8 HxWx3, depth u16 HxW)} for the cameras READ on this rank.  Returns {camera: result} for
+        the cameras hosted here."""
+        # 1. forward the frames of cameras hosted elsewhere / receive those hosted here
+        frames = {}
+        for c in range(self.n):
+            src, host = c % self.world, self.host_of_camera(c)
+            if src == host:
+                if host == self.rank:
+                    frames[c] = my_frames[c]
+            elif src == self.rank:
+                self._send(my_frames[c][0], host)
+                self._send(my_frames[c][1], host)
+            elif host == self.rank:
+                rgb = self._recv(src, np.uint8, (self.H, self.W, 3))
+                frames[c] = (rgb, self._recv(src, np.uint16, (self.H, self.W)))
+        # 2. every hosted camera's frame, in id order
+        out = {}
+        for c in self.hosted():
+            cam = self.cams[c]
+            tick_before = cam.tick()
+            out[c] = cam.processFrame(frames[c][0], frames[c][1])
+            self.pose_graph[c].append((tick_before, cam.pose().copy()))
+            self.last_frame[c] = frames[c]
+        # 3. publish: own map's database, then the all-gather
+        host_counts = [sum(1 for c in range(self.n) if self.host_of_camera(c) == r) for r in range(self.world)]
+        slots = max(host_counts)
+        local = np.zeros((slots, self.block_bytes), np.uint8)
+        for i, c in enumerate(self.hosted()):
+            cam = self.cams[c]
+            blk = cam.thumbnails()
+            pose, tick = cam.pose(), cam.tick()
+            self.ferns[self.frame_of[c]].addBlock(blk, pose, tick, self.fern_threshold)
+            local[i, :len(blk)] = blk
+            meta = np.zeros(META_BYTES // 4, np.float32)
+            meta[:2] = np.array([c, tick], np.int32).view(np.float32)
+            meta[4:20] = np.asarray(pose, np.float32).reshape(16)
+            local[i, len(blk):] = meta.view(np.uint8)
+        gathered = self._allgather(local.reshape(-1)).reshape(self.world, slots, self.block_bytes)
+        blocks = {}
+        for r in range(self.world):
+            for i in range(host_counts[r]):
+                raw = gathered[r, i]
+                meta = raw[self.block_bytes - META_BYTES:].view(np.float32)
+                c, tick = (int(v) for v in meta[:2].view(np.int32))
+                blocks[c] = (raw[:self.block_bytes - META_BYTES], meta[4:20].reshape(4, 4).copy(), tick)
+        # 4. owner computes: every hosted reference frame against every camera of another frame
+        table = np.zeros((self.n, self.n, 18), np.float32)  # [camera a][frame fb] = valid, closest, recoveryPose
+        for fb in sorted(self.ferns):
+            for a in range(self.n):
+                if self.frame_of[a] == fb or k < self.query_from:
+                    continue
+                blk, pose, tick = blocks[a]
+                closest, cand, est = self.ferns[fb].findFrameThumbs(blk, pose, tick, self.inter_map)
+                table[a, fb, 0], table[a, fb, 1] = 1.0, float(closest)
+                table[a, fb, 2:] = np.asarray(est, np.float32).reshape(16)
+                self.matches.append((k, a, fb, closest, cand))
+        tables = self._allgather(table.reshape(-1).view(np.uint8)).view(np.float32).reshape(self.world, self.n, self.n, 18)
+        # 5. the same decision on every rank (oracle/orc_pipeline.Session.step: cameras in id order, frames in id order)
+        decided, busy = [], set()
+        for a in range(self.n):
+            fa = self.frame_of[a]
+            if fa in busy or k < self.query_from:
+                continue
+            for fb in sorted(set(self.frame_of)):
+                if fb == fa or fb in busy:
+                    continue
+                e = tables[self.host_of_frame[fb], a, fb]
+                assert e[0] == 1.0, "no verification result for camera %d against frame %d" % (a, fb)
+                if e[1] < 0:
+                    continue
+                T = self.be.relative_transform(e[2:].reshape(4, 4), blocks[a][1])
+                decided.append((fb, fa, T))
+                busy.update((fa, fb))
+                break
+        # 6. merges
+        for fb, fa, T in decided:
+            self._merge(k, fb, fa, T)
+        return out
+
+    def _allgather(self, local_u8):
+        if self.world == 1:
+            return np.ascontiguousarray(local_u8).reshape(1, -1).copy()
+        l = self._t(np.ascontiguousarray(local_u8))
+        g = torch.zeros((self.world, l.numel()), dtype=torch.uint8, device=self.device)
+        try:
+            dist.all_gather_into_tensor(g.view(-1), l)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([g[r] for r in range(self.world)], l)
+        return g.cpu().numpy()
+
+    def _rebase(self, c, T):
+        self.pose_graph[c] = [(t, self.be.pose_compose(T, p)) for t, p in self.pose_graph[c]]
+        self.relative_cons[c] = [np.concatenate([self.be.transform_point(T, r[:3]), self.be.transform_point(T, r[3:6])]).astype(np.float32)
+                                 for r in self.relative_cons[c]]
+
+    def _merge(self, k, fb, fa, T):
+        """reference frame fb consumes fa (ReferenceFrame::consumeReferenceFrame)"""
+        hb, ha = self.host_of_frame[fb], self.host_of_frame[fa]
+        moving = [c for c in range(self.n) if self.frame_of[c] == fa]
+        if hb == ha:
+            if hb == self.rank:
+                owner = self.cams[next(c for c in self.hosted() if self.frame_of[c] == fb)]
+                founder_first = sorted(moving, key=lambda c: (c != fa, c))  # the camera that owns fa's map carries it over
+                for c in founder_first:
+                    self.cams[c].joinMap(owner, T)
+                    self._rebase(c, T)
+                self.ferns[fb].consume(self.ferns.pop(fa), T, self.fern_threshold)
+        elif ha == self.rank:  # the consumed side: ship everything, free the local copies
+            founder = self.cams[fa]
+            self._send(founder.exportMap(), hb)
+            self._send(self.ferns[fa].exportRecords(), hb)
+            for c in moving:
+                cam = self.cams[c]
+                hdr = np.zeros(20, np.float32)
+                hdr[:2] = np.array([cam.tick(), len(self.pose_graph[c])], np.int32).view(np.float32)
+                hdr[2:3] = np.array([len(self.relative_cons[c])], np.int32).view(np.float32)
+                hdr[4:20] = cam.pose().reshape(16)
+                self._send(hdr, hb)
+                self._send(self.last_frame[c][0], hb)
+                self._send(self.last_frame[c][1], hb)
+                pg = np.zeros((len(self.pose_graph[c]), 17), np.float32)
+                for i, (t, p) in enumerate(self.pose_graph[c]):
+                    pg[i, 0] = np.array([t], np.int32).view(np.float32)[0]
+                    pg[i, 1:] = np.asarray(p, np.float32).reshape(16)
+                self._send(pg, hb)
+                self._send(np.asarray(self.relative_cons[c], np.float32).reshape(-1, 6), hb)
+            for c in moving:
+                self.cams.pop(c).close()
+                self.pose_graph[c], self.relative_cons[c] = [], []
+                self.last_frame.pop(c, None)
+            self.ferns.pop(fa).close()
+        elif hb == self.rank:  # the consuming side
+            owner = self.cams[next(c for c in self.hosted() if self.frame_of[c] == fb)]
+            owner.consumeRecords(self._recv(ha, np.float32).reshape(-1, 20), T)
+            self.ferns[fb].consumeRecords(self._recv(ha, np.uint8), T, self.fern_threshold)
+            for c in moving:
+                hdr = self._recv(ha, np.float32)
+                tick, n_pg = (int(v) for v in hdr[:2].view(np.int32))
+                pose = hdr[4:20].reshape(4, 4)
+                rgb = self._recv(ha, np.uint8, (self.H, self.W, 3))
+                depth = self._recv(ha, np.uint16, (self.H, self.W))
+                pg = self._recv(ha, np.float32).reshape(-1, 17)
+                rc = self._recv(ha, np.float32).reshape(-1, 6)
+                cam = self.be.make_camera(c)
+                cam.importCamera(owner, self.be.pose_compose(T, pose), tick, rgb, depth)
+                self.cams[c] = cam
+                self.pose_graph[c] = [(int(r[:1].view(np.int32)[0]), r[1:].reshape(4, 4).copy()) for r in pg]
+                self.relative_cons[c] = [r.copy() for r in rc]
+                self.last_frame[c] = (rgb, depth)
+                self._rebase(c, T)
+        for c in moving:
+            self.frame_of[c] = fb
+        del self.host_of_frame[fa]
+        self.merges.append((k, fb, fa, np.asarray(T, np.float32).copy()))
+
+    def close(self):
+        for c in list(self.cams):
+            if self.frame_of[c] != c:  # joined cameras first: their owner must outlive them
+                self.cams.pop(c).close()
+        for c in list(self.cams):
+            self.cams.pop(c).close()
+        for f in list(self.ferns):
+            self.ferns.pop(f).close()
+
+
+# ---- the product behind the session's call surface ------------------------------------------------------------------------------
+class _GpuCamera:
+    def __init__(self, be, c):
+        from . import fusion
+
+        self.be, self.c = be, c
+        self.ef = fusion.ElasticFusion(be.W, be.H, be.K, timeIdx=c, num_sensors=be.num_sensors, **be.opts)
+        self._last = None
+        self._block = torch.zeros(be.block_bytes(), dtype=torch.uint8, device=be.device)
+        self._tick, self._pose = 1, np.eye(4, dtype=np.float32)
+
+    def processFrame(self, rgb, depth):
+        r = self.ef.processFrame(rgb, depth)
+        self._last = r
+        self._tick, self._pose = int(r.tick), np.array(r.pose, np.float32).reshape(4, 4)
+        return r
+
+    def tick(self):
+        return self._tick
+
+    def pose(self):
+        return self._pose
+
+    def thumbnails(self):
+        self.ef.thumbnails(self._block.data_ptr(), None)
+        torch.cuda.synchronize(self.be.device)
+        return self._block.cpu().numpy()
+
+    def joinMap(self, owner, T):
+        self.ef.joinMap(owner.ef, T)
+        self._pose = self.be.pose_compose(T, self._pose)
+
+    def exportMap(self):
+        return self.ef.globalModel().downloadMap().view(np.float32).reshape(-1, 20)
+
+    def consumeRecords(self, rec, T):
+        if len(rec):
+            t = torch.from_numpy(np.ascontiguousarray(rec, np.float32)).to(self.be.device)
+            self.ef.globalModel().consumeRecords(t.data_ptr(), len(rec), T)
+
+    def importCamera(self, owner, pose, tick, rgb, depth):
+        r = torch.from_numpy(np.ascontiguousarray(rgb)).to(self.be.device)
+        d = torch.from_numpy(np.ascontiguousarray(depth).view(np.int16)).to(self.be.device)
+        self.ef.importCamera(owner.ef, pose, tick, r.data_ptr(), 3, d.data_ptr())
+        self._tick, self._pose = int(tick), np.asarray(pose, np.float32).reshape(4, 4).copy()
+
+    def model(self):
+        return self.ef.globalModel().downloadMap()
+
+    def close(self):
+        self.ef.close()
+
+
+class _GpuFerns:
+    def __init__(self, be):
+        from . import ferns
+
+        self.be = be
+        self.db = ferns.Ferns(be.W, be.H, be.K, **be.fern_opts)
+
+    def _dev(self, blk):
+        return torch.from_numpy(np.ascontiguousarray(blk)).to(self.be.device)
+
+    def addBlock(self, blk, pose, tick, thr):
+        t = self._dev(blk)
+        p = torch.from_numpy(np.ascontiguousarray(pose, np.float32).reshape(16)).to(self.be.device)
+        self.db.addFrameAsync(t.data_ptr(), p.data_ptr(), int(tick), thr, None)
+        torch.cuda.synchronize(self.be.device)
+
+    def findFrameThumbs(self, blk, pose, tick, inter_map=1):
+        t = self._dev(blk)
+        m, _ = self.db.findFrameThumbs(t.data_ptr(), np.ascontiguousarray(pose, np.float32), int(tick), False, int(inter_map), None)
+        return int(m.closest), int(m.candidate), np.array(m.estPose, np.float32).reshape(4, 4)
+
+    def consume(self, other, T, thr):
+        self.db.consume(other.db, T, thr)
+
+    def exportRecords(self):
+        n, rb = len(self.db), self.db.recordBytes()
+        buf = torch.zeros(max(n, 1) * rb, dtype=torch.uint8, device=self.be.device)
+        got = self.db.exportRecords(buf.data_ptr(), n)
+        return buf[:got * rb].cpu().numpy()
+
+    def consumeRecords(self, raw, T, thr):
+        rb = self.db.recordBytes()
+        if len(raw):
+            t = self._dev(raw)
+            self.db.consumeRecords(t.data_ptr(), len(raw) // rb, T, thr)
+
+    def __len__(self):
+        return len(self.db)
+
+    def close(self):
+        self.db.close()
+
+
+class GpuBackend:
+    """fusion.ElasticFusion + ferns.Ferns (HBM) behind CollabSession."""
+
+    def __init__(self, width, height, K, device, num_sensors=3, fern_opts=None, **opts):
+        from . import collab
+
+        self.W, self.H, self.K, self.device, self.num_sensors, self.opts = width, height, K, device, num_sensors, opts
+        self.fern_opts = dict(num=500, maxDepth_mm=3000, photoThresh=115.0, seed=20260929, capacity=1024)
+        self.fern_opts.update(fern_opts or {})
+        self._bb = collab.thumbnail_bytes(width, height)
+
+    def block_bytes(self):
+        return self._bb
+
+    def make_camera(self, c):
+        return _GpuCamera(self, c)
+
+    def make_ferns(self):
+        return _GpuFerns(self)
+
+    def relative_transform(self, recoveryPose, currPose):
+        from . import fusion
+
+        return fusion.relative_transform(recoveryPose, currPose)
+
+    def pose_compose(self, a, b):
+        from . import fusion
+
+        return fusion.pose_compose(a, b)
+
+    def transform_point(self, T, p):
+        T = np.asarray(T, np.float32).reshape(4, 4)
+        o = np.zeros(3, np.float32)
+        for i in range(3):  # ((T0 x + T1 y) + T2 z) + T3, every operation rounded
+            s = np.float32(T[i, 0] * p[0])
+            s = np.float32(s + np.float32(T[i, 1] * p[1]))
+            s = np.float32(s + np.float32(T[i, 2] * p[2]))
+            o[i] = np.float32(s + T[i, 3])
+        return o

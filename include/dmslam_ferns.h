@@ -86,7 +86,11 @@ typedef struct dms_fern_match {
 } dms_fern_match;
 
 /* Eigen::Matrix4f Ferns::findFrame(constraints, currPose, vertexTexture, normalTexture, imageTexture, time, lost,
- * depthCutoff, interMap) (Ferns.cpp:277-423).  constraints: room for 8 * 64 floats (or NULL).  Synchronises `s`. */
+ * depthCutoff, interMap) (Ferns.cpp:277-423).  constraints: room for 8 * 64 floats (or NULL).  Synchronises `s`.
+ * interMap: 0 / 1 as the reference (1: frames of any age are candidates and the verification tracker runs its pyramid with the SO3
+ * pre-alignment and 50 iterations per level, RGBDOdometry.cpp:387-389); 2 (no reference counterpart, used by the collaborative
+ * session where asked): candidates as for 1, verification with the intra-map settings (one level, 10 iterations) - the 3 x 50
+ * point-to-plane iterations on 80 x 60 thumbnails drift along large planes. */
 int dms_ferns_find_frame(dms_ferns* f, const dms_image2d* vertex, const dms_image2d* normal, const dms_image2d* image_rgba,
                          const float* currPose16, int time, int lost, int interMap, dms_fern_match* match, float* constraints,
                          dms_stream s);
@@ -114,6 +118,15 @@ int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride,
  * re-posed by relativeTransform, goes through addFrame(Frame*, threshold) of `dst` (re-encoded with dst's table).
  * added = frames accepted.  Synchronises. */
 int dms_ferns_consume(dms_ferns* dst, dms_ferns* src, const float* relativeTransform16, float threshold, int* added, dms_stream s);
+
+/* The same when the two databases live on different ranks: the stored key frames as self-contained records of
+ * dms_ferns_record_bytes() bytes each ({thumbnail block | pose | srcTime}), written to / read from HBM so that they travel
+ * point to point (RCCL send / recv, dms_collab_send / _recv); consume_records re-poses each frame by relativeTransform and offers it
+ * to addFrame(Frame*, threshold) exactly like dms_ferns_consume.  Both handles must have been created with the same geometry. */
+size_t dms_ferns_record_bytes(dms_ferns* f);
+int dms_ferns_export_records(dms_ferns* f, void* records_dev, int max_count, int* count, dms_stream s);
+int dms_ferns_consume_records(dms_ferns* dst, const void* records_dev, int count, const float* relativeTransform16, float threshold, int* added,
+                              dms_stream s);
 
 #ifdef __cplusplus
 }

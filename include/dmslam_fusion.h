@@ -319,6 +319,29 @@ int dms_fusion_get_global_loop_constraints(dms_fusion* f, float* rows7_host, int
 int dms_fusion_apply_global_loop_begin(dms_fusion* f, const float* orbTcwOld16, const float* orbTcwNew16, dms_stream s);
 int dms_fusion_apply_global_loop_end(dms_fusion* f, const float* graph_host, int graph_nodes, int accepted, dms_stream s);
 
+/* After a map merge: several cameras, ONE map.  ReferenceFrame::consumeReferenceFrame (ReferenceFrame.h:121-150) appends the consumed
+ * map to the consuming one, moves the consumed map's cameras into the consuming reference frame (currPose = relativeTransform *
+ * currPose) and from then on every camera of that frame tracks against and fuses into the one map, each with its own time slot
+ * (timeIdx = Context::id(); MainController.cpp:262-400 runs them one after the other).
+ *   dms_fusion_join_map      both cameras live in this process (two contexts on one device, as in the reference): `owner`'s map
+ *                            consumes `f`'s (dms_model_consume with relativeTransform), f's pose is re-based, and f's later frames
+ *                            use owner's map.  f keeps its tracker state (tick, last image pyramid): the very next
+ *                            dms_fusion_process_frame continues the camera.
+ *   dms_fusion_import_camera the camera arrives from another rank (its map records went through dms_model_consume_records, its
+ *                            key frames through dms_ferns_consume_records): `f` is a fresh context created with the camera's
+ *                            timeIdx; pose16 = relativeTransform * the camera's pose, tick = its tick, last_rgb / last_depth = the
+ *                            last frame it processed, from which the context rebuilds the live state that frame left behind
+ *                            (the intensity pyramid the next frame's SO3 pre-alignment reads).  Nothing is fused by this call.
+ * Rules: the contexts of one map are driven from ONE host thread on ONE stream, one frame at a time (what the reference does);
+ * `owner` must outlive the contexts that joined it; timeIdx values differ and are < the map's num_sensors.  Both calls synchronise. */
+int dms_fusion_join_map(dms_fusion* f, dms_fusion* owner, const float* relativeTransform16, dms_stream s);
+int dms_fusion_import_camera(dms_fusion* f, dms_fusion* owner, const float* pose16, int tick, const void* last_rgb_dev, int rgb_channels,
+                             const unsigned short* last_depth_dev, dms_stream s);
+/* relativeTransform = recoveryPose * currPose.inverse() (ReferenceFrame.h:98) and c = a * b, row-major 4 x 4 floats on the host, in
+ * the library's fixed operation order (so that two hosts compute the same bits) */
+int dms_relative_transform(const float* recoveryPose16, const float* currPose16, float* out16);
+int dms_pose_compose(const float* a16, const float* b16, float* out16);
+
 dms_model* dms_fusion_model(dms_fusion* f);
 /* Device address of the camera pose (16 floats, row-major, camera-to-world) the frame step keeps in HBM: valid for the
  * life of the context, written by the tracker's last kernel — stream-ordered consumers (e.g. dms_ferns_add_frame_async)

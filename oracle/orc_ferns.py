@@ -198,8 +198,9 @@ class Ferns:
         o = self._make_odometry()
         o.initICPModel(fr.initVerts, fr.initNorms, float(cutoff), fernPose)
         o.initICPMaps(verts, norms, float(cutoff))
+        deep = int(interMap) == 1  # interMap == 2: candidates of any age, verified with the intra-map tracker settings (dmslam_ferns.h)
         t, R, res = o.getIncrementalTransformation(fernPose[:3, 3].copy(), fernPose[:3, :3].copy(), rgbOnly=False, icpWeight=100.0,
-                                                   pyramid=bool(interMap), fastOdom=False, so3=bool(interMap), interMap=bool(interMap))
+                                                   pyramid=deep, fastOdom=False, so3=deep, interMap=deep)
         est = np.eye(4, dtype=np.float32)
         est[:3, :3], est[:3, 3] = R, t
         out["estPose"] = est

@@ -31,7 +31,16 @@ def _mat_vec_f32(M, v):
     return out
 
 
+class MapRef:
+    """One reference frame's surfel map (ReferenceFrame::m_localModel): shared by every camera that has been merged into it."""
+
+    def __init__(self):
+        self.model = np.zeros(0, orc.SURFEL_DTYPE)
+
+
 class ElasticFusion:
+    model = property(lambda self: self.map.model, lambda self, v: setattr(self.map, "model", v))
+
     def __init__(self, width, height, K, timeDelta=200, confidence=10.0, depthCut=3.0, icpWeight=10.0, fastOdom=False, so3=True,
                  frameToFrameRGB=False, pyramid=True, hybrid_tracking=True, rgbOnly=False, timeIdx=0, maxDepthProcessed=25.0,
                  model_capacity=None, nid_keyframing=False, nid_threshold=0.80, nid_depth_lambda=0.7, nid_bins_img=64,
@@ -52,7 +61,7 @@ class ElasticFusion:
         self.local_loop_closure = local_loop_closure
         self.modelToModel = orc.Odometry(width, height, cx, cy, fx, fy) if local_loop_closure else None  # Context.h:317-378
         self.old = None
-        self.model = np.zeros(0, orc.SURFEL_DTYPE)
+        self.map = MapRef()
         self.currPose = np.eye(4, dtype=np.float32)
         self.tick = 1
         self.initialised = False
@@ -285,3 +294,100 @@ class ElasticFusion:
         out.tick = self.tick
         self.last = out
         return out
+
+
+# ---- collaborative session: several cameras, maps that merge (checker of densemonoslam_amd.collab.CollabSession) -----------------
+class Session:
+    """The reference's multi-camera loop in ONE process (GUI/src/MainController.cpp:262-400: every camera's processFrame in turn)
+    with the inter-map block of ElasticFusion::processFrame (ElasticFusion.cpp:595-632, compiled out there with `if (false)`)
+    switched on, in the form DESIGN.md 7 gives it for one camera per GPU:
+
+      per tick, for every camera in id order: processFrame; then every camera offers its frame block (W/8 x H/8 thumbnails of the
+      fill-in textures, pose, tick) to the fern database of ITS map (Ferns::addFrame); then every camera queries the database of
+      every OTHER map in reference-frame order (Ferns::findFrame with interMap = true on the thumbnails: search, code agreement,
+      thumbnail-sized ICP + photometric check); the first verified match merges: relativeTransform = recoveryPose *
+      currPose.inverse() (ReferenceFrame.h:98), the matched map consumes the querying camera's map
+      (ReferenceFrame::consumeReferenceFrame, :121-150: surfels, key frames, cameras - pose, pose graph and relative constraints
+      re-based), at most one merge per map and tick.
+
+    Differences from the compiled-out reference block, all of them: the verification is the fern database's own (thumbnails) -
+    resolveRelativeTransformationFern's second, full-resolution refinement against an INACTIVE prediction (ReferenceFrame.h:72-90)
+    is not run, because a querying camera on another GPU ships thumbnails, not full-resolution textures; queries run after all
+    cameras of the tick have been processed rather than inside each camera's processFrame."""
+
+    def __init__(self, n, width, height, K, fern_seed=20260929, fern_threshold=0.3095, fern_num=500, fern_max_depth_mm=3000,
+                 fern_photo_thresh=115.0, inter_map=1, query_from=0, **opts):
+        from . import orc_ferns
+
+        self.inter_map = inter_map  # Ferns::findFrame's interMap argument (2: see dmslam_ferns.h)
+        self.query_from = query_from  # first tick index at which cameras query other maps (0 = from the start, as the reference would)
+        self.n, self.W, self.H, self.K = n, width, height, tuple(float(v) for v in K)
+        self.cams = [ElasticFusion(width, height, K, timeIdx=i, **opts) for i in range(n)]
+        Kf = self.K
+        mk = lambda: orc_ferns.Ferns(width, height, K, num=fern_num, maxDepth_mm=fern_max_depth_mm, photoThresh=fern_photo_thresh, seed=fern_seed,
+                                     make_odometry=lambda: orc.Odometry(width // 8, height // 8, Kf[2] / 8, Kf[3] / 8, Kf[0] / 8, Kf[1] / 8))
+        self.ferns = [mk() for _ in range(n)]     # one database per reference frame, indexed by the frame's first camera
+        self.frame_of = list(range(n))            # m_contextToReferenceFrameMap: camera -> reference frame
+        self.fern_threshold = fern_threshold
+        self.pose_graph = [[] for _ in range(n)]  # Context::poseGraph(): (tick, pose) per processed frame
+        self.relative_cons = [[] for _ in range(n)]  # Context::relativeCons(): rows {src xyz, target xyz} the caller's solver produced
+        self.merges = []                          # (tick index, consuming frame, consumed frame, relativeTransform)
+        self.matches = []
+
+    def thumbs(self, cam):
+        from . import orc_ferns
+
+        fi, fv, fn = cam.fill
+        th, tw = self.H // 8, self.W // 8
+        return orc_ferns.resize_nearest(fi, th, tw), orc_ferns.resize_nearest(fv, th, tw), orc_ferns.resize_nearest(fn, th, tw)
+
+    def step(self, frames, k):
+        """frames[i] = (rgb, depth) of camera i; k = the tick index (for the log)."""
+        from . import orc_ferns
+
+        outs = []
+        for i, cam in enumerate(self.cams):
+            tick_before = cam.tick
+            outs.append(cam.processFrame(frames[i][0], frames[i][1]))
+            self.pose_graph[i].append((tick_before, cam.currPose.copy()))
+        blocks = [self.thumbs(cam) for cam in self.cams]
+        for i, cam in enumerate(self.cams):  # the own map's database sees every frame of its cameras
+            img, v, nrm = blocks[i]
+            self.ferns[self.frame_of[i]]._add(img, v, nrm, cam.currPose.copy(), cam.tick, self.fern_threshold)
+        busy = set()
+        for a, cam in enumerate(self.cams):  # queries, in camera order
+            fa = self.frame_of[a]
+            if fa in busy or k < self.query_from:
+                continue
+            for fb in sorted(set(self.frame_of)):
+                if fb == fa or fb in busy:
+                    continue
+                m = self.ferns[fb].findFrame(cam.currPose, None, None, None, cam.tick, lost=False, interMap=self.inter_map, thumbs=blocks[a])
+                self.matches.append((k, a, fb, m["closest"], m["candidate"]))
+                if m["closest"] < 0:
+                    continue
+                T = orc_ferns._mul44(m["estPose"], orc.inv4f(cam.currPose))
+                self.consume(fb, fa, T)
+                self.merges.append((k, fb, fa, T.copy()))
+                busy.update((fa, fb))
+                break
+        return outs
+
+    def consume(self, fb, fa, T):
+        """reference frame fb consumes fa (ReferenceFrame::consumeReferenceFrame)"""
+        from . import orc_ferns
+
+        owner = next(c for i, c in enumerate(self.cams) if self.frame_of[i] == fb)
+        other = next(c for i, c in enumerate(self.cams) if self.frame_of[i] == fa)
+        owner.map.model = orc.model_consume(owner.map.model, other.map.model, T)
+        self.ferns[fb].consume(self.ferns[fa], T, self.fern_threshold)
+        for i, cam in enumerate(self.cams):
+            if self.frame_of[i] != fa:
+                continue
+            cam.currPose = orc_ferns._mul44(T, cam.currPose)
+            cam.map = owner.map
+            self.frame_of[i] = fb
+            self.pose_graph[i] = [(t, orc_ferns._mul44(T, p)) for t, p in self.pose_graph[i]]
+            self.relative_cons[i] = [np.concatenate([orc_ferns._mul4v(T, np.append(r[:3], np.float32(1)))[:3],
+                                                     orc_ferns._mul4v(T, np.append(r[3:6], np.float32(1)))[:3]]).astype(np.float32)
+                                     for r in self.relative_cons[i]]

@@ -1,0 +1,261 @@
+"""The collaborative session past the merge (densemonoslam_amd/session.py) over gloo, world size 2, without a GPU:
+publish -> match -> verify -> merge across ranks (surfel records, key-frame records, camera state point to point) -> more frames
+with both cameras fusing into ONE map on the consuming rank, the consumed rank forwarding its camera's frames.
+
+The engines are stand-ins with the product's call surface built on the oracle, so what is under test is the PROTOCOL: who sends what
+to whom, the decision rule, the re-basing of poses / pose graphs / relative constraints.  The checker is oracle/orc_pipeline.Session,
+the same session played in one process the way the reference runs its cameras (MainController.cpp:262-400): merged map, both
+trajectories and the merge transform must be the same bits."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+W, H = 320, 240
+K = (264.0, 264.0, 160.0, 120.0)
+N_TICKS, QUERY_FROM, OFFSET = 14, 4, 14  # camera 1 runs OFFSET frames ahead of camera 0 on the same trajectory
+SESSION_OPTS = dict(inter_map=2, query_from=QUERY_FROM)
+FERN_PHOTO = 1000.0  # (the colour check rejects ICP-only poses in the synthetic room: tests/test_ferns_gpu.py)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def frames_for(synth, k):
+    out = {}
+    for c, off in ((0, 0), (1, OFFSET)):
+        d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True)
+        out[c] = (rgb, d)
+    return out
+
+
+# ---- oracle-backed stand-ins with the call surface of session.GpuBackend's engines ---------------------------------------------------
+class _OrcCamera:
+    def __init__(self, be, c):
+        from oracle import orc_pipeline
+
+        self.be, self.c = be, c
+        self.ef = orc_pipeline.ElasticFusion(W, H, K, timeIdx=c)
+
+    def processFrame(self, rgb, depth):
+        return self.ef.processFrame(rgb, depth)
+
+    def tick(self):
+        return self.ef.tick
+
+    def pose(self):
+        return self.ef.currPose
+
+    def thumbnails(self):
+        from oracle import orc_ferns
+
+        fi, fv, fn = self.ef.fill
+        th, tw = H // 8, W // 8
+        parts = [orc_ferns.resize_nearest(fi, th, tw), orc_ferns.resize_nearest(fv, th, tw), orc_ferns.resize_nearest(fn, th, tw)]
+        return np.concatenate([np.ascontiguousarray(p).view(np.uint8).reshape(-1) for p in parts])
+
+    def joinMap(self, owner, T):
+        from oracle import orc, orc_ferns
+
+        if self.ef.map is not owner.ef.map and len(self.ef.map.model) and self.c == self.be.session.frame_of[self.c]:
+            owner.ef.map.model = orc.model_consume(owner.ef.map.model, self.ef.map.model, T)
+        self.ef.map = owner.ef.map
+        self.ef.currPose = orc_ferns._mul44(T, self.ef.currPose)
+
+    def exportMap(self):
+        return np.ascontiguousarray(self.ef.model).view(np.float32).reshape(-1, 20)
+
+    def consumeRecords(self, rec, T):
+        from oracle import orc
+
+        if len(rec):
+            src = np.ascontiguousarray(rec, np.float32).reshape(-1).view(orc.SURFEL_DTYPE)
+            self.ef.map.model = orc.model_consume(self.ef.map.model, src, T)
+
+    def importCamera(self, owner, pose, tick, rgb, depth):
+        from densemonoslam_amd import synth
+
+        self.ef.map = owner.ef.map
+        self.ef.currPose = np.asarray(pose, np.float32).reshape(4, 4).copy()
+        self.ef.tick = int(tick)
+        self.ef.initialised = True
+        # the state the camera's last frame left in its tracker: the intensity pyramid the next SO3 pre-alignment reads
+        self.ef.frameToModel.initFirstRGB(synth.rgba(np.asarray(rgb)))
+
+    def model(self):
+        return self.ef.model
+
+    def close(self):
+        pass
+
+
+class _OrcFerns:
+    def __init__(self):
+        from oracle import orc, orc_ferns
+
+        self.db = orc_ferns.Ferns(W, H, K, num=500, maxDepth_mm=3000, photoThresh=FERN_PHOTO, seed=20260929,
+                                  make_odometry=lambda: orc.Odometry(W // 8, H // 8, K[2] / 8, K[3] / 8, K[0] / 8, K[1] / 8))
+        self.th, self.tw = H // 8, W // 8
+
+    def _unpack(self, blk):
+        n = self.th * self.tw
+        raw = np.ascontiguousarray(blk, np.uint8)
+        return (raw[:n * 4].reshape(self.th, self.tw, 4).copy(), raw[n * 4:n * 20].view(np.float32).reshape(self.th, self.tw, 4).copy(),
+                raw[n * 20:n * 36].view(np.float32).reshape(self.th, self.tw, 4).copy())
+
+    def addBlock(self, blk, pose, tick, thr):
+        img, v, n = self._unpack(blk)
+        self.db._add(img, v, n, np.asarray(pose, np.float32).reshape(4, 4).copy(), int(tick), thr)
+
+    def findFrameThumbs(self, blk, pose, tick, inter_map=1):
+        m = self.db.findFrame(np.asarray(pose, np.float32).reshape(4, 4), None, None, None, int(tick), lost=False, interMap=inter_map,
+                              thumbs=self._unpack(blk))
+        return m["closest"], m["candidate"], m["estPose"]
+
+    def consume(self, other, T, thr):
+        self.db.consume(other.db, T, thr)
+
+    def exportRecords(self):
+        n = self.th * self.tw
+        recs = []
+        for fr in self.db.frames:
+            meta = np.zeros(20, np.float32)
+            meta[:16] = fr.pose.reshape(16)
+            meta[16:17] = np.array([fr.srcTime], np.int32).view(np.float32)
+            recs.append(np.concatenate([np.ascontiguousarray(fr.initRgb).view(np.uint8).reshape(-1), np.ascontiguousarray(fr.initVerts).view(np.uint8).reshape(-1),
+                                        np.ascontiguousarray(fr.initNorms).view(np.uint8).reshape(-1), meta.view(np.uint8)]))
+            assert len(recs[-1]) == n * 36 + 80
+        return np.concatenate(recs) if recs else np.zeros(0, np.uint8)
+
+    def consumeRecords(self, raw, T, thr):
+        from oracle import orc_ferns
+
+        rb = self.th * self.tw * 36 + 80
+        for j in range(len(raw) // rb):
+            rec = np.ascontiguousarray(raw[j * rb:(j + 1) * rb])
+            img, v, n = self._unpack(rec[:rb - 80])
+            meta = rec[rb - 80:].view(np.float32)
+            self.db._add(img, v, n, orc_ferns._mul44(T, meta[:16].reshape(4, 4)), int(meta[16:17].view(np.int32)[0]), thr)
+
+    def __len__(self):
+        return len(self.db.frames)
+
+    def close(self):
+        pass
+
+
+class _OrcBackend:
+    session = None
+
+    def block_bytes(self):
+        return (W // 8) * (H // 8) * 36
+
+    def make_camera(self, c):
+        return _OrcCamera(self, c)
+
+    def make_ferns(self):
+        return _OrcFerns()
+
+    def relative_transform(self, recoveryPose, currPose):
+        from oracle import orc, orc_ferns
+
+        return orc_ferns._mul44(recoveryPose, orc.inv4f(currPose))
+
+    def pose_compose(self, a, b):
+        from oracle import orc_ferns
+
+        return orc_ferns._mul44(a, b)
+
+    def transform_point(self, T, p):
+        from oracle import orc_ferns
+
+        return orc_ferns._mul4v(T, np.append(np.asarray(p, np.float32), np.float32(1)))[:3]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["OMP_NUM_THREADS"] = "4"
+    import torch.distributed as dist
+
+    from densemonoslam_amd import session, synth
+    from oracle import orc
+
+    orc.set_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = _OrcBackend()
+    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **SESSION_OPTS)
+    be.session = s
+    s.relative_cons[rank].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + rank))  # a constraint row the caller's solver produced before the merge
+    hosted_log = []
+    for k in range(N_TICKS):
+        fr = frames_for(synth, k)
+        s.step(k, {c: fr[c] for c in fr if c % world == rank})
+        hosted_log.append(s.hosted())
+    res = dict(rank=rank, hosted=hosted_log, merges=s.merges, frame_of=s.frame_of,
+               pose_graph={c: s.pose_graph[c] for c in s.hosted()}, relative_cons={c: s.relative_cons[c] for c in s.hosted()},
+               maps={f: np.ascontiguousarray(s.cams[next(c for c in s.hosted() if s.frame_of[c] == f)].model()) for f in sorted(s.ferns)},
+               fern_frames={f: len(s.ferns[f]) for f in s.ferns})
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def oracle_session(orc):
+    from densemonoslam_amd import synth
+    from oracle import orc_pipeline
+
+    s = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=FERN_PHOTO, **SESSION_OPTS)
+    for c in range(2):
+        s.relative_cons[c].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + c))
+    for k in range(N_TICKS):
+        fr = frames_for(synth, k)
+        s.step([fr[0], fr[1]], k)
+    return s
+
+
+def test_two_rank_session_merges_and_continues_like_the_one_process_session(oracle_session):
+    ref = oracle_session
+    assert len(ref.merges) == 1 and ref.merges[0][0] >= QUERY_FROM and N_TICKS - ref.merges[0][0] > 8, ref.merges
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    k_merge, fb, fa, T = ref.merges[0]
+    hb = fb % world  # the consuming frame's rank hosts both cameras afterwards
+    for r in range(world):
+        res = results[r]
+        assert [(m[0], m[1], m[2]) for m in res["merges"]] == [(k_merge, fb, fa)], res["merges"]
+        assert res["merges"][0][3].tobytes() == T.tobytes(), "ranks / oracle disagree about the relative transform"
+        assert res["frame_of"] == ref.frame_of
+        # hosting: one camera each up to and including the merge tick, then both on the consuming rank
+        for k, hosted in enumerate(res["hosted"]):
+            want = [r] if k < k_merge else ([0, 1] if r == hb else [])
+            assert hosted == want, (r, k, hosted)
+    host = results[hb]
+    # the merged map, bit for bit
+    m_ref = ref.cams[fb].model
+    m_got = host["maps"][fb]
+    assert len(m_got) == len(m_ref) and all(np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)) for f in m_ref.dtype.names)
+    assert host["fern_frames"][fb] == len(ref.ferns[fb].frames)
+    # both trajectories (the consumed camera's pre-merge poses re-based into the consuming frame), bit for bit
+    for c in range(2):
+        got, want = host["pose_graph"][c], ref.pose_graph[c]
+        assert [t for t, _ in got] == [t for t, _ in want] and len(got) == N_TICKS
+        for (_, a), (_, b) in zip(got, want):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), c
+        assert len(host["relative_cons"][c]) == 1 and host["relative_cons"][c][0].tobytes() == ref.relative_cons[c][0].tobytes()
+    # and the re-basing did something: the consumed camera's first pose is no longer the identity
+    assert not np.array_equal(host["pose_graph"][fa][0][1], np.eye(4, dtype=np.float32))
