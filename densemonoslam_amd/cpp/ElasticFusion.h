@@ -81,6 +81,9 @@ struct FrontEndOptions {
   bool pyramid = true;
   float maxDepthProcessed = 25.f;  // ElasticFusion.cpp:56
   size_t model_capacity = 0;       // 0 = the reference's MAX_VERTICES
+  float depth = 3.f;                   // Options::get().depth (--d): ReferenceFrame's fern database is built with depth * 1000 (ReferenceFrame.h:17)
+  float interMapPhotoThresh = 115.f;   // Options::get().interMapPhotoThresh
+  float fernThresh = 0.3095f;          // Options::get().fernThresh (ReferenceFrame.h:125)
   static FrontEndOptions& get() {
     static FrontEndOptions o;
     return o;
@@ -113,6 +116,7 @@ class ContextT {
   int& numFused() { return m_numFused; }
   const std::string& filename() const { return m_file; }
   const dms_frame_result& lastResult() const { return last; }
+  float lastKFScore() const { return last.nid_score; }  // Context::lastKFScore (Context.h: nidScores().back())
   // one (tick, pose) per processed frame and its time stamp (ElasticFusion.cpp:571-574)
   std::vector<std::pair<unsigned long long int, Mat4>>& poseGraph() { return m_poseGraph; }
   std::vector<int64_t>& poseLogTimes() { return m_poseLogTimes; }
@@ -157,10 +161,94 @@ class ContextT {
   std::vector<int64_t> m_poseLogTimes;
 };
 
+// The deformation graphs stay with the caller (their optimisation is CPU + CHOLMOD, SURVEY 8 "out of scope"); what the reference's
+// GUI reads of them - the node table of the last constrain() - is kept here (MainController.cpp:583, :741)
+struct Deformation {
+  std::vector<float> graph;  // rawGraph: 16 floats per node (Deformation.cpp:192-201)
+  std::vector<float>& getGraph() { return graph; }
+};
+
+// One map and the cameras that fuse into it: ReferenceFrame (Core/src/ReferenceFrame.h:13-214).  "When a new context is created it
+// is assumed to be in its own reference frame.  As inter-map global loop closures occur reference frames are aligned, with one
+// essentially consuming the other" (ElasticFusion.h:318-323).
+template <class Mat4>
+class ReferenceFrameT {
+ public:
+  typedef ContextT<Mat4> Context;
+  std::string name;
+  std::map<std::string, std::shared_ptr<Context>>& contexts() { return m_contexts; }
+  bool& firstRun() { return m_firstRun; }
+  Deformation& globalDeformation() { return m_globalDeformation; }
+  Deformation& localDeformation() { return m_localDeformation; }
+  // the map: the device object of the frame's founding camera (every camera merged into the frame shares it)
+  GlobalModel globalModel() {
+    Context* c = founder();
+    if (!c || !c->fusion) throw std::runtime_error("ReferenceFrame::globalModel: no camera of this frame has processed a frame yet");
+    return GlobalModel(dms_fusion_model(c->fusion));
+  }
+  // the frame's fern key-frame database: Ferns(500, Options::get().depth * 1000, Options::get().interMapPhotoThresh) (ReferenceFrame.h:17)
+  Ferns& ferns() {
+    if (!m_ferns) {
+      const Resolution& r = Resolution::getInstance();
+      const Intrinsics& k = Intrinsics::getInstance();
+      const FrontEndOptions& o = FrontEndOptions::get();
+      m_ferns.reset(new Ferns(500, (int)(o.depth * 1000), o.interMapPhotoThresh, r.width(), r.height(), k.cx(), k.cy(), k.fx(), k.fy()));
+    }
+    return *m_ferns;
+  }
+  // ReferenceFrame::consumeReferenceFrame (ReferenceFrame.h:121-150): this frame's map consumes `other`'s moved by relativeTransform,
+  // the key-frame databases merge, and other's cameras move over - currPose and pose graph re-based - to fuse into this map from now on
+  void consumeReferenceFrame(ReferenceFrameT& other, Mat4 relativeTransform) {
+    Context* owner = founder();
+    if (!owner || !owner->fusion) throw std::runtime_error("consumeReferenceFrame: the consuming frame has no map yet");
+    float T[16];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T[r * 4 + c] = relativeTransform(r, c);
+    if (other.m_ferns) ferns().consume(*other.m_ferns, T, FrontEndOptions::get().fernThresh);
+    Context* of = other.founder();
+    std::vector<Context*> order;  // the camera that owns other's map carries it over, the rest only move
+    if (of) order.push_back(of);
+    for (auto& kv : other.contexts())
+      if (kv.second.get() != of) order.push_back(kv.second.get());
+    for (Context* c : order) {
+      if (c->fusion) {
+        check(dms_fusion_join_map(c->fusion, owner->fusion, T, nullptr), "consumeReferenceFrame");
+        float p[16], q[16];
+        for (int r = 0; r < 4; ++r)
+          for (int k = 0; k < 4; ++k) p[r * 4 + k] = c->currPose()(r, k);
+        dms_pose_compose(T, p, q);
+        for (int r = 0; r < 4; ++r)
+          for (int k = 0; k < 4; ++k) c->currPose()(r, k) = q[r * 4 + k];
+        for (auto& tp : c->poseGraph()) {
+          for (int r = 0; r < 4; ++r)
+            for (int k = 0; k < 4; ++k) p[r * 4 + k] = tp.second(r, k);
+          dms_pose_compose(T, p, q);
+          for (int r = 0; r < 4; ++r)
+            for (int k = 0; k < 4; ++k) tp.second(r, k) = q[r * 4 + k];
+        }
+      }
+    }
+    for (auto& kv : other.contexts()) m_contexts[kv.first] = kv.second;
+  }
+  // the camera whose device context owns the map's storage: the one the frame was created for
+  Context* founder() {
+    if (m_contexts.empty()) return nullptr;
+    auto it = m_contexts.find(name);  // (frontend() names the frame after the camera it creates it for)
+    return it != m_contexts.end() ? it->second.get() : m_contexts.begin()->second.get();
+  }
+
+ private:
+  std::map<std::string, std::shared_ptr<Context>> m_contexts;
+  Deformation m_globalDeformation, m_localDeformation;
+  std::unique_ptr<Ferns> m_ferns;
+  bool m_firstRun = true;
+};
+
 template <class Mat4>
 class ElasticFusionT {
  public:
   typedef ContextT<Mat4> Context;
+  typedef ReferenceFrameT<Mat4> ReferenceFrame;
   enum SamplingScheme { NID_KEYFRAMING, NONE, UNIFORM };
 
   // the reference's constructor (ElasticFusion.h:69-82)
@@ -172,8 +260,8 @@ class ElasticFusionT {
                  const int num_bins_depth = 500, const int num_bins_img = 64, const int m_nid_pyramid_level = 0)
       : timeDelta(timeDelta), closeLoops(closeLoops), iclnuim(iclnuim), reloc(reloc), confidence(confidence), depthCut(depthCut),
         icpThresh(icpThresh), fastOdom(fastOdom), so3(so3), frameToFrameRGB(frameToFrameRGB), scheme(sampling_scheme),
-        nid_threshold(nid_threshold), nidDepthLambda(nidDepthLambda), bins_depth(num_bins_depth), bins_img(num_bins_img),
-        nid_level(m_nid_pyramid_level), saveFilename(fileName) {
+        nid_threshold(nid_threshold), nidDepthLambda_(nidDepthLambda), bins_depth(num_bins_depth), bins_img(num_bins_img),
+        nid_level(m_nid_pyramid_level), bins_img_now(num_bins_img), bins_depth_now(num_bins_depth), saveFilename(fileName) {
     (void)countThresh;  // icpCountThresh / icpErrThresh / covThresh are the thresholds of the local-loop acceptance test, fixed at the
     (void)errThresh;    // values ElasticFusion.cpp:428-442 hard-codes; photoThresh / fernThresh belong to the fern database
     (void)covThresh;    // (dms::Ferns), whose call sites this fork compiles out (:279, :589, :597)
@@ -186,14 +274,77 @@ class ElasticFusionT {
   std::function<std::vector<float>(const std::vector<float>&, int, bool)> constrain;
 
   // "a context represents a SLAM frontend" (ElasticFusion.h:309-315)
-  std::shared_ptr<Context> frontend(std::string name) {
-    auto it = m_contexts.find(name);
-    if (it != m_contexts.end()) return it->second;
-    auto c = std::make_shared<Context>((int)m_contexts.size(), bins_depth, bins_img, name, iclnuim, reloc);
+  std::shared_ptr<Context> frontend(std::string name) {  // ElasticFusion.cpp:1069-1085
+    for (const auto& rf : m_referenceFrames) {
+      auto ctx = rf->contexts().find(name);
+      if (ctx != rf->contexts().end()) return ctx->second;
+    }
+    std::shared_ptr<ReferenceFrame> rf(new ReferenceFrame());
+    rf->name = name;
+    auto c = std::make_shared<Context>(nextId++, bins_depth, bins_img, name, iclnuim, reloc);
+    m_referenceFrames.push_back(rf);
+    m_contextToReferenceFrameMap[c->id()] = rf;
+    rf->contexts()[name] = c;
     m_contexts[name] = c;
     return c;
   }
-  std::map<std::string, std::shared_ptr<Context>>& contexts() { return m_contexts; }
+  std::map<std::string, std::shared_ptr<Context>>& contextMap() { return m_contexts; }
+  // ElasticFusion::contexts / referenceFrames / whichReferenceFrame (ElasticFusion.h:324-332, ElasticFusion.cpp:1087-1105)
+  std::vector<std::shared_ptr<Context>> contexts() {
+    std::vector<std::shared_ptr<Context>> ctxs;
+    for (auto& rf : m_referenceFrames)
+      for (auto& kv : rf->contexts()) ctxs.push_back(kv.second);
+    return ctxs;
+  }
+  std::vector<std::shared_ptr<ReferenceFrame>>& referenceFrames() { return m_referenceFrames; }
+  ReferenceFrame& whichReferenceFrame(Context& ctx) { return *(m_contextToReferenceFrameMap[ctx.id()]); }
+  // what the (compiled-out) inter-map block does on a verified match (ElasticFusion.cpp:610-627): `consuming` takes over the
+  // frame of `context`, which disappears from referenceFrames(); every camera of it is re-mapped
+  void mergeReferenceFrames(ReferenceFrame& consuming, Context& context, Mat4 relativeTransform) {
+    std::shared_ptr<ReferenceFrame> gone = m_contextToReferenceFrameMap[context.id()];
+    std::shared_ptr<ReferenceFrame> keep;
+    for (auto& rf : m_referenceFrames)
+      if (rf.get() == &consuming) keep = rf;
+    if (!keep || keep == gone) throw std::runtime_error("mergeReferenceFrames: not two different reference frames of this ElasticFusion");
+    consuming.consumeReferenceFrame(*gone, relativeTransform);
+    for (size_t i = 0; i < m_referenceFrames.size(); i++)
+      if (m_referenceFrames[i] == gone) {
+        m_referenceFrames.erase(m_referenceFrames.begin() + i);
+        break;
+      }
+    for (auto& kv : consuming.contexts()) m_contextToReferenceFrameMap[kv.second->id()] = keep;
+  }
+  Ferns& getFerns(Context& ctx) { return whichReferenceFrame(ctx).ferns(); }                                // ElasticFusion.cpp:997
+  Deformation& getLocalDeformation(Context& ctx) { return whichReferenceFrame(ctx).localDeformation(); }  // :1001
+  // the session clock the GUI loop reads and fast-forwards (ElasticFusion.cpp:1050-1054): a plain member there too - the per-camera
+  // clock is Context::tick()
+  const int& getTick() { return tick; }
+  void setTick(const int& val) { tick = val; }
+  // ElasticFusion::predict(context, rf[, confidence]) (ElasticFusion.h:107-108): the model view at the camera's pose + fill-in
+  void predict(Context& context, ReferenceFrame& rf) { predict(context, rf, -1.f); }
+  void predict(Context& context, ReferenceFrame& rf, float confidenceThreshold) {
+    (void)rf;  // (the camera's device context already renders the map of the frame it belongs to)
+    if (context.fusion) check(dms_fusion_predict(context.fusion, confidenceThreshold, nullptr), "predict");
+  }
+  // NID key-framing accessors of the GUI (ElasticFusion.h:336-372, MainController.cpp:470, :777-781)
+  float& nidThreshold() { return nid_threshold; }
+  float& nidDepthLambda() { return nidDepthLambda_; }
+  int& nidPyramidLevel() { return nid_level; }
+  void setNumBinsImg(int numBinsImg) { bins_img_now = numBinsImg; }
+  void setNumBinsDepth(int numBinsDepth) { bins_depth_now = numBinsDepth; }
+  float lastKFScore(Context& context) { return context.lastKFScore(); }
+  float kFThreshold() { return scheme == NID_KEYFRAMING ? nid_threshold : 0.f; }
+  int& numFused(Context& context) { return context.numFused(); }
+  const int& getDeforms() { return deforms; }
+  const int& getFernDeforms() { return fernDeforms; }
+  int surfelCount() {  // ElasticFusion.cpp:1107-1116
+    int count = 0;
+    for (auto& rf : m_referenceFrames) {
+      Context* c = rf->founder();
+      if (c && c->fusion) count += (int)rf->globalModel().lastCount();
+    }
+    return count;
+  }
 
   /**
    * Process an rgb/depth map pair — ElasticFusion::processFrame (ElasticFusion.h:92-100, ElasticFusion.cpp:99-637)
@@ -216,6 +367,13 @@ class ElasticFusionT {
     ensure(context);
     // Context::rgbOnly() is read every frame by the reference (ElasticFusion.cpp:505): keep the device side in step
     check(dms_fusion_set_option(context.fusion, DMS_OPT_RGB_ONLY, (context.rgbOnly() || rgbOnly) ? 1.0 : 0.0), "dms_fusion_set_option");
+    if (scheme == NID_KEYFRAMING) {  // fuseFrame reads these members every frame (ElasticFusion.cpp:646-675); the GUI may have moved them
+      check(dms_fusion_set_option(context.fusion, DMS_OPT_NID_THRESHOLD, nid_threshold), "nid_threshold");
+      check(dms_fusion_set_option(context.fusion, DMS_OPT_NID_DEPTH_LAMBDA, nidDepthLambda_), "nid_depth_lambda");
+      check(dms_fusion_set_option(context.fusion, DMS_OPT_NID_BINS_IMG, bins_img_now), "setNumBinsImg");
+      check(dms_fusion_set_option(context.fusion, DMS_OPT_NID_BINS_DEPTH, bins_depth_now), "setNumBinsDepth");
+      check(dms_fusion_set_option(context.fusion, DMS_OPT_NID_PYRAMID_LEVEL, nid_level), "nidPyramidLevel");
+    }
     const int W = Resolution::getInstance().width(), H = Resolution::getInstance().height();
     check(dms_memcpy_h2d(context.rgb_dev, rgb.get(), (size_t)W * H * 3, nullptr), "upload rgb");
     check(dms_memcpy_h2d(context.depth_dev, depth.get(), (size_t)W * H * 2, nullptr), "upload depth");
@@ -242,6 +400,10 @@ class ElasticFusionT {
         check(dms_fusion_get_global_loop_constraints(context.fusion, rows.data(), cap, &n, nullptr), "global loop constraints");
         rows.resize((size_t)n * 7);
         if (constrain && n > 0) rawGraph = constrain(rows, context.tick(), true);
+        if (!rawGraph.empty()) {
+          fernDeforms += 1;  // :346
+          whichReferenceFrame(context).globalDeformation().graph = rawGraph;
+        }
       }
       if (rawGraph.empty() && closeLoops) {  // `rawGraph.size() == 0` (:399)
         dms_frame_result rl;
@@ -253,6 +415,8 @@ class ElasticFusionT {
           rows.resize((size_t)n * 7);
           rawGraph = constrain(rows, context.tick(), false);
           if (!rawGraph.empty()) {  // context.currPose() = estPose (:489)
+            deforms += 1;  // :487
+            whichReferenceFrame(context).localDeformation().graph = rawGraph;
             std::memcpy(newPose, rl.loop_pose, sizeof(newPose));
             havePose = true;
           }
@@ -385,7 +549,7 @@ class ElasticFusionT {
     p.reloc = c.reloc();
     p.nid_keyframing = scheme == NID_KEYFRAMING;
     p.nid_threshold = nid_threshold;
-    p.nid_depth_lambda = nidDepthLambda;
+    p.nid_depth_lambda = nidDepthLambda_;
     p.nid_bins_depth = bins_depth;
     p.nid_bins_img = bins_img;
     p.nid_pyramid_level = nid_level;
@@ -408,10 +572,17 @@ class ElasticFusionT {
   bool fastOdom, so3, frameToFrameRGB;
   bool rgbOnly = false;  // ElasticFusion::setRgbOnly (:1023): every camera tracks photometrically only and fuses nothing
   const SamplingScheme scheme;
-  const float nid_threshold, nidDepthLambda;
-  const int bins_depth, bins_img, nid_level;
+  float nid_threshold, nidDepthLambda_;  // (the GUI writes them through nidThreshold() / nidDepthLambda() every frame)
+  const int bins_depth, bins_img;        // creation-time bin counts (they size the device workspace)
+  int nid_level;
+  int bins_img_now, bins_depth_now;      // setNumBinsImg / setNumBinsDepth
   const std::string saveFilename;
+  int tick = 1;     // ElasticFusion::tick (ElasticFusion.cpp:35): only getTick / setTick touch it there as well
+  int nextId = 0;
+  int deforms = 0, fernDeforms = 0;
   std::map<std::string, std::shared_ptr<Context>> m_contexts;
+  std::vector<std::shared_ptr<ReferenceFrame>> m_referenceFrames;
+  std::map<int, std::shared_ptr<ReferenceFrame>> m_contextToReferenceFrameMap;
 };
 
 }  // namespace dms

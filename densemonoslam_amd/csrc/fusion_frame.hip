@@ -1523,6 +1523,21 @@ int dms_fusion_set_option(dms_fusion* f, int option, double value) {
       DMS_REQUIRE(value > 0.0, "depth cut-off must be positive");
       f->p.depthCut = (float)value;
       break;
+    case DMS_OPT_NID_THRESHOLD: f->p.nid_threshold = (float)value; break;
+    case DMS_OPT_NID_DEPTH_LAMBDA: f->p.nid_depth_lambda = (float)value; break;
+    case DMS_OPT_NID_BINS_IMG:
+    case DMS_OPT_NID_BINS_DEPTH: {
+      const int nb = (int)value;
+      DMS_REQUIRE(nb >= 1 && nb <= (option == DMS_OPT_NID_BINS_IMG ? 256 : 4096), "bin count out of range");
+      DMS_REQUIRE(!f->nid_ws || nid_workspace_bytes(nb) <= f->nid_ws_bytes,
+                  "more bins than the NID workspace of this context holds (it is sized from the creation-time bin counts)");
+      (option == DMS_OPT_NID_BINS_IMG ? f->p.nid_bins_img : f->p.nid_bins_depth) = nb;
+      break;
+    }
+    case DMS_OPT_NID_PYRAMID_LEVEL:
+      DMS_REQUIRE((int)value >= 0 && (int)value < DMS_NUM_PYRS, "pyramid level out of range");
+      f->p.nid_pyramid_level = (int)value;
+      break;
   }
   return DMS_OK;
 }
@@ -1539,8 +1554,20 @@ int dms_fusion_get_option(dms_fusion* f, int option, double* value) {
     case DMS_OPT_FRAME_TO_FRAME_RGB: *value = f->p.frameToFrameRGB; break;
     case DMS_OPT_CONFIDENCE: *value = f->p.confidence; break;
     case DMS_OPT_DEPTH_CUTOFF: *value = f->p.depthCut; break;
+    case DMS_OPT_NID_THRESHOLD: *value = f->p.nid_threshold; break;
+    case DMS_OPT_NID_DEPTH_LAMBDA: *value = f->p.nid_depth_lambda; break;
+    case DMS_OPT_NID_BINS_IMG: *value = f->p.nid_bins_img; break;
+    case DMS_OPT_NID_BINS_DEPTH: *value = f->p.nid_bins_depth; break;
+    case DMS_OPT_NID_PYRAMID_LEVEL: *value = f->p.nid_pyramid_level; break;
   }
   return DMS_OK;
+}
+
+int dms_fusion_predict(dms_fusion* f, float confidence, dms_stream st) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(!f->in_frame && !f->in_global_loop, "inside a frame");
+  DMS_REQUIRE(f->map_initialised, "no map yet");
+  return predict(f, confidence < 0.f ? f->p.confidence : confidence, (hipStream_t)st);
 }
 
 int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches) {

@@ -342,6 +342,11 @@ int dms_fusion_import_camera(dms_fusion* f, dms_fusion* owner, const float* pose
 int dms_relative_transform(const float* recoveryPose16, const float* currPose16, float* out16);
 int dms_pose_compose(const float* a16, const float* b16, float* out16);
 
+/* ElasticFusion::predict(context, rf[, confidence]) (ElasticFusion.h:107-108, ElasticFusion.cpp:688-746): the ACTIVE model view at the
+ * camera's current pose + fill-in, into the prediction / fill-in images (dms_fusion_get_image 9-15) - what the GUI loop calls for a
+ * paused camera (MainController.cpp:398).  confidence < 0: the context's confidence threshold.  Outside a frame. */
+int dms_fusion_predict(dms_fusion* f, float confidence, dms_stream s);
+
 dms_model* dms_fusion_model(dms_fusion* f);
 /* Device address of the camera pose (16 floats, row-major, camera-to-world) the frame step keeps in HBM: valid for the
  * life of the context, written by the tracker's last kernel — stream-ordered consumers (e.g. dms_ferns_add_frame_async)
@@ -383,7 +388,12 @@ enum {
   DMS_OPT_FRAME_TO_FRAME_RGB = 5,  /* setFrameToFrameRGB    (bool)  */
   DMS_OPT_CONFIDENCE = 6,          /* setConfidenceThreshold(float) */
   DMS_OPT_DEPTH_CUTOFF = 7,        /* setDepthCutoff        (float) */
-  DMS_OPT_COUNT = 8
+  DMS_OPT_NID_THRESHOLD = 8,       /* nidThreshold() = v    (float) ElasticFusion.h:340 */
+  DMS_OPT_NID_DEPTH_LAMBDA = 9,    /* nidDepthLambda() = v  (float) :346 */
+  DMS_OPT_NID_BINS_IMG = 10,       /* setNumBinsImg         (int, <= the creation-time value's workspace) :347 */
+  DMS_OPT_NID_BINS_DEPTH = 11,     /* setNumBinsDepth       (int) :353 */
+  DMS_OPT_NID_PYRAMID_LEVEL = 12,  /* nidPyramidLevel() = v (int 0..2) :362 */
+  DMS_OPT_COUNT = 13
 };
 int dms_fusion_set_option(dms_fusion* f, int option, double value);
 int dms_fusion_get_option(dms_fusion* f, int option, double* value);

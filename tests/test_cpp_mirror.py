@@ -257,3 +257,202 @@ def test_reference_outer_api_runs_frames_and_an_orb_loop_closure():
         traj = open(os.path.join(outdir, "camera0.klg.freiburg")).read().splitlines()
         assert len(traj) == 5 and all(len(line.split()) == 12 and line.endswith(" ") for line in traj)
         assert traj[0].split()[:4] == ["1", "0", "0", "0"]
+
+
+RUNLOOP_SRC = r"""
+// A headless host shaped like MainController::run (GUI/src/MainController.cpp:246-400) - several cameras served in turn, the session
+// clock, frame skipping, the pose prior, a paused camera that only predicts - plus what the GUI half of that loop reads every frame
+// (:406-415, :470, :736-781) and the merge the compiled-out inter-map block performs (ElasticFusion.cpp:610-627), written against
+// densemonoslam_amd/cpp/ElasticFusion.h.  Every eFusion-> call of :248-400 appears here with the reference's argument list.
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+namespace Eigen {
+struct Matrix4f {
+  float m[16];
+  float& operator()(int r, int c) { return m[r * 4 + c]; }
+  const float& operator()(int r, int c) const { return m[r * 4 + c]; }
+  void setIdentity() { for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f; }
+};
+}  // namespace Eigen
+#define DMS_EIGEN_MATRIX4F_DECLARED 1
+#include "densemonoslam_amd/cpp/ElasticFusion.h"
+
+// stands in for GUI/src/Tools/LogReader.h: a synthetic wavy wall seen by a camera that is `shift` pixels further right
+struct LogReader {
+  int W, H, shift, currentFrame = 0, frames;
+  int64_t timestamp = 0;
+  std::shared_ptr<unsigned char> rgb_;
+  std::shared_ptr<unsigned short> depth_;
+  LogReader(int W, int H, int shift, int frames) : W(W), H(H), shift(shift), frames(frames),
+      rgb_(new unsigned char[(size_t)W * H * 3], std::default_delete<unsigned char[]>()),
+      depth_(new unsigned short[(size_t)W * H], std::default_delete<unsigned short[]>()) {}
+  bool hasMore() { return currentFrame < frames; }
+  void getNext() {
+    const int k = currentFrame++;
+    timestamp = 1000 * k;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const size_t i = (size_t)y * W + x;
+        const int xs = x + shift;
+        depth_.get()[i] = (unsigned short)(1500 + (xs / 4) % 7 + 200.0 * std::sin(0.02 * xs) * std::cos(0.03 * y));
+        rgb_.get()[3 * i + 0] = (unsigned char)(128 + 100 * std::sin(0.11 * xs));
+        rgb_.get()[3 * i + 1] = (unsigned char)(128 + 100 * std::sin(0.07 * y));
+        rgb_.get()[3 * i + 2] = (unsigned char)(128 + 60 * std::sin(0.05 * (xs + y)));
+      }
+  }
+  void fastForward(int frame) { currentFrame = frame; }
+  std::shared_ptr<unsigned char> rgb() { return rgb_; }
+  std::shared_ptr<unsigned short> depth() { return depth_; }
+};
+
+int main(int argc, char** argv) {
+  const int W = 320, H = 240;
+  Resolution::getInstance(W, H);
+  Intrinsics::getInstance(264.f, 264.f, 160.f, 120.f);
+  dms::FrontEndOptions::get().hybrid_tracking = true;
+  ElasticFusion* eFusion = new ElasticFusion(200, 35000, 5e-05, 1e-05, /*closeLoops*/ false, false, false, 115, 1, 3, 10, false, 0.3095, true, false, "model",
+                                             ElasticFusion::SamplingScheme::NID_KEYFRAMING, 0.8f, 0.7f, 500, 64, 0);
+  std::map<std::string, std::shared_ptr<LogReader>> logReaders;
+  logReaders["logs/a.klg"] = std::make_shared<LogReader>(W, H, 0, 8);
+  logReaders["logs/b.klg"] = std::make_shared<LogReader>(W, H, 6, 8);
+  const bool run = argc > 1;
+  const int start = 1, end = run ? 7 : 1;
+  int framesToSkip = 0;
+  bool paused_b = false;
+  Context& activeCtx = *(eFusion->frontend("logs/a.klg"));
+  if (eFusion->referenceFrames().size() != 1) return 2;
+  int processed = 0, predicted = 0;
+  // ---- the loop of :254-400 ----
+  while (!(eFusion->getTick() == end)) {
+    for (auto lr : logReaders) {
+      std::shared_ptr<LogReader> logReader = lr.second;
+      std::shared_ptr<Context> ctx = eFusion->frontend(lr.first);
+      if (!(paused_b && lr.first == "logs/b.klg")) {
+        if (logReader->hasMore() && eFusion->getTick() < end) {
+          logReader->getNext();
+          if (eFusion->getTick() < start) {
+            eFusion->setTick(start);
+            logReader->fastForward(start);
+          }
+          float weightMultiplier = framesToSkip + 1;
+          if (framesToSkip > 0) {
+            eFusion->setTick(activeCtx.tick() + framesToSkip);
+            logReader->fastForward(logReader->currentFrame + framesToSkip);
+            framesToSkip = 0;
+          }
+          Eigen::Matrix4f* currentPose = 0;
+          Eigen::Matrix4f* orb_lc_Tcw_old = 0;
+          Eigen::Matrix4f* orb_lc_Tcw_new = 0;
+          int currentCluster = 0;
+          if (ctx->tick() > 1) {  // the pose prior of the front end (:338-356): here the previous pose
+            currentPose = new Eigen::Matrix4f;
+            currentPose->setIdentity();
+            *currentPose = ctx->currPose();
+          }
+          std::shared_ptr<unsigned short> depth_frame = logReader->depth();
+          eFusion->processFrame(logReader->rgb(), depth_frame, logReader->timestamp, *ctx, currentPose, orb_lc_Tcw_old, orb_lc_Tcw_new, currentCluster,
+                                weightMultiplier, false);
+          if (currentPose) delete currentPose;
+          processed++;
+        }
+      } else {
+        eFusion->predict(*ctx, eFusion->whichReferenceFrame(*ctx));
+        predicted++;
+      }
+    }
+    if (!run) break;
+    // the session clock: the GUI loop's exit test reads it, nothing in the back end advances it (ElasticFusion.cpp:35, :1050-1054)
+    eFusion->setTick(eFusion->getTick() + 1);
+    // ---- what the GUI half reads / writes every frame ----
+    Context& active = *(eFusion->frontend("logs/a.klg"));
+    const size_t numMaps = eFusion->referenceFrames().size();
+    for (auto& rf : eFusion->referenceFrames())
+      if (rf->contexts().empty() || rf->name.empty()) return 3;
+    const float score = eFusion->lastKFScore(active), thr = eFusion->kFThreshold();
+    if (!(score >= 0.f) || thr != eFusion->nidThreshold()) return 4;
+    if (eFusion->getGlobalModel(active).lastCount() == 0 || eFusion->surfelCount() <= 0) return 5;
+    (void)eFusion->whichReferenceFrame(active).globalDeformation().getGraph().size();
+    (void)eFusion->getLocalDeformation(active).getGraph().size();
+    (void)eFusion->getDeforms();
+    (void)eFusion->getFernDeforms();
+    (void)eFusion->numFused(active);
+    eFusion->setRgbOnly(false);
+    eFusion->setPyramid(true);
+    eFusion->setFastOdom(false);
+    eFusion->setConfidenceThreshold(1.f);
+    eFusion->setDepthCutoff(3.f);
+    eFusion->setIcpWeight(10.f);
+    eFusion->setSo3(true);
+    eFusion->setFrameToFrameRGB(false);
+    eFusion->nidThreshold() = 0.0f;   // every frame is a key frame: the fusion half runs
+    eFusion->nidDepthLambda() = 0.7f;
+    eFusion->setNumBinsImg(32);
+    eFusion->setNumBinsDepth(250);
+    eFusion->nidPyramidLevel() = 1;
+    if (eFusion->getTick() == 2) framesToSkip = 1;                        // the frame-skip branch (:290-294)
+    if (eFusion->getTick() >= 4 && numMaps == 2) {
+      // a verified inter-map match (ElasticFusion.cpp:610-627): a's frame consumes b's; the two cameras see the same wall 6 px apart
+      Context& b = *(eFusion->frontend("logs/b.klg"));
+      Eigen::Matrix4f T;
+      T.setIdentity();
+      T(0, 3) = 6.f * 1.5f / 264.f;  // b's camera frame expressed in a's: shift * z / fx
+      const unsigned before = eFusion->getGlobalModel(active).lastCount();
+      eFusion->mergeReferenceFrames(eFusion->whichReferenceFrame(active), b, T);
+      if (eFusion->referenceFrames().size() != 1 || &eFusion->whichReferenceFrame(b) != &eFusion->whichReferenceFrame(active)) return 6;
+      if (eFusion->getGlobalModel(active).lastCount() <= before) return 7;
+      if (!(std::fabs(b.currPose()(0, 3) - T(0, 3)) < 0.02f)) return 8;
+      (void)eFusion->getFerns(active).frames();  // the merged frame's key-frame database
+    }
+    if (eFusion->getTick() == 6) paused_b = true;                         // a paused camera only predicts (:397-399)
+    std::printf("tick %d: maps %zu surfels %d a.tick %d b.tick %d score %.3f\n", eFusion->getTick(), eFusion->referenceFrames().size(), eFusion->surfelCount(),
+                active.tick(), eFusion->frontend("logs/b.klg")->tick(), score);
+  }
+  if (run) {
+    Context& a = *(eFusion->frontend("logs/a.klg"));
+    Context& b = *(eFusion->frontend("logs/b.klg"));
+    if (predicted != 1 || processed < 9) return 9;
+    if (eFusion->contexts().size() != 2 || eFusion->referenceFrames().size() != 1) return 10;
+    // after the merge both cameras kept tracking and fusing into ONE map
+    if (a.numFused() < 5 || b.numFused() < 4 || !(b.lastResult().track.lastICPCount > 20000)) return 11;
+    if (!(std::fabs(b.currPose()(0, 3) - 6.f * 1.5f / 264.f) < 0.03f)) return 12;
+    std::printf("ok: %d frames, %d surfels in one map\n", processed, eFusion->surfelCount());
+  }
+  delete eFusion;
+  return 0;
+}
+"""
+
+
+def _build_runloop(td):
+    lib_dir = os.path.join(ROOT, "densemonoslam_amd")
+    src, exe = os.path.join(td, "runloop.cpp"), os.path.join(td, "runloop")
+    with open(src, "w") as f:
+        f.write(RUNLOOP_SRC)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I" + ROOT, src, "-o", exe, "-L" + lib_dir, "-ldmslam_hip", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_reference_run_loop_call_sites_compile_and_link():
+    """Every eFusion-> call of MainController::run's headless part (GUI/src/MainController.cpp:248-400: frontend, getTick, setTick,
+    processFrame, predict(ctx, whichReferenceFrame(ctx))) and of the per-frame GUI half (referenceFrames, lastKFScore, kFThreshold,
+    getFerns, getLocalDeformation, nidThreshold(), setNumBinsImg / Depth, ...) compiles and links against the adapter header."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_runloop(td)
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_reference_run_loop_runs_two_cameras_a_merge_and_a_paused_camera():
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_runloop(td)
+        out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+        assert "ok:" in out.stdout
