@@ -101,6 +101,12 @@ __host__ __device__ __forceinline__ void retry_step(int* E) {
 #pragma unroll
   for (int c = 0; c <= N; ++c) E[c] = clamp_e(E[c] + kRetryStep);
 }
+// The static guesses below assume geometry within a few metres (rotation columns |v x n|^2 <= 2^4).  With a far depth cut-off
+// (--d 40 for the KITTI configuration) the first reduction of most calls outgrew them and was repeated (0.34-0.67 repeated
+// reductions per frame at 1241 x 376 / 40 m); the frame step therefore raises them by this bias, a function of the depth cut-off
+// alone - 0 up to 4 m, so nothing changes for the indoor configurations; +2 already removes every repeat at 40 m
+// (scripts/kitti_retries.py), the rule gives +8 there (exp_of(40) = 6).  oracle/orc_pipeline.py applies the same rule.
+__host__ __device__ __forceinline__ int depth_exp_bias(float depthCut) { return depthCut > 4.0f ? 2 * (exp_of(depthCut) - 2) : 0; }
 // first reduction of a call: per-pixel magnitude guesses times the pixel count (any guess is legal: the check above corrects it)
 __host__ __device__ __forceinline__ void static_icp(int npix, int* E) {
   const int en = exp_of((float)npix);

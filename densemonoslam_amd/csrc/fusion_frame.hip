@@ -16,6 +16,7 @@
 #include "internal.hpp"
 #include "smallmath.hpp"
 #include "surfel.hpp"
+#include "canon.hpp"
 #include "frame_state.hpp"
 #include "live_bodies.hpp"
 #include "fill.hpp"
@@ -1004,6 +1005,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       }
       {
         FTimer t(f, s, "track");
+        (void)dms_odometry_debug_set(f->odom, "exp_bias", canon::depth_exp_bias(f->p.depthCut));  // (canon.hpp: far depth cut-offs)
         if ((rc = odometry_track_enqueue(f->odom, nullptr, nullptr, f->state->cur.pose, f->p.rgbOnly, f->p.icpWeight, f->p.pyramid,
                                          f->p.fastOdom, f->p.so3, 0, s, f->state, weightMultiplier)))
           return rc;
@@ -1068,6 +1070,7 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       }
       {
         FTimer t(f, s, "loop_track");  // getIncrementalTransformation(trans, rot, false, 10, pyramid, fastOdom, false) (:424-425)
+        (void)dms_odometry_debug_set(f->odom_m2m, "exp_bias", canon::depth_exp_bias(f->p.depthCut));
         if ((rc = odometry_track_enqueue(f->odom_m2m, nullptr, nullptr, f->state->cur.pose, 0, 10.f, f->p.pyramid, f->p.fastOdom, 0, 0, s,
                                          nullptr, 1.f)))
           return rc;

@@ -194,6 +194,13 @@ class ElasticFusion:
         self.rgba = rgb
         depth = np.ascontiguousarray(depth, np.uint16)
         # filterDepth / metriciseDepth (:118-119, :748-768)
+        # far depth cut-offs raise the static first-iteration exponents of the canonical sums (csrc/canon.hpp depth_exp_bias: the same rule)
+        import math
+
+        bias = 2 * (math.frexp(float(np.float32(self.depthCut)))[1] - 2) if self.depthCut > 4.0 else 0
+        self.frameToModel.setExpBias(bias)
+        if self.modelToModel is not None:
+            self.modelToModel.setExpBias(bias)
         self.depth_filtered = orc.depth_bilateral(depth, self.depthCut)
         self.depth_metric = orc.depth_metric(depth, self.depthCut)
         self.depth_metric_filtered = orc.depth_metric(self.depth_filtered, self.depthCut)

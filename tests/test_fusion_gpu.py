@@ -1254,9 +1254,10 @@ def test_free_run_identical_at_kitti_size_1241x376(fus, orc, synth):
     from oracle import orc_pipeline
 
     n = int(os.environ.get("DMS_LONG_RUN_FRAMES_KITTI", "25"))
-    # (with geometry out to 40 m the rotation columns of the ICP rows outgrow the static guess of a call's first reduction —
-    # |v x n| of a few metres — on most calls once far walls are in view: 0.67 repeated iterations per frame over 200 frames)
-    _free_run_identical(fus, synth, orc_pipeline, 1241, 376, synth.K_KITTI, n, dict(depthCut=40.0), retries_per_frame=2.0)
+    # (with geometry out to 40 m the rotation columns of the ICP rows outgrew the static guess of a call's first reduction on most
+    # calls - 0.67 repeated iterations per frame over 200 frames in round 3; since round 4 the frame step raises the static exponents
+    # with the depth cut-off, canon.hpp depth_exp_bias, and no reduction is repeated)
+    _free_run_identical(fus, synth, orc_pipeline, 1241, 376, synth.K_KITTI, n, dict(depthCut=40.0), retries_per_frame=0.05)
 
 
 def test_frame_step_api_contract(fus, synth):
