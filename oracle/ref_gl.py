@@ -201,5 +201,22 @@ def fill(which, existing, depth, cam, passthrough):
     return out
 
 
+def fill_rgb(existing_rgba, raw_rgba, passthrough):
+    """FillIn::image"""
+    e, r = _c(existing_rgba, np.uint8), _c(raw_rgba, np.uint8)
+    out = np.zeros_like(e)
+    _ok(lib().rgl_fill_rgb(_p(e), _p(r), e.shape[0], e.shape[1], int(bool(passthrough)), _p(out)), "fill_rgb")
+    return out
+
+
+def resize(src, drows, dcols):
+    """Resize::image (uint8 H x W x 4) / Resize::vertex (float32 H x W x 4)"""
+    src = np.ascontiguousarray(src)
+    which = 1 if src.dtype == np.float32 else 0
+    dst = np.zeros((drows, dcols, 4), src.dtype)
+    _ok(lib().rgl_resize(which, _p(src), src.shape[0], src.shape[1], int(drows), int(dcols), _p(dst)), "resize")
+    return dst
+
+
 def try_program(vs, gs, fs):
     return lib().rgl_try_program(vs.encode(), (gs or "").encode(), (fs or "").encode()) == 0, lib().rgl_error().decode()

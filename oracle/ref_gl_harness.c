@@ -801,6 +801,66 @@ int rgl_fill(int which, const float* existing, const uint16_t* depth, int rows, 
   return gl_ok("fill");
 }
 
+/* FillIn::image (Shaders/FillIn.cpp:65-97): fill_rgb.frag over the full-screen quad.  The program samples with texture2D under
+ * `#version 440 core` (removed from the core language; NVIDIA's compiler lets it pass): it builds under Mesa only with the driconf
+ * switch force_compat_shaders, which oracle/ref_gl.py sets in the environment before the context is created. */
+int rgl_fill_rgb(const uint8_t* existing_rgba, const uint8_t* raw_rgba, int rows, int cols, int passthrough, uint8_t* out_rgba) {
+  GLuint p = program("empty.vert", "quad.geom", "fill_rgb.frag", 0);
+  if (!p) return -1;
+  GLuint te = tex2d(cols, rows, GL_RGBA8, GL_RGBA, GL_UNSIGNED_BYTE, existing_rgba, 0);  /* FillIn's / IndexMap's image textures: nearest */
+  GLuint tr = tex2d(cols, rows, GL_RGBA8, GL_RGBA, GL_UNSIGNED_BYTE, raw_rgba, g_linear); /* GPUTexture::RGB (Context.h:158-160) */
+  GLuint to = tex2d(cols, rows, GL_RGBA8, GL_RGBA, GL_UNSIGNED_BYTE, NULL, 0);
+  Fbo f;
+  if (fbo_make(&f, cols, rows, &to, 1)) return -1;
+  p_glViewport(0, 0, cols, rows);
+  clear_all(&f, 0u);
+  glUseProgram(p);
+  u1i(p, "eSampler", 0);
+  u1i(p, "rSampler", 1);
+  u1i(p, "passthrough", passthrough);
+  p_glActiveTexture(GL_TEXTURE0);
+  p_glBindTexture(GL_TEXTURE_2D, te);
+  p_glActiveTexture(GL_TEXTURE1);
+  p_glBindTexture(GL_TEXTURE_2D, tr);
+  p_glDrawArrays(GL_POINTS, 0, 1);
+  p_glFinish();
+  glUseProgram(0);
+  p_glActiveTexture(GL_TEXTURE0);
+  tex_read(to, GL_RGBA, GL_UNSIGNED_BYTE, out_rgba);
+  fbo_free(&f);
+  GLuint ts[3] = {te, tr, to};
+  p_glDeleteTextures(3, ts);
+  return gl_ok("fill_rgb");
+}
+
+/* Resize::image / Resize::vertex (Shaders/Resize.cpp:67-129): resize.frag (one texture2D fetch at the interpolated quad coordinate)
+ * into a drows x dcols target; which = 0: RGBA8 image, 1: RGBA32F vertex map.  The sources are prediction / fill-in textures:
+ * NEAREST.  (Resize::time, :131-155, runs the same float sampler on an INTEGER texture - undefined in GL, not driven.) */
+int rgl_resize(int which, const void* src, int srows, int scols, int drows, int dcols, void* dst) {
+  GLuint p = program("empty.vert", "quad.geom", "resize.frag", 0);
+  if (!p) return -1;
+  const GLint ifmt = which ? GL_RGBA32F : GL_RGBA8;
+  const GLenum type = which ? GL_FLOAT : GL_UNSIGNED_BYTE;
+  GLuint ts = tex2d(scols, srows, ifmt, GL_RGBA, type, src, 0);
+  GLuint to = tex2d(dcols, drows, ifmt, GL_RGBA, type, NULL, 0);
+  Fbo f;
+  if (fbo_make(&f, dcols, drows, &to, 1)) return -1;
+  p_glViewport(0, 0, dcols, drows);
+  clear_all(&f, 0u);
+  glUseProgram(p);
+  u1i(p, "eSampler", 0);
+  p_glActiveTexture(GL_TEXTURE0);
+  p_glBindTexture(GL_TEXTURE_2D, ts);
+  p_glDrawArrays(GL_POINTS, 0, 1);
+  p_glFinish();
+  glUseProgram(0);
+  tex_read(to, GL_RGBA, type, dst);
+  fbo_free(&f);
+  GLuint tt[2] = {ts, to};
+  p_glDeleteTextures(2, tt);
+  return gl_ok("resize");
+}
+
 /* can the named fragment program of the reference be compiled at all by this (conformant) GLSL compiler?  fill_rgb.frag and
  * resize.frag call texture2D under `#version 440 core`, which the specification removed; NVIDIA's compiler lets it pass */
 int rgl_try_program(const char* vs, const char* gs, const char* fs) {

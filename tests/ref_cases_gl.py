@@ -152,6 +152,13 @@ def chain(be, inp, dtype, feed=None, tex_dim=TEX_DIM):
     r("fill_vertex", be.fill_vertex(act[1], fb, K, False))
     r("fill_normal", be.fill_normal(act[2], fb, K, False))
     r("fill_vertex_pass", be.fill_vertex(act[1], fb, K, True))
+    # FillIn::image on the ACTIVE prediction's colours; Resize::image / ::vertex down to W/20 x H/20 (ElasticFusion.cpp:84-97, :443) and to
+    # the fern thumbnails' W/8 x H/8 (Ferns.cpp:292-300)
+    r("fill_image", be.fill_image(act[0], inp["rgba"], False))
+    r("fill_image_pass", be.fill_image(act[0], inp["rgba"], True))
+    for nm, (dh, dw) in (("20", (H // 20, W // 20)), ("8", (H // 8, W // 8)), ("odd", (7, 11))):
+        r("resize_image_" + nm, be.resize(act[0], dh, dw))
+        r("resize_vertex_" + nm, be.resize(act[1], dh, dw))
     return r.out
 
 
@@ -183,6 +190,12 @@ class GlOps:
     def fill_normal(self, existing, depth, K, passthrough):
         return self.g.fill(1, existing, depth, K, passthrough)
 
+    def fill_image(self, existing, rgba, passthrough):
+        return self.g.fill_rgb(existing, rgba, passthrough)
+
+    def resize(self, src, drows, dcols):
+        return self.g.resize(src, drows, dcols)
+
 
 class OrcOps:
     def __init__(self, orc):
@@ -213,6 +226,14 @@ class OrcOps:
     def fill_normal(self, existing, depth, K, passthrough):
         z = np.zeros(existing.shape[:2] + (4,), np.uint8)
         return self.o.fill_in(existing, existing, z, depth, z, K, passthrough, passthrough)[1]
+
+    def fill_image(self, existing, rgba, passthrough):
+        zf = np.zeros(existing.shape[:2] + (4,), np.float32)
+        zd = np.zeros(existing.shape[:2], np.uint16)
+        return self.o.fill_in(zf, zf, existing, zd, rgba, K, passthrough, passthrough)[2]
+
+    def resize(self, src, drows, dcols):
+        return self.o.resize_nn(src, drows, dcols)
 
 
 # ---- comparison ---------------------------------------------------------------------------------------------------------------
@@ -347,4 +368,42 @@ def compare_all(out, fx, inp, skip=()):
     rep["fill_vertex"] = compare_image("fill_vertex", out["fill_vertex"], fx["fill_vertex"], TOL_POS)
     rep["fill_normal"] = compare_image("fill_normal", out["fill_normal"], fx["fill_normal"], TOL_NRM)
     rep["fill_vertex_pass"] = compare_image("fill_vertex_pass", out["fill_vertex_pass"], fx["fill_vertex_pass"], TOL_POS)
+    for k in sorted(fx):  # the copies: FillIn::image (the same bytes), Resize::image / ::vertex (the same texels)
+        if k.startswith("fill_image"):
+            assert np.asarray(out[k]).tobytes() == np.asarray(fx[k]).tobytes(), k
+            rep[k] = dict(exact=True)
+        elif k.startswith("resize_"):
+            src = fx["act_image" if k.startswith("resize_image") else "act_vertex"]
+            rep[k] = compare_resize(k, out[k], fx[k], src)
     return rep
+
+
+def _resize_texels(n_src, n_dst):
+    """Per destination pixel: the source texel floor((j + 0.5) * n_src / n_dst) of a NEAREST fetch at the quad's interpolated
+    coordinate, and whether that coordinate lies EXACTLY on a texel boundary (then the rasteriser's rounding of the interpolation
+    picks the side: llvmpipe takes the lower row in most of the image and the upper column; the GL specification's exact arithmetic,
+    which the restatement follows, the upper texel.  Every row and column is such a tie at the reference's own sizes -
+    640 x 480 -> 32 x 24 and 80 x 60)."""
+    j = np.arange(n_dst)
+    num, den = (2 * j + 1) * n_src, 2 * n_dst
+    return num // den, num % den == 0
+
+
+def compare_resize(name, got, ref, src):
+    got, ref, src = np.asarray(got), np.asarray(ref), np.asarray(src)
+    assert got.shape == ref.shape and got.dtype == ref.dtype, name
+    (tr, tie_r), (tc, tie_c) = _resize_texels(src.shape[0], got.shape[0]), _resize_texels(src.shape[1], got.shape[1])
+    as_bytes = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], a.shape[1], -1)
+    g, f, s = as_bytes(got), as_bytes(ref), as_bytes(src)
+    tie = tie_r[:, None] | tie_c[None, :]
+    same = (g == f).all(axis=2)
+    assert same[~tie].all(), "%s: differs from the reference's copy away from exact texel boundaries" % name
+    for a, who in ((g, "candidate"), (f, "reference")):
+        ok = np.zeros(tie.shape, bool)
+        for dr in (0, -1):
+            for dc in (0, -1):
+                allowed = (tie_r[:, None] | (dr == 0)) & (tie_c[None, :] | (dc == 0))
+                rr, cc = np.clip(tr + dr, 0, None)[:, None], np.clip(tc + dc, 0, None)[None, :]
+                ok |= allowed & (a == s[rr, cc]).all(axis=2)
+        assert ok.all(), "%s: the %s's copy holds a texel that is not a neighbour of the sample point" % (name, who)
+    return dict(ties=int(tie.sum()), differing_at_ties=int((~same).sum()), pixels=int(tie.size))

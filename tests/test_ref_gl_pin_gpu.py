@@ -85,6 +85,17 @@ class HipOps:
     def fill_normal(self, existing, depth, K_, passthrough):
         return self._fill(1, existing, depth, K_, passthrough)
 
+    def fill_image(self, existing, rgba, passthrough):
+        ex = self.f.PredictionImages(H, W)
+        z = np.zeros((H, W, 4), np.float32)
+        ex.vertex.upload(z)
+        ex.normal.upload(z)
+        ex.image.upload(np.ascontiguousarray(existing, np.uint8))
+        return self.f.fill_in(ex, np.zeros((H, W), np.uint16), rgba, K, passthrough, passthrough).image.download()
+
+    def resize(self, src, drows, dcols):
+        return self.f.resize_nn(np.ascontiguousarray(src), drows, dcols).download()
+
 
 def test_product_equals_the_references_shaders(orc):
     from densemonoslam_amd import capi, fusion, synth
