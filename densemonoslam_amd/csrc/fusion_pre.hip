@@ -5,24 +5,43 @@
 #include "fill.hpp"
 #include "live_bodies.hpp"
 
+#include <mutex>
+
 namespace dms {
 
 static constexpr int BX = 64, BY = 4;
 
 // G1 — depth_bilateral.frag:30-75.  Fragment (x, y) has texcoord ((x+0.5)/cols, (y+0.5)/rows);
 // taps are fetched at (float(cx)/cols, float(cy)/rows) with the NEAREST rule of surfel.hpp.
-// The tap -> texel tables (one fp32 division + floor per column / row) are built once per block
-// in LDS instead of once per tap; the 169-tap sum itself keeps the shader's order and arithmetic.
-// TBY rows per tile.  The kernel walks tiles with a block stride, so the launch decides its footprint: one tile per block
-// (grid = tiles: the whole chip, shortest run) or a few fat blocks that own the same few compute units for the whole image.
-// The frame step uses the second form on its prep stream: the previous frame's tracker runs beside it, and its resident
-// kernels need one EMPTY compute unit per block — with 1 200 small blocks sprinkled over every CU each tracker launch
-// waited for CUs to drain (+40 us on the level-0 kernel and +16 us on level 1 in the rocprof trace of round 2).
-// LUT (fat blocks only): the weight exp(-(space2 / 2 sigma_s^2 + (dv)^2 / 2 sigma_c^2)) depends on (|dx|, |dy|) in 0..6 and on the
-// integer depth difference |dv| in millimetres, and is exactly 0 from |dv| = 396 on (the argument falls below det_expf's
-// -87 cut-off whatever the distance): a 49 x 396 table in LDS, filled once per block with the very expression of the
-// direct form, replaces ~25 instructions per tap by one LDS read — the same bits, a third of the time.
-constexpr int kBilDv = 396;
+// The weight exp(-(space2 / 2 sigma_s^2 + dv^2 / 2 sigma_c^2)) of a tap depends on (|dx|, |dy|) in 0..6 — through dx^2 + dy^2, so on
+// the unordered pair: 28 rows — and on the integer depth difference |dv| in millimetres, and is exactly 0 from |dv| = 396 on (the
+// argument falls below det_expf's -87 cut-off whatever the distance).  It is tabulated ONCE per device with the very expression of
+// the shader (k_bilateral_lut_build: 28 x 397 floats, the last column the zero every larger difference is clamped to); each block
+// copies the table to LDS (44 KB) and stages its tile's source texels (halo included, through the per-column / per-row tap -> texel
+// tables, one fp32 division + floor each), so a tap is two LDS reads and nine vector instructions, no branch: the thirteen taps of
+// a window row are read together, then their thirteen weights — two LDS round trips per row.  The 169-tap sum keeps the shader's
+// order (rows outer, columns inner) and arithmetic, so the bits are the per-tap evaluation's.
+// TBY rows per tile.  The kernel walks tiles with a block stride, so the launch decides its footprint: one 64 x 10 tile per block
+// (two blocks = 20 waves per compute unit; 480 tiles at 640 x 480 are resident at once) or a few fat 64 x 16 blocks that own the same
+// few compute units for the whole image.  The frame step uses the second form on its prep stream: the previous frame's tracker runs
+// beside it, and its resident kernels need one EMPTY compute unit per block — with small blocks sprinkled over every CU each tracker
+// launch waited for CUs to drain (+40 us on the level-0 kernel and +16 us on level 1 in the rocprof trace of round 2).
+constexpr int kBilDv = 396, kBilStride = kBilDv + 1, kBilRows = 28;
+__host__ __device__ constexpr int bil_row(int a, int b) { return a < b ? b * (b + 1) / 2 + a : a * (a + 1) / 2 + b; }
+__device__ float g_bil_lut[kBilRows * kBilStride];
+
+__global__ void k_bilateral_lut_build() {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kBilRows * kBilStride; e += gridDim.x * blockDim.x) {
+    const int row = e / kBilStride, m = e - row * kBilStride;
+    int hi = 0;
+    while ((hi + 1) * (hi + 2) / 2 <= row) ++hi;
+    const int lo = row - hi * (hi + 1) / 2;
+    const float space2 = (float)(lo * lo + hi * hi);
+    const float dc = (float)m;
+    const float color2 = dc * dc;
+    g_bil_lut[e] = m < kBilDv ? det_expf(-(space2 * 0.024691358f + color2 * 0.000555556f)) : 0.f;
+  }
+}
 
 // What else the frame step derives from a filtered depth value, per pixel, in the filter's own store (three launches and two
 // more passes over the image otherwise): its metric form (metriciseDepth of the filtered image, ElasticFusion.cpp:119), the
@@ -52,49 +71,38 @@ __device__ __forceinline__ void bilateral_store(unsigned short* __restrict__ dst
   }
 }
 
-template <int TBY, bool LUT>
+template <int TBY>
 __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
                                                              int cols, int rows, float maxD, BilateralEpilogue ep) {
-  constexpr int HALO = 8;
-  __shared__ int s_sx[BX + 2 * HALO];
-  __shared__ int s_sy[TBY + 2 * HALO];
+  constexpr int HALO = 8, R = 6, D = 2 * R + 1;
+  constexpr int TW = BX + 2 * HALO, TH = TBY + 2 * HALO;
+  __shared__ __attribute__((aligned(16))) float s_lut[kBilRows * kBilStride];
+  __shared__ unsigned short s_tile[TH][TW + 2];
+  __shared__ int s_sx[TW];
+  __shared__ int s_sy[TH];
   const float colsf = (float)cols, rowsf = (float)rows;
   const int tiles_x = (cols + BX - 1) / BX, tiles_y = (rows + TBY - 1) / TBY;
   const int tid = threadIdx.y * BX + threadIdx.x;
-  __shared__ float s_lut[LUT ? 49 * kBilDv : 1];
-  constexpr int TW = BX + 2 * HALO, TH = TBY + 2 * HALO;
-  __shared__ unsigned short s_tile[LUT ? TH : 1][LUT ? TW + 2 : 1];
-  if (LUT) {
-    for (int e = tid; e < 49 * kBilDv; e += BX * TBY) {
-      const int pair = e / kBilDv, m = e - pair * kBilDv;
-      const int ady = pair / 7, adx = pair - ady * 7;
-      const float space2 = (float)(adx * adx + ady * ady);
-      const float dc = (float)m;
-      const float color2 = dc * dc;
-      s_lut[e] = det_expf(-(space2 * 0.024691358f + color2 * 0.000555556f));
-    }
-  }
+  static_assert(kBilRows * kBilStride % 4 == 0, "the table is copied as float4");
+  for (int e = tid; e < kBilRows * kBilStride / 4; e += BX * TBY)
+    reinterpret_cast<float4*>(s_lut)[e] = reinterpret_cast<const float4*>(g_bil_lut)[e];
+  const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
   for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int bx0 = txi * BX - HALO, by0 = tyi * TBY - HALO;
     __syncthreads();  // the tables of the previous tile are no longer read
-    if (tid < BX + 2 * HALO) s_sx[tid] = texel((float)(bx0 + tid) / colsf, colsf, cols);
-    if (tid >= 128 && tid < 128 + TBY + 2 * HALO) s_sy[tid - 128] = texel((float)(by0 + tid - 128) / rowsf, rowsf, rows);
+    if (tid < TW) s_sx[tid] = texel((float)(bx0 + tid) / colsf, colsf, cols);
+    if (tid >= 128 && tid < 128 + TH) s_sy[tid - 128] = texel((float)(by0 + tid - 128) / rowsf, rowsf, rows);
     __syncthreads();
-    if (LUT) {
-      // the tile's source texels (halo included, through the same tap -> texel tables) once, coalesced: the tap loop then
-      // reads LDS only — per tap the direct form pays a dependent table read + global load + weight evaluation
-      for (int e = tid; e < TH * TW; e += BX * TBY) {
-        const int ky = e / TW, kx = e - ky * TW;
-        s_tile[ky][kx] = src[(size_t)s_sy[ky] * cols + s_sx[kx]];
-      }
-      __syncthreads();
+    for (int e = tid; e < TH * TW; e += BX * TBY) {
+      const int ky = e / TW, kx = e - ky * TW;
+      s_tile[ky][kx] = src[(size_t)s_sy[ky] * cols + s_sx[kx]];
     }
+    __syncthreads();
     const int px = txi * BX + threadIdx.x;
     const int py = tyi * TBY + threadIdx.y;
     if (px >= cols || py >= rows) continue;
     const unsigned value = src[(size_t)py * cols + px];
-    const unsigned gate = (unsigned)f2i_rz(maxD * 1000.0f);
     if (value > gate || value < 300U) {
       bilateral_store(dst, ep, px, py, cols, rows, 0, gate);
       continue;
@@ -103,64 +111,48 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
     const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
     const int x = (int)(tcx * colsf);
     const int y = (int)(tcy * rowsf);
-    const float sigma_space2_inv_half = 0.024691358f;
-    const float sigma_color2_inv_half = 0.000555556f;
-    const int R = 6;
-    const int D = R * 2 + 1;
-    const int tx = min(x - D / 2 + D, cols);
-    const int ty = min(y - D / 2 + D, rows);
-    const float fvalue = (float)value;
+    const int x0 = x - R, y0 = y - R;
+    const int kx0 = x0 - bx0, ky0 = y0 - by0;
     float sum1 = 0.f, sum2 = 0.f;
-    if (LUT) {
-      const int kx0 = x - D / 2 - bx0, ky0 = y - D / 2 - by0;
-      // interior pixel whose 13 x 13 window lies in the staged tile: constant trip counts, constant table rows; the same
-      // taps in the same order (rows outer, columns inner) and the same two sums
-      if (x - D / 2 >= 0 && x - D / 2 + D <= cols && y - D / 2 >= 0 && y - D / 2 + D <= rows && kx0 >= 0 && kx0 + D <= TW && ky0 >= 0 &&
-          ky0 + D <= TH) {
+    if (x0 >= 0 && x0 + D <= cols && y0 >= 0 && y0 + D <= rows && kx0 >= 0 && kx0 + D <= TW && ky0 >= 0 && ky0 + D <= TH) {
+      // interior pixel whose 13 x 13 window lies in the image and in the staged tile: constant trip counts
 #pragma unroll 1
-        for (int j = 0; j < D; ++j) {  // (rows stay a loop: 169 unrolled taps hoist more loads than 128 registers hold)
-          constexpr int R6 = D / 2;
-          const int ady = j < R6 ? R6 - j : j - R6;
-          const float* lrow = s_lut + ady * 7 * kBilDv;
-          const unsigned short* trow = &s_tile[ky0 + j][kx0];
+      for (int j = 0; j < D; ++j) {  // (rows stay a loop: 169 unrolled taps hoist more loads than the registers hold)
+        const int ady = j < R ? R - j : j - R;
+        const unsigned short* trow = &s_tile[ky0 + j][kx0];
+        unsigned tap[D];
+        float w[D];
 #pragma unroll
-          for (int i = 0; i < D; ++i) {
-            const unsigned tap = trow[i];
-            const int dv = abs((int)value - (int)tap);
-            const int adx = i < R6 ? R6 - i : i - R6;
-            const float weight = dv < kBilDv ? lrow[adx * kBilDv + dv] : 0.f;
-            sum1 += (float)tap * weight;
-            sum2 += weight;
-          }
+        for (int i = 0; i < D; ++i) tap[i] = trow[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const int adx = i < R ? R - i : i - R;
+          const unsigned dv = min((unsigned)abs((int)value - (int)tap[i]), (unsigned)kBilDv);
+          w[i] = s_lut[bil_row(adx, ady) * kBilStride + dv];
         }
-        bilateral_store(dst, ep, px, py, cols, rows, (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2)), gate);
-        continue;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          sum1 += (float)tap[i] * w[i];
+          sum2 += w[i];
+        }
       }
-    }
-    for (int cy = max(y - D / 2, 0); cy < ty; ++cy) {
-      const int ky = cy - by0;
-      const int sy = (ky >= 0 && ky < TBY + 2 * HALO) ? s_sy[ky] : texel((float)cy / rowsf, rowsf, rows);
-      const unsigned short* srow = src + (size_t)sy * cols;
-      const int dyi = y - cy;
-      for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
-        const int kx = cx - bx0;
-        const int sx = (kx >= 0 && kx < BX + 2 * HALO) ? s_sx[kx] : texel((float)cx / colsf, colsf, cols);
-        const unsigned tap = srow[sx];
-        const float ftmp = (float)tap;
-        // (float(x)-float(cx))^2 + (float(y)-float(cy))^2: small integers, exact in fp32
-        const int dxi = x - cx;
-        float weight;
-        if (LUT) {
-          const int dv = abs((int)value - (int)tap);
-          weight = dv < kBilDv ? s_lut[(abs(dyi) * 7 + abs(dxi)) * kBilDv + dv] : 0.f;
-        } else {
-          const float space2 = (float)(dxi * dxi + dyi * dyi);
-          const float dc = fvalue - ftmp;
-          const float color2 = dc * dc;
-          weight = det_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+    } else {
+      // image border (or a fragment centre that rounds out of its tile): clipped window, texels through the tables where they reach
+      const int tx = min(x0 + D, cols), ty = min(y0 + D, rows);
+      for (int cy = max(y0, 0); cy < ty; ++cy) {
+        const int ky = cy - by0;
+        const int sy = (ky >= 0 && ky < TH) ? s_sy[ky] : texel((float)cy / rowsf, rowsf, rows);
+        const unsigned short* srow = src + (size_t)sy * cols;
+        const int ady = abs(y - cy);
+        for (int cx = max(x0, 0); cx < tx; ++cx) {
+          const int kx = cx - bx0;
+          const int sx = (kx >= 0 && kx < TW) ? s_sx[kx] : texel((float)cx / colsf, colsf, cols);
+          const unsigned tap = srow[sx];
+          const unsigned dv = min((unsigned)abs((int)value - (int)tap), (unsigned)kBilDv);
+          const float weight = s_lut[bil_row(abs(x - cx), ady) * kBilStride + dv];
+          sum1 += (float)tap * weight;
+          sum2 += weight;
         }
-        sum1 += ftmp * weight;
-        sum2 += weight;
       }
     }
     bilateral_store(dst, ep, px, py, cols, rows, (unsigned short)(unsigned)f2i_rz(roundf(sum1 / sum2)), gate);
@@ -232,13 +224,44 @@ int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStr
     ep.cam.cy = cam_l0->cy;
     ep.vmap_cutoff = vmap_cutoff;
   }
+  {  // the weight table, once per device (the first call waits for it, so that any stream may read it afterwards)
+    static std::once_flag built[64];
+    int dev = 0;
+    DMS_HIP(hipGetDevice(&dev));
+    DMS_REQUIRE(dev >= 0 && dev < 64, "device index");
+    hipError_t e = hipSuccess;
+    std::call_once(built[dev], [&] {
+      hipLaunchKernelGGL(k_bilateral_lut_build, dim3(44), dim3(256), 0, s);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    });
+    DMS_HIP(e);
+  }
+  constexpr int WBY = 10;  // whole-chip form: 64 x 10 tiles, 640 threads, two blocks per compute unit
   if (narrow_blocks > 0) {  // a few 1 024-thread blocks that keep to their compute units (see the kernel)
-    hipLaunchKernelGGL((k_depth_bilateral<16, true>), dim3(narrow_blocks), dim3(BX, 16), 0, s, (const unsigned short*)src->data,
+    // ... and to themselves: the launch asks for the rest of the unit's 160 KB of LDS, so no other block — a resident tracker
+    // block above all, which would then run at the pace of a shared unit and hold the whole grid's all-reduces back — is placed
+    // beside a filter block (2100 against 2340 frames/s in the driver's form without it)
+    static const int pad = [] {
+      hipFuncAttributes a;
+      if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_depth_bilateral<16>)) != hipSuccess) return 0;
+      const int rest = 160 * 1024 - (int)a.sharedSizeBytes;
+      return rest > 0 ? rest : 0;
+    }();
+    hipLaunchKernelGGL((k_depth_bilateral<16>), dim3(narrow_blocks), dim3(BX, 16), pad, s, (const unsigned short*)src->data,
                        (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
   } else {
-    const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + BY - 1) / BY);
-    hipLaunchKernelGGL((k_depth_bilateral<BY, false>), dim3(tiles), dim3(BX, BY), 0, s, (const unsigned short*)src->data,
-                       (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
+    static const int wby = getenv("DMS_BIL_WBY") ? atoi(getenv("DMS_BIL_WBY")) : WBY;
+    static const int grid_env = getenv("DMS_BIL_GRID") ? atoi(getenv("DMS_BIL_GRID")) : 0;
+    static const int pad_env = getenv("DMS_BIL_PAD") ? atoi(getenv("DMS_BIL_PAD")) : 0;
+    const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + wby - 1) / wby);
+    const int grid = grid_env > 0 ? grid_env : tiles;
+#define DMS_BIL_LAUNCH(T) hipLaunchKernelGGL((k_depth_bilateral<T>), dim3(grid), dim3(BX, T), pad_env, s, (const unsigned short*)src->data, (unsigned short*)dst->data, src->cols, src->rows, maxD, ep)
+    if (wby == 4) DMS_BIL_LAUNCH(4);
+    else if (wby == 5) DMS_BIL_LAUNCH(5);
+    else if (wby == 8) DMS_BIL_LAUNCH(8);
+    else if (wby == 16) DMS_BIL_LAUNCH(16);
+    else DMS_BIL_LAUNCH(10);
   }
   DMS_CHECK_LAUNCH();
   return DMS_OK;
