@@ -71,6 +71,36 @@ __device__ __forceinline__ void bilateral_store(unsigned short* __restrict__ dst
   }
 }
 
+// the 13 x 13 window of one pixel from the staged tile, row by row: thirteen tile reads, thirteen table reads, then the two sums in
+// the shader's order.  MASKED: taps outside the image take the table's zero column.
+template <int TBY, bool MASKED>
+__device__ __forceinline__ void bilateral_rows(const unsigned short (*tile)[BX + 2 * 8 + 2], const float* lut, unsigned value, int kx0, int ky0, int x0,
+                                               int y0, int cols, int rows, float& sum1, float& sum2) {
+  constexpr int R = 6, D = 2 * R + 1;
+#pragma unroll 1
+  for (int j = 0; j < D; ++j) {  // (rows stay a loop: 169 unrolled taps hoist more loads than the registers hold)
+    const int ady = j < R ? R - j : j - R;
+    const unsigned short* trow = &tile[ky0 + j][kx0];
+    const bool row_in = !MASKED || (unsigned)(y0 + j) < (unsigned)rows;
+    unsigned tap[D];
+    float w[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) tap[i] = trow[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const int adx = i < R ? R - i : i - R;
+      unsigned dv = min((unsigned)abs((int)value - (int)tap[i]), (unsigned)kBilDv);
+      if (MASKED) dv = (row_in && (unsigned)(x0 + i) < (unsigned)cols) ? dv : (unsigned)kBilDv;
+      w[i] = lut[bil_row(adx, ady) * kBilStride + dv];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      sum1 += (float)tap[i] * w[i];
+      sum2 += w[i];
+    }
+  }
+}
+
 template <int TBY>
 __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
                                                              int cols, int rows, float maxD, BilateralEpilogue ep) {
@@ -114,30 +144,17 @@ __global__ __launch_bounds__(BX* TBY) void k_depth_bilateral(const unsigned shor
     const int x0 = x - R, y0 = y - R;
     const int kx0 = x0 - bx0, ky0 = y0 - by0;
     float sum1 = 0.f, sum2 = 0.f;
-    if (x0 >= 0 && x0 + D <= cols && y0 >= 0 && y0 + D <= rows && kx0 >= 0 && kx0 + D <= TW && ky0 >= 0 && ky0 + D <= TH) {
-      // interior pixel whose 13 x 13 window lies in the image and in the staged tile: constant trip counts
-#pragma unroll 1
-      for (int j = 0; j < D; ++j) {  // (rows stay a loop: 169 unrolled taps hoist more loads than the registers hold)
-        const int ady = j < R ? R - j : j - R;
-        const unsigned short* trow = &s_tile[ky0 + j][kx0];
-        unsigned tap[D];
-        float w[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) tap[i] = trow[i];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          const int adx = i < R ? R - i : i - R;
-          const unsigned dv = min((unsigned)abs((int)value - (int)tap[i]), (unsigned)kBilDv);
-          w[i] = s_lut[bil_row(adx, ady) * kBilStride + dv];
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          sum1 += (float)tap[i] * w[i];
-          sum2 += w[i];
-        }
-      }
+    const bool fits = kx0 >= 0 && kx0 + D <= TW && ky0 >= 0 && ky0 + D <= TH;  // the window lies in the staged tile (always, in practice)
+    const bool interior = x0 >= 0 && x0 + D <= cols && y0 >= 0 && y0 + D <= rows;
+    // A window the image clips: the shader's loops skip the taps outside; here they get the table's zero column — a tap of weight
+    // +0 adds +0 to both sums, which leaves them bit for bit — so a border pixel runs the same branch-free rows.  The choice is
+    // per wave (one masked lane makes the wave take the masked rows: two compares + two selects more per tap).
+    if (fits && __builtin_amdgcn_ballot_w64(!interior) == 0ull) {
+      bilateral_rows<TBY, false>(s_tile, s_lut, value, kx0, ky0, x0, y0, cols, rows, sum1, sum2);
+    } else if (fits) {
+      bilateral_rows<TBY, true>(s_tile, s_lut, value, kx0, ky0, x0, y0, cols, rows, sum1, sum2);
     } else {
-      // image border (or a fragment centre that rounds out of its tile): clipped window, texels through the tables where they reach
+      // a fragment centre that rounds out of its tile (not seen; kept as the definition): the shader's loops, texels through the tables where they reach
       const int tx = min(x0 + D, cols), ty = min(y0 + D, rows);
       for (int cy = max(y0, 0); cy < ty; ++cy) {
         const int ky = cy - by0;
