@@ -283,7 +283,7 @@ struct dms_fusion {
   hipStream_t s_prep = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_inputs = nullptr;
   bool fused_live = true;  // the live half as three fused launches (DMS_FUSED_LIVE=0: the operator chain, fifteen)
-  int prep_blocks = 64;  // fat blocks of the bilateral filter on the prep stream: 64 per 640x480 pixels, set at creation (DMS_PREP_BLOCKS; 0 = one tile per block)
+  int prep_blocks = 43;  // fat blocks of the bilateral filter on the prep stream, set at creation (DMS_PREP_BLOCKS; 0 = one tile per block)
   int host_lag = 2;  // the host enqueues frame t once frame t - host_lag has completed (DMS_HOST_LAG = 2 | 3; 3 measured -2.4 %)
   bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
   int last_prep = -1;         // image set whose ev_prep_done marks the end of the last enqueued ingest
@@ -703,17 +703,18 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->s_prep, hipStreamNonBlocking);
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_prep_done[k], hipEventDisableTiming);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_main_done[k], hipEventDisableTiming);
-  {  // 64 fat blocks at 640x480 (1816 -> 1905 frames/s; 40: the prep stream becomes the bottleneck, 128: 1875), scaled with the image
-    const long n = (long)p->width * p->height;
-    long b = (n * 64 + 153600) / 307200;
-    b = b < 32 ? 32 : (b > 160 ? 160 : b);
-    // ... but never more than the resident tracker kernels leave free: a fat block holds a whole compute unit for the length of
-    // the filter, and a resident grid that finds fewer free units than it has blocks starts incomplete — its blocks spin until
-    // the filter's blocks retire (640x480: 200 + 64 > 256 units made the level-0 launch 130 instead of 111 us beside the filter;
-    // 56 blocks: 114 us, 2470 -> 2572 frames/s).  Below 48 the prep stream itself becomes the bottleneck: then the overlap is kept.
+  {  // Fat blocks of the depth pre-filter beside the tracker: at most 48, and never more than the resident tracker kernels leave
+    // free — a fat block holds a whole compute unit for the length of the filter, and a resident grid that finds fewer free units
+    // than it has blocks starts incomplete, its blocks spinning until the filter's retire.  Measured in the driver's form at
+    // 640x480 (round 4, the table form of the filter: 112 us on 56 units): 16 / 24 / 32 / 40 / 43 / 48 / 50 / 56 / 60 blocks ->
+    // 2300 / 2326 / 2375 / 2386 / 2387 / 2388 / 2334 / 2305 / 2290 frames/s.  Below the cap the count is the smallest that keeps the
+    // number of rounds over the image's 64 x 16 tiles (300 tiles, 7 rounds: 43 blocks).
+    const int tiles = ((p->width + 63) / 64) * ((p->height + 15) / 16);
+    int cap = 48;
     const int free_cus = odometry_free_cus(f->odom);
-    if (free_cus >= 48 && free_cus < b) b = free_cus;
-    f->prep_blocks = (int)b;
+    if (free_cus >= 16 && free_cus < cap) cap = free_cus;
+    const int rounds = (tiles + cap - 1) / cap;
+    f->prep_blocks = (tiles + rounds - 1) / rounds;
   }
   if (const char* pb = getenv("DMS_PREP_BLOCKS")) f->prep_blocks = atoi(pb);
   if (const char* fl = getenv("DMS_FUSED_LIVE")) f->fused_live = atoi(fl) != 0;

@@ -254,7 +254,7 @@ int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStr
     });
     DMS_HIP(e);
   }
-  constexpr int WBY = 10;  // whole-chip form: 64 x 10 tiles, 640 threads, two blocks per compute unit
+  constexpr int WBY = 10;  // whole-chip form: 64 x 10 tiles, 640 threads, two blocks per compute unit (8 / 16 / 5 rows: 26 / 34 / 35 us against 24)
   if (narrow_blocks > 0) {  // a few 1 024-thread blocks that keep to their compute units (see the kernel)
     // ... and to themselves: the launch asks for the rest of the unit's 160 KB of LDS, so no other block — a resident tracker
     // block above all, which would then run at the pace of a shared unit and hold the whole grid's all-reduces back — is placed
@@ -268,17 +268,9 @@ int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStr
     hipLaunchKernelGGL((k_depth_bilateral<16>), dim3(narrow_blocks), dim3(BX, 16), pad, s, (const unsigned short*)src->data,
                        (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
   } else {
-    static const int wby = getenv("DMS_BIL_WBY") ? atoi(getenv("DMS_BIL_WBY")) : WBY;
-    static const int grid_env = getenv("DMS_BIL_GRID") ? atoi(getenv("DMS_BIL_GRID")) : 0;
-    static const int pad_env = getenv("DMS_BIL_PAD") ? atoi(getenv("DMS_BIL_PAD")) : 0;
-    const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + wby - 1) / wby);
-    const int grid = grid_env > 0 ? grid_env : tiles;
-#define DMS_BIL_LAUNCH(T) hipLaunchKernelGGL((k_depth_bilateral<T>), dim3(grid), dim3(BX, T), pad_env, s, (const unsigned short*)src->data, (unsigned short*)dst->data, src->cols, src->rows, maxD, ep)
-    if (wby == 4) DMS_BIL_LAUNCH(4);
-    else if (wby == 5) DMS_BIL_LAUNCH(5);
-    else if (wby == 8) DMS_BIL_LAUNCH(8);
-    else if (wby == 16) DMS_BIL_LAUNCH(16);
-    else DMS_BIL_LAUNCH(10);
+    const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + WBY - 1) / WBY);
+    hipLaunchKernelGGL((k_depth_bilateral<WBY>), dim3(tiles), dim3(BX, WBY), 0, s, (const unsigned short*)src->data,
+                       (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
   }
   DMS_CHECK_LAUNCH();
   return DMS_OK;
