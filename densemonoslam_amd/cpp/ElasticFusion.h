@@ -112,6 +112,10 @@ class ContextT {
   bool& rgbOnly() { return m_rgbOnly; }
   Mat4& currPose() { return m_currPose; }
   int& tick() { return m_tick; }
+  // Context::computeFeedbackBuffers (Context.h:211-223): the next new cluster starts from the last processed frame's surfels
+  void computeFeedbackBuffers(const int& /*maxDepthProcessed*/) {
+    if (fusion && dms_fusion_compute_feedback(fusion, nullptr) != DMS_OK) throw std::runtime_error(dms_last_error());
+  }
   bool& lost() { return m_lost; }
   int& numFused() { return m_numFused; }
   const std::string& filename() const { return m_file; }
@@ -184,7 +188,7 @@ class ReferenceFrameT {
   GlobalModel globalModel() {
     Context* c = founder();
     if (!c || !c->fusion) throw std::runtime_error("ReferenceFrame::globalModel: no camera of this frame has processed a frame yet");
-    return GlobalModel(dms_fusion_model(c->fusion));
+    return GlobalModel(dms_fusion_model(c->fusion), c->fusion);
   }
   // the frame's fern key-frame database: Ferns(500, Options::get().depth * 1000, Options::get().interMapPhotoThresh) (ReferenceFrame.h:17)
   Ferns& ferns() {
@@ -353,8 +357,8 @@ class ElasticFusionT {
    * @param timestamp only used for the output poses
    * @param inPose pose prior (the ORB-SLAM3 pose); with hybrid_tracking it is refined by the dense tracker, else taken as is
    * @param orbTcwOld, orbTcwNew the loop-closure candidate of the ORB-SLAM3 front end (hybrid_loops)
-   * @param cluster sub-map of the ground-truth-clusters mode; only cluster 0 exists here (a caller with several keeps one
-   *        ElasticFusion per cluster)
+   * @param cluster id of the ground-truth-clusters mode: a frame that fuses under an id the map does not know starts surfel buffers
+   *        of its own from the context's feedback buffers, and they stay current (GlobalModel.cpp:266-277, dmslam_fusion.h)
    * @param weightMultiplier optional full frame fusion weight
    * @param bootstrap if true, use inPose as a pose guess rather than replacement (re-assigns currPose = *inPose, :188-191)
    */
@@ -363,8 +367,8 @@ class ElasticFusionT {
                     const float weightMultiplier = 1.f, const bool bootstrap = false) {
     (void)bootstrap;
     const int tick_before = context.tick();
-    if (cluster != 0) throw std::runtime_error("processFrame: only cluster 0 is implemented (one surfel store per ElasticFusion)");
     ensure(context);
+    check(dms_fusion_set_cluster(context.fusion, cluster), "dms_fusion_set_cluster");
     // Context::rgbOnly() is read every frame by the reference (ElasticFusion.cpp:505): keep the device side in step
     check(dms_fusion_set_option(context.fusion, DMS_OPT_RGB_ONLY, (context.rgbOnly() || rgbOnly) ? 1.0 : 0.0), "dms_fusion_set_option");
     if (scheme == NID_KEYFRAMING) {  // fuseFrame reads these members every frame (ElasticFusion.cpp:646-675); the GUI may have moved them

@@ -102,7 +102,8 @@ class GlobalModel {
  public:
   static const int TEXTURE_DIMENSION = 5700;  // GlobalModel.cpp:22
   GlobalModel(int width, int height, size_t capacity = 0) : owned(true) { check(dms_model_create(&h, capacity, width, height), "dms_model_create"); }
-  explicit GlobalModel(dms_model* borrowed) : h(borrowed), owned(false) {}
+  // a view of a frame step's map: `ctx` = the context that owns the per-cluster buffers (GlobalModel.h:93-109)
+  explicit GlobalModel(dms_model* borrowed, dms_fusion* ctx = nullptr) : h(borrowed), ctx(ctx), owned(false) {}
   virtual ~GlobalModel() {
     if (owned) dms_model_destroy(h);
   }
@@ -121,7 +122,24 @@ class GlobalModel {
   }
   // GlobalModel::consume (GlobalModel.cpp:898-993): append `other` moved by the row-major 4x4 relativeTransform
   void consume(GlobalModel& other, const float* relativeTransform16) { check(dms_model_consume(h, other.h, relativeTransform16, nullptr), "consume"); }
+  // GlobalModel::clusters / isCluster (GlobalModel.cpp:251-264)
+  std::vector<int> clusters() {
+    std::vector<int> ids(1, 0);
+    if (ctx) {
+      int n = 0;
+      check(dms_fusion_clusters(ctx, nullptr, 0, &n, nullptr), "clusters");
+      ids.assign((size_t)n, 0);
+      check(dms_fusion_clusters(ctx, ids.data(), n, &n, nullptr), "clusters");
+    }
+    return ids;
+  }
+  bool isCluster(const int cluster) {
+    for (int c : clusters())
+      if (c == cluster) return true;
+    return false;
+  }
   dms_model* h = nullptr;
+  dms_fusion* ctx = nullptr;
 
  private:
   bool owned;

@@ -257,6 +257,18 @@ struct dms_fusion {
   dms_model* model = nullptr;
   dms_model* own_model = nullptr;  // the map this context created; != model once it has joined another camera's map
   bool adopting = false;           // dms_fusion_import_camera: the next frame seeds the live state and touches no map
+  // GlobalModel's per-cluster surfel buffers (GlobalModel.h:99-109; ground-truth-clusters mode).  The constructor makes cluster 0
+  // current (GlobalModel.cpp:56-59); a frame that fuses under an id the map does not know adds buffers for it, fills them from
+  // the context's FEEDBACK buffers and makes them current (:266-277, ElasticFusion.cpp:508-515) — nothing switches back, and
+  // every other member works on the current cluster.  The feedback buffers are computed on the first frame only
+  // (ElasticFusion.cpp:133) unless the caller asks again (Context::computeFeedbackBuffers, MainController.cpp:476): what is kept
+  // here is their input — colour, raw and filtered metric depth, tick — from which model_initialise makes the same surfels.
+  // nullptr = the constructor's empty cluster 0 of a context whose first frame arrived under another id.
+  std::map<int, dms_model*> clusters;
+  int cur_cluster = 0, req_cluster = 0;
+  dms_image2d fb_rgba, fb_dm, fb_dmf;
+  int fb_time = 0;
+  bool fb_valid = false;
   dms_odometry* odom = nullptr;
   dms_odometry* odom_m2m = nullptr;  // Context::modelToModel() (local loop closure)
   dms_predict_out pred_old;          // IndexMap old* textures: the INACTIVE view
@@ -374,6 +386,9 @@ void layout(dms_fusion* f, Carve& c) {
   f->depth_filtered = f->live[0].depth_filtered;
   f->depth_metric = f->live[0].depth_metric;
   f->depth_metric_filtered = f->live[0].depth_metric_filtered;
+  f->fb_rgba = mk_img(c.take(N * 4), H, W, 4);
+  f->fb_dm = mk_img(c.take(N * 4), H, W, 4);
+  f->fb_dmf = mk_img(c.take(N * 4), H, W, 4);
   f->imap.index = mk_img(c.take(N * 4), H, W, 4);
   f->imap.vertConf = mk_img(c.take(N * 16), H, W, 16);
   f->imap.colorTime = mk_img(c.take(N * 16), H, W, 16);
@@ -681,6 +696,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   }
   (void)dms_model_set_num_sensors(f->model, f->p.num_sensors);
   f->own_model = f->model;
+  f->clusters[0] = f->model;
   rc = dms_odometry_create(&f->odom, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
   if (rc) {
     dms_model_destroy(f->own_model ? f->own_model : f->model);
@@ -780,8 +796,75 @@ int dms_fusion_destroy(dms_fusion* f) {
   if (f->h_gloop) (void)hipHostFree(f->h_gloop);
   if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
   dms_odometry_destroy(f->odom);
-  dms_model_destroy(f->own_model ? f->own_model : f->model);
+  dms_model* const own = f->own_model ? f->own_model : f->model;
+  for (auto& kv : f->clusters)
+    if (kv.second && kv.second != own) dms_model_destroy(kv.second);
+  dms_model_destroy(own);
   delete f;
+  return DMS_OK;
+}
+
+// Context::computeFeedbackBuffers (Context.h:211-223): keeps the current frame's colour and metric depths and the tick
+static int snapshot_feedback(dms_fusion* f, hipStream_t s) {
+  const size_t N = (size_t)f->p.width * f->p.height;
+  DMS_HIP(hipMemcpyAsync(f->fb_rgba.data, f->rgba.data, N * 4, hipMemcpyDeviceToDevice, s));
+  DMS_HIP(hipMemcpyAsync(f->fb_dm.data, f->depth_metric.data, N * 4, hipMemcpyDeviceToDevice, s));
+  DMS_HIP(hipMemcpyAsync(f->fb_dmf.data, f->depth_metric_filtered.data, N * 4, hipMemcpyDeviceToDevice, s));
+  f->fb_time = f->tick;
+  f->fb_valid = true;
+  return DMS_OK;
+}
+
+int dms_fusion_compute_feedback(dms_fusion* f, dms_stream st) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(!f->in_frame && f->frames > 0, "computeFeedbackBuffers: between frames, after the first");
+  return snapshot_feedback(f, (hipStream_t)st);
+}
+
+int dms_fusion_set_cluster(dms_fusion* f, int cluster) {
+  DMS_REQUIRE(f, "null argument");
+  DMS_REQUIRE(!f->in_frame, "between frames only");
+  f->req_cluster = cluster;
+  return DMS_OK;
+}
+
+int dms_fusion_clusters(dms_fusion* f, int* ids, int max_ids, int* n_ids, int* current) {
+  DMS_REQUIRE(f && n_ids && (ids || max_ids == 0), "null argument");
+  int n = 0;
+  for (auto& kv : f->clusters) {
+    if (n < max_ids) ids[n] = kv.first;
+    ++n;
+  }
+  *n_ids = n;
+  if (current) *current = f->cur_cluster;
+  return DMS_OK;
+}
+
+dms_model* dms_fusion_cluster_model(dms_fusion* f, int cluster) {
+  if (!f) return nullptr;
+  auto it = f->clusters.find(cluster);
+  return it == f->clusters.end() ? nullptr : it->second;
+}
+
+// GlobalModel::initialise for an id the map does not know (GlobalModel.cpp:266-398), from the fusion block of a later frame
+static int cluster_initialise(dms_fusion* f, int cluster, hipStream_t s) {
+  DMS_REQUIRE(f->model == f->own_model && f->model->sharers == 1, "a new cluster on a map that several cameras share is not supported");
+  DMS_REQUIRE(f->fb_valid, "no feedback buffers");
+  dms_model* nm = nullptr;
+  int rc = dms_model_create(&nm, f->p.model_capacity, f->p.width, f->p.height);
+  if (rc) return rc;
+  (void)dms_model_set_num_sensors(nm, f->p.num_sensors);
+  rc = model_initialise(nm, &f->fb_rgba, &f->fb_dm, &f->fb_dmf, &f->cam, f->fb_time, f->p.timeIdx, (float)(int)f->p.maxDepthProcessed, s);
+  if (rc) {
+    dms_model_destroy(nm);
+    return rc;
+  }
+  nm->count_hold = 4;  // the result slots still in flight count the cluster that was current when their frames ran
+  nm->last_writer = f;
+  f->clusters[cluster] = nm;
+  f->cur_cluster = cluster;
+  f->model = f->own_model = nm;
+  f->pre_tick = -1;  // (a prediction rendered ahead of time was of the other cluster)
   return DMS_OK;
 }
 
@@ -978,6 +1061,14 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       if ((rc = model_initialise(f->model, &f->rgba, &f->depth_metric, &f->depth_metric_filtered, &f->cam, f->tick, f->p.timeIdx,
                                  (float)(int)f->p.maxDepthProcessed, s)))
         return rc;
+      if ((rc = snapshot_feedback(f, s))) return rc;
+      if (f->req_cluster != f->cur_cluster && !f->clusters.count(f->req_cluster) && f->model == f->own_model) {
+        // initialise(..., cluster, pose) of the first frame under another id: the surfels go into buffers of their own and the
+        // constructor's cluster stays behind, empty
+        f->clusters[f->cur_cluster] = nullptr;
+        f->clusters[f->req_cluster] = f->model;
+        f->cur_cluster = f->req_cluster;
+      }
     }
     // initFirstRGB (ElasticFusion.cpp:151): the intensity pyramid of this frame already sits in ring set 0
     f->map_initialised = true;
@@ -1156,6 +1247,7 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
     const int timeDeltaEff = f->p.timeDelta + f->frames_since_fusion;  // ElasticFusion.cpp:518,541,563
 
     if (!f->p.rgbOnly && f->tracking_ok && !f->lost && fuse_now) {  // fusion (ElasticFusion.cpp:506-564)
+      if (!f->clusters.count(f->req_cluster) && (rc = cluster_initialise(f, f->req_cluster, s))) return rc;  // :508-515
       {
         FTimer t(f, s, "index_map");
         if ((rc = index_map(f->model, &f->state->cur, &f->cam, f->tick, f->p.timeIdx, f->p.maxDepthProcessed, timeDeltaEff, f->zbuf,

@@ -109,6 +109,11 @@ lib.dms_fusion_fetch_loop.argtypes = [_P, C.POINTER(FrameResult), _P]
 lib.dms_fusion_process_frame_end.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _P]
 lib.dms_fusion_get_loop_constraints.argtypes = [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]
 lib.dms_fusion_join_map.argtypes = [_P, _P, C.POINTER(C.c_float), _P]
+lib.dms_fusion_set_cluster.argtypes = [_P, C.c_int]
+lib.dms_fusion_compute_feedback.argtypes = [_P, _P]
+lib.dms_fusion_clusters.argtypes = [_P, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.dms_fusion_cluster_model.argtypes = [_P, C.c_int]
+lib.dms_fusion_cluster_model.restype = _P
 lib.dms_fusion_import_camera.argtypes = [_P, _P, C.POINTER(C.c_float), _I, _P, _I, _P, _P]
 lib.dms_relative_transform.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 lib.dms_pose_compose.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -525,13 +530,33 @@ class ElasticFusion:
     def odometryHandle(self):
         return C.c_void_p(lib.dms_fusion_odometry(self.h))
 
-    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0):
+    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0, cluster=None):
+        if cluster is not None:
+            self.setCluster(cluster)
         ch = self.upload_frame(rgb, depth)
         self.processFrameAsync(self._rgb.ptr, ch, self._depth.ptr, inPose, weightMultiplier)
         return self.fetch()
 
-    def globalModel(self):
-        return GlobalModel(self.width, self.height, handle=lib.dms_fusion_model(self.h))
+    def globalModel(self, cluster=None):
+        """The current cluster's map (GlobalModel::model()), or the map of `cluster` (None if it has no buffers)."""
+        if cluster is None:
+            return GlobalModel(self.width, self.height, handle=lib.dms_fusion_model(self.h))
+        h = lib.dms_fusion_cluster_model(self.h, int(cluster))
+        return GlobalModel(self.width, self.height, handle=h) if h else None
+
+    # -- per-cluster surfel buffers (processFrame's `cluster`, GlobalModel::isCluster / clusters) ------------
+    def setCluster(self, cluster):
+        check(lib.dms_fusion_set_cluster(self.h, int(cluster)), "dms_fusion_set_cluster")
+
+    def computeFeedbackBuffers(self, stream=None):
+        check(lib.dms_fusion_compute_feedback(self.h, stream), "dms_fusion_compute_feedback")
+
+    def clusters(self):
+        """(ids, current id)"""
+        ids = (C.c_int * 64)()
+        n, cur = C.c_int(0), C.c_int(0)
+        check(lib.dms_fusion_clusters(self.h, ids, 64, C.byref(n), C.byref(cur)), "dms_fusion_clusters")
+        return [int(ids[i]) for i in range(min(n.value, 64))], int(cur.value)
 
     def image(self, which):
         v = Image2D()

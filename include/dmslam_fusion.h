@@ -412,6 +412,23 @@ int dms_model_save_ply(dms_model* m, const char* path, float confidenceThreshold
  * formatting (6 significant digits) and a blank before the newline.  poses16_host: n row-major 4 x 4 camera-to-world matrices. */
 int dms_trajectory_save(const char* path, const float* poses16_host, size_t n);
 
+/* ---- per-cluster surfel buffers (GlobalModel.h:50,93-109, GlobalModel.cpp:251-277; ElasticFusion::processFrame's `cluster`
+ * argument, ElasticFusion.h:98, ElasticFusion.cpp:105,138,508-515; MainController.cpp:373-377 passes the ground-truth cluster of
+ * the frame) ----
+ * dms_fusion_set_cluster: the id the following frames are processed under (default 0).  A frame that FUSES under an id the map
+ * does not know gets surfel buffers of its own, filled from the context's feedback buffers — those of the first frame unless
+ * dms_fusion_compute_feedback (Context::computeFeedbackBuffers, ElasticFusion.h:275 / Context.h:211) has refreshed them from the
+ * last processed frame — and those buffers become the current ones for everything (index map, fuse, clean, predictions,
+ * dms_fusion_model, counts, exports).  As in the reference nothing ever switches back: a known id, current or not, changes
+ * nothing.  Not supported on a map several cameras share (DMS_ERR_INVALID_ARG from the frame).
+ * dms_fusion_clusters: GlobalModel::clusters() (ids in ascending order; *n_ids = how many there are) and the current id;
+ * dms_fusion_cluster_model: a cluster's map (isCluster = non-null; NULL also for the constructor's empty cluster 0 of a context
+ * whose first frame ran under another id), owned by the context. */
+int dms_fusion_set_cluster(dms_fusion* f, int cluster);
+int dms_fusion_compute_feedback(dms_fusion* f, dms_stream stream);
+int dms_fusion_clusters(dms_fusion* f, int* ids, int max_ids, int* n_ids, int* current);
+dms_model* dms_fusion_cluster_model(dms_fusion* f, int cluster);
+
 int dms_fusion_set_profiling(dms_fusion* f, int enabled);
 int dms_fusion_get_kernel_time(dms_fusion* f, const char* name, double* total_ms, int* launches);
 

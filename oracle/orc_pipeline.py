@@ -35,7 +35,25 @@ class MapRef:
     """One reference frame's surfel map (ReferenceFrame::m_localModel): shared by every camera that has been merged into it."""
 
     def __init__(self):
-        self.model = np.zeros(0, orc.SURFEL_DTYPE)
+        # GlobalModel's per-cluster buffers (GlobalModel.h:99-109): the constructor makes cluster 0 and makes it current
+        # (GlobalModel.cpp:56-59); `initialise` with an unknown id adds buffers and switches to them (:266-277) — nothing ever switches
+        # back; every other member (model(), fuse, clean, lastCount, downloadMap, consume) works on the current cluster
+        self.clusters = {0: np.zeros(0, orc.SURFEL_DTYPE)}
+        self.current = 0
+
+    model = property(lambda self: self.clusters[self.current], lambda self, v: self.clusters.__setitem__(self.current, v))
+
+    def isCluster(self, cluster):
+        return cluster in self.clusters
+
+    def initialise(self, surfels, cluster):
+        """GlobalModel::initialise(rawFeedback, filteredFeedback, cluster, pose): `surfels` = what the init program makes of the
+        feedback buffers.  A known cluster's id does NOT make it current (:350: only its buffers are looked up, and what is written
+        and counted afterwards is indexed by current_cluster all the same)."""
+        if cluster not in self.clusters:
+            self.clusters[cluster] = np.zeros(0, orc.SURFEL_DTYPE)
+            self.current = cluster
+        self.clusters[self.current] = surfels
 
 
 class ElasticFusion:
@@ -184,7 +202,14 @@ class ElasticFusion:
         self.nidScores.append(score)
         return score > self.nid_threshold, score
 
-    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0, deform=None, orbTcwOld=None, orbTcwNew=None):
+    def computeFeedbackBuffers(self):
+        """Context::computeFeedbackBuffers (Context.h:211-223): the surfels of the CURRENT textures at the current tick.  processFrame
+        calls it on the first frame only (ElasticFusion.cpp:133); a later `initialise` of a new cluster (:508-515) therefore reads
+        the first frame's buffers unless the caller (the GUI's raw-cloud view, MainController.cpp:476) has computed them again."""
+        self.feedback = orc.model_initialise(self.rgba, self.depth_metric, self.depth_metric_filtered, self.K, self.tick, self.timeIdx,
+                                             float(int(self.maxDepthProcessed)), self.cap)
+
+    def processFrame(self, rgb, depth, inPose=None, weightMultiplier=1.0, deform=None, orbTcwOld=None, orbTcwNew=None, cluster=0):
         """deform(loop) stands in for Deformation::constrain (ElasticFusion.cpp:481, CPU/CHOLMOD, not
         restated): called with the loop candidate, it returns None (no deformation) or
         (rawGraph nodes n x 16, corrected pose)."""
@@ -216,8 +241,8 @@ class ElasticFusion:
             pose = np.eye(4, dtype=np.float32) if inPose is None else np.asarray(inPose, np.float32).reshape(4, 4)
             self.currPose = pose.copy()
             # computeFeedbackBuffers(const int& maxDepthProcessed): 25.0f -> 25 (Context.h:211)
-            self.model = orc.model_initialise(self.rgba, self.depth_metric, self.depth_metric_filtered, self.K, self.tick, self.timeIdx,
-                                              float(int(self.maxDepthProcessed)), self.cap)
+            self.computeFeedbackBuffers()
+            self.map.initialise(self.feedback.copy(), cluster)
             self.frameToModel.initFirstRGB(self.rgba)
             self.initialised = True
             fused = True
@@ -277,6 +302,8 @@ class ElasticFusion:
                 fuse, out.nid_score = self.fuseFrame()  # :501
             td = self.timeDelta + self.framesSinceLastFusion  # :518,:541,:563
             if not self.rgbOnly and trackingOk and not self.lost and fuse:  # fusion (:506-564)
+                if not self.map.isCluster(cluster):  # :508-515
+                    self.map.initialise(self.feedback.copy(), cluster)
                 im = orc.index_map(self.model, self.currPose, self.K, self.H, self.W, self.tick, self.timeIdx, self.maxDepthProcessed, td)
                 self.model, newU, _ = orc.model_fuse(self.model, self.currPose, self.tick, self.timeIdx, self.rgba, self.depth_metric,
                                                      self.depth_metric_filtered, im[0], im[1], im[3], self.K, self.maxDepthProcessed,

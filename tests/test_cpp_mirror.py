@@ -210,6 +210,24 @@ int main(int argc, char** argv) {
   eFusion->saveTimes(outDirectory);
   eFusion->saveStats(outDirectory);
   std::printf("surfels %u\n", ctx.lastResult().surfels);
+  // the ground-truth-clusters mode (MainController.cpp:373-377 passes the frame's cluster; :515 walks globalModel().clusters()):
+  // a frame that fuses under a new id starts buffers of its own from the feedback buffers, here refreshed the way the GUI's
+  // raw-cloud view does (:476)
+  {
+    auto& rf = eFusion->whichReferenceFrame(ctx);
+    if (rf.globalModel().clusters().size() != 1 || !rf.globalModel().isCluster(0) || rf.globalModel().isCluster(2)) return 18;
+    const unsigned before = rf.globalModel().lastCount();
+    ctx.computeFeedbackBuffers(eFusion->getMaxDepthProcessed());
+    Eigen::Matrix4f* prior = new Eigen::Matrix4f(ctx.currPose());
+    eFusion->processFrame(rgb, depth, 5000, ctx, prior, nullptr, nullptr, 2, 1.f, false);
+    delete prior;
+    int listed = 0;
+    for (const auto& c : rf.globalModel().clusters()) listed += c == 0 || c == 2;
+    if (listed != 2 || !rf.globalModel().isCluster(2)) return 19;
+    const unsigned now = rf.globalModel().lastCount();  // the current cluster
+    std::printf("clusters: %u surfels in cluster 0, %u in cluster 2\n", before, now);
+    if (now == 0) return 20;
+  }
   delete eFusion;
   return 0;
 }
