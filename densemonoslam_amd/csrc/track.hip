@@ -130,6 +130,7 @@ struct dms_odometry {
   TrackState* state = nullptr;
   TrackState* host_state = nullptr;  // pinned
   bool profiling = false;
+  bool profiling_level0_only = false;  // dms_odometry_set_profiling(o, 2): one event pair per call, around the level-0 kernel, nothing else perturbed
   std::map<std::string, KernelTime> times;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<hipEvent_t> event_pool;
@@ -1581,8 +1582,9 @@ struct Timer {
   hipStream_t s;
   const char* name;
   hipEvent_t a = nullptr, b = nullptr;
+  bool on() const { return o->profiling && (!o->profiling_level0_only || strcmp(name, "gn_level0") == 0); }
   Timer(dms_odometry* o_, hipStream_t s_, const char* n) : o(o_), s(s_), name(n) {
-    if (!o->profiling) return;
+    if (!on()) return;
     auto get = [&]() {
       hipEvent_t e;
       if (!o->event_pool.empty()) {
@@ -1598,7 +1600,7 @@ struct Timer {
     (void)hipEventRecord(a, s);
   }
   ~Timer() {
-    if (!o->profiling) return;
+    if (!on()) return;
     (void)hipEventRecord(b, s);
     o->pending.push_back({name, {a, b}});
   }
@@ -2278,7 +2280,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.cy = o->cy;
       L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
       L.first_delay = o->first_delay_for(pnb);
-      L.prof = o->profiling ? o->prof : nullptr;
+      L.prof = (o->profiling && !o->profiling_level0_only) ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
       L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
       L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
@@ -2852,6 +2854,7 @@ int dms_odometry_get_buffer(dms_odometry* o, int which, int level, dms_image2d* 
 int dms_odometry_set_profiling(dms_odometry* o, int enabled) {
   DMS_REQUIRE(o, "null argument");
   o->profiling = enabled != 0;
+  o->profiling_level0_only = enabled == 2;
   if (enabled) {
     drain_timers(o);
     o->times.clear();

@@ -329,7 +329,8 @@ int dms_odometry_get_buffer(dms_odometry* o, int which, int level, dms_image2d* 
 
 /* per-kernel device time of the last tracking call, measured with HIP events on the
  * caller's stream (kernel name -> accumulated ms, launches).  names: "gn_pass1", "gn_pass2",
- * "gn_solve", "so3_pass", "so3_solve".  Only filled when profiling was enabled. */
+ * "gn_solve", "so3_pass", "so3_solve".  Only filled when profiling was enabled.  enabled = 2: only "gn_level0" is bracketed
+ * (one event pair per tracking call, no in-kernel phase clocks): the dominant kernel's duration in an otherwise unperturbed run. */
 int dms_odometry_set_profiling(dms_odometry* o, int enabled);
 int dms_odometry_get_kernel_time(dms_odometry* o, const char* name, double* total_ms,
                                  int* launches);
