@@ -295,7 +295,7 @@ struct dms_fusion {
   hipStream_t s_prep = nullptr;
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_inputs = nullptr;
   bool fused_live = true;  // the live half as three fused launches (DMS_FUSED_LIVE=0: the operator chain, fifteen)
-  int prep_blocks = 43;  // fat blocks of the bilateral filter on the prep stream, set at creation (DMS_PREP_BLOCKS; 0 = one tile per block)
+  int prep_blocks = 38;  // fat blocks of the bilateral filter on the prep stream, set at creation (DMS_PREP_BLOCKS; 0 = one tile per block)
   int host_lag = 2;  // the host enqueues frame t once frame t - host_lag has completed (DMS_HOST_LAG = 2 | 3; 3 measured -2.4 %)
   bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
   int last_prep = -1;         // image set whose ev_prep_done marks the end of the last enqueued ingest
@@ -719,14 +719,15 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->s_prep, hipStreamNonBlocking);
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_prep_done[k], hipEventDisableTiming);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&f->ev_main_done[k], hipEventDisableTiming);
-  {  // Fat blocks of the depth pre-filter beside the tracker: at most 48, and never more than the resident tracker kernels leave
+  {  // Fat blocks of the depth pre-filter beside the tracker: at most 40, and never more than the resident tracker kernels leave
     // free — a fat block holds a whole compute unit for the length of the filter, and a resident grid that finds fewer free units
-    // than it has blocks starts incomplete, its blocks spinning until the filter's retire.  Measured in the driver's form at
-    // 640x480 (round 4, the table form of the filter: 112 us on 56 units): 16 / 24 / 32 / 40 / 43 / 48 / 50 / 56 / 60 blocks ->
-    // 2300 / 2326 / 2375 / 2386 / 2387 / 2388 / 2334 / 2305 / 2290 frames/s.  Below the cap the count is the smallest that keeps the
-    // number of rounds over the image's 64 x 16 tiles (300 tiles, 7 rounds: 43 blocks).
+    // than it has blocks starts incomplete, its blocks spinning until the filter's retire.  Measured at 640x480 (round 4, the
+    // table form of the filter: 112 us on 56 units), driver's form: 16 / 24 / 32 / 40 / 43 / 48 / 50 / 56 / 60 blocks ->
+    // 2300 / 2326 / 2375 / 2386 / 2387 / 2388 / 2334 / 2305 / 2290 frames/s; the leg with three predictions per frame: 2412 at
+    // 34 - 40 blocks, 2292 at 43, 2370 at 56.  Below the cap the count is the smallest that keeps the number of rounds over the
+    // image's 64 x 16 tiles (300 tiles, 8 rounds: 38 blocks).
     const int tiles = ((p->width + 63) / 64) * ((p->height + 15) / 16);
-    int cap = 48;
+    int cap = 40;
     const int free_cus = odometry_free_cus(f->odom);
     if (free_cus >= 16 && free_cus < cap) cap = free_cus;
     const int rounds = (tiles + cap - 1) / cap;
