@@ -596,6 +596,21 @@ struct Pose16v {
   float v[16];
 };
 
+// The consuming map's own records go through consume.vert too, with the identity (GlobalModel.cpp:903-949): every finite value
+// comes out as it went in, but a component that is -0 can come out +0 (-0 + 0 * y = +0 for y > 0) — found by running the reference's
+// program (tests/test_ref_gl_pin_*.py, stage `consumed`).  One pass over position and normal, in place; the rest is copied as is.
+__global__ __launch_bounds__(256) void k_consume_identity(SurfelPlanes dst, const unsigned* __restrict__ dcount) {
+  const unsigned n = dcount[0];
+  const float I[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+    const float4 p = dst.pos[i], nr = dst.nrm[i];
+    const f3 q = xform_point(I, mk3(p.x, p.y, p.z));
+    const f3 m = xform_dir(I, mk3(nr.x, nr.y, nr.z));
+    dst.pos[i] = make_float4(q.x, q.y, q.z, p.w);
+    dst.nrm[i] = make_float4(m.x, m.y, m.z, nr.w);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_consume_model(SurfelPlanes dst, size_t dcap, const unsigned* __restrict__ dcount, unsigned* __restrict__ dcount_new,
                                                        SurfelPlanes src, size_t scap, const unsigned* __restrict__ scount, Pose16v T) {
   const unsigned base = dcount[0], ns = scount[0];
@@ -687,6 +702,7 @@ int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStr
   }
   Pose16v T;
   memcpy(T.v, T16, sizeof(T.v));
+  hipLaunchKernelGGL(k_consume_identity, dim3(surfel_grid(dst->count_upper)), dim3(256), 0, s, dst->buf[dst->cur], dst->d_count);
   hipLaunchKernelGGL(k_consume_model, dim3(surfel_grid(src->count_upper)), dim3(256), 0, s, dst->buf[dst->cur], dst->cap, dst->d_count,
                      dst->d_count_alt, src->buf[src->cur], src->cap, src->d_count, T);
   DMS_CHECK_LAUNCH();
@@ -707,6 +723,7 @@ int model_consume_records(dms_model* dst, const float* rec_dev, unsigned n, cons
   }
   Pose16v T;
   memcpy(T.v, T16, sizeof(T.v));
+  hipLaunchKernelGGL(k_consume_identity, dim3(surfel_grid(dst->count_upper)), dim3(256), 0, s, dst->buf[dst->cur], dst->d_count);
   hipLaunchKernelGGL(k_consume_records, dim3(surfel_grid(n)), dim3(256), 0, s, dst->buf[dst->cur], dst->cap, dst->d_count, dst->d_count_alt,
                      rec_dev, n, T);
   DMS_CHECK_LAUNCH();

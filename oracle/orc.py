@@ -578,14 +578,14 @@ def sample_graph(model, sampleRate):
 def model_consume(dst, src, relativeTransform):
     """GlobalModel::consume (GlobalModel.cpp:898-993) with consume.vert: dst ++ transform(src); position
     through the 4x4 (fp32, ((T0 x + T1 y) + T2 z) + T3), normal through its 3x3, everything else kept."""
-    T = np.asarray(relativeTransform, np.float32).reshape(4, 4)
     out = np.concatenate([dst, src]).copy()
-    m = out[len(dst):]
-    p = src["pos"].astype(np.float32)
-    n = src["nrm"].astype(np.float32)
-    for i in range(3):
-        m["pos"][:, i] = ((T[i, 0] * p[:, 0] + T[i, 1] * p[:, 1]) + T[i, 2] * p[:, 2]) + T[i, 3]
-        m["nrm"][:, i] = (T[i, 0] * n[:, 0] + T[i, 1] * n[:, 1]) + T[i, 2] * n[:, 2]
+    # the consuming map's own records go through the program too, with the identity (:903-949): a -0 component can come out +0
+    for part, T in ((out[:len(dst)], np.eye(4, dtype=np.float32)), (out[len(dst):], np.asarray(relativeTransform, np.float32).reshape(4, 4))):
+        p = part["pos"].astype(np.float32).copy()
+        n = part["nrm"].astype(np.float32).copy()
+        for i in range(3):
+            part["pos"][:, i] = ((T[i, 0] * p[:, 0] + T[i, 1] * p[:, 1]) + T[i, 2] * p[:, 2]) + T[i, 3]
+            part["nrm"][:, i] = (T[i, 0] * n[:, 0] + T[i, 1] * n[:, 1]) + T[i, 2] * n[:, 2]
     return out
 
 

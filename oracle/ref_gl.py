@@ -201,6 +201,24 @@ def fill(which, existing, depth, cam, passthrough):
     return out
 
 
+def model_consume(dst, src, relativeTransform):
+    """GlobalModel::consume: dst's records unchanged, then src's moved by relativeTransform"""
+    d, m = to_ref(dst), to_ref(src)
+    T = _c(relativeTransform, np.float32).reshape(16)
+    out = np.zeros((max(len(d) + len(m), 1), 15), np.float32)
+    n = _ok(lib().rgl_model_consume(_p(d), len(d), _p(m), len(m), _p(T), _p(out)), "model_consume")
+    return from_ref(out[:n])
+
+
+def sample_graph(model, sampleRate, timeIdx=0):
+    """Deformation::sampleGraphModel: the program's samples (map order) and then the host's sort by init time (stable here)"""
+    m = to_ref(model)
+    out = np.zeros((max(len(m), 1), 4), np.float32)
+    n = _ok(lib().rgl_graph_sample(_p(m), len(m), int(timeIdx), int(sampleRate), _p(out)), "graph_sample")
+    rows = out[:n].copy()
+    return rows[np.argsort(rows[:, 3], kind="stable")]
+
+
 def fill_rgb(existing_rgba, raw_rgba, passthrough):
     """FillIn::image"""
     e, r = _c(existing_rgba, np.uint8), _c(raw_rgba, np.uint8)

@@ -215,6 +215,7 @@ static GLuint compile(GLenum type, const char* name) {
   return s;
 }
 static const char* TF4[] = {"vPosition0", "vColor0", "vTimes0", "vNormRad0"};
+static const char* TF_DATA[] = {"vData"};
 /* loadProgramFromFile / loadProgramGeomFromFile (Shaders/Shaders.h:69-111); tf != 0: the four interleaved feedback varyings */
 static GLuint program(const char* vs, const char* gs, const char* fs, int tf) {
   GLuint p = glCreateProgram(), s;
@@ -222,7 +223,8 @@ static GLuint program(const char* vs, const char* gs, const char* fs, int tf) {
   glAttachShader(p, s);
   if (gs) { if (!(s = compile(GL_GEOMETRY_SHADER, gs))) return 0; glAttachShader(p, s); }
   if (fs) { if (!(s = compile(GL_FRAGMENT_SHADER, fs))) return 0; glAttachShader(p, s); }
-  if (tf) glTransformFeedbackVaryings(p, 4, TF4, GL_INTERLEAVED_ATTRIBS);
+  if (tf == 1) glTransformFeedbackVaryings(p, 4, TF4, GL_INTERLEAVED_ATTRIBS);
+  if (tf == 2) glTransformFeedbackVaryings(p, 1, TF_DATA, GL_INTERLEAVED_ATTRIBS);  /* Deformation.cpp:35-45: sampleProgram's "vData" */
   glLinkProgram(p);
   GLint ok = 0;
   glGetProgramiv(p, GL_LINK_STATUS, &ok);
@@ -498,6 +500,79 @@ int rgl_model_initialise(const float* raw, const float* filtered, int n, float* 
   glDeleteBuffers(1, &bfil);
   glDeleteBuffers(1, &out);
   return gl_ok("model_initialise") ? -1 : (int)m;
+}
+
+/* GlobalModel::consume (GlobalModel.cpp:898-993): consume.vert twice into ONE feedback buffer - the map's own n_dst records with the
+ * identity, then the other map's n_src records with relativeTransform (row-major here) */
+int rgl_model_consume(const float* dst_model, int n_dst, const float* src_model, int n_src, const float* relative16, float* out_surfels) {
+  GLuint p = program("consume.vert", NULL, NULL, 1);
+  if (!p) return -1;
+  GLuint bd = vbo_make(dst_model, (size_t)n_dst * SURFEL_BYTES), bs = vbo_make(src_model, (size_t)n_src * SURFEL_BYTES);
+  GLuint out = vbo_make(NULL, (size_t)(n_dst + n_src ? n_dst + n_src : 1) * SURFEL_BYTES), q;
+  glGenQueries(1, &q);
+  glUseProgram(p);
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  um4(p, "transform", I);
+  glBindBuffer(GL_ARRAY_BUFFER, bd);
+  surfel_attribs();
+  p_glEnable(GL_RASTERIZER_DISCARD);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, out);
+  glBeginTransformFeedback(GL_POINTS);
+  glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
+  if (n_dst) p_glDrawArrays(GL_POINTS, 0, n_dst);
+  um4(p, "transform", relative16);
+  glBindBuffer(GL_ARRAY_BUFFER, bs);
+  surfel_attribs();
+  if (n_src) p_glDrawArrays(GL_POINTS, 0, n_src);
+  glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
+  glEndTransformFeedback();
+  p_glDisable(GL_RASTERIZER_DISCARD);
+  no_attribs();
+  p_glFinish();
+  GLuint m = 0;
+  glGetQueryObjectuiv(q, GL_QUERY_RESULT, &m);
+  glBindBuffer(GL_ARRAY_BUFFER, out);
+  if (m) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)m * SURFEL_BYTES, out_surfels);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  glUseProgram(0);
+  glDeleteBuffers(1, &bd);
+  glDeleteBuffers(1, &bs);
+  glDeleteBuffers(1, &out);
+  return gl_ok("model_consume") ? -1 : (int)m;
+}
+
+/* Deformation::sampleGraphModel up to the download (Deformation.cpp:250-307): sample.vert + sample.geom over the map, one vec4
+ * {position, init time} per sampleRate-th surfel in map order (the host's std::sort by time follows, :315-325) */
+int rgl_graph_sample(const float* model, int n, int timeIdx, int sampleRate, float* out4) {
+  GLuint p = program("sample.vert", "sample.geom", NULL, 2);
+  if (!p) return -1;
+  GLuint bm = vbo_make(model, (size_t)n * SURFEL_BYTES);
+  GLuint out = vbo_make(NULL, (size_t)(n ? n : 1) * 16), q;
+  glGenQueries(1, &q);
+  glUseProgram(p);
+  u1i(p, "timeIdx", timeIdx);
+  u1i(p, "sampleRate", sampleRate);
+  glBindBuffer(GL_ARRAY_BUFFER, bm);
+  surfel_attribs();
+  p_glEnable(GL_RASTERIZER_DISCARD);
+  glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, out);
+  glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
+  glBeginTransformFeedback(GL_POINTS);
+  if (n) p_glDrawArrays(GL_POINTS, 0, n);
+  glEndTransformFeedback();
+  glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
+  p_glDisable(GL_RASTERIZER_DISCARD);
+  no_attribs();
+  p_glFinish();
+  GLuint m = 0;
+  glGetQueryObjectuiv(q, GL_QUERY_RESULT, &m);
+  glBindBuffer(GL_ARRAY_BUFFER, out);
+  if (m) glGetBufferSubData(GL_ARRAY_BUFFER, 0, (size_t)m * 16, out4);
+  glBindBuffer(GL_ARRAY_BUFFER, 0);
+  glUseProgram(0);
+  glDeleteBuffers(1, &bm);
+  glDeleteBuffers(1, &out);
+  return gl_ok("graph_sample") ? -1 : (int)m;
 }
 
 /* IndexMap::predictIndices (IndexMap.cpp:146-217): index_map.vert + .frag, one GL point per surfel, four attachments.

@@ -111,6 +111,9 @@ class Rec:
         return from15(self(name, rec15(model)), self.dtype)
 
 
+T_CONSUME = np.array([[0.9553365, 0.0, 0.29552022, 0.4], [0.0, 1.0, 0.0, -0.1], [-0.29552022, 0.0, 0.9553365, 0.25], [0.0, 0.0, 0.0, 1.0]], np.float32)  # GlobalModel::consume's relativeTransform
+
+
 # ---- the chain ----------------------------------------------------------------------------------------------------------------
 def chain(be, inp, dtype, feed=None, tex_dim=TEX_DIM):
     r = Rec(feed, dtype)
@@ -123,8 +126,13 @@ def chain(be, inp, dtype, feed=None, tex_dim=TEX_DIM):
     # G3 + G4: first-frame surfels (FeedbackBuffer::compute x 2 + GlobalModel::initialise) from frame 0
     fb0 = be.depth_bilateral(inp["depth0"], MAX_DEPTH) if feed is None else np.asarray(feed["bilateral0"])
     r("bilateral0", fb0)
-    r.surfels("boot", be.model_initialise(inp["rgba0"], be.depth_metric(inp["depth0"], MAX_DEPTH), be.depth_metric(fb0, MAX_DEPTH), K, 1, 0,
-                                          float(int(MAX_DEPTH))))
+    boot = r.surfels("boot", be.model_initialise(inp["rgba0"], be.depth_metric(inp["depth0"], MAX_DEPTH), be.depth_metric(fb0, MAX_DEPTH), K, 1, 0,
+                                                 float(int(MAX_DEPTH))))
+    # GlobalModel::consume (map merge): the frame's map consumes the first frame's surfels moved by a relative transform
+    r.surfels("consumed", be.model_consume(model, boot, T_CONSUME))
+    # Deformation::sampleGraphModel: every 7th / 64th surfel as {position, init time}, ordered by time
+    r("graph_7", be.sample_graph(model, 7))
+    r("graph_64", be.sample_graph(model, 64))
     # G5: IndexMap::predictIndices
     im = be.index_map(model, pose, ti, K, H, W, tick, 0, MAX_DEPTH, td)
     im = [r("idx_" + n, a) for n, a in zip(("index", "vertConf", "colorTime", "normRad"), im)]
@@ -180,6 +188,12 @@ class GlOps:
     def model_fuse(self, model, pose, time, timeIdx, rgba, dr, drf, index, vc, ct, nr, K, maxDepth, weighting, tex_dim):
         return self.g.model_fuse(model, pose, time, timeIdx, rgba, dr, drf, index, vc, ct, nr, K, maxDepth, weighting, texDim=tex_dim)
 
+    def model_consume(self, dst, src, T):
+        return self.g.model_consume(dst, src, T)
+
+    def sample_graph(self, model, rate):
+        return self.g.sample_graph(model, rate)
+
     def model_clean(self, model, newU, pose, ti, time, timeIdx, index, vc, ct, nr, K, conf, td, maxDepth, nodes, dsyn, isFern):
         return self.g.model_clean(model, newU, pose, time, timeIdx, index, vc, ct, nr, K, conf, td, maxDepth, nodes=nodes, depthSynth=dsyn,
                                   isFern=isFern, t_inv=ti)
@@ -214,6 +228,12 @@ class OrcOps:
     def model_fuse(self, model, pose, time, timeIdx, rgba, dr, drf, index, vc, ct, nr, K, maxDepth, weighting, tex_dim):
         m, newU, _ = self.o.model_fuse(model, pose, time, timeIdx, rgba, dr, drf, index, vc, nr, K, maxDepth, weighting)
         return m, newU
+
+    def model_consume(self, dst, src, T):
+        return self.o.model_consume(dst, src, T)
+
+    def sample_graph(self, model, rate):
+        return self.o.sample_graph(model, rate)
 
     def model_clean(self, model, newU, pose, ti, time, timeIdx, index, vc, ct, nr, K, conf, td, maxDepth, nodes, dsyn, isFern):
         return self.o.model_clean(model, newU, pose, time, timeIdx, index, vc, ct, K, conf, td, maxDepth, nodes=nodes, depthSynth=dsyn,
@@ -362,6 +382,10 @@ def compare_all(out, fx, inp, skip=()):
         rep["emitted"]["new_unstable"] = int((np.asarray(fx["emitted"])[:, 7] == -2).sum())
     rep["idx2"] = compare_index_maps("idx2", [out["idx2_" + n] for n in ("index", "vertConf", "colorTime", "normRad")],
                                      [fx["idx2_" + n] for n in ("index", "vertConf", "colorTime", "normRad")], fx["fused"], ti)
+    rep["consumed"] = compare_surfels("consumed", out["consumed"], fx["consumed"], exact_values=True)  # one matrix-vector product per record: the same bits
+    for k in ("graph_7", "graph_64"):  # copies of map values: the same bytes
+        assert np.asarray(out[k], np.float32).tobytes() == np.asarray(fx[k], np.float32).tobytes(), k
+        rep[k] = dict(samples=int(len(np.asarray(fx[k]).reshape(-1, 4))), exact=True)
     rep["cleaned"] = compare_surfels("cleaned", out["cleaned"], fx["cleaned"])
     rep["cleaned_graph"] = compare_surfels("cleaned_graph", out["cleaned_graph"], fx["cleaned_graph"])
     rep["cleaned_fern"] = compare_surfels("cleaned_fern", out["cleaned_fern"], fx["cleaned_fern"])

@@ -34,6 +34,19 @@ class HipOps:
         gm.initialise(rgba, dm, dmf, K_, time, timeIdx, maxDepth)
         return gm.downloadMap()
 
+    def model_consume(self, dst, src, T):
+        a, b = self.f.GlobalModel(W, H, capacity=60000), self.f.GlobalModel(W, H, capacity=60000)
+        for m in (a, b):
+            m.setNumSensors(3)
+        a.upload(dst)
+        b.upload(src)
+        a.consume(b, T)
+        return a.downloadMap()
+
+    def sample_graph(self, model, rate):
+        self.gm.upload(model)
+        return self.gm.sampleGraph(rate)
+
     def index_map(self, model, pose, ti, K_, H_, W_, time, timeIdx, maxDepth, td):
         self.gm.upload(model)
         self.im.predictIndices(self.f.DevicePose(pose), time, timeIdx, self.gm, K_, maxDepth, td)
