@@ -5,6 +5,10 @@
 #include <chrono>
 #include <cstdio>
 
+__global__ void k_spin(long long ticks) {  // holds the stream while the host enqueues what is measured
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 __global__ void k_tiny(unsigned* p) {
   if (threadIdx.x == 0) p[0] += 1;
 }
@@ -47,8 +51,23 @@ int main() {
     for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));
     double us_graph = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * chain);
-    printf("%s kernels, chain of %d: %.2f us per kernel launched one by one, %.2f us per kernel as a graph\n", wide ? "wide (1200 x 256)" : "tiny (1 wave)", chain,
-           us_plain, us_graph);
+    // (c) the same two with the host out of the picture: everything is enqueued behind a 20 ms spinner, device time by events
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms_plain = 0.f, ms_graph = 0.f;
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 2000000LL);
+    CK(hipEventRecord(e0, s));
+    for (int r = 0; r < 50; ++r) enqueue();
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms_plain, e0, e1));
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 2000000LL);
+    CK(hipEventRecord(e0, s));
+    for (int r = 0; r < 50; ++r) CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms_graph, e0, e1));
+    printf("%s kernels, chain of %d: %.2f us per kernel launched one by one, %.2f us as a graph; queued behind a spinner (device side only): %.2f / %.2f us\n",
+           wide ? "wide (1200 x 256)" : "tiny (1 wave)", chain, us_plain, us_graph, ms_plain * 1000.0 / (50 * chain), ms_graph * 1000.0 / (50 * chain));
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
   }
   return 0;
