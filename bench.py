@@ -490,21 +490,34 @@ def main():
             return stages, kern, phases
 
         def level0_pass():
-            """nprof frames enqueued exactly as in the timed region, with ONE event pair per frame: around the dominant kernel's launch.
+            """n0 frames enqueued exactly as in the timed region, with ONE event pair per frame: around the dominant kernel's launch.
             (With a pair around every launch of both streams the prep stream's kernels shift against the tracker's and the level-0
-            launch waits for compute units it never waits for in the timed region.)"""
+            launch waits for compute units it never waits for in the timed region.)  Returns mean, median, max and how many launches
+            took more than 1.5 x the median (a resident grid that started incomplete waits for another stream's blocks to retire)."""
+            n0 = min(args.steps, 100)
             ef.set_profiling(False)
             capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 2))
-            for i in range(next_frame[0], next_frame[0] + nprof):
+            for i in range(next_frame[0], next_frame[0] + n0):
                 step(i, exchange_thumbnails=False)
-            next_frame[0] += nprof
+            next_frame[0] += n0
             ef.fetch(stream)
-            ms, cnt = C.c_double(0), C.c_int(0)
-            capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), b"gn_level0", C.byref(ms), C.byref(cnt)))
-            capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 0))
-            return 1000.0 * ms.value / cnt.value if cnt.value else None
 
-        us_level0_as_timed = level0_pass()
+            def q(name):
+                ms, cnt = C.c_double(0), C.c_int(0)
+                capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), name, C.byref(ms), C.byref(cnt)))
+                return ms.value, cnt.value
+
+            tot, cnt = q(b"gn_level0")
+            med, _ = q(b"gn_level0:median")
+            mx, _ = q(b"gn_level0:max")
+            extra, slow = q(b"gn_level0:slow")
+            capi.check(capi.lib.dms_odometry_set_profiling(C.c_void_p(od), 0))
+            if not cnt:
+                return None, None
+            return 1000.0 * tot / cnt, {"launches": cnt, "median_us": round(1000.0 * med, 2), "max_us": round(1000.0 * mx, 2),
+                                        "launches_over_1p5_median": slow, "their_excess_us_per_launch_overall": round(1000.0 * extra / cnt, 2)}
+
+        us_level0_as_timed, level0_spread = level0_pass()
         _, kern_pipe, _ = kernel_pass(False)
         stages, kern, phases = kernel_pass(True)
         if sum(sum(r.values()) for r in phases.values()) > 0:
@@ -551,6 +564,7 @@ def main():
                 "traffic": None if not pmc else pmc.get("hbm_bytes_per_launch"),
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_us": us_pipe,
+                "launch_spread": level0_spread,
                 "avg_launch_us_every_launch_bracketed": us_all,
                 "avg_launch_us_source": "one HIP event pair per frame around this kernel's launch, on its stream, frames enqueued as in the timed "
                                         "region (pipelined: the next frame's live half runs beside this frame) and nothing else bracketed; "

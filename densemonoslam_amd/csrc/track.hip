@@ -63,6 +63,7 @@ struct Buf {
 struct KernelTime {
   double ms = 0;
   int launches = 0;
+  std::vector<float> samples;  // per launch, ms (profiling only; "<name>:slow" / ":max" / ":median" of dms_odometry_get_kernel_time)
 };
 
 }  // namespace dms
@@ -1613,6 +1614,7 @@ void drain_timers(dms_odometry* o) {
       KernelTime& t = o->times[p.first];
       t.ms += ms;
       t.launches += 1;
+      if (t.samples.size() < 100000) t.samples.push_back(ms);
     }
     o->event_pool.push_back(p.second.first);
     o->event_pool.push_back(p.second.second);
@@ -2875,6 +2877,33 @@ int dms_odometry_get_kernel_time(dms_odometry* o, const char* name, double* tota
     *total_ms = i < 48 ? (double)v * 1e-5 : (double)(v % 100000000ll) * 1e-5;  // (counts: value * 1e-5)  // 10 ns ticks (stamps: modulo 1 s)
     *launches = 1;
     return DMS_OK;
+  }
+  {  // "<kernel>:median" / ":max" (ms) and ":slow" (launches = how many took more than 1.5 x the median)
+    const char* colon = strchr(name, ':');
+    if (colon) {
+      auto it2 = o->times.find(std::string(name, colon - name));
+      *total_ms = 0;
+      *launches = 0;
+      if (it2 == o->times.end() || it2->second.samples.empty()) return DMS_OK;
+      std::vector<float> v = it2->second.samples;
+      std::sort(v.begin(), v.end());
+      const float med = v[v.size() / 2];
+      if (strcmp(colon, ":median") == 0) *total_ms = med;
+      else if (strcmp(colon, ":max") == 0) *total_ms = v.back();
+      else if (strcmp(colon, ":slow") == 0) {
+        int n = 0;
+        double extra = 0;
+        for (float x : v)
+          if (x > 1.5f * med) {
+            ++n;
+            extra += x - med;
+          }
+        *launches = n;
+        *total_ms = extra;  // what the slow launches took beyond the median, summed
+      } else DMS_REQUIRE(false, "unknown suffix");
+      if (strcmp(colon, ":slow") != 0) *launches = (int)v.size();
+      return DMS_OK;
+    }
   }
   auto it = o->times.find(name);
   if (it == o->times.end()) {
