@@ -676,12 +676,21 @@ int orc_model_clean(const orc_surfel* model, int M, const orc_surfel* newUnstabl
   for (int pass = 0; pass < 2; ++pass) { /* glDrawTransformFeedback(model) then (newUnstableFid), GlobalModel.cpp:799,823 */
     const orc_surfel* src = pass == 0 ? model : newUnstable;
     const int cnt = pass == 0 ? M : nNew;
+    /* every vertex is a function of its own record and of the (read-only) index-map images: the vertex stage runs over all of them
+     * in parallel into a scratch copy, the geometry stage's stream-out order is the sequential compaction that follows - the
+     * thread count changes no bit */
+    orc_surfel* tmp = (orc_surfel*)malloc((size_t)(cnt > 0 ? cnt : 1) * sizeof(orc_surfel));
+    unsigned char* keep = (unsigned char*)malloc((size_t)(cnt > 0 ? cnt : 1));
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < cnt; ++i) {
-      orc_surfel v = src[i];
-      const int test = copy_unstable_vertex(&v, t_inv, cx, cy, fx, fy, rows, cols, time, timeIdx, confThreshold, index, vertConf,
-                                            colorTime, nodes, nNodes, depthSynth, maxDepth, timeDelta, isFern);
-      if (test > 0 && n < cap) out[n++] = v; /* copy_unstable.geom:36-50 */
+      tmp[i] = src[i];
+      keep[i] = copy_unstable_vertex(&tmp[i], t_inv, cx, cy, fx, fy, rows, cols, time, timeIdx, confThreshold, index, vertConf, colorTime, nodes,
+                                     nNodes, depthSynth, maxDepth, timeDelta, isFern) > 0;
     }
+    for (int i = 0; i < cnt; ++i)
+      if (keep[i] && n < cap) out[n++] = tmp[i]; /* copy_unstable.geom:36-50 */
+    free(tmp);
+    free(keep);
   }
   return n;
 }
