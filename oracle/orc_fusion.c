@@ -25,6 +25,9 @@
  * See tests/ for the properties that anchor the oracle (brute-force nearest-surfel search,
  * conservation of confidence mass, idempotence of clean without updates).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -280,38 +283,83 @@ static int project_window(const proj_t* a, v3 p, float* xw, float* yw, float* zw
   return 1;
 }
 
+/* The draws below are replayed in two steps that give the sequential result bit for bit with any number of threads: (1) every
+ * thread rasterises a contiguous range of the surfels, in order, into a z-buffer of its own that remembers the winning surfel
+ * (GL_LESS: the first of equal depths stays); the buffers are merged in thread order with the same strict comparison, so the winner
+ * of a pixel is the first surfel of minimal depth, as in one sequential pass; (2) every pixel writes the outputs of its winner,
+ * recomputed with the arithmetic that found it. */
+static int raster_threads(void) {
+  int t = 1;
+#ifdef _OPENMP
+  t = omp_get_max_threads();
+#endif
+  return t < 1 ? 1 : (t > 16 ? 16 : t);
+}
+
 void orc_index_map(const orc_surfel* model, int M, const float* pose16, float cx, float cy, float fx, float fy, int rows, int cols, int time,
                    int timeIdx, float maxDepth, int timeDelta, uint32_t* index, float* vertConf, float* colorTime, float* normRad) {
   const size_t N = (size_t)rows * cols;
   float t_inv[16];
   orc_inv4f(pose16, t_inv);
-  unsigned* zb = (unsigned*)malloc(N * sizeof(unsigned));
-  for (size_t i = 0; i < N; ++i) zb[i] = 0xFFFFFFu; /* glClear depth = 1.0 */
-  memset(index, 0, N * 4);
-  memset(vertConf, 0, N * 16);
-  memset(colorTime, 0, N * 16);
-  memset(normRad, 0, N * 16);
+  const int T = raster_threads();
+  unsigned* zbs = (unsigned*)malloc(N * sizeof(unsigned) * T);
+  int* ids = (int*)malloc(N * sizeof(int) * T);
   proj_t a = {cx, cy, fx, fy, (float)cols, (float)rows, maxDepth, cols, rows};
-  for (int i = 0; i < M; ++i) { /* glDrawTransformFeedback: one point per surfel, in order */
-    const orc_surfel* s = model + i;
-    const v3 ph = m4_point(t_inv, V3(s->pos[0], s->pos[1], s->pos[2]));
-    const float vt = s->times[timeIdx];
-    if (ph.z > maxDepth || ph.z < 0 || (vt != -3 && time - vt > timeDelta)) continue; /* x = y = -10: clipped */
-    float xw, yw, zw;
-    if (!project_window(&a, ph, &xw, &yw, &zw)) continue;
-    const int px = (int)floorf(xw), py = (int)floorf(yw); /* R2 */
-    if (px < 0 || py < 0 || px >= cols || py >= rows) continue;
-    const unsigned d = depth24(zw);
-    const size_t q = (size_t)py * cols + px;
-    if (!(d < zb[q])) continue; /* GL_LESS */
-    zb[q] = d;
-    const v3 nh = vnormalize(m4_dir(t_inv, V3(s->nrm[0], s->nrm[1], s->nrm[2])));
-    index[q] = (uint32_t)i; /* vertexId = gl_VertexID */
-    float* vc = vertConf + 4 * q; vc[0] = ph.x; vc[1] = ph.y; vc[2] = ph.z; vc[3] = s->pos[3];
-    float* ct = colorTime + 4 * q; ct[0] = s->col[0]; ct[1] = s->col[1]; ct[2] = s->col[2]; ct[3] = vt;
-    float* nr = normRad + 4 * q; nr[0] = nh.x; nr[1] = nh.y; nr[2] = nh.z; nr[3] = s->nrm[3];
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+  for (int t = 0; t < T; ++t) {
+    unsigned* zb = zbs + (size_t)t * N;
+    int* id = ids + (size_t)t * N;
+    for (size_t i = 0; i < N; ++i) {
+      zb[i] = 0xFFFFFFu; /* glClear depth = 1.0 */
+      id[i] = -1;
+    }
+    const int lo = (int)((long long)M * t / T), hi = (int)((long long)M * (t + 1) / T);
+    for (int i = lo; i < hi; ++i) { /* glDrawTransformFeedback: one point per surfel, in order */
+      const orc_surfel* s = model + i;
+      const v3 ph = m4_point(t_inv, V3(s->pos[0], s->pos[1], s->pos[2]));
+      const float vt = s->times[timeIdx];
+      if (ph.z > maxDepth || ph.z < 0 || (vt != -3 && time - vt > timeDelta)) continue; /* x = y = -10: clipped */
+      float xw, yw, zw;
+      if (!project_window(&a, ph, &xw, &yw, &zw)) continue;
+      const int px = (int)floorf(xw), py = (int)floorf(yw); /* R2 */
+      if (px < 0 || py < 0 || px >= cols || py >= rows) continue;
+      const unsigned d = depth24(zw);
+      const size_t q = (size_t)py * cols + px;
+      if (!(d < zb[q])) continue; /* GL_LESS */
+      zb[q] = d;
+      id[q] = i;
+    }
   }
-  free(zb);
+#pragma omp parallel for schedule(static) num_threads(T)
+  for (long long qq = 0; qq < (long long)N; ++qq) {
+    const size_t q = (size_t)qq;
+    unsigned best = 0xFFFFFFu;
+    int win = -1;
+    for (int t = 0; t < T; ++t)
+      if (zbs[(size_t)t * N + q] < best) {
+        best = zbs[(size_t)t * N + q];
+        win = ids[(size_t)t * N + q];
+      }
+    float* vc = vertConf + 4 * q;
+    float* ct = colorTime + 4 * q;
+    float* nr = normRad + 4 * q;
+    if (win < 0) {
+      index[q] = 0;
+      vc[0] = vc[1] = vc[2] = vc[3] = 0;
+      ct[0] = ct[1] = ct[2] = ct[3] = 0;
+      nr[0] = nr[1] = nr[2] = nr[3] = 0;
+      continue;
+    }
+    const orc_surfel* s = model + win;
+    const v3 ph = m4_point(t_inv, V3(s->pos[0], s->pos[1], s->pos[2]));
+    const v3 nh = vnormalize(m4_dir(t_inv, V3(s->nrm[0], s->nrm[1], s->nrm[2])));
+    index[q] = (uint32_t)win; /* vertexId = gl_VertexID */
+    vc[0] = ph.x; vc[1] = ph.y; vc[2] = ph.z; vc[3] = s->pos[3];
+    ct[0] = s->col[0]; ct[1] = s->col[1]; ct[2] = s->col[2]; ct[3] = s->times[timeIdx];
+    nr[0] = nh.x; nr[1] = nh.y; nr[2] = nh.z; nr[3] = s->nrm[3];
+  }
+  free(zbs);
+  free(ids);
 }
 
 /* ---- G6 / G6': IndexMap::combinedPredict / synthesizeDepth -------------------------------------- */
@@ -328,81 +376,134 @@ static void sprite_range(float c, float size, int n, int* lo, int* hi) { /* R4 *
   if (*hi > n - 1) *hi = n - 1;
 }
 
+/* vertex stage of one surfel (splat.vert:57-94); 0 = clipped / culled */
+typedef struct { v3 ph, nrm; float rad, conf, xw, yw, size; } splat_v;
+static int splat_vertex(const proj_t* a, const float* t_inv, const orc_surfel* s, float maxDepth, float confThreshold, int time, int timeIdx,
+                        int maxTime, int timeDelta, int actv, splat_v* o) {
+  const v3 ph = m4_point(t_inv, V3(s->pos[0], s->pos[1], s->pos[2]));
+  const float vt = s->times[timeIdx], conf = s->pos[3];
+  if (!(!actv && vt == -3) &&
+      (ph.z > maxDepth || ph.z < 0 || conf < confThreshold || (actv && vt == -3) || (vt != -3 && time - vt > timeDelta) || vt > maxTime))
+    return 0; /* gl_Position = 1000: clipped */
+  float zw0;
+  if (!project_window(a, ph, &o->xw, &o->yw, &zw0)) return 0;
+  const v3 nrm = vnormalize(m4_dir(t_inv, V3(s->nrm[0], s->nrm[1], s->nrm[2])));
+  const float rad = s->nrm[3];
+  const v3 x1n = vnormalize(V3(nrm.y - nrm.z, -nrm.x, nrm.x));
+  const v3 x1 = V3(x1n.x * rad * 1.41421356f, x1n.y * rad * 1.41421356f, x1n.z * rad * 1.41421356f);
+  const v3 y1 = vcross(nrm, x1);
+  const v3 p1 = projectPointImage(a, vadd(ph, x1)), p2 = projectPointImage(a, vadd(ph, y1));
+  const v3 p3 = projectPointImage(a, vsub(ph, y1)), p4 = projectPointImage(a, vsub(ph, x1));
+  const float xmin = fminf(p1.x, fminf(p2.x, fminf(p3.x, p4.x))), xmax = fmaxf(p1.x, fmaxf(p2.x, fmaxf(p3.x, p4.x)));
+  const float ymin = fminf(p1.y, fminf(p2.y, fminf(p3.y, p4.y))), ymax = fmaxf(p1.y, fmaxf(p2.y, fmaxf(p3.y, p4.y)));
+  const float size = fmaxf(0, fmaxf(fabsf(xmax - xmin), fabsf(ymax - ymin))); /* gl_PointSize */
+  if (!(size == size)) return 0;
+  o->ph = ph;
+  o->nrm = nrm;
+  o->rad = rad;
+  o->conf = conf;
+  o->size = size;
+  return 1;
+}
+/* fragment stage at (px, py) (combo_splat.frag:35-60 / depth_splat.frag:29-46); 0 = discard */
+static int splat_fragment(const splat_v* v, float cx, float cy, float fx, float fy, float maxDepth, int px, int py, v3* corrected, unsigned* d) {
+  const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+  const v3 l = vnormalize(V3((fcx - cx) / fx, (fcy - cy) / fy, 1.0f));
+  const float k = vdot(v->ph, v->nrm) / vdot(l, v->nrm);
+  *corrected = V3(k * l.x, k * l.y, k * l.z);
+  const float sqrRad = v->rad * v->rad;
+  const v3 diff = vsub(*corrected, v->ph);
+  if (vdot(diff, diff) > sqrRad) return 0; /* discard */
+  const float zw = (corrected->z / (2 * maxDepth)) + 0.5f; /* gl_FragDepth */
+  *d = depth24(zw);
+  return 1;
+}
+
 void orc_splat_predict(const orc_surfel* model, int M, const float* pose16, float cx, float cy, float fx, float fy, int rows, int cols,
                        float maxDepth, float confThreshold, int time, int timeIdx, int maxTime, int timeDelta, int actv, uint8_t* image,
                        float* vertex, float* normal, uint16_t* timeImg, float* depthOnly) {
   const size_t N = (size_t)rows * cols;
   float t_inv[16];
   orc_inv4f(pose16, t_inv);
-  unsigned* zb = (unsigned*)malloc(N * sizeof(unsigned));
-  for (size_t i = 0; i < N; ++i) zb[i] = 0xFFFFFFu;
-  if (depthOnly) {
-    memset(depthOnly, 0, N * 4);
-  } else {
-    memset(image, 0, N * 4);
-    memset(vertex, 0, N * 16);
-    memset(normal, 0, N * 16);
-    memset(timeImg, 0, N * 2);
-  }
+  const int T = raster_threads(); /* (two steps, as orc_index_map) */
+  unsigned* zbs = (unsigned*)malloc(N * sizeof(unsigned) * T);
+  int* ids = (int*)malloc(N * sizeof(int) * T);
   proj_t a = {cx, cy, fx, fy, (float)cols, (float)rows, maxDepth, cols, rows};
-  for (int i = 0; i < M; ++i) {
-    const orc_surfel* s = model + i;
-    /* splat.vert:57-94 */
-    const v3 ph = m4_point(t_inv, V3(s->pos[0], s->pos[1], s->pos[2]));
-    const float vt = s->times[timeIdx], conf = s->pos[3];
-    if (!(!actv && vt == -3) &&
-        (ph.z > maxDepth || ph.z < 0 || conf < confThreshold || (actv && vt == -3) || (vt != -3 && time - vt > timeDelta) || vt > maxTime))
-      continue; /* gl_Position = 1000: clipped */
-    float xw, yw, zw0;
-    if (!project_window(&a, ph, &xw, &yw, &zw0)) continue;
-    const v3 nrm = vnormalize(m4_dir(t_inv, V3(s->nrm[0], s->nrm[1], s->nrm[2])));
-    const float rad = s->nrm[3];
-    const v3 x1n = vnormalize(V3(nrm.y - nrm.z, -nrm.x, nrm.x));
-    const v3 x1 = V3(x1n.x * rad * 1.41421356f, x1n.y * rad * 1.41421356f, x1n.z * rad * 1.41421356f);
-    const v3 y1 = vcross(nrm, x1);
-    const v3 p1 = projectPointImage(&a, vadd(ph, x1)), p2 = projectPointImage(&a, vadd(ph, y1));
-    const v3 p3 = projectPointImage(&a, vsub(ph, y1)), p4 = projectPointImage(&a, vsub(ph, x1));
-    const float xmin = fminf(p1.x, fminf(p2.x, fminf(p3.x, p4.x))), xmax = fmaxf(p1.x, fmaxf(p2.x, fmaxf(p3.x, p4.x)));
-    const float ymin = fminf(p1.y, fminf(p2.y, fminf(p3.y, p4.y))), ymax = fmaxf(p1.y, fmaxf(p2.y, fmaxf(p3.y, p4.y)));
-    const float size = fmaxf(0, fmaxf(fabsf(xmax - xmin), fabsf(ymax - ymin))); /* gl_PointSize */
-    if (!(size == size)) continue;
-    int x0, x1i, y0, y1i;
-    sprite_range(xw, size, cols, &x0, &x1i);
-    sprite_range(yw, size, rows, &y0, &y1i);
-    for (int py = y0; py <= y1i; ++py)
-      for (int px = x0; px <= x1i; ++px) {
-        /* combo_splat.frag:35-60 / depth_splat.frag:29-46 */
-        const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
-        const v3 l = vnormalize(V3((fcx - cx) / fx, (fcy - cy) / fy, 1.0f));
-        const float k = vdot(ph, nrm) / vdot(l, nrm);
-        const v3 corrected = V3(k * l.x, k * l.y, k * l.z);
-        const float sqrRad = rad * rad;
-        const v3 diff = vsub(corrected, ph);
-        if (vdot(diff, diff) > sqrRad) continue; /* discard */
-        const float zw = (corrected.z / (2 * maxDepth)) + 0.5f; /* gl_FragDepth */
-        const unsigned d = depth24(zw);
-        const size_t q = (size_t)py * cols + px;
-        if (!(d < zb[q])) continue;
-        zb[q] = d;
-        if (depthOnly) {
-          depthOnly[q] = corrected.z;
-          continue;
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+  for (int t = 0; t < T; ++t) {
+    unsigned* zb = zbs + (size_t)t * N;
+    int* id = ids + (size_t)t * N;
+    for (size_t i = 0; i < N; ++i) {
+      zb[i] = 0xFFFFFFu;
+      id[i] = -1;
+    }
+    const int lo = (int)((long long)M * t / T), hi = (int)((long long)M * (t + 1) / T);
+    for (int i = lo; i < hi; ++i) {
+      splat_v v;
+      if (!splat_vertex(&a, t_inv, model + i, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, actv, &v)) continue;
+      int x0, x1i, y0, y1i;
+      sprite_range(v.xw, v.size, cols, &x0, &x1i);
+      sprite_range(v.yw, v.size, rows, &y0, &y1i);
+      for (int py = y0; py <= y1i; ++py)
+        for (int px = x0; px <= x1i; ++px) {
+          v3 corrected;
+          unsigned d;
+          if (!splat_fragment(&v, cx, cy, fx, fy, maxDepth, px, py, &corrected, &d)) continue;
+          const size_t q = (size_t)py * cols + px;
+          if (!(d < zb[q])) continue;
+          zb[q] = d;
+          id[q] = i;
         }
-        const v3 rgb = decodeColor(s->col[0]);
-        uint8_t* im = image + 4 * q; /* RGBA8 target: round(c * 255) */
-        im[0] = (uint8_t)f2i_rn(rgb.x * 255.0f); im[1] = (uint8_t)f2i_rn(rgb.y * 255.0f); im[2] = (uint8_t)f2i_rn(rgb.z * 255.0f); im[3] = 255;
-        const float z = corrected.z;
-        float* v = vertex + 4 * q;
-        v[0] = (fcx - cx) * z * (1.f / fx); v[1] = (fcy - cy) * z * (1.f / fy); v[2] = z; v[3] = conf;
-        float* n = normal + 4 * q;
-        n[0] = nrm.x; n[1] = nrm.y; n[2] = nrm.z; n[3] = rad;
-        const float tz = s->col[2];
-        unsigned tv = tz > 0 ? (unsigned)f2i_rz(tz) : 0u;
-        if (tv > 65535u) tv = 65535u;
-        timeImg[q] = (uint16_t)tv;
-      }
+    }
   }
-  free(zb);
+#pragma omp parallel for schedule(static) num_threads(T)
+  for (long long qq = 0; qq < (long long)N; ++qq) {
+    const size_t q = (size_t)qq;
+    unsigned best = 0xFFFFFFu;
+    int win = -1;
+    for (int t = 0; t < T; ++t)
+      if (zbs[(size_t)t * N + q] < best) {
+        best = zbs[(size_t)t * N + q];
+        win = ids[(size_t)t * N + q];
+      }
+    if (win < 0) {
+      if (depthOnly) {
+        depthOnly[q] = 0;
+      } else {
+        memset(image + 4 * q, 0, 4);
+        memset(vertex + 4 * q, 0, 16);
+        memset(normal + 4 * q, 0, 16);
+        timeImg[q] = 0;
+      }
+      continue;
+    }
+    const orc_surfel* s = model + win;
+    const int px = (int)(q % (size_t)cols), py = (int)(q / (size_t)cols);
+    splat_v v;
+    v3 corrected;
+    unsigned d;
+    (void)splat_vertex(&a, t_inv, s, maxDepth, confThreshold, time, timeIdx, maxTime, timeDelta, actv, &v);
+    (void)splat_fragment(&v, cx, cy, fx, fy, maxDepth, px, py, &corrected, &d);
+    if (depthOnly) {
+      depthOnly[q] = corrected.z;
+      continue;
+    }
+    const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+    const v3 rgb = decodeColor(s->col[0]);
+    uint8_t* im = image + 4 * q; /* RGBA8 target: round(c * 255) */
+    im[0] = (uint8_t)f2i_rn(rgb.x * 255.0f); im[1] = (uint8_t)f2i_rn(rgb.y * 255.0f); im[2] = (uint8_t)f2i_rn(rgb.z * 255.0f); im[3] = 255;
+    const float z = corrected.z;
+    float* vv = vertex + 4 * q;
+    vv[0] = (fcx - cx) * z * (1.f / fx); vv[1] = (fcy - cy) * z * (1.f / fy); vv[2] = z; vv[3] = v.conf;
+    float* n = normal + 4 * q;
+    n[0] = v.nrm.x; n[1] = v.nrm.y; n[2] = v.nrm.z; n[3] = v.rad;
+    const float tz = s->col[2];
+    unsigned tv = tz > 0 ? (unsigned)f2i_rz(tz) : 0u;
+    if (tv > 65535u) tv = 65535u;
+    timeImg[q] = (uint16_t)tv;
+  }
+  free(zbs);
+  free(ids);
 }
 
 /* ---- G7 + G8: GlobalModel::fuse ------------------------------------------------------------------ */
