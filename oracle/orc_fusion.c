@@ -522,6 +522,13 @@ int orc_model_fuse(orc_surfel* model, int M, const float* pose16, int time, int 
   float* upNrm = (float*)calloc((size_t)(M > 0 ? M : 1) * 4, 4);
   unsigned char* upDepthWritten = (unsigned char*)calloc((size_t)(M > 0 ? M : 1), 1);
   int nn = 0, merged = 0;
+  /* the vertex stage of every pixel (independent of the others) in parallel into scratch records; what depends on the draw order -
+   * the feedback buffer's sequence and "the first one stays" of the raster - is the sequential walk that follows */
+  const size_t NP = (size_t)rows * cols;
+  orc_surfel* ev = (orc_surfel*)malloc(NP * sizeof(orc_surfel));
+  unsigned* ebest = (unsigned*)malloc(NP * sizeof(unsigned));
+  unsigned char* ekind = (unsigned char*)calloc(NP, 1); /* 0: nothing emitted, 1: update, 2: new unstable */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < cols; i++)     /* uv buffer order: column-major (GlobalModel.cpp:100-108) */
     for (int j = 0; j < rows; j++) { /* data.vert:76-192 */
       const float tx = uv_coord(i, cols), ty = uv_coord(j, rows);
@@ -574,22 +581,35 @@ int orc_model_fuse(orc_surfel* model, int M, const float* pose16, int time, int 
           }
         if (counter > 0) { updateId = 1; colw = -1; } else { updateId = 2; colw = -2; }
       }
-      /* data.geom:38-59: both kinds are captured by transform feedback into newUnstableVbo */
-      orc_surfel* e = newUnstable + nn++;
+      const size_t slot = (size_t)i * rows + j;
+      orc_surfel* e = ev + slot;
       e->pos[0] = vPos.x; e->pos[1] = vPos.y; e->pos[2] = vPos.z; e->pos[3] = conf;
       e->col[0] = encodeColorBytes(c); e->col[1] = 0; e->col[2] = timef; e->col[3] = colw;
       e->nrm[0] = nG.x; e->nrm[1] = nG.y; e->nrm[2] = nG.z; e->nrm[3] = rad;
       for (int s = 0; s < ORC_MAX_SENSORS; ++s) e->times[s] = s == timeIdx ? colw : -3.f;
-      /* data.frag + raster: a size-1 point at texel `best`, z = 0, GL_LESS: the first one stays */
-      if (updateId == 1 && best < (unsigned)M && !upDepthWritten[best]) {
-        upDepthWritten[best] = 1;
-        memcpy(upPos + 4 * best, e->pos, 16);
-        memcpy(upCol + 4 * best, e->col, 16);
-        memcpy(upNrm + 4 * best, e->nrm, 16);
-      }
+      ebest[slot] = best;
+      ekind[slot] = (unsigned char)updateId;
     }
+  for (size_t slot = 0; slot < NP; ++slot) { /* the draw order: column-major */
+    if (!ekind[slot]) continue;
+    /* data.geom:38-59: both kinds are captured by transform feedback into newUnstableVbo */
+    orc_surfel* e = newUnstable + nn++;
+    *e = ev[slot];
+    const unsigned best = ebest[slot];
+    /* data.frag + raster: a size-1 point at texel `best`, z = 0, GL_LESS: the first one stays */
+    if (ekind[slot] == 1 && best < (unsigned)M && !upDepthWritten[best]) {
+      upDepthWritten[best] = 1;
+      memcpy(upPos + 4 * best, e->pos, 16);
+      memcpy(upCol + 4 * best, e->col, 16);
+      memcpy(upNrm + 4 * best, e->nrm, 16);
+    }
+  }
+  free(ev);
+  free(ebest);
+  free(ekind);
   *nNew = nn;
-  /* update.vert:42-104 over every surfel */
+  /* update.vert:42-104 over every surfel (each one on its own) */
+#pragma omp parallel for schedule(static) reduction(+ : merged)
   for (int id = 0; id < M; ++id) {
     const float* newColor = upCol + 4 * id;
     if (newColor[3] == -1) {
