@@ -654,9 +654,10 @@ def main():
             "host": {"nproc": nproc, "cpu_model": cpu_model()},
             "sample": "%d steady-state frames (after the bootstrap frame and the first tracked one) of the same synthetic stream, %dx%d, run by the "
                       "oracle/ C restatement of the reference algorithm with %d of the host's %d hardware threads: OpenMP covers the per-pixel loops "
-                      "of the tracker, the depth filter and the clean's vertex stage (more threads than this make those short loops slower), while the other surfel-map passes "
-                      "(index map, splats, fuse: about a third of a frame) replay the reference's sequential GL draws on ONE thread by design "
-                      "(draw order decides ties).  So this is a weak baseline - a restatement written to be checked against, not tuned - and says "
+                      "of the tracker, the depth filter and the vertex / rasterisation stages of the surfel-map passes (per-thread z-buffers over "
+                      "contiguous surfel ranges, merged in draw order with GL_LESS, so the bits are the sequential draws'); on one thread stay "
+                      "the parts the draw order defines (the fuse's feedback sequence, the clean's compaction) and the Python glue's array copies.  "
+                      "More threads than this make the short loops slower.  A restatement written to be checked against, not tuned: it says "
                       "nothing about kernel quality; one_core: the same with 1 thread for ~8 s.  Non-target" % (n_all, W, H, cores, nproc),
         }
 
