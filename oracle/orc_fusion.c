@@ -1,11 +1,11 @@
 /*
  * orc_fusion.c — CPU ORACLE (test infrastructure) for the surfel-map half of the hot path.
  *
- * A sequential restatement of the reference's GLSL programs and of the OpenGL pipeline state
- * they run under, written the way OpenGL executes them (clear, then one primitive after the
- * other in draw order through a depth-tested framebuffer; transform feedback appends in
- * order) — deliberately NOT the atomic / compaction formulation of the HIP kernels, so the two
- * check each other.  Sources followed:
+ * A restatement of the reference's GLSL programs and of the OpenGL pipeline state they run under, written the way OpenGL
+ * executes them (clear, then one primitive after the other in draw order through a depth-tested framebuffer; transform feedback
+ * appends in order) — deliberately NOT the atomic / compaction formulation of the HIP kernels, so the two check each other.
+ * (Since round 4 a draw's surfels are split into contiguous ranges that threads rasterise into z-buffers of their own, merged in
+ * draw order with the same GL_LESS: the sequential result with any thread count.)  Sources followed:
  *   Core/src/Shaders/{depth_bilateral,depth_metric}.frag, vertex_feedback.{vert,geom},
  *   init_unstable.vert, index_map.{vert,frag}, splat.vert, combo_splat.frag, depth_splat.frag,
  *   data.{vert,geom,frag}, update.vert, copy_unstable.{vert,geom}, fill_{vertex,normal,rgb}.frag,
@@ -13,8 +13,16 @@
  *   Core/src/{IndexMap.cpp:146-452, GlobalModel.cpp:29-225,266-417,513-853,
  *   ElasticFusion.cpp:84-97,99-637,688-768}, Shaders/{FeedbackBuffer,FillIn,Resize,ComputePack}.cpp.
  *
- * PARITY UNPINNED (no reference vectors exist; GL leaves texel selection at texel boundaries,
- * point-sprite coverage, exp/acos precision to the implementation).  The fixed rules are:
+ * PARITY PINNED (round 4) to the reference's own GLSL programs: oracle/ref_gl_harness.c compiles the shader files where they lie
+ * under /root/reference with Mesa's GLSL compiler and runs them on llvmpipe (software OpenGL 4.5, no GPU, no X server);
+ * tests/golden/ref_glsl.npz holds what they returned for every stage of a 48x36 case (depth filter, metric depth, first-frame
+ * surfels, index map, the three splat predictions, fuse data + update pass, clean plain / with a deformation graph / isFern,
+ * fill-in vertex / normal / image, resize, map merge, graph sampling); tests/test_ref_gl_pin_cpu.py holds this file to it and
+ * tests/test_ref_gl_live_cpu.py runs both live at two more sizes.  Bar: every decision identical (which surfel, which pixel, kept
+ * or removed, merged or new), integer fields exact, floats within a few ulp (llvmpipe's exp / acos / rsqrt are its own), the plain
+ * clean, the splat images, the map merge and the graph samples bit for bit; index-map ids may differ only for surfels within
+ * 1/64 pixel of a pixel boundary (GL leaves sub-pixel snapping to the implementation).  Not driven: Resize::time (a float sampler
+ * on an integer texture: undefined GL).  What GL leaves to the implementation is fixed here by these rules:
  *   R1 NEAREST fetch: texel = clamp(floor(u * n)) with the product in fp32;
  *   R2 point of size 1 owns pixel (floor(xw), floor(yw)), xw = (x_ndc + 1) * (W/2) in fp32;
  *   R3 depth buffer: 24-bit, value round(zw * (2^24-1)), cleared to 2^24-1, test GL_LESS, so

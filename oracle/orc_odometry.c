@@ -2,7 +2,8 @@
  * orc_odometry.c — CPU ORACLE (test infrastructure): restatement of the reference class
  * RGBDOdometry (elasticfusion/Core/src/Utils/RGBDOdometry.cpp:21-610) and of the Eigen
  * host arithmetic it performs between kernels.  See orc_track.c for the status header
- * (PARITY UNPINNED; who may load this library).
+ * (which parts are pinned to the reference's own kernels, and that the Eigen host arithmetic restated here is not; who may load
+ * this library).
  */
 #include <float.h>
 #include <math.h>

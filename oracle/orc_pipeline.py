@@ -6,8 +6,10 @@ Follows elasticfusion/Core/src/ElasticFusion.cpp:99-637 with loop closure off by
 prediction, model-to-model tracking, acceptance test, constraint sampling — and stops where the
 reference hands the constraints to the CPU/CHOLMOD deformation solver), NID keyframing off by default (--nkf: fuseFrame returns
 true, :639-645; nid_keyframing=True restates the gate of :646-675), tracking-failure detection off by default (--rl off: trackingOk is always true; reloc=True restates :204-244), cluster 0.
-PARITY UNPINNED like the functions it chains (the reference has no vectors for this path and cannot be built
-here); its own regression pin is tests/golden/oracle_fusion.npz.
+PARITY: the functions it chains are pinned to the reference's own code (orc_track.c / orc_fusion.c / orc_nid.c headers: reduce.cu
+and cudafuncs.cu built for gfx950, the GLSL programs run by llvmpipe); the CHAINING — the order of the stages in processFrame, the
+host decisions between them, the multi-camera session — follows ElasticFusion.cpp / MainController.cpp line by line but is
+unpinned (that code needs Eigen, Pangolin and CUDA-GL interop to build); its own regression pin is tests/golden/oracle_fusion.npz.
 The deformation graph is empty (it is only filled by loop closures), so clean() runs without
 nodes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """

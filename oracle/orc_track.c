@@ -8,16 +8,21 @@
  *   elasticfusion/Core/src/Utils/OdometryProvider.h:35-93 (Rodrigues, SE3 update)
  * Each function cites the lines it follows.
  *
- * PARITY: the reduction steps (icpStep, computeRgbResidual, rgbStep, so3Step: reduce.cu:235-1103) are PINNED to the
- * reference's own kernels: oracle/ref_build.sh compiles the reference's reduce.cu for gfx950, tests/golden/ref_reduce.npz
- * holds what it returned on an MI355X, tests/test_ref_pin_cpu.py holds this file to it (per-pixel rows and every
- * correspondence bit for bit, whole-image sums to summation-order tolerance).  Everything else here is PARITY UNPINNED:
- * the reference holds no golden vectors, known-answer tests or numeric fixtures for this path (its only harness,
- * GPUTest/src/GPUTest.cpp:146-332, asserts nothing); cudafuncs.cu does not compile from its own sources on this image
- * (legacy texture reference; see ref_build.sh) and the host loop needs Eigen.  Those parts are anchored on (i) the
- * reference's input fixture (the GPUTest RGB-D PNG pair, committed as tests/golden/gputest_pair.npz) run through the
- * harness protocol of GPUTest.cpp:247-286, (ii) analytic properties (synthetic scenes with a known camera motion,
- * finite-difference checks of the Jacobian rows) — see tests/.
+ * PARITY PINNED to the reference's own kernels for everything that runs on the device:
+ *   - the reduction steps (icpStep, computeRgbResidual, rgbStep, so3Step: reduce.cu:235-1103): oracle/ref_build.sh compiles the
+ *     reference's reduce.cu for gfx950, tests/golden/ref_reduce.npz (+ _fma) holds what it returned on an MI355X,
+ *     tests/test_ref_pin_cpu.py holds this file to it (per-pixel rows and every correspondence bit for bit, whole-image sums to
+ *     summation-order tolerance);
+ *   - the pyramid / preparation operators and the NID histograms (cudafuncs.cu:57-757, :1086-1157, :1513-1916; round 4): the
+ *     same recipe compiles cudafuncs.cu minus its legacy texture sampler (lines 641-669 removed by a line-anchored deletion,
+ *     nothing substituted, the surviving text's hash checked), tests/golden/ref_cudafuncs.npz holds its outputs on the GPUTest
+ *     pair and a ragged crop, tests/test_ref_cf_pin_cpu.py holds this file to them: every operator bit for bit, the two that
+ *     call rsqrtf within 1.8e-7 (an approximate instruction on every GPU), the NID scores bit for bit.
+ * PARITY UNPINNED, named: imageBGRToIntensity (the one function removed: gfx950 has no texture sampler for it) and the Eigen
+ * host arithmetic between the steps (ldlt, the exponential map, 4x4 products: RGBDOdometry.cpp:371-385,554-585,
+ * OdometryProvider.h:35-93 — Eigen is absent from the image; restated in orc_scalar.h and anchored on analytic properties:
+ * synthetic scenes with a known camera motion, finite-difference checks of the Jacobian rows, the reference's GPUTest pair run
+ * through the harness protocol of GPUTest.cpp:247-286 — see tests/).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
