@@ -52,7 +52,7 @@ def pmc_passes(args, W, H):
             d = os.path.join(tmp, name)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "r", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--width", str(W), "--height", str(H), "--no-cpu-baseline",
-                   "--no-kernel-pass", "--no-full-leg", "--no-pmc"] + extra
+                   "--no-kernel-pass", "--no-full-leg", "--no-config-legs", "--no-pmc"] + extra
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
             if r.returncode != 0:
                 return None
@@ -62,19 +62,27 @@ def pmc_passes(args, W, H):
                     kn = row["Kernel_Name"]
                     if "k_gn_level" not in kn:
                         continue
-                    key = (row["Dispatch_Id"], int(row["Grid_Size"]), int(row["Workgroup_Size"]))
+                    key = (row["Dispatch_Id"], kn, int(row["Grid_Size"]), int(row["Workgroup_Size"]))
                     per = vals.setdefault(row["Counter_Name"], {})
                     per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
                     durs[key] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3
             if not vals:
                 return None
-            for c, per in vals.items():  # level 0 = the launches with the largest grid
-                big = max(k[1] for k in per)
-                sel = [v for k, v in per.items() if k[1] == big]
+            # level 0 = the instantiation the dominant launch runs: selected by kernel NAME (the resident ICP + RGB kernel with
+            # the most pixels per thread), never by grid size alone — another configuration's level 0 has the same grid
+            names = {k[1] for per in vals.values() for k in per}
+            lvl0 = level0_kernel_name(names)
+            if lvl0 is None:
+                return None
+            res["kernel"] = lvl0
+            for c, per in vals.items():
+                sel = [v for k, v in per.items() if k[1] == lvl0]
                 res[c] = sum(sel) / len(sel)
-                res["blocks"] = big // max(1, next(k[2] for k in per if k[1] == big))
+                res["launches_" + name] = len(sel)
+                k0 = next(k for k in per if k[1] == lvl0)
+                res["blocks"] = k0[2] // max(1, k0[3])
                 if name == "sq":
-                    dd = [v for k, v in durs.items() if k[1] == big]
+                    dd = [v for k, v in durs.items() if k[1] == lvl0]
                     res["launch_us_under_pmc"] = round(sum(dd) / len(dd), 2)
         if "FETCH_SIZE" not in res or "WRITE_SIZE" not in res:
             return None
@@ -85,6 +93,8 @@ def pmc_passes(args, W, H):
             "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two nested 20-step passes of this run's build: "
                       "2 x %.0f KB fetched + %.0f KB written per level-0 launch" % (res["FETCH_SIZE"], res["WRITE_SIZE"]),
             "blocks": res.get("blocks"),
+            "kernel": res.get("kernel"),
+            "launches_averaged": res.get("launches_fetch"),
         }
         if "SQ_INSTS_VALU" in res and "launch_us_under_pmc" in res:
             out["valu_insts_per_launch"] = res["SQ_INSTS_VALU"]
@@ -95,6 +105,19 @@ def pmc_passes(args, W, H):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def level0_kernel_name(names):
+    """The level-0 resident kernel among rocprofv3's kernel names: `k_gn_level<ICP = true, RGB = true, P, EXIT>` with the largest P
+    (pixels per thread: 3 at 640x480, levels 1 / 2 run P = 1)."""
+    import re
+
+    best, best_p = None, -1
+    for n in names:
+        m = re.search(r"k_gn_level<\s*true,\s*true,\s*(\d+)", n)
+        if m and int(m.group(1)) > best_p:
+            best, best_p = n, int(m.group(1))
+    return best
 
 
 def algorithmic_bytes(kernel, W, H, M, level_px):
@@ -579,6 +602,18 @@ def main():
             }
             if pmc:
                 out["roofline"]["traffic_source"] = pmc.get("source")
+                out["roofline"]["traffic_kernel"] = pmc.get("kernel")
+                # the figure must reproduce from profiles/: compare with the committed stand-alone PMC record of the same kernel
+                # (scripts/collect_profiles.sh writes it) and say so loudly when it does not
+                exp_path = os.path.join(ROOT, "profiles", "level0_pmc_expected.json")
+                if (W, H) == (640, 480) and os.path.exists(exp_path):
+                    exp = json.load(open(exp_path))
+                    dev_ = pmc["hbm_bytes_per_launch"] / exp["hbm_bytes_per_launch"] - 1.0
+                    out["roofline"]["traffic_vs_profiles"] = {"expected": exp["hbm_bytes_per_launch"], "source": exp.get("source"), "deviation": round(dev_, 4),
+                                                              "consistent": abs(dev_) <= 0.10}
+                    if abs(dev_) > 0.10:
+                        print("bench.py: WARNING: roofline.traffic %.2f MB deviates %.0f %% from profiles/ (%s: %.2f MB)"
+                              % (pmc["hbm_bytes_per_launch"] / 1e6, 100 * dev_, exp.get("source"), exp["hbm_bytes_per_launch"] / 1e6), file=sys.stderr)
                 if pmc.get("valu_insts_per_launch"):
                     # second roof of the same kernel: vector-instruction issue.  One VALU per SIMD; ACTIVE_INST_VALU counts the
                     # quad-cycles in which a wave executed a vector instruction, summed over the launch's waves.
