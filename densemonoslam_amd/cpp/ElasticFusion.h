@@ -84,6 +84,9 @@ struct FrontEndOptions {
   float depth = 3.f;                   // Options::get().depth (--d): ReferenceFrame's fern database is built with depth * 1000 (ReferenceFrame.h:17)
   float interMapPhotoThresh = 115.f;   // Options::get().interMapPhotoThresh
   float fernThresh = 0.3095f;          // Options::get().fernThresh (ReferenceFrame.h:125)
+  float covThresh = 1e-05f;            // Options::get().covThresh / icpErrThresh / icpCountThresh (Options.h:91-94): the acceptance test of
+  float icpErrThresh = 2e-05f;         // ReferenceFrame::resolveRelativeTransformationFern (ReferenceFrame.h:98-110)
+  int icpCountThresh = 35000;
   static FrontEndOptions& get() {
     static FrontEndOptions o;
     return o;
@@ -117,6 +120,22 @@ class ContextT {
     if (fusion && dms_fusion_compute_feedback(fusion, nullptr) != DMS_OK) throw std::runtime_error(dms_last_error());
   }
   bool& lost() { return m_lost; }
+  // Context::fillIn() (Context.h; FillIn.h:33-35: vertexTexture / normalTexture / imageTexture): views of the context's fill-in
+  // images in HBM, what the inter-map block hands to resolveRelativeTransformationFern (ElasticFusion.cpp:601-603)
+  struct FillInTextures {
+    DeviceTexture imageTexture, vertexTexture, normalTexture;
+    FillInTextures(const dms_image2d& i, const dms_image2d& v, const dms_image2d& n) : imageTexture(i, 4), vertexTexture(v, 16), normalTexture(n, 16) {}
+  };
+  FillInTextures& fillIn() {
+    if (!fusion) throw std::runtime_error("Context::fillIn: the camera has not processed a frame yet");
+    if (!m_fillIn) {
+      dms_image2d i, v, n;
+      if (dms_fusion_get_image(fusion, 13, &i) || dms_fusion_get_image(fusion, 14, &v) || dms_fusion_get_image(fusion, 15, &n))
+        throw std::runtime_error(dms_last_error());
+      m_fillIn.reset(new FillInTextures(i, v, n));
+    }
+    return *m_fillIn;
+  }
   int& numFused() { return m_numFused; }
   const std::string& filename() const { return m_file; }
   const dms_frame_result& lastResult() const { return last; }
@@ -163,6 +182,7 @@ class ContextT {
   Mat4 m_currPose;
   std::vector<std::pair<unsigned long long int, Mat4>> m_poseGraph;
   std::vector<int64_t> m_poseLogTimes;
+  std::unique_ptr<FillInTextures> m_fillIn;
 };
 
 // The deformation graphs stay with the caller (their optimisation is CPU + CHOLMOD, SURVEY 8 "out of scope"); what the reference's
@@ -200,6 +220,44 @@ class ReferenceFrameT {
     }
     return *m_ferns;
   }
+  // ReferenceFrame::resolveRelativeTransformationFern (ReferenceFrame.h:34-110), argument for argument (GPUTexture -> dms::DeviceTexture:
+  // the querying camera's fill-in vertex / normal / colour textures, dense RGBA32F / RGBA32F / RGBA8 on this device): Ferns::findFrame
+  // with interMap = true on this frame's database, then the full-resolution refinement against an INACTIVE prediction of this frame's
+  // map (dms_refframe_refine = m_index + m_rgbd) and the acceptance test on covariance / lastICPError / lastICPCount.
+  // `constraints` receives rows {worldRawPoint xyz1 | worldModelPoint xyz1} (Ferns::SurfaceConstraint).
+  bool resolveRelativeTransformationFern(std::vector<float>& constraints, Mat4& relativeTransform, Mat4& currPose, DeviceTexture& vertexTexture,
+                                         DeviceTexture& normalTexture, DeviceTexture& imageTexture, const int& tick, const bool lost,
+                                         const int depthCutoff, const float& confidenceThreshold, const int& timeIdx, const int& timeDelta,
+                                         const int& maxTime) {
+    Context* owner = founder();
+    if (!owner || !owner->fusion) throw std::runtime_error("resolveRelativeTransformationFern: this frame has no map yet");
+    float cur[16];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) cur[r * 4 + c] = currPose(r, c);
+    const dms_fern_match m = ferns().findFrame(constraints, cur, &vertexTexture, &normalTexture, &imageTexture, tick, lost, true);
+    if (ferns().lastClosest == -1) return false;  // :66
+    if (!m_refine) {
+      const Resolution& rs = Resolution::getInstance();
+      const Intrinsics& k = Intrinsics::getInstance();
+      check(dms_refframe_create(&m_refine, rs.width(), rs.height(), k.cx(), k.cy(), k.fx(), k.fy()), "dms_refframe_create");
+    }
+    const FrontEndOptions& o = FrontEndOptions::get();
+    dms_intermap_result res;
+    check(dms_refframe_refine(m_refine, dms_fusion_model(owner->fusion), m.estPose, cur, (const float*)vertexTexture.ptr,
+                              (const float*)normalTexture.ptr, imageTexture.ptr, depthCutoff, confidenceThreshold, timeIdx, timeDelta, maxTime,
+                              o.covThresh, o.icpErrThresh, (float)o.icpCountThresh, &res, nullptr),
+          "resolveRelativeTransformationFern");
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) relativeTransform(r, c) = res.relativeTransform[r * 4 + c];
+    lastInterMap = res;
+    return res.accepted != 0;
+  }
+  dms_intermap_result lastInterMap{};  // side outputs of the last refinement (covariance diagonal, error, count, iterations)
+  ~ReferenceFrameT() {
+    if (m_refine) dms_refframe_destroy(m_refine);
+  }
+  ReferenceFrameT() = default;
+  ReferenceFrameT(const ReferenceFrameT&) = delete;
   // ReferenceFrame::consumeReferenceFrame (ReferenceFrame.h:121-150): this frame's map consumes `other`'s moved by relativeTransform,
   // the key-frame databases merge, and other's cameras move over - currPose and pose graph re-based - to fuse into this map from now on
   void consumeReferenceFrame(ReferenceFrameT& other, Mat4 relativeTransform) {
@@ -245,6 +303,7 @@ class ReferenceFrameT {
   std::map<std::string, std::shared_ptr<Context>> m_contexts;
   Deformation m_globalDeformation, m_localDeformation;
   std::unique_ptr<Ferns> m_ferns;
+  dms_refframe* m_refine = nullptr;  // m_index + m_rgbd (ReferenceFrame.h:203-214)
   bool m_firstRun = true;
 };
 

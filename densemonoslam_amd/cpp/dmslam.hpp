@@ -38,7 +38,12 @@ class DeviceTexture {
     view.rows = height;
     view.cols = width;
   }
-  ~DeviceTexture() { dms_device_free(ptr); }
+  // a view of an image the library owns (a context's fill-in / prediction textures, dms_fusion_get_image): nothing is allocated or freed
+  DeviceTexture(const dms_image2d& existing, size_t elemBytes)
+      : ptr(existing.data), view(existing), width(existing.cols), height(existing.rows), elem(elemBytes), owned(false) {}
+  ~DeviceTexture() {
+    if (owned) dms_device_free(ptr);
+  }
   DeviceTexture(const DeviceTexture&) = delete;
   DeviceTexture& operator=(const DeviceTexture&) = delete;
   // GPUTexture::texture->Upload(ptr, format, type) (ElasticFusion.cpp:111-114, GPUTest.cpp:39,59)
@@ -49,6 +54,7 @@ class DeviceTexture {
   dms_image2d view;
   const int width, height;
   const size_t elem;
+  const bool owned = true;
 };
 
 class RGBDOdometry {

@@ -672,6 +672,15 @@ void dms_fusion_default_params(dms_fusion_params* p, int width, int height, floa
   p->hybrid_loops = 0;
 }
 
+// far depth cut-offs raise the static exponents of the trackers' first reductions (canon.hpp): set at creation and whenever the
+// cut-off changes, in a field of its own beside the "exp_bias" test hook
+static int set_depth_bias(dms_fusion* f) {
+  const int b = canon::depth_exp_bias(f->p.depthCut);
+  int rc = dms_odometry_debug_set(f->odom, "depth_exp_bias", b);
+  if (!rc && f->odom_m2m) rc = dms_odometry_debug_set(f->odom_m2m, "depth_exp_bias", b);
+  return rc;
+}
+
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   DMS_REQUIRE(out && p, "null argument");
   DMS_REQUIRE(p->width >= 40 && p->height >= 40, "resolution too small");
@@ -705,6 +714,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   }
   rc = odometry_enable_ring(f->odom);
   if (!rc && p->local_loop_closure) rc = dms_odometry_create(&f->odom_m2m, p->width, p->height, p->cx, p->cy, p->fx, p->fy, 0.f, 0.f);
+  if (!rc) rc = set_depth_bias(f);
   if (!rc && f->odom_m2m) odometry_set_early_exit(f->odom_m2m, 1);  // its INACTIVE side is empty on most frames
   if (rc) {
     dms_odometry_destroy(f->odom);
@@ -798,6 +808,7 @@ int dms_fusion_destroy(dms_fusion* f) {
   if (f->odom_m2m) dms_odometry_destroy(f->odom_m2m);
   dms_odometry_destroy(f->odom);
   dms_model* const own = f->own_model ? f->own_model : f->model;
+  if (f->model && f->model != own) f->model->sharers -= 1;  // (a joined camera: the map's owner outlives it, dmslam_fusion.h)
   for (auto& kv : f->clusters)
     if (kv.second && kv.second != own) dms_model_destroy(kv.second);
   dms_model_destroy(own);
@@ -1098,7 +1109,6 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       }
       {
         FTimer t(f, s, "track");
-        (void)dms_odometry_debug_set(f->odom, "exp_bias", canon::depth_exp_bias(f->p.depthCut));  // (canon.hpp: far depth cut-offs)
         if ((rc = odometry_track_enqueue(f->odom, nullptr, nullptr, f->state->cur.pose, f->p.rgbOnly, f->p.icpWeight, f->p.pyramid,
                                          f->p.fastOdom, f->p.so3, 0, s, f->state, weightMultiplier)))
           return rc;
@@ -1163,7 +1173,6 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       }
       {
         FTimer t(f, s, "loop_track");  // getIncrementalTransformation(trans, rot, false, 10, pyramid, fastOdom, false) (:424-425)
-        (void)dms_odometry_debug_set(f->odom_m2m, "exp_bias", canon::depth_exp_bias(f->p.depthCut));
         if ((rc = odometry_track_enqueue(f->odom_m2m, nullptr, nullptr, f->state->cur.pose, 0, 10.f, f->p.pyramid, f->p.fastOdom, 0, 0, s,
                                          nullptr, 1.f)))
           return rc;
@@ -1513,23 +1522,32 @@ static int share_model(dms_fusion* f, dms_fusion* owner) {
   DMS_REQUIRE(f && owner && f != owner, "bad argument");
   DMS_REQUIRE(!f->in_frame && !owner->in_frame && !f->in_global_loop && !owner->in_global_loop, "inside a frame");
   DMS_REQUIRE(f->p.width == owner->p.width && f->p.height == owner->p.height, "cameras of different resolution (the reference shares one Resolution singleton)");
-  DMS_REQUIRE(f->model == f->own_model, "this camera has already joined a map");
+  DMS_REQUIRE(f->model != owner->model, "this camera already tracks against the consuming map");
   DMS_REQUIRE(owner->map_initialised, "the consuming map is empty");
   DMS_REQUIRE(f->p.timeIdx != owner->p.timeIdx, "both cameras use the same time slot (timeIdx = Context::id())");
   DMS_REQUIRE(f->p.timeIdx < owner->model->num_sensors && f->p.timeIdx < DMS_MAX_SENSORS, "the consuming map has no time slot for this camera (num_sensors)");
   return DMS_OK;
 }
 
+// ReferenceFrame::consumeReferenceFrame moves EVERY camera of the consumed frame (ReferenceFrame.h:127-145).  The camera whose own
+// map is the consumed frame's (f->model == f->own_model: the founder) carries the surfels over; a camera that had joined that map
+// earlier, or was imported into it (f->model != f->own_model: a chained merge), only moves: pose re-based, sharer counts, map
+// pointer.  The order in which a frame's cameras are handed over does not matter.
 int dms_fusion_join_map(dms_fusion* f, dms_fusion* owner, const float* relativeTransform16, dms_stream st) {
   int rc = share_model(f, owner);
   if (rc) return rc;
-  DMS_REQUIRE(relativeTransform16 && f->map_initialised, "join_map: a camera with a map of its own and the transform into the consuming map");
+  const bool founder = f->model == f->own_model;
+  DMS_REQUIRE(relativeTransform16, "join_map: the transform into the consuming map");
+  DMS_REQUIRE(!founder || f->map_initialised, "join_map: a camera with a map of its own");
+  DMS_REQUIRE(!f->adopting, "join_map: an imported camera's seeding frame is still pending");
   hipStream_t s = (hipStream_t)st;
   DMS_HIP(hipStreamSynchronize(s));
   if (f->p.pipeline_ingest) DMS_HIP(hipStreamSynchronize(f->s_prep));
-  // m_localModel.consume(other.globalModel().model(), relativeTransform) (ReferenceFrame.h:124)
-  if ((rc = model_flush_pending(f->model, s))) return rc;
-  if ((rc = dms_model_consume(owner->model, f->model, relativeTransform16, st))) return rc;
+  if (founder) {
+    // m_localModel.consume(other.globalModel().model(), relativeTransform) (ReferenceFrame.h:124)
+    if ((rc = model_flush_pending(f->model, s))) return rc;
+    if ((rc = dms_model_consume(owner->model, f->model, relativeTransform16, st))) return rc;
+  }
   // kv.second->currPose() = relativeTransform * kv.second->currPose() (:131); the next frame's lastPose is read from it (:158)
   float cur[16];
   Pose16 np;
@@ -1537,10 +1555,14 @@ int dms_fusion_join_map(dms_fusion* f, dms_fusion* owner, const float* relativeT
   sm::mul44_host(relativeTransform16, cur, np.v);
   hipLaunchKernelGGL(k_pose_override, dim3(1), dim3(64), 0, s, f->state, np);
   DMS_CHECK_LAUNCH();
+  // a projection rendered ahead for the next frame (share_projection) is of the map this camera leaves: its keys are surfel
+  // indices of that map.  predict() only clears zbuf2 while pre_valid is set, so clear it here before dropping the flag.
+  if (f->pre_valid && (rc = clear_zbuf(f->zbuf2, f->p.width * f->p.height, s))) return rc;
+  f->pre_valid = false;
+  if (!founder) f->model->sharers -= 1;  // leaves the map it had joined (that map's founder carries the surfels)
   f->model = owner->model;
   f->model->sharers += 1;
   f->model->count_hold = 3;
-  f->pre_valid = false;
   DMS_HIP(hipStreamSynchronize(s));
   return DMS_OK;
 }
@@ -1619,6 +1641,7 @@ int dms_fusion_set_option(dms_fusion* f, int option, double value) {
     case DMS_OPT_DEPTH_CUTOFF:
       DMS_REQUIRE(value > 0.0, "depth cut-off must be positive");
       f->p.depthCut = (float)value;
+      set_depth_bias(f);
       break;
     case DMS_OPT_NID_THRESHOLD: f->p.nid_threshold = (float)value; break;
     case DMS_OPT_NID_DEPTH_LAMBDA: f->p.nid_depth_lambda = (float)value; break;

@@ -241,32 +241,45 @@ int depth_bilateral(const dms_image2d* src, dms_image2d* dst, float maxD, hipStr
     ep.cam.cy = cam_l0->cy;
     ep.vmap_cutoff = vmap_cutoff;
   }
-  {  // the weight table, once per device (the first call waits for it, so that any stream may read it afterwards)
-    static std::once_flag built[64];
+  {  // the weight table, once per device (the first call waits for it, so that any stream may read it afterwards); marked built
+     // only when the build succeeded: a failed first call is repeated by the next one instead of leaving a zero table behind
+    static std::mutex mu;
+    static bool built[64];
     int dev = 0;
     DMS_HIP(hipGetDevice(&dev));
     DMS_REQUIRE(dev >= 0 && dev < 64, "device index");
-    hipError_t e = hipSuccess;
-    std::call_once(built[dev], [&] {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!built[dev]) {
       hipLaunchKernelGGL(k_bilateral_lut_build, dim3(44), dim3(256), 0, s);
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-    });
-    DMS_HIP(e);
+      DMS_HIP(hipGetLastError());
+      DMS_HIP(hipStreamSynchronize(s));
+      built[dev] = true;
+    }
   }
   constexpr int WBY = 10;  // whole-chip form: 64 x 10 tiles, 640 threads, two blocks per compute unit (8 / 16 / 5 rows: 26 / 34 / 35 us against 24)
   if (narrow_blocks > 0) {  // a few 1 024-thread blocks that keep to their compute units (see the kernel)
     // ... and to themselves: the launch asks for the rest of the unit's 160 KB of LDS, so no other block — a resident tracker
     // block above all, which would then run at the pace of a shared unit and hold the whole grid's all-reduces back — is placed
     // beside a filter block (2100 against 2340 frames/s in the driver's form without it)
+    // (the unit's LDS from the device, not from gfx950's data sheet; a part with less LDS than the static size just gets no pad)
     static const int pad = [] {
       hipFuncAttributes a;
-      if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_depth_bilateral<16>)) != hipSuccess) return 0;
-      const int rest = 160 * 1024 - (int)a.sharedSizeBytes;
+      int dev = 0, lds_unit = 0, lds_block = 0;
+      if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_depth_bilateral<16>)) != hipSuccess || hipGetDevice(&dev) != hipSuccess) return 0;
+      if (hipDeviceGetAttribute(&lds_unit, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess) lds_unit = 0;
+      if (hipDeviceGetAttribute(&lds_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) lds_block = 0;
+      const int avail = lds_unit > lds_block ? lds_unit : lds_block;  // (what a block may ask for is at most the unit's)
+      const int rest = avail - (int)a.sharedSizeBytes;
       return rest > 0 ? rest : 0;
     }();
-    hipLaunchKernelGGL((k_depth_bilateral<16>), dim3(narrow_blocks), dim3(BX, 16), pad, s, (const unsigned short*)src->data,
+    static bool pad_refused = false;
+    hipLaunchKernelGGL((k_depth_bilateral<16>), dim3(narrow_blocks), dim3(BX, 16), pad_refused ? 0 : pad, s, (const unsigned short*)src->data,
                        (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
+    if (!pad_refused && pad > 0 && hipGetLastError() != hipSuccess) {  // the pad is a placement hint, never a reason to fail
+      pad_refused = true;
+      hipLaunchKernelGGL((k_depth_bilateral<16>), dim3(narrow_blocks), dim3(BX, 16), 0, s, (const unsigned short*)src->data,
+                         (unsigned short*)dst->data, src->cols, src->rows, maxD, ep);
+    }
   } else {
     const int tiles = ((src->cols + BX - 1) / BX) * ((src->rows + WBY - 1) / WBY);
     hipLaunchKernelGGL((k_depth_bilateral<WBY>), dim3(tiles), dim3(BX, WBY), 0, s, (const unsigned short*)src->data,

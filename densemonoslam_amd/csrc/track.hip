@@ -126,6 +126,7 @@ struct dms_odometry {
   // the later the last arrival can be after one's own, the longer the pause pays: ~0.4 us on the 150 / 200-block levels, next to
   // nothing on 38 blocks (measured: level 2 is best at 0 - 8 units, levels 1 and 0 at 12 - 20)
   int first_delay_for(int nb) const { return first_delay >= 0 ? first_delay : (nb >= 96 ? 24 : 8); }
+  int depth_bias = 0;                 // production rule (key "depth_exp_bias"): the frame step's depth cut-off raises the static exponents (canon::depth_exp_bias)
   int exp_bias = 0;                   // test hook (dms_odometry_debug_set "exp_bias"): added to the static exponents of a call's first reductions (negative: they do not fit and are repeated)
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
   TrackState* state = nullptr;
@@ -1746,6 +1747,11 @@ int dms_odometry_debug_set(dms_odometry* o, const char* key, int value) {
     o->exp_bias = value;
     return DMS_OK;
   }
+  if (strcmp(key, "depth_exp_bias") == 0) {  // the frame step's rule, kept apart from the test hook: the two add
+    DMS_REQUIRE(value >= 0 && value <= 100, "depth_exp_bias out of range");
+    o->depth_bias = value;
+    return DMS_OK;
+  }
   DMS_REQUIRE(false, "unknown key");
 }
 
@@ -2191,7 +2197,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
       ex.nb_so3 = nbp;
       hipLaunchKernelGGL(k_so3_level, dim3(nbp + ex.gx * ex.gy), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias, o->first_delay_for(nbp), ex);
+                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbp), ex);
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {
@@ -2200,7 +2206,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
         SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
         hipLaunchKernelGGL(k_so3_pass, dim3(nb), dim3(kBlock), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
                            (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, o->tickets, cam, i, i == 9 ? 1 : 0, first_level,
-                           o->exp_bias);
+                           o->exp_bias + o->depth_bias);
         DMS_CHECK_LAUNCH();
       }
     }
@@ -2261,7 +2267,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     a.rows = o->vmaps_curr[l].rows / 3;
     a.level = l;
     a.rgbOnly = rgbOnly ? 1 : 0;
-    a.exp_bias = o->exp_bias;
+    a.exp_bias = o->exp_bias + o->depth_bias;
     const int nb = track_blocks_for(a.cols * a.rows);
     int level_below = l;
     for (int q = l - 1; q >= 0; --q)

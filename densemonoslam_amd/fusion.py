@@ -118,6 +118,22 @@ lib.dms_fusion_import_camera.argtypes = [_P, _P, C.POINTER(C.c_float), _I, _P, _
 lib.dms_relative_transform.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 lib.dms_pose_compose.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 lib.dms_fusion_set_profiling.argtypes = [_P, _I]
+
+
+class InterMapResult(C.Structure):
+    """dms_intermap_result (include/dmslam_fusion.h)"""
+    _fields_ = [("accepted", C.c_int), ("cov_ok", C.c_int), ("relativeTransform", C.c_float * 16), ("refinedPose", C.c_float * 16),
+                ("cov_diag", C.c_double * 6), ("lastICPError", C.c_float), ("lastICPCount", C.c_float), ("lastRGBError", C.c_float),
+                ("lastRGBCount", C.c_float), ("iterations_run", C.c_int * 3), ("so3_iterations_run", C.c_int)]
+
+
+lib.dms_refframe_create.argtypes = [C.POINTER(_P), _I, _I, _F, _F, _F, _F]
+lib.dms_refframe_destroy.argtypes = [_P]
+lib.dms_refframe_refine.argtypes = [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P, _I, _F, _I, _I, _I, _F, _F, _F,
+                                    C.POINTER(InterMapResult), _P]
+lib.dms_refframe_odometry.argtypes = [_P]
+lib.dms_refframe_odometry.restype = _P
+lib.dms_refframe_get_prediction.argtypes = [_P, C.POINTER(PredictOut)]
 lib.dms_fusion_get_kernel_time.argtypes = [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
 
@@ -564,6 +580,12 @@ class ElasticFusion:
         dt, k = _IMG_TYPES[which]
         return capi.download_view(v, dt, k)
 
+    def imagePtr(self, which):
+        """device pointer of one of the context's dense images (dms_fusion_get_image ids; 13 / 14 / 15 = fill-in colour / vertex / normal)"""
+        v = Image2D()
+        check(lib.dms_fusion_get_image(self.h, which, C.byref(v)), "dms_fusion_get_image")
+        return int(v.data)
+
     def thumbnails(self, block_ptr, stream=None):
         """Pack this frame's W/8 x H/8 fill-in thumbnails [image | vertex | normal] into device memory at block_ptr."""
         check(lib.dms_fusion_thumbnails(self.h, C.c_void_p(block_ptr), stream), "dms_fusion_thumbnails")
@@ -601,3 +623,44 @@ class ElasticFusion:
         ms, n = C.c_double(0), C.c_int(0)
         check(lib.dms_fusion_get_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class ReferenceFrameRefiner:
+    """ReferenceFrame's m_index + m_rgbd and the second half of resolveRelativeTransformationFern (ReferenceFrame.h:66-110):
+    dms_refframe_* (include/dmslam_fusion.h)."""
+
+    def __init__(self, width, height, K):
+        h = C.c_void_p()
+        check(lib.dms_refframe_create(C.byref(h), width, height, float(K[2]), float(K[3]), float(K[0]), float(K[1])), "dms_refframe_create")
+        self.h, self.width, self.height = h, width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.dms_refframe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def refine(self, owner, recoveryPose, currPose, vertex_ptr, normal_ptr, image_ptr, timeIdx, maxTime, covThresh=1e-05, icpErrThresh=2e-05,
+               icpCountThresh=35000, stream=None):
+        """owner: the fusion.ElasticFusion whose map was matched (its maxDepthProcessed - truncated to int like the reference's
+        `const int depthCutoff` -, confidence and timeDelta are the call's); vertex / normal / image: device pointers to the
+        querying camera's dense fill-in textures (RGBA32F, RGBA32F, RGBA8)."""
+        r = InterMapResult()
+        p = owner.params
+        (_ra, rp), (_ca, cp) = _f16(recoveryPose), _f16(currPose)
+        check(lib.dms_refframe_refine(self.h, lib.dms_fusion_model(owner.h), rp, cp, C.c_void_p(vertex_ptr),
+                                      C.c_void_p(normal_ptr), C.c_void_p(image_ptr), int(p.maxDepthProcessed), float(owner.getOption("confidence")),
+                                      int(timeIdx), int(p.timeDelta), int(maxTime), float(covThresh), float(icpErrThresh), float(icpCountThresh),
+                                      C.byref(r), stream), "dms_refframe_refine")
+        return r
+
+    def prediction(self):
+        """the INACTIVE prediction of the last refinement: (image u8 HxWx4, vertex f32 HxWx4, normal f32 HxWx4)"""
+        v = PredictOut()
+        check(lib.dms_refframe_get_prediction(self.h, C.byref(v)), "dms_refframe_get_prediction")
+        return capi.download_view(v.image, np.uint8, 4), capi.download_view(v.vertex, np.float32, 4), capi.download_view(v.normal, np.float32, 4)

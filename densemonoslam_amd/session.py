@@ -19,8 +19,13 @@ frame's rank.  Per tick, on every rank, `CollabSession.step`:
   4. query     owner computes: for every reference frame hosted here and every camera of another frame, Ferns::findFrame with
                interMap = true on the gathered thumbnails (search, code agreement, thumbnail-sized ICP + photometric check);
                the (closest, recoveryPose) table is all-gathered (18 floats per pair);
-  5. decide    every rank applies the reference's sequential rule to the same table - cameras in id order, reference frames in
-               id order, first verified match wins, at most one merge per frame and tick - so all ranks agree without a vote;
+  5. decide    every rank walks the same table in the reference's sequential order - cameras in id order, reference frames in
+               id order.  A fern match is a CANDIDATE: the owner of the matched map runs the second half of
+               ReferenceFrame::resolveRelativeTransformationFern (ReferenceFrame.h:72-110, dms_refframe_refine: INACTIVE prediction
+               of its map at recoveryPose, full-resolution ICP + RGB refinement against the querying camera's fill-in textures,
+               acceptance on covariance / error / count).  If the camera lives on another rank its three fill-in textures travel
+               point to point first (36 B per pixel, 11 MB at 640 x 480 - on a candidate only); the owner broadcasts
+               {accepted, relativeTransform} (17 floats).  First accepted candidate wins, at most one merge per frame and tick;
   6. merge     relativeTransform = recoveryPose * currPose.inverse() (ReferenceFrame.h:98).  Same rank: the consuming map
                consumes the other (dms_fusion_join_map), fern databases merge (dms_ferns_consume).  Across ranks: the consumed
                frame's rank sends, point to point, its surfel records, its key-frame records and per camera {pose, tick, last
@@ -35,11 +40,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+DMS_MAX_SENSORS = 8  # include/dmslam.h: time slots of a map = cameras it can hold (one per GPU of the node)
 META_BYTES = 80  # per published block: camera id i32 | tick i32 | 2 x pad | pose 16 x f32
 
 
 class CollabSession:
-    def __init__(self, backend, n_cameras, width, height, rank=0, world=1, device=None, fern_threshold=0.3095, inter_map=1, query_from=0):
+    def __init__(self, backend, n_cameras, width, height, rank=0, world=1, device=None, fern_threshold=0.3095, inter_map=1, query_from=0,
+                 full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05, icp_count_thresh=35000):
         self.be, self.n, self.W, self.H = backend, n_cameras, width, height
         self.rank, self.world = rank, world
         self.device = device or torch.device("cpu")
@@ -58,6 +65,15 @@ class CollabSession:
                 self.ferns[c] = backend.make_ferns()
         self.block_bytes = backend.block_bytes() + META_BYTES
         self.merges, self.matches = [], []
+        # second half of resolveRelativeTransformationFern: one refiner (m_index + m_rgbd) per hosted reference frame, created on
+        # first use; Options::covThresh / icpErrThresh / icpCountThresh (Options.h:91-94)
+        self.full_refine = full_refine
+        self.thresholds = (cov_thresh, icp_err_thresh, icp_count_thresh)
+        self.refiners = {}
+        self.refinements = []  # (tick index, camera, frame, accepted) - the same list on every rank
+        limit = getattr(backend, "num_sensors", None)
+        if limit is not None and n_cameras > limit:
+            raise ValueError("%d cameras but the maps have %d time slots (num_sensors): a merge would fail at join / import" % (n_cameras, limit))
 
     # ---- helpers -------------------------------------------------------------------------------------------------------------
     def host_of_camera(self, c):
@@ -117,7 +133,8 @@ class CollabSession:
             cam = self.cams[c]
             blk = cam.thumbnails()
             pose, tick = cam.pose(), cam.tick()
-            self.ferns[self.frame_of[c]].addBlock(blk, pose, tick, self.fern_threshold)
+            if not cam.lost():  # processFerns sits under `if (!lost)` (ElasticFusion.cpp:588-591)
+                self.ferns[self.frame_of[c]].addBlock(blk, pose, tick, self.fern_threshold)
             local[i, :len(blk)] = blk
             meta = np.zeros(META_BYTES // 4, np.float32)
             meta[:2] = np.array([c, tick], np.int32).view(np.float32)
@@ -131,19 +148,29 @@ class CollabSession:
                 meta = raw[self.block_bytes - META_BYTES:].view(np.float32)
                 c, tick = (int(v) for v in meta[:2].view(np.int32))
                 blocks[c] = (raw[:self.block_bytes - META_BYTES], meta[4:20].reshape(4, 4).copy(), tick)
-        # 4. owner computes: every hosted reference frame against every camera of another frame
-        table = np.zeros((self.n, self.n, 18), np.float32)  # [camera a][frame fb] = valid, closest, recoveryPose
-        for fb in sorted(self.ferns):
-            for a in range(self.n):
-                if self.frame_of[a] == fb or k < self.query_from:
-                    continue
-                blk, pose, tick = blocks[a]
-                closest, cand, est = self.ferns[fb].findFrameThumbs(blk, pose, tick, self.inter_map)
-                table[a, fb, 0], table[a, fb, 1] = 1.0, float(closest)
-                table[a, fb, 2:] = np.asarray(est, np.float32).reshape(16)
-                self.matches.append((k, a, fb, closest, cand))
-        tables = self._allgather(table.reshape(-1).view(np.uint8)).view(np.float32).reshape(self.world, self.n, self.n, 18)
-        # 5. the same decision on every rank (oracle/orc_pipeline.Session.step: cameras in id order, frames in id order)
+        # 4. owner computes: every hosted reference frame against every camera of another frame.  A failure on one rank must not
+        # leave the others waiting in the next collective: it travels in the table's last row and every rank raises together.
+        table = np.zeros((self.n + 1, self.n, 18), np.float32)  # [camera a][frame fb] = valid, closest, recoveryPose; [n][0][0] = error flag
+        failure = None
+        try:
+            for fb in sorted(self.ferns):
+                for a in range(self.n):
+                    if self.frame_of[a] == fb or k < self.query_from:
+                        continue
+                    blk, pose, tick = blocks[a]
+                    closest, cand, est = self.ferns[fb].findFrameThumbs(blk, pose, tick, self.inter_map)
+                    table[a, fb, 0], table[a, fb, 1] = 1.0, float(closest)
+                    table[a, fb, 2:] = np.asarray(est, np.float32).reshape(16)
+                    self.matches.append((k, a, fb, closest, cand))
+        except Exception as e:  # noqa: BLE001 (re-raised below, on every rank)
+            failure = e
+            table[self.n, 0, 0] = 1.0
+        del self.matches[:-4096]
+        tables = self._allgather(table.reshape(-1).view(np.uint8)).view(np.float32).reshape(self.world, self.n + 1, self.n, 18)
+        if tables[:, self.n, 0, 0].any():
+            bad = [r for r in range(self.world) if tables[r, self.n, 0, 0]]
+            raise RuntimeError("inter-map query failed on rank(s) %s at tick %d" % (bad, k)) from failure
+        # 5. the same walk on every rank (oracle/orc_pipeline.Session.step: cameras in id order, frames in id order)
         decided, busy = [], set()
         for a in range(self.n):
             fa = self.frame_of[a]
@@ -153,10 +180,18 @@ class CollabSession:
                 if fb == fa or fb in busy:
                     continue
                 e = tables[self.host_of_frame[fb], a, fb]
-                assert e[0] == 1.0, "no verification result for camera %d against frame %d" % (a, fb)
+                if e[0] != 1.0:
+                    raise RuntimeError("no verification result for camera %d against frame %d" % (a, fb))
                 if e[1] < 0:
                     continue
-                T = self.be.relative_transform(e[2:].reshape(4, 4), blocks[a][1])
+                rec = e[2:].reshape(4, 4)
+                if self.full_refine:
+                    accepted, T = self._refine(k, a, fb, rec, blocks[a][1], blocks[a][2])
+                    self.refinements.append((k, a, fb, accepted))
+                    if not accepted:
+                        continue
+                else:
+                    T = self.be.relative_transform(rec, blocks[a][1])
                 decided.append((fb, fa, T))
                 busy.update((fa, fb))
                 break
@@ -164,6 +199,33 @@ class CollabSession:
         for fb, fa, T in decided:
             self._merge(k, fb, fa, T)
         return out
+
+    def _refine(self, k, a, fb, recoveryPose, currPose, tick):
+        """ReferenceFrame::resolveRelativeTransformationFern's second half for camera a against frame fb, on fb's rank; every rank
+        returns the same (accepted, relativeTransform)."""
+        ha, hb = self.host_of_camera(a), self.host_of_frame[fb]
+        res = np.zeros(17, np.float32)
+        if hb == self.rank:
+            owner = self.cams[next(c for c in self.hosted() if self.frame_of[c] == fb)]
+            if fb not in self.refiners:
+                self.refiners[fb] = self.be.make_refiner()
+            if ha == self.rank:
+                r = self.refiners[fb].refineLocal(owner, self.cams[a], recoveryPose, self.thresholds)
+            else:
+                img = self._recv(ha, np.uint8, (self.H, self.W, 4))
+                vtx = self._recv(ha, np.float32, (self.H, self.W, 4))
+                nrm = self._recv(ha, np.float32, (self.H, self.W, 4))
+                r = self.refiners[fb].refineRemote(owner, (img, vtx, nrm), a, tick, currPose, recoveryPose, self.thresholds)
+            res[0] = 1.0 if r[0] else 0.0
+            res[1:] = np.asarray(r[1], np.float32).reshape(16)
+        elif ha == self.rank:
+            for t in self.cams[a].fillTextures():
+                self._send(t, hb)
+        if self.world > 1:
+            t = self._t(res)
+            dist.broadcast(t, hb)
+            res = t.cpu().numpy()
+        return bool(res[0] == 1.0), res[1:].reshape(4, 4).copy()
 
     def _allgather(self, local_u8):
         if self.world == 1:
@@ -238,6 +300,8 @@ class CollabSession:
                 self._rebase(c, T)
         for c in moving:
             self.frame_of[c] = fb
+        if fa in self.refiners:  # (the consumed reference frame is erased, ElasticFusion.cpp:610-616)
+            self.refiners.pop(fa).close()
         del self.host_of_frame[fa]
         self.merges.append((k, fb, fa, np.asarray(T, np.float32).copy()))
 
@@ -249,6 +313,8 @@ class CollabSession:
             self.cams.pop(c).close()
         for f in list(self.ferns):
             self.ferns.pop(f).close()
+        for f in list(self.refiners):
+            self.refiners.pop(f).close()
 
 
 # ---- the product behind the session's call surface ------------------------------------------------------------------------------
@@ -274,10 +340,17 @@ class _GpuCamera:
     def pose(self):
         return self._pose
 
+    def lost(self):
+        return bool(self._last.lost) if self._last is not None else False
+
     def thumbnails(self):
         self.ef.thumbnails(self._block.data_ptr(), None)
         torch.cuda.synchronize(self.be.device)
         return self._block.cpu().numpy()
+
+    def fillTextures(self):
+        """(image u8 HxWx4, vertex f32 HxWx4, normal f32 HxWx4) of the last frame's fill-in, as host arrays for the transport"""
+        return self.ef.image(13), self.ef.image(14), self.ef.image(15)
 
     def joinMap(self, owner, T):
         self.ef.joinMap(owner.ef, T)
@@ -302,6 +375,33 @@ class _GpuCamera:
 
     def close(self):
         self.ef.close()
+
+
+class _GpuRefiner:
+    """dms_refframe (ReferenceFrame's m_index + m_rgbd) behind the session's call surface"""
+
+    def __init__(self, be):
+        from . import fusion
+
+        self.be = be
+        self.rf = fusion.ReferenceFrameRefiner(be.W, be.H, be.K)
+
+    def _result(self, r):
+        return bool(r.accepted), np.array(r.relativeTransform, np.float32).reshape(4, 4)
+
+    def refineLocal(self, owner, cam, recoveryPose, thresholds):
+        e = cam.ef
+        return self._result(self.rf.refine(owner.ef, recoveryPose, cam.pose(), e.imagePtr(14), e.imagePtr(15), e.imagePtr(13), cam.c, cam.tick(),
+                                           *thresholds))
+
+    def refineRemote(self, owner, textures, timeIdx, tick, currPose, recoveryPose, thresholds):
+        img, vtx, nrm = (torch.from_numpy(np.ascontiguousarray(t)).to(self.be.device) for t in textures)
+        r = self.rf.refine(owner.ef, recoveryPose, currPose, vtx.data_ptr(), nrm.data_ptr(), img.data_ptr(), timeIdx, tick, *thresholds)
+        torch.cuda.synchronize(self.be.device)
+        return self._result(r)
+
+    def close(self):
+        self.rf.close()
 
 
 class _GpuFerns:
@@ -350,7 +450,7 @@ class _GpuFerns:
 class GpuBackend:
     """fusion.ElasticFusion + ferns.Ferns (HBM) behind CollabSession."""
 
-    def __init__(self, width, height, K, device, num_sensors=3, fern_opts=None, **opts):
+    def __init__(self, width, height, K, device, num_sensors=DMS_MAX_SENSORS, fern_opts=None, **opts):
         from . import collab
 
         self.W, self.H, self.K, self.device, self.num_sensors, self.opts = width, height, K, device, num_sensors, opts
@@ -366,6 +466,9 @@ class GpuBackend:
 
     def make_ferns(self):
         return _GpuFerns(self)
+
+    def make_refiner(self):
+        return _GpuRefiner(self)
 
     def relative_transform(self, recoveryPose, currPose):
         from . import fusion

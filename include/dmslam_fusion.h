@@ -342,6 +342,39 @@ int dms_fusion_import_camera(dms_fusion* f, dms_fusion* owner, const float* pose
 int dms_relative_transform(const float* recoveryPose16, const float* currPose16, float* out16);
 int dms_pose_compose(const float* a16, const float* b16, float* out16);
 
+/* The reference frame's own IndexMap + RGBDOdometry (ReferenceFrame.h:203-214: m_index, m_rgbd) and the second half of
+ * ReferenceFrame::resolveRelativeTransformationFern (ReferenceFrame.h:66-110), run by the OWNER of the queried map after
+ * Ferns::findFrame(..., interMap = true) (dms_ferns_find_frame[_thumbs], dmslam_ferns.h) returned a recoveryPose for a camera of
+ * another map: INACTIVE prediction of `map` at recoveryPose (time 0, the querying camera's time slot `timeIdx`, maxTime = its tick,
+ * :72-80), tracker initialised from that prediction (model side) and the querying camera's fill-in vertex / normal / colour textures
+ * (live side: dense W x H RGBA32F, RGBA32F, RGBA8 in this device's HBM - dms_fusion_get_image 14 / 15 / 13 on the same device, one
+ * point-to-point transfer from the camera's rank otherwise), getIncrementalTransformation(t, r, false, 10, true, false, true, true)
+ * (:88-90: SO3 + 3 x 50 ICP + RGB iterations), relativeTransform = refined pose * currPose^-1 (:95), accepted when every covariance
+ * diagonal <= covThresh, lastICPError < icpErrThresh and lastICPCount > icpCountThresh (:98-110; Options.h:91-94 defaults 1e-5, 2e-5,
+ * 35000).  depthCutoff is an int as in the reference's signature (:42: maxDepthProcessed truncated).  The tracker keeps its state
+ * between calls like m_rgbd does (the SO3 pre-alignment compares with the previous refinement's live image).  Two readings of the
+ * compiled-out reference block are stated in csrc/refframe.hip (the model colour image; the first call's lastNextImage).
+ * Synchronises (the acceptance test is host arithmetic on the tracker's result, as in the reference). */
+typedef struct dms_refframe dms_refframe;
+typedef struct dms_intermap_result {
+  int accepted; /* the function's return value in the reference */
+  int cov_ok;
+  float relativeTransform[16]; /* row-major */
+  float refinedPose[16];       /* recoveryPose after the refinement */
+  double cov_diag[6];
+  float lastICPError, lastICPCount, lastRGBError, lastRGBCount;
+  int iterations_run[DMS_NUM_PYRS];
+  int so3_iterations_run;
+} dms_intermap_result;
+int dms_refframe_create(dms_refframe** out, int width, int height, float cx, float cy, float fx, float fy);
+int dms_refframe_destroy(dms_refframe* r);
+int dms_refframe_refine(dms_refframe* r, dms_model* map, const float* recoveryPose16, const float* currPose16, const float* vertex_dev,
+                        const float* normal_dev, const void* image_rgba_dev, int depthCutoff, float confidenceThreshold, int timeIdx,
+                        int timeDelta, int maxTime, float covThresh, float icpErrThresh, float icpCountThresh, dms_intermap_result* out,
+                        dms_stream s);
+dms_odometry* dms_refframe_odometry(dms_refframe* r);                        /* m_rgbd (tests, profiling) */
+int dms_refframe_get_prediction(dms_refframe* r, dms_predict_out* view);     /* m_index's INACTIVE targets of the last refinement */
+
 /* ElasticFusion::predict(context, rf[, confidence]) (ElasticFusion.h:107-108, ElasticFusion.cpp:688-746): the ACTIVE model view at the
  * camera's current pose + fill-in, into the prediction / fill-in images (dms_fusion_get_image 9-15) - what the GUI loop calls for a
  * paused camera (MainController.cpp:398).  confidence < 0: the context's confidence threshold.  Outside a frame. */

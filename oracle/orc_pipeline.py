@@ -332,6 +332,32 @@ class ElasticFusion:
         return out
 
 
+def refine_inter_map(owner, o, fill, timeIdx, tick, currPose, recoveryPose, cov_thresh=1e-05, icp_err_thresh=2e-05, icp_count_thresh=35000):
+    """ReferenceFrame::resolveRelativeTransformationFern after findFrame (ReferenceFrame.h:72-110).  owner: the ElasticFusion whose
+    map was matched; o: the reference frame's m_rgbd (an orc.Odometry that persists between calls); fill = (image, vertex, normal),
+    timeIdx, tick, currPose: the querying camera's fill-in textures, Context::id(), tick and pose."""
+    from . import orc_ferns
+
+    rec = np.asarray(recoveryPose, np.float32).reshape(4, 4).copy()
+    cutoff = float(int(owner.maxDepthProcessed))  # `const int depthCutoff` (:42)
+    oimg, ovtx, onrm, _ = orc.splat_predict(owner.model, rec, owner.K, owner.H, owner.W, cutoff, owner.confidence, 0, timeIdx, tick,
+                                            owner.timeDelta, False)  # :72-80
+    fi, fv, fn = fill
+    o.initICPModel(ovtx, onrm, cutoff, rec)  # :82
+    o.initICPMaps(fv, fn, cutoff)  # :83
+    o.initRGBModel(oimg)  # :85 (stated reading: the INACTIVE prediction's image)
+    o.initRGB(fi)  # :86
+    t, R, res = o.getIncrementalTransformation(rec[:3, 3].copy(), rec[:3, :3].copy(), False, 10.0, True, False, True, interMap=True)  # :88-90
+    refined = rec.copy()
+    refined[:3, 3], refined[:3, :3] = t, R
+    T = orc_ferns._mul44(refined, orc.inv4f(np.asarray(currPose, np.float32).reshape(4, 4)))  # :95
+    covar = orc.covariance(np.array(res.lastA))  # :98
+    covOk = not any(covar[i, i] > float(np.float32(cov_thresh)) for i in range(6))  # :101-108 (double against a float option)
+    ok = bool(covOk and res.lastICPError < np.float32(icp_err_thresh) and res.lastICPCount > icp_count_thresh)  # :110
+    return dict(accepted=ok, cov_ok=covOk, relativeTransform=T, refinedPose=refined, cov_diag=[float(covar[i, i]) for i in range(6)],
+                lastICPError=float(res.lastICPError), lastICPCount=float(res.lastICPCount), track=res, old=(oimg, ovtx, onrm))
+
+
 # ---- collaborative session: several cameras, maps that merge (checker of densemonoslam_amd.collab.CollabSession) -----------------
 class Session:
     """The reference's multi-camera loop in ONE process (GUI/src/MainController.cpp:262-400: every camera's processFrame in turn)
@@ -346,13 +372,17 @@ class Session:
       (ReferenceFrame::consumeReferenceFrame, :121-150: surfels, key frames, cameras - pose, pose graph and relative constraints
       re-based), at most one merge per map and tick.
 
-    Differences from the compiled-out reference block, all of them: the verification is the fern database's own (thumbnails) -
-    resolveRelativeTransformationFern's second, full-resolution refinement against an INACTIVE prediction (ReferenceFrame.h:72-90)
-    is not run, because a querying camera on another GPU ships thumbnails, not full-resolution textures; queries run after all
-    cameras of the tick have been processed rather than inside each camera's processFrame."""
+    On a fern match the owner of the matched map runs the second half of resolveRelativeTransformationFern (`refine` below,
+    ReferenceFrame.h:72-110): INACTIVE prediction of its map at recoveryPose, full-resolution ICP + RGB refinement against the
+    querying camera's fill-in textures, relativeTransform from the REFINED pose, acceptance on covariance / error / count.
+
+    Differences from the compiled-out reference block, all of them: queries run after all cameras of the tick have been processed
+    rather than inside each camera's processFrame; two readings of the block's undefined inputs are stated at `refine`;
+    `full_refine = False` stops after the fern database's own verification (rounds 3-4)."""
 
     def __init__(self, n, width, height, K, fern_seed=20260929, fern_threshold=0.3095, fern_num=500, fern_max_depth_mm=3000,
-                 fern_photo_thresh=115.0, inter_map=1, query_from=0, **opts):
+                 fern_photo_thresh=115.0, inter_map=1, query_from=0, full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05,
+                 icp_count_thresh=35000, **opts):
         from . import orc_ferns
 
         self.inter_map = inter_map  # Ferns::findFrame's interMap argument (2: see dmslam_ferns.h)
@@ -369,6 +399,12 @@ class Session:
         self.relative_cons = [[] for _ in range(n)]  # Context::relativeCons(): rows {src xyz, target xyz} the caller's solver produced
         self.merges = []                          # (tick index, consuming frame, consumed frame, relativeTransform)
         self.matches = []
+        # ReferenceFrame::m_rgbd, one per reference frame (created on first use: it keeps its state between refinements);
+        # Options::covThresh / icpErrThresh / icpCountThresh (Options.h:91-94)
+        self.full_refine = full_refine
+        self.cov_thresh, self.icp_err_thresh, self.icp_count_thresh = cov_thresh, icp_err_thresh, icp_count_thresh
+        self.rgbd = {}
+        self.refinements = []                     # (tick index, camera, frame, accepted, result dict)
 
     def thumbs(self, cam):
         from . import orc_ferns
@@ -387,7 +423,9 @@ class Session:
             outs.append(cam.processFrame(frames[i][0], frames[i][1]))
             self.pose_graph[i].append((tick_before, cam.currPose.copy()))
         blocks = [self.thumbs(cam) for cam in self.cams]
-        for i, cam in enumerate(self.cams):  # the own map's database sees every frame of its cameras
+        for i, cam in enumerate(self.cams):  # the own map's database sees every frame of its cameras (processFerns sits under `if (!lost)`, ElasticFusion.cpp:588-591)
+            if cam.lost:
+                continue
             img, v, nrm = blocks[i]
             self.ferns[self.frame_of[i]]._add(img, v, nrm, cam.currPose.copy(), cam.tick, self.fern_threshold)
         busy = set()
@@ -402,12 +440,35 @@ class Session:
                 self.matches.append((k, a, fb, m["closest"], m["candidate"]))
                 if m["closest"] < 0:
                     continue
-                T = orc_ferns._mul44(m["estPose"], orc.inv4f(cam.currPose))
+                if self.full_refine:
+                    r = self.refine(fb, a, m["estPose"])
+                    self.refinements.append((k, a, fb, r["accepted"], r))
+                    if not r["accepted"]:
+                        continue
+                    T = r["relativeTransform"]
+                else:
+                    T = orc_ferns._mul44(m["estPose"], orc.inv4f(cam.currPose))
                 self.consume(fb, fa, T)
                 self.merges.append((k, fb, fa, T.copy()))
                 busy.update((fa, fb))
                 break
         return outs
+
+    def refine(self, fb, a, recoveryPose):
+        """ReferenceFrame::resolveRelativeTransformationFern after findFrame (ReferenceFrame.h:66-110), for camera a against frame fb.
+        Stated readings (the block is compiled out in the reference and was never run): :85 hands initRGBModel `m_index.imageTex()`,
+        the ACTIVE colour target of an IndexMap that only renders INACTIVE - a texture nothing wrote; the INACTIVE prediction's own
+        image is used (as ElasticFusion.cpp:413 does for the model-to-model tracker).  m_rgbd's lastNextImage before its first call
+        is uninitialised device memory there, zeros here.  Kept literally: the call order initICPModel, initICP, initRGBModel,
+        initRGB (:82-86), which makes lastDepth the LIVE camera's depth (populateRGBDData reads vmaps_tmp), and `const int
+        depthCutoff` (:42), which truncates maxDepthProcessed."""
+        owner = next(c for i, c in enumerate(self.cams) if self.frame_of[i] == fb)
+        cam = self.cams[a]
+        if fb not in self.rgbd:
+            Kf = self.K
+            self.rgbd[fb] = orc.Odometry(self.W, self.H, Kf[2], Kf[3], Kf[0], Kf[1])
+        return refine_inter_map(owner, self.rgbd[fb], cam.fill, cam.timeIdx, cam.tick, cam.currPose, recoveryPose, self.cov_thresh,
+                                self.icp_err_thresh, self.icp_count_thresh)
 
     def consume(self, fb, fa, T):
         """reference frame fb consumes fa (ReferenceFrame::consumeReferenceFrame)"""

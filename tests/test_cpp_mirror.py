@@ -412,6 +412,31 @@ int main(int argc, char** argv) {
     eFusion->setNumBinsDepth(250);
     eFusion->nidPyramidLevel() = 1;
     if (eFusion->getTick() == 2) framesToSkip = 1;                        // the frame-skip branch (:290-294)
+    if (eFusion->getTick() == 3 && numMaps == 2) {
+      // the inter-map block of ElasticFusion::processFrame (ElasticFusion.cpp:596-608), call for call: camera b queries the other
+      // reference frame with its fill-in textures.  The frame's key-frame database is given camera a's current frame first
+      // (processFerns, compiled out at :589), so the query has a candidate and reaches the full-resolution refinement.
+      Context& context = *(eFusion->frontend("logs/b.klg"));
+      auto& other = eFusion->whichReferenceFrame(active);
+      float poseA[16];
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) poseA[r * 4 + c] = active.currPose()(r, c);
+      other.ferns().addFrame(&active.fillIn().imageTexture, &active.fillIn().vertexTexture, &active.fillIn().normalTexture, poseA, active.tick(),
+                             dms::FrontEndOptions::get().fernThresh);
+      std::vector<float> constraints;
+      Eigen::Matrix4f relativeTransform;
+      const float maxDepthProcessed = eFusion->getMaxDepthProcessed(), confidenceThreshold = eFusion->getConfidenceThreshold();
+      const int timeDelta = eFusion->getTimeDelta();
+      bool success = other.resolveRelativeTransformationFern(constraints, relativeTransform, context.currPose(), context.fillIn().vertexTexture,
+                                                             context.fillIn().normalTexture, context.fillIn().imageTexture, context.tick(),
+                                                             context.lost(), maxDepthProcessed, confidenceThreshold, context.id(), timeDelta,
+                                                             context.tick());
+      std::printf("inter-map query: closest %d success %d icp error %.3g count %.0f iterations %d %d %d\n", other.ferns().lastClosest, (int)success,
+                  other.lastInterMap.lastICPError, other.lastInterMap.lastICPCount, other.lastInterMap.iterations_run[0],
+                  other.lastInterMap.iterations_run[1], other.lastInterMap.iterations_run[2]);
+      if (other.ferns().lastClosest != -1 && other.lastInterMap.iterations_run[0] != 50) return 21;  // (interMap = true: 50 per level)
+      if (other.ferns().lastClosest == -1 && success) return 22;
+    }
     if (eFusion->getTick() >= 4 && numMaps == 2) {
       // a verified inter-map match (ElasticFusion.cpp:610-627): a's frame consumes b's; the two cameras see the same wall 6 px apart
       Context& b = *(eFusion->frontend("logs/b.klg"));

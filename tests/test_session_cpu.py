@@ -15,23 +15,40 @@ import pytest
 
 W, H = 320, 240
 K = (264.0, 264.0, 160.0, 120.0)
-N_TICKS, QUERY_FROM, OFFSET = 14, 4, 14  # camera 1 runs OFFSET frames ahead of camera 0 on the same trajectory
-SESSION_OPTS = dict(inter_map=2, query_from=QUERY_FROM)
-FERN_PHOTO = 1000.0  # (the colour check rejects ICP-only poses in the synthetic room: tests/test_ferns_gpu.py)
+
+
+class Scenario:
+    def __init__(self, name, scene, offset, query_from, n_ticks, fern_photo, **session_opts):
+        self.name, self.scene, self.offset, self.query_from, self.n_ticks, self.fern_photo = name, scene, offset, query_from, n_ticks, fern_photo
+        self.opts = dict(query_from=query_from, **session_opts)
+
+    def frames(self, synth, k):
+        """camera 1 runs `offset` frames ahead of camera 0 on the same trajectory"""
+        sc = getattr(synth, self.scene) if self.scene else None
+        out = {}
+        for c, off in ((0, 0), (1, self.offset)):
+            d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=sc)
+            out[c] = (rgb, d)
+        return out
+
+
+# "reference_rule": the merge is triggered by the reference's OWN rule - Ferns::findFrame with interMap = 1 (Ferns.cpp:277-423: SO3 +
+# 3 x 50 point-to-plane iterations on the 40 x 30 thumbnails, photometric check at Options' 115) followed by the full-resolution
+# refinement and acceptance of ReferenceFrame.h:72-110 at Options' default thresholds - in the cluttered-corner scene, whose geometry
+# constrains point-to-plane ICP down to the coarsest thumbnail level (synth.CORNER_SCENE).
+# "thumbnail_only" (rounds 3-4, kept as an extra): inter_map = 2 has no reference counterpart (dmslam_ferns.h) and no refinement; in
+# the default box room the reference's rule never verifies (the thumbnail ICP slides along the walls and diverges).
+SCENARIOS = {
+    "reference_rule": Scenario("reference_rule", "CORNER_SCENE", 8, 6, 15, 115.0, inter_map=1, full_refine=True),
+    "thumbnail_only": Scenario("thumbnail_only", None, 14, 4, 14, 1000.0, inter_map=2, full_refine=False),
+}
+# (the colour check rejects ICP-only poses in the default room: tests/test_ferns_gpu.py - hence 1000 there)
 
 
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
-
-
-def frames_for(synth, k):
-    out = {}
-    for c, off in ((0, 0), (1, OFFSET)):
-        d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True)
-        out[c] = (rgb, d)
-    return out
 
 
 # ---- oracle-backed stand-ins with the call surface of session.GpuBackend's engines ---------------------------------------------------
@@ -50,6 +67,13 @@ class _OrcCamera:
 
     def pose(self):
         return self.ef.currPose
+
+    def lost(self):
+        return bool(self.ef.lost)
+
+    def fillTextures(self):
+        fi, fv, fn = self.ef.fill
+        return np.ascontiguousarray(fi), np.ascontiguousarray(fv), np.ascontiguousarray(fn)
 
     def thumbnails(self):
         from oracle import orc_ferns
@@ -94,11 +118,32 @@ class _OrcCamera:
         pass
 
 
-class _OrcFerns:
+class _OrcRefiner:
+    """ReferenceFrame's m_rgbd behind the session's call surface (oracle/orc_pipeline.refine_inter_map)"""
+
     def __init__(self):
+        from oracle import orc
+
+        self.o = orc.Odometry(W, H, K[2], K[3], K[0], K[1])
+
+    def refineLocal(self, owner, cam, recoveryPose, thresholds):
+        return self.refineRemote(owner, cam.ef.fill, cam.c, cam.tick(), cam.pose(), recoveryPose, thresholds)
+
+    def refineRemote(self, owner, textures, timeIdx, tick, currPose, recoveryPose, thresholds):
+        from oracle import orc_pipeline
+
+        r = orc_pipeline.refine_inter_map(owner.ef, self.o, textures, timeIdx, tick, currPose, recoveryPose, *thresholds)
+        return r["accepted"], r["relativeTransform"]
+
+    def close(self):
+        pass
+
+
+class _OrcFerns:
+    def __init__(self, fern_photo):
         from oracle import orc, orc_ferns
 
-        self.db = orc_ferns.Ferns(W, H, K, num=500, maxDepth_mm=3000, photoThresh=FERN_PHOTO, seed=20260929,
+        self.db = orc_ferns.Ferns(W, H, K, num=500, maxDepth_mm=3000, photoThresh=fern_photo, seed=20260929,
                                   make_odometry=lambda: orc.Odometry(W // 8, H // 8, K[2] / 8, K[3] / 8, K[0] / 8, K[1] / 8))
         self.th, self.tw = H // 8, W // 8
 
@@ -152,6 +197,12 @@ class _OrcFerns:
 class _OrcBackend:
     session = None
 
+    def __init__(self, fern_photo):
+        self.fern_photo = fern_photo
+
+    def make_refiner(self):
+        return _OrcRefiner()
+
     def block_bytes(self):
         return (W // 8) * (H // 8) * 36
 
@@ -159,7 +210,7 @@ class _OrcBackend:
         return _OrcCamera(self, c)
 
     def make_ferns(self):
-        return _OrcFerns()
+        return _OrcFerns(self.fern_photo)
 
     def relative_transform(self, recoveryPose, currPose):
         from oracle import orc, orc_ferns
@@ -177,7 +228,8 @@ class _OrcBackend:
         return orc_ferns._mul4v(T, np.append(np.asarray(p, np.float32), np.float32(1)))[:3]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, scenario):
+    sc = SCENARIOS[scenario]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["OMP_NUM_THREADS"] = "4"
     import torch.distributed as dist
@@ -187,16 +239,16 @@ def _worker(rank, world, port, q):
 
     orc.set_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    be = _OrcBackend()
-    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **SESSION_OPTS)
+    be = _OrcBackend(sc.fern_photo)
+    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **sc.opts)
     be.session = s
     s.relative_cons[rank].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + rank))  # a constraint row the caller's solver produced before the merge
     hosted_log = []
-    for k in range(N_TICKS):
-        fr = frames_for(synth, k)
+    for k in range(sc.n_ticks):
+        fr = sc.frames(synth, k)
         s.step(k, {c: fr[c] for c in fr if c % world == rank})
         hosted_log.append(s.hosted())
-    res = dict(rank=rank, hosted=hosted_log, merges=s.merges, frame_of=s.frame_of,
+    res = dict(rank=rank, hosted=hosted_log, merges=s.merges, frame_of=s.frame_of, refinements=s.refinements,
                pose_graph={c: s.pose_graph[c] for c in s.hosted()}, relative_cons={c: s.relative_cons[c] for c in s.hosted()},
                maps={f: np.ascontiguousarray(s.cams[next(c for c in s.hosted() if s.frame_of[c] == f)].model()) for f in sorted(s.ferns)},
                fern_frames={f: len(s.ferns[f]) for f in s.ferns})
@@ -205,28 +257,47 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def oracle_session(orc):
+def run_oracle_session(scenario, n_ticks=None, relative_cons=True):
     from densemonoslam_amd import synth
     from oracle import orc_pipeline
 
-    s = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=FERN_PHOTO, **SESSION_OPTS)
-    for c in range(2):
-        s.relative_cons[c].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + c))
-    for k in range(N_TICKS):
-        fr = frames_for(synth, k)
+    sc = SCENARIOS[scenario]
+    s = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts)
+    if relative_cons:
+        for c in range(2):
+            s.relative_cons[c].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + c))
+    for k in range(n_ticks or sc.n_ticks):
+        fr = sc.frames(synth, k)
         s.step([fr[0], fr[1]], k)
     return s
 
 
-def test_two_rank_session_merges_and_continues_like_the_one_process_session(oracle_session):
-    ref = oracle_session
+@pytest.mark.parametrize("scenario", ["reference_rule", "thumbnail_only"])
+def test_two_rank_session_merges_and_continues_like_the_one_process_session(orc, scenario):
+    sc = SCENARIOS[scenario]
+    N_TICKS, QUERY_FROM = sc.n_ticks, sc.query_from
+    ref = run_oracle_session(scenario)
     assert len(ref.merges) == 1 and ref.merges[0][0] >= QUERY_FROM and N_TICKS - ref.merges[0][0] > 8, ref.merges
+    if sc.opts.get("full_refine"):
+        # the merge was decided by the reference's rule: a fern match under interMap = 1, then the full-resolution refinement accepted
+        # at Options' default thresholds (50 iterations on every level, SO3 pre-alignment run)
+        acc = [r for r in ref.refinements if r[3]]
+        assert len(acc) == 1 and acc[0][0] == ref.merges[0][0], ref.refinements
+        tr = acc[0][4]["track"]
+        assert list(tr.iterations_run) == [50, 50, 50] and acc[0][4]["lastICPCount"] > 35000 and acc[0][4]["lastICPError"] < 2e-05
+        # ... and it is a sensible transform: camera 1's map origin is camera 1's first pose (frame `offset` of the trajectory)
+        from densemonoslam_amd import synth
+
+        scn = getattr(synth, sc.scene)
+        k_m, fb_, fa_, T_ = ref.merges[0]
+        first = {0: scn.pose_fn(0), 1: scn.pose_fn(sc.offset)}
+        gt = np.linalg.inv(first[fb_]) @ first[fa_]  # map fa -> map fb
+        assert np.abs(T_.astype(np.float64) - gt).max() < 5e-3, (T_, gt)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario)) for r in range(world)]
     for p in procs:
         p.start()
     results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
@@ -240,6 +311,7 @@ def test_two_rank_session_merges_and_continues_like_the_one_process_session(orac
         assert [(m[0], m[1], m[2]) for m in res["merges"]] == [(k_merge, fb, fa)], res["merges"]
         assert res["merges"][0][3].tobytes() == T.tobytes(), "ranks / oracle disagree about the relative transform"
         assert res["frame_of"] == ref.frame_of
+        assert res["refinements"] == [r[:4] for r in ref.refinements]
         # hosting: one camera each up to and including the merge tick, then both on the consuming rank
         for k, hosted in enumerate(res["hosted"]):
             want = [r] if k < k_merge else ([0, 1] if r == hb else [])

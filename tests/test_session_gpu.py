@@ -11,27 +11,35 @@ import os
 import numpy as np
 import pytest
 
-from tests.test_session_cpu import FERN_PHOTO, H, K, OFFSET, QUERY_FROM, W, _free_port, frames_for
+from tests.test_session_cpu import SCENARIOS, H, K, W, _free_port, run_oracle_session
 
 pytestmark = pytest.mark.gpu
-N_TICKS = QUERY_FROM + 21
-SESSION_OPTS = dict(inter_map=2, query_from=QUERY_FROM)
+# "reference_rule": the merge is decided by Ferns::findFrame(interMap = 1) + the full-resolution refinement and acceptance of
+# ReferenceFrame.h:72-110 at Options' default thresholds (dms_refframe_refine on the owner's GPU); "thumbnail_only": rounds 3-4's
+# inter_map = 2 session without the refinement, kept as an extra (tests/test_session_cpu.py)
+_ORACLE = {}
 
 
-@pytest.fixture(scope="module")
-def oracle_session(orc):
-    from densemonoslam_amd import synth
-    from oracle import orc_pipeline
+def n_ticks(scenario):
+    return SCENARIOS[scenario].query_from + 21
 
-    s = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=FERN_PHOTO, **SESSION_OPTS)
-    for k in range(N_TICKS):
-        fr = frames_for(synth, k)
-        s.step([fr[0], fr[1]], k)
-    assert len(s.merges) == 1 and N_TICKS - 1 - s.merges[0][0] >= 20, s.merges
+
+@pytest.fixture(params=["reference_rule", "thumbnail_only"])
+def oracle_session(orc, request):
+    name = request.param
+    if name not in _ORACLE:
+        s = run_oracle_session(name, n_ticks(name), relative_cons=False)
+        assert len(s.merges) == 1 and n_ticks(name) - 1 - s.merges[0][0] >= 20, s.merges
+        if SCENARIOS[name].opts.get("full_refine"):
+            assert [r[3] for r in s.refinements] == [True], s.refinements
+        _ORACLE[name] = s
+    s = _ORACLE[name]
+    s.scenario = name
     return s
 
 
 def _check(ref, host, merges):
+    N_TICKS = n_ticks(ref.scenario)
     k_merge, fb, fa, T = ref.merges[0]
     assert [(m[0], m[1], m[2]) for m in merges] == [(k_merge, fb, fa)], merges
     assert np.asarray(merges[0][3], np.float32).tobytes() == T.tobytes(), "the relative transform differs from the oracle's"
@@ -53,17 +61,20 @@ def test_two_cameras_one_device_merge_and_continue(oracle_session):
     from densemonoslam_amd import capi, session, synth
 
     assert capi.device_count() >= 1, "no MI355X visible"
-    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=FERN_PHOTO), model_capacity=2_000_000)
-    s = session.CollabSession(be, 2, W, H, **SESSION_OPTS)
-    for k in range(N_TICKS):
-        s.step(k, frames_for(synth, k))
+    sc = SCENARIOS[oracle_session.scenario]
+    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=2_000_000)
+    s = session.CollabSession(be, 2, W, H, **sc.opts)
+    for k in range(n_ticks(sc.name)):
+        s.step(k, sc.frames(synth, k))
+    assert s.refinements == [r[:4] for r in oracle_session.refinements]
     fb = oracle_session.merges[0][1]
     host = dict(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph=s.pose_graph)
     _check(oracle_session, host, s.merges)
     s.close()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, scenario):
+    sc = SCENARIOS[scenario]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["DMS_TRACK_MODE"] = "launches"  # two processes on one device must not spin side by side
     import torch
@@ -72,12 +83,12 @@ def _worker(rank, world, port, q):
     from densemonoslam_amd import session, synth
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=FERN_PHOTO), model_capacity=2_000_000)
-    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **SESSION_OPTS)
-    for k in range(N_TICKS):
-        fr = frames_for(synth, k)
+    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=2_000_000)
+    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **sc.opts)
+    for k in range(n_ticks(scenario)):
+        fr = sc.frames(synth, k)
         s.step(k, {c: fr[c] for c in fr if c % world == rank})
-    res = dict(rank=rank, merges=s.merges, hosted=s.hosted())
+    res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements)
     if s.hosted():
         fb = s.frame_of[s.hosted()[0]]
         res.update(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph={c: s.pose_graph[c] for c in s.hosted()})
@@ -92,7 +103,7 @@ def test_two_ranks_merge_across_processes_and_continue(oracle_session):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, oracle_session.scenario)) for r in range(world)]
     for p in procs:
         p.start()
     results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
@@ -103,4 +114,54 @@ def test_two_ranks_merge_across_processes_and_continue(oracle_session):
     hb = fb % world
     assert results[hb]["hosted"] == [0, 1] and results[1 - hb]["hosted"] == []
     assert [(m[0], m[1], m[2]) for m in results[1 - hb]["merges"]] == [(m[0], m[1], m[2]) for m in results[hb]["merges"]]
+    for r in range(world):  # the cross-rank refinement (fill-in textures point to point, result broadcast): the same list on every rank
+        assert results[r]["refinements"] == [x[:4] for x in oracle_session.refinements]
     _check(oracle_session, results[hb], results[hb]["merges"])
+
+
+def test_three_cameras_chained_merge_one_device(orc):
+    """A reference frame that already holds two cameras is consumed by a third map (ReferenceFrame::consumeReferenceFrame moves EVERY
+    camera of the consumed frame, ReferenceFrame.h:127-145): frame 0 consumes camera 1's map at tick 6, then frame 2 consumes frame 0 -
+    its founder carries the surfels over, the camera that had joined it only moves (dms_fusion_join_map on an already joined
+    context).  Same bits as the one-process oracle session 5 frames past the second merge."""
+    import torch
+
+    from densemonoslam_amd import session, synth
+    from oracle import orc_pipeline
+
+    sc = SCENARIOS["reference_rule"]
+    offsets, ticks = (0, 8, 16), 13
+
+    def frames(k):
+        out = {}
+        for c, off in enumerate(offsets):
+            d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
+            out[c] = (rgb, d)
+        return out
+
+    ref = orc_pipeline.Session(3, W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts)
+    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=3_000_000)
+    s = session.CollabSession(be, 3, W, H, **sc.opts)
+    for k in range(ticks):
+        fr = frames(k)
+        ref.step([fr[0], fr[1], fr[2]], k)
+        s.step(k, fr)
+    assert len(ref.merges) == 2 and ref.frame_of == [ref.merges[1][1]] * 3, (ref.merges, ref.frame_of)
+    k2, fb2, fa2, _ = ref.merges[1]
+    assert ticks - 1 - k2 >= 5
+    # the second merge consumed a frame that held two cameras
+    assert ref.merges[0][1] == fa2, ref.merges
+    assert [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
+    for got, want in zip(s.merges, ref.merges):
+        assert np.asarray(got[3], np.float32).tobytes() == want[3].tobytes()
+    assert s.frame_of == ref.frame_of and s.refinements == [r[:4] for r in ref.refinements]
+    m_ref, m_got = ref.cams[fb2].model, s.cams[fb2].model()
+    assert len(m_got) == len(m_ref), (len(m_got), len(m_ref))
+    for f in m_ref.dtype.names:
+        assert np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)), "merged map differs in field " + f
+    for c in range(3):
+        got, want = s.pose_graph[c], ref.pose_graph[c]
+        assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
+        for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
+    s.close()
