@@ -287,7 +287,7 @@ class Odometry:
         self.h = lib.orc_odometry_create(width, height, cx, cy, fx, fy, distThresh, angleThresh)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # (at interpreter shutdown the module globals may already be gone)
             lib.orc_odometry_destroy(self.h)
             self.h = None
 
