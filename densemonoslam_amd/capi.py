@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmslam_hip.so")
+# DMS_LIB_PATH: another build of the same library (A/B measurements of two builds on one box, scripts/ab_lib.sh); never a fallback
+LIB_PATH = os.environ.get("DMS_LIB_PATH") or os.path.join(_HERE, "libdmslam_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -54,5 +54,31 @@ def main(path):
     print("surfels emitted by vertex_feedback with LINEAR / NEAREST filtering of the raw depth:", n_lin, n_near)
 
 
+def main_full(path):
+    """640 x 480 (tests/ref_cases_gl.py "full-size case"): hashes of the restatement's free run (the feed) + samples of what the
+    reference's shaders return stage by stage on that feed + the whole-array comparison report of this recording run."""
+    cg.configure(**cg.FULL)
+    inp = cg.inputs(orc, orc_pipeline, synth)
+    orc_out = cg.chain(cg.OrcOps(orc), inp, orc.SURFEL_DTYPE)
+    gl_out = cg.chain(cg.GlOps(ref_gl), inp, orc.SURFEL_DTYPE, feed=orc_out)
+    again = cg.chain(cg.GlOps(ref_gl), inp, orc.SURFEL_DTYPE, feed=orc_out)
+    for k in gl_out:
+        assert gl_out[k].tobytes() == again[k].tobytes(), "not repeatable: " + k
+    rep = cg.compare_all(orc_out, gl_out, inp, fed=orc_out)  # (a free run of the restatement IS the restatement fed its own outputs)
+    z = {k + "__gl": v for k, v in cg.sample_outputs(gl_out).items()}
+    z.update(cg.input_hashes(inp))
+    z.update(cg.orc_hashes(orc_out))
+    z["report"] = np.array(str(rep))
+    z["meta"] = np.array("reference GLSL programs (elasticfusion/Core/src/Shaders) compiled and run by %s through oracle/ref_gl_harness.c at %d x %d; %d samples "
+                         "per stage; every stage fed the restatement's outputs (hashes: <stage>__orc)" % (ref_gl.renderer(), cg.W, cg.H, cg.N_SAMPLES))
+    np.savez_compressed(path, **z)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    for k, v in rep.items():
+        print(" ", k, v)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "ref_glsl.npz"))
+    if len(sys.argv) > 1 and sys.argv[1] == "--full":
+        main_full(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golden", "ref_glsl_full.npz"))
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "ref_glsl.npz"))

@@ -38,7 +38,18 @@ def configure(**kw):
     """Another image size / warm-up for the live comparison (tests/test_ref_gl_live_cpu.py); returns the previous settings."""
     old = {k: globals()[k] for k in kw}
     globals().update(kw)
+    _scale_tolerances()
     return old
+
+
+def _scale_tolerances():
+    """Normals come from a cross product of DIFFERENCES of neighbouring vertices (geometry.glsl:19-39): the differences are one pixel
+    footprint (z / fx) long while their rounding errors are ulps of the coordinates (<= 3 m), so the normal's error grows with
+    fx: a few ulp(3 m) x fx / z.  2e-5 at the fixture's fx = 39.6 (below), 2.7e-4 at 528, 3.6e-4 at 718.9; radii (depth / |n.z|)
+    inherit it."""
+    global TOL_NRM, TOL_RAD_REL
+    TOL_NRM = 2e-5 * max(1.0, K[0] / 39.6)
+    TOL_RAD_REL = TOL_NRM
 
 
 def sha(a):
@@ -271,7 +282,7 @@ def _colour_bytes(c):
     return np.stack([(c >> 16) & 255, (c >> 8) & 255, c & 255], axis=-1)
 
 
-def compare_surfels(name, got15, want15, exact_values=False):
+def compare_surfels(name, got15, want15, exact_values=False, flips_allowed=0):
     """Two n x 15 record arrays of the same stage, record for record."""
     got15, want15 = np.asarray(got15, np.float32).reshape(-1, 15), np.asarray(want15, np.float32).reshape(-1, 15)
     assert got15.shape == want15.shape, "%s: %d records, the reference's shaders produced %d" % (name, len(got15), len(want15))
@@ -279,8 +290,15 @@ def compare_surfels(name, got15, want15, exact_values=False):
         assert got15.tobytes() == want15.tobytes(), "%s: records differ (expected the same bits)" % name
         return dict(records=len(got15), exact=True)
     g, w = got15, want15
-    # integer-valued fields: colour word's other members (0, init time, stamp) and the per-sensor times - exact
-    assert (g[:, 5:11] == w[:, 5:11]).all(), "%s: init time / stamp / sensor times differ in %d records" % (name, int((g[:, 5:11] != w[:, 5:11]).any(axis=1).sum()))
+    # integer-valued fields: colour word's other members (0, init time, stamp) and the per-sensor times - exact.  `flips`: the fuse
+    # associates a measurement with the NEAREST eligible surfel of its window (data.vert:118-160); where two candidates are within
+    # the arithmetic noise of each other the two implementations may pick different ones - two records then differ (one updated
+    # here, the other there).  Seen at 1241 x 376 (2 of 655 955 records), never at the smaller sizes; counted, bounded, left out
+    # of the value comparison below.
+    flip = (g[:, 5:11] != w[:, 5:11]).any(axis=1)
+    assert flip.sum() <= flips_allowed, "%s: init time / stamp / sensor times differ in %d records" % (name, int(flip.sum()))
+    if flip.any():
+        g, w = g[~flip], w[~flip]
     # packed colour: each 8-bit channel within one count (an average that lands on .5 rounds either way)
     dc = np.abs(_colour_bytes(g[:, 4]) - _colour_bytes(w[:, 4]))
     assert dc.max() <= 1, "%s: a colour channel differs by %d" % (name, int(dc.max()))
@@ -291,7 +309,8 @@ def compare_surfels(name, got15, want15, exact_values=False):
     assert (np.isnan(g[:, 11:15]) == np.isnan(w[:, 11:15])).all(), "%s: NaN normals in different records" % name
     assert np.abs(g[ok, 11:14] - w[ok, 11:14]).max() <= TOL_NRM, "%s: normals differ by %.3e" % (name, np.abs(g[ok, 11:14] - w[ok, 11:14]).max())
     assert (np.abs(g[ok, 14] - w[ok, 14]) <= TOL_RAD_REL * np.abs(w[ok, 14]) + 1e-9).all(), "%s: radii differ by %.3e" % (name, np.abs(g[ok, 14] - w[ok, 14]).max())
-    return dict(records=len(g), exact=bool(g.tobytes() == w.tobytes()), colour_off_by_one=int((dc > 0).any(axis=1).sum()))
+    return dict(records=len(got15), exact=bool(got15.tobytes() == want15.tobytes()), colour_off_by_one=int((dc > 0).any(axis=1).sum()),
+                **({"association_flips": int(flip.sum())} if flips_allowed else {}))
 
 
 def boundary_surfels(model15, t_inv):
@@ -328,7 +347,7 @@ def compare_index_maps(name, got, want, model15, t_inv):
     return dict(pixels_with_a_surfel=int((wi > 0).sum()), ids_differing=int(dif.sum()), boundary_surfels=int(near.sum()))
 
 
-def compare_splat(name, got, want):
+def compare_splat(name, got, want, coords=None):
     """(image rgba8, vertex, normal, time u16) x 2 of a splat prediction: the same pixels covered, the same surfel winning each
     (colour and time are copied from it), its intersection point / normal to tolerance; pixels where two surfels' depths are
     closer than the arithmetic noise may show the other one."""
@@ -336,11 +355,37 @@ def compare_splat(name, got, want):
     wimg, wv, wn, wt = (np.asarray(a) for a in want)
     cov_g, cov_w = gv[..., 2] != 0, wv[..., 2] != 0
     assert (cov_g == cov_w).mean() >= 0.999, "%s: coverage differs at %d pixels" % (name, int((cov_g != cov_w).sum()))
-    same = (gimg == wimg).all(axis=-1) & (gt == wt) & (cov_g == cov_w)
+    # the same surfel won: its colour, time stamp and confidence are copies (at full resolution many surfels share a colour and a
+    # time, so the confidence - a float accumulated per surfel - is part of the identity)
+    same = (gimg == wimg).all(axis=-1) & (gt == wt) & (cov_g == cov_w) & (gv[..., 3] == wv[..., 3])
     assert same.mean() >= 0.995, "%s: another surfel wins at %d pixels" % (name, int((~same).sum()))
-    assert np.abs(gv[same] - wv[same]).max() <= TOL_POS, "%s: vertices differ by %.3e" % (name, np.abs(gv[same] - wv[same]).max())
+    # the fragment's point is the ray / disc intersection k l with k = (p . n) / (l . n) (combo_splat.frag:44-46): its rounding errors
+    # are amplified by 1 / |l . n| on discs seen at a grazing angle
+    if coords is None:
+        hh, ww = gv.shape[:2]
+        u, v = np.meshgrid(np.arange(ww, dtype=np.float64) + 0.5, np.arange(hh, dtype=np.float64) + 0.5)
+    else:  # sampled form: 1-D lists of pixels, coords = (column, row) of each
+        u, v = np.asarray(coords[0], np.float64) + 0.5, np.asarray(coords[1], np.float64) + 0.5
+    l = np.stack([(u - K[2]) / K[0], (v - K[3]) / K[1], np.ones_like(u)], axis=-1)
+    l /= np.linalg.norm(l, axis=-1, keepdims=True)
+    graze = np.maximum(np.abs((l * wn[..., :3].astype(np.float64)).sum(axis=-1)), 0.02)
+    dv = np.abs(gv[..., :3].astype(np.float64) - wv[..., :3]).max(axis=-1)
+    assert (dv[same] <= TOL_POS / graze[same]).all(), "%s: vertices differ by %.3e (x |l.n| = %.3e)" % (name, dv[same].max(), (dv * graze)[same].max())
     assert np.abs(gn[same] - wn[same]).max() <= TOL_NRM, "%s: normals differ by %.3e" % (name, np.abs(gn[same] - wn[same]).max())
     return dict(covered=int(cov_w.sum()), other_winner=int((~same).sum()), exact_images=bool((gimg == wimg).all() and (gt == wt).all()))
+
+
+def compare_depth_splat(name, got, want):
+    """synthesizeDepth's image (depth_splat.frag): the z of the winning surfel's ray / disc intersection.  Like compare_splat, without
+    the attribute maps: a pixel where another surfel wins (two depths closer than the arithmetic noise) shows a different surface
+    - rare, counted -, everywhere else the depth agrees to the intersection's tolerance (grazing discs amplify it, see there)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape and ((got != 0) == (want != 0)).mean() >= 0.999, name + ": coverage differs"
+    d = np.abs(got - want)
+    other = d > 1e-4
+    assert other.mean() <= 0.001, "%s: another surfel wins at %d pixels" % (name, int(other.sum()))
+    assert d[~other].max() <= 25 * TOL_POS, "%s: differs by %.3e" % (name, d[~other].max())
+    return dict(differing=int((d > 0).sum()), above_plain_tolerance=int((d[~other] > TOL_POS).sum()), other_winner=int(other.sum()), worst=float(d[~other].max()))
 
 
 def compare_image(name, got, want, tol):
@@ -357,7 +402,7 @@ def compare_image(name, got, want, tol):
     return dict(differing=int((d > 0).sum()), worst=float(d.max()))
 
 
-def compare_all(out, fx, inp, skip=()):
+def compare_all(out, fx, inp, skip=(), fed=None):
     """Every output of a chain run (`out`) against the fixture / the reference's run (`fx`).  Returns a per-stage summary."""
     rep = {}
     tick, ti = int(inp["tick"]), inp["t_inv"]
@@ -372,16 +417,18 @@ def compare_all(out, fx, inp, skip=()):
     for pre in ("act", "ina", "low"):
         rep[pre] = compare_splat(pre, [out[pre + "_" + n] for n in ("image", "vertex", "normal", "time")],
                                  [fx[pre + "_" + n] for n in ("image", "vertex", "normal", "time")])
-    rep["dsyn"] = compare_image("dsyn", out["dsyn"], fx["dsyn"], TOL_POS)
-    rep["fused"] = compare_surfels("fused", out["fused"], fx["fused"])
-    # which surfels the frame merged into (their time slot carries the tick): identical sets
-    assert ((np.asarray(out["fused"])[:, 8] == tick) == (np.asarray(fx["fused"])[:, 8] == tick)).all()
+    rep["dsyn"] = compare_depth_splat("dsyn", out["dsyn"], fx["dsyn"])
+    n_rec = len(np.asarray(fx["fused"]).reshape(-1, 15))
+    flips = 2 * max(1, n_rec // 200000) if n_rec > 100000 else 0  # (one flipped association = two records; none allowed on small maps)
+    rep["fused"] = compare_surfels("fused", out["fused"], fx["fused"], flips_allowed=flips)
+    # which surfels the frame merged into (their time slot carries the tick): identical sets (up to the flips counted above)
+    assert ((np.asarray(out["fused"])[:, 8] == tick) != (np.asarray(fx["fused"])[:, 8] == tick)).sum() <= flips
     rep["fused"]["merged"] = int((np.asarray(fx["fused"])[:, 8] == tick).sum())
     if "emitted" not in skip:
         rep["emitted"] = compare_surfels("emitted", out["emitted"], fx["emitted"])
         rep["emitted"]["new_unstable"] = int((np.asarray(fx["emitted"])[:, 7] == -2).sum())
     rep["idx2"] = compare_index_maps("idx2", [out["idx2_" + n] for n in ("index", "vertConf", "colorTime", "normRad")],
-                                     [fx["idx2_" + n] for n in ("index", "vertConf", "colorTime", "normRad")], fx["fused"], ti)
+                                     [fx["idx2_" + n] for n in ("index", "vertConf", "colorTime", "normRad")], (fed if fed is not None else fx)["fused"], ti)
     rep["consumed"] = compare_surfels("consumed", out["consumed"], fx["consumed"], exact_values=True)  # one matrix-vector product per record: the same bits
     for k in ("graph_7", "graph_64"):  # copies of map values: the same bytes
         assert np.asarray(out[k], np.float32).tobytes() == np.asarray(fx[k], np.float32).tobytes(), k
@@ -397,7 +444,7 @@ def compare_all(out, fx, inp, skip=()):
             assert np.asarray(out[k]).tobytes() == np.asarray(fx[k]).tobytes(), k
             rep[k] = dict(exact=True)
         elif k.startswith("resize_"):
-            src = fx["act_image" if k.startswith("resize_image") else "act_vertex"]
+            src = (fed if fed is not None else fx)["act_image" if k.startswith("resize_image") else "act_vertex"]  # what both were fed
             rep[k] = compare_resize(k, out[k], fx[k], src)
     return rep
 
@@ -431,3 +478,90 @@ def compare_resize(name, got, ref, src):
                 ok |= allowed & (a == s[rr, cc]).all(axis=2)
         assert ok.all(), "%s: the %s's copy holds a texel that is not a neighbour of the sample point" % (name, who)
     return dict(ties=int(tie.sum()), differing_at_ties=int((~same).sum()), pixels=int(tie.size))
+
+
+# ---- full-size case, recorded as hashes + samples ----------------------------------------------------------------------------
+# At 640 x 480 the chain's outputs are 260 MB - not a fixture.  tests/golden/ref_glsl_full.npz therefore holds, per stage,
+#   <stage>__orc : SHA-256 of the RESTATEMENT's output in a free run of the chain (no feed) - reproducible anywhere, it is the feed;
+#   <stage>__gl  : N_SAMPLES elements (pixels / records, indices from a seeded generator) of what the REFERENCE's SHADERS returned for
+#                  that stage when every stage was fed the restatement's outputs - so a candidate fed the same way saw the same inputs.
+# compare_sampled applies compare_all's rules to those elements.
+N_SAMPLES = 2048
+FULL = dict(W=640, H=480, K=(528.0, 528.0, 320.0, 240.0), N_WARM=26, STRIDE=3)
+_PIXEL_STAGES = ("bilateral", "metric", "metric_f", "bilateral0", "dsyn", "fill_vertex", "fill_normal", "fill_vertex_pass", "fill_image", "fill_image_pass")
+_MAPS = {"idx": ("index", "vertConf", "colorTime", "normRad"), "idx2": ("index", "vertConf", "colorTime", "normRad"),
+         "act": ("image", "vertex", "normal", "time"), "ina": ("image", "vertex", "normal", "time"), "low": ("image", "vertex", "normal", "time")}
+_RECORD_STAGES = ("boot", "consumed", "fused", "emitted", "cleaned", "cleaned_graph", "cleaned_fern")
+
+
+def _sample_idx(name, n):
+    seed = int(hashlib.sha256(name.encode()).hexdigest()[:8], 16)
+    m = min(n, N_SAMPLES)
+    return np.sort(np.random.default_rng(seed).choice(n, m, replace=False)) if n else np.zeros(0, np.int64)
+
+
+def _pix(a, idx):
+    a = np.asarray(a)
+    return a.reshape(H * W, -1)[idx] if a.ndim == 3 else a.reshape(H * W)[idx]
+
+
+def sample_outputs(out):
+    """The elements of a chain run that the full-size fixture keeps (see above)."""
+    z = {}
+    pidx = _sample_idx("pixels", H * W)
+    for k in _PIXEL_STAGES:
+        z[k] = _pix(out[k], pidx)
+    for pre, names in _MAPS.items():
+        for n in names:
+            z[pre + "_" + n] = _pix(out[pre + "_" + n], pidx)
+    for k in _RECORD_STAGES:
+        a = np.asarray(out[k], np.float32).reshape(-1, 15)
+        z[k] = a[_sample_idx(k, len(a))]
+        z[k + "__n"] = np.int64(len(a))
+    for k in ("graph_7", "graph_64"):
+        a = np.asarray(out[k], np.float32).reshape(-1, 4)
+        z[k] = a[_sample_idx(k, len(a))]
+    return z
+
+
+def compare_sampled(out, gl, inp, orc_fused15, skip=()):
+    """`out`: a candidate's chain run, every stage fed the restatement's outputs; `gl`: sample_outputs() of the shaders' run fed the
+    same way (the fixture's <stage>__gl).  compare_all's rules on the sampled elements."""
+    rep = {}
+    tick, ti = int(inp["tick"]), inp["t_inv"]
+    o = sample_outputs(out)
+    pidx = _sample_idx("pixels", H * W)
+    cols, rows = pidx % W, pidx // W
+    rep["bilateral"] = compare_image("bilateral", o["bilateral"], gl["bilateral"], 1)
+    rep["bilateral0"] = compare_image("bilateral0", o["bilateral0"], gl["bilateral0"], 1)
+    for k in ("metric", "metric_f"):
+        assert np.asarray(o[k]).tobytes() == np.asarray(gl[k]).tobytes(), k
+    for k in _RECORD_STAGES:
+        if k in skip:
+            continue
+        assert int(o[k + "__n"]) == int(gl[k + "__n"]), "%s: %d records, the reference's shaders produced %d" % (k, int(o[k + "__n"]), int(gl[k + "__n"]))
+    rep["boot"] = compare_surfels("boot", o["boot"], gl["boot"])
+    m15 = rec15(inp["model"])
+    for pre, model15 in (("idx", m15), ("idx2", orc_fused15)):
+        rep[pre] = compare_index_maps(pre, [o[pre + "_" + n] for n in _MAPS[pre]], [gl[pre + "_" + n] for n in _MAPS[pre]], model15, ti)
+    for pre in ("act", "ina", "low"):
+        rep[pre] = compare_splat(pre, [o[pre + "_" + n] for n in _MAPS[pre]], [gl[pre + "_" + n] for n in _MAPS[pre]], coords=(cols, rows))
+    rep["dsyn"] = compare_depth_splat("dsyn", o["dsyn"], gl["dsyn"])
+    rep["fused"] = compare_surfels("fused", o["fused"], gl["fused"], flips_allowed=2)
+    if "emitted" not in skip:
+        rep["emitted"] = compare_surfels("emitted", o["emitted"], gl["emitted"])
+    rep["consumed"] = compare_surfels("consumed", o["consumed"], gl["consumed"], exact_values=True)
+    for k in ("graph_7", "graph_64"):
+        assert np.asarray(o[k], np.float32).tobytes() == np.asarray(gl[k], np.float32).tobytes(), k
+    for k in ("cleaned", "cleaned_graph", "cleaned_fern"):
+        rep[k] = compare_surfels(k, o[k], gl[k])
+    rep["fill_vertex"] = compare_image("fill_vertex", o["fill_vertex"], gl["fill_vertex"], TOL_POS)
+    rep["fill_normal"] = compare_image("fill_normal", o["fill_normal"], gl["fill_normal"], TOL_NRM)
+    rep["fill_vertex_pass"] = compare_image("fill_vertex_pass", o["fill_vertex_pass"], gl["fill_vertex_pass"], TOL_POS)
+    for k in ("fill_image", "fill_image_pass"):
+        assert np.asarray(o[k]).tobytes() == np.asarray(gl[k]).tobytes(), k
+    return rep
+
+
+def orc_hashes(orc_out):
+    return {k + "__orc": np.array(sha(np.asarray(v))) for k, v in orc_out.items()}

@@ -11,6 +11,7 @@ import pytest
 from tests import ref_cases_gl as cg
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glsl.npz")
+GOLDEN_FULL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_glsl_full.npz")
 
 
 def load():
@@ -55,3 +56,37 @@ def test_fixture_is_the_references():
     # neighbour's depth leak into a hole; recorded so that the NEAREST choice of the harness stays a documented, checked fact
     lin, near = fx["feedback_count_linear_vs_nearest"]
     assert lin > near == len(fx["boot"])
+
+
+def full_case(orc, orc_pipeline, synth):
+    """(fixture, inputs, the restatement's free run of the chain) of the 640 x 480 case; cg.configure(**cg.FULL) must be in effect.
+    Checks that inputs and the restatement's outputs are the ones hashed into the fixture: the restatement's outputs are the FEED the
+    reference's shaders saw when the fixture's samples were recorded."""
+    fx = np.load(GOLDEN_FULL)
+    inp = cg.inputs(orc, orc_pipeline, synth)
+    for k, v in cg.input_hashes(inp).items():
+        assert str(v) == str(fx[k]), "input %s is not what the reference's shaders saw" % k
+    orc_out = cg.chain(cg.OrcOps(orc), inp, orc.SURFEL_DTYPE)
+    for k, v in cg.orc_hashes(orc_out).items():
+        assert str(v) == str(fx[k]), "the restatement's %s is not the feed the fixture was recorded with" % k
+    return fx, inp, orc_out
+
+
+def test_restatement_equals_the_references_shaders_at_640x480(orc):
+    """The pin at a BASELINE size (tests/ref_cases_gl.py "full-size case"): 437 750 surfels, 60 971 merged by the fuse, the update pass's
+    scratch textures addressed far past their first row (GlobalModel.cpp:513-694, TEXTURE_DIMENSION 5700)."""
+    from densemonoslam_amd import synth
+    from oracle import orc_pipeline
+
+    old = cg.configure(**cg.FULL)
+    try:
+        fx, inp, orc_out = full_case(orc, orc_pipeline, synth)
+        gl = {k[:-4]: fx[k] for k in fx.files if k.endswith("__gl")}
+        rep = cg.compare_sampled(orc_out, gl, inp, orc_out["fused"])
+        assert int(gl["fused__n"]) > 5700 * 50 and rep["cleaned"]["exact"] and rep["idx"]["pixels_with_a_surfel"] > 500
+        # what the recording run itself found on the WHOLE arrays (restatement against shaders, stage by stage)
+        whole = str(fx["report"])
+        assert "'merged': 60971" in whole and "'association_flips': 0" in whole and "'cleaned': {'records': 439209, 'exact': True" in whole, whole[:400]
+        print({k: v for k, v in rep.items() if k in ("idx", "act", "fused", "cleaned", "cleaned_graph")})
+    finally:
+        cg.configure(**old)

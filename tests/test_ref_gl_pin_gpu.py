@@ -8,7 +8,6 @@ from tests import ref_cases_gl as cg
 from tests.test_ref_gl_pin_cpu import load
 
 pytestmark = pytest.mark.gpu
-W, H, K = cg.W, cg.H, cg.K
 
 
 class HipOps:
@@ -16,11 +15,12 @@ class HipOps:
     object, so model_fuse hands back no `emitted` records (the chain then feeds the fixture's) and model_clean re-runs the fuse on a
     fresh upload before each clean."""
 
-    def __init__(self, fus, dtype):
-        self.f, self.dtype = fus, dtype
-        self.gm = fus.GlobalModel(W, H, capacity=60000)
+    def __init__(self, fus, dtype, capacity=60000):
+        self.f, self.dtype, self.cap = fus, dtype, capacity
+        self.W, self.H, self.K = cg.W, cg.H, cg.K  # (the case's size at construction: cg.configure switches it for the full-size case)
+        self.gm = fus.GlobalModel(self.W, self.H, capacity=capacity)
         self.gm.setNumSensors(3)  # Shaders/size.glsl: NUM_CAMERAS 3
-        self.im = fus.IndexMap(W, H)
+        self.im = fus.IndexMap(self.W, self.H)
         self.fuse_args = None
 
     def depth_bilateral(self, d, maxD):
@@ -30,12 +30,12 @@ class HipOps:
         return self.f.depth_metric(d, maxD).download()
 
     def model_initialise(self, rgba, dm, dmf, K_, time, timeIdx, maxDepth):
-        gm = self.f.GlobalModel(W, H, capacity=60000)
+        gm = self.f.GlobalModel(self.W, self.H, capacity=self.cap)
         gm.initialise(rgba, dm, dmf, K_, time, timeIdx, maxDepth)
         return gm.downloadMap()
 
     def model_consume(self, dst, src, T):
-        a, b = self.f.GlobalModel(W, H, capacity=60000), self.f.GlobalModel(W, H, capacity=60000)
+        a, b = self.f.GlobalModel(self.W, self.H, capacity=2 * self.cap), self.f.GlobalModel(self.W, self.H, capacity=self.cap)
         for m in (a, b):
             m.setNumSensors(3)
         a.upload(dst)
@@ -84,6 +84,7 @@ class HipOps:
         return self.gm.downloadMap()
 
     def _fill(self, which, existing, depth, K_, passthrough):
+        H, W = self.H, self.W
         ex = self.f.PredictionImages(H, W)
         z = np.zeros((H, W, 4), np.float32)
         ex.vertex.upload(np.ascontiguousarray(existing if which == 0 else z, np.float32))
@@ -99,12 +100,13 @@ class HipOps:
         return self._fill(1, existing, depth, K_, passthrough)
 
     def fill_image(self, existing, rgba, passthrough):
+        H, W = self.H, self.W
         ex = self.f.PredictionImages(H, W)
         z = np.zeros((H, W, 4), np.float32)
         ex.vertex.upload(z)
         ex.normal.upload(z)
         ex.image.upload(np.ascontiguousarray(existing, np.uint8))
-        return self.f.fill_in(ex, np.zeros((H, W), np.uint16), rgba, K, passthrough, passthrough).image.download()
+        return self.f.fill_in(ex, np.zeros((H, W), np.uint16), rgba, self.K, passthrough, passthrough).image.download()
 
     def resize(self, src, drows, dcols):
         return self.f.resize_nn(np.ascontiguousarray(src), drows, dcols).download()
@@ -123,3 +125,28 @@ def test_product_equals_the_references_shaders(orc):
     rep = cg.compare_all(out, fx, inp, skip=("emitted",))
     assert rep["cleaned"]["records"] == len(fx["cleaned"]) and rep["fused"]["merged"] > 100
     print(rep)
+
+
+def test_product_equals_the_references_shaders_at_640x480(orc):
+    """The same pin at a BASELINE size: 640 x 480, a map of 437 750 surfels (the fuse's update pass wraps TEXTURE_DIMENSION = 5700 many
+    times).  The fixture keeps hashes and samples (tests/ref_cases_gl.py "full-size case"): every stage of the product is fed the
+    restatement's outputs - whose hashes the fixture pins - exactly as the reference's shaders were when the samples were recorded, and
+    is held (i) to those samples by compare_all's rules and (ii) to the restatement's own output of the stage, bit for bit."""
+    from densemonoslam_amd import capi, fusion, synth
+    from oracle import orc_pipeline
+    from tests.test_ref_gl_pin_cpu import full_case
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    old = cg.configure(**cg.FULL)
+    try:
+        fx, inp, orc_out = full_case(orc, orc_pipeline, synth)
+        gl = {k[:-4]: fx[k] for k in fx.files if k.endswith("__gl")}
+        out = cg.chain(HipOps(fusion, orc.SURFEL_DTYPE, capacity=800_000), inp, orc.SURFEL_DTYPE, feed=orc_out)
+        rep = cg.compare_sampled(out, gl, inp, orc_out["fused"], skip=("emitted",))
+        assert rep["fused"]["records"] == cg.N_SAMPLES and int(gl["fused__n"]) > 400_000
+        exact = [k for k in out if k != "emitted" and np.asarray(out[k]).tobytes() == np.asarray(orc_out[k]).tobytes()]
+        differ = sorted(set(out) - set(exact) - {"emitted"})
+        assert not differ, "stages whose product output is not the restatement's, bit for bit: %s" % differ
+        print({k: v for k, v in rep.items() if k in ("idx", "act", "fused", "cleaned")})
+    finally:
+        cg.configure(**old)
