@@ -1,0 +1,711 @@
+// The collaborative session behind the C ABI (include/dmslam_session.h): MainController.cpp:262-400's camera loop with the inter-map
+// block of ElasticFusion.cpp:595-632 for one rank of a node, composed from the library's own entry points — dms_fusion_* (the cameras),
+// dms_ferns_* (the reference frames' key-frame databases), dms_refframe_* (ReferenceFrame's m_index + m_rgbd), dms_model_* / dms_ferns_*
+// records (a merge across ranks) — and a dms_transport.  Host code: no kernel of its own.  The protocol is the one of
+// densemonoslam_amd/session.py, step for step (same order of queries, same decision rule, same float operations for the re-basing:
+// dms_pose_compose / dms_relative_transform), so a session run through this file ends in the same bits as the one-process oracle
+// session (tests/test_session_gpu.py).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "../../include/dmslam_session.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMetaBytes = 80;  // per published block: camera id i32 | tick i32 | 2 x pad | pose 16 x f32
+constexpr int kRow = 18;        // table entry: valid, closest, recoveryPose
+
+struct Merge {
+  int k, fb, fa;
+  float T[16];
+};
+struct Refinement {
+  int k, a, fb, accepted;
+};
+struct Camera {
+  dms_fusion* f = nullptr;
+  void* last_rgb = nullptr;              // the last processed frame, for a migration (RGB8 | depth u16)
+  unsigned short* last_depth = nullptr;
+  dms_frame_result last{};
+  int tick = 1;
+  float pose[16];
+  bool has_frame = false;
+  std::vector<int> pg_tick;              // Context::poseGraph()
+  std::vector<float> pg_pose;            // 16 floats each
+};
+
+}  // namespace
+
+struct dms_session {
+  dms_session_params p{};
+  dms_transport t{};
+  bool local_only = true;
+  int rank = 0, world = 1, n = 0, W = 0, H = 0;
+  std::vector<int> frame_of;             // camera -> reference frame
+  std::map<int, int> host_of_frame;      // reference frame -> rank
+  std::map<int, Camera> cams;            // hosted here
+  std::map<int, dms_ferns*> ferns;       // hosted frames
+  std::map<int, dms_refframe*> refiners;
+  std::vector<Merge> merges;
+  std::vector<Refinement> refinements;
+  size_t thumb_bytes = 0, block_bytes = 0;
+  // device scratch
+  unsigned char* d_local = nullptr;      // n x block_bytes
+  unsigned char* d_gathered = nullptr;   // world x n x block_bytes
+  float* d_table = nullptr;              // (1 + world) x (n + 1) x n x kRow
+  float* d_pose = nullptr;               // 16 floats (a pose for addFrame)
+  float* d_small = nullptr;              // 64 floats: broadcast / headers
+  void* d_frame_rgb = nullptr;           // a forwarded frame
+  unsigned short* d_frame_depth = nullptr;
+  unsigned char* d_tex = nullptr;        // a remote camera's fill-in textures (36 B per pixel)
+};
+
+namespace {
+
+using ::dms::set_error;
+
+int host_of_camera(const dms_session* s, int c) { return s->host_of_frame.at(s->frame_of[c]); }
+
+std::vector<int> hosted(const dms_session* s) {
+  std::vector<int> v;
+  for (auto& kv : s->cams) v.push_back(kv.first);
+  return v;  // (std::map: ascending)
+}
+
+int sync(dms_stream st) { return dms_stream_sync(st); }
+
+// ---- transport helpers: the session's own one-rank transport, sized messages ----------------------------------------------------
+int t_allgather(dms_session* s, const void* send, void* recv, size_t bytes, dms_stream st) {
+  if (s->local_only) return dms_memcpy_d2d_async(recv, send, bytes, st);
+  return s->t.allgather(s->t.ctx, send, recv, bytes, st);
+}
+int t_send(dms_session* s, const void* src, size_t bytes, int peer, dms_stream st) { return bytes ? s->t.send(s->t.ctx, src, bytes, peer, st) : 0; }
+int t_recv(dms_session* s, void* dst, size_t bytes, int peer, dms_stream st) { return bytes ? s->t.recv(s->t.ctx, dst, bytes, peer, st) : 0; }
+int t_bcast(dms_session* s, void* buf, size_t bytes, int root, dms_stream st) {
+  if (s->local_only) return 0;
+  return s->t.broadcast(s->t.ctx, buf, bytes, root, st);
+}
+// a host array through the device scratch (headers of a migration: counts, poses)
+int send_host(dms_session* s, const void* host, size_t bytes, int peer, dms_stream st) {
+  void* d = nullptr;
+  int rc = dms_device_alloc(&d, bytes ? bytes : 4);
+  if (rc) return rc;
+  if (bytes) rc = dms_memcpy_h2d(d, host, bytes, st);
+  if (!rc) rc = t_send(s, d, bytes, peer, st);
+  if (!rc) rc = sync(st);
+  dms_device_free(d);
+  return rc;
+}
+int recv_host(dms_session* s, void* host, size_t bytes, int peer, dms_stream st) {
+  void* d = nullptr;
+  int rc = dms_device_alloc(&d, bytes ? bytes : 4);
+  if (rc) return rc;
+  rc = t_recv(s, d, bytes, peer, st);
+  if (!rc) rc = sync(st);
+  if (!rc && bytes) rc = dms_memcpy_d2h(host, d, bytes, st);
+  dms_device_free(d);
+  return rc;
+}
+
+int make_camera(dms_session* s, int c, Camera& cam) {
+  dms_fusion_params fp = s->p.camera;
+  fp.timeIdx = c;
+  int rc = dms_fusion_create(&cam.f, &fp);
+  if (rc) return rc;
+  const size_t N = (size_t)s->W * s->H;
+  if ((rc = dms_device_alloc(&cam.last_rgb, N * 3))) return rc;
+  void* d = nullptr;
+  if ((rc = dms_device_alloc(&d, N * 2))) return rc;
+  cam.last_depth = (unsigned short*)d;
+  for (int i = 0; i < 16; ++i) cam.pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+  return DMS_OK;
+}
+void free_camera(Camera& cam) {
+  if (cam.f) dms_fusion_destroy(cam.f);
+  if (cam.last_rgb) dms_device_free(cam.last_rgb);
+  if (cam.last_depth) dms_device_free(cam.last_depth);
+  cam = Camera();
+}
+int make_ferns(dms_session* s, dms_ferns** out) {
+  const dms_fusion_params& c = s->p.camera;
+  return dms_ferns_create(out, s->p.fern_num, s->p.fern_max_depth_mm, s->p.fern_photo_thresh, s->W, s->H, c.cx, c.cy, c.fx, c.fy, s->p.fern_seed,
+                          s->p.fern_capacity);
+}
+
+void rebase(Camera& cam, const float* T) {  // kv.second->poseGraph()[i].second = relativeTransform * ... (ReferenceFrame.h:138-141)
+  for (size_t i = 0; i < cam.pg_tick.size(); ++i) dms_pose_compose(T, &cam.pg_pose[i * 16], &cam.pg_pose[i * 16]);
+}
+
+Camera* owner_of(dms_session* s, int fb) {
+  for (auto& kv : s->cams)
+    if (s->frame_of[kv.first] == fb) return &kv.second;
+  return nullptr;
+}
+
+// ReferenceFrame::resolveRelativeTransformationFern's second half for camera a against frame fb, on fb's rank; every rank ends with the
+// same {accepted, relativeTransform}
+int refine(dms_session* s, int a, int fb, const float* rec16, const float* curr16, int tick, int* accepted, float* T16, dms_stream st) {
+  const int ha = host_of_camera(s, a), hb = s->host_of_frame.at(fb);
+  const size_t N = (size_t)s->W * s->H;
+  float res[17];
+  memset(res, 0, sizeof(res));
+  int rc = DMS_OK;
+  if (hb == s->rank) {
+    Camera* owner = owner_of(s, fb);
+    DMS_REQUIRE(owner, "the matched frame has no camera here");
+    if (!s->refiners.count(fb)) {
+      const dms_fusion_params& c = s->p.camera;
+      dms_refframe* r = nullptr;
+      if ((rc = dms_refframe_create(&r, s->W, s->H, c.cx, c.cy, c.fx, c.fy))) return rc;
+      s->refiners[fb] = r;
+    }
+    const float *vtx, *nrm;
+    const void* img;
+    if (ha == s->rank) {
+      dms_image2d vi, vv, vn;
+      dms_fusion* q = s->cams.at(a).f;
+      if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) return rc;
+      img = vi.data;
+      vtx = (const float*)vv.data;
+      nrm = (const float*)vn.data;
+    } else {
+      if ((rc = t_recv(s, s->d_tex, N * 4, ha, st)) || (rc = t_recv(s, s->d_tex + N * 4, N * 16, ha, st)) ||
+          (rc = t_recv(s, s->d_tex + N * 20, N * 16, ha, st)) || (rc = sync(st)))
+        return rc;
+      img = s->d_tex;
+      vtx = (const float*)(s->d_tex + N * 4);
+      nrm = (const float*)(s->d_tex + N * 20);
+    }
+    double conf = 0.0;
+    if ((rc = dms_fusion_get_option(owner->f, DMS_OPT_CONFIDENCE, &conf))) return rc;
+    dms_intermap_result r;
+    if ((rc = dms_refframe_refine(s->refiners[fb], dms_fusion_model(owner->f), rec16, curr16, vtx, nrm, img, (int)s->p.camera.maxDepthProcessed,
+                                  (float)conf, a, s->p.camera.timeDelta, tick, s->p.cov_thresh, s->p.icp_err_thresh, s->p.icp_count_thresh, &r, st)))
+      return rc;
+    res[0] = r.accepted ? 1.f : 0.f;
+    memcpy(res + 1, r.relativeTransform, 64);
+  } else if (ha == s->rank) {
+    dms_image2d vi, vv, vn;
+    dms_fusion* q = s->cams.at(a).f;
+    if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) return rc;
+    if ((rc = t_send(s, vi.data, N * 4, hb, st)) || (rc = t_send(s, vv.data, N * 16, hb, st)) || (rc = t_send(s, vn.data, N * 16, hb, st)) ||
+        (rc = sync(st)))
+      return rc;
+  }
+  if (!s->local_only) {
+    if (hb == s->rank && (rc = dms_memcpy_h2d(s->d_small, res, sizeof(res), st))) return rc;
+    if ((rc = t_bcast(s, s->d_small, sizeof(res), hb, st)) || (rc = sync(st)) || (rc = dms_memcpy_d2h(res, s->d_small, sizeof(res), st))) return rc;
+  }
+  *accepted = res[0] == 1.f ? 1 : 0;
+  memcpy(T16, res + 1, 64);
+  return DMS_OK;
+}
+
+struct MigrationHeader {  // per moving camera, consumed side -> consuming side
+  int tick, n_pg, has_frame, pad;
+  float pose[16];
+};
+
+// reference frame fb consumes fa (ReferenceFrame::consumeReferenceFrame)
+int merge(dms_session* s, int k, int fb, int fa, const float* T, dms_stream st) {
+  const int hb = s->host_of_frame.at(fb), ha = s->host_of_frame.at(fa);
+  std::vector<int> moving;
+  for (int c = 0; c < s->n; ++c)
+    if (s->frame_of[c] == fa) moving.push_back(c);
+  const size_t N = (size_t)s->W * s->H;
+  int rc = DMS_OK;
+  if (hb == ha) {
+    if (hb == s->rank) {
+      Camera* owner = owner_of(s, fb);
+      DMS_REQUIRE(owner, "the consuming frame has no camera here");
+      // the camera that owns fa's map carries it over, the rest only move (dms_fusion_join_map)
+      std::vector<int> order = moving;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (x != fa) < (y != fa) || ((x != fa) == (y != fa) && x < y); });
+      for (int c : order) {
+        Camera& cam = s->cams.at(c);
+        if ((rc = dms_fusion_join_map(cam.f, owner->f, T, st))) return rc;
+        dms_pose_compose(T, cam.pose, cam.pose);
+        rebase(cam, T);
+      }
+      int added = 0;
+      if ((rc = dms_ferns_consume(s->ferns.at(fb), s->ferns.at(fa), T, s->p.fern_threshold, &added, st))) return rc;
+      dms_ferns_destroy(s->ferns.at(fa));
+      s->ferns.erase(fa);
+    }
+  } else if (ha == s->rank) {  // the consumed side: ship everything, free the local copies
+    Camera& founder = s->cams.at(fa);
+    dms_model* m = dms_fusion_model(founder.f);
+    unsigned cnt = 0;
+    if ((rc = dms_model_count(m, &cnt, st))) return rc;
+    long long hdr[2] = {(long long)cnt, (long long)dms_ferns_num_frames(s->ferns.at(fa))};
+    if ((rc = send_host(s, hdr, sizeof(hdr), hb, st))) return rc;
+    if (cnt) {
+      void* rec = nullptr;
+      if ((rc = dms_device_alloc(&rec, (size_t)cnt * 80))) return rc;
+      unsigned got = 0;
+      rc = dms_model_export_records(m, (float*)rec, cnt, &got, st);
+      if (!rc) rc = sync(st);
+      if (!rc && got != cnt) {
+        set_error("dms_session: the map changed while it was exported");
+        rc = DMS_ERR_STATE;
+      }
+      if (!rc) rc = t_send(s, rec, (size_t)cnt * 80, hb, st);
+      if (!rc) rc = sync(st);
+      dms_device_free(rec);
+      if (rc) return rc;
+    }
+    if (hdr[1]) {
+      const size_t rb = dms_ferns_record_bytes(s->ferns.at(fa));
+      void* rec = nullptr;
+      if ((rc = dms_device_alloc(&rec, (size_t)hdr[1] * rb))) return rc;
+      int got = 0;
+      rc = dms_ferns_export_records(s->ferns.at(fa), rec, (int)hdr[1], &got, st);
+      if (!rc) rc = sync(st);
+      if (!rc && got != (int)hdr[1]) {
+        set_error("dms_session: the key-frame database changed while it was exported");
+        rc = DMS_ERR_STATE;
+      }
+      if (!rc) rc = t_send(s, rec, (size_t)hdr[1] * rb, hb, st);
+      if (!rc) rc = sync(st);
+      dms_device_free(rec);
+      if (rc) return rc;
+    }
+    for (int c : moving) {
+      Camera& cam = s->cams.at(c);
+      MigrationHeader h;
+      memset(&h, 0, sizeof(h));
+      h.tick = cam.tick;
+      h.n_pg = (int)cam.pg_tick.size();
+      h.has_frame = cam.has_frame ? 1 : 0;
+      memcpy(h.pose, cam.pose, 64);
+      if ((rc = send_host(s, &h, sizeof(h), hb, st))) return rc;
+      if ((rc = t_send(s, cam.last_rgb, N * 3, hb, st)) || (rc = t_send(s, cam.last_depth, N * 2, hb, st)) || (rc = sync(st))) return rc;
+      if ((rc = send_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, hb, st)) || (rc = send_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, hb, st)))
+        return rc;
+    }
+    // joined / imported cameras first: the map's owner outlives them
+    for (int c : moving)
+      if (c != fa) {
+        free_camera(s->cams.at(c));
+        s->cams.erase(c);
+      }
+    free_camera(s->cams.at(fa));
+    s->cams.erase(fa);
+    dms_ferns_destroy(s->ferns.at(fa));
+    s->ferns.erase(fa);
+  } else if (hb == s->rank) {  // the consuming side
+    Camera* owner = owner_of(s, fb);
+    DMS_REQUIRE(owner, "the consuming frame has no camera here");
+    long long hdr[2] = {0, 0};
+    if ((rc = recv_host(s, hdr, sizeof(hdr), ha, st))) return rc;
+    if (hdr[0]) {
+      void* rec = nullptr;
+      if ((rc = dms_device_alloc(&rec, (size_t)hdr[0] * 80))) return rc;
+      rc = t_recv(s, rec, (size_t)hdr[0] * 80, ha, st);
+      if (!rc) rc = sync(st);
+      if (!rc) rc = dms_model_consume_records(dms_fusion_model(owner->f), (const float*)rec, (unsigned)hdr[0], T, st);
+      if (!rc) rc = sync(st);
+      dms_device_free(rec);
+      if (rc) return rc;
+    }
+    if (hdr[1]) {
+      const size_t rb = dms_ferns_record_bytes(s->ferns.at(fb));
+      void* rec = nullptr;
+      if ((rc = dms_device_alloc(&rec, (size_t)hdr[1] * rb))) return rc;
+      int added = 0;
+      rc = t_recv(s, rec, (size_t)hdr[1] * rb, ha, st);
+      if (!rc) rc = sync(st);
+      if (!rc) rc = dms_ferns_consume_records(s->ferns.at(fb), rec, (int)hdr[1], T, s->p.fern_threshold, &added, st);
+      dms_device_free(rec);
+      if (rc) return rc;
+    }
+    for (int c : moving) {
+      MigrationHeader h;
+      if ((rc = recv_host(s, &h, sizeof(h), ha, st))) return rc;
+      Camera& cam = s->cams[c];
+      if ((rc = make_camera(s, c, cam))) return rc;
+      if ((rc = t_recv(s, cam.last_rgb, N * 3, ha, st)) || (rc = t_recv(s, cam.last_depth, N * 2, ha, st)) || (rc = sync(st))) return rc;
+      cam.pg_tick.resize(h.n_pg);
+      cam.pg_pose.resize((size_t)h.n_pg * 16);
+      if ((rc = recv_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, ha, st)) || (rc = recv_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, ha, st)))
+        return rc;
+      float moved[16];
+      dms_pose_compose(T, h.pose, moved);
+      if ((rc = dms_fusion_import_camera(cam.f, owner->f, moved, h.tick, cam.last_rgb, 3, cam.last_depth, st))) return rc;
+      cam.tick = h.tick;
+      memcpy(cam.pose, moved, 64);
+      cam.has_frame = h.has_frame != 0;
+      rebase(cam, T);
+    }
+  }
+  for (int c : moving) s->frame_of[c] = fb;
+  if (s->refiners.count(fa)) {  // (the consumed reference frame is erased, ElasticFusion.cpp:610-616)
+    dms_refframe_destroy(s->refiners.at(fa));
+    s->refiners.erase(fa);
+  }
+  s->host_of_frame.erase(fa);
+  Merge mg;
+  mg.k = k;
+  mg.fb = fb;
+  mg.fa = fa;
+  memcpy(mg.T, T, 64);
+  s->merges.push_back(mg);
+  return DMS_OK;
+}
+
+int query(dms_session* s, int k, const std::vector<int>& host_counts, int slots, std::map<int, std::vector<float>>& poses, std::map<int, int>& ticks,
+          std::map<int, const unsigned char*>& blocks, float* table, dms_stream st) {
+  // owner computes: every hosted reference frame against every camera of another frame
+  (void)host_counts;
+  (void)slots;
+  for (auto& kv : s->ferns) {
+    const int fb = kv.first;
+    for (int a = 0; a < s->n; ++a) {
+      if (s->frame_of[a] == fb || k < s->p.query_from) continue;
+      dms_fern_match m;
+      int rc = dms_ferns_find_frame_thumbs(kv.second, blocks.at(a), poses.at(a).data(), ticks.at(a), 0, s->p.inter_map, &m, nullptr, st);
+      if (rc) return rc;
+      float* e = table + ((size_t)a * s->n + fb) * kRow;
+      e[0] = 1.f;
+      e[1] = (float)m.closest;
+      memcpy(e + 2, m.estPose, 64);
+    }
+  }
+  return DMS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dms_session_default_params(dms_session_params* p, int n_cameras, int width, int height, float fx, float fy, float cx, float cy) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->n_cameras = n_cameras;
+  dms_fusion_default_params(&p->camera, width, height, fx, fy, cx, cy);
+  p->camera.num_sensors = n_cameras > 3 ? n_cameras : 3;
+  p->fern_num = 500;             // ReferenceFrame.h:17
+  p->fern_max_depth_mm = 3000;   // Options::depth (3 m) * 1000
+  p->fern_photo_thresh = 115.f;  // Options::interMapPhotoThresh
+  p->fern_seed = 20260929u;
+  p->fern_capacity = 1024;
+  p->fern_threshold = 0.3095f;   // Options::fernThresh
+  p->inter_map = 1;
+  p->query_from = 0;
+  p->full_refine = 1;
+  p->cov_thresh = 1e-05f;        // Options.h:91-94
+  p->icp_err_thresh = 2e-05f;
+  p->icp_count_thresh = 35000.f;
+}
+
+static int rccl_allgather(void* c, const void* s, void* r, size_t b, dms_stream st) { return dms_collab_allgather((dms_collab*)c, s, r, b, st); }
+static int rccl_send(void* c, const void* s, size_t b, int p, dms_stream st) { return dms_collab_send((dms_collab*)c, s, b, p, st); }
+static int rccl_recv(void* c, void* d, size_t b, int p, dms_stream st) { return dms_collab_recv((dms_collab*)c, d, b, p, st); }
+static int rccl_bcast(void* c, void* buf, size_t b, int root, dms_stream st) {
+  // a broadcast of a few dozen bytes as an all-gather of every rank's copy: the root's is kept
+  dms_collab* cc = (dms_collab*)c;
+  const int w = dms_collab_size(cc);
+  void* all = nullptr;
+  int rc = dms_device_alloc(&all, b * (size_t)w);
+  if (rc) return rc;
+  rc = dms_collab_allgather(cc, buf, all, b, st);
+  if (!rc) rc = dms_memcpy_d2d_async(buf, (const char*)all + (size_t)root * b, b, st);
+  if (!rc) rc = dms_stream_sync(st);
+  dms_device_free(all);
+  return rc;
+}
+int dms_transport_rccl(dms_collab* c, dms_transport* out) {
+  DMS_REQUIRE(c && out, "null argument");
+  out->ctx = c;
+  out->rank = dms_collab_rank(c);
+  out->world = dms_collab_size(c);
+  out->allgather = rccl_allgather;
+  out->send = rccl_send;
+  out->recv = rccl_recv;
+  out->broadcast = rccl_bcast;
+  return DMS_OK;
+}
+
+int dms_session_create(dms_session** out, const dms_session_params* p, const dms_transport* t) {
+  DMS_REQUIRE(out && p, "null argument");
+  DMS_REQUIRE(p->n_cameras >= 1 && p->n_cameras <= DMS_MAX_SENSORS, "1 <= n_cameras <= DMS_MAX_SENSORS (a merged map holds every camera's time slot)");
+  DMS_REQUIRE(p->camera.num_sensors >= p->n_cameras, "num_sensors < n_cameras: a merge would fail at join / import");
+  DMS_REQUIRE(!t || (t->allgather && t->send && t->recv && t->broadcast && t->world >= 1 && t->rank >= 0 && t->rank < t->world), "incomplete transport");
+  dms_session* s = new dms_session();
+  s->p = *p;
+  if (t) {
+    s->t = *t;
+    s->rank = t->rank;
+    s->world = t->world;
+    s->local_only = t->world == 1;
+  }
+  s->n = p->n_cameras;
+  s->W = p->camera.width;
+  s->H = p->camera.height;
+  s->thumb_bytes = (size_t)(s->W / 8) * (s->H / 8) * 36;
+  s->block_bytes = s->thumb_bytes + kMetaBytes;
+  s->frame_of.resize(s->n);
+  int rc = DMS_OK;
+  for (int c = 0; c < s->n && !rc; ++c) {
+    s->frame_of[c] = c;
+    s->host_of_frame[c] = c % s->world;
+    if (c % s->world == s->rank) {
+      rc = make_camera(s, c, s->cams[c]);
+      if (!rc) rc = make_ferns(s, &s->ferns[c]);
+    }
+  }
+  const size_t N = (size_t)s->W * s->H;
+  void* d = nullptr;
+  auto alloc = [&](size_t bytes) -> void* {
+    if (rc) return nullptr;
+    d = nullptr;
+    rc = dms_device_alloc(&d, bytes);
+    if (!rc) rc = dms_memset(d, 0, bytes, nullptr);
+    return d;
+  };
+  s->d_local = (unsigned char*)alloc((size_t)s->n * s->block_bytes);
+  s->d_gathered = (unsigned char*)alloc((size_t)s->world * s->n * s->block_bytes);
+  s->d_table = (float*)alloc((size_t)(1 + s->world) * (s->n + 1) * s->n * kRow * 4);
+  s->d_pose = (float*)alloc(64);
+  s->d_small = (float*)alloc(256);
+  s->d_frame_rgb = alloc(N * 3);
+  s->d_frame_depth = (unsigned short*)alloc(N * 2);
+  s->d_tex = (unsigned char*)alloc(N * 36);
+  if (rc) {
+    dms_session_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return DMS_OK;
+}
+
+int dms_session_destroy(dms_session* s) {
+  if (!s) return DMS_OK;
+  // joined cameras first: their owner must outlive them
+  for (auto it = s->cams.begin(); it != s->cams.end();) {
+    if (s->frame_of[it->first] != it->first) {
+      free_camera(it->second);
+      it = s->cams.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  for (auto& kv : s->cams) free_camera(kv.second);
+  for (auto& kv : s->ferns) dms_ferns_destroy(kv.second);
+  for (auto& kv : s->refiners) dms_refframe_destroy(kv.second);
+  void* bufs[] = {s->d_local, s->d_gathered, s->d_table, s->d_pose, s->d_small, s->d_frame_rgb, s->d_frame_depth, s->d_tex};
+  for (void* b : bufs)
+    if (b) dms_device_free(b);
+  delete s;
+  return DMS_OK;
+}
+
+int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st) {
+  DMS_REQUIRE(s && rgb_dev && depth_dev, "null argument");
+  const size_t N = (size_t)s->W * s->H;
+  int rc = DMS_OK;
+  // 1 + 2. forward the frames of cameras hosted elsewhere; every hosted camera's frame, in id order.  (A frame that arrives from
+  // another rank is processed when its camera's turn comes: receive and process are interleaved in camera order on both sides.)
+  std::map<int, int> read_index;  // camera read here -> position in rgb_dev / depth_dev
+  {
+    int i = 0;
+    for (int c = 0; c < s->n; ++c)
+      if (c % s->world == s->rank) read_index[c] = i++;
+  }
+  for (int c = 0; c < s->n; ++c) {
+    const int src = c % s->world, host = host_of_camera(s, c);
+    if (src != host && src == s->rank) {
+      const int i = read_index.at(c);
+      if ((rc = t_send(s, rgb_dev[i], N * 3, host, st)) || (rc = t_send(s, depth_dev[i], N * 2, host, st)) || (rc = sync(st))) return rc;
+    }
+    if (host != s->rank) continue;
+    const void* rgb;
+    const unsigned short* dep;
+    if (src == s->rank) {
+      rgb = rgb_dev[read_index.at(c)];
+      dep = depth_dev[read_index.at(c)];
+    } else {
+      if ((rc = t_recv(s, s->d_frame_rgb, N * 3, src, st)) || (rc = t_recv(s, s->d_frame_depth, N * 2, src, st)) || (rc = sync(st))) return rc;
+      rgb = s->d_frame_rgb;
+      dep = s->d_frame_depth;
+    }
+    Camera& cam = s->cams.at(c);
+    const int tick_before = cam.tick;
+    if ((rc = dms_fusion_process_frame(cam.f, rgb, 3, dep, nullptr, 1.f, st))) return rc;
+    rc = dms_fusion_fetch(cam.f, &cam.last, st);
+    if (rc && rc != DMS_ERR_CAPACITY) return rc;
+    cam.tick = cam.last.tick;
+    memcpy(cam.pose, cam.last.pose, 64);
+    cam.pg_tick.push_back(tick_before);
+    cam.pg_pose.insert(cam.pg_pose.end(), cam.pose, cam.pose + 16);
+    if ((rc = dms_memcpy_d2d_async(cam.last_rgb, rgb, N * 3, st)) || (rc = dms_memcpy_d2d_async(cam.last_depth, dep, N * 2, st)) || (rc = sync(st))) return rc;
+    cam.has_frame = true;
+  }
+  // 3. publish: own map's database, then the all-gather (slots per rank = the most cameras any rank hosts)
+  std::vector<int> host_counts(s->world, 0);
+  for (int c = 0; c < s->n; ++c) host_counts[host_of_camera(s, c)] += 1;
+  const int slots = *std::max_element(host_counts.begin(), host_counts.end());
+  if ((rc = dms_memset(s->d_local, 0, (size_t)slots * s->block_bytes, st))) return rc;
+  {
+    int i = 0;
+    for (auto& kv : s->cams) {
+      const int c = kv.first;
+      Camera& cam = kv.second;
+      unsigned char* blk = s->d_local + (size_t)i * s->block_bytes;
+      if ((rc = dms_fusion_thumbnails(cam.f, blk, st))) return rc;
+      float meta[kMetaBytes / 4];
+      memset(meta, 0, sizeof(meta));
+      const int ids[2] = {c, cam.tick};
+      memcpy(meta, ids, 8);
+      memcpy(meta + 4, cam.pose, 64);
+      if ((rc = dms_memcpy_h2d(blk + s->thumb_bytes, meta, kMetaBytes, st))) return rc;
+      if (!cam.last.lost) {  // processFerns sits under `if (!lost)` (ElasticFusion.cpp:588-591)
+        if ((rc = dms_ferns_add_frame_async(s->ferns.at(s->frame_of[c]), nullptr, nullptr, nullptr, blk, nullptr, (const float*)(blk + s->thumb_bytes + 16),
+                                            cam.tick, s->p.fern_threshold, st)))
+          return rc;
+        if ((rc = sync(st))) return rc;
+      }
+      ++i;
+    }
+  }
+  const size_t per_rank = (size_t)slots * s->block_bytes;
+  if ((rc = t_allgather(s, s->d_local, s->d_gathered, per_rank, st)) || (rc = sync(st))) return rc;
+  std::map<int, std::vector<float>> poses;
+  std::map<int, int> ticks;
+  std::map<int, const unsigned char*> blocks;
+  for (int r = 0; r < s->world; ++r)
+    for (int i = 0; i < host_counts[r]; ++i) {
+      const unsigned char* raw = s->d_gathered + (size_t)r * per_rank + (size_t)i * s->block_bytes;
+      float meta[kMetaBytes / 4];
+      if ((rc = dms_memcpy_d2h(meta, raw + s->thumb_bytes, kMetaBytes, st))) return rc;
+      int ids[2];
+      memcpy(ids, meta, 8);
+      DMS_REQUIRE(ids[0] >= 0 && ids[0] < s->n, "a gathered block names no camera of this session");
+      blocks[ids[0]] = raw;
+      ticks[ids[0]] = ids[1];
+      poses[ids[0]] = std::vector<float>(meta + 4, meta + 20);
+    }
+  // 4. queries.  A failure on one rank must not leave the others waiting in the next collective: it travels in the table's last
+  // row and every rank returns together.
+  const size_t tab_floats = (size_t)(s->n + 1) * s->n * kRow;
+  std::vector<float> table(tab_floats, 0.f), tables(tab_floats * s->world, 0.f);
+  int qrc = query(s, k, host_counts, slots, poses, ticks, blocks, table.data(), st);
+  if (qrc) table[(size_t)s->n * s->n * kRow] = 1.f;
+  if ((rc = dms_memcpy_h2d(s->d_table, table.data(), tab_floats * 4, st))) return rc;
+  if ((rc = t_allgather(s, s->d_table, s->d_table + tab_floats, tab_floats * 4, st)) || (rc = sync(st))) return rc;
+  if ((rc = dms_memcpy_d2h(tables.data(), s->d_table + tab_floats, tab_floats * 4 * s->world, st))) return rc;
+  for (int r = 0; r < s->world; ++r)
+    if (tables[(size_t)r * tab_floats + (size_t)s->n * s->n * kRow] != 0.f) {
+      if (!qrc) set_error("dms_session_step: the inter-map query failed on rank %d at tick %d", r, k);
+      return qrc ? qrc : DMS_ERR_STATE;
+    }
+  // 5. the same walk on every rank (cameras in id order, frames in id order; first accepted candidate wins, one merge per frame and tick)
+  struct Decided {
+    int fb, fa;
+    float T[16];
+  };
+  std::vector<Decided> decided;
+  std::set<int> busy;
+  for (int a = 0; a < s->n; ++a) {
+    const int fa = s->frame_of[a];
+    if (busy.count(fa) || k < s->p.query_from) continue;
+    std::set<int> frames(s->frame_of.begin(), s->frame_of.end());
+    for (int fb : frames) {
+      if (fb == fa || busy.count(fb)) continue;
+      const float* e = &tables[(size_t)s->host_of_frame.at(fb) * tab_floats + ((size_t)a * s->n + fb) * kRow];
+      DMS_REQUIRE(e[0] == 1.f, "no verification result for a camera / frame pair");
+      if (e[1] < 0.f) continue;
+      Decided d;
+      d.fb = fb;
+      d.fa = fa;
+      if (s->p.full_refine) {
+        int accepted = 0;
+        if ((rc = refine(s, a, fb, e + 2, poses.at(a).data(), ticks.at(a), &accepted, d.T, st))) return rc;
+        s->refinements.push_back(Refinement{k, a, fb, accepted});
+        if (!accepted) continue;
+      } else {
+        dms_relative_transform(e + 2, poses.at(a).data(), d.T);
+      }
+      decided.push_back(d);
+      busy.insert(fa);
+      busy.insert(fb);
+      break;
+    }
+  }
+  // 6. merges
+  for (auto& d : decided)
+    if ((rc = merge(s, k, d.fb, d.fa, d.T, st))) return rc;
+  return DMS_OK;
+}
+
+int dms_session_frame_of(dms_session* s, int* frame_of) {
+  DMS_REQUIRE(s && frame_of, "null argument");
+  for (int c = 0; c < s->n; ++c) frame_of[c] = s->frame_of[c];
+  return DMS_OK;
+}
+int dms_session_host_of_frame(dms_session* s, int frame) {
+  if (!s) return -1;
+  auto it = s->host_of_frame.find(frame);
+  return it == s->host_of_frame.end() ? -1 : it->second;
+}
+int dms_session_num_merges(dms_session* s) { return s ? (int)s->merges.size() : 0; }
+int dms_session_get_merge(dms_session* s, int i, int* k, int* fb, int* fa, float* T16) {
+  DMS_REQUIRE(s && i >= 0 && i < (int)s->merges.size(), "no such merge");
+  const Merge& m = s->merges[i];
+  if (k) *k = m.k;
+  if (fb) *fb = m.fb;
+  if (fa) *fa = m.fa;
+  if (T16) memcpy(T16, m.T, 64);
+  return DMS_OK;
+}
+int dms_session_num_refinements(dms_session* s) { return s ? (int)s->refinements.size() : 0; }
+int dms_session_get_refinement(dms_session* s, int i, int* k, int* camera, int* frame, int* accepted) {
+  DMS_REQUIRE(s && i >= 0 && i < (int)s->refinements.size(), "no such refinement");
+  const Refinement& r = s->refinements[i];
+  if (k) *k = r.k;
+  if (camera) *camera = r.a;
+  if (frame) *frame = r.fb;
+  if (accepted) *accepted = r.accepted;
+  return DMS_OK;
+}
+int dms_session_hosted(dms_session* s, int* cameras, int max, int* n) {
+  DMS_REQUIRE(s && n, "null argument");
+  int i = 0;
+  for (auto& kv : s->cams) {
+    if (cameras && i < max) cameras[i] = kv.first;
+    ++i;
+  }
+  *n = i;
+  return DMS_OK;
+}
+dms_fusion* dms_session_camera(dms_session* s, int camera) {
+  if (!s) return nullptr;
+  auto it = s->cams.find(camera);
+  return it == s->cams.end() ? nullptr : it->second.f;
+}
+dms_ferns* dms_session_ferns(dms_session* s, int frame) {
+  if (!s) return nullptr;
+  auto it = s->ferns.find(frame);
+  return it == s->ferns.end() ? nullptr : it->second;
+}
+int dms_session_last_result(dms_session* s, int camera, dms_frame_result* r) {
+  DMS_REQUIRE(s && r && s->cams.count(camera), "the camera is not hosted here");
+  *r = s->cams.at(camera).last;
+  return DMS_OK;
+}
+int dms_session_pose_graph(dms_session* s, int camera, int* ticks, float* poses16, int max, int* n) {
+  DMS_REQUIRE(s && n && s->cams.count(camera), "the camera is not hosted here");
+  const Camera& cam = s->cams.at(camera);
+  *n = (int)cam.pg_tick.size();
+  for (int i = 0; i < *n && i < max; ++i) {
+    if (ticks) ticks[i] = cam.pg_tick[i];
+    if (poses16) memcpy(poses16 + (size_t)i * 16, &cam.pg_pose[(size_t)i * 16], 64);
+  }
+  return DMS_OK;
+}
+
+}  // extern "C"

@@ -489,3 +489,227 @@ class GpuBackend:
             s = np.float32(s + np.float32(T[i, 2] * p[2]))
             o[i] = np.float32(s + T[i, 3])
         return o
+
+
+# ---- the session behind the C ABI (include/dmslam_session.h, csrc/session.hip) -----------------------------------------------------
+import ctypes as _C  # noqa: E402
+
+
+def _native():
+    from . import capi, fusion
+
+    lib = capi.lib
+    if getattr(lib, "_dms_session_bound", False):
+        return lib, capi, fusion
+
+    class SessionParams(_C.Structure):
+        _fields_ = [("n_cameras", _C.c_int), ("camera", fusion.FusionParams), ("fern_num", _C.c_int), ("fern_max_depth_mm", _C.c_int),
+                    ("fern_capacity", _C.c_int), ("fern_photo_thresh", _C.c_float), ("fern_seed", _C.c_uint), ("fern_threshold", _C.c_float),
+                    ("inter_map", _C.c_int), ("query_from", _C.c_int), ("full_refine", _C.c_int), ("cov_thresh", _C.c_float),
+                    ("icp_err_thresh", _C.c_float), ("icp_count_thresh", _C.c_float)]
+
+    FN_AG = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_void_p)
+    FN_SR = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_int, _C.c_void_p)
+
+    class Transport(_C.Structure):
+        _fields_ = [("ctx", _C.c_void_p), ("rank", _C.c_int), ("world", _C.c_int), ("allgather", FN_AG), ("send", FN_SR), ("recv", FN_SR),
+                    ("broadcast", FN_SR)]
+
+    P = _C.c_void_p
+    lib.dms_session_default_params.argtypes = [_C.POINTER(SessionParams), _C.c_int, _C.c_int, _C.c_int, _C.c_float, _C.c_float, _C.c_float, _C.c_float]
+    lib.dms_session_default_params.restype = None
+    lib.dms_session_create.argtypes = [_C.POINTER(P), _C.POINTER(SessionParams), _C.POINTER(Transport)]
+    lib.dms_session_destroy.argtypes = [P]
+    lib.dms_session_step.argtypes = [P, _C.c_int, _C.POINTER(P), _C.POINTER(P), P]
+    lib.dms_session_frame_of.argtypes = [P, _C.POINTER(_C.c_int)]
+    lib.dms_session_host_of_frame.argtypes = [P, _C.c_int]
+    lib.dms_session_num_merges.argtypes = [P]
+    lib.dms_session_get_merge.argtypes = [P, _C.c_int, _C.POINTER(_C.c_int), _C.POINTER(_C.c_int), _C.POINTER(_C.c_int), _C.POINTER(_C.c_float)]
+    lib.dms_session_num_refinements.argtypes = [P]
+    lib.dms_session_get_refinement.argtypes = [P, _C.c_int] + [_C.POINTER(_C.c_int)] * 4
+    lib.dms_session_hosted.argtypes = [P, _C.POINTER(_C.c_int), _C.c_int, _C.POINTER(_C.c_int)]
+    lib.dms_session_camera.argtypes = [P, _C.c_int]
+    lib.dms_session_camera.restype = P
+    lib.dms_session_ferns.argtypes = [P, _C.c_int]
+    lib.dms_session_ferns.restype = P
+    lib.dms_session_last_result.argtypes = [P, _C.c_int, _C.POINTER(fusion.FrameResult)]
+    lib.dms_session_pose_graph.argtypes = [P, _C.c_int, _C.POINTER(_C.c_int), _C.POINTER(_C.c_float), _C.c_int, _C.POINTER(_C.c_int)]
+    lib.dms_transport_rccl.argtypes = [P, _C.POINTER(Transport)]
+    lib.dms_ferns_num_frames.argtypes = [P]
+    lib._dms_session_types = (SessionParams, Transport, FN_AG, FN_SR)
+    lib._dms_session_bound = True
+    return lib, capi, fusion
+
+
+class TorchTransport:
+    """A dms_transport over torch.distributed for process groups whose tensors live on the host (gloo): device bytes are staged
+    through host arrays around every call.  What the tests use to run the compiled session with two ranks on a one-GPU box; on the
+    node itself the transport is RCCL (dms_transport_rccl)."""
+
+    def __init__(self, rank, world):
+        lib, capi, _ = _native()
+        _, Transport, FN_AG, FN_SR = lib._dms_session_types
+        self.lib, self.rank, self.world = lib, rank, world
+
+        def d2h(ptr, n):
+            a = np.empty(n, np.uint8)
+            capi.check(lib.dms_memcpy_d2h(a.ctypes.data_as(_C.c_void_p), _C.c_void_p(ptr), _C.c_size_t(n), None), "dms_memcpy_d2h")
+            return a
+
+        def h2d(ptr, a):
+            a = np.ascontiguousarray(a)
+            capi.check(lib.dms_memcpy_h2d(_C.c_void_p(ptr), a.ctypes.data_as(_C.c_void_p), _C.c_size_t(a.nbytes), None), "dms_memcpy_h2d")
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:  # noqa: BLE001 (a Python exception must not unwind through the C caller)
+                    import traceback
+
+                    traceback.print_exc()
+                    self.error = e
+                    return -9
+            return wrapped
+
+        def allgather(ctx, send, recv, n, st):
+            lib.dms_stream_sync(st)
+            l = torch.from_numpy(d2h(send, n))
+            g = [torch.empty(n, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(g, l)
+            h2d(recv, torch.cat(g).numpy())
+
+        def send(ctx, src, n, peer, st):
+            lib.dms_stream_sync(st)
+            dist.send(torch.from_numpy(d2h(src, n)), peer)
+
+        def recv(ctx, dst, n, peer, st):
+            t = torch.empty(n, dtype=torch.uint8)
+            dist.recv(t, peer)
+            h2d(dst, t.numpy())
+
+        def broadcast(ctx, buf, n, root, st):
+            lib.dms_stream_sync(st)
+            t = torch.from_numpy(d2h(buf, n))
+            dist.broadcast(t, root)
+            h2d(buf, t.numpy())
+
+        self.error = None
+        self._keep = (FN_AG(guard(allgather)), FN_SR(guard(send)), FN_SR(guard(recv)), FN_SR(guard(broadcast)))
+        self.struct = Transport(None, rank, world, *self._keep)
+
+
+class _NativeCamera:
+    def __init__(self, s, c):
+        self.s, self.c = s, c
+
+    def model(self):
+        lib, _, fusion = _native()
+        h = lib.dms_session_camera(self.s.h, self.c)
+        return fusion.GlobalModel(self.s.W, self.s.H, handle=lib.dms_fusion_model(h)).downloadMap()
+
+
+class _NativeFerns:
+    def __init__(self, s, f):
+        self.s, self.f = s, f
+
+    def __len__(self):
+        lib = _native()[0]
+        return int(lib.dms_ferns_num_frames(lib.dms_session_ferns(self.s.h, self.f)))
+
+
+class NativeSession:
+    """dms_session (include/dmslam_session.h): CollabSession's protocol compiled into the library, the product's engines behind it.
+    The same read-only surface as CollabSession (merges, refinements, frame_of, hosted(), cams[c].model(), len(ferns[f]),
+    pose_graph[c]), so that the session tests run either."""
+
+    def __init__(self, width, height, K, n_cameras, rank=0, world=1, transport=None, fern_photo_thresh=115.0, fern_capacity=1024,
+                 fern_threshold=0.3095, inter_map=1, query_from=0, full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05,
+                 icp_count_thresh=35000, **camera_opts):
+        lib, capi, _ = _native()
+        SessionParams = lib._dms_session_types[0]
+        p = SessionParams()
+        lib.dms_session_default_params(_C.byref(p), n_cameras, width, height, K[0], K[1], K[2], K[3])
+        for k, v in camera_opts.items():
+            if not hasattr(p.camera, k):
+                raise TypeError("unknown camera option %r" % k)
+            setattr(p.camera, k, v)
+        p.fern_photo_thresh, p.fern_capacity, p.fern_threshold = fern_photo_thresh, fern_capacity, fern_threshold
+        p.inter_map, p.query_from, p.full_refine = inter_map, query_from, 1 if full_refine else 0
+        p.cov_thresh, p.icp_err_thresh, p.icp_count_thresh = cov_thresh, icp_err_thresh, icp_count_thresh
+        self.W, self.H, self.n, self.rank, self.world = width, height, n_cameras, rank, world
+        self.transport = transport
+        h = _C.c_void_p()
+        capi.check(lib.dms_session_create(_C.byref(h), _C.byref(p), _C.byref(transport.struct) if transport is not None else None), "dms_session_create")
+        self.h, self.lib, self.capi = h, lib, capi
+        N = width * height
+        self._read = [c for c in range(n_cameras) if c % world == rank]
+        self._rgb = [capi.DeviceBuffer(N * 3) for _ in self._read]
+        self._dep = [capi.DeviceBuffer(N * 2) for _ in self._read]
+
+    def step(self, k, my_frames):
+        """my_frames: {camera id: (rgb u8 HxWx3, depth u16 HxW)} for the cameras READ on this rank"""
+        P = _C.c_void_p
+        rgb, dep = (P * len(self._read))(), (P * len(self._read))()
+        for i, c in enumerate(self._read):
+            r, d = my_frames[c]
+            self._rgb[i].upload(np.ascontiguousarray(r, np.uint8))
+            self._dep[i].upload(np.ascontiguousarray(d, np.uint16))
+            rgb[i], dep[i] = self._rgb[i].ptr, self._dep[i].ptr
+        self.capi.check(self.lib.dms_session_step(self.h, int(k), rgb, dep, None), "dms_session_step")
+
+    # -- the read-only surface of CollabSession ---------------------------------------------------------------------------------
+    @property
+    def frame_of(self):
+        a = (_C.c_int * self.n)()
+        self.capi.check(self.lib.dms_session_frame_of(self.h, a))
+        return list(a)
+
+    def hosted(self):
+        a, n = (_C.c_int * self.n)(), _C.c_int(0)
+        self.capi.check(self.lib.dms_session_hosted(self.h, a, self.n, _C.byref(n)))
+        return [int(a[i]) for i in range(n.value)]
+
+    @property
+    def merges(self):
+        out = []
+        for i in range(self.lib.dms_session_num_merges(self.h)):
+            k, fb, fa, T = _C.c_int(0), _C.c_int(0), _C.c_int(0), (_C.c_float * 16)()
+            self.capi.check(self.lib.dms_session_get_merge(self.h, i, _C.byref(k), _C.byref(fb), _C.byref(fa), T))
+            out.append((k.value, fb.value, fa.value, np.array(T, np.float32).reshape(4, 4)))
+        return out
+
+    @property
+    def refinements(self):
+        out = []
+        for i in range(self.lib.dms_session_num_refinements(self.h)):
+            v = [_C.c_int(0) for _ in range(4)]
+            self.capi.check(self.lib.dms_session_get_refinement(self.h, i, *[_C.byref(x) for x in v]))
+            out.append((v[0].value, v[1].value, v[2].value, bool(v[3].value)))
+        return out
+
+    @property
+    def cams(self):
+        return {c: _NativeCamera(self, c) for c in self.hosted()}
+
+    @property
+    def ferns(self):
+        return {f: _NativeFerns(self, f) for f in sorted(set(self.frame_of)) if self.lib.dms_session_ferns(self.h, f)}
+
+    @property
+    def pose_graph(self):
+        out = {}
+        for c in self.hosted():
+            n = _C.c_int(0)
+            self.capi.check(self.lib.dms_session_pose_graph(self.h, c, None, None, 0, _C.byref(n)))
+            t, p = (_C.c_int * max(n.value, 1))(), (_C.c_float * (16 * max(n.value, 1)))()
+            self.capi.check(self.lib.dms_session_pose_graph(self.h, c, t, p, n.value, _C.byref(n)))
+            P = np.array(p, np.float32).reshape(-1, 4, 4)
+            out[c] = [(int(t[i]), P[i].copy()) for i in range(n.value)]
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dms_session_destroy(self.h)
+            self.h = None

@@ -55,15 +55,28 @@ def _check(ref, host, merges):
             assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
 
 
-def test_two_cameras_one_device_merge_and_continue(oracle_session):
+def _make_session(impl, sc, n, rank=0, world=1, capacity=2_000_000):
+    """impl "python": densemonoslam_amd.session.CollabSession (the protocol in Python over torch.distributed, product engines behind it);
+    "native": dms_session (include/dmslam_session.h: the same protocol compiled into the library, what a C++ front end links)."""
     import torch
 
-    from densemonoslam_amd import capi, session, synth
+    from densemonoslam_amd import session
+
+    if impl == "native":
+        tr = session.TorchTransport(rank, world) if world > 1 else None
+        return session.NativeSession(W, H, K, n, rank=rank, world=world, transport=tr, fern_photo_thresh=sc.fern_photo, model_capacity=capacity,
+                                     **sc.opts)
+    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=capacity)
+    return session.CollabSession(be, n, W, H, rank=rank, world=world, **sc.opts)
+
+
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_two_cameras_one_device_merge_and_continue(oracle_session, impl):
+    from densemonoslam_amd import capi, synth
 
     assert capi.device_count() >= 1, "no MI355X visible"
     sc = SCENARIOS[oracle_session.scenario]
-    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=2_000_000)
-    s = session.CollabSession(be, 2, W, H, **sc.opts)
+    s = _make_session(impl, sc, 2)
     for k in range(n_ticks(sc.name)):
         s.step(k, sc.frames(synth, k))
     assert s.refinements == [r[:4] for r in oracle_session.refinements]
@@ -73,7 +86,7 @@ def test_two_cameras_one_device_merge_and_continue(oracle_session):
     s.close()
 
 
-def _worker(rank, world, port, q, scenario):
+def _worker(rank, world, port, q, scenario, impl):
     sc = SCENARIOS[scenario]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["DMS_TRACK_MODE"] = "launches"  # two processes on one device must not spin side by side
@@ -83,8 +96,7 @@ def _worker(rank, world, port, q, scenario):
     from densemonoslam_amd import session, synth
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=2_000_000)
-    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **sc.opts)
+    s = _make_session(impl, sc, 2, rank, world)
     for k in range(n_ticks(scenario)):
         fr = sc.frames(synth, k)
         s.step(k, {c: fr[c] for c in fr if c % world == rank})
@@ -98,12 +110,13 @@ def _worker(rank, world, port, q, scenario):
     dist.destroy_process_group()
 
 
-def test_two_ranks_merge_across_processes_and_continue(oracle_session):
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_two_ranks_merge_across_processes_and_continue(oracle_session, impl):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, oracle_session.scenario)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, oracle_session.scenario, impl)) for r in range(world)]
     for p in procs:
         p.start()
     results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
@@ -119,7 +132,8 @@ def test_two_ranks_merge_across_processes_and_continue(oracle_session):
     _check(oracle_session, results[hb], results[hb]["merges"])
 
 
-def test_three_cameras_chained_merge_one_device(orc):
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_three_cameras_chained_merge_one_device(orc, impl):
     """A reference frame that already holds two cameras is consumed by a third map (ReferenceFrame::consumeReferenceFrame moves EVERY
     camera of the consumed frame, ReferenceFrame.h:127-145): frame 0 consumes camera 1's map at tick 6, then frame 2 consumes frame 0 -
     its founder carries the surfels over, the camera that had joined it only moves (dms_fusion_join_map on an already joined
@@ -140,8 +154,7 @@ def test_three_cameras_chained_merge_one_device(orc):
         return out
 
     ref = orc_pipeline.Session(3, W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts)
-    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=3_000_000)
-    s = session.CollabSession(be, 3, W, H, **sc.opts)
+    s = _make_session(impl, sc, 3, capacity=3_000_000)
     for k in range(ticks):
         fr = frames(k)
         ref.step([fr[0], fr[1], fr[2]], k)
