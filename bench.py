@@ -52,7 +52,7 @@ def pmc_passes(args, W, H):
             d = os.path.join(tmp, name)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", "r", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--width", str(W), "--height", str(H), "--no-cpu-baseline",
-                   "--no-kernel-pass", "--no-full-leg", "--no-config-legs", "--no-pmc"] + extra
+                   "--no-kernel-pass", "--no-full-leg", "--no-config-legs", "--no-session-leg", "--no-pmc"] + extra
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
             if r.returncode != 0:
                 return None
@@ -166,6 +166,7 @@ def main():
                     help="time the 'full' frame step: local loop closure on (INACTIVE prediction + model-to-model tracking every frame)")
     ap.add_argument("--no-full-leg", action="store_true", help="skip the extra 'full' (loop closure on) leg of the default run")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs for BASELINE configs 2 / 4, n_pred = 3 and the populated full step")
+    ap.add_argument("--no-session-leg", action="store_true", help="skip the collaborative-session leg (dms_session: two cameras, a merge by the reference's rule)")
     ap.add_argument("--time-delta", type=int, default=200,
                     help="active time window in frames (reference default 200); a small value with --loop-closure populates the INACTIVE "
                          "view on this cyclic stream, so the model-to-model tracker has correspondences")
@@ -470,6 +471,44 @@ def main():
             "C4": leg(dict(depthCut=40.0), "BASELINE config 4 geometry: 1241x376, KITTI intrinsics, 40 m depth cut-off, full 3-level ICP+RGB tracking "
                       "+ fusion (synthetic depth in place of the absent depth network)", (10, 5, 4), True, 2, 1, 1241, 376, synth.K_KITTI),
         }
+
+    # ---- the collaborative session behind the boundary (dms_session, include/dmslam_session.h), BASELINE config 5 in the small ----------
+    # Two cameras of one session on this GPU at 640 x 480 in the cluttered-corner scene, camera 1 eight frames ahead of camera 0 on the
+    # same path: independent maps, per-tick publish / query (Ferns::findFrame with interMap = 1 on each other's thumbnails), at tick 6
+    # the reference's rule verifies, the matched map's owner refines at full resolution (ReferenceFrame.h:72-110) and consumes the
+    # other map; from then on both cameras track against and fuse into ONE map.  Timed per tick with the host in the loop (the session
+    # synchronises where the reference does): before the merge, the merge tick itself, after it.  Not part of `value`.
+    if rank == 0 and not distributed and not args.loop_closure and not args.no_session_leg and (W, H) == (640, 480):
+        from densemonoslam_amd import session as session_mod
+
+        n_ticks, q_from, off = 22, 6, 8
+        sframes = [[synth.frame(k + o, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)[:2] for o in (0, off)] for k in range(n_ticks)]
+        ns = session_mod.NativeSession(W, H, K, 2, query_from=q_from, model_capacity=8_000_000)
+        tick_ms = []
+        for k in range(n_ticks):
+            fr = {c: (sframes[k][c][1], sframes[k][c][0]) for c in range(2)}
+            t1 = time.perf_counter()
+            ns.step(k, fr)
+            torch.cuda.synchronize()
+            tick_ms.append(1000.0 * (time.perf_counter() - t1))
+        mg, rf = ns.merges, ns.refinements
+        k_m = mg[0][0] if mg else None
+        pre = tick_ms[1:k_m] if k_m else tick_ms[1:]
+        post = tick_ms[k_m + 1:] if k_m is not None else []
+        out["session"] = {
+            "what": "dms_session (the session's protocol compiled into the library): 2 cameras on this GPU, %dx%d, cluttered-corner scene; per tick both "
+                    "cameras' frame steps, key-frame insertion, thumbnail exchange and the inter-map query (interMap = 1) of each camera against the "
+                    "other map; host in the loop (upload of both frames included)" % (W, H),
+            "merges": [(m[0], m[1], m[2]) for m in mg],
+            "refinements": rf,
+            "ms_per_tick_before_merge": round(float(np.mean(pre)), 3) if pre else None,
+            "frames_per_s_before_merge": round(2000.0 / float(np.mean(pre)), 1) if pre else None,
+            "ms_merge_tick": round(tick_ms[k_m], 3) if k_m is not None else None,
+            "ms_per_tick_after_merge": round(float(np.mean(post)), 3) if post else None,
+            "frames_per_s_after_merge": round(2000.0 / float(np.mean(post)), 1) if post else None,
+            "surfels_after": int(len(ns.cams[mg[0][1]].model())) if mg else None,
+        }
+        ns.close()
 
     # ---- per-kernel timing with HIP events on the launch stream (own passes, not in `value`) ------
     if rank == 0 and not args.no_kernel_pass:

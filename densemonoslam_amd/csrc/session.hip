@@ -441,7 +441,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
     s->t = *t;
     s->rank = t->rank;
     s->world = t->world;
-    s->local_only = t->world == 1;
+    s->local_only = false;  // (a one-rank communicator still carries the collectives: the RCCL calls are exercised on a one-GPU box)
   }
   s->n = p->n_cameras;
   s->W = p->camera.width;

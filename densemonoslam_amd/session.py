@@ -600,6 +600,19 @@ class TorchTransport:
         self.struct = Transport(None, rank, world, *self._keep)
 
 
+class RcclTransport:
+    """dms_transport_rccl over a communicator of include/dmslam_collab.h (collab.RcclCarrier): what the session uses on the node -
+    device buffers, stream-ordered RCCL calls, nothing staged through the host."""
+
+    def __init__(self, carrier):
+        lib, capi, _ = _native()
+        Transport = lib._dms_session_types[1]
+        self.carrier = carrier  # (keeps the communicator alive)
+        self.struct = Transport()
+        capi.check(lib.dms_transport_rccl(carrier.h, _C.byref(self.struct)), "dms_transport_rccl")
+        self.rank, self.world = int(self.struct.rank), int(self.struct.world)
+
+
 class _NativeCamera:
     def __init__(self, s, c):
         self.s, self.c = s, c

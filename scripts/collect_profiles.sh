@@ -6,7 +6,7 @@ tag=$1
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp PYTHONPATH=$PWD
-common="--steps 100 --warmup 10 --no-cpu-baseline --no-kernel-pass --no-full-leg --no-pmc --no-config-legs"
+common="--steps 100 --warmup 10 --no-cpu-baseline --no-kernel-pass --no-full-leg --no-pmc --no-config-legs --no-session-leg"
 rocprofv3 --kernel-trace --stats -d $out/kt -o r -- python bench.py $common > $out/bench_under_rocprof.json 2> $out/kt.err
 db=$(find $out/kt -name "*results.db" | head -1)
 python scripts/rocprof_summary.py $db 110 > $out/kernel_stats.txt
@@ -14,7 +14,7 @@ DMS_NO_PIPELINE=1 rocprofv3 --kernel-trace --stats -d $out/kt1 -o r -- python be
 db=$(find $out/kt1 -name "*results.db" | head -1)
 python scripts/rocprof_summary.py $db 110 > $out/kernel_stats_no_pipeline.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o r --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-full-leg --no-pmc --no-config-legs > /dev/null 2> $out/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o r --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-full-leg --no-pmc --no-config-legs --no-session-leg > /dev/null 2> $out/pmc_$c.err
 done
 python - <<P
 import csv, glob, json, collections

@@ -5,7 +5,7 @@ tag=$1; shift
 out=$PWD/gpurun_out/driver_$tag
 mkdir -p $out
 export TMPDIR=/tmp PYTHONPATH=$PWD
-common="--steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-full-leg --no-pmc --no-config-legs"
+common="--steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-full-leg --no-pmc --no-config-legs --no-session-leg"
 for i in 1 2 3; do python bench.py $common "$@" 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print('driver form', round(j['value'],1), 'surfels', j['config']['surfels_per_map'])"; done
 rocprofv3 --kernel-trace -d $out/kt -o r --output-format csv -- python bench.py $common "$@" > $out/bench.json 2> $out/kt.err
 python - "$out" <<'P'

@@ -178,3 +178,21 @@ def test_three_cameras_chained_merge_one_device(orc, impl):
         for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
             assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
     s.close()
+
+
+def test_native_session_over_a_one_rank_rccl_communicator(orc):
+    """The compiled session with the RCCL transport (dms_transport_rccl): a one-rank communicator is what a one-GPU box can form - both
+    cameras live on rank 0, and every collective of the protocol (block all-gather, table all-gather, the refinement's broadcast) is a
+    real ncclAllGather.  Same merge, same transform bits as the one-process oracle session."""
+    from densemonoslam_amd import capi, collab, session, synth
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    sc = SCENARIOS["reference_rule"]
+    ref = _ORACLE.get("reference_rule") or run_oracle_session("reference_rule", n_ticks("reference_rule"), relative_cons=False)
+    tr = session.RcclTransport(collab.RcclCarrier(0, 1, collab.RcclCarrier.unique_id()))
+    s = session.NativeSession(W, H, K, 2, rank=0, world=1, transport=tr, fern_photo_thresh=sc.fern_photo, model_capacity=2_000_000, **sc.opts)
+    for k in range(ref.merges[0][0] + 3):
+        s.step(k, sc.frames(synth, k))
+    assert [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
+    assert s.merges[0][3].tobytes() == ref.merges[0][3].tobytes() and s.refinements == [r[:4] for r in ref.refinements]
+    s.close()
