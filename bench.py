@@ -731,7 +731,9 @@ def main():
                       "of the tracker, the depth filter and the vertex / rasterisation stages of the surfel-map passes (per-thread z-buffers over "
                       "contiguous surfel ranges, merged in draw order with GL_LESS, so the bits are the sequential draws'); on one thread stay "
                       "the parts the draw order defines (the fuse's feedback sequence, the clean's compaction) and the Python glue's array copies.  "
-                      "More threads than this make the short loops slower.  A restatement written to be checked against, not tuned: it says "
+                      "More threads than this make the short loops slower - measured on this host (profiles/r05_cpu_baseline_threads.jsonl): "
+                      "0.71 / 3.1 / 4.6 / 4.8 / 3.4 / 1.8 / 0.07 frames/s at 1 / 8 / 16 / 32 / 64 / 128 / 256 threads, so `all host cores` (SURVEY 8d) would "
+                      "report 1/65 of this figure; ~100 frames keep the default run inside its time budget.  A restatement written to be checked against, not tuned: it says "
                       "nothing about kernel quality; one_core: the same with 1 thread for ~8 s.  Non-target" % (n_all, W, H, cores, nproc),
         }
 
