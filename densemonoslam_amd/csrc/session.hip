@@ -523,26 +523,30 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
       if ((rc = t_send(s, rgb_dev[i], N * 3, host, st)) || (rc = t_send(s, depth_dev[i], N * 2, host, st)) || (rc = sync(st))) return rc;
     }
     if (host != s->rank) continue;
-    const void* rgb;
-    const unsigned short* dep;
-    if (src == s->rank) {
-      rgb = rgb_dev[read_index.at(c)];
-      dep = depth_dev[read_index.at(c)];
-    } else {
-      if ((rc = t_recv(s, s->d_frame_rgb, N * 3, src, st)) || (rc = t_recv(s, s->d_frame_depth, N * 2, src, st)) || (rc = sync(st))) return rc;
-      rgb = s->d_frame_rgb;
-      dep = s->d_frame_depth;
-    }
+    // Nothing waits for the host between two cameras' frames: they pipeline on the stream like the frames of one camera (each
+    // context's live half on its own prep stream, beside the previous frame).  A frame read here is processed where the caller put
+    // it (the step returns after the fetch below, so the buffer outlives its use) and copied into the camera's last-frame buffer
+    // - what a later migration ships - behind it; a forwarded frame is received straight into that buffer.
     Camera& cam = s->cams.at(c);
+    if (src == s->rank) {
+      const int i = read_index.at(c);
+      if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, st))) return rc;
+      if ((rc = dms_memcpy_d2d_async(cam.last_rgb, rgb_dev[i], N * 3, st)) || (rc = dms_memcpy_d2d_async(cam.last_depth, depth_dev[i], N * 2, st))) return rc;
+    } else {
+      if ((rc = t_recv(s, cam.last_rgb, N * 3, src, st)) || (rc = t_recv(s, cam.last_depth, N * 2, src, st))) return rc;
+      if ((rc = dms_fusion_inputs_ready(cam.f, st))) return rc;  // (a stream-ordered transport: the frame's ingest, on the context's own stream, behind the receive)
+      if ((rc = dms_fusion_process_frame(cam.f, cam.last_rgb, 3, cam.last_depth, nullptr, 1.f, st))) return rc;
+    }
+  }
+  for (auto& kv : s->cams) {  // results (the first fetch waits for the stream, the others find it drained)
+    Camera& cam = kv.second;
     const int tick_before = cam.tick;
-    if ((rc = dms_fusion_process_frame(cam.f, rgb, 3, dep, nullptr, 1.f, st))) return rc;
     rc = dms_fusion_fetch(cam.f, &cam.last, st);
     if (rc && rc != DMS_ERR_CAPACITY) return rc;
     cam.tick = cam.last.tick;
     memcpy(cam.pose, cam.last.pose, 64);
     cam.pg_tick.push_back(tick_before);
     cam.pg_pose.insert(cam.pg_pose.end(), cam.pose, cam.pose + 16);
-    if ((rc = dms_memcpy_d2d_async(cam.last_rgb, rgb, N * 3, st)) || (rc = dms_memcpy_d2d_async(cam.last_depth, dep, N * 2, st)) || (rc = sync(st))) return rc;
     cam.has_frame = true;
   }
   // 3. publish: own map's database, then the all-gather (slots per rank = the most cameras any rank hosts)
@@ -567,7 +571,6 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
         if ((rc = dms_ferns_add_frame_async(s->ferns.at(s->frame_of[c]), nullptr, nullptr, nullptr, blk, nullptr, (const float*)(blk + s->thumb_bytes + 16),
                                             cam.tick, s->p.fern_threshold, st)))
           return rc;
-        if ((rc = sync(st))) return rc;
       }
       ++i;
     }

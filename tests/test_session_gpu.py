@@ -196,3 +196,72 @@ def test_native_session_over_a_one_rank_rccl_communicator(orc):
     assert [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
     assert s.merges[0][3].tobytes() == ref.merges[0][3].tobytes() and s.refinements == [r[:4] for r in ref.refinements]
     s.close()
+
+
+def _worker3(rank, world, port, q, impl, ticks, offsets):
+    sc = SCENARIOS["reference_rule"]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["DMS_TRACK_MODE"] = "launches"  # two processes on one device must not spin side by side
+    import torch.distributed as dist
+
+    from densemonoslam_amd import synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = _make_session(impl, sc, len(offsets), rank, world, capacity=3_000_000)
+    for k in range(ticks):
+        fr = {}
+        for c, off in enumerate(offsets):
+            if c % world == rank:
+                d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
+                fr[c] = (rgb, d)
+        s.step(k, fr)
+    res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements, frame_of=s.frame_of)
+    if s.hosted():
+        fb = s.frame_of[s.hosted()[0]]
+        res.update(map=s.cams[fb].model(), pose_graph={c: s.pose_graph[c] for c in s.hosted()})
+    q.put(res)
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_three_cameras_two_ranks_chained_merge(orc, impl):
+    """Cameras 0 and 2 are read on rank 0, camera 1 on rank 1 (two slots per rank in the block all-gather).  Tick 6: frame 0 (rank 0)
+    consumes camera 1's map ACROSS ranks (records, import, frame forwarding from then on); tick 7: frame 2 consumes frame 0, which
+    now holds its founder and an IMPORTED camera, on the same rank (dms_fusion_join_map of an imported context).  Map, the three
+    trajectories and both transforms are the one-process oracle session's bit for bit."""
+    from densemonoslam_amd import synth
+    from oracle import orc_pipeline
+
+    sc = SCENARIOS["reference_rule"]
+    offsets, ticks, world = (0, 8, 16), 12, 2
+    ref = orc_pipeline.Session(3, W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts)
+    for k in range(ticks):
+        ref.step([tuple(reversed(synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)[:2])) for off in offsets], k)
+    assert [(m[1], m[2]) for m in ref.merges] == [(0, 1), (2, 0)], ref.merges
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, world, port, q, impl, ticks, offsets)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert [(m[0], m[1], m[2]) for m in results[r]["merges"]] == [(m[0], m[1], m[2]) for m in ref.merges]
+        for got, want in zip(results[r]["merges"], ref.merges):
+            assert np.asarray(got[3], np.float32).tobytes() == want[3].tobytes()
+        assert results[r]["frame_of"] == ref.frame_of and results[r]["refinements"] == [x[:4] for x in ref.refinements]
+    assert results[0]["hosted"] == [0, 1, 2] and results[1]["hosted"] == []
+    m_ref, m_got = ref.cams[2].model, results[0]["map"]
+    assert len(m_got) == len(m_ref), (len(m_got), len(m_ref))
+    for f in m_ref.dtype.names:
+        assert np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)), "merged map differs in field " + f
+    for c in range(3):
+        got, want = results[0]["pose_graph"][c], ref.pose_graph[c]
+        assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
+        for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
