@@ -510,6 +510,31 @@ def main():
         }
         ns.close()
 
+    # The same session ACROSS ranks (opt-in: DMS_BENCH_SESSION=1 with --gpus N): one camera per rank, camera r eight frames ahead of
+    # camera r - 1 on the corner path, RCCL transport (dms_transport_rccl) - or gloo through ctypes callbacks in the one-GPU rehearsal.
+    # Cameras migrate to the consuming rank as their maps merge; rank 0 reports the per-tick times and the merge log.  Not part of
+    # `value`; every rank takes part (the session's collectives).
+    if distributed and os.environ.get("DMS_BENCH_SESSION") == "1" and (W, H) == (640, 480):
+        from densemonoslam_amd import session as session_mod
+
+        n_ticks, q_from, off = 16, 6, 8
+        tr = (session_mod.RcclTransport(collab.rccl_carrier_from_process_group(rank, world)) if backend == "nccl"
+              else session_mod.TorchTransport(rank, world))
+        ns = session_mod.NativeSession(W, H, K, world, rank=rank, world=world, transport=tr, query_from=q_from, model_capacity=8_000_000)
+        tick_ms = []
+        for k in range(n_ticks):
+            d, rgbk, _ = synth.frame(k + off * rank, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
+            dist.barrier()
+            t1 = time.perf_counter()
+            ns.step(k, {rank: (rgbk, d)})
+            torch.cuda.synchronize()
+            tick_ms.append(1000.0 * (time.perf_counter() - t1))
+        if rank == 0:
+            out["session_across_ranks"] = {"cameras": world, "transport": "rccl" if backend == "nccl" else backend, "ms_per_tick": [round(t, 3) for t in tick_ms],
+                                           "merges": [(m[0], m[1], m[2]) for m in ns.merges], "refinements": ns.refinements, "frame_of": ns.frame_of,
+                                           "hosted_on_rank0": ns.hosted()}
+        ns.close()
+
     # ---- per-kernel timing with HIP events on the launch stream (own passes, not in `value`) ------
     if rank == 0 and not args.no_kernel_pass:
         od = fusion.lib.dms_fusion_odometry(ef.h)
