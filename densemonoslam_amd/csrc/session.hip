@@ -36,6 +36,7 @@ struct Camera {
   bool has_frame = false;
   std::vector<int> pg_tick;              // Context::poseGraph()
   std::vector<float> pg_pose;            // 16 floats each
+  std::vector<float> rel_cons;           // Context::relativeCons(): 6 floats each {src xyz, target xyz}, what the caller's deformation solver produced
 };
 
 }  // namespace
@@ -138,6 +139,17 @@ int make_ferns(dms_session* s, dms_ferns** out) {
 
 void rebase(Camera& cam, const float* T) {  // kv.second->poseGraph()[i].second = relativeTransform * ... (ReferenceFrame.h:138-141)
   for (size_t i = 0; i < cam.pg_tick.size(); ++i) dms_pose_compose(T, &cam.pg_pose[i * 16], &cam.pg_pose[i * 16]);
+  // relativeCons()[i].src = r * src + t, .target likewise (:133-136): ((T0 x + T1 y) + T2 z) + T3, every operation rounded
+  for (size_t i = 0; i + 2 < cam.rel_cons.size(); i += 3) {
+    float* p = &cam.rel_cons[i];
+    const float x = p[0], y = p[1], z = p[2];
+    for (int r = 0; r < 3; ++r) {
+      float v = T[r * 4 + 0] * x;
+      v = v + T[r * 4 + 1] * y;
+      v = v + T[r * 4 + 2] * z;
+      p[r] = v + T[r * 4 + 3];
+    }
+  }
 }
 
 Camera* owner_of(dms_session* s, int fb) {
@@ -206,7 +218,7 @@ int refine(dms_session* s, int a, int fb, const float* rec16, const float* curr1
 }
 
 struct MigrationHeader {  // per moving camera, consumed side -> consuming side
-  int tick, n_pg, has_frame, pad;
+  int tick, n_pg, has_frame, n_rc;
   float pose[16];
 };
 
@@ -281,10 +293,12 @@ int merge(dms_session* s, int k, int fb, int fa, const float* T, dms_stream st) 
       h.tick = cam.tick;
       h.n_pg = (int)cam.pg_tick.size();
       h.has_frame = cam.has_frame ? 1 : 0;
+      h.n_rc = (int)(cam.rel_cons.size() / 6);
       memcpy(h.pose, cam.pose, 64);
       if ((rc = send_host(s, &h, sizeof(h), hb, st))) return rc;
       if ((rc = t_send(s, cam.last_rgb, N * 3, hb, st)) || (rc = t_send(s, cam.last_depth, N * 2, hb, st)) || (rc = sync(st))) return rc;
-      if ((rc = send_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, hb, st)) || (rc = send_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, hb, st)))
+      if ((rc = send_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, hb, st)) || (rc = send_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, hb, st)) ||
+          (rc = send_host(s, cam.rel_cons.data(), cam.rel_cons.size() * 4, hb, st)))
         return rc;
     }
     // joined / imported cameras first: the map's owner outlives them
@@ -331,7 +345,9 @@ int merge(dms_session* s, int k, int fb, int fa, const float* T, dms_stream st) 
       if ((rc = t_recv(s, cam.last_rgb, N * 3, ha, st)) || (rc = t_recv(s, cam.last_depth, N * 2, ha, st)) || (rc = sync(st))) return rc;
       cam.pg_tick.resize(h.n_pg);
       cam.pg_pose.resize((size_t)h.n_pg * 16);
-      if ((rc = recv_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, ha, st)) || (rc = recv_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, ha, st)))
+      cam.rel_cons.resize((size_t)h.n_rc * 6);
+      if ((rc = recv_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, ha, st)) || (rc = recv_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, ha, st)) ||
+          (rc = recv_host(s, cam.rel_cons.data(), cam.rel_cons.size() * 4, ha, st)))
         return rc;
       float moved[16];
       dms_pose_compose(T, h.pose, moved);
@@ -698,6 +714,21 @@ dms_ferns* dms_session_ferns(dms_session* s, int frame) {
 int dms_session_last_result(dms_session* s, int camera, dms_frame_result* r) {
   DMS_REQUIRE(s && r && s->cams.count(camera), "the camera is not hosted here");
   *r = s->cams.at(camera).last;
+  return DMS_OK;
+}
+int dms_session_add_relative_constraint(dms_session* s, int camera, const float* src3, const float* target3) {
+  DMS_REQUIRE(s && src3 && target3 && s->cams.count(camera), "the camera is not hosted here");
+  Camera& cam = s->cams.at(camera);
+  cam.rel_cons.insert(cam.rel_cons.end(), src3, src3 + 3);
+  cam.rel_cons.insert(cam.rel_cons.end(), target3, target3 + 3);
+  return DMS_OK;
+}
+int dms_session_relative_constraints(dms_session* s, int camera, float* rows6, int max, int* n) {
+  DMS_REQUIRE(s && n && s->cams.count(camera), "the camera is not hosted here");
+  const Camera& cam = s->cams.at(camera);
+  *n = (int)(cam.rel_cons.size() / 6);
+  if (rows6)
+    for (int i = 0; i < *n && i < max; ++i) memcpy(rows6 + (size_t)i * 6, &cam.rel_cons[(size_t)i * 6], 24);
   return DMS_OK;
 }
 int dms_session_pose_graph(dms_session* s, int camera, int* ticks, float* poses16, int max, int* n) {

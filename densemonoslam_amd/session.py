@@ -534,6 +534,8 @@ def _native():
     lib.dms_session_ferns.restype = P
     lib.dms_session_last_result.argtypes = [P, _C.c_int, _C.POINTER(fusion.FrameResult)]
     lib.dms_session_pose_graph.argtypes = [P, _C.c_int, _C.POINTER(_C.c_int), _C.POINTER(_C.c_float), _C.c_int, _C.POINTER(_C.c_int)]
+    lib.dms_session_add_relative_constraint.argtypes = [P, _C.c_int, _C.POINTER(_C.c_float), _C.POINTER(_C.c_float)]
+    lib.dms_session_relative_constraints.argtypes = [P, _C.c_int, _C.POINTER(_C.c_float), _C.c_int, _C.POINTER(_C.c_int)]
     lib.dms_transport_rccl.argtypes = [P, _C.POINTER(Transport)]
     lib.dms_ferns_num_frames.argtypes = [P]
     lib._dms_session_types = (SessionParams, Transport, FN_AG, FN_SR)
@@ -720,6 +722,21 @@ class NativeSession:
             self.capi.check(self.lib.dms_session_pose_graph(self.h, c, t, p, n.value, _C.byref(n)))
             P = np.array(p, np.float32).reshape(-1, 4, 4)
             out[c] = [(int(t[i]), P[i].copy()) for i in range(n.value)]
+        return out
+
+    def addRelativeConstraint(self, camera, src, target):
+        a, b = (_C.c_float * 3)(*[float(v) for v in src]), (_C.c_float * 3)(*[float(v) for v in target])
+        self.capi.check(self.lib.dms_session_add_relative_constraint(self.h, int(camera), a, b), "dms_session_add_relative_constraint")
+
+    @property
+    def relative_cons(self):
+        out = {}
+        for c in self.hosted():
+            n = _C.c_int(0)
+            self.capi.check(self.lib.dms_session_relative_constraints(self.h, c, None, 0, _C.byref(n)))
+            r = (_C.c_float * (6 * max(n.value, 1)))()
+            self.capi.check(self.lib.dms_session_relative_constraints(self.h, c, r, n.value, _C.byref(n)))
+            out[c] = [np.array(r, np.float32).reshape(-1, 6)[i].copy() for i in range(n.value)]
         return out
 
     def close(self):

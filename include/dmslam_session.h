@@ -97,6 +97,11 @@ int dms_session_hosted(dms_session* s, int* cameras, int max, int* n);   /* asce
 dms_fusion* dms_session_camera(dms_session* s, int camera);             /* NULL when the camera is hosted elsewhere */
 dms_ferns* dms_session_ferns(dms_session* s, int frame);                /* NULL when the frame is hosted elsewhere / consumed */
 int dms_session_last_result(dms_session* s, int camera, dms_frame_result* r);
+/* Context::relativeCons() of a hosted camera (ElasticFusion.cpp:489-492: the rows the caller's deformation solver produced for a closed
+ * loop, {src xyz, target xyz}): kept with the camera, re-based by every merge (ReferenceFrame.h:133-136) and shipped with it when it
+ * migrates - the "deformation-graph constraints" that cross xGMI besides the fern descriptors. */
+int dms_session_add_relative_constraint(dms_session* s, int camera, const float* src3, const float* target3);
+int dms_session_relative_constraints(dms_session* s, int camera, float* rows6, int max, int* n);
 /* Context::poseGraph() of a hosted camera: (tick before the frame, pose after it) per processed frame, re-based by every merge */
 int dms_session_pose_graph(dms_session* s, int camera, int* ticks, float* poses16, int max, int* n);
 

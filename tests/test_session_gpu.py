@@ -28,7 +28,7 @@ def n_ticks(scenario):
 def oracle_session(orc, request):
     name = request.param
     if name not in _ORACLE:
-        s = run_oracle_session(name, n_ticks(name), relative_cons=False)
+        s = run_oracle_session(name, n_ticks(name), relative_cons=True)
         assert len(s.merges) == 1 and n_ticks(name) - 1 - s.merges[0][0] >= 20, s.merges
         if SCENARIOS[name].opts.get("full_refine"):
             assert [r[3] for r in s.refinements] == [True], s.refinements
@@ -53,6 +53,9 @@ def _check(ref, host, merges):
         assert [t for t, _ in got] == [t for t, _ in want] and len(got) == N_TICKS
         for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
             assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
+        # Context::relativeCons(): the consumed camera's row re-based by the merge (ReferenceFrame.h:133-136), the other one untouched
+        rc = host["relative_cons"][c]
+        assert len(rc) == 1 and np.asarray(rc[0], np.float32).tobytes() == ref.relative_cons[c][0].tobytes(), "camera %d: relative constraint differs" % c
 
 
 def _make_session(impl, sc, n, rank=0, world=1, capacity=2_000_000):
@@ -62,12 +65,19 @@ def _make_session(impl, sc, n, rank=0, world=1, capacity=2_000_000):
 
     from densemonoslam_amd import session
 
+    row = lambda c: np.arange(6, dtype=np.float32) * np.float32(0.25 + c)  # a constraint row the caller's solver produced before any merge
     if impl == "native":
         tr = session.TorchTransport(rank, world) if world > 1 else None
-        return session.NativeSession(W, H, K, n, rank=rank, world=world, transport=tr, fern_photo_thresh=sc.fern_photo, model_capacity=capacity,
-                                     **sc.opts)
+        s = session.NativeSession(W, H, K, n, rank=rank, world=world, transport=tr, fern_photo_thresh=sc.fern_photo, model_capacity=capacity,
+                                  **sc.opts)
+        for c in s.hosted():
+            s.addRelativeConstraint(c, row(c)[:3], row(c)[3:])
+        return s
     be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=capacity)
-    return session.CollabSession(be, n, W, H, rank=rank, world=world, **sc.opts)
+    s = session.CollabSession(be, n, W, H, rank=rank, world=world, **sc.opts)
+    for c in s.hosted():
+        s.relative_cons[c].append(row(c))
+    return s
 
 
 @pytest.mark.parametrize("impl", ["native", "python"])
@@ -81,7 +91,7 @@ def test_two_cameras_one_device_merge_and_continue(oracle_session, impl):
         s.step(k, sc.frames(synth, k))
     assert s.refinements == [r[:4] for r in oracle_session.refinements]
     fb = oracle_session.merges[0][1]
-    host = dict(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph=s.pose_graph)
+    host = dict(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph=s.pose_graph, relative_cons=s.relative_cons)
     _check(oracle_session, host, s.merges)
     s.close()
 
@@ -103,7 +113,8 @@ def _worker(rank, world, port, q, scenario, impl):
     res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements)
     if s.hosted():
         fb = s.frame_of[s.hosted()[0]]
-        res.update(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph={c: s.pose_graph[c] for c in s.hosted()})
+        res.update(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph={c: s.pose_graph[c] for c in s.hosted()},
+                   relative_cons={c: s.relative_cons[c] for c in s.hosted()})
     q.put(res)
     dist.barrier()
     s.close()
