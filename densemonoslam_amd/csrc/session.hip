@@ -167,39 +167,48 @@ int refine(dms_session* s, int a, int fb, const float* rec16, const float* curr1
   memset(res, 0, sizeof(res));
   int rc = DMS_OK;
   if (hb == s->rank) {
-    Camera* owner = owner_of(s, fb);
-    DMS_REQUIRE(owner, "the matched frame has no camera here");
-    if (!s->refiners.count(fb)) {
-      const dms_fusion_params& c = s->p.camera;
-      dms_refframe* r = nullptr;
-      if ((rc = dms_refframe_create(&r, s->W, s->H, c.cx, c.cy, c.fx, c.fy))) return rc;
-      s->refiners[fb] = r;
-    }
-    const float *vtx, *nrm;
-    const void* img;
-    if (ha == s->rank) {
-      dms_image2d vi, vv, vn;
-      dms_fusion* q = s->cams.at(a).f;
-      if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) return rc;
-      img = vi.data;
-      vtx = (const float*)vv.data;
-      nrm = (const float*)vn.data;
-    } else {
-      if ((rc = t_recv(s, s->d_tex, N * 4, ha, st)) || (rc = t_recv(s, s->d_tex + N * 4, N * 16, ha, st)) ||
-          (rc = t_recv(s, s->d_tex + N * 20, N * 16, ha, st)) || (rc = sync(st)))
+    // (a failure here must not leave the other ranks waiting in the broadcast below: it travels as res[0] = -1)
+    auto owner_side = [&]() -> int {
+      Camera* owner = owner_of(s, fb);
+      DMS_REQUIRE(owner, "the matched frame has no camera here");
+      if (!s->refiners.count(fb)) {
+        const dms_fusion_params& c = s->p.camera;
+        dms_refframe* r = nullptr;
+        if ((rc = dms_refframe_create(&r, s->W, s->H, c.cx, c.cy, c.fx, c.fy))) return rc;
+        s->refiners[fb] = r;
+      }
+      const float *vtx, *nrm;
+      const void* img;
+      if (ha == s->rank) {
+        dms_image2d vi, vv, vn;
+        dms_fusion* q = s->cams.at(a).f;
+        if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) return rc;
+        img = vi.data;
+        vtx = (const float*)vv.data;
+        nrm = (const float*)vn.data;
+      } else {
+        if ((rc = t_recv(s, s->d_tex, N * 4, ha, st)) || (rc = t_recv(s, s->d_tex + N * 4, N * 16, ha, st)) ||
+            (rc = t_recv(s, s->d_tex + N * 20, N * 16, ha, st)) || (rc = sync(st)))
+          return rc;
+        img = s->d_tex;
+        vtx = (const float*)(s->d_tex + N * 4);
+        nrm = (const float*)(s->d_tex + N * 20);
+      }
+      double conf = 0.0;
+      if ((rc = dms_fusion_get_option(owner->f, DMS_OPT_CONFIDENCE, &conf))) return rc;
+      dms_intermap_result r;
+      if ((rc = dms_refframe_refine(s->refiners[fb], dms_fusion_model(owner->f), rec16, curr16, vtx, nrm, img, (int)s->p.camera.maxDepthProcessed,
+                                    (float)conf, a, s->p.camera.timeDelta, tick, s->p.cov_thresh, s->p.icp_err_thresh, s->p.icp_count_thresh, &r, st)))
         return rc;
-      img = s->d_tex;
-      vtx = (const float*)(s->d_tex + N * 4);
-      nrm = (const float*)(s->d_tex + N * 20);
+      res[0] = r.accepted ? 1.f : 0.f;
+      memcpy(res + 1, r.relativeTransform, 64);
+      return DMS_OK;
+    };
+    const int orc_ = owner_side();
+    if (orc_) {
+      res[0] = -1.f;
+      if (s->local_only) return orc_;
     }
-    double conf = 0.0;
-    if ((rc = dms_fusion_get_option(owner->f, DMS_OPT_CONFIDENCE, &conf))) return rc;
-    dms_intermap_result r;
-    if ((rc = dms_refframe_refine(s->refiners[fb], dms_fusion_model(owner->f), rec16, curr16, vtx, nrm, img, (int)s->p.camera.maxDepthProcessed,
-                                  (float)conf, a, s->p.camera.timeDelta, tick, s->p.cov_thresh, s->p.icp_err_thresh, s->p.icp_count_thresh, &r, st)))
-      return rc;
-    res[0] = r.accepted ? 1.f : 0.f;
-    memcpy(res + 1, r.relativeTransform, 64);
   } else if (ha == s->rank) {
     dms_image2d vi, vv, vn;
     dms_fusion* q = s->cams.at(a).f;
@@ -211,6 +220,10 @@ int refine(dms_session* s, int a, int fb, const float* rec16, const float* curr1
   if (!s->local_only) {
     if (hb == s->rank && (rc = dms_memcpy_h2d(s->d_small, res, sizeof(res), st))) return rc;
     if ((rc = t_bcast(s, s->d_small, sizeof(res), hb, st)) || (rc = sync(st)) || (rc = dms_memcpy_d2h(res, s->d_small, sizeof(res), st))) return rc;
+  }
+  if (res[0] < 0.f) {
+    if (hb != s->rank) set_error("dms_session_step: the inter-map refinement failed on rank %d", hb);
+    return DMS_ERR_STATE;
   }
   *accepted = res[0] == 1.f ? 1 : 0;
   memcpy(T16, res + 1, 64);
