@@ -78,6 +78,19 @@ int dms_memcpy_d2d_async(void* dst, const void* src, size_t bytes, dms_stream s)
   DMS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)));
   return DMS_OK;
 }
+// rows of `width` bytes from a pitched source to a pitched destination in ONE launch - the destination may be mapped host memory
+// (a few KB of per-block metadata that the host reads a tick later: a 2-D copy-engine transfer costs more than it moves)
+__global__ void k_copy_rows(unsigned* __restrict__ dst, size_t dpitch_w, const unsigned* __restrict__ src, size_t spitch_w, int width_w) {
+  const size_t r = blockIdx.x;
+  for (int i = threadIdx.x; i < width_w; i += blockDim.x) dst[r * dpitch_w + i] = src[r * spitch_w + i];
+}
+int dms_copy_rows_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, dms_stream s) {
+  DMS_REQUIRE(dst && src && rows >= 1 && width >= 4, "bad argument");
+  DMS_REQUIRE((((uintptr_t)dst | (uintptr_t)src | dpitch | spitch | width) & 3) == 0, "4-byte aligned pointers, pitches and width required");
+  hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)rows), dim3(256), 0, S(s), (unsigned*)dst, dpitch / 4, (const unsigned*)src, spitch / 4, (int)(width / 4));
+  DMS_CHECK_LAUNCH();
+  return DMS_OK;
+}
 int dms_memset(void* dst, int value, size_t bytes, dms_stream s) {
   DMS_HIP(hipMemsetAsync(dst, value, bytes, S(s)));
   return DMS_OK;

@@ -204,6 +204,37 @@ __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __res
   }
 }
 
+// The first half of Ferns::findFrame for a batch of queries, up to the test that decides whether the tracker verifies at all
+// (Ferns.cpp:327-342: minimum dissimilarity, then blockHDAware > 0.3 against the frame it chose): one block per query reads the
+// search's result word and writes {candidate id or -1, dissimilarity bits, codes valid in both, of those equal} - the host (or another
+// rank, the words travel inside the frame block) forms hd_equal / hd_count > 0.3f exactly as find_common does.
+__global__ __launch_bounds__(kFernPad) void k_fern_hd_batch(const unsigned char* __restrict__ db_codes, const unsigned char* __restrict__ base,
+                                                            size_t stride, size_t codes_off, int num, unsigned long long* __restrict__ best,
+                                                            int4* __restrict__ out) {
+  __shared__ int s_c, s_e;
+  const int q = blockIdx.x;
+  const unsigned long long b = best[q];
+  __syncthreads();
+  if (threadIdx.x == 0) best[q] = ~0ull;  // (re-armed for the next search of this handle: no memset between two calls)
+  if (b == ~0ull) {
+    if (threadIdx.x == 0) out[q] = make_int4(-1, 0, 0, 0);
+    return;
+  }
+  if (threadIdx.x == 0) s_c = s_e = 0;
+  __syncthreads();
+  const int id = (int)(b & 0xFFFFFFFFull);
+  const int i = threadIdx.x;
+  if (i < num) {
+    const unsigned char a = base[(size_t)q * stride + codes_off + i], c = db_codes[(size_t)id * kFernPad + i];
+    if (a != DMS_FERN_BAD_CODE && c != DMS_FERN_BAD_CODE) {
+      atomicAdd(&s_c, 1);
+      if (a == c) atomicAdd(&s_e, 1);
+    }
+  }
+  __syncthreads();
+  if (i == 0) out[q] = make_int4(id, (int)(unsigned)(b >> 32), s_c, s_e);
+}
+
 // addFrame's decision (Ferns.cpp:235-275) on the device: (minimum > threshold || empty) && goodCodes > 0 -> the
 // staged frame takes slot n; its metadata is written here, its payload by k_fern_commit
 // `status` (mapped host memory, may be null): {sequence number of this add, frames stored, frames dropped because the database
@@ -415,6 +446,8 @@ struct dms_ferns {
   int adds_issued = 0;
   // dms_ferns_search_blocks with a result mirror: the handle's alternate word set and the sequence it belongs to
   unsigned long long* d_best_alt = nullptr;
+  unsigned long long* d_hd_best = nullptr;  // dms_ferns_search_blocks_hd's result words (armed once, re-armed by its second kernel)
+  int hd_count = 0;
   int* pipe_best = nullptr;
   int pipe_count = 0, pipe_calls = 0;
   bool publish_fused = true;  // dms_ferns_publish_block as one launch while the database is small (DMS_FERNS_PUBLISH_FUSED=0: four)
@@ -766,6 +799,7 @@ int dms_ferns_destroy(dms_ferns* f) {
   if (f->rgbd_odom) dms_odometry_destroy(f->rgbd_odom);
   if (f->arena) (void)hipFree(f->arena);
   if (f->d_best_alt) (void)hipFree(f->d_best_alt);
+  if (f->d_hd_best) (void)hipFree(f->d_hd_best);
   if (f->h_status) (void)hipHostFree((void*)f->h_status);
   if (f->ev_last_add) (void)hipEventDestroy(f->ev_last_add);
   if (f->h_res) (void)hipHostFree(f->h_res);
@@ -959,6 +993,31 @@ int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride,
                        (unsigned long long*)best2_dev);
     DMS_CHECK_LAUNCH();
   }
+  return DMS_OK;
+}
+
+int dms_ferns_search_blocks_hd(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset, int time,
+                               int interMap, int* hits4_dev, dms_stream st) {
+  DMS_REQUIRE(f && blocks_dev && hits4_dev && count >= 1, "bad argument");
+  DMS_REQUIRE(((uintptr_t)blocks_dev & 7) == 0 && (stride & 7) == 0 && (codes_offset & 7) == 0 && (good_offset & 3) == 0 && ((uintptr_t)hits4_dev & 15) == 0,
+              "8-byte aligned blocks, stride and code offset, 16-byte aligned hit rows required");
+  hipStream_t s = (hipStream_t)st;
+  if (f->hd_count < count) {  // the result words of this entry point: armed once, re-armed by k_fern_hd_batch after every read
+    if (f->d_hd_best) (void)hipFree(f->d_hd_best);
+    f->d_hd_best = nullptr;
+    f->hd_count = 0;
+    DMS_HIP(hipMalloc((void**)&f->d_hd_best, (size_t)count * 8));
+    DMS_HIP(hipMemsetAsync(f->d_hd_best, 0xFF, (size_t)count * 8, s));
+    f->hd_count = count;
+  }
+  if (f->n_upper > 0) {
+    hipLaunchKernelGGL(k_fern_search_batch, dim3((f->n_upper + 3) / 4, count), dim3(256), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n,
+                       (const unsigned char*)blocks_dev, stride, codes_offset, good_offset, -1, time, interMap ? 1 : 0, f->d_hd_best);
+    DMS_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_fern_hd_batch, dim3(count), dim3(kFernPad), 0, s, f->d_codes, (const unsigned char*)blocks_dev, stride, codes_offset, f->num,
+                     f->d_hd_best, (int4*)hits4_dev);
+  DMS_CHECK_LAUNCH();
   return DMS_OK;
 }
 

@@ -5,6 +5,8 @@
 // densemonoslam_amd/session.py, step for step (same order of queries, same decision rule, same float operations for the re-basing:
 // dms_pose_compose / dms_relative_transform), so a session run through this file ends in the same bits as the one-process oracle
 // session (tests/test_session_gpu.py).
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -18,6 +20,14 @@ namespace {
 
 constexpr int kMetaBytes = 80;  // per published block: camera id i32 | tick i32 | 2 x pad | pose 16 x f32
 constexpr int kRow = 18;        // table entry: valid, closest, recoveryPose
+// The pipelined step's block: thumbnails | tail, the tail = fern codes 512 | good codes i32 | tick i32 | camera id i32 | pad | pose
+// 16 x f32 | hit rows 64 x {candidate, dissimilarity bits, codes valid in both, of those equal}.  The hit rows of a rank's i-th slot
+// are those of its i-th hosted key-frame database (ascending frame id) against every gathered block, written by the search of the tick
+// BEFORE (a rank hosts at most as many databases as cameras, so there is a slot for each).
+constexpr int kTailCodes = 0, kTailGood = 512, kTailTick = 516, kTailCam = 520, kTailPose = 528, kTailHits = 592, kMaxQueries = 64;
+constexpr int kTailBytes = kTailHits + kMaxQueries * 16;  // 1616
+constexpr int kTailHostBytes = kTailBytes - kTailGood;    // what the host mirrors of every gathered block (everything behind the codes)
+constexpr int kWakeLatency = 3;  // a hit of the search enqueued at tick j runs the full block at tick j + 3 (dmslam_session.h)
 
 struct Merge {
   int k, fb, fa;
@@ -28,8 +38,10 @@ struct Refinement {
 };
 struct Camera {
   dms_fusion* f = nullptr;
-  void* last_rgb = nullptr;              // the last processed frame, for a migration (RGB8 | depth u16)
+  void* last_rgb = nullptr;              // receive buffers of a camera whose frames are forwarded from another rank (RGB8 | depth u16)
   unsigned short* last_depth = nullptr;
+  const void* frame_rgb = nullptr;       // where the frame of the current tick lies - the caller's buffer or the receive buffer: what a
+  const unsigned short* frame_depth = nullptr;  // migration ships (a merge happens inside the step, while the caller's buffers are valid)
   dms_frame_result last{};
   int tick = 1;
   float pose[16];
@@ -63,6 +75,23 @@ struct dms_session {
   void* d_frame_rgb = nullptr;           // a forwarded frame
   unsigned short* d_frame_depth = nullptr;
   unsigned char* d_tex = nullptr;        // a remote camera's fill-in textures (36 B per pixel)
+  // the pipelined step (dms_session_step_async)
+  size_t tail_off = 0, ablock_bytes = 0;
+  unsigned char* d_alocal[2] = {nullptr, nullptr};     // n x ablock_bytes each: this rank's blocks of even / odd ticks
+  unsigned char* d_agathered[2] = {nullptr, nullptr};  // world x n x ablock_bytes each
+  bool can_pipeline = false;
+  int ids_tick = -1;                                   // the camera ids in d_alocal's tails are current (placement as of this many merges)
+  struct Entry {
+    int tick = -1;                 // the tick whose gathered tails this mirror holds (-1: none)
+    bool consumed = true;
+    int slots = 0;
+    unsigned char* host = nullptr; // pinned: world x slots x kTailHostBytes
+    hipEvent_t done = nullptr;
+  } ring[2];
+  int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
+  std::set<int> wake_ticks;        // ticks that run the full inter-map block: a search three ticks earlier hit
+  int wakes = 0, async_ticks = 0;
+  dms_stream last_stream = nullptr;
 };
 
 namespace {
@@ -309,7 +338,8 @@ int merge(dms_session* s, int k, int fb, int fa, const float* T, dms_stream st) 
       h.n_rc = (int)(cam.rel_cons.size() / 6);
       memcpy(h.pose, cam.pose, 64);
       if ((rc = send_host(s, &h, sizeof(h), hb, st))) return rc;
-      if ((rc = t_send(s, cam.last_rgb, N * 3, hb, st)) || (rc = t_send(s, cam.last_depth, N * 2, hb, st)) || (rc = sync(st))) return rc;
+      DMS_REQUIRE(cam.frame_rgb && cam.frame_depth, "a camera migrates before its first frame");
+      if ((rc = t_send(s, cam.frame_rgb, N * 3, hb, st)) || (rc = t_send(s, cam.frame_depth, N * 2, hb, st)) || (rc = sync(st))) return rc;
       if ((rc = send_host(s, cam.pg_tick.data(), cam.pg_tick.size() * 4, hb, st)) || (rc = send_host(s, cam.pg_pose.data(), cam.pg_pose.size() * 4, hb, st)) ||
           (rc = send_host(s, cam.rel_cons.data(), cam.rel_cons.size() * 4, hb, st)))
         return rc;
@@ -366,6 +396,8 @@ int merge(dms_session* s, int k, int fb, int fa, const float* T, dms_stream st) 
       dms_pose_compose(T, h.pose, moved);
       if ((rc = dms_fusion_import_camera(cam.f, owner->f, moved, h.tick, cam.last_rgb, 3, cam.last_depth, st))) return rc;
       cam.tick = h.tick;
+      cam.frame_rgb = cam.last_rgb;
+      cam.frame_depth = cam.last_depth;
       memcpy(cam.pose, moved, 64);
       cam.has_frame = h.has_frame != 0;
       rebase(cam, T);
@@ -386,15 +418,14 @@ int merge(dms_session* s, int k, int fb, int fa, const float* T, dms_stream st) 
   return DMS_OK;
 }
 
-int query(dms_session* s, int k, const std::vector<int>& host_counts, int slots, std::map<int, std::vector<float>>& poses, std::map<int, int>& ticks,
+// `only`: bit a * 8 + fb set = the pair (camera a, frame fb) is due (the pipelined mode's candidates); ~0 = every pair
+int query(dms_session* s, int k, unsigned long long only, std::map<int, std::vector<float>>& poses, std::map<int, int>& ticks,
           std::map<int, const unsigned char*>& blocks, float* table, dms_stream st) {
   // owner computes: every hosted reference frame against every camera of another frame
-  (void)host_counts;
-  (void)slots;
   for (auto& kv : s->ferns) {
     const int fb = kv.first;
     for (int a = 0; a < s->n; ++a) {
-      if (s->frame_of[a] == fb || k < s->p.query_from) continue;
+      if (s->frame_of[a] == fb || k < s->p.query_from || !((only >> (a * 8 + fb)) & 1ull)) continue;
       dms_fern_match m;
       int rc = dms_ferns_find_frame_thumbs(kv.second, blocks.at(a), poses.at(a).data(), ticks.at(a), 0, s->p.inter_map, &m, nullptr, st);
       if (rc) return rc;
@@ -404,6 +435,147 @@ int query(dms_session* s, int k, const std::vector<int>& host_counts, int slots,
       memcpy(e + 2, m.estPose, 64);
     }
   }
+  return DMS_OK;
+}
+
+// ---- the pipelined step's host side ------------------------------------------------------------------------------------------
+std::vector<int> cams_of_rank(const dms_session* s, int r) {
+  std::vector<int> v;
+  for (int c = 0; c < s->n; ++c)
+    if (host_of_camera(s, c) == r) v.push_back(c);
+  return v;
+}
+std::vector<int> frames_of_rank(const dms_session* s, int r) {
+  std::vector<int> v;
+  for (auto& kv : s->host_of_frame)
+    if (kv.second == r) v.push_back(kv.first);
+  return v;
+}
+int slots_now(const dms_session* s) {
+  std::vector<int> host_counts(s->world, 0);
+  for (int c = 0; c < s->n; ++c) host_counts[host_of_camera(s, c)] += 1;
+  return *std::max_element(host_counts.begin(), host_counts.end());
+}
+const unsigned char* entry_tail(const dms_session::Entry& e, int r, int i) { return e.host + ((size_t)r * e.slots + i) * kTailHostBytes; }
+
+// Takes a mirror of gathered tails that the device has finished: the pose graph / pose of the cameras hosted here (unless the tick
+// was fetched), and the hit rows - an eligible hit of the search enqueued at tick j schedules the full block for tick j + 3.  The
+// placement has not changed since the entry was enqueued: a merge consumes every outstanding entry first.
+int consume_entry(dms_session* s, dms_session::Entry& e, bool bookkeep) {
+  if (e.tick < 0 || e.consumed) return DMS_OK;
+  if (hipEventSynchronize(e.done) != hipSuccess) {
+    set_error("dms_session: waiting for the gathered blocks of tick %d failed", e.tick);
+    return DMS_ERR_HIP;
+  }
+  e.consumed = true;
+  if (bookkeep) {
+    const std::vector<int> mine = cams_of_rank(s, s->rank);
+    for (size_t i = 0; i < mine.size(); ++i) {
+      const unsigned char* t = entry_tail(e, s->rank, (int)i);
+      int tick, cam_id;
+      memcpy(&tick, t + (kTailTick - kTailGood), 4);
+      memcpy(&cam_id, t + (kTailCam - kTailGood), 4);
+      DMS_REQUIRE(cam_id == mine[i], "a gathered block is not the camera the placement names");
+      Camera& cam = s->cams.at(mine[i]);
+      memcpy(cam.pose, t + (kTailPose - kTailGood), 64);
+      cam.pg_tick.push_back(tick - 1);  // (never lost in this mode: the tick before the frame)
+      cam.pg_pose.insert(cam.pg_pose.end(), cam.pose, cam.pose + 16);
+      cam.has_frame = true;
+    }
+  }
+  // the hit rows were written by the search of tick e.tick - 1
+  const int searched = e.tick - 1;
+  if (searched < s->valid_from || searched < s->p.query_from) return DMS_OK;
+  for (int r = 0; r < s->world; ++r) {
+    const std::vector<int> dbs = frames_of_rank(s, r);
+    for (size_t d = 0; d < dbs.size(); ++d) {
+      const unsigned char* rows = entry_tail(e, r, (int)d) + (kTailHits - kTailGood);
+      for (int r2 = 0; r2 < s->world; ++r2) {
+        const std::vector<int> qs = cams_of_rank(s, r2);
+        for (size_t i2 = 0; i2 < qs.size(); ++i2) {
+          if (s->frame_of[qs[i2]] == dbs[d]) continue;
+          int row[4];
+          memcpy(row, rows + ((size_t)r2 * e.slots + i2) * 16, 16);
+          if (row[0] >= 0 && (float)row[3] / (float)row[2] > 0.3f) s->wake_ticks.insert(searched + kWakeLatency);  // Ferns.cpp:342
+        }
+      }
+    }
+  }
+  return DMS_OK;
+}
+
+// a merge (or a synchronous step) at tick k: the searches enqueued up to it ran on the placement before it
+void invalidate_searches(dms_session* s, int k) {
+  s->valid_from = k + 1;
+  s->wake_ticks.erase(s->wake_ticks.begin(), s->wake_ticks.lower_bound(s->valid_from + kWakeLatency));
+}
+
+// everything the device still owes the host of earlier pipelined ticks (pose graphs), in tick order
+int drain_entries(dms_session* s) {
+  int order[2] = {0, 1};
+  if (s->ring[0].tick > s->ring[1].tick) std::swap(order[0], order[1]);
+  for (int b : order) {
+    int rc = consume_entry(s, s->ring[b], true);
+    if (rc) return rc;
+  }
+  return DMS_OK;
+}
+
+// Phases 4 - 6 of a tick on the gathered blocks (camera -> thumbnails in HBM, pose, tick): queries, the common decision walk with the
+// full-resolution refinement, merges.  `only` as in query().
+int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<int, std::vector<float>>& poses, std::map<int, int>& ticks,
+                     std::map<int, const unsigned char*>& blocks, dms_stream st) {
+  int rc = DMS_OK;
+  // 4. queries.  A failure on one rank must not leave the others waiting in the next collective: it travels in the table's last
+  // row and every rank returns together.
+  const size_t tab_floats = (size_t)(s->n + 1) * s->n * kRow;
+  std::vector<float> table(tab_floats, 0.f), tables(tab_floats * s->world, 0.f);
+  int qrc = query(s, k, only, poses, ticks, blocks, table.data(), st);
+  if (qrc) table[(size_t)s->n * s->n * kRow] = 1.f;
+  if ((rc = dms_memcpy_h2d(s->d_table, table.data(), tab_floats * 4, st))) return rc;
+  if ((rc = t_allgather(s, s->d_table, s->d_table + tab_floats, tab_floats * 4, st)) || (rc = sync(st))) return rc;
+  if ((rc = dms_memcpy_d2h(tables.data(), s->d_table + tab_floats, tab_floats * 4 * s->world, st))) return rc;
+  for (int r = 0; r < s->world; ++r)
+    if (tables[(size_t)r * tab_floats + (size_t)s->n * s->n * kRow] != 0.f) {
+      if (!qrc) set_error("dms_session_step: the inter-map query failed on rank %d at tick %d", r, k);
+      return qrc ? qrc : DMS_ERR_STATE;
+    }
+  // 5. the same walk on every rank (cameras in id order, frames in id order; first accepted candidate wins, one merge per frame and tick)
+  struct Decided {
+    int fb, fa;
+    float T[16];
+  };
+  std::vector<Decided> decided;
+  std::set<int> busy;
+  for (int a = 0; a < s->n; ++a) {
+    const int fa = s->frame_of[a];
+    if (busy.count(fa) || k < s->p.query_from) continue;
+    std::set<int> frames(s->frame_of.begin(), s->frame_of.end());
+    for (int fb : frames) {
+      if (fb == fa || busy.count(fb) || !((only >> (a * 8 + fb)) & 1ull)) continue;
+      const float* e = &tables[(size_t)s->host_of_frame.at(fb) * tab_floats + ((size_t)a * s->n + fb) * kRow];
+      DMS_REQUIRE(e[0] == 1.f, "no verification result for a camera / frame pair");
+      if (e[1] < 0.f) continue;
+      Decided d;
+      d.fb = fb;
+      d.fa = fa;
+      if (s->p.full_refine) {
+        int accepted = 0;
+        if ((rc = refine(s, a, fb, e + 2, poses.at(a).data(), ticks.at(a), &accepted, d.T, st))) return rc;
+        s->refinements.push_back(Refinement{k, a, fb, accepted});
+        if (!accepted) continue;
+      } else {
+        dms_relative_transform(e + 2, poses.at(a).data(), d.T);
+      }
+      decided.push_back(d);
+      busy.insert(fa);
+      busy.insert(fb);
+      break;
+    }
+  }
+  // 6. merges
+  for (auto& d : decided)
+    if ((rc = merge(s, k, d.fb, d.fa, d.T, st))) return rc;
   return DMS_OK;
 }
 
@@ -476,7 +648,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   s->W = p->camera.width;
   s->H = p->camera.height;
   s->thumb_bytes = (size_t)(s->W / 8) * (s->H / 8) * 36;
-  s->block_bytes = s->thumb_bytes + kMetaBytes;
+  s->block_bytes = (s->thumb_bytes + kMetaBytes + 255) & ~(size_t)255;  // (every block 16-byte aligned whatever the image size: 1241 x 376)
   s->frame_of.resize(s->n);
   int rc = DMS_OK;
   for (int c = 0; c < s->n && !rc; ++c) {
@@ -504,6 +676,17 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   s->d_frame_rgb = alloc(N * 3);
   s->d_frame_depth = (unsigned short*)alloc(N * 2);
   s->d_tex = (unsigned char*)alloc(N * 36);
+  s->tail_off = (s->thumb_bytes + 15) & ~(size_t)15;
+  s->ablock_bytes = (s->tail_off + kTailBytes + 255) & ~(size_t)255;
+  if (s->world * s->n <= kMaxQueries) {  // (larger sessions run the synchronous step only)
+    for (int b = 0; b < 2; ++b) {
+      s->d_alocal[b] = (unsigned char*)alloc((size_t)s->n * s->ablock_bytes);
+      s->d_agathered[b] = (unsigned char*)alloc((size_t)s->world * s->n * s->ablock_bytes);
+      if (!rc && hipHostMalloc((void**)&s->ring[b].host, (size_t)s->world * s->n * kTailHostBytes) != hipSuccess) rc = DMS_ERR_HIP;
+      if (!rc && hipEventCreateWithFlags(&s->ring[b].done, hipEventDisableTiming) != hipSuccess) rc = DMS_ERR_HIP;
+    }
+    s->can_pipeline = !rc;
+  }
   if (rc) {
     dms_session_destroy(s);
     return rc;
@@ -526,7 +709,12 @@ int dms_session_destroy(dms_session* s) {
   for (auto& kv : s->cams) free_camera(kv.second);
   for (auto& kv : s->ferns) dms_ferns_destroy(kv.second);
   for (auto& kv : s->refiners) dms_refframe_destroy(kv.second);
-  void* bufs[] = {s->d_local, s->d_gathered, s->d_table, s->d_pose, s->d_small, s->d_frame_rgb, s->d_frame_depth, s->d_tex};
+  for (int b = 0; b < 2; ++b) {
+    if (s->ring[b].host) (void)hipHostFree(s->ring[b].host);
+    if (s->ring[b].done) (void)hipEventDestroy(s->ring[b].done);
+  }
+  void* bufs[] = {s->d_local, s->d_gathered, s->d_table, s->d_pose, s->d_small, s->d_frame_rgb, s->d_frame_depth, s->d_tex,
+                  s->d_alocal[0], s->d_alocal[1], s->d_agathered[0], s->d_agathered[1]};
   for (void* b : bufs)
     if (b) dms_device_free(b);
   delete s;
@@ -537,6 +725,9 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
   DMS_REQUIRE(s && rgb_dev && depth_dev, "null argument");
   const size_t N = (size_t)s->W * s->H;
   int rc = DMS_OK;
+  if ((rc = drain_entries(s))) return rc;  // (pipelined ticks before this one: their pose-graph rows come first)
+  invalidate_searches(s, k);               // (and their searches wake nothing: this tick queries every pair itself)
+  s->last_stream = st;
   // 1 + 2. forward the frames of cameras hosted elsewhere; every hosted camera's frame, in id order.  (A frame that arrives from
   // another rank is processed when its camera's turn comes: receive and process are interleaved in camera order on both sides.)
   std::map<int, int> read_index;  // camera read here -> position in rgb_dev / depth_dev
@@ -554,14 +745,17 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
     if (host != s->rank) continue;
     // Nothing waits for the host between two cameras' frames: they pipeline on the stream like the frames of one camera (each
     // context's live half on its own prep stream, beside the previous frame).  A frame read here is processed where the caller put
-    // it (the step returns after the fetch below, so the buffer outlives its use) and copied into the camera's last-frame buffer
-    // - what a later migration ships - behind it; a forwarded frame is received straight into that buffer.
+    // it (the step returns after the fetch below, so the buffer outlives its use; a migration inside this step ships it from there)
+    // ; a forwarded frame is received into the camera's own buffer.
     Camera& cam = s->cams.at(c);
     if (src == s->rank) {
       const int i = read_index.at(c);
       if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, st))) return rc;
-      if ((rc = dms_memcpy_d2d_async(cam.last_rgb, rgb_dev[i], N * 3, st)) || (rc = dms_memcpy_d2d_async(cam.last_depth, depth_dev[i], N * 2, st))) return rc;
+      cam.frame_rgb = rgb_dev[i];
+      cam.frame_depth = depth_dev[i];
     } else {
+      cam.frame_rgb = cam.last_rgb;
+      cam.frame_depth = cam.last_depth;
       if ((rc = t_recv(s, cam.last_rgb, N * 3, src, st)) || (rc = t_recv(s, cam.last_depth, N * 2, src, st))) return rc;
       if ((rc = dms_fusion_inputs_ready(cam.f, st))) return rc;  // (a stream-ordered transport: the frame's ingest, on the context's own stream, behind the receive)
       if ((rc = dms_fusion_process_frame(cam.f, cam.last_rgb, 3, cam.last_depth, nullptr, 1.f, st))) return rc;
@@ -621,56 +815,158 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
       ticks[ids[0]] = ids[1];
       poses[ids[0]] = std::vector<float>(meta + 4, meta + 20);
     }
-  // 4. queries.  A failure on one rank must not leave the others waiting in the next collective: it travels in the table's last
-  // row and every rank returns together.
-  const size_t tab_floats = (size_t)(s->n + 1) * s->n * kRow;
-  std::vector<float> table(tab_floats, 0.f), tables(tab_floats * s->world, 0.f);
-  int qrc = query(s, k, host_counts, slots, poses, ticks, blocks, table.data(), st);
-  if (qrc) table[(size_t)s->n * s->n * kRow] = 1.f;
-  if ((rc = dms_memcpy_h2d(s->d_table, table.data(), tab_floats * 4, st))) return rc;
-  if ((rc = t_allgather(s, s->d_table, s->d_table + tab_floats, tab_floats * 4, st)) || (rc = sync(st))) return rc;
-  if ((rc = dms_memcpy_d2h(tables.data(), s->d_table + tab_floats, tab_floats * 4 * s->world, st))) return rc;
-  for (int r = 0; r < s->world; ++r)
-    if (tables[(size_t)r * tab_floats + (size_t)s->n * s->n * kRow] != 0.f) {
-      if (!qrc) set_error("dms_session_step: the inter-map query failed on rank %d at tick %d", r, k);
-      return qrc ? qrc : DMS_ERR_STATE;
+  return decide_and_merge(s, k, ~0ull, poses, ticks, blocks, st);
+}
+
+
+int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st) {
+  DMS_REQUIRE(s && rgb_dev && depth_dev, "null argument");
+  DMS_REQUIRE(s->can_pipeline, "the pipelined step serves world * n_cameras <= 64");
+  DMS_REQUIRE(!s->p.camera.reloc, "the pipelined step does not read the tracker's verdict: relocalisation must be off");
+  const size_t N = (size_t)s->W * s->H;
+  hipStream_t hs = (hipStream_t)st;
+  int rc = DMS_OK;
+  s->last_stream = st;
+  s->async_ticks += 1;
+  // 0. what the device finished two ticks ago: pose-graph rows, and whether a descriptor search (of tick k - 3) hit
+  {
+    dms_session::Entry& e = s->ring[k & 1];
+    DMS_REQUIRE(e.consumed || e.tick == k - 2, "dms_session_step_async: ticks must be consecutive");
+    if ((rc = consume_entry(s, e, true))) return rc;
+  }
+  s->wake_ticks.erase(s->wake_ticks.begin(), s->wake_ticks.lower_bound(k));
+  const bool wake = s->wake_ticks.count(k) != 0;
+  // 1 + 2. frames, as the synchronous step enqueues them; nothing is fetched
+  std::map<int, int> read_index;
+  {
+    int i = 0;
+    for (int c = 0; c < s->n; ++c)
+      if (c % s->world == s->rank) read_index[c] = i++;
+  }
+  for (int c = 0; c < s->n; ++c) {
+    const int src = c % s->world, host = host_of_camera(s, c);
+    if (src != host && src == s->rank) {
+      const int i = read_index.at(c);
+      if ((rc = t_send(s, rgb_dev[i], N * 3, host, st)) || (rc = t_send(s, depth_dev[i], N * 2, host, st))) return rc;
     }
-  // 5. the same walk on every rank (cameras in id order, frames in id order; first accepted candidate wins, one merge per frame and tick)
-  struct Decided {
-    int fb, fa;
-    float T[16];
-  };
-  std::vector<Decided> decided;
-  std::set<int> busy;
-  for (int a = 0; a < s->n; ++a) {
-    const int fa = s->frame_of[a];
-    if (busy.count(fa) || k < s->p.query_from) continue;
-    std::set<int> frames(s->frame_of.begin(), s->frame_of.end());
-    for (int fb : frames) {
-      if (fb == fa || busy.count(fb)) continue;
-      const float* e = &tables[(size_t)s->host_of_frame.at(fb) * tab_floats + ((size_t)a * s->n + fb) * kRow];
-      DMS_REQUIRE(e[0] == 1.f, "no verification result for a camera / frame pair");
-      if (e[1] < 0.f) continue;
-      Decided d;
-      d.fb = fb;
-      d.fa = fa;
-      if (s->p.full_refine) {
-        int accepted = 0;
-        if ((rc = refine(s, a, fb, e + 2, poses.at(a).data(), ticks.at(a), &accepted, d.T, st))) return rc;
-        s->refinements.push_back(Refinement{k, a, fb, accepted});
-        if (!accepted) continue;
-      } else {
-        dms_relative_transform(e + 2, poses.at(a).data(), d.T);
-      }
-      decided.push_back(d);
-      busy.insert(fa);
-      busy.insert(fb);
-      break;
+    if (host != s->rank) continue;
+    Camera& cam = s->cams.at(c);
+    if (src == s->rank) {
+      const int i = read_index.at(c);
+      if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, st))) return rc;
+      cam.frame_rgb = rgb_dev[i];
+      cam.frame_depth = depth_dev[i];
+    } else {
+      cam.frame_rgb = cam.last_rgb;
+      cam.frame_depth = cam.last_depth;
+      if ((rc = t_recv(s, cam.last_rgb, N * 3, src, st)) || (rc = t_recv(s, cam.last_depth, N * 2, src, st))) return rc;
+      if ((rc = dms_fusion_inputs_ready(cam.f, st))) return rc;
+      if ((rc = dms_fusion_process_frame(cam.f, cam.last_rgb, 3, cam.last_depth, nullptr, 1.f, st))) return rc;
+    }
+    if (!wake) cam.tick += 1;  // ElasticFusion.cpp:588-591 (the camera is never lost without relocalisation)
+  }
+  if (wake) {
+    // a woken tick is a synchronous one: the previous tick's rows first, then this tick's results from the contexts
+    if ((rc = consume_entry(s, s->ring[(k + 1) & 1], true))) return rc;
+    s->wakes += 1;
+    for (auto& kv : s->cams) {
+      Camera& cam = kv.second;
+      const int tick_before = cam.tick;
+      rc = dms_fusion_fetch(cam.f, &cam.last, st);
+      if (rc && rc != DMS_ERR_CAPACITY) return rc;
+      cam.tick = cam.last.tick;
+      memcpy(cam.pose, cam.last.pose, 64);
+      cam.pg_tick.push_back(tick_before);
+      cam.pg_pose.insert(cam.pg_pose.end(), cam.pose, cam.pose + 16);
+      cam.has_frame = true;
     }
   }
-  // 6. merges
-  for (auto& d : decided)
-    if ((rc = merge(s, k, d.fb, d.fa, d.T, st))) return rc;
+  // 3. publish: thumbnails, pose and tick leave the context in one launch; descriptor + key-frame insertion read the block in place
+  const int slots = slots_now(s);
+  const std::vector<int> mine = cams_of_rank(s, s->rank);
+  unsigned char* local = s->d_alocal[k & 1];
+  // (a one-rank session without a transport gathers nothing: the search reads the blocks where they were packed)
+  unsigned char* gathered = s->local_only ? local : s->d_agathered[k & 1];
+  const size_t T0 = s->tail_off, B = s->ablock_bytes;
+  if (s->ids_tick != (int)s->merges.size()) {  // the camera id of every slot, in both block sets: constant until the placement changes
+    for (int b = 0; b < 2; ++b)
+      for (int i = 0; i < slots; ++i) {
+        const int c = i < (int)mine.size() ? mine[i] : -1;
+        if ((rc = dms_memcpy_h2d(s->d_alocal[b] + (size_t)i * B + T0 + kTailCam, &c, 4, st))) return rc;
+      }
+    s->ids_tick = (int)s->merges.size();
+  }
+  for (int i = 0; i < slots; ++i) {
+    unsigned char* blk = local + (size_t)i * B;
+    if (i >= (int)mine.size()) {  // an empty slot: no good codes (the search passes it over); its id and hit rows stay
+      if (hipMemsetAsync(blk + T0 + kTailGood, 0, 4, hs) != hipSuccess) return DMS_ERR_HIP;
+      continue;
+    }
+    const int c = mine[i];
+    Camera& cam = s->cams.at(c);
+    if ((rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, st))) return rc;
+    if ((rc = dms_ferns_publish_block(s->ferns.at(s->frame_of[c]), blk, blk + T0 + kTailCodes, (int*)(blk + T0 + kTailGood),
+                                      (const float*)(blk + T0 + kTailPose), cam.tick, s->p.fern_threshold, st)))
+      return rc;
+  }
+  const size_t per_rank = (size_t)slots * B;
+  if (!s->local_only && (rc = t_allgather(s, local, gathered, per_rank, st))) return rc;
+  // 4a. every hosted database against every gathered block; the hit rows ride in the NEXT tick's blocks
+  {
+    int d = 0;
+    unsigned char* next_local = s->d_alocal[(k + 1) & 1];
+    for (auto& kv : s->ferns) {
+      if ((rc = dms_ferns_search_blocks_hd(kv.second, gathered, B, s->world * slots, T0 + kTailCodes, T0 + kTailGood, 0, s->p.inter_map ? 1 : 0,
+                                           (int*)(next_local + (size_t)d * B + T0 + kTailHits), st)))
+        return rc;
+      ++d;
+    }
+  }
+  // the tails come to the host beside the next tick (read at the start of tick k + 2): one launch writes them into mapped memory
+  dms_session::Entry& e = s->ring[k & 1];
+  if ((rc = dms_copy_rows_async(e.host, kTailHostBytes, gathered + T0 + kTailGood, B, kTailHostBytes, (size_t)s->world * slots, st))) return rc;
+  if (hipEventRecord(e.done, hs) != hipSuccess) {
+    set_error("dms_session_step_async: mirroring the gathered tails failed");
+    return DMS_ERR_HIP;
+  }
+  e.tick = k;
+  e.consumed = false;
+  e.slots = slots;
+  if (!wake) return DMS_OK;
+  // 4 - 6. the reference's inter-map block for this tick, on this tick's blocks
+  if ((rc = consume_entry(s, e, false))) return rc;
+  std::map<int, std::vector<float>> poses;
+  std::map<int, int> ticks;
+  std::map<int, const unsigned char*> blocks;
+  for (int r = 0; r < s->world; ++r) {
+    const std::vector<int> cs = cams_of_rank(s, r);
+    for (size_t i = 0; i < cs.size(); ++i) {
+      const unsigned char* t = entry_tail(e, r, (int)i);
+      int tick, cam_id;
+      memcpy(&tick, t + (kTailTick - kTailGood), 4);
+      memcpy(&cam_id, t + (kTailCam - kTailGood), 4);
+      DMS_REQUIRE(cam_id == cs[i], "a gathered block is not the camera the placement names");
+      const float* pose = (const float*)(t + (kTailPose - kTailGood));
+      blocks[cam_id] = gathered + (size_t)r * per_rank + i * B;
+      ticks[cam_id] = tick;
+      poses[cam_id] = std::vector<float>(pose, pose + 16);
+    }
+  }
+  const size_t merges_before = s->merges.size();
+  if ((rc = decide_and_merge(s, k, ~0ull, poses, ticks, blocks, st))) return rc;
+  if (s->merges.size() != merges_before) invalidate_searches(s, k);  // (the searches in flight ran on the placement before the merge)
+  return DMS_OK;
+}
+
+int dms_session_sync(dms_session* s) {
+  DMS_REQUIRE(s, "null argument");
+  return drain_entries(s);
+}
+
+int dms_session_async_stats(dms_session* s, int* ticks, int* wakes) {
+  DMS_REQUIRE(s, "null argument");
+  if (ticks) *ticks = s->async_ticks;
+  if (wakes) *wakes = s->wakes;
   return DMS_OK;
 }
 
@@ -746,6 +1042,8 @@ int dms_session_relative_constraints(dms_session* s, int camera, float* rows6, i
 }
 int dms_session_pose_graph(dms_session* s, int camera, int* ticks, float* poses16, int max, int* n) {
   DMS_REQUIRE(s && n && s->cams.count(camera), "the camera is not hosted here");
+  int rc = drain_entries(s);  // (rows of pipelined ticks the device still owes)
+  if (rc) return rc;
   const Camera& cam = s->cams.at(camera);
   *n = (int)cam.pg_tick.size();
   for (int i = 0; i < *n && i < max; ++i) {

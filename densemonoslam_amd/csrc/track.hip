@@ -954,6 +954,8 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   };
 
   if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 64 && tid < 80) s_held[16 + tid - 64] = L.frame->lastPose[tid - 64];  // for the finalize step
+  // (the pose block's bottom row is not the tracker's to write, see the finalize step: it is carried through)
+  if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 80 && tid < 84) s_held[12 + tid - 80] = L.frame->cur.pose[12 + tid - 80];
   if (tid == 0) {
     s_none = 0;
     s_retries = 0;
@@ -1322,26 +1324,32 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       }
       for (int i = 0; i < 3; ++i) st->out_trans[i] = tc[i];
       for (int i = 0; i < 9; ++i) st->out_rot[i] = Rc[i];
+      // The frame step's pose block IS context.currPose(): the reference assigns the tracker's result to its top three rows only
+      // (`currPose.topRightCorner(3, 1) = trans; currPose.topLeftCorner(3, 3) = rot`, ElasticFusion.cpp:246-247), so a bottom row
+      // that is not exactly (0 0 0 1) - after a map merge, currPose = relativeTransform * currPose with relativeTransform =
+      // recoveryPose * currPose.inverse(), a general 4 x 4 inverse (ReferenceFrame.h:95, :131) - stays with the camera, and
+      // pose.inverse() (every shader's t_inv) sees it.  A pose matrix of the caller's own gets a fresh bottom row.
+      const bool own = L.frame && L.pose16_out == L.frame->cur.pose;
       if (L.pose16_out) {
         for (int i = 0; i < 3; ++i) {
           for (int j = 0; j < 3; ++j) L.pose16_out[i * 4 + j] = Rc[i * 3 + j];
           L.pose16_out[i * 4 + 3] = tc[i];
         }
-        L.pose16_out[12] = 0.f;
-        L.pose16_out[13] = 0.f;
-        L.pose16_out[14] = 0.f;
-        L.pose16_out[15] = 1.f;
+        if (!own) {
+          L.pose16_out[12] = 0.f;
+          L.pose16_out[13] = 0.f;
+          L.pose16_out[14] = 0.f;
+          L.pose16_out[15] = 1.f;
+        }
       }
       if (L.frame) {
-        // (the pose block the frame step hands in IS the frame state's current pose: then this block holds both matrices)
-        const bool own = L.pose16_out == L.frame->cur.pose;
+        // (the pose block the frame step hands in IS the frame state's current pose: then this block holds both matrices;
+        // s_held[12..15] took the block's bottom row at the start of the kernel)
         if (own) {
           for (int i = 0; i < 3; ++i) {
             for (int j = 0; j < 3; ++j) s_held[i * 4 + j] = Rc[i * 3 + j];
             s_held[i * 4 + 3] = tc[i];
           }
-          s_held[12] = s_held[13] = s_held[14] = 0.f;
-          s_held[15] = 1.f;
         }
         frame_after_track_body(L.frame, L.weightMultiplier, __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), own ? s_held : nullptr);
       }
@@ -1511,10 +1519,12 @@ __global__ void k_track_finalize(TrackState* st, int rgb, float* __restrict__ po
       for (int j = 0; j < 3; ++j) pose16_out[i * 4 + j] = st->out_rot[i * 3 + j];
       pose16_out[i * 4 + 3] = st->out_trans[i];
     }
-    pose16_out[12] = 0.f;
-    pose16_out[13] = 0.f;
-    pose16_out[14] = 0.f;
-    pose16_out[15] = 1.f;
+    if (!(frame && pose16_out == frame->cur.pose)) {  // (currPose keeps its bottom row: see the finalize step of k_gn_level)
+      pose16_out[12] = 0.f;
+      pose16_out[13] = 0.f;
+      pose16_out[14] = 0.f;
+      pose16_out[15] = 1.f;
+    }
   }
   // frame step: pose16_out is frame->cur.pose; derive its inverse and the velocity weight here
   // instead of in a launch of their own

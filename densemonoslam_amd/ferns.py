@@ -30,6 +30,7 @@ lib.dms_ferns_add_frame_async.argtypes = [_P, _I2, _I2, _I2, _P, C.POINTER(_F), 
 lib.dms_ferns_encode_thumbs.argtypes = [_P, _P, _P, _P, _P]
 lib.dms_ferns_publish_block.argtypes = [_P, _P, _P, _P, _P, _I, C.c_float, _P]
 lib.dms_ferns_search_blocks.argtypes = [_P, _P, C.c_size_t, _I, _I, C.c_size_t, C.c_size_t, _I, _I, _P, _P, _P]
+lib.dms_ferns_search_blocks_hd.argtypes = [_P, _P, C.c_size_t, _I, C.c_size_t, C.c_size_t, _I, _I, _P, _P]
 lib.dms_ferns_consume.argtypes = [_P, _P, C.POINTER(_F), _F, C.POINTER(_I), _P]
 lib.dms_ferns_record_bytes.argtypes = [_P]
 lib.dms_ferns_record_bytes.restype = C.c_size_t
@@ -149,6 +150,11 @@ class Ferns:
         check(lib.dms_ferns_search_blocks(self.h, C.c_void_p(blocks_ptr), stride, count, skip, codes_offset, good_offset, time, int(interMap),
                                           C.c_void_p(best_ptr), C.c_void_p(previous_out) if previous_out else None, stream),
               "dms_ferns_search_blocks")
+
+    def searchBlocksHd(self, blocks_ptr, stride, count, codes_offset, good_offset, time, interMap, hits_ptr, stream=None):
+        """search + the blockHDAware test's operands for every block: count x {candidate, dissimilarity bits, valid in both, equal}"""
+        check(lib.dms_ferns_search_blocks_hd(self.h, C.c_void_p(blocks_ptr), C.c_size_t(stride), count, C.c_size_t(codes_offset), C.c_size_t(good_offset),
+                                             time, int(interMap), C.c_void_p(hits_ptr), stream), "dms_ferns_search_blocks_hd")
 
     def consume(self, other, relativeTransform, threshold, stream=None):
         T = np.ascontiguousarray(relativeTransform, np.float32).reshape(16)

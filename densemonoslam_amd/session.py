@@ -521,6 +521,9 @@ def _native():
     lib.dms_session_create.argtypes = [_C.POINTER(P), _C.POINTER(SessionParams), _C.POINTER(Transport)]
     lib.dms_session_destroy.argtypes = [P]
     lib.dms_session_step.argtypes = [P, _C.c_int, _C.POINTER(P), _C.POINTER(P), P]
+    lib.dms_session_step_async.argtypes = [P, _C.c_int, _C.POINTER(P), _C.POINTER(P), P]
+    lib.dms_session_sync.argtypes = [P]
+    lib.dms_session_async_stats.argtypes = [P, _C.POINTER(_C.c_int), _C.POINTER(_C.c_int)]
     lib.dms_session_frame_of.argtypes = [P, _C.POINTER(_C.c_int)]
     lib.dms_session_host_of_frame.argtypes = [P, _C.c_int]
     lib.dms_session_num_merges.argtypes = [P]
@@ -660,19 +663,34 @@ class NativeSession:
         self.h, self.lib, self.capi = h, lib, capi
         N = width * height
         self._read = [c for c in range(n_cameras) if c % world == rank]
-        self._rgb = [capi.DeviceBuffer(N * 3) for _ in self._read]
-        self._dep = [capi.DeviceBuffer(N * 2) for _ in self._read]
+        # three sets of frame buffers in turn: the pipelined step reads a tick's frames until the step two ticks later has returned
+        self._rgb = [[capi.DeviceBuffer(N * 3) for _ in self._read] for _ in range(3)]
+        self._dep = [[capi.DeviceBuffer(N * 2) for _ in self._read] for _ in range(3)]
 
-    def step(self, k, my_frames):
-        """my_frames: {camera id: (rgb u8 HxWx3, depth u16 HxW)} for the cameras READ on this rank"""
-        P = _C.c_void_p
-        rgb, dep = (P * len(self._read))(), (P * len(self._read))()
+    def step(self, k, my_frames, pipelined=False, stream=None):
+        """my_frames: {camera id: (rgb u8 HxWx3, depth u16 HxW)} for the cameras READ on this rank.
+        pipelined: dms_session_step_async (no host synchronisation; the full query only on a descriptor hit, three ticks late)."""
+        b = int(k) % 3
         for i, c in enumerate(self._read):
             r, d = my_frames[c]
-            self._rgb[i].upload(np.ascontiguousarray(r, np.uint8))
-            self._dep[i].upload(np.ascontiguousarray(d, np.uint16))
-            rgb[i], dep[i] = self._rgb[i].ptr, self._dep[i].ptr
-        self.capi.check(self.lib.dms_session_step(self.h, int(k), rgb, dep, None), "dms_session_step")
+            self._rgb[b][i].upload(np.ascontiguousarray(r, np.uint8))
+            self._dep[b][i].upload(np.ascontiguousarray(d, np.uint16))
+        self.step_resident(k, [x.ptr for x in self._rgb[b]], [x.ptr for x in self._dep[b]], pipelined, stream)
+
+    def step_resident(self, k, rgb_ptrs, depth_ptrs, pipelined=False, stream=None):
+        """the same for frames that already lie in this device's HBM (one pointer per camera read here, ascending)"""
+        P = _C.c_void_p
+        rgb, dep = (P * len(self._read))(*rgb_ptrs), (P * len(self._read))(*depth_ptrs)
+        fn = self.lib.dms_session_step_async if pipelined else self.lib.dms_session_step
+        self.capi.check(fn(self.h, int(k), rgb, dep, P(stream) if stream else None), "dms_session_step_async" if pipelined else "dms_session_step")
+
+    def sync(self):
+        self.capi.check(self.lib.dms_session_sync(self.h), "dms_session_sync")
+
+    def async_stats(self):
+        t, w = _C.c_int(0), _C.c_int(0)
+        self.capi.check(self.lib.dms_session_async_stats(self.h, _C.byref(t), _C.byref(w)))
+        return {"ticks": t.value, "woken": w.value}
 
     # -- the read-only surface of CollabSession ---------------------------------------------------------------------------------
     @property

@@ -109,6 +109,9 @@ int dms_memcpy_h2d(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memcpy_d2h(void* dst, const void* src, size_t bytes, dms_stream s);
 int dms_memcpy_d2d_async(void* dst, const void* src, size_t bytes, dms_stream s); /* stream ordered, no synchronisation */
 int dms_memset(void* dst, int value, size_t bytes, dms_stream s);
+/* `rows` rows of `width` bytes, pitched source to pitched destination, one launch, stream ordered; everything a multiple of 4 bytes.
+ * The destination may be host memory the device can write (hipHostMalloc): how small per-tick metadata reaches the host. */
+int dms_copy_rows_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, dms_stream s);
 /* free / total HBM of the current device (hipMemGetInfo): sizing maps against the 288 GB, leak checks */
 int dms_mem_info(size_t* free_bytes, size_t* total_bytes);
 int dms_stream_sync(dms_stream s);

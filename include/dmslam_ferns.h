@@ -114,6 +114,14 @@ int dms_ferns_search_codes(dms_ferns* f, const unsigned char* codes_dev, const i
 int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride, int count, int skip, size_t codes_offset,
                             size_t good_offset, int time, int interMap, int* best2_dev, int* previous_out, dms_stream s);
 
+/* The batch search followed, in the same stream, by the test that decides whether findFrame verifies a candidate at all
+ * (Ferns.cpp:340-342): hits4_dev receives count x {candidate id or -1, dissimilarity bits, codes valid in both descriptors, of those
+ * equal} (16 bytes each, 16-byte aligned); blockHDAware = equal / valid, a "hit" is blockHDAware > 0.3f.  No block is skipped.  Two
+ * launches (the second re-arms the handle's result words for the next call).  What the pipelined session (dms_session_step_async)
+ * runs every tick in place of the synchronous query. */
+int dms_ferns_search_blocks_hd(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset,
+                               int time, int interMap, int* hits4_dev, dms_stream s);
+
 /* void Ferns::consume(otherFrames, relativeTransform, threshold) (Ferns.cpp:160-168): every stored frame of `src`,
  * re-posed by relativeTransform, goes through addFrame(Frame*, threshold) of `dst` (re-encoded with dst's table).
  * added = frames accepted.  Synchronises. */

@@ -85,6 +85,23 @@ int dms_session_destroy(dms_session* s);
  * same k.  Returns DMS_ERR_STATE on every rank when the query failed on any of them. */
 int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st);
 
+/* The pipelined tick: the same frames, the same publish, the same all-gather - and no host synchronisation.  Nothing is fetched; the
+ * descriptor half of every inter-map query (Ferns.cpp:327-342: minimum dissimilarity over the stored key frames, then blockHDAware > 0.3
+ * against the frame it chose - the test that decides whether findFrame verifies at all) runs on the device for every (hosted database,
+ * gathered block) pair (dms_ferns_search_blocks_hd), and its result rows travel inside the NEXT tick's blocks, so every rank learns of
+ * a hit from the same bytes.  Rule: tick k runs the reference's full inter-map block (steps 4 - 6 above, on tick k's blocks, after
+ * fetching every hosted camera: a woken tick IS a synchronous tick) iff the search enqueued at tick k - 3 hit for any eligible pair
+ * (camera of another frame, k - 3 >= query_from, no merge at or after tick k - 3).  3 = one tick for the rows to ride the gather, two
+ * for the host to read a tick that the device has certainly finished without ever waiting for the one in flight.  Between hits the host
+ * only enqueues.  Pose graphs are completed from the gathered blocks two ticks late (dms_session_sync / dms_session_pose_graph bring
+ * them up to date); dms_session_last_result holds the last FETCHED frame.  Requirements: camera.reloc == 0 (a lost camera is only
+ * seen by a fetch), world * n_cameras <= 64, consecutive k, and the caller's frame buffers of tick k stay unchanged until the step of
+ * tick k + 2 (or dms_session_sync + a stream synchronisation) has returned.  The two steps may be mixed; a synchronous step discards
+ * the hits in flight.  Restated as oracle/orc_pipeline.Session(wake_latency = 3). */
+int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st);
+int dms_session_sync(dms_session* s);                                   /* host state (poses, pose graphs) up to the last enqueued tick */
+int dms_session_async_stats(dms_session* s, int* ticks, int* wakes);    /* pipelined ticks so far, of which woken */
+
 /* state, identical on every rank */
 int dms_session_frame_of(dms_session* s, int* frame_of);               /* n_cameras entries: camera -> reference frame (its founding camera) */
 int dms_session_host_of_frame(dms_session* s, int frame);             /* rank, or -1 when the frame has been consumed */

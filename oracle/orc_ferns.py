@@ -172,10 +172,8 @@ class Ferns:
         with np.errstate(all="ignore"):
             return np.float32(photoSum) / np.float32(photoCount)
 
-    def findFrame(self, currPose, vertex, normal, image, time, lost=False, interMap=False, thumbs=None):
-        """returns dict(closest, candidate, dissimilarity, blockHDAware, icp_error, icp_count, photo_error, estPose, constraints)"""
-        self.lastClosest = -1
-        img, verts, norms = thumbs if thumbs is not None else self._thumbs(image, vertex, normal)
+    def _search(self, img, verts, time, interMap):
+        """Ferns.cpp:327-339: the stored frame of minimum dissimilarity (-1: none eligible)"""
         codes, good, co = self._encode(img, verts)
         minimum, minId = np.float32(3.402823466e+38), -1
         for i, fr in enumerate(self.frames):
@@ -184,6 +182,23 @@ class Ferns:
                 dissim = np.float32(maxCo - np.float32(co[i])) / maxCo
             if dissim < minimum and (interMap or (time - fr.srcTime > 300)):
                 minimum, minId = dissim, i
+        return codes, minimum, minId
+
+    def searchHit(self, thumbs, time, interMap=True):
+        """The first half of findFrame, up to the test that lets the tracker verify at all (Ferns.cpp:327-342): True when a candidate
+        exists and blockHDAware > 0.3 against it.  (What the pipelined session evaluates every tick, dms_ferns_search_blocks_hd.)"""
+        img, verts, _ = thumbs
+        codes, _, minId = self._search(img, verts, time, interMap)
+        if minId == -1:
+            return False
+        with np.errstate(all="ignore"):
+            return bool(self.blockHDAware(codes, self.frames[minId].codes) > np.float32(0.3))
+
+    def findFrame(self, currPose, vertex, normal, image, time, lost=False, interMap=False, thumbs=None):
+        """returns dict(closest, candidate, dissimilarity, blockHDAware, icp_error, icp_count, photo_error, estPose, constraints)"""
+        self.lastClosest = -1
+        img, verts, norms = thumbs if thumbs is not None else self._thumbs(image, vertex, normal)
+        codes, minimum, minId = self._search(img, verts, time, interMap)
         out = dict(closest=-1, candidate=minId, dissimilarity=float(minimum), blockHDAware=0.0, icp_error=0.0, icp_count=0.0, photo_error=0.0,
                    estPose=np.eye(4, dtype=np.float32), constraints=np.zeros((0, 8), np.float32))
         if minId == -1:

@@ -382,9 +382,11 @@ class Session:
 
     def __init__(self, n, width, height, K, fern_seed=20260929, fern_threshold=0.3095, fern_num=500, fern_max_depth_mm=3000,
                  fern_photo_thresh=115.0, inter_map=1, query_from=0, full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05,
-                 icp_count_thresh=35000, **opts):
+                 icp_count_thresh=35000, wake_latency=None, **opts):
         from . import orc_ferns
 
+        # None: every tick queries (the reference's loop, dms_session_step); 3: dms_session_step_async's schedule
+        self.wake_latency, self.hits, self.woken, self.valid_from = wake_latency, {}, [], 0
         self.inter_map = inter_map  # Ferns::findFrame's interMap argument (2: see dmslam_ferns.h)
         self.query_from = query_from  # first tick index at which cameras query other maps (0 = from the start, as the reference would)
         self.n, self.W, self.H, self.K = n, width, height, tuple(float(v) for v in K)
@@ -428,7 +430,18 @@ class Session:
                 continue
             img, v, nrm = blocks[i]
             self.ferns[self.frame_of[i]]._add(img, v, nrm, cam.currPose.copy(), cam.tick, self.fern_threshold)
+        if self.wake_latency is not None:
+            # dms_session_step_async's rule (dmslam_session.h): the descriptor half of every query runs each tick; the inter-map block
+            # below runs at tick k iff that half hit for any eligible pair at tick k - wake_latency and no merge has happened since
+            self.hits[k] = k >= self.query_from and any(
+                self.ferns[fb].searchHit(blocks[a], cam.tick, interMap=True)
+                for a, cam in enumerate(self.cams) for fb in sorted(set(self.frame_of)) if fb != self.frame_of[a])
+            j = k - self.wake_latency
+            if not (j >= self.valid_from and self.hits.get(j, False)):
+                return outs
+            self.woken.append(k)
         busy = set()
+        n_merges = len(self.merges)
         for a, cam in enumerate(self.cams):  # queries, in camera order
             fa = self.frame_of[a]
             if fa in busy or k < self.query_from:
@@ -452,6 +465,8 @@ class Session:
                 self.merges.append((k, fb, fa, T.copy()))
                 busy.update((fa, fb))
                 break
+        if len(self.merges) != n_merges:
+            self.valid_from = k + 1
         return outs
 
     def refine(self, fb, a, recoveryPose):

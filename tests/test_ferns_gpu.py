@@ -274,6 +274,16 @@ def test_async_add_and_descriptor_search_match_the_synchronous_calls(mods):
         assert (prev.download(np.int32, (nb, 2)) == expect).all(), skip
         ga.searchBlocks(allb.ptr, stride, nb, skip, T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, chk.ptr)  # the plain form of the same search
         expect = chk.download(np.int32, (nb, 2))
+    # dms_ferns_search_blocks_hd (the pipelined session's per-tick query half): the search's result and, against the frame it chose, the
+    # operands of blockHDAware - as the synchronous query reports them; twice (the second kernel re-arms the handle's result words)
+    hits = DeviceBuffer(16 * nb)
+    for _ in range(2):
+        ga.searchBlocksHd(allb.ptr, stride, nb, T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, hits.ptr)
+        rows = hits.download(np.int32, (nb, 4))
+        for i, blk in enumerate(blocks):
+            m, _ = gs.findFrameThumbs(blk.ptr, np.eye(4, dtype=np.float32), 1000, interMap=True)
+            assert rows[i, 0] == m.candidate >= 0 and rows[i, 1:2].view(np.float32)[0] == np.float32(m.dissimilarity), i
+            assert rows[i, 2] > 0 and np.float32(rows[i, 3]) / np.float32(rows[i, 2]) == np.float32(m.blockHDAware), (i, rows[i], m.blockHDAware)
     ga.close()
     gs.close()
     ef.close()

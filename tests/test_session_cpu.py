@@ -257,12 +257,12 @@ def _worker(rank, world, port, q, scenario):
     dist.destroy_process_group()
 
 
-def run_oracle_session(scenario, n_ticks=None, relative_cons=True):
+def run_oracle_session(scenario, n_ticks=None, relative_cons=True, **session_opts):
     from densemonoslam_amd import synth
     from oracle import orc_pipeline
 
     sc = SCENARIOS[scenario]
-    s = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts)
+    s = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts, **session_opts)
     if relative_cons:
         for c in range(2):
             s.relative_cons[c].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + c))

@@ -38,8 +38,8 @@ def oracle_session(orc, request):
     return s
 
 
-def _check(ref, host, merges):
-    N_TICKS = n_ticks(ref.scenario)
+def _check(ref, host, merges, N_TICKS=None):
+    N_TICKS = N_TICKS or n_ticks(ref.scenario)
     k_merge, fb, fa, T = ref.merges[0]
     assert [(m[0], m[1], m[2]) for m in merges] == [(k_merge, fb, fa)], merges
     assert np.asarray(merges[0][3], np.float32).tobytes() == T.tobytes(), "the relative transform differs from the oracle's"
@@ -96,7 +96,7 @@ def test_two_cameras_one_device_merge_and_continue(oracle_session, impl):
     s.close()
 
 
-def _worker(rank, world, port, q, scenario, impl):
+def _worker(rank, world, port, q, scenario, impl, pipelined=False, ticks=None):
     sc = SCENARIOS[scenario]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["DMS_TRACK_MODE"] = "launches"  # two processes on one device must not spin side by side
@@ -107,10 +107,10 @@ def _worker(rank, world, port, q, scenario, impl):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s = _make_session(impl, sc, 2, rank, world)
-    for k in range(n_ticks(scenario)):
+    for k in range(ticks or n_ticks(scenario)):
         fr = sc.frames(synth, k)
-        s.step(k, {c: fr[c] for c in fr if c % world == rank})
-    res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements)
+        s.step(k, {c: fr[c] for c in fr if c % world == rank}, **({"pipelined": True} if pipelined else {}))
+    res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements, stats=s.async_stats() if pipelined else None)
     if s.hosted():
         fb = s.frame_of[s.hosted()[0]]
         res.update(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph={c: s.pose_graph[c] for c in s.hosted()},
@@ -209,7 +209,7 @@ def test_native_session_over_a_one_rank_rccl_communicator(orc):
     s.close()
 
 
-def _worker3(rank, world, port, q, impl, ticks, offsets):
+def _worker3(rank, world, port, q, impl, ticks, offsets, pipelined=False):
     sc = SCENARIOS["reference_rule"]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["DMS_TRACK_MODE"] = "launches"  # two processes on one device must not spin side by side
@@ -225,7 +225,7 @@ def _worker3(rank, world, port, q, impl, ticks, offsets):
             if c % world == rank:
                 d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
                 fr[c] = (rgb, d)
-        s.step(k, fr)
+        s.step(k, fr, **({"pipelined": True} if pipelined else {}))
     res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements, frame_of=s.frame_of)
     if s.hosted():
         fb = s.frame_of[s.hosted()[0]]
@@ -276,3 +276,195 @@ def test_three_cameras_two_ranks_chained_merge(orc, impl):
         assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
         for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
             assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
+
+
+# ---- the pipelined step (dms_session_step_async): no host synchronisation, the full query only three ticks after a descriptor hit ----
+PIPE_TICKS = 21
+
+
+@pytest.fixture
+def pipelined_oracle(orc):
+    if "pipelined" not in _ORACLE:
+        s = run_oracle_session("reference_rule", PIPE_TICKS, relative_cons=True, wake_latency=3)
+        q = SCENARIOS["reference_rule"].query_from
+        # the descriptor search hits at the first tick that may query; the reference's block runs three ticks later, verifies and merges
+        assert s.hits[q] and not any(s.hits[k] for k in range(q)) and s.woken == [q + 3], (s.hits, s.woken)
+        assert [(m[0], m[1], m[2]) for m in s.merges] == [(q + 3, 0, 1)] and [r[3] for r in s.refinements] == [True], (s.merges, s.refinements)
+        s.scenario = "reference_rule"
+        _ORACLE["pipelined"] = s
+    return _ORACLE["pipelined"]
+
+
+def test_pipelined_session_one_device(pipelined_oracle):
+    """Every tick through dms_session_step_async: the frames pipeline, nothing is fetched, pose graphs arrive from the gathered blocks
+    two ticks late; one tick wakes (the search of tick 6 hit), runs the reference's block, merges - then both cameras go on in one map
+    without a host round trip.  The same bits as the oracle session on the same schedule (Session(wake_latency = 3))."""
+    from densemonoslam_amd import capi, synth
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    ref = pipelined_oracle
+    sc = SCENARIOS["reference_rule"]
+    s = _make_session("native", sc, 2)
+    for k in range(PIPE_TICKS):
+        s.step(k, sc.frames(synth, k), pipelined=True)
+    assert s.async_stats() == {"ticks": PIPE_TICKS, "woken": len(ref.woken)}
+    assert s.refinements == [r[:4] for r in ref.refinements]
+    fb = ref.merges[0][1]
+    host = dict(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph=s.pose_graph, relative_cons=s.relative_cons)
+    _check(ref, host, s.merges, PIPE_TICKS)
+    s.close()
+
+
+def test_pipelined_and_synchronous_steps_mix(pipelined_oracle):
+    """Ticks 0 - 4 pipelined, 5 - 8 synchronous: the synchronous step completes the pose graphs first and queries every pair itself, so the
+    session merges where the all-synchronous one does (tick 6), and the pipelined ticks behind it wake nobody."""
+    from densemonoslam_amd import synth
+
+    sc = SCENARIOS["reference_rule"]
+    ref = _ORACLE.get("reference_rule") or run_oracle_session("reference_rule", n_ticks("reference_rule"), relative_cons=False)
+    s = _make_session("native", sc, 2)
+    for k in range(12):
+        s.step(k, sc.frames(synth, k), pipelined=not (5 <= k <= 8))
+    assert [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
+    assert s.merges[0][3].tobytes() == ref.merges[0][3].tobytes() and s.async_stats() == {"ticks": 8, "woken": 0}
+    for c in range(2):
+        got, want = s.pose_graph[c], ref.pose_graph[c][:12]
+        assert [t for t, _ in got] == [t for t, _ in want]
+        for (_, a), (_, b) in zip(got, want):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes()
+    s.close()
+
+
+def test_pipelined_session_two_ranks(pipelined_oracle):
+    """The same across two ranks (gloo transport, one GPU): the hit rows ride the all-gather, both ranks wake at the same tick, the map
+    crosses ranks, and from then on rank 1 only forwards its camera's frames - without a synchronisation of its own."""
+    ref = pipelined_oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "reference_rule", "native", True, PIPE_TICKS)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    fb = ref.merges[0][1]
+    hb = fb % world
+    assert results[hb]["hosted"] == [0, 1] and results[1 - hb]["hosted"] == []
+    for r in range(world):
+        assert results[r]["stats"] == {"ticks": PIPE_TICKS, "woken": len(ref.woken)}
+        assert [(m[0], m[1], m[2]) for m in results[r]["merges"]] == [(m[0], m[1], m[2]) for m in ref.merges]
+        assert results[r]["refinements"] == [x[:4] for x in ref.refinements]
+    _check(ref, results[hb], results[hb]["merges"], PIPE_TICKS)
+
+
+def test_pipelined_three_cameras_two_ranks(orc):
+    """Three cameras on two ranks (two slots per rank, an empty one on rank 1; two databases on rank 0), chained merges, pipelined:
+    same bits as the oracle session on the same schedule."""
+    from densemonoslam_amd import synth
+    from oracle import orc_pipeline
+
+    sc = SCENARIOS["reference_rule"]
+    offsets, ticks, world = (0, 8, 16), 17, 2
+    ref = orc_pipeline.Session(3, W, H, K, fern_photo_thresh=sc.fern_photo, wake_latency=3, **sc.opts)
+    for k in range(ticks):
+        ref.step([tuple(reversed(synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)[:2])) for off in offsets], k)
+    print("woken", ref.woken, "merges", [(m[0], m[1], m[2]) for m in ref.merges])
+    assert len(ref.merges) == 2 and len(set(ref.frame_of)) == 1, ref.merges
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, world, port, q, "native", ticks, offsets, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert [(m[0], m[1], m[2]) for m in results[r]["merges"]] == [(m[0], m[1], m[2]) for m in ref.merges]
+        for got, want in zip(results[r]["merges"], ref.merges):
+            assert np.asarray(got[3], np.float32).tobytes() == want[3].tobytes()
+        assert results[r]["frame_of"] == ref.frame_of and results[r]["refinements"] == [x[:4] for x in ref.refinements]
+    host = [r for r in range(world) if results[r]["hosted"]]
+    assert len(host) == 1 and results[host[0]]["hosted"] == [0, 1, 2]
+    fb = ref.frame_of[0]
+    m_ref, m_got = ref.cams[fb].model, results[host[0]]["map"]
+    assert len(m_got) == len(m_ref), (len(m_got), len(m_ref))
+    for f in m_ref.dtype.names:
+        assert np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)), "merged map differs in field " + f
+    for c in range(3):
+        got, want = results[host[0]]["pose_graph"][c], ref.pose_graph[c]
+        assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
+        for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
+
+
+def test_a_merged_camera_keeps_its_pose_bottom_row(orc):
+    """relativeTransform = recoveryPose * currPose.inverse() is a general 4 x 4 inverse (ReferenceFrame.h:95): its bottom row need not be
+    exactly (0 0 0 1), currPose = relativeTransform * currPose (:131) inherits it, and the tracker only ever assigns the top three rows
+    (ElasticFusion.cpp:246-247) - so it stays with the camera and every pose.inverse() sees it.  (Found by the pipelined schedule: a
+    merge at tick 13 whose transform had such a row.)  Two cameras, a join with a perturbed bottom row, three more frames: same bits."""
+    from densemonoslam_amd import fusion, synth
+    from oracle import orc_ferns, orc_pipeline
+
+    sc = SCENARIOS["reference_rule"]
+    g = [fusion.ElasticFusion(W, H, K, timeIdx=c, num_sensors=3, model_capacity=2_000_000) for c in range(2)]
+    o = [orc_pipeline.ElasticFusion(W, H, K, timeIdx=c) for c in range(2)]
+    T = (np.linalg.inv(synth.CORNER_SCENE.pose_fn(0)) @ synth.CORNER_SCENE.pose_fn(sc.offset)).astype(np.float32)  # map 1 -> map 0
+    T[3] = np.array([3e-9, -2e-9, 1e-9, 0.99999994], np.float32)
+    for k in range(7):
+        for c, off in ((0, 0), (1, sc.offset)):
+            d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
+            ro, rg = o[c].processFrame(rgb, d), g[c].processFrame(rgb, d)
+            assert np.array(rg.pose, np.float32).tobytes() == ro.pose.tobytes(), (k, c)
+            if k > 3 and c == 1:
+                assert ro.pose[3].tobytes() != np.array([0, 0, 0, 1], np.float32).tobytes()  # (the row really is carried)
+        if k == 3:
+            o[0].map.model = orc.model_consume(o[0].map.model, o[1].map.model, T)
+            o[1].currPose = orc_ferns._mul44(T, o[1].currPose)
+            o[1].map = o[0].map
+            g[1].joinMap(g[0], T)
+    m_ref, m_got = o[0].model, g[0].globalModel().downloadMap()
+    assert len(m_ref) == len(m_got)
+    for f in m_ref.dtype.names:
+        assert np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)), "map differs in field " + f
+    g[1].close()
+    g[0].close()
+
+
+def test_pipelined_wakes_continue_while_refinements_reject(orc):
+    """Acceptance thresholds nothing passes (icpCountThresh above the pixel count): every search from query_from on hits, so every tick
+    from query_from + 3 on is woken - the hit rows that arrive DURING a woken tick count like any other - each runs the reference's
+    block, refines, rejects; no merge.  A dms_session_sync between two ticks (pose graphs read mid-run) must not lose a hit either."""
+    from densemonoslam_amd import synth
+
+    sc = SCENARIOS["reference_rule"]
+    ticks = sc.query_from + 8
+    opts = dict(sc.opts, icp_count_thresh=10_000_000)
+    from oracle import orc_pipeline
+
+    ref = orc_pipeline.Session(2, W, H, K, fern_photo_thresh=sc.fern_photo, wake_latency=3, **opts)
+    for k in range(ticks):
+        fr = sc.frames(synth, k)
+        ref.step([fr[0], fr[1]], k)
+    assert ref.woken == list(range(sc.query_from + 3, ticks)) and not ref.merges and len(ref.refinements) >= 2, (ref.woken, [r[:4] for r in ref.refinements])
+    import copy
+
+    sc2 = copy.copy(sc)
+    sc2.opts = opts
+    s = _make_session("native", sc2, 2)
+    for k in range(ticks):
+        s.step(k, sc.frames(synth, k), pipelined=True)
+        if k == sc.query_from + 1:
+            assert len(s.pose_graph[0]) == k + 1  # (dms_session_pose_graph drains the outstanding entries)
+    assert s.async_stats() == {"ticks": ticks, "woken": len(ref.woken)} and s.merges == []
+    assert s.refinements == [r[:4] for r in ref.refinements]
+    for c in range(2):
+        got, want = s.pose_graph[c], ref.pose_graph[c]
+        assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
+        for (_, a), (_, b) in zip(got, want):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes()
+    s.close()
