@@ -585,51 +585,53 @@ def main():
                                            "merges": [(m[0], m[1], m[2]) for m in ns.merges], "refinements": ns.refinements, "frame_of": ns.frame_of,
                                            "hosted_on_rank0": ns.hosted()}
         ns.close()
-
-        # The same session through dms_session_step_async: frames resident in HBM, no host synchronisation on the frame's path (pose
-        # graphs arrive from the gathered blocks two ticks late), the reference's full query only at the tick a descriptor hit wakes
-        # (three ticks after the search that hit).  Timed as a whole per phase - the host only enqueues, so a per-tick clock would
-        # measure the enqueue - with a stream synchronisation at each phase boundary.
+        # ... and through the pipelined step (dms_session_step_async), frames resident: the phase before the first woken tick is the
+        # steady state of N independent cameras with the exchange running (what scales weakly); the phase after the last merge is one
+        # rank serving every camera while the others only forward frames.
         from densemonoslam_amd import capi as capi_mod
 
-        N = W * H
-        dev_frames = []
+        n_ticks = 14 + 4 * world
+        Npx = W * H
+        mine = []
         for k in range(n_ticks):
-            row = []
-            for c in range(2):
-                br, bd = capi_mod.DeviceBuffer(N * 3), capi_mod.DeviceBuffer(N * 2)
-                br.upload(np.ascontiguousarray(sframes[k][c][1], np.uint8))
-                bd.upload(np.ascontiguousarray(sframes[k][c][0], np.uint16))
-                row.append((br, bd))
-            dev_frames.append(row)
-        ns = session_mod.NativeSession(W, H, K, 2, query_from=q_from, model_capacity=8_000_000)
+            d, rgbk, _ = synth.frame(k + off * rank, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
+            br, bd = capi_mod.DeviceBuffer(Npx * 3), capi_mod.DeviceBuffer(Npx * 2)
+            br.upload(np.ascontiguousarray(rgbk, np.uint8))
+            bd.upload(np.ascontiguousarray(d, np.uint16))
+            mine.append((br, bd))
         st = capi_mod.create_stream()
 
-        def run(k0, k1):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for k in range(k0, k1):
-                ns.step_resident(k, [dev_frames[k][c][0].ptr for c in range(2)], [dev_frames[k][c][1].ptr for c in range(2)], pipelined=True, stream=st)
-            ns.sync()
-            capi_mod.lib.dms_stream_sync(st)
-            torch.cuda.synchronize()
-            return 1000.0 * (time.perf_counter() - t1)
+        def pipelined_pass(bounds):
+            ns = session_mod.NativeSession(W, H, K, world, rank=rank, world=world, transport=tr, query_from=q_from, model_capacity=8_000_000)
+            ms = []
+            for k0, k1 in zip(bounds[:-1], bounds[1:]):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t1 = time.perf_counter()
+                for k in range(k0, k1):
+                    ns.step_resident(k, [mine[k][0].ptr], [mine[k][1].ptr], pipelined=True, stream=st)
+                ns.sync()
+                capi_mod.lib.dms_stream_sync(st)
+                torch.cuda.synchronize()
+                dist.barrier()
+                ms.append(1000.0 * (time.perf_counter() - t1))
+            res = (ns.merges, ns.async_stats(), ms, ns.frame_of)
+            ns.close()
+            return res
 
-        run(0, 1)  # (the bootstrap frame)
-        pre_ms = run(1, q_from + 3)              # no query is due before query_from, no wake before query_from + 3
-        wake_ms = run(q_from + 3, q_from + 4)    # the woken tick: fetch, full query, refinement, merge
-        post_ms = run(q_from + 4, n_ticks)
-        mg2 = ns.merges
-        out["session"]["pipelined"] = {
-            "what": "dms_session_step_async on the same frames, resident in HBM; phases timed whole (stream synchronised at the boundaries)",
-            "merges": [(m[0], m[1], m[2]) for m in mg2], "stats": ns.async_stats(),
-            "ms_per_tick_before_merge": round(pre_ms / (q_from + 2), 3),
-            "frames_per_s_before_merge": round(2000.0 * (q_from + 2) / pre_ms, 1),
-            "ms_woken_tick": round(wake_ms, 3),
-            "ms_per_tick_after_merge": round(post_ms / (n_ticks - q_from - 4), 3),
-            "frames_per_s_after_merge": round(2000.0 * (n_ticks - q_from - 4) / post_ms, 1),
-        }
-        ns.close()
+        mg2, _, _, _ = pipelined_pass([0, n_ticks])
+        if mg2 and mg2[-1][0] + 1 < n_ticks and q_from + 3 > 1:
+            first_wake, last = q_from + 3, mg2[-1][0]
+            mg2, stats2, ms2, fo2 = pipelined_pass([0, 1, first_wake, last + 1, n_ticks])
+            if rank == 0:
+                out["session_across_ranks"]["pipelined"] = {
+                    "merges": [(m[0], m[1], m[2]) for m in mg2], "stats": stats2, "frame_of": fo2,
+                    "ms_per_tick_before_first_wake": round(ms2[1] / (first_wake - 1), 3),
+                    "frames_per_s_before_first_wake": round(1000.0 * world * (first_wake - 1) / ms2[1], 1),
+                    "ms_wake_and_merge_phase": round(ms2[2], 3), "ticks_in_that_phase": last + 1 - first_wake,
+                    "ms_per_tick_after_last_merge": round(ms2[3] / (n_ticks - last - 1), 3),
+                    "frames_per_s_after_last_merge": round(1000.0 * world * (n_ticks - last - 1) / ms2[3], 1),
+                }
         capi_mod.destroy_stream(st)
 
     # ---- per-kernel timing with HIP events on the launch stream (own passes, not in `value`) ------

@@ -46,8 +46,13 @@ META_BYTES = 80  # per published block: camera id i32 | tick i32 | 2 x pad | pos
 
 class CollabSession:
     def __init__(self, backend, n_cameras, width, height, rank=0, world=1, device=None, fern_threshold=0.3095, inter_map=1, query_from=0,
-                 full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05, icp_count_thresh=35000):
+                 full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05, icp_count_thresh=35000, wake_latency=None):
         self.be, self.n, self.W, self.H = backend, n_cameras, width, height
+        # None: every tick queries (dms_session_step).  3: dms_session_step_async's schedule in this model - the descriptor half of every
+        # query (Ferns::searchHit) runs each tick on the owner's rank, the flags are gathered, and the inter-map block runs at tick k iff
+        # any eligible pair hit at tick k - 3 and no merge has happened since (include/dmslam_session.h).  The model itself stays
+        # host-synchronous: what it checks is the rule, across ranks.
+        self.wake_latency, self.hits, self.woken, self.valid_from = wake_latency, {}, [], 0
         self.rank, self.world = rank, world
         self.device = device or torch.device("cpu")
         self.fern_threshold = fern_threshold
@@ -148,6 +153,15 @@ class CollabSession:
                 meta = raw[self.block_bytes - META_BYTES:].view(np.float32)
                 c, tick = (int(v) for v in meta[:2].view(np.int32))
                 blocks[c] = (raw[:self.block_bytes - META_BYTES], meta[4:20].reshape(4, 4).copy(), tick)
+        if self.wake_latency is not None:
+            mine = k >= self.query_from and any(self.ferns[fb].searchHit(blocks[a][0]) for fb in sorted(self.ferns) for a in range(self.n)
+                                                if self.frame_of[a] != fb)
+            flags = self._allgather(np.array([1 if mine else 0], np.uint8))
+            self.hits[k] = bool(flags.any())
+            j = k - self.wake_latency
+            if not (j >= self.valid_from and self.hits.get(j, False)):
+                return out
+            self.woken.append(k)
         # 4. owner computes: every hosted reference frame against every camera of another frame.  A failure on one rank must not
         # leave the others waiting in the next collective: it travels in the table's last row and every rank raises together.
         table = np.zeros((self.n + 1, self.n, 18), np.float32)  # [camera a][frame fb] = valid, closest, recoveryPose; [n][0][0] = error flag
@@ -198,6 +212,8 @@ class CollabSession:
         # 6. merges
         for fb, fa, T in decided:
             self._merge(k, fb, fa, T)
+        if decided:
+            self.valid_from = k + 1
         return out
 
     def _refine(self, k, a, fb, recoveryPose, currPose, tick):
@@ -424,6 +440,17 @@ class _GpuFerns:
         t = self._dev(blk)
         m, _ = self.db.findFrameThumbs(t.data_ptr(), np.ascontiguousarray(pose, np.float32), int(tick), False, int(inter_map), None)
         return int(m.closest), int(m.candidate), np.array(m.estPose, np.float32).reshape(4, 4)
+
+    def searchHit(self, blk):
+        """the first half of findFrame up to `blockHDAware > 0.3` (Ferns.cpp:327-342) for one thumbnail block"""
+        T = self.be.block_bytes()
+        t = torch.zeros(T + 1024, dtype=torch.uint8, device=self.be.device)
+        t[:T] = self._dev(blk)
+        rows = torch.zeros(4, dtype=torch.int32, device=self.be.device)
+        self.db.encodeThumbs(t.data_ptr(), t.data_ptr() + T, t.data_ptr() + T + 512, None)
+        self.db.searchBlocksHd(t.data_ptr(), T + 1024, 1, T, T + 512, 0, True, rows.data_ptr(), None)
+        r = rows.cpu().numpy()
+        return bool(r[0] >= 0 and np.float32(r[3]) / np.float32(r[2]) > np.float32(0.3))
 
     def consume(self, other, T, thr):
         self.db.consume(other.db, T, thr)

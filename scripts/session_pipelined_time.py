@@ -1,3 +1,5 @@
+"""Steady-state cost of a pipelined session tick (dms_session_step_async) for n cameras on this GPU, frames resident, no query due:
+    python scripts/session_pipelined_time.py [n_cameras]      (run on the GPU box)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch

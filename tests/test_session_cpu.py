@@ -162,6 +162,9 @@ class _OrcFerns:
                               thumbs=self._unpack(blk))
         return m["closest"], m["candidate"], m["estPose"]
 
+    def searchHit(self, blk):
+        return self.db.searchHit(self._unpack(blk), 0, interMap=True)
+
     def consume(self, other, T, thr):
         self.db.consume(other.db, T, thr)
 
@@ -228,7 +231,7 @@ class _OrcBackend:
         return orc_ferns._mul4v(T, np.append(np.asarray(p, np.float32), np.float32(1)))[:3]
 
 
-def _worker(rank, world, port, q, scenario):
+def _worker(rank, world, port, q, scenario, extra=None):
     sc = SCENARIOS[scenario]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["OMP_NUM_THREADS"] = "4"
@@ -240,7 +243,7 @@ def _worker(rank, world, port, q, scenario):
     orc.set_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     be = _OrcBackend(sc.fern_photo)
-    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **sc.opts)
+    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **sc.opts, **(extra or {}))
     be.session = s
     s.relative_cons[rank].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + rank))  # a constraint row the caller's solver produced before the merge
     hosted_log = []
@@ -251,7 +254,7 @@ def _worker(rank, world, port, q, scenario):
     res = dict(rank=rank, hosted=hosted_log, merges=s.merges, frame_of=s.frame_of, refinements=s.refinements,
                pose_graph={c: s.pose_graph[c] for c in s.hosted()}, relative_cons={c: s.relative_cons[c] for c in s.hosted()},
                maps={f: np.ascontiguousarray(s.cams[next(c for c in s.hosted() if s.frame_of[c] == f)].model()) for f in sorted(s.ferns)},
-               fern_frames={f: len(s.ferns[f]) for f in s.ferns})
+               fern_frames={f: len(s.ferns[f]) for f in s.ferns}, woken=s.woken)
     q.put(res)
     dist.barrier()
     dist.destroy_process_group()
@@ -272,12 +275,17 @@ def run_oracle_session(scenario, n_ticks=None, relative_cons=True, **session_opt
     return s
 
 
-@pytest.mark.parametrize("scenario", ["reference_rule", "thumbnail_only"])
-def test_two_rank_session_merges_and_continues_like_the_one_process_session(orc, scenario):
+# wake = 3: the schedule of the pipelined step (dms_session_step_async): the descriptor half of the queries every tick, the reference's
+# block three ticks after a hit - here the RULE across two ranks (the flags gathered, both ranks woken at the same tick)
+@pytest.mark.parametrize("scenario,wake", [("reference_rule", None), ("thumbnail_only", None), ("reference_rule", 3)])
+def test_two_rank_session_merges_and_continues_like_the_one_process_session(orc, scenario, wake):
     sc = SCENARIOS[scenario]
     N_TICKS, QUERY_FROM = sc.n_ticks, sc.query_from
-    ref = run_oracle_session(scenario)
-    assert len(ref.merges) == 1 and ref.merges[0][0] >= QUERY_FROM and N_TICKS - ref.merges[0][0] > 8, ref.merges
+    extra = {"wake_latency": wake} if wake else {}
+    ref = run_oracle_session(scenario, **extra)
+    assert len(ref.merges) == 1 and ref.merges[0][0] >= QUERY_FROM and N_TICKS - ref.merges[0][0] > (4 if wake else 8), ref.merges
+    if wake:
+        assert ref.woken == [QUERY_FROM + wake] and ref.merges[0][0] == QUERY_FROM + wake, (ref.woken, ref.merges)
     if sc.opts.get("full_refine"):
         # the merge was decided by the reference's rule: a fern match under interMap = 1, then the full-resolution refinement accepted
         # at Options' default thresholds (50 iterations on every level, SO3 pre-alignment run)
@@ -297,7 +305,7 @@ def test_two_rank_session_merges_and_continues_like_the_one_process_session(orc,
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario, extra)) for r in range(world)]
     for p in procs:
         p.start()
     results = {r["rank"]: r for r in [q.get(timeout=900) for _ in range(world)]}
@@ -308,6 +316,7 @@ def test_two_rank_session_merges_and_continues_like_the_one_process_session(orc,
     hb = fb % world  # the consuming frame's rank hosts both cameras afterwards
     for r in range(world):
         res = results[r]
+        assert res["woken"] == ref.woken
         assert [(m[0], m[1], m[2]) for m in res["merges"]] == [(k_merge, fb, fa)], res["merges"]
         assert res["merges"][0][3].tobytes() == T.tobytes(), "ranks / oracle disagree about the relative transform"
         assert res["frame_of"] == ref.frame_of

@@ -468,3 +468,21 @@ def test_pipelined_wakes_continue_while_refinements_reject(orc):
         for (_, a), (_, b) in zip(got, want):
             assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes()
     s.close()
+
+
+def test_python_session_model_on_the_pipelined_schedule(pipelined_oracle):
+    """densemonoslam_amd.session.CollabSession(wake_latency = 3) - the model the CPU tests run over gloo - with the product's engines
+    behind it (its searchHit = dms_ferns_search_blocks_hd on one block): the same wake, merge and bits as the oracle session."""
+    import torch
+
+    from densemonoslam_amd import session, synth
+
+    ref = pipelined_oracle
+    sc = SCENARIOS["reference_rule"]
+    be = session.GpuBackend(W, H, K, torch.device("cuda", 0), fern_opts=dict(photoThresh=sc.fern_photo), model_capacity=2_000_000)
+    s = session.CollabSession(be, 2, W, H, wake_latency=3, **sc.opts)
+    for k in range(ref.merges[0][0] + 3):
+        s.step(k, sc.frames(synth, k))
+    assert s.woken == ref.woken and [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
+    assert np.asarray(s.merges[0][3], np.float32).tobytes() == ref.merges[0][3].tobytes()
+    s.close()
