@@ -561,11 +561,14 @@ def main():
             }
         capi_mod.destroy_stream(st)
 
-    # The same session ACROSS ranks (opt-in: DMS_BENCH_SESSION=1 with --gpus N): one camera per rank, camera r eight frames ahead of
+    # The same session ACROSS ranks (with --gpus N; DMS_BENCH_SESSION=0 skips it, =1 also runs it over gloo): one camera per rank, camera r eight frames ahead of
     # camera r - 1 on the corner path, RCCL transport (dms_transport_rccl) - or gloo through ctypes callbacks in the one-GPU rehearsal.
     # Cameras migrate to the consuming rank as their maps merge; rank 0 reports the per-tick times and the merge log.  Not part of
     # `value`; every rank takes part (the session's collectives).
-    if distributed and os.environ.get("DMS_BENCH_SESSION") == "1" and (W, H) == (640, 480):
+    # It runs AFTER the headline loop and under a watchdog: the library's own RCCL binding (dms_transport_rccl) has only ever formed a
+    # one-rank communicator on the one-GPU boxes this was developed on, so if this leg does not finish (or fails on any rank) rank 0
+    # prints the line with the figures measured so far and an error entry, and every rank exits.
+    def session_across_ranks():
         from densemonoslam_amd import session as session_mod
 
         n_ticks, q_from, off = 16, 6, 8
@@ -633,6 +636,34 @@ def main():
                     "frames_per_s_after_last_merge": round(1000.0 * world * (n_ticks - last - 1) / ms2[3], 1),
                 }
         capi_mod.destroy_stream(st)
+
+    sess_env = os.environ.get("DMS_BENCH_SESSION", "")
+    if distributed and (W, H) == (640, 480) and not args.loop_closure and (sess_env == "1" or (sess_env != "0" and backend == "nccl")):
+        import threading
+
+        limit_s = int(os.environ.get("DMS_BENCH_SESSION_LIMIT", "240"))
+
+        def give_up():
+            if rank == 0:
+                out.setdefault("session_across_ranks", {})["error"] = out.get("session_across_ranks", {}).get("error") or (
+                    "the leg did not finish within %d s; the figures above it were measured before it started" % limit_s)
+                print(json.dumps(out))
+                sys.stdout.flush()
+            os._exit(0)
+
+        timer = threading.Timer(limit_s, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            session_across_ranks()
+        except Exception as e:  # noqa: BLE001 (the other ranks may be waiting in a collective: nobody goes on to the final barrier)
+            import traceback
+
+            traceback.print_exc()
+            if rank == 0:
+                out.setdefault("session_across_ranks", {})["error"] = "%s: %s" % (type(e).__name__, e)
+            threading.Event().wait()  # (until the watchdog ends the process)
+        timer.cancel()
 
     # ---- per-kernel timing with HIP events on the launch stream (own passes, not in `value`) ------
     if rank == 0 and not args.no_kernel_pass:
