@@ -535,7 +535,8 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
     if (!done) {
       const int next_tick = f->lost ? f->tick : f->tick + 1;  // (the tick advances at the end of the frame unless the camera is lost)
       const float second[3] = {0.7f, (float)next_tick, (float)next_tick};
-      const bool dual = mode == 1 && f->p.share_projection && f->p.hybrid_tracking;
+      // (a projection rendered ahead for this camera's next frame is stale by then when other cameras fuse into the same map: not rendered)
+      const bool dual = mode == 1 && f->p.share_projection && f->p.hybrid_tracking && f->model->sharers == 1;
       if (dual && f->pre_valid && (rc = clear_zbuf(f->zbuf2, W * H, s))) return rc;  // (never consumed)
       if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
                               f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s, dual ? second : nullptr, dual ? f->zbuf2 : nullptr, 0,
