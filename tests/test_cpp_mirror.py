@@ -499,3 +499,135 @@ def test_reference_run_loop_runs_two_cameras_a_merge_and_a_paused_camera():
         out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
         assert "ok:" in out.stdout
+
+
+SESSION_SRC = r"""
+// A C++ host written against dms::Session only: MainController::run's camera loop for one rank (here: every camera in this
+// process), through the pipelined tick.  argv[1] = a file of frames {rgb W*H*3, depth W*H*2} per tick and camera.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "densemonoslam_amd/cpp/Session.h"
+int main(int argc, char** argv) {
+  const int W = 320, H = 240, CAMS = 2;
+  dms_session_params p = dms::Session::defaults(CAMS, W, H, 264.f, 264.f, 160.f, 120.f);
+  if (p.n_cameras != CAMS || p.inter_map != 1 || p.full_refine != 1 || p.camera.width != W) return 2;
+  void* fns[] = {(void*)&dms_session_step, (void*)&dms_session_step_async, (void*)&dms_session_sync, (void*)&dms_transport_rccl};
+  for (void* f : fns) if (!f) return 3;
+  if (argc < 4) return 0;  // (compile / link check)
+  const int ticks = std::atoi(argv[2]);
+  p.query_from = std::atoi(argv[3]);
+  p.camera.model_capacity = 2000000;
+  p.camera.num_sensors = 3;
+  int ndev = 0;
+  if (dms_device_count(&ndev) != DMS_OK || ndev < 1) return 10;
+  std::FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 11;
+  const size_t N = (size_t)W * H;
+  std::vector<std::vector<void*>> rgb(ticks, std::vector<void*>(CAMS)), dep(ticks, std::vector<void*>(CAMS));
+  std::vector<unsigned char> host(N * 3);
+  for (int k = 0; k < ticks; ++k)
+    for (int c = 0; c < CAMS; ++c) {  // frames resident in HBM before the loop starts
+      dms::check(dms_device_alloc(&rgb[k][c], N * 3), "alloc");
+      dms::check(dms_device_alloc(&dep[k][c], N * 2), "alloc");
+      if (std::fread(host.data(), 1, N * 3, f) != N * 3) return 12;
+      dms::check(dms_memcpy_h2d(rgb[k][c], host.data(), N * 3, nullptr), "h2d");
+      if (std::fread(host.data(), 1, N * 2, f) != N * 2) return 12;
+      dms::check(dms_memcpy_h2d(dep[k][c], host.data(), N * 2, nullptr), "h2d");
+    }
+  std::fclose(f);
+  dms_stream st = nullptr;
+  dms::check(dms_stream_create(&st), "stream");
+  {
+    dms::Session ses(p);
+    const float a[3] = {0.f, 0.25f, 0.5f}, b[3] = {0.75f, 1.f, 1.25f};
+    ses.addRelativeConstraint(1, a, b);
+    for (int k = 0; k < ticks; ++k) {
+      std::vector<const void*> r = {rgb[k][0], rgb[k][1]};
+      std::vector<const unsigned short*> d = {(const unsigned short*)dep[k][0], (const unsigned short*)dep[k][1]};
+      ses.stepPipelined(k, r, d, st);
+    }
+    ses.sync();
+    int t = 0, w = 0;
+    ses.pipelinedStats(&t, &w);
+    std::printf("stats %d %d\n", t, w);
+    for (const auto& m : ses.merges()) {
+      std::printf("merge %d %d %d", m.tick, m.consumingFrame, m.consumedFrame);
+      for (float v : m.relativeTransform) {
+        unsigned u;
+        std::memcpy(&u, &v, 4);
+        std::printf(" %08x", u);
+      }
+      std::printf("\n");
+    }
+    for (const auto& r : ses.refinements()) std::printf("refinement %d %d %d %d\n", r.tick, r.camera, r.frame, (int)r.accepted);
+    const std::vector<int> fo = ses.frameOf();
+    std::printf("frame_of %d %d hosted %zu pg %zu %zu cons %zu\n", fo[0], fo[1], ses.hosted().size(), ses.poseGraph(0).size(), ses.poseGraph(1).size(),
+                ses.relativeCons(1).size());
+    const auto pg = ses.poseGraph(1);
+    std::printf("last_pose");
+    for (float v : pg.back().second) {
+      unsigned u;
+      std::memcpy(&u, &v, 4);
+      std::printf(" %08x", u);
+    }
+    std::printf("\n");
+  }
+  dms_stream_destroy(st);
+  std::printf("ok\n");
+  return 0;
+}
+"""
+
+
+def _build_session(td):
+    lib_dir = os.path.join(ROOT, "densemonoslam_amd")
+    src, exe = os.path.join(td, "session.cpp"), os.path.join(td, "session")
+    with open(src, "w") as f:
+        f.write(SESSION_SRC)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I" + ROOT, src, "-o", exe, "-L" + lib_dir, "-ldmslam_hip", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_session_mirror_compiles_and_links():
+    """densemonoslam_amd/cpp/Session.h (MainController::run's camera loop for one rank of a node) with a plain host compiler"""
+    with tempfile.TemporaryDirectory() as td:
+        out = subprocess.run([_build_session(td)], capture_output=True, text=True)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_cpp_host_runs_a_pipelined_session_to_the_oracles_merge(orc):
+    """A C++ host against dms::Session: two cameras, the pipelined tick, frames resident - the wake, the merge, the transform's bits and
+    camera 1's last pose are the oracle session's on the same schedule."""
+    import numpy as np
+
+    from densemonoslam_amd import synth
+    from tests.test_session_cpu import SCENARIOS, H, K, W, run_oracle_session
+
+    sc = SCENARIOS["reference_rule"]
+    ticks = sc.query_from + 6
+    ref = run_oracle_session("reference_rule", ticks, relative_cons=False, wake_latency=3)
+    assert (W, H) == (320, 240) and tuple(K) == (264.0, 264.0, 160.0, 120.0) and [(m[0], m[1], m[2]) for m in ref.merges] == [(sc.query_from + 3, 0, 1)]
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_session(td)
+        path = os.path.join(td, "frames.bin")
+        with open(path, "wb") as f:
+            for k in range(ticks):
+                fr = sc.frames(synth, k)
+                for c in range(2):
+                    f.write(np.ascontiguousarray(fr[c][0], np.uint8).tobytes())
+                    f.write(np.ascontiguousarray(fr[c][1], np.uint16).tobytes())
+        out = subprocess.run([exe, path, str(ticks), str(sc.query_from)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+    lines = out.stdout.splitlines()
+    assert "stats %d 1" % ticks in lines
+    hexes = lambda a: " ".join("%08x" % v for v in np.ascontiguousarray(a, np.float32).reshape(-1).view(np.uint32))
+    k, fb, fa, T = ref.merges[0]
+    assert "merge %d %d %d %s" % (k, fb, fa, hexes(T)) in lines, out.stdout
+    assert ["refinement %d %d %d %d" % (r[0], r[1], r[2], int(r[3])) for r in ref.refinements] == [l for l in lines if l.startswith("refinement")]
+    assert "frame_of 0 0 hosted 2 pg %d %d cons 1" % (ticks, ticks) in lines
+    assert "last_pose " + hexes(ref.pose_graph[1][-1][1]) in lines
