@@ -916,8 +916,11 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     int d = 0;
     unsigned char* next_local = s->d_alocal[(k + 1) & 1];
     for (auto& kv : s->ferns) {
-      if ((rc = dms_ferns_search_blocks_hd(kv.second, gathered, B, s->world * slots, T0 + kTailCodes, T0 + kTailGood, 0, s->p.inter_map ? 1 : 0,
-                                           (int*)(next_local + (size_t)d * B + T0 + kTailHits), st)))
+      // (a database whose map already holds every camera has nobody to be queried by - and never will again: frames only merge)
+      bool anyone = false;
+      for (int a = 0; a < s->n; ++a) anyone = anyone || s->frame_of[a] != kv.first;
+      if (anyone && (rc = dms_ferns_search_blocks_hd(kv.second, gathered, B, s->world * slots, T0 + kTailCodes, T0 + kTailGood, 0, s->p.inter_map ? 1 : 0,
+                                                     (int*)(next_local + (size_t)d * B + T0 + kTailHits), st)))
         return rc;
       ++d;
     }
