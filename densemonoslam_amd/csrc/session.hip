@@ -697,6 +697,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
 
 int dms_session_destroy(dms_session* s) {
   if (!s) return DMS_OK;
+  (void)hipDeviceSynchronize();  // (pipelined ticks may still be writing the host mirrors and the block sets freed below)
   // joined cameras first: their owner must outlive them
   for (auto it = s->cams.begin(); it != s->cams.end();) {
     if (s->frame_of[it->first] != it->first) {
