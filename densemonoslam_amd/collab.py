@@ -28,7 +28,17 @@ DESC_CODES, DESC_GOOD, DESC_TICK, DESC_POSE, DESC_BYTES = 0, 512, 516, 520, 592
 
 
 def thumbnail_bytes(width, height):
-    return (width // 8) * (height // 8) * THUMB_BYTES_PER_PIXEL
+    """dms_thumb_block_bytes: n = (W // 8)(H // 8) pixels, [RGBA8 image padded to 16 bytes | RGBA32F vertex | RGBA32F normal] - n * 36 when
+    n is a multiple of 4"""
+    n = (width // 8) * (height // 8)
+    return ((n * 4 + 15) & ~15) + n * 32
+
+
+def thumbnail_offsets(width, height):
+    """(vertex offset, normal offset) inside a thumbnail block"""
+    n = (width // 8) * (height // 8)
+    v = (n * 4 + 15) & ~15
+    return v, v + n * 16
 
 
 def shard_cameras(n_cameras, rank, world):

@@ -4,7 +4,7 @@
 // (`conservatory[i].ids[code]`) to count co-occurrences (Ferns.cpp:208-229) — a pointer chase that is the CPU form
 // of "for every stored frame, how many of its codes equal mine".  Here the database is dense in HBM:
 //   codes  [capacity][512] bytes (500 used, padded with the bad code), one 512-byte line per frame
-//   blocks [capacity][tw*th*36] bytes: RGBA8 image | RGBA32F vertex | RGBA32F normal thumbnails (what verification needs)
+//   blocks [capacity][dms_thumb_block_bytes] bytes: RGBA8 image (padded to 16 bytes) | RGBA32F vertex | RGBA32F normal thumbnails (what verification needs)
 // and a query is three tiny launches on one stream: resize (skipped for a thumbnail block), encode (one block, one lane
 // per fern), search (one wavefront per stored frame: 64 lanes x 8 codes, byte compares, DPP sum, one 64-bit atomicMin of
 // {dissimilarity bits, frame id} — "first strictly smaller" of the reference's loop is "smallest key").  8 000 stored
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void k_fern_thumbs(const uchar4* __restrict__ 
   const size_t q = (size_t)sy * cols + sx;
   const size_t n = (size_t)tw * th;
   reinterpret_cast<uchar4*>(block)[k] = image[q];
-  reinterpret_cast<float4*>(block + n * 4)[k] = vertex[q];
-  reinterpret_cast<float4*>(block + n * 20)[k] = normal[q];
+  reinterpret_cast<float4*>(block + thumb_vertex_off(n))[k] = vertex[q];
+  reinterpret_cast<float4*>(block + thumb_normal_off(n))[k] = normal[q];
 }
 
 // code of every fern (Ferns.cpp:208-233): one lane per fern; also the samples the host-side checks read
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kFernPad) void k_fern_encode(const unsigned char* _
   if (i < num) {
     const size_t n = (size_t)tw * th;
     const int q = (int)tab->y[i] * tw + (int)tab->x[i];
-    v = reinterpret_cast<const float4*>(block + n * 4)[q];
+    v = reinterpret_cast<const float4*>(block + thumb_vertex_off(n))[q];
     pix = reinterpret_cast<const uchar4*>(block)[q];
     if (v.z > 0.f) {
       code = (unsigned char)((((int)pix.x > tab->r[i]) << 3) | (((int)pix.y > tab->g[i]) << 2) | (((int)pix.z > tab->b[i]) << 1) |
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kFernPad) void k_fern_publish(const unsigned char* 
   if (i < num) {
     const size_t n = (size_t)tw * th;
     const int q = (int)tab->y[i] * tw + (int)tab->x[i];
-    v = reinterpret_cast<const float4*>(block + n * 4)[q];
+    v = reinterpret_cast<const float4*>(block + thumb_vertex_off(n))[q];
     pix = reinterpret_cast<const uchar4*>(block)[q];
     if (v.z > 0.f) {
       code = (unsigned char)((((int)pix.x > tab->r[i]) << 3) | (((int)pix.y > tab->g[i]) << 2) | (((int)pix.z > tab->b[i]) << 1) |
@@ -658,8 +658,8 @@ int find_common(dms_ferns* f, const float* currPose16, int time, int lost, int i
   const size_t n = (size_t)f->tw * f->th;
   const unsigned char* fb = f->d_blocks + (size_t)minId * f->block_bytes;
   const float cutoff = (float)f->maxDepth / 1000.0f;
-  if ((rc = dms_odometry_initICPModel(f->rgbd_odom, (const float*)(fb + n * 4), (const float*)(fb + n * 20), cutoff, fernPose, s))) return rc;
-  if ((rc = dms_odometry_initICP_maps(f->rgbd_odom, (const float*)(f->d_cur_block + n * 4), (const float*)(f->d_cur_block + n * 20), cutoff, s)))
+  if ((rc = dms_odometry_initICPModel(f->rgbd_odom, (const float*)(fb + thumb_vertex_off(n)), (const float*)(fb + thumb_normal_off(n)), cutoff, fernPose, s))) return rc;
+  if ((rc = dms_odometry_initICP_maps(f->rgbd_odom, (const float*)(f->d_cur_block + thumb_vertex_off(n)), (const float*)(f->d_cur_block + thumb_normal_off(n)), cutoff, s)))
     return rc;
   DMS_HIP(hipMemcpyAsync(f->h_rgb, fb, n * 4, hipMemcpyDeviceToHost, s));
   float trans[3] = {fernPose[3], fernPose[7], fernPose[11]}, rot[9];
@@ -704,7 +704,7 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
                      float fy, unsigned int seed, int capacity) {
   DMS_REQUIRE(out, "null out");
   DMS_REQUIRE(num >= 1 && num <= DMS_FERN_MAX, "1 <= num <= DMS_FERN_MAX");
-  DMS_REQUIRE(width >= 128 && height >= 128 && width % 8 == 0 && height % 8 == 0, "resolution must be a multiple of 8, at least 128");
+  DMS_REQUIRE(width >= 128 && height >= 128, "resolution at least 128 x 128 (thumbnails are width / 8 x height / 8, Ferns.cpp:23-24)");
   DMS_REQUIRE(maxDepth_mm >= 400, "maxDepth below the depth-threshold range [400, maxDepth] (Ferns.cpp:30)");
   DMS_REQUIRE(capacity >= 1, "capacity");
   dms_ferns* f = new dms_ferns();
@@ -720,7 +720,7 @@ int dms_ferns_create(dms_ferns** out, int num, int maxDepth_mm, float photoThres
   f->cy = cy;
   f->fx = fx;
   f->fy = fy;
-  f->block_bytes = (size_t)f->tw * f->th * 36;
+  f->block_bytes = dms_thumb_block_bytes(width, height);
   // generateFerns (Ferns.cpp:66-84)
   Mt19937 rng(seed);
   f->pos.resize((size_t)num * 2);

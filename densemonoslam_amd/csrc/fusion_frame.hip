@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void k_thumbnails(const uchar4* __restrict__ i
   const size_t q = (size_t)sy * cols + sx;
   const size_t n = (size_t)tw * th;
   reinterpret_cast<uchar4*>(block)[k] = image[q];
-  reinterpret_cast<float4*>(block + n * 4)[k] = vertex[q];
-  reinterpret_cast<float4*>(block + n * 20)[k] = normal[q];
+  reinterpret_cast<float4*>(block + thumb_vertex_off(n))[k] = vertex[q];
+  reinterpret_cast<float4*>(block + thumb_normal_off(n))[k] = normal[q];
 }
 
 // ORB-triggered global loop closure (ElasticFusion.cpp:292-326 inside processFrame; ElasticFusion::applyGlobalLoop, :1148-1200):
@@ -1412,6 +1412,13 @@ int dms_fusion_fetch(dms_fusion* f, dms_frame_result* r, dms_stream st) {
     return DMS_ERR_CAPACITY;
   }
   return report_timeouts(f, hs);
+}
+
+size_t dms_thumb_block_bytes(int width, int height) { return dms::thumb_block_size((size_t)(width / 8) * (size_t)(height / 8)); }
+void dms_thumb_block_offsets(int width, int height, size_t* vertex_offset, size_t* normal_offset) {
+  const size_t n = (size_t)(width / 8) * (size_t)(height / 8);
+  if (vertex_offset) *vertex_offset = dms::thumb_vertex_off(n);
+  if (normal_offset) *normal_offset = dms::thumb_normal_off(n);
 }
 
 int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream st) {

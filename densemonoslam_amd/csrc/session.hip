@@ -647,7 +647,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   s->n = p->n_cameras;
   s->W = p->camera.width;
   s->H = p->camera.height;
-  s->thumb_bytes = (size_t)(s->W / 8) * (s->H / 8) * 36;
+  s->thumb_bytes = dms_thumb_block_bytes(s->W, s->H);
   s->block_bytes = (s->thumb_bytes + kMetaBytes + 255) & ~(size_t)255;  // (every block 16-byte aligned whatever the image size: 1241 x 376)
   s->frame_of.resize(s->n);
   int rc = DMS_OK;

@@ -395,8 +395,15 @@ int dms_fusion_get_image(dms_fusion* f, int which, dms_image2d* view);
 /* Collaborative mode: the per-frame block a camera publishes to the other ranks — the
  * W/8 x H/8 NEAREST thumbnails of its fill-in image (RGBA8), vertex and normal maps (RGBA32F), the
  * inputs of the inter-map fern matcher (Ferns.cpp:277-423) — packed [image | vertex | normal] into
- * (W/8)(H/8) * 36 bytes of device memory, in one launch on `s` (stream-ordered after the frame). */
+ * dms_thumb_block_bytes(W, H) bytes of device memory ((W/8)(H/8) * 36 when that pixel count is a multiple of 4), in one launch on `s`
+ * (stream-ordered after the frame). */
 int dms_fusion_thumbnails(dms_fusion* f, void* block_dev, dms_stream s);
+/* Size and layout of that block for a W x H camera: n = (W / 8)(H / 8) pixels (integer division, as Ferns.cpp:23-24 sizes its
+ * thumbnails), [RGBA8 image: n * 4 bytes, padded to a multiple of 16 | RGBA32F vertex: n * 16 | RGBA32F normal: n * 16].  For n a
+ * multiple of 4 (every size whose thumbnails have an even pixel count in fours, e.g. 640 x 480) that is n * 36 bytes, packed; at
+ * 1241 x 376 (155 x 47) the image section carries 12 bytes of padding. */
+size_t dms_thumb_block_bytes(int width, int height);
+void dms_thumb_block_offsets(int width, int height, size_t* vertex_offset, size_t* normal_offset);
 /* The same launch also copies the frame's pose (16 floats, from its place in HBM) to pose16_dst_dev and writes `tick` to
  * tick_dst_dev (either may be NULL): everything of a published frame block that must be taken before the next frame
  * starts, so that the rest of the exchange (encoding, key-frame database, all-gather, search) can run on a side stream. */

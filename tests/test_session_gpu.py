@@ -486,3 +486,46 @@ def test_python_session_model_on_the_pipelined_schedule(pipelined_oracle):
     assert s.woken == ref.woken and [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
     assert np.asarray(s.merges[0][3], np.float32).tobytes() == ref.merges[0][3].tobytes()
     s.close()
+
+
+@pytest.mark.parametrize("size", ["640x480", "1241x376"])
+def test_pipelined_session_at_the_baseline_sizes(orc, size):
+    """BASELINE's frame sizes (TUM 640 x 480; KITTI 1241 x 376 with its intrinsics: 155 x 47 thumbnails, blocks whose size is no multiple
+    of 16 bytes): two cameras, the pipelined tick, against the oracle session on the same schedule - the wake at tick 9, the merge (fern
+    match under interMap = 1, full-resolution refinement accepted at Options' thresholds), the transform, both trajectories and the
+    merged map three frames past it, bit for bit."""
+    from densemonoslam_amd import session, synth
+    from oracle import orc_pipeline
+
+    sc = SCENARIOS["reference_rule"]
+    W2, H2, K2 = (640, 480, synth.K_640) if size == "640x480" else (1241, 376, synth.K_KITTI)
+    ticks = sc.query_from + 7
+    frames = []
+    for k in range(ticks):
+        fr = {}
+        for c, off in ((0, 0), (1, sc.offset)):
+            d, rgb, _ = synth.frame(k + off, width=W2, height=H2, K=K2, noise=True, scene=synth.CORNER_SCENE)
+            fr[c] = (rgb, d)
+        frames.append(fr)
+    ref = orc_pipeline.Session(2, W2, H2, K2, fern_photo_thresh=sc.fern_photo, wake_latency=3, **sc.opts)
+    for k in range(ticks):
+        ref.step([frames[k][0], frames[k][1]], k)
+    assert ref.woken == [sc.query_from + 3] and [(m[0], m[1], m[2]) for m in ref.merges] == [(sc.query_from + 3, 1, 0)], (ref.woken, ref.merges)
+    assert [r[3] for r in ref.refinements] == [True]
+    s = session.NativeSession(W2, H2, K2, 2, fern_photo_thresh=sc.fern_photo, model_capacity=4_000_000, **sc.opts)
+    for k in range(ticks):
+        s.step(k, frames[k], pipelined=True)
+    assert s.async_stats() == {"ticks": ticks, "woken": 1} and s.refinements == [r[:4] for r in ref.refinements]
+    assert [(m[0], m[1], m[2]) for m in s.merges] == [(m[0], m[1], m[2]) for m in ref.merges]
+    assert s.merges[0][3].tobytes() == ref.merges[0][3].tobytes()
+    fb = ref.merges[0][1]
+    m_ref, m_got = ref.cams[fb].model, s.cams[fb].model()
+    assert len(m_got) == len(m_ref) > 1_000_000, (len(m_got), len(m_ref))
+    for f in m_ref.dtype.names:
+        assert np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)), "merged map differs in field " + f
+    for c in range(2):
+        got, want = s.pose_graph[c], ref.pose_graph[c]
+        assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
+        for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
+            assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
+    s.close()
