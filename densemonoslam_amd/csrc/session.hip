@@ -832,7 +832,8 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
   // 0. what the device finished two ticks ago: pose-graph rows, and whether a descriptor search (of tick k - 3) hit
   {
     dms_session::Entry& e = s->ring[k & 1];
-    DMS_REQUIRE(e.consumed || e.tick == k - 2, "dms_session_step_async: ticks must be consecutive");
+    const dms_session::Entry& e1 = s->ring[(k + 1) & 1];
+    DMS_REQUIRE((e.consumed || e.tick == k - 2) && (e1.consumed || e1.tick == k - 1), "dms_session_step_async: ticks must be consecutive");
     if ((rc = consume_entry(s, e, true))) return rc;
   }
   s->wake_ticks.erase(s->wake_ticks.begin(), s->wake_ticks.lower_bound(k));

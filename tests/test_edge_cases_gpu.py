@@ -96,3 +96,38 @@ def test_large_frame_1280x960_takes_the_launch_per_phase_level_0(fus, orc, synth
         assert int(rg.surfels) == ro.surfels, (k, rg.surfels, ro.surfels)
     surfels_equal(g.globalModel().downloadMap(), o.model, "map at 1280x960")
     g.close()
+
+
+def test_session_and_helper_entry_points_reject_what_they_cannot_serve():
+    """Argument errors of round 5's entry points are reported through the error string, not by a crash: the pipelined step with
+    relocalisation on (a lost camera is only seen by a fetch), non-consecutive pipelined ticks, a synchronous step in between (allowed),
+    dms_copy_rows_async with a misaligned pitch; dms_copy_rows_async itself moves pitched rows into host-visible memory."""
+    import ctypes as C
+
+    from densemonoslam_amd import capi, session, synth
+
+    lib = capi.lib
+    lib.dms_copy_rows_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    src, dst = capi.DeviceBuffer(64 * 10), capi.DeviceBuffer(16 * 10)
+    a = np.arange(640, dtype=np.uint8)
+    src.upload(a)
+    assert lib.dms_copy_rows_async(dst.ptr, 16, src.ptr + 8, 64, 16, 10, None) == 0
+    got = dst.download(np.uint8, (10, 16))
+    assert np.array_equal(got, a.reshape(10, 64)[:, 8:24])
+    assert lib.dms_copy_rows_async(dst.ptr, 16, src.ptr + 8, 62, 16, 10, None) != 0 and b"4-byte" in lib.dms_last_error()
+    frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(5)]
+    fr = lambda k: {0: (frames[k][1], frames[k][0])}
+    s = session.NativeSession(W, H, K, 1, reloc=1)
+    with pytest.raises(capi.DmsError, match="relocalisation"):
+        s.step(0, fr(0), pipelined=True)
+    s.close()
+    s = session.NativeSession(W, H, K, 1)
+    s.step(0, fr(0), pipelined=True)
+    s.step(1, fr(1), pipelined=True)
+    with pytest.raises(capi.DmsError, match="consecutive"):
+        s.step(3, fr(3), pipelined=True)
+    s.step(2, fr(2))  # a synchronous tick completes the pose graph and may follow at any time ...
+    s.step(3, fr(3), pipelined=True)  # ... and the pipelined ticks go on behind it
+    s.step(4, fr(4), pipelined=True)
+    assert [t for t, _ in s.pose_graph[0]] == [1, 2, 3, 4, 5]
+    s.close()
