@@ -88,6 +88,15 @@ struct dms_session {
     unsigned char* host = nullptr; // pinned: world x slots x kTailHostBytes
     hipEvent_t done = nullptr;
   } ring[2];
+  // Pipelined ticks run the cameras of every hosted MAP on a stream of that map's own (cameras that share a map stay serial, as the
+  // reference's loop has them; independent maps overlap, and the exchange on the caller's stream runs beside the next frames).
+  // DMS_SESSION_MAP_STREAMS=0: everything on the caller's stream.
+  struct MapStream {
+    hipStream_t s = nullptr;
+    hipEvent_t blocks = nullptr;  // this tick's frame blocks of the map's cameras are packed
+  };
+  std::map<int, MapStream> map_streams;
+  bool use_map_streams = true;
   int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
   std::set<int> wake_ticks;        // ticks that run the full inter-map block: a search three ticks earlier hit
   int wakes = 0, async_ticks = 0;
@@ -521,6 +530,26 @@ int drain_entries(dms_session* s) {
   return DMS_OK;
 }
 
+// the stream a hosted map's cameras run on in a pipelined tick: its own, unless one of its cameras is read on another rank (the
+// frame arrives through the transport, whose calls stay on the caller's stream)
+int stream_of_map(dms_session* s, int frame, hipStream_t caller, hipStream_t* out, dms_session::MapStream** ms_out) {
+  *out = caller;
+  *ms_out = nullptr;
+  if (!s->use_map_streams) return DMS_OK;
+  for (int c = 0; c < s->n; ++c)
+    if (s->frame_of[c] == frame && c % s->world != s->rank) return DMS_OK;
+  dms_session::MapStream& ms = s->map_streams[frame];
+  if (!ms.s) {
+    if (hipStreamCreateWithFlags(&ms.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ms.blocks, hipEventDisableTiming) != hipSuccess) {
+      set_error("dms_session: could not create a map's stream");
+      return DMS_ERR_HIP;
+    }
+  }
+  *out = ms.s;
+  *ms_out = &ms;
+  return DMS_OK;
+}
+
 // Phases 4 - 6 of a tick on the gathered blocks (camera -> thumbnails in HBM, pose, tick): queries, the common decision walk with the
 // full-resolution refinement, merges.  `only` as in query().
 int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<int, std::vector<float>>& poses, std::map<int, int>& ticks,
@@ -644,6 +673,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
     s->world = t->world;
     s->local_only = false;  // (a one-rank communicator still carries the collectives: the RCCL calls are exercised on a one-GPU box)
   }
+  if (const char* e = getenv("DMS_SESSION_MAP_STREAMS")) s->use_map_streams = atoi(e) != 0;
   s->n = p->n_cameras;
   s->W = p->camera.width;
   s->H = p->camera.height;
@@ -710,6 +740,10 @@ int dms_session_destroy(dms_session* s) {
   for (auto& kv : s->cams) free_camera(kv.second);
   for (auto& kv : s->ferns) dms_ferns_destroy(kv.second);
   for (auto& kv : s->refiners) dms_refframe_destroy(kv.second);
+  for (auto& kv : s->map_streams) {
+    if (kv.second.blocks) (void)hipEventDestroy(kv.second.blocks);
+    if (kv.second.s) (void)hipStreamDestroy(kv.second.s);
+  }
   for (int b = 0; b < 2; ++b) {
     if (s->ring[b].host) (void)hipHostFree(s->ring[b].host);
     if (s->ring[b].done) (void)hipEventDestroy(s->ring[b].done);
@@ -838,13 +872,22 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
   }
   s->wake_ticks.erase(s->wake_ticks.begin(), s->wake_ticks.lower_bound(k));
   const bool wake = s->wake_ticks.count(k) != 0;
-  // 1 + 2. frames, as the synchronous step enqueues them; nothing is fetched
+  // 1 + 2. frames, as the synchronous step enqueues them - each hosted map's cameras on that map's stream; nothing is fetched.  A
+  // camera's frame block (thumbnails, pose, tick: one launch) is packed right behind its frame.
   std::map<int, int> read_index;
   {
     int i = 0;
     for (int c = 0; c < s->n; ++c)
       if (c % s->world == s->rank) read_index[c] = i++;
   }
+  const int slots = slots_now(s);
+  const std::vector<int> mine = cams_of_rank(s, s->rank);
+  unsigned char* local = s->d_alocal[k & 1];
+  // (a one-rank session without a transport gathers nothing: the search reads the blocks where they were packed)
+  unsigned char* gathered = s->local_only ? local : s->d_agathered[k & 1];
+  const size_t T0 = s->tail_off, B = s->ablock_bytes;
+  std::map<int, hipStream_t> cam_stream;
+  std::set<dms_session::MapStream*> used;
   for (int c = 0; c < s->n; ++c) {
     const int src = c % s->world, host = host_of_camera(s, c);
     if (src != host && src == s->rank) {
@@ -853,9 +896,13 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     }
     if (host != s->rank) continue;
     Camera& cam = s->cams.at(c);
+    hipStream_t fs = hs;
+    dms_session::MapStream* ms = nullptr;
+    if ((rc = stream_of_map(s, s->frame_of[c], hs, &fs, &ms))) return rc;
+    cam_stream[c] = fs;
     if (src == s->rank) {
       const int i = read_index.at(c);
-      if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, st))) return rc;
+      if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, (dms_stream)fs))) return rc;
       cam.frame_rgb = rgb_dev[i];
       cam.frame_depth = depth_dev[i];
     } else {
@@ -865,8 +912,19 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
       if ((rc = dms_fusion_inputs_ready(cam.f, st))) return rc;
       if ((rc = dms_fusion_process_frame(cam.f, cam.last_rgb, 3, cam.last_depth, nullptr, 1.f, st))) return rc;
     }
-    if (!wake) cam.tick += 1;  // ElasticFusion.cpp:588-591 (the camera is never lost without relocalisation)
+    if (!wake) {
+      cam.tick += 1;  // ElasticFusion.cpp:588-591 (the camera is never lost without relocalisation)
+      const size_t i = std::find(mine.begin(), mine.end(), c) - mine.begin();
+      unsigned char* blk = local + i * B;
+      if ((rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, (dms_stream)fs))) return rc;
+      if (ms) used.insert(ms);
+    }
   }
+  for (dms_session::MapStream* ms : used)  // the exchange below reads the blocks on the caller's stream
+    if (hipEventRecord(ms->blocks, ms->s) != hipSuccess || hipStreamWaitEvent(hs, ms->blocks, 0) != hipSuccess) {
+      set_error("dms_session_step_async: joining a map's stream failed");
+      return DMS_ERR_HIP;
+    }
   if (wake) {
     // a woken tick is a synchronous one: the previous tick's rows first, then this tick's results from the contexts
     if ((rc = consume_entry(s, s->ring[(k + 1) & 1], true))) return rc;
@@ -874,7 +932,7 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     for (auto& kv : s->cams) {
       Camera& cam = kv.second;
       const int tick_before = cam.tick;
-      rc = dms_fusion_fetch(cam.f, &cam.last, st);
+      rc = dms_fusion_fetch(cam.f, &cam.last, (dms_stream)cam_stream.at(kv.first));  // (synchronises the stream the frame ran on)
       if (rc && rc != DMS_ERR_CAPACITY) return rc;
       cam.tick = cam.last.tick;
       memcpy(cam.pose, cam.last.pose, 64);
@@ -883,13 +941,7 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
       cam.has_frame = true;
     }
   }
-  // 3. publish: thumbnails, pose and tick leave the context in one launch; descriptor + key-frame insertion read the block in place
-  const int slots = slots_now(s);
-  const std::vector<int> mine = cams_of_rank(s, s->rank);
-  unsigned char* local = s->d_alocal[k & 1];
-  // (a one-rank session without a transport gathers nothing: the search reads the blocks where they were packed)
-  unsigned char* gathered = s->local_only ? local : s->d_agathered[k & 1];
-  const size_t T0 = s->tail_off, B = s->ablock_bytes;
+  // 3. publish: descriptor + key-frame insertion read the block in place
   if (s->ids_tick != (int)s->merges.size()) {  // the camera id of every slot, in both block sets: constant until the placement changes
     for (int b = 0; b < 2; ++b)
       for (int i = 0; i < slots; ++i) {
@@ -906,7 +958,7 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     }
     const int c = mine[i];
     Camera& cam = s->cams.at(c);
-    if ((rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, st))) return rc;
+    if (wake && (rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, st))) return rc;
     if ((rc = dms_ferns_publish_block(s->ferns.at(s->frame_of[c]), blk, blk + T0 + kTailCodes, (int*)(blk + T0 + kTailGood),
                                       (const float*)(blk + T0 + kTailPose), cam.tick, s->p.fern_threshold, st)))
       return rc;
