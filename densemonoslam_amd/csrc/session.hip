@@ -90,13 +90,13 @@ struct dms_session {
   } ring[2];
   // Pipelined ticks run the cameras of every hosted MAP on a stream of that map's own (cameras that share a map stay serial, as the
   // reference's loop has them; independent maps overlap, and the exchange on the caller's stream runs beside the next frames).
-  // DMS_SESSION_MAP_STREAMS=0: everything on the caller's stream.
+  // DMS_SESSION_MAP_STREAMS=n: a pool of n streams (default 2), 0: everything on the caller's stream.
   struct MapStream {
     hipStream_t s = nullptr;
     hipEvent_t blocks = nullptr;  // this tick's frame blocks of the map's cameras are packed
   };
-  std::map<int, MapStream> map_streams;
-  bool use_map_streams = true;
+  std::vector<MapStream> map_streams;  // a small pool: the hosted maps take its streams in turn (more streams than hardware queues cost more than they overlap)
+  int n_map_streams = 2;  // (measured on one MI355X, 2 - 8 cameras: two beat one by 5 - 35 %, three and four are no better, four lose with 8 cameras)
   int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
   std::set<int> wake_ticks;        // ticks that run the full inter-map block: a search three ticks earlier hit
   int wakes = 0, async_ticks = 0;
@@ -535,10 +535,14 @@ int drain_entries(dms_session* s) {
 int stream_of_map(dms_session* s, int frame, hipStream_t caller, hipStream_t* out, dms_session::MapStream** ms_out) {
   *out = caller;
   *ms_out = nullptr;
-  if (!s->use_map_streams) return DMS_OK;
+  if (s->n_map_streams <= 0) return DMS_OK;
   for (int c = 0; c < s->n; ++c)
     if (s->frame_of[c] == frame && c % s->world != s->rank) return DMS_OK;
-  dms_session::MapStream& ms = s->map_streams[frame];
+  if (s->map_streams.empty()) s->map_streams.resize(s->n_map_streams);
+  int order = 0;  // this map's place among the maps hosted here (ascending frame id)
+  for (auto& kv : s->host_of_frame)
+    if (kv.second == s->rank && kv.first < frame) ++order;
+  dms_session::MapStream& ms = s->map_streams[order % s->n_map_streams];
   if (!ms.s) {
     if (hipStreamCreateWithFlags(&ms.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ms.blocks, hipEventDisableTiming) != hipSuccess) {
       set_error("dms_session: could not create a map's stream");
@@ -673,7 +677,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
     s->world = t->world;
     s->local_only = false;  // (a one-rank communicator still carries the collectives: the RCCL calls are exercised on a one-GPU box)
   }
-  if (const char* e = getenv("DMS_SESSION_MAP_STREAMS")) s->use_map_streams = atoi(e) != 0;
+  if (const char* e = getenv("DMS_SESSION_MAP_STREAMS")) s->n_map_streams = std::max(0, std::min(16, atoi(e)));
   s->n = p->n_cameras;
   s->W = p->camera.width;
   s->H = p->camera.height;
@@ -740,9 +744,9 @@ int dms_session_destroy(dms_session* s) {
   for (auto& kv : s->cams) free_camera(kv.second);
   for (auto& kv : s->ferns) dms_ferns_destroy(kv.second);
   for (auto& kv : s->refiners) dms_refframe_destroy(kv.second);
-  for (auto& kv : s->map_streams) {
-    if (kv.second.blocks) (void)hipEventDestroy(kv.second.blocks);
-    if (kv.second.s) (void)hipStreamDestroy(kv.second.s);
+  for (auto& ms : s->map_streams) {
+    if (ms.blocks) (void)hipEventDestroy(ms.blocks);
+    if (ms.s) (void)hipStreamDestroy(ms.s);
   }
   for (int b = 0; b < 2; ++b) {
     if (s->ring[b].host) (void)hipHostFree(s->ring[b].host);
