@@ -97,7 +97,11 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
  * them up to date); dms_session_last_result holds the last FETCHED frame.  Requirements: camera.reloc == 0 (a lost camera is only
  * seen by a fetch), world * n_cameras <= 64, consecutive k, and the caller's frame buffers of tick k stay unchanged until the step of
  * tick k + 2 (or dms_session_sync + a stream synchronisation) has returned.  The two steps may be mixed; a synchronous step discards
- * the hits in flight.  Restated as oracle/orc_pipeline.Session(wake_latency = 3). */
+ * the hits in flight.  Restated as oracle/orc_pipeline.Session(wake_latency = 3).
+ * Streams: the frames of the hosted maps run on streams of the session's own (a pool of two that the maps take in turn; cameras that
+ * share a map stay serial on one stream, independent maps overlap; DMS_SESSION_MAP_STREAMS=n sets the pool size, 0 puts everything on
+ * `st`), the exchange on `st`, which joins those streams once per tick: synchronising `st` after a step waits for everything the step
+ * enqueued. */
 int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st);
 int dms_session_sync(dms_session* s);                                   /* host state (poses, pose graphs) up to the last enqueued tick */
 int dms_session_async_stats(dms_session* s, int* ticks, int* wakes);    /* pipelined ticks so far, of which woken */
