@@ -546,6 +546,26 @@ def main():
             ns.close()
             return res
 
+        # one camera, the headline loop's own frames (same K timed steps after W warm-up ticks) through the pipelined tick: what the
+        # session's per-tick exchange costs a GPU that serves ONE camera (without another rank there is no other camera's block to
+        # search: frame block, key-frame insertion and host mirror only)
+        ns1 = session_mod.NativeSession(W, H, K, 1, query_from=1 << 30, model_capacity=8_000_000)
+        for i in range(args.warmup):
+            ns1.step_resident(i, [rgb_t[frame_index(i)].data_ptr()], [dep_t[frame_index(i)].data_ptr()], pipelined=True, stream=st)
+        capi_mod.lib.dms_stream_sync(st)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            ns1.step_resident(i, [rgb_t[frame_index(i)].data_ptr()], [dep_t[frame_index(i)].data_ptr()], pipelined=True, stream=st)
+        ns1.sync()
+        capi_mod.lib.dms_stream_sync(st)
+        torch.cuda.synchronize()
+        el1 = time.perf_counter() - t1
+        ns1.close()
+        out["session"]["one_camera_steady_state"] = {
+            "what": "the headline loop's frames through dms_session_step_async with one camera and no other rank",
+            "frames_per_s": round(args.steps / el1, 1), "of_value": round(args.steps / el1 / fps, 3)}
+
         mg2, _, _ = pipelined_pass([0, n_ticks])  # (where the schedule merges: the timed pass puts its phase boundaries there)
         if mg2:
             km = mg2[0][0]
@@ -622,6 +642,37 @@ def main():
             res = (ns.merges, ns.async_stats(), ms, ns.frame_of)
             ns.close()
             return res
+
+        # ... and the headline's own stream (this rank's camera in the box room, the same K timed steps after W warm-up ticks) through the
+        # pipelined session with no query ever due: N independent cameras with the session's exchange running - the figure to put
+        # beside `value`
+        ns = session_mod.NativeSession(W, H, K, world, rank=rank, world=world, transport=tr, query_from=1 << 30, model_capacity=8_000_000)
+
+        def tick(i):
+            j = frame_index(i)
+            ns.step_resident(i, [rgb_t[j].data_ptr()], [dep_t[j].data_ptr()], pipelined=True, stream=st)
+
+        for i in range(args.warmup):
+            tick(i)
+        capi_mod.lib.dms_stream_sync(st)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            tick(i)
+        ns.sync()
+        capi_mod.lib.dms_stream_sync(st)
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = collab.max_over_ranks(time.perf_counter() - t1, dev)
+        if rank == 0:
+            out["session_across_ranks"]["steady_state"] = {
+                "what": "the headline loop's frames (%d timed steps per rank after %d warm-up ticks) through dms_session_step_async over the "
+                        "transport, no query due: per tick one frame per rank, frame block, key-frame insertion, all-gather, descriptor search of "
+                        "every other camera's block, host mirror" % (args.steps, args.warmup),
+                "frames_per_s": round(world * args.steps / el, 1), "ms_per_tick": round(1000.0 * el / args.steps, 4),
+                "of_value": round(world * args.steps / el / fps, 3)}
+        ns.close()
 
         mg2, _, _, _ = pipelined_pass([0, n_ticks])
         if mg2 and mg2[-1][0] + 1 < n_ticks and q_from + 3 > 1:
