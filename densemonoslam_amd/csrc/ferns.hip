@@ -210,9 +210,15 @@ __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __res
 // rank, the words travel inside the frame block) forms hd_equal / hd_count > 0.3f exactly as find_common does.
 __global__ __launch_bounds__(kFernPad) void k_fern_hd_batch(const unsigned char* __restrict__ db_codes, const unsigned char* __restrict__ base,
                                                             size_t stride, size_t codes_off, int num, unsigned long long* __restrict__ best,
-                                                            int4* __restrict__ out) {
+                                                            int4* __restrict__ out, unsigned* __restrict__ mirror = nullptr, size_t mirror_off = 0,
+                                                            int mirror_words = 0) {
   __shared__ int s_c, s_e;
   const int q = blockIdx.x;
+  // (optional) this block's query block hands `mirror_words` words from byte offset mirror_off on to host-visible memory: the
+  // pipelined session's per-tick metadata (tick, camera, pose, the PREVIOUS search's hit rows) rides this launch instead of one of its own
+  if (mirror)
+    for (int i = threadIdx.x; i < mirror_words; i += blockDim.x)
+      mirror[(size_t)q * mirror_words + i] = reinterpret_cast<const unsigned*>(base + (size_t)q * stride + mirror_off)[i];
   const unsigned long long b = best[q];
   __syncthreads();
   if (threadIdx.x == 0) best[q] = ~0ull;  // (re-armed for the next search of this handle: no memset between two calls)
@@ -998,7 +1004,14 @@ int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride,
 
 int dms_ferns_search_blocks_hd(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset, int time,
                                int interMap, int* hits4_dev, dms_stream st) {
+  return dms_ferns_search_blocks_hd_mirror(f, blocks_dev, stride, count, codes_offset, good_offset, time, interMap, hits4_dev, nullptr, 0, 0, st);
+}
+
+int dms_ferns_search_blocks_hd_mirror(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset,
+                                      int time, int interMap, int* hits4_dev, void* mirror, size_t mirror_offset, size_t mirror_bytes,
+                                      dms_stream st) {
   DMS_REQUIRE(f && blocks_dev && hits4_dev && count >= 1, "bad argument");
+  DMS_REQUIRE(!mirror || ((((uintptr_t)mirror | mirror_offset | mirror_bytes) & 3) == 0 && mirror_bytes >= 4), "4-byte aligned mirror, offset and size required");
   DMS_REQUIRE(((uintptr_t)blocks_dev & 7) == 0 && (stride & 7) == 0 && (codes_offset & 7) == 0 && (good_offset & 3) == 0 && ((uintptr_t)hits4_dev & 15) == 0,
               "8-byte aligned blocks, stride and code offset, 16-byte aligned hit rows required");
   hipStream_t s = (hipStream_t)st;
@@ -1016,7 +1029,7 @@ int dms_ferns_search_blocks_hd(dms_ferns* f, const void* blocks_dev, size_t stri
     DMS_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_fern_hd_batch, dim3(count), dim3(kFernPad), 0, s, f->d_codes, (const unsigned char*)blocks_dev, stride, codes_offset, f->num,
-                     f->d_hd_best, (int4*)hits4_dev);
+                     f->d_hd_best, (int4*)hits4_dev, (unsigned*)mirror, mirror_offset, (int)(mirror_bytes / 4));
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }

@@ -969,23 +969,29 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
   }
   const size_t per_rank = (size_t)slots * B;
   if (!s->local_only && (rc = t_allgather(s, local, gathered, per_rank, st))) return rc;
-  // 4a. every hosted database against every gathered block; the hit rows ride in the NEXT tick's blocks
+  // 4a. every hosted database against every gathered block; the hit rows ride in the NEXT tick's blocks.  The tails come to the host
+  // beside the next tick (read at the start of tick k + 2), written into mapped memory by the first search's second launch (a launch
+  // of its own when no database here has anybody left to be queried by).
+  dms_session::Entry& e = s->ring[k & 1];
   {
     int d = 0;
+    bool mirrored = false;
     unsigned char* next_local = s->d_alocal[(k + 1) & 1];
     for (auto& kv : s->ferns) {
       // (a database whose map already holds every camera has nobody to be queried by - and never will again: frames only merge)
       bool anyone = false;
       for (int a = 0; a < s->n; ++a) anyone = anyone || s->frame_of[a] != kv.first;
-      if (anyone && (rc = dms_ferns_search_blocks_hd(kv.second, gathered, B, s->world * slots, T0 + kTailCodes, T0 + kTailGood, 0, s->p.inter_map ? 1 : 0,
-                                                     (int*)(next_local + (size_t)d * B + T0 + kTailHits), st)))
-        return rc;
+      if (anyone) {
+        if ((rc = dms_ferns_search_blocks_hd_mirror(kv.second, gathered, B, s->world * slots, T0 + kTailCodes, T0 + kTailGood, 0, s->p.inter_map ? 1 : 0,
+                                                    (int*)(next_local + (size_t)d * B + T0 + kTailHits), mirrored ? nullptr : e.host, T0 + kTailGood,
+                                                    kTailHostBytes, st)))
+          return rc;
+        mirrored = true;
+      }
       ++d;
     }
+    if (!mirrored && (rc = dms_copy_rows_async(e.host, kTailHostBytes, gathered + T0 + kTailGood, B, kTailHostBytes, (size_t)s->world * slots, st))) return rc;
   }
-  // the tails come to the host beside the next tick (read at the start of tick k + 2): one launch writes them into mapped memory
-  dms_session::Entry& e = s->ring[k & 1];
-  if ((rc = dms_copy_rows_async(e.host, kTailHostBytes, gathered + T0 + kTailGood, B, kTailHostBytes, (size_t)s->world * slots, st))) return rc;
   if (hipEventRecord(e.done, hs) != hipSuccess) {
     set_error("dms_session_step_async: mirroring the gathered tails failed");
     return DMS_ERR_HIP;

@@ -121,6 +121,12 @@ int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride,
  * runs every tick in place of the synchronous query. */
 int dms_ferns_search_blocks_hd(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset,
                                int time, int interMap, int* hits4_dev, dms_stream s);
+/* The same; its second launch also copies mirror_bytes bytes from byte offset mirror_offset of every block (as they are on entry) to
+ * mirror + q * mirror_bytes - memory the host can read (hipHostMalloc): the per-tick metadata of the gathered blocks reaches the host
+ * without a launch of its own. */
+int dms_ferns_search_blocks_hd_mirror(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset,
+                                      int time, int interMap, int* hits4_dev, void* mirror, size_t mirror_offset, size_t mirror_bytes,
+                                      dms_stream s);
 
 /* void Ferns::consume(otherFrames, relativeTransform, threshold) (Ferns.cpp:160-168): every stored frame of `src`,
  * re-posed by relativeTransform, goes through addFrame(Frame*, threshold) of `dst` (re-encoded with dst's table).
