@@ -239,6 +239,7 @@ struct CleanArgs {
   int transposed;
   int suffix;  // large maps: surfels in the leading run of untouched blocks stay where they are (see model_clean)
   int num_sensors;  // vTimes.length() of copy_unstable.vert: the reference's NUM_CAMERAS = 3 (size.glsl:2), <= DMS_MAX_SENSORS
+  int planes;       // time planes that can hold anything but -3 (surfel.hpp, live_planes): the others are neither read nor moved
 };
 
 // plain aggregates (HIP's float4 is a class with a union inside: as a member of the element it keeps
@@ -266,13 +267,13 @@ struct CleanElem {
 // load element e (map surfel or parked measurement); false when the slot holds nothing
 __device__ __forceinline__ bool clean_load(unsigned e, unsigned M, const SurfelPlanes& sp, size_t cap, const float4* slot_pos,
                                            const float4* slot_col, const float4* slot_nrm, const unsigned char* slot_flag, int nslots,
-                                           int timeIdx, CleanElem& o) {
+                                           int timeIdx, int planes, CleanElem& o) {
   if (e < M) {
     o.pos = ld4(sp.pos + e);
     o.col = ld4(sp.col + e);
     o.nrm = ld4(sp.nrm + e);
 #pragma unroll
-    for (int s = 0; s < DMS_MAX_SENSORS; ++s) o.times[s] = sp.times[(size_t)s * cap + e];
+    for (int s = 0; s < DMS_MAX_SENSORS; ++s) o.times[s] = s < planes ? sp.times[(size_t)s * cap + e] : -3.f;  // (what the plane holds)
     o.vt = sp.times[(size_t)timeIdx * cap + e];
     return true;
   }
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanArgs a, SurfelPlanes s
           // window test of surfels that are in view and inside the time window — fetch them for those only
           v.pos = ld4(sp.pos + e);
 #pragma unroll
-          for (int s = 0; s < DMS_MAX_SENSORS; ++s) v.times[s] = sp.times[(size_t)s * cap + e];
+          for (int s = 0; s < DMS_MAX_SENSORS; ++s) v.times[s] = s < a.planes ? sp.times[(size_t)s * cap + e] : -3.f;
           v.vt = sp.times[(size_t)a.timeIdx * cap + e];
           const f3 lp = xform_point(a.pose->t_inv, mk3(v.pos.x, v.pos.y, v.pos.z));
           const float x = ((a.fx * lp.x) / lp.z) + a.cx, y = ((a.fy * lp.y) / lp.z) + a.cy;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void k_clean_flags(CleanArgs a, SurfelPlanes s
           v.col = windowed ? ld4(sp.col + e) : zero;
           v.nrm = windowed ? ld4(sp.nrm + e) : zero;
           f = (unsigned char)clean_test(a, v);
-        } else if (clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v)) {
+        } else if (clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, a.planes, v)) {
           f = (unsigned char)clean_test(a, v);
         }
         keep[e] = f;
@@ -538,7 +539,7 @@ __device__ void clean_deform(const CleanArgs& a, CleanElem& v) {
 // returns it, so the map stays in one buffer and the traffic is 80 B per surfel for the flags plus
 // 320 B per surfel of the suffix instead of 240 B per surfel of the whole map.
 __global__ __launch_bounds__(256) void k_clean_copy_back(SurfelPlanes staged, SurfelPlanes map, size_t cap, const unsigned* __restrict__ count_new,
-                                                         const unsigned* __restrict__ first_touched) {
+                                                         const unsigned* __restrict__ first_touched, int planes) {
   // a fixed grid walks the blocks behind the prefix that stayed in place: the work follows the suffix, not the map
   const unsigned n = count_new[0];
   for (unsigned b = first_touched[0] + blockIdx.x; (size_t)b * kScanChunk < n; b += gridDim.x) {
@@ -548,7 +549,8 @@ __global__ __launch_bounds__(256) void k_clean_copy_back(SurfelPlanes staged, Su
     map.col[i] = staged.col[i];
     map.nrm[i] = staged.nrm[i];
 #pragma unroll
-    for (int s = 0; s < DMS_MAX_SENSORS; ++s) map.times[(size_t)s * cap + i] = staged.times[(size_t)s * cap + i];
+    for (int s = 0; s < DMS_MAX_SENSORS; ++s)
+      if (s < planes) map.times[(size_t)s * cap + i] = staged.times[(size_t)s * cap + i];
   }
 }
 
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
       const size_t dst = (size_t)running + rank;
       if (dst < cap) {
         CleanElem v;
-        clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v);
+        clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, a.planes, v);
         if (v.vt == -2.f) {  // copy_unstable.vert:124-129
           v.col.w = (float)a.time;
           v.vt = (float)a.time;
@@ -603,7 +605,8 @@ __global__ __launch_bounds__(256) void k_clean_scatter(CleanArgs a, SurfelPlanes
         out.col[dst] = to4(v.col);
         out.nrm[dst] = to4(v.nrm);
 #pragma unroll
-        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? v.vt : v.times[s];
+        for (int s = 0; s < DMS_MAX_SENSORS; ++s)
+          if (s < a.planes) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? v.vt : v.times[s];  // (the other planes hold -3 already)
       }
     }
     // the parked measurement of this element is consumed (a later clean without a fuse must not
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(256) void k_clean_scatter_suffix(CleanArgs a, Surfe
       const size_t dst = (size_t)block_offset[b] + rank;
       if (dst < cap) {
         CleanElem v;
-        clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, v);
+        clean_load(e, M, sp, cap, slot_pos, slot_col, slot_nrm, slot_flag, a.nslots, a.timeIdx, a.planes, v);
         if (v.vt == -2.f) {  // copy_unstable.vert:124-129
           v.col.w = (float)a.time;
           v.vt = (float)a.time;
@@ -641,7 +644,8 @@ __global__ __launch_bounds__(256) void k_clean_scatter_suffix(CleanArgs a, Surfe
         out.col[dst] = to4(v.col);
         out.nrm[dst] = to4(v.nrm);
 #pragma unroll
-        for (int s = 0; s < DMS_MAX_SENSORS; ++s) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? v.vt : v.times[s];
+        for (int s = 0; s < DMS_MAX_SENSORS; ++s)
+          if (s < a.planes) out.times[(size_t)s * cap + dst] = (s == a.timeIdx) ? v.vt : v.times[s];  // (the other planes hold -3 already)
       }
     }
     if (e >= M && e < total) slot_flag[e - M] = 0;  // the parked measurement is consumed
@@ -661,6 +665,7 @@ int model_fuse(dms_model* m, const dms_pose_block* pose, int time, int timeIdx, 
   DMS_REQUIRE(m && pose && rgba && dr && drf && im && cam, "null argument");
   DMS_REQUIRE(!m->pending_update, "a deferred update pass is still pending (index_map applies it)");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  if (m->live_planes < timeIdx + 1) m->live_planes = timeIdx + 1;  // (the update pass stamps times[timeIdx])
   const int W = m->width, H = m->height;
   DMS_REQUIRE(dense_img(*rgba, 4, W, H) && dense_img(*dr, 4, W, H) && dense_img(*drf, 4, W, H) && dense_img(im->index, 4, W, H) &&
                   dense_img(im->vertConf, 16, W, H) && dense_img(im->normRad, 16, W, H),
@@ -763,6 +768,9 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   const bool suffix = graph_nodes == 0 && upper >= m->clean_suffix_min;  // (switch: dms_model_set_clean_suffix_min)
   a.suffix = suffix ? 1 : 0;
   a.num_sensors = m->num_sensors;
+  if (m->live_planes < timeIdx + 1) m->live_planes = timeIdx + 1;
+  static const bool all_planes = getenv("DMS_CLEAN_ALL_PLANES") != nullptr;  // A/B switch: read and move every plane, as before round 5
+  a.planes = all_planes ? DMS_MAX_SENSORS : m->live_planes;
   const SurfelPlanes src = m->buf[m->cur], dst = m->buf[m->cur ^ 1];
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_count, suffix ? m->clean_first : (unsigned*)nullptr);
@@ -784,7 +792,7 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
                        count_out2);
   DMS_CHECK_LAUNCH();
   if (suffix) {
-    hipLaunchKernelGGL(k_clean_copy_back, dim3(suffix_grid), dim3(256), 0, s, dst, src, m->cap, m->d_count_alt, m->clean_first);
+    hipLaunchKernelGGL(k_clean_copy_back, dim3(suffix_grid), dim3(256), 0, s, dst, src, m->cap, m->d_count_alt, m->clean_first, a.planes);
     DMS_CHECK_LAUNCH();
   }
   // the scatter still reads the old count cell; later launches get the new one

@@ -96,6 +96,10 @@ int dms_model_create(dms_model** out, size_t capacity, int width, int height) {
   DMS_HIP(hipMemset(m->d_count, 0, 8 * sizeof(unsigned)));
   hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, 0, m->winner, m->cap, kEmptyWinner);
   DMS_CHECK_LAUNCH();
+  for (int b = 0; b < 2; ++b) {  // every time plane of both buffers: -3.0f, "never seen by this sensor" (surfel.hpp, live_planes)
+    hipLaunchKernelGGL(k_fill_u32, dim3(2048), dim3(256), 0, 0, (unsigned*)m->buf[b].times, m->cap * DMS_MAX_SENSORS, 0xC0400000u);
+    DMS_CHECK_LAUNCH();
+  }
   DMS_HIP(hipDeviceSynchronize());
   m->count_upper = 0;
   if (const char* smin = getenv("DMS_CLEAN_SUFFIX_MIN")) m->clean_suffix_min = (size_t)atoll(smin);  // once, at creation
@@ -202,6 +206,14 @@ static int model_upload_any(dms_model* m, const float* host, unsigned n, int nse
     } else {
       nrm[i] = make_float4(r[8], r[9], r[10], r[11]);
       for (int k = 0; k < nsens; ++k) times[(size_t)k * n + i] = r[12 + k];
+    }
+  }
+  for (int k = DMS_MAX_SENSORS - 1; k >= m->live_planes; --k) {  // the planes the caller's records carry times in (surfel.hpp, live_planes)
+    bool any = false;
+    for (unsigned i = 0; i < n && !any; ++i) any = !(times[(size_t)k * n + i] == -3.0f);
+    if (any) {
+      m->live_planes = k + 1;
+      break;
     }
   }
   const SurfelPlanes& b = m->buf[m->cur];
@@ -363,6 +375,7 @@ int model_initialise(dms_model* m, const dms_image2d* rgba, const dms_image2d* d
   a.maxDepth = maxDepth;
   const int n = a.cols * a.rows;
   const int nb = (n + kScanChunk - 1) / kScanChunk;
+  if (m->live_planes < timeIdx + 1) m->live_planes = timeIdx + 1;
   hipLaunchKernelGGL(k_boot_flags, dim3(nb), dim3(256), 0, s, a, m->keep, m->block_count);
   DMS_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count, (unsigned)m->cap, (unsigned*)nullptr);
@@ -683,6 +696,19 @@ static int consume_finish(dms_model* m, size_t added_upper) {
   return DMS_OK;
 }
 
+// highest time plane (+ 1) in which any record carries something other than the "never seen" marker
+__global__ __launch_bounds__(256) void k_records_live_planes(const float* __restrict__ rec, unsigned n, unsigned* __restrict__ out) {
+  constexpr int stride = 12 + DMS_MAX_SENSORS;
+  unsigned live = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)blockDim.x * gridDim.x)
+    for (int k = DMS_MAX_SENSORS - 1; k >= 0; --k)
+      if (!(rec[i * stride + 12 + k] == -3.0f)) {
+        live = live > (unsigned)(k + 1) ? live : (unsigned)(k + 1);
+        break;
+      }
+  if (live) atomicMax(out, live);
+}
+
 int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStream_t s) {
   DMS_REQUIRE(dst && src && T16 && dst != src, "bad argument");
   {
@@ -706,6 +732,7 @@ int model_consume(dms_model* dst, const dms_model* src, const float* T16, hipStr
   hipLaunchKernelGGL(k_consume_model, dim3(surfel_grid(src->count_upper)), dim3(256), 0, s, dst->buf[dst->cur], dst->cap, dst->d_count,
                      dst->d_count_alt, src->buf[src->cur], src->cap, src->d_count, T);
   DMS_CHECK_LAUNCH();
+  if (dst->live_planes < src->live_planes) dst->live_planes = src->live_planes;
   return consume_finish(dst, src->count_upper);
 }
 
@@ -727,6 +754,16 @@ int model_consume_records(dms_model* dst, const float* rec_dev, unsigned n, cons
   hipLaunchKernelGGL(k_consume_records, dim3(surfel_grid(n)), dim3(256), 0, s, dst->buf[dst->cur], dst->cap, dst->d_count, dst->d_count_alt,
                      rec_dev, n, T);
   DMS_CHECK_LAUNCH();
+  if (n && dst->live_planes < DMS_MAX_SENSORS) {  // which time planes the records carry anything in (surfel.hpp, live_planes)
+    unsigned* cell = dst->clean_first + 2;
+    DMS_HIP(hipMemsetAsync(cell, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_records_live_planes, dim3(surfel_grid(n)), dim3(256), 0, s, rec_dev, n, cell);
+    DMS_CHECK_LAUNCH();
+    unsigned live = 0;
+    DMS_HIP(hipMemcpyAsync(&live, cell, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    DMS_HIP(hipStreamSynchronize(s));
+    if (dst->live_planes < (int)live) dst->live_planes = (int)live;
+  }
   return consume_finish(dst, n);
 }
 

@@ -188,6 +188,11 @@ struct dms_model {
   int pending_time = 0, pending_timeIdx = 0;
   unsigned long version = 0;        // bumped by every operation that changes the map (cached projections are tagged with it)
   int num_sensors = 3;              // per-surfel time slots that take part in the clean's health test (reference NUM_CAMERAS = 3)
+  // Time planes that may hold anything but the "never seen by this sensor" marker -3: plane s carries real times only once a camera
+  // with timeIdx == s has written into this map (or a map / records / an upload that had them was taken in).  Every buffer's planes
+  // are filled with -3 at creation and every writer puts -3 into the planes of the other sensors, so the clean reads and moves only
+  // the first live_planes planes of a surfel (1 for a single camera: 52 instead of 80 bytes per moved surfel).  Never decreases.
+  int live_planes = 0;
   size_t clean_suffix_min = (size_t)1 << 20;  // map size from which the clean runs in suffix mode (DMS_CLEAN_SUFFIX_MIN at create)
   // After a map merge several cameras (frame-step contexts) fuse into this one map (dms_fusion_join_map): how many do, and which of
   // them enqueued the last frame - only that one's result block says anything about the current count.
