@@ -529,3 +529,39 @@ def test_pipelined_session_at_the_baseline_sizes(orc, size):
         for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
             assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
     s.close()
+
+
+def test_pipelined_result_does_not_depend_on_the_stream_arrangement(monkeypatch):
+    """Three cameras on one device, 150 pipelined ticks over a cyclic stream, two merges on the way: pose graphs and the final map are the
+    same bytes whether everything runs on the caller's stream or the maps take a pool of two or three streams (a race between a map's
+    stream and the exchange would show here long before it shows against the oracle's 20 ticks)."""
+    import hashlib
+
+    from densemonoslam_amd import session, synth
+
+    sc = SCENARIOS["reference_rule"]
+    uniq, ticks = 24, 150
+    frames = [{c: tuple(reversed(synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)[:2])) for c, off in enumerate((0, 8, 16))}
+              for k in range(uniq)]
+
+    def run(pool):
+        monkeypatch.setenv("DMS_SESSION_MAP_STREAMS", str(pool))
+        s = session.NativeSession(W, H, K, 3, fern_photo_thresh=sc.fern_photo, model_capacity=3_000_000, **sc.opts)
+        for k in range(ticks):
+            j = k % (2 * (uniq - 1))
+            s.step(k, frames[j if j < uniq else 2 * (uniq - 1) - j], pipelined=True)
+        h = hashlib.sha256()
+        for c, rows in sorted(s.pose_graph.items()):
+            for t, p in rows:
+                h.update(np.int32(t).tobytes() + np.asarray(p, np.float32).tobytes())
+        m = s.cams[s.frame_of[0]].model()
+        for f in m.dtype.names:
+            h.update(np.ascontiguousarray(m[f]).tobytes())
+        out = (h.hexdigest(), [(a, b, c) for a, b, c, _ in s.merges], s.async_stats(), len(m))
+        s.close()
+        return out
+
+    ref = run(0)
+    assert len(ref[1]) == 2 and ref[2]["ticks"] == ticks, ref
+    for pool in (2, 3):
+        assert run(pool) == ref, pool
