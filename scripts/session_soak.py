@@ -1,6 +1,7 @@
 """Determinism soak of the pipelined session (run on the GPU box): 3 cameras on one GPU, several hundred ticks over a cyclic stream;
 the printed hash (pose graphs + final maps) must not depend on the run nor on DMS_SESSION_MAP_STREAMS.
     python scripts/session_soak.py [ticks] [query_from]      (query_from large: three independent maps, no merge)"""
+import hashlib, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 from densemonoslam_amd import synth, session, capi
