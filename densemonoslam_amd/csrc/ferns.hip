@@ -241,6 +241,66 @@ __global__ __launch_bounds__(kFernPad) void k_fern_hd_batch(const unsigned char*
   if (i == 0) out[q] = make_int4(id, (int)(unsigned)(b >> 32), s_c, s_e);
 }
 
+// dms_ferns_search_blocks_hd in ONE launch for databases of up to kPublishFusedMax key frames: one block per query - its 8 waves take
+// the stored frames in turn (the minimum through one LDS word, as k_fern_publish searches), then the block forms the operands of
+// blockHDAware against the frame it chose, and (optionally) mirrors its query block's tail to host-visible memory.  Same arithmetic
+// as k_fern_search_batch + k_fern_hd_batch: the minimum of (dissimilarity bits << 32 | id) does not depend on the order of the visits.
+__global__ __launch_bounds__(kFernPad) void k_fern_search_hd_small(const unsigned char* __restrict__ db_codes, const int* __restrict__ db_good,
+                                                                   const int* __restrict__ db_time, const int* __restrict__ n_dev,
+                                                                   const unsigned char* __restrict__ base, size_t stride, size_t codes_off,
+                                                                   size_t good_off, int time, int all_frames, int num, int4* __restrict__ out,
+                                                                   unsigned* __restrict__ mirror, size_t mirror_off, int mirror_words) {
+  __shared__ unsigned long long s_best;
+  __shared__ int s_c, s_e;
+  const int q = blockIdx.x, i = threadIdx.x;
+  const unsigned char* blk = base + (size_t)q * stride;
+  if (mirror)
+    for (int w = i; w < mirror_words; w += blockDim.x) mirror[(size_t)q * mirror_words + w] = reinterpret_cast<const unsigned*>(blk + mirror_off)[w];
+  if (i == 0) {
+    s_best = ~0ull;
+    s_c = s_e = 0;
+  }
+  __syncthreads();
+  const int n0 = *n_dev;
+  {
+    const int lane = i & 63, wave = i >> 6;
+    const unsigned long long mine = reinterpret_cast<const unsigned long long*>(blk + codes_off)[lane];
+    const int g = *reinterpret_cast<const int*>(blk + good_off);
+    for (int j = wave; j < n0; j += kFernPad / 64) {
+      const unsigned long long theirs = reinterpret_cast<const unsigned long long*>(db_codes + (size_t)j * kFernPad)[lane];
+      int co = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned m = (unsigned)(mine >> (8 * b)) & 0xFFu, t = (unsigned)(theirs >> (8 * b)) & 0xFFu;
+        co += (m != DMS_FERN_BAD_CODE && m == t) ? 1 : 0;
+      }
+      co = wave_sum_i(co);
+      if (lane == 0 && (all_frames || time - db_time[j] > 300)) {
+        const int gj = db_good[j];
+        const float maxCo = (float)(g < gj ? g : gj);
+        const float dissim = (maxCo - (float)co) / maxCo;
+        if (dissim == dissim) atomicMin(&s_best, ((unsigned long long)__float_as_uint(dissim) << 32) | (unsigned)j);
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned long long b = s_best;
+  if (b == ~0ull) {
+    if (i == 0) out[q] = make_int4(-1, 0, 0, 0);
+    return;
+  }
+  const int id = (int)(b & 0xFFFFFFFFull);
+  if (i < num) {
+    const unsigned char a = blk[codes_off + i], c = db_codes[(size_t)id * kFernPad + i];
+    if (a != DMS_FERN_BAD_CODE && c != DMS_FERN_BAD_CODE) {
+      atomicAdd(&s_c, 1);
+      if (a == c) atomicAdd(&s_e, 1);
+    }
+  }
+  __syncthreads();
+  if (i == 0) out[q] = make_int4(id, (int)(unsigned)(b >> 32), s_c, s_e);
+}
+
 // addFrame's decision (Ferns.cpp:235-275) on the device: (minimum > threshold || empty) && goodCodes > 0 -> the
 // staged frame takes slot n; its metadata is written here, its payload by k_fern_commit
 // `status` (mapped host memory, may be null): {sequence number of this add, frames stored, frames dropped because the database
@@ -1015,6 +1075,13 @@ int dms_ferns_search_blocks_hd_mirror(dms_ferns* f, const void* blocks_dev, size
   DMS_REQUIRE(((uintptr_t)blocks_dev & 7) == 0 && (stride & 7) == 0 && (codes_offset & 7) == 0 && (good_offset & 3) == 0 && ((uintptr_t)hits4_dev & 15) == 0,
               "8-byte aligned blocks, stride and code offset, 16-byte aligned hit rows required");
   hipStream_t s = (hipStream_t)st;
+  if (f->n_upper <= kPublishFusedMax && f->publish_fused) {  // a small database: search + test (+ mirror) in one launch
+    hipLaunchKernelGGL(k_fern_search_hd_small, dim3(count), dim3(kFernPad), 0, s, f->d_codes, f->d_good, f->d_time, f->d_n,
+                       (const unsigned char*)blocks_dev, stride, codes_offset, good_offset, time, interMap ? 1 : 0, f->num, (int4*)hits4_dev,
+                       (unsigned*)mirror, mirror_offset, (int)(mirror_bytes / 4));
+    DMS_CHECK_LAUNCH();
+    return DMS_OK;
+  }
   if (f->hd_count < count) {  // the result words of this entry point: armed once, re-armed by k_fern_hd_batch after every read
     if (f->d_hd_best) (void)hipFree(f->d_hd_best);
     f->d_hd_best = nullptr;

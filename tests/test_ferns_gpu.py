@@ -316,9 +316,19 @@ def test_publish_block_in_one_launch_equals_the_four_step_form(mods, monkeypatch
             descs.append(blk.download(np.uint8, (T + collab.DESC_BYTES,))[T:].copy())
         n = len(g)
         frames = [g.frame(i) for i in range(n)]
-        out.append((descs, n, frames, g.status() if hasattr(g, "status") else None))
-    (da, na, fa, sa), (db, nb, fb, sb) = out
+        # the batched search + blockHDAware operands of every block against this database: one launch (fused) or two - the same rows
+        allb = DeviceBuffer(len(blocks) * (T + collab.DESC_BYTES))
+        from densemonoslam_amd.capi import lib
+
+        for i, blk in enumerate(blocks):
+            assert lib.dms_memcpy_d2d_async(allb.ptr + i * (T + collab.DESC_BYTES), blk.ptr, T + collab.DESC_BYTES, None) == 0
+        hits = DeviceBuffer(16 * len(blocks))
+        g.searchBlocksHd(allb.ptr, T + collab.DESC_BYTES, len(blocks), T + collab.DESC_CODES, T + collab.DESC_GOOD, 1000, True, hits.ptr)
+        rows = hits.download(np.int32, (len(blocks), 4)).copy()
+        out.append((descs, n, frames, g.status() if hasattr(g, "status") else None, rows))
+    (da, na, fa, sa, ra), (db, nb, fb, sb, rb) = out
     assert na == nb == 4 and sa == sb
+    assert (ra == rb).all() and (ra[:, 0] >= 0).all() and (ra[:, 2] > 0).all(), (ra, rb)
     for x, y in zip(da, db):
         assert (x == y).all()
     for (pa, ta, ga_, ca), (pb, tb, gb_, cb) in zip(fa, fb):
