@@ -62,3 +62,26 @@ def test_headers_are_plain_c(tmp_path):
     inc = os.path.join(root, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
+
+
+def test_thumbnail_block_layout_for_any_frame_size():
+    """dms_thumb_block_bytes / _offsets (include/dmslam_fusion.h): W/8 x H/8 pixels with truncating division (Ferns.cpp:23-24), the RGBA8
+    section padded to 16 bytes so that the float4 sections stay aligned; the packed n * 36 layout whenever n is a multiple of 4; the
+    Python side (collab.thumbnail_bytes / thumbnail_offsets) says the same."""
+    from densemonoslam_amd import capi, collab
+
+    lib = capi.lib
+    lib.dms_thumb_block_bytes.restype = ctypes.c_size_t
+    lib.dms_thumb_block_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.dms_thumb_block_offsets.restype = None
+    lib.dms_thumb_block_offsets.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    for (w, h) in [(640, 480), (320, 240), (1241, 376), (1280, 960), (333, 251)]:
+        n = (w // 8) * (h // 8)
+        v, nr = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        lib.dms_thumb_block_offsets(w, h, ctypes.byref(v), ctypes.byref(nr))
+        total = lib.dms_thumb_block_bytes(w, h)
+        assert v.value % 16 == 0 and n * 4 <= v.value < n * 4 + 16 and nr.value == v.value + n * 16 and total == nr.value + n * 16
+        assert total == collab.thumbnail_bytes(w, h) and (v.value, nr.value) == collab.thumbnail_offsets(w, h)
+        if n % 4 == 0:
+            assert total == n * 36
+    assert lib.dms_thumb_block_bytes(1241, 376) == 29152 + 155 * 47 * 32
