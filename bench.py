@@ -957,7 +957,7 @@ def main():
                       "These are all the cores this container may use: the host reports %d hardware threads under a cgroup CPU quota of %s CPUs "
                       "(host.cpu_quota_cores), and threads beyond the quota only add barrier time - measured on such a host "
                       "(profiles/r05_cpu_baseline_threads.jsonl): 0.71 / 3.1 / 4.6 / 4.8 / 3.4 / 1.8 / 0.07 frames/s at 1 / 8 / 16 / 32 / 64 / 128 / 256 "
-                      "threads; sixteen independent 16-thread cameras at once deliver 5.4 - 5.6 frames/s in aggregate (DESIGN.md 6).  ~100 frames keep "
+                      "threads; sixteen independent 16-thread cameras at once deliver 3.5 - 5.6 frames/s in aggregate (profiles/r05_cpu_sixteen_replicas.txt, DESIGN.md 6).  ~100 frames keep "
                       "the default run inside its time budget.  A restatement written to be checked against, not tuned: it says nothing about kernel "
                       "quality; one_core: the same with 1 thread for ~8 s.  Non-target" % (n_all, W, H, cores, nproc, nproc, ("%g" % quota) if quota else "no"),
         }
