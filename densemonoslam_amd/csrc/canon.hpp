@@ -106,7 +106,12 @@ __host__ __device__ __forceinline__ void retry_step(int* E) {
 // reductions per frame at 1241 x 376 / 40 m); the frame step therefore raises them by this bias, a function of the depth cut-off
 // alone - 0 up to 4 m, so nothing changes for the indoor configurations; +2 already removes every repeat at 40 m
 // (scripts/kitti_retries.py), the rule gives +8 there (exp_of(40) = 6).  oracle/orc_pipeline.py applies the same rule.
-__host__ __device__ __forceinline__ int depth_exp_bias(float depthCut) { return depthCut > 4.0f ? 2 * (exp_of(depthCut) - 2) : 0; }
+// Clamped to the range the tracker accepts (a "no cut-off" of 1e20 or FLT_MAX is a legal option value; any guess is legal, the
+// totals check corrects it).
+__host__ __device__ __forceinline__ int depth_exp_bias(float depthCut) {
+  const int b = depthCut > 4.0f ? 2 * (exp_of(depthCut) - 2) : 0;
+  return b > 100 ? 100 : b;
+}
 // first reduction of a call: per-pixel magnitude guesses times the pixel count (any guess is legal: the check above corrects it)
 __host__ __device__ __forceinline__ void static_icp(int npix, int* E) {
   const int en = exp_of((float)npix);

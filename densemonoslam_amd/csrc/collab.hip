@@ -2,10 +2,17 @@
 // types come from ROCm's own header, the entry points from dlsym, so a single-camera process neither links nor loads it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <link.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
 
 #include "../../include/dmslam_collab.h"
 #include "common.hpp"
@@ -25,14 +32,36 @@ struct Rccl {
   bool ok = false;
 };
 
+// ONE copy of RCCL per process.  A host that already has one mapped (torch.distributed's "nccl" backend maps torch/lib/librccl.so,
+// a C++ front end may link its own) must not get a second instance on the same device beside it: the copy that is loaded is the
+// copy that is used (RTLD_NOLOAD on the path dl_iterate_phdr reports; then by soname), and only a process without any loads one -
+// DMS_RCCL_PATH if set, else librccl.so.1 / librccl.so from the loader's path, else ROCm's.  dms_collab_library_path() reports
+// what the entry points resolved to (dladdr).
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  const char* path = info->dlpi_name;
+  if (!path || !*path) return 0;
+  const char* base = strrchr(path, '/');
+  base = base ? base + 1 : path;
+  if (strncmp(base, "librccl.so", 10) != 0) return 0;
+  *(std::string*)out = path;
+  return 1;
+}
+
+std::string g_rccl_path;  // written once under rccl()'s once_flag
+
 const Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (r.so) break;
-    }
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) r.so = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!r.so) r.so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (!r.so)
+      if (const char* e = getenv("DMS_RCCL_PATH")) r.so = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (!r.so) r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (!r.so) return;
     auto sym = [&](const char* n) { return dlsym(r.so, n); };
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
@@ -44,6 +73,8 @@ const Rccl& rccl() {
     r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.Send && r.Recv && r.GetErrorString;
+    Dl_info di;
+    if (r.GetUniqueId && dladdr((void*)r.GetUniqueId, &di) && di.dli_fname) g_rccl_path = di.dli_fname;
   });
   return r;
 }
@@ -91,13 +122,57 @@ int dms_collab_create(dms_collab** out, int rank, int nranks, const void* id128)
   dms_collab* c = new dms_collab();
   c->rank = rank;
   c->size = nranks;
-  const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, id, rank);
+  // ncclCommInitRank blocks until every rank has arrived: a rank that never comes (a crashed peer, a wrong id) must end in an error
+  // here, not in a hang.  The call runs on a helper thread bound to the caller's device; the caller waits DMS_RCCL_INIT_TIMEOUT_S
+  // seconds (default 120).  After a timeout the helper is left behind (there is no way to cancel the call) and the caller gets
+  // DMS_ERR_TIMEOUT - the process is expected to report and exit.
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    delete c;
+    dms::set_error("dms_collab_create: no current device");
+    return DMS_ERR_HIP;
+  }
+  struct Init {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t r = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto st = std::make_shared<Init>();
+  std::thread([st, dev, nranks, id, rank] {
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = ncclSystemError;
+    if (hipSetDevice(dev) == hipSuccess) r = rccl().CommInitRank(&comm, nranks, id, rank);
+    std::lock_guard<std::mutex> g(st->m);
+    st->r = r;
+    st->comm = comm;
+    st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  double limit = 120.0;
+  if (const char* e = getenv("DMS_RCCL_INIT_TIMEOUT_S")) limit = atof(e) > 0.0 ? atof(e) : limit;
+  {
+    std::unique_lock<std::mutex> g(st->m);
+    if (!st->cv.wait_for(g, std::chrono::duration<double>(limit), [&] { return st->done; })) {
+      delete c;
+      dms::set_error("dms_collab_create: ncclCommInitRank (rank %d of %d) did not return within %.0f s - a rank is missing", rank, nranks, limit);
+      return DMS_ERR_TIMEOUT;
+    }
+  }
+  const ncclResult_t r = st->r;
+  c->comm = st->comm;
   if (r != ncclSuccess) {
     delete c;
     return comm_fail("dms_collab_create", r);
   }
   *out = c;
   return DMS_OK;
+}
+
+const char* dms_collab_library_path(void) {
+  (void)rccl();
+  return g_rccl_path.c_str();
 }
 
 int dms_collab_rank(const dms_collab* c) { return c ? c->rank : -1; }

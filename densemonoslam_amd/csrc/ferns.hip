@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kFernPad) void k_fern_hd(const unsigned char* __res
 // The first half of Ferns::findFrame for a batch of queries, up to the test that decides whether the tracker verifies at all
 // (Ferns.cpp:327-342: minimum dissimilarity, then blockHDAware > 0.3 against the frame it chose): one block per query reads the
 // search's result word and writes {candidate id or -1, dissimilarity bits, codes valid in both, of those equal} - the host (or another
-// rank, the words travel inside the frame block) forms hd_equal / hd_count > 0.3f exactly as find_common does.
+// rank, the words travel inside the frame block) forms (double)(hd_equal / hd_count) > 0.3 exactly as find_common does.
 __global__ __launch_bounds__(kFernPad) void k_fern_hd_batch(const unsigned char* __restrict__ db_codes, const unsigned char* __restrict__ base,
                                                             size_t stride, size_t codes_off, int num, unsigned long long* __restrict__ best,
                                                             int4* __restrict__ out, unsigned* __restrict__ mirror = nullptr, size_t mirror_off = 0,
@@ -715,7 +715,7 @@ int find_common(dms_ferns* f, const float* currPose16, int time, int lost, int i
   memcpy(&m->dissimilarity, &bits, 4);
   m->candidate = minId;
   m->blockHDAware = (float)r->hd_equal / (float)r->hd_count;
-  if (!(m->blockHDAware > 0.3f)) return DMS_OK;
+  if (!((double)m->blockHDAware > 0.3)) return DMS_OK;  // Ferns.cpp:346: float against the double literal (0.3f = 150 / 500 passes)
 
   // geometric verification with the thumbnail-sized tracker (Ferns.cpp:344-381)
   float fernPose[16];

@@ -1649,8 +1649,7 @@ int dms_fusion_set_option(dms_fusion* f, int option, double value) {
     case DMS_OPT_DEPTH_CUTOFF:
       DMS_REQUIRE(value > 0.0, "depth cut-off must be positive");
       f->p.depthCut = (float)value;
-      set_depth_bias(f);
-      break;
+      return set_depth_bias(f);
     case DMS_OPT_NID_THRESHOLD: f->p.nid_threshold = (float)value; break;
     case DMS_OPT_NID_DEPTH_LAMBDA: f->p.nid_depth_lambda = (float)value; break;
     case DMS_OPT_NID_BINS_IMG:

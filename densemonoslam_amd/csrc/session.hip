@@ -71,7 +71,7 @@ struct dms_session {
   unsigned char* d_gathered = nullptr;   // world x n x block_bytes
   float* d_table = nullptr;              // (1 + world) x (n + 1) x n x kRow
   float* d_pose = nullptr;               // 16 floats (a pose for addFrame)
-  float* d_small = nullptr;              // 64 floats: broadcast / headers
+  float* d_small = nullptr;              // (1 + world) x 32 floats: a refinement's status + result of this rank | of every rank
   void* d_frame_rgb = nullptr;           // a forwarded frame
   unsigned short* d_frame_depth = nullptr;
   unsigned char* d_tex = nullptr;        // a remote camera's fill-in textures (36 B per pixel)
@@ -87,7 +87,11 @@ struct dms_session {
     int slots = 0;
     unsigned char* host = nullptr; // pinned: world x slots x kTailHostBytes
     hipEvent_t done = nullptr;
+    hipEvent_t ag0 = nullptr, ag1 = nullptr;  // params.time_exchange: around the tick's all-gather
+    bool timed = false;
   } ring[2];
+  double ag_ms = 0.0;
+  int ag_n = 0;
   // Pipelined ticks run the cameras of every hosted MAP on a stream of that map's own (cameras that share a map stay serial, as the
   // reference's loop has them; independent maps overlap, and the exchange on the caller's stream runs beside the next frames).
   // DMS_SESSION_MAP_STREAMS=n: a pool of n streams (default 2), 0: everything on the caller's stream.
@@ -124,10 +128,6 @@ int t_allgather(dms_session* s, const void* send, void* recv, size_t bytes, dms_
 }
 int t_send(dms_session* s, const void* src, size_t bytes, int peer, dms_stream st) { return bytes ? s->t.send(s->t.ctx, src, bytes, peer, st) : 0; }
 int t_recv(dms_session* s, void* dst, size_t bytes, int peer, dms_stream st) { return bytes ? s->t.recv(s->t.ctx, dst, bytes, peer, st) : 0; }
-int t_bcast(dms_session* s, void* buf, size_t bytes, int root, dms_stream st) {
-  if (s->local_only) return 0;
-  return s->t.broadcast(s->t.ctx, buf, bytes, root, st);
-}
 // a host array through the device scratch (headers of a migration: counts, poses)
 int send_host(dms_session* s, const void* host, size_t bytes, int peer, dms_stream st) {
   void* d = nullptr;
@@ -197,74 +197,89 @@ Camera* owner_of(dms_session* s, int fb) {
 }
 
 // ReferenceFrame::resolveRelativeTransformationFern's second half for camera a against frame fb, on fb's rank; every rank ends with the
-// same {accepted, relativeTransform}
+// same {accepted, relativeTransform} - or, when ANY rank failed on the way, with an error on every rank: each rank's status rides the
+// all-gather that carries the owner's result, the owner posts its receives before anything that can fail, and the sender sends its three
+// messages whatever happened before them (from the scratch textures if the camera's cannot be read), so nobody is left waiting in a
+// collective or a point-to-point call.
 int refine(dms_session* s, int a, int fb, const float* rec16, const float* curr16, int tick, int* accepted, float* T16, dms_stream st) {
   const int ha = host_of_camera(s, a), hb = s->host_of_frame.at(fb);
   const size_t N = (size_t)s->W * s->H;
-  float res[17];
+  constexpr int kRes = 18;  // status (0 / -1) | accepted | relativeTransform
+  float res[kRes];
   memset(res, 0, sizeof(res));
-  int rc = DMS_OK;
+  int my_rc = DMS_OK, rc = DMS_OK;
   if (hb == s->rank) {
-    // (a failure here must not leave the other ranks waiting in the broadcast below: it travels as res[0] = -1)
+    const float *vtx = nullptr, *nrm = nullptr;
+    const void* img = nullptr;
+    if (ha != s->rank) {  // the receives first
+      if ((rc = t_recv(s, s->d_tex, N * 4, ha, st)) || (rc = t_recv(s, s->d_tex + N * 4, N * 16, ha, st)) ||
+          (rc = t_recv(s, s->d_tex + N * 20, N * 16, ha, st)) || (rc = sync(st)))
+        my_rc = rc;
+      img = s->d_tex;
+      vtx = (const float*)(s->d_tex + N * 4);
+      nrm = (const float*)(s->d_tex + N * 20);
+    }
     auto owner_side = [&]() -> int {
       Camera* owner = owner_of(s, fb);
       DMS_REQUIRE(owner, "the matched frame has no camera here");
+      int r0;
       if (!s->refiners.count(fb)) {
         const dms_fusion_params& c = s->p.camera;
         dms_refframe* r = nullptr;
-        if ((rc = dms_refframe_create(&r, s->W, s->H, c.cx, c.cy, c.fx, c.fy))) return rc;
+        if ((r0 = dms_refframe_create(&r, s->W, s->H, c.cx, c.cy, c.fx, c.fy))) return r0;
         s->refiners[fb] = r;
       }
-      const float *vtx, *nrm;
-      const void* img;
       if (ha == s->rank) {
         dms_image2d vi, vv, vn;
         dms_fusion* q = s->cams.at(a).f;
-        if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) return rc;
+        if ((r0 = dms_fusion_get_image(q, 13, &vi)) || (r0 = dms_fusion_get_image(q, 14, &vv)) || (r0 = dms_fusion_get_image(q, 15, &vn))) return r0;
         img = vi.data;
         vtx = (const float*)vv.data;
         nrm = (const float*)vn.data;
-      } else {
-        if ((rc = t_recv(s, s->d_tex, N * 4, ha, st)) || (rc = t_recv(s, s->d_tex + N * 4, N * 16, ha, st)) ||
-            (rc = t_recv(s, s->d_tex + N * 20, N * 16, ha, st)) || (rc = sync(st)))
-          return rc;
-        img = s->d_tex;
-        vtx = (const float*)(s->d_tex + N * 4);
-        nrm = (const float*)(s->d_tex + N * 20);
       }
       double conf = 0.0;
-      if ((rc = dms_fusion_get_option(owner->f, DMS_OPT_CONFIDENCE, &conf))) return rc;
+      if ((r0 = dms_fusion_get_option(owner->f, DMS_OPT_CONFIDENCE, &conf))) return r0;
       dms_intermap_result r;
-      if ((rc = dms_refframe_refine(s->refiners[fb], dms_fusion_model(owner->f), rec16, curr16, vtx, nrm, img, (int)s->p.camera.maxDepthProcessed,
+      if ((r0 = dms_refframe_refine(s->refiners[fb], dms_fusion_model(owner->f), rec16, curr16, vtx, nrm, img, (int)s->p.camera.maxDepthProcessed,
                                     (float)conf, a, s->p.camera.timeDelta, tick, s->p.cov_thresh, s->p.icp_err_thresh, s->p.icp_count_thresh, &r, st)))
-        return rc;
-      res[0] = r.accepted ? 1.f : 0.f;
-      memcpy(res + 1, r.relativeTransform, 64);
+        return r0;
+      res[1] = r.accepted ? 1.f : 0.f;
+      memcpy(res + 2, r.relativeTransform, 64);
       return DMS_OK;
     };
-    const int orc_ = owner_side();
-    if (orc_) {
-      res[0] = -1.f;
-      if (s->local_only) return orc_;
-    }
+    if (!my_rc) my_rc = owner_side();
   } else if (ha == s->rank) {
     dms_image2d vi, vv, vn;
     dms_fusion* q = s->cams.at(a).f;
-    if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) return rc;
-    if ((rc = t_send(s, vi.data, N * 4, hb, st)) || (rc = t_send(s, vv.data, N * 16, hb, st)) || (rc = t_send(s, vn.data, N * 16, hb, st)) ||
-        (rc = sync(st)))
-      return rc;
+    const void *pi = s->d_tex, *pv = s->d_tex + N * 4, *pn = s->d_tex + N * 20;
+    if ((rc = dms_fusion_get_image(q, 13, &vi)) || (rc = dms_fusion_get_image(q, 14, &vv)) || (rc = dms_fusion_get_image(q, 15, &vn))) {
+      my_rc = rc;  // (the owner has posted three receives: they are matched, with the scratch textures)
+    } else {
+      pi = vi.data;
+      pv = vv.data;
+      pn = vn.data;
+    }
+    if ((rc = t_send(s, pi, N * 4, hb, st)) || (rc = t_send(s, pv, N * 16, hb, st)) || (rc = t_send(s, pn, N * 16, hb, st)) || (rc = sync(st)))
+      if (!my_rc) my_rc = rc;
   }
-  if (!s->local_only) {
-    if (hb == s->rank && (rc = dms_memcpy_h2d(s->d_small, res, sizeof(res), st))) return rc;
-    if ((rc = t_bcast(s, s->d_small, sizeof(res), hb, st)) || (rc = sync(st)) || (rc = dms_memcpy_d2h(res, s->d_small, sizeof(res), st))) return rc;
+  if (s->local_only) {
+    if (my_rc) return my_rc;
+  } else {
+    // (the message of a failure here belongs to this rank's own error; keep it across the calls below)
+    res[0] = my_rc ? -1.f : 0.f;
+    std::vector<float> all((size_t)kRes * s->world, 0.f);
+    if ((rc = dms_memcpy_h2d(s->d_small, res, sizeof(res), st)) || (rc = t_allgather(s, s->d_small, s->d_small + kRes, sizeof(res), st)) || (rc = sync(st)) ||
+        (rc = dms_memcpy_d2h(all.data(), s->d_small + kRes, sizeof(res) * s->world, st)))
+      return my_rc ? my_rc : rc;
+    for (int r = 0; r < s->world; ++r)
+      if (all[(size_t)r * kRes] < 0.f) {
+        if (!my_rc) set_error("dms_session_step: the inter-map refinement of camera %d against frame %d failed on rank %d", a, fb, r);
+        return my_rc ? my_rc : DMS_ERR_STATE;
+      }
+    memcpy(res, &all[(size_t)hb * kRes], sizeof(res));
   }
-  if (res[0] < 0.f) {
-    if (hb != s->rank) set_error("dms_session_step: the inter-map refinement failed on rank %d", hb);
-    return DMS_ERR_STATE;
-  }
-  *accepted = res[0] == 1.f ? 1 : 0;
-  memcpy(T16, res + 1, 64);
+  *accepted = res[1] == 1.f ? 1 : 0;
+  memcpy(T16, res + 2, 64);
   return DMS_OK;
 }
 
@@ -477,6 +492,14 @@ int consume_entry(dms_session* s, dms_session::Entry& e, bool bookkeep) {
     return DMS_ERR_HIP;
   }
   e.consumed = true;
+  if (e.timed) {  // (the tick is complete: so is its all-gather)
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.ag0, e.ag1) == hipSuccess) {
+      s->ag_ms += ms;
+      s->ag_n += 1;
+    }
+    e.timed = false;
+  }
   if (bookkeep) {
     const std::vector<int> mine = cams_of_rank(s, s->rank);
     for (size_t i = 0; i < mine.size(); ++i) {
@@ -505,7 +528,8 @@ int consume_entry(dms_session* s, dms_session::Entry& e, bool bookkeep) {
           if (s->frame_of[qs[i2]] == dbs[d]) continue;
           int row[4];
           memcpy(row, rows + ((size_t)r2 * e.slots + i2) * 16, 16);
-          if (row[0] >= 0 && (float)row[3] / (float)row[2] > 0.3f) s->wake_ticks.insert(searched + kWakeLatency);  // Ferns.cpp:342
+          // Ferns.cpp:346: the FLOAT ratio against the DOUBLE literal 0.3 (150 / 500 rounds to 0.3f, which is above 0.3)
+          if (row[0] >= 0 && (double)((float)row[3] / (float)row[2]) > 0.3) s->wake_ticks.insert(searched + kWakeLatency);
         }
       }
     }
@@ -575,7 +599,8 @@ int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<in
       if (!qrc) set_error("dms_session_step: the inter-map query failed on rank %d at tick %d", r, k);
       return qrc ? qrc : DMS_ERR_STATE;
     }
-  // 5. the same walk on every rank (cameras in id order, frames in id order; first accepted candidate wins, one merge per frame and tick)
+  // 5. the same walk on every rank (cameras in id order, each over the other cameras' frames in camera-id order; first accepted candidate
+  // wins, one merge per frame and tick)
   struct Decided {
     int fb, fa;
     float T[16];
@@ -585,8 +610,11 @@ int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<in
   for (int a = 0; a < s->n; ++a) {
     const int fa = s->frame_of[a];
     if (busy.count(fa) || k < s->p.query_from) continue;
-    std::set<int> frames(s->frame_of.begin(), s->frame_of.end());
-    for (int fb : frames) {
+    // ElasticFusion.cpp:598-599 walks m_contextToReferenceFrameMap - CONTEXT ids in ascending order, each mapped to its frame - so a frame
+    // that holds several cameras is visited once per camera (a revisit repeats the query - same database, same block: the table's row -
+    // and the refinement, whose m_rgbd has moved on by one call)
+    for (int c = 0; c < s->n; ++c) {
+      const int fb = s->frame_of[c];
       if (fb == fa || busy.count(fb) || !((only >> (a * 8 + fb)) & 1ull)) continue;
       const float* e = &tables[(size_t)s->host_of_frame.at(fb) * tab_floats + ((size_t)a * s->n + fb) * kRow];
       DMS_REQUIRE(e[0] == 1.f, "no verification result for a camera / frame pair");
@@ -611,6 +639,87 @@ int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<in
   // 6. merges
   for (auto& d : decided)
     if ((rc = merge(s, k, d.fb, d.fa, d.T, st))) return rc;
+  return DMS_OK;
+}
+
+// dms_session_step with params.query_inside_frame: the reference's order.  ElasticFusion::processFrame of camera c ends with the inter-map
+// block (ElasticFusion.cpp:595-632): camera c has been offered to its own map's database (processFerns, :588-591), queries the other
+// cameras' frames in camera-id order, and a successful query merges at once - all before camera c + 1's processFrame of the same tick
+// (MainController.cpp:262-400 serves the cameras in turn).  Per camera: forward / frame / fetch on its host, ONE block published and
+// gathered (the other ranks contribute an empty one), owner-computes table, walk of that one camera, merge.
+int step_inside(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st) {
+  const size_t N = (size_t)s->W * s->H;
+  int rc = DMS_OK;
+  std::map<int, int> read_index;
+  {
+    int i = 0;
+    for (int c = 0; c < s->n; ++c)
+      if (c % s->world == s->rank) read_index[c] = i++;
+  }
+  for (int c = 0; c < s->n; ++c) {
+    const int src = c % s->world, host = host_of_camera(s, c);
+    if (src != host && src == s->rank) {
+      const int i = read_index.at(c);
+      if ((rc = t_send(s, rgb_dev[i], N * 3, host, st)) || (rc = t_send(s, depth_dev[i], N * 2, host, st)) || (rc = sync(st))) return rc;
+    }
+    if ((rc = dms_memset(s->d_local, 0, s->block_bytes, st))) return rc;
+    if (host == s->rank) {
+      Camera& cam = s->cams.at(c);
+      if (src == s->rank) {
+        const int i = read_index.at(c);
+        if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, st))) return rc;
+        cam.frame_rgb = rgb_dev[i];
+        cam.frame_depth = depth_dev[i];
+      } else {
+        cam.frame_rgb = cam.last_rgb;
+        cam.frame_depth = cam.last_depth;
+        if ((rc = t_recv(s, cam.last_rgb, N * 3, src, st)) || (rc = t_recv(s, cam.last_depth, N * 2, src, st))) return rc;
+        if ((rc = dms_fusion_inputs_ready(cam.f, st))) return rc;
+        if ((rc = dms_fusion_process_frame(cam.f, cam.last_rgb, 3, cam.last_depth, nullptr, 1.f, st))) return rc;
+      }
+      const int tick_before = cam.tick;
+      rc = dms_fusion_fetch(cam.f, &cam.last, st);
+      if (rc && rc != DMS_ERR_CAPACITY) return rc;
+      cam.tick = cam.last.tick;
+      memcpy(cam.pose, cam.last.pose, 64);
+      cam.pg_tick.push_back(tick_before);
+      cam.pg_pose.insert(cam.pg_pose.end(), cam.pose, cam.pose + 16);
+      cam.has_frame = true;
+      unsigned char* blk = s->d_local;
+      if ((rc = dms_fusion_thumbnails(cam.f, blk, st))) return rc;
+      float meta[kMetaBytes / 4];
+      memset(meta, 0, sizeof(meta));
+      const int ids[2] = {c, cam.tick};
+      memcpy(meta, ids, 8);
+      memcpy(meta + 4, cam.pose, 64);
+      if ((rc = dms_memcpy_h2d(blk + s->thumb_bytes, meta, kMetaBytes, st))) return rc;
+      if (!cam.last.lost) {  // processFerns (ElasticFusion.cpp:588-591)
+        if ((rc = dms_ferns_add_frame_async(s->ferns.at(s->frame_of[c]), nullptr, nullptr, nullptr, blk, nullptr, (const float*)(blk + s->thumb_bytes + 16),
+                                            cam.tick, s->p.fern_threshold, st)))
+          return rc;
+      }
+    }
+    if (k < s->p.query_from) continue;  // (uniform: nobody enters the collectives below)
+    bool others = false;
+    for (int c2 = 0; c2 < s->n; ++c2) others = others || s->frame_of[c2] != s->frame_of[c];
+    if (!others) continue;
+    if ((rc = t_allgather(s, s->d_local, s->d_gathered, s->block_bytes, st)) || (rc = sync(st))) return rc;
+    const unsigned char* raw = s->d_gathered + (size_t)host * s->block_bytes;
+    float meta[kMetaBytes / 4];
+    if ((rc = dms_memcpy_d2h(meta, raw + s->thumb_bytes, kMetaBytes, st))) return rc;
+    int ids[2];
+    memcpy(ids, meta, 8);
+    DMS_REQUIRE(ids[0] == c, "the gathered block is not the camera whose turn it is");
+    std::map<int, std::vector<float>> poses;
+    std::map<int, int> ticks;
+    std::map<int, const unsigned char*> blocks;
+    blocks[c] = raw;
+    ticks[c] = ids[1];
+    poses[c] = std::vector<float>(meta + 4, meta + 20);
+    unsigned long long only = 0;
+    for (int fb = 0; fb < s->n; ++fb) only |= 1ull << (c * 8 + fb);
+    if ((rc = decide_and_merge(s, k, only, poses, ticks, blocks, st))) return rc;
+  }
   return DMS_OK;
 }
 
@@ -670,7 +779,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   DMS_REQUIRE(out && p, "null argument");
   DMS_REQUIRE(p->n_cameras >= 1 && p->n_cameras <= DMS_MAX_SENSORS, "1 <= n_cameras <= DMS_MAX_SENSORS (a merged map holds every camera's time slot)");
   DMS_REQUIRE(p->camera.num_sensors >= p->n_cameras, "num_sensors < n_cameras: a merge would fail at join / import");
-  DMS_REQUIRE(!t || (t->allgather && t->send && t->recv && t->broadcast && t->world >= 1 && t->rank >= 0 && t->rank < t->world), "incomplete transport");
+  DMS_REQUIRE(!t || (t->allgather && t->send && t->recv && t->world >= 1 && t->rank >= 0 && t->rank < t->world), "incomplete transport");
   dms_session* s = new dms_session();
   s->p = *p;
   if (t) {
@@ -708,7 +817,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   s->d_gathered = (unsigned char*)alloc((size_t)s->world * s->n * s->block_bytes);
   s->d_table = (float*)alloc((size_t)(1 + s->world) * (s->n + 1) * s->n * kRow * 4);
   s->d_pose = (float*)alloc(64);
-  s->d_small = (float*)alloc(256);
+  s->d_small = (float*)alloc((size_t)(1 + s->world) * 32 * 4);  // a rank's status + result, and everybody's (refine)
   s->d_frame_rgb = alloc(N * 3);
   s->d_frame_depth = (unsigned short*)alloc(N * 2);
   s->d_tex = (unsigned char*)alloc(N * 36);
@@ -720,6 +829,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
       s->d_agathered[b] = (unsigned char*)alloc((size_t)s->world * s->n * s->ablock_bytes);
       if (!rc && hipHostMalloc((void**)&s->ring[b].host, (size_t)s->world * s->n * kTailHostBytes) != hipSuccess) rc = DMS_ERR_HIP;
       if (!rc && hipEventCreateWithFlags(&s->ring[b].done, hipEventDisableTiming) != hipSuccess) rc = DMS_ERR_HIP;
+      if (!rc && p->time_exchange && (hipEventCreate(&s->ring[b].ag0) != hipSuccess || hipEventCreate(&s->ring[b].ag1) != hipSuccess)) rc = DMS_ERR_HIP;
     }
     s->can_pipeline = !rc;
   }
@@ -753,6 +863,8 @@ int dms_session_destroy(dms_session* s) {
   for (int b = 0; b < 2; ++b) {
     if (s->ring[b].host) (void)hipHostFree(s->ring[b].host);
     if (s->ring[b].done) (void)hipEventDestroy(s->ring[b].done);
+    if (s->ring[b].ag0) (void)hipEventDestroy(s->ring[b].ag0);
+    if (s->ring[b].ag1) (void)hipEventDestroy(s->ring[b].ag1);
   }
   void* bufs[] = {s->d_local, s->d_gathered, s->d_table, s->d_pose, s->d_small, s->d_frame_rgb, s->d_frame_depth, s->d_tex,
                   s->d_alocal[0], s->d_alocal[1], s->d_agathered[0], s->d_agathered[1]};
@@ -769,6 +881,7 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
   if ((rc = drain_entries(s))) return rc;  // (pipelined ticks before this one: their pose-graph rows come first)
   invalidate_searches(s, k);               // (and their searches wake nothing: this tick queries every pair itself)
   s->last_stream = st;
+  if (s->p.query_inside_frame) return step_inside(s, k, rgb_dev, depth_dev, st);
   // 1 + 2. forward the frames of cameras hosted elsewhere; every hosted camera's frame, in id order.  (A frame that arrives from
   // another rank is processed when its camera's turn comes: receive and process are interleaved in camera order on both sides.)
   std::map<int, int> read_index;  // camera read here -> position in rgb_dev / depth_dev
@@ -864,6 +977,7 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
   DMS_REQUIRE(s && rgb_dev && depth_dev, "null argument");
   DMS_REQUIRE(s->can_pipeline, "the pipelined step serves world * n_cameras <= 64");
   DMS_REQUIRE(!s->p.camera.reloc, "the pipelined step does not read the tracker's verdict: relocalisation must be off");
+  DMS_REQUIRE(!s->p.query_inside_frame, "query_inside_frame serialises the cameras of a tick: dms_session_step only");
   const size_t N = (size_t)s->W * s->H;
   hipStream_t hs = (hipStream_t)st;
   int rc = DMS_OK;
@@ -970,11 +1084,17 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
       return rc;
   }
   const size_t per_rank = (size_t)slots * B;
-  if (!s->local_only && (rc = t_allgather(s, local, gathered, per_rank, st))) return rc;
+  dms_session::Entry& e = s->ring[k & 1];
+  if (!s->local_only) {
+    const bool timed = e.ag0 != nullptr;
+    if (timed && hipEventRecord(e.ag0, hs) != hipSuccess) return DMS_ERR_HIP;
+    if ((rc = t_allgather(s, local, gathered, per_rank, st))) return rc;
+    if (timed && hipEventRecord(e.ag1, hs) != hipSuccess) return DMS_ERR_HIP;
+    e.timed = timed;
+  }
   // 4a. every hosted database against every gathered block; the hit rows ride in the NEXT tick's blocks.  The tails come to the host
   // beside the next tick (read at the start of tick k + 2), written into mapped memory by the first search's second launch (a launch
   // of its own when no database here has anybody left to be queried by).
-  dms_session::Entry& e = s->ring[k & 1];
   {
     int d = 0;
     bool mirrored = false;
@@ -1036,6 +1156,13 @@ int dms_session_async_stats(dms_session* s, int* ticks, int* wakes) {
   DMS_REQUIRE(s, "null argument");
   if (ticks) *ticks = s->async_ticks;
   if (wakes) *wakes = s->wakes;
+  return DMS_OK;
+}
+
+int dms_session_exchange_time(dms_session* s, double* allgather_ms_sum, int* allgathers) {
+  DMS_REQUIRE(s, "null argument");
+  if (allgather_ms_sum) *allgather_ms_sum = s->ag_ms;
+  if (allgathers) *allgathers = s->ag_n;
   return DMS_OK;
 }
 

@@ -24,8 +24,10 @@ frame's rank.  Per tick, on every rank, `CollabSession.step`:
                ReferenceFrame::resolveRelativeTransformationFern (ReferenceFrame.h:72-110, dms_refframe_refine: INACTIVE prediction
                of its map at recoveryPose, full-resolution ICP + RGB refinement against the querying camera's fill-in textures,
                acceptance on covariance / error / count).  If the camera lives on another rank its three fill-in textures travel
-               point to point first (36 B per pixel, 11 MB at 640 x 480 - on a candidate only); the owner broadcasts
-               {accepted, relativeTransform} (17 floats).  First accepted candidate wins, at most one merge per frame and tick;
+               point to point first (36 B per pixel, 11 MB at 640 x 480 - on a candidate only); {accepted, relativeTransform} and
+               every rank's status travel in one all-gather (18 floats per rank; a failure anywhere raises on every rank).  A camera
+               visits the other cameras' frames in camera-id order (ElasticFusion.cpp:598-599).  First accepted candidate wins, at
+               most one merge per frame and tick;
   6. merge     relativeTransform = recoveryPose * currPose.inverse() (ReferenceFrame.h:98).  Same rank: the consuming map
                consumes the other (dms_fusion_join_map), fern databases merge (dms_ferns_consume).  Across ranks: the consumed
                frame's rank sends, point to point, its surfel records, its key-frame records and per camera {pose, tick, last
@@ -64,6 +66,8 @@ class CollabSession:
         self.pose_graph = {c: [] for c in range(n_cameras)}       # of the cameras hosted here
         self.relative_cons = {c: [] for c in range(n_cameras)}
         self.last_frame = {}                                      # camera -> (rgb, depth) of the last processed frame (host arrays)
+        if hasattr(backend, "num_sensors") and backend.num_sensors is None:
+            backend.num_sensors = max(3, n_cameras)  # (before the first camera is made)
         for c in range(n_cameras):
             if c % world == rank:
                 self.cams[c] = backend.make_camera(c)
@@ -190,7 +194,8 @@ class CollabSession:
             fa = self.frame_of[a]
             if fa in busy or k < self.query_from:
                 continue
-            for fb in sorted(set(self.frame_of)):
+            for c in range(self.n):  # m_contextToReferenceFrameMap: context ids ascending, each mapped to its frame (ElasticFusion.cpp:598-599)
+                fb = self.frame_of[c]
                 if fb == fa or fb in busy:
                     continue
                 e = tables[self.host_of_frame[fb], a, fb]
@@ -218,30 +223,47 @@ class CollabSession:
 
     def _refine(self, k, a, fb, recoveryPose, currPose, tick):
         """ReferenceFrame::resolveRelativeTransformationFern's second half for camera a against frame fb, on fb's rank; every rank
-        returns the same (accepted, relativeTransform)."""
+        returns the same (accepted, relativeTransform) - or raises, on EVERY rank, when any rank failed on the way: each rank's status
+        rides the all-gather that carries the owner's result, the owner receives before anything that can fail, the sender sends its
+        three messages whatever happened before them (csrc/session.hip refine)."""
         ha, hb = self.host_of_camera(a), self.host_of_frame[fb]
-        res = np.zeros(17, np.float32)
+        res = np.zeros(18, np.float32)  # status (0 / -1) | accepted | relativeTransform
+        failure = None
         if hb == self.rank:
-            owner = self.cams[next(c for c in self.hosted() if self.frame_of[c] == fb)]
-            if fb not in self.refiners:
-                self.refiners[fb] = self.be.make_refiner()
-            if ha == self.rank:
-                r = self.refiners[fb].refineLocal(owner, self.cams[a], recoveryPose, self.thresholds)
-            else:
-                img = self._recv(ha, np.uint8, (self.H, self.W, 4))
-                vtx = self._recv(ha, np.float32, (self.H, self.W, 4))
-                nrm = self._recv(ha, np.float32, (self.H, self.W, 4))
-                r = self.refiners[fb].refineRemote(owner, (img, vtx, nrm), a, tick, currPose, recoveryPose, self.thresholds)
-            res[0] = 1.0 if r[0] else 0.0
-            res[1:] = np.asarray(r[1], np.float32).reshape(16)
+            textures = None
+            if ha != self.rank:  # the receives first
+                textures = (self._recv(ha, np.uint8, (self.H, self.W, 4)), self._recv(ha, np.float32, (self.H, self.W, 4)),
+                            self._recv(ha, np.float32, (self.H, self.W, 4)))
+            try:
+                owner = self.cams[next(c for c in self.hosted() if self.frame_of[c] == fb)]
+                if fb not in self.refiners:
+                    self.refiners[fb] = self.be.make_refiner()
+                if ha == self.rank:
+                    r = self.refiners[fb].refineLocal(owner, self.cams[a], recoveryPose, self.thresholds)
+                else:
+                    r = self.refiners[fb].refineRemote(owner, textures, a, tick, currPose, recoveryPose, self.thresholds)
+                res[1] = 1.0 if r[0] else 0.0
+                res[2:] = np.asarray(r[1], np.float32).reshape(16)
+            except Exception as e:  # noqa: BLE001 (re-raised below, on every rank)
+                failure = e
         elif ha == self.rank:
-            for t in self.cams[a].fillTextures():
+            try:
+                tex = self.cams[a].fillTextures()
+            except Exception as e:  # noqa: BLE001
+                failure = e
+                tex = (np.zeros((self.H, self.W, 4), np.uint8), np.zeros((self.H, self.W, 4), np.float32), np.zeros((self.H, self.W, 4), np.float32))
+            for t in tex:
                 self._send(t, hb)
         if self.world > 1:
-            t = self._t(res)
-            dist.broadcast(t, hb)
-            res = t.cpu().numpy()
-        return bool(res[0] == 1.0), res[1:].reshape(4, 4).copy()
+            res[0] = -1.0 if failure is not None else 0.0
+            all_res = self._allgather(res.view(np.uint8)).view(np.float32).reshape(self.world, 18)
+            bad = [r for r in range(self.world) if all_res[r, 0] < 0]
+            if bad:
+                raise RuntimeError("inter-map refinement of camera %d against frame %d failed on rank(s) %s at tick %d" % (a, fb, bad, k)) from failure
+            res = all_res[hb]
+        elif failure is not None:
+            raise failure
+        return bool(res[1] == 1.0), res[2:].reshape(4, 4).copy()
 
     def _allgather(self, local_u8):
         if self.world == 1:
@@ -450,7 +472,7 @@ class _GpuFerns:
         self.db.encodeThumbs(t.data_ptr(), t.data_ptr() + T, t.data_ptr() + T + 512, None)
         self.db.searchBlocksHd(t.data_ptr(), T + 1024, 1, T, T + 512, 0, True, rows.data_ptr(), None)
         r = rows.cpu().numpy()
-        return bool(r[0] >= 0 and np.float32(r[3]) / np.float32(r[2]) > np.float32(0.3))
+        return bool(r[0] >= 0 and float(np.float32(r[3]) / np.float32(r[2])) > 0.3)  # Ferns.cpp:346: float ratio against the double literal
 
     def consume(self, other, T, thr):
         self.db.consume(other.db, T, thr)
@@ -477,9 +499,11 @@ class _GpuFerns:
 class GpuBackend:
     """fusion.ElasticFusion + ferns.Ferns (HBM) behind CollabSession."""
 
-    def __init__(self, width, height, K, device, num_sensors=DMS_MAX_SENSORS, fern_opts=None, **opts):
+    def __init__(self, width, height, K, device, num_sensors=None, fern_opts=None, **opts):
         from . import collab
 
+        # None: max(3, cameras of the session) - set by CollabSession, as dms_session_default_params does (the reference's NUM_CAMERAS
+        # is 3, Shaders/Vertex.cpp:49; the clean's health test walks num_sensors slots, so the count is part of the result)
         self.W, self.H, self.K, self.device, self.num_sensors, self.opts = width, height, K, device, num_sensors, opts
         self.fern_opts = dict(num=500, maxDepth_mm=3000, photoThresh=115.0, seed=20260929, capacity=1024)
         self.fern_opts.update(fern_opts or {})
@@ -533,7 +557,7 @@ def _native():
         _fields_ = [("n_cameras", _C.c_int), ("camera", fusion.FusionParams), ("fern_num", _C.c_int), ("fern_max_depth_mm", _C.c_int),
                     ("fern_capacity", _C.c_int), ("fern_photo_thresh", _C.c_float), ("fern_seed", _C.c_uint), ("fern_threshold", _C.c_float),
                     ("inter_map", _C.c_int), ("query_from", _C.c_int), ("full_refine", _C.c_int), ("cov_thresh", _C.c_float),
-                    ("icp_err_thresh", _C.c_float), ("icp_count_thresh", _C.c_float)]
+                    ("icp_err_thresh", _C.c_float), ("icp_count_thresh", _C.c_float), ("query_inside_frame", _C.c_int), ("time_exchange", _C.c_int)]
 
     FN_AG = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_void_p)
     FN_SR = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_int, _C.c_void_p)
@@ -551,6 +575,7 @@ def _native():
     lib.dms_session_step_async.argtypes = [P, _C.c_int, _C.POINTER(P), _C.POINTER(P), P]
     lib.dms_session_sync.argtypes = [P]
     lib.dms_session_async_stats.argtypes = [P, _C.POINTER(_C.c_int), _C.POINTER(_C.c_int)]
+    lib.dms_session_exchange_time.argtypes = [P, _C.POINTER(_C.c_double), _C.POINTER(_C.c_int)]
     lib.dms_session_frame_of.argtypes = [P, _C.POINTER(_C.c_int)]
     lib.dms_session_host_of_frame.argtypes = [P, _C.c_int]
     lib.dms_session_num_merges.argtypes = [P]
@@ -671,7 +696,7 @@ class NativeSession:
 
     def __init__(self, width, height, K, n_cameras, rank=0, world=1, transport=None, fern_photo_thresh=115.0, fern_capacity=1024,
                  fern_threshold=0.3095, inter_map=1, query_from=0, full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05,
-                 icp_count_thresh=35000, **camera_opts):
+                 icp_count_thresh=35000, query_inside_frame=False, time_exchange=False, **camera_opts):
         lib, capi, _ = _native()
         SessionParams = lib._dms_session_types[0]
         p = SessionParams()
@@ -683,6 +708,7 @@ class NativeSession:
         p.fern_photo_thresh, p.fern_capacity, p.fern_threshold = fern_photo_thresh, fern_capacity, fern_threshold
         p.inter_map, p.query_from, p.full_refine = inter_map, query_from, 1 if full_refine else 0
         p.cov_thresh, p.icp_err_thresh, p.icp_count_thresh = cov_thresh, icp_err_thresh, icp_count_thresh
+        p.query_inside_frame, p.time_exchange = 1 if query_inside_frame else 0, 1 if time_exchange else 0
         self.W, self.H, self.n, self.rank, self.world = width, height, n_cameras, rank, world
         self.transport = transport
         h = _C.c_void_p()
@@ -718,6 +744,12 @@ class NativeSession:
         t, w = _C.c_int(0), _C.c_int(0)
         self.capi.check(self.lib.dms_session_async_stats(self.h, _C.byref(t), _C.byref(w)))
         return {"ticks": t.value, "woken": w.value}
+
+    def exchange_time(self):
+        """(sum of the timed all-gathers' device time in ms, how many) - needs time_exchange=True"""
+        ms, n = _C.c_double(0.0), _C.c_int(0)
+        self.capi.check(self.lib.dms_session_exchange_time(self.h, _C.byref(ms), _C.byref(n)))
+        return ms.value, n.value
 
     # -- the read-only surface of CollabSession ---------------------------------------------------------------------------------
     @property

@@ -35,8 +35,12 @@ typedef struct dms_collab dms_collab;
 
 /* ncclGetUniqueId; DMS_ERR_UNSUPPORTED when librccl cannot be loaded */
 int dms_collab_unique_id(void* id128);
-/* ncclCommInitRank on the calling thread's current device.  nranks >= 1, 0 <= rank < nranks. */
+/* ncclCommInitRank on the calling thread's current device.  nranks >= 1, 0 <= rank < nranks.  Returns DMS_ERR_TIMEOUT (never hangs) when
+ * the other ranks have not arrived within DMS_RCCL_INIT_TIMEOUT_S seconds (environment, default 120). */
 int dms_collab_create(dms_collab** out, int rank, int nranks, const void* id128);
+/* The file the RCCL entry points were resolved from ("" when none could be loaded).  A process uses ONE copy: the one that is
+ * already mapped (torch's torch/lib/librccl.so under torch.distributed, a front end's own), else DMS_RCCL_PATH, else librccl.so.1. */
+const char* dms_collab_library_path(void);
 int dms_collab_rank(const dms_collab* c);
 int dms_collab_size(const dms_collab* c);
 /* every rank contributes `bytes` from send_dev; recv_dev receives nranks * bytes, rank r's block at r * bytes

@@ -116,7 +116,7 @@ int dms_ferns_search_blocks(dms_ferns* f, const void* blocks_dev, size_t stride,
 
 /* The batch search followed, in the same stream, by the test that decides whether findFrame verifies a candidate at all
  * (Ferns.cpp:340-342): hits4_dev receives count x {candidate id or -1, dissimilarity bits, codes valid in both descriptors, of those
- * equal} (16 bytes each, 16-byte aligned); blockHDAware = equal / valid, a "hit" is blockHDAware > 0.3f.  No block is skipped.  Two
+ * equal} (16 bytes each, 16-byte aligned); blockHDAware = equal / valid, a "hit" is (double)blockHDAware > 0.3 (Ferns.cpp:346 compares the float with the double literal: 150 / 500 = 0.3f hits).  No block is skipped.  Two
  * launches (the second re-arms the handle's result words for the next call).  What the pipelined session (dms_session_step_async)
  * runs every tick in place of the synchronous query. */
 int dms_ferns_search_blocks_hd(dms_ferns* f, const void* blocks_dev, size_t stride, int count, size_t codes_offset, size_t good_offset,

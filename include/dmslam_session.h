@@ -23,8 +23,10 @@
  *   5. decide    every rank walks the same table in the reference's order (cameras by id, frames by id); a fern match is a
  *                candidate that the matched map's owner refines at full resolution (dms_refframe_refine, ReferenceFrame.h:72-110;
  *                the querying camera's three fill-in textures travel point to point first when it lives on another rank) and
- *                accepts or rejects; the owner broadcasts {accepted, relativeTransform}.  First accepted candidate of a camera wins,
- *                at most one merge per frame and tick;
+ *                accepts or rejects; {accepted, relativeTransform} and every rank's status travel in one small all-gather (a failure
+ *                anywhere ends the step with an error on EVERY rank).  A camera visits the other cameras' frames in camera-id order
+ *                (m_contextToReferenceFrameMap, ElasticFusion.cpp:598-599: a frame that holds several cameras is visited once per
+ *                camera).  First accepted candidate of a camera wins, at most one merge per frame and tick;
  *   6. merge     same rank: dms_fusion_join_map + dms_ferns_consume.  Across ranks: surfel records, key-frame records and per
  *                camera {pose, tick, last frame, pose graph} point to point; the consuming rank appends them
  *                (dms_model_consume_records, dms_ferns_consume_records) and re-creates each camera (dms_fusion_import_camera);
@@ -48,7 +50,8 @@ extern "C" {
 /* How bytes cross ranks.  Every function moves DEVICE memory of the calling rank and returns 0 on success; a call may be
  * asynchronous on `s` (RCCL) or complete on return (a host-staged test transport) - the session synchronises `s` before it reads
  * what a call delivered.  allgather: every rank contributes `bytes`, recv_dev receives world * bytes in rank order.  broadcast:
- * `bytes` at buf_dev from rank `root` to everybody (in place). */
+ * `bytes` at buf_dev from rank `root` to everybody (in place; not used by the session since round 6 - the refinement's result rides an
+ * all-gather with every rank's status - and may be NULL). */
 typedef struct dms_transport {
   void* ctx;
   int rank, world;
@@ -72,6 +75,15 @@ typedef struct dms_session_params {
   int query_from;           /* first tick index at which cameras query other maps (0: from the start, as the reference would) */
   int full_refine;          /* 1 (default): the second half of resolveRelativeTransformationFern decides; 0: the fern match alone (rounds 3-4) */
   float cov_thresh, icp_err_thresh, icp_count_thresh; /* Options::covThresh / icpErrThresh / icpCountThresh (Options.h:91-94) */
+  /* 0 (default): the inter-map queries of a tick run after ALL cameras' frames of the tick (one publish, one query table, one walk:
+   * two collectives per tick).  1: the reference's ORDER - the block sits inside ElasticFusion::processFrame (ElasticFusion.cpp:595-632),
+   * so camera c queries the other maps, and a successful query merges, BEFORE camera c + 1's frame of the same tick is processed
+   * (camera c + 1's key-frame database does not hold its frame of this tick yet; after a merge at camera c the following cameras of the
+   * tick already track against the merged map).  dms_session_step only: the cameras of a tick are serialised across ranks (publish,
+   * table and walk per camera).  Restated as oracle/orc_pipeline.Session(query_inside_frame = True). */
+  int query_inside_frame;
+  /* 1: dms_session_step_async brackets its per-tick all-gather with a HIP event pair on the caller's stream (dms_session_exchange_time) */
+  int time_exchange;
 } dms_session_params;
 void dms_session_default_params(dms_session_params* p, int n_cameras, int width, int height, float fx, float fy, float cx, float cy);
 
@@ -105,6 +117,10 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
 int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, const unsigned short* const* depth_dev, dms_stream st);
 int dms_session_sync(dms_session* s);                                   /* host state (poses, pose graphs) up to the last enqueued tick */
 int dms_session_async_stats(dms_session* s, int* ticks, int* wakes);    /* pipelined ticks so far, of which woken */
+/* with params.time_exchange: the device time of the pipelined ticks' all-gathers whose completion the host has already seen (the
+ * event pair of tick k is read when tick k + 2 starts, or by dms_session_sync): sum in milliseconds and how many.  Includes the wait
+ * for the slowest rank - it is the time the collective occupies the exchange stream, beside the next frame. */
+int dms_session_exchange_time(dms_session* s, double* allgather_ms_sum, int* allgathers);
 
 /* state, identical on every rank */
 int dms_session_frame_of(dms_session* s, int* frame_of);               /* n_cameras entries: camera -> reference frame (its founding camera) */

@@ -192,7 +192,7 @@ class Ferns:
         if minId == -1:
             return False
         with np.errstate(all="ignore"):
-            return bool(self.blockHDAware(codes, self.frames[minId].codes) > np.float32(0.3))
+            return bool(float(self.blockHDAware(codes, self.frames[minId].codes)) > 0.3)  # float against the DOUBLE literal (Ferns.cpp:346)
 
     def findFrame(self, currPose, vertex, normal, image, time, lost=False, interMap=False, thumbs=None):
         """returns dict(closest, candidate, dissimilarity, blockHDAware, icp_error, icp_count, photo_error, estPose, constraints)"""
@@ -205,7 +205,7 @@ class Ferns:
             return out
         hd = self.blockHDAware(codes, self.frames[minId].codes)
         out["blockHDAware"] = float(hd)
-        if not hd > np.float32(0.3):
+        if not float(hd) > 0.3:  # Ferns.cpp:346: the float return value against the double literal 0.3 (0.3f itself passes)
             return out
         fr = self.frames[minId]
         fernPose = fr.pose

@@ -224,7 +224,7 @@ class ElasticFusion:
         # far depth cut-offs raise the static first-iteration exponents of the canonical sums (csrc/canon.hpp depth_exp_bias: the same rule)
         import math
 
-        bias = 2 * (math.frexp(float(np.float32(self.depthCut)))[1] - 2) if self.depthCut > 4.0 else 0
+        bias = min(100, 2 * (math.frexp(float(np.float32(self.depthCut)))[1] - 2)) if self.depthCut > 4.0 else 0
         self.frameToModel.setExpBias(bias)
         if self.modelToModel is not None:
             self.modelToModel.setExpBias(bias)
@@ -376,14 +376,20 @@ class Session:
     ReferenceFrame.h:72-110): INACTIVE prediction of its map at recoveryPose, full-resolution ICP + RGB refinement against the
     querying camera's fill-in textures, relativeTransform from the REFINED pose, acceptance on covariance / error / count.
 
-    Differences from the compiled-out reference block, all of them: queries run after all cameras of the tick have been processed
-    rather than inside each camera's processFrame; two readings of the block's undefined inputs are stated at `refine`;
+    Differences from the compiled-out reference block, all of them: by default queries run after all cameras of the tick have been
+    processed rather than inside each camera's processFrame (`query_inside_frame = True` is the reference's order); two readings of the block's undefined inputs are stated at `refine`;
     `full_refine = False` stops after the fern database's own verification (rounds 3-4)."""
 
     def __init__(self, n, width, height, K, fern_seed=20260929, fern_threshold=0.3095, fern_num=500, fern_max_depth_mm=3000,
                  fern_photo_thresh=115.0, inter_map=1, query_from=0, full_refine=True, cov_thresh=1e-05, icp_err_thresh=2e-05,
-                 icp_count_thresh=35000, wake_latency=None, **opts):
+                 icp_count_thresh=35000, wake_latency=None, query_inside_frame=False, **opts):
         from . import orc_ferns
+
+        # False: the queries of a tick run after all cameras' frames (the form DESIGN.md 7 gives the block for one camera per GPU).
+        # True: the reference's ORDER - the block sits inside processFrame (ElasticFusion.cpp:595-632), camera c queries and merges
+        # before camera c + 1's frame of the same tick is processed (dms_session_params.query_inside_frame)
+        self.query_inside_frame = query_inside_frame
+        assert not (query_inside_frame and wake_latency is not None)
 
         # None: every tick queries (the reference's loop, dms_session_step); 3: dms_session_step_async's schedule
         self.wake_latency, self.hits, self.woken, self.valid_from = wake_latency, {}, [], 0
@@ -419,6 +425,17 @@ class Session:
         """frames[i] = (rgb, depth) of camera i; k = the tick index (for the log)."""
         from . import orc_ferns
 
+        # time slots of the clean's health test: NUM_CAMERAS = 3 in the reference (Shaders/size.glsl:2), which a fourth camera overruns
+        # (Shaders/Vertex.cpp:49); max(3, cameras) here, as dms_session_default_params.  The oracle's count is a global: set per step.
+        orc.set_num_sensors(max(3, self.n))
+        try:
+            return self._step_inside(frames, k) if self.query_inside_frame else self._step_batched(frames, k)
+        finally:
+            orc.set_num_sensors(3)
+
+    def _step_batched(self, frames, k):
+        from . import orc_ferns
+
         outs = []
         for i, cam in enumerate(self.cams):
             tick_before = cam.tick
@@ -446,7 +463,8 @@ class Session:
             fa = self.frame_of[a]
             if fa in busy or k < self.query_from:
                 continue
-            for fb in sorted(set(self.frame_of)):
+            for c in range(self.n):  # m_contextToReferenceFrameMap: context ids ascending, each mapped to its frame (ElasticFusion.cpp:598-599)
+                fb = self.frame_of[c]  # (a frame that holds several cameras is visited once per camera, as there)
                 if fb == fa or fb in busy:
                     continue
                 m = self.ferns[fb].findFrame(cam.currPose, None, None, None, cam.tick, lost=False, interMap=self.inter_map, thumbs=blocks[a])
@@ -467,6 +485,41 @@ class Session:
                 break
         if len(self.merges) != n_merges:
             self.valid_from = k + 1
+        return outs
+
+    def _step_inside(self, frames, k):
+        """One tick in the reference's order: MainController.cpp:262-400 serves the cameras in turn, and each processFrame ends with
+        processFerns (:588-591) and the inter-map block (:595-632) - before the next camera's frame."""
+        outs = []
+        for a, cam in enumerate(self.cams):
+            tick_before = cam.tick
+            outs.append(cam.processFrame(frames[a][0], frames[a][1]))
+            self.pose_graph[a].append((tick_before, cam.currPose.copy()))
+            blk = self.thumbs(cam)
+            if not cam.lost:
+                self.ferns[self.frame_of[a]]._add(blk[0], blk[1], blk[2], cam.currPose.copy(), cam.tick, self.fern_threshold)
+            if k < self.query_from:
+                continue
+            fa = self.frame_of[a]
+            for c in range(self.n):  # for (auto& kv : m_contextToReferenceFrameMap)
+                fb = self.frame_of[c]
+                if fb == fa:
+                    continue
+                m = self.ferns[fb].findFrame(cam.currPose, None, None, None, cam.tick, lost=False, interMap=self.inter_map, thumbs=blk)
+                self.matches.append((k, a, fb, m["closest"], m["candidate"]))
+                if m["closest"] < 0:
+                    continue
+                if self.full_refine:
+                    r = self.refine(fb, a, m["estPose"])
+                    self.refinements.append((k, a, fb, r["accepted"], r))
+                    if not r["accepted"]:
+                        continue
+                    T = r["relativeTransform"]
+                else:
+                    T = orc_ferns._mul44(m["estPose"], orc.inv4f(cam.currPose))
+                self.consume(fb, fa, T)
+                self.merges.append((k, fb, fa, T.copy()))
+                break
         return outs
 
     def refine(self, fb, a, recoveryPose):

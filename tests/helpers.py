@@ -87,3 +87,36 @@ def planes_equal_where_valid(a, b):
         return False
     ok = ~np.isnan(ax)
     return bool((a[H:2 * H][ok] == b[H:2 * H][ok]).all() and (a[2 * H:][ok] == b[2 * H:][ok]).all())
+
+
+def fern_boundary_thumbnails(o, equal=150):
+    """Two W/8 x H/8 thumbnail sets (RGBA8 image, RGBA32F vertex, RGBA32F normal) whose descriptors under the fern table of `o`
+    (an oracle orc_ferns.Ferns) are valid in all o.num ferns and EQUAL in exactly `equal` of them: blockHDAware = equal / num.
+    With 150 of 500 the float ratio rounds to 0.3f, which Ferns.cpp:346 compares with the DOUBLE literal 0.3 - it passes there."""
+    th, tw = o.height, o.width
+    v = np.zeros((th, tw, 4), np.float32)
+    v[..., 2] = 1.0  # 1000 mm everywhere: every fern valid, the depth bit the same in both frames
+    v[..., 3] = 1.0
+    n = np.zeros((th, tw, 4), np.float32)
+    n[..., 2] = -1.0
+    a = np.zeros((th, tw, 4), np.uint8)
+    a[..., 3] = 255
+    ca, ga, _ = o._encode(a, v)
+    assert ga == o.num
+    full = a.copy()
+    full[..., :3] = 255
+    cf, _, _ = o._encode(full, v)
+    per_pixel = {}
+    for i in range(o.num):  # ferns whose code changes when their pixel turns white, grouped by pixel
+        if cf[i] != ca[i]:
+            per_pixel.setdefault((int(o.pos[i, 1]), int(o.pos[i, 0])), []).append(i)
+    want = o.num - equal
+    b = a.copy()
+    for (y, x), fs in sorted(per_pixel.items(), key=lambda kv: -len(kv[1])):
+        if len(fs) <= want:
+            b[y, x, :3] = 255
+            want -= len(fs)
+    assert want == 0, "could not place the differing ferns"
+    cb, gb, _ = o._encode(b, v)
+    assert gb == o.num and int((ca == cb).sum()) == equal
+    return (a, v, n), (b, v.copy(), n.copy())

@@ -333,3 +333,34 @@ def test_publish_block_in_one_launch_equals_the_four_step_form(mods, monkeypatch
         assert (x == y).all()
     for (pa, ta, ga_, ca), (pb, tb, gb_, cb) in zip(fa, fb):
         assert ta == tb and ga_ == gb_ and (ca == cb).all() and (pa == pb).all()
+
+
+def test_code_agreement_of_exactly_0_3f_verifies_and_wakes(mods):
+    """equal / valid = 150 / 500 rounds to 0.3f, which Ferns.cpp:346 compares with the DOUBLE literal 0.3: the candidate is verified.
+    find_common (the synchronous query) and the hit row of dms_ferns_search_blocks_hd (the pipelined session's wake rule, formed on the
+    host from {valid, equal}) must take that boundary like the reference and the oracle; 149 / 500 stays below on every reading."""
+    ferns, fusion, synth, orc, orc_ferns = mods
+    from densemonoslam_amd.capi import DeviceBuffer
+
+    up = lambda t: np.ascontiguousarray(np.repeat(np.repeat(t, 8, axis=0), 8, axis=1))  # NEAREST at ratio 8 reads texel 8 j + 4
+    I = np.eye(4, dtype=np.float32)
+    for equal, verifies in ((150, True), (149, False)):
+        g, o = make_pair(mods)
+        (ia, va, na), (ib, vb, nb) = helpers.fern_boundary_thumbnails(o, equal)
+        assert g.addFrame(up(ia), up(va), up(na), I, 1, 0.3) and o._add(ia, va, na, I, 1, 0.3)
+        m, _ = g.findFrame(I, up(vb), up(nb), up(ib), 5, interMap=True)
+        r = o.findFrame(I, None, None, None, 5, interMap=True, thumbs=(ib, vb, nb))
+        assert m.candidate == r["candidate"] == 0
+        assert np.float32(m.blockHDAware).tobytes() == np.float32(r["blockHDAware"]).tobytes() == (np.float32(equal) / np.float32(500)).tobytes()
+        assert (m.icp_count > 0) == (r["icp_count"] > 0) == verifies, (equal, m.icp_count, r["icp_count"])
+        assert m.icp_count == r["icp_count"] and m.closest == r["closest"]
+        # the pipelined session's operands: {candidate, dissimilarity bits, valid in both, equal}
+        T = ia.nbytes + va.nbytes + na.nbytes
+        blk, rows = DeviceBuffer(T + 1024), DeviceBuffer(16)
+        blk.upload(np.concatenate([ib.reshape(-1).view(np.uint8), vb.reshape(-1).view(np.uint8), nb.reshape(-1).view(np.uint8), np.zeros(1024, np.uint8)]))
+        g.encodeThumbs(blk.ptr, blk.ptr + T, blk.ptr + T + 512)
+        g.searchBlocksHd(blk.ptr, T + 1024, 1, T, T + 512, 0, True, rows.ptr)
+        row = rows.download(np.int32, (4,))
+        assert list(row[[0, 2, 3]]) == [0, 500, equal]
+        assert (float(np.float32(row[3]) / np.float32(row[2])) > 0.3) == verifies == o.searchHit((ib, vb, nb), 5, True)
+        g.close()

@@ -299,3 +299,25 @@ def test_fern_oracle_generator_known_answer_and_self_consistency():
             assert co[j] == int(((codes == fr.codes) & (codes != F.BAD)).sum())
         f1._add(img, verts, verts, np.eye(4), k, 0.0)
     assert len(f1.frames) == 6
+
+
+def test_fern_code_agreement_of_exactly_0_3f_verifies(orc):
+    """Ferns.cpp:346 compares blockHDAware's FLOAT return value with the DOUBLE literal 0.3: 150 equal codes of 500 give 0.3f =
+    0.300000012, which is above 0.3, so the tracker verifies the candidate (a float32 comparison `> 0.3f` would stop here - the
+    boundary the pipelined session's wake rule and find_common must take the same way, tests/test_ferns_gpu.py)."""
+    from oracle import orc_ferns
+    from tests import helpers
+
+    W, H, K = 640, 480, (528.0, 528.0, 320.0, 240.0)
+    o = orc_ferns.Ferns(W, H, K, seed=11, make_odometry=lambda: orc.Odometry(W // 8, H // 8, K[2] / 8, K[3] / 8, K[0] / 8, K[1] / 8))
+    A, B = helpers.fern_boundary_thumbnails(o, 150)
+    assert o._add(*A, np.eye(4, dtype=np.float32), 1, 0.3)
+    assert np.float32(150) / np.float32(500) == np.float32(0.3) and float(np.float32(0.3)) > 0.3
+    assert o.searchHit(B, 5, True)
+    m = o.findFrame(np.eye(4, dtype=np.float32), None, None, None, 5, interMap=True, thumbs=B)
+    assert m["candidate"] == 0 and np.float32(m["blockHDAware"]) == np.float32(0.3) and m["icp_count"] > 0  # (the tracker ran)
+    # one code fewer: below the threshold on either reading
+    o2 = orc_ferns.Ferns(W, H, K, seed=11, make_odometry=lambda: orc.Odometry(W // 8, H // 8, K[2] / 8, K[3] / 8, K[0] / 8, K[1] / 8))
+    A2, B2 = helpers.fern_boundary_thumbnails(o2, 149)
+    assert o2._add(*A2, np.eye(4, dtype=np.float32), 1, 0.3) and not o2.searchHit(B2, 5, True)
+    assert o2.findFrame(np.eye(4, dtype=np.float32), None, None, None, 5, interMap=True, thumbs=B2)["icp_count"] == 0

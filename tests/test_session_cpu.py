@@ -231,24 +231,37 @@ class _OrcBackend:
         return orc_ferns._mul4v(T, np.append(np.asarray(p, np.float32), np.float32(1)))[:3]
 
 
-def _worker(rank, world, port, q, scenario, extra=None):
+def frames_at(synth, k, offsets):
+    """camera c runs offsets[c] frames ahead of camera 0 on the corner scene's trajectory"""
+    out = {}
+    for c, off in enumerate(offsets):
+        d, rgb, _ = synth.frame(k + off, width=W, height=H, K=K, noise=True, scene=synth.CORNER_SCENE)
+        out[c] = (rgb, d)
+    return out
+
+
+def _worker(rank, world, port, q, scenario, extra=None, offsets=None, ticks=None):
     sc = SCENARIOS[scenario]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ["OMP_NUM_THREADS"] = "4"
+    threads = "4" if world <= 2 else "2"
+    os.environ["OMP_NUM_THREADS"] = threads
     import torch.distributed as dist
 
     from densemonoslam_amd import session, synth
     from oracle import orc
 
-    orc.set_threads(4)
+    orc.set_threads(int(threads))
+    n = len(offsets) if offsets else 2
+    orc.set_num_sensors(max(3, n))  # (the stand-in cameras: the oracle's count is a global of this process)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     be = _OrcBackend(sc.fern_photo)
-    s = session.CollabSession(be, 2, W, H, rank=rank, world=world, **sc.opts, **(extra or {}))
+    s = session.CollabSession(be, n, W, H, rank=rank, world=world, **sc.opts, **(extra or {}))
     be.session = s
-    s.relative_cons[rank].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + rank))  # a constraint row the caller's solver produced before the merge
+    for c in s.hosted():  # a constraint row the caller's solver produced before the merge
+        s.relative_cons[c].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + c))
     hosted_log = []
-    for k in range(sc.n_ticks):
-        fr = sc.frames(synth, k)
+    for k in range(ticks or sc.n_ticks):
+        fr = frames_at(synth, k, offsets) if offsets else sc.frames(synth, k)
         s.step(k, {c: fr[c] for c in fr if c % world == rank})
         hosted_log.append(s.hosted())
     res = dict(rank=rank, hosted=hosted_log, merges=s.merges, frame_of=s.frame_of, refinements=s.refinements,
@@ -340,3 +353,93 @@ def test_two_rank_session_merges_and_continues_like_the_one_process_session(orc,
         assert len(host["relative_cons"][c]) == 1 and host["relative_cons"][c][0].tobytes() == ref.relative_cons[c][0].tobytes()
     # and the re-basing did something: the consumed camera's first pose is no longer the identity
     assert not np.array_equal(host["pose_graph"][fa][0][1], np.eye(4, dtype=np.float32))
+
+
+# ---- BASELINE config 5 at its stated size: --n 4, four cameras, all fusing (MainController.cpp:229,262-400) -------------------------
+FOUR_OFFSETS = (0, 8, 16, 24)
+
+
+def run_oracle_session_n(offsets, ticks, relative_cons=True, **session_opts):
+    from densemonoslam_amd import synth
+    from oracle import orc_pipeline
+
+    sc = SCENARIOS["reference_rule"]
+    s = orc_pipeline.Session(len(offsets), W, H, K, fern_photo_thresh=sc.fern_photo, **sc.opts, **session_opts)
+    if relative_cons:
+        for c in range(len(offsets)):
+            s.relative_cons[c].append(np.arange(6, dtype=np.float32) * np.float32(0.25 + c))
+    for k in range(ticks):
+        fr = frames_at(synth, k, offsets)
+        s.step([fr[c] for c in range(len(offsets))], k)
+    return s
+
+
+def check_four(ref, results, world, ticks, one_map=True):
+    """every rank: the same merges / transforms / refinements / placement as the one-process oracle session; the rank that hosts a
+    final map (a consuming frame never moves: rank fb % world): the map, the key-frame count, its cameras' trajectories and re-based
+    constraint rows, bit for bit.  one_map: the session must have ended in ONE map that holds every camera's time slot."""
+    n = len(ref.cams)
+    last = lambda h: h[-1] if h and isinstance(h[0], list) else h
+    assert len(ref.merges) >= 2, ref.merges
+    if one_map:
+        assert len(set(ref.frame_of)) == 1, ref.frame_of
+    for r in range(world):
+        res = results[r]
+        assert [(m[0], m[1], m[2]) for m in res["merges"]] == [(m[0], m[1], m[2]) for m in ref.merges], (r, res["merges"])
+        for got, want in zip(res["merges"], ref.merges):
+            assert np.asarray(got[3], np.float32).tobytes() == want[3].tobytes(), "rank %d: a relative transform differs from the oracle's" % r
+        assert res["frame_of"] == ref.frame_of and res["refinements"] == [x[:4] for x in ref.refinements]
+        if res.get("woken") is not None:
+            assert res["woken"] == ref.woken
+        assert last(res["hosted"]) == [c for c in range(n) if ref.frame_of[c] % world == r], (r, res["hosted"])
+    for fb in sorted(set(ref.frame_of)):
+        host = results[fb % world]
+        m_ref = ref.cams[fb].model
+        m_got = host["maps"][fb]
+        assert len(m_got) == len(m_ref), (fb, len(m_got), len(m_ref))
+        for f in m_ref.dtype.names:
+            assert np.array_equal(m_got[f].view(np.uint32), m_ref[f].view(np.uint32)), "map of frame %d differs in field %s" % (fb, f)
+        members = [c for c in range(n) if ref.frame_of[c] == fb]
+        # the map holds its cameras' time slots (with four the reference overruns Vertex::MAX_SENSORS = 3, Shaders/Vertex.cpp:49)
+        assert all((m_ref["times"][:, c] > 0).any() for c in members)
+        assert host["fern_frames"][fb] == len(ref.ferns[fb].frames)
+        for c in members:
+            got, want = host["pose_graph"][c], ref.pose_graph[c]
+            assert [t for t, _ in got] == [t for t, _ in want] and len(got) == ticks
+            for i, ((_, a), (_, b)) in enumerate(zip(got, want)):
+                assert np.asarray(a, np.float32).tobytes() == np.asarray(b, np.float32).tobytes(), "camera %d pose %d differs" % (c, i)
+            rc = host["relative_cons"][c]
+            assert len(rc) == 1 and np.asarray(rc[0], np.float32).tobytes() == ref.relative_cons[c][0].tobytes(), "camera %d: relative constraint differs" % c
+
+
+def spawn(world, target, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in [q.get(timeout=1500) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+FOUR_TICKS, FOUR_TICKS_PIPELINED = 11, 20  # merges at ticks 6, 7, 8 (synchronous tick) / 9, 13, 17 (three ticks after each descriptor hit)
+
+
+@pytest.mark.parametrize("world,wake", [(4, None), (2, 3)])
+def test_four_cameras_merge_over_gloo(orc, world, wake):
+    """BASELINE config 5's size: four cameras, all fusing.  World 4, one camera per rank, the synchronous tick: every merge crosses ranks,
+    the third one moves a frame that holds three cameras - its founder, an imported camera and another imported one - and the session
+    ends in ONE map with four time slots on one rank while the other three forward their cameras' frames.  World 2, two cameras per
+    rank, the pipelined schedule (the rule: flags gathered, every rank woken at the same tick), through its first two merges.  The
+    protocol (stand-ins on the oracle) against the one-process oracle session."""
+    ticks = FOUR_TICKS if wake is None else 15
+    extra = {"wake_latency": wake} if wake else {}
+    ref = run_oracle_session_n(FOUR_OFFSETS, ticks, **extra)
+    if wake:
+        assert ref.woken == [9, 13] and len(ref.merges) == 2, (ref.woken, ref.merges)
+    results = spawn(world, _worker, ("reference_rule", extra, FOUR_OFFSETS, ticks))
+    check_four(ref, results, world, ticks, one_map=wake is None)

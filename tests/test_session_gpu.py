@@ -11,7 +11,8 @@ import os
 import numpy as np
 import pytest
 
-from tests.test_session_cpu import SCENARIOS, H, K, W, _free_port, run_oracle_session
+from tests.test_session_cpu import (FOUR_OFFSETS, FOUR_TICKS, FOUR_TICKS_PIPELINED, SCENARIOS, H, K, W, _free_port, check_four, frames_at, run_oracle_session,
+                                    run_oracle_session_n, spawn)
 
 pytestmark = pytest.mark.gpu
 # "reference_rule": the merge is decided by Ferns::findFrame(interMap = 1) + the full-resolution refinement and acceptance of
@@ -565,3 +566,114 @@ def test_pipelined_result_does_not_depend_on_the_stream_arrangement(monkeypatch)
     assert len(ref[1]) == 2 and ref[2]["ticks"] == ticks, ref
     for pool in (2, 3):
         assert run(pool) == ref, pool
+
+
+# ---- BASELINE config 5 at its stated size: --n 4, four cameras, all fusing (MainController.cpp:229,262-400) -------------------------
+_FOUR = {}
+
+
+def four_oracle(wake=None, **opts):
+    key = (wake, tuple(sorted(opts.items())))
+    if key not in _FOUR:
+        ticks = FOUR_TICKS if wake is None else FOUR_TICKS_PIPELINED
+        _FOUR[key] = (run_oracle_session_n(FOUR_OFFSETS, ticks, **({"wake_latency": wake} if wake else {}), **opts), ticks)
+    return _FOUR[key]
+
+
+def _result_of(s, rank=0, pipelined=False):
+    res = dict(rank=rank, merges=s.merges, hosted=s.hosted(), refinements=s.refinements, frame_of=s.frame_of,
+               stats=s.async_stats() if pipelined else None)
+    if s.hosted():
+        frames = sorted({s.frame_of[c] for c in s.hosted()})
+        res.update(maps={f: s.cams[f].model() for f in frames}, fern_frames={f: len(s.ferns[f]) for f in frames},
+                   pose_graph={c: s.pose_graph[c] for c in s.hosted()}, relative_cons={c: s.relative_cons[c] for c in s.hosted()})
+    return res
+
+
+@pytest.mark.parametrize("impl,pipelined", [("native", False), ("native", True), ("python", False)])
+def test_four_cameras_one_device_end_in_one_map(orc, impl, pipelined):
+    """--n 4 on one device: frame 0 consumes camera 1's map, frame 2 consumes frame 0 (two cameras), frame 3 consumes frame 2 (three
+    cameras: its founder and two that had joined) - ONE map with four time slots, and all four cameras keep tracking against and fusing
+    into it.  Synchronous tick (merges at ticks 6, 7, 8) and pipelined tick (each merge three ticks after its descriptor hit).  Map,
+    four trajectories, three transforms, key frames and the re-based constraint rows: the one-process oracle session's bits."""
+    from densemonoslam_amd import synth
+
+    ref, ticks = four_oracle(3 if pipelined else None)
+    sc = SCENARIOS["reference_rule"]
+    s = _make_session(impl, sc, 4, capacity=4_000_000)
+    for k in range(ticks):
+        s.step(k, frames_at(synth, k, FOUR_OFFSETS), **({"pipelined": True} if pipelined else {}))
+    res = _result_of(s, 0, pipelined)
+    if pipelined:
+        assert res["stats"] == {"ticks": ticks, "woken": len(ref.woken)}
+    check_four(ref, {0: res}, 1, ticks)
+    s.close()
+
+
+def _worker_n(rank, world, port, q, impl, ticks, offsets, pipelined, opts=None):
+    sc = SCENARIOS["reference_rule"]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["DMS_TRACK_MODE"] = "launches"  # processes that share a device must not spin side by side (DESIGN.md 2.1)
+    import copy
+
+    import torch.distributed as dist
+
+    from densemonoslam_amd import synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc2 = copy.copy(sc)
+    sc2.opts = dict(sc.opts, **(opts or {}))
+    s = _make_session(impl, sc2, len(offsets), rank, world, capacity=4_000_000)
+    for k in range(ticks):
+        fr = frames_at(synth, k, offsets)
+        s.step(k, {c: fr[c] for c in fr if c % world == rank}, **({"pipelined": True} if pipelined else {}))
+    q.put(_result_of(s, rank, pipelined))
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_four_cameras_two_ranks_end_in_one_map(orc, pipelined):
+    """--n 4 over two ranks (gloo transport, one GPU): cameras 0 and 2 are read on rank 0, 1 and 3 on rank 1.  The first merge crosses
+    ranks (records, import, frame forwarding), the second joins on rank 0, the third ships a frame that holds three cameras - a founder, an
+    IMPORTED camera and a joined one - to rank 1, which ends up hosting all four while rank 0 only forwards frames."""
+    world = 2
+    ref, ticks = four_oracle(3 if pipelined else None)
+    results = spawn(world, _worker_n, ("native", ticks, FOUR_OFFSETS, pipelined))
+    if pipelined:
+        for r in range(world):
+            assert results[r]["stats"] == {"ticks": ticks, "woken": len(ref.woken)}
+    check_four(ref, results, world, ticks)
+
+
+def test_queries_inside_the_frame_as_the_reference_orders_them(orc):
+    """dms_session_params.query_inside_frame: the inter-map block runs INSIDE each camera's processFrame (ElasticFusion.cpp:595-632) -
+    camera c queries, and merges, before camera c + 1's frame of the same tick.  Four cameras on one device: at tick 6 cameras 1 AND 2
+    are consumed by frame 0 in the same tick (the batched order allows one merge per frame and tick: ticks 6, 7, 8 there), and camera 3's
+    frame of that tick... stays in its own map until camera 0 finds it.  Against orc_pipeline.Session(query_inside_frame = True); and the
+    two orders really differ."""
+    from densemonoslam_amd import synth
+
+    ticks = 11
+    ref = run_oracle_session_n(FOUR_OFFSETS, ticks, query_inside_frame=True)
+    batched, _ = four_oracle(None)
+    assert [(m[0], m[1], m[2]) for m in ref.merges] != [(m[0], m[1], m[2]) for m in batched.merges]
+    assert len({m[0] for m in ref.merges}) < len(ref.merges), "two merges in one tick are what the order makes possible"
+    import copy
+
+    sc = copy.copy(SCENARIOS["reference_rule"])
+    sc.opts = dict(sc.opts, query_inside_frame=True)
+    s = _make_session("native", sc, 4, capacity=4_000_000)
+    for k in range(ticks):
+        s.step(k, frames_at(synth, k, FOUR_OFFSETS))
+    check_four(ref, {0: _result_of(s)}, 1, ticks)
+    s.close()
+
+
+def test_queries_inside_the_frame_two_ranks(orc):
+    """the same order across two ranks: per camera one published block, one table, one walk (the cameras of a tick are serialised)"""
+    ticks = 11
+    ref = run_oracle_session_n(FOUR_OFFSETS, ticks, query_inside_frame=True)
+    results = spawn(2, _worker_n, ("native", ticks, FOUR_OFFSETS, False, dict(query_inside_frame=True)))
+    check_four(ref, results, 2, ticks)
