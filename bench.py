@@ -9,9 +9,14 @@ depth bilateral + metric conversion, model prediction + fill-in, tracker pyramid
 initialisation, SO3 pre-alignment + 3-level combined ICP/RGB Gauss-Newton (10/5/4 iterations),
 second prediction, index map, fuse, index map, clean, final prediction
 (ElasticFusion::processFrame with --o --nkf; SURVEY.md §8(d) "frame step").
-Multi-GPU = the collaborative session: one camera (and its own map) per rank, weak scaling;
-the only exchange is the per-frame all-gather of each camera's W/8 x H/8 thumbnails (the fern
-matcher's inputs) over RCCL.
+Multi-GPU = the collaborative session: one camera (and its own map) per rank, weak scaling.  With
+--gpus N > 1 the timed loop IS the compiled session's pipelined tick (dms_session_step_async,
+include/dmslam_session.h) over the library's RCCL transport (dms_transport_rccl): per tick one
+frame per rank, frame block (W/8 x H/8 thumbnails + fern descriptor), key-frame insertion, ONE
+all-gather, descriptor search of every other camera's block, host mirror.
+The round-3 exchange (collab.InterMapMatcher over torch.distributed) runs first as a labelled
+fall-back leg: it becomes the headline only if the session loop cannot be set up or does not finish.
+`--session-loop` runs the same loop at N = 1 (a one-rank RCCL communicator carries the collectives).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
 """
@@ -167,6 +172,8 @@ def main():
     ap.add_argument("--no-full-leg", action="store_true", help="skip the extra 'full' (loop closure on) leg of the default run")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs for BASELINE configs 2 / 4, n_pred = 3 and the populated full step")
     ap.add_argument("--no-session-leg", action="store_true", help="skip the collaborative-session leg (dms_session: two cameras, a merge by the reference's rule)")
+    ap.add_argument("--session-loop", action="store_true",
+                    help="N = 1: time the headline frames through dms_session_step_async over a one-rank RCCL transport (the loop --gpus N > 1 times)")
     ap.add_argument("--time-delta", type=int, default=200,
                     help="active time window in frames (reference default 200); a small value with --loop-closure populates the INACTIVE "
                          "view on this cyclic stream, so the model-to-model tracker has correspondences")
@@ -335,6 +342,111 @@ def main():
 
     elapsed = collab.max_over_ranks(elapsed, dev)  # the slowest rank defines the job time
     M_total = int(collab.sum_over_ranks(M, dev))
+
+    # ---- the headline loop of --gpus N > 1 (and of --session-loop): dms_session_step_async over dms_transport_rccl -----------------
+    # One camera per rank, this rank's frames resident in HBM, no inter-map query due inside the timed region (query_from beyond the
+    # run: the cameras stay one per GPU, which is what scales weakly; the wake / refine / merge path is timed by the
+    # `session_across_ranks` leg below).  Per tick and rank: the frame step, the frame block, key-frame insertion, the all-gather of
+    # world blocks, the descriptor search of the hosted database against every gathered block, the host mirror.  Timed exactly like
+    # the loop above: W untimed ticks, K timed ticks between barrier + synchronize, max over ranks.
+    # The library's RCCL binding had never formed a communicator of more than one rank before this round's first multi-GPU run, so the
+    # loop is guarded: set-up failures are agreed on by all ranks (the fall-back figure above stays the headline, labelled), and a
+    # watchdog prints the line with that figure if the loop does not finish.
+    session_loop = distributed or args.session_loop
+    sess = None
+    headline_loop = "dms_fusion_process_frame (one camera, no session)" if not distributed else (
+        "fall-back: collab.InterMapMatcher over torch.distributed (round-3 exchange)")
+    fallback = None
+    if session_loop and not args.loop_closure:
+        import threading
+
+        from densemonoslam_amd import session as session_mod
+
+        fallback = {"value": world * args.steps / elapsed, "unit": "frames/s", "ms_per_step": 1000.0 * elapsed / args.steps,
+                    "what": "the same frames with the round-3 exchange (collab.InterMapMatcher: frame block, key-frame insertion, all-gather over "
+                            "torch.distributed, descriptor search) - timed first, the headline only if the session loop below fails" if exchange_on
+                            else "the bare frame step (dms_fusion_process_frame, no session)"}
+        sess = {"loop": "dms_session_step_async", "error": None}
+        limit_s = int(os.environ.get("DMS_BENCH_SESSION_LIMIT", "240"))
+        sess_done = threading.Event()
+
+        def headline_watchdog():
+            if sess_done.wait(limit_s):
+                return
+            if rank == 0:
+                line = {"metric": "frames/sec ICP+RGB+fusion @640x480" if (W, H) == (640, 480) else "frames/sec ICP+RGB+fusion @%dx%d" % (W, H),
+                        "value": fallback["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": fallback["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                        "data": "synthetic", "headline_loop": headline_loop,
+                        "session_loop_error": "dms_session_step_async over the transport did not finish within %d s" % limit_s,
+                        "config": {"workload": "TUM fr1/desk-like 640x480 full 3-level ICP+RGB tracking + surfel fusion, one camera per GPU, "
+                                               "round-3 exchange (fall-back)", "resolution": [W, H], "cameras_per_gpu": 1}}
+                print(json.dumps(line))
+                sys.stdout.flush()
+            os._exit(0)
+
+        threading.Thread(target=headline_watchdog, daemon=True).start()
+        tr, err = None, None
+        try:
+            tmode = os.environ.get("DMS_BENCH_SESSION_TRANSPORT", "rccl" if (not distributed or backend == "nccl") else "torch")
+            if tmode == "rccl":
+                tr = session_mod.RcclTransport(collab.rccl_carrier_from_process_group(rank, world))
+            elif tmode == "torch":
+                tr = session_mod.TorchTransport(rank, world)
+            # ("none": a one-rank session without a transport - nothing is gathered, the search reads the blocks where they were packed)
+        except Exception as e:  # noqa: BLE001 (agreed on below: every rank must take the same branch)
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = 0.0 if err else 1.0
+        if distributed:
+            flag = torch.tensor([ok], dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = float(flag.item())
+        if ok < 1.0:
+            sess["error"] = err or "the transport could not be set up on another rank"
+        else:
+            st_s = capi.create_stream()
+            ns = session_mod.NativeSession(W, H, K, world, rank=rank, world=world, transport=tr, query_from=1 << 30, model_capacity=8_000_000,
+                                           time_exchange=tr is not None)
+
+            def tick(i):
+                j = frame_index(i)
+                ns.step_resident(i, [rgb_t[j].data_ptr()], [dep_t[j].data_ptr()], pipelined=True, stream=st_s)
+
+            def sbarrier():
+                ns.sync()
+                capi.lib.dms_stream_sync(st_s)
+                if distributed:
+                    dist.barrier()
+                torch.cuda.synchronize()
+
+            for i in range(args.warmup):
+                tick(i)
+            sbarrier()
+            ag0 = ns.exchange_time()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, n_total):
+                tick(i)
+            t_enq_s = time.perf_counter() - t0
+            sbarrier()
+            el_s = time.perf_counter() - t0
+            ag1 = ns.exchange_time()
+            rs = fusion.FrameResult()
+            capi.check(fusion.lib.dms_fusion_fetch(capi.lib.dms_session_camera(ns.h, rank), C.byref(rs), st_s), "dms_fusion_fetch")
+            el_s = collab.max_over_ranks(el_s, dev)
+            ag_ms = (ag1[0] - ag0[0]) / max(1, ag1[1] - ag0[1]) if tr is not None else 0.0
+            sess.update(elapsed=el_s, t_enq=t_enq_s, surfels=int(rs.surfels), surfels_total=int(collab.sum_over_ranks(int(rs.surfels), dev)),
+                        allgather_ms_per_frame=collab.max_over_ranks(ag_ms, dev), allgather_ms_per_frame_rank0=ag_ms, allgathers_timed=ag1[1] - ag0[1],
+                        transport={"rccl": "dms_transport_rccl (the library's RCCL binding, include/dmslam_collab.h)",
+                                   "torch": "session.TorchTransport (torch.distributed %s through ctypes callbacks: rehearsal only)" % backend,
+                                   "none": "none (one-rank session: nothing gathered)"}[tmode],
+                        rccl_ranks=int(capi.lib.dms_collab_size(tr.carrier.h)) if tmode == "rccl" else 0,
+                        rccl_library=(capi.lib.dms_collab_library_path() or b"").decode() if tmode == "rccl" else None,
+                        block_bytes=int(collab.thumbnail_bytes(W, H)))
+            ns.close()
+            capi.destroy_stream(st_s)
+            headline_loop = "dms_session_step_async over %s" % ("dms_transport_rccl" if tmode == "rccl" else tmode)
+            elapsed, t_enq, M, M_total = el_s, t_enq_s, sess["surfels"], sess["surfels_total"]
+        sess_done.set()
     rank_devices = [{"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(dev)}]
     if distributed:
         gathered = [None] * world
@@ -350,7 +462,15 @@ def main():
         "value": fps,
         "unit": "frames/s",
         "n_gpus": world,
-        "rccl_ranks": dist.get_world_size() if (distributed and backend == "nccl") else (0 if distributed else 1),
+        # ranks of the communicator the timed loop's collectives ran on: the LIBRARY's (dms_collab_size) when the session loop is the
+        # headline, torch.distributed's for the fall-back loop
+        "rccl_ranks": (sess["rccl_ranks"] if sess and not sess["error"] and sess.get("rccl_ranks") else
+                       (dist.get_world_size() if (distributed and backend == "nccl") else (0 if distributed else 1))),
+        "rccl_library": sess.get("rccl_library") if sess and not sess["error"] else None,
+        "headline_loop": headline_loop,
+        "allgather_ms_per_frame": sess.get("allgather_ms_per_frame") if sess and not sess["error"] else None,
+        "session_loop": None if not sess else {k: v for k, v in sess.items() if k not in ("elapsed", "t_enq")},
+        "fallback_exchange_loop": fallback,
         "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend,
         "exchange_carrier": "dms_collab_allgather (library's RCCL binding)" if carrier is not None else ("torch.distributed" if distributed else "none"),
         "rank_devices": rank_devices,
@@ -358,7 +478,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "host_enqueue_ms_per_step": round(1000.0 * t_enq / args.steps, 4),
-        "host_blocked_ms_per_step": round(host_wait_ms / args.steps, 4),  # of which: waiting for frame t-2 (0 = host-bound)
+        "host_blocked_ms_per_step": round(host_wait_ms / args.steps, 4) if not (sess and not sess["error"]) else None,  # of which: waiting for frame t-2 (0 = host-bound)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -381,7 +501,13 @@ def main():
             "loop_icp_count_last_frame": float(res.loop_icp_count) if args.loop_closure else None,
             "surfels_per_map": M,
             "surfels_total": M_total,
-            "exchange": ("all-gather of one %d-byte frame block per camera per frame (592-byte fern descriptor + W/8xH/8 thumbnails), "
+            "session": None if not (sess and not sess["error"]) else (
+                "timed loop = dms_session_step_async (include/dmslam_session.h), one camera per rank over %s: per tick the frame step, the frame "
+                "block (W/8xH/8 thumbnails + 1616-byte tail: fern codes, pose, tick, hit rows), key-frame insertion into the own map's database, ONE "
+                "all-gather of %d x %d bytes, the descriptor search of the hosted database against every gathered block, the host mirror; no inter-map "
+                "verification due inside the timed region (query_from beyond the run), so every camera keeps its own map and GPU"
+                % (sess["transport"], world, sess["block_bytes"] + 1616)),
+            "exchange": ("fall-back leg: all-gather of one %d-byte frame block per camera per frame (592-byte fern descriptor + W/8xH/8 thumbnails), "
                          "every rank searches its fern database (%d key frames on rank 0) with the other cameras' descriptors: "
                          "%d remote descriptors found a candidate on rank 0, %d verified"
                          % (thumb.numel(), len(fern_db), matcher.candidates, len(matcher.verified))) if exchange_on else "none (1 camera)",
@@ -471,6 +597,11 @@ def main():
             "C4": leg(dict(depthCut=40.0), "BASELINE config 4 geometry: 1241x376, KITTI intrinsics, 40 m depth cut-off, full 3-level ICP+RGB tracking "
                       "+ fusion (synthetic depth in place of the absent depth network)", (10, 5, 4), True, 2, 1, 1241, 376, synth.K_KITTI),
         }
+
+        # the frame rate in the REFERENCE's shape (three model predictions per frame, each projecting the map itself:
+        # ElasticFusion.cpp:165,273,586), at top level beside `value` (whose timed region runs the two predictions that are not dead with --o)
+        out["value_ref_shape"] = {"value": out["configs"]["C3_n_pred3"]["value"], "unit": "frames/s", "steps": out["configs"]["C3_n_pred3"]["steps"],
+                                  "surfels": out["configs"]["C3_n_pred3"]["surfels"], "what": "configs.C3_n_pred3: n_pred = 3, no shared projection"}
 
     # ---- the collaborative session behind the boundary (dms_session, include/dmslam_session.h), BASELINE config 5 in the small ----------
     # Two cameras of one session on this GPU at 640 x 480 in the cluttered-corner scene, camera 1 eight frames ahead of camera 0 on the

@@ -79,6 +79,7 @@ class RcclCarrier:
         lib.dms_collab_destroy.argtypes = [C.c_void_p]
         lib.dms_collab_rank.argtypes = [C.c_void_p]
         lib.dms_collab_size.argtypes = [C.c_void_p]
+        lib.dms_collab_library_path.restype = C.c_char_p
         self.h = C.c_void_p()
         capi.check(lib.dms_collab_create(C.byref(self.h), rank, world, bytes(unique_id)), "dms_collab_create")
         self.rank, self.world = lib.dms_collab_rank(self.h), lib.dms_collab_size(self.h)
@@ -113,6 +114,10 @@ class RcclCarrier:
         s = torch.cuda.current_stream() if stream is None else stream
         self._capi.check(self._capi.lib.dms_collab_allreduce_max_f64(self.h, t.data_ptr(), self._C.c_void_p(s.cuda_stream)),
                          "dms_collab_allreduce_max_f64")
+
+    def library_path(self):
+        """the file the library resolved RCCL's entry points from (one copy per process: the one already mapped, if any)"""
+        return (self._capi.lib.dms_collab_library_path() or b"").decode()
 
     def close(self):
         if self.h:
