@@ -387,4 +387,11 @@ inline int xcd_remap_enabled() {
 
 inline dim3 grid2d(int cols, int rows, dim3 block) { return dim3((cols + block.x - 1) / block.x, (rows + block.y - 1) / block.y); }
 
+// The thumbnail block a camera publishes / a key frame stores (include/dmslam_fusion.h, dms_thumb_block_bytes): n = tw * th pixels,
+// [RGBA8 image, padded to a multiple of 16 bytes | RGBA32F vertex | RGBA32F normal] - the float4 sections stay 16-byte aligned for any
+// n (1241 x 376: 155 x 47 thumbnails).  For n a multiple of 4 this is the packed layout of rounds 3 - 4.
+__host__ __device__ inline size_t thumb_vertex_off(size_t n) { return (n * 4 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t thumb_normal_off(size_t n) { return thumb_vertex_off(n) + n * 16; }
+__host__ __device__ inline size_t thumb_block_size(size_t n) { return thumb_vertex_off(n) + n * 32; }
+
 }  // namespace dms

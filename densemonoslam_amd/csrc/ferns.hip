@@ -359,7 +359,8 @@ __global__ __launch_bounds__(kFernPad) void k_fern_publish(const unsigned char* 
                                                            int* __restrict__ good_out, FernHost* __restrict__ res, const unsigned char* __restrict__ db_codes,
                                                            int* __restrict__ db_good, int* __restrict__ db_time, float* __restrict__ db_pose,
                                                            unsigned char* __restrict__ db_blocks, size_t block_bytes, int* __restrict__ n_dev, int capacity,
-                                                           float threshold, int srcTime, const float* __restrict__ pose_dev, volatile int* status, int seq) {
+                                                           float threshold, int srcTime, const float* __restrict__ pose_dev, volatile int* status, int seq,
+                                                           unsigned* __restrict__ mirror, size_t mirror_offset, int mirror_words) {
   __shared__ int s_good, s_slot;
   __shared__ unsigned long long s_best;
   __shared__ __attribute__((aligned(8))) unsigned char s_codes[kFernPad];
@@ -448,6 +449,12 @@ __global__ __launch_bounds__(kFernPad) void k_fern_publish(const unsigned char* 
     }
   }
   __syncthreads();
+  // ---- optional: mirror_words dwords of the block from byte mirror_offset on, as they are now, to memory the host reads (the
+  // session's per-tick metadata: good-code count - written above by thread 0 and taken from the register here -, tick, camera, pose, hit rows)
+  if (mirror) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(block + mirror_offset);
+    for (int w = i; w < mirror_words; w += kFernPad) mirror[w] = (good_out && (const void*)(src + w) == (const void*)good_out) ? (unsigned)good : src[w];
+  }
   // ---- commit: payload of an accepted frame -> its slot
   const int slot = s_slot;
   if (slot < 0) return;
@@ -950,14 +957,21 @@ int dms_ferns_add_frame_async(dms_ferns* f, const dms_image2d* image_rgba, const
 
 int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, const float* pose16_dev,
                             int srcTime, float threshold, dms_stream st) {
+  return dms_ferns_publish_block_mirror(f, thumb_block_dev, codes_dev, good_dev, pose16_dev, srcTime, threshold, nullptr, 0, 0, st);
+}
+
+int dms_ferns_publish_block_mirror(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, const float* pose16_dev,
+                                   int srcTime, float threshold, void* mirror, size_t mirror_offset, size_t mirror_bytes, dms_stream st) {
   DMS_REQUIRE(f && thumb_block_dev && codes_dev && good_dev && pose16_dev, "null argument");
   DMS_REQUIRE(((uintptr_t)thumb_block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  DMS_REQUIRE(!mirror || (mirror_offset % 4 == 0 && mirror_bytes % 4 == 0 && ((uintptr_t)mirror & 3) == 0), "the mirrored range must be made of dwords");
   hipStream_t s = (hipStream_t)st;
   if (f->n_upper <= kPublishFusedMax && f->publish_fused) {  // the four steps in one launch (k_fern_publish)
     f->adds_issued += 1;
     hipLaunchKernelGGL(k_fern_publish, dim3(1), dim3(kFernPad), 0, s, (const unsigned char*)thumb_block_dev, f->tw, f->th, f->d_tab, f->num,
                        f->d_cur_codes, codes_dev, good_dev, f->d_res, (const unsigned char*)f->d_codes, f->d_good, f->d_time, f->d_pose, f->d_blocks,
-                       f->block_bytes, f->d_n, f->capacity, threshold, srcTime, pose16_dev, (volatile int*)f->d_status, f->adds_issued);
+                       f->block_bytes, f->d_n, f->capacity, threshold, srcTime, pose16_dev, (volatile int*)f->d_status, f->adds_issued,
+                       (unsigned*)mirror, mirror_offset, (int)(mirror_bytes / 4));
     DMS_CHECK_LAUNCH();
     after_async_add(f, s);
     return DMS_OK;
@@ -978,6 +992,8 @@ int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned 
                      f->d_blocks, f->d_codes, f->d_res);
   DMS_CHECK_LAUNCH();
   after_async_add(f, s);
+  if (mirror && mirror_bytes)  // (the database has outgrown the one-launch form: the mirror is a launch of its own)
+    return dms_copy_rows_async(mirror, mirror_bytes, (const unsigned char*)thumb_block_dev + mirror_offset, mirror_bytes, mirror_bytes, 1, st);
   return DMS_OK;
 }
 

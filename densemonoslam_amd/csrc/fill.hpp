@@ -27,6 +27,17 @@ struct FillArgs {
   // consumer of the decision sums them (dense_from_counters) — no block has to wait for the others inside the launch
   unsigned* dense_cnt;
   const unsigned* sample_mask;
+  // optional (resolve pass): the frame block of collaborative mode (dms_fusion_arm_frame_block) written by the threads that own a
+  // sample of the W/8 x H/8 NEAREST thumbnails of the FILLED image / vertex / normal (what k_thumbnails reads back in a launch of its
+  // own): thumb_mask = column bits (words 0..63) | row bits (64..127) | samples in the words before (128..191 columns, 192..255
+  // rows) - thumb_sample_masks; block 0 also copies the camera's pose and stores the tick
+  unsigned char* thumb_block;
+  const unsigned* thumb_mask;
+  int thumb_w, thumb_h;
+  const float* thumb_pose_src;
+  float* thumb_pose_dst;
+  int* thumb_tick_dst;
+  int thumb_tick;
   float4* out_vertex;
   float4* out_normal;
   uchar4* out_image;
@@ -41,8 +52,9 @@ __device__ __forceinline__ f3 fill_vertex_at(const FillArgs& a, int sx, int sy, 
   return mk3((((float)x - a.cx) * z) * a.ifx, (((float)y - a.cy) * z) * a.ify, z);
 }
 
-// pixel (px, py) whose existing (predicted) values are sv / sn / si
-__device__ __forceinline__ void fill_pixel(const FillArgs& a, int px, int py, const float4& sv, const float4& sn, const uchar4& si) {
+// pixel (px, py) whose existing (predicted) values are sv / sn / si; ov / on / oi = what was stored
+__device__ __forceinline__ void fill_pixel_out(const FillArgs& a, int px, int py, const float4& sv, const float4& sn, const uchar4& si, float4& ov,
+                                               float4& on, uchar4& oi) {
   const size_t i = (size_t)py * a.cols + px;
   const float colsf = (float)a.cols, rowsf = (float)a.rows;
   const float tcx = ((float)px + 0.5f) / colsf, tcy = ((float)py + 0.5f) / rowsf;
@@ -50,10 +62,11 @@ __device__ __forceinline__ void fill_pixel(const FillArgs& a, int px, int py, co
   {  // fill_vertex.frag:41-55
     if (sv.z == 0.f || a.pass_geom == 1) {
       const f3 v = fill_vertex_at(a, px, py, x, y);
-      a.out_vertex[i] = make_float4(v.x, v.y, v.z, 1.f);
+      ov = make_float4(v.x, v.y, v.z, 1.f);
     } else {
-      a.out_vertex[i] = sv;
+      ov = sv;
     }
+    a.out_vertex[i] = ov;
   }
   {  // fill_normal.frag:33-48 with geometry.glsl:48-58 forward differences
     if (sn.z == 0.f || a.pass_geom == 1) {
@@ -63,17 +76,64 @@ __device__ __forceinline__ void fill_pixel(const FillArgs& a, int px, int py, co
       const f3 vx = fill_vertex_at(a, sxp, py, x + 1, y);
       const f3 vy = fill_vertex_at(a, px, syp, x, y + 1);
       const f3 n = normalized3(cross3(vx - v, vy - v));
-      a.out_normal[i] = make_float4(n.x, n.y, n.z, 1.f);
+      on = make_float4(n.x, n.y, n.z, 1.f);
     } else {
-      a.out_normal[i] = sn;
+      on = sn;
     }
+    a.out_normal[i] = on;
   }
   {  // fill_rgb.frag:29-37: samp.x + samp.y + samp.z == 0 on normalised bytes <=> all three zero
     if ((si.x == 0 && si.y == 0 && si.z == 0) || a.pass_rgb == 1)
-      a.out_image[i] = a.rgba[i];
+      oi = a.rgba[i];
     else
-      a.out_image[i] = si;
+      oi = si;
+    a.out_image[i] = oi;
   }
+}
+__device__ __forceinline__ void fill_pixel(const FillArgs& a, int px, int py, const float4& sv, const float4& sn, const uchar4& si) {
+  float4 ov, on;
+  uchar4 oi;
+  fill_pixel_out(a, px, py, sv, sn, si, ov, on, oi);
+}
+
+// the frame block's thumbnails from the pixel just filled (a.thumb_block != nullptr): NEAREST as resize.frag, the sample of thumbnail
+// texel (i, j) is source texel (texel((i + .5) / tw), texel((j + .5) / th)) - the thread that owns it stores it
+__device__ __forceinline__ void fill_thumb(const FillArgs& a, int px, int py, const float4& ov, const float4& on, const uchar4& oi) {
+  const unsigned cw = a.thumb_mask[px >> 5], rw = a.thumb_mask[64 + (py >> 5)];
+  if (!((cw >> (px & 31)) & (rw >> (py & 31)) & 1u)) return;
+  const int i = (int)a.thumb_mask[128 + (px >> 5)] + __popc(cw & ((1u << (px & 31)) - 1u));
+  const int j = (int)a.thumb_mask[192 + (py >> 5)] + __popc(rw & ((1u << (py & 31)) - 1u));
+  const size_t n = (size_t)a.thumb_w * a.thumb_h, k = (size_t)j * a.thumb_w + i;
+  reinterpret_cast<uchar4*>(a.thumb_block)[k] = oi;
+  reinterpret_cast<float4*>(a.thumb_block + thumb_vertex_off(n))[k] = ov;
+  reinterpret_cast<float4*>(a.thumb_block + thumb_normal_off(n))[k] = on;
+}
+
+// host: masks + prefix counts of the W/8 x H/8 NEAREST subsample (cols, rows <= 2048), 256 words; false when two thumbnail texels
+// would sample the same source texel (the owner-writes form needs distinct owners: sizes below 8 x 8 per sample never occur)
+inline bool thumb_sample_masks(int cols, int rows, unsigned* words256) {
+  for (int i = 0; i < 256; ++i) words256[i] = 0u;
+  const int tw = cols / 8, th = rows / 8;
+  if (tw < 1 || th < 1 || cols > 2048 || rows > 2048) return false;
+  int last = -1;
+  for (int i = 0; i < tw; ++i) {
+    const int sx = texel(((float)i + 0.5f) / (float)tw, (float)cols, cols);
+    if (sx <= last) return false;
+    last = sx;
+    words256[sx >> 5] |= 1u << (sx & 31);
+  }
+  last = -1;
+  for (int j = 0; j < th; ++j) {
+    const int sy = texel(((float)j + 0.5f) / (float)th, (float)rows, rows);
+    if (sy <= last) return false;
+    last = sy;
+    words256[64 + (sy >> 5)] |= 1u << (sy & 31);
+  }
+  for (int w = 1; w < 64; ++w) {
+    words256[128 + w] = words256[128 + w - 1] + (unsigned)__builtin_popcount(words256[w - 1]);
+    words256[192 + w] = words256[192 + w - 1] + (unsigned)__builtin_popcount(words256[64 + w - 1]);
+  }
+  return true;
 }
 
 // host: the column / row masks of the W/20 x H/20 NEAREST subsample (cols, rows <= 2048), 128 words

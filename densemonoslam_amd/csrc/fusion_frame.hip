@@ -254,6 +254,15 @@ using namespace dms;
 struct dms_fusion {
   dms_fusion_params p;
   dms_camera cam;
+  // dms_fusion_arm_frame_block: the frame block the NEXT frame's final resolve + fill-in pass writes (collaborative mode)
+  bool thumb_masks_ok = false;
+  struct ArmedBlock {
+    unsigned char* block = nullptr;
+    float* pose_dst = nullptr;
+    int* tick_dst = nullptr;
+    int tick = 0;
+  } armed, armed_now;  // armed: for the next frame; armed_now: taken over by the frame in progress (process_frame_begin)
+  bool armed_written = false;
   dms_model* model = nullptr;
   dms_model* own_model = nullptr;  // the map this context created; != model once it has joined another camera's map
   bool adopting = false;           // dms_fusion_import_camera: the next frame seeds the live state and touches no map
@@ -434,7 +443,7 @@ void layout(dms_fusion* f, Carve& c) {
   f->untr = c.take(N * 16);
   f->zbuf = (unsigned long long*)c.take(N * 8);
   f->zbuf2 = (unsigned long long*)c.take(N * 8);
-  f->tickets = (unsigned*)c.take(2048 + 512);  // + the subsample masks (128 words at word 512)
+  f->tickets = (unsigned*)c.take(2048 + 512 + 1024);  // + the subsample masks (128 words at word 512) + the thumbnail masks (256 words at word 640)
   f->state = (FrameState*)c.take(sizeof(FrameState));
 }
 
@@ -515,6 +524,17 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
       fa.dense_cnt = f->tickets;
       fa.sample_mask = f->tickets + 512;
       f->dense_by_counters = true;
+    }
+    if (mode == 1 && f->armed_now.block && f->thumb_masks_ok) {  // the frame's last kernel also writes the armed frame block
+      fa.thumb_block = f->armed_now.block;
+      fa.thumb_mask = f->tickets + 640;
+      fa.thumb_w = f->p.width / 8;
+      fa.thumb_h = f->p.height / 8;
+      fa.thumb_pose_src = f->state->cur.pose;
+      fa.thumb_pose_dst = f->armed_now.pose_dst;
+      fa.thumb_tick_dst = f->armed_now.tick_dst;
+      fa.thumb_tick = f->armed_now.tick;
+      f->armed_written = true;
     }
   }
   {
@@ -776,6 +796,9 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     unsigned masks[128];
     fill_sample_masks(p->width < 2048 ? p->width : 2048, p->height < 2048 ? p->height : 2048, masks);
     (void)hipMemcpy(f->tickets + 512, masks, sizeof(masks), hipMemcpyHostToDevice);
+    unsigned tm[256];
+    f->thumb_masks_ok = thumb_sample_masks(p->width, p->height, tm);
+    (void)hipMemcpy(f->tickets + 640, tm, sizeof(tm), hipMemcpyHostToDevice);
   }
   Pose16 I;
   for (int i = 0; i < 16; ++i) I.v[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -908,6 +931,9 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   DMS_REQUIRE(f && rgb_dev && depth_dev, "null argument");
   DMS_REQUIRE(rgb_channels == 3 || rgb_channels == 4, "rgb_channels must be 3 or 4");
   DMS_REQUIRE(!f->in_frame, "dms_fusion_process_frame_end has not been called for the previous frame");
+  f->armed_now = f->armed;  // (the arming holds for this frame only, whatever path it takes)
+  f->armed = dms_fusion::ArmedBlock();
+  f->armed_written = false;
   hipStream_t s = (hipStream_t)st;
   const int W = f->p.width, H = f->p.height, N = W * H;
   int rc;
@@ -1442,6 +1468,19 @@ int dms_fusion_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev
   DMS_CHECK_LAUNCH();
   return DMS_OK;
 }
+
+int dms_fusion_arm_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev, int* tick_dst_dev, int tick) {
+  DMS_REQUIRE(f && block_dev, "null argument");
+  DMS_REQUIRE(((uintptr_t)block_dev & 15) == 0, "thumbnail block must be 16-byte aligned");
+  DMS_REQUIRE(!f->in_frame, "between process_frame_begin and _end");
+  f->armed.block = (unsigned char*)block_dev;
+  f->armed.pose_dst = pose16_dst_dev;
+  f->armed.tick_dst = tick_dst_dev;
+  f->armed.tick = tick;
+  f->armed_written = false;
+  return DMS_OK;
+}
+int dms_fusion_frame_block_written(dms_fusion* f) { return f && f->armed_written ? 1 : 0; }
 
 int dms_fusion_get_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n) {
   DMS_REQUIRE(f && n && (rows7_host || max_rows == 0), "null argument");

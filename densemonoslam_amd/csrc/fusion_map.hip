@@ -1098,6 +1098,10 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
                                                        FillArgs fa) {
   if (FILL) {
     if (fa.mirror_words > 0 && blockIdx.x == 0 && (int)threadIdx.x < fa.mirror_words) fa.mirror_dst[threadIdx.x] = fa.mirror_src[threadIdx.x];
+    if (fa.thumb_block && blockIdx.x == 0) {  // the frame block's pose and tick ride along (k_thumbnails does the same)
+      if (fa.thumb_pose_dst && threadIdx.x < 16) fa.thumb_pose_dst[threadIdx.x] = fa.thumb_pose_src[threadIdx.x];
+      if (fa.thumb_tick_dst && threadIdx.x == 16) *fa.thumb_tick_dst = fa.thumb_tick;
+    }
   }
   // outputs are row-major (the tracker consumes them), the z-buffer is column-major: each wave takes an
   // 8 x 8 pixel tile, lanes running down the columns first, so that a z-buffer access touches 8 full
@@ -1124,7 +1128,12 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
         vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         normal[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         timeImg[p] = 0;
-        if (FILL) fill_pixel(fa, px, py, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_uchar4(0, 0, 0, 0));
+        if (FILL) {
+          float4 ov, on;
+          uchar4 oi;
+          fill_pixel_out(fa, px, py, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_uchar4(0, 0, 0, 0), ov, on, oi);
+          if (fa.thumb_block) fill_thumb(fa, px, py, ov, on, oi);
+        }
       }
       continue;
     }
@@ -1156,7 +1165,12 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
     unsigned tv = tz > 0.f ? (unsigned)f2i_rz(tz) : 0u;
     if (tv > 65535u) tv = 65535u;
     timeImg[p] = (unsigned short)tv;
-    if (FILL) fill_pixel(fa, px, py, o_v, o_n, o_img);
+    if (FILL) {
+      float4 ov, on;
+      uchar4 oi;
+      fill_pixel_out(fa, px, py, o_v, o_n, o_img, ov, on, oi);
+      if (fa.thumb_block) fill_thumb(fa, px, py, ov, on, oi);
+    }
   }
 }
 

@@ -331,6 +331,13 @@ int fill_args(const dms_predict_out* ex, const dms_image2d* depth, const dms_ima
   a.rows_blocks = 0;
   a.dense_cnt = nullptr;
   a.sample_mask = nullptr;
+  a.thumb_block = nullptr;
+  a.thumb_mask = nullptr;
+  a.thumb_w = a.thumb_h = 0;
+  a.thumb_pose_src = nullptr;
+  a.thumb_pose_dst = nullptr;
+  a.thumb_tick_dst = nullptr;
+  a.thumb_tick = 0;
   *res = a;
   return DMS_OK;
 }

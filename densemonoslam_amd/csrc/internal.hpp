@@ -4,12 +4,7 @@
 
 namespace dms {
 
-// The thumbnail block a camera publishes / a key frame stores (include/dmslam_fusion.h, dms_thumb_block_bytes): n = tw * th pixels,
-// [RGBA8 image, padded to a multiple of 16 bytes | RGBA32F vertex | RGBA32F normal] - the float4 sections stay 16-byte aligned for any
-// n (1241 x 376: 155 x 47 thumbnails).  For n a multiple of 4 this is the packed layout of rounds 3 - 4.
-__host__ __device__ inline size_t thumb_vertex_off(size_t n) { return (n * 4 + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t thumb_normal_off(size_t n) { return thumb_vertex_off(n) + n * 16; }
-__host__ __device__ inline size_t thumb_block_size(size_t n) { return thumb_vertex_off(n) + n * 32; }
+// (thumb_vertex_off / thumb_normal_off / thumb_block_size: common.hpp)
 
 struct TrackInitArgs;  // track_init.hpp
 

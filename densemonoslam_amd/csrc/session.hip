@@ -100,6 +100,7 @@ struct dms_session {
     hipEvent_t blocks = nullptr;  // this tick's frame blocks of the map's cameras are packed
   };
   std::vector<MapStream> map_streams;  // a small pool: the hosted maps take its streams in turn (more streams than hardware queues cost more than they overlap)
+  bool fused_block = true;  // the frame block written by the frame's last kernel (DMS_SESSION_FUSED_BLOCK=0: a launch of its own, the A/B switch)
   int n_map_streams = 2;  // (measured on one MI355X, 2 - 8 cameras: two beat one by 5 - 35 %, three and four are no better, four lose with 8 cameras)
   int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
   std::set<int> wake_ticks;        // ticks that run the full inter-map block: a search three ticks earlier hit
@@ -789,6 +790,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
     s->local_only = false;  // (a one-rank communicator still carries the collectives: the RCCL calls are exercised on a one-GPU box)
   }
   if (const char* e = getenv("DMS_SESSION_MAP_STREAMS")) s->n_map_streams = std::max(0, std::min(16, atoi(e)));
+  if (const char* e = getenv("DMS_SESSION_FUSED_BLOCK")) s->fused_block = atoi(e) != 0;
   s->n = p->n_cameras;
   s->W = p->camera.width;
   s->H = p->camera.height;
@@ -1020,6 +1022,10 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     dms_session::MapStream* ms = nullptr;
     if ((rc = stream_of_map(s, s->frame_of[c], hs, &fs, &ms))) return rc;
     cam_stream[c] = fs;
+    // The camera's frame block (thumbnails, pose, tick) is written by the frame's own last kernel (dms_fusion_arm_frame_block): no
+    // launch of its own behind the frame - unless the frame took a path without the fused fill-in.
+    unsigned char* blk = local + (size_t)(std::find(mine.begin(), mine.end(), c) - mine.begin()) * B;
+    if (!wake && s->fused_block && (rc = dms_fusion_arm_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick + 1))) return rc;
     if (src == s->rank) {
       const int i = read_index.at(c);
       if ((rc = dms_fusion_process_frame(cam.f, rgb_dev[i], 3, depth_dev[i], nullptr, 1.f, (dms_stream)fs))) return rc;
@@ -1034,9 +1040,9 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     }
     if (!wake) {
       cam.tick += 1;  // ElasticFusion.cpp:588-591 (the camera is never lost without relocalisation)
-      const size_t i = std::find(mine.begin(), mine.end(), c) - mine.begin();
-      unsigned char* blk = local + i * B;
-      if ((rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, (dms_stream)fs))) return rc;
+      if (!dms_fusion_frame_block_written(cam.f) &&
+          (rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, (dms_stream)fs)))
+        return rc;
       if (ms) used.insert(ms);
     }
   }
@@ -1070,6 +1076,10 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
       }
     s->ids_tick = (int)s->merges.size();
   }
+  bool any_search = false;
+  for (auto& kv : s->ferns)
+    for (int a = 0; a < s->n; ++a) any_search = any_search || s->frame_of[a] != kv.first;
+  const bool publish_mirrors = s->local_only && !any_search && (int)mine.size() == slots;
   for (int i = 0; i < slots; ++i) {
     unsigned char* blk = local + (size_t)i * B;
     if (i >= (int)mine.size()) {  // an empty slot: no good codes (the search passes it over); its id and hit rows stay
@@ -1079,8 +1089,12 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     const int c = mine[i];
     Camera& cam = s->cams.at(c);
     if (wake && (rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, st))) return rc;
-    if ((rc = dms_ferns_publish_block(s->ferns.at(s->frame_of[c]), blk, blk + T0 + kTailCodes, (int*)(blk + T0 + kTailGood),
-                                      (const float*)(blk + T0 + kTailPose), cam.tick, s->p.fern_threshold, st)))
+    // (a one-process session whose cameras all share one map searches nothing: the key-frame insertion's own launch then hands
+    // this block's tail to the host mirror - no launch is left behind the frame but this one)
+    void* mirror = publish_mirrors ? (void*)(s->ring[k & 1].host + (size_t)i * kTailHostBytes) : nullptr;
+    if ((rc = dms_ferns_publish_block_mirror(s->ferns.at(s->frame_of[c]), blk, blk + T0 + kTailCodes, (int*)(blk + T0 + kTailGood),
+                                             (const float*)(blk + T0 + kTailPose), cam.tick, s->p.fern_threshold, mirror, T0 + kTailGood,
+                                             mirror ? (size_t)kTailHostBytes : 0, st)))
       return rc;
   }
   const size_t per_rank = (size_t)slots * B;
@@ -1112,7 +1126,7 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
       }
       ++d;
     }
-    if (!mirrored && (rc = dms_copy_rows_async(e.host, kTailHostBytes, gathered + T0 + kTailGood, B, kTailHostBytes, (size_t)s->world * slots, st))) return rc;
+    if (!mirrored && !publish_mirrors && (rc = dms_copy_rows_async(e.host, kTailHostBytes, gathered + T0 + kTailGood, B, kTailHostBytes, (size_t)s->world * slots, st))) return rc;
   }
   if (hipEventRecord(e.done, hs) != hipSuccess) {
     set_error("dms_session_step_async: mirroring the gathered tails failed");

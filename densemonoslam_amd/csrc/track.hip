@@ -125,7 +125,11 @@ struct dms_odometry {
   int first_delay = -1;               // integer all-reduce: pause before the first read of the totals (DMS_AR_FIRST_DELAY; -1 = by grid size)
   // the later the last arrival can be after one's own, the longer the pause pays: ~0.4 us on the 150 / 200-block levels, next to
   // nothing on 38 blocks (measured: level 2 is best at 0 - 8 units, levels 1 and 0 at 12 - 20)
-  int first_delay_for(int nb) const { return first_delay >= 0 ? first_delay : (nb >= 96 ? 24 : 8); }
+  int first_delay_lvl[4] = {-1, -1, -1, -1};  // per stage (levels 0, 1, 2, SO3): DMS_AR_FIRST_DELAY_BY_LEVEL="l0,l1,l2,so3" (-1 = the rule)
+  int first_delay_for(int nb, int stage = -1) const {
+    if (stage >= 0 && stage < 4 && first_delay_lvl[stage] >= 0) return first_delay_lvl[stage];
+    return first_delay >= 0 ? first_delay : (nb >= 96 ? 24 : 8);
+  }
   int depth_bias = 0;                 // production rule (key "depth_exp_bias"): the frame step's depth cut-off raises the static exponents (canon::depth_exp_bias)
   int exp_bias = 0;                   // test hook (dms_odometry_debug_set "exp_bias"): added to the static exponents of a call's first reductions (negative: they do not fit and are repeated)
   long long* prof = nullptr;          // [16] phase clocks of the persistent kernels (profiling only)
@@ -1745,6 +1749,13 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     if (e && atoi(e) > 0 && atoi(e) < o->max_resident_blocks) o->max_resident_blocks = atoi(e);
     e = getenv("DMS_AR_FIRST_DELAY");  // units of 64 cycles before the first read of the totals; default: by grid size
     if (e && atoi(e) >= 0 && atoi(e) <= 1000) o->first_delay = atoi(e);
+    e = getenv("DMS_AR_FIRST_DELAY_BY_LEVEL");  // "l0,l1,l2,so3" in the same units (-1 keeps the rule for that stage): the per-level sweep
+    if (e) {
+      int v[4] = {-1, -1, -1, -1};
+      if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) >= 1)
+        for (int i = 0; i < 4; ++i)
+          if (v[i] >= 0 && v[i] <= 1000) o->first_delay_lvl[i] = v[i];
+    }
   }
   *out = o;
   return DMS_OK;
@@ -2207,7 +2218,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
       ex.nb_so3 = nbp;
       hipLaunchKernelGGL(k_so3_level, dim3(nbp + ex.gx * ex.gy), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbp), ex);
+                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbp, 3), ex);
       DMS_CHECK_LAUNCH();
     } else
     for (int i = 0; i < 10; ++i) {
@@ -2297,7 +2308,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       L.cx = o->cx;
       L.cy = o->cy;
       L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
-      L.first_delay = o->first_delay_for(pnb);
+      L.first_delay = o->first_delay_for(pnb, l);
       L.prof = (o->profiling && !o->profiling_level0_only) ? o->prof : nullptr;
       // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
       L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);

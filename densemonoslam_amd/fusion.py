@@ -103,6 +103,8 @@ lib.dms_fusion_pose_device.restype = _P
 lib.dms_model_sample_graph.argtypes = [_P, _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_int), _P]
 lib.dms_fusion_thumbnails.argtypes = [_P, _P, _P]
 lib.dms_fusion_frame_block.argtypes = [_P, _P, _P, _P, C.c_int, _P]
+lib.dms_fusion_arm_frame_block.argtypes = [_P, _P, _P, _P, C.c_int]
+lib.dms_fusion_frame_block_written.argtypes = [_P]
 lib.dms_fusion_get_image.argtypes = [_P, _I, _I2]
 lib.dms_fusion_process_frame_begin.argtypes = [_P, _P, _I, _P, C.POINTER(C.c_float), _F, _P]
 lib.dms_fusion_fetch_loop.argtypes = [_P, C.POINTER(FrameResult), _P]
@@ -594,6 +596,14 @@ class ElasticFusion:
         """thumbnails + pose (16 floats) + tick of this frame into device memory, one launch"""
         check(lib.dms_fusion_frame_block(self.h, C.c_void_p(block_ptr), C.c_void_p(pose_ptr), C.c_void_p(tick_ptr), int(tick), stream),
               "dms_fusion_frame_block")
+
+    def armFrameBlock(self, block_ptr, pose_ptr, tick_ptr, tick):
+        """the same block written by the NEXT frame's own last kernel (no launch of its own); frameBlockWritten() tells whether it was"""
+        check(lib.dms_fusion_arm_frame_block(self.h, C.c_void_p(block_ptr), C.c_void_p(pose_ptr), C.c_void_p(tick_ptr), int(tick)),
+              "dms_fusion_arm_frame_block")
+
+    def frameBlockWritten(self):
+        return bool(lib.dms_fusion_frame_block_written(self.h))
 
     def loopConstraints(self):
         """Surface constraints of the last fetched frame's loop candidate: n x 7 float32

@@ -74,6 +74,12 @@ int dms_ferns_encode_thumbs(dms_ferns* f, const void* thumb_block_dev, unsigned 
  * of being staged — it must stay unchanged until the work enqueued here has run. */
 int dms_ferns_publish_block(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, const float* pose16_dev,
                             int srcTime, float threshold, dms_stream s);
+/* The same; the launch also copies mirror_bytes bytes of the block from byte offset mirror_offset on - as they are AFTER the encoding
+ * (codes_dev / good_dev may lie inside that range) - to `mirror`, memory the host can read (hipHostMalloc): a session whose cameras
+ * all share one map has no descriptor search whose launch could carry the per-tick metadata to the host (dms_ferns_search_blocks_hd_mirror).
+ * Offsets and sizes in whole dwords. */
+int dms_ferns_publish_block_mirror(dms_ferns* f, const void* thumb_block_dev, unsigned char* codes_dev, int* good_dev, const float* pose16_dev,
+                                   int srcTime, float threshold, void* mirror, size_t mirror_offset, size_t mirror_bytes, dms_stream s);
 
 typedef struct dms_fern_match {
   int closest;            /* Ferns::lastClosest: accepted frame id or -1 */

@@ -408,6 +408,14 @@ void dms_thumb_block_offsets(int width, int height, size_t* vertex_offset, size_
  * tick_dst_dev (either may be NULL): everything of a published frame block that must be taken before the next frame
  * starts, so that the rest of the exchange (encoding, key-frame database, all-gather, search) can run on a side stream. */
 int dms_fusion_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev, int* tick_dst_dev, int tick, dms_stream s);
+/* The same block WITHOUT a launch of its own (round 6): armed before a frame, it is written by the frame step's last kernel - the
+ * resolve + fill-in pass of the final prediction (ElasticFusion.cpp:586, :704-712), whose threads hold the filled image / vertex /
+ * normal of their pixel: the ones that own a thumbnail sample store it, block 0 copies the pose and the tick.  Same bytes as
+ * dms_fusion_frame_block after the frame.  The arming holds for the NEXT dms_fusion_process_frame / _end only;
+ * dms_fusion_frame_block_written(f) tells whether that frame did write it (1) or ran a path without the fused fill-in (0: fused_fill_in
+ * off, images wider than 2048, the map's first frame) - the caller then calls dms_fusion_frame_block as before. */
+int dms_fusion_arm_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev, int* tick_dst_dev, int tick);
+int dms_fusion_frame_block_written(dms_fusion* f);
 
 /* Surface constraints of the last fetched frame's loop candidate, in the reference's sampling
  * order (columns outer, rows inner, ElasticFusion.cpp:446-447): per row

@@ -8,6 +8,8 @@ the CPU, in the container that holds /root/reference (no GPU involved):
 
     bash oracle/ref_build.sh
     python tests/golden/make_ref_glsl_golden.py            (writes tests/golden/ref_glsl.npz; commit it)
+    python tests/golden/make_ref_glsl_golden.py --full        (640 x 480: tests/golden/ref_glsl_full.npz, hashes + samples)
+    python tests/golden/make_ref_glsl_golden.py --full-kitti  (1241 x 376, KITTI intrinsics: tests/golden/ref_glsl_kitti.npz)
 
 tests/test_ref_gl_pin_cpu.py then holds the CPU restatement (oracle/orc_fusion.c) to these numbers on every round;
 tests/test_ref_gl_pin_gpu.py holds the product's kernels to them on the MI355X.
@@ -54,10 +56,10 @@ def main(path):
     print("surfels emitted by vertex_feedback with LINEAR / NEAREST filtering of the raw depth:", n_lin, n_near)
 
 
-def main_full(path):
-    """640 x 480 (tests/ref_cases_gl.py "full-size case"): hashes of the restatement's free run (the feed) + samples of what the
-    reference's shaders return stage by stage on that feed + the whole-array comparison report of this recording run."""
-    cg.configure(**cg.FULL)
+def main_full(path, case="640x480"):
+    """640 x 480 / 1241 x 376 (tests/ref_cases_gl.py "full-size case"): hashes of the restatement's free run (the feed) + samples of what
+    the reference's shaders return stage by stage on that feed + the whole-array comparison report of this recording run."""
+    cg.configure(**cg.FULL_CASES[case][0])
     inp = cg.inputs(orc, orc_pipeline, synth)
     orc_out = cg.chain(cg.OrcOps(orc), inp, orc.SURFEL_DTYPE)
     gl_out = cg.chain(cg.GlOps(ref_gl), inp, orc.SURFEL_DTYPE, feed=orc_out)
@@ -78,7 +80,8 @@ def main_full(path):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--full":
-        main_full(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golden", "ref_glsl_full.npz"))
+    if len(sys.argv) > 1 and sys.argv[1] in ("--full", "--full-kitti"):
+        case = "640x480" if sys.argv[1] == "--full" else "1241x376"
+        main_full(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golden", cg.FULL_CASES[case][1]), case)
     else:
         main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "ref_glsl.npz"))

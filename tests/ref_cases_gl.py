@@ -488,6 +488,9 @@ def compare_resize(name, got, ref, src):
 # compare_sampled applies compare_all's rules to those elements.
 N_SAMPLES = 2048
 FULL = dict(W=640, H=480, K=(528.0, 528.0, 320.0, 240.0), N_WARM=26, STRIDE=3)
+# BASELINE config 4's size with KITTI's intrinsics (KITTI_RGBD_template_params.yaml): 655 955 surfels after 26 frames
+KITTI = dict(W=1241, H=376, K=(718.856, 718.856, 607.19, 185.22), N_WARM=26, STRIDE=3)
+FULL_CASES = {"640x480": (FULL, "ref_glsl_full.npz"), "1241x376": (KITTI, "ref_glsl_kitti.npz")}
 _PIXEL_STAGES = ("bilateral", "metric", "metric_f", "bilateral0", "dsyn", "fill_vertex", "fill_normal", "fill_vertex_pass", "fill_image", "fill_image_pass")
 _MAPS = {"idx": ("index", "vertConf", "colorTime", "normRad"), "idx2": ("index", "vertConf", "colorTime", "normRad"),
          "act": ("image", "vertex", "normal", "time"), "ina": ("image", "vertex", "normal", "time"), "low": ("image", "vertex", "normal", "time")}

@@ -1703,3 +1703,35 @@ def test_runtime_setters_and_exports_match_the_oracle(fus, orc, synth, tmp_path)
     g2.setOption("pyramid", 0)
     g2.close()
     g.close()
+
+
+@pytest.mark.parametrize("size", ["320x240", "640x480", "1241x376"])
+def test_frame_block_armed_ahead_equals_the_separate_launch(size):
+    """dms_fusion_arm_frame_block: the frame block of collaborative mode (W/8 x H/8 NEAREST thumbnails of the FILLED image / vertex / normal,
+    pose, tick) written by the frame's own last kernel - the final prediction's resolve + fill-in pass - instead of k_thumbnails behind
+    the frame.  Same bytes, frame after frame, from the map's first frame on; 155 x 47 thumbnails at 1241 x 376 (no multiple of 8: the
+    sample columns are not evenly spaced, and the block's image section is padded).  The arming holds for one frame."""
+    from densemonoslam_amd import capi, collab, fusion, synth
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    W2, H2, K2 = {"320x240": (320, 240, (264.0, 264.0, 160.0, 120.0)), "640x480": (640, 480, synth.K_640), "1241x376": (1241, 376, synth.K_KITTI)}[size]
+    ef = fusion.ElasticFusion(W2, H2, K2, model_capacity=3_000_000)
+    T = collab.thumbnail_bytes(W2, H2)
+    a, b = capi.DeviceBuffer(T + 128), capi.DeviceBuffer(T + 128)
+    for k in range(5):
+        d, rgb, _ = synth.frame(3 * k, width=W2, height=H2, K=K2, noise=True)
+        a.upload(np.full(T + 128, 0xAB, np.uint8))
+        b.upload(np.full(T + 128, 0xCD, np.uint8))
+        if k != 3:
+            ef.armFrameBlock(a.ptr, a.ptr + T, a.ptr + T + 64, 100 + k)
+        r = ef.processFrame(rgb, d)
+        ef.frameBlock(b.ptr, b.ptr + T, b.ptr + T + 64, 100 + k)
+        got, want = a.download(np.uint8, (T + 128,)), b.download(np.uint8, (T + 128,))
+        if k == 3:  # not armed for this frame: nothing written, and the arming of frame 2 did not linger
+            assert not ef.frameBlockWritten() and (got == 0xAB).all()
+            continue
+        assert ef.frameBlockWritten(), k
+        assert np.array_equal(got[:T + 68], want[:T + 68]), (size, k, int((got[:T + 68] != want[:T + 68]).sum()))
+        assert (got[T + 68:] == 0xAB).all()
+        assert (got[T:T + 64].view(np.float32) == np.array(r.pose, np.float32).reshape(16)).all() and got[T + 64:T + 68].view(np.int32)[0] == 100 + k
+    ef.close()

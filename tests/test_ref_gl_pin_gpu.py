@@ -127,21 +127,26 @@ def test_product_equals_the_references_shaders(orc):
     print(rep)
 
 
-def test_product_equals_the_references_shaders_at_640x480(orc):
-    """The same pin at a BASELINE size: 640 x 480, a map of 437 750 surfels (the fuse's update pass wraps TEXTURE_DIMENSION = 5700 many
-    times).  The fixture keeps hashes and samples (tests/ref_cases_gl.py "full-size case"): every stage of the product is fed the
-    restatement's outputs - whose hashes the fixture pins - exactly as the reference's shaders were when the samples were recorded, and
-    is held (i) to those samples by compare_all's rules and (ii) to the restatement's own output of the stage, bit for bit."""
+@pytest.mark.parametrize("case", ["640x480", "1241x376"])
+def test_product_equals_the_references_shaders_at_full_size(orc, case):
+    """The same pin at the BASELINE sizes: 640 x 480 (a map of 437 750 surfels) and - round 6 - 1241 x 376 with KITTI's intrinsics (655 955
+    surfels); the fuse's update pass wraps TEXTURE_DIMENSION = 5700 many times.  The fixtures keep hashes and samples
+    (tests/ref_cases_gl.py "full-size case"): every stage of the product is fed the restatement's outputs - whose hashes the fixture
+    pins - exactly as the reference's shaders were when the samples were recorded, and is held (i) to those samples by compare_all's
+    rules and (ii) to the restatement's own output of the stage, bit for bit."""
+    import os
+
     from densemonoslam_amd import capi, fusion, synth
     from oracle import orc_pipeline
-    from tests.test_ref_gl_pin_cpu import full_case
+    from tests.test_ref_gl_pin_cpu import GOLDEN, full_case
 
     assert capi.device_count() >= 1, "no MI355X visible"
-    old = cg.configure(**cg.FULL)
+    cfg, name = cg.FULL_CASES[case]
+    old = cg.configure(**cfg)
     try:
-        fx, inp, orc_out = full_case(orc, orc_pipeline, synth)
+        fx, inp, orc_out = full_case(orc, orc_pipeline, synth, os.path.join(os.path.dirname(GOLDEN), name))
         gl = {k[:-4]: fx[k] for k in fx.files if k.endswith("__gl")}
-        out = cg.chain(HipOps(fusion, orc.SURFEL_DTYPE, capacity=800_000), inp, orc.SURFEL_DTYPE, feed=orc_out)
+        out = cg.chain(HipOps(fusion, orc.SURFEL_DTYPE, capacity=1_400_000), inp, orc.SURFEL_DTYPE, feed=orc_out)
         rep = cg.compare_sampled(out, gl, inp, orc_out["fused"], skip=("emitted",))
         assert rep["fused"]["records"] == cg.N_SAMPLES and int(gl["fused__n"]) > 400_000
         exact = [k for k in out if k != "emitted" and np.asarray(out[k]).tobytes() == np.asarray(orc_out[k]).tobytes()]
