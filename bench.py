@@ -872,7 +872,7 @@ def main():
                 ms, cnt = ef.kernel_time(n)
                 if cnt:
                     stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
-            for n in ("so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
+            for n in ("track_coarse", "so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
                 ms, cnt = C.c_double(0), C.c_int(0)
                 capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
                 if cnt.value:

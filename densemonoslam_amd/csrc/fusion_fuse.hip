@@ -775,7 +775,9 @@ int model_clean(dms_model* m, const dms_pose_block* pose, int time, int timeIdx,
   hipLaunchKernelGGL(k_clean_flags, dim3(nb), dim3(256), 0, s, a, src, m->cap, m->d_count, m->slot_pos, m->slot_col, m->slot_nrm,
                      m->slot_flag, m->keep, m->block_count, suffix ? m->clean_first : (unsigned*)nullptr);
   DMS_CHECK_LAUNCH();
-  const bool inline_scan = nb <= 2048 && !suffix;  // suffix mode needs the block offsets in memory
+  // (every scatter block sums the counts before it itself: nb^2 / 2 count reads from L2 against one launch; DMS_CLEAN_INLINE_SCAN_MAX)
+  static const int inline_max = getenv("DMS_CLEAN_INLINE_SCAN_MAX") ? atoi(getenv("DMS_CLEAN_INLINE_SCAN_MAX")) : 2048;
+  const bool inline_scan = nb <= inline_max && !suffix;  // suffix mode needs the block offsets in memory
   if (!inline_scan) {
     // (limit = the old count: only complete blocks of map surfels can stay in place)
     hipLaunchKernelGGL(k_scan_blocks_par, dim3((nb + 1023) / 1024), dim3(1024), 0, s, m->block_count, m->block_offset, nb, m->d_count_alt,

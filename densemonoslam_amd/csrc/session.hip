@@ -562,7 +562,8 @@ int stream_of_map(dms_session* s, int frame, hipStream_t caller, hipStream_t* ou
   *ms_out = nullptr;
   // One camera in a one-rank session: nothing to overlap (measured 2 % slower across two streams).  One camera per rank of several:
   // the all-gather is a real collective whose latency and whose wait for the slowest rank belong beside the next frame, not in front of it.
-  if (s->n_map_streams <= 0 || (s->cams.size() < 2 && s->world == 1)) return DMS_OK;
+  // (a one-rank session WITH a transport - the one-GPU rehearsal of the multi-rank loop - takes the multi-rank arrangement)
+  if (s->n_map_streams <= 0 || (s->cams.size() < 2 && s->world == 1 && s->local_only)) return DMS_OK;
   for (int c = 0; c < s->n; ++c)
     if (s->frame_of[c] == frame && c % s->world != s->rank) return DMS_OK;
   if (s->map_streams.empty()) s->map_streams.resize(s->n_map_streams);

@@ -125,6 +125,9 @@ struct dms_odometry {
   int first_delay = -1;               // integer all-reduce: pause before the first read of the totals (DMS_AR_FIRST_DELAY; -1 = by grid size)
   // the later the last arrival can be after one's own, the longer the pause pays: ~0.4 us on the 150 / 200-block levels, next to
   // nothing on 38 blocks (measured: level 2 is best at 0 - 8 units, levels 1 and 0 at 12 - 20)
+  bool fuse_coarse = false;           // SO3 + level 2 + level 1 in one resident launch (k_track_coarse; DMS_TRACK_FUSE=1).  Built and bit-identical, but SLOWER on the MI355X: off
+  unsigned* rider_cnt = nullptr;      // device: rider blocks of k_track_coarse launches that have finished (runs over the life of the handle)
+  unsigned rider_issued = 0;          // host: rider blocks enqueued so far
   int first_delay_lvl[4] = {-1, -1, -1, -1};  // per stage (levels 0, 1, 2, SO3): DMS_AR_FIRST_DELAY_BY_LEVEL="l0,l1,l2,so3" (-1 = the rule)
   int first_delay_for(int nb, int stage = -1) const {
     if (stage >= 0 && stage < 4 && first_delay_lvl[stage] >= 0) return first_delay_lvl[stage];
@@ -922,8 +925,12 @@ __device__ __forceinline__ constexpr unsigned so3_diag_mask() {
 // EXIT: leave the level after an iteration without any correspondence (below).  A template parameter because the
 // mere presence of that exit costs the frame-to-model tracker ~1 % (codegen of the resident loop); the frame step
 // instantiates it for the model-to-model pass only.
-template <bool ICP, bool RGB, int P, bool EXIT>
-__global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
+// The level as a stage: `st` is the call's state block in HBM (the sticky timeout flag lives there), `sv` the state the stage reads
+// at its start and leaves at its end - the same block for the stand-alone kernel (block 0 writes it back for the next launch), the
+// block's own LDS copy when several stages run in one launch (k_track_coarse: FUSED; every block holds the same bits, so every
+// block keeps its copy up to date and nothing crosses blocks between two stages).  nb = blocks taking part in the all-reduces.
+template <bool ICP, bool RGB, int P, bool EXIT, bool FUSED>
+__device__ __forceinline__ void gn_level_body(TrackState* st, TrackState* sv, const GnArgs& a, const LevelArgs& L, const int nb) {
   constexpr bool kFma = kTrackerFma;
   __shared__ sc::GnLocal s;
   __shared__ int s_redi[kPWaves][2];
@@ -941,7 +948,6 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   __shared__ int s_retries;
   __shared__ sc::KPre s_k[2];
   const int tid = threadIdx.x;
-  const int nb = gridDim.x;
   int eb_icp = 0, eb_rgb = 0;  // wave 0: bound exponents of the values this lane adds (lanes 0-28) / polls (lane k: ICP k, lane 32 + k: photometric k)
   // optional phase clock (block 0, thread 0): wall_clock64 ticks (10 ns) summed per phase into L.prof
   // (accumulated in LDS and flushed once at the end: a global read-modify-write per phase would
@@ -963,27 +969,27 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   if (tid == 0) {
     s_none = 0;
     s_retries = 0;
-    s_done = st->level_done[L.level];
-    for (int i = 0; i < 16; ++i) s.resultRt[i] = st->resultRt[i];
+    s_done = sv->level_done[L.level];
+    for (int i = 0; i < 16; ++i) s.resultRt[i] = sv->resultRt[i];
     for (int i = 0; i < 9; ++i) {
-      s.Rprev[i] = st->Rprev[i];
-      s.Rprev_inv[i] = st->Rprev_inv[i];
-      s.Rcurr[i] = st->Rcurr[i];
-      s.krkinv[i] = st->krkinv[i];
+      s.Rprev[i] = sv->Rprev[i];
+      s.Rprev_inv[i] = sv->Rprev_inv[i];
+      s.Rcurr[i] = sv->Rcurr[i];
+      s.krkinv[i] = sv->krkinv[i];
     }
     for (int i = 0; i < 3; ++i) {
-      s.tprev[i] = st->tprev[i];
-      s.tcurr[i] = st->tcurr[i];
-      s.kt[i] = st->kt[i];
+      s.tprev[i] = sv->tprev[i];
+      s.tcurr[i] = sv->tcurr[i];
+      s.kt[i] = sv->kt[i];
     }
-    s.lastRGBError = st->lastRGBError;
-    s.lastRGBCount = st->lastRGBCount;
-    s.lastICPError = st->lastICPError;
-    s.lastICPCount = st->lastICPCount;
-    s.iters_run = st->iters_run[L.level];
-    for (int i = 0; i < 36; ++i) s.lastA[i] = st->lastA[i];
-    for (int i = 0; i < 6; ++i) s.lastb[i] = st->lastb[i];
-    level_exponents(st, a, true, s_E[0], s_E[1]);
+    s.lastRGBError = sv->lastRGBError;
+    s.lastRGBCount = sv->lastRGBCount;
+    s.lastICPError = sv->lastICPError;
+    s.lastICPCount = sv->lastICPCount;
+    s.iters_run = sv->iters_run[L.level];
+    for (int i = 0; i < 36; ++i) s.lastA[i] = sv->lastA[i];
+    for (int i = 0; i < 6; ++i) s.lastb[i] = sv->lastb[i];
+    level_exponents(sv, a, true, s_E[0], s_E[1]);
     // camera matrices of this level and of the next one that runs, for the scalar section (thread 0 uses them)
     // (kept in LDS: 24 more live registers per lane would spill the 256-register pixel loop)
     s_k[0] = sc::kpre_of(L.fx, L.fy, L.cx, L.cy, L.level);
@@ -999,7 +1005,10 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     idx[p] = (blockIdx.x * P + p) * kPB + tid;
-    const int ic = idx[p] < N ? idx[p] : 0;  // threads past the end shadow pixel 0 and are masked
+    // threads past the end shadow a pixel of the image and are masked.  (Not pixel 0 for all of them: in k_track_coarse whole blocks lie
+    // past a small level's image, and tens of thousands of lanes loading one address queue up on its cache line - measured: +5 us
+    // at the start of level 2 and +0.7 us per pass.)
+    const int ic = idx[p] < N ? idx[p] : idx[p] % N;
     py[p] = ic / a.cols;
     px[p] = ic - py[p] * a.cols;
     if (ICP) io[p] = icp_load_own(a.maps, px[p], py[p], a.rows);
@@ -1288,31 +1297,31 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
 
   // ---- block 0 hands the state to the next kernel on the stream ----
   __syncthreads();
-  if (blockIdx.x == 0 && tid == 0) {
-    if (ended) st->level_done[L.level] = 1;
-    for (int i = 0; i < 16; ++i) st->resultRt[i] = s.resultRt[i];
+  if ((FUSED || blockIdx.x == 0) && tid == 0) {
+    if (ended) sv->level_done[L.level] = 1;
+    for (int i = 0; i < 16; ++i) sv->resultRt[i] = s.resultRt[i];
     for (int i = 0; i < 9; ++i) {
-      st->Rcurr[i] = s.Rcurr[i];
-      st->krkinv[i] = s.krkinv[i];
+      sv->Rcurr[i] = s.Rcurr[i];
+      sv->krkinv[i] = s.krkinv[i];
     }
     for (int i = 0; i < 3; ++i) {
-      st->tcurr[i] = s.tcurr[i];
-      st->kt[i] = s.kt[i];
+      sv->tcurr[i] = s.tcurr[i];
+      sv->kt[i] = s.kt[i];
     }
-    st->lastRGBError = s.lastRGBError;
-    st->lastRGBCount = s.lastRGBCount;
-    st->lastICPError = s.lastICPError;
-    st->lastICPCount = s.lastICPCount;
-    st->iters_run[L.level] = s.iters_run;
-    for (int i = 0; i < 36; ++i) st->lastA[i] = s.lastA[i];
-    for (int i = 0; i < 6; ++i) st->lastb[i] = s.lastb[i];
+    sv->lastRGBError = s.lastRGBError;
+    sv->lastRGBCount = s.lastRGBCount;
+    sv->lastICPError = s.lastICPError;
+    sv->lastICPCount = s.lastICPCount;
+    sv->iters_run[L.level] = s.iters_run;
+    for (int i = 0; i < 36; ++i) sv->lastA[i] = s.lastA[i];
+    for (int i = 0; i < 6; ++i) sv->lastb[i] = s.lastb[i];
     for (int c2 = 0; c2 < 7; ++c2) {
-      st->E_icp[c2] = s_E[0][c2];
-      st->E_rgb[c2] = s_E[1][c2];
+      sv->E_icp[c2] = s_E[0][c2];
+      sv->E_rgb[c2] = s_E[1][c2];
     }
-    st->have_E = 1;
-    st->canon_retries += s_retries;
-    if (L.finalize) {  // == k_track_finalize, from the values this thread holds
+    sv->have_E = 1;
+    sv->canon_retries += s_retries;
+    if (L.finalize && blockIdx.x == 0) {  // == k_track_finalize, from the values this thread holds
       float tc[3], Rc[9];
       for (int i = 0; i < 3; ++i) tc[i] = s.tcurr[i];
       for (int i = 0; i < 9; ++i) Rc[i] = s.Rcurr[i];
@@ -1322,12 +1331,12 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
       // that are not the sums of the image: the prior pose is kept and the frame step fuses nothing
       const bool timed_out = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
       if (timed_out || (L.fin_rgb && (double)n > 0.3)) {  // RGBDOdometry.cpp:589-593
-        for (int i = 0; i < 9; ++i) Rc[i] = st->Rcurr[i] = s.Rprev[i];
-        for (int i = 0; i < 3; ++i) tc[i] = st->tcurr[i] = s.tprev[i];
-        if (!timed_out) st->rejected_jump = 1;
+        for (int i = 0; i < 9; ++i) Rc[i] = sv->Rcurr[i] = s.Rprev[i];
+        for (int i = 0; i < 3; ++i) tc[i] = sv->tcurr[i] = s.tprev[i];
+        if (!timed_out) sv->rejected_jump = 1;
       }
-      for (int i = 0; i < 3; ++i) st->out_trans[i] = tc[i];
-      for (int i = 0; i < 9; ++i) st->out_rot[i] = Rc[i];
+      for (int i = 0; i < 3; ++i) sv->out_trans[i] = tc[i];
+      for (int i = 0; i < 9; ++i) sv->out_rot[i] = Rc[i];
       // The frame step's pose block IS context.currPose(): the reference assigns the tracker's result to its top three rows only
       // (`currPose.topRightCorner(3, 1) = trans; currPose.topLeftCorner(3, 3) = rot`, ElasticFusion.cpp:246-247), so a bottom row
       // that is not exactly (0 0 0 1) - after a map merge, currPose = relativeTransform * currPose with relativeTransform =
@@ -1366,6 +1375,11 @@ __global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, Leve
   }
 }
 
+template <bool ICP, bool RGB, int P, bool EXIT>
+__global__ __launch_bounds__(kPB) void k_gn_level(TrackState* st, GnArgs a, LevelArgs L) {
+  gn_level_body<ICP, RGB, P, EXIT, false>(st, st, a, L, (int)gridDim.x);
+}
+
 // Independent work riding on the SO3 launch when the call's set-up was folded into the model pyramid kernel (frame step):
 // the pyramid's deferred last step in gx * gy blocks of 64 x 8 pixels behind the nb_so3 resident blocks (gx = 0: none),
 // and the re-arming of the frame step's dense counters.
@@ -1383,18 +1397,27 @@ struct So3Extra {
 // with one all-reduce per iteration.  The state block is copied into LDS
 // and the unchanged scalar code runs on the copy; block 0 writes it back at the end.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
-                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows,
-                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias, int first_delay, So3Extra ex) {
-  // Blocks past the resident grid carry independent work of the same call: the model pyramid's last step, whose output the
-  // first Gauss-Newton level reads (not this kernel) — see So3Extra.  They take no part in the all-reduce.
-  if ((int)blockIdx.x >= ex.nb_so3) {
-    const int c = (int)blockIdx.x - ex.nb_so3, by = c / ex.gx, bx = c - by * ex.gx;
-    model_pyr_step_pixel(bx * 64 + (int)(threadIdx.x & 63), by * (kPB / 64) + (int)(threadIdx.x >> 6), ex.dsrc, ex.ddst, ex.isrc, ex.idst);
-    return;
-  }
-  if (ex.zero16 && blockIdx.x == 0 && threadIdx.x < 16) ex.zero16[threadIdx.x * 16] = 0u;  // the frame step's dense counters (read before this launch)
-  __shared__ TrackState s;
+struct So3Args {
+  const unsigned char* lastImage;
+  size_t last_pitch;
+  const unsigned char* nextImage;
+  size_t next_pitch;
+  int cols, rows;
+  unsigned long long* ar;
+  SolveCam cam;
+  int first_gn_level, max_iter, exp_bias, first_delay;
+};
+
+// The SO3 stage: `s` is the block's LDS copy of the call's state (every block holds the same bits); stand-alone, it is loaded from
+// `st` at the start and block 0 writes it back at the end; inside k_track_coarse (FUSED) it simply stays where it is for the next stage.
+template <bool FUSED>
+__device__ __forceinline__ void so3_body(TrackState* st, TrackState& s, const So3Args& q, const int nb) {
+  const unsigned char* lastImage = q.lastImage;
+  const unsigned char* nextImage = q.nextImage;
+  const size_t last_pitch = q.last_pitch, next_pitch = q.next_pitch;
+  const int cols = q.cols, rows = q.rows, first_gn_level = q.first_gn_level, max_iter = q.max_iter, exp_bias = q.exp_bias, first_delay = q.first_delay;
+  unsigned long long* ar = q.ar;
+  const SolveCam cam = q.cam;
   __shared__ int s_viol;
   __shared__ int s_E[4];
   __shared__ double s_bias[2][32];
@@ -1402,8 +1425,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   __shared__ float s_sums[32];
   int eb_mine = 0;  // wave 0, lane k < 11: bound exponent of value k
   const int tid = threadIdx.x;
-  const int nb = ex.nb_so3;
-  {
+  if (!FUSED) {
     const int* src = reinterpret_cast<const int*>(st);
     int* dst = reinterpret_cast<int*>(&s);
     for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += kPB) dst[i] = src[i];
@@ -1423,7 +1445,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
   const int N = cols * rows;
   const int i = blockIdx.x * kPB + tid;
   const bool live = i < N;
-  const int ic = live ? i : 0;
+  const int ic = live ? i : i % N;  // (masked lanes shadow distinct pixels: see gn_level_body)
   const int y = ic / cols, x = ic - y * cols;
   int pool_used = 0, retries = 0;
   bool on_pool = false, failed = false;
@@ -1487,7 +1509,7 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
     ++it;
   }
   __syncthreads();
-  if (blockIdx.x == 0) {
+  if (FUSED || blockIdx.x == 0) {
     if (tid == 0) {
       if (failed) __hip_atomic_store(&st->sync_timeout, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s.sync_timeout = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1495,10 +1517,97 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
       if (failed && !s.so3_done) {  // the Gauss-Newton levels still need their projection parameters
         s.so3_done = 1;
         double Rt[16];
-        for (int q = 0; q < 16; ++q) Rt[q] = s.resultRt[q];
+        for (int q2 = 0; q2 < 16; ++q2) Rt[q2] = s.resultRt[q2];
         sc::gn_params(Rt, sc::kpre_of(cam.fx, cam.fy, cam.cx, cam.cy, first_gn_level), s.krkinv, s.kt);
       }
     }
+    __syncthreads();
+    if (!FUSED) {
+      const int* src = reinterpret_cast<const int*>(&s);
+      int* dst = reinterpret_cast<int*>(st);
+      for (int k = tid; k < (int)(sizeof(TrackState) / 4); k += kPB) dst[k] = src[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigned char* lastImage, size_t last_pitch,
+                                                   const unsigned char* nextImage, size_t next_pitch, int cols, int rows,
+                                                   unsigned long long* ar, SolveCam cam, int first_gn_level, int max_iter, int exp_bias, int first_delay, So3Extra ex) {
+  // Blocks past the resident grid carry independent work of the same call: the model pyramid's last step, whose output the
+  // first Gauss-Newton level reads (not this kernel) — see So3Extra.  They take no part in the all-reduce.
+  if ((int)blockIdx.x >= ex.nb_so3) {
+    const int c = (int)blockIdx.x - ex.nb_so3, by = c / ex.gx, bx = c - by * ex.gx;
+    model_pyr_step_pixel(bx * 64 + (int)(threadIdx.x & 63), by * (kPB / 64) + (int)(threadIdx.x >> 6), ex.dsrc, ex.ddst, ex.isrc, ex.idst);
+    return;
+  }
+  if (ex.zero16 && blockIdx.x == 0 && threadIdx.x < 16) ex.zero16[threadIdx.x * 16] = 0u;  // the frame step's dense counters (read before this launch)
+  __shared__ TrackState s;
+  const So3Args q = {lastImage, last_pitch, nextImage, next_pitch, cols, rows, ar, cam, first_gn_level, max_iter, exp_bias, first_delay};
+  so3_body<false>(st, s, q, ex.nb_so3);
+}
+
+// ---------------------------------------------------------------------------------------
+// The coarse half of a call in ONE resident launch (round 6): SO3 pre-alignment, level 2, level 1.  Every dependent launch on a
+// stream costs ~3.5 us of dispatch on this device plus the stage's own hand-off through HBM (state written back by block 0, reloaded
+// by every block of the next launch, ~2 us) - 92 us of launches for a quarter of level 0's pixel work.  The stages need nothing from
+// each other but the state block, and every block already holds it bit for bit (each block solves on identical totals): so the
+// stages simply follow one another inside one launch, the state stays in LDS, and the blocks never meet between two stages (each
+// stage's all-reduces have word sets of their own).  Grid = the largest stage's (level 1); a stage with fewer pixels leaves the
+// blocks past its image empty-handed - they still arrive in its all-reduces (with zeros).  Level 0 keeps its launch (three pixels
+// per thread on a larger grid).  The rider blocks of the SO3 launch (So3Extra: the model pyramid's deferred last step, which LEVEL 2
+// reads) are riders of this launch: they release their output and count themselves in, and the resident blocks wait for that count
+// between the SO3 stage and level 2 (long complete by then: a formality with a bounded spin).
+struct CoarseArgs {
+  So3Args so3;
+  GnArgs a2, a1;
+  LevelArgs L2, L1;
+  int run_so3, run_l2, run_l1;
+  unsigned* rider_cnt;     // counts rider blocks that have finished, over the life of the handle
+  unsigned rider_target;   // its value once this launch's riders are done
+};
+
+template <bool ICP, bool RGB, int P1, bool EXIT>
+__global__ __launch_bounds__(kPB) void k_track_coarse(TrackState* st, CoarseArgs F, So3Extra ex) {
+  if ((int)blockIdx.x >= ex.nb_so3) {
+    const int c = (int)blockIdx.x - ex.nb_so3, by = c / ex.gx, bx = c - by * ex.gx;
+    model_pyr_step_pixel(bx * 64 + (int)(threadIdx.x & 63), by * (kPB / 64) + (int)(threadIdx.x >> 6), ex.dsrc, ex.ddst, ex.isrc, ex.idst);
+    __threadfence();  // (release: the stores above reach memory every XCD reads from)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(F.rider_cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (ex.zero16 && blockIdx.x == 0 && threadIdx.x < 16) ex.zero16[threadIdx.x * 16] = 0u;
+  __shared__ TrackState s;
+  const int tid = threadIdx.x, nb = ex.nb_so3;
+  {
+    const int* src = reinterpret_cast<const int*>(st);
+    int* dst = reinterpret_cast<int*>(&s);
+    for (int i = tid; i < (int)(sizeof(TrackState) / 4); i += kPB) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (F.run_so3) so3_body<true>(st, s, F.so3, nb);
+  __syncthreads();
+  if (ex.gx > 0) {  // level 2 reads what this launch's rider blocks wrote
+    if (tid == 0) {
+      unsigned spins = 0;
+      // (wrap-safe comparison: the counter runs over the life of the handle)
+      while ((int)(__hip_atomic_load(F.rider_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - F.rider_target) < 0) {
+        if (++spins > kSpinLimit) {
+          __hip_atomic_store(&st->sync_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // never hang the device
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  if (F.run_l2) gn_level_body<ICP, RGB, 1, EXIT, true>(st, &s, F.a2, F.L2, nb);
+  __syncthreads();
+  if (F.run_l1) gn_level_body<ICP, RGB, P1, EXIT, true>(st, &s, F.a1, F.L1, nb);
+  __syncthreads();
+  if (blockIdx.x == 0) {  // the state goes back to HBM for the level-0 launch
+    if (tid == 0) s.sync_timeout = __hip_atomic_load(&st->sync_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int* src = reinterpret_cast<const int*>(&s);
     int* dst = reinterpret_cast<int*>(st);
@@ -1588,6 +1697,7 @@ void layout(dms_odometry* o, Carver& c) {
   o->part_so3 = (long long*)c.take((size_t)kRecWords * kMaxPartialBlocks * 8);
   o->part_cnt = (int*)c.take((size_t)2 * kMaxPartialBlocks * 4);
   o->tickets = (unsigned*)c.take(64);
+  o->rider_cnt = (unsigned*)c.take(64);
   o->ar = (unsigned long long*)c.take((size_t)kArSets * kArWords * 8);
   o->prof = (long long*)c.take((3 * 16 + 256 * 8) * 8);
   o->state = (TrackState*)c.take(sizeof(TrackState));
@@ -1749,6 +1859,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     if (e && atoi(e) > 0 && atoi(e) < o->max_resident_blocks) o->max_resident_blocks = atoi(e);
     e = getenv("DMS_AR_FIRST_DELAY");  // units of 64 cycles before the first read of the totals; default: by grid size
     if (e && atoi(e) >= 0 && atoi(e) <= 1000) o->first_delay = atoi(e);
+    e = getenv("DMS_TRACK_FUSE");
+    if (e) o->fuse_coarse = atoi(e) != 0;
     e = getenv("DMS_AR_FIRST_DELAY_BY_LEVEL");  // "l0,l1,l2,so3" in the same units (-1 keeps the rule for that stage): the per-level sweep
     if (e) {
       int v[4] = {-1, -1, -1, -1};
@@ -2123,6 +2235,21 @@ static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const 
     launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L);
 }
 
+template <bool ICP, bool RGB>
+static void launch_track_coarse(int P1, bool early_exit, int grid, hipStream_t s, TrackState* st, const CoarseArgs& F, const So3Extra& ex) {
+  if (P1 == 1) {
+    if (early_exit)
+      hipLaunchKernelGGL((k_track_coarse<ICP, RGB, 1, true>), dim3(grid), dim3(kPB), 0, s, st, F, ex);
+    else
+      hipLaunchKernelGGL((k_track_coarse<ICP, RGB, 1, false>), dim3(grid), dim3(kPB), 0, s, st, F, ex);
+  } else {
+    if (early_exit)
+      hipLaunchKernelGGL((k_track_coarse<ICP, RGB, 2, true>), dim3(grid), dim3(kPB), 0, s, st, F, ex);
+    else
+      hipLaunchKernelGGL((k_track_coarse<ICP, RGB, 2, false>), dim3(grid), dim3(kPB), 0, s, st, F, ex);
+  }
+}
+
 // grid of the resident SO3 kernel for this handle; 0 = the SO3 stage runs launch-per-phase
 static int so3_resident_blocks(const dms_odometry* o) {
   const Buf& li = o->lastNextImage[2];
@@ -2206,45 +2333,13 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   }
 
   PersistSection persist(s, o->max_resident_blocks);
-  if (so3) {
-    const int L = 2;
-    const Buf& li = o->lastNextImage[L];
-    const Buf& ni = o->nextImage[L];
-    const int nb = reduce_blocks_for(li.rows * li.cols);
-    const int nbp = so3_resident_blocks(o);
-    if (nbp > 0) {
-      persist.begin();
-      Timer t(o, s, "so3_level");
-      SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
-      ex.nb_so3 = nbp;
-      hipLaunchKernelGGL(k_so3_level, dim3(nbp + ex.gx * ex.gy), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbp, 3), ex);
-      DMS_CHECK_LAUNCH();
-    } else
-    for (int i = 0; i < 10; ++i) {
-      {
-        Timer t(o, s, "so3_pass");
-        SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
-        hipLaunchKernelGGL(k_so3_pass, dim3(nb), dim3(kBlock), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
-                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, o->tickets, cam, i, i == 9 ? 1 : 0, first_level,
-                           o->exp_bias + o->depth_bias);
-        DMS_CHECK_LAUNCH();
-      }
-    }
-  }
 
-  bool finalized_in_kernel = false;
-  for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
-    int pP = 1, pnb = 0;
-    if (o->resident && iterations[l] <= 10)
-      persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, o->max_resident_blocks, pP, pnb);
-    const bool persistent = pnb > 0;
-    if (rgb && !persistent) {  // the persistent kernel rebuilds the cloud point from lastDepth itself
-      dms_camera k = {o->fx, o->fy, o->cx, o->cy};
-      dms_image2d d = o->lastDepth[l].img(), c = o->pointClouds[l].img();
-      if ((rc = projectToPointCloud(&d, &c, &k, l, s))) return rc;
-    }
-    if (iterations[l] == 0) continue;
+  auto level_below_of = [&](int l) {
+    for (int q = l - 1; q >= 0; --q)
+      if (iterations[q] > 0) return q;
+    return l;
+  };
+  auto gn_args_of = [&](int l) {
     const int div = 1 << l;
     GnArgs a;
     memset(&a, 0, sizeof(a));
@@ -2289,34 +2384,119 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     a.level = l;
     a.rgbOnly = rgbOnly ? 1 : 0;
     a.exp_bias = o->exp_bias + o->depth_bias;
-    const int nb = track_blocks_for(a.cols * a.rows);
-    int level_below = l;
-    for (int q = l - 1; q >= 0; --q)
-      if (iterations[q] > 0) {
-        level_below = q;
-        break;
+    return a;
+  };
+  auto level_args_of = [&](int l, int pnb) {
+    LevelArgs L;
+    L.n_iter = iterations[l];
+    L.level = l;
+    L.level_below = level_below_of(l);
+    L.rgbOnly = rgbOnly ? 1 : 0;
+    L.icpWeight = icpWeight;
+    L.fx = o->fx;
+    L.fy = o->fy;
+    L.cx = o->cx;
+    L.cy = o->cy;
+    L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
+    L.first_delay = o->first_delay_for(pnb, l);
+    L.prof = (o->profiling && !o->profiling_level0_only) ? o->prof : nullptr;
+    // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
+    L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
+    L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
+    L.fin_rgb = rgb ? 1 : 0;
+    L.pose16_out = frame ? const_cast<float*>(prior_pose16_dev) : nullptr;
+    L.frame = frame;
+    L.weightMultiplier = weightMultiplier;
+    return L;
+  };
+  auto level_shape = [&](int l, int& pP, int& pnb) {
+    pP = 1;
+    pnb = 0;
+    if (o->resident && iterations[l] <= 10)
+      persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, o->max_resident_blocks, pP, pnb);
+  };
+
+  // SO3 + level 2 + level 1 in one resident launch (k_track_coarse) when all three are resident stages of this call and their shapes
+  // fit one grid: level 1's, with one pixel per thread at level 2
+  bool coarse = false;
+  int cP1 = 1, cnb = 0;
+  if (o->fuse_coarse && o->resident && so3 && iterations[2] > 0 && iterations[1] > 0) {
+    int P2 = 1, nb2 = 0;
+    level_shape(2, P2, nb2);
+    level_shape(1, cP1, cnb);
+    const int nbs = so3_resident_blocks(o);
+    coarse = nbs > 0 && nb2 > 0 && cnb > 0 && P2 == 1 && cP1 <= 2 && nb2 <= cnb && nbs <= cnb;
+  }
+  if (coarse) {
+    const Buf& li = o->lastNextImage[2];
+    const Buf& ni = o->nextImage[2];
+    CoarseArgs F;
+    memset(&F, 0, sizeof(F));
+    F.so3 = {(const unsigned char*)li.p, li.pitch, (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, SolveCam{o->fx, o->fy, o->cx, o->cy},
+             first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(cnb, 3)};
+    F.a2 = gn_args_of(2);
+    F.a1 = gn_args_of(1);
+    F.L2 = level_args_of(2, cnb);
+    F.L1 = level_args_of(1, cnb);
+    F.run_so3 = F.run_l2 = F.run_l1 = 1;
+    F.rider_cnt = o->rider_cnt;
+    o->rider_issued += (unsigned)(ex.gx * ex.gy);
+    F.rider_target = o->rider_issued;
+    ex.nb_so3 = cnb;
+    persist.begin();
+    Timer t(o, s, "track_coarse");
+    const bool ee = F.L1.early_exit != 0;
+    if (icp && rgb)
+      launch_track_coarse<true, true>(cP1, ee, cnb + ex.gx * ex.gy, s, o->state, F, ex);
+    else if (icp)
+      launch_track_coarse<true, false>(cP1, ee, cnb + ex.gx * ex.gy, s, o->state, F, ex);
+    else
+      launch_track_coarse<false, true>(cP1, ee, cnb + ex.gx * ex.gy, s, o->state, F, ex);
+    DMS_CHECK_LAUNCH();
+  } else if (so3) {
+    const int L = 2;
+    const Buf& li = o->lastNextImage[L];
+    const Buf& ni = o->nextImage[L];
+    const int nb = reduce_blocks_for(li.rows * li.cols);
+    const int nbp = so3_resident_blocks(o);
+    if (nbp > 0) {
+      persist.begin();
+      Timer t(o, s, "so3_level");
+      SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
+      ex.nb_so3 = nbp;
+      hipLaunchKernelGGL(k_so3_level, dim3(nbp + ex.gx * ex.gy), dim3(kPB), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                         (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, cam, first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbp, 3), ex);
+      DMS_CHECK_LAUNCH();
+    } else
+    for (int i = 0; i < 10; ++i) {
+      {
+        Timer t(o, s, "so3_pass");
+        SolveCam cam = {o->fx, o->fy, o->cx, o->cy};
+        hipLaunchKernelGGL(k_so3_pass, dim3(nb), dim3(kBlock), 0, s, o->state, (const unsigned char*)li.p, li.pitch,
+                           (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->part_so3, o->tickets, cam, i, i == 9 ? 1 : 0, first_level,
+                           o->exp_bias + o->depth_bias);
+        DMS_CHECK_LAUNCH();
       }
+    }
+  }
+
+  bool finalized_in_kernel = false;
+  for (int l = DMS_NUM_PYRS - 1; l >= 0; --l) {
+    if (coarse && l >= 1) continue;  // (ran inside k_track_coarse; resident levels rebuild the cloud point themselves)
+    int pP = 1, pnb = 0;
+    level_shape(l, pP, pnb);
+    const bool persistent = pnb > 0;
+    if (rgb && !persistent) {  // the persistent kernel rebuilds the cloud point from lastDepth itself
+      dms_camera k = {o->fx, o->fy, o->cx, o->cy};
+      dms_image2d d = o->lastDepth[l].img(), c = o->pointClouds[l].img();
+      if ((rc = projectToPointCloud(&d, &c, &k, l, s))) return rc;
+    }
+    if (iterations[l] == 0) continue;
+    const GnArgs a = gn_args_of(l);
+    const int nb = track_blocks_for(a.cols * a.rows);
+    const int level_below = level_below_of(l);
     if (persistent) {
-      LevelArgs L;
-      L.n_iter = iterations[l];
-      L.level = l;
-      L.level_below = level_below;
-      L.rgbOnly = rgbOnly ? 1 : 0;
-      L.icpWeight = icpWeight;
-      L.fx = o->fx;
-      L.fy = o->fy;
-      L.cx = o->cx;
-      L.cy = o->cy;
-      L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
-      L.first_delay = o->first_delay_for(pnb, l);
-      L.prof = (o->profiling && !o->profiling_level0_only) ? o->prof : nullptr;
-      // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
-      L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
-      L.finalize = (l == 0) ? 1 : 0;  // level 0 always runs last
-      L.fin_rgb = rgb ? 1 : 0;
-      L.pose16_out = frame ? const_cast<float*>(prior_pose16_dev) : nullptr;
-      L.frame = frame;
-      L.weightMultiplier = weightMultiplier;
+      const LevelArgs L = level_args_of(l, pnb);
       if (l == 0) finalized_in_kernel = true;
       persist.begin();
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};

@@ -1731,7 +1731,34 @@ def test_frame_block_armed_ahead_equals_the_separate_launch(size):
             assert not ef.frameBlockWritten() and (got == 0xAB).all()
             continue
         assert ef.frameBlockWritten(), k
-        assert np.array_equal(got[:T + 68], want[:T + 68]), (size, k, int((got[:T + 68] != want[:T + 68]).sum()))
-        assert (got[T + 68:] == 0xAB).all()
+        n = (W2 // 8) * (H2 // 8)
+        vo, no = collab.thumbnail_offsets(W2, H2)
+        assert vo >= n * 4 and no == vo + n * 16 and T == no + n * 16
+        for lo, hi, what in ((0, n * 4, "image"), (vo, no, "vertex"), (no, T, "normal"), (T, T + 68, "pose | tick")):
+            assert np.array_equal(got[lo:hi], want[lo:hi]), (size, k, what, int((got[lo:hi] != want[lo:hi]).sum()))
+        assert (got[n * 4:vo] == 0xAB).all() and (got[T + 68:] == 0xAB).all()  # (the image section's padding and the bytes behind: untouched)
         assert (got[T:T + 64].view(np.float32) == np.array(r.pose, np.float32).reshape(16)).all() and got[T + 64:T + 68].view(np.int32)[0] == 100 + k
     ef.close()
+
+
+def test_frame_step_with_the_coarse_tracker_launch_is_bit_identical(monkeypatch):
+    """DMS_TRACK_FUSE=1 (round 6, off by default: slower on the MI355X): SO3, level 2 and level 1 of the frame's tracker call run as stages
+    of ONE resident launch - state in LDS from stage to stage, the model pyramid's deferred last step as rider blocks whose output level 2
+    waits for (release + counter).  Same poses and the same map as a launch per stage, frame after frame, at both BASELINE sizes."""
+    from densemonoslam_amd import capi, fusion, synth
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    for (W2, H2, K2) in ((640, 480, synth.K_640), (1241, 376, synth.K_KITTI)):
+        out = []
+        for fuse in ("0", "1"):
+            monkeypatch.setenv("DMS_TRACK_FUSE", fuse)
+            ef = fusion.ElasticFusion(W2, H2, K2, model_capacity=4_000_000)
+            poses = []
+            for k in range(6):
+                d, rgb, _ = synth.frame(2 * k, width=W2, height=H2, K=K2, noise=True)
+                poses.append(np.array(ef.processFrame(rgb, d).pose, np.float32).tobytes())
+            m = ef.globalModel().downloadMap()
+            out.append((poses, {f: m[f].tobytes() for f in m.dtype.names}, len(m)))
+            ef.close()
+        assert out[0][2] == out[1][2] > 100_000 and out[0][0] == out[1][0], (W2, H2)
+        assert out[0][1] == out[1][1], "the maps differ"

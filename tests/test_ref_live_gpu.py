@@ -92,3 +92,42 @@ def test_steps_equal_the_references_live(orc, size):
                 assert ro[1] == rr[1]
                 assert np.abs(Ao.astype(np.float64) - Ar).max() <= 2e-6 * max(np.abs(Ar).max(), 1e-30)
     assert n_corr > 1000
+
+
+@pytest.mark.parametrize("pair", ["room_0_3", "room_40_44", "corner_10_12"])
+def test_product_tracker_against_the_reference_driven_tracker_on_synthetic_pairs(orc, pair):
+    """The whole-call evidence of tests/test_ref_pin_gpu.py (HIP tracker object against tracker calls whose every step of every
+    iteration ran the REFERENCE's kernels) rests on ONE image pair, the GPUTest PNGs.  Here the same comparison runs LIVE on three more
+    pairs - frames of the synthetic streams, 640 x 480, with motions of 1 - 4 cm / 0.3 - 1 degree between the two frames - for all five
+    configurations: the north-star bar (1 mm, 0.01 degree) and the same iteration counts and breaks."""
+    from densemonoslam_amd import capi, odometry, synth
+    from oracle import ref
+    from tests import helpers
+
+    if not ref.available():
+        pytest.skip("oracle/_ref/libref_reduce.so not built (needs /root/reference at build time)")
+    assert capi.device_count() >= 1
+    scene, k1, k2 = {"room_0_3": (None, 0, 3), "room_40_44": (None, 40, 44), "corner_10_12": (synth.CORNER_SCENE, 10, 12)}[pair]
+    K = ref_cases.K
+    d1, rgb1, _ = synth.frame(k1, width=640, height=480, K=K, noise=True, scene=scene)
+    d2, rgb2, _ = synth.frame(k2, width=640, height=480, K=K, noise=True, scene=scene)
+    # the GPUTest protocol's inputs (GPUTest.cpp:51-57,69-129): the first frame's depth on the TUM scale (1 / 5000 m), the second in mm
+    p = {"rgb1": rgb1, "rgb2": rgb2, "depth1_raw": (d1.astype(np.uint32) * 5).clip(0, 65535).astype(np.uint16), "depth2": d2}
+    want = ref_cases.run_trackers(orc, p, hooks=ref.step_hooks())
+    verts, norms = helpers.gputest_model_maps(p["depth1_raw"], K)
+    worst = (0.0, 0.0)
+    for name, cfg in ref_cases.TRACKER_CONFIGS.items():
+        g = odometry.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+        g.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+        g.initRGBModel(helpers.rgba(rgb1))
+        g.initICP(d2, 20.0)
+        g.initRGB(helpers.rgba(rgb2))
+        g.initFirstRGB(helpers.rgba(rgb1))
+        t, R, res = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **cfg)
+        dt, da = helpers.assert_pose_close(t, R, want["trk_%s_t" % name], want["trk_%s_R" % name], tol_m=1e-3, tol_deg=1e-2, what="%s %s" % (pair, name))
+        worst = (max(worst[0], dt), max(worst[1], da))
+        assert [res.so3_iterations_run] + list(res.iterations_run) == list(want["trk_%s_iters" % name]), (pair, name)
+        g.close()
+    moved = float(np.linalg.norm(want["trk_C3_full_t"]))
+    assert moved > 2e-3, "the pair must carry a real motion (%.1e m)" % moved
+    print("%s: worst difference to the reference-driven tracker %.2e m, %.2e deg (motion %.3f m)" % (pair, worst[0], worst[1], moved))
