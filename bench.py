@@ -696,6 +696,9 @@ def main():
         out["session"]["one_camera_steady_state"] = {
             "what": "the headline loop's frames through dms_session_step_async with one camera and no other rank",
             "frames_per_s": round(args.steps / el1, 1), "of_value": round(args.steps / el1 / fps, 3)}
+        # the figure the --gpus N > 1 headline loop is to be compared with at N = 1 (python bench.py --session-loop times it as `value`)
+        out["value_session_loop"] = {"value": args.steps / el1, "unit": "frames/s", "of_value": round(args.steps / el1 / fps, 3),
+                                     "what": "session.one_camera_steady_state: the same frames through dms_session_step_async (one camera, no transport)"}
 
         mg2, _, _ = pipelined_pass([0, n_ticks])  # (where the schedule merges: the timed pass puts its phase boundaries there)
         if mg2:

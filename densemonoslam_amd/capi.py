@@ -249,6 +249,7 @@ lib.dms_computeNIDDepth.argtypes = [_I2, _I2, _I2, C.c_int, C.c_float, _P, C.c_s
 lib.dms_odometry_create.argtypes = [C.POINTER(_P), _I, _I, _F, _F, _F, _F, _F, _F]
 lib.dms_odometry_destroy.argtypes = [_P]
 lib.dms_odometry_set_mode.argtypes = [_P, _I, _I, _I, _I]
+lib.dms_odometry_set_exec.argtypes = [_P, _I, _I, _I]
 lib.dms_odometry_inject_timeout.argtypes = [_P, _I]
 lib.dms_odometry_debug_set.argtypes = [_P, C.c_char_p, _I]
 lib.dms_odometry_canon_retries.argtypes = [_P, _IP]

@@ -1961,14 +1961,20 @@ int dms_odometry_inject_timeout(dms_odometry* o, int calls) {
   return DMS_OK;
 }
 
-int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce) {
+int dms_odometry_set_exec(dms_odometry* o, int resident, int early_exit, int coarse_launch) {
   DMS_REQUIRE(o, "null argument");
-  (void)fp64_sums;      // (rounds 1-2: fp64 block sums / record protocol; every sum is the exact integer sum of canon.hpp now)
-  (void)atomic_reduce;
   // resident = 1 on a handle whose device cannot hold a resident kernel's blocks at once (max_resident_blocks = 0) stays off
   if (resident >= 0) o->resident = resident != 0 && o->max_resident_blocks > 0;
   if (early_exit >= 0) o->early_exit_force = early_exit ? 1 : 0;  // -1: unchanged (keeps a DMS_TRACK_EARLY_EXIT choice made at creation)
+  if (coarse_launch >= 0) o->fuse_coarse = coarse_launch != 0;
   return DMS_OK;
+}
+
+// deprecated form (rounds 1-2 had summation variants: fp64 block sums, a record protocol; every sum is the exact integer sum of canon.hpp now)
+int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce) {
+  (void)fp64_sums;
+  (void)atomic_reduce;
+  return dms_odometry_set_exec(o, resident, early_exit, -1);
 }
 
 // the frame step's reaction to a resident kernel that timed out: launch-per-phase from here on, nothing else touched

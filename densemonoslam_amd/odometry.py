@@ -255,10 +255,10 @@ class RGBDOdometry:
             lib.dms_odometry_destroy(self.h)
             self.h = None
 
-    def setMode(self, resident=-1, fp64_sums=-1, early_exit=-1, atomic_reduce=-1):
-        """Execution switches of this handle (dms_odometry_set_mode); -1 keeps / restores the default.
-        (fp64_sums / atomic_reduce: ignored since round 3 — every sum is the order-free integer sum.)"""
-        check(lib.dms_odometry_set_mode(self.h, int(resident), int(fp64_sums), int(early_exit), int(atomic_reduce)), "dms_odometry_set_mode")
+    def setMode(self, resident=-1, fp64_sums=-1, early_exit=-1, atomic_reduce=-1, coarse_launch=-1):
+        """Execution switches of this handle (dms_odometry_set_exec); -1 keeps the current setting.  coarse_launch: SO3 + level 2 + level 1
+        in one resident launch (round 6; same bits).  (fp64_sums / atomic_reduce: accepted and ignored, as the library has since round 3.)"""
+        check(lib.dms_odometry_set_exec(self.h, int(resident), int(early_exit), int(coarse_launch)), "dms_odometry_set_exec")
 
     def getMode(self):
         """(resident, max_resident_blocks, fell_back) of this handle"""

@@ -231,15 +231,18 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
                         float fx, float fy, float distThresh, float angleThresh);
 int dms_odometry_destroy(dms_odometry* o);
 /* Execution switches of one tracker (no reference counterpart).  They are read from the environment ONCE, when the
- * handle is created — DMS_TRACK_MODE=launches, DMS_TRACK_EARLY_EXIT=0|1 — and changed only here:
- *   resident    1 = one resident kernel per pyramid level (default; ignored where the device cannot hold a resident kernel's blocks
- *               at once), 0 = three launches per iteration; -1 = keep
- *   early_exit  1 / 0 = force the resident-kernel variant that leaves a level after an iteration without any
- *               correspondence on / off; -1 = keep (the handle's default - on for the frame step's model-to-model tracker - or
- *               what DMS_TRACK_EARLY_EXIT chose at creation)
- *   fp64_sums, atomic_reduce: ignored (summation variants of rounds 1-2).  Every cross-pixel sum of the tracker is now the
- *               order-free integer sum of csrc/canon.hpp in every execution mode: poses do not depend on these switches,
- *               on the grid size or on the run. */
+ * handle is created - DMS_TRACK_MODE=launches, DMS_TRACK_EARLY_EXIT=0|1, DMS_TRACK_FUSE=0|1 - and changed only here (-1 = keep):
+ *   resident       1 = one resident kernel per pyramid level (default; ignored where the device cannot hold a resident kernel's blocks
+ *                  at once), 0 = three launches per iteration
+ *   early_exit     1 / 0 = force the resident-kernel variant that leaves a level after an iteration without any correspondence on / off
+ *                  (the handle's default - on for the frame step's model-to-model tracker - or what DMS_TRACK_EARLY_EXIT chose)
+ *   coarse_launch  1 = SO3 pre-alignment, level 2 and level 1 as stages of ONE resident launch where their shapes fit one grid
+ *                  (round 6; same bits, slower on the MI355X than a launch per stage: default 0)
+ * Every cross-pixel sum of the tracker is the order-free integer sum of csrc/canon.hpp in every execution mode: poses do not depend on
+ * these switches, on the grid size or on the run. */
+int dms_odometry_set_exec(dms_odometry* o, int resident, int early_exit, int coarse_launch);
+/* DEPRECATED since round 6 (kept for callers built against rounds 1-5): fp64_sums and atomic_reduce have been ignored since round 3;
+ * equals dms_odometry_set_exec(o, resident, early_exit, -1). */
 int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce);
 /* launch-per-phase kernels from now on (what the frame step does after a resident kernel timed out); nothing else changes */
 int dms_odometry_fall_back_to_launches(dms_odometry* o);
