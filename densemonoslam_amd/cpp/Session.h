@@ -130,6 +130,8 @@ class Session {
     return v;
   }
   void pipelinedStats(int* ticks, int* woken) const { check(dms_session_async_stats(h_, ticks, woken), "dms_session_async_stats"); }
+  // with params.time_exchange: device time of the pipelined ticks' all-gathers seen complete so far (sum in ms, how many)
+  void exchangeTime(double* allgather_ms_sum, int* allgathers) const { check(dms_session_exchange_time(h_, allgather_ms_sum, allgathers), "dms_session_exchange_time"); }
 
   dms_session* handle() const { return h_; }
 
