@@ -875,7 +875,7 @@ def main():
                 ms, cnt = ef.kernel_time(n)
                 if cnt:
                     stages[n] = {"ms_per_frame": ms / nprof, "launches_per_frame": cnt / nprof}
-            for n in ("track_coarse", "so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
+            for n in ("track_coarse", "so3_model", "so3_level", "gn_level0", "gn_level1", "gn_level2", "gn_pass1", "gn_pass2", "gn_solve", "so3_pass", "track_init", "track_finalize"):
                 ms, cnt = C.c_double(0), C.c_int(0)
                 capi.check(capi.lib.dms_odometry_get_kernel_time(C.c_void_p(od), n.encode(), C.byref(ms), C.byref(cnt)))
                 if cnt.value:
@@ -921,11 +921,12 @@ def main():
                                         "launches_over_1p5_median": slow, "their_excess_us_per_launch_overall": round(1000.0 * extra / cnt, 2)}
 
         us_level0_as_timed, level0_spread = level0_pass()
-        _, kern_pipe, _ = kernel_pass(False)
+        stages_pipe, kern_pipe, _ = kernel_pass(False)
         stages, kern, phases = kernel_pass(True)
         if sum(sum(r.values()) for r in phases.values()) > 0:
             out["gn_level_phase_us_per_frame"] = phases  # in-kernel clock of block 0, summed over the level's iterations (isolated pass)
         out["stage_ms_per_frame"] = {k: round(v["ms_per_frame"], 4) for k, v in stages.items()}
+        out["stage_ms_per_frame_pipelined"] = {k: round(v["ms_per_frame"], 4) for k, v in stages_pipe.items()}  # (frames enqueued as in the timed region)
         out["tracker_kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern.items()}
         out["tracker_kernels_pipelined"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kern_pipe.items()}
         # dominant kernel: the resident Gauss-Newton kernel of pyramid level 0 (10 iterations in one

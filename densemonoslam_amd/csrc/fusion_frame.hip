@@ -20,6 +20,7 @@
 #include "frame_state.hpp"
 #include "live_bodies.hpp"
 #include "fill.hpp"
+#include "track_init.hpp"
 
 struct dms_odometry;
 
@@ -45,7 +46,7 @@ int untranspose(const void* src, void* dst, int cols, int rows, int elem, hipStr
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime = nullptr,
-                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0, const FillArgs* fill = nullptr);
+                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0, const FillArgs* fill = nullptr, const TrackInitArgs* init = nullptr);
 int model_sample_graph(dms_model* m, int sampleRate, float* rows4_host, int max_rows, int* n_host, hipStream_t s);
 int model_flush_pending(dms_model* m, hipStream_t s);
 // fusion_fuse.hip
@@ -69,6 +70,7 @@ struct TrackFold {  // the track call a model pyramid launch prepares (track.hip
   const float* prior_pose16;
   int pyramid, fastOdom, so3, interMap;
 };
+int odometry_early_init_args(dms_odometry* o, const TrackFold* fold, TrackInitArgs* ti);
 int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, const void* iA, const void* vB, const void* nB,
                              const void* iB, const int* flag_dev, int force_b_img, const float* pose16_dev, hipStream_t s,
                              int defer_last_step = 0, unsigned* dense_cnt = nullptr, int dense_samples = 0, const TrackFold* fold = nullptr);
@@ -506,7 +508,7 @@ void drain(dms_fusion* f) {
 // prediction (confidence 0.7, next tick).  mode 2 (that next frame's begin): resolve zbuf2 if it is still what this
 // prediction would render — nothing changed the map, the pose comes from the previous frame — else project as usual.
 int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror = nullptr, bool dense_test = false, int mode = 0,
-            bool have_prior = false) {
+            bool have_prior = false, const TrackInitArgs* track_init = nullptr, bool* track_init_taken = nullptr) {
   int rc;
   FillArgs fa;
   const FillArgs* fused = nullptr;
@@ -544,7 +546,7 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
     if (mode == 2 && f->pre_valid) {
       if (!have_prior && f->pre_tick == f->tick && f->pre_version == f->model->version) {
         if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
-                                f->p.timeDelta, 1, f->zbuf2, &f->pred, nullptr, 1, s, nullptr, nullptr, 1, fused)))
+                                f->p.timeDelta, 1, f->zbuf2, &f->pred, nullptr, 1, s, nullptr, nullptr, 1, fused, fused ? track_init : nullptr)))
           return rc;
         done = true;
       } else if ((rc = clear_zbuf(f->zbuf2, W * H, s))) {  // stale: the resolve that would have cleaned it never runs
@@ -560,7 +562,7 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
       if (dual && f->pre_valid && (rc = clear_zbuf(f->zbuf2, W * H, s))) return rc;  // (never consumed)
       if ((rc = splat_predict(f->model, &f->state->cur, &f->cam, f->p.maxDepthProcessed, confidence, f->tick, f->p.timeIdx, f->tick,
                               f->p.timeDelta, 1, f->zbuf, &f->pred, nullptr, 1, s, dual ? second : nullptr, dual ? f->zbuf2 : nullptr, 0,
-                              fused)))
+                              fused, fused ? track_init : nullptr)))
         return rc;
       if (dual) {
         f->pre_valid = true;
@@ -569,6 +571,7 @@ int predict(dms_fusion* f, float confidence, hipStream_t s, void* state_mirror =
       }
     }
   }
+  if (track_init_taken) *track_init_taken = fused != nullptr && track_init && track_init->blocks > 0;
   if (!fused) {
     FTimer t(f, s, "fill_in");
     if ((rc = fill_in(&f->pred, &f->depth_filtered, &f->rgba, &f->cam, f->lost ? 1 : 0, (f->lost || f->p.frameToFrameRGB) ? 1 : 0, &f->fill,
@@ -1118,13 +1121,20 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
       DMS_CHECK_LAUNCH();
     }
     // ElasticFusion.cpp:165-167: an extra block of this predict's fill-in launch takes the denseEnough decision
-    if ((rc = predict(f, 0.7f, s, nullptr, true, 2, inPose16 != nullptr))) return rc;
+    // (round 6) the set-up of this frame's tracker call rides on the prediction's resolve pass - a kernel boundary before the model
+    // pyramid launch, which can then run the tracker's SO3 stage beside the pyramid (track.hip: k_so3_model)
+    const TrackFold fold = {f->state->cur.pose, f->p.pyramid, f->p.fastOdom, f->p.so3, 0};
+    TrackInitArgs early;
+    memset(&early, 0, sizeof(early));
+    bool early_taken = false;
+    const bool want_early = f->p.hybrid_tracking && f->fold_track_init && !f->lost && odometry_early_init_args(f->odom, &fold, &early) != 0;
+    if ((rc = predict(f, 0.7f, s, nullptr, true, 2, inPose16 != nullptr, want_early ? &early : nullptr, &early_taken))) return rc;
+    if (want_early && !early_taken) odometry_early_init_args(f->odom, nullptr, &early);  // (no fused resolve pass this frame: the set-up folds into the pyramid kernel as before)
     if (f->p.hybrid_tracking) {
       {
         FTimer t(f, s, "odom_init");
         // WARNING (reference): initICP* must be called before initRGB* (ElasticFusion.cpp:172)
         // (the set-up of the tracker call below rides on the pyramid kernel: no launch of its own, DMS_FOLD_TRACK_INIT=0 to compare)
-        const TrackFold fold = {f->state->cur.pose, f->p.pyramid, f->p.fastOdom, f->p.so3, 0};
         if ((rc = odometry_initModel_fused(f->odom, f->pred.vertex.data, f->pred.normal.data, f->pred.image.data, f->fill.vertex.data,
                                            f->fill.normal.data, f->fill.image.data, &f->state->fill_in, f->p.frameToFrameRGB ? 1 : 0,
                                            f->state->cur.pose, s, 1,  // (last pyramid step: inside the tracker's first kernel, below)

@@ -14,6 +14,7 @@
 #include "smallmath.hpp"
 #include "surfel.hpp"
 #include "fill.hpp"
+#include "track_init.hpp"
 
 namespace dms {
 int model_flush_pending(dms_model* m, hipStream_t s);  // fusion_fuse.hip: applies a fuse's deferred update pass
@@ -1095,7 +1096,16 @@ template <bool DEPTH_ONLY, bool FILL>
 __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes sp, size_t cap, unsigned long long* __restrict__ zbuf,
                                                        uchar4* __restrict__ image, float4* __restrict__ vertex, float4* __restrict__ normal,
                                                        unsigned short* __restrict__ timeImg, float* __restrict__ depthOut, int clear_after,
-                                                       FillArgs fa) {
+                                                       FillArgs fa, TrackInitArgs ti) {
+  // (round 6) the last ti.blocks blocks of the grid carry the set-up of the tracker call that follows two launches later (track_init.hpp):
+  // it depends on the prior pose only, and doing it HERE - a kernel boundary before the model pyramid launch - lets that launch run
+  // the tracker's SO3 stage beside the pyramid (track.hip: k_so3_model)
+  const unsigned nres = gridDim.x - (FILL ? (unsigned)ti.blocks : 0u);
+  if (FILL && blockIdx.x >= nres) {
+    track_init_body((int)(blockIdx.x - nres), ti.blocks, (int)threadIdx.x, (int)blockDim.x, ti.st, ti.prior, ti.prior_pose16, ti.fx, ti.fy, ti.cx, ti.cy,
+                    ti.so3, ti.first_level, ti.sync_words, ti.n_sync, ti.inject_timeout, nullptr);
+    return;
+  }
   if (FILL) {
     if (fa.mirror_words > 0 && blockIdx.x == 0 && (int)threadIdx.x < fa.mirror_words) fa.mirror_dst[threadIdx.x] = fa.mirror_src[threadIdx.x];
     if (fa.thumb_block && blockIdx.x == 0) {  // the frame block's pose and tick ride along (k_thumbnails does the same)
@@ -1109,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
   // is one 128-byte (float4) run
   const int tiles_y = (a.rows + 7) >> 3, tiles_x = (a.cols + 7) >> 3, ntiles = tiles_x * tiles_y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
-  for (int t = xcd_block(blockIdx.x, gridDim.x, a.xcd) * waves_per_block + wave; t < ntiles; t += gridDim.x * waves_per_block) {
+  for (int t = xcd_block(blockIdx.x, nres, a.xcd) * waves_per_block + wave; t < ntiles; t += nres * waves_per_block) {
     const int tx = t / tiles_y, ty = t - tx * tiles_y;
     const int px = tx * 8 + (lane >> 3), py = ty * 8 + (lane & 7);
     if (px >= a.cols || py >= a.rows) continue;
@@ -1177,8 +1187,9 @@ __global__ __launch_bounds__(256) void k_splat_resolve(ProjArgs a, SurfelPlanes 
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime, unsigned long long* zbuf2,
-                  int resolve_only, const FillArgs* fill) {
+                  int resolve_only, const FillArgs* fill, const TrackInitArgs* init) {
   DMS_REQUIRE(m && pose && cam && zbuf, "null argument");
+  DMS_REQUIRE(!init || init->blocks == 0 || (fill && !depth_out), "the tracker set-up rides on the fused resolve + fill-in pass only");
   DMS_REQUIRE(!m->pending_update, "a deferred update pass is still pending (index_map applies it)");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
   const int W = m->width, H = m->height;
@@ -1213,20 +1224,23 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
   }
   DMS_CHECK_LAUNCH();
   const FillArgs no_fill = {};
+  TrackInitArgs no_init;
+  memset(&no_init, 0, sizeof(no_init));
   const dim3 rg(min((n + 255) / 256, 2048));
   if (depth_out) {
     hipLaunchKernelGGL((k_splat_resolve<true, false>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)nullptr,
-                       (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data, zclean, no_fill);
+                       (float4*)nullptr, (float4*)nullptr, (unsigned short*)nullptr, (float*)depth_out->data, zclean, no_fill, no_init);
   } else if (fill) {
     DMS_REQUIRE(fill->ex_image == (const uchar4*)out->image.data && fill->ex_vertex == (const float4*)out->vertex.data &&
                     fill->ex_normal == (const float4*)out->normal.data && fill->cols == W && fill->rows == H &&
                     (!fill->dense_cnt || (fill->sample_mask && W <= 2048 && H <= 2048)) && fill->mirror_words <= 256,
                 "fill-in arguments do not describe this prediction");
-    hipLaunchKernelGGL((k_splat_resolve<false, true>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)out->image.data,
-                       (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, *fill);
+    const TrackInitArgs& ti = (init && init->blocks > 0) ? *init : no_init;
+    hipLaunchKernelGGL((k_splat_resolve<false, true>), dim3(rg.x + ti.blocks), dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)out->image.data,
+                       (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, *fill, ti);
   } else {
     hipLaunchKernelGGL((k_splat_resolve<false, false>), rg, dim3(256), 0, s, a, m->buf[m->cur], m->cap, zbuf, (uchar4*)out->image.data,
-                       (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, no_fill);
+                       (float4*)out->vertex.data, (float4*)out->normal.data, (unsigned short*)out->time.data, (float*)nullptr, zclean, no_fill, no_init);
   }
   DMS_CHECK_LAUNCH();
   return DMS_OK;

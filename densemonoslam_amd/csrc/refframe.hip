@@ -31,7 +31,8 @@ namespace dms {
 int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* cam, float maxDepth, float confThreshold, int time,
                   int timeIdx, int maxTime, int timeDelta, int active, unsigned long long* zbuf, dms_predict_out* out,
                   dms_image2d* depth_out, int zclean, hipStream_t s, const float* second_conf_time_maxtime = nullptr,
-                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0, const struct FillArgs* fill = nullptr);
+                  unsigned long long* zbuf2 = nullptr, int resolve_only = 0, const struct FillArgs* fill = nullptr,
+                  const struct TrackInitArgs* init = nullptr);
 int clear_zbuf(unsigned long long* zbuf, int n, hipStream_t s);
 int model_flush_pending(dms_model* m, hipStream_t s);
 }  // namespace dms

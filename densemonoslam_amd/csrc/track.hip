@@ -36,6 +36,7 @@
 #include "pyr_body.hpp"
 #include "frame_state.hpp"
 #include "track_init.hpp"
+#include "model_bodies.hpp"
 #include "surfel.hpp"
 #include <mutex>
 
@@ -90,6 +91,11 @@ struct dms_odometry {
   // the set-up of the next track call ran inside the model pyramid kernel (odometry_initModel_fused, fold_init): that call then
   // launches no kernel of its own before the SO3 level, which also carries the deferred pyramid step; the promised parameters
   bool init_folded = false;
+  // round 6: the call's set-up enqueued AHEAD, as rider blocks of the frame's first kernel (odometry_early_init_args), so that the SO3
+  // stage can run inside the model pyramid launch (k_so3_model) instead of after it
+  bool early_init = false, so3_in_model = false;
+  bool so3_beside_model = false;  // DMS_SO3_BESIDE_MODEL=1: SO3 stage and model pyramid in ONE launch (k_so3_model).  Built, the same bits, 7.6 us less kernel time per
+                                  // frame - and no faster frame (the resident levels then wait for the prep stream's kernels instead): off
   int folded_so3 = 0, folded_first_level = 0;
   const float* folded_prior = nullptr;
   unsigned* dense_cnt_zero = nullptr;  // the frame step's 16 dense counters (fill.hpp), read by the model pyramid kernel: zeroed by the next track call's first kernel
@@ -831,6 +837,7 @@ struct LevelArgs {
   float fx, fy, cx, cy;  // full-resolution intrinsics
   unsigned long long* ar;    // kArSetsPerKernel word sets of kArWords, zero on entry: one per iteration, then the retry pool
   int first_delay;           // see ar_wait (units of 64 cycles)
+  unsigned* zero16;          // the frame step's 16 dense counters, re-armed by the call's first Gauss-Newton launch when no earlier kernel of the call could (k_so3_model reads them)
   long long* prof;           // optional [3][16] per-level phase clocks of block 0 (null = off)
   // last level of the call: block 0 also does what k_track_finalize does (jump gate, result block,
   // pose write-back, frame bookkeeping) instead of a one-lane launch of its own
@@ -963,6 +970,7 @@ __device__ __forceinline__ void gn_level_body(TrackState* st, TrackState* sv, co
     }
   };
 
+  if (L.zero16 && blockIdx.x == 0 && tid >= 96 && tid < 112) L.zero16[(tid - 96) * 16] = 0u;
   if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 64 && tid < 80) s_held[16 + tid - 64] = L.frame->lastPose[tid - 64];  // for the finalize step
   // (the pose block's bottom row is not the tracker's to write, see the finalize step: it is carried through)
   if (L.finalize && L.frame && blockIdx.x == 0 && tid >= 80 && tid < 84) s_held[12 + tid - 80] = L.frame->cur.pose[12 + tid - 80];
@@ -1547,6 +1555,49 @@ __global__ __launch_bounds__(kPB) void k_so3_level(TrackState* st, const unsigne
 }
 
 // ---------------------------------------------------------------------------------------
+// SO3 BESIDE the model pyramid (round 6).  The SO3 pre-alignment compares two LIVE image pyramids and starts from the prior pose: it
+// needs nothing of the model prediction - yet it ran after the model pyramid kernel, a launch of ~16 us on the frame's critical path
+// behind one of ~14.  Here the resident SO3 blocks are the first blocks of ONE launch whose other blocks are the model pyramid's
+// groups (model_bodies.hpp, as 64 x 8 blocks): the two halves run side by side, the launch ends when the longer one does.  What made
+// the old order necessary is arranged elsewhere: the call's set-up (state block, all-reduce words, timeout flag) rides on the
+// frame's FIRST kernel (the tracking prediction's resolve pass: odometry_early_init_args), so it is complete - across a kernel
+// boundary - before this launch starts; the pyramid's last step, which rode on the SO3 launch, is taken straight from the sources
+// (model_pyr_step2_body); the dense counters this launch reads are re-armed by the first Gauss-Newton launch (LevelArgs::zero16).
+struct ModelGroups {
+  ModelSrc m;
+  int g0x, g0y, g12x, g12y, gsx, gsy, g2x, g2y;
+  int rows0, cols0, rows1, cols1, rows2, cols2;
+  float cutOff;
+  View<float> v0, n0, depth0, v1, n1, v2, n2, depth1, depth2;
+  View<unsigned char> inten0, inten1, inten2;
+};
+
+__global__ __launch_bounds__(kPB) void k_so3_model(TrackState* st, So3Args q, int nb_so3, ModelGroups G) {
+  if ((int)blockIdx.x < nb_so3) {
+    __shared__ TrackState s;
+    so3_body<false>(st, s, q, nb_so3);
+    return;
+  }
+  const int t = (int)threadIdx.x, tx = t & 63, ty = t >> 6;
+  constexpr int BYv = kPB / 64;
+  const int b = (int)blockIdx.x - nb_so3;
+  if (G.m.dense_cnt && b == 0 && t == 0) *G.m.flag_out = model_use_b(G.m) ? 1 : 0;
+  const int nb12 = G.g12x * G.g12y, nbs = G.gsx * G.gsy, nb2 = G.g2x * G.g2y;
+  if (b < nb12) {
+    model_levels12_body(tx, ty, BYv, b % G.g12x, b / G.g12x, G.m, G.cols0, G.rows1, G.cols1, G.rows2, G.cols2, G.v1, G.n1, G.v2, G.n2);
+  } else if (b < nb12 + nbs) {
+    const int c = b - nb12;
+    model_pyr_step1_body<BYv>(tx, ty, c % G.gsx, c / G.gsx, G.m, G.rows0, G.cols0, G.cutOff, G.depth1, G.inten1);
+  } else if (b < nb12 + nbs + nb2) {
+    const int c = b - nb12 - nbs;
+    model_pyr_step2_body<kPB>(t, c % G.g2x, c / G.g2x, G.m, G.rows0, G.cols0, G.cutOff, G.rows1, G.cols1, G.depth2, G.inten2);
+  } else {
+    const int c = b - nb12 - nbs - nb2;
+    model_level0_body(tx, ty, BYv, c % G.g0x, c / G.g0x, G.m, G.rows0, G.cols0, G.v0, G.n0, G.depth0, G.inten0, G.cutOff);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // The coarse half of a call in ONE resident launch (round 6): SO3 pre-alignment, level 2, level 1.  Every dependent launch on a
 // stream costs ~3.5 us of dispatch on this device plus the stage's own hand-off through HBM (state written back by block 0, reloaded
 // by every block of the next launch, ~2 us) - 92 us of launches for a quarter of level 0's pixel work.  The stages need nothing from
@@ -1859,6 +1910,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     if (e && atoi(e) > 0 && atoi(e) < o->max_resident_blocks) o->max_resident_blocks = atoi(e);
     e = getenv("DMS_AR_FIRST_DELAY");  // units of 64 cycles before the first read of the totals; default: by grid size
     if (e && atoi(e) >= 0 && atoi(e) <= 1000) o->first_delay = atoi(e);
+    e = getenv("DMS_SO3_BESIDE_MODEL");
+    if (e) o->so3_beside_model = atoi(e) != 0;
     e = getenv("DMS_TRACK_FUSE");
     if (e) o->fuse_coarse = atoi(e) != 0;
     e = getenv("DMS_AR_FIRST_DELAY_BY_LEVEL");  // "l0,l1,l2,so3" in the same units (-1 keeps the rule for that stage): the per-level sweep
@@ -2299,7 +2352,16 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   const bool folded = o->init_folded;
   So3Extra ex;
   memset(&ex, 0, sizeof(ex));
-  if (folded) {
+  const bool so3_ran = o->so3_in_model;  // the SO3 stage of this call ran inside the model pyramid launch (k_so3_model)
+  unsigned* first_gn_zero16 = nullptr;
+  if (so3_ran) {
+    o->so3_in_model = false;
+    o->early_init = false;
+    DMS_REQUIRE(so3 && o->folded_so3 == 1 && o->folded_first_level == first_level && o->folded_prior == prior_pose16_dev && prior_pose16_dev && !o->deferred_pyr,
+                "track call differs from the one its early set-up and SO3 stage were prepared for");
+    first_gn_zero16 = o->dense_cnt_zero;
+    o->dense_cnt_zero = nullptr;
+  } else if (folded) {
     o->init_folded = false;
     DMS_REQUIRE(so3 && so3_resident_blocks(o) > 0 && o->folded_so3 == (so3 ? 1 : 0) && o->folded_first_level == first_level &&
                     o->folded_prior == prior_pose16_dev && prior_pose16_dev,
@@ -2405,6 +2467,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     L.cy = o->cy;
     L.ar = o->ar + (size_t)(1 + l) * kArSetsPerKernel * kArWords;
     L.first_delay = o->first_delay_for(pnb, l);
+    L.zero16 = nullptr;
     L.prof = (o->profiling && !o->profiling_level0_only) ? o->prof : nullptr;
     // on for trackers that ask for it (the frame step's model-to-model pass) unless forced either way
     L.early_exit = o->early_exit_force >= 0 ? o->early_exit_force : (o->early_exit ? 1 : 0);
@@ -2426,7 +2489,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   // fit one grid: level 1's, with one pixel per thread at level 2
   bool coarse = false;
   int cP1 = 1, cnb = 0;
-  if (o->fuse_coarse && o->resident && so3 && iterations[2] > 0 && iterations[1] > 0) {
+  if (o->fuse_coarse && o->resident && so3 && !so3_ran && iterations[2] > 0 && iterations[1] > 0) {
     int P2 = 1, nb2 = 0;
     level_shape(2, P2, nb2);
     level_shape(1, cP1, cnb);
@@ -2459,7 +2522,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     else
       launch_track_coarse<false, true>(cP1, ee, cnb + ex.gx * ex.gy, s, o->state, F, ex);
     DMS_CHECK_LAUNCH();
-  } else if (so3) {
+  } else if (so3 && !so3_ran) {
     const int L = 2;
     const Buf& li = o->lastNextImage[L];
     const Buf& ni = o->nextImage[L];
@@ -2502,7 +2565,11 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     const int nb = track_blocks_for(a.cols * a.rows);
     const int level_below = level_below_of(l);
     if (persistent) {
-      const LevelArgs L = level_args_of(l, pnb);
+      LevelArgs L = level_args_of(l, pnb);
+      if (first_gn_zero16) {
+        L.zero16 = first_gn_zero16;
+        first_gn_zero16 = nullptr;
+      }
       if (l == 0) finalized_in_kernel = true;
       persist.begin();
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
@@ -2559,6 +2626,9 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     }
   }
 
+  if (first_gn_zero16) {  // (no resident level took it: launch-per-phase levels)
+    DMS_HIP(hipMemsetAsync(first_gn_zero16, 0, 16 * 16 * sizeof(unsigned), s));  // (the 16 counters, 64 bytes apart)
+  }
   if (!finalized_in_kernel) {
     Timer t(o, s, "track_finalize");
     // frame step (frame state given): the result is written back into the pose block the prior came from;
@@ -2834,6 +2904,37 @@ int odometry_next_buffers(dms_odometry* o, int level, dms_image2d* nextImage, dm
   return DMS_OK;
 }
 
+// The set-up of the frame step's NEXT tracker call as a block group of an EARLIER kernel of the frame (the tracking prediction's
+// resolve pass, fusion_map.hip): fills `ti` and returns 1 when this handle can take it (resident SO3 stage, the call odometry_initModel_fused
+// + odometry_track_enqueue are about to make), 0 otherwise (ti->blocks = 0: the set-up stays folded into the model pyramid kernel).
+// With the set-up done a kernel boundary ahead, odometry_initModel_fused runs the SO3 stage beside the model pyramid (k_so3_model).
+int odometry_early_init_args(dms_odometry* o, const TrackFold* fold, TrackInitArgs* ti) {
+  if (!o) return 0;
+  if (!fold && o->early_init && ti->inject_timeout) o->inject_timeouts += 1;  // (cancelled: the injected fault goes to the call's real set-up)
+  memset(ti, 0, sizeof(*ti));
+  o->early_init = false;
+  if (!fold || !o->so3_beside_model || !o->resident || !fold->prior_pose16 || !fold->so3 || fold->interMap || so3_resident_blocks(o) <= 0) return 0;
+  const int it1 = fold->pyramid ? 5 : 0, it2 = fold->pyramid ? 4 : 0;
+  ti->st = o->state;
+  ti->prior_pose16 = fold->prior_pose16;
+  ti->fx = o->fx;
+  ti->fy = o->fy;
+  ti->cx = o->cx;
+  ti->cy = o->cy;
+  ti->so3 = 1;
+  ti->first_level = it2 > 0 ? 2 : (it1 > 0 ? 1 : 0);
+  ti->sync_words = o->ar;
+  ti->n_sync = (int)((size_t)kArSets * kArWords / 2);
+  ti->inject_timeout = o->inject_timeouts > 0 ? 1 : 0;
+  if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
+  ti->blocks = 16;
+  o->early_init = true;
+  o->folded_so3 = 1;
+  o->folded_first_level = ti->first_level;
+  o->folded_prior = fold->prior_pose16;
+  return 1;
+}
+
 // initICPModel + initRGBModel of the frame step in four launches (prep.hip, modelPyramidFused).
 // The operator-layer staging copy vmaps_tmp is not written on this path; nextDepth is aliased to
 // lastDepth by the caller, so nothing reads it.
@@ -2873,14 +2974,76 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
     ti.first_level = it2 > 0 ? 2 : (it1 > 0 ? 1 : 0);
     ti.sync_words = o->ar;
     ti.n_sync = (int)((size_t)kArSets * kArWords / 2);
-    ti.inject_timeout = o->inject_timeouts > 0 ? 1 : 0;
-    if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
+    ti.inject_timeout = (!o->early_init && o->inject_timeouts > 0) ? 1 : 0;
+    if (!o->early_init && o->inject_timeouts > 0) o->inject_timeouts -= 1;
     ti.blocks = 16;
     o->init_folded = true;
     o->folded_so3 = 1;
     o->folded_first_level = ti.first_level;
     o->folded_prior = fold->prior_pose16;
   }
+  if (o->early_init && o->init_folded) {
+    // The set-up ran a kernel ahead: the resident SO3 stage goes beside the model pyramid's groups in ONE launch (k_so3_model), the
+    // pyramid's last step comes straight from the sources in that launch, nothing is deferred.
+    o->init_folded = false;
+    o->deferred_pyr = false;
+    o->so3_in_model = true;
+    ModelGroups G;
+    memset(&G, 0, sizeof(G));
+    G.m.vA = (const float4*)vA;
+    G.m.nA = (const float4*)nA;
+    G.m.iA = (const uchar4*)iA;
+    G.m.vB = (const float4*)vB;
+    G.m.nB = (const float4*)nB;
+    G.m.iB = (const uchar4*)iB;
+    G.m.flag = flag_dev;
+    G.m.dense_cnt = dense_cnt;
+    G.m.dense_samples = dense_samples;
+    G.m.flag_out = const_cast<int*>(flag_dev);
+    G.m.force_b_img = force_b_img;
+    G.m.pose16 = pose16_dev;
+    G.rows0 = v[0].rows / 3;
+    G.cols0 = v[0].cols;
+    G.rows1 = v[1].rows / 3;
+    G.cols1 = v[1].cols;
+    G.rows2 = v[2].rows / 3;
+    G.cols2 = v[2].cols;
+    DMS_REQUIRE(G.rows1 == G.rows0 / 2 && G.cols1 == G.cols0 / 2 && G.rows2 == G.rows1 / 2 && G.cols2 == G.cols1 / 2, "pyramid shapes");
+    constexpr int BYv = kPB / 64;
+    G.g0x = (G.cols0 + 63) / 64;
+    G.g0y = (G.rows0 + BYv - 1) / BYv;
+    G.g12x = ((G.cols1 + 1) / 2 + 15) / 16;
+    G.g12y = ((G.rows1 + 1) / 2 + BYv - 1) / BYv;
+    G.gsx = (d[1].cols + 63) / 64;
+    G.gsy = (d[1].rows + BYv - 1) / BYv;
+    G.g2x = (d[2].cols + 15) / 16;
+    G.g2y = (d[2].rows + 7) / 8;
+    G.cutOff = o->maxDepthRGB;
+    G.v0 = view<float>(&v[0]);
+    G.n0 = view<float>(&n[0]);
+    G.depth0 = view<float>(&d[0]);
+    G.inten0 = view<unsigned char>(&im[0]);
+    G.v1 = view<float>(&v[1]);
+    G.n1 = view<float>(&n[1]);
+    G.v2 = view<float>(&v[2]);
+    G.n2 = view<float>(&n[2]);
+    G.depth1 = view<float>(&d[1]);
+    G.inten1 = view<unsigned char>(&im[1]);
+    G.depth2 = view<float>(&d[2]);
+    G.inten2 = view<unsigned char>(&im[2]);
+    const Buf& li = o->lastNextImage[2];
+    const Buf& ni = o->nextImage[2];
+    const int nbs = so3_resident_blocks(o);
+    const So3Args q = {(const unsigned char*)li.p, li.pitch, (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, SolveCam{o->fx, o->fy, o->cx, o->cy},
+                       o->folded_first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbs, 3)};
+    PersistSection persist(s, o->max_resident_blocks);
+    persist.begin();
+    Timer t(o, s, "so3_model");
+    hipLaunchKernelGGL(k_so3_model, dim3(nbs + G.g12x * G.g12y + G.gsx * G.gsy + G.g2x * G.g2y + G.g0x * G.g0y), dim3(kPB), 0, s, o->state, q, nbs, G);
+    DMS_CHECK_LAUNCH();
+    return DMS_OK;
+  }
+  o->early_init = false;
   return modelPyramidFused(vA, nA, iA, vB, nB, iB, flag_dev, force_b_img, pose16_dev, v, n, d, im, o->maxDepthRGB, s, o->deferred_pyr, dense_cnt,
                            dense_samples, const_cast<int*>(flag_dev), o->init_folded ? &ti : nullptr);
 }

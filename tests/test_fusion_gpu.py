@@ -1762,3 +1762,31 @@ def test_frame_step_with_the_coarse_tracker_launch_is_bit_identical(monkeypatch)
             ef.close()
         assert out[0][2] == out[1][2] > 100_000 and out[0][0] == out[1][0], (W2, H2)
         assert out[0][1] == out[1][1], "the maps differ"
+
+
+def test_frame_step_with_so3_beside_the_model_pyramid_is_bit_identical(monkeypatch):
+    """DMS_SO3_BESIDE_MODEL=1 (round 6, off by default: no faster on the MI355X): the tracker call's set-up rides on the frame's first kernel
+    (rider blocks of the tracking prediction's resolve pass), the resident SO3 stage and the model pyramid's groups run side by side in ONE
+    launch (k_so3_model) and the pyramid's last step is taken straight from the sources (model_pyr_step2_body) instead of riding on the
+    SO3 launch.  Same poses, same map, frame after frame, at both BASELINE sizes and with a pose prior on some frames (no shared
+    projection then: the set-up rides on a resolve pass that follows a projection)."""
+    from densemonoslam_amd import capi, fusion, synth
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    for (W2, H2, K2) in ((640, 480, synth.K_640), (1241, 376, synth.K_KITTI)):
+        out = []
+        for on in ("0", "1"):
+            monkeypatch.setenv("DMS_SO3_BESIDE_MODEL", on)
+            ef = fusion.ElasticFusion(W2, H2, K2, model_capacity=4_000_000)
+            poses, last = [], None
+            for k in range(7):
+                d, rgb, _ = synth.frame(2 * k, width=W2, height=H2, K=K2, noise=True)
+                prior = last if k in (3, 5) else None  # (the previous pose handed back as a prior: same estimate, the other code path)
+                r = ef.processFrame(rgb, d, prior) if prior is not None else ef.processFrame(rgb, d)
+                last = np.array(r.pose, np.float32).reshape(4, 4)
+                poses.append(last.tobytes())
+            m = ef.globalModel().downloadMap()
+            out.append((poses, {f: m[f].tobytes() for f in m.dtype.names}, len(m)))
+            ef.close()
+        assert out[0][2] == out[1][2] > 100_000 and out[0][0] == out[1][0], (W2, H2)
+        assert out[0][1] == out[1][1], "the maps differ"
