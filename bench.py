@@ -354,6 +354,7 @@ def main():
     # watchdog prints the line with that figure if the loop does not finish.
     session_loop = distributed or args.session_loop
     sess = None
+    sess_transport = [None]  # (kept for the session_across_ranks leg)
     headline_loop = "dms_fusion_process_frame (one camera, no session)" if not distributed else (
         "fall-back: collab.InterMapMatcher over torch.distributed (round-3 exchange)")
     fallback = None
@@ -381,6 +382,11 @@ def main():
                         "session_loop_error": "dms_session_step_async over the transport did not finish within %d s" % limit_s,
                         "config": {"workload": "TUM fr1/desk-like 640x480 full 3-level ICP+RGB tracking + surfel fusion, one camera per GPU, "
                                                "round-3 exchange (fall-back)", "resolution": [W, H], "cameras_per_gpu": 1}}
+                try:
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:  # noqa: BLE001
+                    pass
                 print(json.dumps(line))
                 sys.stdout.flush()
             os._exit(0)
@@ -444,6 +450,7 @@ def main():
                         block_bytes=int(collab.thumbnail_bytes(W, H)))
             ns.close()
             capi.destroy_stream(st_s)
+            sess_transport[0] = tr
             headline_loop = "dms_session_step_async over %s" % ("dms_transport_rccl" if tmode == "rccl" else tmode)
             elapsed, t_enq, M, M_total = el_s, t_enq_s, sess["surfels"], sess["surfels_total"]
         sess_done.set()
@@ -727,8 +734,9 @@ def main():
         from densemonoslam_amd import session as session_mod
 
         n_ticks, q_from, off = 16, 6, 8
-        tr = (session_mod.RcclTransport(collab.rccl_carrier_from_process_group(rank, world)) if backend == "nccl"
-              else session_mod.TorchTransport(rank, world))
+        # (the headline loop's transport - ONE communicator of the library's per process - when that loop ran)
+        tr = sess_transport[0] if sess_transport[0] is not None else (
+            session_mod.RcclTransport(collab.rccl_carrier_from_process_group(rank, world)) if backend == "nccl" else session_mod.TorchTransport(rank, world))
         ns = session_mod.NativeSession(W, H, K, world, rank=rank, world=world, transport=tr, query_from=q_from, model_capacity=8_000_000)
         tick_ms = []
         for k in range(n_ticks):
@@ -1098,7 +1106,14 @@ def main():
         }
 
     if rank == 0:
+        # (RCCL prints its version banner through C stdio, which - redirected to a file - is flushed at exit, BEHIND this line:
+        # flush it first so that the JSON line is the last line of stdout)
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(out))
+        sys.stdout.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

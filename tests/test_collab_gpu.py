@@ -73,3 +73,34 @@ def test_matcher_through_the_binding_equals_the_local_copy(carrier):
     for a, b in zip(res[0][0], res[1][0]):
         assert a.tobytes() == b.tobytes()
     assert res[0][1] == res[1][1] >= 1
+
+
+def test_a_rank_that_never_arrives_is_an_error_not_a_hang():
+    """dms_collab_create for rank 0 of 2 whose peer never calls it: ncclCommInitRank would block for ever; the library runs it on a helper
+    thread and returns DMS_ERR_TIMEOUT after DMS_RCCL_INIT_TIMEOUT_S.  In a child process (the stuck helper thread ends with it)."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    code = (
+        "import sys, time, ctypes as C\n"
+        "import torch\n"
+        "from densemonoslam_amd import capi, collab\n"
+        "assert capi.device_count() >= 1\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    collab.RcclCarrier(0, 2, collab.RcclCarrier.unique_id())\n"
+        "    print('CREATED')\n"
+        "except Exception as e:\n"
+        "    print('ERR %.1f %s' % (time.time() - t0, e))\n"
+        "sys.stdout.flush()\n"
+        "import os\n"
+        "os._exit(0)\n")
+    env = dict(os.environ, DMS_RCCL_INIT_TIMEOUT_S="4", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    out = r.stdout.strip().splitlines()
+    line = [l for l in out if l.startswith("ERR") or l.startswith("CREATED")]
+    assert line and line[-1].startswith("ERR"), (r.stdout[-400:], r.stderr[-400:])
+    assert "did not return within" in line[-1] and time.time() - t0 < 120, line[-1]
