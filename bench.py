@@ -368,7 +368,7 @@ def main():
                             "torch.distributed, descriptor search) - timed first, the headline only if the session loop below fails" if exchange_on
                             else "the bare frame step (dms_fusion_process_frame, no session)"}
         sess = {"loop": "dms_session_step_async", "error": None}
-        limit_s = int(os.environ.get("DMS_BENCH_SESSION_LIMIT", "240"))
+        limit_s = int(os.environ.get("DMS_BENCH_SESSION_LIMIT", "180"))
         sess_done = threading.Event()
 
         def headline_watchdog():
@@ -835,7 +835,7 @@ def main():
     if distributed and (W, H) == (640, 480) and not args.loop_closure and (sess_env == "1" or (sess_env != "0" and backend == "nccl")):
         import threading
 
-        limit_s = int(os.environ.get("DMS_BENCH_SESSION_LIMIT", "240"))
+        limit_s = int(os.environ.get("DMS_BENCH_SESSION_LIMIT", "180"))
 
         def give_up():
             if rank == 0:

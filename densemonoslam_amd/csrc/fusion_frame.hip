@@ -1273,7 +1273,6 @@ int dms_fusion_process_frame_end(dms_fusion* f, const float* graph_host, int gra
   DMS_REQUIRE(f->in_frame, "dms_fusion_process_frame_begin has not been called");
   DMS_REQUIRE(graph_nodes == 0 || graph_host, "null graph");
   hipStream_t s = (hipStream_t)st;
-  const int k2 = f->cur_k2;
   int rc;
   int fused = 0;
   bool surfels_written = false;
