@@ -131,6 +131,7 @@ struct dms_odometry {
   int first_delay = -1;               // integer all-reduce: pause before the first read of the totals (DMS_AR_FIRST_DELAY; -1 = by grid size)
   // the later the last arrival can be after one's own, the longer the pause pays: ~0.4 us on the 150 / 200-block levels, next to
   // nothing on 38 blocks (measured: level 2 is best at 0 - 8 units, levels 1 and 0 at 12 - 20)
+  bool long_levels_resident = true;   // levels of more than kArRing iterations (inter-map calls: 50) as resident launches too (DMS_TRACK_LONG_RESIDENT=0: launch-per-phase, as before round 6)
   bool fuse_coarse = false;           // SO3 + level 2 + level 1 in one resident launch (k_track_coarse; DMS_TRACK_FUSE=1).  Built and bit-identical, but SLOWER on the MI355X: off
   unsigned* rider_cnt = nullptr;      // device: rider blocks of k_track_coarse launches that have finished (runs over the life of the handle)
   unsigned rider_issued = 0;          // host: rider blocks enqueued so far
@@ -858,7 +859,8 @@ constexpr int kArPairStride = 16;                   // apart from the lines the 
 constexpr int kArWords = kArPairBase + kArShards * kArPairStride;  // 5 KB per reduction
 constexpr int kArSlotCnt = 0, kArSlotSig = 1;
 constexpr int kArPool = 6;                          // extra word sets per resident launch for repeated reductions
-constexpr int kArSetsPerKernel = 10 + kArPool;      // <= 10 iterations per resident launch
+constexpr int kArRing = 10;                          // word sets a stage cycles through, one per iteration (re-armed in flight when a level runs more iterations)
+constexpr int kArSetsPerKernel = kArRing + kArPool;
 constexpr int kArSets = 4 * kArSetsPerKernel;       // SO3 + three levels
 
 __device__ __forceinline__ unsigned long long pair_pack(unsigned long long v) { return (1ull << 58) + v; }
@@ -1093,7 +1095,9 @@ __device__ __forceinline__ void gn_level_body(TrackState* st, TrackState* sv, co
     // grid-wide reductions): pass 1 done | count pair complete | pass 2 + block sum done | totals complete
     const bool stamp = L.prof && L.level == 0 && it == L.n_iter / 2 && tid == 0;
     if (stamp) L.prof[48 + blockIdx.x * 8 + 0] = wall_clock64();
-    const size_t set = (size_t)(on_pool ? 10 + pool_used - 1 : it) * kArWords;
+    // word set of this iteration: one of a RING of kArRing sets (a level may run more iterations than the ring has sets - the 50 of an
+    // inter-map call: the set of iteration it - 1 is re-armed during iteration it, below), or the next set of the retry pool
+    const size_t set = (size_t)(on_pool ? kArRing + pool_used - 1 : it % kArRing) * kArWords;
     unsigned long long* arw = L.ar + set + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride;
     const unsigned long long* arp = L.ar + set;
     unsigned long long* arq = L.ar + set + kArPairBase + (size_t)(blockIdx.x & (kArShards - 1)) * kArPairStride;
@@ -1224,6 +1228,15 @@ __device__ __forceinline__ void gn_level_body(TrackState* st, TrackState* sv, co
     __syncthreads();
     phase(5);
     if (stamp) L.prof[48 + blockIdx.x * 8 + 3] = wall_clock64();
+    // Re-arm the ring: every block has arrived in THIS iteration's totals, so every block finished reading the previous iteration's set
+    // (a block adds to a set only after it has taken the totals of the set before).  Block 0 zeroes it - only when the level will come
+    // round to it again - and releases the stores; the set is next used kArRing - 1 iterations (>= 60 us) later, by blocks that have seen
+    // block 0's later arrivals.
+    if (L.n_iter > kArRing && blockIdx.x == 0 && it >= 1 && it - 1 + kArRing < L.n_iter) {
+      unsigned long long* prev = L.ar + (size_t)((it - 1) % kArRing) * kArWords;
+      for (int w = tid; w < kArWords; w += kPB) prev[w] = 0ull;
+      __threadfence();
+    }
     if (s_viol) {
       // a diagonal total does not fit the grid its exponents promised: every block saw the same totals, so the whole
       // grid raises the exponents of that reduction and repeats the iteration on a word set of the pool (uniform)
@@ -1466,7 +1479,7 @@ __device__ __forceinline__ void so3_body(TrackState* st, TrackState& s, const So
       found[0] = false;
       rows_[0][0] = rows_[0][1] = rows_[0][2] = rows_[0][3] = 0.f;
     }
-    const size_t set = (size_t)(on_pool ? 10 + pool_used - 1 : it) * kArWords;
+    const size_t set = (size_t)(on_pool ? kArRing + pool_used - 1 : it) * kArWords;  // (max_iter <= kArRing)
     const double pt = canon::block_sum<3, 1, kPWaves>(rows_, found, s_bias, s_red);
     if (tid < kSO3)
       __hip_atomic_fetch_add(ar + set + (size_t)(blockIdx.x & (kArShards - 1)) * kArStride + tid, canon::pack_word(canon::to_units(pt, eb_mine)),
@@ -1910,6 +1923,8 @@ int dms_odometry_create(dms_odometry** out, int width, int height, float cx, flo
     if (e && atoi(e) > 0 && atoi(e) < o->max_resident_blocks) o->max_resident_blocks = atoi(e);
     e = getenv("DMS_AR_FIRST_DELAY");  // units of 64 cycles before the first read of the totals; default: by grid size
     if (e && atoi(e) >= 0 && atoi(e) <= 1000) o->first_delay = atoi(e);
+    e = getenv("DMS_TRACK_LONG_RESIDENT");
+    if (e) o->long_levels_resident = atoi(e) != 0;
     e = getenv("DMS_SO3_BESIDE_MODEL");
     if (e) o->so3_beside_model = atoi(e) != 0;
     e = getenv("DMS_TRACK_FUSE");
@@ -2481,7 +2496,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   auto level_shape = [&](int l, int& pP, int& pnb) {
     pP = 1;
     pnb = 0;
-    if (o->resident && iterations[l] <= 10)
+    if (o->resident && (iterations[l] <= kArRing || o->long_levels_resident))  // (more iterations than ring sets: the ring is re-armed in flight)
       persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, o->max_resident_blocks, pP, pnb);
   };
 
@@ -2489,7 +2504,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
   // fit one grid: level 1's, with one pixel per thread at level 2
   bool coarse = false;
   int cP1 = 1, cnb = 0;
-  if (o->fuse_coarse && o->resident && so3 && !so3_ran && iterations[2] > 0 && iterations[1] > 0) {
+  if (o->fuse_coarse && o->resident && so3 && !so3_ran && iterations[2] > 0 && iterations[1] > 0 && iterations[2] <= kArRing && iterations[1] <= kArRing) {
     int P2 = 1, nb2 = 0;
     level_shape(2, P2, nb2);
     level_shape(1, cP1, cnb);
