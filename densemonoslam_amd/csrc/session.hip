@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <set>
@@ -113,6 +115,19 @@ namespace {
 using ::dms::set_error;
 
 int host_of_camera(const dms_session* s, int c) { return s->host_of_frame.at(s->frame_of[c]); }
+
+// DMS_SESSION_TRACE=1: host-side wall-clock marks of the inter-map block (query, refinement, merge) on stderr - where a woken tick's time goes
+struct Trace {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  Trace() : on(getenv("DMS_SESSION_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what, int a = -1, int b = -1) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dms_session] %-28s %2d %2d  %8.3f ms\n", what, a, b, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 std::vector<int> hosted(const dms_session* s) {
   std::vector<int> v;
@@ -591,7 +606,9 @@ int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<in
   // row and every rank returns together.
   const size_t tab_floats = (size_t)(s->n + 1) * s->n * kRow;
   std::vector<float> table(tab_floats, 0.f), tables(tab_floats * s->world, 0.f);
+  Trace tr;
   int qrc = query(s, k, only, poses, ticks, blocks, table.data(), st);
+  tr.mark("queries (findFrame)", k);
   if (qrc) table[(size_t)s->n * s->n * kRow] = 1.f;
   if ((rc = dms_memcpy_h2d(s->d_table, table.data(), tab_floats * 4, st))) return rc;
   if ((rc = t_allgather(s, s->d_table, s->d_table + tab_floats, tab_floats * 4, st)) || (rc = sync(st))) return rc;
@@ -626,7 +643,9 @@ int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<in
       d.fa = fa;
       if (s->p.full_refine) {
         int accepted = 0;
+        tr.mark("table + walk", a, fb);
         if ((rc = refine(s, a, fb, e + 2, poses.at(a).data(), ticks.at(a), &accepted, d.T, st))) return rc;
+        tr.mark("refine", a, fb);
         s->refinements.push_back(Refinement{k, a, fb, accepted});
         if (!accepted) continue;
       } else {
@@ -639,8 +658,11 @@ int decide_and_merge(dms_session* s, int k, unsigned long long only, std::map<in
     }
   }
   // 6. merges
-  for (auto& d : decided)
+  for (auto& d : decided) {
     if ((rc = merge(s, k, d.fb, d.fa, d.T, st))) return rc;
+    if ((rc = sync(st))) return rc;
+    tr.mark("merge", d.fb, d.fa);
+  }
   return DMS_OK;
 }
 
