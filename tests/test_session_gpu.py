@@ -677,3 +677,32 @@ def test_queries_inside_the_frame_two_ranks(orc):
     ref = run_oracle_session_n(FOUR_OFFSETS, ticks, query_inside_frame=True)
     results = spawn(2, _worker_n, ("native", ticks, FOUR_OFFSETS, False, dict(query_inside_frame=True)))
     check_four(ref, results, 2, ticks)
+
+
+def test_pipelined_session_over_a_one_rank_rccl_communicator(pipelined_oracle):
+    """The pipelined tick with the RCCL transport (what `bench.py --gpus N` times): with a transport even a one-rank session takes the
+    multi-rank arrangement - every map's frames on a stream of its own, the exchange (key-frame insertion, a real ncclAllGather of the frame
+    blocks, descriptor search, host mirror) on the caller's stream beside the next frames, the all-gather bracketed by HIP events
+    (time_exchange).  Same wake, merge and bits as the oracle session on that schedule."""
+    from densemonoslam_amd import capi, collab, session, synth
+
+    assert capi.device_count() >= 1, "no MI355X visible"
+    ref = pipelined_oracle
+    sc = SCENARIOS["reference_rule"]
+    tr = session.RcclTransport(collab.RcclCarrier(0, 1, collab.RcclCarrier.unique_id()))
+    assert "rccl" in tr.carrier.library_path()
+    s = session.NativeSession(W, H, K, 2, rank=0, world=1, transport=tr, fern_photo_thresh=sc.fern_photo, model_capacity=2_000_000, time_exchange=True,
+                              **sc.opts)
+    row = lambda c: np.arange(6, dtype=np.float32) * np.float32(0.25 + c)
+    for c in s.hosted():
+        s.addRelativeConstraint(c, row(c)[:3], row(c)[3:])
+    for k in range(PIPE_TICKS):
+        s.step(k, sc.frames(synth, k), pipelined=True)
+    s.sync()
+    assert s.async_stats() == {"ticks": PIPE_TICKS, "woken": len(ref.woken)}
+    ms, n = s.exchange_time()
+    assert n >= PIPE_TICKS - 3 and 0.0 < ms / n < 5.0, (ms, n)  # (the all-gathers of the ticks whose completion the host has seen; a one-rank gather is a copy)
+    fb = ref.merges[0][1]
+    host = dict(map=s.cams[fb].model(), fern_frames=len(s.ferns[fb]), pose_graph=s.pose_graph, relative_cons=s.relative_cons)
+    _check(ref, host, s.merges, PIPE_TICKS)
+    s.close()
