@@ -10,6 +10,7 @@
 // Pass 1 streams only the position/normal planes; the colour plane is touched for winners only.
 #include <vector>
 
+#include "exact_arith.hpp"
 #include "scan.hpp"
 #include "smallmath.hpp"
 #include "surfel.hpp"
@@ -914,6 +915,34 @@ __device__ __forceinline__ bool splat_fragment(const ProjArgs& a, const SplatSur
   return true;
 }
 
+// The same fragment in fewer instructions for the project pass, whose sprite loop is bound by vector-instruction issue: four IEEE
+// quotients, a square root and the 64-bit depth conversion were 70 of a fragment's 115 instructions.  exact_arith.hpp: the divisors
+// fx, fy and 2 maxDepth are constants of the launch (reciprocal once, two correction steps per quotient); the ray's squared length is
+// in [1, 16) for any pixel within 3.8 focal lengths of the principal point (square root without the small-operand scaling, reciprocal
+// by one Newton step - both compared with the IEEE results over their whole domains on the device).  Same bits as splat_fragment:
+// the accept / reject decision, the depth and `corrected` (a -0 quotient becomes +0 only where 0.5 is added next or the operand is
+// an exact difference, which is never -0; NaN / infinite depths are rejected on both sides).
+struct SplatRay {
+  exact::Divisor fx, fy, z2;
+};
+__device__ __forceinline__ SplatRay splat_ray_consts(const ProjArgs& a) {
+  return SplatRay{exact::divisor(a.fx), exact::divisor(a.fy), exact::divisor(2.f * a.maxDepth)};
+}
+__device__ __forceinline__ bool splat_fragment_lean(const SplatRay& rc, const ProjArgs& a, const SplatSurfel& s, int px, int py, f3& corrected, float& zw) {
+  const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;  // gl_FragCoord
+  const f3 v = mk3(exact::div(fcx - a.cx, rc.fx), exact::div(fcy - a.cy, rc.fy), 1.0f);
+  const float vv = dot3(v, v);
+  const float rn = vv < 16.f ? exact::rcp_1_4(exact::sqrt_normal(vv)) : 1.0f / sqrtf(vv);
+  const f3 l = mk3(v.x * rn, v.y * rn, v.z * rn);
+  const float k = dot3(s.pos, s.nrm) / dot3(l, s.nrm);
+  corrected = mk3(k * l.x, k * l.y, k * l.z);
+  const float sqrRad = s.rad * s.rad;
+  const f3 diff = corrected - s.pos;
+  if (dot3(diff, diff) > sqrRad) return false;
+  zw = exact::div(corrected.z, rc.z2) + 0.5f;
+  return true;
+}
+
 // sprite coverage: pixel centres inside [c - size/2, c + size/2); a size below 1 rasterises as 1
 __device__ __forceinline__ void sprite_range(float c, float size, int n, int& lo, int& hi) {
   const float sz = fmaxf(size, 1.0f);
@@ -943,6 +972,7 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
   __shared__ unsigned s_w[4];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const unsigned M = d_count[0];
+  const SplatRay ray = splat_ray_consts(a);
   // position and time of the next chunk are fetched while this one is scanned and rasterised: on a large map
   // most chunks are culled as a whole, and their cost would otherwise be one exposed memory round trip each
   float4 pc_next = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1067,19 +1097,25 @@ __global__ __launch_bounds__(256) void k_splat_project(ProjArgs a, SurfelPlanes 
           z1[k] = (in && use1) ? zbuf[q] : 0ull;
           z2[k] = (in && use2) ? zbuf2[q] : 0ull;
         }
+        // (the four ray / disc tests first, the atomics behind them: an atomic between two tests made the next test wait for it -
+        // the counter that guards the prefetched cells also counts the atomics in flight)
+        unsigned long long key[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int px = px0 + k;
-          if (px > xb) break;
+          key[k] = ~0ull;
           f3 c;
           float zw;
-          if (!splat_fragment(a, s, px, py, c, zw)) continue;
-          const unsigned d = depth24(zw);
-          if (d >= 0xFFFFFFu) continue;
-          const unsigned long long key = ((unsigned long long)d << 32) | id;
-          const size_t q = (size_t)px * a.rows + py;
-          if (key < z1[k]) atomicMin(zbuf + q, key);
-          if (DUAL && key < z2[k]) atomicMin(zbuf2 + q, key);
+          if (px <= xb && splat_fragment_lean(ray, a, s, px, py, c, zw)) {
+            const unsigned d = depth24(zw);
+            if (d < 0xFFFFFFu) key[k] = ((unsigned long long)d << 32) | id;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const size_t q = (size_t)(px0 + k) * a.rows + py;
+          if (key[k] < z1[k]) atomicMin(zbuf + q, key[k]);
+          if (DUAL && key[k] < z2[k]) atomicMin(zbuf2 + q, key[k]);
         }
       }
     }

@@ -36,7 +36,7 @@ __host__ __device__ __forceinline__ int texel(float u, float n_f, int n) {
 __host__ __device__ __forceinline__ unsigned depth24(float zw) {
   if (!(zw >= 0.f)) return 0xFFFFFFFFu;  // clipped (also NaN)
   if (zw > 1.f) return 0xFFFFFFFFu;
-  return (unsigned)llrint((double)zw * 16777215.0);
+  return (unsigned)(int)rint((double)zw * 16777215.0);  // (at most 2^24 - 1: the 32-bit conversion is the 64-bit one's value)
 }
 
 // mat4 * (p, 1): row-major, accumulated left to right, translation last

@@ -98,6 +98,13 @@ const char* dms_last_error(void); /* thread-local text of the last failure */
 int dms_device_count(int* count);
 int dms_set_device(int device);
 
+/* Device self-test of csrc/exact_arith.hpp: the map kernels' short correctly-rounded quotient / reciprocal / square-root sequences
+ * against the compiler's IEEE sequences, operand by operand on the current device (default stream, synchronous).
+ *   what 0: square root of every finite float >= 2^-96;  1: reciprocal of every float in [1, 4);
+ *        2: a / d for a = 0 and every finite |a| >= 2^-96 whose quotient is finite and >= 2^-96 in size, for the divisor d (a camera constant)
+ * mismatches: operands whose result bits differ (0 is the only acceptable answer); first_bad: the largest such operand's bits. */
+int dms_exact_arith_selftest(int what, float d, unsigned long long* mismatches, unsigned* first_bad);
+
 /* bytes of device workspace the reduction operators need (partials + result) */
 size_t dms_reduce_workspace_bytes(void);
 
