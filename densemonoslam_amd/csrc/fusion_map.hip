@@ -1228,6 +1228,9 @@ int splat_predict(dms_model* m, const dms_pose_block* pose, const dms_camera* ca
   DMS_REQUIRE(!init || init->blocks == 0 || (fill && !depth_out), "the tracker set-up rides on the fused resolve + fill-in pass only");
   DMS_REQUIRE(!m->pending_update, "a deferred update pass is still pending (index_map applies it)");
   DMS_REQUIRE(timeIdx >= 0 && timeIdx < DMS_MAX_SENSORS, "timeIdx out of range");
+  // (the project pass divides by fx, fy and 2 maxDepth through exact_arith.hpp: normal numbers far from the ends of the exponent range)
+  DMS_REQUIRE(fabsf(cam->fx) > 1e-18f && fabsf(cam->fx) < 1e18f && fabsf(cam->fy) > 1e-18f && fabsf(cam->fy) < 1e18f && maxDepth > 1e-18f && maxDepth < 1e18f,
+              "focal lengths and depth cut-off must be finite, non-zero and within 1e-18 .. 1e18");
   const int W = m->width, H = m->height;
   if (depth_out)
     DMS_REQUIRE(dense_img(*depth_out, 4, W, H), "depth target must be dense W×H f32");
