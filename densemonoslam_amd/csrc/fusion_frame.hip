@@ -1505,6 +1505,11 @@ int dms_fusion_arm_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst
   return DMS_OK;
 }
 int dms_fusion_frame_block_written(dms_fusion* f) { return f && f->armed_written ? 1 : 0; }
+int dms_fusion_wait_frame_done(dms_fusion* f, dms_stream waiter) {
+  DMS_REQUIRE(f && f->last_slot >= 0 && f->frames > 0, "no frame has been enqueued");
+  DMS_HIP(hipStreamWaitEvent((hipStream_t)waiter, f->ev_main_done[f->last_slot], 0));
+  return DMS_OK;
+}
 
 int dms_fusion_get_loop_constraints(dms_fusion* f, float* rows7_host, int max_rows, int* n) {
   DMS_REQUIRE(f && n && (rows7_host || max_rows == 0), "null argument");

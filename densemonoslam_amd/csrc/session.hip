@@ -103,6 +103,7 @@ struct dms_session {
   };
   std::vector<MapStream> map_streams;  // a small pool: the hosted maps take its streams in turn (more streams than hardware queues cost more than they overlap)
   bool fused_block = true;  // the frame block written by the frame's last kernel (DMS_SESSION_FUSED_BLOCK=0: a launch of its own, the A/B switch)
+  bool join_by_frame_event = true;  // DMS_SESSION_JOIN_BY_FRAME_EVENT=0: a marker of the session's own behind the frames of every map stream (round 5)
   int n_map_streams = 2;  // (measured on one MI355X, 2 - 8 cameras: two beat one by 5 - 35 %, three and four are no better, four lose with 8 cameras)
   int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
   std::set<int> wake_ticks;        // ticks that run the full inter-map block: a search three ticks earlier hit
@@ -814,6 +815,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   }
   if (const char* e = getenv("DMS_SESSION_MAP_STREAMS")) s->n_map_streams = std::max(0, std::min(16, atoi(e)));
   if (const char* e = getenv("DMS_SESSION_FUSED_BLOCK")) s->fused_block = atoi(e) != 0;
+  if (const char* e = getenv("DMS_SESSION_JOIN_BY_FRAME_EVENT")) s->join_by_frame_event = atoi(e) != 0;
   s->n = p->n_cameras;
   s->W = p->camera.width;
   s->H = p->camera.height;
@@ -1033,6 +1035,8 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
   const size_t T0 = s->tail_off, B = s->ablock_bytes;
   std::map<int, hipStream_t> cam_stream;
   std::set<dms_session::MapStream*> used;
+  std::map<dms_session::MapStream*, int> last_cam_of;   // the camera whose frame is the stream's last this tick
+  std::set<dms_session::MapStream*> own_marker;         // a launch of the session's own follows a frame there: its event must be recorded
   for (int c = 0; c < s->n; ++c) {
     const int src = c % s->world, host = host_of_camera(s, c);
     if (src != host && src == s->rank) {
@@ -1063,17 +1067,27 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
     }
     if (!wake) {
       cam.tick += 1;  // ElasticFusion.cpp:588-591 (the camera is never lost without relocalisation)
-      if (!dms_fusion_frame_block_written(cam.f) &&
-          (rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, (dms_stream)fs)))
+      const bool own_launch = !dms_fusion_frame_block_written(cam.f);
+      if (own_launch && (rc = dms_fusion_frame_block(cam.f, blk, (float*)(blk + T0 + kTailPose), (int*)(blk + T0 + kTailTick), cam.tick, (dms_stream)fs)))
         return rc;
-      if (ms) used.insert(ms);
+      if (ms) {
+        used.insert(ms);
+        last_cam_of[ms] = c;
+        if (own_launch || src != s->rank) own_marker.insert(ms);  // (a forwarded camera's frame runs on the caller's stream: ms is null there anyway)
+      }
     }
   }
-  for (dms_session::MapStream* ms : used)  // the exchange below reads the blocks on the caller's stream
+  for (dms_session::MapStream* ms : used) {  // the exchange below reads the blocks on the caller's stream
+    // (when the frames wrote their blocks themselves, the stream's last frame's own completion event is the join: no marker behind it)
+    if (!own_marker.count(ms) && s->join_by_frame_event) {
+      if ((rc = dms_fusion_wait_frame_done(s->cams.at(last_cam_of.at(ms)).f, st))) return rc;
+      continue;
+    }
     if (hipEventRecord(ms->blocks, ms->s) != hipSuccess || hipStreamWaitEvent(hs, ms->blocks, 0) != hipSuccess) {
       set_error("dms_session_step_async: joining a map's stream failed");
       return DMS_ERR_HIP;
     }
+  }
   if (wake) {
     // a woken tick is a synchronous one: the previous tick's rows first, then this tick's results from the contexts
     if ((rc = consume_entry(s, s->ring[(k + 1) & 1], true))) return rc;

@@ -22,6 +22,7 @@
 // converged/diverged, rgbOnly break) live in a device state block; kernels past an exit
 // return at once, which reproduces the host `break`s.  One D2H copy of the result block
 // (pinned) ends the call.
+#include <hip/hip_ext.h>
 #include <math.h>
 
 #include <map>
@@ -2277,8 +2278,34 @@ struct PersistSection {
     g_persist.used[dev] = true;
     active = true;
   }
+  // The section's LAST resident launch can carry the chain's event itself (its completion signal) instead of a marker recorded behind
+  // it: between two kernels of one stream a marker is a gap of about 7 us (rocprofv3, the session loop: level 0 -> index map).  Returns
+  // null when no event is owed (one stream only so far) - then nothing changes.
+  bool closed = false;
+  hipEvent_t closing_event() {
+    if (!active || !g_persist.chained[dev] || !ext_events()) return nullptr;
+    if (!g_persist.ev[dev] && hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      g_persist.ev[dev] = nullptr;
+      return nullptr;
+    }
+    closed = true;
+    g_persist.ev_valid[dev] = true;
+    return g_persist.ev[dev];
+  }
+  static bool ext_events() {
+    static const bool on = [] {
+      const char* e = getenv("DMS_PERSIST_EXT_EVENT");
+      return !e || atoi(e) != 0;
+    }();
+    return on;
+  }
   ~PersistSection() {
     if (!active) return;
+    if (closed) {
+      g_persist.mu.unlock();
+      return;
+    }
     if (g_persist.chained[dev]) {
       if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
       g_persist.ev_valid[dev] = g_persist.ev[dev] && hipEventRecord(g_persist.ev[dev], s) == hipSuccess;
@@ -2288,25 +2315,33 @@ struct PersistSection {
   }
 };
 
-template <bool ICP, bool RGB, bool EXIT>
-static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
-  if (P == 1)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 1, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
-  else if (P == 2)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 2, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
-  else if (P == 3)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 3, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
-  else if (P == 4)
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 4, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+// `done`: an event that fires with THIS launch's completion signal (hipExtLaunchKernelGGL) - no marker packet behind the kernel
+template <bool ICP, bool RGB, int P, bool EXIT>
+static void launch_gn_level_p(int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L, hipEvent_t done) {
+  if (done)
+    hipExtLaunchKernelGGL((k_gn_level<ICP, RGB, P, EXIT>), dim3(nb), dim3(kPB), 0, s, nullptr, done, 0, st, a, L);
   else
-    hipLaunchKernelGGL((k_gn_level<ICP, RGB, 5, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+    hipLaunchKernelGGL((k_gn_level<ICP, RGB, P, EXIT>), dim3(nb), dim3(kPB), 0, s, st, a, L);
+}
+template <bool ICP, bool RGB, bool EXIT>
+static void launch_gn_level_f(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L, hipEvent_t done) {
+  if (P == 1)
+    launch_gn_level_p<ICP, RGB, 1, EXIT>(nb, s, st, a, L, done);
+  else if (P == 2)
+    launch_gn_level_p<ICP, RGB, 2, EXIT>(nb, s, st, a, L, done);
+  else if (P == 3)
+    launch_gn_level_p<ICP, RGB, 3, EXIT>(nb, s, st, a, L, done);
+  else if (P == 4)
+    launch_gn_level_p<ICP, RGB, 4, EXIT>(nb, s, st, a, L, done);
+  else
+    launch_gn_level_p<ICP, RGB, 5, EXIT>(nb, s, st, a, L, done);
 }
 template <bool ICP, bool RGB>
-static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L) {
+static void launch_gn_level(int P, int nb, hipStream_t s, TrackState* st, const GnArgs& a, const LevelArgs& L, hipEvent_t done = nullptr) {
   if (L.early_exit)
-    launch_gn_level_f<ICP, RGB, true>(P, nb, s, st, a, L);
+    launch_gn_level_f<ICP, RGB, true>(P, nb, s, st, a, L, done);
   else
-    launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L);
+    launch_gn_level_f<ICP, RGB, false>(P, nb, s, st, a, L, done);
 }
 
 template <bool ICP, bool RGB>
@@ -2589,12 +2624,13 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
       persist.begin();
       static const char* const kLevelTimer[3] = {"gn_level0", "gn_level1", "gn_level2"};
       Timer t(o, s, kLevelTimer[l]);
+      hipEvent_t done = (l == 0) ? persist.closing_event() : nullptr;  // level 0 is the section's last resident launch
       if (icp && rgb)
-        launch_gn_level<true, true>(pP, pnb, s, o->state, a, L);
+        launch_gn_level<true, true>(pP, pnb, s, o->state, a, L, done);
       else if (icp)
-        launch_gn_level<true, false>(pP, pnb, s, o->state, a, L);
+        launch_gn_level<true, false>(pP, pnb, s, o->state, a, L, done);
       else
-        launch_gn_level<false, true>(pP, pnb, s, o->state, a, L);
+        launch_gn_level<false, true>(pP, pnb, s, o->state, a, L, done);
       DMS_CHECK_LAUNCH();
       continue;
     }

@@ -416,6 +416,9 @@ int dms_fusion_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev
  * off, images wider than 2048, the map's first frame) - the caller then calls dms_fusion_frame_block as before. */
 int dms_fusion_arm_frame_block(dms_fusion* f, void* block_dev, float* pose16_dst_dev, int* tick_dst_dev, int tick);
 int dms_fusion_frame_block_written(dms_fusion* f);
+/* Makes `waiter` wait for the last frame enqueued on this context - through the event that frame's enqueue recorded anyway (no marker of
+ * the caller's own behind the frame: between two kernels of one stream a marker costs about 7 us on this device). */
+int dms_fusion_wait_frame_done(dms_fusion* f, dms_stream waiter);
 
 /* Surface constraints of the last fetched frame's loop candidate, in the reference's sampling
  * order (columns outer, rows inner, ElasticFusion.cpp:446-447): per row
