@@ -2235,7 +2235,13 @@ struct PersistChain {
   bool used[64] = {};
   bool chained[64] = {};   // several streams have run sections on this device: events from here on
   bool ev_valid[64] = {};
+  // (round 6) ... until one stream has had the device's sections to itself for kQuietAfter calls in a row (a front end that changed
+  // streams between phases; bench.py's loops): the events stop, and the next section from another stream pays one device
+  // synchronisation as the very first change of stream did.  Two cameras that alternate never get there and keep their events.
+  int run[64] = {};
+  bool quiet[64] = {};
 };
+static constexpr int kQuietAfter = 8;
 static PersistChain g_persist;
 // DMS_PERSIST_UNCHAINED=1: the caller guarantees that the resident grids of all handles that may track at the same time fit the
 // device TOGETHER (DMS_PERSIST_MAX_BLOCKS of each, summed, <= compute units; a handle whose bound exceeds half the device stays chained) — then every grid completes whatever the
@@ -2267,12 +2273,17 @@ struct PersistSection {
     (void)hipGetDevice(&dev);
     dev &= 63;
     if (g_persist.used[dev] && g_persist.last[dev] != s) {
-      if (!g_persist.chained[dev]) {
+      if (!g_persist.chained[dev] || g_persist.quiet[dev]) {
         (void)hipDeviceSynchronize();
         g_persist.chained[dev] = true;
       } else if (g_persist.ev_valid[dev]) {
         (void)hipStreamWaitEvent(s, g_persist.ev[dev], 0);
       }
+      g_persist.run[dev] = 0;
+      g_persist.quiet[dev] = false;
+    } else if (g_persist.chained[dev] && !g_persist.quiet[dev] && ++g_persist.run[dev] >= kQuietAfter) {
+      g_persist.quiet[dev] = true;
+      g_persist.ev_valid[dev] = false;
     }
     g_persist.last[dev] = s;
     g_persist.used[dev] = true;
@@ -2283,7 +2294,7 @@ struct PersistSection {
   // null when no event is owed (one stream only so far) - then nothing changes.
   bool closed = false;
   hipEvent_t closing_event() {
-    if (!active || !g_persist.chained[dev] || !ext_events()) return nullptr;
+    if (!active || !g_persist.chained[dev] || g_persist.quiet[dev] || !ext_events()) return nullptr;
     if (!g_persist.ev[dev] && hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       g_persist.ev[dev] = nullptr;
@@ -2306,7 +2317,7 @@ struct PersistSection {
       g_persist.mu.unlock();
       return;
     }
-    if (g_persist.chained[dev]) {
+    if (g_persist.chained[dev] && !g_persist.quiet[dev]) {
       if (!g_persist.ev[dev]) (void)hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming);
       g_persist.ev_valid[dev] = g_persist.ev[dev] && hipEventRecord(g_persist.ev[dev], s) == hipSuccess;
       if (!g_persist.ev_valid[dev]) (void)hipGetLastError();
