@@ -1695,6 +1695,17 @@ int dms_fusion_set_profiling(dms_fusion* f, int enabled) {
 }
 
 // ElasticFusion.cpp:1023-1043 (the reference's setters write members that processFrame reads on the next frame)
+int dms_fusion_set_tracker_budget(dms_fusion* f, int max_blocks, int unchained) {
+  DMS_REQUIRE(f && max_blocks >= 0, "bad argument");
+  if (f->in_frame || f->in_global_loop) {
+    ::dms::set_error("dms_fusion_set_tracker_budget: inside a frame");
+    return DMS_ERR_STATE;
+  }
+  int rc = dms_odometry_set_resident_budget(f->odom, max_blocks, unchained);
+  if (!rc && f->odom_m2m) rc = dms_odometry_set_resident_budget(f->odom_m2m, max_blocks, unchained);
+  return rc;
+}
+
 int dms_fusion_set_option(dms_fusion* f, int option, double value) {
   DMS_REQUIRE(f, "null argument");
   DMS_REQUIRE(option >= 0 && option < DMS_OPT_COUNT, "unknown option");

@@ -103,6 +103,8 @@ struct dms_session {
   };
   std::vector<MapStream> map_streams;  // a small pool: the hosted maps take its streams in turn (more streams than hardware queues cost more than they overlap)
   bool fused_block = true;  // the frame block written by the frame's last kernel (DMS_SESSION_FUSED_BLOCK=0: a launch of its own, the A/B switch)
+  bool share_device = true;  // DMS_SESSION_SHARE_DEVICE=0: the cameras' trackers keep their full grids and the chain (round 5)
+  int tracker_cap = 0;       // the cap the hosted cameras' trackers carry now (0: none)
   bool join_by_frame_event = true;  // DMS_SESSION_JOIN_BY_FRAME_EVENT=0: a marker of the session's own behind the frames of every map stream (round 5)
   int n_map_streams = 2;  // (measured on one MI355X, 2 - 8 cameras: two beat one by 5 - 35 %, three and four are no better, four lose with 8 cameras)
   int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
@@ -571,6 +573,31 @@ int drain_entries(dms_session* s) {
   return DMS_OK;
 }
 
+// Trackers that run at the same time share the device.  In a pipelined tick the cameras of different hosted maps run on different streams;
+// by default resident tracker launches of different streams wait for each other (each needs all its blocks on the device at once:
+// level 0 takes 200 of the 256 units).  With `concurrent` streams the session caps every hosted camera's grids at (units - 16) /
+// concurrent blocks and lifts the chain for them (dms_odometry_set_resident_budget: 120 blocks each for two streams - level 0 then runs
+// five pixels per thread); one stream, a synchronous tick, or a frame too large for the capped grid: full grids, chained.  Same bits
+// either way.  Measured, two cameras before their maps merge: 3 155 against 2 566 frames/s; one stream with the cap: 2 258 against 2 437 -
+// hence per tick, by what the tick will run.  The inter-map trackers (queries, refinement) run in woken ticks, after every frame of
+// the tick has been fetched: alone.
+int apply_tracker_policy(dms_session* s, int concurrent) {
+  int cap = 0;
+  if (s->share_device && concurrent >= 2) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 64) {
+      cap = (cus - 16) / concurrent;
+      const long long px = (long long)s->W * s->H;
+      if (px > (long long)cap * 512 * 5) cap = 0;  // (level 0 at five pixels per thread of 512-thread blocks would not fit: a capped handle falls back to a launch per phase)
+    }
+  }
+  if (cap == s->tracker_cap) return DMS_OK;
+  for (auto& kv : s->cams)
+    if (int rc = dms_fusion_set_tracker_budget(kv.second.f, cap, cap > 0 ? 1 : 0)) return rc;
+  s->tracker_cap = cap;
+  return DMS_OK;
+}
+
 // the stream a hosted map's cameras run on in a pipelined tick: its own, unless one of its cameras is read on another rank (the
 // frame arrives through the transport, whose calls stay on the caller's stream)
 int stream_of_map(dms_session* s, int frame, hipStream_t caller, hipStream_t* out, dms_session::MapStream** ms_out) {
@@ -816,6 +843,7 @@ int dms_session_create(dms_session** out, const dms_session_params* p, const dms
   if (const char* e = getenv("DMS_SESSION_MAP_STREAMS")) s->n_map_streams = std::max(0, std::min(16, atoi(e)));
   if (const char* e = getenv("DMS_SESSION_FUSED_BLOCK")) s->fused_block = atoi(e) != 0;
   if (const char* e = getenv("DMS_SESSION_JOIN_BY_FRAME_EVENT")) s->join_by_frame_event = atoi(e) != 0;
+  if (const char* e = getenv("DMS_SESSION_SHARE_DEVICE")) s->share_device = atoi(e) != 0;
   s->n = p->n_cameras;
   s->W = p->camera.width;
   s->H = p->camera.height;
@@ -908,6 +936,7 @@ int dms_session_step(dms_session* s, int k, const void* const* rgb_dev, const un
   if ((rc = drain_entries(s))) return rc;  // (pipelined ticks before this one: their pose-graph rows come first)
   invalidate_searches(s, k);               // (and their searches wake nothing: this tick queries every pair itself)
   s->last_stream = st;
+  if ((rc = apply_tracker_policy(s, 1))) return rc;  // (every frame of a synchronous tick runs on the caller's stream)
   if (s->p.query_inside_frame) return step_inside(s, k, rgb_dev, depth_dev, st);
   // 1 + 2. forward the frames of cameras hosted elsewhere; every hosted camera's frame, in id order.  (A frame that arrives from
   // another rank is processed when its camera's turn comes: receive and process are interleaved in camera order on both sides.)
@@ -1033,6 +1062,16 @@ int dms_session_step_async(dms_session* s, int k, const void* const* rgb_dev, co
   // (a one-rank session without a transport gathers nothing: the search reads the blocks where they were packed)
   unsigned char* gathered = s->local_only ? local : s->d_agathered[k & 1];
   const size_t T0 = s->tail_off, B = s->ablock_bytes;
+  {  // how many streams this tick's frames run on
+    std::set<hipStream_t> streams;
+    for (auto& kv : s->cams) {
+      hipStream_t fs = hs;
+      dms_session::MapStream* ms = nullptr;
+      if ((rc = stream_of_map(s, s->frame_of[kv.first], hs, &fs, &ms))) return rc;
+      streams.insert(fs);
+    }
+    if ((rc = apply_tracker_policy(s, (int)streams.size()))) return rc;
+  }
   std::map<int, hipStream_t> cam_stream;
   std::set<dms_session::MapStream*> used;
   std::map<dms_session::MapStream*, int> last_cam_of;   // the camera whose frame is the stream's last this tick

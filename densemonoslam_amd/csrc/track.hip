@@ -86,6 +86,10 @@ struct dms_odometry {
   // occupancy API at creation; DMS_PERSIST_MAX_BLOCKS lowers it further.  A level that does not fit with <= 4 pixels per
   // thread runs launch-per-phase.
   int max_resident_blocks = 256;
+  // dms_odometry_set_resident_budget: a cap below the device's own bound, and the owner's word that every handle that may track at the same
+  // time carries a cap such that all their grids fit the device together - such a handle's launches need no chain (PersistSection)
+  int budget_cap = 0;
+  bool unchained_ok = false;
   bool fell_back = false;     // a resident kernel timed out at a grid-wide wait: this handle has switched to launch-per-phase
   // the model pyramid's last step (level 1 -> 2 of lastDepth / lastImage), left to the next track call's first kernel
   bool deferred_pyr = false;
@@ -1957,6 +1961,13 @@ int dms_odometry_debug_set(dms_odometry* o, const char* key, int value) {
   DMS_REQUIRE(false, "unknown key");
 }
 
+int dms_odometry_set_resident_budget(dms_odometry* o, int max_blocks, int unchained) {
+  DMS_REQUIRE(o && max_blocks >= 0, "bad argument");
+  o->budget_cap = max_blocks;
+  o->unchained_ok = unchained != 0 && max_blocks > 0;
+  return DMS_OK;
+}
+
 int dms_odometry_get_mode(dms_odometry* o, int* resident, int* max_resident_blocks, int* fell_back) {
   DMS_REQUIRE(o, "null argument");
   if (resident) *resident = o->resident ? 1 : 0;
@@ -2258,10 +2269,11 @@ struct PersistSection {
   int dev = 0;
   bool active = false;
   int budget;  // largest resident grid of the handle this section belongs to
-  PersistSection(hipStream_t s_, int budget_) : s(s_), budget(budget_) {}
+  bool handle_unchained;
+  PersistSection(hipStream_t s_, int budget_, bool handle_unchained_ = false) : s(s_), budget(budget_), handle_unchained(handle_unchained_) {}
   void begin() {
     if (active) return;
-    if (unchained()) {  // honoured only for handles that hold at most half the device: two of them always fit together
+    if (unchained() || handle_unchained) {  // honoured only for handles that hold at most half the device: two of them always fit together
       static const int cus = [] {
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
@@ -2370,11 +2382,15 @@ static void launch_track_coarse(int P1, bool early_exit, int grid, hipStream_t s
   }
 }
 
+static inline int budget_of(const dms_odometry* o) {
+  return (o->budget_cap > 0 && o->budget_cap < o->max_resident_blocks) ? o->budget_cap : o->max_resident_blocks;
+}
+
 // grid of the resident SO3 kernel for this handle; 0 = the SO3 stage runs launch-per-phase
 static int so3_resident_blocks(const dms_odometry* o) {
   const Buf& li = o->lastNextImage[2];
   const int nbp = (li.rows * li.cols + kPB - 1) / kPB;
-  return (o->resident && nbp <= kMaxPersistBlocks && nbp <= o->max_resident_blocks) ? nbp : 0;
+  return (o->resident && nbp <= kMaxPersistBlocks && nbp <= budget_of(o)) ? nbp : 0;
 }
 
 int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot, const float* prior_pose16_dev, int rgbOnly,
@@ -2461,7 +2477,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     if (o->inject_timeouts > 0) o->inject_timeouts -= 1;
   }
 
-  PersistSection persist(s, o->max_resident_blocks);
+  PersistSection persist(s, budget_of(o), o->unchained_ok);
 
   auto level_below_of = [&](int l) {
     for (int q = l - 1; q >= 0; --q)
@@ -2543,7 +2559,7 @@ int odometry_track_enqueue(dms_odometry* o, const float* trans, const float* rot
     pP = 1;
     pnb = 0;
     if (o->resident && (iterations[l] <= kArRing || o->long_levels_resident))  // (more iterations than ring sets: the ring is re-armed in flight)
-      persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, o->max_resident_blocks, pP, pnb);
+      persistent_shape(o->vmaps_curr[l].cols * (o->vmaps_curr[l].rows / 3), o->persist_target, budget_of(o), pP, pnb);
   };
 
   // SO3 + level 2 + level 1 in one resident launch (k_track_coarse) when all three are resident stages of this call and their shapes
@@ -3098,7 +3114,7 @@ int odometry_initModel_fused(dms_odometry* o, const void* vA, const void* nA, co
     const int nbs = so3_resident_blocks(o);
     const So3Args q = {(const unsigned char*)li.p, li.pitch, (const unsigned char*)ni.p, ni.pitch, ni.cols, ni.rows, o->ar, SolveCam{o->fx, o->fy, o->cx, o->cy},
                        o->folded_first_level, 10, o->exp_bias + o->depth_bias, o->first_delay_for(nbs, 3)};
-    PersistSection persist(s, o->max_resident_blocks);
+    PersistSection persist(s, budget_of(o), o->unchained_ok);
     persist.begin();
     Timer t(o, s, "so3_model");
     hipLaunchKernelGGL(k_so3_model, dim3(nbs + G.g12x * G.g12y + G.gsx * G.gsy + G.g2x * G.g2y + G.g0x * G.g0y), dim3(kPB), 0, s, o->state, q, nbs, G);

@@ -248,6 +248,12 @@ int dms_odometry_destroy(dms_odometry* o);
  * Every cross-pixel sum of the tracker is the order-free integer sum of csrc/canon.hpp in every execution mode: poses do not depend on
  * these switches, on the grid size or on the run. */
 int dms_odometry_set_exec(dms_odometry* o, int resident, int early_exit, int coarse_launch);
+/* Several trackers AT THE SAME TIME on one device (cameras on streams of their own): a resident launch needs all its blocks on the device
+ * at once, so launches of different streams are chained one behind the other by default.  max_blocks > 0 caps this handle's resident
+ * grids (120 of 256 compute units: level 0 runs 5 pixels per thread instead of 3); unchained != 0 is the owner's word that ALL handles that
+ * may track at the same time carry caps whose sum fits the device - their launches then skip the chain and overlap.  0, 0 = the default.
+ * Same bits whatever the grid (the sums are order-free).  dms_session sets this for its cameras by itself. */
+int dms_odometry_set_resident_budget(dms_odometry* o, int max_blocks, int unchained);
 /* DEPRECATED since round 6 (kept for callers built against rounds 1-5): fp64_sums and atomic_reduce have been ignored since round 3;
  * equals dms_odometry_set_exec(o, resident, early_exit, -1). */
 int dms_odometry_set_mode(dms_odometry* o, int resident, int fp64_sums, int early_exit, int atomic_reduce);

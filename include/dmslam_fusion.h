@@ -447,6 +447,9 @@ enum {
   DMS_OPT_COUNT = 13
 };
 int dms_fusion_set_option(dms_fusion* f, int option, double value);
+/* dms_odometry_set_resident_budget (dmslam.h) for this context's trackers (frame-to-model and, with local loop closure, model-to-model);
+ * between frames only. */
+int dms_fusion_set_tracker_budget(dms_fusion* f, int max_blocks, int unchained);
 int dms_fusion_get_option(dms_fusion* f, int option, double* value);
 
 /* End-of-run exports of the reference (MainController.cpp:806-807), host side, byte for byte the reference's files:
