@@ -621,6 +621,23 @@ def test_pose_does_not_depend_on_the_grid_size(dms, gputest_pair, monkeypatch):
         t, R, r = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **CONFIGS["C3_full"])
         outs.append(t.tobytes() + R.tobytes() + np.array(r.lastA).tobytes() + np.array(r.lastb).tobytes())
         g.close()
+    # the per-handle form of the cap (dms_odometry_set_resident_budget: what dms_session gives cameras that share the device), set and
+    # lifted on one handle between calls
+    from densemonoslam_amd.capi import lib
+
+    monkeypatch.delenv("DMS_PERSIST_MAX_BLOCKS", raising=False)
+    monkeypatch.setenv("DMS_PERSIST_BLOCKS", "160")
+    g = dms.RGBDOdometry(640, 480, K[2], K[3], K[0], K[1])
+    for cap, unchained in ((120, 1), (0, 0), (20, 0)):
+        assert lib.dms_odometry_set_resident_budget(g.h, cap, unchained) == 0
+        g.initICPModel(verts, norms, 20.0, np.eye(4, dtype=np.float32))
+        g.initRGBModel(rgba1)
+        g.initICP(gputest_pair["depth2"], 20.0)
+        g.initRGB(rgba2)
+        g.initFirstRGB(rgba1)
+        t, R, r = g.getIncrementalTransformation(np.zeros(3, np.float32), np.eye(3, dtype=np.float32), **CONFIGS["C3_full"])
+        outs.append(t.tobytes() + R.tobytes() + np.array(r.lastA).tobytes() + np.array(r.lastb).tobytes())
+    g.close()
     assert all(o == outs[0] for o in outs[1:])
 
 
