@@ -248,6 +248,7 @@ lib.dms_computeNIDDepth.argtypes = [_I2, _I2, _I2, C.c_int, C.c_float, _P, C.c_s
 
 lib.dms_fusion_wait_frame_done.argtypes = [_P, _P]
 lib.dms_fusion_set_tracker_budget.argtypes = [_P, _I, _I]
+lib.dms_fusion_allow_late_frame.argtypes = [_P, _I]
 lib.dms_odometry_set_resident_budget.argtypes = [_P, _I, _I]
 lib.dms_exact_arith_selftest.argtypes = [_I, _F, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
 

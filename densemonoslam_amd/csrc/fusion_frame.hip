@@ -8,6 +8,7 @@
 // velocity weight (ElasticFusion.cpp:252-268), and every later kernel reads the block through a
 // pointer.  The fill-in decision (`denseEnough`, ElasticFusion.cpp:84-97,166-167), which the
 // reference takes on the host after a glReadPixels, is a device flag consumed by a select-copy.
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <string>
@@ -307,6 +308,20 @@ struct dms_fusion {
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_main_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_inputs = nullptr;
   bool fused_live = true;  // the live half as three fused launches (DMS_FUSED_LIVE=0: the operator chain, fifteen)
   int prep_blocks = 38;  // fat blocks of the bilateral filter on the prep stream, set at creation (DMS_PREP_BLOCKS; 0 = one tile per block)
+  // "Late frame" (round 6): the frame's first kernel needs the live half of the SAME frame, which runs on the prep stream.  A
+  // hipStreamWaitEvent for it is a barrier packet on the frame's queue - about 10 us of idle queue per frame although the event fired
+  // long before.  When the host has that much slack it can wait for the event ITSELF and enqueue the frame behind it: the runtime then
+  // adds no packet (the event is complete).  2 412 - 2 418 -> 2 446 - 2 454 frames/s (driver's form), 2 678 - 2 681 -> 2 711 - 2 715
+  // (300 steps).  It costs the host its run-ahead, so it is (i) only for a context that is driven alone (one live context in the
+  // process, or its owner says so; dms_session says no for its cameras) on a map of its own, and (ii) watched: the host's wait at the
+  // start of a frame (for frame t - 2) is its remaining slack; three frames in a row under 15 us switch the mode off for a while
+  // (64 frames, doubling).  Forced on, the populated full step fell from 1 690 to 1 082 frames/s and two cameras from 3 150 to 2 815 -
+  // both are cases the two rules exclude.  DMS_LATE_MAIN=0 / 1 forces it.
+  bool late_main = false;       // this frame
+  int late_forced = -1;         // DMS_LATE_MAIN
+  int late_owner = -1;          // dms_fusion_allow_late_frame: the owner's word (-1: none - one live context decides)
+  int late_low = 0, late_cool = 0, late_backoff = 64;
+  double host_wait_prep_ms = 0.0;
   int host_lag = 2;  // the host enqueues frame t once frame t - host_lag has completed (DMS_HOST_LAG = 2 | 3; 3 measured -2.4 %)
   bool inputs_armed = false;  // ev_inputs was recorded by dms_fusion_inputs_ready for the next frame
   int last_prep = -1;         // image set whose ev_prep_done marks the end of the last enqueued ingest
@@ -705,6 +720,13 @@ static int set_depth_bias(dms_fusion* f) {
   return rc;
 }
 
+static std::atomic<int> g_live_contexts{0};
+int dms_fusion_allow_late_frame(dms_fusion* f, int allow) {
+  DMS_REQUIRE(f && allow >= -1 && allow <= 1, "bad argument");
+  f->late_owner = allow;
+  return DMS_OK;
+}
+
 int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   DMS_REQUIRE(out && p, "null argument");
   DMS_REQUIRE(p->width >= 40 && p->height >= 40, "resolution too small");
@@ -786,6 +808,7 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
   if (const char* fl = getenv("DMS_FUSED_LIVE")) f->fused_live = atoi(fl) != 0;
   if (const char* ft = getenv("DMS_FOLD_TRACK_INIT")) f->fold_track_init = atoi(ft) != 0;
   if (const char* hl = getenv("DMS_HOST_LAG")) f->host_lag = atoi(hl) == 3 ? 3 : 2;
+  if (const char* lm = getenv("DMS_LATE_MAIN")) f->late_forced = atoi(lm) != 0 ? 1 : 0;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inputs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemset(f->arena, 0, f->arena_bytes);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_state, 4 * sizeof(FrameState), hipHostMallocMapped);
@@ -827,12 +850,14 @@ int dms_fusion_create(dms_fusion** out, const dms_fusion_params* p) {
     (void)hipMemsetD32((hipDeviceptr_t)f->kf_old_dmap[l].data, 0x7fffffff, (size_t)f->kf_old_dmap[l].rows * f->kf_old_dmap[l].cols);  // kept empty from here on: every resolve pass clears what it reads
   (void)hipDeviceSynchronize();
   memset(f->h_state, 0, 4 * sizeof(FrameState));
+  g_live_contexts += 1;
   *out = f;
   return DMS_OK;
 }
 
 int dms_fusion_destroy(dms_fusion* f) {
   if (!f) return DMS_OK;
+  g_live_contexts -= 1;
   (void)hipDeviceSynchronize();
   drain(f);
   for (auto e : f->pool) (void)hipEventDestroy(e);
@@ -1004,7 +1029,32 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
     {
       const auto t0 = std::chrono::steady_clock::now();
       DMS_HIP(hipEventSynchronize(f->ev_main_done[(f->frames + 4 - f->host_lag) % 4]));  // (never recorded: returns at once)
-      f->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      const double waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      f->host_wait_ms += waited_ms;
+      // the late frame's two rules (see `late_main`)
+      const bool alone = f->late_owner >= 0 ? f->late_owner != 0 : g_live_contexts.load() == 1;
+      const bool may = alone && f->model->sharers == 1 && f->map_initialised && f->frames >= 2;
+      if (f->late_forced >= 0) {
+        f->late_main = f->late_forced != 0;
+      } else if (!may) {
+        f->late_main = false;
+        f->late_low = 0;
+      } else if (f->late_cool > 0) {
+        f->late_cool -= 1;
+        f->late_main = false;
+      } else {
+        if (f->late_main && waited_ms < 0.015) {
+          if (++f->late_low >= 3) {  // the host has no slack left: back to the barrier for a while
+            f->late_main = false;
+            f->late_low = 0;
+            f->late_cool = f->late_backoff;
+            if (f->late_backoff < 4096) f->late_backoff *= 2;
+          }
+        } else {
+          f->late_low = 0;
+          f->late_main = true;
+        }
+      }
     }
     DMS_HIP(hipStreamWaitEvent(sp, f->ev_main_done[(f->frames + 2) % 4], 0));  // frame t-2
   }
@@ -1094,7 +1144,14 @@ int dms_fusion_process_frame_begin(dms_fusion* f, const void* rgb_dev, int rgb_c
   }
   if (f->p.pipeline_ingest) {
     DMS_HIP(hipEventRecord(f->ev_prep_done[k2], sp));
-    DMS_HIP(hipStreamWaitEvent(s, f->ev_prep_done[k2], 0));
+    if (f->late_main) {
+      // the HOST waits for the live half and enqueues the frame behind it: no barrier packet on the frame's queue
+      const auto t0 = std::chrono::steady_clock::now();
+      DMS_HIP(hipEventSynchronize(f->ev_prep_done[k2]));
+      f->host_wait_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+      DMS_HIP(hipStreamWaitEvent(s, f->ev_prep_done[k2], 0));
+    }
     f->last_prep = k2;
   }
 

@@ -105,6 +105,7 @@ struct dms_session {
   bool fused_block = true;  // the frame block written by the frame's last kernel (DMS_SESSION_FUSED_BLOCK=0: a launch of its own, the A/B switch)
   bool share_device = true;  // DMS_SESSION_SHARE_DEVICE=0: the cameras' trackers keep their full grids and the chain (round 5)
   int tracker_cap = 0;       // the cap the hosted cameras' trackers carry now (0: none)
+  int late_told = -1;        // what the hosted cameras were told about the late frame (dms_fusion_allow_late_frame)
   bool join_by_frame_event = true;  // DMS_SESSION_JOIN_BY_FRAME_EVENT=0: a marker of the session's own behind the frames of every map stream (round 5)
   int n_map_streams = 2;  // (measured on one MI355X, 2 - 8 cameras: two beat one by 5 - 35 %, three and four are no better, four lose with 8 cameras)
   int valid_from = 0;              // searches enqueued before this tick ran on a layout that a merge has changed since
@@ -590,6 +591,15 @@ int apply_tracker_policy(dms_session* s, int concurrent) {
       const long long px = (long long)s->W * s->H;
       if (px > (long long)cap * 512 * 5) cap = 0;  // (level 0 at five pixels per thread of 512-thread blocks would not fit: a capped handle falls back to a launch per phase)
     }
+  }
+  // (the "late frame" of dmslam_fusion.h is not for a session's cameras: the host has the exchange to enqueue and the earlier ticks'
+  // tails to wait for between two frames, and its slack does not show where the context looks for it - measured with one hosted camera:
+  // 0.945 and 0.878 of the bare frame rate against 0.955 - 0.957)
+  const int late = 0;
+  if (late != s->late_told) {
+    for (auto& kv : s->cams)
+      if (int rc = dms_fusion_allow_late_frame(kv.second.f, late)) return rc;
+    s->late_told = late;
   }
   if (cap == s->tracker_cap) return DMS_OK;
   for (auto& kv : s->cams)

@@ -450,6 +450,14 @@ int dms_fusion_set_option(dms_fusion* f, int option, double value);
 /* dms_odometry_set_resident_budget (dmslam.h) for this context's trackers (frame-to-model and, with local loop closure, model-to-model);
  * between frames only. */
 int dms_fusion_set_tracker_budget(dms_fusion* f, int max_blocks, int unchained);
+/* The "late frame": a context that is driven ALONE lets the host wait for the live half of a frame (the prep stream's event) and enqueue
+ * the frame behind it, instead of a barrier packet on the frame's queue (about 10 us per frame; +1.2 - 1.4 % frame rate) - while the host
+ * has the slack, which the context watches.  By default a context takes itself to be alone when it is the only live dms_fusion context
+ * of the process.  An owner that knows better says so: allow = 1 (this context's frames are the only work the calling thread enqueues
+ * between two of its frames), 0 (several contexts are driven by turns, or the thread has other work between two frames: dms_session says
+ * 0 for its cameras), -1 (back to the default).
+ * Timing only; DMS_LATE_MAIN=0 / 1 forces it for every context. */
+int dms_fusion_allow_late_frame(dms_fusion* f, int allow);
 int dms_fusion_get_option(dms_fusion* f, int option, double* value);
 
 /* End-of-run exports of the reference (MainController.cpp:806-807), host side, byte for byte the reference's files:
