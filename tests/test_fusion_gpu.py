@@ -416,14 +416,17 @@ def test_process_frame_pipeline_parity(fus, orc, synth):
     assert worst_t < 5e-4 and worst_r < 5e-3, (worst_t, worst_r)
 
 
-def test_process_frame_pipelined_equals_serial(fus, synth):
+def test_process_frame_pipelined_equals_serial(fus, synth, monkeypatch):
     """The two-stream frame pipeline (live-frame half of frame t+1 overlapping tracking / fusion of
     frame t, two frames in flight) must be invisible: enqueueing a burst of frames without any
     host synchronisation gives bit-identical poses and maps to (a) synchronising after every frame
-    and (b) the single-stream mode."""
+    and (b) the single-stream mode - with the late frame (the host waits for the live half, no barrier packet; round 6) forced on,
+    forced off and left to itself.  DMS_BURST_FRAMES lengthens the burst (profiles/r06_late_frame.txt: 200 frames)."""
+    import os
+
     from densemonoslam_amd import capi
 
-    n_frames = 7
+    n_frames = int(os.environ.get("DMS_BURST_FRAMES", "7"))
     frames = [synth.frame(k, width=W, height=H, K=K, noise=True) for k in range(n_frames)]
 
     def run(burst, **opts):
@@ -443,9 +446,13 @@ def test_process_frame_pipelined_equals_serial(fus, synth):
         return np.array(r.pose, np.float32), int(r.surfels), m, g.image(10), g.image(2)
 
     ref = run(False, pipeline_ingest=0)
-    for burst, pipe in ((True, 1), (False, 1), (True, 0)):
+    for burst, pipe, late in ((True, 1, None), (False, 1, None), (True, 0, None), (True, 1, "1"), (True, 1, "0"), (False, 1, "1")):
+        if late is None:
+            monkeypatch.delenv("DMS_LATE_MAIN", raising=False)
+        else:
+            monkeypatch.setenv("DMS_LATE_MAIN", late)
         got = run(burst, pipeline_ingest=pipe)
-        what = "burst=%s pipeline=%d" % (burst, pipe)
+        what = "burst=%s pipeline=%d late=%s" % (burst, pipe, late)
         assert (got[0] == ref[0]).all(), what
         assert got[1] == ref[1], what
         surfels_equal(got[2], ref[2], what)
